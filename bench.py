@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- spectral-points/s of an rt_run-equivalent on synthetic O2-A-band atmospheres.
+
+Workload (BASELINE.json configs[1], "C2"): O2-A band 759-770 nm, nStokes = 3, Nquad = 20
+(18 Gauss-Legendre + SZA 40 deg + VZA 30 deg => N = 60), 40 layers, 10 000 spectral points per GPU,
+FP64, Rayleigh (depol 0.0279) + synthetic O2-like absorption (40 pseudo-lines, column tau 1e-4..50),
+Lambertian 0.15, Fourier moments m = 0..2.   A "step" = one full rt_run pass over the batch:
+all m, all layers (elemental -> doubling -> interaction), surface, VZA post-processing, with the layer
+optics already resident in HBM.  N GPUs => N x 10 000 points (weak scaling), one RCCL gather of R/T.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
+kernel (k_elemental_doubling; algorithmic flops / HIP-event launch time) and `cpu_baseline`
+(the oracle port timed on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # MI355X dense MFMA peaks
+
+
+def o2a_atmosphere(S_total, L, seed=20260929):
+    """Synthetic inputs of SURVEY.md 8(d)."""
+    rng = np.random.default_rng(seed)
+    p = np.linspace(0.0, 1.0, L + 1)
+    dp = np.diff(p)                                  # pressure-proportional layer split
+    tau_rayl = np.tile(0.025 * dp, (S_total, 1))
+    nu = np.linspace(12987.0, 13175.0, S_total)
+    nu_k = rng.uniform(12990.0, 13170.0, 40)
+    A_k = 10.0 ** rng.uniform(-3, math.log10(30.0), 40)
+    gam = 0.08
+    col = np.sum(A_k[None, :] * gam ** 2 / ((nu[:, None] - nu_k[None, :]) ** 2 + gam ** 2), axis=1) + 1e-4
+    tau_abs = col[:, None] * dp[None, :]
+    return tau_rayl, tau_abs
+
+
+CONFIGS = {
+    # name: (polarization, l_trunc, FT, layers, points per GPU)
+    "C2": dict(pol="IQU", l_trunc=35, FT="f64", L=40, S=10000, N=60),
+    "C4": dict(pol="IQU", l_trunc=59, FT="f32", L=60, S=12500, N=96),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--points", type=int, default=None, help="spectral points per GPU (default: config)")
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=12, help="spectral points of the CPU-baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import vsmartmom_jl_amd as vsm
+    from vsmartmom_jl_amd import parallel
+
+    rank, world, local = parallel.init_process_group_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    cfg = dict(CONFIGS[args.config])
+    if args.points:
+        cfg["S"] = args.points
+    if args.layers:
+        cfg["L"] = args.layers
+    FT = np.float64 if cfg["FT"] == "f64" else np.float32
+    S_local, L = cfg["S"], cfg["L"]
+    S_total = S_local * world
+    arch = vsm.Architectures.GPU(local)
+    vsm._lib.lib()  # fail loudly if the HIP library is absent
+
+    tau_rayl, tau_abs = o2a_atmosphere(S_total, L)
+    model = vsm.host_model.model_from_arrays(arch, cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl,
+                                             tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2, float_type=FT)
+    N = model.quad_points.Nquad * model.polarization_type.n
+    assert N == cfg["N"], (N, cfg["N"])
+    sl = parallel.shard_slice(S_total, rank, world)
+    t_prep = time.time()
+    scene = vsm.CoreRT.prepare_scene(model, sl)
+    torch.cuda.synchronize()
+    t_prep = time.time() - t_prep
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        R, T = scene.run()
+        Rg = parallel.gather_spectral(R, S_total, rank, world)   # RCCL gather of R/T at the end
+        Tg = parallel.gather_spectral(T, S_total, rank, world)
+        return Rg, Tg
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
+    # one extra pass with an event pair around every k_elemental_doubling launch
+    ev = []
+    orig = vsm.CoreRT.elemental_doubling_
+
+    def timed(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(*a, **k)
+        e1.record()
+        ev.append((e0, e1, a[6]))  # a[6] = ndoubl
+
+    vsm.CoreRT.elemental_doubling_ = timed
+    scene.run()
+    torch.cuda.synchronize()
+    vsm.CoreRT.elemental_doubling_ = orig
+    n3, n2 = float(N) ** 3, float(N) ** 2
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
+    k_flops = sum(S_local * nd * (12 * n3 + 8 * n2) for _, _, nd in ev)   # algorithmic doubling flops
+    achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak = PEAK_TFLOPS[cfg["FT"]]
+
+    if rank == 0:
+        flops_pt = scene.flops_per_point()
+        pts_per_s = S_total * args.steps / dt
+        nds = [ly["nd"] for ly in scene.moments[0]["layers"]]
+        line = {
+            "metric": "spectral-points/s (whole node) for rt_run, O2-A band",
+            "value": pts_per_s, "unit": "spectral-points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": cfg["FT"], "data": "synthetic",
+            "config": {"workload": "%s: O2-A 759-770 nm, nStokes=3, Nquad=%d (N=%d), %d layers, %d spectral points/GPU, "
+                                   "m=0..2, Rayleigh+synthetic O2 absorption, Lambertian 0.15" %
+                                   (args.config, model.quad_points.Nquad, N, L, S_local),
+                       "N": N, "layers": L, "points_per_gpu": S_local, "fourier_moments": 3,
+                       "ndoubl_per_layer": nds, "algorithmic_gflop_per_point": flops_pt / 1e9,
+                       "whole_run_tflops": pts_per_s * flops_pt / 1e12,
+                       "whole_run_frac_of_mfma_peak": pts_per_s * flops_pt / 1e12 / (peak * world),
+                       "prepare_scene_s (host optics + H2D, untimed)": t_prep},
+            "roofline": {"bound": "mfma", "kernel": "k_elemental_doubling", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, L)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def cpu_baseline(cfg, n_sample, L):
+    """The oracle (numpy port of the reference's CPU path) on a bounded sample of the same workload:
+    `n_sample` spectral points evenly spaced over the band, all layers, all moments."""
+    from oracle import vsm_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    FT = np.float64 if cfg["FT"] == "f64" else np.float32
+    tau_rayl, tau_abs = o2a_atmosphere(cfg["S"], L)
+    idx = np.linspace(0, cfg["S"] - 1, n_sample).astype(int)
+    mdl = O.build_model(cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx],
+                        depol=0.0279, albedo=0.15, m_max=2, FT=FT)
+    # NOTE: ndoubl of the sample is recomputed from the sample's own max(tau*varpi); with Rayleigh-only
+    # scattering it equals the full batch's.
+    ctx = threadpool_limits(limits=1) if threadpool_limits else None
+    t0 = time.perf_counter()
+    O.rt_run(mdl)
+    dt = time.perf_counter() - t0
+    if ctx is not None:
+        ctx.restore_original_limits() if hasattr(ctx, "restore_original_limits") else None
+    return {"value": n_sample / dt, "unit": "spectral-points/s", "cores": 1, "kind": "port",
+            "sample": "%d of the %d spectral points (evenly spaced), all %d layers, m=0..2, numpy oracle, 1 BLAS thread, %.1f s"
+                      % (n_sample, cfg["S"], L, dt)}
+
+
+if __name__ == "__main__":
+    main()

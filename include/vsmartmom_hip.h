@@ -1,0 +1,217 @@
+/*
+ * vsmartmom_hip.h -- C ABI of libvsmartmom_hip.so, the MI355X (gfx950) engine for
+ * vSmartMOM.jl's rt_run CoreRT hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one
+ * method that the reference's CUDA extension defines for CuArray, or one
+ * host-level CoreKernel function whose KernelAbstractions kernels the AMD
+ * backend overrides.  The reference-side binding (Julia `ccall`) is shown in
+ * INTEGRATION.md and julia/vSmartMOMROCmExt.jl.
+ *
+ * Conventions
+ *  - All array pointers are DEVICE pointers (HBM) unless the name ends in _h.
+ *  - Layout is the reference's: Julia column-major. A matrix batch `A[N,N,S]`
+ *    has element (i,j,s) at  i + N*j + N*N*s  (0-based); a vector batch
+ *    `v[N,1,S]` has (i,s) at i + N*s. Per-spectral-point scalars are `x[S]`.
+ *    Each spectral point's N*N block is contiguous; the spectral (batch) axis is
+ *    the slowest, so one workgroup streams one point with fully coalesced reads.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *    are asynchronous w.r.t. the host, like the CUBLAS calls they replace.
+ *  - Return value: 0 = VSM_OK, otherwise a vsm_status; vsm_last_error() returns
+ *    a thread-local message.  No C++ exception crosses this boundary.
+ *  - Suffix _f64 / _f32 = the reference's `FT` (Float64 / Float32).
+ *  - N = Nquad*nStokes (the reference's NquadN), S = nSpec.
+ */
+#ifndef VSMARTMOM_HIP_H
+#define VSMARTMOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vsm_status {
+  VSM_OK = 0,
+  VSM_ERR_INVALID_ARG = 1,   /* bad size / null pointer */
+  VSM_ERR_UNSUPPORTED = 2,   /* shape outside what the kernels are built for */
+  VSM_ERR_HIP = 3,           /* a HIP runtime call failed; see vsm_last_error() */
+  VSM_ERR_NO_DEVICE = 4
+} vsm_status;
+
+/* ScatteringInterface tags (src/CoreRT/types.jl ScatteringInterface_00/01/10/11;
+ * selection rule src/CoreRT/tools/rt_helper_functions.jl:15-33). */
+typedef enum vsm_iface {
+  VSM_IFACE_00 = 0,
+  VSM_IFACE_01 = 1,
+  VSM_IFACE_10 = 2,
+  VSM_IFACE_11 = 3
+} vsm_iface;
+
+/* ---- library / device ---------------------------------------------------- */
+int vsm_version(void);                 /* 10000*major + 100*minor + patch */
+const char* vsm_last_error(void);      /* thread-local, never NULL */
+int vsm_device_count(int* count);      /* Architectures.jl:68-96 `_has_cuda`-style probe */
+int vsm_device_name(int device, char* buf, size_t buflen);
+int vsm_sync(void* stream);            /* Architectures.synchronize_if_gpu (Architectures.jl:96) */
+/* Largest N the fused (LDS-resident) layer kernels accept for the element size
+ * (8 = f64, 4 = f32); larger N use the operator-level kernels below. */
+int vsm_fused_max_n(int elem_size);
+
+/* ---- L1 operator API: batched_mul / batch_inv! ---------------------------
+ * Replace ext/gpu_batched_cuda.jl:208-233 (CUBLAS.gemm_strided_batched) and
+ * :97-182 (getrf/getri batched); CPU semantics src/CoreRT/tools/cpu_batched.jl:25-82.
+ * C[M,Nc,S] = A[M,K,S] * B[K,Nc,S].  A batch stride of 0 broadcasts one matrix
+ * over all S (sa/sb are element strides between consecutive slices; pass M*K and
+ * K*Nc for dense batches). S==1 is handled natively (no singleton-batch guard needed). */
+int vsm_batched_mul_f64(int M, int Nc, int K, int S, const double* A, long long sa,
+                        const double* B, long long sb, double* C, void* stream);
+int vsm_batched_mul_f32(int M, int Nc, int K, int S, const float* A, long long sa,
+                        const float* B, long long sb, float* C, void* stream);
+/* X[:,:,s] = inv(A[:,:,s]), partial pivoting (same pivot rule as getrf). A is NOT
+ * clobbered (the reference allows clobbering; callers may alias X == A).
+ * info (nullable, int[S]): 0 ok, k>0 = exact zero pivot at step k (LAPACK convention). */
+int vsm_batch_inv_f64(int N, int S, const double* A, double* X, int* info, void* stream);
+int vsm_batch_inv_f32(int N, int S, const float* A, float* X, int* info, void* stream);
+
+/* ---- L2 CoreKernel API ----------------------------------------------------
+ * Layer state containers (src/CoreRT/types.jl:155-230 AddedLayer / CompositeLayer). */
+typedef struct vsm_added_f64 {
+  double *r_mp, *t_pp, *r_pm, *t_mm;  /* r⁻⁺ t⁺⁺ r⁺⁻ t⁻⁻  [N,N,S] */
+  double *j0_p, *j0_m;                /* j₀⁺ j₀⁻          [N,1,S] */
+  long long mat_stride;               /* element stride between spectral slices of the
+                                         matrices: N*N, or 0 if one matrix is shared by all S
+                                         (surface layers) */
+} vsm_added_f64;
+typedef struct vsm_added_f32 {
+  float *r_mp, *t_pp, *r_pm, *t_mm;
+  float *j0_p, *j0_m;
+  long long mat_stride;
+} vsm_added_f32;
+typedef struct vsm_composite_f64 {
+  double *R_mp, *R_pm, *T_pp, *T_mm;  /* R⁻⁺ R⁺⁻ T⁺⁺ T⁻⁻  [N,N,S] */
+  double *J0_p, *J0_m;                /* J₀⁺ J₀⁻          [N,1,S] */
+} vsm_composite_f64;
+typedef struct vsm_composite_f32 {
+  float *R_mp, *R_pm, *T_pp, *T_mm;
+  float *J0_p, *J0_m;
+} vsm_composite_f32;
+
+/* Quadrature + polarization, as rt_kernel! sees them (QuadPoints, types.jl; pol_type.n). */
+typedef struct vsm_quad_f64 {
+  const double* mu;   /* qp_μN[N]  (device) */
+  const double* wt;   /* wt_μN[N]  (device) */
+  int N;              /* Nquad*nStokes */
+  int n_stokes;       /* pol_type.n  (1..4) */
+  int i_mu0;          /* 0-based node index of the SZA stream (iμ₀-1) */
+  double mu0;         /* quad_points.μ₀ */
+} vsm_quad_f64;
+typedef struct vsm_quad_f32 {
+  const float* mu;
+  const float* wt;
+  int N;
+  int n_stokes;
+  int i_mu0;
+  float mu0;
+} vsm_quad_f32;
+
+/* elemental! + doubling! for one homogeneous layer and one Fourier moment m
+ * (src/CoreRT/CoreKernel/elemental.jl:174-230 with kernels :289-334,:348-392,:403-422;
+ *  doubling.jl:38-99 with rt_helpers.jl:102-166 and apply_D doubling.jl:178-252).
+ * Inputs per spectral point: dtau[S] (= τ/2^ndoubl, rt_kernel.jl:266-287 -- ndoubl is
+ * decided by the host from the batch-global max(τϖ), exactly as the reference does),
+ * varpi[S], tau_sum[S] (optical depth above the layer), F0[n_stokes,S].
+ * Zpp/Zmp are Z⁺⁺/Z⁻⁺ [N,N,S] with slice stride z_stride (0 = one Z for all S).
+ * Fills all six fields of `added`.  ndoubl == 0 reproduces the un-doubled branch. */
+int vsm_elemental_doubling_f64(const vsm_quad_f64* q, int S, int m, int ndoubl,
+                               const double* dtau, const double* varpi, const double* tau_sum,
+                               const double* F0, const double* Zpp, const double* Zmp,
+                               long long z_stride, const vsm_added_f64* added, void* stream);
+int vsm_elemental_doubling_f32(const vsm_quad_f32* q, int S, int m, int ndoubl,
+                               const float* dtau, const float* varpi, const float* tau_sum,
+                               const float* F0, const float* Zpp, const float* Zmp,
+                               long long z_stride, const vsm_added_f32* added, void* stream);
+
+/* The two halves separately (operator-for-operator with the reference; used for
+ * N above vsm_fused_max_n and by the per-kernel parity tests). */
+int vsm_elemental_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau,
+                      const double* varpi, const double* tau_sum, const double* F0,
+                      const double* Zpp, const double* Zmp, long long z_stride,
+                      const vsm_added_f64* added, void* stream);
+int vsm_elemental_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau,
+                      const float* varpi, const float* tau_sum, const float* F0,
+                      const float* Zpp, const float* Zmp, long long z_stride,
+                      const vsm_added_f32* added, void* stream);
+/* doubling!: expk[S] = exp(-dtau/μ₀) is updated in place (squared ndoubl times) like the
+ * reference does.  work = scratch of vsm_doubling_work_elems(N,S) elements. */
+size_t vsm_doubling_work_elems(int N, int S);
+int vsm_doubling_f64(int N, int n_stokes, int S, int ndoubl, double* expk,
+                     const vsm_added_f64* added, double* work, void* stream);
+int vsm_doubling_f32(int N, int n_stokes, int S, int ndoubl, float* expk,
+                     const vsm_added_f32* added, float* work, void* stream);
+
+/* Non-scattering layer (rt_helpers.jl:174-180 zero_added_noscat! + rt_kernel.jl:36-45):
+ * r⁻⁺ = r⁺⁻ = 0, j₀⁻ = 0, t±± = diag exp(-τ/μ).  j₀⁺ is left untouched, as in the reference. */
+int vsm_noscat_layer_f64(const vsm_quad_f64* q, int S, const double* tau,
+                         const vsm_added_f64* added, void* stream);
+int vsm_noscat_layer_f32(const vsm_quad_f32* q, int S, const float* tau,
+                         const vsm_added_f32* added, void* stream);
+
+/* copy_added_to_composite! (rt_helpers.jl:188-200), TOA layer. */
+int vsm_copy_added_to_composite_f64(int N, int S, const vsm_added_f64* added,
+                                    const vsm_composite_f64* comp, void* stream);
+int vsm_copy_added_to_composite_f32(int N, int S, const vsm_added_f32* added,
+                                    const vsm_composite_f32* comp, void* stream);
+
+/* interaction! (src/CoreRT/CoreKernel/interaction.jl:52-285): composite (above) ⊕ added
+ * (below) -> composite, in place, statement order as in the reference.
+ * work = scratch of vsm_interaction_work_elems(N,S) elements (only used when
+ * N > vsm_fused_max_n; may be NULL otherwise). */
+size_t vsm_interaction_work_elems(int N, int S);
+int vsm_interaction_f64(int iface, int N, int S, const vsm_composite_f64* comp,
+                        const vsm_added_f64* added, double* work, void* stream);
+int vsm_interaction_f32(int iface, int N, int S, const vsm_composite_f32* comp,
+                        const vsm_added_f32* added, float* work, void* stream);
+/* Same contract, but always executed operator-for-operator (batched products + batch_inv!,
+ * the way the reference issues it); work must be non-NULL.  Used for N above the fused limit
+ * and as an independent cross-check of the fused kernel. */
+int vsm_interaction_oplevel_f64(int iface, int N, int S, const vsm_composite_f64* comp,
+                                const vsm_added_f64* added, double* work, void* stream);
+int vsm_interaction_oplevel_f32(int iface, int N, int S, const vsm_composite_f32* comp,
+                                const vsm_added_f32* added, float* work, void* stream);
+
+/* create_surface_layer!(::LambertianSurfaceScalar) (src/CoreRT/Surfaces/lambertian_surface.jl:41-95).
+ * Writes ONE shared N×N block into each matrix of `added` (added->mat_stride must be 0)
+ * and the per-point source vectors j₀±[N,1,S] from tau_sum[S] (total column). */
+int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albedo,
+                               const double* tau_sum, const vsm_added_f64* added, void* stream);
+int vsm_lambertian_surface_f32(const vsm_quad_f32* q, int S, int m, float albedo,
+                               const float* tau_sum, const vsm_added_f32* added, void* stream);
+
+/* postprocessing_vza! noRS/SFI (src/CoreRT/tools/postprocessing_vza.jl:23-94):
+ *   R[v,k,s] += w[v,k] * J₀⁻[row0[v]+k, s],  T[v,k,s] += w[v,k] * J₀⁺[row0[v]+k, s]
+ * R,T are [nV,n_stokes,S] column-major (v fastest); row0_h[nV] (host) = n_stokes*(iμ_v-1),
+ * w_h[nV*n_stokes] (host, (v,k) at v + nV*k) = weight*{cos mφ,cos mφ,sin mφ,sin mφ}. */
+int vsm_postprocess_vza_f64(int N, int n_stokes, int S, int nV, const int* row0_h,
+                            const double* w_h, const double* J0_m, const double* J0_p,
+                            double* R, double* T, void* stream);
+int vsm_postprocess_vza_f32(int N, int n_stokes, int S, int nV, const int* row0_h,
+                            const float* w_h, const float* J0_m, const float* J0_p,
+                            float* R, float* T, void* stream);
+
+/* ---- diagnostics used by the parity tests -------------------------------- */
+/* Runs the LDS-resident MFMA tile product used inside the fused kernels on plain
+ * [N,N,S] inputs: C = A*B.  (Checks fragment layouts / swizzle independently.) */
+int vsm_test_lds_mm_f64(int N, int S, const double* A, const double* B, double* C, void* stream);
+int vsm_test_lds_mm_f32(int N, int S, const float* A, const float* B, float* C, void* stream);
+/* Inverse via the fused kernels' LDS path (series fast path + pivoted Gauss-Jordan fallback).
+ * mode: 0 = automatic, 1 = force Gauss-Jordan, 2 = force Neumann series. path_out (nullable,
+ * int[S]) receives the path taken per point (1 = GJ, 2.. = series order + 1). */
+int vsm_test_lds_inv_f64(int N, int S, const double* A, double* X, int mode, int* path_out, void* stream);
+int vsm_test_lds_inv_f32(int N, int S, const float* A, float* X, int mode, int* path_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSMARTMOM_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libvsmartmom_hip.so (C ABI: include/vsmartmom_hip.h).
+
+No compute happens in Python: every function here forwards device pointers to
+the HIP library.  If the library is missing or a call fails this module raises
+-- there is NO CPU fallback on the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvsmartmom_hip.so")
+
+
+class VSMError(RuntimeError):
+    pass
+
+
+class vsm_quad_f64(C.Structure):
+    _fields_ = [("mu", C.c_void_p), ("wt", C.c_void_p), ("N", C.c_int), ("n_stokes", C.c_int),
+                ("i_mu0", C.c_int), ("mu0", C.c_double)]
+
+
+class vsm_quad_f32(C.Structure):
+    _fields_ = [("mu", C.c_void_p), ("wt", C.c_void_p), ("N", C.c_int), ("n_stokes", C.c_int),
+                ("i_mu0", C.c_int), ("mu0", C.c_float)]
+
+
+class vsm_added(C.Structure):  # same layout for f32/f64 (pointers + stride)
+    _fields_ = [("r_mp", C.c_void_p), ("t_pp", C.c_void_p), ("r_pm", C.c_void_p), ("t_mm", C.c_void_p),
+                ("j0_p", C.c_void_p), ("j0_m", C.c_void_p), ("mat_stride", C.c_longlong)]
+
+
+class vsm_composite(C.Structure):
+    _fields_ = [("R_mp", C.c_void_p), ("R_pm", C.c_void_p), ("T_pp", C.c_void_p), ("T_mm", C.c_void_p),
+                ("J0_p", C.c_void_p), ("J0_m", C.c_void_p)]
+
+
+_P, _I, _LL, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
+
+# name -> (restype, argtypes); {T} expands to f64/f32, {R} to c_double/c_float
+_SIGS = {
+    "vsm_version": (_I, []),
+    "vsm_last_error": (C.c_char_p, []),
+    "vsm_device_count": (_I, [C.POINTER(_I)]),
+    "vsm_device_name": (_I, [_I, C.c_char_p, _SZ]),
+    "vsm_sync": (_I, [_P]),
+    "vsm_fused_max_n": (_I, [_I]),
+    "vsm_doubling_work_elems": (_SZ, [_I, _I]),
+    "vsm_interaction_work_elems": (_SZ, [_I, _I]),
+    "vsm_batched_mul_{T}": (_I, [_I, _I, _I, _I, _P, _LL, _P, _LL, _P, _P]),
+    "vsm_batch_inv_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
+    "vsm_elemental_doubling_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
+    "vsm_elemental_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
+    "vsm_doubling_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
+    "vsm_noscat_layer_{T}": (_I, [_P, _I, _P, _P, _P]),
+    "vsm_copy_added_to_composite_{T}": (_I, [_I, _I, _P, _P, _P]),
+    "vsm_interaction_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "vsm_interaction_oplevel_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "vsm_lambertian_surface_{T}": (_I, [_P, _I, _I, "{R}", _P, _P, _P]),
+    "vsm_postprocess_vza_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_test_lds_mm_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
+    "vsm_test_lds_inv_{T}": (_I, [_I, _I, _P, _P, _I, _P, _P]),
+}
+
+
+def exported_symbols():
+    """Every symbol include/vsmartmom_hip.h declares (used by the CPU-side ABI test)."""
+    out = []
+    for name in _SIGS:
+        if "{T}" in name:
+            out += [name.format(T="f64"), name.format(T="f32")]
+        else:
+            out.append(name)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (raises VSMError if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VSMError("libvsmartmom_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        for T, R in (("f64", C.c_double), ("f32", C.c_float)):
+            n = name.format(T=T)
+            fn = getattr(L, n)
+            fn.restype = res
+            fn.argtypes = [R if a == "{R}" else a for a in args]
+            if "{T}" not in name:
+                break
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise VSMError("libvsmartmom_hip: status %d: %s" % (rc, lib().vsm_last_error().decode()))
+
+
+def suffix(dtype) -> str:
+    import torch
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise VSMError("unsupported float type %r (Float64 / Float32 only)" % (dtype,))
+
+
+def call(name, dtype, *args):
+    fn = getattr(lib(), "%s_%s" % (name, suffix(dtype)))
+    check(fn(*args))

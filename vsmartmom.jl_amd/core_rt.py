@@ -1,0 +1,423 @@
+"""CoreRT host layer for the MI355X backend: the reference's operator / CoreKernel
+interface for the rt_run hot path, implemented as calls into libvsmartmom_hip.so.
+
+Mirrors (names follow the reference; Julia's trailing `!` becomes `_`):
+  batched_mul, batch_inv_                       ext/gpu_batched_cuda.jl:97-233, tools/cpu_batched.jl
+  make_added_layer, make_composite_layer        tools/rt_helper_functions.jl:130-151,259-270
+  elemental_, doubling_, interaction_           CoreKernel/elemental.jl, doubling.jl, interaction.jl
+  rt_kernel_                                    CoreKernel/rt_kernel.jl:175-250
+  create_surface_layer_, postprocessing_vza_    Surfaces/lambertian_surface.jl:41-95, tools/postprocessing_vza.jl
+  rt_run                                        rt_run.jl:238-539 (noRS, SFI, Lambertian)
+
+Device arrays are torch tensors (plumbing only: allocation, streams, H2D/D2H).
+Memory layout is the reference's column-major [N,N,S]: a matrix batch is a
+contiguous tensor of shape (S, N, N) whose slice [s] holds the matrix
+*transposed* (element (i,j) at [s, j, i]); vectors [N,1,S] are (S, N).
+`to_device_matrix` / `from_device_matrix` convert from/to math order [S,i,j].
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import host_model as H
+from .architectures import GPU, CPU, architecture, array_type, devi, synchronize_if_gpu, to_host
+
+IFACE = {"00": 0, "01": 1, "10": 2, "11": 3}
+
+
+def _require_gpu(arch):
+    if not isinstance(arch, GPU):
+        raise _lib.VSMError("vsmartmom.jl_amd provides the MI355X path only; architecture %r has no compute path here "
+                            "(no CPU fallback by design)" % (arch,))
+    if not torch.cuda.is_available():
+        raise _lib.VSMError("no MI355X visible to HIP (torch.cuda.is_available() is False)")
+
+
+def _torch_dtype(FT):
+    return torch.float64 if np.dtype(FT) == np.float64 else torch.float32
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def to_device_matrix(A: np.ndarray, arch, FT) -> torch.Tensor:
+    """math order [S,i,j] (or [i,j]) -> device tensor in the reference's column-major layout."""
+    A = np.asarray(A, dtype=FT)
+    if A.ndim == 2:
+        A = A[None]
+    return array_type(arch)(np.ascontiguousarray(A.transpose(0, 2, 1)))
+
+
+def from_device_matrix(t: torch.Tensor) -> np.ndarray:
+    return to_host(t).transpose(0, 2, 1).copy()
+
+
+# ----------------------------------------------------------------------------
+# L1 operator API
+# ----------------------------------------------------------------------------
+def batched_mul(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """`A ⊠ B` (NNlib.batched_mul; ext/gpu_batched_cuda.jl:208-233): allocating, inputs untouched.
+    A: (S, K, M) layout-tensor of an [M,K,S] batch, B: (S, Nc, K) or (S, K) for a vector batch."""
+    _require_gpu(architecture(A))
+    vec = B.dim() == 2
+    S, K, M = A.shape
+    Nc = 1 if vec else B.shape[1]
+    kb = B.shape[1] if vec else B.shape[2]
+    if kb != K or B.shape[0] not in (S, 1):
+        raise _lib.VSMError("batched_mul: dimension mismatch %s x %s" % (tuple(A.shape), tuple(B.shape)))
+    A, B = A.contiguous(), B.contiguous()
+    Cout = torch.empty((S, M) if vec else (S, Nc, M), dtype=A.dtype, device=A.device)
+    sb = 0 if B.shape[0] == 1 and S > 1 else K * Nc
+    _lib.call("vsm_batched_mul", A.dtype, M, Nc, K, S, _ptr(A), M * K, _ptr(B), sb, _ptr(Cout), _stream_ptr())
+    return Cout
+
+
+def batch_inv_(X: torch.Tensor, A: torch.Tensor, info: Optional[torch.Tensor] = None):
+    """`batch_inv!(X, A)` (ext/gpu_batched_cuda.jl:97-182).  X may alias A."""
+    _require_gpu(architecture(A))
+    S, N, N2 = A.shape
+    if N != N2 or X.shape != A.shape:
+        raise _lib.VSMError("batch_inv!: square batches of equal shape required")
+    _lib.call("vsm_batch_inv", A.dtype, N, S, _ptr(A), _ptr(X), _ptr(info), _stream_ptr())
+    return X
+
+
+def batched_pointer_cache(A):
+    """ext/gpu_batched_cuda.jl:65-69 -- no pointer arrays are needed by the HIP kernels."""
+    return None
+
+
+# ----------------------------------------------------------------------------
+# containers
+# ----------------------------------------------------------------------------
+@dataclass
+class DeviceQuad:
+    """Device copy of QuadPoints + the C struct handed to the kernels."""
+    host: H.QuadPoints
+    mu: torch.Tensor
+    wt: torch.Tensor
+    n_stokes: int
+    dtype: torch.dtype
+
+    def cstruct(self):
+        cls = _lib.vsm_quad_f64 if self.dtype == torch.float64 else _lib.vsm_quad_f32
+        return cls(self.mu.data_ptr(), self.wt.data_ptr(), int(self.mu.numel()), self.n_stokes, self.host.imu0,
+                   self.host.mu0)
+
+
+def device_quad(qp: H.QuadPoints, pol: H.PolarizationType, arch, FT) -> DeviceQuad:
+    conv = array_type(arch)
+    return DeviceQuad(qp, conv(qp.qp_muN.astype(FT)), conv(qp.wt_muN.astype(FT)), pol.n, _torch_dtype(FT))
+
+
+class AddedLayer:
+    """src/CoreRT/types.jl:155-230 AddedLayer (elastic fields).  `shared=True` allocates ONE
+    N x N block per matrix, broadcast over the spectral axis (surface layers)."""
+
+    def __init__(self, FT, arch, N, nSpec, shared=False):
+        dev, dt = devi(arch), _torch_dtype(FT)
+        sm = 1 if shared else nSpec
+        z = lambda: torch.zeros((sm, N, N), dtype=dt, device=dev)
+        self.r_mp, self.t_pp, self.r_pm, self.t_mm = z(), z(), z(), z()
+        self.j0_p = torch.zeros((nSpec, N), dtype=dt, device=dev)
+        self.j0_m = torch.zeros((nSpec, N), dtype=dt, device=dev)
+        self.N, self.nSpec, self.shared, self.dtype = N, nSpec, shared, dt
+
+    def cstruct(self):
+        return _lib.vsm_added(self.r_mp.data_ptr(), self.t_pp.data_ptr(), self.r_pm.data_ptr(), self.t_mm.data_ptr(),
+                              self.j0_p.data_ptr(), self.j0_m.data_ptr(), 0 if self.shared else self.N * self.N)
+
+
+class CompositeLayer:
+    """src/CoreRT/types.jl CompositeLayer."""
+
+    def __init__(self, FT, arch, N, nSpec):
+        dev, dt = devi(arch), _torch_dtype(FT)
+        z = lambda: torch.zeros((nSpec, N, N), dtype=dt, device=dev)
+        self.R_mp, self.R_pm, self.T_pp, self.T_mm = z(), z(), z(), z()
+        self.J0_p = torch.zeros((nSpec, N), dtype=dt, device=dev)
+        self.J0_m = torch.zeros((nSpec, N), dtype=dt, device=dev)
+        self.N, self.nSpec, self.dtype = N, nSpec, dt
+
+    def cstruct(self):
+        return _lib.vsm_composite(self.R_mp.data_ptr(), self.R_pm.data_ptr(), self.T_pp.data_ptr(),
+                                  self.T_mm.data_ptr(), self.J0_p.data_ptr(), self.J0_m.data_ptr())
+
+
+def make_added_layer(FT, arch, dims, nSpec, shared=False) -> AddedLayer:
+    _require_gpu(arch)
+    return AddedLayer(FT, arch, dims[0], nSpec, shared)
+
+
+def make_composite_layer(FT, arch, dims, nSpec) -> CompositeLayer:
+    _require_gpu(arch)
+    return CompositeLayer(FT, arch, dims[0], nSpec)
+
+
+@dataclass
+class DeviceLayerOptics:
+    """CoreScatteringOpticalProperties after `expandOpticalProperties` (device side).
+    Z is NOT replicated over the spectral axis when it is shared (z_stride = 0)."""
+    tau: torch.Tensor      # [S]
+    varpi: torch.Tensor    # [S]
+    Zpp: torch.Tensor      # (1|S, N, N) layout tensor
+    Zmp: torch.Tensor
+    max_tau_varpi: float   # host copy of maximum(τ .* ϖ) (rt_kernel.jl:197) -- avoids a device sync
+    tau_h: np.ndarray      # host copies used by get_dtau_ndoubl
+    varpi_h: np.ndarray
+
+    @property
+    def z_stride(self):
+        N = self.Zpp.shape[-1]
+        return 0 if self.Zpp.shape[0] == 1 else N * N
+
+
+def expandOpticalProperties(p: H.CoreScatteringOpticalProperties, arch, FT) -> DeviceLayerOptics:
+    """compEffectiveLayerProperties.jl:106-117 + H2D."""
+    conv = array_type(arch)
+    tau = np.atleast_1d(p.tau).astype(FT)
+    varpi = np.broadcast_to(np.asarray(p.varpi, dtype=FT), tau.shape).copy()
+    return DeviceLayerOptics(conv(tau), conv(varpi), to_device_matrix(p.Zpp, arch, FT), to_device_matrix(p.Zmp, arch, FT),
+                             float(np.max(tau * varpi)), tau, varpi)
+
+
+# ----------------------------------------------------------------------------
+# CoreKernel
+# ----------------------------------------------------------------------------
+def elemental_doubling_(pol: H.PolarizationType, tau_sum: torch.Tensor, dtau: torch.Tensor, F0: torch.Tensor,
+                        props: DeviceLayerOptics, m: int, ndoubl: int, dq: DeviceQuad, added: AddedLayer):
+    """elemental! followed by doubling! (one fused launch when N fits on-chip)."""
+    q, a = dq.cstruct(), added.cstruct()
+    _lib.call("vsm_elemental_doubling", added.dtype, C.byref(q), added.nSpec, m, ndoubl, _ptr(dtau), _ptr(props.varpi),
+              _ptr(tau_sum), _ptr(F0), _ptr(props.Zpp), _ptr(props.Zmp), props.z_stride, C.byref(a), _stream_ptr())
+
+
+def elemental_(pol, tau_sum, dtau, F0, props: DeviceLayerOptics, m, ndoubl, dq: DeviceQuad, added: AddedLayer):
+    """elemental! alone (elemental.jl:174-230)."""
+    q, a = dq.cstruct(), added.cstruct()
+    _lib.call("vsm_elemental", added.dtype, C.byref(q), added.nSpec, m, ndoubl, _ptr(dtau), _ptr(props.varpi),
+              _ptr(tau_sum), _ptr(F0), _ptr(props.Zpp), _ptr(props.Zmp), props.z_stride, C.byref(a), _stream_ptr())
+
+
+def doubling_(pol, expk: torch.Tensor, ndoubl: int, added: AddedLayer):
+    """doubling! alone (doubling.jl:38-131), operator-for-operator."""
+    n = _lib.lib().vsm_doubling_work_elems(added.N, added.nSpec)
+    work = torch.empty(max(int(n), 1), dtype=added.dtype, device=added.r_mp.device)
+    a = added.cstruct()
+    _lib.call("vsm_doubling", added.dtype, added.N, pol.n, added.nSpec, ndoubl, _ptr(expk), C.byref(a), _ptr(work),
+              _stream_ptr())
+
+
+def zero_added_noscat_(added: AddedLayer, tau: torch.Tensor, dq: DeviceQuad):
+    q, a = dq.cstruct(), added.cstruct()
+    _lib.call("vsm_noscat_layer", added.dtype, C.byref(q), added.nSpec, _ptr(tau), C.byref(a), _stream_ptr())
+
+
+def copy_added_to_composite_(comp: CompositeLayer, added: AddedLayer):
+    a, c = added.cstruct(), comp.cstruct()
+    _lib.call("vsm_copy_added_to_composite", added.dtype, added.N, added.nSpec, C.byref(a), C.byref(c), _stream_ptr())
+
+
+_work_cache = {}
+
+
+def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False):
+    """interaction! (interaction.jl:268-285).  `oplevel=True` forces the operator-for-operator path
+    (batched products + batch_inv!, like the reference executes it) instead of the fused kernel."""
+    a, c = added.cstruct(), comp.cstruct()
+    N, S = comp.N, comp.nSpec
+    work = None
+    fused = (scattering_interface == "11" and not oplevel
+             and N <= _lib.lib().vsm_fused_max_n(8 if comp.dtype == torch.float64 else 4))
+    if not fused:
+        key = (N, S, comp.dtype, str(comp.R_mp.device))
+        work = _work_cache.get(key)
+        if work is None:
+            _work_cache.clear()
+            work = torch.empty(int(_lib.lib().vsm_interaction_work_elems(N, S)), dtype=comp.dtype, device=comp.R_mp.device)
+            _work_cache[key] = work
+    name = "vsm_interaction_oplevel" if oplevel else "vsm_interaction"
+    _lib.call(name, comp.dtype, IFACE[scattering_interface], N, S, C.byref(c), C.byref(a), _ptr(work), _stream_ptr())
+
+
+def create_surface_layer_(albedo: float, added_surface: AddedLayer, m: int, dq: DeviceQuad, tau_sum: torch.Tensor):
+    """create_surface_layer!(::LambertianSurfaceScalar) (lambertian_surface.jl:41-95)."""
+    if not added_surface.shared:
+        raise _lib.VSMError("surface AddedLayer must be allocated with shared=True")
+    q, a = dq.cstruct(), added_surface.cstruct()
+    alb = C.c_double(albedo) if added_surface.dtype == torch.float64 else C.c_float(albedo)
+    _lib.call("vsm_lambertian_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, alb, _ptr(tau_sum),
+              C.byref(a), _stream_ptr())
+
+
+def postprocessing_vza_(pol: H.PolarizationType, comp: CompositeLayer, vza, vaz, qp: H.QuadPoints, m: int, weight: float,
+                        R_SFI: torch.Tensor, T_SFI: torch.Tensor):
+    """postprocessing_vza! noRS / SFI (postprocessing_vza.jl:23-94).  R_SFI/T_SFI: (S, nStokes, nVZA) layout tensors
+    of the reference's [nVZA, nStokes, nSpec] arrays."""
+    n, nV = pol.n, len(vza)
+    row0 = (C.c_int * nV)()
+    ctype = C.c_double if comp.dtype == torch.float64 else C.c_float
+    w = (ctype * (nV * n))()
+    for v in range(nV):
+        imu = int(np.argmin(np.abs(qp.qp_mu - qp.qp_mu.dtype.type(H.cosd(vza[v])))))
+        row0[v] = imu * n
+        c, s = H.cosd(m * vaz[v]), H.sind(m * vaz[v])
+        ws = [c, c, s, s][:n]
+        for k in range(n):
+            w[v + nV * k] = weight * ws[k]
+    _lib.call("vsm_postprocess_vza", comp.dtype, comp.N, n, comp.nSpec, nV, row0, w, _ptr(comp.J0_m), _ptr(comp.J0_p),
+              _ptr(R_SFI), _ptr(T_SFI), _stream_ptr())
+
+
+def init_layer(props: DeviceLayerOptics, qp: H.QuadPoints, FT, numerics: H.RTNumericalParameters, arch):
+    """rt_kernel.jl:339-349: (dτ, ndoubl) -- expk = exp(-dτ/μ₀) is formed inside the fused kernel."""
+    dtau_h, nd = H.get_dtau_ndoubl(props.tau_h, props.varpi_h, qp, FT, numerics)
+    return array_type(arch)(dtau_h), nd
+
+
+def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerOptics, scattering_interface: str,
+               tau_sum: torch.Tensor, m: int, dq: DeviceQuad, arch, iz: int, F0: torch.Tensor, FT,
+               numerics: H.RTNumericalParameters, dtau: Optional[torch.Tensor] = None, ndoubl: Optional[int] = None,
+               trace: Optional[list] = None):
+    """rt_kernel!(::noRS, ...) (rt_kernel.jl:175-250).  iz is 1-based.  dtau/ndoubl may be
+    passed pre-computed (they only depend on the layer optics)."""
+    scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps
+    nd = 0
+    if scatter:
+        if dtau is None:
+            dtau, ndoubl = init_layer(props, dq.host, FT, numerics, arch)
+        nd = ndoubl
+        elemental_doubling_(pol, tau_sum, dtau, F0, props, m, nd, dq, added)
+    else:
+        zero_added_noscat_(added, props.tau, dq)
+    if trace is not None:
+        trace.append(dict(iz=iz, m=m, scatter=bool(scatter), ndoubl=nd, iface=scattering_interface))
+    if iz == 1:
+        copy_added_to_composite_(comp, added)
+    else:
+        interaction_(scattering_interface, comp, added)
+
+
+# ----------------------------------------------------------------------------
+# rt_run
+# ----------------------------------------------------------------------------
+class Scene:
+    """Everything `rt_run` needs, resident in HBM: per Fourier moment the layer optics
+    (τ, ϖ, dτ per layer and spectral point; Z per layer), interface tags, ndoubl, τ_sum.
+    Built once by `prepare_scene` (host numpy + H2D), executed by `run()` (device only).
+
+    `spec_slice` selects the spectral shard this rank owns; `ndoubl` and the interface tags
+    are always derived from the FULL spectral axis so that a sharded run is identical to
+    the single-device run (rt_kernel.jl:197,282-283 use batch-global maxima)."""
+
+    def __init__(self, model: H.RTModel, spec_slice: Optional[slice] = None):
+        arch, FT = model.architecture, model.float_type
+        _require_gpu(arch)
+        self.model, self.arch, self.FT = model, arch, FT
+        pol, qp = model.polarization_type, model.quad_points
+        self.pol, self.qp = pol, qp
+        S_full, self.Nz = model.tau_rayl.shape
+        self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
+        self.S = len(range(*self.sl.indices(S_full)))
+        self.N = qp.Nquad * pol.n
+        conv = array_type(arch)
+        self.dq = device_quad(qp, pol, arch, FT)
+        F0 = model.F0
+        if F0 is None:
+            F0 = np.zeros((pol.n, S_full))
+            F0[0, :] = 1.0
+        self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, self.sl].T))  # [n,S] col-major == (S,n)
+        self.moments = []
+        for m in range(model.m_max + 1):
+            lods = H.constructCoreOpticalProperties(model, m)
+            tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
+            layers = []
+            for iz, lo in enumerate(lods):
+                tau_full = np.atleast_1d(lo.tau).astype(FT)
+                varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
+                tw = float(np.max(tau_full * varpi_full))
+                scatter = tw > 2 * np.finfo(FT).eps
+                dtau_full, nd = (H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics) if scatter
+                                 else (tau_full, 0))
+                Zpp, Zmp = np.asarray(lo.Zpp), np.asarray(lo.Zmp)
+                if Zpp.ndim == 3:
+                    Zpp, Zmp = Zpp[self.sl], Zmp[self.sl]
+                props = DeviceLayerOptics(conv(np.ascontiguousarray(tau_full[self.sl])),
+                                          conv(np.ascontiguousarray(varpi_full[self.sl])),
+                                          to_device_matrix(Zpp, arch, FT), to_device_matrix(Zmp, arch, FT), tw,
+                                          tau_full, np.asarray(varpi_full))
+                layers.append(dict(props=props, iface=tags[iz], nd=nd,
+                                   dtau=conv(np.ascontiguousarray(dtau_full[self.sl])),
+                                   tau_sum=conv(np.ascontiguousarray(tau_sum_all[self.sl, iz].astype(FT)))))
+            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1],
+                                     tau_sum_surface=conv(np.ascontiguousarray(tau_sum_all[self.sl, -1].astype(FT)))))
+        N, S = self.N, self.S
+        self.added = make_added_layer(FT, arch, (N, N), S)
+        self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=True)
+        self.composite = make_composite_layer(FT, arch, (N, N), S)
+        nV = len(model.vza)
+        dt, dev = _torch_dtype(FT), devi(arch)
+        self.R_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        self.T_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+
+    def run(self, trace: Optional[list] = None):
+        """The device-resident part of rt_run (rt_run.jl:383-517): Fourier loop -> layer loop ->
+        surface -> interaction -> postprocessing.  Asynchronous; returns the device tensors."""
+        model, pol, FT = self.model, self.pol, self.FT
+        self.R_SFI.zero_()
+        self.T_SFI.zero_()
+        self.added.j0_p.zero_()  # a fresh make_added_layer: zero_added_noscat! never writes j0+ (rt_helpers.jl:174-180)
+        for mom in self.moments:
+            m = mom["m"]
+            weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+            for iz, ly in enumerate(mom["layers"]):
+                rt_kernel_(pol, self.added, self.composite, ly["props"], ly["iface"], ly["tau_sum"], m, self.dq,
+                           self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace)
+            create_surface_layer_(model.albedo, self.added_surface, m, self.dq, mom["tau_sum_surface"])
+            interaction_(mom["iface_surface"], self.composite, self.added_surface)
+            postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
+                                self.T_SFI)
+        return self.R_SFI, self.T_SFI
+
+    def results_host(self):
+        """(R_SFI, T_SFI) as the reference returns them: [nVZA, nStokes, nSpec] numpy arrays."""
+        return to_host(self.R_SFI).transpose(2, 1, 0).copy(), to_host(self.T_SFI).transpose(2, 1, 0).copy()
+
+    def flops_per_point(self) -> float:
+        """ALGORITHMIC flops per spectral point: per moment
+        sum_l nd_l (12N^3+8N^2) + [interactions incl. surface] (24N^3+8N^2)."""
+        N = float(self.N)
+        tot = 0.0
+        for mom in self.moments:
+            for iz, ly in enumerate(mom["layers"]):
+                tot += ly["nd"] * (12 * N ** 3 + 8 * N ** 2)
+                if iz > 0:
+                    tot += 24 * N ** 3 + 8 * N ** 2
+            tot += 24 * N ** 3 + 8 * N ** 2  # surface interaction
+        return tot
+
+
+def prepare_scene(model: H.RTModel, spec_slice: Optional[slice] = None) -> Scene:
+    return Scene(model, spec_slice)
+
+
+def rt_run(model: H.RTModel, trace: Optional[list] = None):
+    """rt_run(model) (rt_run.jl:53-58 -> :238-539): returns (R_SFI, T_SFI) as host arrays
+    [nVZA, nStokes, nSpec] (the reference's first two return values; the Raman/HDRF slots are
+    out of scope of this backend)."""
+    scene = prepare_scene(model)
+    scene.run(trace)
+    synchronize_if_gpu()
+    return scene.results_host()

@@ -1,0 +1,358 @@
+// extern "C" entry points of libvsmartmom_hip.so (see include/vsmartmom_hip.h).
+#include <mutex>
+#include <string.h>
+
+#include "vsm_internal.h"
+
+namespace vsm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+int hip_fail(hipError_t e, const char* what) {
+  set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+  return VSM_ERR_HIP;
+}
+
+// grow-only scratch, one buffer per slot (single stream per device, like the reference's
+// single driving task; see SURVEY.md 8b "Threading").
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+static size_t g_scratch_sz[4] = {0, 0, 0, 0};
+void* scratch(size_t bytes, int slot) {
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (bytes <= g_scratch_sz[slot]) return g_scratch_ptr[slot];
+  if (g_scratch_ptr[slot]) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_scratch_ptr[slot]);
+    g_scratch_ptr[slot] = nullptr;
+    g_scratch_sz[slot] = 0;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipMalloc(scratch)");
+    return nullptr;
+  }
+  g_scratch_ptr[slot] = p;
+  g_scratch_sz[slot] = bytes;
+  return p;
+}
+
+template <typename T, typename Q>
+static quad<T> cvt_quad(const Q* q) {
+  quad<T> r;
+  r.mu = q->mu;
+  r.wt = q->wt;
+  r.N = q->N;
+  r.n_stokes = q->n_stokes;
+  r.i_mu0 = q->i_mu0;
+  r.mu0 = q->mu0;
+  return r;
+}
+template <typename T, typename A>
+static added<T> cvt_added(const A* a) {
+  added<T> r;
+  r.r_mp = a->r_mp;
+  r.t_pp = a->t_pp;
+  r.r_pm = a->r_pm;
+  r.t_mm = a->t_mm;
+  r.j0_p = a->j0_p;
+  r.j0_m = a->j0_m;
+  r.mat_stride = a->mat_stride;
+  return r;
+}
+template <typename T, typename C>
+static composite<T> cvt_comp(const C* c) {
+  composite<T> r;
+  r.R_mp = c->R_mp;
+  r.R_pm = c->R_pm;
+  r.T_pp = c->T_pp;
+  r.T_mm = c->T_mm;
+  r.J0_p = c->J0_p;
+  r.J0_m = c->J0_m;
+  return r;
+}
+
+template <typename Q>
+static int check_quad(const Q* q) {
+  VSM_REQUIRE(q != nullptr, "quad: null");
+  VSM_REQUIRE(q->mu && q->wt, "quad: null mu/wt");
+  VSM_REQUIRE(q->N > 0 && q->n_stokes >= 1 && q->n_stokes <= 4 && q->N % q->n_stokes == 0,
+              "quad: bad N=%d / n_stokes=%d", q->N, q->n_stokes);
+  VSM_REQUIRE(q->i_mu0 >= 0 && (q->i_mu0 + 1) * q->n_stokes <= q->N, "quad: i_mu0=%d out of range", q->i_mu0);
+  return VSM_OK;
+}
+template <typename A>
+static int check_added(const A* a) {
+  VSM_REQUIRE(a != nullptr, "added: null");
+  VSM_REQUIRE(a->r_mp && a->t_pp && a->r_pm && a->t_mm && a->j0_p && a->j0_m, "added: null field");
+  return VSM_OK;
+}
+template <typename C>
+static int check_comp(const C* c) {
+  VSM_REQUIRE(c != nullptr, "composite: null");
+  VSM_REQUIRE(c->R_mp && c->R_pm && c->T_pp && c->T_mm && c->J0_p && c->J0_m, "composite: null field");
+  return VSM_OK;
+}
+
+int launch_expk_f(int S, const void* dtau, double mu0, void* expk, int esz, hipStream_t st);
+
+template <typename T, typename Q, typename A>
+static int elemental_doubling_impl(const Q* q, int S, int m, int ndoubl, const T* dtau, const T* varpi,
+                                   const T* tau_sum, const T* F0, const T* Zpp, const T* Zmp, long long zs,
+                                   const A* ad, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(ad))) return rc;
+  VSM_REQUIRE(S >= 0 && m >= 0 && ndoubl >= 0, "elemental_doubling: bad S/m/ndoubl");
+  VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "elemental_doubling: null input");
+  const quad<T> qq = cvt_quad<T>(q);
+  const added<T> aa = cvt_added<T>(ad);
+  hipStream_t st = as_stream(stream);
+  if (q->N <= fused_max_n<T>())
+    return fused_elemental_doubling<T>(qq, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, aa, st);
+  // operator-level path for N that does not fit on-chip
+  if ((rc = elemental<T>(qq, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, aa, st))) return rc;
+  if (ndoubl == 0) return VSM_OK;
+  const size_t we = vsm_doubling_work_elems(q->N, S);
+  T* work = static_cast<T*>(scratch(we * sizeof(T) + (size_t)S * sizeof(T), 0));
+  if (!work) return VSM_ERR_HIP;
+  T* expk = work + we;
+  // expk = exp(-dtau/mu0)  (rt_kernel.jl:339-349 init_layer)
+  if ((rc = launch_expk_f(S, dtau, (double)q->mu0, expk, (int)sizeof(T), st))) return rc;
+  return doubling<T>(q->N, q->n_stokes, S, ndoubl, expk, aa, work, st);
+}
+
+template <typename T>
+__global__ void k_expk(int S, const T* __restrict__ dtau, T mu0, T* expk) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < S) expk[e] = exp(-dtau[e] / mu0);
+}
+int launch_expk_f(int S, const void* dtau, double mu0, void* expk, int esz, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  if (esz == 8)
+    hipLaunchKernelGGL(k_expk<double>, dim3((S + 255) / 256), dim3(256), 0, st, S, (const double*)dtau, mu0,
+                       (double*)expk);
+  else
+    hipLaunchKernelGGL(k_expk<float>, dim3((S + 255) / 256), dim3(256), 0, st, S, (const float*)dtau, (float)mu0,
+                       (float*)expk);
+  VSM_LAUNCH_CHECK("k_expk");
+  return VSM_OK;
+}
+
+template <typename T, typename C, typename A>
+static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* work, void* stream, bool oplevel) {
+  int rc;
+  if ((rc = check_comp(c)) || (rc = check_added(a))) return rc;
+  VSM_REQUIRE(N > 0 && S >= 0, "interaction: bad N/S");
+  VSM_REQUIRE(iface >= 0 && iface <= 3, "interaction: unknown scattering interface %d", iface);
+  hipStream_t st = as_stream(stream);
+  if (!oplevel && iface == VSM_IFACE_11 && N <= fused_max_n<T>())
+    return fused_interaction<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
+  if (!work) {
+    work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1));
+    if (!work) return VSM_ERR_HIP;
+  }
+  return interaction_generic<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), work, st);
+}
+
+}  // namespace vsm
+
+using namespace vsm;
+
+extern "C" {
+
+int vsm_version(void) { return 100; /* 0.1.0 */ }
+const char* vsm_last_error(void) { return g_err; }
+int vsm_device_count(int* count) {
+  VSM_REQUIRE(count != nullptr, "device_count: null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    hip_fail(e, "hipGetDeviceCount");
+    return VSM_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return VSM_OK;
+}
+int vsm_device_name(int device, char* buf, size_t buflen) {
+  VSM_REQUIRE(buf && buflen > 0, "device_name: bad buffer");
+  hipDeviceProp_t p;
+  VSM_HIP(hipGetDeviceProperties(&p, device));
+  snprintf(buf, buflen, "%s (%s)", p.name, p.gcnArchName);
+  return VSM_OK;
+}
+int vsm_sync(void* stream) {
+  VSM_HIP(hipStreamSynchronize(as_stream(stream)));
+  return VSM_OK;
+}
+int vsm_fused_max_n(int elem_size) { return elem_size == 8 ? fused_max_n<double>() : fused_max_n<float>(); }
+
+// ---- batched_mul / batch_inv! -------------------------------------------------
+int vsm_batched_mul_f64(int M, int Nc, int K, int S, const double* A, long long sa, const double* B, long long sb,
+                        double* C, void* stream) {
+  VSM_REQUIRE(M > 0 && Nc > 0 && K > 0 && S >= 0 && A && B && C, "batched_mul: bad argument");
+  return gemm<double>(M, Nc, K, S, A, sa, B, sb, C, (long long)M * Nc, 1.0, nullptr, 0, 0.0, 0.0, as_stream(stream));
+}
+int vsm_batched_mul_f32(int M, int Nc, int K, int S, const float* A, long long sa, const float* B, long long sb,
+                        float* C, void* stream) {
+  VSM_REQUIRE(M > 0 && Nc > 0 && K > 0 && S >= 0 && A && B && C, "batched_mul: bad argument");
+  return gemm<float>(M, Nc, K, S, A, sa, B, sb, C, (long long)M * Nc, 1.f, nullptr, 0, 0.f, 0.f, as_stream(stream));
+}
+int vsm_batch_inv_f64(int N, int S, const double* A, double* X, int* info, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && A && X, "batch_inv: bad argument");
+  return batch_inv<double>(N, S, A, X, info, as_stream(stream));
+}
+int vsm_batch_inv_f32(int N, int S, const float* A, float* X, int* info, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && A && X, "batch_inv: bad argument");
+  return batch_inv<float>(N, S, A, X, info, as_stream(stream));
+}
+
+// ---- CoreKernel -----------------------------------------------------------------
+int vsm_elemental_doubling_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau,
+                               const double* varpi, const double* tau_sum, const double* F0, const double* Zpp,
+                               const double* Zmp, long long z_stride, const vsm_added_f64* added, void* stream) {
+  return elemental_doubling_impl<double>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, added, stream);
+}
+int vsm_elemental_doubling_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                               const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp,
+                               long long z_stride, const vsm_added_f32* added, void* stream) {
+  return elemental_doubling_impl<float>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, added, stream);
+}
+
+int vsm_elemental_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                      const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp,
+                      long long z_stride, const vsm_added_f64* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "elemental: null input");
+  return elemental<double>(cvt_quad<double>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride,
+                           cvt_added<double>(added), as_stream(stream));
+}
+int vsm_elemental_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                      const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
+                      const vsm_added_f32* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "elemental: null input");
+  return elemental<float>(cvt_quad<float>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride,
+                          cvt_added<float>(added), as_stream(stream));
+}
+
+size_t vsm_doubling_work_elems(int N, int S) {
+  return (size_t)3 * N * N * (size_t)S + (size_t)4 * N * (size_t)S;
+}
+int vsm_doubling_f64(int N, int n_stokes, int S, int ndoubl, double* expk, const vsm_added_f64* added, double* work,
+                     void* stream) {
+  int rc;
+  if ((rc = check_added(added))) return rc;
+  VSM_REQUIRE(N > 0 && S >= 0 && ndoubl >= 0 && expk && (work || ndoubl == 0), "doubling: bad argument");
+  return doubling<double>(N, n_stokes, S, ndoubl, expk, cvt_added<double>(added), work, as_stream(stream));
+}
+int vsm_doubling_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const vsm_added_f32* added, float* work,
+                     void* stream) {
+  int rc;
+  if ((rc = check_added(added))) return rc;
+  VSM_REQUIRE(N > 0 && S >= 0 && ndoubl >= 0 && expk && (work || ndoubl == 0), "doubling: bad argument");
+  return doubling<float>(N, n_stokes, S, ndoubl, expk, cvt_added<float>(added), work, as_stream(stream));
+}
+
+int vsm_noscat_layer_f64(const vsm_quad_f64* q, int S, const double* tau, const vsm_added_f64* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(tau != nullptr, "noscat_layer: null tau");
+  return noscat_layer<double>(cvt_quad<double>(q), S, tau, cvt_added<double>(added), as_stream(stream));
+}
+int vsm_noscat_layer_f32(const vsm_quad_f32* q, int S, const float* tau, const vsm_added_f32* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(tau != nullptr, "noscat_layer: null tau");
+  return noscat_layer<float>(cvt_quad<float>(q), S, tau, cvt_added<float>(added), as_stream(stream));
+}
+
+int vsm_copy_added_to_composite_f64(int N, int S, const vsm_added_f64* added, const vsm_composite_f64* comp,
+                                    void* stream) {
+  int rc;
+  if ((rc = check_added(added)) || (rc = check_comp(comp))) return rc;
+  return copy_added_to_composite<double>(N, S, cvt_added<double>(added), cvt_comp<double>(comp), as_stream(stream));
+}
+int vsm_copy_added_to_composite_f32(int N, int S, const vsm_added_f32* added, const vsm_composite_f32* comp,
+                                    void* stream) {
+  int rc;
+  if ((rc = check_added(added)) || (rc = check_comp(comp))) return rc;
+  return copy_added_to_composite<float>(N, S, cvt_added<float>(added), cvt_comp<float>(comp), as_stream(stream));
+}
+
+size_t vsm_interaction_work_elems(int N, int S) {
+  return (size_t)3 * N * N * (size_t)S + (size_t)2 * N * (size_t)S;
+}
+int vsm_interaction_f64(int iface, int N, int S, const vsm_composite_f64* comp, const vsm_added_f64* added,
+                        double* work, void* stream) {
+  return interaction_impl<double>(iface, N, S, comp, added, work, stream, false);
+}
+int vsm_interaction_oplevel_f64(int iface, int N, int S, const vsm_composite_f64* comp, const vsm_added_f64* added,
+                                double* work, void* stream) {
+  return interaction_impl<double>(iface, N, S, comp, added, work, stream, true);
+}
+int vsm_interaction_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_added_f32* added,
+                        float* work, void* stream) {
+  return interaction_impl<float>(iface, N, S, comp, added, work, stream, false);
+}
+int vsm_interaction_oplevel_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_added_f32* added,
+                                float* work, void* stream) {
+  return interaction_impl<float>(iface, N, S, comp, added, work, stream, true);
+}
+
+int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albedo, const double* tau_sum,
+                               const vsm_added_f64* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(tau_sum != nullptr, "lambertian_surface: null tau_sum");
+  return lambertian_surface<double>(cvt_quad<double>(q), S, m, albedo, tau_sum, cvt_added<double>(added),
+                                    as_stream(stream));
+}
+int vsm_lambertian_surface_f32(const vsm_quad_f32* q, int S, int m, float albedo, const float* tau_sum,
+                               const vsm_added_f32* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(tau_sum != nullptr, "lambertian_surface: null tau_sum");
+  return lambertian_surface<float>(cvt_quad<float>(q), S, m, albedo, tau_sum, cvt_added<float>(added),
+                                   as_stream(stream));
+}
+
+int vsm_postprocess_vza_f64(int N, int n_stokes, int S, int nV, const int* row0_h, const double* w_h,
+                            const double* J0_m, const double* J0_p, double* R, double* T, void* stream) {
+  VSM_REQUIRE(row0_h && w_h && J0_m && J0_p && R && T, "postprocess_vza: null argument");
+  return postprocess_vza<double>(N, n_stokes, S, nV, row0_h, w_h, J0_m, J0_p, R, T, as_stream(stream));
+}
+int vsm_postprocess_vza_f32(int N, int n_stokes, int S, int nV, const int* row0_h, const float* w_h,
+                            const float* J0_m, const float* J0_p, float* R, float* T, void* stream) {
+  VSM_REQUIRE(row0_h && w_h && J0_m && J0_p && R && T, "postprocess_vza: null argument");
+  return postprocess_vza<float>(N, n_stokes, S, nV, row0_h, w_h, J0_m, J0_p, R, T, as_stream(stream));
+}
+
+// ---- diagnostics ----------------------------------------------------------------
+int vsm_test_lds_mm_f64(int N, int S, const double* A, const double* B, double* C, void* stream) {
+  VSM_REQUIRE(N > 0 && A && B && C, "test_lds_mm: bad argument");
+  return test_lds_mm<double>(N, S, A, B, C, as_stream(stream));
+}
+int vsm_test_lds_mm_f32(int N, int S, const float* A, const float* B, float* C, void* stream) {
+  VSM_REQUIRE(N > 0 && A && B && C, "test_lds_mm: bad argument");
+  return test_lds_mm<float>(N, S, A, B, C, as_stream(stream));
+}
+int vsm_test_lds_inv_f64(int N, int S, const double* A, double* X, int mode, int* path_out, void* stream) {
+  VSM_REQUIRE(N > 0 && A && X, "test_lds_inv: bad argument");
+  return test_lds_inv<double>(N, S, A, X, mode, path_out, as_stream(stream));
+}
+int vsm_test_lds_inv_f32(int N, int S, const float* A, float* X, int mode, int* path_out, void* stream) {
+  VSM_REQUIRE(N > 0 && A && X, "test_lds_inv: bad argument");
+  return test_lds_inv<float>(N, S, A, X, mode, path_out, as_stream(stream));
+}
+
+}  // extern "C"

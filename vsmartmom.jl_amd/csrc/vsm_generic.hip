@@ -1,0 +1,523 @@
+// Operator-level ("generic") kernels: any N up to 128, matrices streamed from HBM/L2.
+// These are the drop-in replacements for the reference's batched operators and
+// KernelAbstractions kernels one-for-one; the fused LDS-resident kernels in
+// vsm_fused.hip are the fast path for N that fits on-chip.
+#include "vsm_internal.h"
+#include "vsm_inverse.h"
+
+namespace vsm {
+
+// ---------------------------------------------------------------------------
+// C = alpha * A*B + beta * D + gamma * I      (batched, column-major)
+// Replaces CUBLAS.gemm_strided_batched (ext/gpu_batched_cuda.jl:208-233) plus the
+// broadcast that the reference launches around it (e.g. `I_static .- r ⊠ r`).
+// One wave per 16x16 output tile; operands read straight from global (L2-resident).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm(int M, int Nc, int K, const T* __restrict__ A, long long sa,
+                                              const T* __restrict__ B, long long sb, T* C, long long sc,
+                                              T alpha, const T* D, long long sd, T beta, T gamma) {
+  const int s = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tilesM = (M + 15) >> 4, tilesN = (Nc + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tilesM * tilesN) return;  // wave-uniform
+  const int ti = tile % tilesM, tj = tile / tilesM;
+  const T* As = A + (long long)s * sa;
+  const T* Bs = B + (long long)s * sb;
+  const int ai = ti * 16 + (lane & 15);
+  const int bj = tj * 16 + (lane & 15);
+  const int kq = lane >> 4;
+  typename mfma<T>::acc_t acc = acc_zero<T>();
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + kq;
+    const T a = (ai < M && k < K) ? As[ai + (long long)M * k] : T(0);
+    const T b = (bj < Nc && k < K) ? Bs[k + (long long)K * bj] : T(0);
+    acc = mfma<T>::mma(a, b, acc);
+  }
+  T* Cs = C + (long long)s * sc;
+  const T* Ds = D ? D + (long long)s * sd : nullptr;
+  const int col = tj * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ti * 16 + mfma<T>::crow(lane, r);
+    if (row < M && col < Nc) {
+      T v = alpha * acc[r];
+      if (Ds) v += beta * Ds[row + (long long)M * col];
+      if (row == col) v += gamma;
+      Cs[row + (long long)M * col] = v;
+    }
+  }
+}
+
+template <typename T>
+int gemm(int M, int Nc, int K, int S, const T* A, long long sa, const T* B, long long sb, T* C, long long sc,
+         T alpha, const T* D, long long sd, T beta, T gamma, hipStream_t st) {
+  if (S <= 0 || M <= 0 || Nc <= 0) return VSM_OK;
+  const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
+  dim3 grid((tiles + 3) / 4, S);
+  hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma);
+  VSM_LAUNCH_CHECK("k_gemm");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batch_inv!
+// ---------------------------------------------------------------------------
+template <typename T, int NPAD>
+__global__ __launch_bounds__(256) void k_batch_inv(int N, const T* A, T* X, int* info) {
+  using C = gj_cfg<NPAD>;
+  __shared__ gj_scratch<T, NPAD> sc;
+  const int s = blockIdx.x;
+  const T* As = A + (long long)s * N * N;
+  T* Xs = X + (long long)s * N * N;
+  const int tr = threadIdx.x % C::TR, tc = threadIdx.x / C::TR;
+  T a[C::RB][C::CB];
+#pragma unroll
+  for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < C::CB; ++cb) {
+      const int i = tr + C::TR * rb, j = tc * C::CB + cb;
+      a[rb][cb] = (i < N && j < N) ? As[i + (long long)N * j] : (i == j ? T(1) : T(0));
+    }
+  gj_invert<T, NPAD>(a, N, sc);
+#pragma unroll
+  for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < C::CB; ++cb) {
+      const int i = tr + C::TR * rb, j = tc * C::CB + cb;
+      if (i < N && j < N) Xs[i + (long long)N * sc.dst[j]] = a[rb][cb];
+    }
+  if (info && threadIdx.x == 0) info[s] = sc.info;
+}
+
+template <typename T>
+int batch_inv(int N, int S, const T* A, T* X, int* info, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  if (N > 128) {
+    set_error("batch_inv: N=%d > 128 is not supported by the register-resident Gauss-Jordan kernel", N);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (N <= 32)
+    hipLaunchKernelGGL((k_batch_inv<T, 32>), dim3(S), dim3(256), 0, st, N, A, X, info);
+  else if (N <= 64)
+    hipLaunchKernelGGL((k_batch_inv<T, 64>), dim3(S), dim3(256), 0, st, N, A, X, info);
+  else if (N <= 96)
+    hipLaunchKernelGGL((k_batch_inv<T, 96>), dim3(S), dim3(256), 0, st, N, A, X, info);
+  else
+    hipLaunchKernelGGL((k_batch_inv<T, 128>), dim3(S), dim3(256), 0, st, N, A, X, info);
+  VSM_LAUNCH_CHECK("k_batch_inv");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// elemental!  (get_elem_rt! + apply_D_elemental!, elemental.jl:289-334,403-422)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_elemental(int N, int n_stokes, int m, int ndoubl, const T* __restrict__ dtau,
+                                                   const T* __restrict__ varpi, const T* __restrict__ Zpp,
+                                                   const T* __restrict__ Zmp, long long zs, const T* __restrict__ mu,
+                                                   const T* __restrict__ wt, T* r_mp, T* t_pp, T* r_pm, T* t_mm) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int s = blockIdx.y;
+  const int i = e % N, j = e / N;
+  const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
+  const T mi = mu[i], mj = mu[j];
+  const T d = dtau[s], w = varpi[s];
+  const long long zo = (long long)s * zs + e;
+  T r, t;
+  if (wct > num<T>::eps()) {
+    r = w * Zmp[zo] * (mj / (mi + mj)) * wct * (-expm1(-d * ((T(1) / mi) + (T(1) / mj))));
+    if (mi == mj) {
+      if (i == j)
+        t = exp(-d / mi) * (T(1) + w * Zpp[zo] * (d / mi) * wct);
+      else
+        t = exp(-d / mj) * (w * Zpp[zo] * (d / mi) * wct);
+    } else {
+      t = w * Zpp[zo] * (mj / (mi - mj)) * wct * expdiff_neg<T>(d / mi, d / mj);
+    }
+  } else {
+    r = T(0);
+    t = (i == j) ? exp(-d / mi) : T(0);
+  }
+  const long long o = (long long)s * N * N + e;
+  if (ndoubl < 1) {
+    const bool same = is_uv_row(i, n_stokes) == is_uv_row(j, n_stokes);
+    r_mp[o] = r;
+    t_pp[o] = t;
+    r_pm[o] = same ? r : -r;
+    t_mm[o] = same ? t : -t;
+  } else {
+    r_mp[o] = is_uv_row(i, n_stokes) ? -r : r;
+    t_pp[o] = t;
+  }
+}
+
+// get_elem_rt_SFI! (elemental.jl:348-392)
+template <typename T>
+__global__ __launch_bounds__(256) void k_elemental_sfi(int N, int n_stokes, int S, int m, int ndoubl, int i_mu0,
+                                                       const T* __restrict__ dtau, const T* __restrict__ varpi,
+                                                       const T* __restrict__ tau_sum, const T* __restrict__ F0,
+                                                       const T* __restrict__ Zpp, const T* __restrict__ Zmp,
+                                                       long long zs, const T* __restrict__ mu, T* j0_p, T* j0_m) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * S) return;
+  const int i = e % N, s = e / N;
+  const int i_start = n_stokes * i_mu0;
+  const T wct02 = (m == 0) ? T(0.5) : T(0.25);
+  T zp = 0, zm = 0;
+  for (int q = 0; q < n_stokes; ++q) {
+    const long long zo = (long long)s * zs + i + (long long)N * (i_start + q);
+    const T f = F0[q + (long long)n_stokes * s];
+    zp += Zpp[zo] * f;
+    zm += Zmp[zo] * f;
+  }
+  const T d = dtau[s], w = varpi[s];
+  const T mi = mu[i], ms = mu[i_start];
+  T jp;
+  if (i >= i_start && i < i_start + n_stokes)
+    jp = wct02 * w * zp * (d / mi) * exp(-d / mi);
+  else
+    jp = wct02 * w * zp * (ms / (mi - ms)) * expdiff_neg<T>(d / mi, d / ms);
+  T jm = wct02 * w * zm * (ms / (mi + ms)) * (-expm1(-d * ((T(1) / mi) + (T(1) / ms))));
+  const T att = exp(-tau_sum[s] / ms);
+  jp *= att;
+  jm *= att;
+  if (ndoubl >= 1 && is_uv_row(i, n_stokes)) jm = -jm;
+  j0_p[e] = jp;
+  j0_m[e] = jm;
+}
+
+template <typename T>
+int elemental(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+              const T* F0, const T* Zpp, const T* Zmp, long long zs, const added<T>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int N = q.N;
+  hipLaunchKernelGGL(k_elemental<T>, dim3((N * N + 255) / 256, S), dim3(256), 0, st, N, q.n_stokes, m, ndoubl, dtau,
+                     varpi, Zpp, Zmp, zs, q.mu, q.wt, a.r_mp, a.t_pp, a.r_pm, a.t_mm);
+  VSM_LAUNCH_CHECK("k_elemental");
+  hipLaunchKernelGGL(k_elemental_sfi<T>, dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+                     q.i_mu0, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, q.mu, a.j0_p, a.j0_m);
+  VSM_LAUNCH_CHECK("k_elemental_sfi");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// small elementwise kernels
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_scale2(int N, int S, const T* __restrict__ expk, const T* __restrict__ a, const T* __restrict__ b,
+                         T* oa, T* ob) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * S) return;
+  const T k = expk[e / N];
+  oa[e] = a[e] * k;
+  ob[e] = b[e] * k;
+}
+template <typename T>
+__global__ void k_square(int S, T* x) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < S) x[e] = x[e] * x[e];
+}
+// dst[N*N*S] <- src with slice stride ss (0 = broadcast one matrix)
+template <typename T>
+__global__ void k_copy_strided(long long per, int S, const T* __restrict__ src, long long ss, T* dst) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= per) return;
+  const int s = blockIdx.y;
+  dst[(long long)s * per + e] = src[(long long)s * ss + e];
+}
+template <typename T>
+int copy_strided(long long per, int S, const T* src, long long ss, T* dst, hipStream_t st) {
+  if (S <= 0 || per <= 0) return VSM_OK;
+  hipLaunchKernelGGL(k_copy_strided<T>, dim3((unsigned)((per + 255) / 256), S), dim3(256), 0, st, per, S, src, ss, dst);
+  VSM_LAUNCH_CHECK("k_copy_strided");
+  return VSM_OK;
+}
+
+// apply_D! + apply_D_SFI! after doubling (doubling.jl:178-252)
+template <typename T>
+__global__ void k_apply_D(int N, int n_stokes, T* r_mp, const T* __restrict__ t_pp, T* r_pm, T* t_mm, T* j0_m) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int s = blockIdx.y;
+  const int i = e % N, j = e / N;
+  const long long o = (long long)s * N * N + e;
+  T r = r_mp[o];
+  const T t = t_pp[o];
+  const bool ui = is_uv_row(i, n_stokes), uj = is_uv_row(j, n_stokes);
+  if (ui) r = -r;
+  r_mp[o] = r;
+  r_pm[o] = (ui == uj) ? r : -r;
+  t_mm[o] = (ui == uj) ? t : -t;
+  if (j == 0 && ui) j0_m[(long long)s * N + i] = -j0_m[(long long)s * N + i];
+}
+
+template <typename T>
+int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a, T* work, hipStream_t st) {
+  if (ndoubl == 0 || S <= 0) return VSM_OK;  // doubling.jl:50
+  const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
+  T* W1 = work;
+  T* W2 = W1 + per;
+  T* W3 = W2 + per;
+  T* v1 = W3 + per;  // j1+
+  T* v2 = v1 + pv;   // j1-
+  T* v3 = v2 + pv;
+  T* v4 = v3 + pv;
+  int rc;
+  const T* nul = nullptr;
+  for (int n = 0; n < ndoubl; ++n) {
+    // G = (I - r r)^-1 ; tt = t G            (rt_helpers.jl:102-107)
+    if ((rc = gemm<T>(N, N, N, S, a.r_mp, NN, a.r_mp, NN, W1, NN, T(-1), nul, 0, T(0), T(1), st))) return rc;
+    if ((rc = batch_inv<T>(N, S, W1, W1, nullptr, st))) return rc;
+    if ((rc = gemm<T>(N, N, N, S, a.t_pp, NN, W1, NN, W2, NN, T(1), nul, 0, T(0), T(0), st))) return rc;
+    // sources                                 (rt_helpers.jl:128-134)
+    hipLaunchKernelGGL(k_scale2<T>, dim3((unsigned)((pv + 255) / 256)), dim3(256), 0, st, N, S, expk, a.j0_p, a.j0_m, v1, v2);
+    VSM_LAUNCH_CHECK("k_scale2");
+    if ((rc = gemm<T>(N, 1, N, S, a.r_mp, NN, a.j0_p, N, v3, N, T(1), v2, N, T(1), T(0), st))) return rc;   // j1- + r j0+
+    if ((rc = gemm<T>(N, 1, N, S, W2, NN, v3, N, v4, N, T(1), a.j0_m, N, T(1), T(0), st))) return rc;        // j0- new
+    if ((rc = gemm<T>(N, 1, N, S, a.r_mp, NN, v2, N, v3, N, T(1), a.j0_p, N, T(1), T(0), st))) return rc;    // j0+ + r j1-
+    if ((rc = gemm<T>(N, 1, N, S, W2, NN, v3, N, a.j0_p, N, T(1), v1, N, T(1), T(0), st))) return rc;        // j0+ new
+    if ((rc = copy_strided<T>(pv, 1, v4, 0, a.j0_m, st))) return rc;
+    // r <- r + tt r t ; t <- tt t ; expk <- expk^2   (rt_helpers.jl:161-166)
+    if ((rc = gemm<T>(N, N, N, S, W2, NN, a.r_mp, NN, W3, NN, T(1), nul, 0, T(0), T(0), st))) return rc;
+    if ((rc = gemm<T>(N, N, N, S, W3, NN, a.t_pp, NN, a.r_mp, NN, T(1), a.r_mp, NN, T(1), T(0), st))) return rc;
+    if ((rc = gemm<T>(N, N, N, S, W2, NN, a.t_pp, NN, W3, NN, T(1), nul, 0, T(0), T(0), st))) return rc;
+    if ((rc = copy_strided<T>(per, 1, W3, 0, a.t_pp, st))) return rc;
+    hipLaunchKernelGGL(k_square<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
+    VSM_LAUNCH_CHECK("k_square");
+  }
+  hipLaunchKernelGGL(k_apply_D<T>, dim3((unsigned)((NN + 255) / 256), S), dim3(256), 0, st, N, n_stokes, a.r_mp, a.t_pp,
+                     a.r_pm, a.t_mm, a.j0_m);
+  VSM_LAUNCH_CHECK("k_apply_D");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// non-scattering layer, TOA copy
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_noscat(int N, const T* __restrict__ tau, const T* __restrict__ mu, T* r_mp, T* r_pm, T* t_pp,
+                         T* t_mm, T* j0_m) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int s = blockIdx.y;
+  const int i = e % N, j = e / N;
+  const long long o = (long long)s * N * N + e;
+  const T t = (i == j) ? exp(-tau[s] / mu[i]) : T(0);
+  r_mp[o] = T(0);
+  r_pm[o] = T(0);
+  t_pp[o] = t;
+  t_mm[o] = t;
+  if (j == 0) j0_m[(long long)s * N + i] = T(0);
+}
+template <typename T>
+int noscat_layer(const quad<T>& q, int S, const T* tau, const added<T>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int N = q.N;
+  hipLaunchKernelGGL(k_noscat<T>, dim3((N * N + 255) / 256, S), dim3(256), 0, st, N, tau, q.mu, a.r_mp, a.r_pm, a.t_pp,
+                     a.t_mm, a.j0_m);
+  VSM_LAUNCH_CHECK("k_noscat");
+  return VSM_OK;
+}
+
+template <typename T>
+int copy_added_to_composite(int N, int S, const added<T>& a, const composite<T>& c, hipStream_t st) {
+  const long long NN = (long long)N * N;
+  int rc;
+  if ((rc = copy_strided<T>(NN, S, a.t_pp, a.mat_stride, c.T_pp, st))) return rc;
+  if ((rc = copy_strided<T>(NN, S, a.t_mm, a.mat_stride, c.T_mm, st))) return rc;
+  if ((rc = copy_strided<T>(NN, S, a.r_mp, a.mat_stride, c.R_mp, st))) return rc;
+  if ((rc = copy_strided<T>(NN, S, a.r_pm, a.mat_stride, c.R_pm, st))) return rc;
+  if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_p, 0, c.J0_p, st))) return rc;
+  if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_m, 0, c.J0_m, st))) return rc;
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// interaction!  (interaction.jl:52-266) -- operator-for-operator, reference order
+// ---------------------------------------------------------------------------
+template <typename T>
+int interaction_generic(int iface, int N, int S, const composite<T>& c, const added<T>& a, T* work, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
+  const long long as = a.mat_stride;
+  T* W1 = work;
+  T* W2 = W1 + per;
+  T* W3 = W2 + per;
+  T* v1 = W3 + per;
+  T* v2 = v1 + pv;
+  const T* nul = nullptr;
+  const T one = T(1), zero = T(0);
+  int rc;
+#define G(...)                                   \
+  if ((rc = gemm<T>(__VA_ARGS__, st))) return rc
+  switch (iface) {
+    case VSM_IFACE_00:
+      G(N, 1, N, S, a.t_pp, as, c.J0_p, N, v1, N, one, a.j0_p, N, one, zero);      // J0+ = j0+ + t++ J0+
+      if ((rc = copy_strided<T>(pv, 1, v1, 0, c.J0_p, st))) return rc;
+      G(N, 1, N, S, c.T_mm, NN, a.j0_m, N, c.J0_m, N, one, c.J0_m, N, one, zero);  // J0- += T-- j0-
+      G(N, N, N, S, a.t_mm, as, c.T_mm, NN, W3, NN, one, nul, 0, zero, zero);      // T-- = t-- T--
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_mm, st))) return rc;
+      G(N, N, N, S, a.t_pp, as, c.T_pp, NN, W3, NN, one, nul, 0, zero, zero);      // T++ = t++ T++
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_pp, st))) return rc;
+      break;
+    case VSM_IFACE_01:
+      G(N, 1, N, S, a.r_mp, as, c.J0_p, N, v1, N, one, a.j0_m, N, one, zero);      // r-+ J0+ + j0-
+      G(N, 1, N, S, c.T_mm, NN, v1, N, c.J0_m, N, one, c.J0_m, N, one, zero);      // J0- += T-- (..)
+      G(N, 1, N, S, a.t_pp, as, c.J0_p, N, v1, N, one, a.j0_p, N, one, zero);      // J0+ = j0+ + t++ J0+
+      if ((rc = copy_strided<T>(pv, 1, v1, 0, c.J0_p, st))) return rc;
+      G(N, N, N, S, c.T_mm, NN, a.r_mp, as, W3, NN, one, nul, 0, zero, zero);      // T-- r-+
+      G(N, N, N, S, W3, NN, c.T_pp, NN, c.R_mp, NN, one, nul, 0, zero, zero);      // R-+ = (T-- r-+) T++
+      if ((rc = copy_strided<T>(NN, S, a.r_pm, as, c.R_pm, st))) return rc;        // R+- = r+-
+      G(N, N, N, S, a.t_pp, as, c.T_pp, NN, W3, NN, one, nul, 0, zero, zero);      // T++ = t++ T++
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_pp, st))) return rc;
+      G(N, N, N, S, c.T_mm, NN, a.t_mm, as, W3, NN, one, nul, 0, zero, zero);      // T-- = T-- t--
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_mm, st))) return rc;
+      break;
+    case VSM_IFACE_10:
+      G(N, 1, N, S, c.R_pm, NN, a.j0_m, N, v1, N, one, c.J0_p, N, one, zero);      // J0+ + R+- j0-
+      G(N, 1, N, S, a.t_pp, as, v1, N, c.J0_p, N, one, a.j0_p, N, one, zero);      // J0+ = j0+ + t++ (..)
+      G(N, 1, N, S, c.T_mm, NN, a.j0_m, N, c.J0_m, N, one, c.J0_m, N, one, zero);  // J0- += T-- j0-
+      G(N, N, N, S, a.t_pp, as, c.T_pp, NN, W3, NN, one, nul, 0, zero, zero);      // T++ = t++ T++
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_pp, st))) return rc;
+      G(N, N, N, S, c.T_mm, NN, a.t_mm, as, W3, NN, one, nul, 0, zero, zero);      // T-- = T-- t--
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_mm, st))) return rc;
+      G(N, N, N, S, a.t_pp, as, c.R_pm, NN, W3, NN, one, nul, 0, zero, zero);      // t++ R+-
+      G(N, N, N, S, W3, NN, a.t_mm, as, c.R_pm, NN, one, nul, 0, zero, zero);      // R+- = (t++ R+-) t--
+      break;
+    case VSM_IFACE_11:
+      G(N, N, N, S, a.r_mp, as, c.R_pm, NN, W1, NN, -one, nul, 0, zero, one);      // I - r-+ R+-
+      if ((rc = batch_inv<T>(N, S, W1, W1, nullptr, st))) return rc;
+      G(N, N, N, S, c.T_mm, NN, W1, NN, W2, NN, one, nul, 0, zero, zero);          // T01_inv = T-- G1
+      G(N, 1, N, S, a.r_mp, as, c.J0_p, N, v1, N, one, a.j0_m, N, one, zero);      // r-+ J0+ + j0-
+      G(N, 1, N, S, W2, NN, v1, N, c.J0_m, N, one, c.J0_m, N, one, zero);          // J0- += T01_inv (..)
+      G(N, N, N, S, W2, NN, a.r_mp, as, W3, NN, one, nul, 0, zero, zero);          // T01_inv r-+
+      G(N, N, N, S, W3, NN, c.T_pp, NN, c.R_mp, NN, one, c.R_mp, NN, one, zero);   // R-+ += (..) T++
+      G(N, N, N, S, W2, NN, a.t_mm, as, W3, NN, one, nul, 0, zero, zero);          // T-- = T01_inv t--
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_mm, st))) return rc;
+      G(N, N, N, S, c.R_pm, NN, a.r_mp, as, W1, NN, -one, nul, 0, zero, one);      // I - R+- r-+
+      if ((rc = batch_inv<T>(N, S, W1, W1, nullptr, st))) return rc;
+      G(N, N, N, S, a.t_pp, as, W1, NN, W2, NN, one, nul, 0, zero, zero);          // T21_inv = t++ G2
+      G(N, 1, N, S, c.R_pm, NN, a.j0_m, N, v1, N, one, c.J0_p, N, one, zero);      // J0+ + R+- j0-
+      G(N, 1, N, S, W2, NN, v1, N, c.J0_p, N, one, a.j0_p, N, one, zero);          // J0+ = j0+ + T21_inv (..)
+      G(N, N, N, S, W2, NN, c.T_pp, NN, W3, NN, one, nul, 0, zero, zero);          // T++ = T21_inv T++
+      if ((rc = copy_strided<T>(per, 1, W3, 0, c.T_pp, st))) return rc;
+      G(N, N, N, S, W2, NN, c.R_pm, NN, W3, NN, one, nul, 0, zero, zero);          // T21_inv R+-
+      G(N, N, N, S, W3, NN, a.t_mm, as, c.R_pm, NN, one, a.r_pm, as, one, zero);   // R+- = r+- + (..) t--
+      break;
+    default:
+      set_error("interaction: unknown scattering interface %d", iface);
+      return VSM_ERR_INVALID_ARG;
+  }
+#undef G
+  (void)v2;
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Lambertian surface (lambertian_surface.jl:41-95), postprocessing (postprocessing_vza.jl:23-94)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_lambertian_mats(int N, int n_stokes, int m, T albedo, const T* __restrict__ mu,
+                                  const T* __restrict__ wt, T* r_mp, T* r_pm, T* t_pp, T* t_mm) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int i = e % N, j = e / N;
+  T r = T(0);
+  if (m == 0 && (i % n_stokes) == 0 && (j % n_stokes) == 0) r = T(2) * albedo * (mu[j] * wt[j]);
+  r_mp[e] = r;
+  r_pm[e] = T(0);
+  const T t = (i == j) ? T(1) : T(0);
+  t_pp[e] = t;
+  t_mm[e] = t;
+}
+template <typename T>
+__global__ void k_lambertian_src(int N, int n_stokes, int S, int m, T albedo, int i_mu0, T mu0,
+                                 const T* __restrict__ tau_sum, T* j0_p, T* j0_m) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * S) return;
+  const int i = e % N, s = e / N;
+  T jp = T(0), jm = T(0);
+  if (m == 0) {
+    const T att = exp(-tau_sum[s] / mu0);
+    const int i_start = n_stokes * i_mu0;
+    if (i == i_start) jp = att;                                   // I0 = e1 on the SZA stream
+    if ((i % n_stokes) == 0) jm = mu0 * (T(2) * albedo) * att;    // mu0 * (R_surf * I0_N)
+  }
+  j0_p[e] = jp;
+  j0_m[e] = jm;
+}
+template <typename T>
+int lambertian_surface(const quad<T>& q, int S, int m, T albedo, const T* tau_sum, const added<T>& a, hipStream_t st) {
+  if (a.mat_stride != 0) {
+    set_error("lambertian_surface: added.mat_stride must be 0 (one shared surface block)");
+    return VSM_ERR_INVALID_ARG;
+  }
+  const int N = q.N;
+  hipLaunchKernelGGL(k_lambertian_mats<T>, dim3((N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, m, albedo, q.mu,
+                     q.wt, a.r_mp, a.r_pm, a.t_pp, a.t_mm);
+  VSM_LAUNCH_CHECK("k_lambertian_mats");
+  if (S > 0) {
+    hipLaunchKernelGGL(k_lambertian_src<T>, dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, albedo,
+                       q.i_mu0, q.mu0, tau_sum, a.j0_p, a.j0_m);
+    VSM_LAUNCH_CHECK("k_lambertian_src");
+  }
+  return VSM_OK;
+}
+
+struct pp_args {
+  int row0[64];
+  double w[256];
+};
+template <typename T>
+__global__ void k_postprocess(int N, int n_stokes, int S, int nV, pp_args pa, const T* __restrict__ J0_m,
+                              const T* __restrict__ J0_p, T* R, T* Tt) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long tot = (long long)nV * n_stokes * S;
+  if (e >= tot) return;
+  const int v = (int)(e % nV);
+  const int k = (int)((e / nV) % n_stokes);
+  const long long s = e / ((long long)nV * n_stokes);
+  const T w = (T)pa.w[v + nV * k];
+  const long long src = s * N + pa.row0[v] + k;
+  R[e] += w * J0_m[src];
+  Tt[e] += w * J0_p[src];
+}
+template <typename T>
+int postprocess_vza(int N, int n_stokes, int S, int nV, const int* row0_h, const T* w_h, const T* J0_m, const T* J0_p,
+                    T* R, T* Tt, hipStream_t st) {
+  if (nV > 64 || nV * n_stokes > 256) {
+    set_error("postprocess_vza: at most 64 viewing angles per call (got %d)", nV);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (S <= 0 || nV <= 0) return VSM_OK;
+  pp_args pa;
+  for (int v = 0; v < nV; ++v) pa.row0[v] = row0_h[v];
+  for (int x = 0; x < nV * n_stokes; ++x) pa.w[x] = (double)w_h[x];
+  const long long tot = (long long)nV * n_stokes * S;
+  hipLaunchKernelGGL(k_postprocess<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, n_stokes, S, nV, pa,
+                     J0_m, J0_p, R, Tt);
+  VSM_LAUNCH_CHECK("k_postprocess");
+  return VSM_OK;
+}
+
+// explicit instantiations ------------------------------------------------------
+#define VSM_INST(T)                                                                                                    \
+  template int gemm<T>(int, int, int, int, const T*, long long, const T*, long long, T*, long long, T, const T*,      \
+                       long long, T, T, hipStream_t);                                                                  \
+  template int batch_inv<T>(int, int, const T*, T*, int*, hipStream_t);                                                \
+  template int elemental<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*, const T*, const T*, \
+                            long long, const added<T>&, hipStream_t);                                                  \
+  template int doubling<T>(int, int, int, int, T*, const added<T>&, T*, hipStream_t);                                  \
+  template int noscat_layer<T>(const quad<T>&, int, const T*, const added<T>&, hipStream_t);                           \
+  template int copy_added_to_composite<T>(int, int, const added<T>&, const composite<T>&, hipStream_t);                \
+  template int interaction_generic<T>(int, int, int, const composite<T>&, const added<T>&, T*, hipStream_t);           \
+  template int lambertian_surface<T>(const quad<T>&, int, int, T, const T*, const added<T>&, hipStream_t);             \
+  template int postprocess_vza<T>(int, int, int, int, const int*, const T*, const T*, const T*, T*, T*, hipStream_t);  \
+  template int copy_strided<T>(long long, int, const T*, long long, T*, hipStream_t);
+VSM_INST(double)
+VSM_INST(float)
+
+}  // namespace vsm

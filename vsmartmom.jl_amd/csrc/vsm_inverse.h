@@ -1,0 +1,161 @@
+// Register-resident in-place Gauss-Jordan inversion with partial pivoting for one
+// N x N matrix per 256-thread workgroup (N <= NPAD <= 128).
+//
+// Replaces the reference's batched getrf+getri pair (ext/gpu_batched_cuda.jl:97-182;
+// CPU: src/CoreRT/tools/cpu_batched.jl:32-47 `A \ I`).  Same pivot rule as getrf
+// (largest |a_ik|, first occurrence).  The matrix lives in VGPRs for the whole
+// elimination: thread (tr, tc) owns rows i = tr + TR*rb and columns j = tc*CB + cb.
+// Per pivot step the pivot column and the pivot row are published through LDS
+// (double-buffered by step parity -> two barriers per step).
+#pragma once
+#include "vsm_common.h"
+
+namespace vsm {
+
+template <int NPAD>
+struct gj_cfg {
+  static_assert(NPAD == 32 || NPAD == 64 || NPAD == 96 || NPAD == 128, "NPAD must be 32/64/96/128");
+  static constexpr int TR = (NPAD % 64 == 0) ? 64 : 32;
+  static constexpr int TC = 256 / TR;
+  static constexpr int RB = NPAD / TR;
+  static constexpr int CB = NPAD / TC;
+};
+
+template <typename T, int NPAD>
+struct gj_scratch {
+  T col[2][NPAD];
+  T rowP[2][NPAD];
+  T rowK[2][NPAD];
+  int piv[NPAD];
+  int dst[NPAD];
+  int info;
+};
+
+// a[rb][cb] holds element (tr + TR*rb, tc*CB + cb) of the identity-padded matrix.
+// On exit a holds the inverse with its columns permuted: the caller must store
+// element a[rb][cb] at column sc.dst[tc*CB + cb].  sc.info = 0 or (k+1) of the first
+// exactly-zero pivot.  All 256 threads must call this (contains barriers).
+template <typename T, int NPAD>
+__device__ __forceinline__ void gj_invert(T (&a)[gj_cfg<NPAD>::RB][gj_cfg<NPAD>::CB], int N,
+                                          gj_scratch<T, NPAD>& sc) {
+  using C = gj_cfg<NPAD>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int tr = tid % C::TR;
+  const int tc = tid / C::TR;
+  if (tid == 0) sc.info = 0;
+
+  for (int tck = 0; tck < C::TC; ++tck) {
+#pragma unroll
+    for (int cbk = 0; cbk < C::CB; ++cbk) {
+      const int k = tck * C::CB + cbk;
+      if (k < N) {  // uniform
+        const int par = k & 1;
+        // (a) publish column k
+        if (tc == tck) {
+#pragma unroll
+          for (int rb = 0; rb < C::RB; ++rb) sc.col[par][tr + C::TR * rb] = a[rb][cbk];
+        }
+        __syncthreads();
+        // (b) pivot search, redundantly in every wave (no second barrier needed)
+        T best = T(-1);
+        int bi = k;
+        for (int i = lane; i < NPAD; i += 64) {
+          if (i >= k && i < N) {
+            T v = fabs(sc.col[par][i]);
+            if (v > best) {
+              best = v;
+              bi = i;
+            }
+          }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          T ov = __shfl_xor(best, off);
+          int oi = __shfl_xor(bi, off);
+          if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+          }
+        }
+        const int p = __builtin_amdgcn_readfirstlane(bi);
+        // (c) publish pivot row (old row p) and, if swapping, old row k
+#pragma unroll
+        for (int rb = 0; rb < C::RB; ++rb) {
+          const int i = tr + C::TR * rb;
+          if (i == p) {
+#pragma unroll
+            for (int cb = 0; cb < C::CB; ++cb) sc.rowP[par][tc * C::CB + cb] = a[rb][cb];
+          }
+          if (i == k && p != k) {
+#pragma unroll
+            for (int cb = 0; cb < C::CB; ++cb) sc.rowK[par][tc * C::CB + cb] = a[rb][cb];
+          }
+        }
+        __syncthreads();
+        // (d) eliminate
+        const T pv = sc.rowP[par][k];
+        const T d = T(1) / pv;
+        const T colk = sc.col[par][k];
+        if (tid == 0) {
+          sc.piv[k] = p;
+          if (pv == T(0) && sc.info == 0) sc.info = k + 1;
+        }
+        T u[C::CB];
+#pragma unroll
+        for (int cb = 0; cb < C::CB; ++cb) {
+          const bool jk = (cb == cbk) && (tc == tck);
+          const T rp = sc.rowP[par][tc * C::CB + cb];
+          u[cb] = jk ? d : rp * d;
+        }
+#pragma unroll
+        for (int rb = 0; rb < C::RB; ++rb) {
+          const int i = tr + C::TR * rb;
+          if (i == p && p != k) {  // row p now holds the old row k
+#pragma unroll
+            for (int cb = 0; cb < C::CB; ++cb) a[rb][cb] = sc.rowK[par][tc * C::CB + cb];
+          }
+          const T f = (i == p) ? colk : sc.col[par][i];
+          const bool isk = (i == k);
+#pragma unroll
+          for (int cb = 0; cb < C::CB; ++cb) {
+            const bool jk = (cb == cbk) && (tc == tck);
+            const T base = jk ? T(0) : a[rb][cb];
+            a[rb][cb] = isk ? u[cb] : base - f * u[cb];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // Undo the row interchanges as a column permutation of the inverse:
+  // for k = N-1..0 swap columns k and piv[k].  src[x] = source column of final column x.
+  if (tid < 64) {
+    int s0 = lane, s1 = lane + 64;
+    int p0 = (lane < N) ? sc.piv[lane] : lane;
+    int p1 = (lane + 64 < N) ? sc.piv[(lane + 64) % NPAD] : lane + 64;
+    for (int k = N - 1; k >= 0; --k) {
+      const int ku = __builtin_amdgcn_readfirstlane(k);
+      const int p = (ku < 64) ? __builtin_amdgcn_readlane(p0, ku) : __builtin_amdgcn_readlane(p1, ku - 64);
+      if (p != ku) {
+        const int sk = (ku < 64) ? __builtin_amdgcn_readlane(s0, ku) : __builtin_amdgcn_readlane(s1, ku - 64);
+        const int sp = (p < 64) ? __builtin_amdgcn_readlane(s0, p) : __builtin_amdgcn_readlane(s1, p - 64);
+        if (ku < 64) {
+          if (lane == ku) s0 = sp;
+        } else {
+          if (lane == ku - 64) s1 = sp;
+        }
+        if (p < 64) {
+          if (lane == p) s0 = sk;
+        } else {
+          if (lane == p - 64) s1 = sk;
+        }
+      }
+    }
+    if (lane < NPAD) sc.dst[s0] = lane;
+    if (lane + 64 < NPAD) sc.dst[s1] = lane + 64;
+  }
+  __syncthreads();
+}
+
+}  // namespace vsm

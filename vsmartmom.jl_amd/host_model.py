@@ -1,0 +1,393 @@
+"""Host-side producers of the hot path's inputs (numpy, FP64): streams, Greek
+coefficients, Fourier moments of the phase matrix, layer-optics mixing.
+
+These mirror the reference's host code that runs once per Fourier moment
+*outside* the per-spectral-point loop (SURVEY.md 8f rank 1 -- "next" rows):
+  src/CoreRT/tools/rt_set_streams.jl:25-47                 rt_set_streams (GaussLegQuad)
+  src/Scattering/mie_helper_functions.jl:454-468            get_greek_rayleigh
+  src/Scattering/legendre_functions.jl:24-183               generalized spherical functions
+  src/Scattering/compute_Z_matrices.jl:26-110               compute_Z_moments
+  src/CoreRT/types.jl:1262-1308, LayerOpticalProperties/compEffectiveLayerProperties.jl:11-117
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+# ---- polarization (src/Scattering/types.jl:139-197) ---------------------------
+@dataclass(frozen=True)
+class PolarizationType:
+    name: str
+    n: int
+    D: tuple
+    I0: tuple
+
+
+def Stokes_I():
+    return PolarizationType("Stokes_I", 1, (1.0,), (1.0,))
+
+
+def Stokes_IQ():
+    return PolarizationType("Stokes_IQ", 2, (1.0, 1.0), (1.0, 0.0))
+
+
+def Stokes_IQU():
+    return PolarizationType("Stokes_IQU", 3, (1.0, 1.0, -1.0), (1.0, 0.0, 0.0))
+
+
+def Stokes_IQUV():
+    return PolarizationType("Stokes_IQUV", 4, (1.0, 1.0, -1.0, -1.0), (1.0, 0.0, 0.0, 0.0))
+
+
+def polarization_type(name: str) -> PolarizationType:
+    key = name.replace("()", "").replace("Stokes_", "")
+    return {"I": Stokes_I, "IQ": Stokes_IQ, "IQU": Stokes_IQU, "IQUV": Stokes_IQUV}[key]()
+
+
+# ---- degrees trig with Julia's exact special angles -------------------------------
+_COS_EXACT = {0: 1.0, 60: 0.5, 90: 0.0, 120: -0.5, 180: -1.0, 240: -0.5, 270: 0.0, 300: 0.5}
+_SIN_EXACT = {0: 0.0, 30: 0.5, 90: 1.0, 150: 0.5, 180: 0.0, 210: -0.5, 270: -1.0, 330: -0.5}
+
+
+def cosd(x: float) -> float:
+    r = math.fmod(float(x), 360.0)
+    r = r + 360.0 if r < 0 else r
+    return _COS_EXACT[int(r)] if r == int(r) and int(r) in _COS_EXACT else math.cos(math.radians(r))
+
+
+def sind(x: float) -> float:
+    r = math.fmod(float(x), 360.0)
+    r = r + 360.0 if r < 0 else r
+    return _SIN_EXACT[int(r)] if r == int(r) and int(r) in _SIN_EXACT else math.sin(math.radians(r))
+
+
+# ---- streams -------------------------------------------------------------------------
+@dataclass
+class QuadPoints:
+    """src/CoreRT/types.jl QuadPoints (host copy; device copies live in CoreRT.DeviceQuad)."""
+    mu0: float
+    imu0: int            # 0-based index of the SZA node (reference iμ₀ - 1)
+    qp_mu: np.ndarray
+    wt_mu: np.ndarray
+    qp_muN: np.ndarray
+    wt_muN: np.ndarray
+    Nquad: int
+    Nstreams: int
+
+
+def gauleg(n: int, xmin: float, xmax: float):
+    xi, w = np.polynomial.legendre.leggauss(n)
+    return (xmax - xmin) / 2 * xi + (xmin + xmax) / 2, w * (xmax - xmin) / 2
+
+
+def rt_set_streams(l_trunc: int, sza: float, vza: Sequence[float], pol: PolarizationType, FT=np.float64) -> QuadPoints:
+    nq = (l_trunc + 2) // 2
+    x, w = gauleg(nq, 0.0, 1.0)
+    mu0 = cosd(sza)
+    nodes = [FT(v) for v in x] + [FT(cosd(v)) for v in vza] + [FT(mu0)]
+    uniq = list(dict.fromkeys(float(v) for v in nodes))  # first occurrence kept, order preserved
+    qp = np.array(uniq, dtype=FT)
+    wt = np.zeros(len(qp), dtype=FT)
+    wt[:nq] = w.astype(FT)
+    imu0 = int(np.argmin(np.abs(qp - FT(mu0))))
+    return QuadPoints(float(FT(mu0)), imu0, qp, wt, np.repeat(qp, pol.n), np.repeat(wt, pol.n), len(qp),
+                      int(np.count_nonzero(wt)))
+
+
+# ---- Greek coefficients -----------------------------------------------------------------
+@dataclass
+class GreekCoefs:
+    alpha: np.ndarray
+    beta: np.ndarray
+    gamma: np.ndarray
+    delta: np.ndarray
+    epsilon: np.ndarray
+    zeta: np.ndarray
+
+    @staticmethod
+    def from_dict(d):
+        return GreekCoefs(*(np.asarray(d[k], dtype=np.float64) for k in
+                            ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")))
+
+
+def get_greek_rayleigh(depol: float) -> GreekCoefs:
+    p = (1 - depol) / (1 + depol / 2)
+    r = (1 - 2 * depol) / (1 - depol)
+    z = np.zeros(3)
+    return GreekCoefs(np.array([0, 0, 3 * p]), np.array([1, 0, 0.5 * p]), np.array([0, 0, p * math.sqrt(1.5)]),
+                      np.array([0, 1.5 * p * r, 0]), z.copy(), z.copy())
+
+
+def henyey_greenstein_greek(g: float, nmoments: int) -> GreekCoefs:
+    L = np.arange(nmoments + 1)
+    z = np.zeros(nmoments + 1)
+    return GreekCoefs(z.copy(), (2 * L + 1) * g ** L.astype(float), z.copy(), z.copy(), z.copy(), z.copy())
+
+
+@dataclass
+class AerosolOptics:
+    greek_coefs: GreekCoefs
+    ssa: float          # ω̃
+    f_trunc: float = 0.0  # fᵗ
+
+
+# ---- generalized spherical functions, one Fourier order at a time ---------------------------
+def _prt_for_m(x: np.ndarray, lmax: int, m: int):
+    """P_l^m, R_l^m, T_l^m (reference sign convention: returns the published `-T` array) for
+    l = 0..lmax-1 at fixed m.  Recurrences of legendre_functions.jl:24-183 restricted to one m."""
+    n = len(x)
+    P = np.zeros((lmax, n))
+    R = np.zeros((lmax, n))
+    T = np.zeros((lmax, n))
+    s = np.sqrt(1.0 - x * x)
+    c = x
+    for l in range(m, lmax):
+        if m == 0:
+            if l == 0:
+                P[l] = 1.0
+            elif l == 1:
+                P[l] = c
+            elif l == 2:
+                P[l] = 0.5 * (3 * c * c - 1)
+                R[l] = 0.5 * math.sqrt(1.5) * s * s
+            else:
+                P[l] = (P[l - 1] * (2 * l - 1) * c - P[l - 2] * (l - 1)) / l
+                R[l] = (R[l - 1] * (2 * l - 1) * c - R[l - 2] * math.sqrt((l + 1) * (l - 3))) / math.sqrt(l * l - 4)
+            continue
+        if l == m and m == 1:
+            P[l] = math.sqrt(0.5) * s
+            continue
+        if m == 1 and l == 2:
+            m1 = math.sqrt(1 / 6)
+            P[l] = m1 * 3 * c * s
+            R[l] = -m1 * c * math.sqrt(1.5) * s
+            T[l] = m1 * math.sqrt(1.5) * s
+            continue
+        if l == m:  # m >= 2
+            f1 = np.ones(n)
+            f2 = np.ones(n)
+            for i in range(1, m + 1):
+                f1 = f1 * ((2 * i - 1) * s) / math.sqrt(i * (i + m))
+                f2 = f2 * (s / 2) * (math.sqrt((m + i) / (i - 2)) if i > 2 else 1.0)
+            ok = s > 1e-8
+            lim = 0.5 if m == 2 else 0.0
+            with np.errstate(divide="ignore", invalid="ignore"):
+                P[l] = f1
+                R[l] = np.where(ok, f2 * (1 + c * c) / (s * s), lim)
+                T[l] = -np.where(ok, f2 * (2 * c) / (s * s), lim)
+            continue
+        zc = (2 * m * (2 * l - 1)) / (l * (l - 1))
+        xr = ((l - m) / l) * math.sqrt(l * l - 4)
+        if l == m + 1 and m >= 2:
+            m1 = math.sqrt(1 / (l + m))
+            P[l] = (m1 * P[l - 1] * (2 * l - 1) * c) / (l - m)
+            R[l] = (m1 * R[l - 1] * (2 * l - 1) * c + m1 * T[l - 1] * zc) / xr
+            T[l] = (m1 * T[l - 1] * (2 * l - 1) * c + m1 * R[l - 1] * zc) / xr
+            continue
+        if m == 1:
+            m1 = math.sqrt((l - 1) / (l + 1))
+            m2 = m1 * math.sqrt((l - 2) / l)
+        else:
+            m1 = math.sqrt((l - m) / (l + m))
+            m2 = m1 * math.sqrt((l - m - 1) / (l + m - 1))
+        yr = ((l + m - 1) / (l - 1)) * math.sqrt((l - 3) * (l + 1))
+        P[l] = (m1 * P[l - 1] * (2 * l - 1) * c - m2 * P[l - 2] * (l - 1 + m)) / (l - m)
+        R[l] = (m1 * R[l - 1] * (2 * l - 1) * c - m2 * R[l - 2] * yr + m1 * T[l - 1] * zc) / xr
+        T[l] = (m1 * T[l - 1] * (2 * l - 1) * c - m2 * T[l - 2] * yr + m1 * R[l - 1] * zc) / xr
+    return P, R, -T
+
+
+def compute_Z_moments(pol: PolarizationType, mu: np.ndarray, greek: GreekCoefs, m: int):
+    """Z⁺⁺(m), Z⁻⁺(m) on the stream cosines `mu` (compute_Z_matrices.jl:26-110). Returns [N,N] each."""
+    mu = np.asarray(mu, dtype=np.float64)
+    if not np.all((mu > 0) & (mu <= 1)):
+        raise ValueError("all mu within compute_Z_moments have to be in ]0,1]")
+    nq, n, lmax = len(mu), pol.n, len(greek.beta)
+    fact = 0.5 if m == 0 else 1.0
+
+    def pis(x):
+        P, R, T = _prt_for_m(x, lmax, m)
+        Pi = np.zeros((lmax, nq, n, n))
+        Pi[:, :, 0, 0] = P
+        if n >= 2:
+            Pi[:, :, 1, 1] = R
+        if n >= 3:
+            Pi[:, :, 1, 2] = -T
+            Pi[:, :, 2, 1] = -T
+            Pi[:, :, 2, 2] = R
+        if n == 4:
+            Pi[:, :, 3, 3] = P
+        return Pi
+
+    B = np.zeros((lmax, n, n))
+    B[:, 0, 0] = greek.beta
+    if n >= 2:
+        B[:, 0, 1] = B[:, 1, 0] = greek.gamma
+        B[:, 1, 1] = greek.alpha
+    if n >= 3:
+        B[:, 2, 2] = greek.zeta
+    if n == 4:
+        B[:, 2, 3] = greek.epsilon
+        B[:, 3, 2] = -greek.epsilon
+        B[:, 3, 3] = greek.delta
+    Pp, Pm = pis(mu)[m:], pis(-mu)[m:]
+    left = np.einsum("liab,lbc->liac", Pp, B[m:])
+    App = np.einsum("liac,ljcd->iajd", left, Pp)
+    Amp = np.einsum("liac,ljcd->iajd", left, Pm)
+    sgn = np.ones((n, n))
+    sgn[:2, 2:] = -1
+    sgn[2:, :2] = -1
+    Zpp = (2 * fact * App).reshape(nq * n, nq * n)
+    Zmp = (2 * fact * Amp * sgn[None, :, None, :]).reshape(nq * n, nq * n)
+    return Zpp, Zmp
+
+
+# ---- layer optics ---------------------------------------------------------------------------
+@dataclass
+class CoreScatteringOpticalProperties:
+    """src/CoreRT/types.jl CoreScatteringOpticalProperties (host numpy version)."""
+    tau: np.ndarray     # [S] or scalar
+    varpi: np.ndarray   # [S] or scalar
+    Zpp: np.ndarray     # [N,N] (shared by all S) or [S,N,N]
+    Zmp: np.ndarray
+
+    def __add__(self, other):
+        if isinstance(other, CoreAbsorptionOpticalProperties):
+            tau = self.tau + other.tau
+            varpi = (self.tau * self.varpi) / np.where(tau > 0, tau, 1.0)
+            return CoreScatteringOpticalProperties(tau, varpi, self.Zpp, self.Zmp)
+        x, y = self, other
+        tau = x.tau + y.tau
+        wx, wy = x.tau * x.varpi, y.tau * y.varpi
+        w = wx + wy
+        varpi = w / np.where(tau > 0, tau, 1.0)
+        if np.all(wx == 0.0):
+            return CoreScatteringOpticalProperties(tau, varpi, y.Zpp, y.Zmp)
+        if np.all(wy == 0.0):
+            return CoreScatteringOpticalProperties(tau, varpi, x.Zpp, x.Zmp)
+        w = np.atleast_1d(w)
+        fx = (np.atleast_1d(wx) / w)[:, None, None]
+        fy = (np.atleast_1d(wy) / w)[:, None, None]
+        return CoreScatteringOpticalProperties(tau, varpi, fx * x.Zpp + fy * y.Zpp, fx * x.Zmp + fy * y.Zmp)
+
+
+@dataclass
+class CoreAbsorptionOpticalProperties:
+    tau: np.ndarray
+
+
+def createAero(tau_aer: float, ao: AerosolOptics, Zpp, Zmp) -> CoreScatteringOpticalProperties:
+    f, w = ao.f_trunc, ao.ssa
+    return CoreScatteringOpticalProperties(np.float64((1 - f * w) * tau_aer), np.float64((1 - f) * w / (1 - f * w)), Zpp, Zmp)
+
+
+def get_scattering_interface(prev: str, scatter: bool, iz: int) -> str:
+    """rt_helper_functions.jl:15-33 (iz 1-based)."""
+    if iz == 1:
+        return "11" if scatter else "00"
+    if prev == "00":
+        return "01" if scatter else "00"
+    return "11" if scatter else "10"
+
+
+@dataclass
+class RTNumericalParameters:
+    """src/CoreRT/types.jl:713-756."""
+    dtau_max_threshold: Optional[float] = None
+    dtau_min_floor: Optional[float] = None
+
+
+@dataclass
+class RTModel:
+    """The fields of the reference's RTModel that rt_run consumes on this path (one band)."""
+    architecture: object
+    polarization_type: PolarizationType
+    quad_points: QuadPoints
+    sza: float
+    vza: np.ndarray
+    vaz: np.ndarray
+    tau_rayl: np.ndarray          # τ_rayl[1]  [S, Nz]
+    tau_abs: np.ndarray           # τ_abs[1]   [S, Nz]
+    tau_aer: np.ndarray           # τ_aer[1]   [nAer, Nz]
+    aerosol_optics: List[AerosolOptics]
+    greek_rayleigh: GreekCoefs
+    albedo: float                 # LambertianSurfaceScalar(albedo)
+    m_max: int
+    float_type: type = np.float64
+    varpi_Cabannes: float = 1.0
+    numerics: RTNumericalParameters = field(default_factory=RTNumericalParameters)
+    F0: Optional[np.ndarray] = None   # [nStokes, S]; None = SolarBeam default e1
+
+
+def model_from_arrays(architecture, polarization: str, l_trunc: int, sza: float, vza, vaz, tau_rayl, tau_abs=None,
+                      tau_aer=None, aerosol_optics=(), depol=0.0, albedo=0.0, m_max=2, float_type=np.float64,
+                      numerics=None) -> RTModel:
+    """Build the RTModel subset directly from optical-depth arrays -- what the reference's tests
+    do after model_from_parameters by overwriting model.τ_rayl/τ_abs/τ_aer
+    (e.g. test/vlidort_baseline/cases/case_B_solar_tester.jl:62-74)."""
+    pol = polarization_type(polarization)
+    qp = rt_set_streams(l_trunc, sza, vza, pol, float_type)
+    tau_rayl = np.atleast_2d(np.asarray(tau_rayl, dtype=np.float64))
+    S, L = tau_rayl.shape
+    tau_abs = np.zeros((S, L)) if tau_abs is None else np.atleast_2d(np.asarray(tau_abs, dtype=np.float64))
+    tau_aer = (np.zeros((len(aerosol_optics), L)) if tau_aer is None
+               else np.atleast_2d(np.asarray(tau_aer, dtype=np.float64)))
+    return RTModel(architecture, pol, qp, float(sza), np.asarray(vza, float), np.asarray(vaz, float), tau_rayl,
+                   tau_abs, tau_aer, list(aerosol_optics), get_greek_rayleigh(depol), float(albedo), int(m_max),
+                   float_type, 1.0, numerics or RTNumericalParameters())
+
+
+def constructCoreOpticalProperties(model: RTModel, m: int) -> List[CoreScatteringOpticalProperties]:
+    """compEffectiveLayerProperties.jl:11-65 for one band, noRS."""
+    mu = model.quad_points.qp_mu.astype(np.float64)
+    Nz = model.tau_rayl.shape[1]
+    Rpp, Rmp = compute_Z_moments(model.polarization_type, mu, model.greek_rayleigh, m)
+    combo = [CoreScatteringOpticalProperties(model.tau_rayl[:, i], np.float64(model.varpi_Cabannes), Rpp, Rmp)
+             for i in range(Nz)]
+    for ia, ao in enumerate(model.aerosol_optics):
+        App, Amp = compute_Z_moments(model.polarization_type, mu, ao.greek_coefs, m)
+        combo = [combo[i] + createAero(model.tau_aer[ia, i], ao, App, Amp) for i in range(Nz)]
+    return [combo[i] + CoreAbsorptionOpticalProperties(model.tau_abs[:, i]) for i in range(Nz)]
+
+
+def extractEffectiveProps(lods: List[CoreScatteringOpticalProperties], FT):
+    """compEffectiveLayerProperties.jl:75-93 -> (interface tags, τ_sum_all [S, Nz+1])."""
+    S = len(np.atleast_1d(lods[0].tau))
+    tau_sum = np.zeros((S, len(lods) + 1))
+    tags, tag = [], "00"
+    for iz, lo in enumerate(lods):
+        scatter = bool(np.max(lo.tau * lo.varpi) > 2 * np.finfo(FT).eps)
+        tag = get_scattering_interface(tag, scatter, iz + 1)
+        tags.append(tag)
+        tau_sum[:, iz + 1] = tau_sum[:, iz] + lo.tau
+    return tags, tau_sum
+
+
+def doubling_number(dtau_max, tau_end, FT):
+    """rt_helper_functions.jl:49-69 (arithmetic in FT)."""
+    dtau_max, tau_end = FT(dtau_max), FT(tau_end)
+    if tau_end <= dtau_max:
+        return tau_end, 0
+    q1, q2, q3 = np.log10(FT(2)), np.log10(dtau_max), np.log10(tau_end)
+    tlimit = FT((q3 - q2) / q1)
+    nlimit = int(math.floor(tlimit))
+    if FT(tlimit - FT(nlimit)) < np.finfo(FT).eps:
+        return dtau_max, nlimit
+    nd = nlimit + 1
+    return FT(10) ** (q3 - q1 * FT(nd)), nd
+
+
+def get_dtau_ndoubl(tau: np.ndarray, varpi: np.ndarray, qp: QuadPoints, FT, numerics: RTNumericalParameters):
+    """rt_kernel.jl:266-287.  Returns (dτ[S] in FT, ndoubl); ndoubl is batch-global by construction."""
+    thr = FT(0.001 if numerics.dtau_max_threshold is None else numerics.dtau_max_threshold)
+    floor_val = FT(1024 * np.finfo(FT).eps if numerics.dtau_min_floor is None else numerics.dtau_min_floor)
+    real = qp.qp_mu[qp.wt_mu > np.finfo(FT).eps]
+    mu_min = FT(np.min(real) if len(real) else np.min(qp.qp_mu))
+    tw = FT(np.max(tau.astype(FT) * varpi.astype(FT)))
+    dtau_max = max(floor_val, min(tw, FT(thr * mu_min)))
+    _, nd = doubling_number(dtau_max, tw, FT)
+    return (tau / FT(2 ** nd)).astype(FT), nd

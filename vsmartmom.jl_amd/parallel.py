@@ -1,0 +1,93 @@
+"""Spectral-axis sharding of `rt_run` over the GPUs of one node.
+
+The reference has no multi-device code; its only parallel axis is the
+spectral one, and every operator of the elastic path is independent per spectral
+point.  So: one process per GPU (torch.distributed; backend "nccl" == RCCL over xGMI
+on ROCm, "gloo" in the CPU tests), each rank owns a contiguous block of spectral
+points, NO collective on the data path, and one gather of R/T at the end.
+
+`ndoubl` and the scattering-interface tags are batch-global in the reference
+(rt_kernel.jl:197,282-283; compEffectiveLayerProperties.jl:87).  `Scene` derives them
+from the full spectral axis on every rank, so a sharded run reproduces the
+single-device run exactly.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(S: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous blocks of ceil(S/world) points (the last ranks may get fewer / none)."""
+    per = -(-S // world)
+    lo = min(rank * per, S)
+    return lo, min(lo + per, S)
+
+
+def shard_slice(S: int, rank: int, world: int) -> slice:
+    lo, hi = shard_bounds(S, rank, world)
+    return slice(lo, hi)
+
+
+def init_process_group_from_env(backend: Optional[str] = None):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT from the environment (torchrun)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def gather_spectral(local, S_total: int, rank: int, world: int, dst: int = 0):
+    """Gather per-rank results whose FIRST axis is the local spectral block onto `dst`.
+
+    `local` is a torch tensor of shape (S_local, ...) (device tensor under nccl, CPU under gloo).
+    Returns the concatenated (S_total, ...) tensor on `dst`, None elsewhere.  Blocks are padded
+    to the common block size because gather needs equal shapes."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    per = -(-S_total // world)
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = torch.cat(bufs, dim=0)
+    return out[:S_total]
+
+
+def rt_run_sharded(model, executor: Optional[Callable] = None, rank: int = 0, world: int = 1, dst: int = 0):
+    """rt_run over this rank's spectral block + gather on `dst`.
+
+    `executor(model, spec_slice) -> (R, T)` returns tensors shaped (S_local, nStokes, nVZA); the default
+    is the HIP engine (`CoreRT.prepare_scene(model, slice).run()`).  Returns host arrays
+    [nVZA, nStokes, nSpec] on `dst`, (None, None) on the other ranks."""
+    S = model.tau_rayl.shape[0]
+    sl = shard_slice(S, rank, world)
+    if executor is None:
+        from . import core_rt
+
+        def executor(mdl, s):
+            scene = core_rt.prepare_scene(mdl, s)
+            return scene.run()
+    R, T = executor(model, sl)
+    Rg = gather_spectral(R, S, rank, world, dst)
+    Tg = gather_spectral(T, S, rank, world, dst)
+    if rank != dst:
+        return None, None
+    to_np = lambda t: t.detach().cpu().numpy().transpose(2, 1, 0).copy()
+    return to_np(Rg), to_np(Tg)
