@@ -491,7 +491,7 @@ def _o2a_like(S, L, seed=20260929):
     return tau_rayl, tau_abs
 
 
-@pytest.mark.parametrize("FT,l_trunc,pol,rtol", [(np.float64, 35, "IQU", 1e-8), (np.float32, 61, "IQU", 1e-2)])
+@pytest.mark.parametrize("FT,l_trunc,pol,rtol", [(np.float64, 35, "IQU", 1e-8), (np.float32, 59, "IQU", 1e-2)])
 def test_rt_run_o2a_shape_vs_oracle(vsm, arch, FT, l_trunc, pol, rtol):
     """The benchmark's own shape at reduced S, L: FP64 N = 60 (C2) and FP32 N = 96 (C4), multi-layer,
     absorption spanning 1e-4..50, Lambertian 0.15 -- fused kernels end to end vs the oracle."""
@@ -515,8 +515,10 @@ def test_rt_run_full_size_properties(vsm, arch):
     S, L = 2048, 3
     tau_rayl, tau_abs = _o2a_like(S, L)
     H = vsm.host_model
+    # albedo 0: the Lambertian surface source uses pol_type.I0, not F0 (lambertian_surface.jl:71-76), so only the
+    # atmospheric path is linear in F0
     mk = lambda tr, ta, F0=None: H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0, 50.0], [0.0, 90.0], tau_rayl=tr,
-                                                    tau_abs=ta, depol=0.0279, albedo=0.15, m_max=2)
+                                                    tau_abs=ta, depol=0.0279, albedo=0.0, m_max=2)
     base = mk(tau_rayl, tau_abs)
     R1, T1 = vsm.CoreRT.rt_run(base)
     R1b, _ = vsm.CoreRT.rt_run(base)

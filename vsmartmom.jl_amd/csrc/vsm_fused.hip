@@ -46,75 +46,139 @@ struct acc_block {
   }
 };
 
+// ---- MFMA k-loops ---------------------------------------------------------------------
+// All loops are software-pipelined by hand: the fragments of k-step (k0+4) are requested
+// before the MFMAs of k-step k0 are issued, so LDS (or L2) latency hides behind the
+// 64-cycle f64 / 32-cycle f32 MFMAs.  (hipcc does not pipeline a runtime-trip-count loop.)
+template <typename T, int NP>
+struct frag_set {
+  static constexpr int TM = NP / 32;
+  T a[TM], b[TM];
+};
+
+template <typename T, int NP>
+__device__ __forceinline__ void load_ll(frag_set<T, NP>& f, const T* A, const T* B, int k, int rowA, int colB) {
+  constexpr int TM = NP / 32;
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    f.a[t] = A[lidx<NP>(rowA + 16 * t, k)];
+    f.b[t] = B[lidx<NP>(k, colB + 16 * t)];
+  }
+}
+template <typename T, int NP>
+__device__ __forceinline__ void mma_all(acc_block<T, NP>& acc, const frag_set<T, NP>& f) {
+  constexpr int TM = NP / 32;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc.v[a][b] = mfma<T>::mma(f.a[a], f.b[b], acc.v[a][b]);
+}
+
 // acc += A * B with A, B in (swizzled) LDS.  Kend: multiple of 4 covering N.
 template <typename T, int NP>
 __device__ __forceinline__ void mm_ll(acc_block<T, NP>& acc, const T* A, const T* B, int Kend) {
   constexpr int TM = NP / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15, kq = lane >> 4;
-  for (int k0 = 0; k0 < Kend; k0 += 4) {
-    const int k = k0 + kq;
-    T af[TM], bf[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      af[t] = A[lidx<NP>(16 * (wr * TM + t) + l15, k)];
-      bf[t] = B[lidx<NP>(k, 16 * (wc * TM + t) + l15)];
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) acc.v[a][b] = mfma<T>::mma(af[a], bf[b], acc.v[a][b]);
+  const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
+  const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
+  const int kq = lane >> 4;
+  frag_set<T, NP> f0, f1;
+  load_ll<T, NP>(f0, A, B, kq, rowA, colB);
+  int k0 = 0;
+  for (; k0 + 8 <= Kend; k0 += 8) {
+    load_ll<T, NP>(f1, A, B, k0 + 4 + kq, rowA, colB);
+    mma_all<T, NP>(acc, f0);
+    if (k0 + 8 < Kend) load_ll<T, NP>(f0, A, B, k0 + 8 + kq, rowA, colB);
+    mma_all<T, NP>(acc, f1);
   }
+  if (k0 < Kend) mma_all<T, NP>(acc, f0);  // odd number of k-steps
 }
+
 // two products sharing the B operand: acc1 += A1*B, acc2 += A2*B
 template <typename T, int NP>
 __device__ __forceinline__ void mm_ll2(acc_block<T, NP>& acc1, acc_block<T, NP>& acc2, const T* A1, const T* A2,
                                        const T* B, int Kend) {
   constexpr int TM = NP / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15, kq = lane >> 4;
-  for (int k0 = 0; k0 < Kend; k0 += 4) {
-    const int k = k0 + kq;
-    T a1[TM], a2[TM], bf[TM];
+  const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
+  const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
+  const int kq = lane >> 4;
+  T a1[2][TM], a2[2][TM], bf[2][TM];
+  auto load = [&](int buf, int k) {
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-      const int ia = lidx<NP>(16 * (wr * TM + t) + l15, k);
-      a1[t] = A1[ia];
-      a2[t] = A2[ia];
-      bf[t] = B[lidx<NP>(k, 16 * (wc * TM + t) + l15)];
+      const int ia = lidx<NP>(rowA + 16 * t, k);
+      a1[buf][t] = A1[ia];
+      a2[buf][t] = A2[ia];
+      bf[buf][t] = B[lidx<NP>(k, colB + 16 * t)];
     }
+  };
+  auto mma = [&](int buf) {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        acc1.v[a][b] = mfma<T>::mma(a1[a], bf[b], acc1.v[a][b]);
-        acc2.v[a][b] = mfma<T>::mma(a2[a], bf[b], acc2.v[a][b]);
+        acc1.v[a][b] = mfma<T>::mma(a1[buf][a], bf[buf][b], acc1.v[a][b]);
+        acc2.v[a][b] = mfma<T>::mma(a2[buf][a], bf[buf][b], acc2.v[a][b]);
+      }
+  };
+  load(0, kq);
+  int k0 = 0;
+  for (; k0 + 8 <= Kend; k0 += 8) {
+    load(1, k0 + 4 + kq);
+    mma(0);
+    if (k0 + 8 < Kend) load(0, k0 + 8 + kq);
+    mma(1);
+  }
+  if (k0 < Kend) mma(0);
+}
+
+// A read straight from global memory (column-major N x N), B in LDS.  The A fragments of the
+// whole k-range are requested up front (Kend/4 * TM values per lane) so the L2/HBM latency is
+// paid once, overlapped with whatever the caller does between `prefetch` and `run`.
+template <typename T, int NP>
+struct gl_operand {
+  static constexpr int TM = NP / 32;
+  static constexpr int KS = NP / 4;
+  T a[KS][TM];
+  __device__ __forceinline__ void prefetch(const T* __restrict__ Ag, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = rowA + 16 * t, k = 4 * ks + kq;
+        a[ks][t] = (row < N && k < N) ? Ag[row + (long long)N * k] : T(0);
       }
   }
-}
-// A read straight from global memory (column-major N x N), B in LDS.
+  // acc += A * B
+  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
+    const int kq = lane >> 4;
+    T bf[2][TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) bf[0][t] = B[lidx<NP>(kq, colB + 16 * t)];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) bf[(ks + 1) & 1][t] = B[lidx<NP>(4 * (ks + 1) + kq, colB + 16 * t)];
+      }
+#pragma unroll
+      for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TM; ++y) acc.v[x][y] = mfma<T>::mma(a[ks][x], bf[ks & 1][y], acc.v[x][y]);
+    }
+  }
+};
 template <typename T, int NP>
 __device__ __forceinline__ void mm_gl(acc_block<T, NP>& acc, const T* __restrict__ Ag, int N, const T* B, int Kend) {
-  constexpr int TM = NP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int l15 = lane & 15, kq = lane >> 4;
-  for (int k0 = 0; k0 < Kend; k0 += 4) {
-    const int k = k0 + kq;
-    T af[TM], bf[TM];
-#pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int row = 16 * (wr * TM + t) + l15;
-      af[t] = (row < N && k < N) ? Ag[row + (long long)N * k] : T(0);
-      bf[t] = B[lidx<NP>(k, 16 * (wc * TM + t) + l15)];
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) acc.v[a][b] = mfma<T>::mma(af[a], bf[b], acc.v[a][b]);
-  }
+  gl_operand<T, NP> op;
+  op.prefetch(Ag, N);
+  op.run(acc, B);
 }
 
 // dst(row,col) = f(acc(row,col), row, col) for every accumulator element of this wave.
@@ -164,6 +228,24 @@ __device__ __forceinline__ T acc_fro(const acc_block<T, NP>& acc, T* red) {
   return sqrt(red[0] + red[1] + red[2] + red[3]);
 }
 
+// In-place pivoted Gauss-Jordan of the swizzled LDS matrix V (identity padded).  Ends with a barrier.
+template <typename T, int NP>
+__device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
+  using C = gj_cfg<NP>;
+  const int tr = threadIdx.x % C::TR, tc = threadIdx.x / C::TR;
+  T g[C::RB][C::CB];
+#pragma unroll
+  for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < C::CB; ++cb) g[rb][cb] = V[lidx<NP>(tr + C::TR * rb, tc * C::CB + cb)];
+  gj_invert<T, NP>(g, N, *sc);
+#pragma unroll
+  for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < C::CB; ++cb) V[lidx<NP>(tr + C::TR * rb, sc->dst[tc * C::CB + cb])] = g[rb][cb];
+  __syncthreads();
+}
+
 // G = (I - E)^-1 with E given in the accumulators.  Result -> V.  W is scratch (holds E on the
 // series path).  mode 0 = automatic, 1 = force Gauss-Jordan, 2 = force series.
 // Returns 1 for Gauss-Jordan, 1+K for a series of order K.  Ends with a barrier.
@@ -201,27 +283,17 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* 
     }
     return 1 + K;
   }
-  // general case: V = I - E, pivoted Gauss-Jordan in registers
+  // general case: V = I - E, pivoted Gauss-Jordan in registers (out of line: keeps its register
+  // footprint out of the MFMA loops' allocation)
   acc_store<T, NP>(V, acc, [](T a, int r, int c, T) { return (r == c) ? T(1) - a : -a; });
   __syncthreads();
-  using C = gj_cfg<NP>;
-  const int tr = threadIdx.x % C::TR, tc = threadIdx.x / C::TR;
-  T g[C::RB][C::CB];
-#pragma unroll
-  for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < C::CB; ++cb) g[rb][cb] = V[lidx<NP>(tr + C::TR * rb, tc * C::CB + cb)];
-  gj_invert<T, NP>(g, N, sm.gj);
-#pragma unroll
-  for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < C::CB; ++cb) V[lidx<NP>(tr + C::TR * rb, sm.gj.dst[tc * C::CB + cb])] = g[rb][cb];
-  __syncthreads();
+  gj_lds<T, NP>(V, N, &sm.gj);
   return 1;
 }
 
-// y1 = M*x1, y2 = M*x2 for one row per thread group (M swizzled LDS).  Returns via refs for
-// the lanes with `row < NP` and `q == 0` (all lanes of the group hold the sums).
+// y1 = M*x1, y2 = M*x2: TPR consecutive lanes share a row; each lane walks a statically unrolled
+// strided column range (all LDS reads in flight at once), then a shuffle reduction.  All lanes of a
+// row group receive the sums.
 template <typename T, int NP>
 struct mv_map {
   static constexpr int TPR = (NP <= 64) ? 4 : 2;  // threads per row
@@ -229,13 +301,22 @@ struct mv_map {
 template <typename T, int NP>
 __device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, int N, T& y1, T& y2) {
   constexpr int TPR = mv_map<T, NP>::TPR;
+  constexpr int CNT = NP / TPR;
   const int row = threadIdx.x / TPR, q = threadIdx.x % TPR;
   T s1 = 0, s2 = 0;
   if (row < NP) {
-    for (int j = q; j < N; j += TPR) {
-      const T mv = M[lidx<NP>(row, j)];
-      s1 += mv * x1[j];
-      s2 += mv * x2[j];
+    T mv[CNT], v1[CNT], v2[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int j = q + TPR * c;  // padded columns hold zeros in M and in x
+      mv[c] = M[lidx<NP>(row, j)];
+      v1[c] = x1[j];
+      v2[c] = x2[j];
+    }
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      s1 += mv[c] * v1[c];
+      s2 += mv[c] * v2[c];
     }
   }
 #pragma unroll
