@@ -174,6 +174,69 @@ struct gl_operand {
     }
   }
 };
+// B read straight from global memory (column-major N x N), A in LDS.
+template <typename T, int NP>
+struct gl_operand_b {
+  static constexpr int TM = NP / 32;
+  static constexpr int KS = NP / 4;
+  T b[KS][TM];
+  __device__ __forceinline__ void prefetch(const T* __restrict__ Bg, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
+    const int kq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int col = colB + 16 * t, k = 4 * ks + kq;
+        b[ks][t] = (col < N && k < N) ? Bg[k + (long long)N * col] : T(0);
+      }
+  }
+  // acc += A * B
+  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
+    const int kq = lane >> 4;
+    T af[2][TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) af[0][t] = A[lidx<NP>(rowA + 16 * t, kq)];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int t = 0; t < TM; ++t) af[(ks + 1) & 1][t] = A[lidx<NP>(rowA + 16 * t, 4 * (ks + 1) + kq)];
+      }
+#pragma unroll
+      for (int x = 0; x < TM; ++x)
+#pragma unroll
+        for (int y = 0; y < TM; ++y) acc.v[x][y] = mfma<T>::mma(af[ks & 1][x], b[ks][y], acc.v[x][y]);
+    }
+  }
+};
+
+// global -> LDS staging split in two halves so that the global latency overlaps other work:
+// load() issues the reads into registers, store() writes the swizzled LDS image.
+template <typename T, int NP>
+struct stage_regs {
+  static constexpr int CNT = NP * NP / 256;
+  T v[CNT];
+  __device__ __forceinline__ void load(const T* __restrict__ src, int N) {
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = threadIdx.x + 256 * c;
+      const int i = e % NP, j = e / NP;
+      v[c] = (i < N && j < N) ? src[i + (long long)N * j] : T(0);
+    }
+  }
+  __device__ __forceinline__ void store(T* dst) const {
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = threadIdx.x + 256 * c;
+      dst[lidx<NP>(e % NP, e / NP)] = v[c];
+    }
+  }
+};
+
 template <typename T, int NP>
 __device__ __forceinline__ void mm_gl(acc_block<T, NP>& acc, const T* __restrict__ Ag, int N, const T* B, int Kend) {
   gl_operand<T, NP> op;
@@ -246,39 +309,60 @@ __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
   __syncthreads();
 }
 
-// G = (I - E)^-1 with E given in the accumulators.  Result -> V.  W is scratch (holds E on the
-// series path).  mode 0 = automatic, 1 = force Gauss-Jordan, 2 = force series.
+// G = (I - E)^-1 with E given in the accumulators.  Result -> V.  W is scratch.
+//
+// Series path: G = sum_{k<=K} E^k, built by repeated squaring
+//     (I+E)(I+E^2)(I+E^4)... = sum_{k < 2^p} E^k          (2 MFMA products per doubling of the order)
+// optionally closed with "+ E^(2^p)" (1 product).  Available orders K = 1,2,3,4,7,8,15,16,31 cost
+// 0,1,2,3,4,5,6,7,8 products.  K is the smallest order whose truncation error
+// ||E||^(K+1)/(1-||E||) (Frobenius norm, an upper bound of the 2-norm) stays below eps/4, i.e. the
+// result is the inverse to working precision -- the same contract as the LU of the reference.
+// General path (||E||_F >= 0.3): pivoted Gauss-Jordan.
+// mode 0 = automatic, 1 = force Gauss-Jordan, 2 = force series (order 31 if the bound fails).
 // Returns 1 for Gauss-Jordan, 1+K for a series of order K.  Ends with a barrier.
 template <typename T, int NP>
 __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* W, int N, int Kend,
                                                 fsmem<T, NP>& sm, int mode) {
   const T nrm = acc_fro<T, NP>(acc, sm.red);
-  // truncation error of sum_{k<=K} E^k is <= nrm^(K+1)/(1-nrm); keep it below eps/4.
   const T tol = num<T>::eps() * T(0.25);
   int K = 0;
-  if (nrm < T(0.25)) {
-    T pw = nrm * nrm;  // nrm^(K+1) for K = 1
+  if (nrm < T(0.3)) {
     const T lim = tol * (T(1) - nrm);
-    for (int kk = 1; kk <= 3; ++kk) {
-      if (pw <= lim) {
-        K = kk;
-        break;
-      }
-      pw *= nrm;
-    }
+    const T n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
+    if (n2 <= lim) K = 1;
+    else if (n2 * nrm <= lim) K = 2;
+    else if (n4 <= lim) K = 3;
+    else if (n4 * nrm <= lim) K = 4;
+    else if (n8 <= lim) K = 7;
+    else if (n8 * nrm <= lim) K = 8;
+    else if (n16 <= lim) K = 15;
+    else if (n16 * nrm <= lim) K = 16;
+    else if (n16 * n16 <= lim) K = 31;
   }
   if (mode == 1) K = 0;
-  if (mode == 2 && K == 0) K = 3;
+  if (mode == 2 && K == 0) K = 31;
   if (K > 0) {
     // W = E, V = I + E
     acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
     acc_store<T, NP>(V, acc, [](T a, int r, int c, T) { return (r == c) ? a + T(1) : a; });
     __syncthreads();
-    for (int it = 2; it <= K; ++it) {  // V <- I + E*V  (Horner)
+    int cur = 1;  // W = E^cur, V = sum_{k < 2 cur} E^k
+    while (K > 2 * cur - 1) {
       acc.zero();
-      mm_ll<T, NP>(acc, W, V, Kend);
+      mm_ll<T, NP>(acc, W, W, Kend);  // E^(2 cur)
+      cur *= 2;
+      if (K == cur) {  // close with "+ E^cur"
+        acc_store<T, NP>(V, acc, [](T a, int, int, T old) { return old + a; });
+        __syncthreads();
+        break;
+      }
       __syncthreads();
-      acc_store<T, NP>(V, acc, [](T a, int r, int c, T) { return (r == c) ? a + T(1) : a; });
+      acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
+      __syncthreads();
+      acc.zero();
+      mm_ll<T, NP>(acc, V, W, Kend);  // V * E^cur
+      __syncthreads();
+      acc_store<T, NP>(V, acc, [](T a, int, int, T old) { return old + a; });
       __syncthreads();
     }
     return 1 + K;
@@ -517,8 +601,8 @@ template <typename T, int NP>
 __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, added<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
-  T* L1 = sm.L[0];
-  T* L2 = sm.L[1];
+  T* L1 = sm.L[0];  // R+-  (resident)
+  T* L2 = sm.L[1];  // r-+  (resident)
   T* L3 = sm.L[2];
   T* L4 = sm.L[3];
   T* vJp = sm.vec[0];
@@ -547,26 +631,34 @@ __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, ad
   const bool mlead = (mrow < NP) && (tid % TPR == 0);
 
   acc_block<T, NP> acc;
-  if (tid < NP) {
-    const bool in = tid < N;
-    vJp[tid] = in ? J0_p[tid] : T(0);
-    vJm[tid] = in ? J0_m[tid] : T(0);
-    vjp[tid] = in ? j0_p[tid] : T(0);
-    vjm[tid] = in ? j0_m[tid] : T(0);
+  {
+    stage_regs<T, NP> s1, s2;
+    s1.load(R_pm, N);
+    s2.load(r_mp, N);
+    if (tid < NP) {
+      const bool in = tid < N;
+      vJp[tid] = in ? J0_p[tid] : T(0);
+      vJm[tid] = in ? J0_m[tid] : T(0);
+      vjp[tid] = in ? j0_p[tid] : T(0);
+      vjm[tid] = in ? j0_m[tid] : T(0);
+    }
+    s1.store(L1);
+    s2.store(L2);
   }
-  stage<T, NP>(L1, R_pm, N);  // R+- stays in L1 for the whole kernel
+  gl_operand<T, NP> opA;     // A operands streamed from global: T--, later t++
+  gl_operand_b<T, NP> opB;   // B operands streamed from global: T++, t--
+  opA.prefetch(T_mm, N);     // lands while G1 is being formed
   __syncthreads();
-  // G1 = (I - r-+ R+-)^-1 -> L2
+  // ---- G1 = (I - r-+ R+-)^-1 -> L3 -------------------------------------------------------
   acc.zero();
-  mm_gl<T, NP>(acc, r_mp, N, L1, Kend);
-  invert_one_minus<T, NP>(acc, L2, L3, N, Kend, sm, 0);
-  // T01_inv = T-- G1 -> L3
+  mm_ll<T, NP>(acc, L2, L1, Kend);
+  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, 0);
+  // T01_inv = T-- G1 -> L4
+  opB.prefetch(T_pp, N);
   acc.zero();
-  mm_gl<T, NP>(acc, T_mm, N, L2, Kend);
+  opA.run(acc, L3);
   __syncthreads();
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  stage<T, NP>(L2, r_mp, N);  // r-+ (G1 is dead)
+  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
   // J0- += T01_inv (r-+ J0+ + j0-)
   {
@@ -577,42 +669,40 @@ __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, ad
   __syncthreads();
   {
     T y1, y2;
-    matvec2<T, NP>(L3, vu, vu, N, y1, y2);
+    matvec2<T, NP>(L4, vu, vu, N, y1, y2);
     if (mlead && mrow < N) J0_m[mrow] = vJm[mrow] + y1;
   }
   // R-+ += (T01_inv r-+) T++
   acc.zero();
-  mm_ll<T, NP>(acc, L3, L2, Kend);
-  __syncthreads();
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  stage<T, NP>(L2, T_pp, N);
+  mm_ll<T, NP>(acc, L4, L2, Kend);
+  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });  // G1 is dead (barrier above)
   __syncthreads();
   acc.zero();
-  mm_ll<T, NP>(acc, L4, L2, Kend);
+  opB.run(acc, L3);
+  opB.prefetch(t_mm, N);
   __syncthreads();
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  stage<T, NP>(L2, t_mm, N);  // next B operand
+  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  for (int e = tid; e < N * N; e += 256) R_mp[e] += L4[lidx<NP>(e % N, e / N)];
+  for (int e = tid; e < N * N; e += 256) R_mp[e] += L3[lidx<NP>(e % N, e / N)];
   // T-- = T01_inv t--
   acc.zero();
-  mm_ll<T, NP>(acc, L3, L2, Kend);
+  opB.run(acc, L4);
+  opA.prefetch(t_pp, N);
+  __syncthreads();  // R-+ update finished reading L3
+  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  stage<T, NP>(L2, r_mp, N);  // r-+ as B operand of R+- r-+
-  __syncthreads();
-  lds_to_global<T, NP>(T_mm, L4, N);
-  // G2 = (I - R+- r-+)^-1 -> L3
+  lds_to_global<T, NP>(T_mm, L3, N);
+  // ---- G2 = (I - R+- r-+)^-1 -> L3 -------------------------------------------------------
   acc.zero();
   mm_ll<T, NP>(acc, L1, L2, Kend);
-  __syncthreads();  // everyone is done reading L3/L4 before they are overwritten
+  __syncthreads();  // T-- write-out finished reading L3; T01_inv (L4) is dead
   invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, 0);
   // T21_inv = t++ G2 -> L4
+  opB.prefetch(T_pp, N);  // pre-update T++
   acc.zero();
-  mm_gl<T, NP>(acc, t_pp, N, L3, Kend);
+  opA.run(acc, L3);
   __syncthreads();
   acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  stage<T, NP>(L2, T_pp, N);  // pre-update T++
   __syncthreads();
   // J0+ = j0+ + T21_inv (J0+ + R+- j0-)
   {
@@ -628,20 +718,19 @@ __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, ad
   }
   // T++ = T21_inv T++
   acc.zero();
-  mm_ll<T, NP>(acc, L4, L2, Kend);
-  __syncthreads();
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
-  stage<T, NP>(L2, t_mm, N);
+  opB.run(acc, L4);
+  opB.prefetch(t_mm, N);
+  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });  // G2 is dead (barrier above)
   __syncthreads();
   lds_to_global<T, NP>(T_pp, L3, N);
   // R+- = r+- + (T21_inv R+-) t--
   acc.zero();
   mm_ll<T, NP>(acc, L4, L1, Kend);
-  __syncthreads();
+  __syncthreads();  // T++ write-out finished reading L3
   acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
   acc.zero();
-  mm_ll<T, NP>(acc, L3, L2, Kend);
+  opB.run(acc, L3);
   __syncthreads();
   acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
