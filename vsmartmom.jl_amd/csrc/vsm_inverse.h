@@ -1,5 +1,5 @@
 // Register-resident in-place Gauss-Jordan inversion with partial pivoting for one
-// N x N matrix per 256-thread workgroup (N <= NPAD <= 128).
+// N x N matrix per 256- or 512-thread workgroup (N <= NPAD <= 128).
 //
 // Replaces the reference's batched getrf+getri pair (ext/gpu_batched_cuda.jl:97-182;
 // CPU: src/CoreRT/tools/cpu_batched.jl:32-47 `A \ I`).  Same pivot rule as getrf
@@ -12,13 +12,15 @@
 
 namespace vsm {
 
-template <int NPAD>
+template <int NPAD, int NT = 256>
 struct gj_cfg {
   static_assert(NPAD == 32 || NPAD == 64 || NPAD == 96 || NPAD == 128, "NPAD must be 32/64/96/128");
+  static_assert(NT == 256 || NT == 512, "workgroup of 256 or 512 threads");
   static constexpr int TR = (NPAD % 64 == 0) ? 64 : 32;
-  static constexpr int TC = 256 / TR;
+  static constexpr int TC = NT / TR;
   static constexpr int RB = NPAD / TR;
   static constexpr int CB = NPAD / TC;
+  static_assert(CB * TC == NPAD && RB * TR == NPAD, "thread grid must tile the matrix");
 };
 
 template <typename T, int NPAD>
@@ -34,11 +36,11 @@ struct gj_scratch {
 // a[rb][cb] holds element (tr + TR*rb, tc*CB + cb) of the identity-padded matrix.
 // On exit a holds the inverse with its columns permuted: the caller must store
 // element a[rb][cb] at column sc.dst[tc*CB + cb].  sc.info = 0 or (k+1) of the first
-// exactly-zero pivot.  All 256 threads must call this (contains barriers).
-template <typename T, int NPAD>
-__device__ __forceinline__ void gj_invert(T (&a)[gj_cfg<NPAD>::RB][gj_cfg<NPAD>::CB], int N,
+// exactly-zero pivot.  All NT threads must call this (contains barriers).
+template <typename T, int NPAD, int NT = 256>
+__device__ __forceinline__ void gj_invert(T (&a)[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB], int N,
                                           gj_scratch<T, NPAD>& sc) {
-  using C = gj_cfg<NPAD>;
+  using C = gj_cfg<NPAD, NT>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tr = tid % C::TR;
