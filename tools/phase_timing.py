@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-phase cycle breakdown of k_elemental_doubling (needs the -DVSM_PHASE_TIMING build,
+vsmartmom.jl_amd/lib_dbg/libvsmartmom_hip_timing.so).  Diagnostic tool, not part of the product."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import vsmartmom_jl_amd as vsm  # noqa: E402
+
+vsm._lib.LIB_PATH = os.path.join(ROOT, "vsmartmom.jl_amd", "lib_dbg", "libvsmartmom_hip_timing.so")
+import torch  # noqa: E402
+import bench  # noqa: E402
+
+hip = C.CDLL("libamdhip64.so")
+
+
+def read_stamps(lib_path, n=32):
+    # hipGetSymbolAddress needs the symbol handle; use hipModule-less route: dlsym gives the host shadow var
+    lib = C.CDLL(lib_path)
+    host_sym = C.c_void_p.in_dll(lib, "_ZN3vsm16vsm_phase_cyclesE") if False else None
+    return None
+
+
+def main():
+    S, L = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 4
+    arch = vsm.Architectures.GPU(0)
+    tau_rayl, tau_abs = bench.o2a_atmosphere(S, 40)
+    tau_rayl, tau_abs = tau_rayl[:, :L], tau_abs[:, :L]
+    model = vsm.host_model.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs,
+                                             depol=0.0279, albedo=0.15, m_max=0)
+    scene = vsm.CoreRT.prepare_scene(model)
+    scene.run()
+    torch.cuda.synchronize()
+    lib = C.CDLL(vsm._lib.LIB_PATH)
+    buf = (C.c_ulonglong * 32)()
+    lib.vsm_debug_phase_cycles(None, 1)
+    scene.run()
+    torch.cuda.synchronize()
+    lib.vsm_debug_phase_cycles(buf, 0)
+    names = ["elemental", "r*r", "inverse", "tt=tG+store+bar", "(matvec)+tmp=tt r+store+bar", "two products",
+             "stores+2 bar+combine", "write-out"]
+    v = np.array(list(buf)[:8], dtype=float)
+    launches = L  # one ED launch per layer (m=0 only)
+    nd = scene.moments[0]["layers"][0]["nd"]
+    print("S=%d layers=%d nd=%d ; cycles of workgroup 0 (s_memtime, 100 MHz? see total)" % (S, L, nd))
+    for n, x in zip(names, v):
+        per = x / launches / (nd if n not in ("elemental", "write-out") else 1)
+        print("  %-32s %12.0f total  %10.1f per %s" % (n, x, per, "step" if n not in ("elemental", "write-out") else "launch"))
+    print("  sum per launch: %.0f" % (v.sum() / launches))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,24 +1,58 @@
-// Fused, LDS-resident kernels: ONE 256-thread workgroup owns ONE spectral point and keeps
-// its N x N operators on-chip for a whole layer step.
+// Fused, LDS-resident kernels: ONE workgroup owns ONE spectral point and keeps its N x N
+// operators on-chip for a whole layer step.
 //
 //   k_elemental_doubling : elemental! + ndoubl x doubling step + apply_D!   (1 launch / layer)
 //   k_interaction11      : interaction_helper!(::ScatteringInterface_11)      (1 launch / layer)
 //
-// Data layout in LDS: column-major NP x NP (NP = N rounded up to 32), row index XOR-swizzled
-// by column so that BOTH MFMA operand fetch patterns are bank-conflict free:
-//   A-fragment  (16 consecutive rows  x 2 consecutive k-columns per half-wave)
-//   B-fragment  (2 consecutive k-rows x 16 consecutive columns  per half-wave)
-// MFMA: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, 4 waves in a 2x2 grid, each wave
-// owning a (NP/32 x NP/32) block of 16x16 accumulator tiles.
+// LDS layout: column-major NP x NP (NP = N rounded up to 32), row index XOR-swizzled by column so
+// that both MFMA operand fetch patterns (A: 16 rows x 2 k-columns per half-wave, B: 2 k-rows x 16
+// columns per half-wave) are bank-conflict free for single ds_read_b64/b32.
+// MFMA: v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32.  Waves form a WR x WC grid, each wave owns
+// a TMR x TMC block of 16x16 accumulator tiles:
+//      NP = 32 : 4 waves (2x2), 1x1 tiles        NP = 64 : 8 waves (4x2), 1x2 tiles
+//      NP = 96 : 4 waves (2x2), 3x3 tiles (f32 only; 4 N x N buffers must fit 160 KB of LDS)
+// Two waves per SIMD (NP = 64) let one wave's LDS latency / epilogue hide behind the other's MFMAs;
+// measured on MI355X: 70.3 TF/s (1 wave/SIMD) vs 77.0 TF/s (2 waves/SIMD) for back-to-back f64 MFMA.
 //
-// The matrix inverse (I - E)^-1 that the reference obtains from batched getrf/getri is
-// produced on-chip either by a truncated Neumann series whose truncation error is bounded
-// below rounding by ||E||_F (thin layers: 0-2 extra MFMA products), or by the pivoted
-// Gauss-Jordan of vsm_inverse.h (general case).
+// The inverse (I - E)^-1 that the reference takes from batched getrf/getri is produced on-chip either
+// by a Neumann series built with repeated squaring (orders up to 31; truncation error bounded below
+// rounding by a norm bound on E), or by the pivoted Gauss-Jordan of vsm_inverse.h (general case).
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
 
 namespace vsm {
+
+// Optional phase timing (build with -DVSM_PHASE_TIMING; tools/phase_timing.py): workgroup 0 / thread 0
+// accumulates s_memtime deltas per phase into a device symbol.  Compiled out of the product build.
+#ifdef VSM_PHASE_TIMING
+__device__ unsigned long long vsm_phase_cycles[32];
+#define VSM_STAMP_DECL unsigned long long _t_prev = __builtin_readcyclecounter()
+#define VSM_STAMP(i)                                                     \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
+      const unsigned long long _t = __builtin_readcyclecounter();        \
+      vsm_phase_cycles[i] += _t - _t_prev;                               \
+      _t_prev = _t;                                                      \
+    }                                                                    \
+  } while (0)
+#else
+#define VSM_STAMP_DECL
+#define VSM_STAMP(i)
+#endif
+
+template <int NP>
+struct fcfg {
+  static_assert(NP == 32 || NP == 64 || NP == 96, "NP must be 32, 64 or 96");
+  static constexpr int NW = (NP == 64) ? 8 : 4;       // waves per workgroup
+  static constexpr int NT = 64 * NW;                  // threads
+  static constexpr int WC = 2;                        // wave grid columns
+  static constexpr int WR = NW / WC;                  // wave grid rows
+  static constexpr int TMR = NP / 16 / WR;            // tiles per wave, rows
+  static constexpr int TMC = NP / 16 / WC;            // tiles per wave, cols
+  static constexpr int KS = NP / 4;                   // max k-steps
+  static constexpr int TPR = NT / 128;                // threads per row in the mat-vec (128 rows >= NP)
+  static_assert(TMR * WR * 16 == NP && TMC * WC * 16 == NP, "tile grid must cover NP");
+};
 
 template <int NP>
 __device__ __forceinline__ int lidx(int a, int b) {
@@ -28,202 +62,210 @@ __device__ __forceinline__ int lidx(int a, int b) {
 template <typename T, int NP>
 struct fsmem {
   T L[4][NP * NP];
-  T vec[8][NP];
-  T red[8];
-  int flag[4];
+  T vec[10][NP];
+  unsigned umax[2];
+  int flag[2];
   gj_scratch<T, NP> gj;
 };
 
 template <typename T, int NP>
 struct acc_block {
-  static constexpr int TM = NP / 32;
-  typename mfma<T>::acc_t v[TM][TM];
+  using C = fcfg<NP>;
+  typename mfma<T>::acc_t v[C::TMR][C::TMC];
   __device__ __forceinline__ void zero() {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < C::TMR; ++a)
 #pragma unroll
-      for (int b = 0; b < TM; ++b) v[a][b] = acc_zero<T>();
+      for (int b = 0; b < C::TMC; ++b) v[a][b] = acc_zero<T>();
   }
 };
 
-// ---- MFMA k-loops ---------------------------------------------------------------------
-// All loops are software-pipelined by hand: the fragments of k-step (k0+4) are requested
-// before the MFMAs of k-step k0 are issued, so LDS (or L2) latency hides behind the
-// 64-cycle f64 / 32-cycle f32 MFMAs.  (hipcc does not pipeline a runtime-trip-count loop.)
+template <int NP>
+struct wave_pos {
+  int lane, l15, kq, rowA, colB;  // rowA/colB: first row / column this lane touches in tile 0 of its wave
+  __device__ __forceinline__ wave_pos() {
+    using C = fcfg<NP>;
+    lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    l15 = lane & 15;
+    kq = lane >> 4;
+    rowA = 16 * ((wave / C::WC) * C::TMR) + l15;
+    colB = 16 * ((wave % C::WC) * C::TMC) + l15;
+  }
+};
+
+// ---- MFMA k-loops, software-pipelined by hand: the fragments of k-step (k0+4) are requested before
+// the MFMAs of k-step k0 issue (hipcc does not pipeline a runtime-trip-count loop). -------------------
 template <typename T, int NP>
 struct frag_set {
-  static constexpr int TM = NP / 32;
-  T a[TM], b[TM];
-};
-
-template <typename T, int NP>
-__device__ __forceinline__ void load_ll(frag_set<T, NP>& f, const T* A, const T* B, int k, int rowA, int colB) {
-  constexpr int TM = NP / 32;
+  using C = fcfg<NP>;
+  T a[C::TMR], b[C::TMC];
+  __device__ __forceinline__ void load(const T* A, const T* B, int k, const wave_pos<NP>& w) {
 #pragma unroll
-  for (int t = 0; t < TM; ++t) {
-    f.a[t] = A[lidx<NP>(rowA + 16 * t, k)];
-    f.b[t] = B[lidx<NP>(k, colB + 16 * t)];
+    for (int t = 0; t < C::TMR; ++t) a[t] = A[lidx<NP>(w.rowA + 16 * t, k)];
+#pragma unroll
+    for (int t = 0; t < C::TMC; ++t) b[t] = B[lidx<NP>(k, w.colB + 16 * t)];
   }
-}
-template <typename T, int NP>
-__device__ __forceinline__ void mma_all(acc_block<T, NP>& acc, const frag_set<T, NP>& f) {
-  constexpr int TM = NP / 32;
+  __device__ __forceinline__ void mma(acc_block<T, NP>& acc) const {
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
+    for (int x = 0; x < C::TMR; ++x)
 #pragma unroll
-    for (int b = 0; b < TM; ++b) acc.v[a][b] = mfma<T>::mma(f.a[a], f.b[b], acc.v[a][b]);
-}
+      for (int y = 0; y < C::TMC; ++y) acc.v[x][y] = mfma<T>::mma(a[x], b[y], acc.v[x][y]);
+  }
+};
 
 // acc += A * B with A, B in (swizzled) LDS.  Kend: multiple of 4 covering N.
 template <typename T, int NP>
 __device__ __forceinline__ void mm_ll(acc_block<T, NP>& acc, const T* A, const T* B, int Kend) {
-  constexpr int TM = NP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
-  const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
-  const int kq = lane >> 4;
+  const wave_pos<NP> w;
   frag_set<T, NP> f0, f1;
-  load_ll<T, NP>(f0, A, B, kq, rowA, colB);
+  f0.load(A, B, w.kq, w);
   int k0 = 0;
   for (; k0 + 8 <= Kend; k0 += 8) {
-    load_ll<T, NP>(f1, A, B, k0 + 4 + kq, rowA, colB);
-    mma_all<T, NP>(acc, f0);
-    if (k0 + 8 < Kend) load_ll<T, NP>(f0, A, B, k0 + 8 + kq, rowA, colB);
-    mma_all<T, NP>(acc, f1);
+    f1.load(A, B, k0 + 4 + w.kq, w);
+    f0.mma(acc);
+    if (k0 + 8 < Kend) f0.load(A, B, k0 + 8 + w.kq, w);
+    f1.mma(acc);
   }
-  if (k0 < Kend) mma_all<T, NP>(acc, f0);  // odd number of k-steps
+  if (k0 < Kend) f0.mma(acc);  // odd number of k-steps
 }
 
 // two products sharing the B operand: acc1 += A1*B, acc2 += A2*B
 template <typename T, int NP>
 __device__ __forceinline__ void mm_ll2(acc_block<T, NP>& acc1, acc_block<T, NP>& acc2, const T* A1, const T* A2,
                                        const T* B, int Kend) {
-  constexpr int TM = NP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
-  const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
-  const int kq = lane >> 4;
-  T a1[2][TM], a2[2][TM], bf[2][TM];
+  using C = fcfg<NP>;
+  const wave_pos<NP> w;
+  T a1[2][C::TMR], a2[2][C::TMR], bf[2][C::TMC];
   auto load = [&](int buf, int k) {
 #pragma unroll
-    for (int t = 0; t < TM; ++t) {
-      const int ia = lidx<NP>(rowA + 16 * t, k);
+    for (int t = 0; t < C::TMR; ++t) {
+      const int ia = lidx<NP>(w.rowA + 16 * t, k);
       a1[buf][t] = A1[ia];
       a2[buf][t] = A2[ia];
-      bf[buf][t] = B[lidx<NP>(k, colB + 16 * t)];
     }
+#pragma unroll
+    for (int t = 0; t < C::TMC; ++t) bf[buf][t] = B[lidx<NP>(k, w.colB + 16 * t)];
   };
   auto mma = [&](int buf) {
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int x = 0; x < C::TMR; ++x)
 #pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        acc1.v[a][b] = mfma<T>::mma(a1[buf][a], bf[buf][b], acc1.v[a][b]);
-        acc2.v[a][b] = mfma<T>::mma(a2[buf][a], bf[buf][b], acc2.v[a][b]);
+      for (int y = 0; y < C::TMC; ++y) {
+        acc1.v[x][y] = mfma<T>::mma(a1[buf][x], bf[buf][y], acc1.v[x][y]);
+        acc2.v[x][y] = mfma<T>::mma(a2[buf][x], bf[buf][y], acc2.v[x][y]);
       }
   };
-  load(0, kq);
+  load(0, w.kq);
   int k0 = 0;
   for (; k0 + 8 <= Kend; k0 += 8) {
-    load(1, k0 + 4 + kq);
+    load(1, k0 + 4 + w.kq);
     mma(0);
-    if (k0 + 8 < Kend) load(0, k0 + 8 + kq);
+    if (k0 + 8 < Kend) load(0, k0 + 8 + w.kq);
     mma(1);
   }
   if (k0 < Kend) mma(0);
 }
 
-// A read straight from global memory (column-major N x N), B in LDS.  The A fragments of the
-// whole k-range are requested up front (Kend/4 * TM values per lane) so the L2/HBM latency is
-// paid once, overlapped with whatever the caller does between `prefetch` and `run`.
+// A read straight from global memory (column-major N x N), B in LDS.  The A fragments of the whole
+// k-range are requested up front so the L2/HBM latency is paid once and overlaps whatever the caller
+// does between prefetch() and run().
 template <typename T, int NP>
-struct gl_operand {
-  static constexpr int TM = NP / 32;
-  static constexpr int KS = NP / 4;
-  T a[KS][TM];
+struct gl_operand_a {
+  using C = fcfg<NP>;
+  T a[C::KS][C::TMR];
   __device__ __forceinline__ void prefetch(const T* __restrict__ Ag, int N) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
-    const int kq = lane >> 4;
+    const wave_pos<NP> w;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int row = rowA + 16 * t, k = 4 * ks + kq;
+      for (int t = 0; t < C::TMR; ++t) {
+        const int row = w.rowA + 16 * t, k = 4 * ks + w.kq;
         a[ks][t] = (row < N && k < N) ? Ag[row + (long long)N * k] : T(0);
       }
   }
-  // acc += A * B
-  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* B) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
-    const int kq = lane >> 4;
-    T bf[2][TM];
+  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* B) const {  // acc += A * B
+    const wave_pos<NP> w;
+    T bf[2][C::TMC];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) bf[0][t] = B[lidx<NP>(kq, colB + 16 * t)];
+    for (int t = 0; t < C::TMC; ++t) bf[0][t] = B[lidx<NP>(w.kq, w.colB + 16 * t)];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) bf[(ks + 1) & 1][t] = B[lidx<NP>(4 * (ks + 1) + kq, colB + 16 * t)];
+        for (int t = 0; t < C::TMC; ++t) bf[(ks + 1) & 1][t] = B[lidx<NP>(4 * (ks + 1) + w.kq, w.colB + 16 * t)];
       }
 #pragma unroll
-      for (int x = 0; x < TM; ++x)
+      for (int x = 0; x < C::TMR; ++x)
 #pragma unroll
-        for (int y = 0; y < TM; ++y) acc.v[x][y] = mfma<T>::mma(a[ks][x], bf[ks & 1][y], acc.v[x][y]);
+        for (int y = 0; y < C::TMC; ++y) acc.v[x][y] = mfma<T>::mma(a[ks][x], bf[ks & 1][y], acc.v[x][y]);
     }
   }
 };
-// B read straight from global memory (column-major N x N), A in LDS.
+// B read straight from global memory, A in LDS.
 template <typename T, int NP>
 struct gl_operand_b {
-  static constexpr int TM = NP / 32;
-  static constexpr int KS = NP / 4;
-  T b[KS][TM];
+  using C = fcfg<NP>;
+  T b[C::KS][C::TMC];
   __device__ __forceinline__ void prefetch(const T* __restrict__ Bg, int N) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int colB = 16 * ((wave & 1) * TM) + (lane & 15);
-    const int kq = lane >> 4;
+    const wave_pos<NP> w;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
+    for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < TM; ++t) {
-        const int col = colB + 16 * t, k = 4 * ks + kq;
+      for (int t = 0; t < C::TMC; ++t) {
+        const int col = w.colB + 16 * t, k = 4 * ks + w.kq;
         b[ks][t] = (col < N && k < N) ? Bg[k + (long long)N * col] : T(0);
       }
   }
-  // acc += A * B
-  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* A) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int rowA = 16 * ((wave >> 1) * TM) + (lane & 15);
-    const int kq = lane >> 4;
-    T af[2][TM];
+  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* A) const {  // acc += A * B
+    const wave_pos<NP> w;
+    T af[2][C::TMR];
 #pragma unroll
-    for (int t = 0; t < TM; ++t) af[0][t] = A[lidx<NP>(rowA + 16 * t, kq)];
+    for (int t = 0; t < C::TMR; ++t) af[0][t] = A[lidx<NP>(w.rowA + 16 * t, w.kq)];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
+    for (int ks = 0; ks < C::KS; ++ks) {
+      if (ks + 1 < C::KS) {
 #pragma unroll
-        for (int t = 0; t < TM; ++t) af[(ks + 1) & 1][t] = A[lidx<NP>(rowA + 16 * t, 4 * (ks + 1) + kq)];
+        for (int t = 0; t < C::TMR; ++t) af[(ks + 1) & 1][t] = A[lidx<NP>(w.rowA + 16 * t, 4 * (ks + 1) + w.kq)];
       }
 #pragma unroll
-      for (int x = 0; x < TM; ++x)
+      for (int x = 0; x < C::TMR; ++x)
 #pragma unroll
-        for (int y = 0; y < TM; ++y) acc.v[x][y] = mfma<T>::mma(af[ks & 1][x], b[ks][y], acc.v[x][y]);
+        for (int y = 0; y < C::TMC; ++y) acc.v[x][y] = mfma<T>::mma(af[ks & 1][x], b[ks][y], acc.v[x][y]);
     }
   }
 };
 
-// global -> LDS staging split in two halves so that the global latency overlaps other work:
-// load() issues the reads into registers, store() writes the swizzled LDS image.
+// dst(row,col) = f(acc(row,col), row, col, old) for every accumulator element of this wave.
+template <typename T, int NP, typename F>
+__device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP>& acc, F f) {
+  using C = fcfg<NP>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
+#pragma unroll
+  for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 16 * a + mfma<T>::crow(lane, r);
+        const int col = c0 + 16 * b;
+        const int ix = lidx<NP>(row, col);
+        dst[ix] = f(acc.v[a][b][r], row, col, dst[ix]);
+      }
+}
+
+// global (column-major N x N) -> swizzled LDS, split in two halves so the global latency overlaps
+// other work: load() issues the reads into registers, store() writes the LDS image (zero padded).
 template <typename T, int NP>
 struct stage_regs {
-  static constexpr int CNT = NP * NP / 256;
+  using C = fcfg<NP>;
+  static constexpr int CNT = NP * NP / C::NT;
   T v[CNT];
   __device__ __forceinline__ void load(const T* __restrict__ src, int N) {
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-      const int e = threadIdx.x + 256 * c;
+      const int e = threadIdx.x + C::NT * c;
       const int i = e % NP, j = e / NP;
       v[c] = (i < N && j < N) ? src[i + (long long)N * j] : T(0);
     }
@@ -231,81 +273,85 @@ struct stage_regs {
   __device__ __forceinline__ void store(T* dst) const {
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-      const int e = threadIdx.x + 256 * c;
+      const int e = threadIdx.x + C::NT * c;
       dst[lidx<NP>(e % NP, e / NP)] = v[c];
     }
   }
 };
-
-template <typename T, int NP>
-__device__ __forceinline__ void mm_gl(acc_block<T, NP>& acc, const T* __restrict__ Ag, int N, const T* B, int Kend) {
-  gl_operand<T, NP> op;
-  op.prefetch(Ag, N);
-  op.run(acc, B);
-}
-
-// dst(row,col) = f(acc(row,col), row, col) for every accumulator element of this wave.
-template <typename T, int NP, typename F>
-__device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP>& acc, F f) {
-  constexpr int TM = NP / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * (wr * TM + a) + mfma<T>::crow(lane, r);
-        const int col = 16 * (wc * TM + b) + (lane & 15);
-        const int ix = lidx<NP>(row, col);
-        dst[ix] = f(acc.v[a][b][r], row, col, dst[ix]);
-      }
-}
-
-// global (column-major N x N) -> swizzled LDS, zero padded
 template <typename T, int NP>
 __device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int N) {
-  for (int e = threadIdx.x; e < NP * NP; e += 256) {
-    const int i = e % NP, j = e / NP;
-    dst[lidx<NP>(i, j)] = (i < N && j < N) ? src[i + (long long)N * j] : T(0);
-  }
+  stage_regs<T, NP> s;
+  s.load(src, N);
+  s.store(dst);
 }
-
-// Frobenius norm of the wave-distributed accumulator block (all threads get the result).
 template <typename T, int NP>
-__device__ __forceinline__ T acc_fro(const acc_block<T, NP>& acc, T* red) {
-  constexpr int TM = NP / 32;
-  T s = 0;
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s += acc.v[a][b][r] * acc.v[a][b][r];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  __syncthreads();  // protect red[] from the previous use
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  return sqrt(red[0] + red[1] + red[2] + red[3]);
+__device__ __forceinline__ void lds_to_global(T* __restrict__ dst, const T* L, int N) {
+  for (int e = threadIdx.x; e < N * N; e += fcfg<NP>::NT) dst[e] = L[lidx<NP>(e % N, e / N)];
 }
 
-// In-place pivoted Gauss-Jordan of the swizzled LDS matrix V (identity padded).  Ends with a barrier.
+// ---- norm bound of the N x N block held in the accumulators ---------------------------------------
+// ||E||_2 <= ||E||_F <= N * max|e_ij|.  The max is an order-independent integer reduction
+// (positive floats compare like their bit patterns): DPP row rotations inside a wave, one LDS
+// atomic per wave, one barrier.  `slot` alternates between calls so no extra barrier is needed to
+// re-arm the accumulator.
+__device__ __forceinline__ unsigned wave_umax(unsigned x) {
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));  // row_ror:8
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));  // row_ror:4
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));  // row_ror:2
+  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));  // row_ror:1
+  const unsigned a = __builtin_amdgcn_readlane((int)x, 0), b = __builtin_amdgcn_readlane((int)x, 16);
+  const unsigned c = __builtin_amdgcn_readlane((int)x, 32), d = __builtin_amdgcn_readlane((int)x, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ float abs_up(double x) { return __double2float_ru(fabs(x)); }
+__device__ __forceinline__ float abs_up(float x) { return fabsf(x); }
+
+template <typename T, int NP>
+__device__ __forceinline__ T acc_norm_bound(const acc_block<T, NP>& acc, int N, fsmem<T, NP>& sm, int& slot) {
+  using C = fcfg<NP>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
+  float m = 0.f;
+#pragma unroll
+  for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 16 * a + mfma<T>::crow(lane, r), col = c0 + 16 * b;
+        const float v = abs_up(acc.v[a][b][r]);
+        if (row < N && col < N) m = (v > m || v != v) ? v : m;  // NaN propagates
+      }
+  const unsigned wm = wave_umax(__float_as_uint(m));
+  if (lane == 0) atomicMax(&sm.umax[slot], wm);
+  if (threadIdx.x == 0) sm.umax[slot ^ 1] = 0u;  // re-arm the other slot (last read >= 1 barrier ago)
+  __syncthreads();
+  const float mx = __uint_as_float(sm.umax[slot]);
+  slot ^= 1;
+  return T(mx) * T(N);
+}
+
+// In-place pivoted Gauss-Jordan of the swizzled LDS matrix V (only the N x N block is used).
 template <typename T, int NP>
 __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
-  using C = gj_cfg<NP>;
-  const int tr = threadIdx.x % C::TR, tc = threadIdx.x / C::TR;
-  T g[C::RB][C::CB];
+  using G = gj_cfg<NP, fcfg<NP>::NT>;
+  const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
+  T g[G::RB][G::CB];
 #pragma unroll
-  for (int rb = 0; rb < C::RB; ++rb)
+  for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < C::CB; ++cb) g[rb][cb] = V[lidx<NP>(tr + C::TR * rb, tc * C::CB + cb)];
-  gj_invert<T, NP>(g, N, *sc);
+    for (int cb = 0; cb < G::CB; ++cb) {
+      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
+      g[rb][cb] = (i < N && j < N) ? V[lidx<NP>(i, j)] : ((i == j) ? T(1) : T(0));
+    }
+  gj_invert<T, NP, fcfg<NP>::NT>(g, N, *sc);
 #pragma unroll
-  for (int rb = 0; rb < C::RB; ++rb)
+  for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < C::CB; ++cb) V[lidx<NP>(tr + C::TR * rb, sc->dst[tc * C::CB + cb])] = g[rb][cb];
+    for (int cb = 0; cb < G::CB; ++cb) {
+      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
+      if (i < N && j < N) V[lidx<NP>(i, sc->dst[j])] = g[rb][cb];
+    }
   __syncthreads();
 }
 
@@ -313,17 +359,17 @@ __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
 //
 // Series path: G = sum_{k<=K} E^k, built by repeated squaring
 //     (I+E)(I+E^2)(I+E^4)... = sum_{k < 2^p} E^k          (2 MFMA products per doubling of the order)
-// optionally closed with "+ E^(2^p)" (1 product).  Available orders K = 1,2,3,4,7,8,15,16,31 cost
-// 0,1,2,3,4,5,6,7,8 products.  K is the smallest order whose truncation error
-// ||E||^(K+1)/(1-||E||) (Frobenius norm, an upper bound of the 2-norm) stays below eps/4, i.e. the
-// result is the inverse to working precision -- the same contract as the LU of the reference.
-// General path (||E||_F >= 0.3): pivoted Gauss-Jordan.
+// optionally closed with "+ E^(2^p)" (1 product).  Orders K = 1,2,3,4,7,8,15,16,31 cost
+// 0,1,2,3,4,5,6,7,8 products.  K is the smallest order whose truncation error bound
+// b^(K+1)/(1-b), b >= ||E||_2, stays below eps/4: the result is the inverse to working precision,
+// the same contract as the LU-based inverse of the reference.  b >= 0.3: pivoted Gauss-Jordan.
 // mode 0 = automatic, 1 = force Gauss-Jordan, 2 = force series (order 31 if the bound fails).
-// Returns 1 for Gauss-Jordan, 1+K for a series of order K.  Ends with a barrier.
+// Returns 1 for Gauss-Jordan, 1+K for a series of order K.  Ends with a barrier; on exit every
+// thread may read V.  Precondition: nobody is still reading V or W.
 template <typename T, int NP>
 __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* W, int N, int Kend,
-                                                fsmem<T, NP>& sm, int mode) {
-  const T nrm = acc_fro<T, NP>(acc, sm.red);
+                                                fsmem<T, NP>& sm, int& slot, int mode) {
+  const T nrm = acc_norm_bound<T, NP>(acc, N, sm, slot);
   const T tol = num<T>::eps() * T(0.25);
   int K = 0;
   if (nrm < T(0.3)) {
@@ -341,13 +387,17 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* 
   }
   if (mode == 1) K = 0;
   if (mode == 2 && K == 0) K = 31;
+  auto keep = [N](T a, int r, int c) { return (r < N && c < N) ? a : T(0); };
   if (K > 0) {
-    // W = E, V = I + E
-    acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
-    acc_store<T, NP>(V, acc, [](T a, int r, int c, T) { return (r == c) ? a + T(1) : a; });
+    acc_store<T, NP>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? keep(a, r, c) + T(1) : keep(a, r, c); });
+    if (K == 1) {
+      __syncthreads();
+      return 2;
+    }
+    acc_store<T, NP>(W, acc, [=](T a, int r, int c, T) { return keep(a, r, c); });
     __syncthreads();
     int cur = 1;  // W = E^cur, V = sum_{k < 2 cur} E^k
-    while (K > 2 * cur - 1) {
+    for (;;) {
       acc.zero();
       mm_ll<T, NP>(acc, W, W, Kend);  // E^(2 cur)
       cur *= 2;
@@ -364,12 +414,11 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* 
       __syncthreads();
       acc_store<T, NP>(V, acc, [](T a, int, int, T old) { return old + a; });
       __syncthreads();
+      if (K == 2 * cur - 1) break;
     }
     return 1 + K;
   }
-  // general case: V = I - E, pivoted Gauss-Jordan in registers (out of line: keeps its register
-  // footprint out of the MFMA loops' allocation)
-  acc_store<T, NP>(V, acc, [](T a, int r, int c, T) { return (r == c) ? T(1) - a : -a; });
+  acc_store<T, NP>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? T(1) - keep(a, r, c) : -keep(a, r, c); });
   __syncthreads();
   gj_lds<T, NP>(V, N, &sm.gj);
   return 1;
@@ -377,14 +426,10 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* 
 
 // y1 = M*x1, y2 = M*x2: TPR consecutive lanes share a row; each lane walks a statically unrolled
 // strided column range (all LDS reads in flight at once), then a shuffle reduction.  All lanes of a
-// row group receive the sums.
+// row group receive the sums.  M's and x's padding must be zero.
 template <typename T, int NP>
-struct mv_map {
-  static constexpr int TPR = (NP <= 64) ? 4 : 2;  // threads per row
-};
-template <typename T, int NP>
-__device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, int N, T& y1, T& y2) {
-  constexpr int TPR = mv_map<T, NP>::TPR;
+__device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, T& y1, T& y2) {
+  constexpr int TPR = fcfg<NP>::TPR;
   constexpr int CNT = NP / TPR;
   const int row = threadIdx.x / TPR, q = threadIdx.x % TPR;
   T s1 = 0, s2 = 0;
@@ -392,7 +437,7 @@ __device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, in
     T mv[CNT], v1[CNT], v2[CNT];
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
-      const int j = q + TPR * c;  // padded columns hold zeros in M and in x
+      const int j = q + TPR * c;
       mv[c] = M[lidx<NP>(row, j)];
       v1[c] = x1[j];
       v2[c] = x2[j];
@@ -416,11 +461,11 @@ __device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, in
 // elemental! + doubling! + apply_D!
 // ---------------------------------------------------------------------------
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, int ndoubl, const T* __restrict__ dtau,
-                                                            const T* __restrict__ varpi,
-                                                            const T* __restrict__ tau_sum, const T* __restrict__ F0,
-                                                            const T* __restrict__ Zpp, const T* __restrict__ Zmp,
-                                                            long long zs, added<T> out) {
+__global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
+    quad<T> q, int m, int ndoubl, const T* __restrict__ dtau, const T* __restrict__ varpi,
+    const T* __restrict__ tau_sum, const T* __restrict__ F0, const T* __restrict__ Zpp, const T* __restrict__ Zmp,
+    long long zs, added<T> out) {
+  using C = fcfg<NP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
   T* R = sm.L[0];
@@ -431,15 +476,21 @@ __global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, in
   T* jm = sm.vec[1];
   T* j1p = sm.vec[2];
   T* j1m = sm.vec[3];
-  T* uu = sm.vec[4];
-  T* vv = sm.vec[5];
+  T* uu = sm.vec[4];   // matvec path: u ;  spare-column path: tmp*j0+
+  T* vv = sm.vec[5];   //              v ;                      tmp*j1-
   T* mus = sm.vec[6];
   T* wcs = sm.vec[7];
+  T* xa = sm.vec[8];   // spare-column path: tt*j0+
+  T* xb = sm.vec[9];   //                    tt*j1-
 
   const int s = blockIdx.x;
   const int N = q.N, ns = q.n_stokes;
   const int tid = threadIdx.x;
   const int Kend = ((N + 3) >> 2) << 2;
+  // Two free padded columns (>= Kend, never read by any k-loop) carry j0+ and j1- through the last
+  // two products of the step, so the source update costs no extra pass (rt_helpers.jl:128-134).
+  const bool spare = (Kend + 2 <= NP);
+  const int c1 = Kend, c2 = Kend + 1;
   const T d = dtau[s], w = varpi[s];
   const T* Zp = Zpp + (long long)s * zs;
   const T* Zm = Zmp + (long long)s * zs;
@@ -449,10 +500,13 @@ __global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, in
     const T wt = (tid < N) ? q.wt[tid] : T(0);
     wcs[tid] = (m == 0) ? wt / T(2) : wt / T(4);
   }
+  if (tid < 2) {
+    sm.umax[tid] = 0u;
+  }
   __syncthreads();
 
   // ---- elemental (elemental.jl:289-334) -------------------------------------
-  for (int e = tid; e < NP * NP; e += 256) {
+  for (int e = tid; e < NP * NP; e += C::NT) {
     const int i = e % NP, j = e / NP;
     T r = T(0), t = T(0);
     if (i < N && j < N) {
@@ -509,40 +563,44 @@ __global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, in
 
   // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------
   T expk = exp(-d / q.mu0);
+  int slot = 0;
   acc_block<T, NP> acc, acc2;
+  VSM_STAMP_DECL;
+  VSM_STAMP(0);  // elemental
   for (int n = 0; n < ndoubl; ++n) {
     // G = (I - r r)^-1  -> V
     acc.zero();
     mm_ll<T, NP>(acc, R, R, Kend);
-    invert_one_minus<T, NP>(acc, V, W, N, Kend, sm, 0);
-    // tt = t G -> W
+    VSM_STAMP(1);  // r*r
+    invert_one_minus<T, NP>(acc, V, W, N, Kend, sm, slot, 0);
+    VSM_STAMP(2);  // inverse
+    // tt = t G -> W   (W is free: its readers finished before the barrier that ended the inverse)
     acc.zero();
     mm_ll<T, NP>(acc, Tm, V, Kend);
-    __syncthreads();
     acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
     if (tid < NP) {
-      j1p[tid] = jp[tid] * expk;
-      j1m[tid] = jm[tid] * expk;
+      const T a1 = jp[tid] * expk, a2 = jm[tid] * expk;
+      j1p[tid] = a1;
+      j1m[tid] = a2;
+      if (spare) {  // columns c1/c2 of t are outside every k-range: safe to write while t is being read
+        Tm[lidx<NP>(tid, c1)] = jp[tid];
+        Tm[lidx<NP>(tid, c2)] = a2;
+      }
     }
-    __syncthreads();
-    // sources: u = j1- + r j0+ ; v = j0+ + r j1-
-    {
+    __syncthreads();  // tt complete; V (=G) no longer read
+    VSM_STAMP(3);  // tt = t G + store + barrier
+    if (!spare) {
+      // sources by mat-vec: u = j1- + r j0+ ; v = j0+ + r j1-
       T y1, y2;
-      matvec2<T, NP>(R, jp, j1m, N, y1, y2);
-      constexpr int TPR = mv_map<T, NP>::TPR;
-      const int row = tid / TPR;
-      if (row < NP && (tid % TPR) == 0) {
+      matvec2<T, NP>(R, jp, j1m, y1, y2);
+      const int row = tid / C::TPR;
+      if (row < NP && (tid % C::TPR) == 0) {
         uu[row] = j1m[row] + y1;
         vv[row] = jp[row] + y2;
       }
-    }
-    __syncthreads();
-    {
-      T y1, y2;
-      matvec2<T, NP>(W, uu, vv, N, y1, y2);
-      constexpr int TPR = mv_map<T, NP>::TPR;
-      const int row = tid / TPR;
-      if (row < NP && (tid % TPR) == 0) {
+      __syncthreads();
+      matvec2<T, NP>(W, uu, vv, y1, y2);
+      if (row < NP && (tid % C::TPR) == 0) {
         jm[row] = jm[row] + y1;   // j0- <- j0- + tt (j1- + r j0+)
         jp[row] = j1p[row] + y2;  // j0+ <- j1+ + tt (j0+ + r j1-)
       }
@@ -550,26 +608,45 @@ __global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, in
     // tmp = tt r -> V
     acc.zero();
     mm_ll<T, NP>(acc, W, R, Kend);
-    __syncthreads();
     acc_store<T, NP>(V, acc, [](T a, int, int, T) { return a; });
     __syncthreads();
-    // r <- r + tmp t ; t <- tt t
+    VSM_STAMP(4);  // (matvec +) tmp = tt r + store + barrier
+    // r <- r + tmp t ; t <- tt t   (+ columns c1,c2: tmp*j0+, tmp*j1-, tt*j0+, tt*j1-)
     acc.zero();
     acc2.zero();
     mm_ll2<T, NP>(acc, acc2, V, W, Tm, Kend);
-    __syncthreads();
-    acc_store<T, NP>(R, acc, [](T a, int, int, T old) { return old + a; });
-    acc_store<T, NP>(Tm, acc2, [](T a, int, int, T) { return a; });
+    VSM_STAMP(5);  // two products
+    // r is not an operand of this product: update it right away
+    acc_store<T, NP>(R, acc, [=](T a, int r, int c, T old) {
+      if (spare && c == c1) uu[r] = a;
+      if (spare && c == c2) vv[r] = a;
+      return (c < N) ? old + a : T(0);
+    });
+    __syncthreads();  // everybody finished reading t
+    acc_store<T, NP>(Tm, acc2, [=](T a, int r, int c, T) {
+      if (spare && c == c1) xa[r] = a;
+      if (spare && c == c2) xb[r] = a;
+      return (c < N) ? a : T(0);
+    });
     expk = expk * expk;
     __syncthreads();
+    if (spare && tid < NP) {
+      const T njm = jm[tid] + xb[tid] + uu[tid];   // j0- + tt j1- + (tt r) j0+
+      const T njp = j1p[tid] + xa[tid] + vv[tid];  // j1+ + tt j0+ + (tt r) j1-
+      jm[tid] = (tid < N) ? njm : T(0);
+      jp[tid] = (tid < N) ? njp : T(0);
+    }
+    // (jp/jm are next read after the barriers of the following inverse)
+    VSM_STAMP(6);  // stores + 2 barriers + source combine
   }
+  __syncthreads();
 
   // ---- apply_D (doubling.jl:178-252) + write the added layer -------------------------
   T* g_rmp = out.r_mp + (long long)s * out.mat_stride;
   T* g_tpp = out.t_pp + (long long)s * out.mat_stride;
   T* g_rpm = out.r_pm + (long long)s * out.mat_stride;
   T* g_tmm = out.t_mm + (long long)s * out.mat_stride;
-  for (int e = tid; e < N * N; e += 256) {
+  for (int e = tid; e < N * N; e += C::NT) {
     const int i = e % N, j = e / N;
     const int ix = lidx<NP>(i, j);
     T r = R[ix];
@@ -587,18 +664,15 @@ __global__ __launch_bounds__(256) void k_elemental_doubling(quad<T> q, int m, in
     out.j0_p[(long long)s * N + tid] = jp[tid];
     out.j0_m[(long long)s * N + tid] = vjm;
   }
+  VSM_STAMP(7);  // write-out
 }
 
 // ---------------------------------------------------------------------------
 // interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266)
 // ---------------------------------------------------------------------------
 template <typename T, int NP>
-__device__ __forceinline__ void lds_to_global(T* __restrict__ dst, const T* L, int N) {
-  for (int e = threadIdx.x; e < N * N; e += 256) dst[e] = L[lidx<NP>(e % N, e / N)];
-}
-
-template <typename T, int NP>
-__global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, added<T> a) {
+__global__ __launch_bounds__(fcfg<NP>::NT) void k_interaction11(int N, composite<T> c, added<T> a) {
+  using C = fcfg<NP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
   T* L1 = sm.L[0];  // R+-  (resident)
@@ -626,9 +700,9 @@ __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, ad
   const T* t_mm = a.t_mm + s * a.mat_stride;
   const T* j0_p = a.j0_p + (long long)s * N;
   const T* j0_m = a.j0_m + (long long)s * N;
-  constexpr int TPR = mv_map<T, NP>::TPR;
-  const int mrow = tid / TPR;
-  const bool mlead = (mrow < NP) && (tid % TPR == 0);
+  const int mrow = tid / C::TPR;
+  const bool mlead = (mrow < NP) && (tid % C::TPR == 0);
+  int slot = 0;
 
   acc_block<T, NP> acc;
   {
@@ -642,106 +716,104 @@ __global__ __launch_bounds__(256) void k_interaction11(int N, composite<T> c, ad
       vjp[tid] = in ? j0_p[tid] : T(0);
       vjm[tid] = in ? j0_m[tid] : T(0);
     }
+    if (tid < 2) sm.umax[tid] = 0u;
     s1.store(L1);
     s2.store(L2);
   }
-  gl_operand<T, NP> opA;     // A operands streamed from global: T--, later t++
+  gl_operand_a<T, NP> opA;   // A operands streamed from global: T--, later t++
   gl_operand_b<T, NP> opB;   // B operands streamed from global: T++, t--
   opA.prefetch(T_mm, N);     // lands while G1 is being formed
   __syncthreads();
   // ---- G1 = (I - r-+ R+-)^-1 -> L3 -------------------------------------------------------
   acc.zero();
   mm_ll<T, NP>(acc, L2, L1, Kend);
-  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, 0);
-  // T01_inv = T-- G1 -> L4
+  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, slot, 0);
+  // T01_inv = T-- G1 -> L4   (L4 = scratch of the inverse, free after its final barrier)
   opB.prefetch(T_pp, N);
   acc.zero();
   opA.run(acc, L3);
-  __syncthreads();
   acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  // J0- += T01_inv (r-+ J0+ + j0-)
+  // u = r-+ J0+ + j0-
   {
     T y1, y2;
-    matvec2<T, NP>(L2, vJp, vJp, N, y1, y2);
+    matvec2<T, NP>(L2, vJp, vJp, y1, y2);
     if (mlead) vu[mrow] = y1 + vjm[mrow];
   }
-  __syncthreads();
+  opA.prefetch(t_pp, N);  // needed only for G2; lands during the next three products
+  __syncthreads();        // T01_inv and u complete; G1 (L3) no longer read
+  // J0- += T01_inv u
   {
     T y1, y2;
-    matvec2<T, NP>(L4, vu, vu, N, y1, y2);
+    matvec2<T, NP>(L4, vu, vu, y1, y2);
     if (mlead && mrow < N) J0_m[mrow] = vJm[mrow] + y1;
   }
   // R-+ += (T01_inv r-+) T++
   acc.zero();
   mm_ll<T, NP>(acc, L4, L2, Kend);
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });  // G1 is dead (barrier above)
+  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
   acc.zero();
   opB.run(acc, L3);
   opB.prefetch(t_mm, N);
-  __syncthreads();
+  __syncthreads();  // everybody finished reading L3 (as A operand)
   acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  for (int e = tid; e < N * N; e += 256) R_mp[e] += L3[lidx<NP>(e % N, e / N)];
+  for (int e = tid; e < N * N; e += C::NT) R_mp[e] += L3[lidx<NP>(e % N, e / N)];
   // T-- = T01_inv t--
   acc.zero();
   opB.run(acc, L4);
-  opA.prefetch(t_pp, N);
-  __syncthreads();  // R-+ update finished reading L3
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  lds_to_global<T, NP>(T_mm, L3, N);
+  opB.prefetch(T_pp, N);  // pre-update T++ again, for T++ = T21_inv T++
+  __syncthreads();        // R-+ update finished reading L3; T01_inv (L4) no longer read
+  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
   // ---- G2 = (I - R+- r-+)^-1 -> L3 -------------------------------------------------------
   acc.zero();
   mm_ll<T, NP>(acc, L1, L2, Kend);
-  __syncthreads();  // T-- write-out finished reading L3; T01_inv (L4) is dead
-  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, 0);
+  __syncthreads();  // new T-- complete in L4
+  lds_to_global<T, NP>(T_mm, L4, N);
+  __syncthreads();  // L4 free again (scratch of the inverse)
+  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, slot, 0);
   // T21_inv = t++ G2 -> L4
-  opB.prefetch(T_pp, N);  // pre-update T++
   acc.zero();
   opA.run(acc, L3);
-  __syncthreads();
   acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  // J0+ = j0+ + T21_inv (J0+ + R+- j0-)
+  // z = J0+ + R+- j0-
   {
     T y1, y2;
-    matvec2<T, NP>(L1, vjm, vjm, N, y1, y2);
+    matvec2<T, NP>(L1, vjm, vjm, y1, y2);
     if (mlead) vz[mrow] = vJp[mrow] + y1;
   }
-  __syncthreads();
+  __syncthreads();  // T21_inv and z complete; G2 (L3) no longer read
+  // J0+ = j0+ + T21_inv z
   {
     T y1, y2;
-    matvec2<T, NP>(L4, vz, vz, N, y1, y2);
+    matvec2<T, NP>(L4, vz, vz, y1, y2);
     if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y1;
   }
-  // T++ = T21_inv T++
+  // T++ = T21_inv T++   and   tmp = T21_inv R+-
+  acc_block<T, NP> acc2;
   acc.zero();
   opB.run(acc, L4);
   opB.prefetch(t_mm, N);
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });  // G2 is dead (barrier above)
+  acc2.zero();
+  mm_ll<T, NP>(acc2, L4, L1, Kend);
+  acc_store<T, NP>(L3, acc2, [](T x, int, int, T) { return x; });  // tmp -> L3
+  __syncthreads();  // all waves finished reading r-+ (L2, last used for G2) long ago; L1/L4 reads done
+  acc_store<T, NP>(L2, acc, [](T x, int, int, T) { return x; });   // new T++ -> L2 (r-+ is dead)
   __syncthreads();
-  lds_to_global<T, NP>(T_pp, L3, N);
-  // R+- = r+- + (T21_inv R+-) t--
-  acc.zero();
-  mm_ll<T, NP>(acc, L4, L1, Kend);
-  __syncthreads();  // T++ write-out finished reading L3
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
+  lds_to_global<T, NP>(T_pp, L2, N);
+  // R+- = r+- + tmp t--
   acc.zero();
   opB.run(acc, L3);
+  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });  // T21_inv (L4) dead since the barrier above
   __syncthreads();
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  for (int e = tid; e < N * N; e += 256) R_pm[e] = r_pm[e] + L3[lidx<NP>(e % N, e / N)];
+  for (int e = tid; e < N * N; e += C::NT) R_pm[e] = r_pm[e] + L4[lidx<NP>(e % N, e / N)];
 }
 
 // ---------------------------------------------------------------------------
 // diagnostics: LDS tile product and LDS inverse on plain inputs
 // ---------------------------------------------------------------------------
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void k_test_mm(int N, const T* A, const T* B, T* C) {
+__global__ __launch_bounds__(fcfg<NP>::NT) void k_test_mm(int N, const T* A, const T* B, T* Cout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
   const long long o = (long long)blockIdx.x * N * N;
@@ -754,27 +826,30 @@ __global__ __launch_bounds__(256) void k_test_mm(int N, const T* A, const T* B, 
   mm_ll<T, NP>(acc, sm.L[0], sm.L[1], Kend);
   acc_store<T, NP>(sm.L[2], acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  lds_to_global<T, NP>(C + o, sm.L[2], N);
+  lds_to_global<T, NP>(Cout + o, sm.L[2], N);
 }
 template <typename T, int NP>
-__global__ __launch_bounds__(256) void k_test_inv(int N, const T* A, T* X, int mode, int* path_out) {
+__global__ __launch_bounds__(fcfg<NP>::NT) void k_test_inv(int N, const T* A, T* X, int mode, int* path_out) {
+  using C = fcfg<NP>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
   const long long o = (long long)blockIdx.x * N * N;
   const int Kend = ((N + 3) >> 2) << 2;
   // E = I - A, formed as a product so that it arrives in accumulator layout: E = (I - A) * I
-  for (int e = threadIdx.x; e < NP * NP; e += 256) {
+  for (int e = threadIdx.x; e < NP * NP; e += C::NT) {
     const int i = e % NP, j = e / NP;
     const T av = (i < N && j < N) ? A[o + i + (long long)N * j] : ((i == j) ? T(1) : T(0));
     sm.L[0][lidx<NP>(i, j)] = ((i == j) ? T(1) : T(0)) - av;
     sm.L[1][lidx<NP>(i, j)] = (i == j) ? T(1) : T(0);
   }
+  if (threadIdx.x < 2) sm.umax[threadIdx.x] = 0u;
   __syncthreads();
   acc_block<T, NP> acc;
   acc.zero();
   mm_ll<T, NP>(acc, sm.L[0], sm.L[1], NP);
   __syncthreads();
-  const int path = invert_one_minus<T, NP>(acc, sm.L[2], sm.L[3], N, Kend, sm, mode);
+  int slot = 0;
+  const int path = invert_one_minus<T, NP>(acc, sm.L[2], sm.L[3], N, Kend, sm, slot, mode);
   lds_to_global<T, NP>(X + o, sm.L[2], N);
   if (path_out && threadIdx.x == 0) path_out[blockIdx.x] = path;
 }
@@ -824,7 +899,8 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
     const size_t bytes = sizeof(fsmem<T, NP>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
+                       zs, a);
     VSM_LAUNCH_CHECK("k_elemental_doubling");
     return (int)VSM_OK;
   });
@@ -843,14 +919,14 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     const size_t bytes = sizeof(fsmem<T, NP>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, c, a);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, c, a);
     VSM_LAUNCH_CHECK("k_interaction11");
     return (int)VSM_OK;
   });
 }
 
 template <typename T>
-int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st) {
+int test_lds_mm(int N, int S, const T* A, const T* B, T* Cout, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
@@ -858,7 +934,7 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st) {
     const size_t bytes = sizeof(fsmem<T, NP>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, A, B, C);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, A, B, Cout);
     VSM_LAUNCH_CHECK("k_test_mm");
     return (int)VSM_OK;
   });
@@ -873,7 +949,7 @@ int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStr
     const size_t bytes = sizeof(fsmem<T, NP>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, A, X, mode, path_out);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, A, X, mode, path_out);
     VSM_LAUNCH_CHECK("k_test_inv");
     return (int)VSM_OK;
   });
@@ -889,3 +965,14 @@ VSM_INST_F(double)
 VSM_INST_F(float)
 
 }  // namespace vsm
+
+#ifdef VSM_PHASE_TIMING
+extern "C" int vsm_debug_phase_cycles(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_phase_cycles), z, sizeof(z));
+  }
+  return 0;
+}
+#endif

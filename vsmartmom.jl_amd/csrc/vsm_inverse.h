@@ -37,9 +37,11 @@ struct gj_scratch {
 // On exit a holds the inverse with its columns permuted: the caller must store
 // element a[rb][cb] at column sc.dst[tc*CB + cb].  sc.info = 0 or (k+1) of the first
 // exactly-zero pivot.  All NT threads must call this (contains barriers).
+template <typename T, int NPAD, int NT>
+using gj_regs = T[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB];
+
 template <typename T, int NPAD, int NT = 256>
-__device__ __forceinline__ void gj_invert(T (&a)[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB], int N,
-                                          gj_scratch<T, NPAD>& sc) {
+__device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, gj_scratch<T, NPAD>& sc) {
   using C = gj_cfg<NPAD, NT>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
