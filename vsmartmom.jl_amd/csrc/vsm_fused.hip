@@ -40,10 +40,11 @@ __device__ unsigned long long vsm_phase_cycles[32];
 #define VSM_STAMP(i)
 #endif
 
-template <int NP>
+template <int NP, int NW_>
 struct fcfg {
   static_assert(NP == 32 || NP == 64 || NP == 96, "NP must be 32, 64 or 96");
-  static constexpr int NW = (NP == 64) ? 8 : 4;       // waves per workgroup
+  static_assert(NW_ == 4 || (NW_ == 8 && NP == 64), "4 waves, or 8 waves for NP = 64");
+  static constexpr int NW = NW_;                      // waves per workgroup
   static constexpr int NT = 64 * NW;                  // threads
   static constexpr int WC = 2;                        // wave grid columns
   static constexpr int WR = NW / WC;                  // wave grid rows
@@ -59,18 +60,18 @@ __device__ __forceinline__ int lidx(int a, int b) {
   return (a ^ (((b & 1) << 4) | (((b >> 1) & 7) << 1))) + NP * b;
 }
 
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct fsmem {
   T L[4][NP * NP];
   T vec[10][NP];
-  unsigned umax[2];
+  float red[2][8];
   int flag[2];
   gj_scratch<T, NP> gj;
 };
 
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct acc_block {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   typename mfma<T>::acc_t v[C::TMR][C::TMC];
   __device__ __forceinline__ void zero() {
 #pragma unroll
@@ -80,11 +81,11 @@ struct acc_block {
   }
 };
 
-template <int NP>
+template <int NP, int NW>
 struct wave_pos {
   int lane, l15, kq, rowA, colB;  // rowA/colB: first row / column this lane touches in tile 0 of its wave
   __device__ __forceinline__ wave_pos() {
-    using C = fcfg<NP>;
+    using C = fcfg<NP, NW>;
     lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     l15 = lane & 15;
@@ -96,17 +97,17 @@ struct wave_pos {
 
 // ---- MFMA k-loops, software-pipelined by hand: the fragments of k-step (k0+4) are requested before
 // the MFMAs of k-step k0 issue (hipcc does not pipeline a runtime-trip-count loop). -------------------
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct frag_set {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   T a[C::TMR], b[C::TMC];
-  __device__ __forceinline__ void load(const T* A, const T* B, int k, const wave_pos<NP>& w) {
+  __device__ __forceinline__ void load(const T* A, const T* B, int k, const wave_pos<NP, NW>& w) {
 #pragma unroll
     for (int t = 0; t < C::TMR; ++t) a[t] = A[lidx<NP>(w.rowA + 16 * t, k)];
 #pragma unroll
     for (int t = 0; t < C::TMC; ++t) b[t] = B[lidx<NP>(k, w.colB + 16 * t)];
   }
-  __device__ __forceinline__ void mma(acc_block<T, NP>& acc) const {
+  __device__ __forceinline__ void mma(acc_block<T, NP, NW>& acc) const {
 #pragma unroll
     for (int x = 0; x < C::TMR; ++x)
 #pragma unroll
@@ -115,10 +116,10 @@ struct frag_set {
 };
 
 // acc += A * B with A, B in (swizzled) LDS.  Kend: multiple of 4 covering N.
-template <typename T, int NP>
-__device__ __forceinline__ void mm_ll(acc_block<T, NP>& acc, const T* A, const T* B, int Kend) {
-  const wave_pos<NP> w;
-  frag_set<T, NP> f0, f1;
+template <typename T, int NP, int NW>
+__device__ __forceinline__ void mm_ll(acc_block<T, NP, NW>& acc, const T* A, const T* B, int Kend) {
+  const wave_pos<NP, NW> w;
+  frag_set<T, NP, NW> f0, f1;
   f0.load(A, B, w.kq, w);
   int k0 = 0;
   for (; k0 + 8 <= Kend; k0 += 8) {
@@ -131,11 +132,11 @@ __device__ __forceinline__ void mm_ll(acc_block<T, NP>& acc, const T* A, const T
 }
 
 // two products sharing the B operand: acc1 += A1*B, acc2 += A2*B
-template <typename T, int NP>
-__device__ __forceinline__ void mm_ll2(acc_block<T, NP>& acc1, acc_block<T, NP>& acc2, const T* A1, const T* A2,
+template <typename T, int NP, int NW>
+__device__ __forceinline__ void mm_ll2(acc_block<T, NP, NW>& acc1, acc_block<T, NP, NW>& acc2, const T* A1, const T* A2,
                                        const T* B, int Kend) {
-  using C = fcfg<NP>;
-  const wave_pos<NP> w;
+  using C = fcfg<NP, NW>;
+  const wave_pos<NP, NW> w;
   T a1[2][C::TMR], a2[2][C::TMR], bf[2][C::TMC];
   auto load = [&](int buf, int k) {
 #pragma unroll
@@ -170,12 +171,12 @@ __device__ __forceinline__ void mm_ll2(acc_block<T, NP>& acc1, acc_block<T, NP>&
 // A read straight from global memory (column-major N x N), B in LDS.  The A fragments of the whole
 // k-range are requested up front so the L2/HBM latency is paid once and overlaps whatever the caller
 // does between prefetch() and run().
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct gl_operand_a {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   T a[C::KS][C::TMR];
   __device__ __forceinline__ void prefetch(const T* __restrict__ Ag, int N) {
-    const wave_pos<NP> w;
+    const wave_pos<NP, NW> w;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
@@ -184,8 +185,8 @@ struct gl_operand_a {
         a[ks][t] = (row < N && k < N) ? Ag[row + (long long)N * k] : T(0);
       }
   }
-  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* B) const {  // acc += A * B
-    const wave_pos<NP> w;
+  __device__ __forceinline__ void run(acc_block<T, NP, NW>& acc, const T* B) const {  // acc += A * B
+    const wave_pos<NP, NW> w;
     T bf[2][C::TMC];
 #pragma unroll
     for (int t = 0; t < C::TMC; ++t) bf[0][t] = B[lidx<NP>(w.kq, w.colB + 16 * t)];
@@ -203,12 +204,12 @@ struct gl_operand_a {
   }
 };
 // B read straight from global memory, A in LDS.
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct gl_operand_b {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   T b[C::KS][C::TMC];
   __device__ __forceinline__ void prefetch(const T* __restrict__ Bg, int N) {
-    const wave_pos<NP> w;
+    const wave_pos<NP, NW> w;
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks)
 #pragma unroll
@@ -217,8 +218,8 @@ struct gl_operand_b {
         b[ks][t] = (col < N && k < N) ? Bg[k + (long long)N * col] : T(0);
       }
   }
-  __device__ __forceinline__ void run(acc_block<T, NP>& acc, const T* A) const {  // acc += A * B
-    const wave_pos<NP> w;
+  __device__ __forceinline__ void run(acc_block<T, NP, NW>& acc, const T* A) const {  // acc += A * B
+    const wave_pos<NP, NW> w;
     T af[2][C::TMR];
 #pragma unroll
     for (int t = 0; t < C::TMR; ++t) af[0][t] = A[lidx<NP>(w.rowA + 16 * t, w.kq)];
@@ -237,9 +238,9 @@ struct gl_operand_b {
 };
 
 // dst(row,col) = f(acc(row,col), row, col, old) for every accumulator element of this wave.
-template <typename T, int NP, typename F>
-__device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP>& acc, F f) {
-  using C = fcfg<NP>;
+template <typename T, int NP, int NW, typename F>
+__device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP, NW>& acc, F f) {
+  using C = fcfg<NP, NW>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
 #pragma unroll
@@ -257,9 +258,9 @@ __device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP>& acc, F
 
 // global (column-major N x N) -> swizzled LDS, split in two halves so the global latency overlaps
 // other work: load() issues the reads into registers, store() writes the LDS image (zero padded).
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 struct stage_regs {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   static constexpr int CNT = NP * NP / C::NT;
   T v[CNT];
   __device__ __forceinline__ void load(const T* __restrict__ src, int N) {
@@ -278,40 +279,74 @@ struct stage_regs {
     }
   }
 };
-template <typename T, int NP>
+// N x N block of global memory held in registers in flat (coalesced) order: element e = tid + NT*c.
+template <typename T, int NP, int NW>
+struct flat_regs {
+  using C = fcfg<NP, NW>;
+  static constexpr int CNT = NP * NP / C::NT;
+  T v[CNT];
+  __device__ __forceinline__ void load(const T* __restrict__ src, int N) {
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = threadIdx.x + C::NT * c;
+      v[c] = (e < N * N) ? src[e] : T(0);
+    }
+  }
+  // dst[e] = v[e] + L(e)   (L swizzled LDS)
+  __device__ __forceinline__ void add_lds_store(T* __restrict__ dst, const T* L, int N) const {
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = threadIdx.x + C::NT * c;
+      if (e < N * N) dst[e] = v[c] + L[lidx<NP>(e % N, e / N)];
+    }
+  }
+};
+template <typename T, int NP, int NW>
 __device__ __forceinline__ void stage(T* dst, const T* __restrict__ src, int N) {
-  stage_regs<T, NP> s;
+  stage_regs<T, NP, NW> s;
   s.load(src, N);
   s.store(dst);
 }
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 __device__ __forceinline__ void lds_to_global(T* __restrict__ dst, const T* L, int N) {
-  for (int e = threadIdx.x; e < N * N; e += fcfg<NP>::NT) dst[e] = L[lidx<NP>(e % N, e / N)];
+  for (int e = threadIdx.x; e < N * N; e += fcfg<NP, NW>::NT) dst[e] = L[lidx<NP>(e % N, e / N)];
 }
 
-// ---- norm bound of the N x N block held in the accumulators ---------------------------------------
-// ||E||_2 <= ||E||_F <= N * max|e_ij|.  The max is an order-independent integer reduction
-// (positive floats compare like their bit patterns): DPP row rotations inside a wave, one LDS
-// atomic per wave, one barrier.  `slot` alternates between calls so no extra barrier is needed to
-// re-arm the accumulator.
-__device__ __forceinline__ unsigned wave_umax(unsigned x) {
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false));  // row_ror:8
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x124, 0xf, 0xf, false));  // row_ror:4
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x122, 0xf, 0xf, false));  // row_ror:2
-  x = max(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x121, 0xf, 0xf, false));  // row_ror:1
-  const unsigned a = __builtin_amdgcn_readlane((int)x, 0), b = __builtin_amdgcn_readlane((int)x, 16);
-  const unsigned c = __builtin_amdgcn_readlane((int)x, 32), d = __builtin_amdgcn_readlane((int)x, 48);
-  return max(max(a, b), max(c, d));
+// ---- norm of the N x N block held in the accumulators -----------------------------------------------
+// ||E||_2 <= ||E||_F.  Deterministic reduction: per-lane sum of squares (in T), rounded UP to float,
+// DPP row-rotation adds inside a wave, one LDS slot per wave, one barrier, fixed-order final sum; the
+// result is inflated by 1e-3 to cover the float rounding of the <= 80 additions.  `slot` alternates
+// between calls so no extra barrier is needed before the slots are reused.
+__device__ __forceinline__ float dpp_ror_add(float x, const int ctrl_is_8_4_2_1) {
+  float y;
+  switch (ctrl_is_8_4_2_1) {
+    case 8: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)); break;
+    case 4: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)); break;
+    case 2: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)); break;
+    default: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)); break;
+  }
+  return x + y;
 }
-__device__ __forceinline__ float abs_up(double x) { return __double2float_ru(fabs(x)); }
-__device__ __forceinline__ float abs_up(float x) { return fabsf(x); }
+__device__ __forceinline__ float wave_sum(float x) {
+  x = dpp_ror_add(x, 8);
+  x = dpp_ror_add(x, 4);
+  x = dpp_ror_add(x, 2);
+  x = dpp_ror_add(x, 1);  // every lane of a 16-lane row now holds the row sum
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+  return (a + b) + (c + d);
+}
+__device__ __forceinline__ float to_float_up(double x) { return __double2float_ru(x); }
+__device__ __forceinline__ float to_float_up(float x) { return x; }
 
-template <typename T, int NP>
-__device__ __forceinline__ T acc_norm_bound(const acc_block<T, NP>& acc, int N, fsmem<T, NP>& sm, int& slot) {
-  using C = fcfg<NP>;
+template <typename T, int NP, int NW>
+__device__ __forceinline__ T acc_norm_bound(const acc_block<T, NP, NW>& acc, int N, fsmem<T, NP, NW>& sm, int& slot) {
+  using C = fcfg<NP, NW>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
-  float m = 0.f;
+  T ss = 0;
 #pragma unroll
   for (int a = 0; a < C::TMR; ++a)
 #pragma unroll
@@ -319,22 +354,24 @@ __device__ __forceinline__ T acc_norm_bound(const acc_block<T, NP>& acc, int N, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = r0 + 16 * a + mfma<T>::crow(lane, r), col = c0 + 16 * b;
-        const float v = abs_up(acc.v[a][b][r]);
-        if (row < N && col < N) m = (v > m || v != v) ? v : m;  // NaN propagates
+        const T v = acc.v[a][b][r];
+        if (row < N && col < N) ss += v * v;
       }
-  const unsigned wm = wave_umax(__float_as_uint(m));
-  if (lane == 0) atomicMax(&sm.umax[slot], wm);
-  if (threadIdx.x == 0) sm.umax[slot ^ 1] = 0u;  // re-arm the other slot (last read >= 1 barrier ago)
+  const float ws = wave_sum(to_float_up(ss));
+  if (lane == 0) sm.red[slot][wave] = ws;
   __syncthreads();
-  const float mx = __uint_as_float(sm.umax[slot]);
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) tot += sm.red[slot][w];
   slot ^= 1;
-  return T(mx) * T(N);
+  // NaN/Inf propagate: every comparison in the caller then fails and the general path is taken
+  return T(sqrtf(tot) * 1.001f);
 }
 
 // In-place pivoted Gauss-Jordan of the swizzled LDS matrix V (only the N x N block is used).
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
-  using G = gj_cfg<NP, fcfg<NP>::NT>;
+  using G = gj_cfg<NP, fcfg<NP, NW>::NT>;
   const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
   T g[G::RB][G::CB];
 #pragma unroll
@@ -344,7 +381,7 @@ __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
       g[rb][cb] = (i < N && j < N) ? V[lidx<NP>(i, j)] : ((i == j) ? T(1) : T(0));
     }
-  gj_invert<T, NP, fcfg<NP>::NT>(g, N, *sc);
+  gj_invert<T, NP, fcfg<NP, NW>::NT>(g, N, *sc);
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
@@ -366,10 +403,10 @@ __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
 // mode 0 = automatic, 1 = force Gauss-Jordan, 2 = force series (order 31 if the bound fails).
 // Returns 1 for Gauss-Jordan, 1+K for a series of order K.  Ends with a barrier; on exit every
 // thread may read V.  Precondition: nobody is still reading V or W.
-template <typename T, int NP>
-__device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* W, int N, int Kend,
-                                                fsmem<T, NP>& sm, int& slot, int mode) {
-  const T nrm = acc_norm_bound<T, NP>(acc, N, sm, slot);
+template <typename T, int NP, int NW>
+__device__ __forceinline__ int invert_one_minus(acc_block<T, NP, NW>& acc, T* V, T* W, int N, int Kend,
+                                                fsmem<T, NP, NW>& sm, int& slot, int mode) {
+  const T nrm = acc_norm_bound<T, NP, NW>(acc, N, sm, slot);
   const T tol = num<T>::eps() * T(0.25);
   int K = 0;
   if (nrm < T(0.3)) {
@@ -389,47 +426,47 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP>& acc, T* V, T* 
   if (mode == 2 && K == 0) K = 31;
   auto keep = [N](T a, int r, int c) { return (r < N && c < N) ? a : T(0); };
   if (K > 0) {
-    acc_store<T, NP>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? keep(a, r, c) + T(1) : keep(a, r, c); });
+    acc_store<T, NP, NW>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? keep(a, r, c) + T(1) : keep(a, r, c); });
     if (K == 1) {
       __syncthreads();
       return 2;
     }
-    acc_store<T, NP>(W, acc, [=](T a, int r, int c, T) { return keep(a, r, c); });
+    acc_store<T, NP, NW>(W, acc, [=](T a, int r, int c, T) { return keep(a, r, c); });
     __syncthreads();
     int cur = 1;  // W = E^cur, V = sum_{k < 2 cur} E^k
     for (;;) {
       acc.zero();
-      mm_ll<T, NP>(acc, W, W, Kend);  // E^(2 cur)
+      mm_ll<T, NP, NW>(acc, W, W, Kend);  // E^(2 cur)
       cur *= 2;
       if (K == cur) {  // close with "+ E^cur"
-        acc_store<T, NP>(V, acc, [](T a, int, int, T old) { return old + a; });
+        acc_store<T, NP, NW>(V, acc, [](T a, int, int, T old) { return old + a; });
         __syncthreads();
         break;
       }
       __syncthreads();
-      acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
+      acc_store<T, NP, NW>(W, acc, [](T a, int, int, T) { return a; });
       __syncthreads();
       acc.zero();
-      mm_ll<T, NP>(acc, V, W, Kend);  // V * E^cur
+      mm_ll<T, NP, NW>(acc, V, W, Kend);  // V * E^cur
       __syncthreads();
-      acc_store<T, NP>(V, acc, [](T a, int, int, T old) { return old + a; });
+      acc_store<T, NP, NW>(V, acc, [](T a, int, int, T old) { return old + a; });
       __syncthreads();
       if (K == 2 * cur - 1) break;
     }
     return 1 + K;
   }
-  acc_store<T, NP>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? T(1) - keep(a, r, c) : -keep(a, r, c); });
+  acc_store<T, NP, NW>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? T(1) - keep(a, r, c) : -keep(a, r, c); });
   __syncthreads();
-  gj_lds<T, NP>(V, N, &sm.gj);
+  gj_lds<T, NP, NW>(V, N, &sm.gj);
   return 1;
 }
 
 // y1 = M*x1, y2 = M*x2: TPR consecutive lanes share a row; each lane walks a statically unrolled
 // strided column range (all LDS reads in flight at once), then a shuffle reduction.  All lanes of a
 // row group receive the sums.  M's and x's padding must be zero.
-template <typename T, int NP>
+template <typename T, int NP, int NW>
 __device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, T& y1, T& y2) {
-  constexpr int TPR = fcfg<NP>::TPR;
+  constexpr int TPR = fcfg<NP, NW>::TPR;
   constexpr int CNT = NP / TPR;
   const int row = threadIdx.x / TPR, q = threadIdx.x % TPR;
   T s1 = 0, s2 = 0;
@@ -460,14 +497,14 @@ __device__ __forceinline__ void matvec2(const T* M, const T* x1, const T* x2, T&
 // ---------------------------------------------------------------------------
 // elemental! + doubling! + apply_D!
 // ---------------------------------------------------------------------------
-template <typename T, int NP>
-__global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
     quad<T> q, int m, int ndoubl, const T* __restrict__ dtau, const T* __restrict__ varpi,
     const T* __restrict__ tau_sum, const T* __restrict__ F0, const T* __restrict__ Zpp, const T* __restrict__ Zmp,
     long long zs, added<T> out) {
-  using C = fcfg<NP>;
+  using C = fcfg<NP, NW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
   T* R = sm.L[0];
   T* Tm = sm.L[1];
   T* W = sm.L[2];
@@ -499,9 +536,6 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
     mus[tid] = (tid < N) ? q.mu[tid] : T(1);
     const T wt = (tid < N) ? q.wt[tid] : T(0);
     wcs[tid] = (m == 0) ? wt / T(2) : wt / T(4);
-  }
-  if (tid < 2) {
-    sm.umax[tid] = 0u;
   }
   __syncthreads();
 
@@ -564,20 +598,20 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
   // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------
   T expk = exp(-d / q.mu0);
   int slot = 0;
-  acc_block<T, NP> acc, acc2;
+  acc_block<T, NP, NW> acc, acc2;
   VSM_STAMP_DECL;
   VSM_STAMP(0);  // elemental
   for (int n = 0; n < ndoubl; ++n) {
     // G = (I - r r)^-1  -> V
     acc.zero();
-    mm_ll<T, NP>(acc, R, R, Kend);
+    mm_ll<T, NP, NW>(acc, R, R, Kend);
     VSM_STAMP(1);  // r*r
-    invert_one_minus<T, NP>(acc, V, W, N, Kend, sm, slot, 0);
+    invert_one_minus<T, NP, NW>(acc, V, W, N, Kend, sm, slot, 0);
     VSM_STAMP(2);  // inverse
     // tt = t G -> W   (W is free: its readers finished before the barrier that ended the inverse)
     acc.zero();
-    mm_ll<T, NP>(acc, Tm, V, Kend);
-    acc_store<T, NP>(W, acc, [](T a, int, int, T) { return a; });
+    mm_ll<T, NP, NW>(acc, Tm, V, Kend);
+    acc_store<T, NP, NW>(W, acc, [](T a, int, int, T) { return a; });
     if (tid < NP) {
       const T a1 = jp[tid] * expk, a2 = jm[tid] * expk;
       j1p[tid] = a1;
@@ -592,14 +626,14 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
     if (!spare) {
       // sources by mat-vec: u = j1- + r j0+ ; v = j0+ + r j1-
       T y1, y2;
-      matvec2<T, NP>(R, jp, j1m, y1, y2);
+      matvec2<T, NP, NW>(R, jp, j1m, y1, y2);
       const int row = tid / C::TPR;
       if (row < NP && (tid % C::TPR) == 0) {
         uu[row] = j1m[row] + y1;
         vv[row] = jp[row] + y2;
       }
       __syncthreads();
-      matvec2<T, NP>(W, uu, vv, y1, y2);
+      matvec2<T, NP, NW>(W, uu, vv, y1, y2);
       if (row < NP && (tid % C::TPR) == 0) {
         jm[row] = jm[row] + y1;   // j0- <- j0- + tt (j1- + r j0+)
         jp[row] = j1p[row] + y2;  // j0+ <- j1+ + tt (j0+ + r j1-)
@@ -607,23 +641,23 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
     }
     // tmp = tt r -> V
     acc.zero();
-    mm_ll<T, NP>(acc, W, R, Kend);
-    acc_store<T, NP>(V, acc, [](T a, int, int, T) { return a; });
+    mm_ll<T, NP, NW>(acc, W, R, Kend);
+    acc_store<T, NP, NW>(V, acc, [](T a, int, int, T) { return a; });
     __syncthreads();
     VSM_STAMP(4);  // (matvec +) tmp = tt r + store + barrier
     // r <- r + tmp t ; t <- tt t   (+ columns c1,c2: tmp*j0+, tmp*j1-, tt*j0+, tt*j1-)
     acc.zero();
     acc2.zero();
-    mm_ll2<T, NP>(acc, acc2, V, W, Tm, Kend);
+    mm_ll2<T, NP, NW>(acc, acc2, V, W, Tm, Kend);
     VSM_STAMP(5);  // two products
     // r is not an operand of this product: update it right away
-    acc_store<T, NP>(R, acc, [=](T a, int r, int c, T old) {
+    acc_store<T, NP, NW>(R, acc, [=](T a, int r, int c, T old) {
       if (spare && c == c1) uu[r] = a;
       if (spare && c == c2) vv[r] = a;
       return (c < N) ? old + a : T(0);
     });
     __syncthreads();  // everybody finished reading t
-    acc_store<T, NP>(Tm, acc2, [=](T a, int r, int c, T) {
+    acc_store<T, NP, NW>(Tm, acc2, [=](T a, int r, int c, T) {
       if (spare && c == c1) xa[r] = a;
       if (spare && c == c2) xb[r] = a;
       return (c < N) ? a : T(0);
@@ -670,11 +704,11 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_elemental_doubling(
 // ---------------------------------------------------------------------------
 // interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266)
 // ---------------------------------------------------------------------------
-template <typename T, int NP>
-__global__ __launch_bounds__(fcfg<NP>::NT) void k_interaction11(int N, composite<T> c, added<T> a) {
-  using C = fcfg<NP>;
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c, added<T> a) {
+  using C = fcfg<NP, NW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
   T* L1 = sm.L[0];  // R+-  (resident)
   T* L2 = sm.L[1];  // r-+  (resident)
   T* L3 = sm.L[2];
@@ -704,11 +738,15 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_interaction11(int N, composite
   const bool mlead = (mrow < NP) && (tid % C::TPR == 0);
   int slot = 0;
 
-  acc_block<T, NP> acc;
+  VSM_STAMP_DECL;
+  acc_block<T, NP, NW> acc;
+  flat_regs<T, NP, NW> oldRmp, addrpm;  // R-+ (accumulated into) and r+- (added at the very end)
   {
-    stage_regs<T, NP> s1, s2;
+    stage_regs<T, NP, NW> s1, s2;
     s1.load(R_pm, N);
     s2.load(r_mp, N);
+    oldRmp.load(R_mp, N);
+    addrpm.load(r_pm, N);
     if (tid < NP) {
       const bool in = tid < N;
       vJp[tid] = in ? J0_p[tid] : T(0);
@@ -716,123 +754,133 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_interaction11(int N, composite
       vjp[tid] = in ? j0_p[tid] : T(0);
       vjm[tid] = in ? j0_m[tid] : T(0);
     }
-    if (tid < 2) sm.umax[tid] = 0u;
     s1.store(L1);
     s2.store(L2);
   }
-  gl_operand_a<T, NP> opA;   // A operands streamed from global: T--, later t++
-  gl_operand_b<T, NP> opB;   // B operands streamed from global: T++, t--
+  gl_operand_a<T, NP, NW> opA;   // A operands streamed from global: T--, later t++
+  gl_operand_b<T, NP, NW> opB;   // B operands streamed from global: T++, t--
   opA.prefetch(T_mm, N);     // lands while G1 is being formed
   __syncthreads();
+  VSM_STAMP(8);   // stage
   // ---- G1 = (I - r-+ R+-)^-1 -> L3 -------------------------------------------------------
   acc.zero();
-  mm_ll<T, NP>(acc, L2, L1, Kend);
-  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, slot, 0);
+  mm_ll<T, NP, NW>(acc, L2, L1, Kend);
+  VSM_STAMP(9);   // r R
+  invert_one_minus<T, NP, NW>(acc, L3, L4, N, Kend, sm, slot, 0);
+  VSM_STAMP(10);  // inverse 1
   // T01_inv = T-- G1 -> L4   (L4 = scratch of the inverse, free after its final barrier)
   opB.prefetch(T_pp, N);
   acc.zero();
   opA.run(acc, L3);
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
+  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
   // u = r-+ J0+ + j0-
   {
     T y1, y2;
-    matvec2<T, NP>(L2, vJp, vJp, y1, y2);
+    matvec2<T, NP, NW>(L2, vJp, vJp, y1, y2);
     if (mlead) vu[mrow] = y1 + vjm[mrow];
   }
   opA.prefetch(t_pp, N);  // needed only for G2; lands during the next three products
   __syncthreads();        // T01_inv and u complete; G1 (L3) no longer read
+  VSM_STAMP(11);  // T01 = T-- G1, matvec u
   // J0- += T01_inv u
   {
     T y1, y2;
-    matvec2<T, NP>(L4, vu, vu, y1, y2);
+    matvec2<T, NP, NW>(L4, vu, vu, y1, y2);
     if (mlead && mrow < N) J0_m[mrow] = vJm[mrow] + y1;
   }
   // R-+ += (T01_inv r-+) T++
   acc.zero();
-  mm_ll<T, NP>(acc, L4, L2, Kend);
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
+  mm_ll<T, NP, NW>(acc, L4, L2, Kend);
+  acc_store<T, NP, NW>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
+  VSM_STAMP(12);  // matvec J0-, T01 r
   acc.zero();
   opB.run(acc, L3);
   opB.prefetch(t_mm, N);
   __syncthreads();  // everybody finished reading L3 (as A operand)
-  acc_store<T, NP>(L3, acc, [](T x, int, int, T) { return x; });
+  acc_store<T, NP, NW>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  for (int e = tid; e < N * N; e += C::NT) R_mp[e] += L3[lidx<NP>(e % N, e / N)];
+  oldRmp.add_lds_store(R_mp, L3, N);
+  VSM_STAMP(13);  // (..) T++ -> R-+ update
   // T-- = T01_inv t--
   acc.zero();
   opB.run(acc, L4);
   opB.prefetch(T_pp, N);  // pre-update T++ again, for T++ = T21_inv T++
   __syncthreads();        // R-+ update finished reading L3; T01_inv (L4) no longer read
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
+  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
   // ---- G2 = (I - R+- r-+)^-1 -> L3 -------------------------------------------------------
   acc.zero();
-  mm_ll<T, NP>(acc, L1, L2, Kend);
+  mm_ll<T, NP, NW>(acc, L1, L2, Kend);
   __syncthreads();  // new T-- complete in L4
-  lds_to_global<T, NP>(T_mm, L4, N);
+  lds_to_global<T, NP, NW>(T_mm, L4, N);
   __syncthreads();  // L4 free again (scratch of the inverse)
-  invert_one_minus<T, NP>(acc, L3, L4, N, Kend, sm, slot, 0);
+  VSM_STAMP(14);  // T-- = T01 t--, R r, write T--
+  invert_one_minus<T, NP, NW>(acc, L3, L4, N, Kend, sm, slot, 0);
+  VSM_STAMP(15);  // inverse 2
   // T21_inv = t++ G2 -> L4
   acc.zero();
   opA.run(acc, L3);
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });
+  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
   // z = J0+ + R+- j0-
   {
     T y1, y2;
-    matvec2<T, NP>(L1, vjm, vjm, y1, y2);
+    matvec2<T, NP, NW>(L1, vjm, vjm, y1, y2);
     if (mlead) vz[mrow] = vJp[mrow] + y1;
   }
   __syncthreads();  // T21_inv and z complete; G2 (L3) no longer read
+  VSM_STAMP(16);  // T21 = t++ G2, matvec z
   // J0+ = j0+ + T21_inv z
   {
     T y1, y2;
-    matvec2<T, NP>(L4, vz, vz, y1, y2);
+    matvec2<T, NP, NW>(L4, vz, vz, y1, y2);
     if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y1;
   }
   // T++ = T21_inv T++   and   tmp = T21_inv R+-
-  acc_block<T, NP> acc2;
+  acc_block<T, NP, NW> acc2;
   acc.zero();
   opB.run(acc, L4);
   opB.prefetch(t_mm, N);
   acc2.zero();
-  mm_ll<T, NP>(acc2, L4, L1, Kend);
-  acc_store<T, NP>(L3, acc2, [](T x, int, int, T) { return x; });  // tmp -> L3
+  mm_ll<T, NP, NW>(acc2, L4, L1, Kend);
+  acc_store<T, NP, NW>(L3, acc2, [](T x, int, int, T) { return x; });  // tmp -> L3
   __syncthreads();  // all waves finished reading r-+ (L2, last used for G2) long ago; L1/L4 reads done
-  acc_store<T, NP>(L2, acc, [](T x, int, int, T) { return x; });   // new T++ -> L2 (r-+ is dead)
+  acc_store<T, NP, NW>(L2, acc, [](T x, int, int, T) { return x; });   // new T++ -> L2 (r-+ is dead)
   __syncthreads();
-  lds_to_global<T, NP>(T_pp, L2, N);
+  lds_to_global<T, NP, NW>(T_pp, L2, N);
+  VSM_STAMP(17);  // T21 T++, T21 R+-, write T++
   // R+- = r+- + tmp t--
   acc.zero();
   opB.run(acc, L3);
-  acc_store<T, NP>(L4, acc, [](T x, int, int, T) { return x; });  // T21_inv (L4) dead since the barrier above
+  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });  // T21_inv (L4) dead since the barrier above
   __syncthreads();
-  for (int e = tid; e < N * N; e += C::NT) R_pm[e] = r_pm[e] + L4[lidx<NP>(e % N, e / N)];
+  addrpm.add_lds_store(R_pm, L4, N);
+  VSM_STAMP(18);  // (..) t-- -> R+-
 }
 
 // ---------------------------------------------------------------------------
 // diagnostics: LDS tile product and LDS inverse on plain inputs
 // ---------------------------------------------------------------------------
-template <typename T, int NP>
-__global__ __launch_bounds__(fcfg<NP>::NT) void k_test_mm(int N, const T* A, const T* B, T* Cout) {
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_test_mm(int N, const T* A, const T* B, T* Cout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
   const long long o = (long long)blockIdx.x * N * N;
   const int Kend = ((N + 3) >> 2) << 2;
-  stage<T, NP>(sm.L[0], A + o, N);
-  stage<T, NP>(sm.L[1], B + o, N);
+  stage<T, NP, NW>(sm.L[0], A + o, N);
+  stage<T, NP, NW>(sm.L[1], B + o, N);
   __syncthreads();
-  acc_block<T, NP> acc;
+  acc_block<T, NP, NW> acc;
   acc.zero();
-  mm_ll<T, NP>(acc, sm.L[0], sm.L[1], Kend);
-  acc_store<T, NP>(sm.L[2], acc, [](T x, int, int, T) { return x; });
+  mm_ll<T, NP, NW>(acc, sm.L[0], sm.L[1], Kend);
+  acc_store<T, NP, NW>(sm.L[2], acc, [](T x, int, int, T) { return x; });
   __syncthreads();
-  lds_to_global<T, NP>(Cout + o, sm.L[2], N);
+  lds_to_global<T, NP, NW>(Cout + o, sm.L[2], N);
 }
-template <typename T, int NP>
-__global__ __launch_bounds__(fcfg<NP>::NT) void k_test_inv(int N, const T* A, T* X, int mode, int* path_out) {
-  using C = fcfg<NP>;
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_test_inv(int N, const T* A, T* X, int mode, int* path_out) {
+  using C = fcfg<NP, NW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem<T, NP>& sm = *reinterpret_cast<fsmem<T, NP>*>(smem_raw);
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
   const long long o = (long long)blockIdx.x * N * N;
   const int Kend = ((N + 3) >> 2) << 2;
   // E = I - A, formed as a product so that it arrives in accumulator layout: E = (I - A) * I
@@ -842,15 +890,14 @@ __global__ __launch_bounds__(fcfg<NP>::NT) void k_test_inv(int N, const T* A, T*
     sm.L[0][lidx<NP>(i, j)] = ((i == j) ? T(1) : T(0)) - av;
     sm.L[1][lidx<NP>(i, j)] = (i == j) ? T(1) : T(0);
   }
-  if (threadIdx.x < 2) sm.umax[threadIdx.x] = 0u;
   __syncthreads();
-  acc_block<T, NP> acc;
+  acc_block<T, NP, NW> acc;
   acc.zero();
-  mm_ll<T, NP>(acc, sm.L[0], sm.L[1], NP);
+  mm_ll<T, NP, NW>(acc, sm.L[0], sm.L[1], NP);
   __syncthreads();
   int slot = 0;
-  const int path = invert_one_minus<T, NP>(acc, sm.L[2], sm.L[3], N, Kend, sm, slot, mode);
-  lds_to_global<T, NP>(X + o, sm.L[2], N);
+  const int path = invert_one_minus<T, NP, NW>(acc, sm.L[2], sm.L[3], N, Kend, sm, slot, mode);
+  lds_to_global<T, NP, NW>(X + o, sm.L[2], N);
   if (path_out && threadIdx.x == 0) path_out[blockIdx.x] = path;
 }
 
@@ -863,6 +910,14 @@ int fused_max_n() {
 }
 template int fused_max_n<double>();
 template int fused_max_n<float>();
+
+// waves per workgroup of the NP = 64 instantiations (build-time tunables)
+#ifndef ED_WAVES_64
+#define ED_WAVES_64 8
+#endif
+#ifndef IA_WAVES_64
+#define IA_WAVES_64 4
+#endif
 
 template <typename K>
 static int enable_lds(K kern, size_t bytes) {
@@ -895,11 +950,12 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(q.N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    auto kern = k_elemental_doubling<T, NP>;
-    const size_t bytes = sizeof(fsmem<T, NP>);
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    auto kern = k_elemental_doubling<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
                        zs, a);
     VSM_LAUNCH_CHECK("k_elemental_doubling");
     return (int)VSM_OK;
@@ -915,11 +971,12 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
   }
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    auto kern = k_interaction11<T, NP>;
-    const size_t bytes = sizeof(fsmem<T, NP>);
+    constexpr int NW = (NP == 64) ? IA_WAVES_64 : 4;
+    auto kern = k_interaction11<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, c, a);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, c, a);
     VSM_LAUNCH_CHECK("k_interaction11");
     return (int)VSM_OK;
   });
@@ -930,11 +987,12 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* Cout, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    auto kern = k_test_mm<T, NP>;
-    const size_t bytes = sizeof(fsmem<T, NP>);
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    auto kern = k_test_mm<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, A, B, Cout);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, B, Cout);
     VSM_LAUNCH_CHECK("k_test_mm");
     return (int)VSM_OK;
   });
@@ -945,11 +1003,12 @@ int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStr
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    auto kern = k_test_inv<T, NP>;
-    const size_t bytes = sizeof(fsmem<T, NP>);
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    auto kern = k_test_inv<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
-    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP>::NT), bytes, st, N, A, X, mode, path_out);
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, X, mode, path_out);
     VSM_LAUNCH_CHECK("k_test_inv");
     return (int)VSM_OK;
   });
