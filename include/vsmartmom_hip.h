@@ -83,11 +83,19 @@ typedef struct vsm_added_f64 {
   long long mat_stride;               /* element stride between spectral slices of the
                                          matrices: N*N, or 0 if one matrix is shared by all S
                                          (surface layers) */
+  int d_symmetric;                    /* 0: all four matrices are materialised (the reference's AddedLayer).
+                                         n>0 (= nStokes): r⁺⁻/t⁻⁻ are NOT read or written; consumers derive
+                                         them by the D-symmetry r⁺⁻ = D r⁻⁺ D, t⁻⁻ = D t⁺⁺ D
+                                         (doubling.jl:178-201), halving the layer's HBM traffic.  Only the
+                                         fused kernels accept n>0. */
+  int reserved;
 } vsm_added_f64;
 typedef struct vsm_added_f32 {
   float *r_mp, *t_pp, *r_pm, *t_mm;
   float *j0_p, *j0_m;
   long long mat_stride;
+  int d_symmetric;
+  int reserved;
 } vsm_added_f32;
 typedef struct vsm_composite_f64 {
   double *R_mp, *R_pm, *T_pp, *T_mm;  /* R⁻⁺ R⁺⁻ T⁺⁺ T⁻⁻  [N,N,S] */

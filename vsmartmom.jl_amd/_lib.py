@@ -29,7 +29,8 @@ class vsm_quad_f32(C.Structure):
 
 class vsm_added(C.Structure):  # same layout for f32/f64 (pointers + stride)
     _fields_ = [("r_mp", C.c_void_p), ("t_pp", C.c_void_p), ("r_pm", C.c_void_p), ("t_mm", C.c_void_p),
-                ("j0_p", C.c_void_p), ("j0_m", C.c_void_p), ("mat_stride", C.c_longlong)]
+                ("j0_p", C.c_void_p), ("j0_m", C.c_void_p), ("mat_stride", C.c_longlong),
+                ("d_symmetric", C.c_int), ("reserved", C.c_int)]
 
 
 class vsm_composite(C.Structure):

@@ -126,18 +126,25 @@ class AddedLayer:
     """src/CoreRT/types.jl:155-230 AddedLayer (elastic fields).  `shared=True` allocates ONE
     N x N block per matrix, broadcast over the spectral axis (surface layers)."""
 
-    def __init__(self, FT, arch, N, nSpec, shared=False):
+    def __init__(self, FT, arch, N, nSpec, shared=False, d_symmetric=0):
         dev, dt = devi(arch), _torch_dtype(FT)
         sm = 1 if shared else nSpec
         z = lambda: torch.zeros((sm, N, N), dtype=dt, device=dev)
-        self.r_mp, self.t_pp, self.r_pm, self.t_mm = z(), z(), z(), z()
+        self.r_mp, self.t_pp = z(), z()
+        # d_symmetric = nStokes: r+-/t-- are never materialised (derived as D r-+ D, D t++ D by the fused
+        # kernels) -- half the HBM traffic of a layer.  0 = the reference's full AddedLayer.
+        self.d_symmetric = int(d_symmetric)
+        self.r_pm, self.t_mm = (None, None) if self.d_symmetric else (z(), z())
         self.j0_p = torch.zeros((nSpec, N), dtype=dt, device=dev)
         self.j0_m = torch.zeros((nSpec, N), dtype=dt, device=dev)
         self.N, self.nSpec, self.shared, self.dtype = N, nSpec, shared, dt
 
     def cstruct(self):
-        return _lib.vsm_added(self.r_mp.data_ptr(), self.t_pp.data_ptr(), self.r_pm.data_ptr(), self.t_mm.data_ptr(),
-                              self.j0_p.data_ptr(), self.j0_m.data_ptr(), 0 if self.shared else self.N * self.N)
+        return _lib.vsm_added(self.r_mp.data_ptr(), self.t_pp.data_ptr(),
+                              0 if self.r_pm is None else self.r_pm.data_ptr(),
+                              0 if self.t_mm is None else self.t_mm.data_ptr(),
+                              self.j0_p.data_ptr(), self.j0_m.data_ptr(), 0 if self.shared else self.N * self.N,
+                              self.d_symmetric, 0)
 
 
 class CompositeLayer:
@@ -156,9 +163,9 @@ class CompositeLayer:
                                   self.T_mm.data_ptr(), self.J0_p.data_ptr(), self.J0_m.data_ptr())
 
 
-def make_added_layer(FT, arch, dims, nSpec, shared=False) -> AddedLayer:
+def make_added_layer(FT, arch, dims, nSpec, shared=False, d_symmetric=0) -> AddedLayer:
     _require_gpu(arch)
-    return AddedLayer(FT, arch, dims[0], nSpec, shared)
+    return AddedLayer(FT, arch, dims[0], nSpec, shared, d_symmetric)
 
 
 def make_composite_layer(FT, arch, dims, nSpec) -> CompositeLayer:
@@ -364,7 +371,11 @@ class Scene:
             self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1],
                                      tau_sum_surface=conv(np.ascontiguousarray(tau_sum_all[self.sl, -1].astype(FT)))))
         N, S = self.N, self.S
-        self.added = make_added_layer(FT, arch, (N, N), S)
+        # every layer scatters and N fits on chip -> all steps run in the fused kernels, which can derive
+        # r+-/t-- by D-symmetry instead of moving them through HBM
+        all11 = all(ly["iface"] == "11" for mom in self.moments for ly in mom["layers"])
+        fused_ok = N <= _lib.lib().vsm_fused_max_n(8 if np.dtype(FT) == np.float64 else 4)
+        self.added = make_added_layer(FT, arch, (N, N), S, d_symmetric=pol.n if (all11 and fused_ok) else 0)
         self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=True)
         self.composite = make_composite_layer(FT, arch, (N, N), S)
         nV = len(model.vza)

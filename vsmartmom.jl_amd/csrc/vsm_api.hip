@@ -65,6 +65,7 @@ static added<T> cvt_added(const A* a) {
   r.j0_p = a->j0_p;
   r.j0_m = a->j0_m;
   r.mat_stride = a->mat_stride;
+  r.d_symmetric = a->d_symmetric;
   return r;
 }
 template <typename T, typename C>
@@ -91,7 +92,9 @@ static int check_quad(const Q* q) {
 template <typename A>
 static int check_added(const A* a) {
   VSM_REQUIRE(a != nullptr, "added: null");
-  VSM_REQUIRE(a->r_mp && a->t_pp && a->r_pm && a->t_mm && a->j0_p && a->j0_m, "added: null field");
+  VSM_REQUIRE(a->r_mp && a->t_pp && a->j0_p && a->j0_m, "added: null field");
+  VSM_REQUIRE(a->d_symmetric > 0 || (a->r_pm && a->t_mm), "added: null r_pm/t_mm without d_symmetric");
+  VSM_REQUIRE(a->d_symmetric >= 0 && a->d_symmetric <= 4, "added: bad d_symmetric");
   return VSM_OK;
 }
 template <typename C>
@@ -117,6 +120,7 @@ static int elemental_doubling_impl(const Q* q, int S, int m, int ndoubl, const T
   if (q->N <= fused_max_n<T>())
     return fused_elemental_doubling<T>(qq, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, aa, st);
   // operator-level path for N that does not fit on-chip
+  VSM_REQUIRE(ad->d_symmetric == 0, "elemental_doubling: d_symmetric layers need the fused kernels (N=%d too large)", q->N);
   if ((rc = elemental<T>(qq, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, aa, st))) return rc;
   if (ndoubl == 0) return VSM_OK;
   const size_t we = vsm_doubling_work_elems(q->N, S);
@@ -154,6 +158,7 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
   hipStream_t st = as_stream(stream);
   if (!oplevel && iface == VSM_IFACE_11 && N <= fused_max_n<T>())
     return fused_interaction<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
+  VSM_REQUIRE(a->d_symmetric == 0, "interaction: d_symmetric layers are only accepted by the fused 11 kernel");
   if (!work) {
     work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1));
     if (!work) return VSM_ERR_HIP;
@@ -230,6 +235,7 @@ int vsm_elemental_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const dou
                       const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp,
                       long long z_stride, const vsm_added_f64* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_elemental_f64: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "elemental: null input");
   return elemental<double>(cvt_quad<double>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride,
@@ -239,6 +245,7 @@ int vsm_elemental_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const flo
                       const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
                       const vsm_added_f32* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_elemental_f32: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "elemental: null input");
   return elemental<float>(cvt_quad<float>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride,
@@ -251,6 +258,7 @@ size_t vsm_doubling_work_elems(int N, int S) {
 int vsm_doubling_f64(int N, int n_stokes, int S, int ndoubl, double* expk, const vsm_added_f64* added, double* work,
                      void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_doubling_f64: d_symmetric layers are not accepted here");
   if ((rc = check_added(added))) return rc;
   VSM_REQUIRE(N > 0 && S >= 0 && ndoubl >= 0 && expk && (work || ndoubl == 0), "doubling: bad argument");
   return doubling<double>(N, n_stokes, S, ndoubl, expk, cvt_added<double>(added), work, as_stream(stream));
@@ -258,6 +266,7 @@ int vsm_doubling_f64(int N, int n_stokes, int S, int ndoubl, double* expk, const
 int vsm_doubling_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const vsm_added_f32* added, float* work,
                      void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_doubling_f32: d_symmetric layers are not accepted here");
   if ((rc = check_added(added))) return rc;
   VSM_REQUIRE(N > 0 && S >= 0 && ndoubl >= 0 && expk && (work || ndoubl == 0), "doubling: bad argument");
   return doubling<float>(N, n_stokes, S, ndoubl, expk, cvt_added<float>(added), work, as_stream(stream));
@@ -265,12 +274,14 @@ int vsm_doubling_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const 
 
 int vsm_noscat_layer_f64(const vsm_quad_f64* q, int S, const double* tau, const vsm_added_f64* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_noscat_layer_f64: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(tau != nullptr, "noscat_layer: null tau");
   return noscat_layer<double>(cvt_quad<double>(q), S, tau, cvt_added<double>(added), as_stream(stream));
 }
 int vsm_noscat_layer_f32(const vsm_quad_f32* q, int S, const float* tau, const vsm_added_f32* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_noscat_layer_f32: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(tau != nullptr, "noscat_layer: null tau");
   return noscat_layer<float>(cvt_quad<float>(q), S, tau, cvt_added<float>(added), as_stream(stream));
@@ -312,6 +323,7 @@ int vsm_interaction_oplevel_f32(int iface, int N, int S, const vsm_composite_f32
 int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albedo, const double* tau_sum,
                                const vsm_added_f64* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_lambertian_surface_f64: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(tau_sum != nullptr, "lambertian_surface: null tau_sum");
   return lambertian_surface<double>(cvt_quad<double>(q), S, m, albedo, tau_sum, cvt_added<double>(added),
@@ -320,6 +332,7 @@ int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albed
 int vsm_lambertian_surface_f32(const vsm_quad_f32* q, int S, int m, float albedo, const float* tau_sum,
                                const vsm_added_f32* added, void* stream) {
   int rc;
+  VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_lambertian_surface_f32: d_symmetric layers are not accepted here");
   if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
   VSM_REQUIRE(tau_sum != nullptr, "lambertian_surface: null tau_sum");
   return lambertian_surface<float>(cvt_quad<float>(q), S, m, albedo, tau_sum, cvt_added<float>(added),

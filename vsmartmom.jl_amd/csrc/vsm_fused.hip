@@ -218,6 +218,18 @@ struct gl_operand_b {
         b[ks][t] = (col < N && k < N) ? Bg[k + (long long)N * col] : T(0);
       }
   }
+  // B = D Bg D (t-- from t++): sign (+) when row k and column have the same U/V parity
+  __device__ __forceinline__ void prefetch_dsym(const T* __restrict__ Bg, int N, int ns) {
+    const wave_pos<NP, NW> w;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < C::TMC; ++t) {
+        const int col = w.colB + 16 * t, k = 4 * ks + w.kq;
+        const T v = (col < N && k < N) ? Bg[k + (long long)N * col] : T(0);
+        b[ks][t] = (is_uv_row(k, ns) == is_uv_row(col, ns)) ? v : -v;
+      }
+  }
   __device__ __forceinline__ void run(acc_block<T, NP, NW>& acc, const T* A) const {  // acc += A * B
     const wave_pos<NP, NW> w;
     T af[2][C::TMR];
@@ -290,6 +302,14 @@ struct flat_regs {
     for (int c = 0; c < CNT; ++c) {
       const int e = threadIdx.x + C::NT * c;
       v[c] = (e < N * N) ? src[e] : T(0);
+    }
+  }
+  __device__ __forceinline__ void load_dsym(const T* __restrict__ src, int N, int ns) {  // D src D
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = threadIdx.x + C::NT * c;
+      const T x = (e < N * N) ? src[e] : T(0);
+      v[c] = (is_uv_row(e % N, ns) == is_uv_row(e / N, ns)) ? x : -x;
     }
   }
   // dst[e] = v[e] + L(e)   (L swizzled LDS)
@@ -689,8 +709,10 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
     if (ndoubl >= 1 && ui) r = -r;
     g_rmp[e] = r;
     g_tpp[e] = t;
-    g_rpm[e] = (ui == uj) ? r : -r;
-    g_tmm[e] = (ui == uj) ? t : -t;
+    if (!out.d_symmetric) {
+      g_rpm[e] = (ui == uj) ? r : -r;
+      g_tmm[e] = (ui == uj) ? t : -t;
+    }
   }
   if (tid < N) {
     T vjm = jm[tid];
@@ -746,7 +768,7 @@ __global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c
     s1.load(R_pm, N);
     s2.load(r_mp, N);
     oldRmp.load(R_mp, N);
-    addrpm.load(r_pm, N);
+    if (a.d_symmetric) addrpm.load_dsym(r_mp, N, a.d_symmetric); else addrpm.load(r_pm, N);
     if (tid < NP) {
       const bool in = tid < N;
       vJp[tid] = in ? J0_p[tid] : T(0);
@@ -796,7 +818,7 @@ __global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c
   VSM_STAMP(12);  // matvec J0-, T01 r
   acc.zero();
   opB.run(acc, L3);
-  opB.prefetch(t_mm, N);
+  if (a.d_symmetric) opB.prefetch_dsym(t_pp, N, a.d_symmetric); else opB.prefetch(t_mm, N);
   __syncthreads();  // everybody finished reading L3 (as A operand)
   acc_store<T, NP, NW>(L3, acc, [](T x, int, int, T) { return x; });
   __syncthreads();
@@ -839,7 +861,7 @@ __global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c
   acc_block<T, NP, NW> acc2;
   acc.zero();
   opB.run(acc, L4);
-  opB.prefetch(t_mm, N);
+  if (a.d_symmetric) opB.prefetch_dsym(t_pp, N, a.d_symmetric); else opB.prefetch(t_mm, N);
   acc2.zero();
   mm_ll<T, NP, NW>(acc2, L4, L1, Kend);
   acc_store<T, NP, NW>(L3, acc2, [](T x, int, int, T) { return x; });  // tmp -> L3

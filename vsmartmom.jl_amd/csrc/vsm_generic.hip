@@ -322,13 +322,33 @@ int noscat_layer(const quad<T>& q, int S, const T* tau, const added<T>& a, hipSt
   return VSM_OK;
 }
 
+// dst = D src D  (r+- from r-+, t-- from t++; doubling.jl:178-201)
+template <typename T>
+__global__ void k_copy_dsym(int N, int ns, const T* __restrict__ src, long long ss, T* dst) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int s = blockIdx.y;
+  const T x = src[(long long)s * ss + e];
+  dst[(long long)s * N * N + e] = (is_uv_row(e % N, ns) == is_uv_row(e / N, ns)) ? x : -x;
+}
 template <typename T>
 int copy_added_to_composite(int N, int S, const added<T>& a, const composite<T>& c, hipStream_t st) {
   const long long NN = (long long)N * N;
   int rc;
   if ((rc = copy_strided<T>(NN, S, a.t_pp, a.mat_stride, c.T_pp, st))) return rc;
-  if ((rc = copy_strided<T>(NN, S, a.t_mm, a.mat_stride, c.T_mm, st))) return rc;
   if ((rc = copy_strided<T>(NN, S, a.r_mp, a.mat_stride, c.R_mp, st))) return rc;
+  if (a.d_symmetric) {
+    if (S > 0) {
+      dim3 grid((unsigned)((NN + 255) / 256), S);
+      hipLaunchKernelGGL(k_copy_dsym<T>, grid, dim3(256), 0, st, N, a.d_symmetric, a.t_pp, a.mat_stride, c.T_mm);
+      hipLaunchKernelGGL(k_copy_dsym<T>, grid, dim3(256), 0, st, N, a.d_symmetric, a.r_mp, a.mat_stride, c.R_pm);
+      VSM_LAUNCH_CHECK("k_copy_dsym");
+    }
+    if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_p, 0, c.J0_p, st))) return rc;
+    if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_m, 0, c.J0_m, st))) return rc;
+    return VSM_OK;
+  }
+  if ((rc = copy_strided<T>(NN, S, a.t_mm, a.mat_stride, c.T_mm, st))) return rc;
   if ((rc = copy_strided<T>(NN, S, a.r_pm, a.mat_stride, c.R_pm, st))) return rc;
   if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_p, 0, c.J0_p, st))) return rc;
   if ((rc = copy_strided<T>((long long)N * S, 1, a.j0_m, 0, c.J0_m, st))) return rc;

@@ -18,6 +18,7 @@ template <typename T>
 struct added {
   T *r_mp, *t_pp, *r_pm, *t_mm, *j0_p, *j0_m;
   long long mat_stride;
+  int d_symmetric;  // 0, or nStokes: r+-/t-- derived by D-symmetry, never touched
 };
 template <typename T>
 struct composite {
