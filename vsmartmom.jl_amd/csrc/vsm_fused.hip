@@ -250,6 +250,29 @@ struct gl_operand_b {
 };
 
 // dst(row,col) = f(acc(row,col), row, col, old) for every accumulator element of this wave.
+// The swizzled element offsets are loop invariant: built once per kernel (acc_map) and reused by every
+// store of the layer step.
+template <int NP, int NW>
+struct acc_map {
+  using C = fcfg<NP, NW>;
+  int ix[C::TMR][C::TMC][4];
+  int r0, c0, lane;
+  __device__ __forceinline__ acc_map() {
+    lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    r0 = 16 * ((wave / C::WC) * C::TMR);
+    c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
+  }
+  template <typename T>
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+      for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ix[a][b][r] = lidx<NP>(r0 + 16 * a + mfma<T>::crow(lane, r), c0 + 16 * b);
+  }
+};
 template <typename T, int NP, int NW, typename F>
 __device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP, NW>& acc, F f) {
   using C = fcfg<NP, NW>;
@@ -264,6 +287,21 @@ __device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP, NW>& ac
         const int row = r0 + 16 * a + mfma<T>::crow(lane, r);
         const int col = c0 + 16 * b;
         const int ix = lidx<NP>(row, col);
+        dst[ix] = f(acc.v[a][b][r], row, col, dst[ix]);
+      }
+}
+template <typename T, int NP, int NW, typename F>
+__device__ __forceinline__ void acc_store(T* dst, const acc_block<T, NP, NW>& acc, const acc_map<NP, NW>& m, F f) {
+  using C = fcfg<NP, NW>;
+#pragma unroll
+  for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m.r0 + 16 * a + mfma<T>::crow(m.lane, r);
+        const int col = m.c0 + 16 * b;
+        const int ix = m.ix[a][b][r];
         dst[ix] = f(acc.v[a][b][r], row, col, dst[ix]);
       }
 }
@@ -425,7 +463,14 @@ __device__ __noinline__ void gj_lds(T* V, int N, gj_scratch<T, NP>* sc) {
 // thread may read V.  Precondition: nobody is still reading V or W.
 template <typename T, int NP, int NW>
 __device__ __forceinline__ int invert_one_minus(acc_block<T, NP, NW>& acc, T* V, T* W, int N, int Kend,
-                                                fsmem<T, NP, NW>& sm, int& slot, int mode) {
+                                                fsmem<T, NP, NW>& sm, int& slot, int mode,
+                                                const acc_map<NP, NW>* mp = nullptr) {
+  acc_map<NP, NW> local_map;
+  if (!mp) {
+    local_map.template init<T>();
+    mp = &local_map;
+  }
+  const acc_map<NP, NW>& amap = *mp;
   const T nrm = acc_norm_bound<T, NP, NW>(acc, N, sm, slot);
   const T tol = num<T>::eps() * T(0.25);
   int K = 0;
@@ -446,12 +491,12 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP, NW>& acc, T* V,
   if (mode == 2 && K == 0) K = 31;
   auto keep = [N](T a, int r, int c) { return (r < N && c < N) ? a : T(0); };
   if (K > 0) {
-    acc_store<T, NP, NW>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? keep(a, r, c) + T(1) : keep(a, r, c); });
+    acc_store<T, NP, NW>(V, acc, amap, [=](T a, int r, int c, T) { return (r == c) ? keep(a, r, c) + T(1) : keep(a, r, c); });
     if (K == 1) {
       __syncthreads();
       return 2;
     }
-    acc_store<T, NP, NW>(W, acc, [=](T a, int r, int c, T) { return keep(a, r, c); });
+    acc_store<T, NP, NW>(W, acc, amap, [=](T a, int r, int c, T) { return keep(a, r, c); });
     __syncthreads();
     int cur = 1;  // W = E^cur, V = sum_{k < 2 cur} E^k
     for (;;) {
@@ -459,23 +504,23 @@ __device__ __forceinline__ int invert_one_minus(acc_block<T, NP, NW>& acc, T* V,
       mm_ll<T, NP, NW>(acc, W, W, Kend);  // E^(2 cur)
       cur *= 2;
       if (K == cur) {  // close with "+ E^cur"
-        acc_store<T, NP, NW>(V, acc, [](T a, int, int, T old) { return old + a; });
+        acc_store<T, NP, NW>(V, acc, amap, [](T a, int, int, T old) { return old + a; });
         __syncthreads();
         break;
       }
       __syncthreads();
-      acc_store<T, NP, NW>(W, acc, [](T a, int, int, T) { return a; });
+      acc_store<T, NP, NW>(W, acc, amap, [](T a, int, int, T) { return a; });
       __syncthreads();
       acc.zero();
       mm_ll<T, NP, NW>(acc, V, W, Kend);  // V * E^cur
       __syncthreads();
-      acc_store<T, NP, NW>(V, acc, [](T a, int, int, T old) { return old + a; });
+      acc_store<T, NP, NW>(V, acc, amap, [](T a, int, int, T old) { return old + a; });
       __syncthreads();
       if (K == 2 * cur - 1) break;
     }
     return 1 + K;
   }
-  acc_store<T, NP, NW>(V, acc, [=](T a, int r, int c, T) { return (r == c) ? T(1) - keep(a, r, c) : -keep(a, r, c); });
+  acc_store<T, NP, NW>(V, acc, amap, [=](T a, int r, int c, T) { return (r == c) ? T(1) - keep(a, r, c) : -keep(a, r, c); });
   __syncthreads();
   gj_lds<T, NP, NW>(V, N, &sm.gj);
   return 1;
@@ -540,6 +585,7 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
   T* xa = sm.vec[8];   // spare-column path: tt*j0+
   T* xb = sm.vec[9];   //                    tt*j1-
 
+  VSM_STAMP_DECL;
   const int s = blockIdx.x;
   const int N = q.N, ns = q.n_stokes;
   const int tid = threadIdx.x;
@@ -560,30 +606,60 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
   __syncthreads();
 
   // ---- elemental (elemental.jl:289-334) -------------------------------------
-  for (int e = tid; e < NP * NP; e += C::NT) {
-    const int i = e % NP, j = e / NP;
-    T r = T(0), t = T(0);
-    if (i < N && j < N) {
-      const T mi = mus[i], mj = mus[j], wct = wcs[j];
-      const long long zo = i + (long long)N * j;
-      if (wct > num<T>::eps()) {
-        r = w * Zm[zo] * (mj / (mi + mj)) * wct * (-expm1(-d * ((T(1) / mi) + (T(1) / mj))));
-        if (mi == mj) {
-          if (i == j)
-            t = exp(-d / mi) * (T(1) + w * Zp[zo] * (d / mi) * wct);
-          else
-            t = exp(-d / mj) * (w * Zp[zo] * (d / mi) * wct);
-        } else {
-          t = w * Zp[zo] * (mj / (mi - mj)) * wct * expdiff_neg<T>(d / mi, d / mj);
-        }
-      } else {
-        t = (i == j) ? exp(-d / mi) : T(0);
-      }
-      if (ndoubl >= 1 && is_uv_row(i, ns)) r = -r;  // starred R* = D R (apply_D_elemental!, elemental.jl:403-422)
+  // Per-stream factors once per workgroup: x_i = dtau/mu_i, e_i = exp(-x_i), em_i = expm1(-x_i).
+  // Then   -expm1(-(x_i+x_j)) = -(em_i + em_j + em_i em_j)        (exact identity, no cancellation)
+  //        exp(-x_i)-exp(-x_j) = em_i - em_j  when the arguments are small and well separated
+  //                              (relative error <= 16 eps), else the reference's expdiff_neg.
+  T* xs = j1p;   // these three vectors are not used before the doubling loop
+  T* es = j1m;
+  T* ems = uu;
+  if (tid < NP) {
+    const T x = d / mus[tid];
+    xs[tid] = x;
+    es[tid] = exp(-x);
+    ems[tid] = expm1(-x);
+  }
+  __syncthreads();
+  {
+    constexpr int CNT = NP * NP / C::NT;
+    T zp[CNT], zm[CNT];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {  // raw loads from clamped addresses: all in flight together
+      const int e = tid + C::NT * c;
+      const long long zo = min(e % NP, N - 1) + (long long)N * min(e / NP, N - 1);
+      zp[c] = Zp[zo];
+      zm[c] = Zm[zo];
     }
-    const int ix = lidx<NP>(i, j);
-    R[ix] = r;
-    Tm[ix] = t;
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+      const int e = tid + C::NT * c;
+      const int i = e % NP, j = e / NP;
+      T r = T(0), t = T(0);
+      if (i < N && j < N) {
+        const T mi = mus[i], mj = mus[j], wct = wcs[j];
+        const T xi = xs[i], xj = xs[j];
+        if (wct > num<T>::eps()) {
+          const T emi = ems[i], emj = ems[j];
+          r = w * zm[c] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
+          if (mi == mj) {
+            if (i == j)
+              t = es[i] * (T(1) + w * zp[c] * xi * wct);
+            else
+              t = es[j] * (w * zp[c] * xi * wct);
+          } else {
+            const T xm = fmax(xi, xj);
+            const T ediff = (xm < T(0.5) && fabs(xi - xj) > T(0.125) * xm) ? (emi - emj) : expdiff_neg<T>(xi, xj);
+            t = w * zp[c] * (mj / (mi - mj)) * wct * ediff;
+          }
+        } else {
+          t = (i == j) ? es[i] : T(0);
+        }
+        if (ndoubl >= 1 && is_uv_row(i, ns)) r = -r;  // starred R* = D R (apply_D_elemental!, elemental.jl:403-422)
+      }
+      const int ix = lidx<NP>(i, j);
+      R[ix] = r;
+      Tm[ix] = t;
+    }
   }
   // ---- SFI source (elemental.jl:348-392) ---------------------------------------
   if (tid < NP) {
@@ -619,19 +695,20 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
   T expk = exp(-d / q.mu0);
   int slot = 0;
   acc_block<T, NP, NW> acc, acc2;
-  VSM_STAMP_DECL;
+  acc_map<NP, NW> amap;
+  amap.template init<T>();
   VSM_STAMP(0);  // elemental
   for (int n = 0; n < ndoubl; ++n) {
     // G = (I - r r)^-1  -> V
     acc.zero();
     mm_ll<T, NP, NW>(acc, R, R, Kend);
     VSM_STAMP(1);  // r*r
-    invert_one_minus<T, NP, NW>(acc, V, W, N, Kend, sm, slot, 0);
+    invert_one_minus<T, NP, NW>(acc, V, W, N, Kend, sm, slot, 0, &amap);
     VSM_STAMP(2);  // inverse
     // tt = t G -> W   (W is free: its readers finished before the barrier that ended the inverse)
     acc.zero();
     mm_ll<T, NP, NW>(acc, Tm, V, Kend);
-    acc_store<T, NP, NW>(W, acc, [](T a, int, int, T) { return a; });
+    acc_store<T, NP, NW>(W, acc, amap, [](T a, int, int, T) { return a; });
     if (tid < NP) {
       const T a1 = jp[tid] * expk, a2 = jm[tid] * expk;
       j1p[tid] = a1;
@@ -662,7 +739,7 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
     // tmp = tt r -> V
     acc.zero();
     mm_ll<T, NP, NW>(acc, W, R, Kend);
-    acc_store<T, NP, NW>(V, acc, [](T a, int, int, T) { return a; });
+    acc_store<T, NP, NW>(V, acc, amap, [](T a, int, int, T) { return a; });
     __syncthreads();
     VSM_STAMP(4);  // (matvec +) tmp = tt r + store + barrier
     // r <- r + tmp t ; t <- tt t   (+ columns c1,c2: tmp*j0+, tmp*j1-, tt*j0+, tt*j1-)
@@ -671,13 +748,13 @@ __global__ __launch_bounds__(64 * NW) void k_elemental_doubling(
     mm_ll2<T, NP, NW>(acc, acc2, V, W, Tm, Kend);
     VSM_STAMP(5);  // two products
     // r is not an operand of this product: update it right away
-    acc_store<T, NP, NW>(R, acc, [=](T a, int r, int c, T old) {
+    acc_store<T, NP, NW>(R, acc, amap, [=](T a, int r, int c, T old) {
       if (spare && c == c1) uu[r] = a;
       if (spare && c == c2) vv[r] = a;
       return (c < N) ? old + a : T(0);
     });
     __syncthreads();  // everybody finished reading t
-    acc_store<T, NP, NW>(Tm, acc2, [=](T a, int r, int c, T) {
+    acc_store<T, NP, NW>(Tm, acc2, amap, [=](T a, int r, int c, T) {
       if (spare && c == c1) xa[r] = a;
       if (spare && c == c2) xb[r] = a;
       return (c < N) ? a : T(0);
