@@ -208,6 +208,84 @@ int vsm_postprocess_vza_f32(int N, int n_stokes, int S, int nV, const int* row0_
                             const float* w_h, const float* J0_m, const float* J0_p,
                             float* R, float* T, void* stream);
 
+/* ---- linearized (Jacobian) pass: rt_run(model, lin_model, NAer, NGas, NSurf) ----------------------
+ * Derivative stacks follow the reference's layout [N,N,S,P] / [N,1,S,P] (parameter axis slowest;
+ * src/CoreRT/types_lin.jl:20-97 AddedLayerLin `ap_*` fields / CompositeLayerLin). */
+typedef struct vsm_added_lin_f64 {
+  double *ap_r_mp, *ap_t_pp, *ap_r_pm, *ap_t_mm;  /* ap_ṙ⁻⁺ ap_ṫ⁺⁺ ap_ṙ⁺⁻ ap_ṫ⁻⁻ */
+  double *ap_J0_p, *ap_J0_m;                      /* ap_J̇₀⁺ ap_J̇₀⁻ */
+  int P;                                          /* Nparams */
+  int reserved;
+  long long mat_stride;                           /* N*N, or 0: one block per parameter shared by all S */
+} vsm_added_lin_f64;
+typedef struct vsm_added_lin_f32 {
+  float *ap_r_mp, *ap_t_pp, *ap_r_pm, *ap_t_mm;
+  float *ap_J0_p, *ap_J0_m;
+  int P;
+  int reserved;
+  long long mat_stride;
+} vsm_added_lin_f32;
+typedef struct vsm_composite_lin_f64 {
+  double *R_mp, *R_pm, *T_pp, *T_mm, *J0_p, *J0_m;  /* Ṙ⁻⁺ Ṙ⁺⁻ Ṫ⁺⁺ Ṫ⁻⁻ J̇₀⁺ J̇₀⁻ */
+  int P;
+  int reserved;
+} vsm_composite_lin_f64;
+typedef struct vsm_composite_lin_f32 {
+  float *R_mp, *R_pm, *T_pp, *T_mm, *J0_p, *J0_m;
+  int P;
+  int reserved;
+} vsm_composite_lin_f32;
+
+/* elemental! (lin) = get_elem_rt_fused! + get_elem_rt_SFI_fused! (elemental_lin.jl:77-206,456-712): forward
+ * r,t,j AND the chain rule to the first p_layer parameter slots.  dtau_dot[S,p_layer] = τ̇/2^ndoubl,
+ * varpi_dot[S,p_layer], tau_sum_dot[S,p_layer]; Zpp_dot/Zmp_dot (nullable = 0): element (i,j,s,p) at
+ * i + N*j + s*zd_stride_s + p*zd_stride_p.  All P slots of added_lin are zeroed first. */
+int vsm_elemental_lin_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                          const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp,
+                          long long z_stride, int p_layer, const double* dtau_dot, const double* varpi_dot,
+                          const double* tau_sum_dot, const double* Zpp_dot, const double* Zmp_dot,
+                          long long zd_stride_s, long long zd_stride_p, const vsm_added_f64* added,
+                          const vsm_added_lin_f64* added_lin, void* stream);
+int vsm_elemental_lin_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                          const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp,
+                          long long z_stride, int p_layer, const float* dtau_dot, const float* varpi_dot,
+                          const float* tau_sum_dot, const float* Zpp_dot, const float* Zmp_dot,
+                          long long zd_stride_s, long long zd_stride_p, const vsm_added_f32* added,
+                          const vsm_added_lin_f32* added_lin, void* stream);
+/* doubling_allparams! (doubling_lin.jl:216-339): forward + the first n_active parameter slots; the D-symmetry at
+ * the end covers all P slots.  dtau_dot_all[S,P] (zero beyond the layer parameters); expk[S] updated in place. */
+size_t vsm_doubling_lin_work_elems(int N, int S, int P);
+int vsm_doubling_lin_f64(int N, int n_stokes, int S, int ndoubl, double* expk, const double* dtau_dot_all, double mu0,
+                         int n_active, const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, double* work,
+                         void* stream);
+int vsm_doubling_lin_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const float* dtau_dot_all, float mu0,
+                         int n_active, const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, float* work,
+                         void* stream);
+/* interaction! (lin), ScatteringInterface_11 (interaction_lin.jl:217-331); forward composite updated as well. */
+size_t vsm_interaction_lin_work_elems(int N, int S, int P);
+int vsm_interaction_lin_f64(int iface, int N, int S, const vsm_composite_f64* comp, const vsm_composite_lin_f64* comp_lin,
+                            const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, double* work, void* stream);
+int vsm_interaction_lin_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_composite_lin_f32* comp_lin,
+                            const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, float* work, void* stream);
+/* TOA copy of the derivative stacks (rt_kernel_lin.jl:148-166). */
+int vsm_copy_added_to_composite_lin_f64(int N, int S, const vsm_added_lin_f64* added_lin,
+                                        const vsm_composite_lin_f64* comp_lin, void* stream);
+int vsm_copy_added_to_composite_lin_f32(int N, int S, const vsm_added_lin_f32* added_lin,
+                                        const vsm_composite_lin_f32* comp_lin, void* stream);
+/* create_surface_layer! (lin, LambertianSurfaceScalar; lambertian_surface_lin.jl:48-162).  iparam = slot of the
+ * albedo (0-based); shared blocks (mat_stride 0) for the matrices of `added` and `added_lin`. */
+int vsm_lambertian_surface_lin_f64(const vsm_quad_f64* q, int S, int m, double albedo, int iparam, const double* tau_sum,
+                                   const double* tau_sum_dot, int p_layer, const double* F0, const vsm_added_f64* added,
+                                   const vsm_added_lin_f64* added_lin, void* stream);
+int vsm_lambertian_surface_lin_f32(const vsm_quad_f32* q, int S, int m, float albedo, int iparam, const float* tau_sum,
+                                   const float* tau_sum_dot, int p_layer, const float* F0, const vsm_added_f32* added,
+                                   const vsm_added_lin_f32* added_lin, void* stream);
+/* postprocessing_vza! (lin) (postprocessing_vza_lin.jl:18-48): Rdot/Tdot [nV,n_stokes,S,P] += w * Jdot0∓. */
+int vsm_postprocess_vza_lin_f64(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const double* w_h,
+                                const double* Jdot0_m, const double* Jdot0_p, double* Rdot, double* Tdot, void* stream);
+int vsm_postprocess_vza_lin_f32(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const float* w_h,
+                                const float* Jdot0_m, const float* Jdot0_p, float* Rdot, float* Tdot, void* stream);
+
 /* ---- diagnostics used by the parity tests -------------------------------- */
 /* Runs the LDS-resident MFMA tile product used inside the fused kernels on plain
  * [N,N,S] inputs: C = A*B.  (Checks fragment layouts / swizzle independently.) */

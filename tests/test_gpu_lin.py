@@ -1,0 +1,180 @@
+"""GPU parity of the linearized (Jacobian) pass vs the linearized oracle (itself validated against finite
+differences, tests/test_oracle_lin.py).  Tolerance FP64 1e-9 relative to each array's max magnitude."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vsm_oracle as O
+from oracle import vsm_oracle_lin as OL
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def vsm():
+    import vsmartmom_jl_amd as v
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    v._lib.lib()
+    return v
+
+
+@pytest.fixture(scope="module")
+def arch(vsm):
+    return vsm.Architectures.GPU()
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _layer(pol_name, l_trunc, FT, S=4, P=3, seed=1):
+    rng = np.random.default_rng(seed)
+    pol = O.polarization(pol_name)
+    qp = O.rt_set_streams_gausslegquad(l_trunc, 40.0, [30.0, 0.0], pol, FT)
+    N = qp.Nquad * pol.n
+    mu = qp.qp_mu.astype(np.float64)
+    tau = 0.02 + 0.1 * rng.random(S) + 10.0 ** rng.uniform(-3, 0, S)
+    varpi = rng.uniform(0.2, 1.0, S)
+    Zpp, Zmp = O.compute_Z_moments(pol, mu, O.get_greek_rayleigh(0.0279), 0)
+    lin = OL.LayerOpticsLin(rng.standard_normal((S, P)) * tau[:, None], rng.standard_normal((S, P)) * 0.1,
+                            0.3 * rng.standard_normal((P, S, N, N)), 0.3 * rng.standard_normal((P, S, N, N)))
+    return pol, qp, N, tau.astype(FT), varpi.astype(FT), Zpp, Zmp, lin, rng
+
+
+def _dev(vsm, arch, FT, qp, pol):
+    H = vsm.host_model
+    hq = H.QuadPoints(qp.mu0, qp.imu0, qp.qp_mu, qp.wt_mu, qp.qp_muN, qp.wt_muN, qp.Nquad, qp.Nstreams)
+    hpol = H.polarization_type(pol.name)
+    return vsm.CoreRT.device_quad(hq, hpol, arch, FT), hpol
+
+
+def _al_host(vsm, al):
+    f = lambda t: vsm.Architectures.to_host(t).transpose(0, 1, 3, 2)
+    h = vsm.Architectures.to_host
+    return dict(ap_r_mp=f(al.ap_r_mp), ap_t_pp=f(al.ap_t_pp), ap_r_pm=f(al.ap_r_pm), ap_t_mm=f(al.ap_t_mm),
+                ap_J0_p=h(al.ap_J0_p), ap_J0_m=h(al.ap_J0_m))
+
+
+@pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7)])
+@pytest.mark.parametrize("ndoubl", [0, 3])
+def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl):
+    FT = np.float64
+    pol, qp, N, tau, varpi, Zpp, Zmp, lin, rng = _layer(pol_name, l_trunc, FT)
+    S, P_layer = len(tau), lin.tau_dot.shape[1]
+    P = P_layer + 1
+    dtau = (tau / 2 ** ndoubl).astype(FT)
+    tau_sum = rng.random(S)
+    tsd = rng.standard_normal((S, P_layer)) * 0.1
+    F0 = np.zeros((pol.n, S))
+    F0[0] = 1.0
+    if pol.n > 1:
+        F0[1] = 0.2
+    oa, oal = O.make_added_layer(FT, N, S), OL.make_added_layer_lin(FT, P, N, S)
+    OL.elemental_lin(pol, tau_sum, tsd, dtau, F0, varpi, Zpp, Zmp, lin, 0, ndoubl, qp, oa, oal, FT)
+    dq, hpol = _dev(vsm, arch, FT, qp, pol)
+    CR, CL = vsm.CoreRT, vsm.CoreRTLin
+    conv = vsm.Architectures.array_type(arch)
+    props = CR.expandOpticalProperties(vsm.host_model.CoreScatteringOpticalProperties(tau, varpi, Zpp, Zmp), arch, FT)
+    pa, pal = CR.AddedLayer(FT, arch, N, S), CL.AddedLayerLin(FT, arch, P, N, S)
+    zpd, zs_, zp_ = CL.to_device_zdot(lin.Zpp_dot, arch, FT)
+    zmd, _, _ = CL.to_device_zdot(lin.Zmp_dot, arch, FT)
+    dtd = lin.tau_dot / 2 ** ndoubl
+    CL.elemental_lin_(hpol, conv(tau_sum), CL.to_device_sp(tsd, arch, FT), conv(dtau), CL.to_device_sp(dtd, arch, FT),
+                      conv(np.ascontiguousarray(F0.T)), props, CL.to_device_sp(lin.varpi_dot, arch, FT), zpd, zmd,
+                      (zs_, zp_), P_layer, 0, ndoubl, dq, pa, pal)
+    got = _al_host(vsm, pal)
+    keys = ["ap_r_mp", "ap_t_pp", "ap_J0_p", "ap_J0_m"] + (["ap_r_pm", "ap_t_mm"] if ndoubl == 0 else [])
+    for k in keys:
+        assert _rel(got[k], getattr(oal, k)) < 1e-11, ("elemental_lin", k)
+    assert _rel(vsm.CoreRT.from_device_matrix(pa.r_mp), oa.r_mp) < 1e-12
+    if ndoubl == 0:
+        return
+    # doubling, all parameters
+    expk = np.exp(-dtau / qp.mu0)
+    dall = np.zeros((S, P))
+    dall[:, :P_layer] = dtd
+    OL.doubling_lin(pol, expk, ndoubl, oa, oal, dall, qp.mu0, P_layer, FT)
+    CL.doubling_allparams_(hpol, conv(expk), ndoubl, pa, pal, CL.to_device_sp(dall, arch, FT), qp.mu0, P_layer)
+    got = _al_host(vsm, pal)
+    for k in got:
+        assert _rel(got[k], getattr(oal, k)) < 1e-9, ("doubling_lin", k)
+    for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+        assert _rel(vsm.CoreRT.from_device_matrix(getattr(pa, k)), getattr(oa, k)) < 1e-10, k
+    assert _rel(vsm.Architectures.to_host(pa.j0_m), oa.j0_m) < 1e-10
+
+
+@pytest.mark.parametrize("N,shared", [(12, False), (60, False), (36, True)])
+def test_interaction_lin(vsm, arch, N, shared):
+    FT = np.float64
+    rng = np.random.default_rng(3)
+    S, P = 3, 3
+    refl = lambda sc, lead=(S,): (sc * rng.random(lead + (N, N)) / N).astype(FT)
+    trans = lambda lead=(S,): (np.eye(N) * rng.uniform(0.3, 0.95, lead + (N, 1)) + 0.05 * rng.random(lead + (N, N)) / N).astype(FT)
+    comp = O.CompositeLayer(refl(1.5), refl(1.5), trans(), trans(), rng.random((S, N)), rng.random((S, N)))
+    add = O.AddedLayer(refl(1.0), trans(), refl(1.0), trans(), rng.random((S, N)), rng.random((S, N)))
+    cl = OL.CompositeLayerLin(*(0.1 * rng.standard_normal((P, S, N, N)) for _ in range(4)),
+                              0.1 * rng.standard_normal((P, S, N)), 0.1 * rng.standard_normal((P, S, N)))
+    al = OL.AddedLayerLin(*(0.1 * rng.standard_normal((P, S, N, N)) for _ in range(4)),
+                          0.1 * rng.standard_normal((P, S, N)), 0.1 * rng.standard_normal((P, S, N)))
+    if shared:
+        for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+            getattr(add, k)[...] = getattr(add, k)[:1]
+        for k in ("ap_r_mp", "ap_t_pp", "ap_r_pm", "ap_t_mm"):
+            getattr(al, k)[...] = getattr(al, k)[:, :1]
+    CR, CL = vsm.CoreRT, vsm.CoreRTLin
+    conv_v = vsm.Architectures.array_type(arch)
+    cm = lambda x: CR.to_device_matrix(x, arch, FT)
+    pc, pa = CR.CompositeLayer(FT, arch, N, S), CR.AddedLayer(FT, arch, N, S, shared=shared)
+    pcl, pal = CL.CompositeLayerLin(FT, arch, P, N, S), CL.AddedLayerLin(FT, arch, P, N, S, shared=shared)
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        getattr(pc, k).copy_(cm(getattr(comp, k)))
+        getattr(pcl, k).copy_(conv_v(np.ascontiguousarray(getattr(cl, k).transpose(0, 1, 3, 2))))
+    for k in ("J0_p", "J0_m"):
+        getattr(pc, k).copy_(conv_v(getattr(comp, k)))
+        getattr(pcl, k).copy_(conv_v(getattr(cl, k)))
+    for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+        src = getattr(add, k)
+        getattr(pa, k).copy_(cm(src[:1] if shared else src))
+        srcl = getattr(al, "ap_" + k)
+        getattr(pal, "ap_" + k).copy_(conv_v(np.ascontiguousarray((srcl[:, :1] if shared else srcl).transpose(0, 1, 3, 2))))
+    pa.j0_p.copy_(conv_v(add.j0_p)); pa.j0_m.copy_(conv_v(add.j0_m))
+    pal.ap_J0_p.copy_(conv_v(al.ap_J0_p)); pal.ap_J0_m.copy_(conv_v(al.ap_J0_m))
+    OL.interaction_lin("11", comp, cl, add, al, FT)
+    CL.interaction_lin_("11", pc, pcl, pa, pal)
+    f4 = lambda t: vsm.Architectures.to_host(t).transpose(0, 1, 3, 2)
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        assert _rel(CR.from_device_matrix(getattr(pc, k)), getattr(comp, k)) < 1e-10, k
+        assert _rel(f4(getattr(pcl, k)), getattr(cl, k)) < 1e-9, "d" + k
+    for k in ("J0_p", "J0_m"):
+        assert _rel(vsm.Architectures.to_host(getattr(pc, k)), getattr(comp, k)) < 1e-10, k
+        assert _rel(vsm.Architectures.to_host(getattr(pcl, k)), getattr(cl, k)) < 1e-9, "d" + k
+
+
+@pytest.mark.parametrize("pol", ["I", "IQU"])
+def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol):
+    """rt_run(model, lin_model, 0, NGas, 1): R, T and the Jacobians vs the oracle; the albedo Jacobian also vs a
+    finite difference of the device forward run (the reference's own check: test_jacobians_unit.jl:105-123)."""
+    rng = np.random.default_rng(0)
+    S, L = 3, 3
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))
+    ga, gb = 10.0 ** rng.uniform(-2.5, -0.5, (S, L)), 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    H = vsm.host_model
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga + gb, depol=0.0279, m_max=2)
+    om = O.build_model(pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    pm = H.model_from_arrays(arch, pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga, gb]))
+    R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga, gb]), 0, 2, 1)
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9
+    for p in range(3):
+        assert _rel(Rd[..., p], Rdo[..., p]) < 1e-8, p
+        assert _rel(Td[..., p], Tdo[..., p]) < 1e-8, p
+    h = 1e-4
+    Rp, _ = vsm.CoreRT.rt_run(H.model_from_arrays(arch, pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2 + h, **kw))
+    R0, _ = vsm.CoreRT.rt_run(pm)
+    fd = (Rp - R0) / h
+    err = np.abs(fd - Rd[..., 2]) / np.abs(fd).max()
+    assert err.max() < 1e-3 and err.mean() < 1e-4

@@ -38,6 +38,17 @@ class vsm_composite(C.Structure):
                 ("J0_p", C.c_void_p), ("J0_m", C.c_void_p)]
 
 
+class vsm_added_lin(C.Structure):
+    _fields_ = [("ap_r_mp", C.c_void_p), ("ap_t_pp", C.c_void_p), ("ap_r_pm", C.c_void_p), ("ap_t_mm", C.c_void_p),
+                ("ap_J0_p", C.c_void_p), ("ap_J0_m", C.c_void_p), ("P", C.c_int), ("reserved", C.c_int),
+                ("mat_stride", C.c_longlong)]
+
+
+class vsm_composite_lin(C.Structure):
+    _fields_ = [("R_mp", C.c_void_p), ("R_pm", C.c_void_p), ("T_pp", C.c_void_p), ("T_mm", C.c_void_p),
+                ("J0_p", C.c_void_p), ("J0_m", C.c_void_p), ("P", C.c_int), ("reserved", C.c_int)]
+
+
 _P, _I, _LL, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
 
 # name -> (restype, argtypes); {T} expands to f64/f32, {R} to c_double/c_float
@@ -61,6 +72,14 @@ _SIGS = {
     "vsm_interaction_oplevel_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "vsm_lambertian_surface_{T}": (_I, [_P, _I, _I, "{R}", _P, _P, _P]),
     "vsm_postprocess_vza_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_doubling_lin_work_elems": (_SZ, [_I, _I, _I]),
+    "vsm_interaction_lin_work_elems": (_SZ, [_I, _I, _I]),
+    "vsm_elemental_lin_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _P]),
+    "vsm_doubling_lin_{T}": (_I, [_I, _I, _I, _I, _P, _P, "{R}", _I, _P, _P, _P, _P]),
+    "vsm_interaction_lin_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_copy_added_to_composite_lin_{T}": (_I, [_I, _I, _P, _P, _P]),
+    "vsm_lambertian_surface_lin_{T}": (_I, [_P, _I, _I, "{R}", _I, _P, _P, _I, _P, _P, _P, _P]),
+    "vsm_postprocess_vza_lin_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_test_lds_mm_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_test_lds_inv_{T}": (_I, [_I, _I, _P, _P, _I, _P, _P]),
 }

@@ -369,3 +369,101 @@ int vsm_test_lds_inv_f32(int N, int S, const float* A, float* X, int mode, int* 
 }
 
 }  // extern "C"
+
+// ---- linearized pass ----------------------------------------------------------------
+namespace vsm {
+template <typename T, typename A>
+static added_lin<T> cvt_al(const A* a) {
+  added_lin<T> r;
+  r.ap_r_mp = a->ap_r_mp; r.ap_t_pp = a->ap_t_pp; r.ap_r_pm = a->ap_r_pm; r.ap_t_mm = a->ap_t_mm;
+  r.ap_J0_p = a->ap_J0_p; r.ap_J0_m = a->ap_J0_m; r.P = a->P; r.mat_stride = a->mat_stride;
+  return r;
+}
+template <typename T, typename C>
+static composite_lin<T> cvt_cl(const C* c) {
+  composite_lin<T> r;
+  r.R_mp = c->R_mp; r.R_pm = c->R_pm; r.T_pp = c->T_pp; r.T_mm = c->T_mm; r.J0_p = c->J0_p; r.J0_m = c->J0_m; r.P = c->P;
+  return r;
+}
+template <typename A>
+static int check_al(const A* a) {
+  VSM_REQUIRE(a != nullptr, "added_lin: null");
+  VSM_REQUIRE(a->ap_r_mp && a->ap_t_pp && a->ap_r_pm && a->ap_t_mm && a->ap_J0_p && a->ap_J0_m, "added_lin: null field");
+  VSM_REQUIRE(a->P >= 1 && a->P <= 64, "added_lin: bad P=%d", a->P);
+  return VSM_OK;
+}
+template <typename C>
+static int check_cl(const C* c) {
+  VSM_REQUIRE(c != nullptr, "composite_lin: null");
+  VSM_REQUIRE(c->R_mp && c->R_pm && c->T_pp && c->T_mm && c->J0_p && c->J0_m, "composite_lin: null field");
+  VSM_REQUIRE(c->P >= 1 && c->P <= 64, "composite_lin: bad P=%d", c->P);
+  return VSM_OK;
+}
+}  // namespace vsm
+
+#define VSM_LIN_API(T, SFX)                                                                                            \
+  int vsm_elemental_lin_##SFX(const vsm_quad_##SFX* q, int S, int m, int ndoubl, const T* dtau, const T* varpi,        \
+                              const T* tau_sum, const T* F0, const T* Zpp, const T* Zmp, long long z_stride,           \
+                              int p_layer, const T* dtau_dot, const T* varpi_dot, const T* tau_sum_dot,                \
+                              const T* Zpp_dot, const T* Zmp_dot, long long zds, long long zdp,                        \
+                              const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al, void* stream) {             \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q)) || (rc = check_added(added)) || (rc = check_al(al))) return rc;                           \
+    VSM_REQUIRE(added->d_symmetric == 0, "elemental_lin: d_symmetric layers are not accepted here");                   \
+    VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp && dtau_dot && varpi_dot && tau_sum_dot,                  \
+                "elemental_lin: null input");                                                                          \
+    VSM_REQUIRE(p_layer >= 0 && p_layer <= al->P && (!Zpp_dot == !Zmp_dot), "elemental_lin: bad p_layer / Zdot");      \
+    return elemental_lin<T>(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, p_layer,       \
+                            dtau_dot, varpi_dot, tau_sum_dot, Zpp_dot, Zmp_dot, zds, zdp, cvt_added<T>(added),         \
+                            cvt_al<T>(al), as_stream(stream));                                                         \
+  }                                                                                                                    \
+  int vsm_doubling_lin_##SFX(int N, int n_stokes, int S, int ndoubl, T* expk, const T* dtau_dot_all, T mu0,            \
+                             int n_active, const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al, T* work,       \
+                             void* stream) {                                                                           \
+    int rc;                                                                                                            \
+    if ((rc = check_added(added)) || (rc = check_al(al))) return rc;                                                   \
+    VSM_REQUIRE(added->d_symmetric == 0, "doubling_lin: d_symmetric layers are not accepted here");                    \
+    VSM_REQUIRE(N > 0 && N <= 128 && S >= 0 && ndoubl >= 0 && expk && dtau_dot_all && (work || ndoubl == 0) &&         \
+                    n_active >= 0 && n_active <= al->P, "doubling_lin: bad argument");                                 \
+    return doubling_lin<T>(N, n_stokes, S, ndoubl, expk, dtau_dot_all, mu0, n_active, cvt_added<T>(added),             \
+                           cvt_al<T>(al), work, as_stream(stream));                                                    \
+  }                                                                                                                    \
+  int vsm_interaction_lin_##SFX(int iface, int N, int S, const vsm_composite_##SFX* comp,                              \
+                                const vsm_composite_lin_##SFX* cl, const vsm_added_##SFX* added,                       \
+                                const vsm_added_lin_##SFX* al, T* work, void* stream) {                                \
+    int rc;                                                                                                            \
+    if ((rc = check_comp(comp)) || (rc = check_cl(cl)) || (rc = check_added(added)) || (rc = check_al(al))) return rc; \
+    VSM_REQUIRE(added->d_symmetric == 0, "interaction_lin: d_symmetric layers are not accepted here");                 \
+    VSM_REQUIRE(N > 0 && N <= 128 && S >= 0 && work && cl->P == al->P, "interaction_lin: bad argument");               \
+    return interaction_lin<T>(iface, N, S, cvt_comp<T>(comp), cvt_cl<T>(cl), cvt_added<T>(added), cvt_al<T>(al), work, \
+                              as_stream(stream));                                                                      \
+  }                                                                                                                    \
+  int vsm_copy_added_to_composite_lin_##SFX(int N, int S, const vsm_added_lin_##SFX* al,                               \
+                                            const vsm_composite_lin_##SFX* cl, void* stream) {                         \
+    int rc;                                                                                                            \
+    if ((rc = check_al(al)) || (rc = check_cl(cl))) return rc;                                                         \
+    VSM_REQUIRE(al->P == cl->P, "copy_added_to_composite_lin: P mismatch");                                            \
+    return copy_added_to_composite_lin<T>(N, S, cvt_al<T>(al), cvt_cl<T>(cl), as_stream(stream));                      \
+  }                                                                                                                    \
+  int vsm_lambertian_surface_lin_##SFX(const vsm_quad_##SFX* q, int S, int m, T albedo, int iparam, const T* tau_sum,  \
+                                       const T* tau_sum_dot, int p_layer, const T* F0, const vsm_added_##SFX* added,   \
+                                       const vsm_added_lin_##SFX* al, void* stream) {                                  \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q)) || (rc = check_added(added)) || (rc = check_al(al))) return rc;                           \
+    VSM_REQUIRE(tau_sum && F0 && (tau_sum_dot || p_layer == 0) && iparam >= 0 && iparam < al->P && p_layer <= al->P,   \
+                "lambertian_surface_lin: bad argument");                                                               \
+    return lambertian_surface_lin<T>(cvt_quad<T>(q), S, m, albedo, iparam, tau_sum, tau_sum_dot, p_layer, F0,          \
+                                     cvt_added<T>(added), cvt_al<T>(al), as_stream(stream));                           \
+  }                                                                                                                    \
+  int vsm_postprocess_vza_lin_##SFX(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const T* w_h,        \
+                                    const T* Jm, const T* Jp, T* Rd, T* Td, void* stream) {                            \
+    VSM_REQUIRE(row0_h && w_h && Jm && Jp && Rd && Td, "postprocess_vza_lin: null argument");                          \
+    return postprocess_vza_lin<T>(N, n_stokes, S, nV, P, row0_h, w_h, Jm, Jp, Rd, Td, as_stream(stream));              \
+  }
+
+extern "C" {
+size_t vsm_doubling_lin_work_elems(int N, int S, int P) { return doubling_lin_work_elems<double>(N, S, P); }
+size_t vsm_interaction_lin_work_elems(int N, int S, int P) { return interaction_lin_work_elems<double>(N, S, P); }
+VSM_LIN_API(double, f64)
+VSM_LIN_API(float, f32)
+}

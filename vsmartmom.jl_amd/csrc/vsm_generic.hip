@@ -16,7 +16,13 @@ namespace vsm {
 template <typename T>
 __global__ __launch_bounds__(256) void k_gemm(int M, int Nc, int K, const T* __restrict__ A, long long sa,
                                               const T* __restrict__ B, long long sb, T* C, long long sc,
-                                              T alpha, const T* D, long long sd, T beta, T gamma) {
+                                              T alpha, const T* D, long long sd, T beta, T gamma,
+                                              long long pa, long long pb, long long pc, long long pd) {
+  // second batch level (blockIdx.z = parameter index of the linearized pass); stride 0 = shared
+  A += (long long)blockIdx.z * pa;
+  B += (long long)blockIdx.z * pb;
+  C += (long long)blockIdx.z * pc;
+  if (D) D += (long long)blockIdx.z * pd;
   const int s = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tilesM = (M + 15) >> 4, tilesN = (Nc + 15) >> 4;
@@ -56,8 +62,22 @@ int gemm(int M, int Nc, int K, int S, const T* A, long long sa, const T* B, long
   if (S <= 0 || M <= 0 || Nc <= 0) return VSM_OK;
   const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
   dim3 grid((tiles + 3) / 4, S);
-  hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma);
+  hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, 0LL,
+                     0LL, 0LL, 0LL);
   VSM_LAUNCH_CHECK("k_gemm");
+  return VSM_OK;
+}
+// two-level batch: S spectral points x P parameters
+template <typename T>
+int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long long pa, const T* B, long long sb,
+          long long pb, T* C, long long sc, long long pc, T alpha, const T* D, long long sd, long long pd, T beta,
+          T gamma, hipStream_t st) {
+  if (S <= 0 || P <= 0 || M <= 0 || Nc <= 0) return VSM_OK;
+  const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
+  dim3 grid((tiles + 3) / 4, S, P);
+  hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, pa,
+                     pb, pc, pd);
+  VSM_LAUNCH_CHECK("k_gemm(P)");
   return VSM_OK;
 }
 
@@ -525,6 +545,8 @@ int postprocess_vza(int N, int n_stokes, int S, int nV, const int* row0_h, const
 
 // explicit instantiations ------------------------------------------------------
 #define VSM_INST(T)                                                                                                    \
+  template int gemm2<T>(int, int, int, int, int, const T*, long long, long long, const T*, long long, long long, T*,  \
+                        long long, long long, T, const T*, long long, long long, T, T, hipStream_t);                   \
   template int gemm<T>(int, int, int, int, const T*, long long, const T*, long long, T*, long long, T, const T*,      \
                        long long, T, T, hipStream_t);                                                                  \
   template int batch_inv<T>(int, int, const T*, T*, int*, hipStream_t);                                                \

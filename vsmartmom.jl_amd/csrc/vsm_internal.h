@@ -30,6 +30,10 @@ template <typename T>
 int gemm(int M, int Nc, int K, int S, const T* A, long long sa, const T* B, long long sb, T* C, long long sc,
          T alpha, const T* D, long long sd, T beta, T gamma, hipStream_t st);
 template <typename T>
+int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long long pa, const T* B, long long sb,
+          long long pb, T* C, long long sc, long long pc, T alpha, const T* D, long long sd, long long pd, T beta,
+          T gamma, hipStream_t st);
+template <typename T>
 int batch_inv(int N, int S, const T* A, T* X, int* info, hipStream_t st);
 template <typename T>
 int elemental(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
@@ -49,6 +53,43 @@ int postprocess_vza(int N, int n_stokes, int S, int nV, const int* row0_h, const
                     T* R, T* Tt, hipStream_t st);
 template <typename T>
 int copy_strided(long long per, int S, const T* src, long long ss, T* dst, hipStream_t st);
+
+// ---- linearized (Jacobian) pass, operator level: vsm_lin.hip ---------------------------------------
+template <typename T>
+struct added_lin {
+  T *ap_r_mp, *ap_t_pp, *ap_r_pm, *ap_t_mm, *ap_J0_p, *ap_J0_m;  // [N,N,S,P] / [N,1,S,P]
+  int P;
+  long long mat_stride;  // N*N, or 0: ONE block per parameter shared by all S (surface)
+};
+template <typename T>
+struct composite_lin {
+  T *R_mp, *R_pm, *T_pp, *T_mm, *J0_p, *J0_m;
+  int P;
+};
+template <typename T>
+int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                  const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
+                  const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
+                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st);
+template <typename T>
+size_t doubling_lin_work_elems(int N, int S, int P);
+template <typename T>
+int doubling_lin(int N, int n_stokes, int S, int ndoubl, T* expk, const T* dtau_dot_all, T mu0, int n_active,
+                 const added<T>& a, const added_lin<T>& al, T* work, hipStream_t st);
+template <typename T>
+size_t interaction_lin_work_elems(int N, int S, int P);
+template <typename T>
+int interaction_lin(int iface, int N, int S, const composite<T>& c, const composite_lin<T>& cl, const added<T>& a,
+                    const added_lin<T>& al, T* work, hipStream_t st);
+template <typename T>
+int lambertian_surface_lin(const quad<T>& q, int S, int m, T albedo, int iparam, const T* tau_sum,
+                           const T* tau_sum_dot, int p_layer, const T* F0, const added<T>& a, const added_lin<T>& al,
+                           hipStream_t st);
+template <typename T>
+int copy_added_to_composite_lin(int N, int S, const added_lin<T>& al, const composite_lin<T>& cl, hipStream_t st);
+template <typename T>
+int postprocess_vza_lin(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const T* w_h, const T* Jd_m,
+                        const T* Jd_p, T* Rd, T* Td, hipStream_t st);
 
 // ---- fused (LDS-resident) path: vsm_fused.hip ---------------------------------
 template <typename T>

@@ -391,3 +391,56 @@ def get_dtau_ndoubl(tau: np.ndarray, varpi: np.ndarray, qp: QuadPoints, FT, nume
     dtau_max = max(floor_val, min(tw, FT(thr * mu_min)))
     _, nd = doubling_number(dtau_max, tw, FT)
     return (tau / FT(2 ** nd)).astype(FT), nd
+
+
+# ---- linearized inputs (src/CoreRT/parameter_layout.jl:20-66, types_lin.jl:141-150) -------------------------
+@dataclass
+class ParameterLayout:
+    """Order of the Jacobian slots: [7 per aerosol] ++ gases ++ surface (parameter_layout.jl:28-56)."""
+    n_aerosols: int = 0
+    n_gases: int = 0
+    n_surface: int = 0
+    aerosol_params: int = 7
+
+    @property
+    def n_layer_params(self):
+        return self.aerosol_params * self.n_aerosols + self.n_gases
+
+    @property
+    def n_total(self):
+        return self.n_layer_params + self.n_surface
+
+    def surface_index(self, i: int) -> int:  # 0-based slot of the i-th (0-based) surface parameter
+        return self.n_layer_params + i
+
+
+@dataclass
+class CoreScatteringOpticalPropertiesLin:
+    """d(tau, varpi, Z++, Z-+)/dx for one layer (host numpy)."""
+    tau_dot: np.ndarray             # [S, p]
+    varpi_dot: np.ndarray           # [S, p]
+    Zpp_dot: Optional[np.ndarray]   # [p, N, N] / [p, S, N, N] / None
+    Zmp_dot: Optional[np.ndarray]
+
+
+@dataclass
+class LinModel:
+    """The part of the reference's lin_model the hot path consumes for gas Jacobians:
+    tau_abs_dot[g][S, Nz] = d tau_abs / d x_g (lin_model.τ̇_abs).  Aerosol (Mie) derivatives are upstream of
+    the hot path and out of scope (SURVEY.md 8c 'parity unpinned')."""
+    tau_abs_dot: List[np.ndarray]
+
+
+def constructCoreOpticalPropertiesLin(model: RTModel, lin_model: LinModel,
+                                      lods: List[CoreScatteringOpticalProperties]) -> List[CoreScatteringOpticalPropertiesLin]:
+    """Absorption-only parameters: tau = tau_sc + tau_abs, varpi = w_sc / tau (types.jl:1302-1308)
+    => tau_dot = tau_abs_dot, varpi_dot = -(varpi / tau) tau_dot, Z_dot = 0
+    (the gas block of compEffectiveLayerProperties_lin.jl:43-473)."""
+    out = []
+    for iz, lo in enumerate(lods):
+        tau = np.atleast_1d(lo.tau)
+        varpi = np.broadcast_to(np.asarray(lo.varpi), tau.shape)
+        td = np.stack([g[:, iz] for g in lin_model.tau_abs_dot], axis=1)
+        wd = -(varpi / np.where(tau > 0, tau, 1.0))[:, None] * td
+        out.append(CoreScatteringOpticalPropertiesLin(td, wd, None, None))
+    return out
