@@ -72,7 +72,10 @@ def array_type(arch: AbstractArchitecture):
     def convert(x):
         if isinstance(x, torch.Tensor):
             return x.to(dev)
-        return torch.as_tensor(np.ascontiguousarray(x)).to(dev)
+        a = np.ascontiguousarray(x)
+        if not a.flags.writeable:
+            a = a.copy()
+        return torch.as_tensor(a).to(dev)
 
     return convert
 

@@ -178,9 +178,10 @@ def rt_run_lin(model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NS
         # surface
         q_, a_, al_ = dq.cstruct(), added_s.cstruct(), als.cstruct()
         alb = C.c_double(model.albedo) if dt == torch.float64 else C.c_float(model.albedo)
+        ts_surf = conv(tau_sum_all[:, -1].astype(FT))           # keep the device buffers alive across the launch
+        tsd_surf = to_device_sp(tsd[:, :, -1], arch, FT)
         _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, layout.surface_index(0),
-                  CR._ptr(conv(tau_sum_all[:, -1].astype(FT))), CR._ptr(to_device_sp(tsd[:, :, -1], arch, FT)), pl,
-                  CR._ptr(F0d), C.byref(a_), C.byref(al_), CR._stream_ptr())
+                  CR._ptr(ts_surf), CR._ptr(tsd_surf), pl, CR._ptr(F0d), C.byref(a_), C.byref(al_), CR._stream_ptr())
         interaction_lin_(tags[-1], comp, cl, added_s, als)
         CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), R, T)
         n = pol.n
