@@ -136,6 +136,7 @@ def main():
     k_flops = sum(S_local * nd * (12 * n3 + 8 * n2) for _, _, nd in ev)   # algorithmic doubling flops
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
+    traffic, traffic_src = hbm_traffic_per_launch("k_elemental_doubling", cfg, S_local)
 
     if rank == 0:
         flops_pt = scene.flops_per_point()
@@ -155,7 +156,8 @@ def main():
                        "whole_run_frac_of_mfma_peak": pts_per_s * flops_pt / 1e12 / (peak * world),
                        "prepare_scene_s (host optics + H2D, untimed)": t_prep},
             "roofline": {"bound": "mfma", "kernel": "k_elemental_doubling", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1)},
         }
         if not args.no_cpu_baseline:
@@ -164,6 +166,22 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def hbm_traffic_per_launch(kernel, cfg, S_local):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
+    figure of profiles/r01/hbm_traffic_c2_s4096.json times the points of one launch.  PMC counters cannot be
+    read from inside the timed process, so this is the profiled value, not a live one; null when the profile
+    does not cover the configuration."""
+    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_c2_s4096.json")
+    try:
+        prof = json.load(open(path))
+        if prof["N"] != cfg["N"] or prof["dtype"] != cfg["FT"]:
+            return None, None
+        return prof["kernels"][kernel]["hbm_bytes_per_point"] * S_local, os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(cfg, n_sample, L):
