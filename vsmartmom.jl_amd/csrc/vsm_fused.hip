@@ -19,6 +19,7 @@
 // rounding by a norm bound on E), or by the pivoted Gauss-Jordan of vsm_inverse.h (general case).
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
+#include "vsm_lds.h"
 
 namespace vsm {
 
@@ -54,11 +55,6 @@ struct fcfg {
   static constexpr int TPR = NT / 128;                // threads per row in the mat-vec (128 rows >= NP)
   static_assert(TMR * WR * 16 == NP && TMC * WC * 16 == NP, "tile grid must cover NP");
 };
-
-template <int NP>
-__device__ __forceinline__ int lidx(int a, int b) {
-  return (a ^ (((b & 1) << 4) | (((b >> 1) & 7) << 1))) + NP * b;
-}
 
 template <typename T, int NP, int NW>
 struct fsmem {
@@ -375,30 +371,6 @@ __device__ __forceinline__ void lds_to_global(T* __restrict__ dst, const T* L, i
 // DPP row-rotation adds inside a wave, one LDS slot per wave, one barrier, fixed-order final sum; the
 // result is inflated by 1e-3 to cover the float rounding of the <= 80 additions.  `slot` alternates
 // between calls so no extra barrier is needed before the slots are reused.
-__device__ __forceinline__ float dpp_ror_add(float x, const int ctrl_is_8_4_2_1) {
-  float y;
-  switch (ctrl_is_8_4_2_1) {
-    case 8: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)); break;
-    case 4: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)); break;
-    case 2: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)); break;
-    default: y = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)); break;
-  }
-  return x + y;
-}
-__device__ __forceinline__ float wave_sum(float x) {
-  x = dpp_ror_add(x, 8);
-  x = dpp_ror_add(x, 4);
-  x = dpp_ror_add(x, 2);
-  x = dpp_ror_add(x, 1);  // every lane of a 16-lane row now holds the row sum
-  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0));
-  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
-  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32));
-  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
-  return (a + b) + (c + d);
-}
-__device__ __forceinline__ float to_float_up(double x) { return __double2float_ru(x); }
-__device__ __forceinline__ float to_float_up(float x) { return x; }
-
 template <typename T, int NP, int NW>
 __device__ __forceinline__ T acc_norm_bound(const acc_block<T, NP, NW>& acc, int N, fsmem<T, NP, NW>& sm, int& slot) {
   using C = fcfg<NP, NW>;

@@ -15,7 +15,7 @@ namespace vsm {
 template <int NPAD, int NT = 256>
 struct gj_cfg {
   static_assert(NPAD == 32 || NPAD == 64 || NPAD == 96 || NPAD == 128, "NPAD must be 32/64/96/128");
-  static_assert(NT == 256 || NT == 512, "workgroup of 256 or 512 threads");
+  static_assert(NT % 64 == 0 && NT >= 128 && NT <= 512, "workgroup of 2..8 waves");
   static constexpr int TR = (NPAD % 64 == 0) ? 64 : 32;
   static constexpr int TC = NT / TR;
   static constexpr int RB = NPAD / TR;
