@@ -51,8 +51,8 @@ def main():
         per = x / launches / (nd if n not in ("elemental", "write-out") else 1)
         print("  %-32s %12.0f total  %10.1f per %s" % (n, x, per, "step" if n not in ("elemental", "write-out") else "launch"))
     print("  sum per launch: %.0f" % (v.sum() / launches))
-    inames = ["stage R+-,r-+", "r R", "inverse 1", "T01=T-- G1 + u", "J0- ; T01 r", "(..)T++ -> R-+", "T--=T01 t--; R r; write",
-              "inverse 2", "T21=t++ G2 + z", "T21 T++; T21 R+-; write T++", "(..) t-- -> R+-"]
+    inames = ["stage R+-,r-+", "r R", "inverse 1", "H=G1 r; T01=T-- G1; u", "T-- H", "J0-; (..)T++ -> R-+",
+              "T--=T01 t--; G2=I+R H; write", "(unused)", "T21=t++ G2 + z", "T21 T++; T21 R+-; write T++", "(..) t-- -> R+-"]
     w = np.array(list(buf)[8:19], dtype=float)
     ni = L  # L-1 layer interactions + 1 surface
     print("k_interaction11 (per launch, %d launches):" % ni)

@@ -833,72 +833,83 @@ __global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c
   opA.prefetch(T_mm, N);     // lands while G1 is being formed
   __syncthreads();
   VSM_STAMP(8);   // stage
+  auto ident = [](T x, int, int, T) { return x; };
   // ---- G1 = (I - r-+ R+-)^-1 -> L3 -------------------------------------------------------
   acc.zero();
   mm_ll<T, NP, NW>(acc, L2, L1, Kend);
   VSM_STAMP(9);   // r R
   invert_one_minus<T, NP, NW>(acc, L3, L4, N, Kend, sm, slot, 0);
   VSM_STAMP(10);  // inverse 1
-  // T01_inv = T-- G1 -> L4   (L4 = scratch of the inverse, free after its final barrier)
   opB.prefetch(T_pp, N);
+  // H = G1 r-+ -> L4 (scratch of the inverse, free after its final barrier).  H serves twice:
+  //   T01_inv r-+ = T-- H, and the second inverse of the reference (interaction.jl:243) by the
+  //   push-through identity (I - R+- r-+)^-1 = I + R+- (I - r-+ R+-)^-1 r-+ = I + R+- H,
+  // which replaces a second series / Gauss-Jordan by one product.
   acc.zero();
-  opA.run(acc, L3);
-  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
+  mm_ll<T, NP, NW>(acc, L3, L2, Kend);
+  acc_store<T, NP, NW>(L4, acc, ident);
+  // T01_inv = T-- G1 (kept in registers until every wave is done reading G1)
+  acc_block<T, NP, NW> acc2;
+  acc2.zero();
+  opA.run(acc2, L3);
   // u = r-+ J0+ + j0-
   {
     T y1, y2;
     matvec2<T, NP, NW>(L2, vJp, vJp, y1, y2);
     if (mlead) vu[mrow] = y1 + vjm[mrow];
   }
-  opA.prefetch(t_pp, N);  // needed only for G2; lands during the next three products
-  __syncthreads();        // T01_inv and u complete; G1 (L3) no longer read
-  VSM_STAMP(11);  // T01 = T-- G1, matvec u
+  __syncthreads();  // G1 (L3) and r-+ (L2) no longer read; H and u complete
+  VSM_STAMP(11);  // H = G1 r, T01 = T-- G1, matvec u
+  acc_store<T, NP, NW>(L3, acc2, ident);  // T01_inv -> L3
+  // T01_inv r-+ = T-- H -> L2
+  acc.zero();
+  opA.run(acc, L4);
+  acc_store<T, NP, NW>(L2, acc, ident);
+  opA.prefetch(t_pp, N);  // needed only for T21_inv; lands during the next products
+  __syncthreads();        // T01_inv (L3) and T01_inv r-+ (L2) complete
+  VSM_STAMP(12);  // T-- H
   // J0- += T01_inv u
   {
     T y1, y2;
-    matvec2<T, NP, NW>(L4, vu, vu, y1, y2);
+    matvec2<T, NP, NW>(L3, vu, vu, y1, y2);
     if (mlead && mrow < N) J0_m[mrow] = vJm[mrow] + y1;
   }
   // R-+ += (T01_inv r-+) T++
   acc.zero();
-  mm_ll<T, NP, NW>(acc, L4, L2, Kend);
-  acc_store<T, NP, NW>(L3, acc, [](T x, int, int, T) { return x; });
-  __syncthreads();
-  VSM_STAMP(12);  // matvec J0-, T01 r
-  acc.zero();
-  opB.run(acc, L3);
+  opB.run(acc, L2);
   if (a.d_symmetric) opB.prefetch_dsym(t_pp, N, a.d_symmetric); else opB.prefetch(t_mm, N);
-  __syncthreads();  // everybody finished reading L3 (as A operand)
-  acc_store<T, NP, NW>(L3, acc, [](T x, int, int, T) { return x; });
+  __syncthreads();  // everybody finished reading L2 (as A operand)
+  acc_store<T, NP, NW>(L2, acc, ident);
   __syncthreads();
-  oldRmp.add_lds_store(R_mp, L3, N);
+  oldRmp.add_lds_store(R_mp, L2, N);
   VSM_STAMP(13);  // (..) T++ -> R-+ update
   // T-- = T01_inv t--
   acc.zero();
-  opB.run(acc, L4);
+  opB.run(acc, L3);
   opB.prefetch(T_pp, N);  // pre-update T++ again, for T++ = T21_inv T++
-  __syncthreads();        // R-+ update finished reading L3; T01_inv (L4) no longer read
-  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
-  // ---- G2 = (I - R+- r-+)^-1 -> L3 -------------------------------------------------------
-  acc.zero();
-  mm_ll<T, NP, NW>(acc, L1, L2, Kend);
-  __syncthreads();  // new T-- complete in L4
-  lds_to_global<T, NP, NW>(T_mm, L4, N);
-  __syncthreads();  // L4 free again (scratch of the inverse)
-  VSM_STAMP(14);  // T-- = T01 t--, R r, write T--
-  invert_one_minus<T, NP, NW>(acc, L3, L4, N, Kend, sm, slot, 0);
-  VSM_STAMP(15);  // inverse 2
+  // ---- G2 = (I - R+- r-+)^-1 = I + R+- H -> L2 --------------------------------------------
+  acc2.zero();
+  mm_ll<T, NP, NW>(acc2, L1, L4, Kend);
+  __syncthreads();  // T01_inv (L3), H (L4) no longer read; R-+ write-out finished reading L2
+  acc_store<T, NP, NW>(L3, acc, ident);  // new T-- -> L3
+  acc_store<T, NP, NW>(L2, acc2, [=](T x, int r, int c, T) {
+    const T v = (r < N && c < N) ? x : T(0);
+    return (r == c) ? v + T(1) : v;
+  });
+  __syncthreads();
+  lds_to_global<T, NP, NW>(T_mm, L3, N);
+  VSM_STAMP(14);  // T-- = T01 t--, G2 = I + R H, write T--
   // T21_inv = t++ G2 -> L4
   acc.zero();
-  opA.run(acc, L3);
-  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });
+  opA.run(acc, L2);
+  acc_store<T, NP, NW>(L4, acc, ident);
   // z = J0+ + R+- j0-
   {
     T y1, y2;
     matvec2<T, NP, NW>(L1, vjm, vjm, y1, y2);
     if (mlead) vz[mrow] = vJp[mrow] + y1;
   }
-  __syncthreads();  // T21_inv and z complete; G2 (L3) no longer read
+  __syncthreads();  // T21_inv and z complete; G2 (L2) no longer read; T-- write-out finished reading L3
   VSM_STAMP(16);  // T21 = t++ G2, matvec z
   // J0+ = j0+ + T21_inv z
   {
@@ -907,22 +918,20 @@ __global__ __launch_bounds__(64 * NW) void k_interaction11(int N, composite<T> c
     if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y1;
   }
   // T++ = T21_inv T++   and   tmp = T21_inv R+-
-  acc_block<T, NP, NW> acc2;
   acc.zero();
   opB.run(acc, L4);
   if (a.d_symmetric) opB.prefetch_dsym(t_pp, N, a.d_symmetric); else opB.prefetch(t_mm, N);
   acc2.zero();
   mm_ll<T, NP, NW>(acc2, L4, L1, Kend);
-  acc_store<T, NP, NW>(L3, acc2, [](T x, int, int, T) { return x; });  // tmp -> L3
-  __syncthreads();  // all waves finished reading r-+ (L2, last used for G2) long ago; L1/L4 reads done
-  acc_store<T, NP, NW>(L2, acc, [](T x, int, int, T) { return x; });   // new T++ -> L2 (r-+ is dead)
+  acc_store<T, NP, NW>(L3, acc2, ident);  // tmp -> L3
+  acc_store<T, NP, NW>(L2, acc, ident);   // new T++ -> L2 (G2 is dead)
   __syncthreads();
   lds_to_global<T, NP, NW>(T_pp, L2, N);
   VSM_STAMP(17);  // T21 T++, T21 R+-, write T++
   // R+- = r+- + tmp t--
   acc.zero();
   opB.run(acc, L3);
-  acc_store<T, NP, NW>(L4, acc, [](T x, int, int, T) { return x; });  // T21_inv (L4) dead since the barrier above
+  acc_store<T, NP, NW>(L4, acc, ident);  // T21_inv (L4) dead since the barrier above
   __syncthreads();
   addrpm.add_lds_store(R_pm, L4, N);
   VSM_STAMP(18);  // (..) t-- -> R+-
