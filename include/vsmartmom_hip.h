@@ -286,6 +286,92 @@ int vsm_postprocess_vza_lin_f64(int N, int n_stokes, int S, int nV, int P, const
 int vsm_postprocess_vza_lin_f32(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const float* w_h,
                                 const float* Jdot0_m, const float* Jdot0_p, float* Rdot, float* Tdot, void* stream);
 
+/* ---- rotational Raman scattering (RRS), operator level ---------------------
+ * Inelastic layer state (src/CoreRT/types.jl:278-335 AddedLayerRS / CompositeLayerRS): 4-D arrays
+ * [N,N,S,K] / [N,1,S,K], K = number of Raman offsets (length of RS_type.i_lambda1lambda0); element
+ * (i,j,n1,dn) at i + N*j + N*N*n1 + N*N*S*dn.  Block (n1,dn) couples recipient point n1 with donor point
+ * n0 = n1 + shift[dn] (src/Inelastic/inelastic_helper.jl:19-26); pairs with n0 outside [0,S) stay zero. */
+typedef struct vsm_added_rs_f64 {
+  double *ier_mp, *iet_pp, *ier_pm, *iet_mm;  /* ier-+ iet++ ier+- iet--  [N,N,S,K] */
+  double *ieJ0_p, *ieJ0_m;                    /* ieJ0+ ieJ0-              [N,1,S,K] */
+  int K;
+  int reserved;
+} vsm_added_rs_f64;
+typedef struct vsm_added_rs_f32 {
+  float *ier_mp, *iet_pp, *ier_pm, *iet_mm;
+  float *ieJ0_p, *ieJ0_m;
+  int K;
+  int reserved;
+} vsm_added_rs_f32;
+typedef struct vsm_composite_rs_f64 {
+  double *ieR_mp, *ieR_pm, *ieT_pp, *ieT_mm;
+  double *ieJ0_p, *ieJ0_m;
+  int K;
+  int reserved;
+} vsm_composite_rs_f64;
+typedef struct vsm_composite_rs_f32 {
+  float *ieR_mp, *ieR_pm, *ieT_pp, *ieT_mm;
+  float *ieJ0_p, *ieJ0_m;
+  int K;
+  int reserved;
+} vsm_composite_rs_f32;
+/* The fields of RRS{FT} (src/Inelastic/types.jl) read by the CoreRT kernels; all DEVICE pointers. */
+typedef struct vsm_rrs_f64 {
+  const int* shift;        /* i_lambda1lambda0[K] */
+  const double* varpi_ie;  /* varpi_lambda1lambda0[K] */
+  const double* fscatt;    /* fscattRayl[S] of the current layer (rt_run.jl:221-223) */
+  const double* Zpp;       /* Z++_lambda1lambda0 [N,N] of the current Fourier moment (inelastic_helper.jl:917-924) */
+  const double* Zmp;       /* Z-+_lambda1lambda0 [N,N] */
+} vsm_rrs_f64;
+typedef struct vsm_rrs_f32 {
+  const int* shift;
+  const float* varpi_ie;
+  const float* fscatt;
+  const float* Zpp;
+  const float* Zmp;
+} vsm_rrs_f32;
+/* elemental_inelastic!(::RRS) (CoreKernel/elemental_inelastic.jl:23-105; kernels get_elem_rt_RRS! :117-206,
+ * get_elem_rt_SFI_RRS! :479-610, apply_D_elemental_RRS! :619-637).  Fills the six fields of added_rs
+ * (ier+-/iet-- only when ndoubl < 1, like the reference). */
+int vsm_elemental_inelastic_rrs_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau,
+                                    const double* tau_sum, const double* F0, const vsm_rrs_f64* rs,
+                                    const vsm_added_rs_f64* added_rs, void* stream);
+int vsm_elemental_inelastic_rrs_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau,
+                                    const float* tau_sum, const float* F0, const vsm_rrs_f32* rs,
+                                    const vsm_added_rs_f32* added_rs, void* stream);
+/* doubling_inelastic! = doubling_helper!(::RRS) (CoreKernel/doubling_inelastic.jl:13-164): doubles the elastic AND
+ * the inelastic fields together (the elastic recurrences are interleaved with the inelastic ones), then applies
+ * the D-matrix kernels (:336-356, :408-416).  expk[S] is squared in place ndoubl times.  `added` must be a full
+ * per-point AddedLayer.  work: vsm_doubling_inelastic_work_elems(N,S,K) elements. */
+size_t vsm_doubling_inelastic_work_elems(int N, int S, int K);
+int vsm_doubling_inelastic_rrs_f64(int N, int n_stokes, int S, int ndoubl, double* expk, const int* shift,
+                                   const vsm_added_f64* added, const vsm_added_rs_f64* added_rs, double* work, void* stream);
+int vsm_doubling_inelastic_rrs_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const int* shift,
+                                   const vsm_added_f32* added, const vsm_added_rs_f32* added_rs, float* work, void* stream);
+/* interaction_helper!(::RRS, ::ScatteringInterface_11) (CoreKernel/interaction_inelastic.jl:319-521): updates the
+ * inelastic composite from pre-update elastic/inelastic values, then the elastic composite.  Other interface tags
+ * return VSM_ERR_UNSUPPORTED (the RRS rt_kernel! hard-wires scatter = true, rt_kernel.jl:365).  `added` may be a
+ * shared-block surface layer (mat_stride 0) with an all-zero added_rs.
+ * work: vsm_interaction_inelastic_work_elems(N,S,K) elements. */
+size_t vsm_interaction_inelastic_work_elems(int N, int S, int K);
+int vsm_interaction_inelastic_rrs_f64(int iface, int N, int S, const int* shift, const vsm_composite_f64* comp,
+                                      const vsm_composite_rs_f64* comp_rs, const vsm_added_f64* added,
+                                      const vsm_added_rs_f64* added_rs, double* work, void* stream);
+int vsm_interaction_inelastic_rrs_f32(int iface, int N, int S, const int* shift, const vsm_composite_f32* comp,
+                                      const vsm_composite_rs_f32* comp_rs, const vsm_added_f32* added,
+                                      const vsm_added_rs_f32* added_rs, float* work, void* stream);
+/* copy_added_to_composite_ie! (rt_helpers.jl:222-228), inelastic fields only (pair with vsm_copy_added_to_composite). */
+int vsm_copy_added_to_composite_ie_f64(int N, int S, const vsm_added_rs_f64* added_rs, const vsm_composite_rs_f64* comp_rs,
+                                       void* stream);
+int vsm_copy_added_to_composite_ie_f32(int N, int S, const vsm_added_rs_f32* added_rs, const vsm_composite_rs_f32* comp_rs,
+                                       void* stream);
+/* postprocessing_vza!(::RRS) inelastic accumulation (tools/postprocessing_vza.jl:139-142):
+ * ieR/ieT [nV,n_stokes,S] += w * sum_dn ieJ0-/+[rows(vza), 1, s, dn].  row0_h/w_h as in vsm_postprocess_vza. */
+int vsm_postprocess_vza_ie_f64(int N, int n_stokes, int S, int K, int nV, const int* row0_h, const double* w_h,
+                               const double* ieJ0_m, const double* ieJ0_p, double* ieR, double* ieT, void* stream);
+int vsm_postprocess_vza_ie_f32(int N, int n_stokes, int S, int K, int nV, const int* row0_h, const float* w_h,
+                               const float* ieJ0_m, const float* ieJ0_p, float* ieR, float* ieT, void* stream);
+
 /* ---- diagnostics used by the parity tests -------------------------------- */
 /* Runs the LDS-resident MFMA tile product used inside the fused kernels on plain
  * [N,N,S] inputs: C = A*B.  (Checks fragment layouts / swizzle independently.) */

@@ -1,0 +1,291 @@
+"""GPU parity tests of the rotational-Raman (RRS) pass: every vsm_*_inelastic_rrs_* entry point is called through
+the C ABI and compared with oracle/vsm_oracle_raman.py on the same seeded inputs, then rt_run(RS_type, model)
+end to end, then a size-independent property at a larger size.
+
+Tolerances: FP64 operators 1e-10 relative to the array maximum (summation order only), FP64 end-to-end 1e-8,
+FP32 operators 5e-4 / end-to-end 1e-2 (the reference's own FP32 gate, test/test_float32.jl:58-64).
+"""
+import numpy as np
+import pytest
+
+from oracle import vsm_oracle as O
+from oracle import vsm_oracle_raman as OR
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def vsm():
+    import vsmartmom_jl_amd as v
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X; torch.cuda.is_available() is False")
+    v._lib.lib()
+    return v
+
+
+@pytest.fixture(scope="module")
+def arch(vsm):
+    return vsm.Architectures.GPU()
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+TOL = {np.float64: 1e-10, np.float32: 5e-4}
+SHIFTS = np.array([-5, -2, -1, 1, 3, 40, 0])      # 40: never in band for S <= 40
+W_IE = np.array([0.004, 0.012, 0.02, 0.018, 0.007, 0.3, 0.009])
+
+
+def _m4(vsm, arch, A, FT):   # [K,S,i,j] math order -> device [N,N,S,K] column-major
+    return vsm.Architectures.array_type(arch)(np.ascontiguousarray(np.asarray(A, dtype=FT).transpose(0, 1, 3, 2)))
+
+
+def _h4(vsm, t):
+    return vsm.Architectures.to_host(t).transpose(0, 1, 3, 2)
+
+
+def _setup(vsm, arch, FT, pol_name, S=14, l_trunc=7, seed=0):
+    """Quadrature, a random-but-physical elemental layer and the RRS inputs on both sides."""
+    rng = np.random.default_rng(seed)
+    pol = O.polarization(pol_name)
+    qp = O.rt_set_streams_gausslegquad(l_trunc, 35.0, [20.0, 50.0], pol, FT)
+    Hm = vsm.host_model
+    hpol = Hm.polarization_type(pol_name)
+    hqp = Hm.rt_set_streams(l_trunc, 35.0, [20.0, 50.0], hpol, FT)
+    N = qp.Nquad * pol.n
+    greek = O.get_greek_rayleigh(0.03)
+    graman = O.get_greek_rayleigh(0.1)
+    tau = (0.02 + 0.2 * rng.random(S)) * (1 + 5 * (rng.random(S) < 0.3))
+    varpi = 0.3 + 0.6 * rng.random(S)
+    fscatt = 0.5 + 0.5 * rng.random(S)
+    tau_sum = 0.1 * rng.random(S)
+    F0 = np.zeros((pol.n, S))
+    F0[0] = 0.5 + rng.random(S)
+    return dict(rng=rng, pol=pol, qp=qp, hpol=hpol, hqp=hqp, N=N, S=S, greek=greek, graman=graman, tau=tau.astype(FT),
+                varpi=varpi.astype(FT), fscatt=fscatt.astype(FT), tau_sum=tau_sum.astype(FT), F0=F0.astype(FT))
+
+
+def _oracle_added(c, FT, m, ndoubl_mode):
+    """Oracle elemental (elastic + inelastic) for the setup `c`; returns everything needed downstream."""
+    pol, qp, S, N = c["pol"], c["qp"], c["S"], c["N"]
+    dtau, nd = O.get_dtau_ndoubl(c["tau"], c["varpi"], qp, FT)
+    if ndoubl_mode == 0:
+        dtau, nd = c["tau"].astype(FT), 0
+    elif ndoubl_mode > 0:
+        nd = ndoubl_mode
+        dtau = (c["tau"] / FT(2 ** nd)).astype(FT)
+    Zpp, Zmp = O.compute_Z_moments(pol, qp.qp_mu, c["greek"], m)
+    rs = OR.RRS(i_shift=SHIFTS, varpi_ie=W_IE, greek_raman=c["graman"], fscatt_rayl=c["fscatt"])
+    rs.Zpp_ie, rs.Zmp_ie = O.compute_Z_moments(pol, qp.qp_mu, c["graman"], m)
+    add = O.make_added_layer(FT, N, S)
+    ars = OR.make_added_layer_rs(FT, len(SHIFTS), N, S)
+    OR.elemental_inelastic(rs, pol, c["tau_sum"], dtau, c["F0"], m, nd, qp, ars, FT)
+    O.elemental(pol, c["tau_sum"], dtau, c["F0"], c["varpi"], Zpp, Zmp, m, nd, qp, add, FT)
+    return rs, add, ars, dtau, nd, (Zpp, Zmp)
+
+
+def _device_side(vsm, arch, c, FT, rs, m):
+    CR, RR = vsm.CoreRT, vsm.CoreRTRaman
+    dq = CR.device_quad(c["hqp"], c["hpol"], arch, FT)
+    hrs = RR.RRS(SHIFTS, W_IE, None)
+    drs = RR.device_rrs(hrs, arch, FT)
+    conv = vsm.Architectures.array_type(arch)
+    drs.fscatt = conv(c["fscatt"])
+    drs.Zpp, drs.Zmp = CR.to_device_matrix(rs.Zpp_ie, arch, FT), CR.to_device_matrix(rs.Zmp_ie, arch, FT)
+    return dq, drs, conv
+
+
+def _upload_added(vsm, arch, add, ars, FT):
+    CR, RR = vsm.CoreRT, vsm.CoreRTRaman
+    S, N = add.r_mp.shape[0], add.r_mp.shape[1]
+    K = ars.ier_mp.shape[0]
+    conv = vsm.Architectures.array_type(arch)
+    pa = CR.make_added_layer(FT, arch, (N, N), S)
+    for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+        getattr(pa, k).copy_(CR.to_device_matrix(getattr(add, k), arch, FT))
+    pa.j0_p.copy_(conv(add.j0_p))
+    pa.j0_m.copy_(conv(add.j0_m))
+    pr = RR.AddedLayerRS(FT, arch, K, N, S)
+    for k in ("ier_mp", "iet_pp", "ier_pm", "iet_mm"):
+        getattr(pr, k).copy_(_m4(vsm, arch, getattr(ars, k), FT))
+    pr.ieJ0_p.copy_(conv(ars.ieJ0_p))
+    pr.ieJ0_m.copy_(conv(ars.ieJ0_m))
+    return pa, pr
+
+
+def _check_rs(vsm, dev, ora, tol, names_m, names_v):
+    for k in names_m:
+        got, ref = _h4(vsm, getattr(dev, k)), getattr(ora, k)
+        assert _rel(got, ref) <= tol, (k, _rel(got, ref))
+    for k in names_v:
+        got, ref = vsm.Architectures.to_host(getattr(dev, k)), getattr(ora, k)
+        assert _rel(got, ref) <= tol, (k, _rel(got, ref))
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+@pytest.mark.parametrize("pol", ["I", "IQU", "IQUV"])
+@pytest.mark.parametrize("m,ndmode", [(0, 0), (0, -1), (1, -1), (2, 3)])
+def test_elemental_inelastic(vsm, arch, FT, pol, m, ndmode):
+    c = _setup(vsm, arch, FT, pol)
+    rs, add, ars, dtau, nd, _ = _oracle_added(c, FT, m, ndmode)
+    dq, drs, conv = _device_side(vsm, arch, c, FT, rs, m)
+    pr = vsm.CoreRTRaman.AddedLayerRS(FT, arch, len(SHIFTS), c["N"], c["S"])
+    vsm.CoreRTRaman.elemental_inelastic_(drs, conv(c["tau_sum"]), conv(dtau), conv(np.ascontiguousarray(c["F0"].T)), m, nd, dq, pr)
+    mats = ("ier_mp", "iet_pp") + (("ier_pm", "iet_mm") if (nd < 1 or c["pol"].n == 1) else ())
+    _check_rs(vsm, pr, ars, 1e-12 if FT == np.float64 else 2e-5, mats, ("ieJ0_p", "ieJ0_m"))
+    # out-of-band couplings are exactly zero
+    assert float(pr.ier_mp[5].abs().max()) == 0.0 and float(pr.ieJ0_p[5].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+@pytest.mark.parametrize("pol,l_trunc", [("I", 7), ("IQU", 7), ("IQU", 35)])
+def test_doubling_inelastic(vsm, arch, FT, pol, l_trunc):
+    S = 14 if l_trunc < 20 else 9
+    c = _setup(vsm, arch, FT, pol, S=S, l_trunc=l_trunc, seed=3)
+    nd = 5
+    rs, add, ars, dtau, nd, _ = _oracle_added(c, FT, 0, nd)
+    pa, pr = _upload_added(vsm, arch, add, ars, FT)
+    dq, drs, conv = _device_side(vsm, arch, c, FT, rs, 0)
+    expk = np.exp(-dtau / FT(c["qp"].mu0)).astype(FT)
+    OR.doubling_inelastic(rs, c["pol"], expk, nd, add, ars, FT)
+    vsm.CoreRTRaman.doubling_inelastic_(drs, c["hpol"], conv(expk), nd, pa, pr)
+    tol = TOL[FT]
+    _check_rs(vsm, pr, ars, tol, ("ier_mp", "iet_pp", "ier_pm", "iet_mm"), ("ieJ0_p", "ieJ0_m"))
+    f = vsm.CoreRT.from_device_matrix
+    for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+        assert _rel(f(getattr(pa, k)), getattr(add, k)) <= tol, k
+    for k in ("j0_p", "j0_m"):
+        assert _rel(vsm.Architectures.to_host(getattr(pa, k)), getattr(add, k)) <= tol, k
+
+
+def _random_composite(c, FT, rng):
+    S, N, K = c["S"], c["N"], len(SHIFTS)
+    comp = O.make_composite_layer(FT, N, S)
+    crs = OR.make_composite_layer_rs(FT, K, N, S)
+    for k in ("R_mp", "R_pm"):
+        getattr(comp, k)[...] = 0.3 * rng.random((S, N, N)) / N
+    for k in ("T_pp", "T_mm"):
+        getattr(comp, k)[...] = 0.3 * rng.random((S, N, N)) / N + 0.6 * np.eye(N)[None]
+    comp.J0_p[...] = rng.random((S, N))
+    comp.J0_m[...] = rng.random((S, N))
+    for dn, sh in enumerate(SHIFTS):
+        n0, n1 = OR.get_n0_n1(S, int(sh))
+        L = n1.stop - n1.start
+        if L <= 0:
+            continue
+        for k in ("ieR_mp", "ieR_pm", "ieT_pp", "ieT_mm"):
+            getattr(crs, k)[dn, n1] = 0.05 * rng.standard_normal((L, N, N)) / N
+        crs.ieJ0_p[dn, n1] = 0.05 * rng.standard_normal((L, N))
+        crs.ieJ0_m[dn, n1] = 0.05 * rng.standard_normal((L, N))
+    return comp, crs
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+@pytest.mark.parametrize("pol,l_trunc,surface", [("I", 7, False), ("IQU", 7, False), ("IQU", 7, True), ("IQU", 35, False)])
+def test_interaction_inelastic(vsm, arch, FT, pol, l_trunc, surface):
+    CR, RR = vsm.CoreRT, vsm.CoreRTRaman
+    S = 14 if l_trunc < 20 else 9
+    c = _setup(vsm, arch, FT, pol, S=S, l_trunc=l_trunc, seed=5)
+    rs, add, ars, dtau, nd, _ = _oracle_added(c, FT, 0, 4)
+    expk = np.exp(-dtau / FT(c["qp"].mu0)).astype(FT)
+    OR.doubling_inelastic(rs, c["pol"], expk, nd, add, ars, FT)
+    if surface:
+        O.create_surface_layer_lambertian(0.3, add, 0, c["pol"], c["qp"], c["tau_sum"], FT)
+        for k in ("ier_mp", "iet_pp", "ier_pm", "iet_mm", "ieJ0_p", "ieJ0_m"):
+            getattr(ars, k)[...] = 0
+    comp, crs = _random_composite(c, FT, c["rng"])
+    conv = vsm.Architectures.array_type(arch)
+    # device copies
+    pa, pr = _upload_added(vsm, arch, add, ars, FT)
+    if surface:
+        ps = CR.make_added_layer(FT, arch, (c["N"], c["N"]), S, shared=True)
+        for k in ("r_mp", "t_pp", "r_pm", "t_mm"):
+            getattr(ps, k).copy_(CR.to_device_matrix(getattr(add, k)[:1], arch, FT))
+        ps.j0_p.copy_(conv(add.j0_p))
+        ps.j0_m.copy_(conv(add.j0_m))
+        pa = ps
+    pc = CR.make_composite_layer(FT, arch, (c["N"], c["N"]), S)
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        getattr(pc, k).copy_(CR.to_device_matrix(getattr(comp, k), arch, FT))
+    pc.J0_p.copy_(conv(comp.J0_p))
+    pc.J0_m.copy_(conv(comp.J0_m))
+    pcr = RR.CompositeLayerRS(FT, arch, len(SHIFTS), c["N"], S)
+    for k in ("ieR_mp", "ieR_pm", "ieT_pp", "ieT_mm"):
+        getattr(pcr, k).copy_(_m4(vsm, arch, getattr(crs, k), FT))
+    pcr.ieJ0_p.copy_(conv(crs.ieJ0_p))
+    pcr.ieJ0_m.copy_(conv(crs.ieJ0_m))
+    dq, drs, _ = _device_side(vsm, arch, c, FT, rs, 0)
+    OR.interaction_inelastic_11(rs, comp, crs, add, ars, FT)
+    RR.interaction_inelastic_(drs, "11", pc, pcr, pa, pr)
+    tol = TOL[FT]
+    _check_rs(vsm, pcr, crs, tol, ("ieR_mp", "ieR_pm", "ieT_pp", "ieT_mm"), ("ieJ0_p", "ieJ0_m"))
+    f = CR.from_device_matrix
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        assert _rel(f(getattr(pc, k)), getattr(comp, k)) <= tol, k
+    for k in ("J0_p", "J0_m"):
+        assert _rel(vsm.Architectures.to_host(getattr(pc, k)), getattr(comp, k)) <= tol, k
+    with pytest.raises(vsm.VSMError):
+        RR.interaction_inelastic_(drs, "10", pc, pcr, pa, pr)
+
+
+def _raman_models(vsm, arch, pol, l_trunc, S, L, FT, uniform=False, seed=11, m_max=2):
+    rng = np.random.default_rng(seed)
+    tau_rayl = np.tile(np.linspace(0.02, 0.05, L), (S, 1))
+    if uniform:
+        tau_abs = np.tile(np.linspace(0.03, 0.01, L), (S, 1))
+    else:
+        tau_abs = (10.0 ** rng.uniform(-3, 0.3, (S, 1))) * np.linspace(0.5, 1.5, L)[None, :] / L
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.12, m_max=m_max)
+    om = O.build_model(pol, l_trunc, 35.0, [20.0, 50.0], [0.0, 60.0], FT=FT, **kw)
+    om.varpi_cabannes = 0.96
+    pm = vsm.host_model.model_from_arrays(arch, pol, l_trunc, 35.0, [20.0, 50.0], [0.0, 60.0], float_type=FT, **kw)
+    pm.varpi_Cabannes = 0.96
+    F0 = np.zeros((om.pol.n, S))
+    F0[0] = 0.8 + 0.4 * rng.random(S)
+    om.F0, pm.F0 = F0, F0
+    return om, pm
+
+
+@pytest.mark.parametrize("FT,pol,l_trunc,S", [(np.float64, "I", 7, 24), (np.float64, "IQU", 7, 24), (np.float64, "IQU", 35, 8),
+                                              (np.float32, "IQU", 7, 24)])
+def test_rt_run_rrs_end_to_end(vsm, arch, FT, pol, l_trunc, S):
+    """rt_run(RS_type::RRS, model, iBand) vs the oracle: spectrally varying absorption and source, 3 layers, Lambertian."""
+    om, pm = _raman_models(vsm, arch, pol, l_trunc, S, 3, FT)
+    graman = O.get_greek_rayleigh(6.0 / 7.0 * 0.5)
+    ors = OR.RRS(i_shift=SHIFTS, varpi_ie=W_IE, greek_raman=graman)
+    Hm = vsm.host_model
+    prs = vsm.CoreRTRaman.RRS(SHIFTS, W_IE, Hm.GreekCoefs(**vars(graman)))
+    tro, trg = [], []
+    ref = OR.rt_run_rrs(om, ors, trace=tro)
+    got = vsm.CoreRTRaman.rt_run(prs, pm, 1, trace=trg)
+    assert [t["ndoubl"] for t in tro] == [t["ndoubl"] for t in trg]
+    tol = 1e-8 if FT == np.float64 else 1e-2
+    for name, g, r in zip(("R", "T", "ieR", "ieT"), got, ref):
+        assert _rel(g, r) <= tol, (name, _rel(g, r))
+    assert np.max(np.abs(ref[2])) > 1e-5
+
+
+def test_rt_run_rrs_perturbation_property_large(vsm, arch):
+    """Size-independent property at S = 96, K = 7, N = 24: on a spectrally uniform atmosphere with the Raman phase
+    matrix equal to the elastic one, ieR(n1) = dR/d(varpi_Cabannes) * sum of the in-band varpi_ie (first-order
+    perturbation identity); the derivative comes from central differences of the DEVICE elastic rt_run."""
+    FT, S, L = np.float64, 96, 3
+    om, pm = _raman_models(vsm, arch, "IQU", 7, S, L, FT, uniform=True)
+    pm.F0 = None
+    Hm = vsm.host_model
+    fsc = pm.tau_rayl / (pm.tau_rayl + pm.tau_abs)
+    prs = vsm.CoreRTRaman.RRS(SHIFTS, W_IE, pm.greek_rayleigh, fscattRayl=fsc)
+    R, T, ieR, ieT = vsm.CoreRTRaman.rt_run(prs, pm, 1)
+    h = 1e-5
+    pm.varpi_Cabannes = 0.96 + h
+    Rp, Tp = vsm.CoreRT.rt_run(pm)
+    pm.varpi_Cabannes = 0.96 - h
+    Rm, Tm = vsm.CoreRT.rt_run(pm)
+    dR, dT = (Rp - Rm) / (2 * h), (Tp - Tm) / (2 * h)
+    wsum = np.array([sum(w for s, w in zip(SHIFTS, W_IE) if 0 <= n1 + s < S) for n1 in range(S)])
+    assert _rel(ieR, dR * wsum[None, None, :]) <= 5e-7
+    assert _rel(ieT, dT * wsum[None, None, :]) <= 5e-7

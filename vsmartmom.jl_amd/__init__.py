@@ -10,6 +10,8 @@ Sub-modules
     Architectures   CPU()/GPU() dispatch surface (src/Architectures.jl)
     CoreRT          batched_mul / batch_inv_ / elemental_ / doubling_ / interaction_ / rt_kernel_ / rt_run
     host_model      host-side producers of the hot path's inputs (streams, Z moments, layer mixing)
+    CoreRTLin       linearized (Jacobian) pass: rt_run(model, lin_model, ...)
+    CoreRTRaman     rotational-Raman pass: rt_run(RS_type::RRS, model, iBand)
     parallel        spectral-axis sharding over the GPUs of one node (torch.distributed / RCCL)
 """
 from . import _lib, host_model  # noqa: F401
@@ -17,6 +19,7 @@ from . import architectures as Architectures  # noqa: F401
 from . import core_rt as CoreRT  # noqa: F401
 from . import parallel  # noqa: F401
 from . import core_rt_lin as CoreRTLin  # noqa: F401
+from . import core_rt_raman as CoreRTRaman  # noqa: F401
 from ._lib import VSMError, LIB_PATH  # noqa: F401
 
 __version__ = "0.1.0"

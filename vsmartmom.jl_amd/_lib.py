@@ -49,6 +49,21 @@ class vsm_composite_lin(C.Structure):
                 ("J0_p", C.c_void_p), ("J0_m", C.c_void_p), ("P", C.c_int), ("reserved", C.c_int)]
 
 
+class vsm_added_rs(C.Structure):
+    _fields_ = [("ier_mp", C.c_void_p), ("iet_pp", C.c_void_p), ("ier_pm", C.c_void_p), ("iet_mm", C.c_void_p),
+                ("ieJ0_p", C.c_void_p), ("ieJ0_m", C.c_void_p), ("K", C.c_int), ("reserved", C.c_int)]
+
+
+class vsm_composite_rs(C.Structure):
+    _fields_ = [("ieR_mp", C.c_void_p), ("ieR_pm", C.c_void_p), ("ieT_pp", C.c_void_p), ("ieT_mm", C.c_void_p),
+                ("ieJ0_p", C.c_void_p), ("ieJ0_m", C.c_void_p), ("K", C.c_int), ("reserved", C.c_int)]
+
+
+class vsm_rrs(C.Structure):
+    _fields_ = [("shift", C.c_void_p), ("varpi_ie", C.c_void_p), ("fscatt", C.c_void_p), ("Zpp", C.c_void_p),
+                ("Zmp", C.c_void_p)]
+
+
 _P, _I, _LL, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
 
 # name -> (restype, argtypes); {T} expands to f64/f32, {R} to c_double/c_float
@@ -80,6 +95,13 @@ _SIGS = {
     "vsm_copy_added_to_composite_lin_{T}": (_I, [_I, _I, _P, _P, _P]),
     "vsm_lambertian_surface_lin_{T}": (_I, [_P, _I, _I, "{R}", _I, _P, _P, _I, _P, _P, _P, _P]),
     "vsm_postprocess_vza_lin_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_doubling_inelastic_work_elems": (_SZ, [_I, _I, _I]),
+    "vsm_interaction_inelastic_work_elems": (_SZ, [_I, _I, _I]),
+    "vsm_elemental_inelastic_rrs_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_doubling_inelastic_rrs_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_interaction_inelastic_rrs_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_copy_added_to_composite_ie_{T}": (_I, [_I, _I, _P, _P, _P]),
+    "vsm_postprocess_vza_ie_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_test_lds_mm_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_test_lds_inv_{T}": (_I, [_I, _I, _P, _P, _I, _P, _P]),
 }

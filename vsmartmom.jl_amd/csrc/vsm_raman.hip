@@ -1,0 +1,637 @@
+// Rotational-Raman (RRS) pass of the CoreRT hot path, operator level.
+//
+//   vsm_elemental_inelastic_rrs   elemental_inelastic!(::RRS)            elemental_inelastic.jl:23-105
+//   vsm_doubling_inelastic_rrs    doubling_helper!(::RRS)                doubling_inelastic.jl:13-164
+//   vsm_interaction_inelastic_rrs interaction_helper!(::RRS, ::_11)      interaction_inelastic.jl:319-521
+//   vsm_copy_added_to_composite_ie, vsm_postprocess_vza_ie               rt_helpers.jl:222-228, postprocessing_vza.jl:117-151
+//
+// The reference walks the Raman offsets dn one at a time on the host and, per offset, multiplies views
+// A[:,:,n1,dn] (x) B[:,:,n0] with n0 = n1 + i_lambda1lambda0[dn].  Here ONE launch covers every
+// (n1, dn) pair: k_gemm_rs resolves, per workgroup, where each operand block lives -- the 3-D elastic
+// arrays at the recipient point n1 or the donor point n0, or the 4-D inelastic arrays at (n1, dn) --
+// and skips pairs whose donor is out of band, so the launch count of a layer step does not depend on
+// the number of Raman lines.  Inelastic arrays are [N,N,S,K] column-major like the reference's.
+#include "vsm_internal.h"
+
+namespace vsm {
+
+enum rs_kind { RS_N1 = 0, RS_N0 = 1, RS_4D = 2 };
+
+template <typename T>
+struct rs_op {
+  const T* p;
+  int kind;
+  long long stride;  // elements between consecutive spectral blocks (0 = one block shared by all points)
+};
+template <typename T>
+static rs_op<T> at_n1(const T* p, long long stride) { return rs_op<T>{p, RS_N1, stride}; }
+template <typename T>
+static rs_op<T> at_n0(const T* p, long long stride) { return rs_op<T>{p, RS_N0, stride}; }
+template <typename T>
+static rs_op<T> at_4d(const T* p, long long stride) { return rs_op<T>{p, RS_4D, stride}; }
+
+template <typename T>
+__device__ __forceinline__ const T* rs_block(const rs_op<T>& o, int n1, int n0, int dn, int S) {
+  if (o.kind == RS_N1) return o.p + (long long)n1 * o.stride;
+  if (o.kind == RS_N0) return o.p + (long long)n0 * o.stride;
+  return o.p + ((long long)n1 + (long long)S * dn) * o.stride;
+}
+
+// C[:,:,n1,dn] = alpha * A * B + beta * D      for every in-band (n1, dn); out-of-band blocks are left
+// untouched (zero_oob = 0) or zeroed (zero_oob = 1).  One wave per 16x16 output tile.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_rs(int M, int Nc, int K, int S, const int* __restrict__ shift, rs_op<T> A,
+                                                 rs_op<T> B, T* C, T alpha, rs_op<T> D, T beta, int zero_oob) {
+  const int n1 = blockIdx.y, dn = blockIdx.z;
+  const int n0 = n1 + shift[dn];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tilesM = (M + 15) >> 4, tilesN = (Nc + 15) >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= tilesM * tilesN) return;
+  const int ti = tile % tilesM, tj = tile / tilesM;
+  T* Cs = C + ((long long)n1 + (long long)S * dn) * ((long long)M * Nc);
+  const int col = tj * 16 + (lane & 15);
+  if (n0 < 0 || n0 >= S) {
+    if (zero_oob) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = ti * 16 + mfma<T>::crow(lane, r);
+        if (row < M && col < Nc) Cs[row + (long long)M * col] = T(0);
+      }
+    }
+    return;
+  }
+  const T* As = rs_block(A, n1, n0, dn, S);
+  const T* Bs = rs_block(B, n1, n0, dn, S);
+  const int ai = ti * 16 + (lane & 15);
+  const int kq = lane >> 4;
+  typename mfma<T>::acc_t acc = acc_zero<T>();
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const int k = k0 + kq;
+    const T a = (ai < M && k < K) ? As[ai + (long long)M * k] : T(0);
+    const T b = (col < Nc && k < K) ? Bs[k + (long long)K * col] : T(0);
+    acc = mfma<T>::mma(a, b, acc);
+  }
+  const T* Ds = D.p ? rs_block(D, n1, n0, dn, S) : nullptr;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = ti * 16 + mfma<T>::crow(lane, r);
+    if (row < M && col < Nc) {
+      T v = alpha * acc[r];
+      if (Ds) v += beta * Ds[row + (long long)M * col];
+      Cs[row + (long long)M * col] = v;
+    }
+  }
+}
+
+template <typename T>
+static int gemm_rs(int M, int Nc, int K, int S, int Kr, const int* shift, rs_op<T> A, rs_op<T> B, T* C, rs_op<T> D,
+                   hipStream_t st, int zero_oob = 0) {
+  if (S <= 0 || Kr <= 0) return VSM_OK;
+  const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
+  dim3 grid((tiles + 3) / 4, S, Kr);
+  hipLaunchKernelGGL(k_gemm_rs<T>, grid, dim3(256), 0, st, M, Nc, K, S, shift, A, B, C, T(1), D, T(1), zero_oob);
+  VSM_LAUNCH_CHECK("k_gemm_rs");
+  return VSM_OK;
+}
+
+// dst[:, n1, dn] = src[:, n1, dn] (* scale[n0])   for in-band pairs; `per` elements per block
+template <typename T>
+__global__ void k_copy_rs(long long per, int S, const int* __restrict__ shift, const T* __restrict__ src,
+                          const T* __restrict__ scale_n0, T* dst) {
+  const int n1 = blockIdx.y, dn = blockIdx.z;
+  const int n0 = n1 + shift[dn];
+  if (n0 < 0 || n0 >= S) return;
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= per) return;
+  const long long o = ((long long)n1 + (long long)S * dn) * per + e;
+  dst[o] = scale_n0 ? src[o] * scale_n0[n0] : src[o];
+}
+template <typename T>
+static int copy_rs(long long per, int S, int Kr, const int* shift, const T* src, const T* scale_n0, T* dst, hipStream_t st) {
+  if (S <= 0 || Kr <= 0) return VSM_OK;
+  hipLaunchKernelGGL(k_copy_rs<T>, dim3((unsigned)((per + 255) / 256), S, Kr), dim3(256), 0, st, per, S, shift, src, scale_n0,
+                     dst);
+  VSM_LAUNCH_CHECK("k_copy_rs");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// elemental_inelastic!(::RRS)
+// ---------------------------------------------------------------------------
+template <typename T>
+struct tol;
+template <>
+struct tol<double> {
+  static __device__ __forceinline__ double weight() { return 1e-8; }  // rt_helpers.jl:56-58
+  static __device__ __forceinline__ double close() { return 1e-8; }   // :66-68
+  static __device__ __forceinline__ double loose() { return 1e-6; }   // :76
+};
+template <>
+struct tol<float> {
+  static __device__ __forceinline__ float weight() { return 1e-8f; }
+  static __device__ __forceinline__ float close() { return 1e-8f; }
+  static __device__ __forceinline__ float loose() { return 1e-6f; }
+};
+
+// get_elem_rt_RRS! (elemental_inelastic.jl:117-206) + apply_D_elemental_RRS! (:619-637)
+template <typename T>
+__global__ __launch_bounds__(256) void k_elemental_rrs(int N, int ns, int S, int m, int ndoubl, const int* __restrict__ shift,
+                                                       const T* __restrict__ varpi_ie, const T* __restrict__ fscatt,
+                                                       const T* __restrict__ dtau, const T* __restrict__ Zpp,
+                                                       const T* __restrict__ Zmp, const T* __restrict__ mu,
+                                                       const T* __restrict__ wt, T* ier_mp, T* iet_pp, T* ier_pm, T* iet_mm) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const int n1 = blockIdx.y, dn = blockIdx.z;
+  const int n0 = n1 + shift[dn];
+  const int i = e % N, j = e / N;
+  T r = T(0), t = T(0);
+  const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
+  if (n0 >= 0 && n0 < S && wct > tol<T>::weight()) {
+    const T mi = mu[i], mj = mu[j];
+    const T d1 = dtau[n1], d0 = dtau[n0];
+    const T w = varpi_ie[dn], f = fscatt[n0];
+    const T ratio = d1 / d0;
+    r = f * w * Zmp[e] * (T(1) / ((mi / mj) + ratio)) * (-expm1(-((d1 / mi) + (d0 / mj)))) * wct;
+    if (mi == mj) {
+      if (fabs(d0 - d1) > tol<T>::loose())
+        t = w * f * Zpp[e] * wct * expdiff_neg<T>(d1 / mi, d0 / mj) / (T(1) - ratio);
+      else
+        t = (d0 / mi) * w * f * Zpp[e] * wct * exp(-d0 / mj);
+    } else {
+      const T den = (mi / mj) - ratio;
+      if (fabs(den) < tol<T>::close())
+        t = (d0 / mi) * w * f * Zpp[e] * wct * exp(-d0 / mj);
+      else
+        t = w * f * Zpp[e] * (T(1) / den) * wct * expdiff_neg<T>(d1 / mi, d0 / mj);
+    }
+  }
+  const long long o = ((long long)n1 + (long long)S * dn) * N * N + e;
+  if (ns == 1) {
+    ier_mp[o] = r;
+    iet_pp[o] = t;
+    ier_pm[o] = r;
+    iet_mm[o] = t;
+  } else if (ndoubl < 1) {
+    const bool same = is_uv_row(i, ns) == is_uv_row(j, ns);
+    ier_mp[o] = r;
+    iet_pp[o] = t;
+    ier_pm[o] = same ? r : -r;
+    iet_mm[o] = same ? t : -t;
+  } else {
+    ier_mp[o] = is_uv_row(i, ns) ? -r : r;
+    iet_pp[o] = t;
+  }
+}
+
+// get_elem_rt_SFI_RRS! (elemental_inelastic.jl:479-610)
+template <typename T>
+__global__ __launch_bounds__(256) void k_elemental_sfi_rrs(int N, int ns, int S, int m, int ndoubl, int i_mu0,
+                                                           const int* __restrict__ shift, const T* __restrict__ varpi_ie,
+                                                           const T* __restrict__ fscatt, const T* __restrict__ dtau,
+                                                           const T* __restrict__ tau_sum, const T* __restrict__ F0,
+                                                           const T* __restrict__ Zpp, const T* __restrict__ Zmp,
+                                                           const T* __restrict__ mu, T* ieJ0_p, T* ieJ0_m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int n1 = blockIdx.y, dn = blockIdx.z;
+  const int n0 = n1 + shift[dn];
+  T jp = T(0), jm = T(0);
+  if (n0 >= 0 && n0 < S) {
+    const int i_start = ns * i_mu0;
+    const T wct02 = (m == 0) ? T(0.5) : T(0.25);
+    T zp = 0, zm = 0;
+    for (int q = 0; q < ns; ++q) {
+      const long long zo = i + (long long)N * (i_start + q);
+      const T f0 = F0[q + (long long)ns * n0];
+      zp += Zpp[zo] * f0;
+      zm += Zmp[zo] * f0;
+    }
+    const T mi = mu[i], ms = mu[i_start];
+    const T d1 = dtau[n1], d0 = dtau[n0];
+    const T w = varpi_ie[dn], f = fscatt[n0];
+    const T ratio = d1 / d0;
+    if (i >= i_start && i < i_start + ns) {
+      if (fabs(d0 - d1) > tol<T>::close())
+        jp = w * f * zp * wct02 * expdiff_neg<T>(d1 / mi, d0 / mi) / (T(1) - ratio);
+      else
+        jp = (d0 / mi) * wct02 * w * f * zp * exp(-d0 / mi);
+    } else {
+      const T den = (mi / ms) - ratio;
+      if (fabs(den) < tol<T>::close())
+        jp = (d0 / mi) * wct02 * w * f * zp * exp(-d0 / ms);
+      else
+        jp = wct02 * w * f * zp * (T(1) / den) * expdiff_neg<T>(d1 / mi, d0 / ms);
+    }
+    jm = wct02 * w * f * zm * (T(1) / ((mi / ms) + ratio)) * (-expm1(-((d1 / mi) + (d0 / ms))));
+    const T att = exp(-tau_sum[n0] / ms);
+    jp *= att;
+    jm *= att;
+  }
+  if (ndoubl >= 1 && is_uv_row(i, ns)) jm = -jm;
+  const long long o = ((long long)n1 + (long long)S * dn) * N + i;
+  ieJ0_p[o] = jp;
+  ieJ0_m[o] = jm;
+}
+
+template <typename T>
+struct added_rs {
+  T *ier_mp, *iet_pp, *ier_pm, *iet_mm, *ieJ0_p, *ieJ0_m;
+  int K;
+};
+template <typename T>
+struct composite_rs {
+  T *ieR_mp, *ieR_pm, *ieT_pp, *ieT_mm, *ieJ0_p, *ieJ0_m;
+  int K;
+};
+template <typename T>
+struct rrs_in {
+  const int* shift;   // device int[K]
+  const T* varpi_ie;  // device [K]
+  const T* fscatt;    // device [S]
+  const T* Zpp;       // device [N,N]
+  const T* Zmp;
+};
+
+template <typename T>
+static int elemental_inelastic_rrs(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* tau_sum, const T* F0,
+                                   const rrs_in<T>& rs, const added_rs<T>& a, hipStream_t st) {
+  if (S <= 0 || a.K <= 0) return VSM_OK;
+  const int N = q.N;
+  hipLaunchKernelGGL(k_elemental_rrs<T>, dim3((N * N + 255) / 256, S, a.K), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+                     rs.shift, rs.varpi_ie, rs.fscatt, dtau, rs.Zpp, rs.Zmp, q.mu, q.wt, a.ier_mp, a.iet_pp, a.ier_pm,
+                     a.iet_mm);
+  VSM_LAUNCH_CHECK("k_elemental_rrs");
+  hipLaunchKernelGGL(k_elemental_sfi_rrs<T>, dim3((N + 255) / 256, S, a.K), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+                     q.i_mu0, rs.shift, rs.varpi_ie, rs.fscatt, dtau, tau_sum, F0, rs.Zpp, rs.Zmp, q.mu, a.ieJ0_p, a.ieJ0_m);
+  VSM_LAUNCH_CHECK("k_elemental_sfi_rrs");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// doubling_helper!(::RRS)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_scale_vec(int N, int S, const T* __restrict__ expk, const T* __restrict__ a, T* out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)N * S) return;
+  out[e] = a[e] * expk[e / N];
+}
+template <typename T>
+__global__ void k_square_v(int S, T* x) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < S) x[s] = x[s] * x[s];
+}
+// apply_D_matrix! + apply_D_matrix_SFI! on a batch of B blocks (doubling.jl:178-252; for the 4-D inelastic
+// arrays apply_D_IE_RRS! / apply_D_SFI_IE_RRS!, doubling_inelastic.jl:336-356,408-416, with B = S*K)
+template <typename T>
+__global__ void k_apply_D_batch(int N, int ns, T* r_mp, const T* __restrict__ t_pp, T* r_pm, T* t_mm, T* j0_m) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * N) return;
+  const long long b = blockIdx.y;
+  const int i = e % N, j = e / N;
+  const long long o = b * N * N + e;
+  const bool ui = is_uv_row(i, ns), uj = is_uv_row(j, ns);
+  if (ns == 1) {
+    r_pm[o] = r_mp[o];
+    t_mm[o] = t_pp[o];
+    return;
+  }
+  T r = r_mp[o];
+  if (ui) r = -r;
+  r_mp[o] = r;
+  const T t = t_pp[o];
+  r_pm[o] = (ui == uj) ? r : -r;
+  t_mm[o] = (ui == uj) ? t : -t;
+  if (j == 0 && ui) j0_m[b * N + i] = -j0_m[b * N + i];
+}
+
+template <typename T>
+static size_t doubling_rs_work_elems(int N, int S, int K) {
+  const size_t NN = (size_t)N * N;
+  return 7 * NN * S + 6 * (size_t)N * S + 4 * NN * S * K + 5 * (size_t)N * S * K;
+}
+
+template <typename T>
+static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, const int* shift, const added<T>& a,
+                                  const added_rs<T>& ie, T* work, hipStream_t st) {
+  if (ndoubl == 0 || S <= 0) return VSM_OK;  // doubling_inelastic.jl:35 (returns before apply_D)
+  const int K = ie.K;
+  const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
+  T* p = work;
+  auto take = [&](long long n) { T* r = p; p += n; return r; };
+  T *gp = take(per), *ttg = take(per), *gt = take(per), *gr = take(per), *grt = take(per), *tM = take(per), *tM2 = take(per);
+  T *j1p = take(pv), *j1m = take(pv), *tmp1 = take(pv), *tmp2 = take(pv), *u = take(pv), *u2 = take(pv);
+  T *W1 = take(per * K), *W2 = take(per * K), *W3 = take(per * K), *W4 = take(per * K);
+  T *ieJ1p = take(pv * K), *ieJ1m = take(pv * K), *V1 = take(pv * K), *V2 = take(pv * K), *V3 = take(pv * K);
+  const T* nul = nullptr;
+  const T one = T(1), zero = T(0);
+  const rs_op<T> none{nullptr, 0, 0};
+  int rc;
+#define G3(...) if ((rc = gemm<T>(__VA_ARGS__, st))) return rc
+#define G4(M_, Nc_, A_, B_, C_, D_) if ((rc = gemm_rs<T>(M_, Nc_, N, S, K, shift, A_, B_, C_, D_, st))) return rc
+  const dim3 gv((unsigned)((pv + 255) / 256));
+  for (int n = 0; n < ndoubl; ++n) {
+    // gp = (I - r r)^-1 ; ttg = t gp
+    G3(N, N, N, S, a.r_mp, NN, a.r_mp, NN, tM, NN, -one, nul, 0, zero, one);
+    if ((rc = batch_inv<T>(N, S, tM, gp, nullptr, st))) return rc;
+    G3(N, N, N, S, a.t_pp, NN, gp, NN, ttg, NN, one, nul, 0, zero, zero);
+    // J1+- = J0+- expk
+    hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_p, j1p);
+    hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_m, j1m);
+    VSM_LAUNCH_CHECK("k_scale_vec");
+    // tmp1 = gp (J0+ + r J1-) ; tmp2 = gp (J1- + r J0+)
+    G3(N, 1, N, S, a.r_mp, NN, j1m, N, u, N, one, a.j0_p, N, one, zero);
+    G3(N, 1, N, S, gp, NN, u, N, tmp1, N, one, nul, 0, zero, zero);
+    G3(N, 1, N, S, a.r_mp, NN, a.j0_p, N, u2, N, one, j1m, N, one, zero);
+    G3(N, 1, N, S, gp, NN, u2, N, tmp2, N, one, nul, 0, zero, zero);
+    // ieJ1+- = ieJ0+- expk[n0]
+    if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_p, expk, ieJ1p, st))) return rc;
+    if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_m, expk, ieJ1m, st))) return rc;
+    // X = ier r[n0] + r[n1] ier -> W1
+    G4(N, N, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.r_mp, NN), W1, none);
+    G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ier_mp, NN), W1, at_4d<T>(W1, NN));
+    // tmp3 = ieJ1+ + ttg[n1] (ieJ0+ + r[n1] ieJ1- + ier J1-[n0] + X tmp1[n0]) + iet tmp1[n0]   -> V2
+    G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ieJ1m, N), V1, at_4d<T>(ie.ieJ0_p, N));
+    G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(j1m, N), V1, at_4d<T>(V1, N));
+    G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp1, N), V1, at_4d<T>(V1, N));
+    G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp1, N), V2, at_4d<T>(ieJ1p, N));
+    G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V2, at_4d<T>(V2, N));
+    // tmp4 = ieJ0- + ttg[n1] (ieJ1- + ier J0+[n0] + r[n1] ieJ0+ + X tmp2[n0]) + iet tmp2[n0]   -> V3
+    G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.j0_p, N), V1, at_4d<T>(ieJ1m, N));
+    G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ieJ0_p, N), V1, at_4d<T>(V1, N));
+    G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp2, N), V1, at_4d<T>(V1, N));
+    G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp2, N), V3, at_4d<T>(ie.ieJ0_m, N));
+    G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V3, at_4d<T>(V3, N));
+    if ((rc = copy_rs<T>(N, S, K, shift, V2, nul, ie.ieJ0_p, st))) return rc;
+    if ((rc = copy_rs<T>(N, S, K, shift, V3, nul, ie.ieJ0_m, st))) return rc;
+    // J0- += ttg (J1- + r J0+) ; J0+ = J1+ + ttg (J0+ + r J1-)      (u2, u from above: old J0+)
+    G3(N, 1, N, S, ttg, NN, u2, N, a.j0_m, N, one, a.j0_m, N, one, zero);
+    G3(N, 1, N, S, ttg, NN, u, N, a.j0_p, N, one, j1p, N, one, zero);
+    hipLaunchKernelGGL(k_square_v<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
+    VSM_LAUNCH_CHECK("k_square_v");
+    // gt = gp t ; gr = gp r ; grt = gr t
+    G3(N, N, N, S, gp, NN, a.t_pp, NN, gt, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
+    // tmp5 = ttg[n1] (iet + X gt[n0]) + iet gt[n0]   -> W3
+    G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gt, NN), W2, at_4d<T>(ie.iet_pp, NN));
+    G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(gt, NN), W3, none);
+    G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W2, NN), W3, at_4d<T>(W3, NN));
+    // tmp6 = ier + iet grt[n0] + ttg[n1] (r[n1] iet + (ier + X gr[n0]) t[n0])   -> W2
+    G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gr, NN), W2, at_4d<T>(ie.ier_mp, NN));
+    G4(N, N, at_4d<T>(W2, NN), at_n0<T>(a.t_pp, NN), W4, none);
+    G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.iet_pp, NN), W4, at_4d<T>(W4, NN));
+    G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(grt, NN), W2, at_4d<T>(ie.ier_mp, NN));
+    G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W4, NN), W2, at_4d<T>(W2, NN));
+    if ((rc = copy_rs<T>(NN, S, K, shift, W3, nul, ie.iet_pp, st))) return rc;
+    if ((rc = copy_rs<T>(NN, S, K, shift, W2, nul, ie.ier_mp, st))) return rc;
+    // r <- r + ttg r t ; t <- ttg t
+    G3(N, N, N, S, ttg, NN, a.r_mp, NN, tM, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, ttg, NN, a.t_pp, NN, tM2, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, tM, NN, a.t_pp, NN, a.r_mp, NN, one, a.r_mp, NN, one, zero);
+    if ((rc = copy_strided<T>(per, 1, tM2, 0, a.t_pp, st))) return rc;
+  }
+  const dim3 gm((unsigned)((NN + 255) / 256), S);
+  hipLaunchKernelGGL(k_apply_D_batch<T>, gm, dim3(256), 0, st, N, ns, a.r_mp, a.t_pp, a.r_pm, a.t_mm, a.j0_m);
+  const dim3 gk((unsigned)((NN + 255) / 256), (unsigned)((long long)S * K));
+  hipLaunchKernelGGL(k_apply_D_batch<T>, gk, dim3(256), 0, st, N, ns, ie.ier_mp, ie.iet_pp, ie.ier_pm, ie.iet_mm, ie.ieJ0_m);
+  VSM_LAUNCH_CHECK("k_apply_D_batch");
+  return VSM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// interaction_helper!(::RRS, ::ScatteringInterface_11)
+// ---------------------------------------------------------------------------
+template <typename T>
+static size_t interaction_rs_work_elems(int N, int S, int K) {
+  const size_t NN = (size_t)N * N;
+  return (8 * NN * S + 4 * (size_t)N * S) + 4 * NN * S * K + 2 * (size_t)N * S * K + (3 * NN * S + 2 * (size_t)N * S);
+}
+
+template <typename T>
+static int interaction_inelastic_rrs(int N, int S, const int* shift, const composite<T>& c, const composite_rs<T>& cie,
+                                     const added<T>& a, const added_rs<T>& aie, T* work, size_t elastic_work_elems,
+                                     hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int K = cie.K;
+  const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
+  const long long as = a.mat_stride;
+  T* p = work;
+  auto take = [&](long long n) { T* r = p; p += n; return r; };
+  T *G = take(per), *Tinv = take(per), *tM = take(per), *gA = take(per), *gB = take(per), *tM2 = take(per);
+  take(2 * per);  // (reserved)
+  T *v = take(pv), *u = take(pv);
+  take(2 * pv);
+  T *W1 = take(per * K), *W2 = take(per * K), *W3 = take(per * K), *W4 = take(per * K);
+  T *V1 = take(pv * K), *V2 = take(pv * K);
+  T* ework = p;
+  const T* nul = nullptr;
+  const T one = T(1), zero = T(0);
+  const rs_op<T> none{nullptr, 0, 0};
+  int rc;
+  // ---- pass 1: G1 = (I - r-+ R+-)^-1, T01 = T-- G1 ------------------------------------------------
+  G3(N, N, N, S, a.r_mp, as, c.R_pm, NN, tM, NN, -one, nul, 0, zero, one);
+  if ((rc = batch_inv<T>(N, S, tM, G, nullptr, st))) return rc;
+  G3(N, N, N, S, c.T_mm, NN, G, NN, Tinv, NN, one, nul, 0, zero, zero);
+  // v = G1 (j0- + r-+ J0+)
+  G3(N, 1, N, S, a.r_mp, as, c.J0_p, N, u, N, one, a.j0_m, N, one, zero);
+  G3(N, 1, N, S, G, NN, u, N, v, N, one, nul, 0, zero, zero);
+  // gA = G1 r-+ T++ ; gB = G1 t--
+  G3(N, N, N, S, G, NN, a.r_mp, as, tM, NN, one, nul, 0, zero, zero);
+  G3(N, N, N, S, tM, NN, c.T_pp, NN, gA, NN, one, nul, 0, zero, zero);
+  G3(N, N, N, S, G, NN, a.t_mm, as, gB, NN, one, nul, 0, zero, zero);
+  // Y = T01[n1] (ier R+-[n0] + r[n1] ieR+-) + ieT--   -> W2
+  G4(N, N, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.R_pm, NN), W1, none);
+  G4(N, N, at_n1<T>(a.r_mp, as), at_4d<T>(cie.ieR_pm, NN), W1, at_4d<T>(W1, NN));
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(W1, NN), W2, at_4d<T>(cie.ieT_mm, NN));
+  // ieJ0- = ieJ0- + T01[n1] (ier J0+[n0] + r[n1] ieJ0+ + iej0-) + Y v[n0]
+  G4(N, 1, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.J0_p, N), V1, at_4d<T>(aie.ieJ0_m, N));
+  G4(N, 1, at_n1<T>(a.r_mp, as), at_4d<T>(cie.ieJ0_p, N), V1, at_4d<T>(V1, N));
+  G4(N, 1, at_n1<T>(Tinv, NN), at_4d<T>(V1, N), V2, at_4d<T>(cie.ieJ0_m, N));
+  if ((rc = gemm_rs<T>(N, 1, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(v, N), cie.ieJ0_m, at_4d<T>(V2, N), st, 1))) return rc;
+  // ieR-+ = ieR-+ + T01[n1] (ier T++[n0] + r[n1] ieT++) + Y gA[n0]
+  G4(N, N, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.T_pp, NN), W3, none);
+  G4(N, N, at_n1<T>(a.r_mp, as), at_4d<T>(cie.ieT_pp, NN), W3, at_4d<T>(W3, NN));
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(W3, NN), W4, at_4d<T>(cie.ieR_mp, NN));
+  if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gA, NN), cie.ieR_mp, at_4d<T>(W4, NN), st, 1))) return rc;
+  // ieT-- = T01[n1] iet-- + Y gB[n0]
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(aie.iet_mm, NN), W3, none);
+  if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gB, NN), cie.ieT_mm, at_4d<T>(W3, NN), st, 1))) return rc;
+  // ---- pass 2: G2 = (I - R+- r-+)^-1, T21 = t++ G2 ------------------------------------------------
+  G3(N, N, N, S, c.R_pm, NN, a.r_mp, as, tM, NN, -one, nul, 0, zero, one);
+  if ((rc = batch_inv<T>(N, S, tM, G, nullptr, st))) return rc;
+  G3(N, N, N, S, a.t_pp, as, G, NN, Tinv, NN, one, nul, 0, zero, zero);
+  // v = G2 (J0+ + R+- j0-)
+  G3(N, 1, N, S, c.R_pm, NN, a.j0_m, N, u, N, one, c.J0_p, N, one, zero);
+  G3(N, 1, N, S, G, NN, u, N, v, N, one, nul, 0, zero, zero);
+  // gA = G2 T++ ; gB = G2 R+- t--
+  G3(N, N, N, S, G, NN, c.T_pp, NN, gA, NN, one, nul, 0, zero, zero);
+  G3(N, N, N, S, G, NN, c.R_pm, NN, tM2, NN, one, nul, 0, zero, zero);
+  G3(N, N, N, S, tM2, NN, a.t_mm, as, gB, NN, one, nul, 0, zero, zero);
+  // Y = T21[n1] (ieR+- r-+[n0] + R+-[n1] ier-+) + iet++   -> W2
+  G4(N, N, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.r_mp, as), W1, none);
+  G4(N, N, at_n1<T>(c.R_pm, NN), at_4d<T>(aie.ier_mp, NN), W1, at_4d<T>(W1, NN));
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(W1, NN), W2, at_4d<T>(aie.iet_pp, NN));
+  // ieJ0+ = iej0+ + T21[n1] (ieJ0+ + ieR+- j0-[n0] + R+-[n1] iej0-) + Y v[n0]
+  G4(N, 1, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.j0_m, N), V1, at_4d<T>(cie.ieJ0_p, N));
+  G4(N, 1, at_n1<T>(c.R_pm, NN), at_4d<T>(aie.ieJ0_m, N), V1, at_4d<T>(V1, N));
+  G4(N, 1, at_n1<T>(Tinv, NN), at_4d<T>(V1, N), V2, at_4d<T>(aie.ieJ0_p, N));
+  if ((rc = gemm_rs<T>(N, 1, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(v, N), cie.ieJ0_p, at_4d<T>(V2, N), st, 1))) return rc;
+  // ieR+- = ier+- + T21[n1] (ieR+- t--[n0] + R+-[n1] iet--) + Y gB[n0]     (before ieT++ is overwritten: independent)
+  G4(N, N, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.t_mm, as), W3, none);
+  G4(N, N, at_n1<T>(c.R_pm, NN), at_4d<T>(aie.iet_mm, NN), W3, at_4d<T>(W3, NN));
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(W3, NN), W4, at_4d<T>(aie.ier_pm, NN));
+  if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gB, NN), cie.ieR_pm, at_4d<T>(W4, NN), st, 1))) return rc;
+  // ieT++ = T21[n1] ieT++ + Y gA[n0]
+  G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(cie.ieT_pp, NN), W3, none);
+  if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gA, NN), cie.ieT_pp, at_4d<T>(W3, NN), st, 1))) return rc;
+  // ---- elastic part last (every inelastic right-hand side above used the pre-update composite) -----
+  (void)elastic_work_elems;
+  return interaction_generic<T>(VSM_IFACE_11, N, S, c, a, ework, st);
+}
+#undef G3
+#undef G4
+
+// postprocessing_vza!(::RRS) inelastic accumulation (postprocessing_vza.jl:139-142):
+// ieR[v,k,s] += w[v,k] * sum_dn ieJ0-[row0[v]+k, s, dn]
+struct pp_rs_args {
+  int row0[16];
+  double w[64];
+};
+template <typename T>
+__global__ void k_postprocess_rs(int N, int ns, int S, int K, int nV, pp_rs_args pa, const T* __restrict__ ieJ_m,
+                                 const T* __restrict__ ieJ_p, T* ieR, T* ieT) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)S * ns * nV) return;
+  const int v = (int)(e % nV), k = (int)((e / nV) % ns);
+  const long long s = e / ((long long)nV * ns);
+  T sm = 0, sp = 0;
+  for (int dn = 0; dn < K; ++dn) {
+    const long long o = (s + (long long)S * dn) * N + pa.row0[v] + k;
+    sm += ieJ_m[o];
+    sp += ieJ_p[o];
+  }
+  const T w = (T)pa.w[v + nV * k];
+  ieR[e] += w * sm;
+  ieT[e] += w * sp;
+}
+
+}  // namespace vsm
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace vsm;
+
+template <typename T, typename A>
+static added_rs<T> cvt_ars(const A* a) {
+  return added_rs<T>{a->ier_mp, a->iet_pp, a->ier_pm, a->iet_mm, a->ieJ0_p, a->ieJ0_m, a->K};
+}
+template <typename T, typename C>
+static composite_rs<T> cvt_crs(const C* c) {
+  return composite_rs<T>{c->ieR_mp, c->ieR_pm, c->ieT_pp, c->ieT_mm, c->ieJ0_p, c->ieJ0_m, c->K};
+}
+template <typename T, typename A>
+static added<T> cvt_added_rs(const A* a) {
+  added<T> r;
+  r.r_mp = a->r_mp; r.t_pp = a->t_pp; r.r_pm = a->r_pm; r.t_mm = a->t_mm; r.j0_p = a->j0_p; r.j0_m = a->j0_m;
+  r.mat_stride = a->mat_stride; r.d_symmetric = a->d_symmetric;
+  return r;
+}
+template <typename T, typename C>
+static composite<T> cvt_comp_rs(const C* c) {
+  composite<T> r;
+  r.R_mp = c->R_mp; r.R_pm = c->R_pm; r.T_pp = c->T_pp; r.T_mm = c->T_mm; r.J0_p = c->J0_p; r.J0_m = c->J0_m;
+  return r;
+}
+
+extern "C" {
+
+size_t vsm_doubling_inelastic_work_elems(int N, int S, int K) { return doubling_rs_work_elems<double>(N, S, K); }
+size_t vsm_interaction_inelastic_work_elems(int N, int S, int K) { return interaction_rs_work_elems<double>(N, S, K); }
+
+#define VSM_RAMAN_API(T, SFX)                                                                                          \
+  int vsm_elemental_inelastic_rrs_##SFX(const vsm_quad_##SFX* q, int S, int m, int ndoubl, const T* dtau,              \
+                                        const T* tau_sum, const T* F0, const vsm_rrs_##SFX* rs,                        \
+                                        const vsm_added_rs_##SFX* added_rs_, void* stream) {                           \
+    VSM_REQUIRE(q && rs && added_rs_ && dtau && tau_sum && F0, "elemental_inelastic_rrs: null argument");              \
+    VSM_REQUIRE(q->mu && q->wt && q->N > 0 && q->n_stokes >= 1 && q->n_stokes <= 4 && q->N % q->n_stokes == 0,         \
+                "elemental_inelastic_rrs: bad quad");                                                                  \
+    VSM_REQUIRE(rs->shift && rs->varpi_ie && rs->fscatt && rs->Zpp && rs->Zmp, "elemental_inelastic_rrs: null RRS field"); \
+    VSM_REQUIRE(added_rs_->K >= 0 && added_rs_->K <= 65535 && S >= 0 && S <= 65535,                                    \
+                "elemental_inelastic_rrs: S and K must be <= 65535");                                                  \
+    VSM_REQUIRE(added_rs_->ier_mp && added_rs_->iet_pp && added_rs_->ieJ0_p && added_rs_->ieJ0_m &&                    \
+                    (ndoubl >= 1 || (added_rs_->ier_pm && added_rs_->iet_mm)),                                          \
+                "elemental_inelastic_rrs: null AddedLayerRS field");                                                   \
+    quad<T> qq;                                                                                                        \
+    qq.mu = q->mu; qq.wt = q->wt; qq.N = q->N; qq.n_stokes = q->n_stokes; qq.i_mu0 = q->i_mu0; qq.mu0 = q->mu0;        \
+    const rrs_in<T> r{rs->shift, rs->varpi_ie, rs->fscatt, rs->Zpp, rs->Zmp};                                          \
+    return elemental_inelastic_rrs<T>(qq, S, m, ndoubl, dtau, tau_sum, F0, r, cvt_ars<T>(added_rs_), as_stream(stream)); \
+  }                                                                                                                    \
+  int vsm_doubling_inelastic_rrs_##SFX(int N, int n_stokes, int S, int ndoubl, T* expk, const int* shift,              \
+                                       const vsm_added_##SFX* added_, const vsm_added_rs_##SFX* added_rs_, T* work,    \
+                                       void* stream) {                                                                 \
+    VSM_REQUIRE(added_ && added_rs_ && shift && expk && (work || ndoubl == 0), "doubling_inelastic_rrs: null argument"); \
+    VSM_REQUIRE(added_->d_symmetric == 0 && added_->r_pm && added_->t_mm && added_->mat_stride == (long long)N * N,    \
+                "doubling_inelastic_rrs: a full (non d_symmetric, per-point) AddedLayer is required");                 \
+    VSM_REQUIRE(N > 0 && S >= 0 && S <= 65535 && added_rs_->K >= 0 && added_rs_->K <= 65535 &&                         \
+                    (long long)S * added_rs_->K <= 2147483647LL,                                                       \
+                "doubling_inelastic_rrs: bad N/S/K");                                                                  \
+    VSM_REQUIRE(added_rs_->ier_mp && added_rs_->iet_pp && added_rs_->ier_pm && added_rs_->iet_mm &&                    \
+                    added_rs_->ieJ0_p && added_rs_->ieJ0_m,                                                            \
+                "doubling_inelastic_rrs: null AddedLayerRS field");                                                    \
+    return doubling_inelastic_rrs<T>(N, n_stokes, S, ndoubl, expk, shift, cvt_added_rs<T>(added_), cvt_ars<T>(added_rs_), \
+                                     work, as_stream(stream));                                                         \
+  }                                                                                                                    \
+  int vsm_interaction_inelastic_rrs_##SFX(int iface, int N, int S, const int* shift, const vsm_composite_##SFX* comp,  \
+                                          const vsm_composite_rs_##SFX* comp_rs, const vsm_added_##SFX* added_,        \
+                                          const vsm_added_rs_##SFX* added_rs_, T* work, void* stream) {                \
+    VSM_REQUIRE(comp && comp_rs && added_ && added_rs_ && shift && work, "interaction_inelastic_rrs: null argument");  \
+    if (iface != VSM_IFACE_11) {                                                                                       \
+      set_error("interaction_inelastic_rrs: only ScatteringInterface_11 exists for RRS (rt_kernel.jl:365 hard-wires "  \
+                "scatter = true)");                                                                                    \
+      return VSM_ERR_UNSUPPORTED;                                                                                      \
+    }                                                                                                                  \
+    VSM_REQUIRE(added_->d_symmetric == 0 && added_->r_pm && added_->t_mm,                                              \
+                "interaction_inelastic_rrs: a full (non d_symmetric) AddedLayer is required");                         \
+    VSM_REQUIRE(N > 0 && S >= 0 && S <= 65535 && comp_rs->K == added_rs_->K && comp_rs->K >= 0 && comp_rs->K <= 65535, \
+                "interaction_inelastic_rrs: bad N/S/K");                                                               \
+    return interaction_inelastic_rrs<T>(N, S, shift, cvt_comp_rs<T>(comp), cvt_crs<T>(comp_rs), cvt_added_rs<T>(added_), \
+                                        cvt_ars<T>(added_rs_), work, 0, as_stream(stream));                            \
+  }                                                                                                                    \
+  int vsm_copy_added_to_composite_ie_##SFX(int N, int S, const vsm_added_rs_##SFX* a, const vsm_composite_rs_##SFX* c, \
+                                           void* stream) {                                                             \
+    VSM_REQUIRE(a && c && a->K == c->K && N > 0 && S >= 0, "copy_added_to_composite_ie: bad argument");                \
+    const long long per = (long long)N * N * S * a->K, pv = (long long)N * S * a->K;                                   \
+    hipStream_t st = as_stream(stream);                                                                                \
+    int rc;                                                                                                            \
+    if ((rc = copy_strided<T>(per, 1, a->iet_pp, 0, c->ieT_pp, st))) return rc;                                        \
+    if ((rc = copy_strided<T>(per, 1, a->iet_mm, 0, c->ieT_mm, st))) return rc;                                        \
+    if ((rc = copy_strided<T>(per, 1, a->ier_mp, 0, c->ieR_mp, st))) return rc;                                        \
+    if ((rc = copy_strided<T>(per, 1, a->ier_pm, 0, c->ieR_pm, st))) return rc;                                        \
+    if ((rc = copy_strided<T>(pv, 1, a->ieJ0_p, 0, c->ieJ0_p, st))) return rc;                                         \
+    return copy_strided<T>(pv, 1, a->ieJ0_m, 0, c->ieJ0_m, st);                                                        \
+  }                                                                                                                    \
+  int vsm_postprocess_vza_ie_##SFX(int N, int n_stokes, int S, int K, int nV, const int* row0_h, const T* w_h,         \
+                                   const T* ieJ0_m, const T* ieJ0_p, T* ieR, T* ieT, void* stream) {                   \
+    VSM_REQUIRE(row0_h && w_h && ieJ0_m && ieJ0_p && ieR && ieT, "postprocess_vza_ie: null argument");                 \
+    VSM_REQUIRE(nV >= 1 && nV <= 16 && n_stokes >= 1 && n_stokes <= 4, "postprocess_vza_ie: nV <= 16, nStokes <= 4");  \
+    if (S <= 0 || K <= 0) return VSM_OK;                                                                               \
+    pp_rs_args pa;                                                                                                     \
+    for (int v = 0; v < nV; ++v) {                                                                                     \
+      VSM_REQUIRE(row0_h[v] >= 0 && row0_h[v] + n_stokes <= N, "postprocess_vza_ie: row0 out of range");               \
+      pa.row0[v] = row0_h[v];                                                                                          \
+    }                                                                                                                  \
+    for (int i = 0; i < nV * n_stokes; ++i) pa.w[i] = (double)w_h[i];                                                  \
+    const long long tot = (long long)S * n_stokes * nV;                                                                \
+    hipLaunchKernelGGL(k_postprocess_rs<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream), N,   \
+                       n_stokes, S, K, nV, pa, ieJ0_m, ieJ0_p, ieR, ieT);                                              \
+    VSM_LAUNCH_CHECK("k_postprocess_rs");                                                                              \
+    return VSM_OK;                                                                                                     \
+  }
+VSM_RAMAN_API(double, f64)
+VSM_RAMAN_API(float, f32)
+
+}  // extern "C"
