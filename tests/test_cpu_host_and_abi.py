@@ -194,3 +194,77 @@ def test_scene_uses_global_ndoubl_for_shards(vsm):
     assert full == first_half_alone + 6
     src = open(os.path.join(ROOT, "vsmartmom.jl_amd", "core_rt.py")).read()
     assert "get_dtau_ndoubl(tau_full, varpi_full" in src  # Scene derives ndoubl before slicing
+
+
+def test_raman_halo_slices(vsm):
+    """Raman sharding host logic: the halo-extended slice holds every donor of every owned recipient."""
+    hs = vsm.parallel.raman_halo_slices
+    assert hs(100, slice(0, 50), [-3, 2, 7]) == (slice(0, 57), slice(0, 50))
+    assert hs(100, slice(50, 100), [-3, 2, 7]) == (slice(43, 100), slice(7, 57))
+    assert hs(100, slice(40, 60), [500, -1]) == (slice(39, 61), slice(1, 21))     # |shift| >= S never couples
+    assert hs(10, slice(10, 10), [1]) == (slice(10, 10), slice(0, 0))             # empty shard
+    S, shifts = 37, [-5, 4, 11]
+    for world in (2, 3, 8):
+        for rank in range(world):
+            own = vsm.parallel.shard_slice(S, rank, world)
+            ext, crop = hs(S, own, shifts)
+            assert (ext.start + crop.start, ext.start + crop.stop) == (own.start, own.stop) or own.stop <= own.start
+            for n1 in range(own.start, own.stop):
+                for s in shifts:
+                    if 0 <= n1 + s < S:
+                        assert ext.start <= n1 + s < ext.stop
+
+
+def _worker_raman(rank, world, port, q):
+    """2-rank gloo run of the Raman sharding: the HIP engine is replaced by the oracle on the halo-extended slice."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import vsmartmom_jl_amd as v
+    from oracle import vsm_oracle as Oo
+    from oracle import vsm_oracle_raman as ORr
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, L = 11, 2
+    rng = np.random.default_rng(2)
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))         # tau*varpi is spectrally flat -> ndoubl is shard-independent
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    shifts, w_ie = np.array([-2, 1, 3]), np.array([0.01, 0.02, 0.005])
+    geo = ("IQU", 7, 40.0, [30.0], [0.0])
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.01, albedo=0.2, m_max=1)
+    model = v.host_model.model_from_arrays(v.Architectures.CPU(), *geo, **kw)
+    greek = Oo.get_greek_rayleigh(0.2)
+    prs = v.CoreRTRaman.RRS(shifts, w_ie, None)
+
+    def run_oracle(sl):
+        kws = dict(kw, tau_rayl=tau_rayl[sl], tau_abs=tau_abs[sl])
+        return ORr.rt_run_rrs(Oo.build_model(*geo, **kws), ORr.RRS(i_shift=shifts, varpi_ie=w_ie, greek_raman=greek))
+
+    def oracle_executor(rs, mdl, sl):
+        ext, crop = v.parallel.raman_halo_slices(S, sl, rs.i_lambda1lambda0)
+        return tuple(torch.from_numpy(np.ascontiguousarray(a[:, :, crop].transpose(2, 1, 0))) for a in run_oracle(ext))
+
+    res = v.CoreRTRaman.rt_run_sharded(prs, model, rank=rank, world=world, executor=oracle_executor)
+    if rank == 0:
+        full = run_oracle(slice(0, S))
+        q.put(tuple(float(np.max(np.abs(a - b)) / np.max(np.abs(b))) for a, b in zip(res, full)))
+    else:
+        assert all(r is None for r in res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_raman_halo_shard_and_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_raman, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert max(res) <= 1e-13, res

@@ -289,3 +289,21 @@ def test_rt_run_rrs_perturbation_property_large(vsm, arch):
     wsum = np.array([sum(w for s, w in zip(SHIFTS, W_IE) if 0 <= n1 + s < S) for n1 in range(S)])
     assert _rel(ieR, dR * wsum[None, None, :]) <= 5e-7
     assert _rel(ieT, dT * wsum[None, None, :]) <= 5e-7
+
+
+def test_rt_run_rrs_halo_shard_equals_full(vsm, arch):
+    """Multi-GPU decomposition of the Raman pass: a rank that owns a block of recipient points and
+    computes on the halo-extended slice reproduces the full run on its block (ndoubl from the full axis)."""
+    FT, S = np.float64, 40
+    om, pm = _raman_models(vsm, arch, "IQU", 7, S, 3, FT)
+    pm.tau_rayl[S - 1] *= 30.0     # one point dominates max(tau*varpi): ndoubl must come from the full axis
+    graman = vsm.host_model.get_greek_rayleigh(0.2)
+    prs = vsm.CoreRTRaman.RRS(SHIFTS, W_IE, graman)
+    full = vsm.CoreRTRaman.rt_run(prs, pm, 1)
+    for world in (2, 3):
+        for rank in range(world):
+            sl = vsm.parallel.shard_slice(S, rank, world)
+            part = vsm.CoreRTRaman.rt_run(prs, pm, 1, spec_slice=sl)
+            for g, f in zip(part, full):
+                assert g.shape[2] == sl.stop - sl.start
+                assert _rel(g, f[:, :, sl]) <= 1e-13

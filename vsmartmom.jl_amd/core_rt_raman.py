@@ -132,12 +132,13 @@ def copy_added_to_composite_ie_(comp, comp_rs: CompositeLayerRS, added, added_rs
 
 
 def rt_kernel_rrs_(drs: DeviceRRS, pol, added, added_rs, comp, comp_rs, props: CR.DeviceLayerOptics, tau_sum, m, dq, arch, iz,
-                   F0, FT, numerics, dtau=None, ndoubl=None, trace=None):
-    """rt_kernel!(::RRS, ...) (rt_kernel.jl:352-391): scatter is hard-wired to true (:365)."""
-    dtau_h, nd_h = H.get_dtau_ndoubl(props.tau_h, props.varpi_h, dq.host, FT, numerics)
+                   F0, FT, numerics, dtau=None, ndoubl=None, expk=None, trace=None):
+    """rt_kernel!(::RRS, ...) (rt_kernel.jl:352-391): scatter is hard-wired to true (:365).
+    dtau / ndoubl / expk may be passed pre-computed (sharded runs derive them from the full spectral axis)."""
     if dtau is None:
-        dtau, ndoubl = array_type(arch)(dtau_h), nd_h
-    expk = array_type(arch)(np.exp(-dtau_h / FT(dq.host.mu0)).astype(FT))   # arr_type(exp.(-dτ/μ₀)) (rt_kernel.jl:367)
+        dtau_h, ndoubl = H.get_dtau_ndoubl(props.tau_h, props.varpi_h, dq.host, FT, numerics)
+        dtau = array_type(arch)(dtau_h)
+        expk = array_type(arch)(np.exp(-dtau_h / FT(dq.host.mu0)).astype(FT))   # arr_type(exp.(-dτ/μ₀)) (rt_kernel.jl:367)
     elemental_inelastic_(drs, tau_sum, dtau, F0, m, ndoubl, dq, added_rs)
     CR.elemental_(pol, tau_sum, dtau, F0, props, m, ndoubl, dq, added)
     doubling_inelastic_(drs, pol, expk, ndoubl, added, added_rs)
@@ -175,50 +176,90 @@ def default_fscatt(model: H.RTModel) -> np.ndarray:
     return model.tau_rayl / tau_sc
 
 
-def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list] = None):
+def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list] = None, spec_slice: Optional[slice] = None,
+           device_out: bool = False):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:238-535): returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI) as host arrays
     [nVZA, nStokes, nSpec].  `model.greek_rayleigh` must hold the Cabannes phase matrix and `model.varpi_Cabannes`
-    the elastic Rayleigh single-scattering albedo (compEffectiveLayerProperties.jl:36-41)."""
+    the elastic Rayleigh single-scattering albedo (compEffectiveLayerProperties.jl:36-41).
+
+    `spec_slice` = the recipient points this rank owns (multi-GPU): the run covers the slice extended
+    by a halo of max|i_λ₁λ₀| donor points on each side (`parallel.raman_halo_slices`), ndoubl comes from the FULL
+    spectral axis, and only the owned points are returned -- no exchange step is needed.
+    `device_out=True` returns the four (S_local, nStokes, nVZA) device tensors instead (for the gather)."""
+    from . import parallel
     arch, FT = model.architecture, model.float_type
     CR._require_gpu(arch)
     if iBand != 1:
         raise _lib.VSMError("single-band models only (iBand = 1)")
     pol, qp = model.polarization_type, model.quad_points
-    S, Nz = model.tau_rayl.shape
+    S_full, Nz = model.tau_rayl.shape
+    if spec_slice is None:
+        ext, crop = slice(0, S_full), slice(0, S_full)
+    else:
+        ext, crop = parallel.raman_halo_slices(S_full, spec_slice, RS_type.i_lambda1lambda0)
+    S = ext.stop - ext.start
     N = qp.Nquad * pol.n
     conv = array_type(arch)
+    up = lambda x: conv(np.ascontiguousarray(np.asarray(x, dtype=FT)))
     dq = CR.device_quad(qp, pol, arch, FT)
     drs = device_rrs(RS_type, arch, FT)
     K = drs.K
     fscatt = RS_type.fscattRayl if RS_type.fscattRayl is not None else default_fscatt(model)
     F0 = model.F0
     if F0 is None:
-        F0 = np.zeros((pol.n, S))
+        F0 = np.zeros((pol.n, S_full))
         F0[0, :] = 1.0
-    F0d = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT).T))
+    F0d = up(np.asarray(F0)[:, ext].T)
     dt, dev = CR._torch_dtype(FT), devi(arch)
     nV = len(model.vza)
     out = [torch.zeros((S, pol.n, nV), dtype=dt, device=dev) for _ in range(4)]
     R_SFI, T_SFI, ieR_SFI, ieT_SFI = out
-    added = CR.make_added_layer(FT, arch, (N, N), S)
-    added_surface = CR.make_added_layer(FT, arch, (N, N), S, shared=True)
-    comp = CR.make_composite_layer(FT, arch, (N, N), S)
-    added_rs = AddedLayerRS(FT, arch, K, N, S)
-    surf_rs = AddedLayerRS(FT, arch, K, N, S)      # stays zero: the surface has no inelastic part
-    comp_rs = CompositeLayerRS(FT, arch, K, N, S)
-    for m in range(model.m_max + 1):
+    if S > 0:
+        added = CR.make_added_layer(FT, arch, (N, N), S)
+        added_surface = CR.make_added_layer(FT, arch, (N, N), S, shared=True)
+        comp = CR.make_composite_layer(FT, arch, (N, N), S)
+        added_rs = AddedLayerRS(FT, arch, K, N, S)
+        surf_rs = AddedLayerRS(FT, arch, K, N, S)      # stays zero: the surface has no inelastic part
+        comp_rs = CompositeLayerRS(FT, arch, K, N, S)
+    for m in range(model.m_max + 1 if S > 0 else 0):
         weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
         Zpp_ie, Zmp_ie = H.compute_Z_moments(pol, qp.qp_mu, RS_type.greek_raman, m)   # computeRamanZλ! (:917-924)
         drs.Zpp, drs.Zmp = CR.to_device_matrix(Zpp_ie, arch, FT), CR.to_device_matrix(Zmp_ie, arch, FT)
         lods = H.constructCoreOpticalProperties(model, m)
         _, tau_sum_all = H.extractEffectiveProps(lods, FT)
         for iz, lo in enumerate(lods):
-            drs.fscatt = conv(np.ascontiguousarray(np.asarray(fscatt[:, iz], dtype=FT)))   # _expand_layer_rayleigh!
-            props = CR.expandOpticalProperties(lo, arch, FT)
-            rt_kernel_rrs_(drs, pol, added, added_rs, comp, comp_rs, props, conv(np.ascontiguousarray(tau_sum_all[:, iz].astype(FT))),
-                           m, dq, arch, iz + 1, F0d, FT, model.numerics, trace=trace)
-        CR.create_surface_layer_(model.albedo, added_surface, m, dq, conv(np.ascontiguousarray(tau_sum_all[:, -1].astype(FT))))
+            tau_full = np.atleast_1d(lo.tau).astype(FT)
+            varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
+            dtau_full, nd = H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics)   # batch-global ndoubl
+            Zpp, Zmp = np.asarray(lo.Zpp), np.asarray(lo.Zmp)
+            if Zpp.ndim == 3:
+                Zpp, Zmp = Zpp[ext], Zmp[ext]
+            props = CR.DeviceLayerOptics(up(tau_full[ext]), up(varpi_full[ext]), CR.to_device_matrix(Zpp, arch, FT),
+                                         CR.to_device_matrix(Zmp, arch, FT), float(np.max(tau_full * varpi_full)), tau_full,
+                                         np.asarray(varpi_full))
+            drs.fscatt = up(np.asarray(fscatt)[ext, iz])                                      # _expand_layer_rayleigh!
+            expk = up(np.exp(-dtau_full[ext] / FT(qp.mu0)))                                   # rt_kernel.jl:367
+            rt_kernel_rrs_(drs, pol, added, added_rs, comp, comp_rs, props, up(tau_sum_all[ext, iz]), m, dq, arch, iz + 1, F0d,
+                           FT, model.numerics, dtau=up(dtau_full[ext]), ndoubl=nd, expk=expk, trace=trace)
+        CR.create_surface_layer_(model.albedo, added_surface, m, dq, up(tau_sum_all[ext, -1]))
         interaction_inelastic_(drs, "11", comp, comp_rs, added_surface, surf_rs)
         postprocessing_vza_rs_(pol, comp, comp_rs, model.vza, model.vaz, qp, m, float(weight), R_SFI, T_SFI, ieR_SFI, ieT_SFI)
+    if device_out:
+        return tuple(t[crop].contiguous() for t in out)
     synchronize_if_gpu()
-    return tuple(to_host(t).transpose(2, 1, 0).copy() for t in out)
+    return tuple(to_host(t[crop]).transpose(2, 1, 0).copy() for t in out)
+
+
+def rt_run_sharded(RS_type: RRS, model: H.RTModel, rank: int = 0, world: int = 1, dst: int = 0, executor=None):
+    """rt_run(RS_type, model) over this rank's block of recipient points + one gather of R/T/ieR/ieT on `dst`.
+    `executor(RS_type, model, spec_slice)` must return four (S_local, nStokes, nVZA) tensors (default: the HIP engine)."""
+    from . import parallel
+    S = model.tau_rayl.shape[0]
+    sl = parallel.shard_slice(S, rank, world)
+    if executor is None:
+        executor = lambda rs, mdl, s: rt_run(rs, mdl, 1, spec_slice=s, device_out=True)
+    parts = executor(RS_type, model, sl)
+    gathered = [parallel.gather_spectral(t, S, rank, world, dst) for t in parts]
+    if rank != dst:
+        return (None,) * 4
+    return tuple(g.detach().cpu().numpy().transpose(2, 1, 0).copy() for g in gathered)

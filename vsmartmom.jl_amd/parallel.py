@@ -31,6 +31,20 @@ def shard_slice(S: int, rank: int, world: int) -> slice:
     return slice(lo, hi)
 
 
+def raman_halo_slices(S: int, owned: slice, shifts) -> Tuple[slice, slice]:
+    """Raman (RRS) sharding: recipient point n1 reads elastic fields of the donor n0 = n1 + shift
+    (src/Inelastic/inelastic_helper.jl:19-26), so a rank that owns `owned` computes on the slice extended by
+    max|shift| points on each side (clipped to the band) and needs no exchange.  Shifts that can never be in band
+    (|shift| >= S) do not widen the halo.  Returns (extended slice of the full axis, owned points inside it)."""
+    lo, hi, _ = owned.indices(S)
+    if hi <= lo:
+        return slice(lo, lo), slice(0, 0)
+    sh = [abs(int(x)) for x in np.asarray(shifts).ravel() if abs(int(x)) < S]
+    h = max(sh) if sh else 0
+    elo, ehi = max(0, lo - h), min(S, hi + h)
+    return slice(elo, ehi), slice(lo - elo, hi - elo)
+
+
 def init_process_group_from_env(backend: Optional[str] = None):
     """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT from the environment (torchrun)."""
     import torch
