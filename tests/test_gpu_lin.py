@@ -107,8 +107,9 @@ def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl):
     assert _rel(vsm.Architectures.to_host(pa.j0_m), oa.j0_m) < 1e-10
 
 
+@pytest.mark.parametrize("iface", ["11", "00", "01", "10"])
 @pytest.mark.parametrize("N,shared", [(12, False), (60, False), (36, True)])
-def test_interaction_lin(vsm, arch, N, shared):
+def test_interaction_lin(vsm, arch, N, shared, iface):
     FT = np.float64
     rng = np.random.default_rng(3)
     S, P = 3, 3
@@ -143,8 +144,8 @@ def test_interaction_lin(vsm, arch, N, shared):
         getattr(pal, "ap_" + k).copy_(conv_v(np.ascontiguousarray((srcl[:, :1] if shared else srcl).transpose(0, 1, 3, 2))))
     pa.j0_p.copy_(conv_v(add.j0_p)); pa.j0_m.copy_(conv_v(add.j0_m))
     pal.ap_J0_p.copy_(conv_v(al.ap_J0_p)); pal.ap_J0_m.copy_(conv_v(al.ap_J0_m))
-    OL.interaction_lin("11", comp, cl, add, al, FT)
-    CL.interaction_lin_("11", pc, pcl, pa, pal)
+    OL.interaction_lin(iface, comp, cl, add, al, FT)
+    CL.interaction_lin_(iface, pc, pcl, pa, pal)
     f4 = lambda t: vsm.Architectures.to_host(t).transpose(0, 1, 3, 2)
     for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
         assert _rel(CR.from_device_matrix(getattr(pc, k)), getattr(comp, k)) < 1e-10, k

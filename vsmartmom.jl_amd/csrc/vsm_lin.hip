@@ -376,10 +376,9 @@ template <typename T>
 int interaction_lin(int iface, int N, int S, const composite<T>& c, const composite_lin<T>& cl, const added<T>& a,
                     const added_lin<T>& al, T* work, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  if (iface != VSM_IFACE_11) {
-    set_error("interaction_lin: only ScatteringInterface_11 is implemented on the device "
-              "(the linearized rt_kernel! treats every layer as scattering, rt_kernel_lin.jl:87)");
-    return VSM_ERR_UNSUPPORTED;
+  if (iface < VSM_IFACE_00 || iface > VSM_IFACE_11) {
+    set_error("interaction_lin: unknown scattering interface %d", iface);
+    return VSM_ERR_INVALID_ARG;
   }
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
@@ -413,6 +412,95 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
   const T* nul = nullptr;
   int rc;
 #define MM(...) if ((rc = gemm2<T>(__VA_ARGS__, st))) return rc
+#define CP(n, src, dst) if ((rc = copy_strided<T>(n, 1, src, 0, dst, st))) return rc
+  if (iface != VSM_IFACE_11) {
+    // ---- interfaces without multiple reflections between the two layers (interaction_lin.jl:62-215).  Every new
+    // value goes to scratch first and is committed at the end, so all right-hand sides see pre-update values.
+    if (iface == VSM_IFACE_00) {            // :62-96
+      MM(N, 1, N, S, P, a.t_pp, as, 0, cl.J0_p, N, VS, nJpl, N, VS, one, al.ap_J0_p, N, VS, one, zero);
+      MM(N, 1, N, S, P, al.ap_t_pp, als, alp, c.J0_p, N, 0, nJpl, N, VS, one, nJpl, N, VS, one, zero);
+      MM(N, 1, N, S, P, c.T_mm, NN, 0, al.ap_J0_m, N, VS, nJml, N, VS, one, cl.J0_m, N, VS, one, zero);
+      MM(N, 1, N, S, P, cl.T_mm, NN, MS, a.j0_m, N, 0, nJml, N, VS, one, nJml, N, VS, one, zero);
+      MM(N, 1, N, S, 1, a.t_pp, as, 0, c.J0_p, N, 0, nJp, N, 0, one, a.j0_p, N, 0, one, zero);
+      MM(N, 1, N, S, 1, c.T_mm, NN, 0, a.j0_m, N, 0, nJm, N, 0, one, c.J0_m, N, 0, one, zero);
+      MM(N, N, N, S, P, al.ap_t_mm, als, alp, c.T_mm, NN, 0, nB, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.t_mm, as, 0, cl.T_mm, NN, MS, nB, NN, MS, one, nB, NN, MS, one, zero);      // new Tdot--
+      MM(N, N, N, S, P, al.ap_t_pp, als, alp, c.T_pp, NN, 0, nA, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.t_pp, as, 0, cl.T_pp, NN, MS, nA, NN, MS, one, nA, NN, MS, one, zero);      // new Tdot++
+      MM(N, N, N, S, 1, a.t_mm, as, 0, c.T_mm, NN, 0, nTmm, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, 1, a.t_pp, as, 0, c.T_pp, NN, 0, W, NN, 0, one, nul, 0, 0, zero, zero);
+      CP(MS * P, nB, cl.T_mm);
+      CP(MS * P, nA, cl.T_pp);
+      CP(MS, nTmm, c.T_mm);
+      CP(MS, W, c.T_pp);
+    } else if (iface == VSM_IFACE_01) {     // :104-147
+      MM(N, 1, N, S, 1, a.r_mp, as, 0, c.J0_p, N, 0, Av, N, 0, one, a.j0_m, N, 0, one, zero);
+      MM(N, 1, N, S, P, al.ap_r_mp, als, alp, c.J0_p, N, 0, wv, N, VS, one, al.ap_J0_m, N, VS, one, zero);
+      MM(N, 1, N, S, P, a.r_mp, as, 0, cl.J0_p, N, VS, wv, N, VS, one, wv, N, VS, one, zero);
+      MM(N, 1, N, S, P, cl.T_mm, NN, MS, Av, N, 0, nJml, N, VS, one, cl.J0_m, N, VS, one, zero);
+      MM(N, 1, N, S, P, c.T_mm, NN, 0, wv, N, VS, nJml, N, VS, one, nJml, N, VS, one, zero);
+      MM(N, 1, N, S, P, al.ap_t_pp, als, alp, c.J0_p, N, 0, nJpl, N, VS, one, al.ap_J0_p, N, VS, one, zero);
+      MM(N, 1, N, S, P, a.t_pp, as, 0, cl.J0_p, N, VS, nJpl, N, VS, one, nJpl, N, VS, one, zero);
+      MM(N, 1, N, S, 1, c.T_mm, NN, 0, Av, N, 0, nJm, N, 0, one, c.J0_m, N, 0, one, zero);
+      MM(N, 1, N, S, 1, a.t_pp, as, 0, c.J0_p, N, 0, nJp, N, 0, one, a.j0_p, N, 0, one, zero);
+      MM(N, N, N, S, 1, a.r_mp, as, 0, c.T_pp, NN, 0, rT, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, al.ap_r_mp, als, alp, c.T_pp, NN, 0, X1, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.r_mp, as, 0, cl.T_pp, NN, MS, X1, NN, MS, one, X1, NN, MS, one, zero);
+      MM(N, N, N, S, P, cl.T_mm, NN, MS, rT, NN, 0, nA, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, c.T_mm, NN, 0, X1, NN, MS, nA, NN, MS, one, nA, NN, MS, one, zero);           // new Rdot-+
+      MM(N, N, N, S, P, al.ap_t_pp, als, alp, c.T_pp, NN, 0, nB, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.t_pp, as, 0, cl.T_pp, NN, MS, nB, NN, MS, one, nB, NN, MS, one, zero);      // new Tdot++
+      MM(N, N, N, S, P, cl.T_mm, NN, MS, a.t_mm, as, 0, X2, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, c.T_mm, NN, 0, al.ap_t_mm, als, alp, X2, NN, MS, one, X2, NN, MS, one, zero); // new Tdot--
+      MM(N, N, N, S, 1, c.T_mm, NN, 0, rT, NN, 0, nRmp, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, 1, a.t_pp, as, 0, c.T_pp, NN, 0, W, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, 1, c.T_mm, NN, 0, a.t_mm, as, 0, nTmm, NN, 0, one, nul, 0, 0, zero, zero);
+      CP(MS * P, nA, cl.R_mp);
+      for (int p = 0; p < P; ++p)
+        if ((rc = copy_strided<T>(NN, S, al.ap_r_pm + (long long)p * alp, als, cl.R_pm + (long long)p * MS, st))) return rc;
+      CP(MS * P, nB, cl.T_pp);
+      CP(MS * P, X2, cl.T_mm);
+      CP(MS, nRmp, c.R_mp);
+      if ((rc = copy_strided<T>(NN, S, a.r_pm, as, c.R_pm, st))) return rc;
+      CP(MS, W, c.T_pp);
+      CP(MS, nTmm, c.T_mm);
+    } else {                                // ScatteringInterface_10, :155-215
+      MM(N, 1, N, S, 1, c.R_pm, NN, 0, a.j0_m, N, 0, Bv, N, 0, one, c.J0_p, N, 0, one, zero);
+      MM(N, 1, N, S, P, cl.R_pm, NN, MS, a.j0_m, N, 0, wv, N, VS, one, cl.J0_p, N, VS, one, zero);
+      MM(N, 1, N, S, P, c.R_pm, NN, 0, al.ap_J0_m, N, VS, wv, N, VS, one, wv, N, VS, one, zero);
+      MM(N, 1, N, S, P, al.ap_t_pp, als, alp, Bv, N, 0, nJpl, N, VS, one, al.ap_J0_p, N, VS, one, zero);
+      MM(N, 1, N, S, P, a.t_pp, as, 0, wv, N, VS, nJpl, N, VS, one, nJpl, N, VS, one, zero);
+      MM(N, 1, N, S, P, cl.T_mm, NN, MS, a.j0_m, N, 0, nJml, N, VS, one, cl.J0_m, N, VS, one, zero);
+      MM(N, 1, N, S, P, c.T_mm, NN, 0, al.ap_J0_m, N, VS, nJml, N, VS, one, nJml, N, VS, one, zero);
+      MM(N, 1, N, S, 1, a.t_pp, as, 0, Bv, N, 0, nJp, N, 0, one, a.j0_p, N, 0, one, zero);
+      MM(N, 1, N, S, 1, c.T_mm, NN, 0, a.j0_m, N, 0, nJm, N, 0, one, c.J0_m, N, 0, one, zero);
+      MM(N, N, N, S, P, al.ap_t_pp, als, alp, c.T_pp, NN, 0, nA, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.t_pp, as, 0, cl.T_pp, NN, MS, nA, NN, MS, one, nA, NN, MS, one, zero);      // new Tdot++
+      MM(N, N, N, S, P, cl.T_mm, NN, MS, a.t_mm, as, 0, X2, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, c.T_mm, NN, 0, al.ap_t_mm, als, alp, X2, NN, MS, one, X2, NN, MS, one, zero); // new Tdot--
+      MM(N, N, N, S, 1, c.R_pm, NN, 0, a.t_mm, as, 0, Rt, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, cl.R_pm, NN, MS, a.t_mm, as, 0, X1, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, c.R_pm, NN, 0, al.ap_t_mm, als, alp, X1, NN, MS, one, X1, NN, MS, one, zero);
+      MM(N, N, N, S, P, al.ap_t_pp, als, alp, Rt, NN, 0, nB, NN, MS, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, P, a.t_pp, as, 0, X1, NN, MS, nB, NN, MS, one, nB, NN, MS, one, zero);           // new Rdot+-
+      MM(N, N, N, S, 1, a.t_pp, as, 0, c.T_pp, NN, 0, W, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, 1, c.T_mm, NN, 0, a.t_mm, as, 0, nTmm, NN, 0, one, nul, 0, 0, zero, zero);
+      MM(N, N, N, S, 1, a.t_pp, as, 0, Rt, NN, 0, G, NN, 0, one, nul, 0, 0, zero, zero);
+      CP(MS * P, nA, cl.T_pp);
+      CP(MS * P, X2, cl.T_mm);
+      CP(MS * P, nB, cl.R_pm);
+      CP(MS, W, c.T_pp);
+      CP(MS, nTmm, c.T_mm);
+      CP(MS, G, c.R_pm);
+    }
+    CP(VS, nJp, c.J0_p);
+    CP(VS, nJm, c.J0_m);
+    CP(VS * P, nJpl, cl.J0_p);
+    CP(VS * P, nJml, cl.J0_m);
+    (void)v1;
+    (void)v2;
+    return VSM_OK;
+  }
   // ---- first half: G1, T01_inv and everything that hangs off them --------------------------------
   MM(N, N, N, S, 1, a.r_mp, as, 0, c.R_pm, NN, 0, G, NN, 0, -one, nul, 0, 0, zero, one);
   if ((rc = batch_inv<T>(N, S, G, G, nullptr, st))) return rc;
@@ -491,6 +579,7 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
   if ((rc = copy_strided<T>(MS * P, 1, nB, 0, cl.R_pm, st))) return rc;
   if ((rc = copy_strided<T>(MS * P, 1, nA, 0, cl.T_pp, st))) return rc;
 #undef MM
+#undef CP
   (void)v1;
   (void)v2;
   return VSM_OK;
