@@ -19,6 +19,8 @@
 // rounding by a norm bound on E), or by the pivoted Gauss-Jordan of vsm_inverse.h (general case).
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
+#include <stdlib.h>
+
 #include "vsm_lds.h"
 
 namespace vsm {
@@ -1028,6 +1030,11 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
                              const T* tau_sum, const T* F0, const T* Zpp, const T* Zmp, long long zs,
                              const added<T>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr;   // A/B switch for benchmarking
+    if (!no_strip && strip_supported(q.N))
+      return strip_elemental_doubling(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a, st);
+  }
   return dispatch_np<T>(q.N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
     constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;

@@ -106,6 +106,12 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st);
 template <typename T>
 int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStream_t st);
 
+// ---- column-strip kernels (FP64, 32 < N <= 60; two workgroups per CU): vsm_strip.hip ----------------
+bool strip_supported(int N);
+int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                             const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
+                             const added<double>& a, hipStream_t st);
+
 // grow-only device scratch (one per element type); not for concurrent streams.
 void* scratch(size_t bytes, int slot);
 

@@ -1,0 +1,518 @@
+// Column-strip kernels (FP64, 32 < N <= 60): elemental! + ndoubl x doubling step + apply_D! with HALF the LDS
+// footprint of vsm_fused.hip, so that TWO workgroups share a CU and one workgroup's barriers, LDS stores and
+// pipeline fill hide behind the other's MFMAs.
+//
+// Layout.  A workgroup (4 waves) owns one spectral point.  Wave w owns the 16-column strip [16w, 16w+16) of
+// EVERY matrix and keeps it in registers in the v_mfma_f64_16x16x4 accumulator layout: 4 row tiles, element r
+// of tile ta = (row 16 ta + (lane>>4) + 4 r, column 16 w + (lane&15)).  For the f64 MFMA that layout IS the
+// B-operand layout of four consecutive k-steps (k = 4 r + (lane>>4)), so a product  C_s = A * B_s  takes its B
+// operand straight from the registers that hold B's strip -- results of one product feed the next without
+// touching LDS.  Only A operands live in LDS ("A-form": column-major 64 x 64, the swizzle of vsm_lds.h), and
+// at most two of them are alive at a time:  2 x 32 KB + vectors < 80 KB per workgroup.
+//
+//   per doubling step (rt_helpers.jl:102-166):      A operand (LDS)      B operand (registers)
+//     E   = r r                                      P = r                r_s
+//     G   = (I - E)^-1   series by squaring          P = E^(2^p)          powers / partial sums
+//     tt  = t G                                      Q = t                G_s
+//     tmp = tt r ;  t' = tt t   (share A)            P = tt               r_s ; t_s (+ j0+, j1- in spare columns)
+//     r'  = r + tmp t                                Q = tmp              t_s
+#include "vsm_internal.h"
+#include "vsm_inverse.h"
+#include "vsm_lds.h"
+
+namespace vsm {
+
+namespace {
+
+constexpr int SNP = 64;    // padded matrix size
+constexpr int SNT = 256;   // threads per workgroup (4 waves)
+
+struct sstrip {
+  d4_t v[4];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) v[a] = acc_zero<double>();
+  }
+};
+
+struct ssmem {
+  double P[SNP * SNP];
+  double Q[SNP * SNP];
+  double vec[8][SNP];
+  float red[2][4];
+  gj_scratch<double, SNP> gj;
+};
+
+// Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h), split into per-lane bases and compile-time
+// offsets so that every LDS access of a product is "base register + immediate":
+//   A fragment (row 16 t + l15, column 4 ks + kq):  lidx = ab[ks & 3][t] + 256 ks      (one base per (ks & 3, t):
+//   bases that differ by a small constant would be fused into ds_read2_b64, whose 8-bit offsets cannot hold 256 ks)
+//   strip element (row 16 ta + kq + 4 r, column col): lidx = ((16 ta + 4 r) ^ cm_hi) + c_lo
+struct spos {
+  int lane, wave, l15, kq, col;
+  int ab[4][4];
+  int cm_hi, c_lo;
+  __device__ __forceinline__ spos() {
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    l15 = lane & 15;
+    kq = lane >> 4;
+    col = 16 * wave + l15;
+    const int L = l15 ^ ((kq >> 1) << 1), pq = kq & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ab[j][t] = 64 * kq + (L ^ (4 * j)) + 16 * (t ^ pq);
+    const int m = ((col & 1) << 4) | (((col >> 1) & 7) << 1);
+    cm_hi = m & 0x3C;
+    c_lo = (kq ^ (m & 3)) + SNP * col;
+  }
+  __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
+  __device__ __forceinline__ int aidx(int t, int ks) const { return ab[ks & 3][t] + 256 * ks; }
+  __device__ __forceinline__ int sidx(int ta, int r) const { return ((16 * ta + 4 * r) ^ cm_hi) + c_lo; }
+  // hide the loop invariance of the bases from LICM (hoisting every derived address costs > 100 VGPRs)
+  __device__ __forceinline__ void opaque() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(ab[j][t]));
+    asm volatile("" : "+v"(cm_hi));
+    asm volatile("" : "+v"(c_lo));
+  }
+};
+
+// acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
+template <int KS>
+__device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip& B, spos& p) {
+  p.opaque();
+  double a[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+    }
+    const double b = B.v[ks >> 2][ks & 3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc.v[t] = mfma<double>::mma(a[ks & 1][t], b, acc.v[t]);
+  }
+}
+// acc1 += A * B1 ; acc2 += A * B2   (shared A fragments)
+template <int KS>
+__device__ __forceinline__ void mm_ab2(sstrip& acc1, sstrip& acc2, const double* A, const sstrip& B1, const sstrip& B2,
+                                       spos& p) {
+  p.opaque();
+  double a[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+    }
+    const double b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc1.v[t] = mfma<double>::mma(a[ks & 1][t], b1, acc1.v[t]);
+      acc2.v[t] = mfma<double>::mma(a[ks & 1][t], b2, acc2.v[t]);
+    }
+  }
+}
+
+// strip -> A-form in LDS, through f(value, row, col)
+template <typename F>
+__device__ __forceinline__ void store_strip(double* dst, const sstrip& s, const spos& p, F f) {
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      dst[p.sidx(ta, r)] = f(s.v[ta][r], row, p.col);
+    }
+}
+__device__ __forceinline__ void load_strip(sstrip& s, const double* src, const spos& p) {
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s.v[ta][r] = src[p.sidx(ta, r)];
+}
+
+// Frobenius-norm bound of the N x N block whose strips the waves hold (deterministic; see vsm_fused.hip).
+// Contains ONE barrier: on return every wave has finished whatever it did before the call.
+__device__ __forceinline__ double strip_norm_bound(const sstrip& e, int N, ssmem& sm, int& slot, const spos& p) {
+  double ss = 0;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double v = e.v[ta][r];
+      if (p.row(ta, r) < N && p.col < N) ss += v * v;
+    }
+  const float ws = wave_sum(to_float_up(ss));
+  if (p.lane == 0) sm.red[slot][p.wave] = ws;
+  __syncthreads();
+  const float tot = (sm.red[slot][0] + sm.red[slot][1]) + (sm.red[slot][2] + sm.red[slot][3]);
+  slot ^= 1;
+  return (double)(sqrtf(tot) * 1.001f);
+}
+
+// In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block), 256 threads.  Ends with a barrier.
+__device__ __forceinline__ void gj_lds_strip(double* V, int N, gj_scratch<double, SNP>* sc) {
+  using G = gj_cfg<SNP, SNT>;
+  const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
+  double g[G::RB][G::CB];
+#pragma unroll
+  for (int rb = 0; rb < G::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb) {
+      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
+      g[rb][cb] = (i < N && j < N) ? V[lidx<SNP>(i, j)] : ((i == j) ? 1.0 : 0.0);
+    }
+  gj_invert<double, SNP, SNT>(g, N, *sc);
+#pragma unroll
+  for (int rb = 0; rb < G::RB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < G::CB; ++cb) {
+      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
+      if (i < N && j < N) V[lidx<SNP>(i, sc->dst[j])] = g[rb][cb];
+    }
+  __syncthreads();
+}
+
+// G_s = strip of (I - E)^-1, E given as strips.  W (LDS, A-form scratch) must not be read by anybody once the
+// first barrier inside has been passed (the norm reduction), which the callers guarantee.  On return other
+// waves may still be READING W: barrier before overwriting it.  Returns 1 (Gauss-Jordan) or 1 + series order.
+template <int KS>
+__device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int N, ssmem& sm, int& slot, spos& p,
+                                            int mode) {
+  const double nrm = strip_norm_bound(E, N, sm, slot, p);
+  const double tol = num<double>::eps() * 0.25;
+  int K = 0;
+  if (nrm < 0.3) {
+    const double lim = tol * (1.0 - nrm);
+    const double n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
+    if (n2 <= lim) K = 1;
+    else if (n2 * nrm <= lim) K = 2;
+    else if (n4 <= lim) K = 3;
+    else if (n4 * nrm <= lim) K = 4;
+    else if (n8 <= lim) K = 7;
+    else if (n8 * nrm <= lim) K = 8;
+    else if (n16 <= lim) K = 15;
+    else if (n16 * nrm <= lim) K = 16;
+    else if (n16 * n16 <= lim) K = 31;
+  }
+  if (mode == 1) K = 0;
+  if (mode == 2 && K == 0) K = 31;
+  auto keep = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
+  if (K == 0) {
+    store_strip(W, E, p, [=](double a, int r, int c) { return (r == c) ? 1.0 - keep(a, r, c) : -keep(a, r, c); });
+    __syncthreads();
+    gj_lds_strip(W, N, &sm.gj);
+    load_strip(G, W, p);
+    return 1;
+  }
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      const double e = keep(E.v[ta][r], row, p.col);
+      E.v[ta][r] = e;
+      G.v[ta][r] = (row == p.col && row < N) ? e + 1.0 : e;
+    }
+  if (K == 1) return 2;
+  store_strip(W, E, p, [](double a, int, int) { return a; });
+  __syncthreads();
+  int cur = 1;  // W = E^cur (A-form), E = its strip, G = strip of sum_{k < 2 cur} E^k
+  for (;;) {
+    sstrip W2;
+    W2.zero();
+    mm_ab<KS>(W2, W, E, p);  // E^(2 cur)
+    cur *= 2;
+    if (K == cur) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta) G.v[ta] += W2.v[ta];
+      break;
+    }
+    __syncthreads();  // everybody finished reading W
+    store_strip(W, W2, p, [](double a, int, int) { return a; });
+    __syncthreads();
+    sstrip T;
+    T.zero();
+    mm_ab<KS>(T, W, G, p);  // E^cur * G   (powers of E commute)
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) G.v[ta] += T.v[ta];
+    if (K == 2 * cur - 1) break;
+    E = W2;
+  }
+  return 1 + K;
+}
+
+// ---------------------------------------------------------------------------
+// elemental! + doubling! + apply_D!   (strip form)
+// ---------------------------------------------------------------------------
+template <int KS>   // k-steps of every product: 4 KS >= N (columns >= N of the A-forms are zero)
+__global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
+                                                     const double* __restrict__ varpi, const double* __restrict__ tau_sum,
+                                                     const double* __restrict__ F0, const double* __restrict__ Zpp,
+                                                     const double* __restrict__ Zmp, long long zs, added<double> out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  double* P = sm.P;
+  double* Q = sm.Q;
+  double* jp = sm.vec[0];
+  double* jm = sm.vec[1];
+  double* mus = sm.vec[2];
+  double* wcs = sm.vec[3];
+  double* xs = sm.vec[4];
+  double* es = sm.vec[5];
+  double* ems = sm.vec[6];
+  spos p;
+  const int s = blockIdx.x;
+  const int N = q.N, ns = q.n_stokes;
+  const int tid = threadIdx.x;
+  const int Kend = ((N + 3) >> 2) << 2;
+  // spare columns Kend, Kend+1 (>= N, never read as k) carry j0+ and j1- through the products of a step
+  const int c1 = Kend, c2 = Kend + 1;
+  const bool own_wave = (p.wave == (c1 >> 4));
+  const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
+  const double* jsrc = laneB ? jm : jp;                      // per-lane source / destination of the source vectors
+  double* jdst = laneA ? jp : (laneB ? jm : sm.vec[7]);
+  const double d = dtau[s], w = varpi[s];
+  const double* Zp = Zpp + (long long)s * zs;
+  const double* Zm = Zmp + (long long)s * zs;
+
+  if (tid < SNP) {
+    mus[tid] = (tid < N) ? q.mu[tid] : 1.0;
+    const double wt = (tid < N) ? q.wt[tid] : 0.0;
+    wcs[tid] = (m == 0) ? wt / 2.0 : wt / 4.0;
+    const double x = d / mus[tid];
+    xs[tid] = x;
+    es[tid] = exp(-x);
+    ems[tid] = expm1(-x);
+  }
+  __syncthreads();
+
+  // ---- elemental (elemental.jl:289-334), each lane computes the 16 elements of its strip -----------------
+  sstrip r_s, t_s;
+  {
+    const int j = p.col;
+    const int jc = min(j, N - 1);
+    const double mj = mus[j], wct = wcs[j], xj = xs[j], emj = ems[j], ej = es[j];
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) {
+      double zp[4], zm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jc;
+        zp[r] = Zp[zo];
+        zm[r] = Zm[zo];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = p.row(ta, r);
+        double rr = 0.0, tt = 0.0;
+        if (i < N && j < N) {
+          const double mi = mus[i], xi = xs[i];
+          if (wct > num<double>::eps()) {
+            const double emi = ems[i];
+            rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
+            if (mi == mj) {
+              if (i == j)
+                tt = es[i] * (1.0 + w * zp[r] * xi * wct);
+              else
+                tt = ej * (w * zp[r] * xi * wct);
+            } else {
+              const double xm = fmax(xi, xj);
+              const double ediff =
+                  (xm < 0.5 && fabs(xi - xj) > 0.125 * xm) ? (emi - emj) : expdiff_neg<double>(xi, xj);
+              tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
+            }
+          } else {
+            tt = (i == j) ? es[i] : 0.0;
+          }
+          if (ndoubl >= 1 && is_uv_row(i, ns)) rr = -rr;  // starred R* = D R (elemental.jl:403-422)
+        }
+        r_s.v[ta][r] = rr;
+        t_s.v[ta][r] = tt;
+      }
+    }
+  }
+  // ---- SFI source (elemental.jl:348-392) -> LDS vectors jp, jm ---------------------------------------------
+  if (tid < SNP) {
+    double vjp = 0.0, vjm = 0.0;
+    if (tid < N) {
+      const int i = tid;
+      const int i_start = ns * q.i_mu0;
+      const double wct02 = (m == 0) ? 0.5 : 0.25;
+      double zp = 0, zm = 0;
+      for (int qq = 0; qq < ns; ++qq) {
+        const long long zo = i + (long long)N * (i_start + qq);
+        const double f = F0[qq + (long long)ns * s];
+        zp += Zp[zo] * f;
+        zm += Zm[zo] * f;
+      }
+      const double mi = mus[i], ms = mus[i_start];
+      if (i >= i_start && i < i_start + ns)
+        vjp = wct02 * w * zp * (d / mi) * exp(-d / mi);
+      else
+        vjp = wct02 * w * zp * (ms / (mi - ms)) * expdiff_neg<double>(d / mi, d / ms);
+      vjm = wct02 * w * zm * (ms / (mi + ms)) * (-expm1(-d * ((1.0 / mi) + (1.0 / ms))));
+      const double att = exp(-tau_sum[s] / ms);
+      vjp *= att;
+      vjm *= att;
+      if (ndoubl >= 1 && is_uv_row(i, ns)) vjm = -vjm;
+    }
+    jp[tid] = vjp;
+    jm[tid] = vjm;
+  }
+  auto keepN = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
+  if (ndoubl > 0) {
+    store_strip(P, r_s, p, keepN);
+    store_strip(Q, t_s, p, keepN);
+  }
+  __syncthreads();
+
+  // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------
+  double expk = exp(-d / q.mu0);
+  int slot = 0;
+  for (int n = 0; n < ndoubl; ++n) {
+    // on entry: P = r, Q = t (A-form), r_s / t_s in registers, all waves past a barrier
+    sstrip G;
+    {
+      sstrip E;
+      E.zero();
+      mm_ab<KS>(E, P, r_s, p);
+      invert_strip<KS>(E, G, P, N, sm, slot, p, 0);  // (its first barrier: every wave is done reading P = r)
+    }
+    // tt = t G
+    sstrip tt;
+    tt.zero();
+    mm_ab<KS>(tt, Q, G, p);
+    load_strip(t_s, Q, p);  // t's strip is not kept in registers across the inverse (register budget: 256)
+    __syncthreads();  // P (series powers) and Q (t) no longer read
+    store_strip(P, tt, p, keepN);
+    // j0+ and j1- = j0- expk ride in the spare columns of t_s (same wave that owns jp/jm's columns; LDS is in
+    // order within a wave, so no barrier is needed for the vectors)
+    if (own_wave) {  // (wave-uniform; the lanes of the wave read jsrc together, lanes A / B keep the value)
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = jsrc[p.row(ta, r)] * (laneB ? expk : 1.0);
+          t_s.v[ta][r] = laneAB ? v : t_s.v[ta][r];
+        }
+    }
+    __syncthreads();  // tt complete in P
+    // tmp = tt r ; t' = tt t  (+ tt j0+, tt j1- in the spare columns)
+    sstrip tmp, tn;
+    tmp.zero();
+    tn.zero();
+    mm_ab2<KS>(tmp, tn, P, r_s, t_s, p);
+    store_strip(Q, tmp, p, keepN);  // Q (t) is dead since the barrier before the tt store
+    __syncthreads();                // tmp complete in Q
+    // r' = r + tmp t   (+ tmp j0+, tmp j1- in the spare columns, on top of r_s's zero padding)
+    mm_ab<KS>(r_s, Q, t_s, p);
+    // sources: j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134)
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          const double x = tn.v[ta][r];                    // lane A: tt j0+    lane B: tt j1-
+          const double u = __shfl_xor(r_s.v[ta][r], 1);    // lane A: tmp j1-   lane B: tmp j0+
+          const double base = jsrc[row] * (laneB ? 1.0 : expk);   // lane A: j1+ = j0+ expk   lane B: j0-
+          jdst[row] = (row < N) ? base + x + u : 0.0;      // (other lanes write to a dummy vector)
+          r_s.v[ta][r] = laneAB ? 0.0 : r_s.v[ta][r];
+          tn.v[ta][r] = laneAB ? 0.0 : tn.v[ta][r];
+        }
+    }
+    t_s = tn;
+    expk = expk * expk;
+    if (n + 1 < ndoubl) {
+      __syncthreads();  // everybody finished reading P (tt) and Q (tmp)
+      store_strip(P, r_s, p, keepN);
+      store_strip(Q, t_s, p, keepN);
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+
+  // ---- apply_D (doubling.jl:178-252) + write the added layer through LDS (coalesced stores) ---------------
+  const bool sgn = ndoubl >= 1;
+  store_strip(P, r_s, p, [=](double a, int r, int c) { return (r < N && c < N) ? ((sgn && is_uv_row(r, ns)) ? -a : a) : 0.0; });
+  store_strip(Q, t_s, p, keepN);
+  __syncthreads();
+  double* g_rmp = out.r_mp + (long long)s * out.mat_stride;
+  double* g_tpp = out.t_pp + (long long)s * out.mat_stride;
+  double* g_rpm = out.r_pm + (long long)s * out.mat_stride;
+  double* g_tmm = out.t_mm + (long long)s * out.mat_stride;
+  for (int e = tid; e < N * N; e += SNT) {
+    const int i = e % N, j = e / N;
+    const int ix = lidx<SNP>(i, j);
+    const double r = P[ix], t = Q[ix];
+    g_rmp[e] = r;
+    g_tpp[e] = t;
+    if (!out.d_symmetric) {
+      const bool same = is_uv_row(i, ns) == is_uv_row(j, ns);
+      g_rpm[e] = same ? r : -r;
+      g_tmm[e] = same ? t : -t;
+    }
+  }
+  if (tid < N) {
+    double vjm = jm[tid];
+    if (sgn && is_uv_row(tid, ns)) vjm = -vjm;
+    out.j0_p[(long long)s * N + tid] = jp[tid];
+    out.j0_m[(long long)s * N + tid] = vjm;
+  }
+}
+
+}  // namespace
+
+bool strip_supported(int N) {
+  const int Kend = ((N + 3) >> 2) << 2;
+  return N > 32 && Kend + 2 <= SNP;
+}
+
+template <int KS>
+static int launch_ed_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                           const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
+                           const added<double>& a, hipStream_t st) {
+  const size_t bytes = sizeof(ssmem);
+  static int prepared = [&]() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ed_strip<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ed_strip)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_ed_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a);
+  VSM_LAUNCH_CHECK("k_ed_strip");
+  return VSM_OK;
+}
+
+int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                             const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
+                             const added<double>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+#define VSM_STRIP_CASE(KS) \
+  case KS: return launch_ed_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a, st)
+  switch ((q.N + 3) >> 2) {
+    VSM_STRIP_CASE(9);
+    VSM_STRIP_CASE(10);
+    VSM_STRIP_CASE(11);
+    VSM_STRIP_CASE(12);
+    VSM_STRIP_CASE(13);
+    VSM_STRIP_CASE(14);
+    VSM_STRIP_CASE(15);
+    default: break;
+  }
+#undef VSM_STRIP_CASE
+  set_error("strip_elemental_doubling: N=%d outside (32, 60]", q.N);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+}  // namespace vsm
