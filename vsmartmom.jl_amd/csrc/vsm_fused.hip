@@ -1056,6 +1056,10 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     set_error("fused_interaction: only ScatteringInterface_11 is fused");
     return VSM_ERR_UNSUPPORTED;
   }
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_IA") != nullptr;
+    if (!no_strip && strip_supported(N)) return strip_interaction11(N, S, c, a, st);
+  }
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
     constexpr int NW = (NP == 64) ? IA_WAVES_64 : 4;

@@ -471,6 +471,248 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266), strip form
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void load_strip_global(sstrip& s, const double* __restrict__ g, int N, const spos& p) {
+  const int cc = min(p.col, N - 1);
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      const double v = g[min(row, N - 1) + (long long)N * cc];   // clamped address, masked value
+      s.v[ta][r] = (row < N && p.col < N) ? v : 0.0;
+    }
+}
+__device__ __forceinline__ void store_strip_global(double* __restrict__ g, const sstrip& s, int N, const spos& p) {
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      if (row < N && p.col < N) g[row + (long long)N * p.col] = s.v[ta][r];
+    }
+}
+// D X D: sign (+) where row and column have the same U/V parity (doubling.jl:178-201)
+__device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, int ns, const spos& p) {
+  const bool uc = is_uv_row(p.col, ns);
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d.v[ta][r] = (is_uv_row(p.row(ta, r), ns) == uc) ? x.v[ta][r] : -x.v[ta][r];
+}
+// global column-major N x N -> A-form in LDS (zero padded); one column per wave and pass, coalesced reads
+__device__ __forceinline__ void stage_aform(double* L, const double* __restrict__ g, int N, const spos& p) {
+#pragma unroll 4
+  for (int j = p.wave; j < SNP; j += 4) {
+    const double v = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
+    L[lidx<SNP>(p.lane, j)] = v;
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c, added<double> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  double* P = sm.P;
+  double* Q = sm.Q;
+  double* vJp = sm.vec[0];
+  double* vJm = sm.vec[1];
+  double* vjp = sm.vec[2];
+  double* vjm = sm.vec[3];
+  double* vu = sm.vec[4];
+  double* vz = sm.vec[5];
+  spos p;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int ns = a.d_symmetric;   // n_stokes when the added layer is D-symmetric, else 0 (then r+-/t-- are read)
+  const long long NN = (long long)N * N;
+  double* R_mp = c.R_mp + s * NN;
+  double* R_pm = c.R_pm + s * NN;
+  double* T_pp = c.T_pp + s * NN;
+  double* T_mm = c.T_mm + s * NN;
+  double* J0_p = c.J0_p + (long long)s * N;
+  double* J0_m = c.J0_m + (long long)s * N;
+  const double* r_mp = a.r_mp + s * a.mat_stride;
+  const double* r_pm = a.r_pm + s * a.mat_stride;
+  const double* t_pp = a.t_pp + s * a.mat_stride;
+  const double* t_mm = a.t_mm + s * a.mat_stride;
+  const double* j0_p = a.j0_p + (long long)s * N;
+  const double* j0_m = a.j0_m + (long long)s * N;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const int c1 = Kend, c2 = Kend + 1;
+  const bool own_wave = (p.wave == (c1 >> 4));
+  const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
+  auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
+  auto ident = [](double x, int, int) { return x; };
+  int slot = 0;
+
+  // ---- stage: vectors, [r-+] -> P, [T--] -> Q, strips r_s, R+-_s ---------------------------------------
+  if (tid < SNP) {
+    const bool in = tid < N;
+    vJp[tid] = in ? J0_p[tid] : 0.0;
+    vJm[tid] = in ? J0_m[tid] : 0.0;
+    vjp[tid] = in ? j0_p[tid] : 0.0;
+    vjm[tid] = in ? j0_m[tid] : 0.0;
+  }
+  sstrip r_s, X;
+  load_strip_global(r_s, r_mp, N, p);
+  load_strip_global(X, R_pm, N, p);           // X = R+- strip
+  stage_aform(P, r_mp, N, p);
+  stage_aform(Q, T_mm, N, p);
+  __syncthreads();
+  if (own_wave) {  // J0+ rides in the spare column c1 of R+-_s:  E1[:, c1] = r-+ J0+
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X.v[ta][r] = laneA ? vJp[p.row(ta, r)] : X.v[ta][r];
+  }
+  // ---- E1 = r-+ R+- ; u = r-+ J0+ + j0- ; G1 = (I - E1)^-1 -------------------------------------------------
+  sstrip G;
+  {
+    sstrip E;
+    E.zero();
+    mm_ab<KS>(E, P, X, p);
+    if (own_wave) {
+      double* ud = laneA ? vu : sm.vec[7];
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          ud[row] = E.v[ta][r] + vjm[row];
+        }
+    }
+    invert_strip<KS>(E, G, P, N, sm, slot, p, 0);   // (masks the columns >= N of E; P = [r-+] is free after its first barrier)
+  }
+  __syncthreads();                        // nobody reads P (series powers) any more
+  store_strip(P, G, p, keepN);            // [G1] -> P
+  __syncthreads();
+  // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H ----------------------------------------------------------
+  sstrip H, A1;
+  H.zero();
+  mm_ab<KS>(H, P, r_s, p);
+  A1.zero();
+  mm_ab<KS>(A1, Q, G, p);
+  X.zero();
+  mm_ab<KS>(X, Q, H, p);                  // X = T01_inv r-+
+  __syncthreads();                        // [G1] (P) and [T--] (Q) no longer read
+  store_strip(P, X, p, keepN);            // [T01 r-+] -> P
+  store_strip(Q, A1, p, keepN);           // [T01] -> Q
+  __syncthreads();
+  // ---- R-+ += (T01 r-+) T++ ------------------------------------------------------------------------------
+  {
+    sstrip Tpp, acc;
+    load_strip_global(Tpp, T_pp, N, p);
+    load_strip_global(acc, R_mp, N, p);
+    mm_ab<KS>(acc, P, Tpp, p);
+    store_strip_global(R_mp, acc, N, p);
+  }
+  // ---- T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--) ---------------------------------------
+  sstrip t_s;
+  load_strip_global(t_s, t_pp, N, p);
+  {
+    sstrip tmm, acc;
+    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global(tmm, t_mm, N, p);
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tmm.v[ta][r] = laneA ? vu[p.row(ta, r)] : tmm.v[ta][r];
+    }
+    acc.zero();
+    mm_ab<KS>(acc, Q, tmm, p);
+    store_strip_global(T_mm, acc, N, p);
+    if (laneA) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          if (row < N) J0_m[row] = vJm[row] + acc.v[ta][r];
+        }
+    }
+  }
+  __syncthreads();                        // [T01 r-+] (P) and [T01] (Q) no longer read
+  // ---- G2 = (I - R+- r-+)^-1 = I + R+- H  (push-through identity, see vsm_fused.hip) ; z = J0+ + R+- j0- -----
+  stage_aform(P, R_pm, N, p);             // [R+-] -> P
+  store_strip(Q, t_s, p, keepN);          // [t++] -> Q
+  if (own_wave) {  // j0- rides in the spare column c2 of H
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H.v[ta][r] = laneB ? vjm[p.row(ta, r)] : H.v[ta][r];
+  }
+  __syncthreads();
+  G.zero();
+  mm_ab<KS>(G, P, H, p);
+  if (own_wave) {
+    double* zd = laneB ? vz : sm.vec[7];
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        zd[row] = vJp[row] + G.v[ta][r];
+      }
+  }
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      const double g = keepN(G.v[ta][r], row, p.col);
+      G.v[ta][r] = (row == p.col && row < N) ? g + 1.0 : g;
+    }
+  // ---- T21 = t++ G2 -------------------------------------------------------------------------------------------
+  X.zero();
+  mm_ab<KS>(X, Q, G, p);                  // X = T21_inv
+  __syncthreads();                        // [R+-] (P), [t++] (Q) no longer read
+  store_strip(P, X, p, keepN);            // [T21] -> P
+  __syncthreads();
+  // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; tmp = T21 R+- ----------------------------------
+  {
+    sstrip Tpp, Rpm, acc1, acc2;
+    load_strip_global(Tpp, T_pp, N, p);
+    load_strip_global(Rpm, R_pm, N, p);
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
+    }
+    acc1.zero();
+    acc2.zero();
+    mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);
+    store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
+    __syncthreads();                      // everybody has read the old T++ / R+- strips from global; tmp complete
+    store_strip_global(T_pp, acc1, N, p);
+    if (laneA) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          if (row < N) J0_p[row] = vjp[row] + acc1.v[ta][r];
+        }
+    }
+  }
+  // ---- R+- = r+- + tmp t-- ---------------------------------------------------------------------------------------
+  {
+    sstrip tmm, acc;
+    if (ns) {
+      dsym_strip(tmm, t_s, ns, p);
+      dsym_strip(acc, r_s, ns, p);
+    } else {
+      load_strip_global(tmm, t_mm, N, p);
+      load_strip_global(acc, r_pm, N, p);
+    }
+    mm_ab<KS>(acc, Q, tmm, p);
+    store_strip_global(R_pm, acc, N, p);
+  }
+}
+
 }  // namespace
 
 bool strip_supported(int N) {
@@ -492,6 +734,39 @@ static int launch_ed_strip(const quad<double>& q, int S, int m, int ndoubl, cons
   hipLaunchKernelGGL(k_ed_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a);
   VSM_LAUNCH_CHECK("k_ed_strip");
   return VSM_OK;
+}
+
+template <int KS>
+static int launch_ia_strip(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+  const size_t bytes = sizeof(ssmem);
+  static int prepared = [&]() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia_strip<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ia_strip)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_ia_strip<KS>, dim3(S), dim3(SNT), bytes, st, N, c, a);
+  VSM_LAUNCH_CHECK("k_ia_strip");
+  return VSM_OK;
+}
+
+int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+#define VSM_STRIP_CASE(KS) \
+  case KS: return launch_ia_strip<KS>(N, S, c, a, st)
+  switch ((N + 3) >> 2) {
+    VSM_STRIP_CASE(9);
+    VSM_STRIP_CASE(10);
+    VSM_STRIP_CASE(11);
+    VSM_STRIP_CASE(12);
+    VSM_STRIP_CASE(13);
+    VSM_STRIP_CASE(14);
+    VSM_STRIP_CASE(15);
+    default: break;
+  }
+#undef VSM_STRIP_CASE
+  set_error("strip_interaction11: N=%d outside (32, 60]", N);
+  return VSM_ERR_UNSUPPORTED;
 }
 
 int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
