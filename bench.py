@@ -9,7 +9,7 @@ all m, all layers (elemental -> doubling -> interaction), surface, VZA post-proc
 optics already resident in HBM.  N GPUs => N x 10 000 points (weak scaling), one RCCL gather of R/T.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
-kernel (k_elemental_doubling; algorithmic flops / HIP-event launch time) and `cpu_baseline`
+kernel (the fused layer step k_layer_strip; algorithmic flops / HIP-event launch time) and `cpu_baseline`
 (the oracle port timed on a bounded sample of the same workload).
 """
 import argparse
@@ -118,25 +118,27 @@ def main():
     # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
     # one extra pass with an event pair around every k_elemental_doubling launch
     ev = []
-    orig = vsm.CoreRT.elemental_doubling_
+    orig = vsm.CoreRT.layer_forward_
 
     def timed(*a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         orig(*a, **k)
         e1.record()
-        ev.append((e0, e1, a[6]))  # a[6] = ndoubl
+        ev.append((e0, e1, a[5], a[7]))  # ndoubl, toa
 
-    vsm.CoreRT.elemental_doubling_ = timed
+    vsm.CoreRT.layer_forward_ = timed
     scene.run()
     torch.cuda.synchronize()
-    vsm.CoreRT.elemental_doubling_ = orig
+    vsm.CoreRT.layer_forward_ = orig
     n3, n2 = float(N) ** 3, float(N) ** 2
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in ev)
-    k_flops = sum(S_local * nd * (12 * n3 + 8 * n2) for _, _, nd in ev)   # algorithmic doubling flops
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ev)
+    # algorithmic flops of one layer step: nd doublings + (unless TOA) one _11 interaction
+    k_flops = sum(S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2)) for _, _, nd, toa in ev)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
-    traffic, traffic_src = hbm_traffic_per_launch("k_elemental_doubling", cfg, S_local)
+    kernel_name = "k_layer_strip" if (cfg["FT"] == "f64" and 32 < N <= 60) else "k_elemental_doubling + k_interaction11"
+    traffic, traffic_src = hbm_traffic_per_launch(kernel_name, cfg, S_local)
 
     if rank == 0:
         flops_pt = scene.flops_per_point()
@@ -155,7 +157,7 @@ def main():
                        "whole_run_tflops": pts_per_s * flops_pt / 1e12,
                        "whole_run_frac_of_mfma_peak": pts_per_s * flops_pt / 1e12 / (peak * world),
                        "prepare_scene_s (host optics + H2D, untimed)": t_prep},
-            "roofline": {"bound": "mfma", "kernel": "k_elemental_doubling", "achieved": achieved, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1)},
@@ -174,7 +176,7 @@ def hbm_traffic_per_launch(kernel, cfg, S_local):
     figure of profiles/r01/hbm_traffic_c2_s4096.json times the points of one launch.  PMC counters cannot be
     read from inside the timed process, so this is the profiled value, not a live one; null when the profile
     does not cover the configuration."""
-    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_c2_s4096.json")
+    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_c2_s4096_layer.json")
     try:
         prof = json.load(open(path))
         if prof["N"] != cfg["N"] or prof["dtype"] != cfg["FT"]:

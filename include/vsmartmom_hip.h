@@ -286,6 +286,18 @@ int vsm_postprocess_vza_lin_f64(int N, int n_stokes, int S, int nV, int P, const
 int vsm_postprocess_vza_lin_f32(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const float* w_h,
                                 const float* Jdot0_m, const float* Jdot0_p, float* Rdot, float* Tdot, void* stream);
 
+/* rt_kernel!(::noRS) for ONE scattering layer (src/CoreRT/CoreKernel/rt_kernel.jl:175-250): elemental! + doubling!
+ * followed by copy_added_to_composite! (toa != 0, i.e. iz == 1; rt_helpers.jl:188-200) or
+ * interaction!(::ScatteringInterface_11) (interaction.jl:207-266).  Arguments as vsm_elemental_doubling_*.
+ * FP64 with 32 < N <= 60 runs as ONE launch whose added layer never leaves the chip (`added_scratch` is then not
+ * touched and may be NULL); other shapes run the two launches through `added_scratch`. */
+int vsm_layer_forward_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                          const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
+                          int toa, const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream);
+int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                          const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
+                          int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream);
+
 /* ---- rotational Raman scattering (RRS), operator level ---------------------
  * Inelastic layer state (src/CoreRT/types.jl:278-335 AddedLayerRS / CompositeLayerRS): 4-D arrays
  * [N,N,S,K] / [N,1,S,K], K = number of Raman offsets (length of RS_type.i_lambda1lambda0); element

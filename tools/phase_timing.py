@@ -38,6 +38,7 @@ def main():
     lib = C.CDLL(vsm._lib.LIB_PATH)
     buf = (C.c_ulonglong * 32)()
     lib.vsm_debug_phase_cycles(None, 1)
+    lib.vsm_debug_phase_cycles_strip(None, 1)
     scene.run()
     torch.cuda.synchronize()
     lib.vsm_debug_phase_cycles(buf, 0)
@@ -51,13 +52,14 @@ def main():
         per = x / launches / (nd if n not in ("elemental", "write-out") else 1)
         print("  %-32s %12.0f total  %10.1f per %s" % (n, x, per, "step" if n not in ("elemental", "write-out") else "launch"))
     print("  sum per launch: %.0f" % (v.sum() / launches))
-    inames = ["stage R+-,r-+", "r R", "inverse 1", "H=G1 r; T01=T-- G1; u", "T-- H", "J0-; (..)T++ -> R-+",
-              "T--=T01 t--; G2=I+R H; write", "(unused)", "T21=t++ G2 + z", "T21 T++; T21 R+-; write T++", "(..) t-- -> R+-"]
-    w = np.array(list(buf)[8:19], dtype=float)
+    inames = ["stage [r],[T--], strips", "E1 = r R+-, u", "G1 (series) + store", "H, T01, T01 r + stores", "R-+ update (global)",
+              "T-- = T01 t--, J0- (global)", "stage [R+-], [t]", "G2, z, T21 + store", "T21 T++, T21 R+- (global)", "R+- (global)"]
+    lib.vsm_debug_phase_cycles_strip(buf, 0)
+    w = np.array(list(buf)[8:18], dtype=float)
     ni = L  # L-1 layer interactions + 1 surface
-    print("k_interaction11 (per launch, %d launches):" % ni)
+    print("k_ia_strip (per launch, %d launches; two workgroups share the CU, so waits include the other one's work):" % ni)
     for n, x in zip(inames, w):
-        print("  %-32s %10.1f" % (n, x / ni))
+        print("  %-36s %10.1f" % (n, x / ni))
     print("  sum per launch: %.0f" % (w.sum() / ni))
 
 

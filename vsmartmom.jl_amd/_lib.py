@@ -79,6 +79,7 @@ _SIGS = {
     "vsm_batched_mul_{T}": (_I, [_I, _I, _I, _I, _P, _LL, _P, _LL, _P, _P]),
     "vsm_batch_inv_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_elemental_doubling_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
+    "vsm_layer_forward_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P]),
     "vsm_elemental_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
     "vsm_doubling_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "vsm_noscat_layer_{T}": (_I, [_P, _I, _P, _P, _P]),

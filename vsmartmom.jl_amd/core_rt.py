@@ -211,6 +211,15 @@ def elemental_doubling_(pol: H.PolarizationType, tau_sum: torch.Tensor, dtau: to
               _ptr(tau_sum), _ptr(F0), _ptr(props.Zpp), _ptr(props.Zmp), props.z_stride, C.byref(a), _stream_ptr())
 
 
+def layer_forward_(tau_sum, dtau, F0, props: DeviceLayerOptics, m: int, ndoubl: int, dq: DeviceQuad, toa: bool,
+                   comp: CompositeLayer, added: AddedLayer):
+    """The scattering branch of rt_kernel! (rt_kernel.jl:204-249): elemental! + doubling! + (TOA copy | interaction!(::_11))."""
+    q, a, c = dq.cstruct(), added.cstruct(), comp.cstruct()
+    _lib.call("vsm_layer_forward", comp.dtype, C.byref(q), comp.nSpec, m, ndoubl, _ptr(dtau), _ptr(props.varpi),
+              _ptr(tau_sum), _ptr(F0), _ptr(props.Zpp), _ptr(props.Zmp), props.z_stride, 1 if toa else 0, C.byref(c),
+              C.byref(a), _stream_ptr())
+
+
 def elemental_(pol, tau_sum, dtau, F0, props: DeviceLayerOptics, m, ndoubl, dq: DeviceQuad, added: AddedLayer):
     """elemental! alone (elemental.jl:174-230)."""
     q, a = dq.cstruct(), added.cstruct()
@@ -306,6 +315,12 @@ def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerO
         if dtau is None:
             dtau, ndoubl = init_layer(props, dq.host, FT, numerics, arch)
         nd = ndoubl
+        if iz == 1 or scattering_interface == "11":
+            # the whole layer step in one call (one launch when the strip kernels take the shape)
+            if trace is not None:
+                trace.append(dict(iz=iz, m=m, scatter=True, ndoubl=nd, iface=scattering_interface))
+            layer_forward_(tau_sum, dtau, F0, props, m, nd, dq, iz == 1, comp, added)
+            return
         elemental_doubling_(pol, tau_sum, dtau, F0, props, m, nd, dq, added)
     else:
         zero_added_noscat_(added, props.tau, dq)

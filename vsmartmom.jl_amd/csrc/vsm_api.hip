@@ -1,5 +1,6 @@
 // extern "C" entry points of libvsmartmom_hip.so (see include/vsmartmom_hip.h).
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "vsm_internal.h"
@@ -166,6 +167,27 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
   return interaction_generic<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), work, st);
 }
 
+template <typename T, typename Q, typename C, typename A>
+static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                              const T* F0, const T* Zpp, const T* Zmp, long long zs, int toa, const C* c, const A* ad,
+                              void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_comp(c))) return rc;
+  VSM_REQUIRE(S >= 0 && m >= 0 && ndoubl >= 0, "layer_forward: bad S/m/ndoubl");
+  VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "layer_forward: null input");
+  hipStream_t st = as_stream(stream);
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_fuse = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_LAYER_FUSION") != nullptr;
+    if (!no_fuse && strip_supported(q->N))
+      return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, toa, cvt_comp<T>(c), st);
+  }
+  // two launches through the caller's AddedLayer
+  VSM_REQUIRE(ad != nullptr, "layer_forward: this shape needs an AddedLayer as scratch (N=%d)", q->N);
+  if ((rc = elemental_doubling_impl<T>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, ad, stream))) return rc;
+  if (toa) return copy_added_to_composite<T>(q->N, S, cvt_added<T>(ad), cvt_comp<T>(c), st);
+  return interaction_impl<T>(VSM_IFACE_11, q->N, S, c, ad, (T*)nullptr, stream, false);
+}
+
 }  // namespace vsm
 
 using namespace vsm;
@@ -318,6 +340,18 @@ int vsm_interaction_f32(int iface, int N, int S, const vsm_composite_f32* comp, 
 int vsm_interaction_oplevel_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_added_f32* added,
                                 float* work, void* stream) {
   return interaction_impl<float>(iface, N, S, comp, added, work, stream, true);
+}
+int vsm_layer_forward_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                          const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
+                          int toa, const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream) {
+  return layer_forward_impl<double>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, toa, comp, added_scratch,
+                                    stream);
+}
+int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                          const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
+                          int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream) {
+  return layer_forward_impl<float>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, toa, comp, added_scratch,
+                                   stream);
 }
 
 int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albedo, const double* tau_sum,

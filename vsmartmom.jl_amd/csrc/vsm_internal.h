@@ -113,6 +113,9 @@ int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, co
                              const added<double>& a, hipStream_t st);
 
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
+int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                        const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs, int toa,
+                        const composite<double>& c, hipStream_t st);
 
 // grow-only device scratch (one per element type); not for concurrent streams.
 void* scratch(size_t bytes, int slot);

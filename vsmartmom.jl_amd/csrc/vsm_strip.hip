@@ -22,6 +22,22 @@
 
 namespace vsm {
 
+#ifdef VSM_PHASE_TIMING
+__device__ unsigned long long vsm_phase_cycles_strip[32];
+#define VSM_STAMP_DECL unsigned long long _t_prev = __builtin_readcyclecounter()
+#define VSM_STAMP(i)                                                     \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
+      const unsigned long long _t = __builtin_readcyclecounter();        \
+      vsm_phase_cycles_strip[i] += _t - _t_prev;                               \
+      _t_prev = _t;                                                      \
+    }                                                                    \
+  } while (0)
+#else
+#define VSM_STAMP_DECL
+#define VSM_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int SNP = 64;    // padded matrix size
@@ -254,13 +270,14 @@ __device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int
 // ---------------------------------------------------------------------------
 // elemental! + doubling! + apply_D!   (strip form)
 // ---------------------------------------------------------------------------
+// Body shared by k_ed_strip and k_layer_strip.  On return (all waves past a barrier): r_s = strip of the final
+// r-+ (row signs of apply_D applied), t_s = strip of t++, sm.vec[0] = j0+, sm.vec[1] = j0- (final sign).
 template <int KS>   // k-steps of every product: 4 KS >= N (columns >= N of the A-forms are zero)
-__global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
-                                                     const double* __restrict__ varpi, const double* __restrict__ tau_sum,
-                                                     const double* __restrict__ F0, const double* __restrict__ Zpp,
-                                                     const double* __restrict__ Zmp, long long zs, added<double> out) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+__device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& q, int m, int ndoubl,
+                                        const double* __restrict__ dtau, const double* __restrict__ varpi,
+                                        const double* __restrict__ tau_sum, const double* __restrict__ F0,
+                                        const double* __restrict__ Zpp, const double* __restrict__ Zmp, long long zs,
+                                        sstrip& r_s, sstrip& t_s) {
   double* P = sm.P;
   double* Q = sm.Q;
   double* jp = sm.vec[0];
@@ -270,7 +287,6 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   double* xs = sm.vec[4];
   double* es = sm.vec[5];
   double* ems = sm.vec[6];
-  spos p;
   const int s = blockIdx.x;
   const int N = q.N, ns = q.n_stokes;
   const int tid = threadIdx.x;
@@ -297,7 +313,6 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   __syncthreads();
 
   // ---- elemental (elemental.jl:289-334), each lane computes the 16 elements of its strip -----------------
-  sstrip r_s, t_s;
   {
     const int j = p.col;
     const int jc = min(j, N - 1);
@@ -442,9 +457,36 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   }
   __syncthreads();
 
-  // ---- apply_D (doubling.jl:178-252) + write the added layer through LDS (coalesced stores) ---------------
-  const bool sgn = ndoubl >= 1;
-  store_strip(P, r_s, p, [=](double a, int r, int c) { return (r < N && c < N) ? ((sgn && is_uv_row(r, ns)) ? -a : a) : 0.0; });
+  // ---- apply_D (doubling.jl:178-252): r-+ = D r*, j0- = D j0-* ------------------------------------------------
+  if (ndoubl >= 1) {
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (is_uv_row(p.row(ta, r), ns)) r_s.v[ta][r] = -r_s.v[ta][r];
+    if (tid < SNP && is_uv_row(tid, ns)) jm[tid] = -jm[tid];
+  }
+  __syncthreads();
+}
+
+template <int KS>
+__global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
+                                                     const double* __restrict__ varpi, const double* __restrict__ tau_sum,
+                                                     const double* __restrict__ F0, const double* __restrict__ Zpp,
+                                                     const double* __restrict__ Zmp, long long zs, added<double> out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  spos p;
+  sstrip r_s, t_s;
+  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, r_s, t_s);
+  const int s = blockIdx.x, tid = threadIdx.x, N = q.N, ns = q.n_stokes;
+  double* P = sm.P;
+  double* Q = sm.Q;
+  const double* jp = sm.vec[0];
+  const double* jm = sm.vec[1];
+  auto keepN = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
+  // ---- write the added layer through LDS (coalesced stores) -----------------------------------------------------
+  store_strip(P, r_s, p, keepN);
   store_strip(Q, t_s, p, keepN);
   __syncthreads();
   double* g_rmp = out.r_mp + (long long)s * out.mat_stride;
@@ -464,10 +506,8 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
     }
   }
   if (tid < N) {
-    double vjm = jm[tid];
-    if (sgn && is_uv_row(tid, ns)) vjm = -vjm;
     out.j0_p[(long long)s * N + tid] = jp[tid];
-    out.j0_m[(long long)s * N + tid] = vjm;
+    out.j0_m[(long long)s * N + tid] = jm[tid];
   }
 }
 
@@ -512,21 +552,21 @@ __device__ __forceinline__ void stage_aform(double* L, const double* __restrict_
   }
 }
 
+// Body shared by k_ia_strip and k_layer_strip.  On entry: r_s / t_s = strips of the added layer's r-+ / t++,
+// sm.vec[0] / vec[1] = its j0+ / j0-, all waves past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D
+// (added layers from doubling); ns == 0: they are read from r_pm / t_mm (surface layers).
 template <int KS>
-__global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c, added<double> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+__device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const composite<double>& c, sstrip& r_s,
+                                        sstrip& t_s, const double* __restrict__ r_pm, const double* __restrict__ t_mm) {
   double* P = sm.P;
   double* Q = sm.Q;
-  double* vJp = sm.vec[0];
-  double* vJm = sm.vec[1];
-  double* vjp = sm.vec[2];
-  double* vjm = sm.vec[3];
+  double* vjp = sm.vec[0];
+  double* vjm = sm.vec[1];
+  double* vJp = sm.vec[2];
+  double* vJm = sm.vec[3];
   double* vu = sm.vec[4];
   double* vz = sm.vec[5];
-  spos p;
   const int s = blockIdx.x, tid = threadIdx.x;
-  const int ns = a.d_symmetric;   // n_stokes when the added layer is D-symmetric, else 0 (then r+-/t-- are read)
   const long long NN = (long long)N * N;
   double* R_mp = c.R_mp + s * NN;
   double* R_pm = c.R_pm + s * NN;
@@ -534,34 +574,26 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
   double* T_mm = c.T_mm + s * NN;
   double* J0_p = c.J0_p + (long long)s * N;
   double* J0_m = c.J0_m + (long long)s * N;
-  const double* r_mp = a.r_mp + s * a.mat_stride;
-  const double* r_pm = a.r_pm + s * a.mat_stride;
-  const double* t_pp = a.t_pp + s * a.mat_stride;
-  const double* t_mm = a.t_mm + s * a.mat_stride;
-  const double* j0_p = a.j0_p + (long long)s * N;
-  const double* j0_m = a.j0_m + (long long)s * N;
   const int Kend = ((N + 3) >> 2) << 2;
   const int c1 = Kend, c2 = Kend + 1;
   const bool own_wave = (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
   auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
-  auto ident = [](double x, int, int) { return x; };
   int slot = 0;
 
-  // ---- stage: vectors, [r-+] -> P, [T--] -> Q, strips r_s, R+-_s ---------------------------------------
+  VSM_STAMP_DECL;
+  // ---- stage: composite vectors, [r-+] -> P, [T--] -> Q, strip of R+- -------------------------------------------
   if (tid < SNP) {
     const bool in = tid < N;
     vJp[tid] = in ? J0_p[tid] : 0.0;
     vJm[tid] = in ? J0_m[tid] : 0.0;
-    vjp[tid] = in ? j0_p[tid] : 0.0;
-    vjm[tid] = in ? j0_m[tid] : 0.0;
   }
-  sstrip r_s, X;
-  load_strip_global(r_s, r_mp, N, p);
+  sstrip X;
   load_strip_global(X, R_pm, N, p);           // X = R+- strip
-  stage_aform(P, r_mp, N, p);
+  store_strip(P, r_s, p, keepN);
   stage_aform(Q, T_mm, N, p);
   __syncthreads();
+  VSM_STAMP(8);
   if (own_wave) {  // J0+ rides in the spare column c1 of R+-_s:  E1[:, c1] = r-+ J0+
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -584,11 +616,13 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
           ud[row] = E.v[ta][r] + vjm[row];
         }
     }
+    VSM_STAMP(9);
     invert_strip<KS>(E, G, P, N, sm, slot, p, 0);   // (masks the columns >= N of E; P = [r-+] is free after its first barrier)
   }
   __syncthreads();                        // nobody reads P (series powers) any more
   store_strip(P, G, p, keepN);            // [G1] -> P
   __syncthreads();
+  VSM_STAMP(10);
   // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H ----------------------------------------------------------
   sstrip H, A1;
   H.zero();
@@ -601,17 +635,18 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
   store_strip(P, X, p, keepN);            // [T01 r-+] -> P
   store_strip(Q, A1, p, keepN);           // [T01] -> Q
   __syncthreads();
+  VSM_STAMP(11);
   // ---- R-+ += (T01 r-+) T++ ------------------------------------------------------------------------------
+  sstrip Tpp;                             // old T++ strip: kept in registers until T++ = T21 T++
+  load_strip_global(Tpp, T_pp, N, p);
   {
-    sstrip Tpp, acc;
-    load_strip_global(Tpp, T_pp, N, p);
+    sstrip acc;
     load_strip_global(acc, R_mp, N, p);
     mm_ab<KS>(acc, P, Tpp, p);
     store_strip_global(R_mp, acc, N, p);
   }
+  VSM_STAMP(12);
   // ---- T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--) ---------------------------------------
-  sstrip t_s;
-  load_strip_global(t_s, t_pp, N, p);
   {
     sstrip tmm, acc;
     if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global(tmm, t_mm, N, p);
@@ -635,6 +670,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
     }
   }
   __syncthreads();                        // [T01 r-+] (P) and [T01] (Q) no longer read
+  VSM_STAMP(13);
   // ---- G2 = (I - R+- r-+)^-1 = I + R+- H  (push-through identity, see vsm_fused.hip) ; z = J0+ + R+- j0- -----
   stage_aform(P, R_pm, N, p);             // [R+-] -> P
   store_strip(Q, t_s, p, keepN);          // [t++] -> Q
@@ -645,8 +681,11 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
       for (int r = 0; r < 4; ++r) H.v[ta][r] = laneB ? vjm[p.row(ta, r)] : H.v[ta][r];
   }
   __syncthreads();
+  VSM_STAMP(14);
   G.zero();
   mm_ab<KS>(G, P, H, p);
+  sstrip Rpm;
+  load_strip(Rpm, P, p);                  // R+- strip from its A-form (no second global read)
   if (own_wave) {
     double* zd = laneB ? vz : sm.vec[7];
 #pragma unroll
@@ -671,11 +710,13 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
   __syncthreads();                        // [R+-] (P), [t++] (Q) no longer read
   store_strip(P, X, p, keepN);            // [T21] -> P
   __syncthreads();
+  VSM_STAMP(15);
   // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; tmp = T21 R+- ----------------------------------
   {
-    sstrip Tpp, Rpm, acc1, acc2;
-    load_strip_global(Tpp, T_pp, N, p);
-    load_strip_global(Rpm, R_pm, N, p);
+    sstrip acc1, acc2;
+#ifndef VSM_IA_KEEP_TPP
+    load_strip_global(Tpp, T_pp, N, p);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
+#endif
     if (own_wave) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
@@ -684,7 +725,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
     }
     acc1.zero();
     acc2.zero();
-    mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);
+    mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);   // (Rpm: strip of R+-, read back from its A-form before that was overwritten)
     store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
     __syncthreads();                      // everybody has read the old T++ / R+- strips from global; tmp complete
     store_strip_global(T_pp, acc1, N, p);
@@ -698,6 +739,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
         }
     }
   }
+  VSM_STAMP(16);
   // ---- R+- = r+- + tmp t-- ---------------------------------------------------------------------------------------
   {
     sstrip tmm, acc;
@@ -711,6 +753,60 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
     mm_ab<KS>(acc, Q, tmm, p);
     store_strip_global(R_pm, acc, N, p);
   }
+  VSM_STAMP(17);
+}
+
+template <int KS>
+__global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c, added<double> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  spos p;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  if (tid < SNP) {
+    const bool in = tid < N;
+    sm.vec[0][tid] = in ? a.j0_p[(long long)s * N + tid] : 0.0;
+    sm.vec[1][tid] = in ? a.j0_m[(long long)s * N + tid] : 0.0;
+  }
+  sstrip r_s, t_s;
+  load_strip_global(r_s, a.r_mp + s * a.mat_stride, N, p);
+  load_strip_global(t_s, a.t_pp + s * a.mat_stride, N, p);
+  __syncthreads();
+  ia_body<KS>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
+              a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride);
+}
+
+// rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
+// either the TOA copy (iz == 1: copy_added_to_composite!, rt_helpers.jl:188-200) or interaction!(::_11).  The added
+// layer never leaves the chip.
+template <int KS>
+__global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
+                                                        const double* __restrict__ varpi,
+                                                        const double* __restrict__ tau_sum, const double* __restrict__ F0,
+                                                        const double* __restrict__ Zpp, const double* __restrict__ Zmp,
+                                                        long long zs, int toa, composite<double> c) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  spos p;
+  sstrip r_s, t_s;
+  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, r_s, t_s);
+  const int N = q.N, ns = q.n_stokes;
+  if (toa) {
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const long long NN = (long long)N * N;
+    store_strip_global(c.R_mp + s * NN, r_s, N, p);
+    store_strip_global(c.T_pp + s * NN, t_s, N, p);
+    sstrip d;
+    dsym_strip(d, r_s, ns, p);
+    store_strip_global(c.R_pm + s * NN, d, N, p);
+    dsym_strip(d, t_s, ns, p);
+    store_strip_global(c.T_mm + s * NN, d, N, p);
+    if (tid < N) {
+      c.J0_p[(long long)s * N + tid] = sm.vec[0][tid];
+      c.J0_m[(long long)s * N + tid] = sm.vec[1][tid];
+    }
+    return;
+  }
+  ia_body<KS>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
 }
 
 }  // namespace
@@ -748,6 +844,44 @@ static int launch_ia_strip(int N, int S, const composite<double>& c, const added
   hipLaunchKernelGGL(k_ia_strip<KS>, dim3(S), dim3(SNT), bytes, st, N, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip");
   return VSM_OK;
+}
+
+template <int KS>
+static int launch_layer_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                              const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
+                              int toa, const composite<double>& c, hipStream_t st) {
+  const size_t bytes = sizeof(ssmem);
+  static int prepared = [&]() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_strip<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_layer_strip)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_layer_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
+                     zs, toa, c);
+  VSM_LAUNCH_CHECK("k_layer_strip");
+  return VSM_OK;
+}
+
+int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                        const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs, int toa,
+                        const composite<double>& c, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+#define VSM_STRIP_CASE(KS) \
+  case KS: return launch_layer_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, toa, c, st)
+  switch ((q.N + 3) >> 2) {
+    VSM_STRIP_CASE(9);
+    VSM_STRIP_CASE(10);
+    VSM_STRIP_CASE(11);
+    VSM_STRIP_CASE(12);
+    VSM_STRIP_CASE(13);
+    VSM_STRIP_CASE(14);
+    VSM_STRIP_CASE(15);
+    default: break;
+  }
+#undef VSM_STRIP_CASE
+  set_error("strip_layer_forward: N=%d outside (32, 60]", q.N);
+  return VSM_ERR_UNSUPPORTED;
 }
 
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
@@ -791,3 +925,14 @@ int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, co
 }
 
 }  // namespace vsm
+
+#ifdef VSM_PHASE_TIMING
+extern "C" int vsm_debug_phase_cycles_strip(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_strip), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_phase_cycles_strip), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
