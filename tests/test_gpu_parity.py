@@ -552,3 +552,56 @@ def test_noscat_and_mixed_interfaces(vsm, arch):
     assert [t["iface"] for t in trg[:4]] == ["00", "00", "01", "11"]
     assert [t["iface"] for t in tro] == [t["iface"] for t in trg]
     assert _rel(Rg, Ro) < 1e-9 and _rel(Tg, To) < 1e-9
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
+def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
+    """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers
+    over a bright surface drive the doubling through every inverse path (series orders 1..31 and the pivoted
+    Gauss-Jordan) and the interaction through large ||r R||; thin absorbing points share the batch."""
+    S = 5
+    tau_rayl = np.array([[0.05, 1.5, 4.0]] * S)
+    tau_abs = np.array([[1e-3, 1e-4, 1e-5], [0.5, 0.2, 0.1], [5.0, 1.0, 3.0], [0.0, 0.0, 0.0], [1e-2, 30.0, 1e-2]])
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 50.0, [0.0, 60.0], [30.0, 120.0], tau_rayl=tau_rayl, tau_abs=tau_abs,
+                          depol=0.03, albedo=0.8, m_max=3)
+    N = om.quad_points.Nquad * om.pol.n
+    assert 32 < N <= 60, N
+    tro, trg = [], []
+    Ro, To = O.rt_run(om, trace=tro)
+    Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
+    assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
+    assert max(t["ndoubl"] for t in tro) >= 12
+    assert _rel(Rg, Ro) < 1e-8 and _rel(Tg, To) < 1e-8, (N, _rel(Rg, Ro), _rel(Tg, To))
+
+
+@pytest.mark.parametrize("FT,pol,l_trunc", [(np.float64, "IQU", 35), (np.float64, "IQU", 21), (np.float32, "IQU", 35),
+                                            (np.float64, "IQUV", 35)])
+@pytest.mark.parametrize("toa", [True, False])
+def test_layer_forward_entry_point(vsm, arch, FT, pol, l_trunc, toa):
+    """vsm_layer_forward (the scattering branch of rt_kernel!, one call per layer) vs the oracle's elemental ->
+    doubling -> (copy | interaction 11): FP64 N = 60 / 36 take the fused strip kernel, FP32 and N = 80 the two-launch path."""
+    pol_o, qp, props, rng = _scene(pol, l_trunc, 40.0, [30.0, 0.0], FT)
+    lo = props[1]
+    S, N = len(lo.tau), qp.Nquad * pol_o.n
+    dtau, nd = O.get_dtau_ndoubl(lo.tau, lo.varpi, qp, FT)
+    tau_sum = rng.random(S).astype(FT)
+    F0 = np.zeros((pol_o.n, S), dtype=FT)
+    F0[0] = 1.0
+    oa = O.make_added_layer(FT, N, S)
+    O.elemental(pol_o, tau_sum, dtau, F0, lo.varpi, lo.Zpp, lo.Zmp, 1, nd, qp, oa, FT)
+    O.doubling(pol_o, np.exp(-dtau / FT(qp.mu0)).astype(FT), nd, oa, FT)
+    comp, _ = _random_layers(rng, N, S, FT, None)
+    pc, _pa = _upload_layers(vsm, arch, comp, oa, FT)
+    if toa:
+        O.copy_added_to_composite(comp, oa)
+    else:
+        O.interaction("11", comp, oa, FT)
+    dq, hpol = _product_quad(vsm, arch, qp, pol_o, FT)
+    conv = vsm.Architectures.array_type(arch)
+    pp = _product_props(vsm, arch, lo, FT)
+    scratch = vsm.CoreRT.make_added_layer(FT, arch, (N, N), S)
+    vsm.CoreRT.layer_forward_(conv(tau_sum), conv(dtau), conv(np.ascontiguousarray(F0.T)), pp, 1, nd, dq, toa, pc, scratch)
+    got = _comp_to_host(vsm, pc)
+    tol = 1e-10 if FT == np.float64 else 5e-4
+    for k, v in got.items():
+        assert _rel(v, getattr(comp, k)) < tol, (k, _rel(v, getattr(comp, k)))
