@@ -172,16 +172,19 @@ def main():
 
 def hbm_traffic_per_launch(kernel, cfg, S_local):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in
-    separate rocprofv3 runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
-    figure of profiles/r01/hbm_traffic_c2_s4096.json times the points of one launch.  PMC counters cannot be
-    read from inside the timed process, so this is the profiled value, not a live one; null when the profile
-    does not cover the configuration."""
-    path = os.path.join(ROOT, "profiles", "r01", "hbm_traffic_c2_s4096_layer.json")
+    separate rocprofv3 runs by tools/profile_round.sh, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+    gfx950): the per-point figure of profiles/r01/pmc_summary_c2_s4096_layer.json times the points of one launch.
+    PMC counters cannot be read from inside the timed process, so this is the profiled value, not a live one; null
+    when the profile does not cover the configuration."""
+    path = os.path.join(ROOT, "profiles", "r01", "pmc_summary_c2_s4096_layer.json")
     try:
         prof = json.load(open(path))
         if prof["N"] != cfg["N"] or prof["dtype"] != cfg["FT"]:
             return None, None
-        return prof["kernels"][kernel]["hbm_bytes_per_point"] * S_local, os.path.relpath(path, ROOT)
+        for name, rec in prof["kernels"].items():
+            if kernel in name:
+                return rec["hbm_bytes_per_point"] * S_local, os.path.relpath(path, ROOT)
+        return None, None
     except Exception:
         return None, None
 
