@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o s -- python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-tail -1 $OUT/stats.log > $OUT/bench_line.json
+grep "^{\"metric\"" $OUT/stats.log > $OUT/bench_line.json
 B="python bench.py --points 4096 --steps 1 --warmup 0 --no-cpu-baseline"
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- $B > $OUT/write.log 2>&1
