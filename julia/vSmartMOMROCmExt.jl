@@ -64,11 +64,12 @@ batched_pointer_cache(::ROCArray) = nothing                # route to the 2-arg 
 
 # ---- CoreKernel overrides (north_star: no KernelAbstractions on this backend) --------------------
 struct VsmAdded;     r_mp::Ptr{Cvoid}; t_pp::Ptr{Cvoid}; r_pm::Ptr{Cvoid}; t_mm::Ptr{Cvoid}
-                     j0_p::Ptr{Cvoid}; j0_m::Ptr{Cvoid}; mat_stride::Clonglong end
+                     j0_p::Ptr{Cvoid}; j0_m::Ptr{Cvoid}; mat_stride::Clonglong
+                     d_symmetric::Cint; reserved::Cint end          # = vsm_added_f64 / _f32
 struct VsmComposite; R_mp::Ptr{Cvoid}; R_pm::Ptr{Cvoid}; T_pp::Ptr{Cvoid}; T_mm::Ptr{Cvoid}
                      J0_p::Ptr{Cvoid}; J0_m::Ptr{Cvoid} end
 _c(a::AddedLayer) = VsmAdded(_p(a.r⁻⁺), _p(a.t⁺⁺), _p(a.r⁺⁻), _p(a.t⁻⁻), _p(a.j₀⁺), _p(a.j₀⁻),
-                             size(a.r⁻⁺, 3) == 1 ? 0 : size(a.r⁻⁺, 1)^2)
+                             size(a.r⁻⁺, 3) == 1 ? 0 : size(a.r⁻⁺, 1)^2, 0, 0)
 _c(c::CompositeLayer) = VsmComposite(_p(c.R⁻⁺), _p(c.R⁺⁻), _p(c.T⁺⁺), _p(c.T⁻⁻), _p(c.J₀⁺), _p(c.J₀⁻))
 _tag(::ScatteringInterface_00) = 0; _tag(::ScatteringInterface_01) = 1
 _tag(::ScatteringInterface_10) = 2; _tag(::ScatteringInterface_11) = 3
@@ -82,4 +83,32 @@ function interaction!(iface, SFI, c::CompositeLayer{FT}, a::AddedLayer{FT}, I_st
 end
 # elemental! (elemental.jl:174-230) stores its inputs; doubling! (doubling.jl:112-131) then launches the fused
 # vsm_elemental_doubling_* with them -- see INTEGRATION.md for the two-line patch in rt_kernel!.
+
+# rt_kernel!(::noRS) scattering branch (rt_kernel.jl:204-249) as ONE call: elemental! + doubling! + (TOA copy | interaction!(_11))
+struct VsmQuad{FT}; mu::Ptr{Cvoid}; wt::Ptr{Cvoid}; N::Cint; n_stokes::Cint; i_mu0::Cint; mu0::FT end
+function layer_forward!(q::VsmQuad{Float64}, nSpec, m, ndoubl, dτ, ϖ, τ_sum, F₀, Z⁺⁺, Z⁻⁺, iz,
+                        c::CompositeLayer{Float64}, a::AddedLayer{Float64})
+    zs = size(Z⁺⁺, 3) == 1 ? 0 : size(Z⁺⁺, 1)^2
+    _chk(ccall((:vsm_layer_forward_f64, libvsm), Cint,
+               (Ref{VsmQuad{Float64}}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
+                Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, Ptr{Cvoid}),
+               q, nSpec, m, ndoubl, _p(dτ), _p(ϖ), _p(τ_sum), _p(F₀), _p(Z⁺⁺), _p(Z⁻⁺), zs, iz == 1 ? 1 : 0, _c(c), _c(a),
+               _stream()))
+end
+
+# Rotational Raman (CoreKernel/*_inelastic.jl): the 4-D arrays keep the reference layout [N,N,nSpec,nRaman]
+struct VsmAddedRS;     ier_mp::Ptr{Cvoid}; iet_pp::Ptr{Cvoid}; ier_pm::Ptr{Cvoid}; iet_mm::Ptr{Cvoid}
+                       ieJ0_p::Ptr{Cvoid}; ieJ0_m::Ptr{Cvoid}; K::Cint; reserved::Cint end
+struct VsmCompositeRS; ieR_mp::Ptr{Cvoid}; ieR_pm::Ptr{Cvoid}; ieT_pp::Ptr{Cvoid}; ieT_mm::Ptr{Cvoid}
+                       ieJ0_p::Ptr{Cvoid}; ieJ0_m::Ptr{Cvoid}; K::Cint; reserved::Cint end
+_c_rs(a) = VsmAddedRS(_p(a.ier⁻⁺), _p(a.iet⁺⁺), _p(a.ier⁺⁻), _p(a.iet⁻⁻), _p(a.ieJ₀⁺), _p(a.ieJ₀⁻), size(a.ier⁻⁺, 4), 0)
+_C_rs(c) = VsmCompositeRS(_p(c.ieR⁻⁺), _p(c.ieR⁺⁻), _p(c.ieT⁺⁺), _p(c.ieT⁻⁻), _p(c.ieJ₀⁺), _p(c.ieJ₀⁻), size(c.ieR⁻⁺, 4), 0)
+# interaction!(RS_type::RRS, ::ScatteringInterface_11, ...) (interaction_inelastic.jl:683-700); i_λ₁λ₀_dev = ROCArray{Cint}
+function interaction_rrs!(i_λ₁λ₀_dev, c, a, work::ROCArray{Float64})
+    N, _, S = size(c.R⁻⁺)
+    _chk(ccall((:vsm_interaction_inelastic_rrs_f64, libvsm), Cint,
+               (Cint, Cint, Cint, Ptr{Cvoid}, Ref{VsmComposite}, Ref{VsmCompositeRS}, Ref{VsmAdded}, Ref{VsmAddedRS},
+                Ptr{Cvoid}, Ptr{Cvoid}),
+               3, N, S, _p(i_λ₁λ₀_dev), _c(c), _C_rs(c), _c(a), _c_rs(a), _p(work), _stream()))
+end
 end # module

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Timing of the rotational-Raman pass on a C5-shaped problem (BASELINE.json configs[4]): nStokes = 3, spectral points S,
+K Raman offsets, L layers.  Diagnostic (numbers quoted in DESIGN.md); not the bench contract."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import vsmartmom_jl_amd as vsm  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--lines", type=int, default=40)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--l-trunc", type=int, default=9)
+    ap.add_argument("--oracle-points", type=int, default=0)
+    a = ap.parse_args()
+    S, K, L = a.points, a.lines, a.layers
+    rng = np.random.default_rng(20260929)
+    arch = vsm.Architectures.GPU(0)
+    dp = np.full(L, 1.0 / L)
+    tau_rayl = np.tile(0.3 * dp, (S, 1))
+    tau_abs = (10.0 ** rng.uniform(-4, 0, (S, 1))) * dp[None, :]
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.05, m_max=2)
+    model = vsm.host_model.model_from_arrays(arch, "IQU", a.l_trunc, 40.0, [30.0], [0.0], **kw)
+    model.varpi_Cabannes = 0.96
+    N = model.quad_points.Nquad * 3
+    shifts = np.unique(np.concatenate([np.arange(-K // 2, 0), np.arange(1, K - K // 2 + 1)]) * 7)
+    w_ie = np.full(len(shifts), 0.04 / len(shifts))
+    rs = vsm.CoreRTRaman.RRS(shifts, w_ie, vsm.host_model.get_greek_rayleigh(0.75))
+    t0 = time.perf_counter()
+    out = vsm.CoreRTRaman.rt_run(rs, model, 1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = vsm.CoreRTRaman.rt_run(rs, model, 1)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("Raman RRS: N=%d S=%d K=%d L=%d m=0..2: first run %.2f s, second run %.2f s -> %.0f spectral-points/s; peak device memory %.1f GB"
+          % (N, S, len(shifts), L, t1 - t0, t2 - t1, S / (t2 - t1), torch.cuda.max_memory_allocated() / 1e9))
+    print("  max |ieR| = %.3e, max |R| = %.3e" % (np.abs(out[2]).max(), np.abs(out[0]).max()))
+    if a.oracle_points:
+        from oracle import vsm_oracle as O
+        from oracle import vsm_oracle_raman as OR
+        n = a.oracle_points
+        om = O.build_model("IQU", a.l_trunc, 40.0, [30.0], [0.0], tau_rayl=tau_rayl[:n], tau_abs=tau_abs[:n], depol=0.0075,
+                           albedo=0.05, m_max=2)
+        om.varpi_cabannes = 0.96
+        t0 = time.perf_counter()
+        OR.rt_run_rrs(om, OR.RRS(i_shift=shifts, varpi_ie=w_ie, greek_raman=O.get_greek_rayleigh(0.75)))
+        dt = time.perf_counter() - t0
+        print("  numpy oracle on the first %d points: %.2f s -> %.1f spectral-points/s (1 process)" % (n, dt, n / dt))
+
+
+if __name__ == "__main__":
+    main()
