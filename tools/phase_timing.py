@@ -42,16 +42,17 @@ def main():
     scene.run()
     torch.cuda.synchronize()
     lib.vsm_debug_phase_cycles(buf, 0)
-    names = ["elemental", "r*r", "inverse", "tt=tG+store+bar", "(matvec)+tmp=tt r+store+bar", "two products",
-             "stores+2 bar+combine", "write-out"]
-    v = np.array(list(buf)[:8], dtype=float)
-    launches = L  # one ED launch per layer (m=0 only)
+    lib.vsm_debug_phase_cycles_strip(buf, 0)
+    names = ["elemental (per launch)", "E = r r", "norm + inverse", "tt = t G, store, 2 barriers", "tmp = tt r ; t' = tt t, store, barrier",
+             "r' = r + tmp t, sources", "barrier, store r t, barrier"]
+    v = np.array(list(buf)[:7], dtype=float)
+    launches = L
     nd = scene.moments[0]["layers"][0]["nd"]
-    print("S=%d layers=%d nd=%d ; cycles of workgroup 0 (s_memtime, 100 MHz? see total)" % (S, L, nd))
-    for n, x in zip(names, v):
-        per = x / launches / (nd if n not in ("elemental", "write-out") else 1)
-        print("  %-32s %12.0f total  %10.1f per %s" % (n, x, per, "step" if n not in ("elemental", "write-out") else "launch"))
-    print("  sum per launch: %.0f" % (v.sum() / launches))
+    print("S=%d layers=%d nd=%d ; cycles of workgroup 0 / thread 0 of k_layer_strip" % (S, L, nd))
+    for i, (n, x) in enumerate(zip(names, v)):
+        per = x / launches / (nd if i else 1)
+        print("  %-44s %12.0f total  %10.1f per %s" % (n, x, per, "step" if i else "launch"))
+    print("  doubling loop per step: %.0f" % (v[1:].sum() / launches / nd))
     inames = ["stage [r],[T--], strips", "E1 = r R+-, u", "G1 (series) + store", "H, T01, T01 r + stores", "R-+ update (global)",
               "T-- = T01 t--, J0- (global)", "stage [R+-], [t]", "G2, z, T21 + store", "T21 T++, T21 R+- (global)", "R+- (global)"]
     lib.vsm_debug_phase_cycles_strip(buf, 0)

@@ -394,6 +394,8 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------
   double expk = exp(-d / q.mu0);
   int slot = 0;
+  VSM_STAMP_DECL;
+  VSM_STAMP(0);
   for (int n = 0; n < ndoubl; ++n) {
     // on entry: P = r, Q = t (A-form), r_s / t_s in registers, all waves past a barrier
     sstrip G;
@@ -401,7 +403,9 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
       sstrip E;
       E.zero();
       mm_ab<KS>(E, P, r_s, p);
-      invert_strip<KS>(E, G, P, N, sm, slot, p, 0);  // (its first barrier: every wave is done reading P = r)
+      VSM_STAMP(1);
+      invert_strip<KS>(E, G, P, N, sm, slot, p, 0);
+      VSM_STAMP(2);  // (its first barrier: every wave is done reading P = r)
     }
     // tt = t G
     sstrip tt;
@@ -422,6 +426,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
         }
     }
     __syncthreads();  // tt complete in P
+    VSM_STAMP(3);
     // tmp = tt r ; t' = tt t  (+ tt j0+, tt j1- in the spare columns)
     sstrip tmp, tn;
     tmp.zero();
@@ -429,6 +434,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     mm_ab2<KS>(tmp, tn, P, r_s, t_s, p);
     store_strip(Q, tmp, p, keepN);  // Q (t) is dead since the barrier before the tt store
     __syncthreads();                // tmp complete in Q
+    VSM_STAMP(4);
     // r' = r + tmp t   (+ tmp j0+, tmp j1- in the spare columns, on top of r_s's zero padding)
     mm_ab<KS>(r_s, Q, t_s, p);
     // sources: j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134)
@@ -446,6 +452,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
           tn.v[ta][r] = laneAB ? 0.0 : tn.v[ta][r];
         }
     }
+    VSM_STAMP(5);
     t_s = tn;
     expk = expk * expk;
     if (n + 1 < ndoubl) {
@@ -454,6 +461,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
       store_strip(Q, t_s, p, keepN);
       __syncthreads();
     }
+    VSM_STAMP(6);
   }
   __syncthreads();
 
