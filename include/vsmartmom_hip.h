@@ -298,6 +298,27 @@ int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
                           const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
                           int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream);
 
+/* Layer optics with several scatterers: the reference mixes Z per spectral point on the host,
+ * Z = sum_k (tau_k varpi_k Z_k) / sum_k (tau_k varpi_k)  (`+` of CoreScatteringOpticalProperties, src/CoreRT/types.jl:1262-1292;
+ * compEffectiveLayerProperties.jl:43-54) and ships [N,N,nSpec] arrays to the device.  Here the ncomp component
+ * matrices Zpp_comp / Zmp_comp [N,N,ncomp] (one stack per Fourier moment) and the per-point weights fcomp [ncomp,S]
+ * (fcomp[k + ncomp*s]) are handed over instead.
+ * vsm_layer_forward_mix_*: as vsm_layer_forward_*, mixing Z where the elemental step consumes it (fused strip kernel,
+ *   ncomp <= 4); other shapes materialise Z into z_scratch (2*N*N*S elements; NULL = library scratch) first.
+ * vsm_mix_Z_*: the materialising kernel on its own: Zpp/Zmp [N,N,S]. */
+int vsm_layer_forward_mix_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                              const double* tau_sum, const double* F0, int ncomp, const double* Zpp_comp,
+                              const double* Zmp_comp, const double* fcomp, double* z_scratch, int toa,
+                              const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream);
+int vsm_layer_forward_mix_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                              const float* tau_sum, const float* F0, int ncomp, const float* Zpp_comp, const float* Zmp_comp,
+                              const float* fcomp, float* z_scratch, int toa, const vsm_composite_f32* comp,
+                              const vsm_added_f32* added_scratch, void* stream);
+int vsm_mix_Z_f64(int N, int S, int ncomp, const double* Zpp_comp, const double* Zmp_comp, const double* fcomp, double* Zpp,
+                  double* Zmp, void* stream);
+int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Zmp_comp, const float* fcomp, float* Zpp,
+                  float* Zmp, void* stream);
+
 /* ---- rotational Raman scattering (RRS), operator level ---------------------
  * Inelastic layer state (src/CoreRT/types.jl:278-335 AddedLayerRS / CompositeLayerRS): 4-D arrays
  * [N,N,S,K] / [N,1,S,K], K = number of Raman offsets (length of RS_type.i_lambda1lambda0); element

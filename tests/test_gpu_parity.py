@@ -605,3 +605,37 @@ def test_layer_forward_entry_point(vsm, arch, FT, pol, l_trunc, toa):
     tol = 1e-10 if FT == np.float64 else 5e-4
     for k, v in got.items():
         assert _rel(v, getattr(comp, k)) < tol, (k, _rel(v, getattr(comp, k)))
+
+
+@pytest.mark.parametrize("FT,pol,l_trunc,tol", [(np.float64, "IQU", 33, 1e-8), (np.float64, "IQU", 19, 1e-8), (np.float64, "I", 9, 1e-8),
+                                                (np.float64, "IQUV", 41, 1e-8), (np.float32, "IQU", 33, 1e-2)])
+def test_rt_run_component_mixing_on_device(vsm, arch, FT, pol, l_trunc, tol):
+    """Layers with Rayleigh + two aerosol types and a spectrally varying Rayleigh optical depth: Z differs from point
+    to point.  The host ships only the component matrices and per-point weights; the strip kernel mixes Z on the fly
+    (FP64, 32 < N <= 60), the other shapes through vsm_mix_Z.  Compared with the oracle, which mixes pairwise on the host
+    like the reference (types.jl:1262-1292)."""
+    rng = np.random.default_rng(5)
+    S, L = 6, 4
+    tau_rayl = 0.03 * (1.0 + rng.random((S, L)))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    tau_aer = np.array([[0.0, 0.05, 0.2, 0.1], [0.03, 0.0, 0.1, 0.3]])
+    aos = [O.AerosolOptics(O.hg_greek(0.7, 12), 0.95, 0.1), O.AerosolOptics(O.hg_greek(0.5, 8), 0.9, 0.0)]
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 40.0, [30.0, 0.0], [0.0, 75.0], FT=FT, tau_rayl=tau_rayl, tau_abs=tau_abs,
+                          tau_aer=tau_aer, aerosols=aos, depol=0.03, albedo=0.1, m_max=4)
+    tro, trg = [], []
+    Ro, To = O.rt_run(om, trace=tro)
+    Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
+    assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
+    assert _rel(Rg, Ro) < tol and _rel(Tg, To) < tol, (_rel(Rg, Ro), _rel(Tg, To))
+    # the materialising kernel on its own
+    H = vsm.host_model
+    Zc_pp, Zc_mp, lay = H.constructLayerOpticsComponents(pm, 1)
+    lo = lay[2]
+    assert lo.coef.ndim == 2
+    conv = vsm.Architectures.array_type(arch)
+    props = vsm.CoreRT.DeviceLayerOptics(conv(lo.tau.astype(FT)), conv(lo.varpi.astype(FT)),
+                                         vsm.CoreRT.to_device_matrix(Zc_pp, arch, FT), vsm.CoreRT.to_device_matrix(Zc_mp, arch, FT),
+                                         1.0, lo.tau, lo.varpi, conv(np.ascontiguousarray(lo.coef.astype(FT))))
+    mat = props.materialize()
+    ref = np.einsum("sk,kij->sij", lo.coef, Zc_pp)
+    assert _rel(vsm.CoreRT.from_device_matrix(mat.Zpp), ref) < (1e-14 if FT == np.float64 else 1e-6)

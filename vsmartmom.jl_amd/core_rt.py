@@ -184,11 +184,28 @@ class DeviceLayerOptics:
     max_tau_varpi: float   # host copy of maximum(τ .* ϖ) (rt_kernel.jl:197) -- avoids a device sync
     tau_h: np.ndarray      # host copies used by get_dtau_ndoubl
     varpi_h: np.ndarray
+    # several scatterers: Zpp/Zmp hold the ncomp COMPONENT matrices (ncomp, N, N) and fcomp (S, ncomp) the per-point
+    # weights; Z = sum_k fcomp[s,k] Z_k is formed where it is consumed (vsm_layer_forward_mix) or by materialize()
+    fcomp: Optional[torch.Tensor] = None
 
     @property
     def z_stride(self):
+        if self.fcomp is not None:
+            raise _lib.VSMError("component-mixed layer optics: call materialize() for kernels that take Z[N,N,S]")
         N = self.Zpp.shape[-1]
         return 0 if self.Zpp.shape[0] == 1 else N * N
+
+    def materialize(self) -> "DeviceLayerOptics":
+        """Z[N,N,S] = sum_k fcomp[s,k] Z_k on the device (vsm_mix_Z; types.jl:1262-1292)."""
+        if self.fcomp is None:
+            return self
+        S, C = self.fcomp.shape
+        N = self.Zpp.shape[-1]
+        Zpp = torch.empty((S, N, N), dtype=self.Zpp.dtype, device=self.Zpp.device)
+        Zmp = torch.empty_like(Zpp)
+        _lib.call("vsm_mix_Z", Zpp.dtype, N, S, C, _ptr(self.Zpp), _ptr(self.Zmp), _ptr(self.fcomp), _ptr(Zpp), _ptr(Zmp),
+                  _stream_ptr())
+        return DeviceLayerOptics(self.tau, self.varpi, Zpp, Zmp, self.max_tau_varpi, self.tau_h, self.varpi_h)
 
 
 def expandOpticalProperties(p: H.CoreScatteringOpticalProperties, arch, FT) -> DeviceLayerOptics:
@@ -215,6 +232,11 @@ def layer_forward_(tau_sum, dtau, F0, props: DeviceLayerOptics, m: int, ndoubl: 
                    comp: CompositeLayer, added: AddedLayer):
     """The scattering branch of rt_kernel! (rt_kernel.jl:204-249): elemental! + doubling! + (TOA copy | interaction!(::_11))."""
     q, a, c = dq.cstruct(), added.cstruct(), comp.cstruct()
+    if props.fcomp is not None:
+        _lib.call("vsm_layer_forward_mix", comp.dtype, C.byref(q), comp.nSpec, m, ndoubl, _ptr(dtau), _ptr(props.varpi),
+                  _ptr(tau_sum), _ptr(F0), int(props.fcomp.shape[1]), _ptr(props.Zpp), _ptr(props.Zmp), _ptr(props.fcomp),
+                  None, 1 if toa else 0, C.byref(c), C.byref(a), _stream_ptr())
+        return
     _lib.call("vsm_layer_forward", comp.dtype, C.byref(q), comp.nSpec, m, ndoubl, _ptr(dtau), _ptr(props.varpi),
               _ptr(tau_sum), _ptr(F0), _ptr(props.Zpp), _ptr(props.Zmp), props.z_stride, 1 if toa else 0, C.byref(c),
               C.byref(a), _stream_ptr())
@@ -321,7 +343,7 @@ def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerO
                 trace.append(dict(iz=iz, m=m, scatter=True, ndoubl=nd, iface=scattering_interface))
             layer_forward_(tau_sum, dtau, F0, props, m, nd, dq, iz == 1, comp, added)
             return
-        elemental_doubling_(pol, tau_sum, dtau, F0, props, m, nd, dq, added)
+        elemental_doubling_(pol, tau_sum, dtau, F0, props.materialize(), m, nd, dq, added)
     else:
         zero_added_noscat_(added, props.tau, dq)
     if trace is not None:
@@ -363,8 +385,11 @@ class Scene:
         self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, self.sl].T))  # [n,S] col-major == (S,n)
         self.moments = []
         for m in range(model.m_max + 1):
-            lods = H.constructCoreOpticalProperties(model, m)
+            # layer optics with Z carried as per-point coefficients over the component phase matrices
+            # (Rayleigh, aerosols): nothing of size N^2 S is built on the host or shipped over PCIe
+            Zc_pp, Zc_mp, lods = H.constructLayerOpticsComponents(model, m)
             tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
+            dZc_pp, dZc_mp = to_device_matrix(Zc_pp, arch, FT), to_device_matrix(Zc_mp, arch, FT)
             layers = []
             for iz, lo in enumerate(lods):
                 tau_full = np.atleast_1d(lo.tau).astype(FT)
@@ -373,13 +398,15 @@ class Scene:
                 scatter = tw > 2 * np.finfo(FT).eps
                 dtau_full, nd = (H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics) if scatter
                                  else (tau_full, 0))
-                Zpp, Zmp = np.asarray(lo.Zpp), np.asarray(lo.Zmp)
-                if Zpp.ndim == 3:
-                    Zpp, Zmp = Zpp[self.sl], Zmp[self.sl]
+                if lo.coef.ndim == 1:   # one scatterer: its Z is shared by all spectral points
+                    k = int(np.argmax(lo.coef))
+                    Zpp_d, Zmp_d, fcomp = dZc_pp[k:k + 1], dZc_mp[k:k + 1], None
+                else:
+                    Zpp_d, Zmp_d = dZc_pp, dZc_mp
+                    fcomp = conv(np.ascontiguousarray(lo.coef[self.sl].astype(FT)))
                 props = DeviceLayerOptics(conv(np.ascontiguousarray(tau_full[self.sl])),
-                                          conv(np.ascontiguousarray(varpi_full[self.sl])),
-                                          to_device_matrix(Zpp, arch, FT), to_device_matrix(Zmp, arch, FT), tw,
-                                          tau_full, np.asarray(varpi_full))
+                                          conv(np.ascontiguousarray(varpi_full[self.sl])), Zpp_d, Zmp_d, tw,
+                                          tau_full, np.asarray(varpi_full), fcomp)
                 layers.append(dict(props=props, iface=tags[iz], nd=nd,
                                    dtau=conv(np.ascontiguousarray(dtau_full[self.sl])),
                                    tau_sum=conv(np.ascontiguousarray(tau_sum_all[self.sl, iz].astype(FT)))))

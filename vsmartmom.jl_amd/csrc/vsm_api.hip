@@ -169,17 +169,30 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
 
 template <typename T, typename Q, typename C, typename A>
 static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
-                              const T* F0, const T* Zpp, const T* Zmp, long long zs, int toa, const C* c, const A* ad,
-                              void* stream) {
+                              const T* F0, const T* Zpp, const T* Zmp, long long zs, int ncomp, const T* fcomp, T* z_scratch,
+                              int toa, const C* c, const A* ad, void* stream) {
   int rc;
   if ((rc = check_quad(q)) || (rc = check_comp(c))) return rc;
   VSM_REQUIRE(S >= 0 && m >= 0 && ndoubl >= 0, "layer_forward: bad S/m/ndoubl");
   VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp, "layer_forward: null input");
+  VSM_REQUIRE(ncomp >= 0 && (ncomp == 0 || fcomp), "layer_forward: bad component mix");
   hipStream_t st = as_stream(stream);
   if constexpr (sizeof(T) == 8) {
     static const bool no_fuse = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_LAYER_FUSION") != nullptr;
-    if (!no_fuse && strip_supported(q->N))
-      return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, toa, cvt_comp<T>(c), st);
+    if (!no_fuse && strip_supported(q->N) && ncomp <= 4)
+      return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
+                                 toa, cvt_comp<T>(c), st);
+  }
+  if (ncomp > 0) {  // materialise Z[N,N,S] for the kernels that do not mix on the fly
+    const long long per = (long long)q->N * q->N * S;
+    if (!z_scratch) {
+      z_scratch = static_cast<T*>(scratch((size_t)(2 * per) * sizeof(T), 2));
+      if (!z_scratch) return VSM_ERR_HIP;
+    }
+    if ((rc = mix_Z<T>(q->N, S, ncomp, Zpp, Zmp, fcomp, z_scratch, z_scratch + per, st))) return rc;
+    Zpp = z_scratch;
+    Zmp = z_scratch + per;
+    zs = (long long)q->N * q->N;
   }
   // two launches through the caller's AddedLayer
   VSM_REQUIRE(ad != nullptr, "layer_forward: this shape needs an AddedLayer as scratch (N=%d)", q->N);
@@ -344,14 +357,40 @@ int vsm_interaction_oplevel_f32(int iface, int N, int S, const vsm_composite_f32
 int vsm_layer_forward_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                           const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
                           int toa, const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream) {
-  return layer_forward_impl<double>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, toa, comp, added_scratch,
-                                    stream);
+  return layer_forward_impl<double>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, 0, nullptr, nullptr, toa,
+                                    comp, added_scratch, stream);
+}
+int vsm_layer_forward_mix_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                              const double* tau_sum, const double* F0, int ncomp, const double* Zpp_comp,
+                              const double* Zmp_comp, const double* fcomp, double* z_scratch, int toa,
+                              const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream) {
+  VSM_REQUIRE(ncomp >= 1, "layer_forward_mix: ncomp >= 1 required");
+  return layer_forward_impl<double>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp_comp, Zmp_comp, 0, ncomp, fcomp, z_scratch,
+                                    toa, comp, added_scratch, stream);
+}
+int vsm_layer_forward_mix_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                              const float* tau_sum, const float* F0, int ncomp, const float* Zpp_comp, const float* Zmp_comp,
+                              const float* fcomp, float* z_scratch, int toa, const vsm_composite_f32* comp,
+                              const vsm_added_f32* added_scratch, void* stream) {
+  VSM_REQUIRE(ncomp >= 1, "layer_forward_mix: ncomp >= 1 required");
+  return layer_forward_impl<float>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp_comp, Zmp_comp, 0, ncomp, fcomp, z_scratch,
+                                   toa, comp, added_scratch, stream);
+}
+int vsm_mix_Z_f64(int N, int S, int ncomp, const double* Zpp_comp, const double* Zmp_comp, const double* fcomp, double* Zpp,
+                  double* Zmp, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 1 && Zpp_comp && Zmp_comp && fcomp && Zpp && Zmp, "mix_Z: bad argument");
+  return mix_Z<double>(N, S, ncomp, Zpp_comp, Zmp_comp, fcomp, Zpp, Zmp, as_stream(stream));
+}
+int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Zmp_comp, const float* fcomp, float* Zpp,
+                  float* Zmp, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 1 && Zpp_comp && Zmp_comp && fcomp && Zpp && Zmp, "mix_Z: bad argument");
+  return mix_Z<float>(N, S, ncomp, Zpp_comp, Zmp_comp, fcomp, Zpp, Zmp, as_stream(stream));
 }
 int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
                           int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream) {
-  return layer_forward_impl<float>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, toa, comp, added_scratch,
-                                   stream);
+  return layer_forward_impl<float>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, 0, nullptr, nullptr, toa,
+                                   comp, added_scratch, stream);
 }
 
 int vsm_lambertian_surface_f64(const vsm_quad_f64* q, int S, int m, double albedo, const double* tau_sum,

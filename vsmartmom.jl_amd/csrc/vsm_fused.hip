@@ -1033,7 +1033,7 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
   if constexpr (sizeof(T) == 8) {
     static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr;   // A/B switch for benchmarking
     if (!no_strip && strip_supported(q.N))
-      return strip_elemental_doubling(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a, st);
+      return strip_elemental_doubling(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<double>{Zpp, Zmp, zs, 0, nullptr}, a, st);
   }
   return dispatch_np<T>(q.N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;

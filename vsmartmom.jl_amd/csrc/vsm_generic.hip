@@ -82,6 +82,38 @@ int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long lon
 }
 
 // ---------------------------------------------------------------------------
+// Z of a layer with several scatterers: Z[:,:,s] = sum_k f[k,s] Z_k   (`+` of CoreScatteringOpticalProperties,
+// types.jl:1262-1292, with f_k = tau_k varpi_k / sum_j tau_j varpi_j).  Materialises Z for the kernels that do not
+// mix on the fly.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void k_mix_Z(long long NN, int ncomp, const T* __restrict__ Zc_pp, const T* __restrict__ Zc_mp,
+                        const T* __restrict__ fcomp, T* Zpp, T* Zmp) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= NN) return;
+  const long long s = blockIdx.y;
+  T ap = 0, am = 0;
+  for (int k = 0; k < ncomp; ++k) {
+    const T f = fcomp[s * ncomp + k];
+    ap += f * Zc_pp[k * NN + e];
+    am += f * Zc_mp[k * NN + e];
+  }
+  Zpp[s * NN + e] = ap;
+  Zmp[s * NN + e] = am;
+}
+template <typename T>
+int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T* fcomp, T* Zpp, T* Zmp, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const long long NN = (long long)N * N;
+  hipLaunchKernelGGL(k_mix_Z<T>, dim3((unsigned)((NN + 255) / 256), S), dim3(256), 0, st, NN, ncomp, Zpp_comp, Zmp_comp, fcomp,
+                     Zpp, Zmp);
+  VSM_LAUNCH_CHECK("k_mix_Z");
+  return VSM_OK;
+}
+template int mix_Z<double>(int, int, int, const double*, const double*, const double*, double*, double*, hipStream_t);
+template int mix_Z<float>(int, int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
+
+// ---------------------------------------------------------------------------
 // batch_inv!
 // ---------------------------------------------------------------------------
 template <typename T, int NPAD>

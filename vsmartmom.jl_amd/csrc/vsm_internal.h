@@ -106,16 +106,29 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st);
 template <typename T>
 int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStream_t st);
 
+// Where a layer's Z++ / Z-+ come from: one N x N block per point (stride zs; 0 = shared by all points), or -- ncomp > 0
+// -- the per-point mix  sum_k fcomp[s, k] Z_k  of ncomp <= 4 component blocks stacked in Zpp / Zmp ([N,N,ncomp]).
+template <typename T>
+struct zsrc {
+  const T* Zpp;
+  const T* Zmp;
+  long long zs;
+  int ncomp;
+  const T* fcomp;  // [ncomp, S] column-major: fcomp[s * ncomp + k]
+};
+template <typename T>
+int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T* fcomp, T* Zpp, T* Zmp, hipStream_t st);
+
 // ---- column-strip kernels (FP64, 32 < N <= 60; two workgroups per CU): vsm_strip.hip ----------------
 bool strip_supported(int N);
 int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                             const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
-                             const added<double>& a, hipStream_t st);
+                             const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
+                             hipStream_t st);
 
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                        const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs, int toa,
-                        const composite<double>& c, hipStream_t st);
+                        const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,
+                        hipStream_t st);
 
 // grow-only device scratch (one per element type); not for concurrent streams.
 void* scratch(size_t bytes, int slot);

@@ -276,8 +276,7 @@ template <int KS>   // k-steps of every product: 4 KS >= N (columns >= N of the 
 __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& q, int m, int ndoubl,
                                         const double* __restrict__ dtau, const double* __restrict__ varpi,
                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                        const double* __restrict__ Zpp, const double* __restrict__ Zmp, long long zs,
-                                        sstrip& r_s, sstrip& t_s) {
+                                        const zsrc<double>& z, sstrip& r_s, sstrip& t_s) {
   double* P = sm.P;
   double* Q = sm.Q;
   double* jp = sm.vec[0];
@@ -298,8 +297,24 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const double* jsrc = laneB ? jm : jp;                      // per-lane source / destination of the source vectors
   double* jdst = laneA ? jp : (laneB ? jm : sm.vec[7]);
   const double d = dtau[s], w = varpi[s];
-  const double* Zp = Zpp + (long long)s * zs;
-  const double* Zm = Zmp + (long long)s * zs;
+  // Z of this point: one block (z.ncomp == 0), or the mix  sum_k f_k(s) Z_k  of up to 4 scattering components
+  // (types.jl:1262-1292 `+` of CoreScatteringOpticalProperties, evaluated where Z is consumed)
+  const int ncomp = z.ncomp;
+  const long long NNz = (long long)q.N * q.N;
+  const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+  const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+  double fk[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+  auto zget = [&](const double* Z, long long zo) {
+    if (ncomp == 0) return Z[zo];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+    return acc;
+  };
 
   if (tid < SNP) {
     mus[tid] = (tid < N) ? q.mu[tid] : 1.0;
@@ -323,8 +338,8 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jc;
-        zp[r] = Zp[zo];
-        zm[r] = Zm[zo];
+        zp[r] = zget(Zp, zo);
+        zm[r] = zget(Zm, zo);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -367,8 +382,8 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
       for (int qq = 0; qq < ns; ++qq) {
         const long long zo = i + (long long)N * (i_start + qq);
         const double f = F0[qq + (long long)ns * s];
-        zp += Zp[zo] * f;
-        zm += Zm[zo] * f;
+        zp += zget(Zp, zo) * f;
+        zm += zget(Zm, zo) * f;
       }
       const double mi = mus[i], ms = mus[i_start];
       if (i >= i_start && i < i_start + ns)
@@ -480,13 +495,12 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
 template <int KS>
 __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
                                                      const double* __restrict__ varpi, const double* __restrict__ tau_sum,
-                                                     const double* __restrict__ F0, const double* __restrict__ Zpp,
-                                                     const double* __restrict__ Zmp, long long zs, added<double> out) {
+                                                     const double* __restrict__ F0, zsrc<double> z, added<double> out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, r_s, t_s);
+  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int s = blockIdx.x, tid = threadIdx.x, N = q.N, ns = q.n_stokes;
   double* P = sm.P;
   double* Q = sm.Q;
@@ -790,13 +804,12 @@ template <int KS>
 __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
                                                         const double* __restrict__ varpi,
                                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                                        const double* __restrict__ Zpp, const double* __restrict__ Zmp,
-                                                        long long zs, int toa, composite<double> c) {
+                                                        zsrc<double> z, int toa, composite<double> c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, r_s, t_s);
+  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -826,8 +839,8 @@ bool strip_supported(int N) {
 
 template <int KS>
 static int launch_ed_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                           const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
-                           const added<double>& a, hipStream_t st) {
+                           const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
+                           hipStream_t st) {
   const size_t bytes = sizeof(ssmem);
   static int prepared = [&]() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ed_strip<KS>),
@@ -835,7 +848,7 @@ static int launch_ed_strip(const quad<double>& q, int S, int m, int ndoubl, cons
     return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ed_strip)");
   }();
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ed_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a);
+  hipLaunchKernelGGL(k_ed_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, a);
   VSM_LAUNCH_CHECK("k_ed_strip");
   return VSM_OK;
 }
@@ -856,8 +869,8 @@ static int launch_ia_strip(int N, int S, const composite<double>& c, const added
 
 template <int KS>
 static int launch_layer_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                              const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
-                              int toa, const composite<double>& c, hipStream_t st) {
+                              const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
+                              const composite<double>& c, hipStream_t st) {
   const size_t bytes = sizeof(ssmem);
   static int prepared = [&]() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_strip<KS>),
@@ -865,18 +878,17 @@ static int launch_layer_strip(const quad<double>& q, int S, int m, int ndoubl, c
     return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_layer_strip)");
   }();
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_layer_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
-                     zs, toa, c);
+  hipLaunchKernelGGL(k_layer_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip");
   return VSM_OK;
 }
 
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                        const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs, int toa,
+                        const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
                         const composite<double>& c, hipStream_t st) {
   if (S <= 0) return VSM_OK;
 #define VSM_STRIP_CASE(KS) \
-  case KS: return launch_layer_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, toa, c, st)
+  case KS: return launch_layer_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st)
   switch ((q.N + 3) >> 2) {
     VSM_STRIP_CASE(9);
     VSM_STRIP_CASE(10);
@@ -912,11 +924,11 @@ int strip_interaction11(int N, int S, const composite<double>& c, const added<do
 }
 
 int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                             const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long zs,
-                             const added<double>& a, hipStream_t st) {
+                             const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
+                             hipStream_t st) {
   if (S <= 0) return VSM_OK;
 #define VSM_STRIP_CASE(KS) \
-  case KS: return launch_ed_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, a, st)
+  case KS: return launch_ed_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, a, st)
   switch ((q.N + 3) >> 2) {
     VSM_STRIP_CASE(9);
     VSM_STRIP_CASE(10);

@@ -354,6 +354,51 @@ def constructCoreOpticalProperties(model: RTModel, m: int) -> List[CoreScatterin
     return [combo[i] + CoreAbsorptionOpticalProperties(model.tau_abs[:, i]) for i in range(Nz)]
 
 
+@dataclass
+class LayerOpticsComponents:
+    """One layer's optics with Z carried as coefficients over the component phase matrices (not materialised)."""
+    tau: np.ndarray       # [S]
+    varpi: np.ndarray     # [S]
+    coef: np.ndarray      # [C] (unit vector: ONE component's Z, shared by all points) or [S, C] (per-point mix)
+
+
+def constructLayerOpticsComponents(model: RTModel, m: int):
+    """compEffectiveLayerProperties.jl:11-65 with the SAME pairwise arithmetic as constructCoreOpticalProperties
+    (types.jl:1262-1308), except that Z = fx Zx + fy Zy is tracked as coefficients over the components
+    [Rayleigh, aerosol 1, ...] -- the device mixes where Z is consumed (vsm_layer_forward_mix).
+    Returns (Zc_pp [C,N,N], Zc_mp [C,N,N], [LayerOpticsComponents per layer])."""
+    mu = model.quad_points.qp_mu.astype(np.float64)
+    S, Nz = model.tau_rayl.shape
+    Zs = [compute_Z_moments(model.polarization_type, mu, model.greek_rayleigh, m)]
+    for ao in model.aerosol_optics:
+        Zs.append(compute_Z_moments(model.polarization_type, mu, ao.greek_coefs, m))
+    C = len(Zs)
+    layers = []
+    for i in range(Nz):
+        tau = model.tau_rayl[:, i].astype(np.float64)
+        varpi = np.full(S, np.float64(model.varpi_Cabannes))
+        coef = np.eye(C)[0]
+        for ia, ao in enumerate(model.aerosol_optics):
+            y = createAero(model.tau_aer[ia, i], ao, None, None)
+            tau2 = tau + y.tau
+            wx, wy = tau * varpi, y.tau * y.varpi
+            w = wx + wy
+            varpi2 = w / np.where(tau2 > 0, tau2, 1.0)
+            e = np.eye(C)[ia + 1]
+            if np.all(wx == 0.0):
+                coef = e
+            elif np.all(wy == 0.0):
+                pass
+            else:
+                fx, fy = (np.atleast_1d(wx) / w)[:, None], (np.atleast_1d(wy) / w)[:, None]
+                coef = fx * np.broadcast_to(coef, (S, C)) + fy * e[None, :]
+            tau, varpi = tau2, varpi2
+        tau3 = tau + model.tau_abs[:, i]
+        varpi = (tau * varpi) / np.where(tau3 > 0, tau3, 1.0)
+        layers.append(LayerOpticsComponents(tau3, varpi, coef))
+    return np.stack([z[0] for z in Zs]), np.stack([z[1] for z in Zs]), layers
+
+
 def extractEffectiveProps(lods: List[CoreScatteringOpticalProperties], FT):
     """compEffectiveLayerProperties.jl:75-93 -> (interface tags, τ_sum_all [S, Nz+1])."""
     S = len(np.atleast_1d(lods[0].tau))
