@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="spectral points per GPU (default: config)")
     ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--variant", default="rayleigh", choices=["rayleigh", "aerosol"],
+                    help="aerosol: SURVEY 8(d) variant -- HG aerosol (g=0.7, ssa=0.95, tau=0.2) in the lowest 6 layers, "
+                         "2*nstreams-1 moments: Z differs per point and all 2*nstreams Fourier moments run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="spectral points PER HOST CORE of the CPU-baseline sample")
     args = ap.parse_args()
@@ -81,8 +84,18 @@ def main():
     vsm._lib.lib()  # fail loudly if the HIP library is absent
 
     tau_rayl, tau_abs = o2a_atmosphere(S_total, L)
+    extra = {}
+    m_max = 2
+    if args.variant == "aerosol":
+        Hm = vsm.host_model
+        nstreams = (cfg["l_trunc"] + 2) // 2
+        tau_aer = np.zeros((1, L))
+        tau_aer[0, -6:] = 0.2 / 6.0
+        extra = dict(tau_aer=tau_aer, aerosol_optics=[Hm.AerosolOptics(Hm.henyey_greenstein_greek(0.7, 2 * nstreams - 1), 0.95, 0.0)])
+        m_max = 2 * nstreams - 1
+        args.no_cpu_baseline = True
     model = vsm.host_model.model_from_arrays(arch, cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl,
-                                             tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2, float_type=FT)
+                                             tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=m_max, float_type=FT, **extra)
     N = model.quad_points.Nquad * model.polarization_type.n
     assert N == cfg["N"], (N, cfg["N"])
     sl = parallel.shard_slice(S_total, rank, world)
@@ -150,9 +163,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": cfg["FT"], "data": "synthetic",
             "config": {"workload": "%s: O2-A 759-770 nm, nStokes=3, Nquad=%d (N=%d), %d layers, %d spectral points/GPU, "
-                                   "m=0..2, Rayleigh+synthetic O2 absorption, Lambertian 0.15" %
-                                   (args.config, model.quad_points.Nquad, N, L, S_local),
-                       "N": N, "layers": L, "points_per_gpu": S_local, "fourier_moments": 3,
+                                   "m=0..%d, Rayleigh%s+synthetic O2 absorption, Lambertian 0.15" %
+                                   (args.config, model.quad_points.Nquad, N, L, S_local, m_max,
+                                    "+HG aerosol (lowest 6 layers)" if args.variant == "aerosol" else ""),
+                       "N": N, "layers": L, "points_per_gpu": S_local, "fourier_moments": m_max + 1,
                        "ndoubl_per_layer": nds, "algorithmic_gflop_per_point": flops_pt / 1e9,
                        "whole_run_tflops": pts_per_s * flops_pt / 1e12,
                        "whole_run_frac_of_mfma_peak": pts_per_s * flops_pt / 1e12 / (peak * world),

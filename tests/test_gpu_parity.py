@@ -639,3 +639,38 @@ def test_rt_run_component_mixing_on_device(vsm, arch, FT, pol, l_trunc, tol):
     mat = props.materialize()
     ref = np.einsum("sk,kij->sij", lo.coef, Zc_pp)
     assert _rel(vsm.CoreRT.from_device_matrix(mat.Zpp), ref) < (1e-14 if FT == np.float64 else 1e-6)
+
+
+def test_c2_full_size_properties_and_oracle_sample(vsm, arch):
+    """BASELINE.json configs[1] at its FULL size (N = 60, 40 layers, 10 000 spectral points, FP64, m = 0..2) through the
+    fused strip layer kernel: determinism, permutation equivariance over the spectral axis, linearity in F0, |Q|,|U| <= I,
+    and agreement with the oracle on a sample of points spread over the band (the oracle needs ~0.1 s per point)."""
+    import bench
+    S, L = 10000, 40
+    tau_rayl, tau_abs = bench.o2a_atmosphere(S, L)
+    H = vsm.host_model
+    geo = ("IQU", 35, 40.0, [30.0], [0.0])
+    mk = lambda tr, ta, alb: H.model_from_arrays(arch, *geo, tau_rayl=tr, tau_abs=ta, depol=0.0279, albedo=alb, m_max=2)
+    base = mk(tau_rayl, tau_abs, 0.15)
+    assert base.quad_points.Nquad * 3 == 60
+    R1, T1 = vsm.CoreRT.rt_run(base)
+    R1b, T1b = vsm.CoreRT.rt_run(base)
+    assert np.array_equal(R1, R1b) and np.array_equal(T1, T1b)
+    assert np.all(np.isfinite(R1)) and np.all(R1[:, 0, :] > 0)
+    assert np.all(np.hypot(R1[:, 1, :], R1[:, 2, :]) <= R1[:, 0, :] * (1 + 1e-12))
+    perm = np.random.default_rng(1).permutation(S)
+    R2, T2 = vsm.CoreRT.rt_run(mk(tau_rayl[perm], tau_abs[perm], 0.15))
+    assert np.array_equal(R2, R1[:, :, perm]) and np.array_equal(T2, T1[:, :, perm])
+    # linearity in F0 (albedo 0: the Lambertian source uses pol_type.I0, not F0)
+    m0 = mk(tau_rayl, tau_abs, 0.0)
+    Ra, _ = vsm.CoreRT.rt_run(m0)
+    F0 = np.zeros((3, S))
+    F0[0] = 2.0
+    m0.F0 = F0
+    Rb, _ = vsm.CoreRT.rt_run(m0)
+    assert np.max(np.abs(Rb - 2 * Ra)) <= 1e-12 * np.abs(Ra).max()
+    # oracle on a sample (tau*varpi is spectrally flat here, so ndoubl of the sample equals the full batch's)
+    idx = np.linspace(0, S - 1, 6).astype(int)
+    om = O.build_model(*geo, tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx], depol=0.0279, albedo=0.15, m_max=2)
+    Ro, To = O.rt_run(om)
+    assert _rel(R1[:, :, idx], Ro) < 1e-8 and _rel(T1[:, :, idx], To) < 1e-8
