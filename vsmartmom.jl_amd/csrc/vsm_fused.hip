@@ -983,6 +983,27 @@ __global__ __launch_bounds__(64 * NW) void k_test_inv(int N, const T* A, T* X, i
   if (path_out && threadIdx.x == 0) path_out[blockIdx.x] = path;
 }
 
+// X = (I - A B)^-1 in one launch (replaces the `I_static .- A ⊠ B` product + batch_inv! pair of the operator-level
+// paths: rt_helpers.jl:103-104, interaction.jl:220-222,243-244): product, series inverse or Gauss-Jordan, all in LDS.
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_inv_one_minus_ab(int N, const T* __restrict__ A, long long sa,
+                                                              const T* __restrict__ B, long long sb, T* X) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
+  const long long s = blockIdx.x;
+  const int Kend = ((N + 3) >> 2) << 2;
+  stage<T, NP, NW>(sm.L[0], A + s * sa, N);
+  stage<T, NP, NW>(sm.L[1], B + s * sb, N);
+  __syncthreads();
+  acc_block<T, NP, NW> acc;
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, sm.L[0], sm.L[1], Kend);
+  __syncthreads();
+  int slot = 0;
+  invert_one_minus<T, NP, NW>(acc, sm.L[2], sm.L[3], N, Kend, sm, slot, 0);
+  lds_to_global<T, NP, NW>(X + s * (long long)N * N, sm.L[2], N);
+}
+
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
@@ -1105,10 +1126,29 @@ int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStr
   });
 }
 
+// (I - A B)^-1 ; VSM_ERR_UNSUPPORTED when N exceeds the on-chip limit (callers then use gemm + batch_inv)
+template <typename T>
+int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, long long sb, T* X, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  if (N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
+  return dispatch_np<T>(N, [&](auto tag) {
+    constexpr int NP = decltype(tag)::value;
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    auto kern = k_inv_one_minus_ab<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
+    static int prepared = enable_lds(kern, bytes);
+    if (prepared) return prepared;
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, sa, B, sb, X);
+    VSM_LAUNCH_CHECK("k_inv_one_minus_ab");
+    return (int)VSM_OK;
+  });
+}
+
 #define VSM_INST_F(T)                                                                                               \
   template int fused_elemental_doubling<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*,  \
                                            const T*, const T*, long long, const added<T>&, hipStream_t);           \
   template int fused_interaction<T>(int, int, int, const composite<T>&, const added<T>&, hipStream_t);              \
+  template int inv_one_minus_product<T>(int, int, const T*, long long, const T*, long long, T*, hipStream_t);       \
   template int test_lds_mm<T>(int, int, const T*, const T*, T*, hipStream_t);                                       \
   template int test_lds_inv<T>(int, int, const T*, T*, int, int*, hipStream_t);
 VSM_INST_F(double)

@@ -60,6 +60,10 @@ template <typename T>
 int gemm(int M, int Nc, int K, int S, const T* A, long long sa, const T* B, long long sb, T* C, long long sc,
          T alpha, const T* D, long long sd, T beta, T gamma, hipStream_t st) {
   if (S <= 0 || M <= 0 || Nc <= 0) return VSM_OK;
+  if constexpr (sizeof(T) == 8) {
+    const int rc = strip_gemm(M, Nc, K, S, 1, A, sa, 0, B, sb, 0, C, sc, 0, alpha, D, sd, 0, beta, gamma, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
   const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
   dim3 grid((tiles + 3) / 4, S);
   hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, 0LL,
@@ -73,6 +77,10 @@ int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long lon
           long long pb, T* C, long long sc, long long pc, T alpha, const T* D, long long sd, long long pd, T beta,
           T gamma, hipStream_t st) {
   if (S <= 0 || P <= 0 || M <= 0 || Nc <= 0) return VSM_OK;
+  if constexpr (sizeof(T) == 8) {
+    const int rc = strip_gemm(M, Nc, K, S, P, A, sa, pa, B, sb, pb, C, sc, pc, alpha, D, sd, pd, beta, gamma, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
   const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
   dim3 grid((tiles + 3) / 4, S, P);
   hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, pa,

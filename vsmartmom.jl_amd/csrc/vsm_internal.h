@@ -101,6 +101,19 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
                              const added<T>& a, hipStream_t st);
 template <typename T>
 int fused_interaction(int iface, int N, int S, const composite<T>& c, const added<T>& a, hipStream_t st);
+// X = (I - A B)^-1, product + series/Gauss-Jordan inverse in one LDS-resident launch (N <= fused_max_n, else
+// VSM_ERR_UNSUPPORTED).  sa / sb: element strides between spectral slices (0 = shared block).
+template <typename T>
+int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, long long sb, T* X, hipStream_t st);
+// (I - A B)^-1 by the fused kernel when N fits, else gemm + batch_inv through `tmp` ([N,N,S] scratch)
+template <typename T>
+inline int inv_one_minus(int N, int S, const T* A, long long sa, const T* B, long long sb, T* X, T* tmp, hipStream_t st) {
+  int rc = inv_one_minus_product<T>(N, S, A, sa, B, sb, X, st);
+  if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  const long long NN = (long long)N * N;
+  if ((rc = gemm<T>(N, N, N, S, A, sa, B, sb, tmp, NN, T(-1), (const T*)nullptr, 0, T(0), T(1), st))) return rc;
+  return batch_inv<T>(N, S, tmp, X, nullptr, st);
+}
 template <typename T>
 int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st);
 template <typename T>
@@ -125,6 +138,9 @@ int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, co
                              const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
                              hipStream_t st);
 
+int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa, long long pa, const double* B, long long sb,
+               long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
+               double beta, double gamma, hipStream_t st);
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,

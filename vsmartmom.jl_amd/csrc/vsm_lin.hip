@@ -304,8 +304,7 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
   VSM_LAUNCH_CHECK("k_ekl_init");
   for (int n = 0; n < ndoubl; ++n) {
     // forward: G = (I - r r)^-1, tt = t G
-    MM(N, N, N, S, 1, a.r_mp, NN, 0, a.r_mp, NN, 0, G, NN, 0, -one, nul, 0, 0, zero, one);
-    if ((rc = batch_inv<T>(N, S, G, G, nullptr, st))) return rc;
+    if ((rc = inv_one_minus<T>(N, S, a.r_mp, NN, a.r_mp, NN, G, G, st))) return rc;   // one fused launch when N fits on chip
     MM(N, N, N, S, 1, a.t_pp, NN, 0, G, NN, 0, tt, NN, 0, one, nul, 0, 0, zero, zero);
     // Gl_p = G (ar_p r + r ar_p) G ; ttl_p = at_p G + t Gl_p
     MM(N, N, N, S, P, ar, NN, MS, a.r_mp, NN, 0, X1, NN, MS, one, nul, 0, 0, zero, zero);
@@ -502,8 +501,7 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
     return VSM_OK;
   }
   // ---- first half: G1, T01_inv and everything that hangs off them --------------------------------
-  MM(N, N, N, S, 1, a.r_mp, as, 0, c.R_pm, NN, 0, G, NN, 0, -one, nul, 0, 0, zero, one);
-  if ((rc = batch_inv<T>(N, S, G, G, nullptr, st))) return rc;
+  if ((rc = inv_one_minus<T>(N, S, a.r_mp, as, c.R_pm, NN, G, G, st))) return rc;
   MM(N, N, N, S, 1, c.T_mm, NN, 0, G, NN, 0, T01, NN, 0, one, nul, 0, 0, zero, zero);
   MM(N, N, N, S, 1, a.r_mp, as, 0, c.T_pp, NN, 0, rT, NN, 0, one, nul, 0, 0, zero, zero);
   // G1l_p = G (ar_p R+- + r Rdot+-_p) G
@@ -537,8 +535,7 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
   if ((rc = copy_strided<T>(MS * P, 1, nA, 0, cl.R_mp, st))) return rc;
   if ((rc = copy_strided<T>(MS * P, 1, nB, 0, cl.T_mm, st))) return rc;
   // ---- second half: G2, T21_inv ---------------------------------------------------------------------
-  MM(N, N, N, S, 1, c.R_pm, NN, 0, a.r_mp, as, 0, G, NN, 0, -one, nul, 0, 0, zero, one);
-  if ((rc = batch_inv<T>(N, S, G, G, nullptr, st))) return rc;
+  if ((rc = inv_one_minus<T>(N, S, c.R_pm, NN, a.r_mp, as, G, G, st))) return rc;
   MM(N, N, N, S, 1, a.t_pp, as, 0, G, NN, 0, T21, NN, 0, one, nul, 0, 0, zero, zero);
   MM(N, N, N, S, 1, c.R_pm, NN, 0, a.t_mm, as, 0, Rt, NN, 0, one, nul, 0, 0, zero, zero);
   // G2l_p = G (R+- ar_p + Rdot+-_p r) G

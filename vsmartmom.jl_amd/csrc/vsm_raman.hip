@@ -334,8 +334,7 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
   const dim3 gv((unsigned)((pv + 255) / 256));
   for (int n = 0; n < ndoubl; ++n) {
     // gp = (I - r r)^-1 ; ttg = t gp
-    G3(N, N, N, S, a.r_mp, NN, a.r_mp, NN, tM, NN, -one, nul, 0, zero, one);
-    if ((rc = batch_inv<T>(N, S, tM, gp, nullptr, st))) return rc;
+    if ((rc = inv_one_minus<T>(N, S, a.r_mp, NN, a.r_mp, NN, gp, tM, st))) return rc;
     G3(N, N, N, S, a.t_pp, NN, gp, NN, ttg, NN, one, nul, 0, zero, zero);
     // J1+- = J0+- expk
     hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_p, j1p);
@@ -432,8 +431,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   const rs_op<T> none{nullptr, 0, 0};
   int rc;
   // ---- pass 1: G1 = (I - r-+ R+-)^-1, T01 = T-- G1 ------------------------------------------------
-  G3(N, N, N, S, a.r_mp, as, c.R_pm, NN, tM, NN, -one, nul, 0, zero, one);
-  if ((rc = batch_inv<T>(N, S, tM, G, nullptr, st))) return rc;
+  if ((rc = inv_one_minus<T>(N, S, a.r_mp, as, c.R_pm, NN, G, tM, st))) return rc;
   G3(N, N, N, S, c.T_mm, NN, G, NN, Tinv, NN, one, nul, 0, zero, zero);
   // v = G1 (j0- + r-+ J0+)
   G3(N, 1, N, S, a.r_mp, as, c.J0_p, N, u, N, one, a.j0_m, N, one, zero);
@@ -460,8 +458,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(aie.iet_mm, NN), W3, none);
   if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gB, NN), cie.ieT_mm, at_4d<T>(W3, NN), st, 1))) return rc;
   // ---- pass 2: G2 = (I - R+- r-+)^-1, T21 = t++ G2 ------------------------------------------------
-  G3(N, N, N, S, c.R_pm, NN, a.r_mp, as, tM, NN, -one, nul, 0, zero, one);
-  if ((rc = batch_inv<T>(N, S, tM, G, nullptr, st))) return rc;
+  if ((rc = inv_one_minus<T>(N, S, c.R_pm, NN, a.r_mp, as, G, tM, st))) return rc;
   G3(N, N, N, S, a.t_pp, as, G, NN, Tinv, NN, one, nul, 0, zero, zero);
   // v = G2 (J0+ + R+- j0-)
   G3(N, 1, N, S, c.R_pm, NN, a.j0_m, N, u, N, one, c.J0_p, N, one, zero);

@@ -16,6 +16,8 @@
 //     tt  = t G                                      Q = t                G_s
 //     tmp = tt r ;  t' = tt t   (share A)            P = tt               r_s ; t_s (+ j0+, j1- in spare columns)
 //     r'  = r + tmp t                                Q = tmp              t_s
+#include <stdlib.h>
+
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
 #include "vsm_lds.h"
@@ -830,6 +832,62 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
   ia_body<KS>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
 }
 
+
+// ---------------------------------------------------------------------------
+// Operator-level batched product in strip form:  C = alpha A*B + beta D + gamma I   (FP64, M, Nc, K <= 64)
+// One workgroup per (spectral point, parameter): A is staged ONCE into LDS (coalesced), every wave takes its 16-column
+// strip of B straight from global memory into the MFMA B-operand registers and writes its strip of C -- each operand
+// crosses the memory system once, where k_gemm's tile-waves re-read A rows / B columns 16/3 times at N = 60.
+// 40 KB of LDS per workgroup: four workgroups per CU.
+// ---------------------------------------------------------------------------
+struct gsmem {
+  double A[SNP * SNP];
+};
+template <int KS>
+__global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, const double* __restrict__ A, long long sa,
+                                                       long long pa, const double* __restrict__ B, long long sb, long long pb,
+                                                       double* C, long long sc, long long pc, double alpha, const double* D,
+                                                       long long sd, long long pd, double beta, double gamma) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  gsmem& sm = *reinterpret_cast<gsmem*>(smem_raw);
+  spos p;
+  const long long s = blockIdx.x, pp = blockIdx.y;
+  const double* As = A + s * sa + pp * pa;
+  const double* Bs = B + s * sb + pp * pb;
+  double* Cs = C + s * sc + pp * pc;
+  const double* Ds = D ? D + s * sd + pp * pd : nullptr;
+#pragma unroll 4
+  for (int j = p.wave; j < 4 * KS; j += 4)
+    sm.A[lidx<SNP>(p.lane, j)] = (p.lane < M && j < K) ? As[p.lane + (long long)M * j] : 0.0;
+  sstrip b, acc;
+  const int cc = min(p.col, Nc - 1);
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      const double v = Bs[min(row, K - 1) + (long long)K * cc];
+      b.v[ta][r] = (row < K && p.col < Nc) ? v : 0.0;
+    }
+  __syncthreads();
+  acc.zero();
+  mm_ab<KS>(acc, sm.A, b, p);
+  if (p.col < Nc) {
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        if (row < M) {
+          double v = alpha * acc.v[ta][r];
+          if (Ds) v += beta * Ds[row + (long long)M * p.col];
+          if (row == p.col) v += gamma;
+          Cs[row + (long long)M * p.col] = v;
+        }
+      }
+  }
+}
+
 }  // namespace
 
 bool strip_supported(int N) {
@@ -864,6 +922,32 @@ static int launch_ia_strip(int N, int S, const composite<double>& c, const added
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_ia_strip<KS>, dim3(S), dim3(SNT), bytes, st, N, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip");
+  return VSM_OK;
+}
+
+template <int KS>
+static void launch_gemm_strip(int M, int Nc, int K, int S, int P, const double* A, long long sa, long long pa, const double* B,
+                              long long sb, long long pb, double* C, long long sc, long long pc, double alpha, const double* D,
+                              long long sd, long long pd, double beta, double gamma, hipStream_t st) {
+  hipLaunchKernelGGL(k_gemm_strip<KS>, dim3(S, P), dim3(SNT), sizeof(gsmem), st, M, Nc, K, A, sa, pa, B, sb, pb, C, sc, pc, alpha,
+                     D, sd, pd, beta, gamma);
+}
+// returns VSM_ERR_UNSUPPORTED when the shape is left to k_gemm
+int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa, long long pa, const double* B, long long sb,
+               long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
+               double beta, double gamma, hipStream_t st) {
+  if (M > SNP || Nc > SNP || K > SNP || M <= 16 || Nc <= 8 || K <= 8 || S > 2147483647 || P > 65535) return VSM_ERR_UNSUPPORTED;
+  static const bool off = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_GEMM") != nullptr;
+  if (off) return VSM_ERR_UNSUPPORTED;
+  const int ks = (K + 3) >> 2;
+#define VSM_G(KS) launch_gemm_strip<KS>(M, Nc, K, S, P, A, sa, pa, B, sb, pb, C, sc, pc, alpha, D, sd, pd, beta, gamma, st)
+  if (ks <= 4) VSM_G(4);
+  else if (ks <= 8) VSM_G(8);
+  else if (ks <= 12) VSM_G(12);
+  else if (ks <= 15) VSM_G(15);
+  else VSM_G(16);
+#undef VSM_G
+  VSM_LAUNCH_CHECK("k_gemm_strip");
   return VSM_OK;
 }
 
