@@ -274,7 +274,7 @@ __device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int
 // ---------------------------------------------------------------------------
 // Body shared by k_ed_strip and k_layer_strip.  On return (all waves past a barrier): r_s = strip of the final
 // r-+ (row signs of apply_D applied), t_s = strip of t++, sm.vec[0] = j0+, sm.vec[1] = j0- (final sign).
-template <int KS>   // k-steps of every product: 4 KS >= N (columns >= N of the A-forms are zero)
+template <int KS, bool MIX>   // KS k-steps per product: 4 KS >= N (columns >= N of the A-forms are zero); MIX: Z = sum_k f_k Z_k
 __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& q, int m, int ndoubl,
                                         const double* __restrict__ dtau, const double* __restrict__ varpi,
                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
@@ -301,7 +301,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const double d = dtau[s], w = varpi[s];
   // Z of this point: one block (z.ncomp == 0), or the mix  sum_k f_k(s) Z_k  of up to 4 scattering components
   // (types.jl:1262-1292 `+` of CoreScatteringOpticalProperties, evaluated where Z is consumed)
-  const int ncomp = z.ncomp;
+  const int ncomp = MIX ? z.ncomp : 0;   // (a compile-time switch: the run-time one cost 4.5 % on the plain path)
   const long long NNz = (long long)q.N * q.N;
   const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
   const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
+  ed_body<KS, false>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int s = blockIdx.x, tid = threadIdx.x, N = q.N, ns = q.n_stokes;
   double* P = sm.P;
   double* Q = sm.Q;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
 // rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
 // either the TOA copy (iz == 1: copy_added_to_composite!, rt_helpers.jl:188-200) or interaction!(::_11).  The added
 // layer never leaves the chip.
-template <int KS>
+template <int KS, bool MIX>
 __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
                                                         const double* __restrict__ varpi,
                                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
+  ed_body<KS, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -890,39 +890,73 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
 
 }  // namespace
 
-bool strip_supported(int N) {
-  const int Kend = ((N + 3) >> 2) << 2;
-  return N > 32 && Kend + 2 <= SNP;
-}
+// The layer kernels are instantiated per KS in separately compiled objects (make: vsm_strip_<KS>.o is this file built
+// with -DVSM_STRIP_KS=<KS>) so that the seven instantiations build in parallel; the object built WITHOUT the macro holds
+// the dispatchers and the strip GEMM.
+#define VSM_CAT2(a, b) a##b
+#define VSM_CAT(a, b) VSM_CAT2(a, b)
+#define VSM_STRIP_DECL(KS)                                                                                                  \
+  int VSM_CAT(launch_ed_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,       \
+                                    const double*, const zsrc<double>&, const added<double>&, hipStream_t);                 \
+  int VSM_CAT(launch_ia_strip_, KS)(int, int, const composite<double>&, const added<double>&, hipStream_t);                \
+  int VSM_CAT(launch_layer_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,    \
+                                       const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t);
 
-template <int KS>
-static int launch_ed_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                           const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
-                           hipStream_t st) {
-  const size_t bytes = sizeof(ssmem);
-  static int prepared = [&]() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ed_strip<KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ed_strip)");
-  }();
+#ifdef VSM_STRIP_KS
+VSM_STRIP_DECL(VSM_STRIP_KS)
+template <typename K>
+static int strip_enable_lds(K kern, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)sizeof(ssmem));
+  return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
+}
+int VSM_CAT(launch_ed_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
+                                            const double* varpi, const double* tau_sum, const double* F0,
+                                            const zsrc<double>& z, const added<double>& a, hipStream_t st) {
+  static int prepared = strip_enable_lds(k_ed_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ed_strip)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ed_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, a);
+  hipLaunchKernelGGL(k_ed_strip<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z,
+                     a);
   VSM_LAUNCH_CHECK("k_ed_strip");
   return VSM_OK;
 }
-
-template <int KS>
-static int launch_ia_strip(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
-  const size_t bytes = sizeof(ssmem);
-  static int prepared = [&]() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia_strip<KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ia_strip)");
-  }();
+int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+  static int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ia_strip)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ia_strip<KS>, dim3(S), dim3(SNT), bytes, st, N, c, a);
+  hipLaunchKernelGGL(k_ia_strip<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(ssmem), st, N, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip");
   return VSM_OK;
+}
+int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
+                                               const double* varpi, const double* tau_sum, const double* F0,
+                                               const zsrc<double>& z, int toa, const composite<double>& c, hipStream_t st) {
+  static int prepared = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_layer_strip)");
+  static int prepared_mix = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_layer_strip mix)");
+  if (prepared) return prepared;
+  if (prepared_mix) return prepared_mix;
+  if (z.ncomp > 0)
+    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
+                       tau_sum, F0, z, toa, c);
+  else
+    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
+                       tau_sum, F0, z, toa, c);
+  VSM_LAUNCH_CHECK("k_layer_strip");
+  return VSM_OK;
+}
+
+#else  // ---- dispatcher object -----------------------------------------------------------------------------------------
+
+VSM_STRIP_DECL(9)
+VSM_STRIP_DECL(10)
+VSM_STRIP_DECL(11)
+VSM_STRIP_DECL(12)
+VSM_STRIP_DECL(13)
+VSM_STRIP_DECL(14)
+VSM_STRIP_DECL(15)
+
+bool strip_supported(int N) {
+  const int Kend = ((N + 3) >> 2) << 2;
+  return N > 32 && Kend + 2 <= SNP;
 }
 
 template <int KS>
@@ -936,7 +970,7 @@ static void launch_gemm_strip(int M, int Nc, int K, int S, int P, const double* 
 int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa, long long pa, const double* B, long long sb,
                long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
                double beta, double gamma, hipStream_t st) {
-  if (M > SNP || Nc > SNP || K > SNP || M <= 16 || Nc <= 8 || K <= 8 || S > 2147483647 || P > 65535) return VSM_ERR_UNSUPPORTED;
+  if (M > SNP || Nc > SNP || K > SNP || M <= 16 || Nc <= 8 || K <= 8 || P > 65535) return VSM_ERR_UNSUPPORTED;
   static const bool off = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_GEMM") != nullptr;
   if (off) return VSM_ERR_UNSUPPORTED;
   const int ks = (K + 3) >> 2;
@@ -951,58 +985,34 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
   return VSM_OK;
 }
 
-template <int KS>
-static int launch_layer_strip(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                              const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
-                              const composite<double>& c, hipStream_t st) {
-  const size_t bytes = sizeof(ssmem);
-  static int prepared = [&]() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_strip<KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_layer_strip)");
-  }();
-  if (prepared) return prepared;
-  hipLaunchKernelGGL(k_layer_strip<KS>, dim3(S), dim3(SNT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
-  VSM_LAUNCH_CHECK("k_layer_strip");
-  return VSM_OK;
-}
+#define VSM_STRIP_SWITCH(N_, CALL)        \
+  switch (((N_) + 3) >> 2) {               \
+    case 9: return CALL(9);                \
+    case 10: return CALL(10);              \
+    case 11: return CALL(11);              \
+    case 12: return CALL(12);              \
+    case 13: return CALL(13);              \
+    case 14: return CALL(14);              \
+    case 15: return CALL(15);              \
+    default: break;                        \
+  }
 
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
                         const composite<double>& c, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-#define VSM_STRIP_CASE(KS) \
-  case KS: return launch_layer_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st)
-  switch ((q.N + 3) >> 2) {
-    VSM_STRIP_CASE(9);
-    VSM_STRIP_CASE(10);
-    VSM_STRIP_CASE(11);
-    VSM_STRIP_CASE(12);
-    VSM_STRIP_CASE(13);
-    VSM_STRIP_CASE(14);
-    VSM_STRIP_CASE(15);
-    default: break;
-  }
-#undef VSM_STRIP_CASE
+#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st)
+  VSM_STRIP_SWITCH(q.N, VSM_CALL)
+#undef VSM_CALL
   set_error("strip_layer_forward: N=%d outside (32, 60]", q.N);
   return VSM_ERR_UNSUPPORTED;
 }
 
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-#define VSM_STRIP_CASE(KS) \
-  case KS: return launch_ia_strip<KS>(N, S, c, a, st)
-  switch ((N + 3) >> 2) {
-    VSM_STRIP_CASE(9);
-    VSM_STRIP_CASE(10);
-    VSM_STRIP_CASE(11);
-    VSM_STRIP_CASE(12);
-    VSM_STRIP_CASE(13);
-    VSM_STRIP_CASE(14);
-    VSM_STRIP_CASE(15);
-    default: break;
-  }
-#undef VSM_STRIP_CASE
+#define VSM_CALL(KS) VSM_CAT(launch_ia_strip_, KS)(N, S, c, a, st)
+  VSM_STRIP_SWITCH(N, VSM_CALL)
+#undef VSM_CALL
   set_error("strip_interaction11: N=%d outside (32, 60]", N);
   return VSM_ERR_UNSUPPORTED;
 }
@@ -1011,26 +1021,17 @@ int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, co
                              const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
                              hipStream_t st) {
   if (S <= 0) return VSM_OK;
-#define VSM_STRIP_CASE(KS) \
-  case KS: return launch_ed_strip<KS>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, a, st)
-  switch ((q.N + 3) >> 2) {
-    VSM_STRIP_CASE(9);
-    VSM_STRIP_CASE(10);
-    VSM_STRIP_CASE(11);
-    VSM_STRIP_CASE(12);
-    VSM_STRIP_CASE(13);
-    VSM_STRIP_CASE(14);
-    VSM_STRIP_CASE(15);
-    default: break;
-  }
-#undef VSM_STRIP_CASE
+#define VSM_CALL(KS) VSM_CAT(launch_ed_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, a, st)
+  VSM_STRIP_SWITCH(q.N, VSM_CALL)
+#undef VSM_CALL
   set_error("strip_elemental_doubling: N=%d outside (32, 60]", q.N);
   return VSM_ERR_UNSUPPORTED;
 }
+#endif  // VSM_STRIP_KS
 
 }  // namespace vsm
 
-#ifdef VSM_PHASE_TIMING
+#if defined(VSM_PHASE_TIMING) && defined(VSM_STRIP_KS) && VSM_STRIP_KS == 15   // stamps of the C2 instantiation
 extern "C" int vsm_debug_phase_cycles_strip(unsigned long long* out_h, int reset) {
   if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_strip), sizeof(unsigned long long) * 32);
   if (reset) {
