@@ -46,7 +46,7 @@ __device__ unsigned long long vsm_phase_cycles[32];
 template <int NP, int NW_>
 struct fcfg {
   static_assert(NP == 32 || NP == 64 || NP == 96, "NP must be 32, 64 or 96");
-  static_assert(NW_ == 4 || (NW_ == 8 && NP == 64), "4 waves, or 8 waves for NP = 64");
+  static_assert(NW_ == 4 || (NW_ == 8 && NP == 64) || (NW_ == 6 && NP == 96), "4 waves, 8 for NP = 64, or 6 for NP = 96");
   static constexpr int NW = NW_;                      // waves per workgroup
   static constexpr int NT = 64 * NW;                  // threads
   static constexpr int WC = 2;                        // wave grid columns
@@ -54,7 +54,7 @@ struct fcfg {
   static constexpr int TMR = NP / 16 / WR;            // tiles per wave, rows
   static constexpr int TMC = NP / 16 / WC;            // tiles per wave, cols
   static constexpr int KS = NP / 4;                   // max k-steps
-  static constexpr int TPR = NT / 128;                // threads per row in the mat-vec (128 rows >= NP)
+  static constexpr int TPR = (NT >= 512) ? 4 : 2;     // threads per row in the mat-vec (power of two; NT / TPR rows >= NP)
   static_assert(TMR * WR * 16 == NP && TMC * WC * 16 == NP, "tile grid must cover NP");
 };
 
@@ -1021,6 +1021,14 @@ template int fused_max_n<float>();
 #ifndef IA_WAVES_64
 #define IA_WAVES_64 4
 #endif
+// waves per workgroup of the NP = 96 (FP32) instantiations: 4 (2x2 grid, 3x3 tiles); 6 (3x2 grid, 2x3 tiles) loads the
+// SIMDs unevenly and measured 24 % slower on C4
+#ifndef ED_WAVES_96
+#define ED_WAVES_96 4
+#endif
+#ifndef IA_WAVES_96
+#define IA_WAVES_96 4
+#endif
 
 template <typename K>
 static int enable_lds(K kern, size_t bytes) {
@@ -1058,7 +1066,7 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
   }
   return dispatch_np<T>(q.N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_elemental_doubling<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
@@ -1083,7 +1091,7 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
   }
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    constexpr int NW = (NP == 64) ? IA_WAVES_64 : 4;
+    constexpr int NW = (NP == 64) ? IA_WAVES_64 : (NP == 96) ? IA_WAVES_96 : 4;
     auto kern = k_interaction11<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
@@ -1099,7 +1107,7 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* Cout, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_test_mm<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
@@ -1115,7 +1123,7 @@ int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStr
   if (S <= 0) return VSM_OK;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_test_inv<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
@@ -1133,7 +1141,7 @@ int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, lo
   if (N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
-    constexpr int NW = (NP == 64) ? ED_WAVES_64 : 4;
+    constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_inv_one_minus_ab<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
     static int prepared = enable_lds(kern, bytes);
