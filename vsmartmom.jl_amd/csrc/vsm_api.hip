@@ -183,6 +183,12 @@ static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dta
       return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
                                  toa, cvt_comp<T>(c), st);
   }
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_fuse32 = getenv("VSM_NO_LAYER_FUSION") != nullptr;
+    if (!no_fuse32 && strip32_supported(q->N) && ncomp <= 4)
+      return strip32_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
+                                   toa, cvt_comp<T>(c), st);
+  }
   if (ncomp > 0) {  // materialise Z[N,N,S] for the kernels that do not mix on the fly
     const long long per = (long long)q->N * q->N * S;
     if (!z_scratch) {

@@ -1089,6 +1089,9 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_IA") != nullptr;
     if (!no_strip && strip_supported(N)) return strip_interaction11(N, S, c, a, st);
   }
+  if constexpr (sizeof(T) == 4) {
+    if (strip32_supported(N)) return strip32_interaction11(N, S, c, a, st);
+  }
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
     constexpr int NW = (NP == 64) ? IA_WAVES_64 : (NP == 96) ? IA_WAVES_96 : 4;

@@ -146,6 +146,13 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,
                         hipStream_t st);
 
+// ---- column-strip kernels, FP32 (64 < N <= 96; two workgroups of 6 waves per CU): vsm_strip32.hip ----
+bool strip32_supported(int N);
+int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                          const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
+                          hipStream_t st);
+int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st);
+
 // grow-only device scratch (one per element type); not for concurrent streams.
 void* scratch(size_t bytes, int slot);
 
