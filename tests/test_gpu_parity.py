@@ -608,11 +608,12 @@ def test_layer_forward_entry_point(vsm, arch, FT, pol, l_trunc, toa):
 
 
 @pytest.mark.parametrize("FT,pol,l_trunc,tol", [(np.float64, "IQU", 33, 1e-8), (np.float64, "IQU", 19, 1e-8), (np.float64, "I", 9, 1e-8),
-                                                (np.float64, "IQUV", 41, 1e-8), (np.float32, "IQU", 33, 1e-2)])
+                                                (np.float64, "IQUV", 41, 1e-8), (np.float32, "IQU", 33, 1e-2),
+                                                (np.float32, "IQU", 57, 1e-2), (np.float32, "IQU", 43, 1e-2)])
 def test_rt_run_component_mixing_on_device(vsm, arch, FT, pol, l_trunc, tol):
     """Layers with Rayleigh + two aerosol types and a spectrally varying Rayleigh optical depth: Z differs from point
     to point.  The host ships only the component matrices and per-point weights; the strip kernel mixes Z on the fly
-    (FP64, 32 < N <= 60), the other shapes through vsm_mix_Z.  Compared with the oracle, which mixes pairwise on the host
+    (FP64, 32 < N <= 60; FP32, 64 < N <= 96: N = 93 and 72 here), the other shapes through vsm_mix_Z.  Compared with the oracle, which mixes pairwise on the host
     like the reference (types.jl:1262-1292)."""
     rng = np.random.default_rng(5)
     S, L = 6, 4
@@ -674,3 +675,24 @@ def test_c2_full_size_properties_and_oracle_sample(vsm, arch):
     om = O.build_model(*geo, tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx], depol=0.0279, albedo=0.15, m_max=2)
     Ro, To = O.rt_run(om)
     assert _rel(R1[:, :, idx], Ro) < 1e-8 and _rel(T1[:, :, idx], To) < 1e-8
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 57), ("IQUV", 31), ("I", 131)])
+def test_rt_run_fp32_strip_kernels(vsm, arch, pol, l_trunc):
+    """FP32, 64 < N <= 96: the FP32 column-strip layer kernel (6 waves, mat-vec sources).  Moderately thick layers
+    (several doublings, series orders > 1, bright surface); compared with the FP64 oracle at the reference's FP32 gate
+    (max rel 1e-2, test/test_float32.jl:58-64) and with the FP32 oracle's ndoubl / interface trace."""
+    S = 5
+    tau_rayl = np.array([[0.05, 0.5, 1.0]] * S)
+    tau_abs = np.array([[1e-3, 1e-4, 1e-5], [0.5, 0.2, 0.1], [5.0, 1.0, 3.0], [0.0, 0.0, 0.0], [1e-2, 30.0, 1e-2]])
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.6, m_max=3)
+    om32, pm = _both_models(vsm, arch, pol, l_trunc, 50.0, [0.0, 60.0], [30.0, 120.0], FT=np.float32, **kw)
+    om64 = O.build_model(pol, l_trunc, 50.0, [0.0, 60.0], [30.0, 120.0], FT=np.float64, **kw)
+    N = om32.quad_points.Nquad * om32.pol.n
+    assert 64 < N <= 96, N
+    tro, trg = [], []
+    O.rt_run(om32, trace=tro)
+    R64, T64 = O.rt_run(om64)
+    Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
+    assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
+    assert _rel(Rg, R64) < 1e-2 and _rel(Tg, T64) < 1e-2, (N, _rel(Rg, R64), _rel(Tg, T64))
