@@ -23,7 +23,7 @@ def vsm():
 def test_library_exports_every_declared_symbol(vsm):
     header = open(os.path.join(ROOT, "include", "vsmartmom_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(vsm_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(vsm_[A-Za-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     bound = set(vsm._lib.exported_symbols())
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
