@@ -16,6 +16,22 @@
 
 namespace vsm {
 
+#ifdef VSM_PHASE_TIMING
+__device__ unsigned long long vsm_phase_cycles_strip32[32];
+#define VSM_STAMP_DECL unsigned long long _t_prev = __builtin_readcyclecounter()
+#define VSM_STAMP(i)                                                     \
+  do {                                                                   \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
+      const unsigned long long _t = __builtin_readcyclecounter();        \
+      vsm_phase_cycles_strip32[i] += _t - _t_prev;                       \
+      _t_prev = _t;                                                      \
+    }                                                                    \
+  } while (0)
+#else
+#define VSM_STAMP_DECL
+#define VSM_STAMP(i)
+#endif
+
 namespace {
 
 constexpr int FNP = 96;    // padded matrix size
@@ -39,15 +55,22 @@ struct fsmem32 {
   gj_scratch<float, FNP> gj;
 };
 
-// Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h) as "base register + immediate":
-//   A fragment (row 16 t + l15, column k = 16 tb + 4 kq + r, ks = 4 tb + r):
-//        lidx = ab[t ^ (r & 1)][r >> 1] + 96 (16 tb + r)
-//   strip element (row 16 ta + 4 kq + r, column col):  lidx = sr[r] + ((16 ta) ^ p16)
-// (Unlike the FP64 kernels, hiding the bases from LICM and the minreg scheduler both HURT here: measured on C4
-//  3405 points/s with both, 4313 without minreg, 5048 with neither.)
+// A-form swizzle of the FP32 strips.  The generic lidx() of vsm_lds.h separates the four k of an A fragment by the LOW
+// bits of k; here a lane group (lane>>4 = kq) covers k = 16 tb + 4 kq + r, so the row XOR must depend on bits 2..3 of k:
+//     lidx32(row, k) = (row ^ s32(k)) + 96 k ,   s32(k) = (k & 3) | (k & 8) | ((k & 4) << 2)
+// s32 maps the low four bits of k onto span{1, 2, 8, 16} (4 is left out): both the A-fragment reads (16 rows x two kq
+// per 32-lane group) and the accumulator-layout stores (rows 4 kq + r x 16 columns) hit 32 distinct banks
+// (checked exhaustively; the generic swizzle gave 2-way conflicts on every fragment read and products at 1/3 of the
+// MFMA rate).
+__device__ __forceinline__ int s32(int b) { return (b & 3) | (b & 8) | ((b & 4) << 2); }
+__device__ __forceinline__ int lidx32(int a, int b) { return (a ^ s32(b)) + FNP * b; }
+
+// Per-lane addressing as "two base registers + immediate":
+//   A fragment (row 16 t + l15, column k = 16 tb + 4 kq + r, ks = 4 tb + r):  lidx32 = ar[r] + bt[t] + 96 (16 tb + r)
+//   strip element (row 16 ta + 4 kq + r, column col):                        lidx32 = sr[r] + ((16 ta) ^ p16)
 struct fpos {
   int lane, wave, l15, kq, col;
-  int ab[FTL][2];
+  int ar[4], bt[FTL];
   int sr[4], p16;
   __device__ __forceinline__ fpos() {
     lane = threadIdx.x & 63;
@@ -55,56 +78,64 @@ struct fpos {
     l15 = lane & 15;
     kq = lane >> 4;
     col = 16 * wave + l15;
+    const int L = l15 ^ ((kq >> 1) << 3), pq = kq & 1;
 #pragma unroll
-    for (int u = 0; u < FTL; ++u)
+    for (int r = 0; r < 4; ++r) ar[r] = (L ^ r) + 4 * FNP * kq;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) ab[u][h] = 16 * u + ((l15 ^ (4 * kq)) ^ (2 * h)) + 4 * FNP * kq;
-    const int m = ((col & 1) << 4) | (((col >> 1) & 7) << 1);
+    for (int t = 0; t < FTL; ++t) bt[t] = 16 * (t ^ pq);
+    const int m = s32(col);
     p16 = m & 16;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sr[r] = (r ^ (m & 2)) + ((4 * kq) ^ (m & 12)) + FNP * col;
+    for (int r = 0; r < 4; ++r) sr[r] = (r ^ (m & 3)) + ((4 * kq) ^ (m & 8)) + FNP * col;
   }
   __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + 4 * kq + r; }
   __device__ __forceinline__ int aidx(int t, int ks) const {
-    return ab[t ^ (ks & 1)][(ks & 3) >> 1] + FNP * (16 * (ks >> 2) + (ks & 3));
+    return ar[ks & 3] + bt[t] + FNP * (16 * (ks >> 2) + (ks & 3));
   }
   __device__ __forceinline__ int sidx(int ta, int r) const { return sr[r] + ((16 * ta) ^ p16); }
 };
 
 // acc += A * B   (A: A-form in LDS, B: strip in registers); KS = 4 ceil(N / 16) MFMA steps
+// Fragments are requested PF k-steps ahead: one f32 k-step is only 6 x 32 = 192 MFMA cycles, less than the LDS latency
+// under load, so the single-step lookahead of the FP64 kernels (4 x 64 cycles per step) leaves the pipe at 40 %.
+constexpr int PF = 1;
 template <int KS>
 __device__ __forceinline__ void mm_ab(fstrip& acc, const float* A, const fstrip& B, fpos& p) {
-  float a[2][FTL];
+  float a[PF + 1][FTL];
 #pragma unroll
-  for (int t = 0; t < FTL; ++t) a[0][t] = A[p.aidx(t, 0)];
+  for (int s0 = 0; s0 < PF; ++s0)
+#pragma unroll
+    for (int t = 0; t < FTL; ++t) a[s0][t] = A[p.aidx(t, s0)];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
+    if (ks + PF < KS) {
 #pragma unroll
-      for (int t = 0; t < FTL; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+      for (int t = 0; t < FTL; ++t) a[(ks + PF) % (PF + 1)][t] = A[p.aidx(t, ks + PF)];
     }
     const float b = B.v[ks >> 2][ks & 3];
 #pragma unroll
-    for (int t = 0; t < FTL; ++t) acc.v[t] = mfma<float>::mma(a[ks & 1][t], b, acc.v[t]);
+    for (int t = 0; t < FTL; ++t) acc.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b, acc.v[t]);
   }
 }
 template <int KS>
 __device__ __forceinline__ void mm_ab2(fstrip& acc1, fstrip& acc2, const float* A, const fstrip& B1, const fstrip& B2,
                                        fpos& p) {
-  float a[2][FTL];
+  float a[PF + 1][FTL];
 #pragma unroll
-  for (int t = 0; t < FTL; ++t) a[0][t] = A[p.aidx(t, 0)];
+  for (int s0 = 0; s0 < PF; ++s0)
+#pragma unroll
+    for (int t = 0; t < FTL; ++t) a[s0][t] = A[p.aidx(t, s0)];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
+    if (ks + PF < KS) {
 #pragma unroll
-      for (int t = 0; t < FTL; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+      for (int t = 0; t < FTL; ++t) a[(ks + PF) % (PF + 1)][t] = A[p.aidx(t, ks + PF)];
     }
     const float b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
 #pragma unroll
     for (int t = 0; t < FTL; ++t) {
-      acc1.v[t] = mfma<float>::mma(a[ks & 1][t], b1, acc1.v[t]);
-      acc2.v[t] = mfma<float>::mma(a[ks & 1][t], b2, acc2.v[t]);
+      acc1.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b1, acc1.v[t]);
+      acc2.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b2, acc2.v[t]);
     }
   }
 }
@@ -157,31 +188,32 @@ __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, c
 __device__ __forceinline__ void stage_aform(float* L, const float* __restrict__ g, int N, const fpos& p) {
   for (int j = p.wave; j < FNP; j += FNW) {
     const float v0 = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0f;
-    L[lidx<FNP>(p.lane, j)] = v0;
+    L[lidx32(p.lane, j)] = v0;
     if (p.lane < 32) {
       const int i = 64 + p.lane;
-      L[lidx<FNP>(i, j)] = (i < N && j < N) ? g[i + (long long)N * j] : 0.0f;
+      L[lidx32(i, j)] = (i < N && j < N) ? g[i + (long long)N * j] : 0.0f;
     }
   }
 }
 
-// y1 = A x1, y2 = A x2 over the A-form in LDS: 4 lanes per row (row = 16 wave + lane/4), two shuffles.  The lanes with
-// (lane & 3) == 0 receive the sums.  x entries beyond N must be zero.
+// y1 = A x1, y2 = A x2 (x2 scaled) over the A-form in LDS.  Lane (kq, l15) of wave w walks row 16 w + l15 over the
+// columns k = 16 tb + 4 kq + r -- exactly the A-fragment pattern of tile w, hence conflict-free -- and the four kq
+// groups are summed with two shuffles.  Lanes with kq == 0 receive the sums.  x entries beyond N must be zero.
 __device__ __forceinline__ void matvec2(const float* A, const float* x1, const float* x2, float scale2, float& y1, float& y2,
                                         const fpos& p) {
-  const int row = 16 * p.wave + (p.lane >> 2), part = p.lane & 3;
   float s1 = 0.f, s2 = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < FNP / 4; ++i) {
-    const int k = part + 4 * i;
-    const float a = A[lidx<FNP>(row, k)];
+#pragma unroll
+  for (int ks = 0; ks < 4 * FTL; ++ks) {
+    const int k = 16 * (ks >> 2) + 4 * p.kq + (ks & 3);
+    const float a = A[p.ar[ks & 3] + 16 * (p.wave ^ (p.kq & 1)) + FNP * (16 * (ks >> 2) + (ks & 3))];
     s1 += a * x1[k];
-    s2 += a * (x2[k] * scale2);
+    s2 += a * x2[k];
   }
-  s1 += __shfl_xor(s1, 1);
-  s2 += __shfl_xor(s2, 1);
-  s1 += __shfl_xor(s1, 2);
-  s2 += __shfl_xor(s2, 2);
+  s2 *= scale2;
+  s1 += __shfl_xor(s1, 16);
+  s2 += __shfl_xor(s2, 16);
+  s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 32);
   y1 = s1;
   y2 = s2;
 }
@@ -214,7 +246,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, gj_scratch<float, 
 #pragma unroll
     for (int cb = 0; cb < G::CB; ++cb) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      g[rb][cb] = (i < N && j < N) ? V[lidx<FNP>(i, j)] : ((i == j) ? 1.0f : 0.0f);
+      g[rb][cb] = (i < N && j < N) ? V[lidx32(i, j)] : ((i == j) ? 1.0f : 0.0f);
     }
   gj_invert<float, FNP, FNT>(g, N, *sc);
 #pragma unroll
@@ -222,7 +254,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, gj_scratch<float, 
 #pragma unroll
     for (int cb = 0; cb < G::CB; ++cb) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      if (i < N && j < N) V[lidx<FNP>(i, sc->dst[j])] = g[rb][cb];
+      if (i < N && j < N) V[lidx32(i, sc->dst[j])] = g[rb][cb];
     }
   __syncthreads();
 }
@@ -428,15 +460,19 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   // ---- doubling (rt_helpers.jl:102-166) ------------------------------------------------------------------------
   float expk = exp(-d / q.mu0);
   int slot = 0;
-  const int mrow = 16 * p.wave + (p.lane >> 2);
-  const bool mlead = (p.lane & 3) == 0;
+  const int mrow = 16 * p.wave + p.l15;   // row / lead lane of the mat-vecs
+  const bool mlead = p.kq == 0;
+  VSM_STAMP_DECL;
+  VSM_STAMP(0);
   for (int n = 0; n < ndoubl; ++n) {
     fstrip G;
     {
       fstrip E;
       E.zero();
       mm_ab<KS>(E, P, r_s, p);
+      VSM_STAMP(1);
       invert_strip<KS>(E, G, P, N, sm, slot, p);
+      VSM_STAMP(2);
     }
     fstrip tt;
     tt.zero();
@@ -445,6 +481,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     __syncthreads();  // P (series powers) and Q (t) no longer read
     store_strip(P, tt, p, keepN);
     __syncthreads();  // tt complete in P
+    VSM_STAMP(3);
     {
       float y1, y2;
       matvec2(P, jp, jm, expk, y1, y2, p);  // tt j0+ , tt j1-  (j1- = j0- expk)
@@ -453,12 +490,14 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
         vb[mrow] = y2;
       }
     }
+    VSM_STAMP(4);
     fstrip tmp, tn;
     tmp.zero();
     tn.zero();
     mm_ab2<KS>(tmp, tn, P, r_s, t_s, p);
     store_strip(Q, tmp, p, keepN);
     __syncthreads();  // tmp complete in Q
+    VSM_STAMP(5);
     {
       float y1, y2;
       matvec2(Q, jp, jm, expk, y1, y2, p);  // tmp j0+ , tmp j1-
@@ -467,9 +506,11 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
         vd[mrow] = y2;
       }
     }
+    VSM_STAMP(6);
     mm_ab<KS>(r_s, Q, t_s, p);  // r' = r + tmp t
     t_s = tn;
     __syncthreads();  // everybody finished reading P (tt), Q (tmp), jp, jm ; va..vd complete
+    VSM_STAMP(7);
     // j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134)
     if (tid < FNP) {
       const float njm = jm[tid] + vb[tid] + vc[tid];
@@ -483,6 +524,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
       store_strip(Q, t_s, p, keepN);
     }
     __syncthreads();
+    VSM_STAMP(8);
   }
 
   // ---- apply_D (doubling.jl:178-252) -----------------------------------------------------------------------------
@@ -520,8 +562,8 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   float* J0_p = c.J0_p + (long long)s * N;
   float* J0_m = c.J0_m + (long long)s * N;
   auto keepN = [N](float x, int r, int cc) { return (r < N && cc < N) ? x : 0.0f; };
-  const int mrow = 16 * p.wave + (p.lane >> 2);
-  const bool mlead = (p.lane & 3) == 0;
+  const int mrow = 16 * p.wave + p.l15;   // row / lead lane of the mat-vecs
+  const bool mlead = p.kq == 0;
   int slot = 0;
 
   if (tid < FNP) {
@@ -532,8 +574,10 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   fstrip X;
   load_strip_global(X, R_pm, N, p);  // R+- strip
   store_strip(P, r_s, p, keepN);     // [r-+] -> P
+  VSM_STAMP_DECL;
   stage_aform(Q, T_mm, N, p);        // [T--] -> Q
   __syncthreads();
+  VSM_STAMP(10);
   // u = r-+ J0+ + j0-
   {
     float y1, y2;
@@ -546,11 +590,13 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     fstrip E;
     E.zero();
     mm_ab<KS>(E, P, X, p);
+    VSM_STAMP(11);
     invert_strip<KS>(E, G, P, N, sm, slot, p);
   }
   __syncthreads();
   store_strip(P, G, p, keepN);  // [G1] -> P
   __syncthreads();
+  VSM_STAMP(12);
   // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H -------------------------------------------------------------------
   fstrip H, A1;
   H.zero();
@@ -563,6 +609,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   store_strip(P, X, p, keepN);   // [T01 r-+] -> P
   store_strip(Q, A1, p, keepN);  // [T01] -> Q
   __syncthreads();
+  VSM_STAMP(13);
   // J0- += T01 u
   {
     float y1, y2;
@@ -574,9 +621,11 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     fstrip Tpp, acc;
     load_strip_global(Tpp, T_pp, N, p);
     load_strip_global(acc, R_mp, N, p);
+    VSM_STAMP(14);
     mm_ab<KS>(acc, P, Tpp, p);
     store_strip_global(R_mp, acc, N, p);
   }
+  VSM_STAMP(15);
   // ---- T-- = T01 t-- -------------------------------------------------------------------------------------------------
   {
     fstrip tmm, acc;
@@ -586,10 +635,12 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     store_strip_global(T_mm, acc, N, p);
   }
   __syncthreads();  // [T01 r-+] (P) and [T01] (Q) no longer read
+  VSM_STAMP(16);
   // ---- G2 = I + R+- H  (push-through identity) ; z = J0+ + R+- j0- -----------------------------------------------------
   stage_aform(P, R_pm, N, p);      // [R+-] -> P
   store_strip(Q, t_s, p, keepN);   // [t++] -> Q
   __syncthreads();
+  VSM_STAMP(17);
   G.zero();
   mm_ab<KS>(G, P, H, p);
   fstrip Rpm;
@@ -613,6 +664,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   __syncthreads();  // [R+-] (P), [t++] (Q) no longer read ; z complete
   store_strip(P, X, p, keepN);  // [T21] -> P
   __syncthreads();
+  VSM_STAMP(18);
   // J0+ = j0+ + T21 z
   {
     float y1, y2;
@@ -630,6 +682,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     __syncthreads();
     store_strip_global(T_pp, acc1, N, p);
   }
+  VSM_STAMP(19);
   // ---- R+- = r+- + tmp t-- -------------------------------------------------------------------------------------------------
   {
     fstrip tmm, acc;
@@ -643,10 +696,11 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     mm_ab<KS>(acc, Q, tmm, p);
     store_strip_global(R_pm, acc, N, p);
   }
+  VSM_STAMP(20);
 }
 
 template <int KS>
-__global__ __launch_bounds__(FNT, 3) void k_ia_strip32(int N, composite<float> c, added<float> a) {
+__global__ __launch_bounds__(FNT, 2) void k_ia_strip32(int N, composite<float> c, added<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem32& sm = *reinterpret_cast<fsmem32*>(smem_raw);
   fpos p;
@@ -665,7 +719,7 @@ __global__ __launch_bounds__(FNT, 3) void k_ia_strip32(int N, composite<float> c
 }
 
 template <int KS, bool MIX>
-__global__ __launch_bounds__(FNT, 3) void k_layer_strip32(quad<float> q, int m, int ndoubl, const float* __restrict__ dtau,
+__global__ __launch_bounds__(FNT, 2) void k_layer_strip32(quad<float> q, int m, int ndoubl, const float* __restrict__ dtau,
                                                           const float* __restrict__ varpi,
                                                           const float* __restrict__ tau_sum, const float* __restrict__ F0,
                                                           zsrc<float> z, int toa, composite<float> c) {
@@ -749,3 +803,14 @@ int strip32_interaction11(int N, int S, const composite<float>& c, const added<f
 }
 
 }  // namespace vsm
+
+#ifdef VSM_PHASE_TIMING
+extern "C" int vsm_debug_phase_cycles_strip32(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_strip32), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_phase_cycles_strip32), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
