@@ -150,7 +150,12 @@ def main():
     k_flops = sum(S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2)) for _, _, nd, toa in ev)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
-    kernel_name = "k_layer_strip" if (cfg["FT"] == "f64" and 32 < N <= 60) else "k_elemental_doubling + k_interaction11"
+    if cfg["FT"] == "f64" and 32 < N <= 60:
+        kernel_name = "k_layer_strip"
+    elif cfg["FT"] == "f32" and 64 < N <= 96:
+        kernel_name = "k_layer_strip32"
+    else:
+        kernel_name = "k_elemental_doubling + k_interaction11"
     traffic, traffic_src = hbm_traffic_per_launch(kernel_name, cfg, S_local)
 
     if rank == 0:
