@@ -1005,6 +1005,168 @@ __global__ __launch_bounds__(64 * NW) void k_inv_one_minus_ab(int N, const T* __
 }
 
 // ---------------------------------------------------------------------------
+// Rotational-Raman doubling, inelastic part of ONE doubling step for all Raman lines of one recipient point
+// (doubling_inelastic.jl:62-123: the two `for dn` loops), N <= 30.
+// One workgroup per recipient point n1 walks the lines dn; per line the ten N^3 products
+//     X = ier r0 + r1 ier ;  X gt0, X gr0, iet gt0, iet grt0, r1 iet, (ier + X gr0) t0, ttg1 (..), ttg1 (..)
+// run on LDS-resident operands (NP = 32: 16 buffers of 8 KB in FP64), and EVERY matrix-vector product of the source
+// recurrences rides along as a spare column (N, N+1) of a B operand -- ier j1-, ier j0+ with r0; X tmp1 / iet tmp1
+// with gt0; X tmp2 with gr0; iet tmp2 with grt0; r1 iej1-, r1 iej0+ with iet; ttg1 a3 / ttg1 a4 with the last two
+// products.  The operator-level path streams the 4-D arrays through ~30 launches per step; here each block of
+// ier / iet / ieJ is read once and written once.  (subscripts: 1 = recipient point n1, 0 = donor n0 = n1 + shift[dn])
+// ---------------------------------------------------------------------------
+template <typename T>
+struct rdsmem {
+  T B[16][32 * 32];
+  T v[12][32];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_raman_doubling_lines(
+    int N, int S, int K, const int* __restrict__ shift, const T* __restrict__ r, const T* __restrict__ t,
+    const T* __restrict__ ttg, const T* __restrict__ gt, const T* __restrict__ gr, const T* __restrict__ grt,
+    const T* __restrict__ jp, const T* __restrict__ j1m, const T* __restrict__ tmp1, const T* __restrict__ tmp2,
+    const T* __restrict__ expk, T* ier, T* iet, T* ieJp, T* ieJm) {
+  constexpr int NP = 32, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  rdsmem<T>& sm = *reinterpret_cast<rdsmem<T>*>(smem_raw);
+  T* R1 = sm.B[0];
+  T* TTG = sm.B[1];
+  T* IER = sm.B[2];
+  T* IET = sm.B[3];    // + columns N, N+1: iej1- , iej0+
+  T* R0 = sm.B[4];     // + columns N, N+1: j1-[n0], j0+[n0]
+  T* GT = sm.B[5];     // + column N: tmp1[n0]
+  T* GR = sm.B[6];     // + column N: tmp2[n0]
+  T* GRT = sm.B[7];    // + column N: tmp2[n0]
+  T* T0 = sm.B[8];
+  T* X = sm.B[9];
+  T* W1 = sm.B[10];    // iet + X gt0 (+ column N: a3)
+  T* W3 = sm.B[11];    // (ier + X gr0) t0 + r1 iet (+ column N: a4)
+  T* IETGT = sm.B[12];
+  T* IETGRT = sm.B[13];
+  T* R1IET = sm.B[14];
+  T* WA = sm.B[15];    // ier + X gr0
+  T* v1 = sm.v[0];     // ier j1-
+  T* v2 = sm.v[1];     // ier j0+
+  T* v3 = sm.v[2];     // X tmp1
+  T* v4 = sm.v[3];     // X tmp2
+  T* v5 = sm.v[4];     // iet tmp1
+  T* v6 = sm.v[5];     // iet tmp2
+  T* v7 = sm.v[6];     // r1 iej1-
+  T* v8 = sm.v[7];     // r1 iej0+
+  T* vJp = sm.v[8];    // iej0+
+  T* vJ1m = sm.v[9];   // iej1-
+  T* vJm = sm.v[10];   // iej0-
+  const int n1 = blockIdx.x, tid = threadIdx.x;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const long long NN = (long long)N * N;
+  const int cA = N, cB = N + 1;  // spare columns (N <= 30)
+  stage<T, NP, NW>(R1, r + n1 * NN, N);
+  stage<T, NP, NW>(TTG, ttg + n1 * NN, N);
+  acc_block<T, NP, NW> acc;
+  for (int dn = 0; dn < K; ++dn) {
+    const int n0 = n1 + shift[dn];
+    if (n0 < 0 || n0 >= S) continue;  // (uniform) out-of-band coupling: the blocks stay zero
+    const long long o4 = ((long long)n1 + (long long)S * dn) * NN, o4v = ((long long)n1 + (long long)S * dn) * N;
+    const T e0 = expk[n0];
+    __syncthreads();  // previous line's readers of the buffers are done
+    stage<T, NP, NW>(IER, ier + o4, N);
+    stage<T, NP, NW>(IET, iet + o4, N);
+    stage<T, NP, NW>(R0, r + n0 * NN, N);
+    stage<T, NP, NW>(GT, gt + n0 * NN, N);
+    stage<T, NP, NW>(GR, gr + n0 * NN, N);
+    stage<T, NP, NW>(GRT, grt + n0 * NN, N);
+    stage<T, NP, NW>(T0, t + n0 * NN, N);
+    __syncthreads();
+    if (tid < N) {
+      const T a = ieJp[o4v + tid], b = ieJm[o4v + tid];
+      vJp[tid] = a;
+      vJm[tid] = b;
+      vJ1m[tid] = b * e0;
+      IET[lidx<NP>(tid, cA)] = b * e0;
+      IET[lidx<NP>(tid, cB)] = a;
+      R0[lidx<NP>(tid, cA)] = j1m[(long long)n0 * N + tid];
+      R0[lidx<NP>(tid, cB)] = jp[(long long)n0 * N + tid];
+      const T x1 = tmp1[(long long)n0 * N + tid], x2 = tmp2[(long long)n0 * N + tid];
+      GT[lidx<NP>(tid, cA)] = x1;
+      GR[lidx<NP>(tid, cA)] = x2;
+      GRT[lidx<NP>(tid, cA)] = x2;
+    }
+    __syncthreads();
+    // X = ier r0 + r1 ier  (+ v1 = ier j1-, v2 = ier j0+) ;  r1 iet (+ v7 = r1 iej1-, v8 = r1 iej0+)
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, IER, R0, Kend);
+    acc_store<T, NP, NW>(X, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v1[rr] = a;
+      if (c == cB) v2[rr] = a;
+      return a;
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, R1, IET, Kend);
+    acc_store<T, NP, NW>(R1IET, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v7[rr] = a;
+      if (c == cB) v8[rr] = a;
+      return a;
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, R1, IER, Kend);
+    __syncthreads();  // X (first half) stored by every wave
+    acc_store<T, NP, NW>(X, acc, [=](T a, int, int c, T old) { return (c < N) ? old + a : T(0); });
+    __syncthreads();
+    // X gt0 (+ v3), X gr0 (+ v4), iet gt0 (+ v5), iet grt0 (+ v6)
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, X, GT, Kend);
+    acc_store<T, NP, NW>(W1, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v3[rr] = a;
+      return (c < N) ? a + IET[lidx<NP>(rr, c)] : T(0);
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, X, GR, Kend);
+    acc_store<T, NP, NW>(WA, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v4[rr] = a;
+      return (c < N) ? a + IER[lidx<NP>(rr, c)] : T(0);
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, IET, GT, Kend);
+    acc_store<T, NP, NW>(IETGT, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v5[rr] = a;
+      return a;
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, IET, GRT, Kend);
+    acc_store<T, NP, NW>(IETGRT, acc, [=](T a, int rr, int c, T) {
+      if (c == cA) v6[rr] = a;
+      return a;
+    });
+    __syncthreads();
+    // a3 = iej0+ + r1 iej1- + ier j1- + X tmp1 -> column N of W1 ;  W3 = (ier + X gr0) t0 + r1 iet
+    if (tid < N) W1[lidx<NP>(tid, cA)] = vJp[tid] + v7[tid] + v1[tid] + v3[tid];
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, WA, T0, Kend);
+    acc_store<T, NP, NW>(W3, acc, [=](T a, int rr, int c, T) { return (c < N) ? a + R1IET[lidx<NP>(rr, c)] : T(0); });
+    __syncthreads();
+    // a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2 -> column N of W3
+    if (tid < N) W3[lidx<NP>(tid, cA)] = vJ1m[tid] + v2[tid] + v8[tid] + v4[tid];
+    __syncthreads();
+    // tmp5 = ttg1 W1 + iet gt0 (+ tmp3 from column N) ;  tmp6 = ier + iet grt0 + ttg1 W3 (+ tmp4)
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, TTG, W1, Kend);
+    acc_store<T, NP, NW>(X, acc, [=](T a, int rr, int c, T) {   // X is free: reuse as the output image of tmp5
+      if (c == cA && rr < N) ieJp[o4v + rr] = vJp[rr] * e0 + a + v5[rr];
+      return a + IETGT[lidx<NP>(rr, c)];
+    });
+    acc.zero();
+    mm_ll<T, NP, NW>(acc, TTG, W3, Kend);
+    acc_store<T, NP, NW>(WA, acc, [=](T a, int rr, int c, T) {  // WA is free: output image of tmp6
+      if (c == cA && rr < N) ieJm[o4v + rr] = vJm[rr] + a + v6[rr];
+      return a + IER[lidx<NP>(rr, c)] + IETGRT[lidx<NP>(rr, c)];
+    });
+    __syncthreads();
+    lds_to_global<T, NP, NW>(iet + o4, X, N);
+    lds_to_global<T, NP, NW>(ier + o4, WA, N);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
 template <typename T>
@@ -1155,11 +1317,32 @@ int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, lo
   });
 }
 
+// inelastic part of one Raman doubling step (all lines); VSM_ERR_UNSUPPORTED for N > 30 (callers use the operator-level chain)
+template <typename T>
+int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
+                         const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,
+                         T* ieJp, T* ieJm, hipStream_t st) {
+  if (S <= 0 || K <= 0) return VSM_OK;
+  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr;
+  if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
+  auto kern = k_raman_doubling_lines<T>;
+  const size_t bytes = sizeof(rdsmem<T>);
+  static int prepared = enable_lds(kern, bytes);
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier,
+                     iet, ieJp, ieJm);
+  VSM_LAUNCH_CHECK("k_raman_doubling_lines");
+  return VSM_OK;
+}
+
 #define VSM_INST_F(T)                                                                                               \
   template int fused_elemental_doubling<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*,  \
                                            const T*, const T*, long long, const added<T>&, hipStream_t);           \
   template int fused_interaction<T>(int, int, int, const composite<T>&, const added<T>&, hipStream_t);              \
   template int inv_one_minus_product<T>(int, int, const T*, long long, const T*, long long, T*, hipStream_t);       \
+  template int raman_doubling_lines<T>(int, int, int, const int*, const T*, const T*, const T*, const T*, const T*, \
+                                       const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*,  \
+                                       hipStream_t);                                                                \
   template int test_lds_mm<T>(int, int, const T*, const T*, T*, hipStream_t);                                       \
   template int test_lds_inv<T>(int, int, const T*, T*, int, int*, hipStream_t);
 VSM_INST_F(double)

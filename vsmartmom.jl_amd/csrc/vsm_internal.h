@@ -114,6 +114,11 @@ inline int inv_one_minus(int N, int S, const T* A, long long sa, const T* B, lon
   if ((rc = gemm<T>(N, N, N, S, A, sa, B, sb, tmp, NN, T(-1), (const T*)nullptr, 0, T(0), T(1), st))) return rc;
   return batch_inv<T>(N, S, tmp, X, nullptr, st);
 }
+// Raman: inelastic part of one doubling step for all lines, LDS-resident (N <= 30; else VSM_ERR_UNSUPPORTED)
+template <typename T>
+int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
+                         const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,
+                         T* ieJp, T* ieJm, hipStream_t st);
 template <typename T>
 int test_lds_mm(int N, int S, const T* A, const T* B, T* C, hipStream_t st);
 template <typename T>

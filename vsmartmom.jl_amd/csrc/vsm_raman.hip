@@ -345,47 +345,55 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
     G3(N, 1, N, S, gp, NN, u, N, tmp1, N, one, nul, 0, zero, zero);
     G3(N, 1, N, S, a.r_mp, NN, a.j0_p, N, u2, N, one, j1m, N, one, zero);
     G3(N, 1, N, S, gp, NN, u2, N, tmp2, N, one, nul, 0, zero, zero);
-    // ieJ1+- = ieJ0+- expk[n0]
-    if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_p, expk, ieJ1p, st))) return rc;
-    if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_m, expk, ieJ1m, st))) return rc;
-    // X = ier r[n0] + r[n1] ier -> W1
-    G4(N, N, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.r_mp, NN), W1, none);
-    G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ier_mp, NN), W1, at_4d<T>(W1, NN));
-    // tmp3 = ieJ1+ + ttg[n1] (ieJ0+ + r[n1] ieJ1- + ier J1-[n0] + X tmp1[n0]) + iet tmp1[n0]   -> V2
-    G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ieJ1m, N), V1, at_4d<T>(ie.ieJ0_p, N));
-    G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(j1m, N), V1, at_4d<T>(V1, N));
-    G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp1, N), V1, at_4d<T>(V1, N));
-    G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp1, N), V2, at_4d<T>(ieJ1p, N));
-    G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V2, at_4d<T>(V2, N));
-    // tmp4 = ieJ0- + ttg[n1] (ieJ1- + ier J0+[n0] + r[n1] ieJ0+ + X tmp2[n0]) + iet tmp2[n0]   -> V3
-    G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.j0_p, N), V1, at_4d<T>(ieJ1m, N));
-    G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ieJ0_p, N), V1, at_4d<T>(V1, N));
-    G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp2, N), V1, at_4d<T>(V1, N));
-    G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp2, N), V3, at_4d<T>(ie.ieJ0_m, N));
-    G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V3, at_4d<T>(V3, N));
-    if ((rc = copy_rs<T>(N, S, K, shift, V2, nul, ie.ieJ0_p, st))) return rc;
-    if ((rc = copy_rs<T>(N, S, K, shift, V3, nul, ie.ieJ0_m, st))) return rc;
+    // gt = gp t ; gr = gp r ; grt = gr t   (old r, t)
+    G3(N, N, N, S, gp, NN, a.t_pp, NN, gt, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
+    G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
+    // ---- inelastic recurrences of this step (they read the OLD elastic r, t, J0+, expk) -------------------------------
+    rc = raman_doubling_lines<T>(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk, ie.ier_mp,
+                                 ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);   // N <= 30: one LDS-resident launch for all lines
+    if (rc == VSM_ERR_UNSUPPORTED) {
+      // operator-level chain: one launch per batched operator over all (n1, dn) pairs
+      // ieJ1+- = ieJ0+- expk[n0]
+      if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_p, expk, ieJ1p, st))) return rc;
+      if ((rc = copy_rs<T>(N, S, K, shift, ie.ieJ0_m, expk, ieJ1m, st))) return rc;
+      // X = ier r[n0] + r[n1] ier -> W1
+      G4(N, N, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.r_mp, NN), W1, none);
+      G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ier_mp, NN), W1, at_4d<T>(W1, NN));
+      // tmp3 = ieJ1+ + ttg[n1] (ieJ0+ + r[n1] ieJ1- + ier J1-[n0] + X tmp1[n0]) + iet tmp1[n0]   -> V2
+      G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ieJ1m, N), V1, at_4d<T>(ie.ieJ0_p, N));
+      G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(j1m, N), V1, at_4d<T>(V1, N));
+      G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp1, N), V1, at_4d<T>(V1, N));
+      G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp1, N), V2, at_4d<T>(ieJ1p, N));
+      G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V2, at_4d<T>(V2, N));
+      // tmp4 = ieJ0- + ttg[n1] (ieJ1- + ier J0+[n0] + r[n1] ieJ0+ + X tmp2[n0]) + iet tmp2[n0]   -> V3
+      G4(N, 1, at_4d<T>(ie.ier_mp, NN), at_n0<T>(a.j0_p, N), V1, at_4d<T>(ieJ1m, N));
+      G4(N, 1, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.ieJ0_p, N), V1, at_4d<T>(V1, N));
+      G4(N, 1, at_4d<T>(W1, NN), at_n0<T>(tmp2, N), V1, at_4d<T>(V1, N));
+      G4(N, 1, at_4d<T>(ie.iet_pp, NN), at_n0<T>(tmp2, N), V3, at_4d<T>(ie.ieJ0_m, N));
+      G4(N, 1, at_n1<T>(ttg, NN), at_4d<T>(V1, N), V3, at_4d<T>(V3, N));
+      if ((rc = copy_rs<T>(N, S, K, shift, V2, nul, ie.ieJ0_p, st))) return rc;
+      if ((rc = copy_rs<T>(N, S, K, shift, V3, nul, ie.ieJ0_m, st))) return rc;
+      // tmp5 = ttg[n1] (iet + X gt[n0]) + iet gt[n0]   -> W3
+      G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gt, NN), W2, at_4d<T>(ie.iet_pp, NN));
+      G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(gt, NN), W3, none);
+      G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W2, NN), W3, at_4d<T>(W3, NN));
+      // tmp6 = ier + iet grt[n0] + ttg[n1] (r[n1] iet + (ier + X gr[n0]) t[n0])   -> W2
+      G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gr, NN), W2, at_4d<T>(ie.ier_mp, NN));
+      G4(N, N, at_4d<T>(W2, NN), at_n0<T>(a.t_pp, NN), W4, none);
+      G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.iet_pp, NN), W4, at_4d<T>(W4, NN));
+      G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(grt, NN), W2, at_4d<T>(ie.ier_mp, NN));
+      G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W4, NN), W2, at_4d<T>(W2, NN));
+      if ((rc = copy_rs<T>(NN, S, K, shift, W3, nul, ie.iet_pp, st))) return rc;
+      if ((rc = copy_rs<T>(NN, S, K, shift, W2, nul, ie.ier_mp, st))) return rc;
+    } else if (rc) {
+      return rc;
+    }
     // J0- += ttg (J1- + r J0+) ; J0+ = J1+ + ttg (J0+ + r J1-)      (u2, u from above: old J0+)
     G3(N, 1, N, S, ttg, NN, u2, N, a.j0_m, N, one, a.j0_m, N, one, zero);
     G3(N, 1, N, S, ttg, NN, u, N, a.j0_p, N, one, j1p, N, one, zero);
     hipLaunchKernelGGL(k_square_v<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
     VSM_LAUNCH_CHECK("k_square_v");
-    // gt = gp t ; gr = gp r ; grt = gr t
-    G3(N, N, N, S, gp, NN, a.t_pp, NN, gt, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
-    // tmp5 = ttg[n1] (iet + X gt[n0]) + iet gt[n0]   -> W3
-    G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gt, NN), W2, at_4d<T>(ie.iet_pp, NN));
-    G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(gt, NN), W3, none);
-    G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W2, NN), W3, at_4d<T>(W3, NN));
-    // tmp6 = ier + iet grt[n0] + ttg[n1] (r[n1] iet + (ier + X gr[n0]) t[n0])   -> W2
-    G4(N, N, at_4d<T>(W1, NN), at_n0<T>(gr, NN), W2, at_4d<T>(ie.ier_mp, NN));
-    G4(N, N, at_4d<T>(W2, NN), at_n0<T>(a.t_pp, NN), W4, none);
-    G4(N, N, at_n1<T>(a.r_mp, NN), at_4d<T>(ie.iet_pp, NN), W4, at_4d<T>(W4, NN));
-    G4(N, N, at_4d<T>(ie.iet_pp, NN), at_n0<T>(grt, NN), W2, at_4d<T>(ie.ier_mp, NN));
-    G4(N, N, at_n1<T>(ttg, NN), at_4d<T>(W4, NN), W2, at_4d<T>(W2, NN));
-    if ((rc = copy_rs<T>(NN, S, K, shift, W3, nul, ie.iet_pp, st))) return rc;
-    if ((rc = copy_rs<T>(NN, S, K, shift, W2, nul, ie.ier_mp, st))) return rc;
     // r <- r + ttg r t ; t <- ttg t
     G3(N, N, N, S, ttg, NN, a.r_mp, NN, tM, NN, one, nul, 0, zero, zero);
     G3(N, N, N, S, ttg, NN, a.t_pp, NN, tM2, NN, one, nul, 0, zero, zero);
