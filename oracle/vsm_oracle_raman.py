@@ -9,16 +9,17 @@ cites the reference file:line it follows.
 Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import
 this module.  The shipped package (vsmartmom.jl_amd) never does.
 
-PARITY UNPINNED: the only quantitative RRS fixture of the reference
-(test/reference/phase1b_RRS_sanghavi_q0.jld2) needs the N2/O2 molecular constants
-and the HDF5 reader of src/Inelastic, which are outside the hot path and not
-reproducible without Julia.  This restatement is instead validated by an exact
-property of the equations it restates (tests/test_oracle_raman.py): the inelastic
-recurrences are the first-order perturbation of the elastic ones, so on a
-spectrally uniform atmosphere with the Raman phase matrix set to the elastic one,
-Sum_dn ieJ equals  eps * d(elastic J)/d(varpi)  at every interior spectral point
-(checked against central finite differences of the pinned elastic oracle), and
-out-of-band couplings contribute exactly zero.
+PINNED by the reference's only quantitative RRS fixture, test/reference/phase1b_RRS_sanghavi_q0.jld2 (R, T, ieR,
+ieT of test_parameters/Phase1b_RRS_761-764nm.yaml; extracted to tests/golden/phase1b_rrs_sanghavi_q0.json by
+tests/golden/make_fixtures.py), at the reference's own gate atol 1e-6 / rtol 0.02
+(test/test_forward_raman_phase1b.jl:84-100): observed R 2.4e-4, ieR 9e-4, ieT 1e-2, T 1.4e-2 (the stored Float32 T
+carries single-pixel noise).  The scene inputs (N2/O2 molecular constants -> Raman lines, Cabannes optics, Bodhaine
+Rayleigh depth, reduced profile) come from the host-side producers vsmartmom.jl_amd/raman_inputs.py.
+Also validated by an exact property of the equations it restates (tests/test_oracle_raman.py): the inelastic
+recurrences are the first-order perturbation of the elastic ones, so on a spectrally uniform atmosphere with the
+Raman phase matrix set to the elastic one, Sum_dn ieJ equals  eps * d(elastic J)/d(varpi)  at every interior
+spectral point (central finite differences of the pinned elastic oracle), and out-of-band couplings contribute
+exactly zero.
 
 Array conventions (numpy, batch-first): 3-D arrays as in vsm_oracle.py
 (A[s, i, j], v[s, i]); inelastic 4-D arrays are A[dn, s, i, j] and v[dn, s, i]

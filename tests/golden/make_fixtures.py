@@ -14,6 +14,8 @@ Sources (all under /root/reference/test/):
   vlidort_baseline/reference_data/solar_tester_vector_truth.jl IQU truth
   benchmarks/natraj_trues.jl                                   Natraj 2009 Rayleigh tau=0.5 I,Q,U
   benchmarks/6SV1_R_trues.jl                                   6SV1 reflectances, 6 cases
+  reference/phase1b_RRS_sanghavi_q0.jld2                       rotational-Raman regression arrays R, T, ieR, ieT
+  test_parameters/Phase1b_RRS_761-764nm.yaml                   the scene of that regression (profile, geometry)
 
 The procedure each fixture is used with (geometry, tolerances) is recorded in
 the fixture's "procedure" field with the reference file:line it restates.
@@ -214,10 +216,88 @@ def solar_vector():
     return "solar_tester_vector.json", fx
 
 
+def _jld2_arrays(path):
+    """Minimal reader for the HDF5 subset JLD2 writes: version-2 object headers (OHDR), link messages in the root
+    group, contiguous little-endian float datasets.  Addresses are relative to the 512-byte superblock offset."""
+    import struct
+    d = open(path, "rb").read()
+    base = 512
+
+    def msgs(off):
+        assert d[off:off + 4] == b"OHDR"
+        flags = d[off + 5]
+        p = off + 6 + (16 if flags & 0x20 else 0) + (4 if flags & 0x10 else 0)
+        szb = 1 << (flags & 3)
+        size = int.from_bytes(d[p:p + szb], "little")
+        p += szb
+        end, out = p + size, []
+        while p < end - 4:
+            t, sz = d[p], struct.unpack("<H", d[p + 1:p + 3])[0]
+            p += 4 + (2 if flags & 0x04 else 0)
+            out.append((t, d[p:p + sz]))
+            p += sz
+        return out
+
+    links = {}
+    for m in re.finditer(b"OHDR", d):
+        for t, b in msgs(m.start()):
+            if t == 6:  # link message
+                fl, q = b[1], 2
+                lt = 0
+                if fl & 0x08:
+                    lt, q = b[q], q + 1
+                q += (8 if fl & 0x04 else 0) + (1 if fl & 0x10 else 0)
+                ls = 1 << (fl & 3)
+                ln = int.from_bytes(b[q:q + ls], "little")
+                q += ls
+                name = b[q:q + ln].decode()
+                if lt == 0:
+                    links[name] = struct.unpack("<Q", b[q + ln:q + ln + 8])[0]
+    out = {}
+    for name, addr in links.items():
+        dims = dt = lay = None
+        for t, b in msgs(base + addr):
+            if t == 1:
+                dims = struct.unpack("<%dQ" % b[1], b[4:4 + 8 * b[1]])
+            elif t == 3:
+                dt = (b[0] & 15, struct.unpack("<I", b[4:8])[0])
+            elif t == 8 and b[1] == 1:
+                lay = struct.unpack("<QQ", b[2:18])
+        if dims and len(dims) > 0 and dt and dt[0] == 1 and lay:
+            a = np.frombuffer(d[base + lay[0]:base + lay[0] + lay[1]], dtype="<f%d" % dt[1])
+            out[name] = a.reshape(dims)   # HDF5 (row-major) dims = reversed Julia dims
+    return out
+
+
+def raman_phase1b():
+    import yaml
+    arrs = _jld2_arrays(os.path.join(REF, "test/reference/phase1b_RRS_sanghavi_q0.jld2"))
+    with open(os.path.join(REF, "test/test_parameters/Phase1b_RRS_761-764nm.yaml"), encoding="utf-8") as f:
+        y = yaml.safe_load(f)
+    rt, geo, atm = y["radiative_transfer"], y["geometry"], y["atmospheric_profile"]
+    assert rt["spec_bands"] == ["(1e7/765):0.5:(1e7/762)"], rt["spec_bands"]
+    fx = dict(
+        source="test/reference/phase1b_RRS_sanghavi_q0.jld2 + test/test_parameters/Phase1b_RRS_761-764nm.yaml",
+        procedure="test/test_forward_raman_phase1b.jl:41-103: Stokes_IQU, nstreams 3, Float32, depol auto, Lambertian "
+                  "albedo 0, F0 = e1; n2/o2 at the column-mean temperature; getRamanSSProp!(RS, 1e7/mean(nu), nu); "
+                  "compare R, T, ieR, ieT [nVZA, nStokes, nSpec] with atol 1e-6, rtol 0.02 (I, Q) and atol 1e-6 (U)",
+        nu_start=1e7 / 765, nu_step=0.5, nu_stop=1e7 / 762,
+        nstreams=int(rt["nstreams"]), depol=float(rt["depol"]), polarization="IQU", albedo=0.0,
+        sza=float(geo["sza"]), vza=[float(v) for v in geo["vza"]], vaz=[float(v) for v in geo["vaz"]],
+        T=[float(v) for v in atm["T"]], p=[float(v) for v in atm["p"]], q=[float(v) for v in atm["q"]],
+        profile_reduction=int(atm["profile_reduction"]),
+        atol=1e-6, rtol=0.02,
+    )
+    for k in ("R_rrs", "T_rrs", "ieR", "ieT"):
+        a = arrs[k]                      # [nSpec, nStokes, nVZA] in file order
+        fx[k] = np.transpose(a, (2, 1, 0)).astype(float).tolist()
+    return "phase1b_rrs_sanghavi_q0.json", fx
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at %s (fixtures are committed; nothing to do)" % REF)
-    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector):
+    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector, raman_phase1b):
         name, fx = fn()
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(fx, f, indent=1)

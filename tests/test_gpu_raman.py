@@ -307,3 +307,26 @@ def test_rt_run_rrs_halo_shard_equals_full(vsm, arch):
             for g, f in zip(part, full):
                 assert g.shape[2] == sl.stop - sl.start
                 assert _rel(g, f[:, :, sl]) <= 1e-13
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+def test_rt_run_rrs_reference_regression_phase1b(vsm, arch, golden_dir, FT):
+    """The reference's own RRS regression (test/test_forward_raman_phase1b.jl; the stored run is Float32): device
+    rt_run(RS_type::RRS, model, 1) on the scene of Phase1b_RRS_761-764nm.yaml, inputs from vsmartmom.jl_amd/raman_inputs.py,
+    against the stored R, T, ieR, ieT at the reference's gate (atol 1e-6, rtol 0.02) -- and against the oracle."""
+    from test_oracle_raman import phase1b_scene, check_phase1b
+    fx, bs = phase1b_scene(golden_dir)
+    Hm = vsm.host_model
+    pm = Hm.model_from_arrays(arch, "IQU", 2 * fx["nstreams"] - 1, fx["sza"], fx["vza"], fx["vaz"], bs.tau_rayl,
+                              depol=bs.depol_cabannes, albedo=fx["albedo"], m_max=2, float_type=FT)
+    pm.varpi_Cabannes = bs.varpi_cabannes_rs
+    prs = vsm.CoreRTRaman.RRS(bs.i_shift, bs.varpi_ie, Hm.GreekCoefs.from_dict(bs.greek_raman))
+    got = [np.asarray(g) for g in vsm.CoreRTRaman.rt_run(prs, pm, 1)]
+    check_phase1b(fx, got, tight=dict(R_rrs=1e-3, ieR=3e-3))
+    om = O.build_model("IQU", 2 * fx["nstreams"] - 1, fx["sza"], fx["vza"], fx["vaz"], bs.tau_rayl,
+                       depol=bs.depol_cabannes, albedo=fx["albedo"], m_max=2, FT=FT)
+    om.varpi_cabannes = bs.varpi_cabannes_rs
+    ref = OR.rt_run_rrs(om, OR.RRS(i_shift=bs.i_shift, varpi_ie=bs.varpi_ie, greek_raman=O.greek_from_dict(bs.greek_raman)))
+    tol = 1e-8 if FT == np.float64 else 1e-2
+    for name, g, r in zip(("R", "T", "ieR", "ieT"), got, ref):
+        assert _rel(g, r) <= tol, (name, _rel(g, r))

@@ -1,7 +1,8 @@
 """Validation of the Raman (RRS) oracle, CPU only.
 
-PARITY UNPINNED for Raman (see oracle/vsm_oracle_raman.py).  The check used here is an exact property of the
-restated equations: the inelastic recurrences are the first-order perturbation of the elastic ones in the
+Two legs: (1) the reference's own quantitative RRS regression (test/reference/phase1b_RRS_sanghavi_q0.jld2 ->
+tests/golden/phase1b_rrs_sanghavi_q0.json) at the reference's gate, which PINS the oracle (bottom of this file);
+(2) an exact property of the restated equations: the inelastic recurrences are the first-order perturbation of the elastic ones in the
 single-scattering albedo.  On a spectrally uniform atmosphere, with the Raman phase matrix equal to the
 elastic one and fScattRayleigh = tau_rayl / tau, the Raman field at spectral point n1 must equal
     d(elastic field)/d(varpi_Cabannes) * Sum_{dn : n1 + shift[dn] in band} varpi_ie[dn].
@@ -79,3 +80,61 @@ def test_raman_shift_moves_spectral_structure():
     assert np.all(chg[[0, 1, 2, 3, 4, 6, 7]] <= 1e-15)
     assert np.allclose(ieR_b[:, :, 5], 3.0 * ieR_a[:, :, 5], rtol=1e-12)
     assert np.all(ieR_a[:, :, 8:] == 0)  # donors out of band
+
+
+# ---------------------------------------------------------------------------
+# The reference's quantitative RRS regression (test/test_forward_raman_phase1b.jl): pins the Raman oracle
+# ---------------------------------------------------------------------------
+def phase1b_scene(golden_dir):
+    """Scene of test_parameters/Phase1b_RRS_761-764nm.yaml, built by the host-side input producers
+    (vsmartmom.jl_amd/raman_inputs.py: N2/O2 constants -> Raman lines on the band grid, Cabannes optics, Bodhaine tau)."""
+    import json
+    import os
+    import vsmartmom_jl_amd as V
+    with open(os.path.join(golden_dir, "phase1b_rrs_sanghavi_q0.json")) as f:
+        fx = json.load(f)
+    nu = fx["nu_start"] + fx["nu_step"] * np.arange(int(np.floor((fx["nu_stop"] - fx["nu_start"]) / fx["nu_step"])) + 1)
+    bs = V.raman_inputs.rrs_band_setup(nu, fx["T"], fx["p"], fx["q"], fx["profile_reduction"], fx["depol"])
+    return fx, bs
+
+
+def check_phase1b(fx, got, tight=None):
+    """isapprox(got, ref; atol, rtol) per pixel as test_forward_raman_phase1b.jl:84-100; `tight` adds our own bound."""
+    worst = {}
+    for name, a in zip(("R_rrs", "T_rrs", "ieR", "ieT"), got):
+        ref = np.asarray(fx[name])
+        a = np.asarray(a, dtype=np.float64)
+        assert a.shape == ref.shape, (name, a.shape, ref.shape)
+        for ip in range(ref.shape[1]):
+            d = np.abs(a[:, ip] - ref[:, ip])
+            rtol = fx["rtol"] if ip < 2 else 0.0
+            tol = np.maximum(fx["atol"], rtol * np.maximum(np.abs(a[:, ip]), np.abs(ref[:, ip])))
+            assert np.all(d <= tol), (name, ip, float(d.max()))
+        worst[name] = float(np.max(np.abs(a[:, :2] - ref[:, :2]) / np.abs(ref[:, :2])))
+    if tight:
+        for k, v in tight.items():
+            assert worst[k] <= v, (k, worst[k])
+    return worst
+
+
+def test_phase1b_rrs_inputs(golden_dir):
+    fx, bs = phase1b_scene(golden_dir)
+    assert len(bs.nu) == np.asarray(fx["ieR"]).shape[2] == 103
+    assert bs.tau_rayl.shape == (103, 12)
+    # N2 J=0,1 and O2 J=1 Stokes/anti-Stokes pairs fall inside the 51 cm^-1 band; each is split over two grid points
+    assert list(bs.i_shift) == [-40, -39, -29, -28, -24, -23, 23, 24, 28, 29, 39, 40]
+    assert abs(bs.varpi_ie.sum() - (1 - bs.varpi_cabannes_model)) < 1e-15
+    assert 0.96 < bs.varpi_cabannes_rs < 0.97 and 0.007 < bs.depol_cabannes < 0.0075 and 0.028 < bs.depol_rayleigh < 0.0285
+    assert abs(bs.greek_raman["beta"][2] - 0.5 * (1 - 6 / 7) / (1 + 3 / 7)) < 1e-15
+
+
+def test_phase1b_rrs_golden_pins_the_oracle(golden_dir):
+    """rt_run(RRS) of the oracle against the reference's stored R, T, ieR, ieT at the reference's own gate
+    (atol 1e-6, rtol 0.02); observed: R 2.4e-4, ieR 9e-4, ieT 1e-2, T 1.4e-2 (the stored T carries FP32 noise)."""
+    fx, bs = phase1b_scene(golden_dir)
+    model = O.build_model("IQU", 2 * fx["nstreams"] - 1, fx["sza"], fx["vza"], fx["vaz"], bs.tau_rayl,
+                          depol=bs.depol_cabannes, albedo=fx["albedo"], m_max=2)
+    model.varpi_cabannes = bs.varpi_cabannes_rs
+    rs = OR.RRS(i_shift=bs.i_shift, varpi_ie=bs.varpi_ie, greek_raman=O.greek_from_dict(bs.greek_raman))
+    got = OR.rt_run_rrs(model, rs)
+    check_phase1b(fx, got, tight=dict(R_rrs=1e-3, ieR=3e-3))
