@@ -59,7 +59,8 @@ def _al_host(vsm, al):
                 ap_J0_p=h(al.ap_J0_p), ap_J0_m=h(al.ap_J0_m))
 
 
-@pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7)])
+@pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7),
+                                              ("I", 71), ("IQU", 27), ("IQUV", 25), ("IQU", 33)])   # N = 38, 48, 60, 57: fused strip step
 @pytest.mark.parametrize("ndoubl", [0, 3])
 def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl):
     FT = np.float64

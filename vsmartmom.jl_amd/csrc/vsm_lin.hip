@@ -8,6 +8,8 @@
 //   interaction_lin         interaction_lin.jl:62-331
 //   lambertian_surface_lin  Surfaces/lambertian_surface_lin.jl:48-162
 //   postprocess_vza_lin     tools/postprocessing_vza_lin.jl:18-48
+#include <type_traits>
+
 #include "vsm_internal.h"
 
 namespace vsm {
@@ -302,7 +304,16 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
 #define MM(...) if ((rc = gemm2<T>(__VA_ARGS__, st))) return rc
   hipLaunchKernelGGL(k_ekl_init<T>, dim3((S * P + 255) / 256), dim3(256), 0, st, S, P, expk, dtau_dot_all, mu0, ekl);
   VSM_LAUNCH_CHECK("k_ekl_init");
-  for (int n = 0; n < ndoubl; ++n) {
+  int n0 = 0;
+  if constexpr (std::is_same<T, double>::value) {
+    // fused column-strip step (vsm_striplin.hip): one launch per doubling step, forward + all active parameters
+    for (; n0 < ndoubl; ++n0) {
+      rc = strip_doubling_lin_step(N, S, P, expk, ekl, a, al, st);
+      if (rc == VSM_ERR_UNSUPPORTED && n0 == 0) break;
+      if (rc) return rc;
+    }
+  }
+  for (int n = n0; n < ndoubl; ++n) {
     // forward: G = (I - r r)^-1, tt = t G
     if ((rc = inv_one_minus<T>(N, S, a.r_mp, NN, a.r_mp, NN, G, G, st))) return rc;   // one fused launch when N fits on chip
     MM(N, N, N, S, 1, a.t_pp, NN, 0, G, NN, 0, tt, NN, 0, one, nul, 0, 0, zero, zero);

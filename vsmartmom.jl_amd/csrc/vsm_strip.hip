@@ -40,234 +40,11 @@ __device__ unsigned long long vsm_phase_cycles_strip[32];
 #define VSM_STAMP(i)
 #endif
 
+}  // namespace vsm
+#include "vsm_strip_dev.h"
+namespace vsm {
 namespace {
 
-constexpr int SNP = 64;    // padded matrix size
-constexpr int SNT = 256;   // threads per workgroup (4 waves)
-
-struct sstrip {
-  d4_t v[4];
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) v[a] = acc_zero<double>();
-  }
-};
-
-struct ssmem {
-  double P[SNP * SNP];
-  double Q[SNP * SNP];
-  double vec[8][SNP];
-  float red[2][4];
-  gj_scratch<double, SNP> gj;
-};
-
-// Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h), split into per-lane bases and compile-time
-// offsets so that every LDS access of a product is "base register + immediate":
-//   A fragment (row 16 t + l15, column 4 ks + kq):  lidx = ab[ks & 3][t] + 256 ks      (one base per (ks & 3, t):
-//   bases that differ by a small constant would be fused into ds_read2_b64, whose 8-bit offsets cannot hold 256 ks)
-//   strip element (row 16 ta + kq + 4 r, column col): lidx = ((16 ta + 4 r) ^ cm_hi) + c_lo
-struct spos {
-  int lane, wave, l15, kq, col;
-  int ab[4][4];
-  int cm_hi, c_lo;
-  __device__ __forceinline__ spos() {
-    lane = threadIdx.x & 63;
-    wave = threadIdx.x >> 6;
-    l15 = lane & 15;
-    kq = lane >> 4;
-    col = 16 * wave + l15;
-    const int L = l15 ^ ((kq >> 1) << 1), pq = kq & 1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) ab[j][t] = 64 * kq + (L ^ (4 * j)) + 16 * (t ^ pq);
-    const int m = ((col & 1) << 4) | (((col >> 1) & 7) << 1);
-    cm_hi = m & 0x3C;
-    c_lo = (kq ^ (m & 3)) + SNP * col;
-  }
-  __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
-  __device__ __forceinline__ int aidx(int t, int ks) const { return ab[ks & 3][t] + 256 * ks; }
-  __device__ __forceinline__ int sidx(int ta, int r) const { return ((16 * ta + 4 * r) ^ cm_hi) + c_lo; }
-  // hide the loop invariance of the bases from LICM (hoisting every derived address costs > 100 VGPRs)
-  __device__ __forceinline__ void opaque() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(ab[j][t]));
-    asm volatile("" : "+v"(cm_hi));
-    asm volatile("" : "+v"(c_lo));
-  }
-};
-
-// acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
-template <int KS>
-__device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip& B, spos& p) {
-  p.opaque();
-  double a[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
-    }
-    const double b = B.v[ks >> 2][ks & 3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc.v[t] = mfma<double>::mma(a[ks & 1][t], b, acc.v[t]);
-  }
-}
-// acc1 += A * B1 ; acc2 += A * B2   (shared A fragments)
-template <int KS>
-__device__ __forceinline__ void mm_ab2(sstrip& acc1, sstrip& acc2, const double* A, const sstrip& B1, const sstrip& B2,
-                                       spos& p) {
-  p.opaque();
-  double a[2][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
-    }
-    const double b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc1.v[t] = mfma<double>::mma(a[ks & 1][t], b1, acc1.v[t]);
-      acc2.v[t] = mfma<double>::mma(a[ks & 1][t], b2, acc2.v[t]);
-    }
-  }
-}
-
-// strip -> A-form in LDS, through f(value, row, col)
-template <typename F>
-__device__ __forceinline__ void store_strip(double* dst, const sstrip& s, const spos& p, F f) {
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      dst[p.sidx(ta, r)] = f(s.v[ta][r], row, p.col);
-    }
-}
-__device__ __forceinline__ void load_strip(sstrip& s, const double* src, const spos& p) {
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s.v[ta][r] = src[p.sidx(ta, r)];
-}
-
-// Frobenius-norm bound of the N x N block whose strips the waves hold (deterministic; see vsm_fused.hip).
-// Contains ONE barrier: on return every wave has finished whatever it did before the call.
-__device__ __forceinline__ double strip_norm_bound(const sstrip& e, int N, ssmem& sm, int& slot, const spos& p) {
-  double ss = 0;
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double v = e.v[ta][r];
-      if (p.row(ta, r) < N && p.col < N) ss += v * v;
-    }
-  const float ws = wave_sum(to_float_up(ss));
-  if (p.lane == 0) sm.red[slot][p.wave] = ws;
-  __syncthreads();
-  const float tot = (sm.red[slot][0] + sm.red[slot][1]) + (sm.red[slot][2] + sm.red[slot][3]);
-  slot ^= 1;
-  return (double)(sqrtf(tot) * 1.001f);
-}
-
-// In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block), 256 threads.  Ends with a barrier.
-__device__ __forceinline__ void gj_lds_strip(double* V, int N, gj_scratch<double, SNP>* sc) {
-  using G = gj_cfg<SNP, SNT>;
-  const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
-  double g[G::RB][G::CB];
-#pragma unroll
-  for (int rb = 0; rb < G::RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb) {
-      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      g[rb][cb] = (i < N && j < N) ? V[lidx<SNP>(i, j)] : ((i == j) ? 1.0 : 0.0);
-    }
-  gj_invert<double, SNP, SNT>(g, N, *sc);
-#pragma unroll
-  for (int rb = 0; rb < G::RB; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < G::CB; ++cb) {
-      const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      if (i < N && j < N) V[lidx<SNP>(i, sc->dst[j])] = g[rb][cb];
-    }
-  __syncthreads();
-}
-
-// G_s = strip of (I - E)^-1, E given as strips.  W (LDS, A-form scratch) must not be read by anybody once the
-// first barrier inside has been passed (the norm reduction), which the callers guarantee.  On return other
-// waves may still be READING W: barrier before overwriting it.  Returns 1 (Gauss-Jordan) or 1 + series order.
-template <int KS>
-__device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int N, ssmem& sm, int& slot, spos& p,
-                                            int mode) {
-  const double nrm = strip_norm_bound(E, N, sm, slot, p);
-  const double tol = num<double>::eps() * 0.25;
-  int K = 0;
-  if (nrm < 0.3) {
-    const double lim = tol * (1.0 - nrm);
-    const double n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
-    if (n2 <= lim) K = 1;
-    else if (n2 * nrm <= lim) K = 2;
-    else if (n4 <= lim) K = 3;
-    else if (n4 * nrm <= lim) K = 4;
-    else if (n8 <= lim) K = 7;
-    else if (n8 * nrm <= lim) K = 8;
-    else if (n16 <= lim) K = 15;
-    else if (n16 * nrm <= lim) K = 16;
-    else if (n16 * n16 <= lim) K = 31;
-  }
-  if (mode == 1) K = 0;
-  if (mode == 2 && K == 0) K = 31;
-  auto keep = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
-  if (K == 0) {
-    store_strip(W, E, p, [=](double a, int r, int c) { return (r == c) ? 1.0 - keep(a, r, c) : -keep(a, r, c); });
-    __syncthreads();
-    gj_lds_strip(W, N, &sm.gj);
-    load_strip(G, W, p);
-    return 1;
-  }
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const double e = keep(E.v[ta][r], row, p.col);
-      E.v[ta][r] = e;
-      G.v[ta][r] = (row == p.col && row < N) ? e + 1.0 : e;
-    }
-  if (K == 1) return 2;
-  store_strip(W, E, p, [](double a, int, int) { return a; });
-  __syncthreads();
-  int cur = 1;  // W = E^cur (A-form), E = its strip, G = strip of sum_{k < 2 cur} E^k
-  for (;;) {
-    sstrip W2;
-    W2.zero();
-    mm_ab<KS>(W2, W, E, p);  // E^(2 cur)
-    cur *= 2;
-    if (K == cur) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta) G.v[ta] += W2.v[ta];
-      break;
-    }
-    __syncthreads();  // everybody finished reading W
-    store_strip(W, W2, p, [](double a, int, int) { return a; });
-    __syncthreads();
-    sstrip T;
-    T.zero();
-    mm_ab<KS>(T, W, G, p);  // E^cur * G   (powers of E commute)
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta) G.v[ta] += T.v[ta];
-    if (K == 2 * cur - 1) break;
-    E = W2;
-  }
-  return 1 + K;
-}
 
 // ---------------------------------------------------------------------------
 // elemental! + doubling! + apply_D!   (strip form)
@@ -539,42 +316,6 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
 // ---------------------------------------------------------------------------
 // interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266), strip form
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void load_strip_global(sstrip& s, const double* __restrict__ g, int N, const spos& p) {
-  const int cc = min(p.col, N - 1);
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const double v = g[min(row, N - 1) + (long long)N * cc];   // clamped address, masked value
-      s.v[ta][r] = (row < N && p.col < N) ? v : 0.0;
-    }
-}
-__device__ __forceinline__ void store_strip_global(double* __restrict__ g, const sstrip& s, int N, const spos& p) {
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      if (row < N && p.col < N) g[row + (long long)N * p.col] = s.v[ta][r];
-    }
-}
-// D X D: sign (+) where row and column have the same U/V parity (doubling.jl:178-201)
-__device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, int ns, const spos& p) {
-  const bool uc = is_uv_row(p.col, ns);
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) d.v[ta][r] = (is_uv_row(p.row(ta, r), ns) == uc) ? x.v[ta][r] : -x.v[ta][r];
-}
-// global column-major N x N -> A-form in LDS (zero padded); one column per wave and pass, coalesced reads
-__device__ __forceinline__ void stage_aform(double* L, const double* __restrict__ g, int N, const spos& p) {
-#pragma unroll 4
-  for (int j = p.wave; j < SNP; j += 4) {
-    const double v = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
-    L[lidx<SNP>(p.lane, j)] = v;
-  }
-}
 
 // Body shared by k_ia_strip and k_layer_strip.  On entry: r_s / t_s = strips of the added layer's r-+ / t++,
 // sm.vec[0] / vec[1] = its j0+ / j0-, all waves past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D
