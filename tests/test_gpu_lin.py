@@ -156,8 +156,8 @@ def test_interaction_lin(vsm, arch, N, shared, iface):
         assert _rel(vsm.Architectures.to_host(getattr(pcl, k)), getattr(cl, k)) < 1e-9, "d" + k
 
 
-@pytest.mark.parametrize("pol", ["I", "IQU"])
-def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol):
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 7, 21, 57 (fused strip kernels)
+def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     """rt_run(model, lin_model, 0, NGas, 1): R, T and the Jacobians vs the oracle; the albedo Jacobian also vs a
     finite difference of the device forward run (the reference's own check: test_jacobians_unit.jl:105-123)."""
     rng = np.random.default_rng(0)
@@ -166,8 +166,8 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol):
     ga, gb = 10.0 ** rng.uniform(-2.5, -0.5, (S, L)), 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
     H = vsm.host_model
     kw = dict(tau_rayl=tau_rayl, tau_abs=ga + gb, depol=0.0279, m_max=2)
-    om = O.build_model(pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
-    pm = H.model_from_arrays(arch, pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    pm = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
     Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga, gb]))
     R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga, gb]), 0, 2, 1)
     assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9
@@ -175,7 +175,7 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol):
         assert _rel(Rd[..., p], Rdo[..., p]) < 1e-8, p
         assert _rel(Td[..., p], Tdo[..., p]) < 1e-8, p
     h = 1e-4
-    Rp, _ = vsm.CoreRT.rt_run(H.model_from_arrays(arch, pol, 9, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2 + h, **kw))
+    Rp, _ = vsm.CoreRT.rt_run(H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2 + h, **kw))
     R0, _ = vsm.CoreRT.rt_run(pm)
     fd = (Rp - R0) / h
     err = np.abs(fd - Rd[..., 2]) / np.abs(fd).max()

@@ -147,6 +147,8 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
                long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
                double beta, double gamma, hipStream_t st);
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
+int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
+                            const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st);
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,

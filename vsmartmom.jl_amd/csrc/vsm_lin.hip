@@ -511,6 +511,11 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
     (void)v2;
     return VSM_OK;
   }
+  if constexpr (std::is_same<T, double>::value) {
+    // fused column-strip form (vsm_striplin.hip): two launches instead of ~60
+    rc = strip_interaction11_lin(N, S, c, cl, a, al, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
   // ---- first half: G1, T01_inv and everything that hangs off them --------------------------------
   if ((rc = inv_one_minus<T>(N, S, a.r_mp, as, c.R_pm, NN, G, G, st))) return rc;
   MM(N, N, N, S, 1, c.T_mm, NN, 0, G, NN, 0, T01, NN, 0, one, nul, 0, 0, zero, zero);

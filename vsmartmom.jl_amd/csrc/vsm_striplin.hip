@@ -29,7 +29,30 @@
 #include "vsm_internal.h"
 #include "vsm_strip_dev.h"
 
+#ifndef VSM_EXP
+#define VSM_EXP 0
+#endif
+#define EXP_NO_STORE (VSM_EXP & 1)
+#define EXP_NO_LOAD (VSM_EXP & 2)
+#define EXP_NO_MMA (VSM_EXP & 4)
+#define EXP_NO_STAGE (VSM_EXP & 8)
+
 namespace vsm {
+
+// pointer bindings of one half of the linearized interaction (see k_ia_lin_half)
+struct ia_half {
+  const double *LA, *ER, *LT, *S2, *S3, *ACC0;
+  long long sLA, sER, sLT, sS2, sS3, sACC0;
+  double *OUT0, *OUT1;
+  const double *VR, *VADD, *VACC;
+  double* VOUT;
+  const double *PA, *D1, *D2, *YI, *ACCP, *D3;
+  long long sPA, pPA, sD1, pD1, sD2, pD2, sYI, pYI, sACCP, pACCP, sD3, pD3;
+  double *OUTP0, *OUTP1;
+  const double *VDR, *VDADD, *VDACC;
+  double* VDOUT;
+};
+
 namespace {
 
 struct lsmem {
@@ -37,10 +60,108 @@ struct lsmem {
   double BT[SNP * SNP];
   double BX[SNP * SNP];
   double BY[SNP * SNP];
-  double vec[4][SNP];   // j0+, j0-, aJ+_p, aJ-_p
+  double vec[6][SNP];   // doubling: j0+, j0-, aJ+_p, aJ-_p ; interaction halves: VR, VADD, VACC, VDR, VDADD, VDACC
   float red[2][4];
   gj_scratch<double, SNP> gj;
+  double xw[4][16 * 34];   // per-wave transposer of load/store_strip_global_c
 };
+
+// global column-major N x N -> A-form in LDS with ALL loads in flight before the first LDS write (one wave per SIMD:
+// nothing else hides a round trip, and stage_aform's batches of four make four of them)
+__device__ __forceinline__ void stage_aform_full(double* L, const double* __restrict__ g, int N, const spos& p) {
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = p.wave + 4 * i;
+    v[i] = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) L[lidx<SNP>(p.lane, p.wave + 4 * i)] = v[i];
+}
+__device__ __forceinline__ void stage_aform_full2(double* L1, const double* __restrict__ g1, double* L2,
+                                                  const double* __restrict__ g2, int N, const spos& p) {
+  double v[16], w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = p.wave + 4 * i;
+    const bool ok = p.lane < N && j < N;
+    v[i] = ok ? g1[p.lane + (long long)N * j] : 0.0;
+    w[i] = ok ? g2[p.lane + (long long)N * j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    L1[lidx<SNP>(p.lane, p.wave + 4 * i)] = v[i];
+    L2[lidx<SNP>(p.lane, p.wave + 4 * i)] = w[i];
+  }
+}
+
+// Strip <-> global through a per-wave LDS transposer.  load_strip_global / store_strip_global touch 16 columns x 32 B
+// per instruction (sixteen half-used cache lines, re-fetched from L2 by the next instruction because the four waves'
+// strips overflow the vector L1): measured at half the time of k_ia_lin_half.  Here each lane moves 64 contiguous
+// bytes of one column (full lines, 16-byte accesses) and the (row, lane) permutation to the MFMA layout happens in a
+// wave-private 16 x 32 tile of LDS -- wave-private, so no barrier (LDS operations of one wave complete in order).
+constexpr int XS = 34;   // column stride of the tile in doubles: 2 l15 + kq is conflict-free over a 32-lane pass
+struct d2_t {
+  double a, b;
+} __attribute__((aligned(8)));
+__device__ __forceinline__ void load_strip_global_c(sstrip& x, const double* __restrict__ g, int N, const spos& p,
+                                                    double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  const double* src = g + (long long)N * min(col, N - 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row0 = 32 * h + 8 * q;
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const int r = row0 + i;
+      if (col < N && r + 1 < N) {
+        const d2_t t = *reinterpret_cast<const d2_t*>(src + r);
+        v[i] = t.a;
+        v[i + 1] = t.b;
+      } else {
+        v[i] = (col < N && r < N) ? src[r] : 0.0;
+        v[i + 1] = 0.0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xw[c * XS + 8 * q + i] = v[i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x.v[2 * h + t][r] = xw[p.l15 * XS + 16 * t + p.kq + 4 * r];
+  }
+}
+__device__ __forceinline__ void store_strip_global_c(double* __restrict__ g, const sstrip& x, int N, const spos& p,
+                                                     double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  double* dst = g + (long long)N * min(col, N - 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xw[p.l15 * XS + 16 * t + p.kq + 4 * r] = x.v[2 * h + t][r];
+    __builtin_amdgcn_wave_barrier();
+    const int row0 = 32 * h + 8 * q;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const int r = row0 + i;
+      d2_t t;
+      t.a = xw[c * XS + 8 * q + i];
+      t.b = xw[c * XS + 8 * q + i + 1];
+      if (col < N && r + 1 < N)
+        *reinterpret_cast<d2_t*>(dst + r) = t;
+      else if (col < N && r < N)
+        dst[r] = t.a;
+    }
+  }
+}
 
 // spare-column access: lanes of the owning wave with col == c1 (A) / c1 + 1 (B)
 struct spare {
@@ -68,7 +189,7 @@ struct spare {
   }
   // dstA[row] = x[:, c1], dstB[row] = x[:, c1+1]   (global vectors of length N)
   __device__ __forceinline__ void get(const sstrip& x, const spos& p, int N, double* dstA, double* dstB) const {
-    if (AB) {
+    if (AB && (A || dstB != nullptr)) {
       double* d = A ? dstA : dstB;
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
@@ -99,13 +220,13 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int Kend = ((N + 3) >> 2) << 2;
   const spare sp(p, Kend);
+  double* xw = sm.xw[p.wave];
   const double k = expk[s];
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
   auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
 
-  stage_aform(BR, g_r, N, p);
-  stage_aform(BT, g_t, N, p);
+  stage_aform_full2(BR, g_r, BT, g_t, N, p);
   if (tid < SNP) {
     jp[tid] = (tid < N) ? a.j0_p[(long long)s * N + tid] : 0.0;
     jm[tid] = (tid < N) ? a.j0_m[(long long)s * N + tid] : 0.0;
@@ -141,8 +262,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     double* g_at = al.ap_t_pp + (long long)pp * MS + (long long)s * NN;
     double* g_ajp = al.ap_J0_p + (long long)pp * VS + (long long)s * N;
     double* g_ajm = al.ap_J0_m + (long long)pp * VS + (long long)s * N;
-    stage_aform(BX, g_ar, N, p);
-    stage_aform(BY, g_at, N, p);
+    stage_aform_full2(BX, g_ar, BY, g_at, N, p);
     if (tid < SNP) {
       ajp[tid] = (tid < N) ? g_ajp[tid] : 0.0;
       ajm[tid] = (tid < N) ? g_ajm[tid] : 0.0;
@@ -188,8 +308,8 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     tdn.zero();
     mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);   // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
     mm_ab2<KS>(rd, tdn, BT, Q2, td, p);    // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
-    store_strip_global(g_ar, rd, N, p);
-    store_strip_global(g_at, tdn, N, p);
+    store_strip_global_c(g_ar, rd, N, p, xw);
+    store_strip_global_c(g_at, tdn, N, p, xw);
     sp.get(rd, p, N, g_ajm, g_ajp);
     if (tid == 0) ekl[s + (long long)S * pp] = 2.0 * k * kl;
     __syncthreads();   // BX, BY, aJ+- free for the next parameter
@@ -200,18 +320,144 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   sstrip tn;
   tn.zero();
   mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
-  store_strip_global(g_r, r_s, N, p);
-  store_strip_global(g_t, tn, N, p);
+  store_strip_global_c(g_r, r_s, N, p, xw);
+  store_strip_global_c(g_t, tn, N, p, xw);
   sp.get(r_s, p, N, a.j0_m + (long long)s * N, a.j0_p + (long long)s * N);
   if (tid == 0) expk[s] = k * k;
+}
+
+// ---------------------------------------------------------------------------
+// Linearized interaction, ScatteringInterface_11 (interaction_lin.jl:217-331): each of its two halves has the shape of
+// the doubling step above,
+//     G = (I - LA ER)^-1 ; tt = LT G ; rt = LA S2 ;                    out0 = ACC0 + tt rt ; out1 = tt S3
+//     X1 = PA ER + LA D1 ; X2 = PA S2 + LA D2 ; Y = YI + tt X1 ; ttdot = Y G
+//     outp0 = ACCP + ttdot rt + tt X2 ;  outp1 = ttdot S3 + tt D3
+// with one source recurrence riding in spare column c1:  rt[:,c1] = LA VR + VADD,  X2[:,c1] = PA VR + LA VDR + VDADD,
+//     outp0[:,c1] = VDACC + ttdot rt[:,c1] + tt X2[:,c1],  out0[:,c1] = VACC + tt rt[:,c1].
+//   first half  (G1, T01):  LA = r-+  ER = R+-  LT = T--  S2 = T++  S3 = t--  ACC0 = R-+ -> R-+, T--   sources: J0-
+//   second half (G2, T21):  LA = R+-  ER = r-+  LT = t++  S2 = t--  S3 = T++  ACC0 = r+- -> R+-, T++   sources: J0+
+// The second half reads only arrays the first half leaves untouched, so the two halves are two launches of one kernel.
+
+template <int KS>
+__global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_half h) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  lsmem& sm = *reinterpret_cast<lsmem*>(smem_raw);
+  double* BR = sm.BR;
+  double* BT = sm.BT;
+  double* BX = sm.BX;
+  double* BY = sm.BY;
+  double* vr = sm.vec[0];
+  double* vadd = sm.vec[1];
+  double* vacc = sm.vec[2];
+  double* vdr = sm.vec[3];
+  double* vdadd = sm.vec[4];
+  double* vdacc = sm.vec[5];
+  spos p;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const spare sp(p, Kend);
+  double* xw = sm.xw[p.wave];
+  auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
+  auto keep_old = [](int, double o) { return o; };
+
+  if (!EXP_NO_STAGE) stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
+  if (tid < SNP) {
+    const long long o = (long long)s * N + tid;
+    vr[tid] = (tid < N) ? h.VR[o] : 0.0;
+    vadd[tid] = (tid < N) ? h.VADD[o] : 0.0;
+    vacc[tid] = (tid < N) ? h.VACC[o] : 0.0;
+  }
+  __syncthreads();
+  sstrip er, s2, G, rt;
+  if (EXP_NO_LOAD) er.zero(); else load_strip_global_c(er, h.ER + s * h.sER, N, p, xw);
+  if (EXP_NO_LOAD) s2.zero(); else load_strip_global_c(s2, h.S2 + s * h.sS2, N, p, xw);
+  int slot = 0;
+  {
+    sstrip E;
+    E.zero();
+    if (!EXP_NO_MMA) mm_ab<KS>(E, BR, er, p);
+    invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+  }
+  sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
+  {
+    sstrip tt;
+    tt.zero();
+    if (!EXP_NO_MMA) mm_ab<KS>(tt, BT, G, p);
+    rt.zero();
+    if (!EXP_NO_MMA) mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
+    __syncthreads();            // BT (LT) and BY (series powers) no longer read
+    store_strip(BT, tt, p, keepN);
+  }
+  sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
+  __syncthreads();   // tt complete in BT
+
+  // Global strip loads are issued one phase ahead of their use (before the preceding barrier): with one wave per SIMD
+  // nothing else hides their latency.
+  sstrip s3;
+  if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
+  for (int pp = 0; pp < P; ++pp) {
+    sstrip d1, d2;
+    if (EXP_NO_LOAD) d1.zero(); else load_strip_global_c(d1, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
+    if (EXP_NO_LOAD) d2.zero(); else load_strip_global_c(d2, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
+    if (!EXP_NO_STAGE) stage_aform_full(BX, h.PA + s * h.sPA + pp * h.pPA, N, p);
+    if (tid < SNP) {
+      const long long o = (long long)pp * VS + (long long)s * N + tid;
+      vdr[tid] = (tid < N) ? h.VDR[o] : 0.0;
+      vdadd[tid] = (tid < N) ? h.VDADD[o] : 0.0;
+      vdacc[tid] = (tid < N) ? h.VDACC[o] : 0.0;
+    }
+    __syncthreads();
+    sstrip Y;
+    if (EXP_NO_LOAD) Y.zero(); else load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
+    sstrip X1, X2;
+    X1.zero();
+    X2.zero();
+    if (!EXP_NO_MMA) mm_ab2<KS>(X1, X2, BX, er, s2, p);   // PA ER ; PA S2 (+ PA VR)
+    sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
+    if (!EXP_NO_MMA) mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
+    sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
+    if (!EXP_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
+    store_strip(BY, Y, p, keepN);
+    sstrip acc, d3;
+    if (EXP_NO_LOAD) acc.zero(); else load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
+    if (EXP_NO_LOAD) d3.zero(); else load_strip_global_c(d3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
+    __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
+    {
+      sstrip ttl;
+      ttl.zero();
+      if (!EXP_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+      store_strip(BX, ttl, p, keepN);
+    }
+    sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
+    sstrip tdn;
+    tdn.zero();
+    __syncthreads();   // ttdot complete in BX
+    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
+    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BT, X2, d3, p);   // + tt X2 ; + tt D3
+    if (!EXP_NO_STORE) store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
+    if (!EXP_NO_STORE) store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
+    sp.get(acc, p, N, h.VDOUT + (long long)pp * VS + (long long)s * N, nullptr);
+    __syncthreads();   // BX, BY, the parameter's vectors free
+  }
+
+  sstrip acc0, tn;
+  if (EXP_NO_LOAD) acc0.zero(); else load_strip_global_c(acc0, h.ACC0 + s * h.sACC0, N, p, xw);
+  sp.put(acc0, p, [&](int row, double) { return vacc[row]; }, keep_old);
+  tn.zero();
+  if (!EXP_NO_MMA) mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
+  if (!EXP_NO_STORE) store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
+  if (!EXP_NO_STORE) store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
+  sp.get(acc0, p, N, h.VOUT + (long long)s * N, nullptr);
 }
 
 }  // namespace
 
 #define VSM_CAT2(a, b) a##b
 #define VSM_CAT(a, b) VSM_CAT2(a, b)
-#define VSM_STRIPLIN_DECL(KS) \
-  int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
+#define VSM_STRIPLIN_DECL(KS)                                                                                                      \
+  int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t); \
+  int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIPLIN_DECL(VSM_STRIP_KS)
@@ -225,6 +471,18 @@ int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* exp
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_dbl_lin_step<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_step");
+  return VSM_OK;
+}
+
+int VSM_CAT(launch_ia_lin_half_, VSM_STRIP_KS)(int N, int S, int P, const ia_half& h, hipStream_t st) {
+  static int prepared = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia_lin_half<VSM_STRIP_KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ia_lin_half)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_ia_lin_half<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, h);
+  VSM_LAUNCH_CHECK("k_ia_lin_half");
   return VSM_OK;
 }
 
@@ -262,6 +520,68 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
   }
 }
 
+// Fused ScatteringInterface_11 interaction with derivatives: two launches (first half, second half).
+int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
+                            const added_lin<double>& al, hipStream_t st) {
+  static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_STRIP_LIN_IA") != nullptr;
+  if (off || !strip_supported(N)) return VSM_ERR_UNSUPPORTED;
+  const int P = cl.P;
+  const long long NN = (long long)N * N, MS = NN * S;
+  const long long as = a.mat_stride, als = al.mat_stride, alp = (als == 0) ? NN : MS;
+  ia_half h1{};
+  h1.LA = a.r_mp;   h1.sLA = as;
+  h1.ER = c.R_pm;   h1.sER = NN;
+  h1.LT = c.T_mm;   h1.sLT = NN;
+  h1.S2 = c.T_pp;   h1.sS2 = NN;
+  h1.S3 = a.t_mm;   h1.sS3 = as;
+  h1.ACC0 = c.R_mp; h1.sACC0 = NN;
+  h1.OUT0 = c.R_mp; h1.OUT1 = c.T_mm;
+  h1.VR = c.J0_p; h1.VADD = a.j0_m; h1.VACC = c.J0_m; h1.VOUT = c.J0_m;
+  h1.PA = al.ap_r_mp; h1.sPA = als; h1.pPA = alp;
+  h1.D1 = cl.R_pm;    h1.sD1 = NN;  h1.pD1 = MS;
+  h1.D2 = cl.T_pp;    h1.sD2 = NN;  h1.pD2 = MS;
+  h1.YI = cl.T_mm;    h1.sYI = NN;  h1.pYI = MS;
+  h1.ACCP = cl.R_mp;  h1.sACCP = NN; h1.pACCP = MS;
+  h1.D3 = al.ap_t_mm; h1.sD3 = als; h1.pD3 = alp;
+  h1.OUTP0 = cl.R_mp; h1.OUTP1 = cl.T_mm;
+  h1.VDR = cl.J0_p; h1.VDADD = al.ap_J0_m; h1.VDACC = cl.J0_m; h1.VDOUT = cl.J0_m;
+  ia_half h2{};
+  h2.LA = c.R_pm;   h2.sLA = NN;
+  h2.ER = a.r_mp;   h2.sER = as;
+  h2.LT = a.t_pp;   h2.sLT = as;
+  h2.S2 = a.t_mm;   h2.sS2 = as;
+  h2.S3 = c.T_pp;   h2.sS3 = NN;
+  h2.ACC0 = a.r_pm; h2.sACC0 = as;
+  h2.OUT0 = c.R_pm; h2.OUT1 = c.T_pp;
+  h2.VR = a.j0_m; h2.VADD = c.J0_p; h2.VACC = a.j0_p; h2.VOUT = c.J0_p;
+  h2.PA = cl.R_pm;    h2.sPA = NN;  h2.pPA = MS;
+  h2.D1 = al.ap_r_mp; h2.sD1 = als; h2.pD1 = alp;
+  h2.D2 = al.ap_t_mm; h2.sD2 = als; h2.pD2 = alp;
+  h2.YI = al.ap_t_pp; h2.sYI = als; h2.pYI = alp;
+  h2.ACCP = al.ap_r_pm; h2.sACCP = als; h2.pACCP = alp;
+  h2.D3 = cl.T_pp;    h2.sD3 = NN;  h2.pD3 = MS;
+  h2.OUTP0 = cl.R_pm; h2.OUTP1 = cl.T_pp;
+  h2.VDR = al.ap_J0_m; h2.VDADD = cl.J0_p; h2.VDACC = al.ap_J0_p; h2.VDOUT = cl.J0_p;
+  int rc;
+  switch ((N + 3) / 4) {
+#define VSM_CASE(KS)                                                          \
+  case KS:                                                                    \
+    if ((rc = VSM_CAT(launch_ia_lin_half_, KS)(N, S, P, h1, st))) return rc;  \
+    return VSM_CAT(launch_ia_lin_half_, KS)(N, S, P, h2, st);
+    VSM_CASE(9)
+    VSM_CASE(10)
+    VSM_CASE(11)
+    VSM_CASE(12)
+    VSM_CASE(13)
+    VSM_CASE(14)
+    VSM_CASE(15)
+#undef VSM_CASE
+    default:
+      return VSM_ERR_UNSUPPORTED;
+  }
+}
+
 #endif
+
 
 }  // namespace vsm
