@@ -36,6 +36,13 @@
 #define EXP_NO_LOAD (VSM_EXP & 2)
 #define EXP_NO_MMA (VSM_EXP & 4)
 #define EXP_NO_STAGE (VSM_EXP & 8)
+#ifndef VSM_EXPD
+#define VSM_EXPD 0
+#endif
+#define EXPD_NO_STORE (VSM_EXPD & 1)
+#define EXPD_NO_MMA (VSM_EXPD & 4)
+#define EXPD_NO_STAGE (VSM_EXPD & 8)
+#define EXPD_PLAIN_STORE (VSM_EXPD & 16)
 
 namespace vsm {
 
@@ -226,34 +233,38 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   double* g_t = a.t_pp + (long long)s * NN;
   auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
 
-  stage_aform_full2(BR, g_r, BT, g_t, N, p);
+  if (!EXPD_NO_STAGE) stage_aform_full2(BR, g_r, BT, g_t, N, p);
   if (tid < SNP) {
     jp[tid] = (tid < N) ? a.j0_p[(long long)s * N + tid] : 0.0;
     jm[tid] = (tid < N) ? a.j0_m[(long long)s * N + tid] : 0.0;
   }
   __syncthreads();
-  sstrip r_s, t_s, G, rt;
-  load_strip(r_s, BR, p);
+  // r's strip is re-read from BR where it is needed (register budget); t's is kept (BT is overwritten by tt)
+  auto load_r_with_riders = [&](sstrip& x) {
+    load_strip(x, BR, p);
+    sp.put(x, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
+  };
+  sstrip t_s, G, rt;
   load_strip(t_s, BT, p);
   int slot = 0;
   {
-    sstrip E;
+    sstrip E, r_s;
+    load_strip(r_s, BR, p);
     E.zero();
-    mm_ab<KS>(E, BR, r_s, p);
+    if (!EXPD_NO_MMA) mm_ab<KS>(E, BR, r_s, p);
     invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
   }
   sp.put(t_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
   {
     sstrip tt;
     tt.zero();
-    mm_ab<KS>(tt, BT, G, p);
+    if (!EXPD_NO_MMA) mm_ab<KS>(tt, BT, G, p);
     rt.zero();
-    mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
+    if (!EXPD_NO_MMA) mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
     __syncthreads();             // BT (t) and BY (series powers) no longer read
     store_strip(BT, tt, p, keepN);
   }
   sp.put(rt, p, [&](int row, double o) { return jm[row] * k + o; }, [&](int row, double o) { return jp[row] + o; });
-  sp.put(r_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
   __syncthreads();   // tt complete in BT
 
   for (int pp = 0; pp < P; ++pp) {
@@ -262,21 +273,27 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     double* g_at = al.ap_t_pp + (long long)pp * MS + (long long)s * NN;
     double* g_ajp = al.ap_J0_p + (long long)pp * VS + (long long)s * N;
     double* g_ajm = al.ap_J0_m + (long long)pp * VS + (long long)s * N;
-    stage_aform_full2(BX, g_ar, BY, g_at, N, p);
+    if (!EXPD_NO_STAGE) stage_aform_full2(BX, g_ar, BY, g_at, N, p);
     if (tid < SNP) {
       ajp[tid] = (tid < N) ? g_ajp[tid] : 0.0;
       ajm[tid] = (tid < N) ? g_ajm[tid] : 0.0;
     }
     __syncthreads();
-    sstrip rd, td;
-    load_strip(rd, BX, p);
-    load_strip(td, BY, p);
-    sp.put(rd, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl; });
     sstrip X1, Q2;
     X1.zero();
     Q2.zero();
-    mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
-    mm_ab2<KS>(X1, Q2, BR, rd, td, p);     // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
+    {
+      sstrip r_s;
+      load_r_with_riders(r_s);
+      if (!EXPD_NO_MMA) mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
+    }
+    {
+      sstrip rd, td;   // (scoped: the strips of rdot / tdot are re-read where they are needed again -- register budget)
+      load_strip(rd, BX, p);
+      load_strip(td, BY, p);
+      sp.put(rd, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl; });
+      if (!EXPD_NO_MMA) mm_ab2<KS>(X1, Q2, BR, rd, td, p);     // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
+    }
     // v = aJ1- + rdot j0+ + r aJ+ ; u = aJ+ + rdot j1- + r aJ1-   -> spare columns of Q2
     if (sp.own) {
 #pragma unroll
@@ -290,38 +307,46 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
         }
     }
     {
-      sstrip Y = td;
-      mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
-      __syncthreads();           // every wave has its tdot strip (BY) and is done with rdot's A-form (BX)
+      sstrip Y;
+      load_strip(Y, BY, p);      // tdot
+      if (!EXPD_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
+      __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
       store_strip(BY, Y, p, keepN);
     }
     __syncthreads();   // Y complete in BY
     {
       sstrip ttl;
       ttl.zero();
-      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+      if (!EXPD_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
       store_strip(BX, ttl, p, keepN);
     }
+    sstrip rd, tdn;
+    load_strip_global_c(rd, g_ar, N, p, xw);
     sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl; });
-    __syncthreads();   // ttdot complete in BX
-    sstrip tdn;
     tdn.zero();
-    mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);   // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
-    mm_ab2<KS>(rd, tdn, BT, Q2, td, p);    // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
-    store_strip_global_c(g_ar, rd, N, p, xw);
-    store_strip_global_c(g_at, tdn, N, p, xw);
+    __syncthreads();   // ttdot complete in BX
+    if (!EXPD_NO_MMA) mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);   // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
+    {
+      sstrip td;
+      load_strip_global_c(td, g_at, N, p, xw);
+      if (!EXPD_NO_MMA) mm_ab2<KS>(rd, tdn, BT, Q2, td, p);    // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
+    }
+    if (EXPD_PLAIN_STORE) store_strip_global(g_ar, rd, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_ar, rd, N, p, xw);
+    if (EXPD_PLAIN_STORE) store_strip_global(g_at, tdn, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_at, tdn, N, p, xw);
     sp.get(rd, p, N, g_ajm, g_ajp);
     if (tid == 0) ekl[s + (long long)S * pp] = 2.0 * k * kl;
     __syncthreads();   // BX, BY, aJ+- free for the next parameter
   }
 
   // forward update: r' = r + tt rt (+ tt A, tt B on top of j0-, j1+) ; t' = tt t
+  sstrip r_s;
+  load_strip(r_s, BR, p);
   sp.put(r_s, p, [&](int row, double) { return jm[row]; }, [&](int row, double) { return jp[row] * k; });
   sstrip tn;
   tn.zero();
-  mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
-  store_strip_global_c(g_r, r_s, N, p, xw);
-  store_strip_global_c(g_t, tn, N, p, xw);
+  if (!EXPD_NO_MMA) mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
+  if (EXPD_PLAIN_STORE) store_strip_global(g_r, r_s, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_r, r_s, N, p, xw);
+  if (EXPD_PLAIN_STORE) store_strip_global(g_t, tn, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_t, tn, N, p, xw);
   sp.get(r_s, p, N, a.j0_m + (long long)s * N, a.j0_p + (long long)s * N);
   if (tid == 0) expk[s] = k * k;
 }
@@ -394,8 +419,6 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
 
   // Global strip loads are issued one phase ahead of their use (before the preceding barrier): with one wave per SIMD
   // nothing else hides their latency.
-  sstrip s3;
-  if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
   for (int pp = 0; pp < P; ++pp) {
     sstrip d1, d2;
     if (EXP_NO_LOAD) d1.zero(); else load_strip_global_c(d1, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
@@ -408,8 +431,6 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       vdacc[tid] = (tid < N) ? h.VDACC[o] : 0.0;
     }
     __syncthreads();
-    sstrip Y;
-    if (EXP_NO_LOAD) Y.zero(); else load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
     sstrip X1, X2;
     X1.zero();
     X2.zero();
@@ -417,11 +438,14 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
     if (!EXP_NO_MMA) mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
     sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
-    if (!EXP_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
-    store_strip(BY, Y, p, keepN);
-    sstrip acc, d3;
+    {
+      sstrip Y;
+      if (EXP_NO_LOAD) Y.zero(); else load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
+      if (!EXP_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
+      store_strip(BY, Y, p, keepN);
+    }
+    sstrip acc;
     if (EXP_NO_LOAD) acc.zero(); else load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
-    if (EXP_NO_LOAD) d3.zero(); else load_strip_global_c(d3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
     __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
     {
       sstrip ttl;
@@ -430,11 +454,13 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       store_strip(BX, ttl, p, keepN);
     }
     sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
-    sstrip tdn;
+    sstrip tdn, s3;
     tdn.zero();
+    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
     __syncthreads();   // ttdot complete in BX
     if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
-    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BT, X2, d3, p);   // + tt X2 ; + tt D3
+    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
+    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BT, X2, s3, p);   // + tt X2 ; + tt D3
     if (!EXP_NO_STORE) store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
     if (!EXP_NO_STORE) store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
     sp.get(acc, p, N, h.VDOUT + (long long)pp * VS + (long long)s * N, nullptr);
@@ -445,7 +471,11 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   if (EXP_NO_LOAD) acc0.zero(); else load_strip_global_c(acc0, h.ACC0 + s * h.sACC0, N, p, xw);
   sp.put(acc0, p, [&](int row, double) { return vacc[row]; }, keep_old);
   tn.zero();
-  if (!EXP_NO_MMA) mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
+  {
+    sstrip s3;
+    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
+    if (!EXP_NO_MMA) mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
+  }
   if (!EXP_NO_STORE) store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
   if (!EXP_NO_STORE) store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
   sp.get(acc0, p, N, h.VOUT + (long long)s * N, nullptr);
