@@ -345,6 +345,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
   auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
   int slot = 0;
+  double* xw = sm.xw[p.wave];
 
   VSM_STAMP_DECL;
   // ---- stage: composite vectors, [r-+] -> P, [T--] -> Q, strip of R+- -------------------------------------------
@@ -354,7 +355,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     vJm[tid] = in ? J0_m[tid] : 0.0;
   }
   sstrip X;
-  load_strip_global(X, R_pm, N, p);           // X = R+- strip
+  load_strip_global_c8(X, R_pm, N, p, xw);           // X = R+- strip
   store_strip(P, r_s, p, keepN);
   stage_aform(Q, T_mm, N, p);
   __syncthreads();
@@ -403,18 +404,18 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   VSM_STAMP(11);
   // ---- R-+ += (T01 r-+) T++ ------------------------------------------------------------------------------
   sstrip Tpp;                             // old T++ strip: kept in registers until T++ = T21 T++
-  load_strip_global(Tpp, T_pp, N, p);
+  load_strip_global_c8(Tpp, T_pp, N, p, xw);
   {
     sstrip acc;
-    load_strip_global(acc, R_mp, N, p);
+    load_strip_global_c8(acc, R_mp, N, p, xw);
     mm_ab<KS>(acc, P, Tpp, p);
-    store_strip_global(R_mp, acc, N, p);
+    store_strip_global_c8(R_mp, acc, N, p, xw);
   }
   VSM_STAMP(12);
   // ---- T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--) ---------------------------------------
   {
     sstrip tmm, acc;
-    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global(tmm, t_mm, N, p);
+    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global_c8(tmm, t_mm, N, p, xw);
     if (own_wave) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
@@ -423,7 +424,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     }
     acc.zero();
     mm_ab<KS>(acc, Q, tmm, p);
-    store_strip_global(T_mm, acc, N, p);
+    store_strip_global_c8(T_mm, acc, N, p, xw);
     if (laneA) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
@@ -480,7 +481,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   {
     sstrip acc1, acc2;
 #ifndef VSM_IA_KEEP_TPP
-    load_strip_global(Tpp, T_pp, N, p);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
+    load_strip_global_c8(Tpp, T_pp, N, p, xw);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
 #endif
     if (own_wave) {
 #pragma unroll
@@ -493,7 +494,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);   // (Rpm: strip of R+-, read back from its A-form before that was overwritten)
     store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
     __syncthreads();                      // everybody has read the old T++ / R+- strips from global; tmp complete
-    store_strip_global(T_pp, acc1, N, p);
+    store_strip_global_c8(T_pp, acc1, N, p, xw);
     if (laneA) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
@@ -512,11 +513,11 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
       dsym_strip(tmm, t_s, ns, p);
       dsym_strip(acc, r_s, ns, p);
     } else {
-      load_strip_global(tmm, t_mm, N, p);
-      load_strip_global(acc, r_pm, N, p);
+      load_strip_global_c8(tmm, t_mm, N, p, xw);
+      load_strip_global_c8(acc, r_pm, N, p, xw);
     }
     mm_ab<KS>(acc, Q, tmm, p);
-    store_strip_global(R_pm, acc, N, p);
+    store_strip_global_c8(R_pm, acc, N, p, xw);
   }
   VSM_STAMP(17);
 }
@@ -533,8 +534,8 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
     sm.vec[1][tid] = in ? a.j0_m[(long long)s * N + tid] : 0.0;
   }
   sstrip r_s, t_s;
-  load_strip_global(r_s, a.r_mp + s * a.mat_stride, N, p);
-  load_strip_global(t_s, a.t_pp + s * a.mat_stride, N, p);
+  load_strip_global_c8(r_s, a.r_mp + s * a.mat_stride, N, p, sm.xw[p.wave]);
+  load_strip_global_c8(t_s, a.t_pp + s * a.mat_stride, N, p, sm.xw[p.wave]);
   __syncthreads();
   ia_body<KS>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
               a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride);
@@ -557,13 +558,14 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
     const long long NN = (long long)N * N;
-    store_strip_global(c.R_mp + s * NN, r_s, N, p);
-    store_strip_global(c.T_pp + s * NN, t_s, N, p);
+    double* xw = sm.xw[p.wave];
+    store_strip_global_c8(c.R_mp + s * NN, r_s, N, p, xw);
+    store_strip_global_c8(c.T_pp + s * NN, t_s, N, p, xw);
     sstrip d;
     dsym_strip(d, r_s, ns, p);
-    store_strip_global(c.R_pm + s * NN, d, N, p);
+    store_strip_global_c8(c.R_pm + s * NN, d, N, p, xw);
     dsym_strip(d, t_s, ns, p);
-    store_strip_global(c.T_mm + s * NN, d, N, p);
+    store_strip_global_c8(c.T_mm + s * NN, d, N, p, xw);
     if (tid < N) {
       c.J0_p[(long long)s * N + tid] = sm.vec[0][tid];
       c.J0_m[(long long)s * N + tid] = sm.vec[1][tid];

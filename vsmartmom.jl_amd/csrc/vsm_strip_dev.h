@@ -25,6 +25,7 @@ struct ssmem {
   double vec[8][SNP];
   float red[2][4];
   gj_scratch<double, SNP> gj;
+  double xw[4][16 * 10];   // wave-private transposer tiles of load/store_strip_global_c8
 };
 
 // Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h), split into per-lane bases and compile-time
@@ -270,6 +271,66 @@ __device__ __forceinline__ void stage_aform(double* L, const double* __restrict_
   for (int j = p.wave; j < SNP; j += 4) {
     const double v = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
     L[lidx<SNP>(p.lane, j)] = v;
+  }
+}
+
+// Strip <-> global through a wave-private 16 x 8 tile of LDS (XS8 = 10 doubles per column: conflict-free).  The
+// direct versions above touch 16 columns x 32 B per instruction -- sixteen quarter-used cache lines that the next
+// instruction fetches from L2 again.  Here a lane moves 16 contiguous bytes of one column (one dwordx4; a wave covers
+// 16 columns x 64 B) and the permutation to the MFMA layout happens in LDS, in place in the strip's registers.
+// Wave-private, so no workgroup barrier: LDS operations of one wave complete in order.
+constexpr int XS8 = 10;
+struct d2_t {
+  double a, b;
+} __attribute__((aligned(8)));
+__device__ __forceinline__ void load_strip_global_c8(sstrip& x, const double* __restrict__ g, int N, const spos& p,
+                                                     double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  const double* src = g + (long long)N * min(col, N - 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 8 * j + 2 * q;
+    double a = 0.0, b = 0.0;
+    if (col < N && r + 1 < N) {
+      const d2_t t = *reinterpret_cast<const d2_t*>(src + r);
+      a = t.a;
+      b = t.b;
+    } else if (col < N && r < N) {
+      a = src[r];
+    }
+    x.v[j >> 1][2 * (j & 1)] = a;
+    x.v[j >> 1][2 * (j & 1) + 1] = b;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __builtin_amdgcn_wave_barrier();
+    xw[c * XS8 + 2 * q] = x.v[j >> 1][2 * (j & 1)];
+    xw[c * XS8 + 2 * q + 1] = x.v[j >> 1][2 * (j & 1) + 1];
+    __builtin_amdgcn_wave_barrier();
+    x.v[j >> 1][2 * (j & 1)] = xw[p.l15 * XS8 + p.kq];
+    x.v[j >> 1][2 * (j & 1) + 1] = xw[p.l15 * XS8 + p.kq + 4];
+  }
+}
+__device__ __forceinline__ void store_strip_global_c8(double* __restrict__ g, const sstrip& x, int N, const spos& p,
+                                                      double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  double* dst = g + (long long)N * min(col, N - 1);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __builtin_amdgcn_wave_barrier();
+    xw[p.l15 * XS8 + p.kq] = x.v[j >> 1][2 * (j & 1)];
+    xw[p.l15 * XS8 + p.kq + 4] = x.v[j >> 1][2 * (j & 1) + 1];
+    __builtin_amdgcn_wave_barrier();
+    d2_t t;
+    t.a = xw[c * XS8 + 2 * q];
+    t.b = xw[c * XS8 + 2 * q + 1];
+    const int r = 8 * j + 2 * q;
+    if (col < N && r + 1 < N)
+      *reinterpret_cast<d2_t*>(dst + r) = t;
+    else if (col < N && r < N)
+      dst[r] = t.a;
   }
 }
 

@@ -108,9 +108,6 @@ __device__ __forceinline__ void stage_aform_full2(double* L1, const double* __re
 // bytes of one column (full lines, 16-byte accesses) and the (row, lane) permutation to the MFMA layout happens in a
 // wave-private 16 x 32 tile of LDS -- wave-private, so no barrier (LDS operations of one wave complete in order).
 constexpr int XS = 34;   // column stride of the tile in doubles: 2 l15 + kq is conflict-free over a 32-lane pass
-struct d2_t {
-  double a, b;
-} __attribute__((aligned(8)));
 __device__ __forceinline__ void load_strip_global_c(sstrip& x, const double* __restrict__ g, int N, const spos& p,
                                                     double* __restrict__ xw) {
   const int c = p.lane >> 2, q = p.lane & 3;
