@@ -1063,30 +1063,65 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
   stage<T, NP, NW>(R1, r + n1 * NN, N);
   stage<T, NP, NW>(TTG, ttg + n1 * NN, N);
   acc_block<T, NP, NW> acc;
-  for (int dn = 0; dn < K; ++dn) {
-    const int n0 = n1 + shift[dn];
-    if (n0 < 0 || n0 >= S) continue;  // (uniform) out-of-band coupling: the blocks stay zero
+  // The inputs of the NEXT in-band line are fetched into registers while the current line is being computed (one
+  // workgroup per CU: nothing else hides the global round trips).
+  stage_regs<T, NP, NW> pf[7];
+  T pv[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0)};   // ieJ0+, ieJ0-, j1-[n0], j0+[n0], tmp1[n0], tmp2[n0], expk[n0]
+  auto next_line = [&](int from) {
+    int d = from;
+    while (d < K) {
+      const int n0 = n1 + shift[d];
+      if (n0 >= 0 && n0 < S) break;
+      ++d;
+    }
+    return d;
+  };
+  auto prefetch = [&](int d) {
+    if (d >= K) return;
+    const int n0 = n1 + shift[d];
+    const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
+    pf[0].load(ier + o4, N);
+    pf[1].load(iet + o4, N);
+    pf[2].load(r + n0 * NN, N);
+    pf[3].load(gt + n0 * NN, N);
+    pf[4].load(gr + n0 * NN, N);
+    pf[5].load(grt + n0 * NN, N);
+    pf[6].load(t + n0 * NN, N);
+    pv[6] = expk[n0];
+    if (tid < N) {
+      pv[0] = ieJp[o4v + tid];
+      pv[1] = ieJm[o4v + tid];
+      pv[2] = j1m[(long long)n0 * N + tid];
+      pv[3] = jp[(long long)n0 * N + tid];
+      pv[4] = tmp1[(long long)n0 * N + tid];
+      pv[5] = tmp2[(long long)n0 * N + tid];
+    }
+  };
+  int dn = next_line(0);
+  prefetch(dn);
+  for (; dn < K;) {
     const long long o4 = ((long long)n1 + (long long)S * dn) * NN, o4v = ((long long)n1 + (long long)S * dn) * N;
-    const T e0 = expk[n0];
     __syncthreads();  // previous line's readers of the buffers are done
-    stage<T, NP, NW>(IER, ier + o4, N);
-    stage<T, NP, NW>(IET, iet + o4, N);
-    stage<T, NP, NW>(R0, r + n0 * NN, N);
-    stage<T, NP, NW>(GT, gt + n0 * NN, N);
-    stage<T, NP, NW>(GR, gr + n0 * NN, N);
-    stage<T, NP, NW>(GRT, grt + n0 * NN, N);
-    stage<T, NP, NW>(T0, t + n0 * NN, N);
+    pf[0].store(IER);
+    pf[1].store(IET);
+    pf[2].store(R0);
+    pf[3].store(GT);
+    pf[4].store(GR);
+    pf[5].store(GRT);
+    pf[6].store(T0);
+    const T e0 = pv[6];
+    const T a_jp = pv[0], b_jm = pv[1], x_j1m = pv[2], x_jp = pv[3], x1 = pv[4], x2 = pv[5];
+    const int dn_next = next_line(dn + 1);
+    prefetch(dn_next);
     __syncthreads();
     if (tid < N) {
-      const T a = ieJp[o4v + tid], b = ieJm[o4v + tid];
-      vJp[tid] = a;
-      vJm[tid] = b;
-      vJ1m[tid] = b * e0;
-      IET[lidx<NP>(tid, cA)] = b * e0;
-      IET[lidx<NP>(tid, cB)] = a;
-      R0[lidx<NP>(tid, cA)] = j1m[(long long)n0 * N + tid];
-      R0[lidx<NP>(tid, cB)] = jp[(long long)n0 * N + tid];
-      const T x1 = tmp1[(long long)n0 * N + tid], x2 = tmp2[(long long)n0 * N + tid];
+      vJp[tid] = a_jp;
+      vJm[tid] = b_jm;
+      vJ1m[tid] = b_jm * e0;
+      IET[lidx<NP>(tid, cA)] = b_jm * e0;
+      IET[lidx<NP>(tid, cB)] = a_jp;
+      R0[lidx<NP>(tid, cA)] = x_j1m;
+      R0[lidx<NP>(tid, cB)] = x_jp;
       GT[lidx<NP>(tid, cA)] = x1;
       GR[lidx<NP>(tid, cA)] = x2;
       GRT[lidx<NP>(tid, cA)] = x2;
@@ -1163,6 +1198,7 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
     __syncthreads();
     lds_to_global<T, NP, NW>(iet + o4, X, N);
     lds_to_global<T, NP, NW>(ier + o4, WA, N);
+    dn = dn_next;
   }
 }
 
