@@ -696,3 +696,53 @@ def test_rt_run_fp32_strip_kernels(vsm, arch, pol, l_trunc):
     Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
     assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
     assert _rel(Rg, R64) < 1e-2 and _rel(Tg, T64) < 1e-2, (N, _rel(Rg, R64), _rel(Tg, T64))
+
+
+QUICKSTART_YAML = """
+# same scene as the reference's config/quickstart.yaml (one point, Stokes I, two layers, Lambertian 0.15, no absorption)
+radiative_transfer:
+  spec_bands: ["[12987.0]"]
+  surface: [LambertianSurfaceScalar(0.15)]
+  nstreams: 3
+  polarization_type: Stokes_I()
+  truncation: NoTruncation()
+  depol: -1
+  float_type: Float64
+  architecture: CPU()
+geometry: {sza: 60.0, vza: [60.0], vaz: [180.0], obs_alt: 1000.0}
+atmospheric_profile: {T: [250.0, 275.0], p: [100.0, 500.0, 1000.0], profile_reduction: -1}
+"""
+LAND_YAML = """
+# the shape of config/lambertian_land.yaml: IQUV, 11 streams, 9 viewing angles, two points, a 6-layer profile
+radiative_transfer:
+  spec_bands: ["[19417.0 19418.0]"]
+  surface: [LambertianSurfaceScalar(0.15)]
+  nstreams: 11
+  truncation: auto
+  polarization_type: Stokes_IQUV()
+  depol: -1
+  float_type: Float64
+  architecture: default_architecture
+geometry: {sza: 30, vza: [60, 45, 30, 15, 0, 15, 30, 45, 60], vaz: [180, 180, 180, 180, 0, 0, 0, 0, 0], obs_alt: 1000.0}
+atmospheric_profile: {T: [220.0, 230.0, 250.0, 265.0, 280.0, 287.0], p: [1.0, 50.0, 200.0, 400.0, 650.0, 850.0, 1000.0], profile_reduction: -1}
+"""
+
+
+@pytest.mark.parametrize("text,N", [(QUICKSTART_YAML, 3), (LAND_YAML, 60)])
+def test_rt_run_from_yaml(vsm, arch, text, N):
+    """parameters_from_yaml -> model_from_parameters -> rt_run(model), the reference's quickstart call sequence
+    (README.md:83-86), against the oracle on the same optical depths.  (GL-3 / GL-11 on [0,1] have the node 0.5 = cos 60 deg,
+    so the 60-degree angles of these scenes merge with a weighted stream: N = 3 and 15 x 4 = 60.)"""
+    io = vsm.io_yaml
+    params = io.parameters_from_yaml(text)
+    model = io.model_from_parameters(params, arch)
+    assert model.quad_points.Nquad * model.polarization_type.n == N
+    R, T = vsm.CoreRT.rt_run(model)
+    nS = len(params.spec_bands[0])
+    assert R.shape == (len(params.vza), model.polarization_type.n, nS)
+    om = O.build_model(params.polarization_type, params.l_trunc, params.sza, params.vza, params.vaz, model.tau_rayl,
+                       depol=0.0, albedo=params.albedo[0], m_max=2)
+    om.greek_rayleigh = O.GreekCoefs(**{k: np.asarray(getattr(model.greek_rayleigh, k)) for k in
+                                        ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")})
+    Ro, To = O.rt_run(om)
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9

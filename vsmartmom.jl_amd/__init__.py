@@ -21,6 +21,7 @@ from . import parallel  # noqa: F401
 from . import core_rt_lin as CoreRTLin  # noqa: F401
 from . import core_rt_raman as CoreRTRaman  # noqa: F401
 from . import raman_inputs  # noqa: F401
+from . import io_yaml  # noqa: F401
 from ._lib import VSMError, LIB_PATH  # noqa: F401
 
 __version__ = "0.1.0"

@@ -1,0 +1,149 @@
+"""YAML -> parameters -> RTModel for the Rayleigh + Lambertian subset of the reference's scene files.
+
+Host-side mirror of `parameters_from_yaml` (src/IO/Parameters.jl:1021-1075, the new `nstreams` schema :1102-1175) and of
+the parts of `model_from_parameters` (src/CoreRT/tools/model_from_parameters.jl:211-302) that such scenes exercise:
+quadrature from `nstreams`, profile fields / reduction, the depolarization rule (`depol < 0`: from the N2/O2 molecular
+constants), Bodhaine Rayleigh optical depth.  `config/quickstart.yaml` and `config/lambertian_land.yaml` of the reference
+are of this kind.  Blocks that need components outside this backend (absorption -> HITRAN tables, scattering -> Mie,
+non-Lambertian surfaces) raise NotImplementedError instead of being silently ignored.
+"""
+from __future__ import annotations
+
+import ast
+import operator
+import re
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import host_model as H
+from . import raman_inputs as RI
+
+
+@dataclass
+class vSmartMOM_Parameters:
+    spec_bands: List[np.ndarray]
+    albedo: List[float]
+    nstreams: int
+    polarization_type: str
+    depol: float
+    float_type: type
+    architecture: str
+    sza: float
+    vza: List[float]
+    vaz: List[float]
+    obs_alt: float
+    T: List[float]
+    p: List[float]
+    q: List[float]
+    profile_reduction_n: int = -1
+    l_trunc: int = field(init=False)
+    max_m: int = field(init=False)
+
+    def __post_init__(self):
+        if self.nstreams < 3:   # Parameters.jl:1131-1137
+            raise ValueError("radiative_transfer.nstreams = %d; must be >= 3 for solar/scattering scenes" % self.nstreams)
+        self.l_trunc = 2 * self.nstreams - 1    # stream_l_cap (Parameters.jl:1141-1156)
+        self.max_m = self.l_trunc + 1
+
+
+_OPS = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
+        ast.Pow: operator.pow, ast.USub: operator.neg, ast.UAdd: operator.pos}
+
+
+def _num(expr: str) -> float:
+    """Arithmetic on literals only (the scene files write e.g. `1e7/765`)."""
+    def ev(n):
+        if isinstance(n, ast.Constant) and isinstance(n.value, (int, float)):
+            return float(n.value)
+        if isinstance(n, ast.BinOp) and type(n.op) in _OPS:
+            return _OPS[type(n.op)](ev(n.left), ev(n.right))
+        if isinstance(n, ast.UnaryOp) and type(n.op) in _OPS:
+            return _OPS[type(n.op)](ev(n.operand))
+        raise ValueError("unsupported expression %r" % expr)
+    return ev(ast.parse(expr.strip().replace("^", "**"), mode="eval").body)
+
+
+def parse_spec_band(s: str) -> np.ndarray:
+    """`[a b c]` (Julia vector literal) or `start:step:stop` (Julia range, stop inclusive when hit)."""
+    s = str(s).strip()
+    if s.startswith("["):
+        return np.array([_num(x) for x in re.split(r"[\s,;]+", s.strip("[] ")) if x], dtype=np.float64)
+    parts = []
+    depth, cur = 0, ""
+    for ch in s:
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+        if ch == ":" and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    if len(parts) == 2:
+        a, st, b = _num(parts[0]), 1.0, _num(parts[1])
+    elif len(parts) == 3:
+        a, st, b = (_num(x) for x in parts)
+    else:
+        raise ValueError("cannot parse spec_band %r" % s)
+    n = int(np.floor((b - a) / st + 1e-12)) + 1
+    return a + st * np.arange(n)
+
+
+def _surface_albedo(s: str) -> float:
+    m = re.fullmatch(r"LambertianSurfaceScalar(?:\{\w+\})?\(([^)]*)\)", str(s).strip())
+    if not m:
+        raise NotImplementedError("surface %r: only LambertianSurfaceScalar is built in this backend" % s)
+    return _num(m.group(1))
+
+
+def parameters_from_dict(d: dict) -> vSmartMOM_Parameters:
+    for blk in ("absorption", "scattering"):
+        if d.get(blk):
+            raise NotImplementedError("the `%s` block needs components outside this backend (SURVEY 8 out of scope)" % blk)
+    rt, geo, atm = d["radiative_transfer"], d["geometry"], d["atmospheric_profile"]
+    if rt.get("quadrature_type") not in (None, "GaussLegQuad()", "GaussLegQuad"):
+        raise NotImplementedError("quadrature_type %r (GaussLegQuad only)" % rt.get("quadrature_type"))
+    pol = re.sub(r"[()\s]", "", str(rt["polarization_type"])).replace("Stokes_", "")
+    ft = {"Float64": np.float64, "Float32": np.float32}[str(rt.get("float_type", "Float64"))]
+    T = [float(x) for x in atm["T"]]
+    q = [float(x) for x in atm.get("q", [0.0] * len(T))]
+    return vSmartMOM_Parameters(
+        spec_bands=[parse_spec_band(b) for b in rt["spec_bands"]], albedo=[_surface_albedo(s) for s in rt["surface"]],
+        nstreams=int(rt.get("nstreams", 8)), polarization_type=pol, depol=float(rt["depol"]), float_type=ft,
+        architecture=str(rt.get("architecture", "default_architecture")), sza=float(geo["sza"]),
+        vza=[float(x) for x in geo["vza"]], vaz=[float(x) for x in geo["vaz"]], obs_alt=float(geo.get("obs_alt", 0.0)),
+        T=T, p=[float(x) for x in atm["p"]], q=q, profile_reduction_n=int(atm.get("profile_reduction", -1)))
+
+
+def parameters_from_yaml(path_or_text: str) -> vSmartMOM_Parameters:
+    import os
+    import yaml
+    if os.path.exists(path_or_text):
+        with open(path_or_text, encoding="utf-8") as f:
+            return parameters_from_dict(yaml.safe_load(f))
+    return parameters_from_dict(yaml.safe_load(path_or_text))
+
+
+def model_from_parameters(params: vSmartMOM_Parameters, architecture, iBand: int = 1) -> H.RTModel:
+    """One band (rt_run(model) of this backend runs one band per call, like the reference's iBand = 1 default)."""
+    nu = params.spec_bands[iBand - 1]
+    prof = RI.compute_atmos_profile_fields(params.T, params.p, params.q)
+    if params.profile_reduction_n != -1:
+        prof = RI.reduce_profile(params.profile_reduction_n, prof)
+    nu_m = 0.5 * (nu[0] + nu[-1])
+    if params.depol < 0:
+        n2, o2 = RI.get_raman_atmo_constants(nu_m, 300.0)
+        g = RI.compute_gamma_air_rayleigh(n2, o2)
+        depol = 2 * g / (1 + g)
+    else:
+        depol = params.depol
+    tau_rayl = RI.rayleigh_layer_optical_depth(prof.p_half[-1], 1e4 / nu, depol, prof.vcd_dry)
+    # Fourier bound: Rayleigh declares m <= 2, Lambertian and the solar beam 0; the stream cap 2 nstreams - 1 >= 5 never
+    # binds (component_m_max.jl:72-131)
+    return H.model_from_arrays(architecture, params.polarization_type, params.l_trunc, params.sza, params.vza, params.vaz,
+                               tau_rayl, depol=depol, albedo=params.albedo[iBand - 1], m_max=2,
+                               float_type=params.float_type)
