@@ -1017,11 +1017,32 @@ __global__ __launch_bounds__(64 * NW) void k_inv_one_minus_ab(int N, const T* __
 // ---------------------------------------------------------------------------
 template <typename T>
 struct rdsmem {
-  T B[16][32 * 32];
+  T B[9][32 * 32];
   T v[12][32];
 };
+// element-wise visit of the accumulator tiles: f(value, row, col)
+template <typename T, int NP, int NW, typename F>
+__device__ __forceinline__ void acc_visit(const acc_block<T, NP, NW>& acc, F f) {
+  using C = fcfg<NP, NW>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
+#pragma unroll
+  for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f(acc.v[a][b][r], r0 + 16 * a + mfma<T>::crow(lane, r), c0 + 16 * b);
+}
+// One workgroup per recipient point n1, all Raman lines of it in a loop (doubling_inelastic.jl:56-131 per line):
+//   X   = ier r0 + r1 ier                         W1 = iet + X gt0        WA = ier + X gr0        W3 = WA t0 + r1 iet
+//   iet' = ttg1 W1 + iet gt0                      ier' = ier + iet grt0 + ttg1 W3
+// with the six source mat-vecs riding in the spare columns N, N+1 of the right operands.  Nine 32 x 32 LDS images
+// (72 KB: TWO workgroups per CU -- the kernel is latency-bound: ten barriers around 32 x 32 x 24 products): inputs that
+// are only right operands give their image to the intermediate that replaces them (r0 -> X -> iet', gt0 -> W1, gr0 -> WA,
+// grt0 -> W3, t0 -> ier'), addend-only intermediates (r1 iet, iet gt0, iet grt0) stay in accumulator registers, and the
+// next in-band line's inputs are fetched into registers while the current line is computed.
 template <typename T>
-__global__ __launch_bounds__(256) void k_raman_doubling_lines(
+__global__ __launch_bounds__(256, 2) void k_raman_doubling_lines(
     int N, int S, int K, const int* __restrict__ shift, const T* __restrict__ r, const T* __restrict__ t,
     const T* __restrict__ ttg, const T* __restrict__ gt, const T* __restrict__ gr, const T* __restrict__ grt,
     const T* __restrict__ jp, const T* __restrict__ j1m, const T* __restrict__ tmp1, const T* __restrict__ tmp2,
@@ -1033,21 +1054,13 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
   T* TTG = sm.B[1];
   T* IER = sm.B[2];
   T* IET = sm.B[3];    // + columns N, N+1: iej1- , iej0+
-  T* R0 = sm.B[4];     // + columns N, N+1: j1-[n0], j0+[n0]
-  T* GT = sm.B[5];     // + column N: tmp1[n0]
-  T* GR = sm.B[6];     // + column N: tmp2[n0]
-  T* GRT = sm.B[7];    // + column N: tmp2[n0]
-  T* T0 = sm.B[8];
-  T* X = sm.B[9];
-  T* W1 = sm.B[10];    // iet + X gt0 (+ column N: a3)
-  T* W3 = sm.B[11];    // (ier + X gr0) t0 + r1 iet (+ column N: a4)
-  T* IETGT = sm.B[12];
-  T* IETGRT = sm.B[13];
-  T* R1IET = sm.B[14];
-  T* WA = sm.B[15];    // ier + X gr0
+  T* R0X = sm.B[4];    // r0 (+ columns N, N+1: j1-[n0], j0+[n0]) -> X -> image of iet'
+  T* GTW1 = sm.B[5];   // gt0 (+ column N: tmp1[n0]) -> W1 (+ column N: a3)
+  T* GRWA = sm.B[6];   // gr0 (+ column N: tmp2[n0]) -> WA
+  T* GRTW3 = sm.B[7];  // grt0 (+ column N: tmp2[n0]) -> W3 (+ column N: a4)
+  T* T0O = sm.B[8];    // t0 -> image of ier'
   T* v1 = sm.v[0];     // ier j1-
   T* v2 = sm.v[1];     // ier j0+
-  T* v3 = sm.v[2];     // X tmp1
   T* v4 = sm.v[3];     // X tmp2
   T* v5 = sm.v[4];     // iet tmp1
   T* v6 = sm.v[5];     // iet tmp2
@@ -1062,9 +1075,6 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
   const int cA = N, cB = N + 1;  // spare columns (N <= 30)
   stage<T, NP, NW>(R1, r + n1 * NN, N);
   stage<T, NP, NW>(TTG, ttg + n1 * NN, N);
-  acc_block<T, NP, NW> acc;
-  // The inputs of the NEXT in-band line are fetched into registers while the current line is being computed (one
-  // workgroup per CU: nothing else hides the global round trips).
   stage_regs<T, NP, NW> pf[7];
   T pv[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0)};   // ieJ0+, ieJ0-, j1-[n0], j0+[n0], tmp1[n0], tmp2[n0], expk[n0]
   auto next_line = [&](int from) {
@@ -1101,14 +1111,14 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
   prefetch(dn);
   for (; dn < K;) {
     const long long o4 = ((long long)n1 + (long long)S * dn) * NN, o4v = ((long long)n1 + (long long)S * dn) * N;
-    __syncthreads();  // previous line's readers of the buffers are done
+    __syncthreads();  // previous line's readers of the images are done
     pf[0].store(IER);
     pf[1].store(IET);
-    pf[2].store(R0);
-    pf[3].store(GT);
-    pf[4].store(GR);
-    pf[5].store(GRT);
-    pf[6].store(T0);
+    pf[2].store(R0X);
+    pf[3].store(GTW1);
+    pf[4].store(GRWA);
+    pf[5].store(GRTW3);
+    pf[6].store(T0O);
     const T e0 = pv[6];
     const T a_jp = pv[0], b_jm = pv[1], x_j1m = pv[2], x_jp = pv[3], x1 = pv[4], x2 = pv[5];
     const int dn_next = next_line(dn + 1);
@@ -1120,84 +1130,98 @@ __global__ __launch_bounds__(256) void k_raman_doubling_lines(
       vJ1m[tid] = b_jm * e0;
       IET[lidx<NP>(tid, cA)] = b_jm * e0;
       IET[lidx<NP>(tid, cB)] = a_jp;
-      R0[lidx<NP>(tid, cA)] = x_j1m;
-      R0[lidx<NP>(tid, cB)] = x_jp;
-      GT[lidx<NP>(tid, cA)] = x1;
-      GR[lidx<NP>(tid, cA)] = x2;
-      GRT[lidx<NP>(tid, cA)] = x2;
+      R0X[lidx<NP>(tid, cA)] = x_j1m;
+      R0X[lidx<NP>(tid, cB)] = x_jp;
+      GTW1[lidx<NP>(tid, cA)] = x1;
+      GRWA[lidx<NP>(tid, cA)] = x2;
+      GRTW3[lidx<NP>(tid, cA)] = x2;
     }
     __syncthreads();
-    // X = ier r0 + r1 ier  (+ v1 = ier j1-, v2 = ier j0+) ;  r1 iet (+ v7 = r1 iej1-, v8 = r1 iej0+)
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, IER, R0, Kend);
-    acc_store<T, NP, NW>(X, acc, [=](T a, int rr, int c, T) {
-      if (c == cA) v1[rr] = a;
-      if (c == cB) v2[rr] = a;
-      return a;
-    });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, R1, IET, Kend);
-    acc_store<T, NP, NW>(R1IET, acc, [=](T a, int rr, int c, T) {
+    // X = ier r0 + r1 ier  (+ v1 = ier j1-, v2 = ier j0+) ;  r1 iet stays in registers (+ v7 = r1 iej1-, v8 = r1 iej0+)
+    acc_block<T, NP, NW> accX, accR1IET;
+    accX.zero();
+    mm_ll<T, NP, NW>(accX, IER, R0X, Kend);
+    mm_ll<T, NP, NW>(accX, R1, IER, Kend);       // (ier's image is zero in the columns >= N: the riders are untouched)
+    accR1IET.zero();
+    mm_ll<T, NP, NW>(accR1IET, R1, IET, Kend);
+    acc_visit<T, NP, NW>(accR1IET, [=](T a, int rr, int c) {
       if (c == cA) v7[rr] = a;
       if (c == cB) v8[rr] = a;
-      return a;
     });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, R1, IER, Kend);
-    __syncthreads();  // X (first half) stored by every wave
-    acc_store<T, NP, NW>(X, acc, [=](T a, int, int c, T old) { return (c < N) ? old + a : T(0); });
+    __syncthreads();  // r0, and iet / ier as right operands, have been read by every wave
+    acc_store<T, NP, NW>(R0X, accX, [=](T a, int rr, int c, T) {
+      if (c == cA) v1[rr] = a;
+      if (c == cB) v2[rr] = a;
+      return (c < N) ? a : T(0);
+    });
     __syncthreads();
     // X gt0 (+ v3), X gr0 (+ v4), iet gt0 (+ v5), iet grt0 (+ v6)
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, X, GT, Kend);
-    acc_store<T, NP, NW>(W1, acc, [=](T a, int rr, int c, T) {
-      if (c == cA) v3[rr] = a;
+    acc_block<T, NP, NW> accW1, accWA, accIETGT, accIETGRT;
+    accW1.zero();
+    mm_ll<T, NP, NW>(accW1, R0X, GTW1, Kend);
+    accWA.zero();
+    mm_ll<T, NP, NW>(accWA, R0X, GRWA, Kend);
+    accIETGT.zero();
+    mm_ll<T, NP, NW>(accIETGT, IET, GTW1, Kend);
+    accIETGRT.zero();
+    mm_ll<T, NP, NW>(accIETGRT, IET, GRTW3, Kend);
+    __syncthreads();  // X, gt0, gr0, grt0 have been read by every wave
+    // W1 = iet + X gt0, its column N = a3 = iej0+ + r1 iej1- + ier j1- + X tmp1 ;  WA = ier + X gr0
+    acc_store<T, NP, NW>(GTW1, accW1, [=](T a, int rr, int c, T) {
+      if (c == cA) return (rr < N) ? vJp[rr] + v7[rr] + v1[rr] + a : T(0);   // (rows >= N of the vectors are never written)
       return (c < N) ? a + IET[lidx<NP>(rr, c)] : T(0);
     });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, X, GR, Kend);
-    acc_store<T, NP, NW>(WA, acc, [=](T a, int rr, int c, T) {
+    acc_store<T, NP, NW>(GRWA, accWA, [=](T a, int rr, int c, T) {
       if (c == cA) v4[rr] = a;
       return (c < N) ? a + IER[lidx<NP>(rr, c)] : T(0);
     });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, IET, GT, Kend);
-    acc_store<T, NP, NW>(IETGT, acc, [=](T a, int rr, int c, T) {
+    acc_visit<T, NP, NW>(accIETGT, [=](T a, int rr, int c) {
       if (c == cA) v5[rr] = a;
-      return a;
     });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, IET, GRT, Kend);
-    acc_store<T, NP, NW>(IETGRT, acc, [=](T a, int rr, int c, T) {
+    acc_visit<T, NP, NW>(accIETGRT, [=](T a, int rr, int c) {
       if (c == cA) v6[rr] = a;
-      return a;
     });
     __syncthreads();
-    // a3 = iej0+ + r1 iej1- + ier j1- + X tmp1 -> column N of W1 ;  W3 = (ier + X gr0) t0 + r1 iet
-    if (tid < N) W1[lidx<NP>(tid, cA)] = vJp[tid] + v7[tid] + v1[tid] + v3[tid];
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, WA, T0, Kend);
-    acc_store<T, NP, NW>(W3, acc, [=](T a, int rr, int c, T) { return (c < N) ? a + R1IET[lidx<NP>(rr, c)] : T(0); });
+    // W3 = WA t0 + r1 iet, its column N = a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2   (grt0's image is free)
+    {
+      acc_block<T, NP, NW> acc;
+      acc.zero();
+      mm_ll<T, NP, NW>(acc, GRWA, T0O, Kend);
+      acc.v[0][0] += accR1IET.v[0][0];
+      acc_store<T, NP, NW>(GRTW3, acc, [=](T a, int rr, int c, T) {
+        if (c == cA) return (rr < N) ? vJ1m[rr] + v2[rr] + v8[rr] + v4[rr] : T(0);
+        return (c < N) ? a : T(0);
+      });
+    }
     __syncthreads();
-    // a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2 -> column N of W3
-    if (tid < N) W3[lidx<NP>(tid, cA)] = vJ1m[tid] + v2[tid] + v8[tid] + v4[tid];
+    // iet' = ttg1 W1 + iet gt0 (+ ieJ0+' from column N) ;  ier' = ier + iet grt0 + ttg1 W3 (+ ieJ0-')
+    {
+      acc_block<T, NP, NW> acc;
+      acc.zero();
+      mm_ll<T, NP, NW>(acc, TTG, GTW1, Kend);
+      const acc_block<T, NP, NW> add = accIETGT;
+      int q = 0;
+      acc_store<T, NP, NW>(R0X, acc, [&](T a, int rr, int c, T) {   // X is dead: image of iet'
+        const T g = add.v[0][0][q++];
+        if (c == cA && rr < N) ieJp[o4v + rr] = vJp[rr] * e0 + a + v5[rr];
+        return a + g;
+      });
+    }
+    {
+      acc_block<T, NP, NW> acc;
+      acc.zero();
+      mm_ll<T, NP, NW>(acc, TTG, GRTW3, Kend);
+      const acc_block<T, NP, NW> add = accIETGRT;
+      int q = 0;
+      acc_store<T, NP, NW>(T0O, acc, [&](T a, int rr, int c, T) {   // t0 is dead: image of ier'
+        const T g = add.v[0][0][q++];
+        if (c == cA && rr < N) ieJm[o4v + rr] = vJm[rr] + a + v6[rr];
+        return a + IER[lidx<NP>(rr, c)] + g;
+      });
+    }
     __syncthreads();
-    // tmp5 = ttg1 W1 + iet gt0 (+ tmp3 from column N) ;  tmp6 = ier + iet grt0 + ttg1 W3 (+ tmp4)
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, TTG, W1, Kend);
-    acc_store<T, NP, NW>(X, acc, [=](T a, int rr, int c, T) {   // X is free: reuse as the output image of tmp5
-      if (c == cA && rr < N) ieJp[o4v + rr] = vJp[rr] * e0 + a + v5[rr];
-      return a + IETGT[lidx<NP>(rr, c)];
-    });
-    acc.zero();
-    mm_ll<T, NP, NW>(acc, TTG, W3, Kend);
-    acc_store<T, NP, NW>(WA, acc, [=](T a, int rr, int c, T) {  // WA is free: output image of tmp6
-      if (c == cA && rr < N) ieJm[o4v + rr] = vJm[rr] + a + v6[rr];
-      return a + IER[lidx<NP>(rr, c)] + IETGRT[lidx<NP>(rr, c)];
-    });
-    __syncthreads();
-    lds_to_global<T, NP, NW>(iet + o4, X, N);
-    lds_to_global<T, NP, NW>(ier + o4, WA, N);
+    lds_to_global<T, NP, NW>(iet + o4, R0X, N);
+    lds_to_global<T, NP, NW>(ier + o4, T0O, N);
     dn = dn_next;
   }
 }
