@@ -746,3 +746,25 @@ def test_rt_run_from_yaml(vsm, arch, text, N):
                                         ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")})
     Ro, To = O.rt_run(om)
     assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9
+
+
+def test_edge_cases_empty_batch_singleton_and_size_limits(vsm, arch):
+    """Empty batches are a no-op (the reference's batched operators accept size-0 third dimensions), a singleton batch
+    takes the same path as any other (`cpu_batched.jl:72-76` special-cases it), sizes above the on-chip limit fail loudly."""
+    CR = vsm.CoreRT
+    conv = vsm.Architectures.array_type(arch)
+    rng = np.random.default_rng(5)
+    for S in (0, 1):
+        A, B = rng.standard_normal((S, 7, 7)), rng.standard_normal((S, 7, 7))
+        C = vsm.Architectures.to_host(CR.batched_mul(conv(A), conv(B)))
+        assert C.shape == (S, 7, 7)
+        if S:
+            assert _rel(C, B @ A) < 1e-13   # layout tensors hold the transposes (column-major [M,K,S] batches)
+    X = np.eye(5)[None] * 2.0
+    tX = conv(X.copy())
+    out = torch.empty_like(tX)
+    CR.batch_inv_(out, tX)
+    assert _rel(vsm.Architectures.to_host(out), np.eye(5)[None] / 2.0) < 1e-14
+    big = conv(np.tile(np.eye(129)[None], (2, 1, 1)))
+    with pytest.raises(vsm.VSMError):
+        CR.batch_inv_(torch.empty_like(big), big)

@@ -243,19 +243,23 @@ int vsm_fused_max_n(int elem_size) { return elem_size == 8 ? fused_max_n<double>
 // ---- batched_mul / batch_inv! -------------------------------------------------
 int vsm_batched_mul_f64(int M, int Nc, int K, int S, const double* A, long long sa, const double* B, long long sb,
                         double* C, void* stream) {
+  if (S == 0 && M > 0 && Nc > 0 && K > 0) return VSM_OK;   // empty batch: nothing to do (pointers may be null)
   VSM_REQUIRE(M > 0 && Nc > 0 && K > 0 && S >= 0 && A && B && C, "batched_mul: bad argument");
   return gemm<double>(M, Nc, K, S, A, sa, B, sb, C, (long long)M * Nc, 1.0, nullptr, 0, 0.0, 0.0, as_stream(stream));
 }
 int vsm_batched_mul_f32(int M, int Nc, int K, int S, const float* A, long long sa, const float* B, long long sb,
                         float* C, void* stream) {
+  if (S == 0 && M > 0 && Nc > 0 && K > 0) return VSM_OK;   // empty batch: nothing to do (pointers may be null)
   VSM_REQUIRE(M > 0 && Nc > 0 && K > 0 && S >= 0 && A && B && C, "batched_mul: bad argument");
   return gemm<float>(M, Nc, K, S, A, sa, B, sb, C, (long long)M * Nc, 1.f, nullptr, 0, 0.f, 0.f, as_stream(stream));
 }
 int vsm_batch_inv_f64(int N, int S, const double* A, double* X, int* info, void* stream) {
+  if (S == 0 && N > 0) return VSM_OK;
   VSM_REQUIRE(N > 0 && S >= 0 && A && X, "batch_inv: bad argument");
   return batch_inv<double>(N, S, A, X, info, as_stream(stream));
 }
 int vsm_batch_inv_f32(int N, int S, const float* A, float* X, int* info, void* stream) {
+  if (S == 0 && N > 0) return VSM_OK;
   VSM_REQUIRE(N > 0 && S >= 0 && A && X, "batch_inv: bad argument");
   return batch_inv<float>(N, S, A, X, info, as_stream(stream));
 }
