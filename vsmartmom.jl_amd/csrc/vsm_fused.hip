@@ -1226,6 +1226,164 @@ __global__ __launch_bounds__(256, 2) void k_raman_doubling_lines(
   }
 }
 
+// element-wise load of an N x N global block into the accumulator layout (addend-only operands)
+template <typename T, int NP, int NW>
+__device__ __forceinline__ void acc_load_global(acc_block<T, NP, NW>& acc, const T* __restrict__ g, int N) {
+  using C = fcfg<NP, NW>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r0 = 16 * ((wave / C::WC) * C::TMR), c0 = 16 * ((wave % C::WC) * C::TMC) + (lane & 15);
+#pragma unroll
+  for (int a = 0; a < C::TMR; ++a)
+#pragma unroll
+    for (int b = 0; b < C::TMC; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + 16 * a + mfma<T>::crow(lane, r), col = c0 + 16 * b;
+        acc.v[a][b][r] = (row < N && col < N) ? g[row + (long long)N * col] : T(0);
+      }
+}
+// One pass of interaction_helper!(::RRS, ::ScatteringInterface_11) (interaction_inelastic.jl:319-521) for every line of
+// one recipient point (see rs_ia_pass in vsm_internal.h for the operand roles):
+//   W1 = L1 E0[n0] + L2 I1 ;  Y = TI W1 + YA ;  W3 = L1 E3[n0] + L2 I3
+//   OUTA = ACCA + TI W3 + Y GX[n0] ;  OUTB = TI I4 + Y GY[n0]
+//   V1 = L1 VE0[n0] + L2 VI1 + VADD ;  VOUT = VACC + TI V1 + Y VV[n0]        (riding in spare column N)
+// Same scheme as k_raman_doubling_lines: nine 32 x 32 images (two workgroups per CU), dead right operands give their
+// image to the intermediate that replaces them (E0 -> W1, I1 -> Y, E3 -> W3, I3 -> OUTA, I4 -> OUTB, L1 -> GY), the next
+// line's operands are prefetched into registers.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_raman_interaction_lines(int N, int S, int K, const int* __restrict__ shift,
+                                                                    rs_ia_pass<T> h) {
+  constexpr int NP = 32, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  rdsmem<T>& sm = *reinterpret_cast<rdsmem<T>*>(smem_raw);
+  T* L2 = sm.B[0];
+  T* TI = sm.B[1];
+  T* L1GY = sm.B[2];   // L1 -> GY
+  T* E0W1 = sm.B[3];   // E0 (+ column N: VE0[n0]) -> W1 (+ column N: V1)
+  T* I1Y = sm.B[4];    // I1 (+ column N: VI1) -> Y
+  T* E3W3 = sm.B[5];   // E3 -> W3
+  T* I3OA = sm.B[6];   // I3 -> image of OUTA
+  T* GX = sm.B[7];     // (+ column N: VV[n0])
+  T* I4OB = sm.B[8];   // I4 -> image of OUTB
+  T* vadd = sm.v[0];
+  T* vacc = sm.v[1];
+  T* vt = sm.v[2];     // TI V1
+  const int n1 = blockIdx.x, tid = threadIdx.x;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const long long NN = (long long)N * N;
+  const int cA = N;
+  stage<T, NP, NW>(L2, h.L2 + n1 * h.sL2, N);
+  stage<T, NP, NW>(TI, h.TI + n1 * NN, N);
+  stage_regs<T, NP, NW> pf[8];   // L1, E0, I1, E3, I3, GX, I4, GY
+  acc_block<T, NP, NW> pYA, pACC;
+  T pv[5] = {T(0), T(0), T(0), T(0), T(0)};   // VE0[n0], VI1, VV[n0], VADD, VACC
+  auto next_line = [&](int from) {
+    int d = from;
+    while (d < K) {
+      const int n0 = n1 + shift[d];
+      if (n0 >= 0 && n0 < S) break;
+      ++d;
+    }
+    return d;
+  };
+  auto prefetch = [&](int d) {
+    if (d >= K) return;
+    const int n0 = n1 + shift[d];
+    const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
+    pf[0].load(h.L1 + o4, N);
+    pf[1].load(h.E0 + n0 * h.sE0, N);
+    pf[2].load(h.I1 + o4, N);
+    pf[3].load(h.E3 + n0 * h.sE3, N);
+    pf[4].load(h.I3 + o4, N);
+    pf[5].load(h.GX + n0 * NN, N);
+    pf[6].load(h.I4 + o4, N);
+    pf[7].load(h.GY + n0 * NN, N);
+    acc_load_global<T, NP, NW>(pYA, h.YA + o4, N);
+    acc_load_global<T, NP, NW>(pACC, h.ACCA + o4, N);
+    if (tid < N) {
+      pv[0] = h.VE0[(long long)n0 * N + tid];
+      pv[1] = h.VI1[o4v + tid];
+      pv[2] = h.VV[(long long)n0 * N + tid];
+      pv[3] = h.VADD[o4v + tid];
+      pv[4] = h.VACC[o4v + tid];
+    }
+  };
+  int dn = next_line(0);
+  prefetch(dn);
+  for (; dn < K;) {
+    const long long o4 = ((long long)n1 + (long long)S * dn) * NN, o4v = ((long long)n1 + (long long)S * dn) * N;
+    __syncthreads();  // previous line's readers of the images are done
+    pf[0].store(L1GY);
+    pf[1].store(E0W1);
+    pf[2].store(I1Y);
+    pf[3].store(E3W3);
+    pf[4].store(I3OA);
+    pf[5].store(GX);
+    pf[6].store(I4OB);
+    const stage_regs<T, NP, NW> gy = pf[7];   // stored into L1's image once L1 is dead
+    const acc_block<T, NP, NW> aYA = pYA, aACC = pACC;
+    const T x_ve0 = pv[0], x_vi1 = pv[1], x_vv = pv[2], x_vadd = pv[3], x_vacc = pv[4];
+    const int dn_next = next_line(dn + 1);
+    prefetch(dn_next);
+    __syncthreads();
+    if (tid < N) {
+      E0W1[lidx<NP>(tid, cA)] = x_ve0;
+      I1Y[lidx<NP>(tid, cA)] = x_vi1;
+      GX[lidx<NP>(tid, cA)] = x_vv;
+      vadd[tid] = x_vadd;
+      vacc[tid] = x_vacc;
+    }
+    __syncthreads();
+    acc_block<T, NP, NW> accW1, accW3;
+    accW1.zero();
+    mm_ll<T, NP, NW>(accW1, L1GY, E0W1, Kend);   // (+ L1 VE0)
+    mm_ll<T, NP, NW>(accW1, L2, I1Y, Kend);      // (+ L2 VI1)
+    accW3.zero();
+    mm_ll<T, NP, NW>(accW3, L1GY, E3W3, Kend);
+    mm_ll<T, NP, NW>(accW3, L2, I3OA, Kend);
+    __syncthreads();  // L1, E0, I1, E3, I3 have been read by every wave
+    acc_store<T, NP, NW>(E0W1, accW1, [=](T a, int rr, int c, T) {
+      if (c == cA) return (rr < N) ? a + vadd[rr] : T(0);   // V1
+      return (c < N) ? a : T(0);
+    });
+    acc_store<T, NP, NW>(E3W3, accW3, [=](T a, int, int c, T) { return (c < N) ? a : T(0); });
+    gy.store(L1GY);
+    __syncthreads();
+    acc_block<T, NP, NW> accA, accB;
+    {
+      acc_block<T, NP, NW> accY;
+      accY.zero();
+      mm_ll<T, NP, NW>(accY, TI, E0W1, Kend);    // TI W1 (+ TI V1)
+      accA.zero();
+      mm_ll<T, NP, NW>(accA, TI, E3W3, Kend);    // TI W3
+      accB.zero();
+      mm_ll<T, NP, NW>(accB, TI, I4OB, Kend);    // TI I4
+      int q = 0;
+      acc_store<T, NP, NW>(I1Y, accY, [&](T a, int rr, int c, T) {   // I1 is dead since the barrier above
+        const T ya = aYA.v[0][0][q++];
+        if (c == cA) vt[rr] = a;
+        return (c < N) ? a + ya : T(0);
+      });
+    }
+    __syncthreads();  // Y complete; W1, W3, I4 have been read
+    mm_ll<T, NP, NW>(accA, I1Y, GX, Kend);       // + Y GX (+ Y VV)
+    mm_ll<T, NP, NW>(accB, I1Y, L1GY, Kend);     // + Y GY
+    {
+      int q = 0;
+      acc_store<T, NP, NW>(I3OA, accA, [&](T a, int rr, int c, T) {   // I3 is dead: image of OUTA
+        const T g = aACC.v[0][0][q++];
+        if (c == cA && rr < N) h.VOUT[o4v + rr] = vacc[rr] + vt[rr] + a;
+        return a + g;
+      });
+    }
+    acc_store<T, NP, NW>(I4OB, accB, [=](T a, int, int, T) { return a; });   // I4 is dead: image of OUTB
+    __syncthreads();
+    lds_to_global<T, NP, NW>(h.OUTA + o4, I3OA, N);
+    lds_to_global<T, NP, NW>(h.OUTB + o4, I4OB, N);
+    dn = dn_next;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
@@ -1395,6 +1553,20 @@ int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, cons
   return VSM_OK;
 }
 
+template <typename T>
+int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st) {
+  if (S <= 0 || K <= 0) return VSM_OK;
+  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_IA_FUSION") != nullptr;
+  if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
+  auto kern = k_raman_interaction_lines<T>;
+  const size_t bytes = sizeof(rdsmem<T>);
+  static int prepared = enable_lds(kern, bytes);
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, S, K, shift, h);
+  VSM_LAUNCH_CHECK("k_raman_interaction_lines");
+  return VSM_OK;
+}
+
 #define VSM_INST_F(T)                                                                                               \
   template int fused_elemental_doubling<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*,  \
                                            const T*, const T*, long long, const added<T>&, hipStream_t);           \
@@ -1403,6 +1575,7 @@ int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, cons
   template int raman_doubling_lines<T>(int, int, int, const int*, const T*, const T*, const T*, const T*, const T*, \
                                        const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*,  \
                                        hipStream_t);                                                                \
+  template int raman_interaction_lines<T>(int, int, int, const int*, const rs_ia_pass<T>&, hipStream_t);            \
   template int test_lds_mm<T>(int, int, const T*, const T*, T*, hipStream_t);                                       \
   template int test_lds_inv<T>(int, int, const T*, T*, int, int*, hipStream_t);
 VSM_INST_F(double)

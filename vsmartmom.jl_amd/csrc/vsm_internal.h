@@ -115,6 +115,20 @@ inline int inv_one_minus(int N, int S, const T* A, long long sa, const T* B, lon
   return batch_inv<T>(N, S, tmp, X, nullptr, st);
 }
 // Raman: inelastic part of one doubling step for all lines, LDS-resident (N <= 30; else VSM_ERR_UNSUPPORTED)
+// One pass (G1/T01 or G2/T21) of the inelastic ScatteringInterface_11 interaction, all lines of a recipient point in one
+// workgroup (vsm_fused.hip: k_raman_interaction_lines).  "4d": inelastic arrays [N,N,S,K] / [N,S,K] at (n1, line);
+// "n0" / "n1": elastic arrays at the donor / recipient point.
+template <typename T>
+struct rs_ia_pass {
+  const T *L1 /*4d, left*/, *E0 /*n0*/, *L2 /*n1, left*/, *I1 /*4d*/, *TI /*n1, left*/, *YA /*4d addend*/;
+  const T *E3 /*n0*/, *I3 /*4d*/, *ACCA /*4d addend*/, *GX /*n0*/, *I4 /*4d*/, *GY /*n0*/;
+  long long sE0, sL2, sE3;          // strides over the spectral axis of elastic operands that may be shared (0)
+  T *OUTA, *OUTB;                   // 4d
+  const T *VE0 /*n0*/, *VADD /*4d*/, *VI1 /*4d*/, *VACC /*4d*/, *VV /*n0*/;
+  T* VOUT;                          // 4d
+};
+template <typename T>
+int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st);
 template <typename T>
 int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
                          const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,

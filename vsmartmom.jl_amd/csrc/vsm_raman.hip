@@ -448,6 +448,18 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   G3(N, N, N, S, G, NN, a.r_mp, as, tM, NN, one, nul, 0, zero, zero);
   G3(N, N, N, S, tM, NN, c.T_pp, NN, gA, NN, one, nul, 0, zero, zero);
   G3(N, N, N, S, G, NN, a.t_mm, as, gB, NN, one, nul, 0, zero, zero);
+  bool fused1 = false;
+  {
+    rs_ia_pass<T> h{};
+    h.L1 = aie.ier_mp; h.E0 = c.R_pm; h.sE0 = NN; h.L2 = a.r_mp; h.sL2 = as; h.I1 = cie.ieR_pm; h.TI = Tinv; h.YA = cie.ieT_mm;
+    h.E3 = c.T_pp; h.sE3 = NN; h.I3 = cie.ieT_pp; h.ACCA = cie.ieR_mp; h.GX = gA; h.I4 = aie.iet_mm; h.GY = gB;
+    h.OUTA = cie.ieR_mp; h.OUTB = cie.ieT_mm;
+    h.VE0 = c.J0_p; h.VADD = aie.ieJ0_m; h.VI1 = cie.ieJ0_p; h.VACC = cie.ieJ0_m; h.VV = v; h.VOUT = cie.ieJ0_m;
+    rc = raman_interaction_lines<T>(N, S, K, shift, h, st);   // every line of a recipient point in one workgroup (N <= 30)
+    if (rc == VSM_OK) fused1 = true;
+    else if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
+  if (!fused1) {
   // Y = T01[n1] (ier R+-[n0] + r[n1] ieR+-) + ieT--   -> W2
   G4(N, N, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.R_pm, NN), W1, none);
   G4(N, N, at_n1<T>(a.r_mp, as), at_4d<T>(cie.ieR_pm, NN), W1, at_4d<T>(W1, NN));
@@ -465,6 +477,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   // ieT-- = T01[n1] iet-- + Y gB[n0]
   G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(aie.iet_mm, NN), W3, none);
   if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gB, NN), cie.ieT_mm, at_4d<T>(W3, NN), st, 1))) return rc;
+  }
   // ---- pass 2: G2 = (I - R+- r-+)^-1, T21 = t++ G2 ------------------------------------------------
   if ((rc = inv_one_minus<T>(N, S, c.R_pm, NN, a.r_mp, as, G, tM, st))) return rc;
   G3(N, N, N, S, a.t_pp, as, G, NN, Tinv, NN, one, nul, 0, zero, zero);
@@ -475,6 +488,18 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   G3(N, N, N, S, G, NN, c.T_pp, NN, gA, NN, one, nul, 0, zero, zero);
   G3(N, N, N, S, G, NN, c.R_pm, NN, tM2, NN, one, nul, 0, zero, zero);
   G3(N, N, N, S, tM2, NN, a.t_mm, as, gB, NN, one, nul, 0, zero, zero);
+  bool fused2 = false;
+  {
+    rs_ia_pass<T> h{};
+    h.L1 = cie.ieR_pm; h.E0 = a.r_mp; h.sE0 = as; h.L2 = c.R_pm; h.sL2 = NN; h.I1 = aie.ier_mp; h.TI = Tinv; h.YA = aie.iet_pp;
+    h.E3 = a.t_mm; h.sE3 = as; h.I3 = aie.iet_mm; h.ACCA = aie.ier_pm; h.GX = gB; h.I4 = cie.ieT_pp; h.GY = gA;
+    h.OUTA = cie.ieR_pm; h.OUTB = cie.ieT_pp;
+    h.VE0 = a.j0_m; h.VADD = cie.ieJ0_p; h.VI1 = aie.ieJ0_m; h.VACC = aie.ieJ0_p; h.VV = v; h.VOUT = cie.ieJ0_p;
+    rc = raman_interaction_lines<T>(N, S, K, shift, h, st);
+    if (rc == VSM_OK) fused2 = true;
+    else if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
+  if (!fused2) {
   // Y = T21[n1] (ieR+- r-+[n0] + R+-[n1] ier-+) + iet++   -> W2
   G4(N, N, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.r_mp, as), W1, none);
   G4(N, N, at_n1<T>(c.R_pm, NN), at_4d<T>(aie.ier_mp, NN), W1, at_4d<T>(W1, NN));
@@ -492,6 +517,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   // ieT++ = T21[n1] ieT++ + Y gA[n0]
   G4(N, N, at_n1<T>(Tinv, NN), at_4d<T>(cie.ieT_pp, NN), W3, none);
   if ((rc = gemm_rs<T>(N, N, N, S, K, shift, at_4d<T>(W2, NN), at_n0<T>(gA, NN), cie.ieT_pp, at_4d<T>(W3, NN), st, 1))) return rc;
+  }
   // ---- elastic part last (every inelastic right-hand side above used the pre-update composite) -----
   (void)elastic_work_elems;
   return interaction_generic<T>(VSM_IFACE_11, N, S, c, a, ework, st);
