@@ -357,7 +357,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   sstrip X;
   load_strip_global_c8(X, R_pm, N, p, xw);           // X = R+- strip
   store_strip(P, r_s, p, keepN);
-  stage_aform(Q, T_mm, N, p);
+  stage_aform_full(Q, T_mm, N, p);   // all 16 column loads in flight: one round trip instead of four
   __syncthreads();
   VSM_STAMP(8);
   if (own_wave) {  // J0+ rides in the spare column c1 of R+-_s:  E1[:, c1] = r-+ J0+
@@ -400,14 +400,14 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   __syncthreads();                        // [G1] (P) and [T--] (Q) no longer read
   store_strip(P, X, p, keepN);            // [T01 r-+] -> P
   store_strip(Q, A1, p, keepN);           // [T01] -> Q
-  __syncthreads();
-  VSM_STAMP(11);
-  // ---- R-+ += (T01 r-+) T++ ------------------------------------------------------------------------------
-  sstrip Tpp;                             // old T++ strip: kept in registers until T++ = T21 T++
+  // ---- R-+ += (T01 r-+) T++  (its global operands are requested before the barrier) --------------------------------
+  sstrip Tpp;                             // old T++ strip
   load_strip_global_c8(Tpp, T_pp, N, p, xw);
   {
     sstrip acc;
     load_strip_global_c8(acc, R_mp, N, p, xw);
+    __syncthreads();
+    VSM_STAMP(11);
     mm_ab<KS>(acc, P, Tpp, p);
     store_strip_global_c8(R_mp, acc, N, p, xw);
   }
@@ -438,7 +438,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   __syncthreads();                        // [T01 r-+] (P) and [T01] (Q) no longer read
   VSM_STAMP(13);
   // ---- G2 = (I - R+- r-+)^-1 = I + R+- H  (push-through identity, see vsm_fused.hip) ; z = J0+ + R+- j0- -----
-  stage_aform(P, R_pm, N, p);             // [R+-] -> P
+  stage_aform_full(P, R_pm, N, p);        // [R+-] -> P
   store_strip(Q, t_s, p, keepN);          // [t++] -> Q
   if (own_wave) {  // j0- rides in the spare column c2 of H
 #pragma unroll

@@ -334,5 +334,34 @@ __device__ __forceinline__ void store_strip_global_c8(double* __restrict__ g, co
   }
 }
 
+// global column-major N x N -> A-form in LDS with ALL loads in flight before the first LDS write (one wave per SIMD:
+// nothing else hides a round trip, and stage_aform's batches of four make four of them)
+__device__ __forceinline__ void stage_aform_full(double* L, const double* __restrict__ g, int N, const spos& p) {
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = p.wave + 4 * i;
+    v[i] = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) L[lidx<SNP>(p.lane, p.wave + 4 * i)] = v[i];
+}
+__device__ __forceinline__ void stage_aform_full2(double* L1, const double* __restrict__ g1, double* L2,
+                                                  const double* __restrict__ g2, int N, const spos& p) {
+  double v[16], w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = p.wave + 4 * i;
+    const bool ok = p.lane < N && j < N;
+    v[i] = ok ? g1[p.lane + (long long)N * j] : 0.0;
+    w[i] = ok ? g2[p.lane + (long long)N * j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    L1[lidx<SNP>(p.lane, p.wave + 4 * i)] = v[i];
+    L2[lidx<SNP>(p.lane, p.wave + 4 * i)] = w[i];
+  }
+}
+
 }  // namespace
 }  // namespace vsm
