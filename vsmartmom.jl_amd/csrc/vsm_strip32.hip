@@ -186,13 +186,21 @@ __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, c
 // global column-major N x N -> A-form in LDS (zero padded); 96 of the 384 threads' lanes... one column per wave and
 // pass: lanes 0..63 take rows 0..63, then rows 64..95
 __device__ __forceinline__ void stage_aform(float* L, const float* __restrict__ g, int N, const fpos& p) {
-  for (int j = p.wave; j < FNP; j += FNW) {
-    const float v0 = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0f;
-    L[lidx32(p.lane, j)] = v0;
-    if (p.lane < 32) {
-      const int i = 64 + p.lane;
-      L[lidx32(i, j)] = (i < N && j < N) ? g[i + (long long)N * j] : 0.0f;
-    }
+  // all column loads in flight before the first LDS write (one workgroup per CU: a round trip per column is exposed)
+  constexpr int NJ = FNP / FNW;
+  float v0[NJ], v1[NJ];
+#pragma unroll
+  for (int c = 0; c < NJ; ++c) {
+    const int j = p.wave + FNW * c;
+    v0[c] = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0f;
+    const int i = 64 + (p.lane & 31);
+    v1[c] = (p.lane < 32 && i < N && j < N) ? g[i + (long long)N * j] : 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < NJ; ++c) {
+    const int j = p.wave + FNW * c;
+    L[lidx32(p.lane, j)] = v0[c];
+    if (p.lane < 32) L[lidx32(64 + p.lane, j)] = v1[c];
   }
 }
 
