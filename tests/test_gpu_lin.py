@@ -31,7 +31,7 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def _layer(pol_name, l_trunc, FT, S=4, P=3, seed=1):
+def _layer(pol_name, l_trunc, FT, S=4, P=3, seed=1, thick=False):
     rng = np.random.default_rng(seed)
     pol = O.polarization(pol_name)
     qp = O.rt_set_streams_gausslegquad(l_trunc, 40.0, [30.0, 0.0], pol, FT)
@@ -39,6 +39,8 @@ def _layer(pol_name, l_trunc, FT, S=4, P=3, seed=1):
     mu = qp.qp_mu.astype(np.float64)
     tau = 0.02 + 0.1 * rng.random(S) + 10.0 ** rng.uniform(-3, 0, S)
     varpi = rng.uniform(0.2, 1.0, S)
+    if thick:   # strongly reflecting layers: ||r r|| large enough for the long series orders and the Gauss-Jordan fallback
+        tau, varpi = rng.uniform(1.5, 6.0, S), rng.uniform(0.99, 1.0, S)
     Zpp, Zmp = O.compute_Z_moments(pol, mu, O.get_greek_rayleigh(0.0279), 0)
     lin = OL.LayerOpticsLin(rng.standard_normal((S, P)) * tau[:, None], rng.standard_normal((S, P)) * 0.1,
                             0.3 * rng.standard_normal((P, S, N, N)), 0.3 * rng.standard_normal((P, S, N, N)))
@@ -61,10 +63,12 @@ def _al_host(vsm, al):
 
 @pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7),
                                               ("I", 71), ("IQU", 27), ("IQUV", 25), ("IQU", 33)])   # N = 38, 48, 60, 57: fused strip step
-@pytest.mark.parametrize("ndoubl", [0, 3])
+@pytest.mark.parametrize("ndoubl", [0, 3, -2])   # -2: two doublings of THICK layers (every inverse path of the fused step)
 def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl):
     FT = np.float64
-    pol, qp, N, tau, varpi, Zpp, Zmp, lin, rng = _layer(pol_name, l_trunc, FT)
+    thick = ndoubl < 0
+    ndoubl = abs(ndoubl)
+    pol, qp, N, tau, varpi, Zpp, Zmp, lin, rng = _layer(pol_name, l_trunc, FT, thick=thick)
     S, P_layer = len(tau), lin.tau_dot.shape[1]
     P = P_layer + 1
     dtau = (tau / 2 ** ndoubl).astype(FT)
