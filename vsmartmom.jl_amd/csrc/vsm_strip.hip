@@ -403,18 +403,17 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   // ---- R-+ += (T01 r-+) T++  (its global operands are requested before the barrier) --------------------------------
   sstrip Tpp;                             // old T++ strip
   load_strip_global_c8(Tpp, T_pp, N, p, xw);
+  double rpm_v[16];                       // columns of [R+-] for the second half
   {
-    sstrip acc;
-    load_strip_global_c8(acc, R_mp, N, p, xw);
+    // Both first-half results stay in their accumulators until the second half's global operand has been REQUESTED:
+    // loads and stores retire through one in-order counter, so a load issued after a store waits for the store.
+    sstrip accR, accT, tmm;
+    load_strip_global_c8(accR, R_mp, N, p, xw);
     __syncthreads();
     VSM_STAMP(11);
-    mm_ab<KS>(acc, P, Tpp, p);
-    store_strip_global_c8(R_mp, acc, N, p, xw);
-  }
-  VSM_STAMP(12);
-  // ---- T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--) ---------------------------------------
-  {
-    sstrip tmm, acc;
+    mm_ab<KS>(accR, P, Tpp, p);           // R-+ += (T01 r-+) T++
+    VSM_STAMP(12);
+    // T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--)
     if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global_c8(tmm, t_mm, N, p, xw);
     if (own_wave) {
 #pragma unroll
@@ -422,23 +421,30 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) tmm.v[ta][r] = laneA ? vu[p.row(ta, r)] : tmm.v[ta][r];
     }
-    acc.zero();
-    mm_ab<KS>(acc, Q, tmm, p);
-    store_strip_global_c8(T_mm, acc, N, p, xw);
+    accT.zero();
+    mm_ab<KS>(accT, Q, tmm, p);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = p.wave + 4 * i;
+      rpm_v[i] = (p.lane < N && j < N) ? R_pm[p.lane + (long long)N * j] : 0.0;
+    }
+    store_strip_global_c8(R_mp, accR, N, p, xw);
+    store_strip_global_c8(T_mm, accT, N, p, xw);
     if (laneA) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-          if (row < N) J0_m[row] = vJm[row] + acc.v[ta][r];
+          if (row < N) J0_m[row] = vJm[row] + accT.v[ta][r];
         }
     }
   }
   __syncthreads();                        // [T01 r-+] (P) and [T01] (Q) no longer read
   VSM_STAMP(13);
   // ---- G2 = (I - R+- r-+)^-1 = I + R+- H  (push-through identity, see vsm_fused.hip) ; z = J0+ + R+- j0- -----
-  stage_aform_full(P, R_pm, N, p);        // [R+-] -> P
+#pragma unroll
+  for (int i = 0; i < 16; ++i) P[lidx<SNP>(p.lane, p.wave + 4 * i)] = rpm_v[i];   // [R+-] -> P
   store_strip(Q, t_s, p, keepN);          // [t++] -> Q
   if (own_wave) {  // j0- rides in the spare column c2 of H
 #pragma unroll
@@ -493,7 +499,19 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     acc2.zero();
     mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);   // (Rpm: strip of R+-, read back from its A-form before that was overwritten)
     store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
+    // ---- R+- = r+- + tmp t-- ;  both results are stored at the very end: loads and stores retire through one in-order
+    // counter, so anything fetched after a store (here: the spilled strips of the added layer) would wait for it
+    sstrip tmm, acc;
+    if (ns) {
+      dsym_strip(tmm, t_s, ns, p);
+      dsym_strip(acc, r_s, ns, p);
+    } else {
+      load_strip_global_c8(tmm, t_mm, N, p, xw);
+      load_strip_global_c8(acc, r_pm, N, p, xw);
+    }
     __syncthreads();                      // everybody has read the old T++ / R+- strips from global; tmp complete
+    VSM_STAMP(16);
+    mm_ab<KS>(acc, Q, tmm, p);
     store_strip_global_c8(T_pp, acc1, N, p, xw);
     if (laneA) {
 #pragma unroll
@@ -504,19 +522,6 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
           if (row < N) J0_p[row] = vjp[row] + acc1.v[ta][r];
         }
     }
-  }
-  VSM_STAMP(16);
-  // ---- R+- = r+- + tmp t-- ---------------------------------------------------------------------------------------
-  {
-    sstrip tmm, acc;
-    if (ns) {
-      dsym_strip(tmm, t_s, ns, p);
-      dsym_strip(acc, r_s, ns, p);
-    } else {
-      load_strip_global_c8(tmm, t_mm, N, p, xw);
-      load_strip_global_c8(acc, r_pm, N, p, xw);
-    }
-    mm_ab<KS>(acc, Q, tmm, p);
     store_strip_global_c8(R_pm, acc, N, p, xw);
   }
   VSM_STAMP(17);
