@@ -416,6 +416,10 @@ int vsm_test_lds_mm_f32(int N, int S, const float* A, const float* B, float* C, 
 int vsm_test_lds_inv_f64(int N, int S, const double* A, double* X, int mode, int* path_out, void* stream);
 int vsm_test_lds_inv_f32(int N, int S, const float* A, float* X, int mode, int* path_out, void* stream);
 
+/* Fills the whole LDS of every CU with NaN bit patterns (the GPU tests call it before every test: no kernel may depend
+ * on what a previous workgroup left in LDS). */
+int vsm_test_poison_lds(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,7 @@ _SIGS = {
     "vsm_postprocess_vza_ie_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_test_lds_mm_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_test_lds_inv_{T}": (_I, [_I, _I, _P, _P, _I, _P, _P]),
+    "vsm_test_poison_lds": (_I, [_P]),
 }
 
 

@@ -434,6 +434,26 @@ int vsm_postprocess_vza_f32(int N, int n_stokes, int S, int nV, const int* row0_
 }
 
 // ---- diagnostics ----------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void k_poison_lds(int n64) {
+  extern __shared__ unsigned long long poison_smem[];
+  for (int i = threadIdx.x; i < n64; i += 256) poison_smem[i] = 0x7ff8dead7fc0beefULL;   // NaN as f64 and as 2 x f32
+  __syncthreads();
+  if (poison_smem[(threadIdx.x * 97) % n64] == 0) asm volatile("s_nop 0");   // keep the stores
+}
+}  // namespace
+int vsm_test_poison_lds(void* stream) {
+  const int bytes = 160 * 1024;
+  static int prepared = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_poison_lds)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), bytes, as_stream(stream), bytes / 8);
+  VSM_LAUNCH_CHECK("k_poison_lds");
+  return VSM_OK;
+}
 int vsm_test_lds_mm_f64(int N, int S, const double* A, const double* B, double* C, void* stream) {
   VSM_REQUIRE(N > 0 && A && B && C, "test_lds_mm: bad argument");
   return test_lds_mm<double>(N, S, A, B, C, as_stream(stream));
