@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    os.environ.setdefault("VSM_POISON_WORK", "1")   # host layer fills work buffers with NaN before handing them to the library
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 

@@ -146,6 +146,14 @@ def lib():
     return L
 
 
+def poison(t):
+    """Work buffers are handed to the library uninitialised; with VSM_POISON_WORK=1 (a test-run switch) they are filled
+    with NaN first, so that a kernel reading scratch it has not written shows up as NaN instead of stale data."""
+    if os.environ.get("VSM_POISON_WORK"):
+        t.fill_(float("nan"))
+    return t
+
+
 def check(rc):
     if rc != 0:
         raise VSMError("libvsmartmom_hip: status %d: %s" % (rc, lib().vsm_last_error().decode()))

@@ -252,7 +252,7 @@ def elemental_(pol, tau_sum, dtau, F0, props: DeviceLayerOptics, m, ndoubl, dq: 
 def doubling_(pol, expk: torch.Tensor, ndoubl: int, added: AddedLayer):
     """doubling! alone (doubling.jl:38-131), operator-for-operator."""
     n = _lib.lib().vsm_doubling_work_elems(added.N, added.nSpec)
-    work = torch.empty(max(int(n), 1), dtype=added.dtype, device=added.r_mp.device)
+    work = _lib.poison(torch.empty(max(int(n), 1), dtype=added.dtype, device=added.r_mp.device))
     a = added.cstruct()
     _lib.call("vsm_doubling", added.dtype, added.N, pol.n, added.nSpec, ndoubl, _ptr(expk), C.byref(a), _ptr(work),
               _stream_ptr())
@@ -284,7 +284,7 @@ def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLa
         work = _work_cache.get(key)
         if work is None:
             _work_cache.clear()
-            work = torch.empty(int(_lib.lib().vsm_interaction_work_elems(N, S)), dtype=comp.dtype, device=comp.R_mp.device)
+            work = _lib.poison(torch.empty(int(_lib.lib().vsm_interaction_work_elems(N, S)), dtype=comp.dtype, device=comp.R_mp.device))
             _work_cache[key] = work
     name = "vsm_interaction_oplevel" if oplevel else "vsm_interaction"
     _lib.call(name, comp.dtype, IFACE[scattering_interface], N, S, C.byref(c), C.byref(a), _ptr(work), _stream_ptr())

@@ -91,7 +91,7 @@ def _work(kind, n, dtype, device):
     key = (kind, dtype, str(device))
     w = _lin_work.get(key)
     if w is None or w.numel() < n:
-        w = torch.empty(int(n), dtype=dtype, device=device)
+        w = _lib.poison(torch.empty(int(n), dtype=dtype, device=device))
         _lin_work[key] = w
     return w
 

@@ -93,7 +93,7 @@ def _workbuf(name, elems, dtype, device):
     key = (name, str(device), dtype)
     w = _work.get(key)
     if w is None or w.numel() < elems:
-        w = torch.empty(max(int(elems), 1), dtype=dtype, device=device)
+        w = _lib.poison(torch.empty(max(int(elems), 1), dtype=dtype, device=device))
         _work[key] = w
     return w
 
