@@ -768,3 +768,15 @@ def test_edge_cases_empty_batch_singleton_and_size_limits(vsm, arch):
     big = conv(np.tile(np.eye(129)[None], (2, 1, 1)))
     with pytest.raises(vsm.VSMError):
         CR.batch_inv_(torch.empty_like(big), big)
+
+
+def test_scene_run_graph_replay_is_identical(vsm, arch):
+    """Scene.run_graph(): the launch sequence of a scene captured into a HIP graph and replayed gives the same bits."""
+    params = vsm.io_yaml.parameters_from_yaml(QUICKSTART_YAML)
+    model = vsm.io_yaml.model_from_parameters(params, arch)
+    scene = vsm.CoreRT.prepare_scene(model)
+    ref = [x.clone() for x in scene.run()]
+    for _ in range(2):
+        out = scene.run_graph()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))

@@ -30,12 +30,22 @@ def run(name, pol, l_trunc, S, L, FT, vza=(30.0,), reps=20):
         scene.run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    ref = [x.clone() for x in scene.run()]
+    scene.run_graph()
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    for _ in range(reps):
+        out = scene.run_graph()
+    torch.cuda.synchronize()
+    dt_graph = (time.perf_counter() - tg) / reps
+    same = all(torch.equal(a, b) for a, b in zip(ref, out))
     t1 = time.perf_counter()
     for _ in range(5):
         vsm.CoreRT.rt_run(model)
     dt_full = (time.perf_counter() - t1) / 5
-    print("%-28s N=%3d S=%5d L=%2d %s: device pass %.2f ms -> %.3g points/s ; full rt_run(model) incl. host optics + H2D %.2f ms -> %.3g points/s"
-          % (name, N, S, L, FT.__name__, 1e3 * dt, S / dt, 1e3 * dt_full, S / dt_full))
+    print("%-28s N=%3d S=%5d L=%2d %s: device pass %.2f ms -> %.3g points/s ; HIP-graph replay %.2f ms -> %.3g points/s (bit-identical: %s) ; "
+          "full rt_run(model) incl. host optics + H2D %.2f ms -> %.3g points/s"
+          % (name, N, S, L, FT.__name__, 1e3 * dt, S / dt, 1e3 * dt_graph, S / dt_graph, same, 1e3 * dt_full, S / dt_full))
 
 
 if __name__ == "__main__":

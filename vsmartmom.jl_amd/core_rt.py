@@ -444,6 +444,20 @@ class Scene:
                                 self.T_SFI)
         return self.R_SFI, self.T_SFI
 
+    def run_graph(self):
+        """`run()` replayed from a HIP graph: the launch sequence of a scene (per moment: one launch per layer, surface,
+        interaction, post-processing) is captured once and replayed -- for launch-bound scenes (few spectral points,
+        small N) the replay removes the per-launch host cost; the results are the same device tensors as `run()`."""
+        if getattr(self, "_graph", None) is None:
+            self.run()                      # warm-up outside the capture: lazy initialisation inside the library
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.run()
+            self._graph = g
+        self._graph.replay()
+        return self.R_SFI, self.T_SFI
+
     def results_host(self):
         """(R_SFI, T_SFI) as the reference returns them: [nVZA, nStokes, nSpec] numpy arrays."""
         return to_host(self.R_SFI).transpose(2, 1, 0).copy(), to_host(self.T_SFI).transpose(2, 1, 0).copy()
