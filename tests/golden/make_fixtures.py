@@ -16,6 +16,8 @@ Sources (all under /root/reference/test/):
   benchmarks/6SV1_R_trues.jl                                   6SV1 reflectances, 6 cases
   reference/phase1b_RRS_sanghavi_q0.jld2                       rotational-Raman regression arrays R, T, ieR, ieT
   test_parameters/Phase1b_RRS_761-764nm.yaml                   the scene of that regression (profile, geometry)
+and one data table from src/ that the Cox-Munk oracle needs:
+  src/CoreRT/Surfaces/water_refraction.jl                      Segelstein (1981) water refractive index table
 
 The procedure each fixture is used with (geometry, tolerances) is recorded in
 the fixture's "procedure" field with the reference file:line it restates.
@@ -294,10 +296,21 @@ def raman_phase1b():
     return "phase1b_rrs_sanghavi_q0.json", fx
 
 
+def water_table():
+    """The three literal columns of src/CoreRT/Surfaces/water_refraction.jl:15-57 (published Segelstein 1981 values)."""
+    with open(os.path.join(REF, "src/CoreRT/Surfaces/water_refraction.jl"), encoding="utf-8") as f:
+        text = _strip_comments(f.read())
+    fx = dict(source="src/CoreRT/Surfaces/water_refraction.jl:15-57 (Segelstein 1981)",
+              wavelength_nm=_vector(text, "_WATER_RI_TABLE_NM"), n_real=_vector(text, "_WATER_N_REAL"),
+              k_imag=_vector(text, "_WATER_K_IMAG"))
+    assert len(fx["wavelength_nm"]) == len(fx["n_real"]) == len(fx["k_imag"]) == 92
+    return "segelstein1981_water.json", fx
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at %s (fixtures are committed; nothing to do)" % REF)
-    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector, raman_phase1b):
+    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector, raman_phase1b, water_table):
         name, fx = fn()
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(fx, f, indent=1)
