@@ -286,6 +286,54 @@ int vsm_postprocess_vza_lin_f64(int N, int n_stokes, int S, int nV, int P, const
 int vsm_postprocess_vza_lin_f32(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const float* w_h,
                                 const float* Jdot0_m, const float* Jdot0_p, float* Rdot, float* Tdot, void* stream);
 
+/* ---- BRDF surfaces: Cox-Munk ocean + the generic BRDF surface layer ------------------------------------------
+ * CoxMunkSurface{FT} (src/CoreRT/types.jl:525-536); n_water is the complex index the reference's call sites use
+ * (`_get_n_water(surf, 550)`, coxmunk_surface.jl:434-444: the Segelstein table at 550 nm unless the surface carries one). */
+typedef struct vsm_coxmunk_f64 {
+  double wind_speed, n_water_re, n_water_im, whitecap_albedo;
+  int include_whitecaps, shadowing;
+} vsm_coxmunk_f64;
+typedef struct vsm_coxmunk_f32 {
+  float wind_speed, n_water_re, n_water_im, whitecap_albedo;
+  int include_whitecaps, shadowing;
+} vsm_coxmunk_f32;
+/* reflectance(surf, pol, qp_mu, m) and reflectance_and_deriv (coxmunk_surface.jl:381-460): the Fourier moment m of the
+ * BRDF Mueller matrix over the streams of `q` (node k = q->mu[k*n_stokes]) and, if drho_dU != NULL, of its derivative
+ * with respect to wind speed: rho[N,N] column-major, rho[(i n+a) + N (j n+b)] = ff/pi sum_phi w M_ab(mu_i, mu_j, phi) az_ab(m phi),
+ * ff = 1 (m = 0) | 2.  phi/wphi (device, nphi <= 128) are the azimuth quadrature on [0, pi] the host hands over (the
+ * reference: 100-point Gauss-Legendre, CanopyOptics.gauleg). */
+int vsm_coxmunk_reflectance_f64(const vsm_coxmunk_f64* surf, const vsm_quad_f64* q, int m, int nphi, const double* phi,
+                                const double* wphi, double* rho, double* drho_dU, void* stream);
+int vsm_coxmunk_reflectance_f32(const vsm_coxmunk_f32* surf, const vsm_quad_f32* q, int m, int nphi, const float* phi,
+                                const float* wphi, float* rho, float* drho_dU, void* stream);
+/* create_surface_layer!(brdf::AbstractSurfaceType, ...) (src/CoreRT/Surfaces/rpv_surface.jl:51-97) from a Fourier
+ * reflectance block rho[N,N] = reflectance(brdf, pol, qp_mu, m): r-+ = f rho diag(mu w) (f = 2 for m = 0, else 1), r+- = 0,
+ * t++ = t-- = I, j0+ = I0_N exp(-tau_sum/mu0), j0- = mu0 (f rho I0_N) exp(-tau_sum/mu0).  Shared block (mat_stride 0). */
+int vsm_brdf_surface_f64(const vsm_quad_f64* q, int S, int m, const double* rho, const double* tau_sum,
+                         const vsm_added_f64* added, void* stream);
+int vsm_brdf_surface_f32(const vsm_quad_f32* q, int S, int m, const float* rho, const float* tau_sum,
+                         const vsm_added_f32* added, void* stream);
+/* create_surface_layer!(::noRS, ::CoxMunkSurface, added, added_lin, iparam, ...) (coxmunk_surface_lin.jl:27-102): the same
+ * with the surface-parameter derivative block drho[N,N] in slot iparam, the beam-attenuation derivatives in the first
+ * p_layer slots, F0 [n_stokes,S] instead of I0, and the linearized builder's quirks (j0+ = 0, t-- = 0). */
+int vsm_brdf_surface_lin_f64(const vsm_quad_f64* q, int S, int m, const double* rho, const double* drho, int iparam,
+                             const double* tau_sum, const double* tau_sum_dot, int p_layer, const double* F0,
+                             const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, void* stream);
+int vsm_brdf_surface_lin_f32(const vsm_quad_f32* q, int S, int m, const float* rho, const float* drho, int iparam,
+                             const float* tau_sum, const float* tau_sum_dot, int p_layer, const float* F0,
+                             const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, void* stream);
+/* apply_ss_correction! (TMS; coxmunk_surface.jl:481-569, called at rt_run.jl:520-524):
+ *   coef[v + nV k] = M_exact[k,1](mu_v, mu0, dphi_v) - sum_{m<=m_max} w_m az_k1(m dphi_v) c_m[k,1](mu_v, mu0)
+ *   R_SFI[v,k,s]  += mu0 exp(-tau_total[s]/mu0) coef[v + nV k]
+ * mu_v_h / dphi_h: host arrays [nV] (cos of the viewing zenith, relative azimuth in radians); coef: device [nV*n_stokes]
+ * (output); R_SFI [nV,n_stokes,S] may be NULL (coefficients only). */
+int vsm_coxmunk_ss_correction_f64(const vsm_coxmunk_f64* surf, int n_stokes, int S, int nV, const double* mu_v_h,
+                                  const double* dphi_h, double mu0, int m_max, int nphi, const double* phi,
+                                  const double* wphi, const double* tau_total, double* coef, double* R_SFI, void* stream);
+int vsm_coxmunk_ss_correction_f32(const vsm_coxmunk_f32* surf, int n_stokes, int S, int nV, const float* mu_v_h,
+                                  const float* dphi_h, float mu0, int m_max, int nphi, const float* phi, const float* wphi,
+                                  const float* tau_total, float* coef, float* R_SFI, void* stream);
+
 /* rt_kernel!(::noRS) for ONE scattering layer (src/CoreRT/CoreKernel/rt_kernel.jl:175-250): elemental! + doubling!
  * followed by copy_added_to_composite! (toa != 0, i.e. iz == 1; rt_helpers.jl:188-200) or
  * interaction!(::ScatteringInterface_11) (interaction.jl:207-266).  Arguments as vsm_elemental_doubling_*.

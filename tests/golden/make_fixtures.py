@@ -18,6 +18,8 @@ Sources (all under /root/reference/test/):
   test_parameters/Phase1b_RRS_761-764nm.yaml                   the scene of that regression (profile, geometry)
 and one data table from src/ that the Cox-Munk oracle needs:
   src/CoreRT/Surfaces/water_refraction.jl                      Segelstein (1981) water refractive index table
+and the parsed parameters of one shipped scene file:
+  config/ocean_coxmunk.yaml                                    BASELINE config C3 (Cox-Munk ocean, 33 layers, IQUV)
 
 The procedure each fixture is used with (geometry, tolerances) is recorded in
 the fixture's "procedure" field with the reference file:line it restates.
@@ -307,10 +309,21 @@ def water_table():
     return "segelstein1981_water.json", fx
 
 
+def ocean_coxmunk_scene():
+    """BASELINE config C3: the scene parameters of config/ocean_coxmunk.yaml (parsed values: band, surface constructor,
+    streams, geometry, 33-layer profile) -- the input the linearized Cox-Munk parity test runs on."""
+    import yaml
+    with open(os.path.join(REF, "config/ocean_coxmunk.yaml"), encoding="utf-8") as f:
+        d = yaml.safe_load(f)
+    d["source"] = "config/ocean_coxmunk.yaml (parsed with yaml.safe_load)"
+    assert len(d["atmospheric_profile"]["T"]) == 33 and len(d["atmospheric_profile"]["p"]) == 34
+    return "ocean_coxmunk_scene.json", d
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference tree not found at %s (fixtures are committed; nothing to do)" % REF)
-    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector, raman_phase1b, water_table):
+    for fn in (siewert, natraj, sixsv, solar_scalar, solar_vector, raman_phase1b, water_table, ocean_coxmunk_scene):
         name, fx = fn()
         with open(os.path.join(OUT, name), "w") as f:
             json.dump(fx, f, indent=1)

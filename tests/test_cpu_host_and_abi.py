@@ -294,8 +294,15 @@ atmospheric_profile: {T: [250.0, 275.0], p: [100.0, 500.0, 1000.0]}
     assert m.tau_rayl.shape == (1, 2) and abs(m.tau_rayl[0, 1] / m.tau_rayl[0, 0] - 500.0 / 400.0) < 1e-12
     assert m.quad_points.Nquad == 3 and m.quad_points.Nstreams == 3      # cos 60 deg IS the middle GL-3 node
     assert 0.0244 < m.tau_rayl.sum() < 0.0245   # Bodhaine 1999 at 770 nm x 1000/1013.25 hPa
+    pc = io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", '"CoxMunkSurface(wind_speed=5.0, shadowing=false)"'))
+    mc = io.model_from_parameters(pc, None)
+    assert mc.surface == V.host_model.CoxMunkSurface(5.0, None, 0.22, True, False) and mc.m_max == 5   # user_l_cap = 2*3 - 1
+    assert io.parse_surface("CoxMunkSurface(3.5)").wind_speed == 3.5
+    assert io.parse_surface("CoxMunkSurface(wind_speed=4, n_water=1.34+0.01im)").n_water == complex(1.34, 0.01)
     with pytest.raises(NotImplementedError):
-        io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", "CoxMunkSurface(wind_speed=5.0)"))
+        io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", '"rpvSurfaceScalar(0.1, 0.2, 0.3, 0.4)"'))
+    with pytest.raises(ValueError):
+        io.parse_surface("CoxMunkSurface(n_water=1.33)")
     with pytest.raises(NotImplementedError):
         io.parameters_from_yaml(text + "absorption: {molecules: [[O2]]}\n")
     with pytest.raises(ValueError):

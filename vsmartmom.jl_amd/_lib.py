@@ -59,6 +59,16 @@ class vsm_composite_rs(C.Structure):
                 ("ieJ0_p", C.c_void_p), ("ieJ0_m", C.c_void_p), ("K", C.c_int), ("reserved", C.c_int)]
 
 
+class vsm_coxmunk_f64(C.Structure):
+    _fields_ = [("wind_speed", C.c_double), ("n_water_re", C.c_double), ("n_water_im", C.c_double),
+                ("whitecap_albedo", C.c_double), ("include_whitecaps", C.c_int), ("shadowing", C.c_int)]
+
+
+class vsm_coxmunk_f32(C.Structure):
+    _fields_ = [("wind_speed", C.c_float), ("n_water_re", C.c_float), ("n_water_im", C.c_float),
+                ("whitecap_albedo", C.c_float), ("include_whitecaps", C.c_int), ("shadowing", C.c_int)]
+
+
 class vsm_rrs(C.Structure):
     _fields_ = [("shift", C.c_void_p), ("varpi_ie", C.c_void_p), ("fscatt", C.c_void_p), ("Zpp", C.c_void_p),
                 ("Zmp", C.c_void_p)]
@@ -90,6 +100,10 @@ _SIGS = {
     "vsm_interaction_oplevel_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "vsm_lambertian_surface_{T}": (_I, [_P, _I, _I, "{R}", _P, _P, _P]),
     "vsm_postprocess_vza_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_coxmunk_reflectance_{T}": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "vsm_brdf_surface_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "vsm_brdf_surface_lin_{T}": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "vsm_coxmunk_ss_correction_{T}": (_I, [_P, _I, _I, _I, _P, _P, "{R}", _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_doubling_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_interaction_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_elemental_lin_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _P]),

@@ -6,7 +6,8 @@ Mirrors (names follow the reference; Julia's trailing `!` becomes `_`):
   make_added_layer, make_composite_layer        tools/rt_helper_functions.jl:130-151,259-270
   elemental_, doubling_, interaction_           CoreKernel/elemental.jl, doubling.jl, interaction.jl
   rt_kernel_                                    CoreKernel/rt_kernel.jl:175-250
-  create_surface_layer_, postprocessing_vza_    Surfaces/lambertian_surface.jl:41-95, tools/postprocessing_vza.jl
+  create_surface_layer_, postprocessing_vza_    Surfaces/lambertian_surface.jl:41-95, rpv_surface.jl:51-97, tools/postprocessing_vza.jl
+  reflectance, apply_ss_correction_             Surfaces/coxmunk_surface.jl:381-460, 481-569
   rt_run                                        rt_run.jl:238-539 (noRS, SFI, Lambertian)
 
 Device arrays are torch tensors (plumbing only: allocation, streams, H2D/D2H).
@@ -38,6 +39,12 @@ def _require_gpu(arch):
                             "(no CPU fallback by design)" % (arch,))
     if not torch.cuda.is_available():
         raise _lib.VSMError("no MI355X visible to HIP (torch.cuda.is_available() is False)")
+    # One process drives ONE GPU: kernels are launched on the current device's stream and the library keeps its scratch
+    # and kernel attributes per process, so data on any other device would be touched from the wrong GPU.
+    if arch.device_index != torch.cuda.current_device():
+        raise _lib.VSMError("architecture GPU(%d) is not the current HIP device (%d): one process per GPU -- call "
+                            "torch.cuda.set_device(%d) first" % (arch.device_index, torch.cuda.current_device(),
+                                                                 arch.device_index))
 
 
 def _torch_dtype(FT):
@@ -290,14 +297,78 @@ def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLa
     _lib.call(name, comp.dtype, IFACE[scattering_interface], N, S, C.byref(c), C.byref(a), _ptr(work), _stream_ptr())
 
 
-def create_surface_layer_(albedo: float, added_surface: AddedLayer, m: int, dq: DeviceQuad, tau_sum: torch.Tensor):
-    """create_surface_layer!(::LambertianSurfaceScalar) (lambertian_surface.jl:41-95)."""
+_phi_cache = {}
+
+
+def brdf_azimuth_quadrature(arch, FT):
+    """The azimuth nodes / weights of reflectance(): 100-point Gauss-Legendre on [0, pi] (coxmunk_surface.jl:394-395,
+    CanopyOptics.gauleg), as device vectors."""
+    key = (str(devi(arch)), np.dtype(FT).str)
+    if key not in _phi_cache:
+        phi, w = H.gauleg(H.NQUAD_PHI_BRDF, 0.0, math.pi)
+        conv = array_type(arch)
+        _phi_cache[key] = (conv(phi.astype(FT)), conv(w.astype(FT)))
+    return _phi_cache[key]
+
+
+def _coxmunk_cstruct(surf: H.CoxMunkSurface, dtype):
+    nw = H.get_n_water(surf)
+    cls = _lib.vsm_coxmunk_f64 if dtype == torch.float64 else _lib.vsm_coxmunk_f32
+    return cls(float(surf.wind_speed), nw.real, nw.imag, float(surf.whitecap_albedo), int(bool(surf.include_whitecaps)),
+               int(bool(surf.shadowing)))
+
+
+def reflectance(surf: H.CoxMunkSurface, dq: DeviceQuad, m: int, arch, FT, deriv: bool = False):
+    """reflectance(surf, pol_type, qp_mu, m) / reflectance_and_deriv (coxmunk_surface.jl:381-460) on the device.
+    Returns layout tensors (N, N) [column-major rho[N,N]]; drho/dU is None unless deriv."""
+    N = int(dq.mu.numel())
+    rho = torch.empty((N, N), dtype=dq.dtype, device=dq.mu.device)
+    drho = torch.empty_like(rho) if deriv else None
+    phi, w = brdf_azimuth_quadrature(arch, FT)
+    cs, q = _coxmunk_cstruct(surf, dq.dtype), dq.cstruct()
+    _lib.call("vsm_coxmunk_reflectance", dq.dtype, C.byref(cs), C.byref(q), m, int(phi.numel()), _ptr(phi), _ptr(w), _ptr(rho),
+              _ptr(drho), _stream_ptr())
+    return rho, drho
+
+
+def create_surface_layer_(surface, added_surface: AddedLayer, m: int, dq: DeviceQuad, tau_sum: torch.Tensor, rho=None,
+                          arch=None, FT=None):
+    """create_surface_layer!: LambertianSurfaceScalar (lambertian_surface.jl:41-95; `surface` may be the bare albedo) or a
+    BRDF surface through its Fourier reflectance block (rpv_surface.jl:51-97; CoxMunkSurface: coxmunk_surface.jl:381-460).
+    `rho` = a precomputed reflectance(surface, pol, qp_mu, m) block (Scene caches one per moment)."""
     if not added_surface.shared:
         raise _lib.VSMError("surface AddedLayer must be allocated with shared=True")
     q, a = dq.cstruct(), added_surface.cstruct()
-    alb = C.c_double(albedo) if added_surface.dtype == torch.float64 else C.c_float(albedo)
-    _lib.call("vsm_lambertian_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, alb, _ptr(tau_sum),
-              C.byref(a), _stream_ptr())
+    if isinstance(surface, H.LambertianSurfaceScalar):
+        surface = surface.albedo
+    if isinstance(surface, (int, float)):
+        alb = C.c_double(surface) if added_surface.dtype == torch.float64 else C.c_float(surface)
+        _lib.call("vsm_lambertian_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, alb, _ptr(tau_sum),
+                  C.byref(a), _stream_ptr())
+        return
+    if isinstance(surface, H.CoxMunkSurface):
+        if rho is None:
+            rho, _ = reflectance(surface, dq, m, arch, FT)
+        _lib.call("vsm_brdf_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, _ptr(rho), _ptr(tau_sum),
+                  C.byref(a), _stream_ptr())
+        return
+    raise _lib.VSMError("surface %r is not built in this backend (LambertianSurfaceScalar, CoxMunkSurface)" % (surface,))
+
+
+def apply_ss_correction_(R_SFI: torch.Tensor, surf: H.CoxMunkSurface, pol, vza, vaz, mu0, tau_total: torch.Tensor, m_max: int,
+                         arch, FT):
+    """apply_ss_correction! (coxmunk_surface.jl:481-545; rt_run.jl:520-524): R_SFI (S, n, nV) layout tensor, in place.
+    Returns the per-geometry coefficients [nV, n] (device (n, nV) layout tensor) for inspection."""
+    nV, S = len(vza), int(R_SFI.shape[0])
+    ctype = C.c_double if R_SFI.dtype == torch.float64 else C.c_float
+    mu_v = (ctype * nV)(*[float(FT(H.cosd(v))) for v in vza])
+    dph = (ctype * nV)(*[float(FT(math.radians(float(a)))) for a in vaz])
+    coef = torch.empty((pol.n, nV), dtype=R_SFI.dtype, device=R_SFI.device)
+    phi, w = brdf_azimuth_quadrature(arch, FT)
+    cs = _coxmunk_cstruct(surf, R_SFI.dtype)
+    _lib.call("vsm_coxmunk_ss_correction", R_SFI.dtype, C.byref(cs), pol.n, S, nV, mu_v, dph, ctype(float(mu0)), int(m_max),
+              int(phi.numel()), _ptr(phi), _ptr(w), _ptr(tau_total), _ptr(coef), _ptr(R_SFI), _stream_ptr())
+    return coef
 
 
 def postprocessing_vza_(pol: H.PolarizationType, comp: CompositeLayer, vza, vaz, qp: H.QuadPoints, m: int, weight: float,
@@ -372,6 +443,7 @@ class Scene:
         self.model, self.arch, self.FT = model, arch, FT
         pol, qp = model.polarization_type, model.quad_points
         self.pol, self.qp = pol, qp
+        self.ss_correction = True   # Cox-Munk TMS term (tests switch it off to look at the Fourier-summed field)
         S_full, self.Nz = model.tau_rayl.shape
         self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
         self.S = len(range(*self.sl.indices(S_full)))
@@ -410,7 +482,10 @@ class Scene:
                 layers.append(dict(props=props, iface=tags[iz], nd=nd,
                                    dtau=conv(np.ascontiguousarray(dtau_full[self.sl])),
                                    tau_sum=conv(np.ascontiguousarray(tau_sum_all[self.sl, iz].astype(FT)))))
-            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1],
+            rho = None
+            if isinstance(model.surface, H.CoxMunkSurface):   # scene constant like Z(m): one N x N block per moment
+                rho, _ = reflectance(model.surface, self.dq, m, arch, FT)
+            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho,
                                      tau_sum_surface=conv(np.ascontiguousarray(tau_sum_all[self.sl, -1].astype(FT)))))
         N, S = self.N, self.S
         # every layer scatters and N fits on chip -> all steps run in the fused kernels, which can derive
@@ -431,6 +506,8 @@ class Scene:
         model, pol, FT = self.model, self.pol, self.FT
         self.R_SFI.zero_()
         self.T_SFI.zero_()
+        if self.S == 0:          # a rank that owns no spectral point (world > nSpec): nothing to launch
+            return self.R_SFI, self.T_SFI
         self.added.j0_p.zero_()  # a fresh make_added_layer: zero_added_noscat! never writes j0+ (rt_helpers.jl:174-180)
         for mom in self.moments:
             m = mom["m"]
@@ -438,10 +515,13 @@ class Scene:
             for iz, ly in enumerate(mom["layers"]):
                 rt_kernel_(pol, self.added, self.composite, ly["props"], ly["iface"], ly["tau_sum"], m, self.dq,
                            self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace)
-            create_surface_layer_(model.albedo, self.added_surface, m, self.dq, mom["tau_sum_surface"])
+            create_surface_layer_(model.surface, self.added_surface, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
             interaction_(mom["iface_surface"], self.composite, self.added_surface)
             postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
                                 self.T_SFI)
+        if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
+            apply_ss_correction_(self.R_SFI, model.surface, pol, model.vza, model.vaz, self.qp.mu0,
+                                 self.moments[-1]["tau_sum_surface"], model.m_max, self.arch, FT)
         return self.R_SFI, self.T_SFI
 
     def run_graph(self):

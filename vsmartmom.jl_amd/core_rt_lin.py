@@ -3,8 +3,9 @@
 
 Mirrors: make_added_layer / make_composite_layer (LinMode) (tools/rt_helper_functions_lin.jl:15-80),
 elemental! / doubling_allparams! / interaction! (lin) (CoreKernel/*_lin.jl), create_surface_layer! (lin),
-postprocessing_vza! (lin).  This round the linearized kernels are operator-level (batched MFMA products
-over (spectral point, parameter)); inverses are shared by all parameters like in the reference.
+postprocessing_vza! (lin).  FP64 with 32 < N <= 60 runs the fused column-strip kernels (vsm_striplin.hip: one launch
+per doubling step, two per interaction); other shapes run operator level (batched MFMA products over (spectral point,
+parameter)); inverses are shared by all parameters like in the reference.  `SceneLin` keeps every input in HBM.
 """
 from __future__ import annotations
 
@@ -116,87 +117,190 @@ def interaction_lin_(scattering_interface, comp: CR.CompositeLayer, comp_lin: Co
               C.byref(cl), C.byref(a), C.byref(al), CR._ptr(work), CR._stream_ptr())
 
 
-def rt_run_lin(model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int):
-    """rt_run(model, lin_model, NAer, NGas, NSurf) -> (R, T, Rdot, Tdot); Rdot/Tdot: [nVZA, nStokes, nSpec, Nparams].
-    Supported this round: NAer = 0, NGas = len(lin_model.tau_abs_dot), NSurf = 1 (Lambertian albedo)."""
-    if NAer != 0 or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
-        raise _lib.VSMError("rt_run (linearized): only NAer=0, NGas=len(lin_model.tau_abs_dot), NSurf=1 are wired up")
-    arch, FT = model.architecture, model.float_type
-    CR._require_gpu(arch)
-    pol, qp = model.polarization_type, model.quad_points
-    layout = H.ParameterLayout(n_aerosols=NAer, n_gases=NGas, n_surface=NSurf)
-    P, pl = layout.n_total, layout.n_layer_params
-    S, Nz = model.tau_rayl.shape
-    N = qp.Nquad * pol.n
-    nV = len(model.vza)
-    conv = array_type(arch)
-    dt, dev = CR._torch_dtype(FT), devi(arch)
-    dq = CR.device_quad(qp, pol, arch, FT)
-    F0 = model.F0
-    if F0 is None:
-        F0 = np.zeros((pol.n, S))
-        F0[0, :] = 1.0
-    F0d = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT).T))
-    added, added_s = CR.AddedLayer(FT, arch, N, S), CR.AddedLayer(FT, arch, N, S, shared=True)
-    comp = CR.CompositeLayer(FT, arch, N, S)
-    al, als = AddedLayerLin(FT, arch, P, N, S), AddedLayerLin(FT, arch, P, N, S, shared=True)
-    cl = CompositeLayerLin(FT, arch, P, N, S)
-    R = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
-    T = torch.zeros_like(R)
-    Rd = torch.zeros((P, S, pol.n, nV), dtype=dt, device=dev)
-    Td = torch.zeros_like(Rd)
-    for m in range(model.m_max + 1):
-        weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
-        lods = H.constructCoreOpticalProperties(model, m)
-        lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods)
-        tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
-        if any(t != "11" for t in tags):
-            raise _lib.VSMError("rt_run (linearized): every layer must scatter (rt_kernel_lin.jl:87 hard-codes scatter=true)")
-        tsd = np.zeros((S, pl, Nz + 1))
-        for iz in range(Nz):
-            tsd[:, :, iz + 1] = tsd[:, :, iz] + lins[iz].tau_dot
-        for iz in range(Nz):
-            props = CR.expandOpticalProperties(lods[iz], arch, FT)
-            dtau_h, nd = H.get_dtau_ndoubl(props.tau_h, props.varpi_h, qp, FT, model.numerics)
-            dtau = conv(dtau_h)
-            expk = conv(np.exp(-dtau_h / FT(qp.mu0)).astype(FT))
-            dtd = lins[iz].tau_dot / FT(2 ** nd)
-            zpd, zs_, zp_ = to_device_zdot(lins[iz].Zpp_dot, arch, FT)
-            zmd, _, _ = to_device_zdot(lins[iz].Zmp_dot, arch, FT)
-            elemental_lin_(pol, conv(tau_sum_all[:, iz].astype(FT)), to_device_sp(tsd[:, :, iz], arch, FT), dtau,
-                           to_device_sp(dtd, arch, FT), F0d, props, to_device_sp(lins[iz].varpi_dot, arch, FT), zpd, zmd,
-                           (zs_, zp_), pl, m, nd, dq, added, al)
-            dall = np.zeros((S, P))
-            dall[:, :pl] = dtd
-            doubling_allparams_(pol, expk, nd, added, al, to_device_sp(dall, arch, FT), qp.mu0, pl)
-            if iz == 0:
-                CR.copy_added_to_composite_(comp, added)
-                a_, c_ = al.cstruct(), cl.cstruct()
-                _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
+def _pp_args(pol, qp, vza, vaz, m, weight, dtype):
+    """row0 / weights of postprocessing_vza! (postprocessing_vza.jl:23-94) as ctypes arrays."""
+    n, nV = pol.n, len(vza)
+    row0 = (C.c_int * nV)()
+    ctype = C.c_double if dtype == torch.float64 else C.c_float
+    w = (ctype * (nV * n))()
+    for v in range(nV):
+        imu = int(np.argmin(np.abs(qp.qp_mu - qp.qp_mu.dtype.type(H.cosd(vza[v])))))
+        row0[v] = imu * n
+        c0, s0 = H.cosd(m * vaz[v]), H.sind(m * vaz[v])
+        for k in range(n):
+            w[v + nV * k] = float(weight) * [c0, c0, s0, s0][k]
+    return row0, w
+
+
+class SceneLin:
+    """Everything rt_run(model, lin_model, NAer, NGas, NSurf) needs, resident in HBM (the linearized twin of
+    CoreRT.Scene): per Fourier moment and layer tau, varpi, dtau, exp(-dtau/mu0), tau_sum and their parameter
+    derivatives, Z (shared) and Zdot, interface tags and ndoubl -- built once from host numpy, then `run()` only
+    launches kernels.  `spec_slice` selects this rank's spectral shard; ndoubl and the tags always come from the FULL
+    spectral axis (rt_kernel_lin.jl:87-95 uses batch-global maxima like the forward kernel).
+
+    Parameter slots (parameter_layout.jl:28-56): gases first, then ONE surface slot -- the Lambertian albedo
+    (lambertian_surface_lin.jl:48-162) or the Cox-Munk wind speed (coxmunk_surface_lin.jl:27-102)."""
+
+    def __init__(self, model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int,
+                 spec_slice: Optional[slice] = None):
+        if NAer != 0 or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
+            raise _lib.VSMError("rt_run (linearized): only NAer=0, NGas=len(lin_model.tau_abs_dot), NSurf=1 are wired up")
+        if not isinstance(model.surface, (H.LambertianSurfaceScalar, H.CoxMunkSurface)):
+            raise _lib.VSMError("rt_run (linearized): surface %r has no linearized builder here" % (model.surface,))
+        arch, FT = model.architecture, model.float_type
+        CR._require_gpu(arch)
+        self.model, self.arch, self.FT = model, arch, FT
+        pol, qp = model.polarization_type, model.quad_points
+        self.pol, self.qp = pol, qp
+        self.layout = H.ParameterLayout(n_aerosols=NAer, n_gases=NGas, n_surface=NSurf)
+        P, pl = self.layout.n_total, self.layout.n_layer_params
+        self.P, self.pl = P, pl
+        S_full, Nz = model.tau_rayl.shape
+        self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
+        sl = self.sl
+        S = self.S = len(range(*sl.indices(S_full)))
+        N = self.N = qp.Nquad * pol.n
+        nV = len(model.vza)
+        conv = array_type(arch)
+        dt, dev = CR._torch_dtype(FT), devi(arch)
+        self.dt = dt
+        self.dq = CR.device_quad(qp, pol, arch, FT)
+        F0 = model.F0
+        if F0 is None:
+            F0 = np.zeros((pol.n, S_full))
+            F0[0, :] = 1.0
+        self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, sl].T))
+        cut = lambda x: np.ascontiguousarray(np.asarray(x)[sl])
+        self.moments = []
+        shared = None     # tau/varpi/derivative tensors do not depend on m when no aerosol is mixed in: upload once
+        for m in range(model.m_max + 1):
+            lods = H.constructCoreOpticalProperties(model, m)
+            lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods)
+            tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
+            if any(t != "11" for t in tags):
+                raise _lib.VSMError("rt_run (linearized): every layer must scatter (rt_kernel_lin.jl:87 hard-codes scatter=true)")
+            tsd = np.zeros((S_full, pl, Nz + 1))
+            for iz in range(Nz):
+                tsd[:, :, iz + 1] = tsd[:, :, iz] + lins[iz].tau_dot
+            reuse = shared is not None and not model.aerosol_optics
+            layers = []
+            for iz in range(Nz):
+                lo = lods[iz]
+                tau_full = np.atleast_1d(lo.tau).astype(FT)
+                varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
+                Zpp, Zmp = CR.to_device_matrix(lo.Zpp, arch, FT), CR.to_device_matrix(lo.Zmp, arch, FT)
+                if Zpp.shape[0] != 1:
+                    Zpp, Zmp = Zpp[sl].contiguous(), Zmp[sl].contiguous()
+                if reuse:
+                    ly = dict(shared[iz])
+                    ly["props"] = CR.DeviceLayerOptics(ly["props"].tau, ly["props"].varpi, Zpp, Zmp, ly["props"].max_tau_varpi,
+                                                       tau_full, np.asarray(varpi_full))
+                    layers.append(ly)
+                    continue
+                dtau_h, nd = H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics)
+                dtd = lins[iz].tau_dot / FT(2 ** nd)
+                dall = np.zeros((S_full, P))
+                dall[:, :pl] = dtd
+                zpd, zs_, zp_ = to_device_zdot(lins[iz].Zpp_dot, arch, FT)
+                zmd, _, _ = to_device_zdot(lins[iz].Zmp_dot, arch, FT)
+                props = CR.DeviceLayerOptics(conv(cut(tau_full)), conv(cut(varpi_full)), Zpp, Zmp,
+                                             float(np.max(tau_full * varpi_full)), tau_full, np.asarray(varpi_full))
+                layers.append(dict(props=props, nd=nd, iface=tags[iz], dtau=conv(cut(dtau_h)),
+                                   expk0=conv(cut(np.exp(-dtau_h / FT(qp.mu0)).astype(FT))),
+                                   dtau_dot=to_device_sp(cut(dtd), arch, FT), dall=to_device_sp(cut(dall), arch, FT),
+                                   varpi_dot=to_device_sp(cut(lins[iz].varpi_dot), arch, FT),
+                                   tau_sum=conv(cut(tau_sum_all[:, iz].astype(FT))),
+                                   tau_sum_dot=to_device_sp(cut(tsd[:, :, iz]), arch, FT), zpd=zpd, zmd=zmd, zds=(zs_, zp_)))
+            if shared is None:
+                shared = layers
+            rho = drho = None
+            if isinstance(model.surface, H.CoxMunkSurface):
+                rho, drho = CR.reflectance(model.surface, self.dq, m, arch, FT, deriv=True)
+            surf = (shared_surf if reuse else
+                    dict(tau_sum=conv(cut(tau_sum_all[:, -1].astype(FT))), tau_sum_dot=to_device_sp(cut(tsd[:, :, -1]), arch, FT)))
+            shared_surf = surf
+            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, drho=drho, **surf))
+        self.added, self.added_s = CR.AddedLayer(FT, arch, N, S), CR.AddedLayer(FT, arch, N, S, shared=True)
+        self.comp = CR.CompositeLayer(FT, arch, N, S)
+        self.al, self.als = AddedLayerLin(FT, arch, P, N, S), AddedLayerLin(FT, arch, P, N, S, shared=True)
+        self.cl = CompositeLayerLin(FT, arch, P, N, S)
+        self.expk = torch.empty(max(S, 1), dtype=dt, device=dev)
+        self.R = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        self.T = torch.zeros_like(self.R)
+        self.Rd = torch.zeros((P, S, pol.n, nV), dtype=dt, device=dev)
+        self.Td = torch.zeros_like(self.Rd)
+
+    def run(self):
+        """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing."""
+        model, pol, qp, FT, dt = self.model, self.pol, self.qp, self.FT, self.dt
+        N, S, P, pl = self.N, self.S, self.P, self.pl
+        for t in (self.R, self.T, self.Rd, self.Td):
+            t.zero_()
+        if S == 0:
+            return self.R, self.T, self.Rd, self.Td
+        added, al, comp, cl = self.added, self.al, self.comp, self.cl
+        isurf = self.layout.surface_index(0)
+        for mom in self.moments:
+            m = mom["m"]
+            weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+            for iz, ly in enumerate(mom["layers"]):
+                elemental_lin_(pol, ly["tau_sum"], ly["tau_sum_dot"], ly["dtau"], ly["dtau_dot"], self.F0, ly["props"],
+                               ly["varpi_dot"], ly["zpd"], ly["zmd"], ly["zds"], pl, m, ly["nd"], self.dq, added, al)
+                self.expk[:S].copy_(ly["expk0"])      # doubling! squares exp(-dtau/mu0) in place
+                doubling_allparams_(pol, self.expk, ly["nd"], added, al, ly["dall"], qp.mu0, pl)
+                if iz == 0:
+                    CR.copy_added_to_composite_(comp, added)
+                    a_, c_ = al.cstruct(), cl.cstruct()
+                    _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
+                else:
+                    interaction_lin_(ly["iface"], comp, cl, added, al)
+            q_, a_, al_ = self.dq.cstruct(), self.added_s.cstruct(), self.als.cstruct()
+            if isinstance(model.surface, H.CoxMunkSurface):
+                _lib.call("vsm_brdf_surface_lin", dt, C.byref(q_), S, m, CR._ptr(mom["rho"]), CR._ptr(mom["drho"]), isurf,
+                          CR._ptr(mom["tau_sum"]), CR._ptr(mom["tau_sum_dot"]), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_),
+                          CR._stream_ptr())
             else:
-                interaction_lin_(tags[iz], comp, cl, added, al)
-        # surface
-        q_, a_, al_ = dq.cstruct(), added_s.cstruct(), als.cstruct()
-        alb = C.c_double(model.albedo) if dt == torch.float64 else C.c_float(model.albedo)
-        ts_surf = conv(tau_sum_all[:, -1].astype(FT))           # keep the device buffers alive across the launch
-        tsd_surf = to_device_sp(tsd[:, :, -1], arch, FT)
-        _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, layout.surface_index(0),
-                  CR._ptr(ts_surf), CR._ptr(tsd_surf), pl, CR._ptr(F0d), C.byref(a_), C.byref(al_), CR._stream_ptr())
-        interaction_lin_(tags[-1], comp, cl, added_s, als)
-        CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), R, T)
-        n = pol.n
-        row0 = (C.c_int * nV)()
-        ctype = C.c_double if dt == torch.float64 else C.c_float
-        w = (ctype * (nV * n))()
-        for v in range(nV):
-            imu = int(np.argmin(np.abs(qp.qp_mu - qp.qp_mu.dtype.type(H.cosd(model.vza[v])))))
-            row0[v] = imu * n
-            c0, s0 = H.cosd(m * model.vaz[v]), H.sind(m * model.vaz[v])
-            for k in range(n):
-                w[v + nV * k] = float(weight) * [c0, c0, s0, s0][k]
-        _lib.call("vsm_postprocess_vza_lin", dt, N, n, S, nV, P, row0, w, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p), CR._ptr(Rd),
-                  CR._ptr(Td), CR._stream_ptr())
+                alb = C.c_double(model.surface.albedo) if dt == torch.float64 else C.c_float(model.surface.albedo)
+                _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(mom["tau_sum"]),
+                          CR._ptr(mom["tau_sum_dot"]), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
+            interaction_lin_(mom["iface_surface"], comp, cl, self.added_s, self.als)
+            CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), self.R, self.T)
+            row0, w = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
+            _lib.call("vsm_postprocess_vza_lin", dt, N, pol.n, S, len(model.vza), P, row0, w, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p),
+                      CR._ptr(self.Rd), CR._ptr(self.Td), CR._stream_ptr())
+        return self.R, self.T, self.Rd, self.Td
+
+    def results_host(self):
+        """(R, T, Rdot, Tdot) as the reference returns them: [nVZA, nStokes, nSpec] and [nVZA, nStokes, nSpec, Nparams]."""
+        tr = lambda t: to_host(t).transpose(2, 1, 0).copy()
+        tr4 = lambda t: to_host(t).transpose(3, 2, 1, 0).copy()
+        return tr(self.R), tr(self.T), tr4(self.Rd), tr4(self.Td)
+
+    def flops_per_point(self) -> float:
+        """ALGORITHMIC flops per spectral point: forward + per parameter nd (24N^3+16N^2) per layer for
+        the layer parameters and (48N^3+16N^2) per interaction for every parameter."""
+        N = float(self.N)
+        tot = 0.0
+        for mom in self.moments:
+            for iz, ly in enumerate(mom["layers"]):
+                tot += ly["nd"] * ((12 + 24 * self.pl) * N ** 3 + (8 + 16 * self.pl) * N ** 2)
+                if iz > 0:
+                    tot += (24 + 48 * self.P) * N ** 3 + (8 + 16 * self.P) * N ** 2
+            tot += (24 + 48 * self.P) * N ** 3 + (8 + 16 * self.P) * N ** 2
+        return tot
+
+
+def prepare_scene_lin(model, lin_model, NAer, NGas, NSurf, spec_slice: Optional[slice] = None) -> SceneLin:
+    return SceneLin(model, lin_model, NAer, NGas, NSurf, spec_slice)
+
+
+def rt_run_lin(model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int):
+    """rt_run(model, lin_model, NAer, NGas, NSurf) (rt_run_lin.jl:72-78 -> :102-326) -> (R, T, Rdot, Tdot);
+    Rdot/Tdot: [nVZA, nStokes, nSpec, Nparams].  Supported: NAer = 0, NGas = len(lin_model.tau_abs_dot), NSurf = 1
+    (Lambertian albedo or Cox-Munk wind speed, by the model's surface).  Like the reference's linearized driver this
+    path applies no TMS correction."""
+    scene = SceneLin(model, lin_model, NAer, NGas, NSurf)
+    scene.run()
     synchronize_if_gpu()
-    tr = lambda t: to_host(t).transpose(2, 1, 0).copy()
-    tr4 = lambda t: to_host(t).transpose(3, 2, 1, 0).copy()
-    return tr(R), tr(T), tr4(Rd), tr4(Td)
+    return scene.results_host()

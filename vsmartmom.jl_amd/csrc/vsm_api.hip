@@ -570,3 +570,56 @@ size_t vsm_interaction_lin_work_elems(int N, int S, int P) { return interaction_
 VSM_LIN_API(double, f64)
 VSM_LIN_API(float, f32)
 }
+
+// ---- BRDF surfaces ---------------------------------------------------------------------------------------------------
+#define VSM_SURF_API(T, SFX)                                                                                           \
+  static cm_surf<T> cvt_cm(const vsm_coxmunk_##SFX* c) {                                                               \
+    cm_surf<T> r;                                                                                                      \
+    r.wind_speed = c->wind_speed;                                                                                      \
+    r.n_re = c->n_water_re;                                                                                            \
+    r.n_im = c->n_water_im;                                                                                            \
+    r.whitecap_albedo = c->whitecap_albedo;                                                                            \
+    r.include_whitecaps = c->include_whitecaps;                                                                        \
+    r.shadowing = c->shadowing;                                                                                        \
+    return r;                                                                                                          \
+  }                                                                                                                    \
+  extern "C" int vsm_coxmunk_reflectance_##SFX(const vsm_coxmunk_##SFX* surf, const vsm_quad_##SFX* q, int m, int nphi, \
+                                               const T* phi, const T* wphi, T* rho, T* drho_dU, void* stream) {        \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q))) return rc;                                                                               \
+    VSM_REQUIRE(surf && m >= 0 && phi && wphi && rho && q->N % q->n_stokes == 0, "coxmunk_reflectance: bad argument"); \
+    return coxmunk_reflectance<T>(cvt_cm(surf), q->n_stokes, q->N / q->n_stokes, q->mu, m, nphi, phi, wphi, rho,       \
+                                  drho_dU, as_stream(stream));                                                         \
+  }                                                                                                                    \
+  extern "C" int vsm_brdf_surface_##SFX(const vsm_quad_##SFX* q, int S, int m, const T* rho, const T* tau_sum,         \
+                                        const vsm_added_##SFX* added, void* stream) {                                  \
+    int rc;                                                                                                            \
+    VSM_REQUIRE(added && added->d_symmetric == 0, "brdf_surface: d_symmetric layers are not accepted here");           \
+    if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;                                                  \
+    VSM_REQUIRE(S >= 0 && m >= 0 && rho && (tau_sum || S == 0), "brdf_surface: bad argument");                         \
+    return brdf_surface<T>(cvt_quad<T>(q), S, m, rho, tau_sum, cvt_added<T>(added), as_stream(stream));                \
+  }                                                                                                                    \
+  extern "C" int vsm_brdf_surface_lin_##SFX(const vsm_quad_##SFX* q, int S, int m, const T* rho, const T* drho,        \
+                                            int iparam, const T* tau_sum, const T* tau_sum_dot, int p_layer,           \
+                                            const T* F0, const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al,  \
+                                            void* stream) {                                                            \
+    int rc;                                                                                                            \
+    VSM_REQUIRE(added && added->d_symmetric == 0, "brdf_surface_lin: d_symmetric layers are not accepted here");       \
+    if ((rc = check_quad(q)) || (rc = check_added(added)) || (rc = check_al(al))) return rc;                           \
+    VSM_REQUIRE(S >= 0 && m >= 0 && rho && drho && tau_sum && F0 && (tau_sum_dot || p_layer == 0) && iparam >= 0 &&    \
+                    iparam < al->P && p_layer >= 0 && p_layer <= al->P,                                                \
+                "brdf_surface_lin: bad argument");                                                                     \
+    return brdf_surface_lin<T>(cvt_quad<T>(q), S, m, rho, drho, iparam, tau_sum, tau_sum_dot, p_layer, F0,             \
+                               cvt_added<T>(added), cvt_al<T>(al), as_stream(stream));                                 \
+  }                                                                                                                    \
+  extern "C" int vsm_coxmunk_ss_correction_##SFX(const vsm_coxmunk_##SFX* surf, int n_stokes, int S, int nV,           \
+                                                 const T* mu_v_h, const T* dphi_h, T mu0, int m_max, int nphi,         \
+                                                 const T* phi, const T* wphi, const T* tau_total, T* coef, T* R_SFI,   \
+                                                 void* stream) {                                                       \
+    VSM_REQUIRE(surf && mu_v_h && dphi_h && phi && wphi && coef && S >= 0 && (R_SFI == nullptr || tau_total || S == 0), \
+                "coxmunk_ss_correction: bad argument");                                                                \
+    return coxmunk_ss_correction<T>(cvt_cm(surf), n_stokes, S, nV, mu_v_h, dphi_h, mu0, m_max, nphi, phi, wphi,        \
+                                    tau_total, coef, R_SFI, as_stream(stream));                                        \
+  }
+VSM_SURF_API(double, f64)
+VSM_SURF_API(float, f32)

@@ -91,6 +91,24 @@ template <typename T>
 int postprocess_vza_lin(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const T* w_h, const T* Jd_m,
                         const T* Jd_p, T* Rd, T* Td, hipStream_t st);
 
+// ---- BRDF surfaces (Cox-Munk reflectance, generic BRDF surface layer, TMS correction): vsm_surface.hip ----
+template <typename T>
+struct cm_surf {
+  T wind_speed, n_re, n_im, whitecap_albedo;
+  int include_whitecaps, shadowing;
+};
+template <typename T>
+int coxmunk_reflectance(const cm_surf<T>& sf, int n_stokes, int Nmu, const T* muN, int m, int nphi, const T* phi, const T* wphi,
+                        T* rho, T* drho, hipStream_t st);
+template <typename T>
+int brdf_surface(const quad<T>& q, int S, int m, const T* rho, const T* tau_sum, const added<T>& a, hipStream_t st);
+template <typename T>
+int brdf_surface_lin(const quad<T>& q, int S, int m, const T* rho, const T* drho, int iparam, const T* tau_sum,
+                     const T* tau_sum_dot, int p_layer, const T* F0, const added<T>& a, const added_lin<T>& al, hipStream_t st);
+template <typename T>
+int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, const T* mu_v_h, const T* dphi_h, T mu0, int m_max,
+                          int nphi, const T* phi, const T* wphi, const T* tau_total, T* coef, T* R_SFI, hipStream_t st);
+
 // ---- fused (LDS-resident) path: vsm_fused.hip ---------------------------------
 template <typename T>
 int fused_max_n();

@@ -294,6 +294,90 @@ def get_scattering_interface(prev: str, scatter: bool, iz: int) -> str:
     return "11" if scatter else "10"
 
 
+# ---- surfaces (src/CoreRT/types.jl:470-536) -----------------------------------------------------------------
+@dataclass
+class LambertianSurfaceScalar:
+    albedo: float
+
+
+@dataclass
+class CoxMunkSurface:
+    """src/CoreRT/types.jl:525-536: Cox-Munk (1954) ocean, isotropic slope variance 0.003 + 0.00512 U."""
+    wind_speed: float
+    n_water: Optional[complex] = None     # None -> Segelstein (1981) table at 550 nm (coxmunk_surface.jl:434-444)
+    whitecap_albedo: float = 0.22
+    include_whitecaps: bool = True
+    shadowing: bool = True
+
+
+# Segelstein (1981) liquid-water refractive index, the columns of src/CoreRT/Surfaces/water_refraction.jl:15-57 (data)
+_WATER_NM = (
+    200.0, 210.0, 220.0, 230.0, 240.0, 250.0, 260.0, 270.0, 280.0, 290.0,
+    300.0, 310.0, 320.0, 330.0, 340.0, 350.0, 360.0, 370.0, 380.0, 390.0,
+    400.0, 410.0, 420.0, 430.0, 440.0, 450.0, 460.0, 470.0, 480.0, 490.0,
+    500.0, 510.0, 520.0, 530.0, 540.0, 550.0, 560.0, 570.0, 580.0, 590.0,
+    600.0, 610.0, 620.0, 630.0, 640.0, 650.0, 660.0, 670.0, 680.0, 690.0,
+    700.0, 720.0, 740.0, 760.0, 780.0, 800.0, 820.0, 840.0, 860.0, 880.0,
+    900.0, 920.0, 940.0, 960.0, 980.0, 1000.0, 1050.0, 1100.0, 1150.0, 1200.0,
+    1250.0, 1300.0, 1350.0, 1400.0, 1450.0, 1500.0, 1550.0, 1600.0, 1650.0, 1700.0,
+    1750.0, 1800.0, 1850.0, 1900.0, 1950.0, 2000.0, 2100.0, 2200.0, 2300.0, 2400.0,
+    2500.0, 2600.0,
+)
+_WATER_N = (
+    1.396, 1.373, 1.362, 1.354, 1.349, 1.346, 1.343, 1.341, 1.339, 1.338,
+    1.337, 1.336, 1.335, 1.335, 1.334, 1.334, 1.333, 1.333, 1.333, 1.332,
+    1.332, 1.332, 1.331, 1.331, 1.331, 1.331, 1.330, 1.330, 1.330, 1.330,
+    1.329, 1.329, 1.329, 1.329, 1.328, 1.328, 1.328, 1.328, 1.327, 1.327,
+    1.327, 1.326, 1.326, 1.326, 1.325, 1.325, 1.325, 1.325, 1.324, 1.324,
+    1.324, 1.323, 1.322, 1.322, 1.321, 1.320, 1.319, 1.319, 1.318, 1.317,
+    1.316, 1.315, 1.314, 1.313, 1.312, 1.311, 1.308, 1.306, 1.303, 1.300,
+    1.296, 1.293, 1.289, 1.285, 1.277, 1.268, 1.261, 1.255, 1.253, 1.255,
+    1.260, 1.268, 1.279, 1.295, 1.306, 1.304, 1.279, 1.232, 1.188, 1.147,
+    1.131, 1.129,
+)
+_WATER_K = (
+    1.42e-07, 7.00e-08, 4.00e-08, 2.60e-08, 1.80e-08, 1.40e-08, 1.10e-08, 9.00e-09, 7.50e-09, 6.50e-09,
+    6.00e-09, 4.60e-09, 3.50e-09, 2.70e-09, 2.20e-09, 1.80e-09, 1.60e-09, 1.40e-09, 1.30e-09, 1.30e-09,
+    1.30e-09, 1.40e-09, 1.50e-09, 1.60e-09, 1.70e-09, 1.80e-09, 1.90e-09, 2.05e-09, 2.30e-09, 2.69e-09,
+    3.21e-09, 3.81e-09, 4.36e-09, 4.78e-09, 5.14e-09, 5.69e-09, 6.49e-09, 7.63e-09, 9.22e-09, 1.09e-08,
+    1.26e-08, 1.39e-08, 1.48e-08, 1.55e-08, 1.63e-08, 1.74e-08, 1.91e-08, 2.20e-08, 2.72e-08, 3.59e-08,
+    4.78e-08, 7.50e-08, 1.10e-07, 1.43e-07, 1.65e-07, 1.72e-07, 1.63e-07, 1.46e-07, 1.32e-07, 1.28e-07,
+    1.38e-07, 1.65e-07, 2.41e-07, 4.42e-07, 7.40e-07, 1.06e-06, 1.79e-06, 1.65e-06, 1.10e-06, 9.60e-07,
+    1.32e-06, 2.26e-06, 4.58e-06, 1.07e-05, 2.94e-05, 5.88e-05, 7.15e-05, 6.71e-05, 5.68e-05, 4.65e-05,
+    3.85e-05, 3.44e-05, 3.72e-05, 5.63e-05, 1.27e-04, 2.98e-04, 6.56e-04, 1.14e-03, 1.67e-03, 1.89e-03,
+    1.67e-03, 1.19e-03,
+)
+
+
+def water_refractive_index(lam_nm: float) -> complex:
+    """water_refraction.jl:61-102: n linear, k log-linear in log(wavelength); clamped outside 200-2600 nm."""
+    lg = [math.log(x) for x in _WATER_NM]
+    x = math.log(float(lam_nm))
+    if x <= lg[0]:
+        return complex(_WATER_N[0], _WATER_K[0])
+    if x >= lg[-1]:
+        return complex(_WATER_N[-1], _WATER_K[-1])
+    lo, hi = 1, len(lg)                     # the reference's 1-based bisection
+    while hi - lo > 1:
+        mid = (lo + hi) >> 1
+        if lg[mid - 1] <= x:
+            lo = mid
+        else:
+            hi = mid
+    lo, hi = lo - 1, hi - 1
+    t = (x - lg[lo]) / (lg[hi] - lg[lo])
+    lk0, lk1 = math.log(_WATER_K[lo]), math.log(_WATER_K[hi])
+    return complex(_WATER_N[lo] + t * (_WATER_N[hi] - _WATER_N[lo]), math.exp(lk0 + t * (lk1 - lk0)))
+
+
+def get_n_water(surf: CoxMunkSurface, lam_nm: float = 550.0) -> complex:
+    """_get_n_water (coxmunk_surface.jl:434-444); every reference call site evaluates it at 550 nm."""
+    return water_refractive_index(lam_nm) if surf.n_water is None else complex(surf.n_water)
+
+
+NQUAD_PHI_BRDF = 100   # azimuth nodes of reflectance() (coxmunk_surface.jl:394, rpv_surface.jl:174: "hardcoded for now")
+
+
 @dataclass
 class RTNumericalParameters:
     """src/CoreRT/types.jl:713-756."""
@@ -321,11 +405,18 @@ class RTModel:
     varpi_Cabannes: float = 1.0
     numerics: RTNumericalParameters = field(default_factory=RTNumericalParameters)
     F0: Optional[np.ndarray] = None   # [nStokes, S]; None = SolarBeam default e1
+    surface: Optional[object] = None  # LambertianSurfaceScalar | CoxMunkSurface; None = LambertianSurfaceScalar(albedo)
+
+    def __post_init__(self):
+        if self.surface is None:
+            self.surface = LambertianSurfaceScalar(float(self.albedo))
+        elif isinstance(self.surface, LambertianSurfaceScalar):
+            self.albedo = float(self.surface.albedo)
 
 
 def model_from_arrays(architecture, polarization: str, l_trunc: int, sza: float, vza, vaz, tau_rayl, tau_abs=None,
                       tau_aer=None, aerosol_optics=(), depol=0.0, albedo=0.0, m_max=2, float_type=np.float64,
-                      numerics=None) -> RTModel:
+                      numerics=None, surface=None) -> RTModel:
     """Build the RTModel subset directly from optical-depth arrays -- what the reference's tests
     do after model_from_parameters by overwriting model.τ_rayl/τ_abs/τ_aer
     (e.g. test/vlidort_baseline/cases/case_B_solar_tester.jl:62-74)."""
@@ -338,7 +429,7 @@ def model_from_arrays(architecture, polarization: str, l_trunc: int, sza: float,
                else np.atleast_2d(np.asarray(tau_aer, dtype=np.float64)))
     return RTModel(architecture, pol, qp, float(sza), np.asarray(vza, float), np.asarray(vaz, float), tau_rayl,
                    tau_abs, tau_aer, list(aerosol_optics), get_greek_rayleigh(depol), float(albedo), int(m_max),
-                   float_type, 1.0, numerics or RTNumericalParameters())
+                   float_type, 1.0, numerics or RTNumericalParameters(), None, surface)
 
 
 def constructCoreOpticalProperties(model: RTModel, m: int) -> List[CoreScatteringOpticalProperties]:

@@ -1,11 +1,12 @@
-"""YAML -> parameters -> RTModel for the Rayleigh + Lambertian subset of the reference's scene files.
+"""YAML -> parameters -> RTModel for the Rayleigh + Lambertian / Cox-Munk subset of the reference's scene files.
 
 Host-side mirror of `parameters_from_yaml` (src/IO/Parameters.jl:1021-1075, the new `nstreams` schema :1102-1175) and of
 the parts of `model_from_parameters` (src/CoreRT/tools/model_from_parameters.jl:211-302) that such scenes exercise:
 quadrature from `nstreams`, profile fields / reduction, the depolarization rule (`depol < 0`: from the N2/O2 molecular
 constants), Bodhaine Rayleigh optical depth.  `config/quickstart.yaml` and `config/lambertian_land.yaml` of the reference
 are of this kind.  Blocks that need components outside this backend (absorption -> HITRAN tables, scattering -> Mie,
-non-Lambertian surfaces) raise NotImplementedError instead of being silently ignored.
+surfaces other than Lambertian / Cox-Munk) raise NotImplementedError instead of being silently ignored.  `config/ocean_coxmunk.yaml`
+(BASELINE config C3) parses to a CoxMunkSurface model with the Fourier bound of the reference's trait aggregator (m <= 21).
 """
 from __future__ import annotations
 
@@ -24,7 +25,7 @@ from . import raman_inputs as RI
 @dataclass
 class vSmartMOM_Parameters:
     spec_bands: List[np.ndarray]
-    albedo: List[float]
+    albedo: List[float]               # NaN for non-Lambertian surfaces
     nstreams: int
     polarization_type: str
     depol: float
@@ -38,6 +39,7 @@ class vSmartMOM_Parameters:
     p: List[float]
     q: List[float]
     profile_reduction_n: int = -1
+    brdf: List[object] = field(default_factory=list)   # params.brdf: one surface per band
     l_trunc: int = field(init=False)
     max_m: int = field(init=False)
 
@@ -93,11 +95,72 @@ def parse_spec_band(s: str) -> np.ndarray:
     return a + st * np.arange(n)
 
 
-def _surface_albedo(s: str) -> float:
-    m = re.fullmatch(r"LambertianSurfaceScalar(?:\{\w+\})?\(([^)]*)\)", str(s).strip())
+def _split_args(body: str):
+    """Top-level comma split of a constructor argument list; `k=v` items go to the keyword dict."""
+    args, kw, depth, cur = [], {}, 0, ""
+    for ch in body + ",":
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            item = cur.strip()
+            cur = ""
+            if not item:
+                continue
+            if "=" in item:
+                k, v = item.split("=", 1)
+                kw[k.strip()] = v.strip()
+            else:
+                args.append(item)
+        else:
+            cur += ch
+    return args, kw
+
+
+def _complex(v: str) -> complex:
+    m = re.fullmatch(r"(?:complex|Complex)\((.*),(.*)\)", v.replace(" ", ""))
+    if m:
+        return complex(_num(m.group(1)), _num(m.group(2)))
+    m = re.fullmatch(r"(.+?)([+-].+)im", v.replace(" ", ""))
+    if m:
+        return complex(_num(m.group(1)), _num(m.group(2)))
+    return complex(_num(v), 0.0)
+
+
+def parse_surface(s: str):
+    """`parse_surface` (src/IO/Parameters.jl:145-156,327-372): a constructor call string, without eval.
+    Built here: LambertianSurfaceScalar(albedo), CoxMunkSurface(U) / CoxMunkSurface(wind_speed=U, n_water=, whitecap_albedo=,
+    include_whitecaps=, shadowing=)."""
+    m = re.fullmatch(r"(\w+)(?:\{\w+\})?\((.*)\)", str(s).strip())
     if not m:
-        raise NotImplementedError("surface %r: only LambertianSurfaceScalar is built in this backend" % s)
-    return _num(m.group(1))
+        raise ValueError("cannot parse surface %r" % s)
+    name, (args, kw) = m.group(1), _split_args(m.group(2))
+    if name == "LambertianSurfaceScalar":
+        if len(args) != 1 or kw:
+            raise ValueError("LambertianSurfaceScalar expects 1 argument (albedo)")
+        return H.LambertianSurfaceScalar(_num(args[0]))
+    if name == "CoxMunkSurface":
+        if kw:
+            if args or "wind_speed" not in kw:
+                raise ValueError("CoxMunkSurface keyword arguments require wind_speed.")
+            unknown = set(kw) - {"wind_speed", "n_water", "whitecap_albedo", "include_whitecaps", "shadowing"}
+            if unknown:
+                raise ValueError("CoxMunkSurface: unknown keyword(s) %s" % sorted(unknown))
+            b = lambda k, d: d if k not in kw else {"true": True, "false": False}[kw[k].lower()]
+            return H.CoxMunkSurface(wind_speed=_num(kw["wind_speed"]),
+                                    n_water=None if kw.get("n_water", "nothing") == "nothing" else _complex(kw["n_water"]),
+                                    whitecap_albedo=_num(kw.get("whitecap_albedo", "0.22")),
+                                    include_whitecaps=b("include_whitecaps", True), shadowing=b("shadowing", True))
+        if len(args) != 1:
+            raise ValueError("CoxMunkSurface expects 1 argument (wind_speed)")
+        return H.CoxMunkSurface(wind_speed=_num(args[0]))
+    raise NotImplementedError("surface %r: LambertianSurfaceScalar and CoxMunkSurface are built in this backend" % s)
+
+
+def _surface_albedo(s: str) -> float:
+    surf = parse_surface(s)
+    return surf.albedo if isinstance(surf, H.LambertianSurfaceScalar) else float("nan")
 
 
 def parameters_from_dict(d: dict) -> vSmartMOM_Parameters:
@@ -116,7 +179,8 @@ def parameters_from_dict(d: dict) -> vSmartMOM_Parameters:
         nstreams=int(rt.get("nstreams", 8)), polarization_type=pol, depol=float(rt["depol"]), float_type=ft,
         architecture=str(rt.get("architecture", "default_architecture")), sza=float(geo["sza"]),
         vza=[float(x) for x in geo["vza"]], vaz=[float(x) for x in geo["vaz"]], obs_alt=float(geo.get("obs_alt", 0.0)),
-        T=T, p=[float(x) for x in atm["p"]], q=q, profile_reduction_n=int(atm.get("profile_reduction", -1)))
+        T=T, p=[float(x) for x in atm["p"]], q=q, profile_reduction_n=int(atm.get("profile_reduction", -1)),
+        brdf=[parse_surface(s) for s in rt["surface"]])
 
 
 def parameters_from_yaml(path_or_text: str) -> vSmartMOM_Parameters:
@@ -142,8 +206,12 @@ def model_from_parameters(params: vSmartMOM_Parameters, architecture, iBand: int
     else:
         depol = params.depol
     tau_rayl = RI.rayleigh_layer_optical_depth(prof.p_half[-1], 1e4 / nu, depol, prof.vcd_dry)
-    # Fourier bound: Rayleigh declares m <= 2, Lambertian and the solar beam 0; the stream cap 2 nstreams - 1 >= 5 never
-    # binds (component_m_max.jl:72-131)
+    # Fourier bound (component_m_max.jl:60-131, model_from_parameters.jl:109-131): the maximum over the band's components --
+    # Rayleigh 2, Lambertian / solar beam 0, Cox-Munk user_l_cap = min(2 nstreams - 1, max_m - 1, l_trunc) -- clamped to
+    # user_l_cap (>= 5 here, so it never binds for Rayleigh + Lambertian).
+    surface = params.brdf[iBand - 1]
+    user_l_cap = min(2 * params.nstreams - 1, params.max_m - 1, params.l_trunc)
+    m_max = min(max(2, user_l_cap if isinstance(surface, H.CoxMunkSurface) else 0), user_l_cap)
+    alb = surface.albedo if isinstance(surface, H.LambertianSurfaceScalar) else 0.0
     return H.model_from_arrays(architecture, params.polarization_type, params.l_trunc, params.sza, params.vza, params.vaz,
-                               tau_rayl, depol=depol, albedo=params.albedo[iBand - 1], m_max=2,
-                               float_type=params.float_type)
+                               tau_rayl, depol=depol, albedo=alb, m_max=m_max, float_type=params.float_type, surface=surface)

@@ -105,3 +105,38 @@ def rt_run_sharded(model, executor: Optional[Callable] = None, rank: int = 0, wo
         return None, None
     to_np = lambda t: t.detach().cpu().numpy().transpose(2, 1, 0).copy()
     return to_np(Rg), to_np(Tg)
+
+
+def rt_run_lin_sharded(model, lin_model, NAer: int, NGas: int, NSurf: int, executor: Optional[Callable] = None, rank: int = 0,
+                       world: int = 1, dst: int = 0):
+    """rt_run(model, lin_model, NAer, NGas, NSurf) over this rank's spectral block + ONE gather of R, T, Rdot, Tdot on `dst`
+    (rt_run_lin.jl:185-190,324: Rdot/Tdot [nVZA, nStokes, nSpec, Nparams]).
+
+    `executor(model, lin_model, spec_slice) -> (R, T, Rd, Td)` returns tensors whose spectral axis is the local block:
+    R/T (S_local, nStokes, nVZA), Rd/Td (P, S_local, nStokes, nVZA); the default is the HIP engine
+    (`CoreRTLin.SceneLin(model, lin_model, ..., slice).run()`).  The four arrays travel in one buffer per rank
+    ([S_local, (2 + 2P) nStokes nVZA]), so the data path has exactly one collective.  Returns host arrays in the
+    reference's axis order on `dst`, Nones elsewhere."""
+    import torch
+    S = model.tau_rayl.shape[0]
+    sl = shard_slice(S, rank, world)
+    if executor is None:
+        from . import core_rt_lin
+
+        def executor(mdl, lin, s):
+            return core_rt_lin.SceneLin(mdl, lin, NAer, NGas, NSurf, s).run()
+    R, T, Rd, Td = executor(model, lin_model, sl)
+    P = Rd.shape[0]
+    Sl, n, nV = R.shape
+    packed = torch.cat([R.reshape(Sl, -1), T.reshape(Sl, -1), Rd.permute(1, 0, 2, 3).reshape(Sl, -1),
+                        Td.permute(1, 0, 2, 3).reshape(Sl, -1)], dim=1).contiguous()
+    g = gather_spectral(packed, S, rank, world, dst)
+    if rank != dst:
+        return None, None, None, None
+    g = g.detach().cpu().numpy()
+    k = n * nV
+    Rg, Tg = g[:, :k].reshape(S, n, nV), g[:, k:2 * k].reshape(S, n, nV)
+    Rdg = g[:, 2 * k:(2 + P) * k].reshape(S, P, n, nV)
+    Tdg = g[:, (2 + P) * k:].reshape(S, P, n, nV)
+    return (Rg.transpose(2, 1, 0).copy(), Tg.transpose(2, 1, 0).copy(), Rdg.transpose(3, 2, 0, 1).copy(),
+            Tdg.transpose(3, 2, 0, 1).copy())
