@@ -334,6 +334,37 @@ int vsm_coxmunk_ss_correction_f32(const vsm_coxmunk_f32* surf, int n_stokes, int
                                   const float* dphi_h, float mu0, int m_max, int nphi, const float* phi, const float* wphi,
                                   const float* tau_total, float* coef, float* R_SFI, void* stream);
 
+/* ---- per-scene layer optics on the device ---------------------------------------------------
+ * The reference builds these on the host once per Fourier moment (rt_run.jl:390-394) and ships per-layer arrays inside
+ * the layer loop (expandOpticalProperties, compEffectiveLayerProperties.jl:106-117).  Here the raw optical depths are
+ * uploaded once per scene and the inputs of the layer kernels are produced in HBM.
+ *
+ * compute_Z_moments(pol, mu, greek_coefs, m) (src/Scattering/compute_Z_matrices.jl:26-110): Z++ / Z-+ [N,N] over the
+ * streams of `q` (node k = q->mu[k*n_stokes]) from the Greek coefficients greek[6*lmax] = alpha | beta | gamma | delta |
+ * epsilon | zeta (device, FP64), each of length lmax. */
+int vsm_compute_Z_moments_f64(const vsm_quad_f64* q, int m, int lmax, const double* greek, double* Zpp, double* Zmp,
+                              void* stream);
+int vsm_compute_Z_moments_f32(const vsm_quad_f32* q, int m, int lmax, const double* greek, float* Zpp, float* Zmp,
+                              void* stream);
+/* constructCoreOpticalProperties + extractEffectiveProps (compEffectiveLayerProperties.jl:11-93) for one band, noRS:
+ * Rayleigh (tau_rayl[S,L], varpi_cabannes) + nAer aerosols (tau_aer[nAer,L], ssa[nAer], ftrunc[nAer]; createAero delta-M
+ * scaling :67-72) + absorption (tau_abs[S,L]); arrays are the reference's column-major [nSpec, Nz] ((s,l) at s + S*l), all
+ * device pointers, FP64 inputs.  mode[nAer,L] (int, (ia,l) at ia + nAer*l) resolves the batch-global branches of the
+ * mixing `+` (types.jl:1262-1292): 0 = per-point mix, 1 = no point scatters before this aerosol (take its Z),
+ * 2 = the aerosol does not scatter (keep Z).  Outputs: tau, varpi [S,L]; tau_sum [S,L+1] (column l = optical depth above
+ * layer l, column L = total); fcomp (nullable) [nAer+1, S, L] per-point weights of the component phase matrices
+ * (Rayleigh, aerosol 1, ...) as consumed by vsm_layer_forward_mix_*; max_tau_varpi[L] = maximum(tau .* varpi) per layer
+ * (rt_kernel.jl:197,282 -- the host turns it into ndoubl and the scattering-interface tags). */
+int vsm_layer_optics_f64(int S, int L, int nAer, const double* tau_rayl, const double* tau_abs, double varpi_cabannes,
+                         const double* tau_aer, const double* ssa, const double* ftrunc, const int* mode, double* tau,
+                         double* varpi, double* tau_sum, double* fcomp, double* max_tau_varpi, void* stream);
+int vsm_layer_optics_f32(int S, int L, int nAer, const double* tau_rayl, const double* tau_abs, double varpi_cabannes,
+                         const double* tau_aer, const double* ssa, const double* ftrunc, const int* mode, float* tau,
+                         float* varpi, float* tau_sum, float* fcomp, float* max_tau_varpi, void* stream);
+/* dtau[S,L] = tau ./ 2^ndoubl[l] (get_dtau_ndoubl, rt_kernel.jl:266-287); ndoubl: device int[L]. */
+int vsm_layer_dtau_f64(int S, int L, const int* ndoubl, const double* tau, double* dtau, void* stream);
+int vsm_layer_dtau_f32(int S, int L, const int* ndoubl, const float* tau, float* dtau, void* stream);
+
 /* rt_kernel!(::noRS) for ONE scattering layer (src/CoreRT/CoreKernel/rt_kernel.jl:175-250): elemental! + doubling!
  * followed by copy_added_to_composite! (toa != 0, i.e. iz == 1; rt_helpers.jl:188-200) or
  * interaction!(::ScatteringInterface_11) (interaction.jl:207-266).  Arguments as vsm_elemental_doubling_*.

@@ -100,6 +100,9 @@ _SIGS = {
     "vsm_interaction_oplevel_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "vsm_lambertian_surface_{T}": (_I, [_P, _I, _I, "{R}", _P, _P, _P]),
     "vsm_postprocess_vza_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_compute_Z_moments_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
+    "vsm_layer_optics_{T}": (_I, [_I, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vsm_layer_dtau_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_coxmunk_reflectance_{T}": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "vsm_brdf_surface_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_lin_{T}": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),

@@ -278,15 +278,15 @@ def copy_added_to_composite_(comp: CompositeLayer, added: AddedLayer):
 _work_cache = {}
 
 
-def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False):
+def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False,
+                 work: Optional[torch.Tensor] = None):
     """interaction! (interaction.jl:268-285).  `oplevel=True` forces the operator-for-operator path
     (batched products + batch_inv!, like the reference executes it) instead of the fused kernel."""
     a, c = added.cstruct(), comp.cstruct()
     N, S = comp.N, comp.nSpec
-    work = None
     fused = (scattering_interface == "11" and not oplevel
              and N <= _lib.lib().vsm_fused_max_n(8 if comp.dtype == torch.float64 else 4))
-    if not fused:
+    if not fused and work is None:
         key = (N, S, comp.dtype, str(comp.R_mp.device))
         work = _work_cache.get(key)
         if work is None:
@@ -399,7 +399,7 @@ def init_layer(props: DeviceLayerOptics, qp: H.QuadPoints, FT, numerics: H.RTNum
 def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerOptics, scattering_interface: str,
                tau_sum: torch.Tensor, m: int, dq: DeviceQuad, arch, iz: int, F0: torch.Tensor, FT,
                numerics: H.RTNumericalParameters, dtau: Optional[torch.Tensor] = None, ndoubl: Optional[int] = None,
-               trace: Optional[list] = None):
+               trace: Optional[list] = None, work: Optional[torch.Tensor] = None):
     """rt_kernel!(::noRS, ...) (rt_kernel.jl:175-250).  iz is 1-based.  dtau/ndoubl may be
     passed pre-computed (they only depend on the layer optics)."""
     scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps
@@ -422,83 +422,187 @@ def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerO
     if iz == 1:
         copy_added_to_composite_(comp, added)
     else:
-        interaction_(scattering_interface, comp, added)
+        interaction_(scattering_interface, comp, added, work=work)
 
 
 # ----------------------------------------------------------------------------
 # rt_run
 # ----------------------------------------------------------------------------
 class Scene:
-    """Everything `rt_run` needs, resident in HBM: per Fourier moment the layer optics
-    (τ, ϖ, dτ per layer and spectral point; Z per layer), interface tags, ndoubl, τ_sum.
-    Built once by `prepare_scene` (host numpy + H2D), executed by `run()` (device only).
+    """Everything `rt_run` needs, resident in HBM.  The raw optical depths (tau_rayl, tau_abs [nSpec, Nz], the aerosol
+    tables) are uploaded ONCE (`upload()`); `prepare()` then builds the layer-kernel inputs on the device: tau, varpi,
+    tau_sum per (point, layer), the per-point weights of the component phase matrices, max(tau*varpi) per layer
+    (vsm_layer_optics), the Fourier moments Z(m) of every scatterer (vsm_compute_Z_moments), and -- after ONE small D2H of
+    the per-layer maxima, from which the host derives ndoubl and the interface tags exactly like the reference's host
+    reductions (rt_kernel.jl:197,282-283; compEffectiveLayerProperties.jl:87) -- dtau = tau / 2^ndoubl (vsm_layer_dtau).
+    `run()` is device only.
 
-    `spec_slice` selects the spectral shard this rank owns; `ndoubl` and the interface tags
-    are always derived from the FULL spectral axis so that a sharded run is identical to
-    the single-device run (rt_kernel.jl:197,282-283 use batch-global maxima)."""
+    `spec_slice` selects the spectral shard this rank owns.  The optics pass always covers the FULL spectral axis (it is
+    O(nSpec Nz) elementwise work, microseconds) so that ndoubl and the tags are batch-global on every rank without a
+    collective; only the shard's columns feed the layer kernels.  `host_optics=True` builds the same inputs with the
+    host mirror (host_model.constructLayerOpticsComponents) instead -- kept as a cross-check."""
 
-    def __init__(self, model: H.RTModel, spec_slice: Optional[slice] = None):
+    def __init__(self, model: H.RTModel, spec_slice: Optional[slice] = None, host_optics: bool = False):
         arch, FT = model.architecture, model.float_type
         _require_gpu(arch)
         self.model, self.arch, self.FT = model, arch, FT
         pol, qp = model.polarization_type, model.quad_points
         self.pol, self.qp = pol, qp
         self.ss_correction = True   # Cox-Munk TMS term (tests switch it off to look at the Fourier-summed field)
+        self.host_optics = bool(host_optics)
         S_full, self.Nz = model.tau_rayl.shape
+        self.S_full = S_full
         self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
-        self.S = len(range(*self.sl.indices(S_full)))
+        self.lo, self.hi, _ = self.sl.indices(S_full)
+        self.hi = max(self.hi, self.lo)
+        self.S = self.hi - self.lo
         self.N = qp.Nquad * pol.n
         conv = array_type(arch)
+        dt, dev = _torch_dtype(FT), devi(arch)
+        self.dt, self.dev = dt, dev
         self.dq = device_quad(qp, pol, arch, FT)
         F0 = model.F0
         if F0 is None:
             F0 = np.zeros((pol.n, S_full))
             F0[0, :] = 1.0
         self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, self.sl].T))  # [n,S] col-major == (S,n)
+        N, S, L, C_ = self.N, self.S, self.Nz, 1 + len(model.aerosol_optics)
+        # device state of the optics pass (full spectral axis; layout [nSpec, Nz] column-major == tensors (Nz, nSpec))
+        z = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
+        self.tau, self.varpi, self.dtau, self.tau_sum = z(L, S_full), z(L, S_full), z(L, S_full), z(L + 1, S_full)
+        self.fcomp = z(L, S_full, C_) if C_ > 1 else None
+        self.max_tw = z(L)
+        self.nd_dev = torch.zeros(L, dtype=torch.int32, device=dev)
+        self.Zc = [(z(C_, N, N), z(C_, N, N)) for _ in range(model.m_max + 1)]
+        self.greek_dev = None
+        self.moments = []
+        # every layer scatters and N fits on chip -> all steps run in the fused kernels, which can derive
+        # r+-/t-- by D-symmetry instead of moving them through HBM (decided in prepare(), allocated lazily)
+        self.added = None
+        self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=True)
+        self.composite = make_composite_layer(FT, arch, (N, N), S)
+        # the interaction work buffer belongs to the scene (a captured graph must not point into a shared cache)
+        self.work = _lib.poison(torch.empty(max(int(_lib.lib().vsm_interaction_work_elems(N, max(S, 1))), 1), dtype=dt, device=dev))
+        nV = len(model.vza)
+        self.R_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        self.T_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        self.upload()
+        self.prepare()
+
+    # -- inputs -----------------------------------------------------------------------------------------------------------
+    def upload(self):
+        """H2D of the scene's raw inputs: tau_rayl, tau_abs [nSpec, Nz] (FP64, the reference's model arrays) and the small
+        aerosol / Greek tables.  Everything else is derived on the device by `prepare()`."""
+        model = self.model
+        conv = array_type(self.arch)
+        L, nA = self.Nz, len(model.aerosol_optics)
+        # numpy holds [S, L] row-major; the C ABI wants the reference's column-major [nSpec, Nz]: transpose on the device
+        self.tau_rayl_d = conv(np.asarray(model.tau_rayl, dtype=np.float64)).t().contiguous()
+        self.tau_abs_d = conv(np.asarray(model.tau_abs, dtype=np.float64)).t().contiguous()
+        if nA:
+            self.tau_aer_d = conv(np.ascontiguousarray(np.asarray(model.tau_aer, dtype=np.float64).T))   # (L, nAer)
+            self.ssa_d = conv(np.array([ao.ssa for ao in model.aerosol_optics], dtype=np.float64))
+            self.ftr_d = conv(np.array([ao.f_trunc for ao in model.aerosol_optics], dtype=np.float64))
+            modes, self.zcomp = H.layer_mix_modes(model)
+            self.mode_d = conv(np.ascontiguousarray(modes.T.astype(np.int32)))                          # (L, nAer)
+        else:
+            self.tau_aer_d = self.ssa_d = self.ftr_d = self.mode_d = None
+            self.zcomp = [(False, 0)] * L
+        if self.greek_dev is None:
+            self.greek_dev = []
+            for g in [model.greek_rayleigh] + [ao.greek_coefs for ao in model.aerosol_optics]:
+                tab = np.stack([np.asarray(getattr(g, k), dtype=np.float64) for k in
+                                ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")])
+                self.greek_dev.append((conv(np.ascontiguousarray(tab)), tab.shape[1]))
+
+    # -- device optics ----------------------------------------------------------------------------------------------------
+    def prepare(self):
+        model, FT, dt = self.model, self.FT, self.dt
+        qp, L, S_full, N = self.qp, self.Nz, self.S_full, self.N
+        nA = len(model.aerosol_optics)
+        if self.host_optics:
+            return self._prepare_host()
+        _lib.call("vsm_layer_optics", dt, S_full, L, nA, _ptr(self.tau_rayl_d), _ptr(self.tau_abs_d),
+                  C.c_double(float(model.varpi_Cabannes)), _ptr(self.tau_aer_d), _ptr(self.ssa_d), _ptr(self.ftr_d),
+                  _ptr(self.mode_d), _ptr(self.tau), _ptr(self.varpi), _ptr(self.tau_sum), _ptr(self.fcomp), _ptr(self.max_tw),
+                  _stream_ptr())
+        q = self.dq.cstruct()
+        for m in range(model.m_max + 1):
+            Zpp, Zmp = self.Zc[m]
+            for k, (gd, lmax) in enumerate(self.greek_dev):
+                _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, lmax, _ptr(gd), _ptr(Zpp[k]), _ptr(Zmp[k]), _stream_ptr())
+        mx = self.max_tw.cpu().numpy()          # the ONE device -> host hand-off of the optics pass (Nz scalars)
+        nds, tags, tag = [], [], "00"
+        for iz in range(L):
+            tw = FT(mx[iz])
+            scatter = bool(tw > 2 * np.finfo(FT).eps)
+            nds.append(H.ndoubl_from_max(tw, qp, FT, model.numerics) if scatter else 0)
+            tag = H.get_scattering_interface(tag, scatter, iz + 1)
+            tags.append(tag)
+        self.nd_dev.copy_(torch.as_tensor(np.asarray(nds, dtype=np.int32)))
+        _lib.call("vsm_layer_dtau", dt, S_full, L, _ptr(self.nd_dev), _ptr(self.tau), _ptr(self.dtau), _stream_ptr())
+        self._assemble(nds, tags, [float(v) for v in mx])
+
+    def _assemble(self, nds, tags, maxima):
+        """Per-moment / per-layer views into the optics tensors, as `run()` walks them."""
+        model, FT, L, lo, hi = self.model, self.FT, self.Nz, self.lo, self.hi
         self.moments = []
         for m in range(model.m_max + 1):
-            # layer optics with Z carried as per-point coefficients over the component phase matrices
-            # (Rayleigh, aerosols): nothing of size N^2 S is built on the host or shipped over PCIe
-            Zc_pp, Zc_mp, lods = H.constructLayerOpticsComponents(model, m)
-            tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
-            dZc_pp, dZc_mp = to_device_matrix(Zc_pp, arch, FT), to_device_matrix(Zc_mp, arch, FT)
+            Zpp, Zmp = self.Zc[m]
             layers = []
+            for iz in range(L):
+                mixed, k = self.zcomp[iz]
+                if mixed:
+                    Zp, Zm, fc = Zpp, Zmp, self.fcomp[iz, lo:hi]
+                else:
+                    Zp, Zm, fc = Zpp[k:k + 1], Zmp[k:k + 1], None
+                props = DeviceLayerOptics(self.tau[iz, lo:hi], self.varpi[iz, lo:hi], Zp, Zm, maxima[iz], None, None, fc)
+                layers.append(dict(props=props, iface=tags[iz], nd=nds[iz], dtau=self.dtau[iz, lo:hi],
+                                   tau_sum=self.tau_sum[iz, lo:hi]))
+            rho = None
+            if isinstance(model.surface, H.CoxMunkSurface):   # scene constant like Z(m): one N x N block per moment
+                rho, _ = reflectance(model.surface, self.dq, m, self.arch, FT)
+            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, tau_sum_surface=self.tau_sum[L, lo:hi]))
+        all11 = all(t == "11" for t in tags)
+        fused_ok = self.N <= _lib.lib().vsm_fused_max_n(8 if np.dtype(FT) == np.float64 else 4)
+        dsym = self.pol.n if (all11 and fused_ok) else 0
+        if self.added is None or self.added.d_symmetric != dsym:
+            self.added = make_added_layer(FT, self.arch, (self.N, self.N), self.S, d_symmetric=dsym)
+
+    def _prepare_host(self):
+        """The same inputs from the host mirror (numpy): the reference's own structure, per Fourier moment."""
+        model, FT, L, S_full = self.model, self.FT, self.Nz, self.S_full
+        conv = array_type(self.arch)
+        nds = tags = maxima = None
+        for m in range(model.m_max + 1):
+            Zc_pp, Zc_mp, lods = H.constructLayerOpticsComponents(model, m)
+            self.Zc[m][0].copy_(to_device_matrix(Zc_pp, self.arch, FT))
+            self.Zc[m][1].copy_(to_device_matrix(Zc_mp, self.arch, FT))
+            if m > 0:
+                continue
+            tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
+            nds, maxima = [], []
+            zcomp = []
             for iz, lo in enumerate(lods):
                 tau_full = np.atleast_1d(lo.tau).astype(FT)
                 varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
                 tw = float(np.max(tau_full * varpi_full))
                 scatter = tw > 2 * np.finfo(FT).eps
-                dtau_full, nd = (H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics) if scatter
-                                 else (tau_full, 0))
-                if lo.coef.ndim == 1:   # one scatterer: its Z is shared by all spectral points
-                    k = int(np.argmax(lo.coef))
-                    Zpp_d, Zmp_d, fcomp = dZc_pp[k:k + 1], dZc_mp[k:k + 1], None
+                dtau_full, nd = (H.get_dtau_ndoubl(tau_full, varpi_full, self.qp, FT, model.numerics) if scatter else (tau_full, 0))
+                nds.append(nd)
+                maxima.append(tw)
+                self.tau[iz].copy_(conv(tau_full))
+                self.varpi[iz].copy_(conv(np.ascontiguousarray(varpi_full)))
+                self.dtau[iz].copy_(conv(np.ascontiguousarray(dtau_full)))
+                self.tau_sum[iz].copy_(conv(tau_sum_all[:, iz].astype(FT)))
+                if lo.coef.ndim == 1:
+                    zcomp.append((False, int(np.argmax(lo.coef))))
                 else:
-                    Zpp_d, Zmp_d = dZc_pp, dZc_mp
-                    fcomp = conv(np.ascontiguousarray(lo.coef[self.sl].astype(FT)))
-                props = DeviceLayerOptics(conv(np.ascontiguousarray(tau_full[self.sl])),
-                                          conv(np.ascontiguousarray(varpi_full[self.sl])), Zpp_d, Zmp_d, tw,
-                                          tau_full, np.asarray(varpi_full), fcomp)
-                layers.append(dict(props=props, iface=tags[iz], nd=nd,
-                                   dtau=conv(np.ascontiguousarray(dtau_full[self.sl])),
-                                   tau_sum=conv(np.ascontiguousarray(tau_sum_all[self.sl, iz].astype(FT)))))
-            rho = None
-            if isinstance(model.surface, H.CoxMunkSurface):   # scene constant like Z(m): one N x N block per moment
-                rho, _ = reflectance(model.surface, self.dq, m, arch, FT)
-            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho,
-                                     tau_sum_surface=conv(np.ascontiguousarray(tau_sum_all[self.sl, -1].astype(FT)))))
-        N, S = self.N, self.S
-        # every layer scatters and N fits on chip -> all steps run in the fused kernels, which can derive
-        # r+-/t-- by D-symmetry instead of moving them through HBM
-        all11 = all(ly["iface"] == "11" for mom in self.moments for ly in mom["layers"])
-        fused_ok = N <= _lib.lib().vsm_fused_max_n(8 if np.dtype(FT) == np.float64 else 4)
-        self.added = make_added_layer(FT, arch, (N, N), S, d_symmetric=pol.n if (all11 and fused_ok) else 0)
-        self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=True)
-        self.composite = make_composite_layer(FT, arch, (N, N), S)
-        nV = len(model.vza)
-        dt, dev = _torch_dtype(FT), devi(arch)
-        self.R_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
-        self.T_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+                    zcomp.append((True, 0))
+                    self.fcomp[iz].copy_(conv(np.ascontiguousarray(lo.coef.astype(FT))))
+            self.tau_sum[L].copy_(conv(tau_sum_all[:, -1].astype(FT)))
+            self.zcomp = zcomp
+        self._assemble(nds, tags, maxima)
 
     def run(self, trace: Optional[list] = None):
         """The device-resident part of rt_run (rt_run.jl:383-517): Fourier loop -> layer loop ->
@@ -514,9 +618,10 @@ class Scene:
             weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
             for iz, ly in enumerate(mom["layers"]):
                 rt_kernel_(pol, self.added, self.composite, ly["props"], ly["iface"], ly["tau_sum"], m, self.dq,
-                           self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace)
+                           self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace,
+                           work=self.work)
             create_surface_layer_(model.surface, self.added_surface, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
-            interaction_(mom["iface_surface"], self.composite, self.added_surface)
+            interaction_(mom["iface_surface"], self.composite, self.added_surface, work=self.work)
             postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
                                 self.T_SFI)
         if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
@@ -529,6 +634,12 @@ class Scene:
         interaction, post-processing) is captured once and replayed -- for launch-bound scenes (few spectral points,
         small N) the replay removes the per-launch host cost; the results are the same device tensors as `run()`."""
         if getattr(self, "_graph", None) is None:
+            # every buffer a captured launch points at must belong to the scene: the interaction work tensor does
+            # (self.work); the library's grow-only scratch (Z materialisation of component-mixed layers outside the strip
+            # kernels, the non-"11" operator chains) does not, so such scenes are refused
+            if self.added.d_symmetric == 0 or any(ly["props"].fcomp is not None for ly in self.moments[0]["layers"]):
+                raise _lib.VSMError("run_graph(): only scenes that run entirely in the fused layer kernels (every layer "
+                                    "scattering, N within the on-chip limit, one scatterer per layer) can be captured")
             self.run()                      # warm-up outside the capture: lazy initialisation inside the library
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()

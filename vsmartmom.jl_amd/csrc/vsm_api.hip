@@ -623,3 +623,31 @@ VSM_LIN_API(float, f32)
   }
 VSM_SURF_API(double, f64)
 VSM_SURF_API(float, f32)
+
+// ---- per-scene layer optics --------------------------------------------------------------------------------------------
+#define VSM_OPT_API(T, SFX)                                                                                            \
+  extern "C" int vsm_compute_Z_moments_##SFX(const vsm_quad_##SFX* q, int m, int lmax, const double* greek, T* Zpp,    \
+                                             T* Zmp, void* stream) {                                                   \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q))) return rc;                                                                               \
+    VSM_REQUIRE(m >= 0 && lmax >= 0 && (greek || lmax == 0) && Zpp && Zmp && q->N % q->n_stokes == 0,                  \
+                "compute_Z_moments: bad argument");                                                                    \
+    return compute_Z_moments<T>(q->N / q->n_stokes, q->n_stokes, q->mu, m, lmax, greek, Zpp, Zmp, as_stream(stream));  \
+  }                                                                                                                    \
+  extern "C" int vsm_layer_optics_##SFX(int S, int L, int nAer, const double* tau_rayl, const double* tau_abs,         \
+                                        double varpi_cabannes, const double* tau_aer, const double* ssa,               \
+                                        const double* ftrunc, const int* mode, T* tau, T* varpi, T* tau_sum, T* fcomp, \
+                                        T* max_tau_varpi, void* stream) {                                              \
+    VSM_REQUIRE(S >= 0 && L >= 0 && nAer >= 0 && max_tau_varpi &&                                                      \
+                    (S == 0 || (tau_rayl && tau_abs && tau && varpi && tau_sum)) &&                                    \
+                    (nAer == 0 || (tau_aer && ssa && ftrunc && mode)),                                                 \
+                "layer_optics: bad argument");                                                                         \
+    return layer_optics<T>(S, L, nAer, tau_rayl, tau_abs, varpi_cabannes, tau_aer, ssa, ftrunc, mode, tau, varpi,      \
+                           tau_sum, fcomp, max_tau_varpi, as_stream(stream));                                          \
+  }                                                                                                                    \
+  extern "C" int vsm_layer_dtau_##SFX(int S, int L, const int* ndoubl, const T* tau, T* dtau, void* stream) {          \
+    VSM_REQUIRE(S >= 0 && L >= 0 && (S == 0 || L == 0 || (ndoubl && tau && dtau)), "layer_dtau: bad argument");       \
+    return layer_dtau<T>(S, L, ndoubl, tau, dtau, as_stream(stream));                                                  \
+  }
+VSM_OPT_API(double, f64)
+VSM_OPT_API(float, f32)

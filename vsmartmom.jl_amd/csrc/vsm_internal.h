@@ -109,6 +109,16 @@ template <typename T>
 int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, const T* mu_v_h, const T* dphi_h, T mu0, int m_max,
                           int nphi, const T* phi, const T* wphi, const T* tau_total, T* coef, T* R_SFI, hipStream_t st);
 
+// ---- per-scene layer optics on the device: vsm_optics.hip ----
+template <typename T>
+int compute_Z_moments(int Nq, int n_stokes, const T* muN, int m, int lmax, const double* greek, T* Zpp, T* Zmp, hipStream_t st);
+template <typename T>
+int layer_optics(int S, int L, int nAer, const double* tau_rayl, const double* tau_abs, double varpi_cab, const double* tau_aer,
+                 const double* ssa, const double* ftrunc, const int* mode, T* tau, T* varpi, T* tau_sum, T* fcomp, T* max_tw,
+                 hipStream_t st);
+template <typename T>
+int layer_dtau(int S, int L, const int* nd, const T* tau, T* dtau, hipStream_t st);
+
 // ---- fused (LDS-resident) path: vsm_fused.hip ---------------------------------
 template <typename T>
 int fused_max_n();

@@ -517,16 +517,47 @@ def doubling_number(dtau_max, tau_end, FT):
     return FT(10) ** (q3 - q1 * FT(nd)), nd
 
 
-def get_dtau_ndoubl(tau: np.ndarray, varpi: np.ndarray, qp: QuadPoints, FT, numerics: RTNumericalParameters):
-    """rt_kernel.jl:266-287.  Returns (dτ[S] in FT, ndoubl); ndoubl is batch-global by construction."""
+def ndoubl_from_max(tw, qp: QuadPoints, FT, numerics: RTNumericalParameters) -> int:
+    """The ndoubl rule of rt_kernel.jl:266-287 from tw = maximum(tau .* varpi) (already in FT)."""
     thr = FT(0.001 if numerics.dtau_max_threshold is None else numerics.dtau_max_threshold)
     floor_val = FT(1024 * np.finfo(FT).eps if numerics.dtau_min_floor is None else numerics.dtau_min_floor)
     real = qp.qp_mu[qp.wt_mu > np.finfo(FT).eps]
     mu_min = FT(np.min(real) if len(real) else np.min(qp.qp_mu))
-    tw = FT(np.max(tau.astype(FT) * varpi.astype(FT)))
+    tw = FT(tw)
     dtau_max = max(floor_val, min(tw, FT(thr * mu_min)))
     _, nd = doubling_number(dtau_max, tw, FT)
+    return nd
+
+
+def get_dtau_ndoubl(tau: np.ndarray, varpi: np.ndarray, qp: QuadPoints, FT, numerics: RTNumericalParameters):
+    """rt_kernel.jl:266-287.  Returns (dτ[S] in FT, ndoubl); ndoubl is batch-global by construction."""
+    nd = ndoubl_from_max(FT(np.max(tau.astype(FT) * varpi.astype(FT))), qp, FT, numerics)
     return (tau / FT(2 ** nd)).astype(FT), nd
+
+
+def layer_mix_modes(model: "RTModel"):
+    """How `rayleigh + createAero(...) + ...` (compEffectiveLayerProperties.jl:43-54) resolves per (aerosol, layer): the
+    mixing `+` (types.jl:1262-1292) branches on batch-global conditions -- 1: no spectral point scatters before this aerosol
+    (all tau_x varpi_x == 0) -> the sum takes the aerosol's Z; 2: the aerosol does not scatter -> Z unchanged; 0: per-point
+    mix.  Returns (modes int[nAer, Nz], per layer (mixed?, index of the single component whose Z the layer uses))."""
+    nA, L = len(model.aerosol_optics), model.tau_rayl.shape[1]
+    modes = np.zeros((nA, L), dtype=np.int32)
+    rayl_zero = np.all(np.asarray(model.tau_rayl) * float(model.varpi_Cabannes) == 0.0, axis=0)
+    zcomp = []
+    for l in range(L):
+        x_zero, mixed, k = bool(rayl_zero[l]), False, 0
+        for ia, ao in enumerate(model.aerosol_optics):
+            y = createAero(model.tau_aer[ia, l], ao, None, None)
+            wy_zero = bool(y.tau * y.varpi == 0.0)
+            if x_zero:
+                modes[ia, l], k, mixed = 1, ia + 1, False
+                x_zero = wy_zero
+            elif wy_zero:
+                modes[ia, l] = 2
+            else:
+                modes[ia, l], mixed = 0, True
+        zcomp.append((mixed, k))
+    return modes, zcomp
 
 
 # ---- linearized inputs (src/CoreRT/parameter_layout.jl:20-66, types_lin.jl:141-150) -------------------------
