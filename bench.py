@@ -4,9 +4,11 @@
 Workload (BASELINE.json configs[1], "C2"): O2-A band 759-770 nm, nStokes = 3, Nquad = 20
 (18 Gauss-Legendre + SZA 40 deg + VZA 30 deg => N = 60), 40 layers, 10 000 spectral points per GPU,
 FP64, Rayleigh (depol 0.0279) + synthetic O2-like absorption (40 pseudo-lines, column tau 1e-4..50),
-Lambertian 0.15, Fourier moments m = 0..2.   A "step" = one full rt_run pass over the batch:
-all m, all layers (elemental -> doubling -> interaction), surface, VZA post-processing, with the layer
-optics already resident in HBM.  N GPUs => N x 10 000 points (weak scaling), one RCCL gather of R/T.
+Lambertian 0.15, Fourier moments m = 0..2.   A "step" = one full rt_run-equivalent over the batch:
+H2D of the raw optical depths, layer optics on the device, all m, all layers (elemental -> doubling ->
+interaction), surface, VZA post-processing, ONE gather of R/T over the ranks and the D2H of the result.
+N GPUs => N x 10 000 points (weak scaling; `--total-points` = strong scaling).  `--gpus N` without a launcher
+starts its own N ranks (torch.distributed.run, one process per GPU over RCCL) or fails if N GPUs are not visible.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
 kernel (the fused layer step k_layer_strip; algorithmic flops / HIP-event launch time) and `cpu_baseline`
@@ -49,6 +51,13 @@ CONFIGS = {
 }
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +65,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--points", type=int, default=None, help="spectral points per GPU (default: config)")
+    ap.add_argument("--total-points", type=int, default=None,
+                    help="strong scaling: this many spectral points in total, split over the GPUs (C4: 100000)")
     ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--variant", default="rayleigh", choices=["rayleigh", "aerosol"],
                     help="aerosol: SURVEY 8(d) variant -- HG aerosol (g=0.7, ssa=0.95, tau=0.2) in the lowest 6 layers, "
@@ -65,18 +76,32 @@ def main():
     args = ap.parse_args()
 
     import torch
+    # --gpus N without a launcher: start the N ranks ourselves (one process per GPU over RCCL), or fail loudly
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit("bench.py: --gpus %d requested but only %d GPU(s) are visible -- refusing to report a smaller run" % (args.gpus, have))
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
+                  + sys.argv[1:])
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match the launcher's WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE")))
+
     import vsmartmom_jl_amd as vsm
     from vsmartmom_jl_amd import parallel
 
     rank, world, local = parallel.init_process_group_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
     cfg = dict(CONFIGS[args.config])
     if args.points:
         cfg["S"] = args.points
     if args.layers:
         cfg["L"] = args.layers
+    scaling = "weak"
+    if args.total_points:
+        scaling = "strong"
+        if args.total_points % world:
+            sys.exit("bench.py: --total-points must be divisible by --gpus")
+        cfg["S"] = args.total_points // world
     FT = np.float64 if cfg["FT"] == "f64" else np.float32
     S_local, L = cfg["S"], cfg["L"]
     S_total = S_local * world
@@ -99,21 +124,41 @@ def main():
     N = model.quad_points.Nquad * model.polarization_type.n
     assert N == cfg["N"], (N, cfg["N"])
     sl = parallel.shard_slice(S_total, rank, world)
-    t_prep = time.time()
-    scene = vsm.CoreRT.prepare_scene(model, sl)
+    scene = vsm.CoreRT.prepare_scene(model, sl)     # allocations (the reference's make_added_layer / make_composite_layer)
     torch.cuda.synchronize()
-    t_prep = time.time() - t_prep
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def step():
+    phase = {"h2d": 0.0, "optics": 0.0, "run": 0.0, "gather_d2h": 0.0}
+
+    def step(split=False):
+        """One rt_run-equivalent: H2D of the raw optical depths, layer optics on the device, all Fourier
+        moments x layers x (elemental -> doubling -> interaction), surface, post-processing, ONE gather of R/T over the
+        ranks, D2H of the result on rank 0.  `split` adds synchronisations to attribute the time to phases (untimed pass)."""
+        t = [time.perf_counter()]
+
+        def mark():
+            if split:
+                torch.cuda.synchronize()
+                t.append(time.perf_counter())
+
+        scene.upload()
+        mark()
+        scene.prepare()
+        mark()
         R, T = scene.run()
-        Rg = parallel.gather_spectral(R, S_total, rank, world)   # RCCL gather of R/T at the end
-        Tg = parallel.gather_spectral(T, S_total, rank, world)
-        return Rg, Tg
+        mark()
+        packed = torch.cat([R.reshape(R.shape[0], -1), T.reshape(T.shape[0], -1)], dim=1)
+        g = parallel.gather_spectral(packed, S_total, rank, world)   # the one collective (RCCL) of the data path
+        out = g.cpu() if g is not None else None                     # D2H of R/T [nVZA, nStokes, nSpec] on rank 0
+        mark()
+        if split:
+            for k, a, b in zip(phase, t[:-1], t[1:]):
+                phase[k] = b - a
+        return out
 
     for _ in range(args.warmup):
         step()
@@ -127,9 +172,10 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+    step(split=True)   # phase attribution, outside the timed region
 
     # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
-    # one extra pass with an event pair around every k_elemental_doubling launch
+    # one extra pass with an event pair around every layer-step launch; the same pass gives the device-only time of run()
     ev = []
     orig = vsm.CoreRT.layer_forward_
 
@@ -141,9 +187,13 @@ def main():
         ev.append((e0, e1, a[5], a[7]))  # ndoubl, toa
 
     vsm.CoreRT.layer_forward_ = timed
+    r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    r0.record()
     scene.run()
+    r1.record()
     torch.cuda.synchronize()
     vsm.CoreRT.layer_forward_ = orig
+    run_ms = r0.elapsed_time(r1)
     n3, n2 = float(N) ** 3, float(N) ** 2
     k_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ev)
     # algorithmic flops of one layer step: nd doublings + (unless TOA) one _11 interaction
@@ -166,16 +216,21 @@ def main():
             "metric": "spectral-points/s (whole node) for rt_run, O2-A band",
             "value": pts_per_s, "unit": "spectral-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": cfg["FT"], "data": "synthetic",
+            "scaling": scaling, "vs_baseline": None, "dtype": cfg["FT"], "data": "synthetic",
             "config": {"workload": "%s: O2-A 759-770 nm, nStokes=3, Nquad=%d (N=%d), %d layers, %d spectral points/GPU, "
                                    "m=0..%d, Rayleigh%s+synthetic O2 absorption, Lambertian 0.15" %
                                    (args.config, model.quad_points.Nquad, N, L, S_local, m_max,
                                     "+HG aerosol (lowest 6 layers)" if args.variant == "aerosol" else ""),
+                       "timed_step": "full rt_run-equivalent: H2D of tau_rayl/tau_abs + device layer optics + all moments/layers/"
+                                     "surface/post-processing + gather + D2H of R,T",
+                       "ranks": world, "collective_backend": "nccl (RCCL)" if world > 1 else "none (1 rank)",
                        "N": N, "layers": L, "points_per_gpu": S_local, "fourier_moments": m_max + 1,
                        "ndoubl_per_layer": nds, "algorithmic_gflop_per_point": flops_pt / 1e9,
                        "whole_run_tflops": pts_per_s * flops_pt / 1e12,
                        "whole_run_frac_of_mfma_peak": pts_per_s * flops_pt / 1e12 / (peak * world),
-                       "prepare_scene_s (host optics + H2D, untimed)": t_prep},
+                       "phase_ms (one extra untimed pass with syncs)": {k: 1e3 * v for k, v in phase.items()},
+                       "device_pass_ms (run() only, HIP events)": run_ms,
+                       "device_pass_points_per_s_per_gpu": S_local / (run_ms * 1e-3)},
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
