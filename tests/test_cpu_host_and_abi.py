@@ -181,6 +181,62 @@ def test_two_rank_gloo_shard_and_gather():
     assert res == (True, True, (2, 3, 9))
 
 
+def _worker_lin(rank, world, port, q):
+    """One rank of the gloo test of the sharded LINEARIZED run: rt_run_lin_sharded gathers R, T, Rdot, Tdot in one collective.
+    The HIP engine is replaced by the oracle (Cox-Munk ocean, gas + wind-speed slots) evaluated on the full axis and cut to
+    the rank's block -- the contract SceneLin implements (ndoubl / tags from the full spectral axis)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import vsmartmom_jl_amd as v
+    from oracle import vsm_oracle as Oo
+    from oracle import vsm_oracle_lin as OLl
+    from oracle import vsm_oracle_coxmunk as CMm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, L = 5, 2                      # 5 points over 2 ranks: blocks of 3 and 2 (padding in the gather)
+    rng = np.random.default_rng(1)
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, -1, (S, L))
+    g = tau_abs * rng.uniform(0.5, 1.5, (S, L))
+    geo = ("IQU", 5, 30.0, [20.0, 50.0], [0.0, 180.0])
+    surf = v.host_model.CoxMunkSurface(wind_speed=6.0)
+    model = v.host_model.model_from_arrays(v.Architectures.CPU(), *geo, tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03,
+                                           m_max=3, surface=surf)
+    om = Oo.build_model(*geo, tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, m_max=3)
+    full = CMm.rt_run_lin(om, OLl.LinModel([g]), CMm.CoxMunkSurface(6.0))
+
+    def oracle_executor(mdl, lin, sl):
+        R, T, Rd, Td = full
+        t3 = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, :, sl].transpose(2, 1, 0)))
+        t4 = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, :, sl, :].transpose(3, 2, 1, 0)))
+        return t3(R), t3(T), t4(Rd), t4(Td)
+
+    out = v.parallel.rt_run_lin_sharded(model, v.host_model.LinModel([g]), 0, 1, 1, executor=oracle_executor, rank=rank, world=world)
+    if rank == 0:
+        q.put(tuple(bool(np.array_equal(a, b)) for a, b in zip(out, full)) + (out[2].shape,))
+    else:
+        assert all(x is None for x in out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_linearized_shard_and_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_lin, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == (True, True, True, True, (2, 3, 5, 2))
+
+
 def test_scene_uses_global_ndoubl_for_shards(vsm):
     """`ndoubl` of a shard must come from the full spectral axis (rt_kernel.jl:197,282-283 are batch-global)."""
     H = vsm.host_model
@@ -193,7 +249,8 @@ def test_scene_uses_global_ndoubl_for_shards(vsm):
     first_half_alone = H.get_dtau_ndoubl(lods[0].tau[:4], np.broadcast_to(np.asarray(lods[0].varpi)[...,None] if np.ndim(lods[0].varpi)==0 else lods[0].varpi[:4], (4,)), m.quad_points, np.float64, m.numerics)[1]
     assert full == first_half_alone + 6
     src = open(os.path.join(ROOT, "vsmartmom.jl_amd", "core_rt.py")).read()
-    assert "get_dtau_ndoubl(tau_full, varpi_full" in src  # Scene derives ndoubl before slicing
+    # Scene runs the optics pass (and the per-layer maxima that decide ndoubl) over the FULL spectral axis, then slices
+    assert '_lib.call("vsm_layer_optics", dt, S_full, L' in src and "self.tau[iz, lo:hi]" in src
 
 
 def test_raman_halo_slices(vsm):

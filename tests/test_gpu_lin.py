@@ -184,3 +184,30 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     fd = (Rp - R0) / h
     err = np.abs(fd - Rd[..., 2]) / np.abs(fd).max()
     assert err.max() < 1e-3 and err.mean() < 1e-4
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 7, 21, 57
+def test_rt_run_lin_fp32(vsm, arch, pol, l_trunc):
+    """The FP32 linearized entry points (vsm_*_lin_f32; FP32 runs operator level): rt_run(model, lin_model, 0, 2, 1) in
+    Float32 vs the FP64 oracle at the reference's FP32 gate (test/test_float32.jl:58-64: max relative deviation < 1e-2;
+    observed ~1e-5) for R, T and every Jacobian column, and the layer operators vs the FP32 oracle."""
+    rng = np.random.default_rng(0)
+    S, L = 3, 3
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))
+    ga, gb = 10.0 ** rng.uniform(-2.5, -0.5, (S, L)), 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    H = vsm.host_model
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga + gb, depol=0.0279, m_max=2)
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    pm = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, float_type=np.float32, **kw)
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga, gb]))
+    R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga, gb]), 0, 2, 1)
+    assert R.dtype == np.float32 and Rd.dtype == np.float32 and Rd.shape == Rdo.shape
+    assert _rel(R, Ro) < 1e-2 and _rel(T, To) < 1e-2
+    for p in range(3):
+        assert _rel(Rd[..., p], Rdo[..., p]) < 1e-2 and _rel(Td[..., p], Tdo[..., p]) < 1e-2, p
+    # tighter: the same scene through the FP32 oracle (same ndoubl rule with the FP32 floor) -- rounding-level agreement
+    om32 = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, FT=np.float32, **kw)
+    R32, T32, Rd32, Td32 = OL.rt_run_lin(om32, OL.LinModel([ga, gb]))
+    assert _rel(R, R32) < 5e-4 and _rel(T, T32) < 5e-4
+    for p in range(3):
+        assert _rel(Rd[..., p], Rd32[..., p]) < 2e-3 and _rel(Td[..., p], Td32[..., p]) < 2e-3, p
