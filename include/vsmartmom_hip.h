@@ -75,6 +75,15 @@ int vsm_batched_mul_f32(int M, int Nc, int K, int S, const float* A, long long s
 int vsm_batch_inv_f64(int N, int S, const double* A, double* X, int* info, void* stream);
 int vsm_batch_inv_f32(int N, int S, const float* A, float* X, int* info, void* stream);
 
+/* batch_solve!(X, A, B) (ext/gpu_batched_cuda.jl:72-94 getrf+getrs; CPU: cpu_batched.jl:25-29): X[:,:,s] = A[:,:,s] \ B[:,:,s],
+ * A [N,N,S], B and X [N,Nrhs,S].  Executed as the pivoted Gauss-Jordan inverse of vsm_batch_inv into `work` (N*N*S elements)
+ * followed by one batched product; A and B are not clobbered; X must not alias B.  info as in vsm_batch_inv.  (Unused on
+ * the reference's forward hot path; exported because it is part of the operator API a backend extension provides.) */
+int vsm_batch_solve_f64(int N, int Nrhs, int S, const double* A, const double* B, double* X, double* work, int* info,
+                        void* stream);
+int vsm_batch_solve_f32(int N, int Nrhs, int S, const float* A, const float* B, float* X, float* work, int* info,
+                        void* stream);
+
 /* ---- L2 CoreKernel API ----------------------------------------------------
  * Layer state containers (src/CoreRT/types.jl:155-230 AddedLayer / CompositeLayer). */
 typedef struct vsm_added_f64 {

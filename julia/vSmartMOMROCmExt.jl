@@ -1,114 +1,198 @@
-# vSmartMOMROCmExt.jl -- reference-side binding for libvsmartmom_hip.so (NOT executed in this repo:
-# Julia is not available in the build image).  It mirrors the method table of
-# ext/vSmartMOMCUDAExt.jl + ext/gpu_batched_cuda.jl for an AMD array type `ROCArray`
-# (AMDGPU.jl provides allocation / H2D / D2H only; no rocBLAS, no KernelAbstractions).
-#
-# Drop it under ext/, add to Project.toml:  [weakdeps] AMDGPU = "..."; [extensions] vSmartMOMROCmExt = "AMDGPU"
+# vSmartMOMROCmExt.jl -- reference-side binding of libvsmartmom_hip.so (C ABI: include/vsmartmom_hip.h).
+# NOT executed in this repo (no Julia in the build image); it is the method table a maintainer drops under ext/ --
+# the counterpart of ext/vSmartMOMCUDAExt.jl + ext/gpu_batched_cuda.jl for an AMD array type (`ROCArray`; AMDGPU.jl
+# provides allocation / H2D / D2H only: no rocBLAS, no KernelAbstractions).  Project.toml: [weakdeps] AMDGPU,
+# [extensions] vSmartMOMROCmExt = "AMDGPU".  Every method is a plain `ccall`; the kernels behind an entry point are
+# chosen inside the library from N and the float type.  rt_run(model) and rt_run(model, lin_model, NAer, NGas, NSurf)
+# reach these methods through the reference's own drivers (rt_run.jl:383-517, rt_run_lin.jl:200-322): see INTEGRATION.md.
 module vSmartMOMROCmExt
 
 using AMDGPU
 using vSmartMOM
 import vSmartMOM.Architectures: devi, array_type, architecture, GPU, _has_cuda, _sync_gpu
-import vSmartMOM.CoreRT: batched_mul, batch_inv!, batch_solve!, batched_pointer_cache,
-                         elemental!, doubling!, interaction!, AddedLayer, CompositeLayer,
-                         ScatteringInterface_00, ScatteringInterface_01, ScatteringInterface_10,
-                         ScatteringInterface_11
+import vSmartMOM.CoreRT: batched_mul, batch_inv!, batch_solve!, batched_pointer_cache, elemental!, doubling!,
+    doubling_allparams!, interaction!, rt_kernel!, create_surface_layer!, postprocessing_vza!, copy_added_to_composite!,
+    AddedLayer, CompositeLayer, AddedLayerLin, CompositeLayerLin, AddedLayerRS, CompositeLayerRS, noRS, RRS,
+    LambertianSurfaceScalar, CoxMunkSurface, QuadPoints, CoreScatteringOpticalProperties,
+    CoreScatteringOpticalPropertiesLin, ScatteringInterface_00, ScatteringInterface_01, ScatteringInterface_10,
+    ScatteringInterface_11, get_dtau_ndoubl, _get_n_water
 
 const libvsm = get(ENV, "VSMARTMOM_HIP_LIB", "libvsmartmom_hip.so")
-
+const FTs = Union{Float32,Float64}
+const PV = Ptr{Cvoid}
+_sfx(::Type{Float64}) = "f64"
+_sfx(::Type{Float32}) = "f32"
+_fn(base, FT) = Symbol(base, "_", _sfx(FT))            # e.g. :vsm_interaction_f64 (resolved by dlsym at call time)
 @inline function _chk(rc::Cint)
-    rc == 0 || error("libvsmartmom_hip: status $rc: " *
-                     unsafe_string(ccall((:vsm_last_error, libvsm), Cstring, ())))
+    rc == 0 || error("libvsmartmom_hip: status $rc: " * unsafe_string(ccall((:vsm_last_error, libvsm), Cstring, ())))
     nothing
 end
-_stream() = Ptr{Cvoid}(AMDGPU.stream().stream)           # hipStream_t of the current task
-_p(A::ROCArray) = Ptr{Cvoid}(pointer(A))
+_call(f::Symbol, types::Tuple, args...) = _chk(ccall(Libdl.dlsym(Libdl.dlopen(libvsm), f), Cint, types, args...))
+_stream() = PV(AMDGPU.stream().stream)                  # hipStream_t of the current task
+_p(A::ROCArray) = PV(pointer(A))
+_p(::Nothing) = C_NULL
 
-# ---- Architectures.jl:68-96 ----------------------------------------------------------------
+# ---- Architectures.jl:68-96 / vSmartMOMCUDAExt.jl:21-27,46-57 ------------------------------------------------------
 array_type(::GPU) = ROCArray
 architecture(::ROCArray) = GPU()
 function __init__()
     n = Ref{Cint}(0)
     if ccall((:vsm_device_count, libvsm), Cint, (Ref{Cint},), n) == 0 && n[] > 0
-        _has_cuda[] = true                                 # "a GPU backend is present"
-        _sync_gpu[] = () -> _chk(ccall((:vsm_sync, libvsm), Cint, (Ptr{Cvoid},), _stream()))
+        _has_cuda[] = true
+        _sync_gpu[] = () -> _chk(ccall((:vsm_sync, libvsm), Cint, (PV,), _stream()))
     else
-        @warn "vSmartMOMROCmExt: no MI355X visible; staying on CPU"   # vSmartMOMCUDAExt.jl:59-62
+        @warn "vSmartMOMROCmExt: no MI355X visible; staying on CPU"      # vSmartMOMCUDAExt.jl:59-62
     end
 end
 
-# ---- gpu_batched_cuda.jl:208-233 ---------------------------------------------------------------
-for (FT, sfx) in ((Float64, :f64), (Float32, :f32))
-    mul = Symbol(:vsm_batched_mul_, sfx); inv = Symbol(:vsm_batch_inv_, sfx)
-    ia  = Symbol(:vsm_interaction_, sfx); ed = Symbol(:vsm_elemental_doubling_, sfx)
-    @eval begin
-        function batched_mul(A::ROCArray{$FT,3}, B::ROCArray{$FT,3})
-            M, K, S = size(A); Nc = size(B, 2)
-            C = ROCArray{$FT}(undef, M, Nc, S)
-            _chk(ccall(($(QuoteNode(mul)), libvsm), Cint,
-                       (Cint, Cint, Cint, Cint, Ptr{Cvoid}, Clonglong, Ptr{Cvoid}, Clonglong, Ptr{Cvoid}, Ptr{Cvoid}),
-                       M, Nc, K, S, _p(A), M * K, _p(B), size(B, 3) == 1 ? 0 : K * Nc, _p(C), _stream()))
-            C
-        end
-        # gpu_batched_cuda.jl:97-182 (all three call forms land here; A is not clobbered)
-        function batch_inv!(X::ROCArray{$FT,3}, A::ROCArray{$FT,3}, args...)
-            N, _, S = size(A)
-            _chk(ccall(($(QuoteNode(inv)), libvsm), Cint,
-                       (Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cint}, Ptr{Cvoid}),
-                       N, S, _p(A), _p(X), C_NULL, _stream()))
-            X
-        end
-    end
-end
-batched_pointer_cache(::ROCArray) = nothing                # route to the 2-arg inverse
-
-# ---- CoreKernel overrides (north_star: no KernelAbstractions on this backend) --------------------
-struct VsmAdded;     r_mp::Ptr{Cvoid}; t_pp::Ptr{Cvoid}; r_pm::Ptr{Cvoid}; t_mm::Ptr{Cvoid}
-                     j0_p::Ptr{Cvoid}; j0_m::Ptr{Cvoid}; mat_stride::Clonglong
-                     d_symmetric::Cint; reserved::Cint end          # = vsm_added_f64 / _f32
-struct VsmComposite; R_mp::Ptr{Cvoid}; R_pm::Ptr{Cvoid}; T_pp::Ptr{Cvoid}; T_mm::Ptr{Cvoid}
-                     J0_p::Ptr{Cvoid}; J0_m::Ptr{Cvoid} end
-_c(a::AddedLayer) = VsmAdded(_p(a.r⁻⁺), _p(a.t⁺⁺), _p(a.r⁺⁻), _p(a.t⁻⁻), _p(a.j₀⁺), _p(a.j₀⁻),
-                             size(a.r⁻⁺, 3) == 1 ? 0 : size(a.r⁻⁺, 1)^2, 0, 0)
+# ---- C structs (include/vsmartmom_hip.h) -------------------------------------------------------------------------------
+struct VsmQuad{FT}; mu::PV; wt::PV; N::Cint; n_stokes::Cint; i_mu0::Cint; mu0::FT end
+struct VsmAdded; r_mp::PV; t_pp::PV; r_pm::PV; t_mm::PV; j0_p::PV; j0_m::PV; mat_stride::Clonglong; d_symmetric::Cint; reserved::Cint end
+struct VsmComposite; R_mp::PV; R_pm::PV; T_pp::PV; T_mm::PV; J0_p::PV; J0_m::PV end
+struct VsmAddedLin; r_mp::PV; t_pp::PV; r_pm::PV; t_mm::PV; J0_p::PV; J0_m::PV; P::Cint; reserved::Cint; mat_stride::Clonglong end
+struct VsmCompositeLin; R_mp::PV; R_pm::PV; T_pp::PV; T_mm::PV; J0_p::PV; J0_m::PV; P::Cint; reserved::Cint end
+struct VsmAddedRS; ier_mp::PV; iet_pp::PV; ier_pm::PV; iet_mm::PV; ieJ0_p::PV; ieJ0_m::PV; K::Cint; reserved::Cint end
+struct VsmCompositeRS; ieR_mp::PV; ieR_pm::PV; ieT_pp::PV; ieT_mm::PV; ieJ0_p::PV; ieJ0_m::PV; K::Cint; reserved::Cint end
+struct VsmRRS; shift::PV; varpi_ie::PV; fscatt::PV; Zpp::PV; Zmp::PV end
+struct VsmCoxMunk{FT}; wind_speed::FT; n_re::FT; n_im::FT; whitecap_albedo::FT; include_whitecaps::Cint; shadowing::Cint end
+_ms(A) = size(A, 3) == 1 ? 0 : size(A, 1)^2             # slice stride; 0 = one block shared by all spectral points
+_q(qp::QuadPoints, n, ::Type{FT}) where {FT} = VsmQuad{FT}(_p(qp.qp_μN), _p(qp.wt_μN), length(qp.qp_μN), n, qp.iμ₀ - 1, FT(qp.μ₀))
+_c(a::AddedLayer) = VsmAdded(_p(a.r⁻⁺), _p(a.t⁺⁺), _p(a.r⁺⁻), _p(a.t⁻⁻), _p(a.j₀⁺), _p(a.j₀⁻), _ms(a.r⁻⁺), 0, 0)
 _c(c::CompositeLayer) = VsmComposite(_p(c.R⁻⁺), _p(c.R⁺⁻), _p(c.T⁺⁺), _p(c.T⁻⁻), _p(c.J₀⁺), _p(c.J₀⁻))
+_c(a::AddedLayerLin) = VsmAddedLin(_p(a.ap_ṙ⁻⁺), _p(a.ap_ṫ⁺⁺), _p(a.ap_ṙ⁺⁻), _p(a.ap_ṫ⁻⁻), _p(a.ap_J̇₀⁺), _p(a.ap_J̇₀⁻),
+                                   size(a.ap_ṙ⁻⁺, 4), 0, _ms(a.ap_ṙ⁻⁺))
+_c(c::CompositeLayerLin) = VsmCompositeLin(_p(c.Ṙ⁻⁺), _p(c.Ṙ⁺⁻), _p(c.Ṫ⁺⁺), _p(c.Ṫ⁻⁻), _p(c.J̇₀⁺), _p(c.J̇₀⁻), size(c.Ṙ⁻⁺, 4), 0)
+_crs(a) = VsmAddedRS(_p(a.ier⁻⁺), _p(a.iet⁺⁺), _p(a.ier⁺⁻), _p(a.iet⁻⁻), _p(a.ieJ₀⁺), _p(a.ieJ₀⁻), size(a.ier⁻⁺, 4), 0)
+_Crs(c) = VsmCompositeRS(_p(c.ieR⁻⁺), _p(c.ieR⁺⁻), _p(c.ieT⁺⁺), _p(c.ieT⁻⁻), _p(c.ieJ₀⁺), _p(c.ieJ₀⁻), size(c.ieR⁻⁺, 4), 0)
 _tag(::ScatteringInterface_00) = 0; _tag(::ScatteringInterface_01) = 1
 _tag(::ScatteringInterface_10) = 2; _tag(::ScatteringInterface_11) = 3
+_work(FT, f::Symbol, dims...) = ROCArray{FT}(undef, max(1, Int(ccall((f, libvsm), Csize_t, ntuple(_ -> Cint, length(dims)), dims...))))
 
-# interaction.jl:268-285
-function interaction!(iface, SFI, c::CompositeLayer{FT}, a::AddedLayer{FT}, I_static) where {FT}
+# ---- L1 operator API: gpu_batched_cuda.jl:65-233 -----------------------------------------------------------------------
+function batched_mul(A::ROCArray{FT,3}, B::ROCArray{FT,3}) where {FT<:FTs}
+    M, K, S = size(A); Nc = size(B, 2)
+    C = ROCArray{FT}(undef, M, Nc, S)
+    _call(_fn("vsm_batched_mul", FT), (Cint, Cint, Cint, Cint, PV, Clonglong, PV, Clonglong, PV, PV),
+          M, Nc, K, S, _p(A), M * K, _p(B), size(B, 3) == 1 && S > 1 ? 0 : K * Nc, _p(C), _stream())
+    C
+end
+function batch_inv!(X::ROCArray{FT,3}, A::ROCArray{FT,3}, args...) where {FT<:FTs}     # all three call forms; A intact
+    _call(_fn("vsm_batch_inv", FT), (Cint, Cint, PV, PV, PV, PV), size(A, 1), size(A, 3), _p(A), _p(X), C_NULL, _stream()); X
+end
+function batch_solve!(X::ROCArray{FT,3}, A::ROCArray{FT,3}, B::ROCArray{FT,3}) where {FT<:FTs}
+    _call(_fn("vsm_batch_solve", FT), (Cint, Cint, Cint, PV, PV, PV, PV, PV, PV), size(A, 1), size(B, 2), size(A, 3),
+          _p(A), _p(B), _p(X), _p(similar(A)), C_NULL, _stream()); X
+end
+batched_pointer_cache(::ROCArray) = nothing              # route batch_inv! to the 2-argument form
+
+# ---- L2 CoreKernel, forward (north_star: host-level functions are overridden, no KernelAbstractions kernels run) ------
+# elemental! (elemental.jl:174-230)
+function elemental!(pol_type, SFI::Bool, τ_sum::ROCArray, dτ::ROCArray, F₀::ROCArray, p::CoreScatteringOpticalProperties,
+                    m::Int, ndoubl::Int, scatter::Bool, qp::QuadPoints, a::AddedLayer{FT}, arch) where {FT<:FTs}
+    _call(_fn("vsm_elemental", FT), (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Ref{VsmAdded}, PV),
+          _q(qp, pol_type.n, FT), length(dτ), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺), _ms(p.Z⁺⁺), _c(a), _stream())
+end
+# doubling! (doubling.jl:121-131); expk is squared in place ndoubl times like the reference
+function doubling!(pol_type, SFI, expk::ROCArray{FT}, ndoubl::Int, a::AddedLayer, I_static, arch) where {FT<:FTs}
+    N, _, S = size(a.r⁻⁺)
+    _call(_fn("vsm_doubling", FT), (Cint, Cint, Cint, Cint, PV, Ref{VsmAdded}, PV, PV), N, pol_type.n, S, ndoubl, _p(expk), _c(a),
+          _p(_work(FT, :vsm_doubling_work_elems, N, S)), _stream())
+end
+# interaction! (interaction.jl:278-285); `work` is required off the fused "11" path, so it is always supplied
+function interaction!(iface, SFI, c::CompositeLayer{FT}, a::AddedLayer{FT}, I_static) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺)
-    f = FT === Float64 ? :vsm_interaction_f64 : :vsm_interaction_f32
-    _chk(ccall((f, libvsm), Cint, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmAdded}, Ptr{Cvoid}, Ptr{Cvoid}),
-               _tag(iface), N, S, _c(c), _c(a), C_NULL, _stream()))
+    _call(_fn("vsm_interaction", FT), (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV, PV), _tag(iface), N, S, _c(c), _c(a),
+          _p(_work(FT, :vsm_interaction_work_elems, N, S)), _stream())
 end
-# elemental! (elemental.jl:174-230) stores its inputs; doubling! (doubling.jl:112-131) then launches the fused
-# vsm_elemental_doubling_* with them -- see INTEGRATION.md for the two-line patch in rt_kernel!.
+function copy_added_to_composite!(c::CompositeLayer{FT}, a::AddedLayer{FT}) where {FT<:FTs}
+    _call(_fn("vsm_copy_added_to_composite", FT), (Cint, Cint, Ref{VsmAdded}, Ref{VsmComposite}, PV), size(c.R⁻⁺, 1), size(c.R⁻⁺, 3), _c(a), _c(c), _stream())
+end
+# rt_kernel!(::noRS) (rt_kernel.jl:175-250): the scattering branch of a "11" / TOA layer is ONE call (elemental! + doubling! +
+# copy | interaction!); the other branches keep the reference's sequence, whose pieces are the methods above.
+function rt_kernel!(RS::noRS{FT}, pol_type, SFI, a::AddedLayer{FT}, c::CompositeLayer{FT}, p::CoreScatteringOpticalProperties,
+                    iface, τ_sum::ROCArray, m, qp, I_static, arch, qp_μN, iz; workspace=nothing, prepared_sources=nothing,
+                    dτ_max_threshold=nothing, dτ_min_floor=nothing) where {FT<:FTs}
+    scatter = maximum(Array(p.τ .* p.ϖ)) > 2eps(FT)
+    if scatter && (iz == 1 || iface isa ScatteringInterface_11)
+        dτ, ndoubl = get_dtau_ndoubl(p, qp; dτ_max_threshold, dτ_min_floor)
+        return _call(_fn("vsm_layer_forward", FT),
+                     (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV),
+                     _q(qp, pol_type.n, FT), length(τ_sum), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(RS.F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺),
+                     _ms(p.Z⁺⁺), iz == 1 ? 1 : 0, _c(c), _c(a), _stream())
+    end
+    invoke(rt_kernel!, Tuple{noRS, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any}, RS, pol_type, SFI, a, c, p, iface,
+           τ_sum, m, qp, I_static, arch, qp_μN, iz; workspace, dτ_max_threshold, dτ_min_floor)
+end
 
-# rt_kernel!(::noRS) scattering branch (rt_kernel.jl:204-249) as ONE call: elemental! + doubling! + (TOA copy | interaction!(_11))
-struct VsmQuad{FT}; mu::Ptr{Cvoid}; wt::Ptr{Cvoid}; N::Cint; n_stokes::Cint; i_mu0::Cint; mu0::FT end
-function layer_forward!(q::VsmQuad{Float64}, nSpec, m, ndoubl, dτ, ϖ, τ_sum, F₀, Z⁺⁺, Z⁻⁺, iz,
-                        c::CompositeLayer{Float64}, a::AddedLayer{Float64})
-    zs = size(Z⁺⁺, 3) == 1 ? 0 : size(Z⁺⁺, 1)^2
-    _chk(ccall((:vsm_layer_forward_f64, libvsm), Cint,
-               (Ref{VsmQuad{Float64}}, Cint, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid},
-                Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, Ptr{Cvoid}),
-               q, nSpec, m, ndoubl, _p(dτ), _p(ϖ), _p(τ_sum), _p(F₀), _p(Z⁺⁺), _p(Z⁻⁺), zs, iz == 1 ? 1 : 0, _c(c), _c(a),
-               _stream()))
+# ---- surfaces + post-processing ------------------------------------------------------------------------------------------
+function create_surface_layer!(s::LambertianSurfaceScalar{FT}, a::AddedLayer, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
+    _call(_fn("vsm_lambertian_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, FT, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT),
+          length(τ_sum), m, s.albedo, _p(τ_sum), _c(a), _stream())
+end
+_cm(s::CoxMunkSurface{FT}) where {FT} = (n = _get_n_water(s, FT(550)); VsmCoxMunk{FT}(s.wind_speed, real(n), imag(n), s.whitecap_albedo, s.include_whitecaps, s.shadowing))
+const _ϕw = Dict{DataType,Any}()                        # 100-point Gauss-Legendre on [0, π] (coxmunk_surface.jl:394), device copy
+_phi(FT) = get!(() -> map(x -> ROCArray(FT.(x)), vSmartMOM.CoreRT.CanopyOptics.gauleg(100, 0.0, Float64(π))), _ϕw, FT)
+function _reflectance(s::CoxMunkSurface{FT}, q, m, N, deriv) where {FT}
+    ρ = ROCArray{FT}(undef, N, N); ρ̇ = deriv ? similar(ρ) : nothing; ϕ, w = _phi(FT)
+    _call(_fn("vsm_coxmunk_reflectance", FT), (Ref{VsmCoxMunk{FT}}, Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, PV, PV), _cm(s), q, m,
+          length(ϕ), _p(ϕ), _p(w), _p(ρ), _p(ρ̇), _stream())
+    ρ, ρ̇
+end
+function create_surface_layer!(s::CoxMunkSurface{FT}, a::AddedLayer, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
+    q = _q(qp, pol_type.n, FT); ρ, _ = _reflectance(s, q, m, size(a.r⁻⁺, 1), false)
+    _call(_fn("vsm_brdf_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), q, length(τ_sum), m, _p(ρ), _p(τ_sum), _c(a), _stream())
+end
+# apply_ss_correction! (coxmunk_surface.jl:481-545); R_SFI lives on the device until the end of rt_run
+function apply_ss_correction!(R_SFI::ROCArray{FT,3}, s::CoxMunkSurface{FT}, pol_type, vza, vaz, μ₀, τ_total::ROCArray, m_max, nSpec) where {FT<:FTs}
+    ϕ, w = _phi(FT); nV = length(vza); coef = ROCArray{FT}(undef, nV, pol_type.n)
+    _call(_fn("vsm_coxmunk_ss_correction", FT), (Ref{VsmCoxMunk{FT}}, Cint, Cint, Cint, Ptr{FT}, Ptr{FT}, FT, Cint, Cint, PV, PV, PV, PV, PV, PV),
+          _cm(s), pol_type.n, nSpec, nV, FT.(cosd.(vza)), FT.(deg2rad.(vaz)), FT(μ₀), m_max, length(ϕ), _p(ϕ), _p(w), _p(τ_total), _p(coef), _p(R_SFI), _stream())
+end
+# postprocessing_vza! noRS/SFI (postprocessing_vza.jl:23-94) on device-resident R_SFI / T_SFI: no per-moment D2H of J₀∓
+function postprocessing_vza!(::noRS, iμ₀, pol_type, c::CompositeLayer{FT}, vza, qp_μ, m, vaz, μ₀, weight, nSpec, SFI, R, R_SFI::ROCArray, T, T_SFI::ROCArray, ie...) where {FT<:FTs}
+    n = pol_type.n; nV = length(vza)
+    row0 = Cint[n * (vSmartMOM.CoreRT.nearest_point(qp_μ, cosd(v)) - 1) for v in vza]
+    w = FT[weight * (k <= 2 ? cosd(m * vaz[v]) : sind(m * vaz[v])) for v in 1:nV, k in 1:n]
+    _call(_fn("vsm_postprocess_vza", FT), (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{FT}, PV, PV, PV, PV, PV), size(c.J₀⁻, 1), n, nSpec, nV,
+          row0, w, _p(c.J₀⁻), _p(c.J₀⁺), _p(R_SFI), _p(T_SFI), _stream())
 end
 
-# Rotational Raman (CoreKernel/*_inelastic.jl): the 4-D arrays keep the reference layout [N,N,nSpec,nRaman]
-struct VsmAddedRS;     ier_mp::Ptr{Cvoid}; iet_pp::Ptr{Cvoid}; ier_pm::Ptr{Cvoid}; iet_mm::Ptr{Cvoid}
-                       ieJ0_p::Ptr{Cvoid}; ieJ0_m::Ptr{Cvoid}; K::Cint; reserved::Cint end
-struct VsmCompositeRS; ieR_mp::Ptr{Cvoid}; ieR_pm::Ptr{Cvoid}; ieT_pp::Ptr{Cvoid}; ieT_mm::Ptr{Cvoid}
-                       ieJ0_p::Ptr{Cvoid}; ieJ0_m::Ptr{Cvoid}; K::Cint; reserved::Cint end
-_c_rs(a) = VsmAddedRS(_p(a.ier⁻⁺), _p(a.iet⁺⁺), _p(a.ier⁺⁻), _p(a.iet⁻⁻), _p(a.ieJ₀⁺), _p(a.ieJ₀⁻), size(a.ier⁻⁺, 4), 0)
-_C_rs(c) = VsmCompositeRS(_p(c.ieR⁻⁺), _p(c.ieR⁺⁻), _p(c.ieT⁺⁺), _p(c.ieT⁻⁻), _p(c.ieJ₀⁺), _p(c.ieJ₀⁻), size(c.ieR⁻⁺, 4), 0)
-# interaction!(RS_type::RRS, ::ScatteringInterface_11, ...) (interaction_inelastic.jl:683-700); i_λ₁λ₀_dev = ROCArray{Cint}
-function interaction_rrs!(i_λ₁λ₀_dev, c, a, work::ROCArray{Float64})
-    N, _, S = size(c.R⁻⁺)
-    _chk(ccall((:vsm_interaction_inelastic_rrs_f64, libvsm), Cint,
-               (Cint, Cint, Cint, Ptr{Cvoid}, Ref{VsmComposite}, Ref{VsmCompositeRS}, Ref{VsmAdded}, Ref{VsmAddedRS},
-                Ptr{Cvoid}, Ptr{Cvoid}),
-               3, N, S, _p(i_λ₁λ₀_dev), _c(c), _C_rs(c), _c(a), _c_rs(a), _p(work), _stream()))
+# ---- linearized pass: rt_run(model, lin_model, NAer, NGas, NSurf) (rt_run_lin.jl; CoreKernel/*_lin.jl) --------------------
+function elemental!(pol_type, SFI::Bool, τ_sum::ROCArray, τ̇_sum::ROCArray, dτ::ROCArray, F₀::ROCArray, p, ṗ::CoreScatteringOpticalPropertiesLin,
+                    m::Int, ndoubl::Int, scatter::Bool, qp::QuadPoints, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}, arch; kw...) where {FT<:FTs}
+    pl = size(ṗ.τ̇, 2); dτ̇ = ṗ.τ̇ ./ FT(2)^ndoubl; Ż = ṗ.Ż⁺⁺
+    _call(_fn("vsm_elemental_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, PV, PV, PV, PV, PV, Clonglong,
+                                         Clonglong, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+          _q(qp, pol_type.n, FT), length(dτ), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺), _ms(p.Z⁺⁺), pl, _p(dτ̇), _p(ṗ.ϖ̇),
+          _p(τ̇_sum), _p(Ż), _p(ṗ.Ż⁻⁺), _ms(Ż), size(Ż, 1)^2 * size(Ż, 3), _c(a), _c(ȧ), _stream())
 end
+function doubling_allparams!(pol_type, SFI, expk::ROCArray{FT}, ndoubl::Int, a::AddedLayer, ȧ::AddedLayerLin, I_static, arch, dτ̇::ROCArray, μ₀; N_active::Int=0) where {FT<:FTs}
+    N, _, S = size(a.r⁻⁺); P = size(ȧ.ap_ṙ⁻⁺, 4)
+    _call(_fn("vsm_doubling_lin", FT), (Cint, Cint, Cint, Cint, PV, PV, FT, Cint, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV), N, pol_type.n, S, ndoubl,
+          _p(expk), _p(dτ̇), FT(μ₀), N_active, _c(a), _c(ȧ), _p(_work(FT, :vsm_doubling_lin_work_elems, N, S, P)), _stream())
+end
+function interaction!(iface, SFI, c::CompositeLayer{FT}, ċ::CompositeLayerLin{FT}, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}, I_static) where {FT<:FTs}
+    N, _, S = size(c.R⁻⁺); P = size(ċ.Ṙ⁻⁺, 4)
+    _call(_fn("vsm_interaction_lin", FT), (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmCompositeLin}, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV),
+          _tag(iface), N, S, _c(c), _c(ċ), _c(a), _c(ȧ), _p(_work(FT, :vsm_interaction_lin_work_elems, N, S, P)), _stream())
+end
+function create_surface_layer!(::noRS, s::LambertianSurfaceScalar{FT}, a::AddedLayer, ȧ::AddedLayerLin, iparam::Int, SFI, m::Int, pol_type, qp, τ_sum, τ̇_sum, F₀, arch) where {FT<:FTs}
+    _call(_fn("vsm_lambertian_surface_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, FT, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+          _q(qp, pol_type.n, FT), length(τ_sum), m, s.albedo, iparam - 1, _p(τ_sum), _p(τ̇_sum), size(τ̇_sum, 2), _p(F₀), _c(a), _c(ȧ), _stream())
+end
+function create_surface_layer!(::noRS, s::CoxMunkSurface{FT}, a::AddedLayer, ȧ::AddedLayerLin, iparam::Int, SFI, m::Int, pol_type, qp, τ_sum, τ̇_sum, F₀, arch) where {FT<:FTs}
+    q = _q(qp, pol_type.n, FT); ρ, ρ̇ = _reflectance(s, q, m, size(a.r⁻⁺, 1), true)
+    _call(_fn("vsm_brdf_surface_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+          q, length(τ_sum), m, _p(ρ), _p(ρ̇), iparam - 1, _p(τ_sum), _p(τ̇_sum), size(τ̇_sum, 2), _p(F₀), _c(a), _c(ȧ), _stream())
+end
+
+# ---- rotational Raman (CoreKernel/*_inelastic.jl): 4-D arrays keep the reference layout [N,N,nSpec,nRaman] ------------------
+_rrs(RS, fscatt) = VsmRRS(_p(RS.i_λ₁λ₀), _p(RS.ϖ_λ₁λ₀), _p(fscatt), _p(RS.Z⁺⁺_λ₁λ₀), _p(RS.Z⁻⁺_λ₁λ₀))   # i_λ₁λ₀ as ROCArray{Cint}
+function interaction!(RS::RRS{FT}, iface::ScatteringInterface_11, SFI, c, a, I_static; workspace=nothing) where {FT<:FTs}
+    N, _, S = size(c.R⁻⁺); K = size(c.ieR⁻⁺, 4)
+    _call(_fn("vsm_interaction_inelastic_rrs", FT), (Cint, Cint, Cint, PV, Ref{VsmComposite}, Ref{VsmCompositeRS}, Ref{VsmAdded}, Ref{VsmAddedRS}, PV, PV),
+          3, N, S, _p(RS.i_λ₁λ₀), _c(c), _Crs(c), _c(a), _crs(a), _p(_work(FT, :vsm_interaction_inelastic_work_elems, N, S, K)), _stream())
+end
+# elemental_inelastic! -> vsm_elemental_inelastic_rrs_*, doubling_inelastic! -> vsm_doubling_inelastic_rrs_*, copy_added_to_composite_ie!
+# -> vsm_copy_added_to_composite_ie_*, postprocessing_vza!(::RRS) -> vsm_postprocess_vza_ie_*: same pattern (signatures in the header).
 end # module

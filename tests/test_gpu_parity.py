@@ -108,6 +108,33 @@ def test_batch_inv(vsm, arch, FT, N):
     assert np.array_equal(vsm.CoreRT.from_device_matrix(tA).astype(np.float64), X)
 
 
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+@pytest.mark.parametrize("N,nrhs", [(4, 1), (15, 3), (60, 60), (96, 2)])
+def test_batch_solve(vsm, arch, FT, N, nrhs):
+    """batch_solve!(X, A, B) (ext/gpu_batched_cuda.jl:72-94) vs numpy.linalg.solve: one and several right-hand sides, matrices
+    that need pivoting, inputs not clobbered; residual gate of the operator tests (50 eps N cond)."""
+    rng = np.random.default_rng(N + nrhs)
+    S = 4
+    A = rng.standard_normal((S, N, N))
+    A[1] = np.eye(N) - 0.3 * rng.random((N, N)) / N
+    A[2, 0, 0] = 0.0
+    B = rng.standard_normal((S, N, nrhs))
+    A, B = A.astype(FT), B.astype(FT)
+    tA = vsm.CoreRT.to_device_matrix(A, arch, FT)
+    tB = vsm.CoreRT.to_device_matrix(B, arch, FT)            # (S, nrhs, N)
+    if nrhs == 1:
+        tB = tB[:, 0, :].contiguous()                        # vector-batch form [N,1,S]
+    tX = torch.full_like(tB, float("nan"))
+    vsm.CoreRT.batch_solve_(tX, tA, tB)
+    X = vsm.Architectures.to_host(tX).astype(np.float64)
+    X = X[:, :, None] if nrhs == 1 else X.transpose(0, 2, 1)
+    assert np.array_equal(vsm.CoreRT.from_device_matrix(tA), A)
+    A64, B64 = A.astype(np.float64), B.astype(np.float64)
+    for s in range(S):
+        ref = np.linalg.solve(A64[s], B64[s])
+        assert np.max(np.abs(X[s] - ref)) <= 50 * np.finfo(FT).eps * N * np.linalg.cond(A64[s]) * max(1.0, np.max(np.abs(ref))), s
+
+
 def test_batch_inv_singular_info(vsm, arch):
     A = np.zeros((2, 6, 6))
     A[0] = np.eye(6)

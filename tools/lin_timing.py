@@ -39,8 +39,14 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, out
 
-    t_fwd, _ = timed(lambda: vsm.CoreRT.rt_run(model))
-    t_lin, out = timed(lambda: vsm.CoreRTLin.rt_run_lin(model, lin, 0, a.gases, 1))
+    fwd_scene = vsm.CoreRT.prepare_scene(model)
+    t_fwd, _ = timed(lambda: fwd_scene.run())
+    t0 = time.perf_counter()
+    lin_scene = vsm.CoreRTLin.SceneLin(model, lin, 0, a.gases, 1)
+    torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t0
+    t_lin, _ = timed(lambda: lin_scene.run())
+    out = lin_scene.results_host()
     nd = 8
     n3, n2 = float(N) ** 3, float(N) ** 2
     f_fwd = 3 * (L * nd * (12 * n3 + 8 * n2) + L * (24 * n3 + 8 * n2))
@@ -49,6 +55,10 @@ def main():
           % (N, S, L, P, a.gases, t_fwd, S / t_fwd, t_lin, S / t_lin, t_lin / t_fwd))
     print("  algorithmic GFLOP/point: forward %.2f, linearized adds %.2f (SURVEY 8d) -> %.1f TFLOP/s in the linearized run"
           % (f_fwd / 1e9, f_lin / 1e9, (f_fwd + f_lin) * S / t_lin / 1e12))
+    f_tot = lin_scene.flops_per_point()
+    print("  device passes only (scene.run()); SceneLin build (host optics + H2D) %.3f s; algorithmic GFLOP/point of the "
+          "linearized run %.2f -> %.1f TFLOP/s = %.3f of the FP64 MFMA peak; wall ratio %.2f vs flop ratio %.2f"
+          % (t_prep, f_tot / 1e9, f_tot * S / t_lin / 1e12, f_tot * S / t_lin / 78.6e12, t_lin / t_fwd, f_tot / fwd_scene.flops_per_point()))
     print("  max |dR/dalbedo| = %.3e" % np.abs(out[2][..., -1]).max())
 
 

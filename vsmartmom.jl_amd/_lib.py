@@ -88,6 +88,7 @@ _SIGS = {
     "vsm_interaction_work_elems": (_SZ, [_I, _I]),
     "vsm_batched_mul_{T}": (_I, [_I, _I, _I, _I, _P, _LL, _P, _LL, _P, _P]),
     "vsm_batch_inv_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
+    "vsm_batch_solve_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_elemental_doubling_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
     "vsm_layer_forward_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P]),
     "vsm_layer_forward_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),

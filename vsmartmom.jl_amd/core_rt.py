@@ -101,6 +101,20 @@ def batch_inv_(X: torch.Tensor, A: torch.Tensor, info: Optional[torch.Tensor] = 
     return X
 
 
+def batch_solve_(X: torch.Tensor, A: torch.Tensor, B: torch.Tensor, info: Optional[torch.Tensor] = None):
+    """`batch_solve!(X, A, B)` (ext/gpu_batched_cuda.jl:72-94): X[:,:,s] = A[:,:,s] \\ B[:,:,s].  A: (S, N, N) layout tensor,
+    B / X: (S, Nrhs, N) (or (S, N) for one right-hand side per slice)."""
+    _require_gpu(architecture(A))
+    S, N, N2 = A.shape
+    nrhs = 1 if B.dim() == 2 else B.shape[1]
+    if N != N2 or B.shape[0] != S or B.shape[-1] != N or X.shape != B.shape:
+        raise _lib.VSMError("batch_solve!: A [N,N,S] and B, X [N,Nrhs,S] required")
+    work = _lib.poison(torch.empty_like(A))
+    _lib.call("vsm_batch_solve", A.dtype, N, nrhs, S, _ptr(A.contiguous()), _ptr(B.contiguous()), _ptr(X), _ptr(work), _ptr(info),
+              _stream_ptr())
+    return X
+
+
 def batched_pointer_cache(A):
     """ext/gpu_batched_cuda.jl:65-69 -- no pointer arrays are needed by the HIP kernels."""
     return None

@@ -651,3 +651,18 @@ VSM_SURF_API(float, f32)
   }
 VSM_OPT_API(double, f64)
 VSM_OPT_API(float, f32)
+
+// ---- batch_solve! ------------------------------------------------------------------------------------------------------
+#define VSM_SOLVE_API(T, SFX)                                                                                          \
+  extern "C" int vsm_batch_solve_##SFX(int N, int Nrhs, int S, const T* A, const T* B, T* X, T* work, int* info,       \
+                                       void* stream) {                                                                 \
+    VSM_REQUIRE(N > 0 && Nrhs > 0 && S >= 0, "batch_solve: bad size");                                                 \
+    if (S == 0) return VSM_OK;                                                                                         \
+    VSM_REQUIRE(A && B && X && work && X != B, "batch_solve: null argument / X must not alias B");                     \
+    int rc = batch_inv<T>(N, S, A, work, info, as_stream(stream));                                                     \
+    if (rc) return rc;                                                                                                 \
+    return gemm<T>(N, Nrhs, N, S, work, (long long)N * N, B, (long long)N * Nrhs, X, (long long)N * Nrhs, T(1),        \
+                   (const T*)nullptr, 0, T(0), T(0), as_stream(stream));                                               \
+  }
+VSM_SOLVE_API(double, f64)
+VSM_SOLVE_API(float, f32)
