@@ -295,6 +295,16 @@ int vsm_postprocess_vza_lin_f64(int N, int n_stokes, int S, int nV, int P, const
 int vsm_postprocess_vza_lin_f32(int N, int n_stokes, int S, int nV, int P, const int* row0_h, const float* w_h,
                                 const float* Jdot0_m, const float* Jdot0_p, float* Rdot, float* Tdot, void* stream);
 
+/* create_surface_layer!(::LambertianSurfaceLegendre / ::LambertianSurfaceSpline) (src/CoreRT/Surfaces/lambertian_surface.jl:97-213):
+ * Lambertian surface whose albedo varies over the band, albedo[S] (device; the host evaluates the Legendre series / the spline
+ * on the band grid).  One block per spectral point (added->mat_stride = N*N): r-+[:,:,s] = 2 albedo[s] E11 (x) (mu w), r+- = 0,
+ * t++ = t-- = I, j0- = mu0 2 albedo[s] exp(-tau_sum/mu0) on the I rows; as in the reference j0+ = 0 and for m > 0 ALL blocks
+ * (including t++ / t--) are zero. */
+int vsm_lambertian_surface_spectral_f64(const vsm_quad_f64* q, int S, int m, const double* albedo, const double* tau_sum,
+                                        const vsm_added_f64* added, void* stream);
+int vsm_lambertian_surface_spectral_f32(const vsm_quad_f32* q, int S, int m, const float* albedo, const float* tau_sum,
+                                        const vsm_added_f32* added, void* stream);
+
 /* ---- BRDF surfaces: Cox-Munk ocean + the generic BRDF surface layer ------------------------------------------
  * CoxMunkSurface{FT} (src/CoreRT/types.jl:525-536); n_water is the complex index the reference's call sites use
  * (`_get_n_water(surf, 550)`, coxmunk_surface.jl:434-444: the Segelstein table at 550 nm unless the surface carries one). */

@@ -794,6 +794,45 @@ def create_surface_layer_lambertian(albedo, added: AddedLayer, m, pol, qp: QuadP
         added.j0_m[...] = 0
 
 
+def legendre_albedo(legendre_coeff, nSpec, FT=np.float64):
+    """lambertian_surface.jl:113-117: albedo = P(x) coeff on x = range(-1, 1, length = nSpec) with P from
+    Scattering.compute_legendre_poly (legendre_functions.jl:223-252, the P0 column)."""
+    c = np.asarray(legendre_coeff, dtype=FT)
+    assert len(c) > 1
+    x = np.linspace(FT(-1), FT(1), nSpec).astype(FT)
+    P = np.zeros((nSpec, len(c)), dtype=FT)
+    P[:, 0] = 1
+    P[:, 1] = x
+    for n in range(2, len(c)):
+        l = n - 1
+        P[:, n] = ((2 * l + 1) * x * P[:, n - 1] - l * P[:, n - 2]) / (l + 1)
+    return P @ c
+
+
+def create_surface_layer_lambertian_spectral(albedo, added: AddedLayer, m, pol, qp: QuadPoints, tau_sum, FT):
+    """src/CoreRT/Surfaces/lambertian_surface.jl:97-213 (LambertianSurfaceLegendre / LambertianSurfaceSpline): `albedo` [S].
+    Reference quirks kept: j0+ = 0; for m > 0 also t++ = t-- = 0."""
+    S, N = added.j0_p.shape
+    n = pol.n
+    if m == 0:
+        rho = FT(2) * np.asarray(albedo, dtype=FT)
+        R_surf = np.zeros((N, N), dtype=FT)
+        R_surf[0::n, 0::n] = 1
+        I0N = np.zeros(N, dtype=FT)
+        I0N[n * qp.imu0:n * qp.imu0 + n] = pol.I0
+        att = np.exp(-np.asarray(tau_sum, dtype=FT) / FT(qp.mu0))
+        added.j0_p[...] = 0
+        added.j0_m[...] = (FT(qp.mu0) * (R_surf @ I0N))[None, :] * (rho * att)[:, None]
+        Rw = R_surf * (qp.qp_muN.astype(FT) * qp.wt_muN.astype(FT))[None, :]
+        added.r_mp[...] = rho[:, None, None] * Rw[None]
+        added.r_pm[...] = 0
+        added.t_pp[...] = np.eye(N, dtype=FT)[None]
+        added.t_mm[...] = np.eye(N, dtype=FT)[None]
+    else:
+        for arr in (added.r_mp, added.t_pp, added.t_mm, added.j0_p, added.j0_m):
+            arr[...] = 0
+
+
 def postprocessing_vza(pol, comp: CompositeLayer, vza, vaz, qp: QuadPoints, m, weight, R_SFI, T_SFI):
     """src/CoreRT/tools/postprocessing_vza.jl:23-94 (noRS, SFI branch).  R_SFI/T_SFI: [nVZA, nStokes, S]."""
     n = pol.n
@@ -830,7 +869,10 @@ def rt_run(model: RTModel, trace=None, per_m=None):
             lo = expand_optical_properties(lods[iz], FT)
             rt_kernel(pol, added, comp, lo, ifaces[iz], tau_sum_all[:, iz].astype(FT), m, qp, iz + 1, F0, FT,
                       model.numerics, trace)
-        create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
+        if np.ndim(model.albedo) == 1:     # spectrally varying Lambertian albedo (Legendre / spline surfaces)
+            create_surface_layer_lambertian_spectral(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
+        else:
+            create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
         interaction(ifaces[-1], comp, added_surf, FT)
         if per_m is not None:
             per_m.append(dict(m=m, J0_m=comp.J0_m.copy(), J0_p=comp.J0_p.copy(), weight=weight))

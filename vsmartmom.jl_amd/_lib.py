@@ -105,6 +105,7 @@ _SIGS = {
     "vsm_layer_optics_{T}": (_I, [_I, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_layer_dtau_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_coxmunk_reflectance_{T}": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "vsm_lambertian_surface_spectral_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_lin_{T}": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
     "vsm_coxmunk_ss_correction_{T}": (_I, [_P, _I, _I, _I, _P, _P, "{R}", _I, _I, _P, _P, _P, _P, _P, _P]),

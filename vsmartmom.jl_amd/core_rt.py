@@ -350,9 +350,16 @@ def create_surface_layer_(surface, added_surface: AddedLayer, m: int, dq: Device
     """create_surface_layer!: LambertianSurfaceScalar (lambertian_surface.jl:41-95; `surface` may be the bare albedo) or a
     BRDF surface through its Fourier reflectance block (rpv_surface.jl:51-97; CoxMunkSurface: coxmunk_surface.jl:381-460).
     `rho` = a precomputed reflectance(surface, pol, qp_mu, m) block (Scene caches one per moment)."""
+    q, a = dq.cstruct(), added_surface.cstruct()
+    if isinstance(surface, (H.LambertianSurfaceLegendre, H.LambertianSurfaceSpline)):
+        # lambertian_surface.jl:97-213: `rho` = the per-point albedo [nSpec] (device), one r-+ block per spectral point
+        if added_surface.shared or rho is None:
+            raise _lib.VSMError("spectral Lambertian surfaces need a per-point surface AddedLayer and their albedo spectrum")
+        _lib.call("vsm_lambertian_surface_spectral", added_surface.dtype, C.byref(q), added_surface.nSpec, m, _ptr(rho),
+                  _ptr(tau_sum), C.byref(a), _stream_ptr())
+        return
     if not added_surface.shared:
         raise _lib.VSMError("surface AddedLayer must be allocated with shared=True")
-    q, a = dq.cstruct(), added_surface.cstruct()
     if isinstance(surface, H.LambertianSurfaceScalar):
         surface = surface.albedo
     if isinstance(surface, (int, float)):
@@ -366,7 +373,8 @@ def create_surface_layer_(surface, added_surface: AddedLayer, m: int, dq: Device
         _lib.call("vsm_brdf_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, _ptr(rho), _ptr(tau_sum),
                   C.byref(a), _stream_ptr())
         return
-    raise _lib.VSMError("surface %r is not built in this backend (LambertianSurfaceScalar, CoxMunkSurface)" % (surface,))
+    raise _lib.VSMError("surface %r is not built in this backend (LambertianSurfaceScalar / Legendre / Spline, CoxMunkSurface)"
+                        % (surface,))
 
 
 def apply_ss_correction_(R_SFI: torch.Tensor, surf: H.CoxMunkSurface, pol, vza, vaz, mu0, tau_total: torch.Tensor, m_max: int,
@@ -493,7 +501,10 @@ class Scene:
         # every layer scatters and N fits on chip -> all steps run in the fused kernels, which can derive
         # r+-/t-- by D-symmetry instead of moving them through HBM (decided in prepare(), allocated lazily)
         self.added = None
-        self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=True)
+        self.spectral_surface = isinstance(model.surface, (H.LambertianSurfaceLegendre, H.LambertianSurfaceSpline))
+        self.added_surface = make_added_layer(FT, arch, (N, N), S, shared=not self.spectral_surface)
+        self.albedo_d = (conv(np.ascontiguousarray(H.surface_albedo_spectrum(model.surface, S_full, FT)[self.sl]))
+                         if self.spectral_surface else None)
         self.composite = make_composite_layer(FT, arch, (N, N), S)
         # the interaction work buffer belongs to the scene (a captured graph must not point into a shared cache)
         self.work = _lib.poison(torch.empty(max(int(_lib.lib().vsm_interaction_work_elems(N, max(S, 1))), 1), dtype=dt, device=dev))
@@ -573,7 +584,7 @@ class Scene:
                 props = DeviceLayerOptics(self.tau[iz, lo:hi], self.varpi[iz, lo:hi], Zp, Zm, maxima[iz], None, None, fc)
                 layers.append(dict(props=props, iface=tags[iz], nd=nds[iz], dtau=self.dtau[iz, lo:hi],
                                    tau_sum=self.tau_sum[iz, lo:hi]))
-            rho = None
+            rho = self.albedo_d
             if isinstance(model.surface, H.CoxMunkSurface):   # scene constant like Z(m): one N x N block per moment
                 rho, _ = reflectance(model.surface, self.dq, m, self.arch, FT)
             self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, tau_sum_surface=self.tau_sum[L, lo:hi]))

@@ -599,6 +599,15 @@ VSM_LIN_API(float, f32)
     VSM_REQUIRE(S >= 0 && m >= 0 && rho && (tau_sum || S == 0), "brdf_surface: bad argument");                         \
     return brdf_surface<T>(cvt_quad<T>(q), S, m, rho, tau_sum, cvt_added<T>(added), as_stream(stream));                \
   }                                                                                                                    \
+  extern "C" int vsm_lambertian_surface_spectral_##SFX(const vsm_quad_##SFX* q, int S, int m, const T* albedo,         \
+                                                       const T* tau_sum, const vsm_added_##SFX* added, void* stream) { \
+    int rc;                                                                                                            \
+    VSM_REQUIRE(added && added->d_symmetric == 0, "lambertian_surface_spectral: d_symmetric layers are not accepted"); \
+    if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;                                                  \
+    VSM_REQUIRE(S >= 0 && m >= 0 && (S == 0 || (albedo && tau_sum)), "lambertian_surface_spectral: bad argument");     \
+    return lambertian_surface_spectral<T>(cvt_quad<T>(q), S, m, albedo, tau_sum, cvt_added<T>(added),                  \
+                                          as_stream(stream));                                                          \
+  }                                                                                                                    \
   extern "C" int vsm_brdf_surface_lin_##SFX(const vsm_quad_##SFX* q, int S, int m, const T* rho, const T* drho,        \
                                             int iparam, const T* tau_sum, const T* tau_sum_dot, int p_layer,           \
                                             const T* F0, const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al,  \

@@ -103,6 +103,8 @@ int coxmunk_reflectance(const cm_surf<T>& sf, int n_stokes, int Nmu, const T* mu
 template <typename T>
 int brdf_surface(const quad<T>& q, int S, int m, const T* rho, const T* tau_sum, const added<T>& a, hipStream_t st);
 template <typename T>
+int lambertian_surface_spectral(const quad<T>& q, int S, int m, const T* albedo, const T* tau_sum, const added<T>& a, hipStream_t st);
+template <typename T>
 int brdf_surface_lin(const quad<T>& q, int S, int m, const T* rho, const T* drho, int iparam, const T* tau_sum,
                      const T* tau_sum_dot, int p_layer, const T* F0, const added<T>& a, const added_lin<T>& al, hipStream_t st);
 template <typename T>

@@ -392,6 +392,47 @@ int brdf_surface_lin(const quad<T>& q, int S, int m, const T* rho, const T* drho
   return VSM_OK;
 }
 
+// ---- Lambertian surface with a spectrally varying albedo (LambertianSurfaceLegendre / LambertianSurfaceSpline,
+// lambertian_surface.jl:97-213): per-point blocks r-+[:,:,s] = 2 a_s E11 (x) (mu w); the builder's quirks kept: j0+ = 0, and for
+// m > 0 the transmission blocks are ZERO (the scalar builder writes the identity there).
+template <typename T>
+__global__ void k_lambertian_spectral(int N, int ns, long long S, int m, const T* __restrict__ albedo, const T* __restrict__ mu,
+                                      const T* __restrict__ wt, int i_mu0, T mu0, const T* __restrict__ tau_sum, T* r_mp, T* r_pm,
+                                      T* t_pp, T* t_mm, T* j0_p, T* j0_m) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long NN = (long long)N * N;
+  if (e >= NN * S) return;
+  const long long s = e / NN;
+  const int x = (int)(e % NN), i = x % N, j = x / N;
+  const T rho = T(2) * albedo[s];
+  const bool ii = (m == 0) && (i % ns == 0) && (j % ns == 0);
+  r_mp[e] = ii ? rho * (mu[j] * wt[j]) : T(0);
+  r_pm[e] = T(0);
+  const T d = (m == 0 && i == j) ? T(1) : T(0);
+  t_pp[e] = d;
+  t_mm[e] = d;
+  if (j == 0) {
+    const long long o = s * N + i;
+    j0_p[o] = T(0);
+    j0_m[o] = (m == 0 && (i % ns) == 0) ? mu0 * (rho * exp(-tau_sum[s] / mu0)) : T(0);
+  }
+  (void)i_mu0;
+}
+template <typename T>
+int lambertian_surface_spectral(const quad<T>& q, int S, int m, const T* albedo, const T* tau_sum, const added<T>& a, hipStream_t st) {
+  const int N = q.N;
+  if (a.mat_stride != (long long)N * N) {
+    set_error("lambertian_surface_spectral: the surface layer needs one block per spectral point (mat_stride = N*N)");
+    return VSM_ERR_INVALID_ARG;
+  }
+  if (S <= 0) return VSM_OK;
+  const long long tot = (long long)N * N * S;
+  hipLaunchKernelGGL(k_lambertian_spectral<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, q.n_stokes, (long long)S, m,
+                     albedo, q.mu, q.wt, q.i_mu0, q.mu0, tau_sum, a.r_mp, a.r_pm, a.t_pp, a.t_mm, a.j0_p, a.j0_m);
+  VSM_LAUNCH_CHECK("k_lambertian_spectral");
+  return VSM_OK;
+}
+
 // ---- TMS single-scattering correction (coxmunk_surface.jl:481-569) ---------------------------------------------------
 struct ss_geom {
   double mu_v[64];
@@ -476,6 +517,7 @@ int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, con
 #define VSM_INST_SURF(T)                                                                                                     \
   template int coxmunk_reflectance<T>(const cm_surf<T>&, int, int, const T*, int, int, const T*, const T*, T*, T*, hipStream_t); \
   template int brdf_surface<T>(const quad<T>&, int, int, const T*, const T*, const added<T>&, hipStream_t);                   \
+  template int lambertian_surface_spectral<T>(const quad<T>&, int, int, const T*, const T*, const added<T>&, hipStream_t);    \
   template int brdf_surface_lin<T>(const quad<T>&, int, int, const T*, const T*, int, const T*, const T*, int, const T*,      \
                                    const added<T>&, const added_lin<T>&, hipStream_t);                                        \
   template int coxmunk_ss_correction<T>(const cm_surf<T>&, int, int, int, const T*, const T*, T, int, int, const T*, const T*, \

@@ -301,6 +301,39 @@ class LambertianSurfaceScalar:
 
 
 @dataclass
+class LambertianSurfaceLegendre:
+    """types.jl:540-543: albedo = sum_k legendre_coeff[k] P_k(x) on x = range(-1, 1, length = nSpec)."""
+    legendre_coeff: Sequence[float]
+
+
+@dataclass
+class LambertianSurfaceSpline:
+    """types.jl:546-549 with the interpolator already evaluated on the band grid: albedo[nSpec] = interpolator(wlGrid)."""
+    albedo: Sequence[float]
+
+
+def surface_albedo_spectrum(surface, nSpec: int, FT=np.float64) -> np.ndarray:
+    """The per-point albedo of the spectrally varying Lambertian surfaces (lambertian_surface.jl:113-117, 178): Legendre
+    basis by the three-term recurrence of compute_legendre_poly (legendre_functions.jl:223-252), arithmetic in FT."""
+    if isinstance(surface, LambertianSurfaceSpline):
+        a = np.asarray(surface.albedo, dtype=FT)
+        if a.shape != (nSpec,):
+            raise ValueError("LambertianSurfaceSpline: albedo must be given on the band grid (%d points)" % nSpec)
+        return a
+    c = np.asarray(surface.legendre_coeff, dtype=FT)
+    if len(c) < 2:
+        raise ValueError("LambertianSurfaceLegendre needs at least two coefficients (compute_legendre_poly asserts nmax > 1)")
+    x = np.linspace(FT(-1), FT(1), nSpec).astype(FT)
+    P = np.zeros((nSpec, len(c)), dtype=FT)
+    P[:, 0] = 1
+    P[:, 1] = x
+    for n in range(2, len(c)):
+        l = n - 1
+        P[:, n] = ((2 * l + 1) * x * P[:, n - 1] - l * P[:, n - 2]) / (l + 1)
+    return (P @ c).astype(FT)
+
+
+@dataclass
 class CoxMunkSurface:
     """src/CoreRT/types.jl:525-536: Cox-Munk (1954) ocean, isotropic slope variance 0.003 + 0.00512 U."""
     wind_speed: float

@@ -140,6 +140,10 @@ def parse_surface(s: str):
         if len(args) != 1 or kw:
             raise ValueError("LambertianSurfaceScalar expects 1 argument (albedo)")
         return H.LambertianSurfaceScalar(_num(args[0]))
+    if name == "LambertianSurfaceLegendre":
+        if len(args) != 1 or kw:
+            raise ValueError("LambertianSurfaceLegendre expects 1 argument (coefficient vector)")
+        return H.LambertianSurfaceLegendre([_num(x) for x in re.split(r"[\s,;]+", args[0].strip("[] ")) if x])
     if name == "CoxMunkSurface":
         if kw:
             if args or "wind_speed" not in kw:
@@ -155,7 +159,8 @@ def parse_surface(s: str):
         if len(args) != 1:
             raise ValueError("CoxMunkSurface expects 1 argument (wind_speed)")
         return H.CoxMunkSurface(wind_speed=_num(args[0]))
-    raise NotImplementedError("surface %r: LambertianSurfaceScalar and CoxMunkSurface are built in this backend" % s)
+    raise NotImplementedError("surface %r: LambertianSurfaceScalar / LambertianSurfaceLegendre and CoxMunkSurface are built in "
+                              "this backend" % s)
 
 
 def _surface_albedo(s: str) -> float:
@@ -213,5 +218,7 @@ def model_from_parameters(params: vSmartMOM_Parameters, architecture, iBand: int
     user_l_cap = min(2 * params.nstreams - 1, params.max_m - 1, params.l_trunc)
     m_max = min(max(2, user_l_cap if isinstance(surface, H.CoxMunkSurface) else 0), user_l_cap)
     alb = surface.albedo if isinstance(surface, H.LambertianSurfaceScalar) else 0.0
+    if isinstance(surface, H.LambertianSurfaceLegendre) and len(surface.legendre_coeff) < 2:
+        raise ValueError("LambertianSurfaceLegendre needs at least two coefficients")
     return H.model_from_arrays(architecture, params.polarization_type, params.l_trunc, params.sza, params.vza, params.vaz,
                                tau_rayl, depol=depol, albedo=alb, m_max=m_max, float_type=params.float_type, surface=surface)
