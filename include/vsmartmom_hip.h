@@ -341,6 +341,19 @@ int vsm_brdf_surface_lin_f64(const vsm_quad_f64* q, int S, int m, const double* 
 int vsm_brdf_surface_lin_f32(const vsm_quad_f32* q, int S, int m, const float* rho, const float* drho, int iparam,
                              const float* tau_sum, const float* tau_sum_dot, int p_layer, const float* F0,
                              const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, void* stream);
+/* interaction_hdrf! (src/CoreRT/CoreKernel/interaction_hdrf.jl:4-42), called after the surface interaction of each Fourier
+ * moment (rt_run.jl:467-476): hdr_J[N,S] = r-+_surf J0+ + j0-_surf; for m == 0 also the hemispheric fluxes bhr_uw / bhr_dw
+ * [n_stokes, S] (for m > 0 they are not touched).  The surface layer may be shared (mat_stride 0) or per point. */
+int vsm_interaction_hdrf_f64(const vsm_quad_f64* q, int S, int m, const vsm_composite_f64* comp,
+                             const vsm_added_f64* added_surface, double* hdr_J, double* bhr_uw, double* bhr_dw, void* stream);
+int vsm_interaction_hdrf_f32(const vsm_quad_f32* q, int S, int m, const vsm_composite_f32* comp,
+                             const vsm_added_f32* added_surface, float* hdr_J, float* bhr_uw, float* bhr_dw, void* stream);
+/* postprocessing_vza_hdrf! (tools/postprocessing_vza.jl:103-115): hdr[v,k,s] += w[v,k] hdr_J[row0[v]+k, s]; row0_h / w_h as in
+ * vsm_postprocess_vza_*. */
+int vsm_postprocess_vza_hdrf_f64(int N, int n_stokes, int S, int nV, const int* row0_h, const double* w_h, const double* hdr_J,
+                                 double* hdr, void* stream);
+int vsm_postprocess_vza_hdrf_f32(int N, int n_stokes, int S, int nV, const int* row0_h, const float* w_h, const float* hdr_J,
+                                 float* hdr, void* stream);
 /* apply_ss_correction! (TMS; coxmunk_surface.jl:481-569, called at rt_run.jl:520-524):
  *   coef[v + nV k] = M_exact[k,1](mu_v, mu0, dphi_v) - sum_{m<=m_max} w_m az_k1(m dphi_v) c_m[k,1](mu_v, mu0)
  *   R_SFI[v,k,s]  += mu0 exp(-tau_total[s]/mu0) coef[v + nV k]

@@ -845,8 +845,24 @@ def postprocessing_vza(pol, comp: CompositeLayer, vza, vaz, qp: QuadPoints, m, w
         T_SFI[i] += w[:, None] * comp.J0_p[:, istart:istart + n].T
 
 
-def rt_run(model: RTModel, trace=None, per_m=None):
-    """src/CoreRT/rt_run.jl:238-539 (noRS, SFI=true, Lambertian surface).  Returns (R_SFI, T_SFI)."""
+def interaction_hdrf(comp: CompositeLayer, added_surf: AddedLayer, m, pol, qp: QuadPoints, bhr_uw, bhr_dw):
+    """src/CoreRT/CoreKernel/interaction_hdrf.jl:4-42.  Returns hdr_J0- [S, N]; for m == 0 fills bhr_uw / bhr_dw [n, S]."""
+    N = comp.J0_p.shape[1]
+    n = pol.n
+    hdr_J = np.einsum("sij,sj->si", added_surf.r_mp, comp.J0_p) + added_surf.j0_m
+    if m == 0:
+        wmu = qp.wt_muN * qp.qp_muN
+        i0 = n * qp.imu0
+        for i in range(n):
+            j = slice(i, N, n)
+            bhr_uw[i] = np.sum(hdr_J[:, j] * wmu[j][None, :], axis=1)
+            bhr_dw[i] = np.sum(comp.J0_p[:, j] * wmu[j][None, :], axis=1) + added_surf.j0_p[:, i0] * qp.qp_muN[i0]
+    return hdr_J
+
+
+def rt_run(model: RTModel, trace=None, per_m=None, hdrf=None):
+    """src/CoreRT/rt_run.jl:238-539 (noRS, SFI=true, Lambertian surface).  Returns (R_SFI, T_SFI); with `hdrf` = a dict it is
+    filled with hdr [nVZA, nStokes, S], bhr_uw, bhr_dw [nStokes, S] (the reference returns bhr_uw[1,:], bhr_dw[1,:])."""
     FT = model.FT
     pol, qp = model.pol, model.quad_points
     S, L = model.tau_rayl.shape
@@ -876,6 +892,13 @@ def rt_run(model: RTModel, trace=None, per_m=None):
         interaction(ifaces[-1], comp, added_surf, FT)
         if per_m is not None:
             per_m.append(dict(m=m, J0_m=comp.J0_m.copy(), J0_p=comp.J0_p.copy(), weight=weight))
+        if hdrf is not None:
+            if m == 0:
+                hdrf.update(hdr=np.zeros((nV, pol.n, S), dtype=FT), bhr_uw=np.zeros((pol.n, S), dtype=FT),
+                            bhr_dw=np.zeros((pol.n, S), dtype=FT))
+            hj = interaction_hdrf(comp, added_surf, m, pol, qp, hdrf["bhr_uw"], hdrf["bhr_dw"])
+            hc = CompositeLayer(None, None, None, None, np.zeros_like(hj), hj)        # postprocessing_vza_hdrf!: the J0- leg only
+            postprocessing_vza(pol, hc, model.vza, model.vaz, qp, m, weight, hdrf["hdr"], np.zeros_like(hdrf["hdr"]))
         postprocessing_vza(pol, comp, model.vza, model.vaz, qp, m, weight, R_SFI, T_SFI)
     return R_SFI, T_SFI
 

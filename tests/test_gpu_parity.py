@@ -838,3 +838,31 @@ def test_rt_run_spectrally_varying_lambertian_surfaces(vsm, arch, pol, l_trunc, 
     assert isinstance(vsm.io_yaml.parse_surface("LambertianSurfaceLegendre([0.2, 0.05])"), H.LambertianSurfaceLegendre)
     with pytest.raises(vsm.VSMError):
         vsm.CoreRTLin.rt_run_lin(flat, H.LinModel([tau_abs]), 0, 1, 1)     # the reference has no linearized builder for them
+
+
+@pytest.mark.parametrize("pol,l_trunc,albedo", [("I", 9, 0.3), ("IQU", 33, 0.15), ("IQUV", 7, 0.0)])
+def test_rt_run_full_output_hdrf_bhr(vsm, arch, pol, l_trunc, albedo):
+    """The reference's SFI return tuple (rt_run.jl:535): hdr (interaction_hdrf! + postprocessing_vza_hdrf!), bhr_uw[1,:],
+    bhr_dw[1,:] vs the oracle; zero inelastic slots; for a Lambertian surface the m = 0 flux ratio is the albedo
+    (bhr_uw = albedo * bhr_dw: every stream of the upwelling field is 2 a sum_j mu_j w_j J_j + the direct-beam term)."""
+    H = vsm.host_model
+    rng = np.random.default_rng(4)
+    S, L = 6, 3
+    tau_rayl = np.tile(0.05 * np.ones(L), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, -0.5, (S, L))
+    geo = (pol, l_trunc, 35.0, [20.0, 0.0, 50.0], [30.0, 0.0, 170.0])
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=albedo, m_max=2)
+    out = vsm.CoreRT.rt_run(H.model_from_arrays(arch, *geo, **kw), full_output=True)
+    assert len(out) == 7
+    R, T, ieR, ieT, hdr, bhr_uw, bhr_dw = out
+    hd = {}
+    Ro, To = O.rt_run(O.build_model(*geo, **kw), hdrf=hd)
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9
+    assert not ieR.any() and not ieT.any() and ieR.shape == R.shape
+    assert hdr.shape == R.shape and bhr_uw.shape == (S,) and bhr_dw.shape == (S,)
+    if albedo > 0:
+        assert _rel(hdr, hd["hdr"]) < 1e-9 and _rel(bhr_uw, hd["bhr_uw"][0]) < 1e-9
+        assert np.allclose(bhr_uw / bhr_dw, albedo, rtol=1e-9)
+    else:
+        assert not hdr.any() and not bhr_uw.any()
+    assert _rel(bhr_dw, hd["bhr_dw"][0]) < 1e-9

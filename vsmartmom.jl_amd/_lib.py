@@ -108,6 +108,8 @@ _SIGS = {
     "vsm_lambertian_surface_spectral_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_lin_{T}": (_I, [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "vsm_interaction_hdrf_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_postprocess_vza_hdrf_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "vsm_coxmunk_ss_correction_{T}": (_I, [_P, _I, _I, _I, _P, _P, "{R}", _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_doubling_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_interaction_lin_work_elems": (_SZ, [_I, _I, _I]),

@@ -412,6 +412,33 @@ def postprocessing_vza_(pol: H.PolarizationType, comp: CompositeLayer, vza, vaz,
               _ptr(R_SFI), _ptr(T_SFI), _stream_ptr())
 
 
+def _vza_rows_weights(pol, vza, vaz, qp, m, weight, dtype):
+    """_precompute_vza_weights (postprocessing_vza.jl): first row of each viewing stream and weight * {cos, cos, sin, sin}(m vaz)."""
+    n, nV = pol.n, len(vza)
+    row0 = (C.c_int * nV)()
+    ctype = C.c_double if dtype == torch.float64 else C.c_float
+    w = (ctype * (nV * n))()
+    for v in range(nV):
+        imu = int(np.argmin(np.abs(qp.qp_mu - qp.qp_mu.dtype.type(H.cosd(vza[v])))))
+        row0[v] = imu * n
+        c, s = H.cosd(m * vaz[v]), H.sind(m * vaz[v])
+        for k in range(n):
+            w[v + nV * k] = weight * [c, c, s, s][k]
+    return row0, w
+
+
+def interaction_hdrf_(pol, comp: CompositeLayer, added_surface: AddedLayer, m: int, dq: DeviceQuad, vza, vaz, qp, weight: float,
+                      hdr_J: torch.Tensor, hdr: torch.Tensor, bhr_uw: torch.Tensor, bhr_dw: torch.Tensor):
+    """interaction_hdrf! + postprocessing_vza_hdrf! (CoreKernel/interaction_hdrf.jl:4-42, tools/postprocessing_vza.jl:103-115):
+    hdr (S, n, nV) += w * (r-+_surf J0+ + j0-_surf)[rows(vza)]; bhr_uw / bhr_dw (S, n) written for m == 0."""
+    q, c, a = dq.cstruct(), comp.cstruct(), added_surface.cstruct()
+    _lib.call("vsm_interaction_hdrf", comp.dtype, C.byref(q), comp.nSpec, m, C.byref(c), C.byref(a), _ptr(hdr_J), _ptr(bhr_uw),
+              _ptr(bhr_dw), _stream_ptr())
+    row0, w = _vza_rows_weights(pol, vza, vaz, qp, m, weight, comp.dtype)
+    _lib.call("vsm_postprocess_vza_hdrf", comp.dtype, comp.N, pol.n, comp.nSpec, len(vza), row0, w, _ptr(hdr_J), _ptr(hdr),
+              _stream_ptr())
+
+
 def init_layer(props: DeviceLayerOptics, qp: H.QuadPoints, FT, numerics: H.RTNumericalParameters, arch):
     """rt_kernel.jl:339-349: (dτ, ndoubl) -- expk = exp(-dτ/μ₀) is formed inside the fused kernel."""
     dtau_h, nd = H.get_dtau_ndoubl(props.tau_h, props.varpi_h, qp, FT, numerics)
@@ -511,6 +538,12 @@ class Scene:
         nV = len(model.vza)
         self.R_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
         self.T_SFI = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        # HDRF / BHR diagnostics of the reference's 7-tuple (rt_run.jl:300-303,467-494,535)
+        self.compute_hdrf = True
+        self.hdr = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
+        self.hdr_J = torch.zeros((S, N), dtype=dt, device=dev)
+        self.bhr_uw = torch.zeros((S, pol.n), dtype=dt, device=dev)
+        self.bhr_dw = torch.zeros((S, pol.n), dtype=dt, device=dev)
         self.upload()
         self.prepare()
 
@@ -635,6 +668,7 @@ class Scene:
         model, pol, FT = self.model, self.pol, self.FT
         self.R_SFI.zero_()
         self.T_SFI.zero_()
+        self.hdr.zero_()
         if self.S == 0:          # a rank that owns no spectral point (world > nSpec): nothing to launch
             return self.R_SFI, self.T_SFI
         self.added.j0_p.zero_()  # a fresh make_added_layer: zero_added_noscat! never writes j0+ (rt_helpers.jl:174-180)
@@ -647,6 +681,9 @@ class Scene:
                            work=self.work)
             create_surface_layer_(model.surface, self.added_surface, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
             interaction_(mom["iface_surface"], self.composite, self.added_surface, work=self.work)
+            if self.compute_hdrf:
+                interaction_hdrf_(pol, self.composite, self.added_surface, m, self.dq, model.vza, model.vaz, self.qp, float(weight),
+                                  self.hdr_J, self.hdr, self.bhr_uw, self.bhr_dw)
             postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
                                 self.T_SFI)
         if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
@@ -678,6 +715,13 @@ class Scene:
         """(R_SFI, T_SFI) as the reference returns them: [nVZA, nStokes, nSpec] numpy arrays."""
         return to_host(self.R_SFI).transpose(2, 1, 0).copy(), to_host(self.T_SFI).transpose(2, 1, 0).copy()
 
+    def results_host_full(self):
+        """The reference's SFI return tuple (rt_run.jl:535): (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:]);
+        the inelastic slots are zero for noRS, like the reference's freshly allocated arrays."""
+        R, T = self.results_host()
+        return (R, T, np.zeros_like(R), np.zeros_like(T), to_host(self.hdr).transpose(2, 1, 0).copy(),
+                to_host(self.bhr_uw)[:, 0].copy(), to_host(self.bhr_dw)[:, 0].copy())
+
     def flops_per_point(self) -> float:
         """ALGORITHMIC flops per spectral point: per moment
         sum_l nd_l (12N^3+8N^2) + [interactions incl. surface] (24N^3+8N^2)."""
@@ -696,11 +740,12 @@ def prepare_scene(model: H.RTModel, spec_slice: Optional[slice] = None) -> Scene
     return Scene(model, spec_slice)
 
 
-def rt_run(model: H.RTModel, trace: Optional[list] = None):
-    """rt_run(model) (rt_run.jl:53-58 -> :238-539): returns (R_SFI, T_SFI) as host arrays
-    [nVZA, nStokes, nSpec] (the reference's first two return values; the Raman/HDRF slots are
-    out of scope of this backend)."""
+def rt_run(model: H.RTModel, trace: Optional[list] = None, full_output: bool = False):
+    """rt_run(model) (rt_run.jl:53-58 -> :238-539): returns (R_SFI, T_SFI) as host arrays [nVZA, nStokes, nSpec] -- the
+    reference's first two return values -- or, with `full_output`, its whole SFI tuple
+    (R_SFI, T_SFI, ieR_SFI, ieT_SFI, hdr, bhr_uw[1,:], bhr_dw[1,:]) (rt_run.jl:535)."""
     scene = prepare_scene(model)
+    scene.compute_hdrf = bool(full_output)
     scene.run(trace)
     synchronize_if_gpu()
-    return scene.results_host()
+    return scene.results_host_full() if full_output else scene.results_host()

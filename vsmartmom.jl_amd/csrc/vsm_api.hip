@@ -621,6 +621,20 @@ VSM_LIN_API(float, f32)
     return brdf_surface_lin<T>(cvt_quad<T>(q), S, m, rho, drho, iparam, tau_sum, tau_sum_dot, p_layer, F0,             \
                                cvt_added<T>(added), cvt_al<T>(al), as_stream(stream));                                 \
   }                                                                                                                    \
+  extern "C" int vsm_interaction_hdrf_##SFX(const vsm_quad_##SFX* q, int S, int m, const vsm_composite_##SFX* comp,    \
+                                            const vsm_added_##SFX* added_surface, T* hdr_J, T* bhr_uw, T* bhr_dw,      \
+                                            void* stream) {                                                            \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q)) || (rc = check_comp(comp)) || (rc = check_added(added_surface))) return rc;               \
+    VSM_REQUIRE(S >= 0 && m >= 0 && (S == 0 || (hdr_J && (m > 0 || (bhr_uw && bhr_dw)))), "interaction_hdrf: bad argument"); \
+    return interaction_hdrf<T>(cvt_quad<T>(q), S, m, cvt_comp<T>(comp), cvt_added<T>(added_surface), hdr_J, bhr_uw,    \
+                               bhr_dw, as_stream(stream));                                                             \
+  }                                                                                                                    \
+  extern "C" int vsm_postprocess_vza_hdrf_##SFX(int N, int n_stokes, int S, int nV, const int* row0_h, const T* w_h,   \
+                                                const T* hdr_J, T* hdr, void* stream) {                                \
+    VSM_REQUIRE(row0_h && w_h && hdr_J && hdr, "postprocess_vza_hdrf: null argument");                                 \
+    return postprocess_vza_hdrf<T>(N, n_stokes, S, nV, row0_h, w_h, hdr_J, hdr, as_stream(stream));                    \
+  }                                                                                                                    \
   extern "C" int vsm_coxmunk_ss_correction_##SFX(const vsm_coxmunk_##SFX* surf, int n_stokes, int S, int nV,           \
                                                  const T* mu_v_h, const T* dphi_h, T mu0, int m_max, int nphi,         \
                                                  const T* phi, const T* wphi, const T* tau_total, T* coef, T* R_SFI,   \

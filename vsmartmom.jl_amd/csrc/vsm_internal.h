@@ -108,6 +108,11 @@ template <typename T>
 int brdf_surface_lin(const quad<T>& q, int S, int m, const T* rho, const T* drho, int iparam, const T* tau_sum,
                      const T* tau_sum_dot, int p_layer, const T* F0, const added<T>& a, const added_lin<T>& al, hipStream_t st);
 template <typename T>
+int interaction_hdrf(const quad<T>& q, int S, int m, const composite<T>& c, const added<T>& a, T* hdr_J, T* bhr_uw, T* bhr_dw,
+                     hipStream_t st);
+template <typename T>
+int postprocess_vza_hdrf(int N, int ns, int S, int nV, const int* row0_h, const T* w_h, const T* hdr_J, T* hdr, hipStream_t st);
+template <typename T>
 int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, const T* mu_v_h, const T* dphi_h, T mu0, int m_max,
                           int nphi, const T* phi, const T* wphi, const T* tau_total, T* coef, T* R_SFI, hipStream_t st);
 

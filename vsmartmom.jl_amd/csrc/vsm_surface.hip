@@ -434,6 +434,10 @@ int lambertian_surface_spectral(const quad<T>& q, int S, int m, const T* albedo,
 }
 
 // ---- TMS single-scattering correction (coxmunk_surface.jl:481-569) ---------------------------------------------------
+struct pp_args_s {
+  int row0[64];
+  double w[256];
+};
 struct ss_geom {
   double mu_v[64];
   double dphi[64];
@@ -514,12 +518,88 @@ int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, con
   return VSM_OK;
 }
 
+// ---- HDRF / BHR diagnostics (CoreKernel/interaction_hdrf.jl:4-42; postprocessing_vza_hdrf!, postprocessing_vza.jl:103-115) ----
+// after the surface interaction: hdr_J0-[:, s] = r-+_surf J0+ + j0-_surf (the upwelling field just above the surface) and, for
+// m = 0, the hemispheric fluxes per Stokes component  bhr_uw[c, s] = sum_{j = c mod n} hdr_J0-[j] w_j mu_j,
+// bhr_dw[c, s] = sum_{j = c mod n} J0+[j] w_j mu_j + j0+_surf[i_mu0 n] mu[i_mu0 n]  (the reference adds the I entry of the direct
+// beam to every component).  One workgroup per spectral point.
+template <typename T>
+__global__ void __launch_bounds__(128) k_interaction_hdrf(int N, int ns, int m, int i_mu0, const T* __restrict__ mu,
+                                                          const T* __restrict__ wt, const T* __restrict__ r_mp, long long rstride,
+                                                          const T* __restrict__ j0_p, const T* __restrict__ j0_m,
+                                                          const T* __restrict__ J0_p, T* hdr_J, T* bhr_uw, T* bhr_dw) {
+  __shared__ T Jp[128];
+  __shared__ T up[128];
+  const long long s = blockIdx.x;
+  const int i = threadIdx.x;
+  Jp[i] = (i < N) ? J0_p[s * N + i] : T(0);
+  __syncthreads();
+  T h = T(0);
+  if (i < N) {
+    const T* r = r_mp + s * rstride;
+    for (int k = 0; k < N; ++k) h += r[i + (long long)N * k] * Jp[k];
+    h += j0_m[s * N + i];
+    hdr_J[s * N + i] = h;
+  }
+  up[i] = h;
+  __syncthreads();
+  if (m == 0 && i < ns) {
+    T u = T(0), d = T(0);
+    for (int j = i; j < N; j += ns) {
+      u += up[j] * wt[j] * mu[j];
+      d += Jp[j] * wt[j] * mu[j];
+    }
+    const int i0 = ns * i_mu0;
+    bhr_uw[i + (long long)ns * s] = u;
+    bhr_dw[i + (long long)ns * s] = d + j0_p[s * N + i0] * mu[i0];
+  }
+}
+template <typename T>
+__global__ void k_postprocess_hdrf(int N, int ns, long long S, int nV, pp_args_s pa, const T* __restrict__ hdr_J, T* hdr) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)nV * ns * S) return;
+  const int v = (int)(e % nV), k = (int)((e / nV) % ns);
+  const long long s = e / ((long long)nV * ns);
+  hdr[e] += (T)pa.w[v + nV * k] * hdr_J[s * N + pa.row0[v] + k];
+}
+template <typename T>
+int interaction_hdrf(const quad<T>& q, int S, int m, const composite<T>& c, const added<T>& a, T* hdr_J, T* bhr_uw, T* bhr_dw,
+                     hipStream_t st) {
+  if (q.N > 128) {
+    set_error("interaction_hdrf: N <= 128 (got %d)", q.N);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (S <= 0) return VSM_OK;
+  hipLaunchKernelGGL(k_interaction_hdrf<T>, dim3(S), dim3(128), 0, st, q.N, q.n_stokes, m, q.i_mu0, q.mu, q.wt, a.r_mp,
+                     a.mat_stride, a.j0_p, a.j0_m, c.J0_p, hdr_J, bhr_uw, bhr_dw);
+  VSM_LAUNCH_CHECK("k_interaction_hdrf");
+  return VSM_OK;
+}
+template <typename T>
+int postprocess_vza_hdrf(int N, int ns, int S, int nV, const int* row0_h, const T* w_h, const T* hdr_J, T* hdr, hipStream_t st) {
+  if (nV > 64 || nV * ns > 256) {
+    set_error("postprocess_vza_hdrf: at most 64 viewing angles per call (got %d)", nV);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (S <= 0 || nV <= 0) return VSM_OK;
+  pp_args_s pa;
+  for (int v = 0; v < nV; ++v) pa.row0[v] = row0_h[v];
+  for (int x = 0; x < nV * ns; ++x) pa.w[x] = (double)w_h[x];
+  const long long tot = (long long)nV * ns * S;
+  hipLaunchKernelGGL(k_postprocess_hdrf<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, ns, (long long)S, nV, pa,
+                     hdr_J, hdr);
+  VSM_LAUNCH_CHECK("k_postprocess_hdrf");
+  return VSM_OK;
+}
+
 #define VSM_INST_SURF(T)                                                                                                     \
   template int coxmunk_reflectance<T>(const cm_surf<T>&, int, int, const T*, int, int, const T*, const T*, T*, T*, hipStream_t); \
   template int brdf_surface<T>(const quad<T>&, int, int, const T*, const T*, const added<T>&, hipStream_t);                   \
   template int lambertian_surface_spectral<T>(const quad<T>&, int, int, const T*, const T*, const added<T>&, hipStream_t);    \
   template int brdf_surface_lin<T>(const quad<T>&, int, int, const T*, const T*, int, const T*, const T*, int, const T*,      \
                                    const added<T>&, const added_lin<T>&, hipStream_t);                                        \
+  template int interaction_hdrf<T>(const quad<T>&, int, int, const composite<T>&, const added<T>&, T*, T*, T*, hipStream_t);  \
+  template int postprocess_vza_hdrf<T>(int, int, int, int, const int*, const T*, const T*, T*, hipStream_t);                  \
   template int coxmunk_ss_correction<T>(const cm_surf<T>&, int, int, int, const T*, const T*, T, int, int, const T*, const T*, \
                                         const T*, T*, T*, hipStream_t);
 VSM_INST_SURF(double)
