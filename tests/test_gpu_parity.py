@@ -866,3 +866,32 @@ def test_rt_run_full_output_hdrf_bhr(vsm, arch, pol, l_trunc, albedo):
     else:
         assert not hdr.any() and not bhr_uw.any()
     assert _rel(bhr_dw, hd["bhr_dw"][0]) < 1e-9
+
+
+def test_c4_full_size_properties_and_oracle_sample(vsm, arch):
+    """BASELINE.json configs[3], one GPU's share at its FULL size (N = 96 = 32 streams x IQU, 60 layers, 12 500 of the 100 000
+    spectral points, FP32, m = 0..2) through the FP32 strip layer kernel: determinism, permutation equivariance over the
+    spectral axis, |Q|,|U| <= I, and the FP64 oracle on a sample spread over the band at the reference's FP32 gate
+    (max relative deviation 1e-2, test/test_float32.jl:58-64).  The 8-GPU run is this block repeated on every rank plus one
+    gather (tests/test_cpu_host_and_abi.py covers the sharding logic)."""
+    import bench
+    S, L = 12500, 60
+    tau_rayl, tau_abs = bench.o2a_atmosphere(S, L)
+    H = vsm.host_model
+    geo = ("IQU", 59, 40.0, [30.0], [0.0])
+    mk = lambda tr, ta: H.model_from_arrays(arch, *geo, tau_rayl=tr, tau_abs=ta, depol=0.0279, albedo=0.15, m_max=2,
+                                            float_type=np.float32)
+    base = mk(tau_rayl, tau_abs)
+    assert base.quad_points.Nquad * 3 == 96
+    R1, T1 = vsm.CoreRT.rt_run(base)
+    R1b, T1b = vsm.CoreRT.rt_run(base)
+    assert R1.dtype == np.float32 and np.array_equal(R1, R1b) and np.array_equal(T1, T1b)
+    assert np.all(np.isfinite(R1)) and np.all(R1[:, 0, :] > 0)
+    assert np.all(np.hypot(R1[:, 1, :], R1[:, 2, :]) <= R1[:, 0, :] * (1 + 1e-5))
+    perm = np.random.default_rng(2).permutation(S)
+    R2, T2 = vsm.CoreRT.rt_run(mk(tau_rayl[perm], tau_abs[perm]))
+    assert np.array_equal(R2, R1[:, :, perm]) and np.array_equal(T2, T1[:, :, perm])
+    idx = np.linspace(0, S - 1, 6).astype(int)
+    om = O.build_model(*geo, tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx], depol=0.0279, albedo=0.15, m_max=2)
+    Ro, To = O.rt_run(om)
+    assert _rel(R1[:, :, idx], Ro) < 1e-2 and _rel(T1[:, :, idx], To) < 1e-2, (_rel(R1[:, :, idx], Ro), _rel(T1[:, :, idx], To))

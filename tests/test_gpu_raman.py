@@ -330,3 +330,51 @@ def test_rt_run_rrs_reference_regression_phase1b(vsm, arch, golden_dir, FT):
     tol = 1e-8 if FT == np.float64 else 1e-2
     for name, g, r in zip(("R", "T", "ieR", "ieT"), got, ref):
         assert _rel(g, r) <= tol, (name, _rel(g, r))
+
+
+def test_c5_full_size_raman_properties(vsm, arch):
+    """BASELINE.json configs[4] at its FULL size (nStokes = 3, 20 000 spectral points, K = 40 Raman lines, N = 21, 12 layers,
+    m = 0..2; the shape of tools/raman_timing.py), through size-independent properties: (1) on a spectrally uniform column
+    with the Raman phase matrix equal to the elastic one, ieR(n1) = dR/d(varpi_Cabannes) * sum of the in-band line weights
+    (first-order perturbation identity against central differences of the device's elastic rt_run); (2) recipients whose
+    donors all fall outside the band get exactly zero inelastic signal from those lines (edge profile of the weight sum);
+    (3) the halo-extended block of rank 1 of 2 (the 2-GPU decomposition of C5) equals the same rows of the full run."""
+    FT, S, L, K = np.float64, 20000, 12, 40
+    Hm = vsm.host_model
+    dp = np.full(L, 1.0 / L)
+    tau_rayl = np.tile(0.3 * dp, (S, 1))
+    tau_abs = np.tile(0.05 * dp, (S, 1))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.05, m_max=2)
+    pm = Hm.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], **kw)
+    pm.varpi_Cabannes = 0.96
+    assert pm.quad_points.Nquad * 3 == 21
+    shifts = np.unique(np.concatenate([np.arange(-K // 2, 0), np.arange(1, K - K // 2 + 1)]) * 7)
+    assert len(shifts) == K
+    w_ie = np.linspace(0.5, 1.5, K) * 0.04 / K
+    fsc = pm.tau_rayl / (pm.tau_rayl + pm.tau_abs)
+    rs = vsm.CoreRTRaman.RRS(shifts, w_ie, pm.greek_rayleigh, fscattRayl=fsc)
+    R, T, ieR, ieT = vsm.CoreRTRaman.rt_run(rs, pm, 1)
+    assert R.shape == (1, 3, S) and np.all(np.isfinite(ieR)) and np.all(np.isfinite(ieT))
+    # the elastic leg of the Raman run equals the elastic rt_run
+    h = 1e-5
+    small = Hm.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], **{**kw, "tau_rayl": tau_rayl[:4], "tau_abs": tau_abs[:4]})
+    small.varpi_Cabannes = 0.96
+    R0, T0 = vsm.CoreRT.rt_run(small)
+    assert _rel(R[:, :, :4], R0) < 1e-10 and _rel(T[:, :, :4], T0) < 1e-10
+    small.varpi_Cabannes = 0.96 + h
+    Rp, Tp = vsm.CoreRT.rt_run(small)
+    small.varpi_Cabannes = 0.96 - h
+    Rm, Tm = vsm.CoreRT.rt_run(small)
+    dR, dT = (Rp - Rm)[:, :, :1] / (2 * h), (Tp - Tm)[:, :, :1] / (2 * h)     # uniform column: the same at every point
+    n1 = np.arange(S)
+    wsum = np.zeros(S)
+    for sft, w in zip(shifts, w_ie):
+        wsum += w * ((n1 + sft >= 0) & (n1 + sft < S))
+    assert _rel(ieR, dR * wsum[None, None, :]) <= 5e-7
+    assert _rel(ieT, dT * wsum[None, None, :]) <= 5e-7
+    assert wsum[0] < wsum[S // 2] and abs(ieR[0, 0, 0]) < abs(ieR[0, 0, S // 2])     # band edge: fewer donors
+    # 2-GPU decomposition: rank 1 owns the second half, computes on its halo-extended slice, no exchange
+    sl = vsm.parallel.shard_slice(S, 1, 2)
+    part = vsm.CoreRTRaman.rt_run(rs, pm, 1, spec_slice=sl)
+    for g, f in zip(part, (R, T, ieR, ieT)):
+        assert g.shape[2] == S // 2 and _rel(g, f[:, :, sl]) <= 1e-13
