@@ -45,6 +45,21 @@ def main():
     print("Raman RRS: N=%d S=%d K=%d L=%d m=0..2: first run %.2f s, second run %.2f s -> %.0f spectral-points/s; peak device memory %.1f GB"
           % (N, S, len(shifts), L, t1 - t0, t2 - t1, S / (t2 - t1), torch.cuda.max_memory_allocated() / 1e9))
     print("  max |ieR| = %.3e, max |R| = %.3e" % (np.abs(out[2]).max(), np.abs(out[0]).max()))
+    # ALGORITHMIC flops (counted from the reference's statements): per doubling step the elastic 12N^3+8N^2 plus,
+    # per in-band Raman line, 16 products + 10 mat-vecs (doubling_inelastic.jl:13-164); per interaction the elastic 24N^3+8N^2
+    # plus, per in-band line, 18 products + 8 mat-vecs (interaction_inelastic.jl:319-521)
+    H = vsm.host_model
+    n3, n2 = float(N) ** 3, float(N) ** 2
+    lods = H.constructCoreOpticalProperties(model, 0)
+    nds = [H.get_dtau_ndoubl(np.atleast_1d(lo.tau), np.broadcast_to(np.asarray(lo.varpi), np.atleast_1d(lo.tau).shape),
+                             model.quad_points, np.float64, model.numerics)[1] for lo in lods]
+    n1 = np.arange(S)
+    kin = sum(((n1 + int(sh) >= 0) & (n1 + int(sh) < S)).astype(float) for sh in shifts).mean()     # in-band lines per recipient
+    per_m = sum(nd * (12 * n3 + 8 * n2 + kin * (32 * n3 + 20 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (36 * n3 + 16 * n2))
+    flops_pt = 3 * per_m
+    tf = flops_pt * S / (t2 - t1) / 1e12
+    print("  ndoubl per layer %s, %.1f in-band lines per recipient: algorithmic %.2f GFLOP/point -> %.1f TFLOP/s = %.3f of the FP64 MFMA "
+          "peak (78.6 TF)" % (nds, kin, flops_pt / 1e9, tf, tf / 78.6))
     if a.oracle_points:
         from oracle import vsm_oracle as O
         from oracle import vsm_oracle_raman as OR

@@ -226,7 +226,12 @@ def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list]
         Zpp_ie, Zmp_ie = H.compute_Z_moments(pol, qp.qp_mu, RS_type.greek_raman, m)   # computeRamanZλ! (:917-924)
         drs.Zpp, drs.Zmp = CR.to_device_matrix(Zpp_ie, arch, FT), CR.to_device_matrix(Zmp_ie, arch, FT)
         lods = H.constructCoreOpticalProperties(model, m)
-        _, tau_sum_all = H.extractEffectiveProps(lods, FT)
+        tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
+        # the reference dispatches interaction!(RS_type, scattering_interfaces_all[iz], ...) on these tags; only the
+        # ScatteringInterface_11 inelastic method is built here (rt_kernel!(::RRS) hard-wires scatter = true, rt_kernel.jl:365)
+        if any(t != "11" for t in tags):
+            raise _lib.VSMError("rt_run(::RRS): a layer with max(tau*varpi) <= 2 eps gives interface tags %s; only "
+                                "ScatteringInterface_11 is implemented for the inelastic interaction" % sorted(set(tags)))
         for iz, lo in enumerate(lods):
             tau_full = np.atleast_1d(lo.tau).astype(FT)
             varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
@@ -242,7 +247,7 @@ def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list]
             rt_kernel_rrs_(drs, pol, added, added_rs, comp, comp_rs, props, up(tau_sum_all[ext, iz]), m, dq, arch, iz + 1, F0d,
                            FT, model.numerics, dtau=up(dtau_full[ext]), ndoubl=nd, expk=expk, trace=trace)
         CR.create_surface_layer_(model.albedo, added_surface, m, dq, up(tau_sum_all[ext, -1]))
-        interaction_inelastic_(drs, "11", comp, comp_rs, added_surface, surf_rs)
+        interaction_inelastic_(drs, tags[-1], comp, comp_rs, added_surface, surf_rs)
         postprocessing_vza_rs_(pol, comp, comp_rs, model.vza, model.vaz, qp, m, float(weight), R_SFI, T_SFI, ieR_SFI, ieT_SFI)
     if device_out:
         return tuple(t[crop].contiguous() for t in out)
