@@ -72,7 +72,7 @@ def main():
                     help="aerosol: SURVEY 8(d) variant -- HG aerosol (g=0.7, ssa=0.95, tau=0.2) in the lowest 6 layers, "
                          "2*nstreams-1 moments: Z differs per point and all 2*nstreams Fourier moments run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="spectral points PER HOST CORE of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="spectral points PER HOST CORE of the CPU-baseline sample")
     args = ap.parse_args()
 
     import torch
@@ -264,7 +264,7 @@ def hbm_traffic_per_launch(kernel, cfg, S_local):
 
 
 def _cpu_worker(job):
-    """One worker of the CPU baseline: the numpy oracle on its share of the sample (1 BLAS thread per worker)."""
+    """One worker of the FP32 CPU baseline: the numpy oracle on its share of the sample (1 BLAS thread per worker)."""
     cfg, L, idx = job
     from oracle import vsm_oracle as O
     FT = np.float64 if cfg["FT"] == "f64" else np.float32
@@ -279,14 +279,35 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(cfg, n_per_core, L):
-    """The oracle (numpy port of the reference's CPU path) on a bounded sample of the same workload, on ALL host
-    cores: one single-threaded worker process per core (the reference's CPU path threads over the spectral axis
-    with blas_threads = 1), `n_per_core` spectral points each, evenly spaced over the band, all
-    layers, all moments.  ndoubl of a share is recomputed from the share's own max(tau*varpi); with Rayleigh-only
-    scattering (spectrally flat tau*varpi) it equals the full batch's."""
+    """CPU baseline on a bounded sample of the same workload, on ALL host cores of the box.
+
+    FP64 configurations: the C + OpenMP restatement (oracle/vsm_oracle_c.c; one LU per point, threads over the spectral
+    axis -- the structure of the reference's CPU path, src/CoreRT/tools/cpu_batched.jl:25-82), `n_per_core` points per core,
+    evenly spaced over the band, all layers, all moments.  FP32 configurations: the numpy oracle in single precision, one
+    single-threaded worker process per core.  ndoubl of the sample is recomputed from the sample's own max(tau*varpi); with
+    Rayleigh-only scattering (spectrally flat tau*varpi) it equals the full batch's."""
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    n_sample = cores * n_per_core
+    idx = np.linspace(0, cfg["S"] - 1, n_sample).astype(int)
+    if cfg["FT"] == "f64":
+        from oracle import vsm_oracle as O, vsm_oracle_c as OC
+        OC.lib()
+        tau_rayl, tau_abs = o2a_atmosphere(cfg["S"], L)
+        mk = lambda ii: O.build_model(cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl[ii], tau_abs=tau_abs[ii],
+                                      depol=0.0279, albedo=0.15, m_max=2)
+        OC.rt_run(mk(idx[:cores]), nthreads=cores)      # thread start-up + page-in, untimed
+        mdl = mk(idx)
+        t0 = time.perf_counter()
+        OC.rt_run(mdl, nthreads=cores)
+        dt = time.perf_counter() - t0
+        return {"value": n_sample / dt, "unit": "spectral-points/s", "cores": cores, "kind": "port",
+                "sample": "%d of the %d spectral points (evenly spaced, %d per core), all %d layers, m=0..2, C + OpenMP "
+                          "restatement (oracle/vsm_oracle_c.c, gcc -O3 -march=x86-64-v3), %d threads over the spectral axis, "
+                          "%.1f s wall" % (n_sample, cfg["S"], n_per_core, L, cores, dt)}
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
-    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    cores = min(cores, 64)
+    n_per_core = max(1, n_per_core // 2)
     n_sample = cores * n_per_core
     idx = np.linspace(0, cfg["S"] - 1, n_sample).astype(int)
     shares = [idx[c::cores] for c in range(cores)]
@@ -305,7 +326,7 @@ def cpu_baseline(cfg, n_per_core, L):
             else:
                 os.environ[k] = v
     return {"value": n_sample / dt, "unit": "spectral-points/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %d spectral points (evenly spaced, %d per core), all %d layers, m=0..2, numpy oracle, "
+            "sample": "%d of the %d spectral points (evenly spaced, %d per core), all %d layers, m=0..2, numpy oracle (FP32), "
                       "%d single-threaded worker processes, %.1f s wall (%.1f s CPU)"
                       % (n_sample, cfg["S"], n_per_core, L, cores, dt, sum(busy))}
 
