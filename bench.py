@@ -72,7 +72,7 @@ def main():
                     help="aerosol: SURVEY 8(d) variant -- HG aerosol (g=0.7, ssa=0.95, tau=0.2) in the lowest 6 layers, "
                          "2*nstreams-1 moments: Z differs per point and all 2*nstreams Fourier moments run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="spectral points PER HOST CORE of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="upper bound of spectral points PER HOST CORE of the CPU-baseline sample (sized for ~15 s)")
     args = ap.parse_args()
 
     import torch
@@ -278,6 +278,19 @@ def _cpu_worker(job):
     return time.perf_counter() - t0
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (cpu.max: the GPU boxes expose 256
+    hardware threads under a 16-CPU quota -- 256 threads then run 2x slower in total than 32)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(float(quota) / float(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(cfg, n_per_core, L):
     """CPU baseline on a bounded sample of the same workload, on ALL host cores of the box.
 
@@ -286,7 +299,7 @@ def cpu_baseline(cfg, n_per_core, L):
     evenly spaced over the band, all layers, all moments.  FP32 configurations: the numpy oracle in single precision, one
     single-threaded worker process per core.  ndoubl of the sample is recomputed from the sample's own max(tau*varpi); with
     Rayleigh-only scattering (spectrally flat tau*varpi) it equals the full batch's."""
-    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = host_cores()
     n_sample = cores * n_per_core
     idx = np.linspace(0, cfg["S"] - 1, n_sample).astype(int)
     if cfg["FT"] == "f64":
@@ -296,6 +309,12 @@ def cpu_baseline(cfg, n_per_core, L):
         mk = lambda ii: O.build_model(cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl[ii], tau_abs=tau_abs[ii],
                                       depol=0.0279, albedo=0.15, m_max=2)
         OC.rt_run(mk(idx[:cores]), nthreads=cores)      # thread start-up + page-in, untimed
+        t0 = time.perf_counter()
+        OC.rt_run(mk(idx[:2 * cores]), nthreads=cores)  # calibration: size the sample for ~15 s of wall time
+        rate = 2 * cores / (time.perf_counter() - t0)
+        n_per_core = int(min(max(4, round(15.0 * rate / cores)), n_per_core, max(1, cfg["S"] // cores)))
+        n_sample = cores * n_per_core
+        idx = np.linspace(0, cfg["S"] - 1, n_sample).astype(int)
         mdl = mk(idx)
         t0 = time.perf_counter()
         OC.rt_run(mdl, nthreads=cores)
