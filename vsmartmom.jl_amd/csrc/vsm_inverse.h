@@ -40,8 +40,10 @@ struct gj_scratch {
 template <typename T, int NPAD, int NT>
 using gj_regs = T[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB];
 
-template <typename T, int NPAD, int NT = 256>
-__device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, gj_scratch<T, NPAD>& sc) {
+// SC: gj_scratch<T, NPAD> or any type with the same members (col / rowP / rowK indexable as [parity][i], piv / dst as
+// [i], info assignable) -- the FP32 strip kernels keep the scratch in the padding columns of an LDS matrix.
+template <typename T, int NPAD, int NT = 256, typename SC>
+__device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc) {
   using C = gj_cfg<NPAD, NT>;
   const int tid = threadIdx.x;
   const int lane = tid & 63;

@@ -1,13 +1,29 @@
 // Column-strip kernels, FP32 edition (64 < N <= 96): the fused layer step of vsm_strip.hip for the hyperspectral
-// configuration (N = 96, Float32).  Same scheme -- every matrix lives as 16-column strips in the accumulator registers of
-// the wave that owns the strip, B operands come straight from those registers, A operands from one of TWO LDS buffers,
-// two workgroups per CU -- with the differences the f32 MFMA imposes:
-//   * v_mfma_f32_16x16x4_f32 accumulator element r of a tile is row 4 (lane>>4) + r (f64: (lane>>4) + 4 r), so the tile
-//     held by a lane, used as B operand of "k-step r", covers k = 16 tb + 4 (lane>>4) + r: the products walk k in that
-//     permuted order (any order is fine as long as the A fragment is fetched for the same k);
-//   * 6 waves (6 strips of 16 columns, 6 row tiles of 4 f32 = 24 VGPRs per strip), 384 threads;
-//   * N = 96 leaves no spare column for the source vectors: their products  tt j, tmp j, r J0+, T01 u, R+- j0-, T21 z
-//     are VALU mat-vecs over the A-form in LDS (4 lanes per row, two shuffles).
+// configuration (N = 96, Float32).  Every matrix lives as 16-column strips in the accumulator registers of the wave that
+// owns the strip, B operands come straight from those registers, A operands from one of TWO LDS buffers.
+//
+// Shape of a workgroup: 6 waves (6 strips of 16 columns; 6 row tiles of 4 f32 = 24 VGPRs per strip), built for THREE waves
+// per SIMD (<= 168 registers): two workgroups per CU = 12 waves = 3 per SIMD.  (One 6-wave workgroup per CU leaves the four
+// SIMDs with 2, 2, 1, 1 waves -- at most 75 % of the MFMA rate -- and every barrier and LDS round trip exposed.)
+//
+// LDS layout ("A-form", k-major): element (row, k) of an A operand at word  k + LDK * row,  LDK = 104.
+//   * v_mfma_f32_16x16x4_f32 keeps accumulator element r of a tile at row 4 (lane>>4) + r, so a strip tile used as B operand
+//     of "k-step r" covers k = 16 tb + 4 kq + r (kq = lane>>4): the four k-steps of a block need A[row][16 tb + 4 kq + 0..3] --
+//     16 contiguous bytes: ONE ds_read_b128 feeds four MFMAs (the earlier layout: four ds_read_b32);
+//   * every LDS address is "one per-lane base + immediate":  fragment (row 16 t + l15)  = afrag + 16 tb + 16 LDK t,
+//     strip element (row 16 ta + 4 kq + r, column col) = sbase + LDK (16 ta + r) -- no XOR swizzle, nothing for the
+//     compiler to hoist;
+//   * LDK = 104: the b128 fragment reads are conflict-free in the hardware's 4 x 16 lane groups (checked exhaustively for
+//     LDK in 96..128; 100 / 108 are 2-way), the strip stores are 2-way on ds_write_b32, which is free (the instruction's
+//     VGPR transfer costs as much);
+//   * the 8 padding words of each row of a buffer are 8 strided vector slots; the Gauss-Jordan fallback keeps its scratch
+//     there (in the padding of the very matrix it inverts), so two buffers + five contiguous vectors = 81 860 B: two
+//     workgroups per CU.
+// N = 96 leaves no spare column for the source vectors: their products  tt j, tmp j, r J0+, T01 u, R+- j0-, T21 z  are VALU
+// mat-vecs over the A-form (the A-fragment pattern of the wave's own row tile: conflict-free; two shuffles).
+// Rows / columns >= N of every strip and every A-form are exactly zero BY CONSTRUCTION (the elemental step and the global
+// loads mask them, products of zero-padded operands stay zero, the identity is only added where row < N), so no store needs
+// a mask.
 #include <stdlib.h>
 
 #include "vsm_internal.h"
@@ -34,10 +50,12 @@ __device__ unsigned long long vsm_phase_cycles_strip32[32];
 
 namespace {
 
-constexpr int FNP = 96;    // padded matrix size
-constexpr int FNW = 6;     // waves = column strips
+constexpr int FNP = 96;        // padded matrix size
+constexpr int FNW = 6;         // waves = column strips
 constexpr int FNT = 64 * FNW;
 constexpr int FTL = FNP / 16;  // row tiles per strip
+constexpr int LDK = 104;       // words per row of an A-form
+constexpr int NVEC = 5;
 
 struct fstrip {
   f4_t v[FTL];
@@ -48,134 +66,154 @@ struct fstrip {
 };
 
 struct fsmem32 {
-  float P[FNP * FNP];
-  float Q[FNP * FNP];
-  float vec[10][FNP];
+  float P[FNP * LDK];
+  float Q[FNP * LDK];
+  float vec[NVEC][FNP];
   float red[2][8];
-  gj_scratch<float, FNP> gj;
+  int gj_info;
+};
+static_assert(sizeof(fsmem32) <= 81920, "two workgroups per CU");
+
+// Gauss-Jordan scratch in the padding words (k = 96 .. 103) of the rows of the matrix being inverted
+struct pad_vec {
+  float* b;
+  __device__ __forceinline__ float& operator[](int i) const { return b[LDK * i]; }
+};
+struct pad_vec2 {
+  float* b;
+  __device__ __forceinline__ pad_vec operator[](int par) const { return pad_vec{b + par}; }
+};
+struct pad_ivec {
+  int* b;
+  __device__ __forceinline__ int& operator[](int i) const { return b[LDK * i]; }
+};
+struct gj_pad_scratch {
+  pad_vec2 col, rowP, rowK;
+  pad_ivec piv, dst;
+  int& info;
 };
 
-// A-form swizzle of the FP32 strips.  The generic lidx() of vsm_lds.h separates the four k of an A fragment by the LOW
-// bits of k; here a lane group (lane>>4 = kq) covers k = 16 tb + 4 kq + r, so the row XOR must depend on bits 2..3 of k:
-//     lidx32(row, k) = (row ^ s32(k)) + 96 k ,   s32(k) = (k & 3) | (k & 8) | ((k & 4) << 2)
-// s32 maps the low four bits of k onto span{1, 2, 8, 16} (4 is left out): both the A-fragment reads (16 rows x two kq
-// per 32-lane group) and the accumulator-layout stores (rows 4 kq + r x 16 columns) hit 32 distinct banks
-// (checked exhaustively; the generic swizzle gave 2-way conflicts on every fragment read and products at 1/3 of the
-// MFMA rate).
-__device__ __forceinline__ int s32(int b) { return (b & 3) | (b & 8) | ((b & 4) << 2); }
-__device__ __forceinline__ int lidx32(int a, int b) { return (a ^ s32(b)) + FNP * b; }
-
-// Per-lane addressing as "two base registers + immediate":
-//   A fragment (row 16 t + l15, column k = 16 tb + 4 kq + r, ks = 4 tb + r):  lidx32 = ar[r] + bt[t] + 96 (16 tb + r)
-//   strip element (row 16 ta + 4 kq + r, column col):                        lidx32 = sr[r] + ((16 ta) ^ p16)
 struct fpos {
   int lane, wave, l15, kq, col;
-  int ar[4], bt[FTL];
-  int sr[4], p16;
+  int afrag;   // 4 kq + LDK l15
+  int sbase;   // col + 4 LDK kq
+  int dr;      // l15 - 4 kq: the diagonal of the wave's strip is element r == dr of tile ta == wave (when 0 <= dr < 4)
   __device__ __forceinline__ fpos() {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     l15 = lane & 15;
     kq = lane >> 4;
     col = 16 * wave + l15;
-    const int L = l15 ^ ((kq >> 1) << 3), pq = kq & 1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ar[r] = (L ^ r) + 4 * FNP * kq;
-#pragma unroll
-    for (int t = 0; t < FTL; ++t) bt[t] = 16 * (t ^ pq);
-    const int m = s32(col);
-    p16 = m & 16;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sr[r] = (r ^ (m & 3)) + ((4 * kq) ^ (m & 8)) + FNP * col;
+    afrag = 4 * kq + LDK * l15;
+    sbase = col + 4 * LDK * kq;
+    dr = l15 - 4 * kq;
   }
   __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + 4 * kq + r; }
-  __device__ __forceinline__ int aidx(int t, int ks) const {
-    return ar[ks & 3] + bt[t] + FNP * (16 * (ks >> 2) + (ks & 3));
-  }
-  __device__ __forceinline__ int sidx(int ta, int r) const { return sr[r] + ((16 * ta) ^ p16); }
 };
 
-// acc += A * B   (A: A-form in LDS, B: strip in registers); KS = 4 ceil(N / 16) MFMA steps
-// Fragments are requested PF k-steps ahead: one f32 k-step is only 6 x 32 = 192 MFMA cycles, less than the LDS latency
-// under load, so the single-step lookahead of the FP64 kernels (4 x 64 cycles per step) leaves the pipe at 40 %.
-constexpr int PF = 1;
-template <int KS>
-__device__ __forceinline__ void mm_ab(fstrip& acc, const float* A, const fstrip& B, fpos& p) {
-  float a[PF + 1][FTL];
+__device__ __forceinline__ f4_t lds4(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
+
+// acc += A * B   (A: A-form in LDS, B: strip in registers); KB = ceil(N / 16) blocks of four MFMA k-steps.
+// Row tiles go in pairs (two independent accumulators alternate: the 40-cycle dependent latency of the f32 MFMA never
+// stalls its 32-cycle issue); the fragments of the next pair are requested before the MFMAs of the current one.
+template <int KB>
+__device__ __forceinline__ void mm_ab(fstrip& acc, const float* A, const fstrip& B, const fpos& p) {
+  const float* a0 = A + p.afrag;
+  constexpr int NP = 3 * KB;
+  f4_t fa[2][2];
+  fa[0][0] = lds4(a0);
+  fa[0][1] = lds4(a0 + 16 * LDK);
 #pragma unroll
-  for (int s0 = 0; s0 < PF; ++s0)
-#pragma unroll
-    for (int t = 0; t < FTL; ++t) a[s0][t] = A[p.aidx(t, s0)];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + PF < KS) {
-#pragma unroll
-      for (int t = 0; t < FTL; ++t) a[(ks + PF) % (PF + 1)][t] = A[p.aidx(t, ks + PF)];
+  for (int i = 0; i < NP; ++i) {
+    if (i + 1 < NP) {
+      const int tb = (i + 1) / 3, t0 = 2 * ((i + 1) % 3);
+      fa[(i + 1) & 1][0] = lds4(a0 + 16 * tb + 16 * LDK * t0);
+      fa[(i + 1) & 1][1] = lds4(a0 + 16 * tb + 16 * LDK * (t0 + 1));
     }
-    const float b = B.v[ks >> 2][ks & 3];
+    const int tb = i / 3, t0 = 2 * (i % 3);
 #pragma unroll
-    for (int t = 0; t < FTL; ++t) acc.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b, acc.v[t]);
+    for (int r = 0; r < 4; ++r) {
+      acc.v[t0] = mfma<float>::mma(fa[i & 1][0][r], B.v[tb][r], acc.v[t0]);
+      acc.v[t0 + 1] = mfma<float>::mma(fa[i & 1][1][r], B.v[tb][r], acc.v[t0 + 1]);
+    }
   }
 }
-template <int KS>
+// acc1 += A * B1 ; acc2 += A * B2   (shared A fragments: eight MFMAs per ds_read_b128)
+template <int KB>
 __device__ __forceinline__ void mm_ab2(fstrip& acc1, fstrip& acc2, const float* A, const fstrip& B1, const fstrip& B2,
-                                       fpos& p) {
-  float a[PF + 1][FTL];
+                                       const fpos& p) {
+  const float* a0 = A + p.afrag;
+  constexpr int NP = 6 * KB;
+  f4_t fa[2];
+  fa[0] = lds4(a0);
 #pragma unroll
-  for (int s0 = 0; s0 < PF; ++s0)
-#pragma unroll
-    for (int t = 0; t < FTL; ++t) a[s0][t] = A[p.aidx(t, s0)];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + PF < KS) {
-#pragma unroll
-      for (int t = 0; t < FTL; ++t) a[(ks + PF) % (PF + 1)][t] = A[p.aidx(t, ks + PF)];
+  for (int i = 0; i < NP; ++i) {
+    if (i + 1 < NP) {
+      const int tb = (i + 1) / 6, t = (i + 1) % 6;
+      fa[(i + 1) & 1] = lds4(a0 + 16 * tb + 16 * LDK * t);
     }
-    const float b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
+    const int tb = i / 6, t = i % 6;
 #pragma unroll
-    for (int t = 0; t < FTL; ++t) {
-      acc1.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b1, acc1.v[t]);
-      acc2.v[t] = mfma<float>::mma(a[ks % (PF + 1)][t], b2, acc2.v[t]);
+    for (int r = 0; r < 4; ++r) {
+      acc1.v[t] = mfma<float>::mma(fa[i & 1][r], B1.v[tb][r], acc1.v[t]);
+      acc2.v[t] = mfma<float>::mma(fa[i & 1][r], B2.v[tb][r], acc2.v[t]);
     }
   }
 }
 
-template <typename F>
-__device__ __forceinline__ void store_strip(float* dst, const fstrip& s, const fpos& p, F f) {
+__device__ __forceinline__ void store_strip(float* dst, const fstrip& s, const fpos& p) {
+  float* d0 = dst + p.sbase;
 #pragma unroll
   for (int ta = 0; ta < FTL; ++ta)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      dst[p.sidx(ta, r)] = f(s.v[ta][r], row, p.col);
-    }
+    for (int r = 0; r < 4; ++r) d0[LDK * (16 * ta + r)] = s.v[ta][r];
 }
 __device__ __forceinline__ void load_strip(fstrip& s, const float* src, const fpos& p) {
+  const float* s0 = src + p.sbase;
 #pragma unroll
   for (int ta = 0; ta < FTL; ++ta)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s.v[ta][r] = src[p.sidx(ta, r)];
+    for (int r = 0; r < 4; ++r) s.v[ta][r] = s0[LDK * (16 * ta + r)];
 }
+// Strip <-> global column-major N x N.  A lane's four elements of a tile are four consecutive rows of one column: one
+// 16-byte access when N % 4 == 0 (then the rows of a tile are all inside or all outside the matrix).
 __device__ __forceinline__ void load_strip_global(fstrip& s, const float* __restrict__ g, int N, const fpos& p) {
   const int cc = min(p.col, N - 1);
+  const float* g0 = g + (long long)N * cc + 4 * p.kq;
+  if ((N & 3) == 0) {
 #pragma unroll
-  for (int ta = 0; ta < FTL; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const float v = g[min(row, N - 1) + (long long)N * cc];
-      s.v[ta][r] = (row < N && p.col < N) ? v : 0.0f;
+    for (int ta = 0; ta < FTL; ++ta) {
+      const bool in = p.col < N && 16 * ta + 4 * p.kq < N;
+      const f4_t v = *reinterpret_cast<const f4_t*>(in ? g0 + 16 * ta : g);
+      s.v[ta] = in ? v : acc_zero<float>();
     }
+  } else {
+#pragma unroll
+    for (int ta = 0; ta < FTL; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        const float v = g[min(row, N - 1) + (long long)N * cc];
+        s.v[ta][r] = (row < N && p.col < N) ? v : 0.0f;
+      }
+  }
 }
 __device__ __forceinline__ void store_strip_global(float* __restrict__ g, const fstrip& s, int N, const fpos& p) {
+  if (p.col >= N) return;
+  float* g0 = g + (long long)N * p.col + 4 * p.kq;
+  if ((N & 3) == 0) {
 #pragma unroll
-  for (int ta = 0; ta < FTL; ++ta)
+    for (int ta = 0; ta < FTL; ++ta)
+      if (16 * ta + 4 * p.kq < N) *reinterpret_cast<f4_t*>(g0 + 16 * ta) = s.v[ta];
+  } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      if (row < N && p.col < N) g[row + (long long)N * p.col] = s.v[ta][r];
-    }
+    for (int ta = 0; ta < FTL; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (p.row(ta, r) < N) g0[16 * ta + r] = s.v[ta][r];
+  }
 }
+// D X D: sign (+) where row and column have the same U/V parity (doubling.jl:178-201)
 __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, const fpos& p) {
   const bool uc = is_uv_row(p.col, ns);
 #pragma unroll
@@ -183,39 +221,24 @@ __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) d.v[ta][r] = (is_uv_row(p.row(ta, r), ns) == uc) ? x.v[ta][r] : -x.v[ta][r];
 }
-// global column-major N x N -> A-form in LDS (zero padded); 96 of the 384 threads' lanes... one column per wave and
-// pass: lanes 0..63 take rows 0..63, then rows 64..95
-__device__ __forceinline__ void stage_aform(float* L, const float* __restrict__ g, int N, const fpos& p) {
-  // all column loads in flight before the first LDS write (one workgroup per CU: a round trip per column is exposed)
-  constexpr int NJ = FNP / FNW;
-  float v0[NJ], v1[NJ];
-#pragma unroll
-  for (int c = 0; c < NJ; ++c) {
-    const int j = p.wave + FNW * c;
-    v0[c] = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0f;
-    const int i = 64 + (p.lane & 31);
-    v1[c] = (p.lane < 32 && i < N && j < N) ? g[i + (long long)N * j] : 0.0f;
-  }
-#pragma unroll
-  for (int c = 0; c < NJ; ++c) {
-    const int j = p.wave + FNW * c;
-    L[lidx32(p.lane, j)] = v0[c];
-    if (p.lane < 32) L[lidx32(64 + p.lane, j)] = v1[c];
-  }
-}
-
-// y1 = A x1, y2 = A x2 (x2 scaled) over the A-form in LDS.  Lane (kq, l15) of wave w walks row 16 w + l15 over the
-// columns k = 16 tb + 4 kq + r -- exactly the A-fragment pattern of tile w, hence conflict-free -- and the four kq
-// groups are summed with two shuffles.  Lanes with kq == 0 receive the sums.  x entries beyond N must be zero.
+// y1 = A x1, y2 = scale2 * A x2 over the A-form in LDS: lane (kq, l15) of wave w walks row 16 w + l15 over the columns
+// k = 16 tb + 4 kq + 0..3 -- the A-fragment reads of row tile w -- and the four kq groups are summed with two shuffles
+// (every lane receives the sums).  x1 / x2: contiguous vectors, entries >= N zero.
+template <int KB>
 __device__ __forceinline__ void matvec2(const float* A, const float* x1, const float* x2, float scale2, float& y1, float& y2,
                                         const fpos& p) {
+  const float* a0 = A + p.afrag + 16 * LDK * p.wave;
+  const float* u0 = x1 + 4 * p.kq;
+  const float* v0 = x2 + 4 * p.kq;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 4 * FTL; ++ks) {
-    const int k = 16 * (ks >> 2) + 4 * p.kq + (ks & 3);
-    const float a = A[p.ar[ks & 3] + 16 * (p.wave ^ (p.kq & 1)) + FNP * (16 * (ks >> 2) + (ks & 3))];
-    s1 += a * x1[k];
-    s2 += a * x2[k];
+  for (int tb = 0; tb < KB; ++tb) {
+    const f4_t a = lds4(a0 + 16 * tb), u = lds4(u0 + 16 * tb), v = lds4(v0 + 16 * tb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1 += a[r] * u[r];
+      s2 += a[r] * v[r];
+    }
   }
   s2 *= scale2;
   s1 += __shfl_xor(s1, 16);
@@ -225,16 +248,29 @@ __device__ __forceinline__ void matvec2(const float* A, const float* x1, const f
   y1 = s1;
   y2 = s2;
 }
+template <int KB>
+__device__ __forceinline__ float matvec1(const float* A, const float* x, const fpos& p) {
+  const float* a0 = A + p.afrag + 16 * LDK * p.wave;
+  const float* u0 = x + 4 * p.kq;
+  float s1 = 0.f;
+#pragma unroll
+  for (int tb = 0; tb < KB; ++tb) {
+    const f4_t a = lds4(a0 + 16 * tb), u = lds4(u0 + 16 * tb);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s1 += a[r] * u[r];
+  }
+  s1 += __shfl_xor(s1, 16);
+  s1 += __shfl_xor(s1, 32);
+  return s1;
+}
 
-__device__ __forceinline__ float strip_norm_bound(const fstrip& e, int N, fsmem32& sm, int& slot, const fpos& p) {
+// Frobenius-norm bound of the block whose strips the waves hold (padding is zero).  Contains ONE barrier.
+__device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, int& slot, const fpos& p) {
   float ss = 0;
 #pragma unroll
   for (int ta = 0; ta < FTL; ++ta)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = e.v[ta][r];
-      if (p.row(ta, r) < N && p.col < N) ss += v * v;
-    }
+    for (int r = 0; r < 4; ++r) ss += e.v[ta][r] * e.v[ta][r];
   const float ws = wave_sum(ss * 1.0001f);
   if (p.lane == 0) sm.red[slot][p.wave] = ws;
   __syncthreads();
@@ -245,7 +281,8 @@ __device__ __forceinline__ float strip_norm_bound(const fstrip& e, int N, fsmem3
   return sqrtf(tot) * 1.001f;
 }
 
-__device__ __forceinline__ void gj_lds_strip(float* V, int N, gj_scratch<float, FNP>* sc) {
+// In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block, identity-padded), 384 threads; ends with a barrier.
+__device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm) {
   using G = gj_cfg<FNP, FNT>;
   const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
   float g[G::RB][G::CB];
@@ -254,23 +291,38 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, gj_scratch<float, 
 #pragma unroll
     for (int cb = 0; cb < G::CB; ++cb) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      g[rb][cb] = (i < N && j < N) ? V[lidx32(i, j)] : ((i == j) ? 1.0f : 0.0f);
+      g[rb][cb] = (i < N && j < N) ? V[j + LDK * i] : ((i == j) ? 1.0f : 0.0f);
     }
-  gj_invert<float, FNP, FNT>(g, N, *sc);
+  float* pad = V + FNP;
+  gj_pad_scratch sc{pad_vec2{pad}, pad_vec2{pad + 2}, pad_vec2{pad + 4}, pad_ivec{reinterpret_cast<int*>(pad + 6)},
+                    pad_ivec{reinterpret_cast<int*>(pad + 7)}, sm.gj_info};
+  gj_invert<float, FNP, FNT>(g, N, sc);
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
     for (int cb = 0; cb < G::CB; ++cb) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
-      if (i < N && j < N) V[lidx32(i, sc->dst[j])] = g[rb][cb];
+      if (i < N && j < N) V[sc.dst[j] + LDK * i] = g[rb][cb];
     }
   __syncthreads();
 }
 
-// G_s = strip of (I - E)^-1 (see invert_strip in vsm_strip.hip)
-template <int KS>
-__device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int N, fsmem32& sm, int& slot, fpos& p) {
-  const float nrm = strip_norm_bound(E, N, sm, slot, p);
+// x + I on the rows < N of the strip
+__device__ __forceinline__ void add_identity(fstrip& x, int N, const fpos& p) {
+  const bool d = p.dr >= 0 && p.dr < 4 && p.col < N;
+#pragma unroll
+  for (int ta = 0; ta < FTL; ++ta)
+    if (ta == p.wave) {   // (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x.v[ta][r] += (d && r == p.dr) ? 1.0f : 0.0f;
+    }
+}
+
+// G_s = strip of (I - E)^-1, E given as strips (see invert_strip in vsm_strip_dev.h).  W: A-form scratch.  Returns after
+// a point where other waves may still be READING W: barrier before overwriting it.
+template <int KB>
+__device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int N, fsmem32& sm, int& slot, const fpos& p) {
+  const float nrm = strip_norm_bound(E, sm, slot, p);
   const float tol = num<float>::eps() * 0.25f;
   int K = 0;
   if (nrm < 0.3f) {
@@ -286,31 +338,26 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
     else if (n16 * nrm <= lim) K = 16;
     else if (n16 * n16 <= lim) K = 31;
   }
-  auto keep = [N](float a, int r, int c) { return (r < N && c < N) ? a : 0.0f; };
   if (K == 0) {
-    store_strip(W, E, p, [=](float a, int r, int c) { return (r == c) ? 1.0f - keep(a, r, c) : -keep(a, r, c); });
+#pragma unroll
+    for (int ta = 0; ta < FTL; ++ta) G.v[ta] = -E.v[ta];
+    add_identity(G, N, p);
+    store_strip(W, G, p);
     __syncthreads();
-    gj_lds_strip(W, N, &sm.gj);
+    gj_lds_strip(W, N, sm);
     load_strip(G, W, p);
     return 1;
   }
-#pragma unroll
-  for (int ta = 0; ta < FTL; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const float e = keep(E.v[ta][r], row, p.col);
-      E.v[ta][r] = e;
-      G.v[ta][r] = (row == p.col && row < N) ? e + 1.0f : e;
-    }
+  G = E;
+  add_identity(G, N, p);
   if (K == 1) return 2;
-  store_strip(W, E, p, [](float a, int, int) { return a; });
+  store_strip(W, E, p);
   __syncthreads();
-  int cur = 1;
+  int cur = 1;  // W = E^cur (A-form), E = its strip, G = strip of sum_{k < 2 cur} E^k
   for (;;) {
     fstrip W2;
     W2.zero();
-    mm_ab<KS>(W2, W, E, p);
+    mm_ab<KB>(W2, W, E, p);  // E^(2 cur)
     cur *= 2;
     if (K == cur) {
 #pragma unroll
@@ -318,11 +365,11 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
       break;
     }
     __syncthreads();
-    store_strip(W, W2, p, [](float a, int, int) { return a; });
+    store_strip(W, W2, p);
     __syncthreads();
     fstrip T;
     T.zero();
-    mm_ab<KS>(T, W, G, p);
+    mm_ab<KB>(T, W, G, p);   // E^cur * G   (powers of E commute)
 #pragma unroll
     for (int ta = 0; ta < FTL; ++ta) G.v[ta] += T.v[ta];
     if (K == 2 * cur - 1) break;
@@ -333,26 +380,21 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
 
 // ---------------------------------------------------------------------------
 // elemental! + doubling! + apply_D!  (see ed_body in vsm_strip.hip; sources by mat-vec)
-// On return: r_s = strip of r-+, t_s = strip of t++, sm.vec[0] = j0+, sm.vec[1] = j0-, all waves past a barrier.
+// On return: r_s = strip of r-+, t_s = strip of t++, sm.vec[2 jpair] = j0+, sm.vec[2 jpair + 1] = j0-, all waves past a
+// barrier.
 // ---------------------------------------------------------------------------
-template <int KS, bool MIX>
+template <int KB, bool MIX>
 __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>& q, int m, int ndoubl,
                                         const float* __restrict__ dtau, const float* __restrict__ varpi,
                                         const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                        const zsrc<float>& z, fstrip& r_s, fstrip& t_s) {
+                                        const zsrc<float>& z, fstrip& r_s, fstrip& t_s, int& jpair) {
   float* P = sm.P;
   float* Q = sm.Q;
-  float* jp = sm.vec[0];
-  float* jm = sm.vec[1];
-  float* mus = sm.vec[2];
-  float* wcs = sm.vec[3];
-  float* xs = sm.vec[4];
-  float* es = sm.vec[5];
-  float* ems = sm.vec[6];
-  float* va = sm.vec[2];  // after the elemental step the five helper vectors are free:  tt j0+, tt j1-, tmp j0+, tmp j1-
-  float* vb = sm.vec[3];
-  float* vc = sm.vec[4];
-  float* vd = sm.vec[5];
+  float* mus = sm.vec[0];
+  float* wcs = sm.vec[1];
+  float* xs = sm.vec[2];
+  float* es = sm.vec[3];
+  float* ems = sm.vec[4];
   const int s = blockIdx.x;
   const int N = q.N, ns = q.n_stokes;
   const int tid = threadIdx.x;
@@ -453,85 +495,80 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     vjm *= att;
     if (ndoubl >= 1 && is_uv_row(i, ns)) vjm = -vjm;
   }
-  auto keepN = [N](float a, int r, int c) { return (r < N && c < N) ? a : 0.0f; };
   if (ndoubl > 0) {
-    store_strip(P, r_s, p, keepN);
-    store_strip(Q, t_s, p, keepN);
+    store_strip(P, r_s, p);
+    store_strip(Q, t_s, p);
   }
   __syncthreads();  // (the helper vectors mus.. are dead from here on)
+  jpair = 0;
   if (tid < FNP) {
-    jp[tid] = vjp;
-    jm[tid] = vjm;
+    sm.vec[0][tid] = vjp;
+    sm.vec[1][tid] = vjm;
   }
   __syncthreads();
 
   // ---- doubling (rt_helpers.jl:102-166) ------------------------------------------------------------------------
   float expk = exp(-d / q.mu0);
   int slot = 0;
-  const int mrow = 16 * p.wave + p.l15;   // row / lead lane of the mat-vecs
+  const int mrow = 16 * p.wave + p.l15;   // row of the mat-vecs
   const bool mlead = p.kq == 0;
   VSM_STAMP_DECL;
   VSM_STAMP(0);
   for (int n = 0; n < ndoubl; ++n) {
+    // on entry: P = r, Q = t (A-form), r_s in registers, all waves past a barrier
+    const float* jp = sm.vec[2 * jpair];
+    const float* jm = sm.vec[2 * jpair + 1];
+    float* njp = sm.vec[2 * (jpair ^ 1)];
+    float* njm = sm.vec[2 * (jpair ^ 1) + 1];
     fstrip G;
     {
       fstrip E;
       E.zero();
-      mm_ab<KS>(E, P, r_s, p);
+      mm_ab<KB>(E, P, r_s, p);
       VSM_STAMP(1);
-      invert_strip<KS>(E, G, P, N, sm, slot, p);
+      invert_strip<KB>(E, G, P, N, sm, slot, p);
       VSM_STAMP(2);
     }
     fstrip tt;
     tt.zero();
-    mm_ab<KS>(tt, Q, G, p);
-    load_strip(t_s, Q, p);
-    __syncthreads();  // P (series powers) and Q (t) no longer read
-    store_strip(P, tt, p, keepN);
-    __syncthreads();  // tt complete in P
+    mm_ab<KB>(tt, Q, G, p);
+    load_strip(t_s, Q, p);  // t's strip is not kept in registers across the inverse
+    __syncthreads();        // P (series powers) and Q (t) no longer read
+    store_strip(P, tt, p);
+    __syncthreads();        // tt complete in P
     VSM_STAMP(3);
-    {
-      float y1, y2;
-      matvec2(P, jp, jm, expk, y1, y2, p);  // tt j0+ , tt j1-  (j1- = j0- expk)
-      if (mlead) {
-        va[mrow] = y1;
-        vb[mrow] = y2;
-      }
-    }
+    float a1, a2;           // tt j0+ , tt j1-  (j1- = j0- expk)
+    matvec2<KB>(P, jp, jm, expk, a1, a2, p);
     VSM_STAMP(4);
-    fstrip tmp, tn;
-    tmp.zero();
-    tn.zero();
-    mm_ab2<KS>(tmp, tn, P, r_s, t_s, p);
-    store_strip(Q, tmp, p, keepN);
-    __syncthreads();  // tmp complete in Q
-    VSM_STAMP(5);
+    fstrip tn;
     {
-      float y1, y2;
-      matvec2(Q, jp, jm, expk, y1, y2, p);  // tmp j0+ , tmp j1-
-      if (mlead) {
-        vc[mrow] = y1;
-        vd[mrow] = y2;
-      }
+      fstrip tmp;
+      tmp.zero();
+      tn.zero();
+      mm_ab2<KB>(tmp, tn, P, r_s, t_s, p);
+      store_strip(Q, tmp, p);
     }
+    __syncthreads();        // tmp complete in Q
+    VSM_STAMP(5);
+    float b1, b2;           // tmp j0+ , tmp j1-
+    matvec2<KB>(Q, jp, jm, expk, b1, b2, p);
     VSM_STAMP(6);
-    mm_ab<KS>(r_s, Q, t_s, p);  // r' = r + tmp t
+    mm_ab<KB>(r_s, Q, t_s, p);  // r' = r + tmp t
     t_s = tn;
-    __syncthreads();  // everybody finished reading P (tt), Q (tmp), jp, jm ; va..vd complete
-    VSM_STAMP(7);
-    // j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134)
-    if (tid < FNP) {
-      const float njm = jm[tid] + vb[tid] + vc[tid];
-      const float njp = jp[tid] * expk + va[tid] + vd[tid];
-      jm[tid] = (tid < N) ? njm : 0.0f;
-      jp[tid] = (tid < N) ? njp : 0.0f;
+    // j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134), into the other pair
+    if (mlead) {
+      njm[mrow] = (mrow < N) ? jm[mrow] + a2 + b1 : 0.0f;
+      njp[mrow] = (mrow < N) ? jp[mrow] * expk + a1 + b2 : 0.0f;
     }
+    jpair ^= 1;
     expk = expk * expk;
+    __syncthreads();  // everybody finished reading P (tt), Q (tmp), the old sources
+    VSM_STAMP(7);
     if (n + 1 < ndoubl) {
-      store_strip(P, r_s, p, keepN);
-      store_strip(Q, t_s, p, keepN);
+      store_strip(P, r_s, p);
+      store_strip(Q, t_s, p);
+      __syncthreads();
     }
-    __syncthreads();
     VSM_STAMP(8);
   }
 
@@ -542,25 +579,28 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (is_uv_row(p.row(ta, r), ns)) r_s.v[ta][r] = -r_s.v[ta][r];
+    float* jm = sm.vec[2 * jpair + 1];
     if (tid < FNP && is_uv_row(tid, ns)) jm[tid] = -jm[tid];
   }
   __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
-// interaction_helper!(::ScatteringInterface_11)  (see ia_body in vsm_strip.hip)
+// interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266; see ia_body in vsm_strip.hip)
+// On entry: r_s / t_s = strips of the added layer's r-+ / t++, sm.vec[2 jpair] / [2 jpair + 1] = its j0+ / j0-, all waves
+// past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D; ns == 0: read from r_pm / t_mm (surface layers).
 // ---------------------------------------------------------------------------
-template <int KS>
+template <int KB>
 __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, const composite<float>& c, fstrip& r_s,
-                                        fstrip& t_s, const float* __restrict__ r_pm, const float* __restrict__ t_mm) {
+                                        fstrip& t_s, const float* __restrict__ r_pm, const float* __restrict__ t_mm,
+                                        int jpair) {
   float* P = sm.P;
   float* Q = sm.Q;
-  float* vjp = sm.vec[0];
-  float* vjm = sm.vec[1];
-  float* vJp = sm.vec[2];
-  float* vJm = sm.vec[3];
-  float* vu = sm.vec[4];
-  float* vz = sm.vec[5];
+  const float* vjp = sm.vec[2 * jpair];
+  const float* vjm = sm.vec[2 * jpair + 1];
+  float* vu = sm.vec[2 * (jpair ^ 1)];
+  float* vz = sm.vec[2 * (jpair ^ 1) + 1];
+  float* vJp = sm.vec[4];
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N;
   float* R_mp = c.R_mp + s * NN;
@@ -569,60 +609,61 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   float* T_mm = c.T_mm + s * NN;
   float* J0_p = c.J0_p + (long long)s * N;
   float* J0_m = c.J0_m + (long long)s * N;
-  auto keepN = [N](float x, int r, int cc) { return (r < N && cc < N) ? x : 0.0f; };
-  const int mrow = 16 * p.wave + p.l15;   // row / lead lane of the mat-vecs
+  const int mrow = 16 * p.wave + p.l15;   // row of the mat-vecs
   const bool mlead = p.kq == 0;
   int slot = 0;
 
-  if (tid < FNP) {
-    const bool in = tid < N;
-    vJp[tid] = in ? J0_p[tid] : 0.0f;
-    vJm[tid] = in ? J0_m[tid] : 0.0f;
-  }
+  if (tid < FNP) vJp[tid] = (tid < N) ? J0_p[tid] : 0.0f;
+  const float Jm_old = (mlead && mrow < N) ? J0_m[mrow] : 0.0f;
   fstrip X;
   load_strip_global(X, R_pm, N, p);  // R+- strip
-  store_strip(P, r_s, p, keepN);     // [r-+] -> P
+  store_strip(P, r_s, p);            // [r-+] -> P
   VSM_STAMP_DECL;
-  stage_aform(Q, T_mm, N, p);        // [T--] -> Q
+  {
+    fstrip Y;                        // [T--] -> Q: each wave moves its own 16 columns (global strip -> A-form)
+    load_strip_global(Y, T_mm, N, p);
+    store_strip(Q, Y, p);
+  }
   __syncthreads();
   VSM_STAMP(10);
   // u = r-+ J0+ + j0-
   {
-    float y1, y2;
-    matvec2(P, vJp, vJp, 1.0f, y1, y2, p);
-    if (mlead) vu[mrow] = y1 + vjm[mrow];
+    const float y = matvec1<KB>(P, vJp, p);
+    if (mlead) vu[mrow] = (mrow < N) ? y + vjm[mrow] : 0.0f;
   }
   // ---- G1 = (I - r-+ R+-)^-1 --------------------------------------------------------------------------------------
   fstrip G;
   {
     fstrip E;
     E.zero();
-    mm_ab<KS>(E, P, X, p);
+    mm_ab<KB>(E, P, X, p);
     VSM_STAMP(11);
-    invert_strip<KS>(E, G, P, N, sm, slot, p);
+    invert_strip<KB>(E, G, P, N, sm, slot, p);
   }
   __syncthreads();
-  store_strip(P, G, p, keepN);  // [G1] -> P
+  store_strip(P, G, p);  // [G1] -> P
   __syncthreads();
   VSM_STAMP(12);
   // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H -------------------------------------------------------------------
-  fstrip H, A1;
+  fstrip H;
   H.zero();
-  mm_ab<KS>(H, P, r_s, p);
-  A1.zero();
-  mm_ab<KS>(A1, Q, G, p);
-  X.zero();
-  mm_ab<KS>(X, Q, H, p);
-  __syncthreads();
-  store_strip(P, X, p, keepN);   // [T01 r-+] -> P
-  store_strip(Q, A1, p, keepN);  // [T01] -> Q
+  mm_ab<KB>(H, P, r_s, p);
+  {
+    fstrip A1;
+    A1.zero();
+    mm_ab<KB>(A1, Q, G, p);
+    X.zero();
+    mm_ab<KB>(X, Q, H, p);
+    __syncthreads();
+    store_strip(P, X, p);   // [T01 r-+] -> P
+    store_strip(Q, A1, p);  // [T01] -> Q
+  }
   __syncthreads();
   VSM_STAMP(13);
   // J0- += T01 u
   {
-    float y1, y2;
-    matvec2(Q, vu, vu, 1.0f, y1, y2, p);
-    if (mlead && mrow < N) J0_m[mrow] = vJm[mrow] + y1;
+    const float y = matvec1<KB>(Q, vu, p);
+    if (mlead && mrow < N) J0_m[mrow] = Jm_old + y;
   }
   // ---- R-+ += (T01 r-+) T++ -----------------------------------------------------------------------------------------
   {
@@ -630,7 +671,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     load_strip_global(Tpp, T_pp, N, p);
     load_strip_global(acc, R_mp, N, p);
     VSM_STAMP(14);
-    mm_ab<KS>(acc, P, Tpp, p);
+    mm_ab<KB>(acc, P, Tpp, p);
     store_strip_global(R_mp, acc, N, p);
   }
   VSM_STAMP(15);
@@ -639,45 +680,40 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     fstrip tmm, acc;
     if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global(tmm, t_mm, N, p);
     acc.zero();
-    mm_ab<KS>(acc, Q, tmm, p);
+    mm_ab<KB>(acc, Q, tmm, p);
     store_strip_global(T_mm, acc, N, p);
   }
   __syncthreads();  // [T01 r-+] (P) and [T01] (Q) no longer read
   VSM_STAMP(16);
   // ---- G2 = I + R+- H  (push-through identity) ; z = J0+ + R+- j0- -----------------------------------------------------
-  stage_aform(P, R_pm, N, p);      // [R+-] -> P
-  store_strip(Q, t_s, p, keepN);   // [t++] -> Q
+  {
+    fstrip Y;                  // [R+-] -> P
+    load_strip_global(Y, R_pm, N, p);
+    store_strip(P, Y, p);
+  }
+  store_strip(Q, t_s, p);      // [t++] -> Q
   __syncthreads();
   VSM_STAMP(17);
   G.zero();
-  mm_ab<KS>(G, P, H, p);
-  fstrip Rpm;
-  load_strip(Rpm, P, p);  // R+- strip from its A-form
+  mm_ab<KB>(G, P, H, p);
+  add_identity(G, N, p);
   {
-    float y1, y2;
-    matvec2(P, vjm, vjm, 1.0f, y1, y2, p);
-    if (mlead) vz[mrow] = vJp[mrow] + y1;
+    const float y = matvec1<KB>(P, vjm, p);
+    if (mlead) vz[mrow] = (mrow < N) ? vJp[mrow] + y : 0.0f;
   }
-#pragma unroll
-  for (int ta = 0; ta < FTL; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const float g = keepN(G.v[ta][r], row, p.col);
-      G.v[ta][r] = (row == p.col && row < N) ? g + 1.0f : g;
-    }
   // ---- T21 = t++ G2 -----------------------------------------------------------------------------------------------------
   X.zero();
-  mm_ab<KS>(X, Q, G, p);
-  __syncthreads();  // [R+-] (P), [t++] (Q) no longer read ; z complete
-  store_strip(P, X, p, keepN);  // [T21] -> P
+  mm_ab<KB>(X, Q, G, p);
+  fstrip Rpm;
+  load_strip(Rpm, P, p);  // R+- strip from its A-form
+  __syncthreads();        // [R+-] (P), [t++] (Q) no longer read ; z complete
+  store_strip(P, X, p);   // [T21] -> P
   __syncthreads();
   VSM_STAMP(18);
   // J0+ = j0+ + T21 z
   {
-    float y1, y2;
-    matvec2(P, vz, vz, 1.0f, y1, y2, p);
-    if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y1;
+    const float y = matvec1<KB>(P, vz, p);
+    if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y;
   }
   // ---- T++ = T21 T++ ; tmp = T21 R+- -------------------------------------------------------------------------------------
   {
@@ -685,9 +721,9 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     load_strip_global(Tpp, T_pp, N, p);
     acc1.zero();
     acc2.zero();
-    mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);
-    store_strip(Q, acc2, p, keepN);  // [T21 R+-] -> Q
-    __syncthreads();
+    mm_ab2<KB>(acc1, acc2, P, Tpp, Rpm, p);
+    store_strip(Q, acc2, p);  // [T21 R+-] -> Q
+    __syncthreads();          // (everybody has read the old T++ strip; tmp complete)
     store_strip_global(T_pp, acc1, N, p);
   }
   VSM_STAMP(19);
@@ -701,14 +737,14 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
       load_strip_global(tmm, t_mm, N, p);
       load_strip_global(acc, r_pm, N, p);
     }
-    mm_ab<KS>(acc, Q, tmm, p);
+    mm_ab<KB>(acc, Q, tmm, p);
     store_strip_global(R_pm, acc, N, p);
   }
   VSM_STAMP(20);
 }
 
-template <int KS>
-__global__ __launch_bounds__(FNT, 2) void k_ia_strip32(int N, composite<float> c, added<float> a) {
+template <int KB>
+__global__ __launch_bounds__(FNT, 3) void k_ia_strip32(int N, composite<float> c, added<float> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   fsmem32& sm = *reinterpret_cast<fsmem32*>(smem_raw);
   fpos p;
@@ -722,12 +758,12 @@ __global__ __launch_bounds__(FNT, 2) void k_ia_strip32(int N, composite<float> c
   load_strip_global(r_s, a.r_mp + s * a.mat_stride, N, p);
   load_strip_global(t_s, a.t_pp + s * a.mat_stride, N, p);
   __syncthreads();
-  ia_body<KS>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
-              a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride);
+  ia_body<KB>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
+              a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
 }
 
-template <int KS, bool MIX>
-__global__ __launch_bounds__(FNT, 2) void k_layer_strip32(quad<float> q, int m, int ndoubl, const float* __restrict__ dtau,
+template <int KB, bool MIX>
+__global__ __launch_bounds__(FNT, 3) void k_layer_strip32(quad<float> q, int m, int ndoubl, const float* __restrict__ dtau,
                                                           const float* __restrict__ varpi,
                                                           const float* __restrict__ tau_sum, const float* __restrict__ F0,
                                                           zsrc<float> z, int toa, composite<float> c) {
@@ -735,7 +771,8 @@ __global__ __launch_bounds__(FNT, 2) void k_layer_strip32(quad<float> q, int m, 
   fsmem32& sm = *reinterpret_cast<fsmem32*>(smem_raw);
   fpos p;
   fstrip r_s, t_s;
-  ed_body<KS, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
+  int jpair;
+  ed_body<KB, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -748,12 +785,12 @@ __global__ __launch_bounds__(FNT, 2) void k_layer_strip32(quad<float> q, int m, 
     dsym_strip(d, t_s, ns, p);
     store_strip_global(c.T_mm + s * NN, d, N, p);
     if (tid < N) {
-      c.J0_p[(long long)s * N + tid] = sm.vec[0][tid];
-      c.J0_m[(long long)s * N + tid] = sm.vec[1][tid];
+      c.J0_p[(long long)s * N + tid] = sm.vec[2 * jpair][tid];
+      c.J0_m[(long long)s * N + tid] = sm.vec[2 * jpair + 1][tid];
     }
     return;
   }
-  ia_body<KS>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
+  ia_body<KB>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr, jpair);
 }
 
 template <typename K>
@@ -763,33 +800,44 @@ static int enable_lds32(K kern, const char* what) {
   return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
 }
 
-template <int KS>
+template <int KB>
 static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st) {
-  static int prepared = enable_lds32(k_layer_strip32<KS, false>, "hipFuncSetAttribute(k_layer_strip32)");
-  static int prepared_mix = enable_lds32(k_layer_strip32<KS, true>, "hipFuncSetAttribute(k_layer_strip32 mix)");
+  static int prepared = enable_lds32(k_layer_strip32<KB, false>, "hipFuncSetAttribute(k_layer_strip32)");
+  static int prepared_mix = enable_lds32(k_layer_strip32<KB, true>, "hipFuncSetAttribute(k_layer_strip32 mix)");
   if (prepared) return prepared;
   if (prepared_mix) return prepared_mix;
   if (z.ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip32<KS, true>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
+    hipLaunchKernelGGL((k_layer_strip32<KB, true>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
                        F0, z, toa, c);
   else
-    hipLaunchKernelGGL((k_layer_strip32<KS, false>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
+    hipLaunchKernelGGL((k_layer_strip32<KB, false>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
                        F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip32");
   return VSM_OK;
 }
-template <int KS>
+template <int KB>
 static int launch_ia32(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
-  static int prepared = enable_lds32(k_ia_strip32<KS>, "hipFuncSetAttribute(k_ia_strip32)");
+  static int prepared = enable_lds32(k_ia_strip32<KB>, "hipFuncSetAttribute(k_ia_strip32)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ia_strip32<KS>, dim3(S), dim3(FNT), sizeof(fsmem32), st, N, c, a);
+  hipLaunchKernelGGL(k_ia_strip32<KB>, dim3(S), dim3(FNT), sizeof(fsmem32), st, N, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip32");
   return VSM_OK;
 }
 
 }  // namespace
+
+// the previous generation (one workgroup per CU, XOR-swizzled column-major A-forms): vsm_strip32_v1.hip, kept for A/B runs
+bool strip32v1_supported(int N);
+int strip32v1_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                            const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
+                            hipStream_t st);
+int strip32v1_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st);
+static bool use_v1() {
+  static const bool v1 = getenv("VSM_STRIP32_V1") != nullptr;
+  return v1;
+}
 
 bool strip32_supported(int N) {
   static const bool off = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP32") != nullptr;
@@ -800,14 +848,16 @@ int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const 
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  if (q.N > 80) return launch_layer32<24>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  return launch_layer32<20>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  if (use_v1()) return strip32v1_layer_forward(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  if (q.N > 80) return launch_layer32<6>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  return launch_layer32<5>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
 }
 
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  if (N > 80) return launch_ia32<24>(N, S, c, a, st);
-  return launch_ia32<20>(N, S, c, a, st);
+  if (use_v1()) return strip32v1_interaction11(N, S, c, a, st);
+  if (N > 80) return launch_ia32<6>(N, S, c, a, st);
+  return launch_ia32<5>(N, S, c, a, st);
 }
 
 }  // namespace vsm
