@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvsmartmom_hip.so")
+LIB_PATH = os.environ.get("VSM_LIB_PATH") or os.path.join(_HERE, "lib", "libvsmartmom_hip.so")   # (override: A/B builds)
 
 
 class VSMError(RuntimeError):

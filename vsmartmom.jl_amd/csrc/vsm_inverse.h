@@ -42,10 +42,13 @@ using gj_regs = T[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB];
 
 // SC: gj_scratch<T, NPAD> or any type with the same members (col / rowP / rowK indexable as [parity][i], piv / dst as
 // [i], info assignable) -- the FP32 strip kernels keep the scratch in the padding columns of an LDS matrix.
-template <typename T, int NPAD, int NT = 256, typename SC>
-__device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc) {
+// SYNC: barrier over the NT threads that share the matrix (default: the whole workgroup); `tid`: index within them.
+struct wg_sync {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+template <typename T, int NPAD, int NT = 256, typename SC, typename SYNC = wg_sync>
+__device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc, int tid = threadIdx.x, SYNC sync = SYNC()) {
   using C = gj_cfg<NPAD, NT>;
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tr = tid % C::TR;
   const int tc = tid / C::TR;
@@ -62,7 +65,7 @@ __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc
 #pragma unroll
           for (int rb = 0; rb < C::RB; ++rb) sc.col[par][tr + C::TR * rb] = a[rb][cbk];
         }
-        __syncthreads();
+        sync();
         // (b) pivot search, redundantly in every wave (no second barrier needed)
         T best = T(-1);
         int bi = k;
@@ -98,7 +101,7 @@ __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc
             for (int cb = 0; cb < C::CB; ++cb) sc.rowK[par][tc * C::CB + cb] = a[rb][cb];
           }
         }
-        __syncthreads();
+        sync();
         // (d) eliminate
         const T pv = sc.rowP[par][k];
         const T d = T(1) / pv;
@@ -133,7 +136,7 @@ __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc
       }
     }
   }
-  __syncthreads();
+  sync();
   // Undo the row interchanges as a column permutation of the inverse:
   // for k = N-1..0 swap columns k and piv[k].  src[x] = source column of final column x.
   if (tid < 64) {
@@ -161,7 +164,7 @@ __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc
     if (lane < NPAD) sc.dst[s0] = lane;
     if (lane + 64 < NPAD) sc.dst[s1] = lane + 64;
   }
-  __syncthreads();
+  sync();
 }
 
 }  // namespace vsm

@@ -65,14 +65,15 @@ struct fstrip {
   }
 };
 
-struct fsmem32 {
+struct fsmem32 {   // LDS of ONE spectral point (one half of a workgroup)
   float P[FNP * LDK];
   float Q[FNP * LDK];
   float vec[NVEC][FNP];
   float red[2][8];
   int gj_info;
+  unsigned bar;    // arrival counter of the half's software barrier
 };
-static_assert(sizeof(fsmem32) <= 81920, "two workgroups per CU");
+static_assert(2 * sizeof(fsmem32) <= 163840, "two spectral points per CU");
 
 // Gauss-Jordan scratch in the padding words (k = 96 .. 103) of the rows of the matrix being inverted
 struct pad_vec {
@@ -94,13 +95,20 @@ struct gj_pad_scratch {
 };
 
 struct fpos {
-  int lane, wave, l15, kq, col;
+  int s;                               // spectral point of this half
+  int tid, lane, wave, l15, kq, col;   // tid / wave: within the half (0..383 / 0..5)
+  unsigned* bar;
+  mutable unsigned epoch;
   int afrag;   // 4 kq + LDK l15
   int sbase;   // col + 4 LDK kq
   int dr;      // l15 - 4 kq: the diagonal of the wave's strip is element r == dr of tile ta == wave (when 0 <= dr < 4)
-  __device__ __forceinline__ fpos() {
-    lane = threadIdx.x & 63;
-    wave = threadIdx.x >> 6;
+  __device__ __forceinline__ fpos(int s_, int tid_, unsigned* bar_) {
+    s = s_;
+    tid = tid_;
+    bar = bar_;
+    epoch = 0;
+    lane = tid & 63;
+    wave = tid >> 6;
     l15 = lane & 15;
     kq = lane >> 4;
     col = 16 * wave + l15;
@@ -112,6 +120,25 @@ struct fpos {
 };
 
 __device__ __forceinline__ f4_t lds4(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
+
+// Barrier over the SIX waves of one spectral point.  A 6-wave workgroup lands on the four SIMDs as 2, 2, 1, 1 waves and the
+// dispatcher starts every workgroup on the same SIMD, so a second 6-wave workgroup never fits beside the first at three waves
+// per SIMD (residency census: tools/occ_probe.hip) -- the kernels therefore run TWO points per 12-wave workgroup (3 waves on
+// every SIMD) and the two halves must not share s_barrier (their barrier counts differ: the series order of an inverse is
+// data dependent; and one half's barrier stalls are what the other half's MFMAs hide).  Arrival counter in LDS: the LDS
+// unit of a CU executes in order, and the release fence drains this wave's LDS traffic (lgkmcnt) before it arrives; global
+// traffic is NOT drained (no wave reads global data that another wave of its point wrote after the start of the kernel).
+__device__ __forceinline__ void half_barrier(const fpos& p) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  p.epoch += FNW;
+  if (p.lane == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while ((int)(__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - p.epoch) < 0) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+struct half_sync {
+  const fpos* p;
+  __device__ __forceinline__ void operator()() const { half_barrier(*p); }
+};
 
 // acc += A * B   (A: A-form in LDS, B: strip in registers); KB = ceil(N / 16) blocks of four MFMA k-steps.
 // Row tiles go in pairs (two independent accumulators alternate: the 40-cycle dependent latency of the f32 MFMA never
@@ -177,10 +204,18 @@ __device__ __forceinline__ void load_strip(fstrip& s, const float* src, const fp
 }
 // Strip <-> global column-major N x N.  A lane's four elements of a tile are four consecutive rows of one column: one
 // 16-byte access when N % 4 == 0 (then the rows of a tile are all inside or all outside the matrix).
+// (decided at run time although AL is known: with a compile-time branch the scheduler hoists every global load to the top of
+// its phase and pays for it in spills -- measured 8.4k vs 9.7k points/s on C4)
+#ifdef VSM_AL_STATIC
+#define VSM_ALIGNED(AL, N) (AL)
+#else
+#define VSM_ALIGNED(AL, N) (((N) & 3) == 0)
+#endif
+template <bool AL>   // AL: N % 4 == 0
 __device__ __forceinline__ void load_strip_global(fstrip& s, const float* __restrict__ g, int N, const fpos& p) {
   const int cc = min(p.col, N - 1);
   const float* g0 = g + (long long)N * cc + 4 * p.kq;
-  if ((N & 3) == 0) {
+  if (VSM_ALIGNED(AL, N)) {
 #pragma unroll
     for (int ta = 0; ta < FTL; ++ta) {
       const bool in = p.col < N && 16 * ta + 4 * p.kq < N;
@@ -198,10 +233,11 @@ __device__ __forceinline__ void load_strip_global(fstrip& s, const float* __rest
       }
   }
 }
+template <bool AL>
 __device__ __forceinline__ void store_strip_global(float* __restrict__ g, const fstrip& s, int N, const fpos& p) {
   if (p.col >= N) return;
   float* g0 = g + (long long)N * p.col + 4 * p.kq;
-  if ((N & 3) == 0) {
+  if (VSM_ALIGNED(AL, N)) {
 #pragma unroll
     for (int ta = 0; ta < FTL; ++ta)
       if (16 * ta + 4 * p.kq < N) *reinterpret_cast<f4_t*>(g0 + 16 * ta) = s.v[ta];
@@ -227,6 +263,11 @@ __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, c
 template <int KB>
 __device__ __forceinline__ void matvec2(const float* A, const float* x1, const float* x2, float scale2, float& y1, float& y2,
                                         const fpos& p) {
+#ifdef VSM_EXP_NOMATVEC
+  y1 = x1[p.l15];
+  y2 = x2[p.l15] * scale2;
+  return;
+#endif
   const float* a0 = A + p.afrag + 16 * LDK * p.wave;
   const float* u0 = x1 + 4 * p.kq;
   const float* v0 = x2 + 4 * p.kq;
@@ -250,6 +291,9 @@ __device__ __forceinline__ void matvec2(const float* A, const float* x1, const f
 }
 template <int KB>
 __device__ __forceinline__ float matvec1(const float* A, const float* x, const fpos& p) {
+#ifdef VSM_EXP_NOMATVEC
+  return x[p.l15];
+#endif
   const float* a0 = A + p.afrag + 16 * LDK * p.wave;
   const float* u0 = x + 4 * p.kq;
   float s1 = 0.f;
@@ -273,7 +317,7 @@ __device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, 
     for (int r = 0; r < 4; ++r) ss += e.v[ta][r] * e.v[ta][r];
   const float ws = wave_sum(ss * 1.0001f);
   if (p.lane == 0) sm.red[slot][p.wave] = ws;
-  __syncthreads();
+  half_barrier(p);
   float tot = 0.f;
 #pragma unroll
   for (int w = 0; w < FNW; ++w) tot += sm.red[slot][w];
@@ -282,9 +326,9 @@ __device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, 
 }
 
 // In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block, identity-padded), 384 threads; ends with a barrier.
-__device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm) {
+__device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm, const fpos& p) {
   using G = gj_cfg<FNP, FNT>;
-  const int tr = threadIdx.x % G::TR, tc = threadIdx.x / G::TR;
+  const int tr = p.tid % G::TR, tc = p.tid / G::TR;
   float g[G::RB][G::CB];
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
@@ -296,7 +340,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm) {
   float* pad = V + FNP;
   gj_pad_scratch sc{pad_vec2{pad}, pad_vec2{pad + 2}, pad_vec2{pad + 4}, pad_ivec{reinterpret_cast<int*>(pad + 6)},
                     pad_ivec{reinterpret_cast<int*>(pad + 7)}, sm.gj_info};
-  gj_invert<float, FNP, FNT>(g, N, sc);
+  gj_invert<float, FNP, FNT>(g, N, sc, p.tid, half_sync{&p});
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
@@ -304,7 +348,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm) {
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
       if (i < N && j < N) V[sc.dst[j] + LDK * i] = g[rb][cb];
     }
-  __syncthreads();
+  half_barrier(p);
 }
 
 // x + I on the rows < N of the strip
@@ -343,8 +387,8 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
     for (int ta = 0; ta < FTL; ++ta) G.v[ta] = -E.v[ta];
     add_identity(G, N, p);
     store_strip(W, G, p);
-    __syncthreads();
-    gj_lds_strip(W, N, sm);
+    half_barrier(p);
+    gj_lds_strip(W, N, sm, p);
     load_strip(G, W, p);
     return 1;
   }
@@ -352,7 +396,7 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
   add_identity(G, N, p);
   if (K == 1) return 2;
   store_strip(W, E, p);
-  __syncthreads();
+  half_barrier(p);
   int cur = 1;  // W = E^cur (A-form), E = its strip, G = strip of sum_{k < 2 cur} E^k
   for (;;) {
     fstrip W2;
@@ -364,9 +408,9 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
       for (int ta = 0; ta < FTL; ++ta) G.v[ta] += W2.v[ta];
       break;
     }
-    __syncthreads();
+    half_barrier(p);
     store_strip(W, W2, p);
-    __syncthreads();
+    half_barrier(p);
     fstrip T;
     T.zero();
     mm_ab<KB>(T, W, G, p);   // E^cur * G   (powers of E commute)
@@ -395,9 +439,9 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   float* xs = sm.vec[2];
   float* es = sm.vec[3];
   float* ems = sm.vec[4];
-  const int s = blockIdx.x;
+  const int s = p.s;
   const int N = q.N, ns = q.n_stokes;
-  const int tid = threadIdx.x;
+  const int tid = p.tid;
   const float d = dtau[s], w = varpi[s];
   const int ncomp = MIX ? z.ncomp : 0;
   const long long NNz = (long long)q.N * q.N;
@@ -425,7 +469,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     es[tid] = exp(-x);
     ems[tid] = expm1(-x);
   }
-  __syncthreads();
+  half_barrier(p);
 
   // ---- elemental (elemental.jl:289-334) ------------------------------------------------------------------------
   {
@@ -458,7 +502,11 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
             } else {
               const float xm = fmax(xi, xj);
               const float ediff =
+#ifdef VSM_EXP_NOELEM
+                  (emi - emj);
+#else
                   (xm < 0.5f && fabs(xi - xj) > 0.125f * xm) ? (emi - emj) : expdiff_neg<float>(xi, xj);
+#endif
               tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
             }
           } else {
@@ -499,13 +547,13 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     store_strip(P, r_s, p);
     store_strip(Q, t_s, p);
   }
-  __syncthreads();  // (the helper vectors mus.. are dead from here on)
+  half_barrier(p);  // (the helper vectors mus.. are dead from here on)
   jpair = 0;
   if (tid < FNP) {
     sm.vec[0][tid] = vjp;
     sm.vec[1][tid] = vjm;
   }
-  __syncthreads();
+  half_barrier(p);
 
   // ---- doubling (rt_helpers.jl:102-166) ------------------------------------------------------------------------
   float expk = exp(-d / q.mu0);
@@ -514,6 +562,9 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   const bool mlead = p.kq == 0;
   VSM_STAMP_DECL;
   VSM_STAMP(0);
+#ifdef VSM_EXP_NODBL
+  ndoubl = min(ndoubl, 0);
+#endif
   for (int n = 0; n < ndoubl; ++n) {
     // on entry: P = r, Q = t (A-form), r_s in registers, all waves past a barrier
     const float* jp = sm.vec[2 * jpair];
@@ -533,9 +584,9 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     tt.zero();
     mm_ab<KB>(tt, Q, G, p);
     load_strip(t_s, Q, p);  // t's strip is not kept in registers across the inverse
-    __syncthreads();        // P (series powers) and Q (t) no longer read
+    half_barrier(p);        // P (series powers) and Q (t) no longer read
     store_strip(P, tt, p);
-    __syncthreads();        // tt complete in P
+    half_barrier(p);        // tt complete in P
     VSM_STAMP(3);
     float a1, a2;           // tt j0+ , tt j1-  (j1- = j0- expk)
     matvec2<KB>(P, jp, jm, expk, a1, a2, p);
@@ -548,7 +599,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
       mm_ab2<KB>(tmp, tn, P, r_s, t_s, p);
       store_strip(Q, tmp, p);
     }
-    __syncthreads();        // tmp complete in Q
+    half_barrier(p);        // tmp complete in Q
     VSM_STAMP(5);
     float b1, b2;           // tmp j0+ , tmp j1-
     matvec2<KB>(Q, jp, jm, expk, b1, b2, p);
@@ -562,12 +613,12 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     }
     jpair ^= 1;
     expk = expk * expk;
-    __syncthreads();  // everybody finished reading P (tt), Q (tmp), the old sources
+    half_barrier(p);  // everybody finished reading P (tt), Q (tmp), the old sources
     VSM_STAMP(7);
     if (n + 1 < ndoubl) {
       store_strip(P, r_s, p);
       store_strip(Q, t_s, p);
-      __syncthreads();
+      half_barrier(p);
     }
     VSM_STAMP(8);
   }
@@ -582,7 +633,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
     float* jm = sm.vec[2 * jpair + 1];
     if (tid < FNP && is_uv_row(tid, ns)) jm[tid] = -jm[tid];
   }
-  __syncthreads();
+  half_barrier(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -590,7 +641,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
 // On entry: r_s / t_s = strips of the added layer's r-+ / t++, sm.vec[2 jpair] / [2 jpair + 1] = its j0+ / j0-, all waves
 // past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D; ns == 0: read from r_pm / t_mm (surface layers).
 // ---------------------------------------------------------------------------
-template <int KB>
+template <int KB, bool AL>
 __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, const composite<float>& c, fstrip& r_s,
                                         fstrip& t_s, const float* __restrict__ r_pm, const float* __restrict__ t_mm,
                                         int jpair) {
@@ -601,7 +652,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   float* vu = sm.vec[2 * (jpair ^ 1)];
   float* vz = sm.vec[2 * (jpair ^ 1) + 1];
   float* vJp = sm.vec[4];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = p.s, tid = p.tid;
   const long long NN = (long long)N * N;
   float* R_mp = c.R_mp + s * NN;
   float* R_pm = c.R_pm + s * NN;
@@ -616,15 +667,15 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   if (tid < FNP) vJp[tid] = (tid < N) ? J0_p[tid] : 0.0f;
   const float Jm_old = (mlead && mrow < N) ? J0_m[mrow] : 0.0f;
   fstrip X;
-  load_strip_global(X, R_pm, N, p);  // R+- strip
+  load_strip_global<AL>(X, R_pm, N, p);  // R+- strip
   store_strip(P, r_s, p);            // [r-+] -> P
   VSM_STAMP_DECL;
   {
     fstrip Y;                        // [T--] -> Q: each wave moves its own 16 columns (global strip -> A-form)
-    load_strip_global(Y, T_mm, N, p);
+    load_strip_global<AL>(Y, T_mm, N, p);
     store_strip(Q, Y, p);
   }
-  __syncthreads();
+  half_barrier(p);
   VSM_STAMP(10);
   // u = r-+ J0+ + j0-
   {
@@ -640,9 +691,9 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     VSM_STAMP(11);
     invert_strip<KB>(E, G, P, N, sm, slot, p);
   }
-  __syncthreads();
+  half_barrier(p);
   store_strip(P, G, p);  // [G1] -> P
-  __syncthreads();
+  half_barrier(p);
   VSM_STAMP(12);
   // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H -------------------------------------------------------------------
   fstrip H;
@@ -654,11 +705,11 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     mm_ab<KB>(A1, Q, G, p);
     X.zero();
     mm_ab<KB>(X, Q, H, p);
-    __syncthreads();
+    half_barrier(p);
     store_strip(P, X, p);   // [T01 r-+] -> P
     store_strip(Q, A1, p);  // [T01] -> Q
   }
-  __syncthreads();
+  half_barrier(p);
   VSM_STAMP(13);
   // J0- += T01 u
   {
@@ -668,31 +719,31 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   // ---- R-+ += (T01 r-+) T++ -----------------------------------------------------------------------------------------
   {
     fstrip Tpp, acc;
-    load_strip_global(Tpp, T_pp, N, p);
-    load_strip_global(acc, R_mp, N, p);
+    load_strip_global<AL>(Tpp, T_pp, N, p);
+    load_strip_global<AL>(acc, R_mp, N, p);
     VSM_STAMP(14);
     mm_ab<KB>(acc, P, Tpp, p);
-    store_strip_global(R_mp, acc, N, p);
+    store_strip_global<AL>(R_mp, acc, N, p);
   }
   VSM_STAMP(15);
   // ---- T-- = T01 t-- -------------------------------------------------------------------------------------------------
   {
     fstrip tmm, acc;
-    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global(tmm, t_mm, N, p);
+    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global<AL>(tmm, t_mm, N, p);
     acc.zero();
     mm_ab<KB>(acc, Q, tmm, p);
-    store_strip_global(T_mm, acc, N, p);
+    store_strip_global<AL>(T_mm, acc, N, p);
   }
-  __syncthreads();  // [T01 r-+] (P) and [T01] (Q) no longer read
+  half_barrier(p);  // [T01 r-+] (P) and [T01] (Q) no longer read
   VSM_STAMP(16);
   // ---- G2 = I + R+- H  (push-through identity) ; z = J0+ + R+- j0- -----------------------------------------------------
   {
     fstrip Y;                  // [R+-] -> P
-    load_strip_global(Y, R_pm, N, p);
+    load_strip_global<AL>(Y, R_pm, N, p);
     store_strip(P, Y, p);
   }
   store_strip(Q, t_s, p);      // [t++] -> Q
-  __syncthreads();
+  half_barrier(p);
   VSM_STAMP(17);
   G.zero();
   mm_ab<KB>(G, P, H, p);
@@ -706,9 +757,9 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   mm_ab<KB>(X, Q, G, p);
   fstrip Rpm;
   load_strip(Rpm, P, p);  // R+- strip from its A-form
-  __syncthreads();        // [R+-] (P), [t++] (Q) no longer read ; z complete
+  half_barrier(p);        // [R+-] (P), [t++] (Q) no longer read ; z complete
   store_strip(P, X, p);   // [T21] -> P
-  __syncthreads();
+  half_barrier(p);
   VSM_STAMP(18);
   // J0+ = j0+ + T21 z
   {
@@ -717,14 +768,29 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   }
   // ---- T++ = T21 T++ ; tmp = T21 R+- -------------------------------------------------------------------------------------
   {
+#ifdef VSM_IA_SPLIT2
+    {
+      fstrip acc2;
+      acc2.zero();
+      mm_ab<KB>(acc2, P, Rpm, p);
+      store_strip(Q, acc2, p);  // [T21 R+-] -> Q
+    }
+    fstrip Tpp, acc1;
+    load_strip_global<AL>(Tpp, T_pp, N, p);
+    acc1.zero();
+    mm_ab<KB>(acc1, P, Tpp, p);
+    half_barrier(p);
+    store_strip_global<AL>(T_pp, acc1, N, p);
+#else
     fstrip Tpp, acc1, acc2;
-    load_strip_global(Tpp, T_pp, N, p);
+    load_strip_global<AL>(Tpp, T_pp, N, p);
     acc1.zero();
     acc2.zero();
     mm_ab2<KB>(acc1, acc2, P, Tpp, Rpm, p);
     store_strip(Q, acc2, p);  // [T21 R+-] -> Q
-    __syncthreads();          // (everybody has read the old T++ strip; tmp complete)
-    store_strip_global(T_pp, acc1, N, p);
+    half_barrier(p);          // (everybody has read the old T++ strip; tmp complete)
+    store_strip_global<AL>(T_pp, acc1, N, p);
+#endif
   }
   VSM_STAMP(19);
   // ---- R+- = r+- + tmp t-- -------------------------------------------------------------------------------------------------
@@ -734,94 +800,109 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
       dsym_strip(tmm, t_s, ns, p);
       dsym_strip(acc, r_s, ns, p);
     } else {
-      load_strip_global(tmm, t_mm, N, p);
-      load_strip_global(acc, r_pm, N, p);
+      load_strip_global<AL>(tmm, t_mm, N, p);
+      load_strip_global<AL>(acc, r_pm, N, p);
     }
     mm_ab<KB>(acc, Q, tmm, p);
-    store_strip_global(R_pm, acc, N, p);
+    store_strip_global<AL>(R_pm, acc, N, p);
   }
   VSM_STAMP(20);
 }
 
-template <int KB>
-__global__ __launch_bounds__(FNT, 3) void k_ia_strip32(int N, composite<float> c, added<float> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem32& sm = *reinterpret_cast<fsmem32*>(smem_raw);
-  fpos p;
-  const int s = blockIdx.x, tid = threadIdx.x;
+// Common prologue: the two halves of the 12-wave workgroup (two spectral points), their LDS and barrier counters.
+#define VSM_HALF_PROLOGUE()                                                              \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];               \
+  const int half = threadIdx.x / FNT;                                                    \
+  fsmem32& sm = reinterpret_cast<fsmem32*>(smem_raw)[half];                              \
+  if (threadIdx.x % FNT == 0) sm.bar = 0;                                                \
+  __syncthreads(); /* the only workgroup-wide barrier: counters initialised */           \
+  fpos p(2 * blockIdx.x + half, threadIdx.x % FNT, &sm.bar);                             \
+  if (p.s >= S) return
+
+template <int KB, bool AL>
+__global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composite<float> c, added<float> a) {
+  VSM_HALF_PROLOGUE();
+  const int s = p.s, tid = p.tid;
   if (tid < FNP) {
     const bool in = tid < N;
     sm.vec[0][tid] = in ? a.j0_p[(long long)s * N + tid] : 0.0f;
     sm.vec[1][tid] = in ? a.j0_m[(long long)s * N + tid] : 0.0f;
   }
   fstrip r_s, t_s;
-  load_strip_global(r_s, a.r_mp + s * a.mat_stride, N, p);
-  load_strip_global(t_s, a.t_pp + s * a.mat_stride, N, p);
-  __syncthreads();
-  ia_body<KB>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
-              a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
+  load_strip_global<AL>(r_s, a.r_mp + s * a.mat_stride, N, p);
+  load_strip_global<AL>(t_s, a.t_pp + s * a.mat_stride, N, p);
+  half_barrier(p);
+  ia_body<KB, AL>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
+                  a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
 }
 
-template <int KB, bool MIX>
-__global__ __launch_bounds__(FNT, 3) void k_layer_strip32(quad<float> q, int m, int ndoubl, const float* __restrict__ dtau,
-                                                          const float* __restrict__ varpi,
-                                                          const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                                          zsrc<float> z, int toa, composite<float> c) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  fsmem32& sm = *reinterpret_cast<fsmem32*>(smem_raw);
-  fpos p;
+template <int KB, bool MIX, bool AL>
+__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int S, int m, int ndoubl,
+                                                              const float* __restrict__ dtau, const float* __restrict__ varpi,
+                                                              const float* __restrict__ tau_sum, const float* __restrict__ F0,
+                                                              zsrc<float> z, int toa, composite<float> c) {
+  VSM_HALF_PROLOGUE();
   fstrip r_s, t_s;
   int jpair;
   ed_body<KB, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
-    const int s = blockIdx.x, tid = threadIdx.x;
+    const int s = p.s, tid = p.tid;
     const long long NN = (long long)N * N;
-    store_strip_global(c.R_mp + s * NN, r_s, N, p);
-    store_strip_global(c.T_pp + s * NN, t_s, N, p);
+    store_strip_global<AL>(c.R_mp + s * NN, r_s, N, p);
+    store_strip_global<AL>(c.T_pp + s * NN, t_s, N, p);
     fstrip d;
     dsym_strip(d, r_s, ns, p);
-    store_strip_global(c.R_pm + s * NN, d, N, p);
+    store_strip_global<AL>(c.R_pm + s * NN, d, N, p);
     dsym_strip(d, t_s, ns, p);
-    store_strip_global(c.T_mm + s * NN, d, N, p);
+    store_strip_global<AL>(c.T_mm + s * NN, d, N, p);
     if (tid < N) {
       c.J0_p[(long long)s * N + tid] = sm.vec[2 * jpair][tid];
       c.J0_m[(long long)s * N + tid] = sm.vec[2 * jpair + 1][tid];
     }
     return;
   }
-  ia_body<KB>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr, jpair);
+#ifdef VSM_EXP_NOIA
+  if (q.N > 0) {
+    const int s = p.s;
+    const long long NN = (long long)N * N;
+    store_strip_global<AL>(c.R_mp + s * NN, r_s, N, p);
+    store_strip_global<AL>(c.T_pp + s * NN, t_s, N, p);
+    return;
+  }
+#endif
+  ia_body<KB, AL>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr, jpair);
 }
 
 template <typename K>
 static int enable_lds32(K kern, const char* what) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(fsmem32));
+                                     (int)(2 * sizeof(fsmem32)));
   return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
 }
 
-template <int KB>
+template <int KB, bool AL>
 static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st) {
-  static int prepared = enable_lds32(k_layer_strip32<KB, false>, "hipFuncSetAttribute(k_layer_strip32)");
-  static int prepared_mix = enable_lds32(k_layer_strip32<KB, true>, "hipFuncSetAttribute(k_layer_strip32 mix)");
+  static int prepared = enable_lds32(k_layer_strip32<KB, false, AL>, "hipFuncSetAttribute(k_layer_strip32)");
+  static int prepared_mix = enable_lds32(k_layer_strip32<KB, true, AL>, "hipFuncSetAttribute(k_layer_strip32 mix)");
   if (prepared) return prepared;
   if (prepared_mix) return prepared_mix;
   if (z.ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip32<KB, true>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
+    hipLaunchKernelGGL((k_layer_strip32<KB, true, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, q, S, m, ndoubl, dtau, varpi, tau_sum,
                        F0, z, toa, c);
   else
-    hipLaunchKernelGGL((k_layer_strip32<KB, false>), dim3(S), dim3(FNT), sizeof(fsmem32), st, q, m, ndoubl, dtau, varpi, tau_sum,
+    hipLaunchKernelGGL((k_layer_strip32<KB, false, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, q, S, m, ndoubl, dtau, varpi, tau_sum,
                        F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip32");
   return VSM_OK;
 }
-template <int KB>
+template <int KB, bool AL>
 static int launch_ia32(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
-  static int prepared = enable_lds32(k_ia_strip32<KB>, "hipFuncSetAttribute(k_ia_strip32)");
+  static int prepared = enable_lds32(k_ia_strip32<KB, AL>, "hipFuncSetAttribute(k_ia_strip32)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ia_strip32<KB>, dim3(S), dim3(FNT), sizeof(fsmem32), st, N, c, a);
+  hipLaunchKernelGGL((k_ia_strip32<KB, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, N, S, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip32");
   return VSM_OK;
 }
@@ -849,15 +930,18 @@ int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const 
                           hipStream_t st) {
   if (S <= 0) return VSM_OK;
   if (use_v1()) return strip32v1_layer_forward(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  if (q.N > 80) return launch_layer32<6>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  return launch_layer32<5>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  // N % 4 != 0: element-wise global accesses, one instantiation (KB = 6) for all such N
+  if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  return launch_layer32<5, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
 }
 
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   if (use_v1()) return strip32v1_interaction11(N, S, c, a, st);
-  if (N > 80) return launch_ia32<6>(N, S, c, a, st);
-  return launch_ia32<5>(N, S, c, a, st);
+  if (N & 3) return launch_ia32<6, false>(N, S, c, a, st);
+  if (N > 80) return launch_ia32<6, true>(N, S, c, a, st);
+  return launch_ia32<5, true>(N, S, c, a, st);
 }
 
 }  // namespace vsm
