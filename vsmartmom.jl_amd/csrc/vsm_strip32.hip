@@ -65,7 +65,7 @@ struct fstrip {
   }
 };
 
-struct fsmem32 {   // LDS of ONE spectral point (one half of a workgroup)
+struct __attribute__((aligned(16))) fsmem32 {   // LDS of ONE spectral point (one half of a workgroup); 16-byte multiple: b128 reads
   float P[FNP * LDK];
   float Q[FNP * LDK];
   float vec[NVEC][FNP];
@@ -73,7 +73,7 @@ struct fsmem32 {   // LDS of ONE spectral point (one half of a workgroup)
   int gj_info;
   unsigned bar;    // arrival counter of the half's software barrier
 };
-static_assert(2 * sizeof(fsmem32) <= 163840, "two spectral points per CU");
+static_assert(2 * sizeof(fsmem32) <= 163840 && sizeof(fsmem32) % 16 == 0, "two spectral points per CU, both 16-byte aligned");
 
 // Gauss-Jordan scratch in the padding words (k = 96 .. 103) of the rows of the matrix being inverted
 struct pad_vec {
@@ -128,11 +128,14 @@ __device__ __forceinline__ f4_t lds4(const float* p) { return *reinterpret_cast<
 // data dependent; and one half's barrier stalls are what the other half's MFMAs hide).  Arrival counter in LDS: the LDS
 // unit of a CU executes in order, and the release fence drains this wave's LDS traffic (lgkmcnt) before it arrives; global
 // traffic is NOT drained (no wave reads global data that another wave of its point wrote after the start of the kernel).
+#ifndef VSM_BAR_SLEEP
+#define VSM_BAR_SLEEP 1
+#endif
 __device__ __forceinline__ void half_barrier(const fpos& p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   p.epoch += FNW;
   if (p.lane == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while ((int)(__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - p.epoch) < 0) __builtin_amdgcn_s_sleep(1);
+  while ((int)(__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - p.epoch) < 0) __builtin_amdgcn_s_sleep(VSM_BAR_SLEEP);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 struct half_sync {
@@ -411,13 +414,15 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
     half_barrier(p);
     store_strip(W, W2, p);
     half_barrier(p);
-    fstrip T;
-    T.zero();
-    mm_ab<KB>(T, W, G, p);   // E^cur * G   (powers of E commute)
+    {
+      fstrip& T = W2;        // (its value now lives in W; the strip is re-read from there if another squaring follows)
+      T.zero();
+      mm_ab<KB>(T, W, G, p);   // E^cur * G   (powers of E commute)
 #pragma unroll
-    for (int ta = 0; ta < FTL; ++ta) G.v[ta] += T.v[ta];
+      for (int ta = 0; ta < FTL; ++ta) G.v[ta] += T.v[ta];
+    }
     if (K == 2 * cur - 1) break;
-    E = W2;
+    load_strip(E, W, p);
   }
   return 1 + K;
 }
@@ -728,15 +733,24 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   VSM_STAMP(15);
   // ---- T-- = T01 t-- -------------------------------------------------------------------------------------------------
   {
-    fstrip tmm, acc;
-    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global<AL>(tmm, t_mm, N, p);
+    fstrip acc;
     acc.zero();
-    mm_ab<KB>(acc, Q, tmm, p);
+    if (ns) {   // t-- = D t++ D formed in place and undone afterwards (D is an involution): no second strip
+      dsym_strip(t_s, t_s, ns, p);
+      mm_ab<KB>(acc, Q, t_s, p);
+      dsym_strip(t_s, t_s, ns, p);
+    } else {
+      fstrip tmm;
+      load_strip_global<AL>(tmm, t_mm, N, p);
+      mm_ab<KB>(acc, Q, tmm, p);
+    }
     store_strip_global<AL>(T_mm, acc, N, p);
   }
   half_barrier(p);  // [T01 r-+] (P) and [T01] (Q) no longer read
   VSM_STAMP(16);
-  // ---- G2 = I + R+- H  (push-through identity) ; z = J0+ + R+- j0- -----------------------------------------------------
+  // ---- G2 = I + R+- H  (push-through identity) ; Z = R+- t-- ; z = J0+ + R+- j0- ------------------------------------------
+  // (R+- = r+- + (T21 R+-) t-- is evaluated as r+- + T21 (R+- t--): Z shares the fragments of [R+-] with G2, the last two
+  //  products share those of [T21], and neither [T21 R+-] nor the R+- strip has to go through LDS)
   {
     fstrip Y;                  // [R+-] -> P
     load_strip_global<AL>(Y, R_pm, N, p);
@@ -745,8 +759,13 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   store_strip(Q, t_s, p);      // [t++] -> Q
   half_barrier(p);
   VSM_STAMP(17);
-  G.zero();
-  mm_ab<KB>(G, P, H, p);
+  fstrip Z;
+  {
+    if (ns) dsym_strip(t_s, t_s, ns, p); else load_strip_global<AL>(t_s, t_mm, N, p);   // t_s <- t--
+    G.zero();
+    Z.zero();
+    mm_ab2<KB>(G, Z, P, H, t_s, p);
+  }
   add_identity(G, N, p);
   {
     const float y = matvec1<KB>(P, vjm, p);
@@ -755,8 +774,6 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   // ---- T21 = t++ G2 -----------------------------------------------------------------------------------------------------
   X.zero();
   mm_ab<KB>(X, Q, G, p);
-  fstrip Rpm;
-  load_strip(Rpm, P, p);  // R+- strip from its A-form
   half_barrier(p);        // [R+-] (P), [t++] (Q) no longer read ; z complete
   store_strip(P, X, p);   // [T21] -> P
   half_barrier(p);
@@ -766,46 +783,17 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     const float y = matvec1<KB>(P, vz, p);
     if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y;
   }
-  // ---- T++ = T21 T++ ; tmp = T21 R+- -------------------------------------------------------------------------------------
+  // ---- T++ = T21 T++ ; R+- = r+- + T21 Z ---------------------------------------------------------------------------------
   {
-#ifdef VSM_IA_SPLIT2
-    {
-      fstrip acc2;
-      acc2.zero();
-      mm_ab<KB>(acc2, P, Rpm, p);
-      store_strip(Q, acc2, p);  // [T21 R+-] -> Q
-    }
     fstrip Tpp, acc1;
     load_strip_global<AL>(Tpp, T_pp, N, p);
+    if (ns) dsym_strip(r_s, r_s, ns, p); else load_strip_global<AL>(r_s, r_pm, N, p);   // r_s <- r+-
     acc1.zero();
-    mm_ab<KB>(acc1, P, Tpp, p);
-    half_barrier(p);
+    mm_ab2<KB>(acc1, r_s, P, Tpp, Z, p);
     store_strip_global<AL>(T_pp, acc1, N, p);
-#else
-    fstrip Tpp, acc1, acc2;
-    load_strip_global<AL>(Tpp, T_pp, N, p);
-    acc1.zero();
-    acc2.zero();
-    mm_ab2<KB>(acc1, acc2, P, Tpp, Rpm, p);
-    store_strip(Q, acc2, p);  // [T21 R+-] -> Q
-    half_barrier(p);          // (everybody has read the old T++ strip; tmp complete)
-    store_strip_global<AL>(T_pp, acc1, N, p);
-#endif
+    store_strip_global<AL>(R_pm, r_s, N, p);
   }
   VSM_STAMP(19);
-  // ---- R+- = r+- + tmp t-- -------------------------------------------------------------------------------------------------
-  {
-    fstrip tmm, acc;
-    if (ns) {
-      dsym_strip(tmm, t_s, ns, p);
-      dsym_strip(acc, r_s, ns, p);
-    } else {
-      load_strip_global<AL>(tmm, t_mm, N, p);
-      load_strip_global<AL>(acc, r_pm, N, p);
-    }
-    mm_ab<KB>(acc, Q, tmm, p);
-    store_strip_global<AL>(R_pm, acc, N, p);
-  }
   VSM_STAMP(20);
 }
 
