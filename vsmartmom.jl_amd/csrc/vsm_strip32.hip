@@ -99,11 +99,15 @@ struct fpos {
   int tid, lane, wave, l15, kq, col;   // tid / wave: within the half (0..383 / 0..5)
   unsigned* bar;
   mutable unsigned epoch;
+  bool active;                         // false: the odd point out of a workgroup (lockstep build: computes, never stores)
+  const float* red_other;              // lockstep build: the other half's norm partials
   int afrag;   // 4 kq + LDK l15
   int sbase;   // col + 4 LDK kq
   int dr;      // l15 - 4 kq: the diagonal of the wave's strip is element r == dr of tile ta == wave (when 0 <= dr < 4)
   __device__ __forceinline__ fpos(int s_, int tid_, unsigned* bar_) {
     s = s_;
+    active = true;
+    red_other = nullptr;
     tid = tid_;
     bar = bar_;
     epoch = 0;
@@ -121,17 +125,29 @@ struct fpos {
 
 __device__ __forceinline__ f4_t lds4(const float* p) { return *reinterpret_cast<const f4_t*>(p); }
 
-// Barrier over the SIX waves of one spectral point.  A 6-wave workgroup lands on the four SIMDs as 2, 2, 1, 1 waves and the
-// dispatcher starts every workgroup on the same SIMD, so a second 6-wave workgroup never fits beside the first at three waves
-// per SIMD (residency census: tools/occ_probe.hip) -- the kernels therefore run TWO points per 12-wave workgroup (3 waves on
-// every SIMD) and the two halves must not share s_barrier (their barrier counts differ: the series order of an inverse is
-// data dependent; and one half's barrier stalls are what the other half's MFMAs hide).  Arrival counter in LDS: the LDS
-// unit of a CU executes in order, and the release fence drains this wave's LDS traffic (lgkmcnt) before it arrives; global
-// traffic is NOT drained (no wave reads global data that another wave of its point wrote after the start of the kernel).
+// Barriers.  A 6-wave workgroup lands on the four SIMDs as 2, 2, 1, 1 waves and the dispatcher starts every workgroup on the
+// same SIMD, so a second 6-wave workgroup never fits beside the first at three waves per SIMD (residency census:
+// tools/occ_probe.hip).  The kernels therefore run TWO spectral points per 12-wave workgroup: 3 waves on every SIMD.
+// The two points walk ONE barrier sequence in lockstep (hardware s_barrier): in every product phase each SIMD then carries
+// three equally loaded waves, where independent halves leave the 2-2-1-1 imbalance of whichever half is alone in its MFMA
+// phase (measured on C4: independent halves with an LDS arrival-counter barrier 11.9k points/s, lockstep 12.8k).  The only
+// data-dependent barrier count is the inverse (series order / Gauss-Jordan): after the shared norm reduction every wave knows
+// BOTH points' orders and the point that needs fewer barriers pads its sequence (invert_strip) -- the arithmetic of a point
+// never depends on its neighbour, so results are independent of the pairing.  The fences order LDS traffic only: global
+// loads and stores are not drained at a barrier (no wave reads global data another wave wrote after the start of the kernel:
+// each wave loads and stores its own 16 columns of the composite; J0+- are read at the start, many barriers before they are
+// written).  -DVSM_SOFT_BARRIER builds the independent-halves variant.
 #ifndef VSM_BAR_SLEEP
 #define VSM_BAR_SLEEP 1
 #endif
 __device__ __forceinline__ void half_barrier(const fpos& p) {
+#ifndef VSM_SOFT_BARRIER
+  // lockstep build: both points of the workgroup walk the same barrier sequence (the hardware barrier; LDS-only fences)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   p.epoch += FNW;
   if (p.lane == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -149,6 +165,20 @@ struct half_sync {
 template <int KB>
 __device__ __forceinline__ void mm_ab(fstrip& acc, const float* A, const fstrip& B, const fpos& p) {
   const float* a0 = A + p.afrag;
+#ifndef VSM_MM_PAIRS
+  // variant: the six fragments of a k-block are requested together, then 24 MFMAs walk r-major over the six accumulators
+#pragma unroll
+  for (int tb = 0; tb < KB; ++tb) {
+    f4_t fb[FTL];
+#pragma unroll
+    for (int t = 0; t < FTL; ++t) fb[t] = lds4(a0 + 16 * tb + 16 * LDK * t);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int t = 0; t < FTL; ++t) acc.v[t] = mfma<float>::mma(fb[t][r], B.v[tb][r], acc.v[t]);
+  }
+  return;
+#endif
   constexpr int NP = 3 * KB;
   f4_t fa[2][2];
   fa[0][0] = lds4(a0);
@@ -238,7 +268,7 @@ __device__ __forceinline__ void load_strip_global(fstrip& s, const float* __rest
 }
 template <bool AL>
 __device__ __forceinline__ void store_strip_global(float* __restrict__ g, const fstrip& s, int N, const fpos& p) {
-  if (p.col >= N) return;
+  if (p.col >= N || !p.active) return;
   float* g0 = g + (long long)N * p.col + 4 * p.kq;
   if (VSM_ALIGNED(AL, N)) {
 #pragma unroll
@@ -312,7 +342,7 @@ __device__ __forceinline__ float matvec1(const float* A, const float* x, const f
 }
 
 // Frobenius-norm bound of the block whose strips the waves hold (padding is zero).  Contains ONE barrier.
-__device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, int& slot, const fpos& p) {
+__device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, int& slot, const fpos& p, float& nrm_other) {
   float ss = 0;
 #pragma unroll
   for (int ta = 0; ta < FTL; ++ta)
@@ -321,11 +351,44 @@ __device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, 
   const float ws = wave_sum(ss * 1.0001f);
   if (p.lane == 0) sm.red[slot][p.wave] = ws;
   half_barrier(p);
-  float tot = 0.f;
+  float tot = 0.f, tot2 = 0.f;
 #pragma unroll
   for (int w = 0; w < FNW; ++w) tot += sm.red[slot][w];
+#ifndef VSM_SOFT_BARRIER
+#pragma unroll
+  for (int w = 0; w < FNW; ++w) tot2 += p.red_other[8 * slot + w];
+#endif
   slot ^= 1;
+  nrm_other = sqrtf(tot2) * 1.001f;
   return sqrtf(tot) * 1.001f;
+}
+// Series order for a norm bound (0: Gauss-Jordan) and the number of barriers invert_strip executes after the norm reduction
+__device__ __forceinline__ int series_order(float nrm) {
+  const float tol = num<float>::eps() * 0.25f;
+  int K = 0;
+  if (nrm < 0.3f) {
+    const float lim = tol * (1.0f - nrm);
+    const float n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
+    if (n2 <= lim) K = 1;
+    else if (n2 * nrm <= lim) K = 2;
+    else if (n4 <= lim) K = 3;
+    else if (n4 * nrm <= lim) K = 4;
+    else if (n8 <= lim) K = 7;
+    else if (n8 * nrm <= lim) K = 8;
+    else if (n16 <= lim) K = 15;
+    else if (n16 * nrm <= lim) K = 16;
+    else if (n16 * n16 <= lim) K = 31;
+  }
+  return K;
+}
+__device__ __forceinline__ int inverse_barriers(int K, int N) {
+  if (K == 0) return 2 * N + 4;   // store | 2 per pivot step | permutation, end of gj_invert | end of gj_lds_strip
+  if (K == 1) return 0;
+  if (K == 2) return 1;
+  if (K <= 4) return 3;
+  if (K <= 8) return 5;
+  if (K <= 16) return 7;
+  return 9;
 }
 
 // In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block, identity-padded), 384 threads; ends with a barrier.
@@ -368,23 +431,22 @@ __device__ __forceinline__ void add_identity(fstrip& x, int N, const fpos& p) {
 // G_s = strip of (I - E)^-1, E given as strips (see invert_strip in vsm_strip_dev.h).  W: A-form scratch.  Returns after
 // a point where other waves may still be READING W: barrier before overwriting it.
 template <int KB>
+__device__ __forceinline__ int invert_strip_own(fstrip& E, fstrip& G, float* W, int N, fsmem32& sm, const fpos& p, int K);
+template <int KB>
 __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int N, fsmem32& sm, int& slot, const fpos& p) {
-  const float nrm = strip_norm_bound(E, sm, slot, p);
-  const float tol = num<float>::eps() * 0.25f;
-  int K = 0;
-  if (nrm < 0.3f) {
-    const float lim = tol * (1.0f - nrm);
-    const float n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
-    if (n2 <= lim) K = 1;
-    else if (n2 * nrm <= lim) K = 2;
-    else if (n4 <= lim) K = 3;
-    else if (n4 * nrm <= lim) K = 4;
-    else if (n8 <= lim) K = 7;
-    else if (n8 * nrm <= lim) K = 8;
-    else if (n16 <= lim) K = 15;
-    else if (n16 * nrm <= lim) K = 16;
-    else if (n16 * n16 <= lim) K = 31;
-  }
+  float nrm_other;
+  const float nrm = strip_norm_bound(E, sm, slot, p, nrm_other);
+  const int K = series_order(nrm);
+  const int rc = invert_strip_own<KB>(E, G, W, N, sm, p, K);
+#ifndef VSM_SOFT_BARRIER
+  // the other point of the workgroup may need more barriers for its inverse: keep the two barrier sequences equal
+  const int own = inverse_barriers(K, N), oth = inverse_barriers(series_order(nrm_other), N);
+  for (int i = own; i < oth; ++i) half_barrier(p);
+#endif
+  return rc;
+}
+template <int KB>
+__device__ __forceinline__ int invert_strip_own(fstrip& E, fstrip& G, float* W, int N, fsmem32& sm, const fpos& p, int K) {
   if (K == 0) {
 #pragma unroll
     for (int ta = 0; ta < FTL; ++ta) G.v[ta] = -E.v[ta];
@@ -719,7 +781,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   // J0- += T01 u
   {
     const float y = matvec1<KB>(Q, vu, p);
-    if (mlead && mrow < N) J0_m[mrow] = Jm_old + y;
+    if (mlead && mrow < N && p.active) J0_m[mrow] = Jm_old + y;
   }
   // ---- R-+ += (T01 r-+) T++ -----------------------------------------------------------------------------------------
   {
@@ -781,7 +843,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   // J0+ = j0+ + T21 z
   {
     const float y = matvec1<KB>(P, vz, p);
-    if (mlead && mrow < N) J0_p[mrow] = vjp[mrow] + y;
+    if (mlead && mrow < N && p.active) J0_p[mrow] = vjp[mrow] + y;
   }
   // ---- T++ = T21 T++ ; R+- = r+- + T21 Z ---------------------------------------------------------------------------------
   {
@@ -798,6 +860,15 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
 }
 
 // Common prologue: the two halves of the 12-wave workgroup (two spectral points), their LDS and barrier counters.
+#ifndef VSM_SOFT_BARRIER
+#define VSM_HALF_PROLOGUE()                                                              \
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];               \
+  const int half = threadIdx.x / FNT;                                                    \
+  fsmem32& sm = reinterpret_cast<fsmem32*>(smem_raw)[half];                              \
+  fpos p(min(2 * (int)blockIdx.x + half, S - 1), threadIdx.x % FNT, &sm.bar);            \
+  p.active = 2 * (int)blockIdx.x + half < S;                                             \
+  p.red_other = &reinterpret_cast<fsmem32*>(smem_raw)[half ^ 1].red[0][0]
+#else
 #define VSM_HALF_PROLOGUE()                                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];               \
   const int half = threadIdx.x / FNT;                                                    \
@@ -806,6 +877,7 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   __syncthreads(); /* the only workgroup-wide barrier: counters initialised */           \
   fpos p(2 * blockIdx.x + half, threadIdx.x % FNT, &sm.bar);                             \
   if (p.s >= S) return
+#endif
 
 template <int KB, bool AL>
 __global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composite<float> c, added<float> a) {
@@ -844,7 +916,7 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int
     store_strip_global<AL>(c.R_pm + s * NN, d, N, p);
     dsym_strip(d, t_s, ns, p);
     store_strip_global<AL>(c.T_mm + s * NN, d, N, p);
-    if (tid < N) {
+    if (tid < N && p.active) {
       c.J0_p[(long long)s * N + tid] = sm.vec[2 * jpair][tid];
       c.J0_m[(long long)s * N + tid] = sm.vec[2 * jpair + 1][tid];
     }
