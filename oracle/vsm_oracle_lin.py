@@ -387,27 +387,163 @@ def create_surface_layer_lambertian_lin(albedo, added: O.AddedLayer, al: AddedLa
 
 
 @dataclass
+class LinAerosolOptics:
+    """lin_aerosol_optics[iaer] as the hot path consumes it (compEffectiveLayerProperties_lin.jl:330-395): derivatives of the
+    aerosol's Greek coefficients, single-scattering albedo and truncation factor with respect to the four Mie parameters
+    (n_r, n_i, r_m, sigma_r).  Mie theory itself (the producer of these numbers) is upstream of the hot path."""
+    greek_dot: List[O.GreekCoefs]   # 4 entries
+    ssa_dot: np.ndarray             # [4]
+    f_trunc_dot: np.ndarray         # [4]
+
+
+@dataclass
 class LinModel:
-    """What the hot path needs from `lin_model` for gas + surface Jacobians: tau_abs_dot[g][S, L] =
-    d tau_abs / d x_g per layer (NGas slots), plus one Lambertian-albedo slot (NSurf = 1)."""
+    """What the hot path needs from `lin_model`: tau_abs_dot[g][S, L] = d tau_abs / d x_g per layer (NGas slots); for aerosol
+    Jacobians tau_aer_dot[iaer][7, L] = d tau_aer / d (tau_ref, n_r, n_i, r_m, sigma_r, p0, sigma_p) per layer and
+    lin_aerosol_optics[iaer]; plus one surface slot (NSurf = 1).  Slot order (parameter_layout.jl:28-56): 7 per aerosol,
+    then the gases, then the surface."""
     tau_abs_dot: List[np.ndarray]
+    tau_aer_dot: Optional[np.ndarray] = None            # [nAer, 7, L]
+    lin_aerosol_optics: Optional[List[LinAerosolOptics]] = None
+
+    @property
+    def n_aer(self):
+        return 0 if self.tau_aer_dot is None else len(self.tau_aer_dot)
 
     @property
     def n_layer_params(self):
-        return len(self.tau_abs_dot)
+        return 7 * self.n_aer + len(self.tau_abs_dot)
 
 
-def layer_optics_lin(model: O.RTModel, lin: LinModel, lods: List[O.CoreScatteringOpticalProperties]) -> List[LayerOpticsLin]:
-    """d(tau, varpi, Z)/dx for absorption-only parameters: tau = tau_s + tau_abs, varpi = w_s/tau
-    (types.jl:1302-1308) => tau_dot = tau_abs_dot, varpi_dot = -varpi/tau * tau_dot, Z_dot = 0."""
+def create_aero_lin(tau_aer, ao: O.AerosolOptics, tau_aer_dot7, lao: LinAerosolOptics, AZpp_dot4, AZmp_dot4):
+    """createAero with derivatives (compEffectiveLayerProperties_lin.jl:330-395): delta-M scaled (tau, varpi) of one aerosol in
+    one layer and their derivatives with respect to its 7 sub-parameters; Zdot is non-zero for the Mie slots 2..5 only."""
+    f, w = ao.f_trunc, ao.ssa
+    wd = np.zeros(7)
+    fd = np.zeros(7)
+    wd[1:5] = lao.ssa_dot
+    fd[1:5] = lao.f_trunc_dot
+    tau_mod = (1.0 - f * w) * tau_aer
+    varpi_mod = (1.0 - f) * w / (1.0 - f * w)
+    td = np.zeros(7)
+    vd = np.zeros(7)
+    td[0] = (1.0 - f * w) * tau_aer_dot7[0]
+    for k in range(1, 5):
+        td[k] = (1.0 - f * w) * tau_aer_dot7[k] - (f * wd[k] + w * fd[k]) * tau_aer
+        vd[k] = (wd[k] * (1.0 - f) - fd[k] * (w * (1.0 - w))) / (1.0 - f * w) ** 2
+    for k in (5, 6):
+        td[k] = (1.0 - f * w) * tau_aer_dot7[k]
+    N = AZpp_dot4.shape[-1]
+    Zpd = np.zeros((7, N, N))
+    Zmd = np.zeros((7, N, N))
+    Zpd[1:5] = AZpp_dot4
+    Zmd[1:5] = AZmp_dot4
+    return tau_mod, varpi_mod, td, vd, Zpd, Zmd
+
+
+def _b(a, S):
+    return np.broadcast_to(np.asarray(a, dtype=np.float64), (S,)).copy()
+
+
+def _zs(Z, S):
+    Z = np.asarray(Z, dtype=np.float64)
+    return np.broadcast_to(Z, (S,) + Z.shape[-2:]) if Z.ndim == 2 else Z
+
+
+def _mix_lin(x, xd, y, yd, S):
+    """`+` of two scattering layers with derivatives (types_lin.jl:196-298): tau = tau_x + tau_y, varpi = (w_x + w_y) / tau with
+    w = tau varpi, Z = (w_x Z_x + w_y Z_y) / (w_x + w_y); the derivative blocks of x and y are concatenated (x first).
+    x / y: (tau [S], varpi [S], Zpp [S,N,N], Zmp); xd / yd: None or (tau_dot [S,n], varpi_dot [S,n], Zpp_dot [n,S,N,N], Zmp_dot)."""
+    tx, vx, Zxp, Zxm = x
+    ty, vy, Zyp, Zym = y
+    tau = tx + ty
+    wx, wy = tx * vx, ty * vy
+    w = wx + wy
+    varpi = w / tau
+    Zpp = (wx[:, None, None] * Zxp + wy[:, None, None] * Zyp) / w[:, None, None]
+    Zmp = (wx[:, None, None] * Zxm + wy[:, None, None] * Zym) / w[:, None, None]
+    tds, wds, nums_p, nums_m = [], [], [], []
+    for (t_, v_, Zp_, Zm_), d in (((tx, vx, Zxp, Zxm), xd), ((ty, vy, Zyp, Zym), yd)):
+        if d is None:
+            continue
+        td, vd, Zpd, Zmd = d
+        wdot = td * v_[:, None] + t_[:, None] * vd                       # d(tau varpi) of this constituent  [S, n]
+        tds.append(td)
+        wds.append(wdot)
+        nums_p.append(wdot.T[:, :, None, None] * Zp_[None] + (t_ * v_)[None, :, None, None] * Zpd)
+        nums_m.append(wdot.T[:, :, None, None] * Zm_[None] + (t_ * v_)[None, :, None, None] * Zmd)
+    tau_dot = np.concatenate(tds, axis=1)
+    w_dot = np.concatenate(wds, axis=1)
+    varpi_dot = (w_dot - varpi[:, None] * tau_dot) / tau[:, None]
+    tot = tau[:, None] * varpi_dot + tau_dot * varpi[:, None]            # = d(tau varpi) of the mixture
+    Zpp_dot = (np.concatenate(nums_p, axis=0) - tot.T[:, :, None, None] * Zpp[None]) / w[None, :, None, None]
+    Zmp_dot = (np.concatenate(nums_m, axis=0) - tot.T[:, :, None, None] * Zmp[None]) / w[None, :, None, None]
+    return (tau, varpi, Zpp, Zmp), (tau_dot, varpi_dot, Zpp_dot, Zmp_dot)
+
+
+def _add_absorption_lin(x, xd, tau_abs, tau_abs_dot):
+    """`+` of a scattering layer and an absorber with derivatives (types_lin.jl:300-380): tau += tau_abs, varpi = w_x / tau,
+    Z unchanged; gas slots are appended after the slots of x."""
+    tx, vx, Zp, Zm = x
+    tau = tx + tau_abs
+    w = tx * vx
+    varpi = w / tau
+    n2 = tau_abs_dot.shape[1]
+    if xd is None:
+        return (tau, varpi, Zp, Zm), (tau_abs_dot, -(varpi / tau)[:, None] * tau_abs_dot, None, None)
+    td, vd, Zpd, Zmd = xd
+    wdot = td * vx[:, None] + tx[:, None] * vd
+    tau_dot = np.concatenate([td, tau_abs_dot], axis=1)
+    varpi_dot = np.concatenate([(wdot - varpi[:, None] * td) / tau[:, None], -(varpi / tau)[:, None] * tau_abs_dot], axis=1)
+    tot = tau[:, None] * varpi_dot + tau_dot * varpi[:, None]
+    S, N = len(tau), Zp.shape[-1]
+    num_p = np.concatenate([wdot.T[:, :, None, None] * Zp[None] + w[None, :, None, None] * Zpd, np.zeros((n2, S, N, N))], axis=0)
+    num_m = np.concatenate([wdot.T[:, :, None, None] * Zm[None] + w[None, :, None, None] * Zmd, np.zeros((n2, S, N, N))], axis=0)
+    Zpp_dot = (num_p - tot.T[:, :, None, None] * Zp[None]) / w[None, :, None, None]
+    Zmp_dot = (num_m - tot.T[:, :, None, None] * Zm[None]) / w[None, :, None, None]
+    return (tau, varpi, Zp, Zm), (tau_dot, varpi_dot, Zpp_dot, Zmp_dot)
+
+
+def layer_optics_lin(model: O.RTModel, lin: LinModel, lods: List[O.CoreScatteringOpticalProperties], m: int = 0) -> List[LayerOpticsLin]:
+    """d(tau, varpi, Z)/dx per layer (constructCoreOpticalProperties with lin_model, compEffectiveLayerProperties_lin.jl:43-197).
+    Without aerosol slots: tau = tau_s + tau_abs, varpi = w_s/tau (types.jl:1302-1308) => tau_dot = tau_abs_dot,
+    varpi_dot = -varpi/tau * tau_dot, Z_dot = 0.  With aerosol slots the Rayleigh layer (no derivatives) is mixed with every
+    aerosol (7 slots each) and the absorbers are added last, each `+` propagating the quotient rule."""
     out = []
-    for iz, lo in enumerate(lods):
-        tau = np.atleast_1d(lo.tau)
-        varpi = np.broadcast_to(np.asarray(lo.varpi), tau.shape)
-        td = np.stack([g[:, iz] for g in lin.tau_abs_dot], axis=1)
-        safe = np.where(tau > 0, tau, 1.0)
-        wd = -(varpi / safe)[:, None] * td
-        out.append(LayerOpticsLin(td, wd, None, None))
+    if lin.n_aer == 0:
+        for iz, lo in enumerate(lods):
+            tau = np.atleast_1d(lo.tau)
+            varpi = np.broadcast_to(np.asarray(lo.varpi), tau.shape)
+            td = np.stack([g[:, iz] for g in lin.tau_abs_dot], axis=1)
+            safe = np.where(tau > 0, tau, 1.0)
+            wd = -(varpi / safe)[:, None] * td
+            out.append(LayerOpticsLin(td, wd, None, None))
+        return out
+    assert lin.n_aer == len(model.aerosol_optics), "one derivative block per aerosol of the model"
+    mu = model.quad_points.qp_mu.astype(np.float64)
+    S, L = model.tau_rayl.shape
+    RZpp, RZmp = O.compute_Z_moments(model.pol, mu, model.greek_rayleigh, m)
+    aer = []
+    for ia, ao in enumerate(model.aerosol_optics):
+        AZpp, AZmp = O.compute_Z_moments(model.pol, mu, ao.greek, m)
+        Zd = [O.compute_Z_moments(model.pol, mu, g, m) for g in lin.lin_aerosol_optics[ia].greek_dot]   # Z is linear in the Greek coefficients
+        aer.append((AZpp, AZmp, np.stack([z[0] for z in Zd]), np.stack([z[1] for z in Zd])))
+    for iz in range(L):
+        x = (model.tau_rayl[:, iz].astype(np.float64), _b(model.varpi_cabannes, S), _zs(RZpp, S), _zs(RZmp, S))
+        xd = None
+        for ia, ao in enumerate(model.aerosol_optics):
+            AZpp, AZmp, AZpd, AZmd = aer[ia]
+            tm, vm, td7, vd7, Zpd7, Zmd7 = create_aero_lin(model.tau_aer[ia, iz], ao, lin.tau_aer_dot[ia][:, iz],
+                                                           lin.lin_aerosol_optics[ia], AZpd, AZmd)
+            y = (_b(tm, S), _b(vm, S), _zs(AZpp, S), _zs(AZmp, S))
+            yd = (np.tile(td7, (S, 1)), np.tile(vd7, (S, 1)), np.broadcast_to(Zpd7[:, None], (7, S) + Zpd7.shape[-2:]),
+                  np.broadcast_to(Zmd7[:, None], (7, S) + Zmd7.shape[-2:]))
+            x, xd = _mix_lin(x, xd, y, yd, S)
+        gd = (np.stack([g[:, iz] for g in lin.tau_abs_dot], axis=1) if lin.tau_abs_dot else np.zeros((S, 0)))
+        x, xd = _add_absorption_lin(x, xd, model.tau_abs[:, iz].astype(np.float64), gd)
+        # the forward part must reproduce the forward construction
+        assert np.allclose(x[0], np.atleast_1d(lods[iz].tau), rtol=1e-13, atol=0) and np.allclose(x[1], lods[iz].varpi, rtol=1e-12, atol=0)
+        out.append(LayerOpticsLin(xd[0], xd[1], xd[2], xd[3]))
     return out
 
 
@@ -434,7 +570,7 @@ def rt_run_lin(model: O.RTModel, lin: LinModel):
     for m in range(model.m_max + 1):
         weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
         lods = O.construct_core_optical_properties(model, m)
-        lins = layer_optics_lin(model, lin, lods)
+        lins = layer_optics_lin(model, lin, lods, m)
         ifaces, tau_sum_all = O.extract_effective_props(lods, FT)
         tsd = np.zeros((S, pl, L + 1))
         for iz in range(L):

@@ -364,3 +364,26 @@ atmospheric_profile: {T: [250.0, 275.0], p: [100.0, 500.0, 1000.0]}
         io.parameters_from_yaml(text + "absorption: {molecules: [[O2]]}\n")
     with pytest.raises(ValueError):
         io.parameters_from_yaml(text.replace("nstreams: 3", "nstreams: 2"))
+
+
+def test_host_aerosol_jacobian_optics_equal_the_oracle_chain():
+    """host_model.constructCoreOpticalPropertiesLin with aerosol slots (closed-form derivatives of the mixed layer) against the
+    oracle's restatement of the reference's pairwise `+` chain (types_lin.jl:196-380, compEffectiveLayerProperties_lin.jl:330-395)."""
+    import vsmartmom_jl_amd as vsm
+    from oracle import vsm_oracle as O, vsm_oracle_lin as OL
+    from tests.test_oracle_lin import _aerosol_scene
+    H = vsm.host_model
+    om, ol = _aerosol_scene("IQU")
+    ao, lao = om.aerosol_optics[0], ol.lin_aerosol_optics[0]
+    pm = H.model_from_arrays(vsm.Architectures.CPU(), "IQU", 9, 35.0, [20.0, 50.0], [0.0, 120.0], tau_rayl=om.tau_rayl,
+                             tau_abs=om.tau_abs, tau_aer=om.tau_aer,
+                             aerosol_optics=[H.AerosolOptics(H.GreekCoefs(**vars(ao.greek)), ao.ssa, ao.f_trunc)], depol=0.03,
+                             albedo=om.albedo, m_max=om.m_max)
+    pl = H.LinModel(ol.tau_abs_dot, tau_aer_dot=ol.tau_aer_dot,
+                    lin_aerosol_optics=[H.LinAerosolOptics([H.GreekCoefs(**vars(g)) for g in lao.greek_dot], lao.ssa_dot, lao.f_trunc_dot)])
+    for m in (0, 1, 3):
+        a = H.constructCoreOpticalPropertiesLin(pm, pl, H.constructCoreOpticalProperties(pm, m), m)
+        b = OL.layer_optics_lin(om, ol, O.construct_core_optical_properties(om, m), m)
+        for x, y in zip(a, b):
+            for u, v in ((x.tau_dot, y.tau_dot), (x.varpi_dot, y.varpi_dot), (x.Zpp_dot, y.Zpp_dot), (x.Zmp_dot, y.Zmp_dot)):
+                assert np.max(np.abs(u - v)) <= 1e-12 * max(np.max(np.abs(v)), 1e-30), m

@@ -211,3 +211,41 @@ def test_rt_run_lin_fp32(vsm, arch, pol, l_trunc):
     assert _rel(R, R32) < 5e-4 and _rel(T, T32) < 5e-4
     for p in range(3):
         assert _rel(Rd[..., p], Rd32[..., p]) < 2e-3 and _rel(Td[..., p], Td32[..., p]) < 2e-3, p
+
+
+def _host_aerosol_scene(vsm, arch, pol, l_trunc, x=None, FT=np.float64):
+    """The parametric aerosol scene of tests/test_oracle_lin.py as (oracle model, oracle lin, host model, host lin)."""
+    from tests.test_oracle_lin import _aerosol_scene
+    H = vsm.host_model
+    om, ol = _aerosol_scene(pol, x, l_trunc=l_trunc)
+    ao = om.aerosol_optics[0]
+    pm = H.model_from_arrays(arch, pol, l_trunc, 35.0, [20.0, 50.0], [0.0, 120.0], tau_rayl=om.tau_rayl, tau_abs=om.tau_abs,
+                             tau_aer=om.tau_aer, aerosol_optics=[H.AerosolOptics(H.GreekCoefs(**vars(ao.greek)), ao.ssa, ao.f_trunc)],
+                             depol=0.03, albedo=om.albedo, m_max=om.m_max, float_type=FT)
+    lao = ol.lin_aerosol_optics[0]
+    pl = H.LinModel(ol.tau_abs_dot, tau_aer_dot=ol.tau_aer_dot,
+                    lin_aerosol_optics=[H.LinAerosolOptics([H.GreekCoefs(**vars(g)) for g in lao.greek_dot], lao.ssa_dot, lao.f_trunc_dot)])
+    return om, ol, pm, pl
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 6..., 57 (fused strip kernels)
+def test_rt_run_lin_aerosol_slots(vsm, arch, pol, l_trunc):
+    """rt_run(model, lin_model, NAer = 1, NGas = 1, NSurf = 1): the 7 aerosol slots (tau_ref, n_r, n_i, r_m, sigma_r, p0,
+    sigma_p; parameter_layout.jl:28-56) + gas + albedo against the oracle (whose aerosol chain rule is itself checked by
+    finite differences in tests/test_oracle_lin.py), and tau_ref / n_r / p0 against central differences of the DEVICE forward run."""
+    om, ol, pm, pl = _host_aerosol_scene(vsm, arch, pol, l_trunc)
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, ol)
+    R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, pl, 1, 1, 1)
+    assert Rd.shape == Rdo.shape and Rd.shape[-1] == 9
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9
+    for p in range(9):
+        assert _rel(Rd[..., p], Rdo[..., p]) < 1e-8 and _rel(Td[..., p], Tdo[..., p]) < 1e-8, p
+    h = 1e-5
+    for k in (0, 1, 5):
+        e = np.zeros(7)
+        e[k] = h
+        Rp, Tp = vsm.CoreRT.rt_run(_host_aerosol_scene(vsm, arch, pol, l_trunc, e)[2])
+        Rm, Tm = vsm.CoreRT.rt_run(_host_aerosol_scene(vsm, arch, pol, l_trunc, -e)[2])
+        for an, fd in ((Rd[..., k], (Rp - Rm) / (2 * h)), (Td[..., k], (Tp - Tm) / (2 * h))):
+            err = np.abs(fd - an) / np.abs(fd).max()
+            assert err.max() < 1e-3 and err.mean() < 1e-4, (k, err.max())

@@ -139,13 +139,15 @@ class SceneLin:
     launches kernels.  `spec_slice` selects this rank's spectral shard; ndoubl and the tags always come from the FULL
     spectral axis (rt_kernel_lin.jl:87-95 uses batch-global maxima like the forward kernel).
 
-    Parameter slots (parameter_layout.jl:28-56): gases first, then ONE surface slot -- the Lambertian albedo
+    Parameter slots (parameter_layout.jl:28-56): 7 per aerosol (tau_ref, n_r, n_i, r_m, sigma_r, p0, sigma_p; their optics
+    derivatives are inputs: LinModel.tau_aer_dot / lin_aerosol_optics), the gases, then ONE surface slot -- the Lambertian albedo
     (lambertian_surface_lin.jl:48-162) or the Cox-Munk wind speed (coxmunk_surface_lin.jl:27-102)."""
 
     def __init__(self, model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int,
                  spec_slice: Optional[slice] = None):
-        if NAer != 0 or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
-            raise _lib.VSMError("rt_run (linearized): only NAer=0, NGas=len(lin_model.tau_abs_dot), NSurf=1 are wired up")
+        if NAer != lin_model.n_aer or NAer != len(model.aerosol_optics) or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
+            raise _lib.VSMError("rt_run (linearized): NAer must equal the aerosols of model and lin_model, NGas = "
+                                "len(lin_model.tau_abs_dot), NSurf = 1")
         if not isinstance(model.surface, (H.LambertianSurfaceScalar, H.CoxMunkSurface)):
             raise _lib.VSMError("rt_run (linearized): surface %r has no linearized builder here" % (model.surface,))
         arch, FT = model.architecture, model.float_type
@@ -176,7 +178,7 @@ class SceneLin:
         shared = None     # tau/varpi/derivative tensors do not depend on m when no aerosol is mixed in: upload once
         for m in range(model.m_max + 1):
             lods = H.constructCoreOpticalProperties(model, m)
-            lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods)
+            lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods, m)
             tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
             if any(t != "11" for t in tags):
                 raise _lib.VSMError("rt_run (linearized): every layer must scatter (rt_kernel_lin.jl:87 hard-codes scatter=true)")
@@ -297,7 +299,8 @@ def prepare_scene_lin(model, lin_model, NAer, NGas, NSurf, spec_slice: Optional[
 
 def rt_run_lin(model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int):
     """rt_run(model, lin_model, NAer, NGas, NSurf) (rt_run_lin.jl:72-78 -> :102-326) -> (R, T, Rdot, Tdot);
-    Rdot/Tdot: [nVZA, nStokes, nSpec, Nparams].  Supported: NAer = 0, NGas = len(lin_model.tau_abs_dot), NSurf = 1
+    Rdot/Tdot: [nVZA, nStokes, nSpec, Nparams].  Supported: NAer = number of aerosols of the model (7 slots each, optics
+    derivatives supplied in lin_model), NGas = len(lin_model.tau_abs_dot), NSurf = 1
     (Lambertian albedo or Cox-Munk wind speed, by the model's surface).  Like the reference's linearized driver this
     path applies no TMS correction."""
     scene = SceneLin(model, lin_model, NAer, NGas, NSurf)

@@ -624,23 +624,108 @@ class CoreScatteringOpticalPropertiesLin:
 
 
 @dataclass
+class LinAerosolOptics:
+    """lin_aerosol_optics[iaer] (compEffectiveLayerProperties_lin.jl:330-395): derivatives of the aerosol's Greek coefficients,
+    single-scattering albedo and truncation factor with respect to the four Mie parameters (n_r, n_i, r_m, sigma_r).  Mie
+    theory (their producer) is upstream of the hot path: the numbers are inputs here."""
+    lin_greek_coefs: List[GreekCoefs]   # 4 entries
+    ssa_dot: np.ndarray                 # [4]  (lin_aerosol_optics.ω̃̇)
+    f_trunc_dot: np.ndarray             # [4]  (lin_aerosol_optics.ḟᵗ)
+
+
+@dataclass
 class LinModel:
-    """The part of the reference's lin_model the hot path consumes for gas Jacobians:
-    tau_abs_dot[g][S, Nz] = d tau_abs / d x_g (lin_model.τ̇_abs).  Aerosol (Mie) derivatives are upstream of
-    the hot path and out of scope (SURVEY.md 8c 'parity unpinned')."""
+    """The part of the reference's lin_model the hot path consumes: tau_abs_dot[g][S, Nz] = d tau_abs / d x_g (lin_model.τ̇_abs);
+    for aerosol Jacobians tau_aer_dot[iaer][7, Nz] = d tau_aer / d (tau_ref, n_r, n_i, r_m, sigma_r, p0, sigma_p) per layer
+    (lin_model.τ̇_aer) and lin_aerosol_optics[iaer]."""
     tau_abs_dot: List[np.ndarray]
+    tau_aer_dot: Optional[np.ndarray] = None
+    lin_aerosol_optics: Optional[List[LinAerosolOptics]] = None
+
+    @property
+    def n_aer(self) -> int:
+        return 0 if self.tau_aer_dot is None else len(self.tau_aer_dot)
 
 
-def constructCoreOpticalPropertiesLin(model: RTModel, lin_model: LinModel,
-                                      lods: List[CoreScatteringOpticalProperties]) -> List[CoreScatteringOpticalPropertiesLin]:
-    """Absorption-only parameters: tau = tau_sc + tau_abs, varpi = w_sc / tau (types.jl:1302-1308)
-    => tau_dot = tau_abs_dot, varpi_dot = -(varpi / tau) tau_dot, Z_dot = 0
-    (the gas block of compEffectiveLayerProperties_lin.jl:43-473)."""
+def createAeroLin(tau_aer: float, ao: AerosolOptics, tau_aer_dot7: np.ndarray, lao: LinAerosolOptics):
+    """The scalar part of createAero with derivatives (compEffectiveLayerProperties_lin.jl:330-395): delta-M scaled
+    (tau, varpi) and d/d(7 sub-parameters); only the Mie slots 1..4 (0-based) move varpi."""
+    f, w = ao.f_trunc, ao.ssa
+    wd, fd = np.zeros(7), np.zeros(7)
+    wd[1:5], fd[1:5] = lao.ssa_dot, lao.f_trunc_dot
+    g = 1.0 - f * w
+    td = g * np.asarray(tau_aer_dot7, dtype=np.float64) - (f * wd + w * fd) * tau_aer
+    vd = (wd * (1.0 - f) - fd * (w * (1.0 - w))) / g ** 2
+    return g * tau_aer, (1.0 - f) * w / g, td, vd
+
+
+def constructCoreOpticalPropertiesLin(model: RTModel, lin_model: LinModel, lods: List[CoreScatteringOpticalProperties],
+                                      m: int = 0) -> List[CoreScatteringOpticalPropertiesLin]:
+    """d(tau, varpi, Z)/dx per layer (constructCoreOpticalProperties with lin_model, compEffectiveLayerProperties_lin.jl:43-197).
+
+    The reference chains the quotient rule through its pairwise `+` (types_lin.jl:196-380); the layer's optics are
+    tau = sum_c tau_c + tau_abs, W = sum_c w_c (w_c = tau_c varpi_c), varpi = W / tau, Z = sum_c w_c Z_c / W over the scatterers
+    c = Rayleigh, aerosol 1, ..., so for a parameter p of aerosol a (w_dot = tau_dot_a varpi_a + tau_a varpi_dot_a):
+        tau_dot = tau_dot_a,  varpi_dot = (w_dot - varpi tau_dot) / tau,  Z_dot = (w_dot (Z_a - Z) + w_a Zdot_a) / W
+    and for a gas: tau_dot = tau_abs_dot, varpi_dot = -varpi tau_dot / tau, Z_dot = 0 -- evaluated here in that closed form."""
     out = []
-    for iz, lo in enumerate(lods):
-        tau = np.atleast_1d(lo.tau)
-        varpi = np.broadcast_to(np.asarray(lo.varpi), tau.shape)
-        td = np.stack([g[:, iz] for g in lin_model.tau_abs_dot], axis=1)
-        wd = -(varpi / np.where(tau > 0, tau, 1.0))[:, None] * td
-        out.append(CoreScatteringOpticalPropertiesLin(td, wd, None, None))
+    nA = lin_model.n_aer
+    if nA == 0:
+        for iz, lo in enumerate(lods):
+            tau = np.atleast_1d(lo.tau)
+            varpi = np.broadcast_to(np.asarray(lo.varpi), tau.shape)
+            td = np.stack([g[:, iz] for g in lin_model.tau_abs_dot], axis=1)
+            wd = -(varpi / np.where(tau > 0, tau, 1.0))[:, None] * td
+            out.append(CoreScatteringOpticalPropertiesLin(td, wd, None, None))
+        return out
+    if nA != len(model.aerosol_optics):
+        raise ValueError("lin_model carries %d aerosol blocks, the model %d aerosols" % (nA, len(model.aerosol_optics)))
+    pol, mu = model.polarization_type, model.quad_points.qp_mu.astype(np.float64)
+    S, Nz = model.tau_rayl.shape
+    nG = len(lin_model.tau_abs_dot)
+    pl = 7 * nA + nG
+    Zc = [compute_Z_moments(pol, mu, model.greek_rayleigh, m)] + [compute_Z_moments(pol, mu, ao.greek_coefs, m)
+                                                                  for ao in model.aerosol_optics]
+    Zcp, Zcm = np.stack([z[0] for z in Zc]), np.stack([z[1] for z in Zc])          # [C, N, N]
+    Zdp = [np.stack([compute_Z_moments(pol, mu, g, m)[0] for g in lao.lin_greek_coefs]) for lao in lin_model.lin_aerosol_optics]
+    Zdm = [np.stack([compute_Z_moments(pol, mu, g, m)[1] for g in lao.lin_greek_coefs]) for lao in lin_model.lin_aerosol_optics]
+    N = Zcp.shape[-1]
+    for iz in range(Nz):
+        tau_c = [model.tau_rayl[:, iz].astype(np.float64)]
+        var_c = [np.full(S, np.float64(model.varpi_Cabannes))]
+        aer = []
+        for ia, ao in enumerate(model.aerosol_optics):
+            tm, vm, td7, vd7 = createAeroLin(model.tau_aer[ia, iz], ao, lin_model.tau_aer_dot[ia][:, iz], lin_model.lin_aerosol_optics[ia])
+            tau_c.append(np.full(S, tm))
+            var_c.append(np.full(S, vm))
+            aer.append((td7, vd7))
+        w_c = np.stack([t * v for t, v in zip(tau_c, var_c)])                      # [C, S]
+        W = w_c.sum(axis=0)
+        tau = np.sum(tau_c, axis=0) + model.tau_abs[:, iz]
+        varpi = W / tau
+        fz = w_c / W                                                                # [C, S]
+        Zp = np.einsum("cs,cij->sij", fz, Zcp)
+        Zm = np.einsum("cs,cij->sij", fz, Zcm)
+        tau_dot = np.zeros((S, pl))
+        varpi_dot = np.zeros((S, pl))
+        Zpp_dot = np.zeros((pl, S, N, N))
+        Zmp_dot = np.zeros((pl, S, N, N))
+        for ia in range(nA):
+            td7, vd7 = aer[ia]
+            ta, va = tau_c[1 + ia], var_c[1 + ia]
+            for k in range(7):
+                p = 7 * ia + k
+                wdot = td7[k] * va + ta * vd7[k]
+                tau_dot[:, p] = td7[k]
+                varpi_dot[:, p] = (wdot - varpi * td7[k]) / tau
+                Zpp_dot[p] = (wdot / W)[:, None, None] * (Zcp[1 + ia][None] - Zp)
+                Zmp_dot[p] = (wdot / W)[:, None, None] * (Zcm[1 + ia][None] - Zm)
+                if 1 <= k <= 4:
+                    Zpp_dot[p] += fz[1 + ia][:, None, None] * Zdp[ia][k - 1][None]
+                    Zmp_dot[p] += fz[1 + ia][:, None, None] * Zdm[ia][k - 1][None]
+        for g in range(nG):
+            p = 7 * nA + g
+            tau_dot[:, p] = lin_model.tau_abs_dot[g][:, iz]
+            varpi_dot[:, p] = -(varpi / tau) * tau_dot[:, p]
+        out.append(CoreScatteringOpticalPropertiesLin(tau_dot, varpi_dot, Zpp_dot, Zmp_dot))
     return out
