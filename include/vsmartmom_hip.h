@@ -175,6 +175,15 @@ int vsm_noscat_layer_f64(const vsm_quad_f64* q, int S, const double* tau,
 int vsm_noscat_layer_f32(const vsm_quad_f32* q, int S, const float* tau,
                          const vsm_added_f32* added, void* stream);
 
+/* Thermal-emission source slot (`:thermal` of j₀_by_src): contribute!(::PreparedThermalEmission, ...)
+ * (src/CoreRT/Sources/thermal_emission.jl:241-301) -- j₀⁺ = j₀⁻ = 2π (1-ϖ) B (1 - exp(-dτ/μᵢ)) on the Stokes-I rows of the
+ * elemental layer, zero on Q/U/V; B[S] = Planck radiance of the layer per spectral point.  Written into added->j0_p / j0_m
+ * AFTER vsm_elemental_* and BEFORE vsm_doubling_*, which then runs with the slot's own expk = 1 (doubling.jl:62-81). */
+int vsm_thermal_source_f64(const vsm_quad_f64* q, int S, const double* dtau, const double* varpi, const double* B,
+                           const vsm_added_f64* added, void* stream);
+int vsm_thermal_source_f32(const vsm_quad_f32* q, int S, const float* dtau, const float* varpi, const float* B,
+                           const vsm_added_f32* added, void* stream);
+
 /* copy_added_to_composite! (rt_helpers.jl:188-200), TOA layer. */
 int vsm_copy_added_to_composite_f64(int N, int S, const vsm_added_f64* added,
                                     const vsm_composite_f64* comp, void* stream);

@@ -904,6 +904,83 @@ def rt_run(model: RTModel, trace=None, per_m=None, hdrf=None):
 
 
 # ----------------------------------------------------------------------------
+# thermal emission: the per-source slot `:thermal` of the source-term framework
+# ----------------------------------------------------------------------------
+
+
+def planck_spectrum_wn(T, nu):
+    """src/SolarModel/SolarModel.jl:26-35: Planck radiance in mW / (m^2 sr cm^-1) on a wavenumber grid [cm^-1]."""
+    nu = np.asarray(nu, dtype=np.float64)
+    return 1.1910427e-5 * nu ** 3 / (np.exp(1.4387752 * nu / T) - 1.0)
+
+
+def thermal_source(pol: Polarization, qp: QuadPoints, dtau, varpi, B, FT):
+    """contribute!(::PreparedThermalEmission, ...) (src/CoreRT/Sources/thermal_emission.jl:241-301): the elemental layer's
+    thermal source, identical up and down, on the Stokes-I rows:  2 pi (1 - varpi) B (1 - exp(-dtau / mu_i)).  [S, N]"""
+    mu = qp.qp_mu.astype(FT)
+    n = pol.n
+    S = len(dtau)
+    j = np.zeros((S, len(mu) * n), dtype=FT)
+    coeff = FT(2 * math.pi) * (FT(1) - np.asarray(varpi, dtype=FT)) * np.asarray(B, dtype=FT)
+    for i, mi in enumerate(mu):
+        if mi > eps(FT):
+            j[:, i * n] = coeff * (-np.expm1(-np.asarray(dtau, dtype=FT) / mi))
+    return j
+
+
+def rt_run_thermal(model: RTModel, B_layer):
+    """The `:thermal` per-source slot of rt_run (rt_kernel.jl:205-232 slot reset + contribute!, doubling.jl:62-81 per-source
+    source update with the slot's own expk = 1, interaction.jl:52-75 ... per-source J0 recurrences, postprocessing_vza.jl:68-82):
+    the same linear source recurrences as the solar slot, driven by the thermal source, m = 0 only (isotropic).  Returns the
+    slot's contribution (R_th, T_th) -- rt_run adds it to R_SFI / T_SFI.  B_layer: [L, S] Planck radiance per layer.
+    The slot recurrences are evaluated on a copy of the layer (its r, t evolve exactly like the solar pass's).
+    Deviation (documented in DESIGN.md): a non-scattering layer contributes no thermal source, like the reference (its
+    contribute! sits in the scatter branch), but the slot is ZEROED there, whereas the reference leaves the previous layer's
+    doubled slot in place (rt_kernel.jl:217-221 resets only in the scatter branch)."""
+    FT = model.FT
+    pol, qp = model.pol, model.quad_points
+    S, L = model.tau_rayl.shape
+    N = qp.Nquad * pol.n
+    nV = len(model.vza)
+    R_th = np.zeros((nV, pol.n, S), dtype=FT)
+    T_th = np.zeros((nV, pol.n, S), dtype=FT)
+    B_layer = np.asarray(B_layer, dtype=FT)
+    F0 = np.zeros((pol.n, S), dtype=FT)
+    added, added_surf, comp = make_added_layer(FT, N, S), make_added_layer(FT, N, S), make_composite_layer(FT, N, S)
+    m = 0
+    weight = FT(0.5 / math.pi)
+    lods = construct_core_optical_properties(model, m)
+    ifaces, tau_sum_all = extract_effective_props(lods, FT)
+    for iz in range(L):
+        lo = expand_optical_properties(lods[iz], FT)
+        tau, varpi = lo.tau, lo.varpi
+        if np.max(tau * varpi) > 2 * eps(FT):
+            dtau, nd = get_dtau_ndoubl(tau, varpi, qp, FT, model.numerics)
+            elemental(pol, tau_sum_all[:, iz].astype(FT), dtau, F0, varpi, lo.Zpp, lo.Zmp, m, nd, qp, added, FT)
+            j = thermal_source(pol, qp, dtau, varpi, B_layer[iz], FT) if iz < B_layer.shape[0] else np.zeros((S, N), dtype=FT)
+            added.j0_p[...] = j
+            added.j0_m[...] = j
+            doubling(pol, np.ones(S, dtype=FT), nd, added, FT)
+        else:
+            zero_added_noscat(added, tau, qp, FT)
+            added.j0_p[...] = 0
+            added.j0_m[...] = 0
+        if iz == 0:
+            copy_added_to_composite(comp, added)
+        else:
+            interaction(ifaces[iz], comp, added, FT)
+    if np.ndim(model.albedo) == 1:
+        create_surface_layer_lambertian_spectral(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
+    else:
+        create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
+    added_surf.j0_p[...] = 0          # no solar beam in this slot (surface emission is a separate source type)
+    added_surf.j0_m[...] = 0
+    interaction(ifaces[-1], comp, added_surf, FT)
+    postprocessing_vza(pol, comp, model.vza, model.vaz, qp, m, weight, R_th, T_th)
+    return R_th, T_th
+
+
+# ----------------------------------------------------------------------------
 # model builders used by the golden tests and the synthetic benchmarks
 # ----------------------------------------------------------------------------
 

@@ -1,0 +1,99 @@
+"""Thermal-emission source slot on the device (vsm_thermal_source + the per-source slot pass of rt_run) against the oracle and
+the reference's own physics checks (test/test_thermal_emission.jl T-A1, T-A6, T-A7)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import vsm_oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsm():
+    import vsmartmom_jl_amd as v
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    v._lib.lib()
+    return v
+
+
+@pytest.fixture(scope="module")
+def arch(vsm):
+    return vsm.Architectures.GPU()
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _models(vsm, arch, sza, tau_abs, sources, pol="IQUV", S=3, L=4, albedo=0.1, FT=np.float64, m_max=2):
+    tau_rayl = np.tile(np.array([0.02, 0.05, 0.1, 0.2])[:L], (S, 1))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=np.full((S, L), tau_abs) * (1 + 0.3 * np.arange(S))[:, None], depol=0.03, albedo=albedo,
+              m_max=m_max)
+    om = O.build_model(pol, 9, sza, [0.0, 35.0], [0.0, 60.0], FT=FT, **kw)
+    pm = vsm.host_model.model_from_arrays(arch, pol, 9, sza, [0.0, 35.0], [0.0, 60.0], float_type=FT, sources=sources, **kw)
+    return om, pm
+
+
+@pytest.mark.parametrize("FT", [np.float64, np.float32])
+def test_thermal_source_operator(vsm, arch, FT):
+    """vsm_thermal_source_* == contribute!(::PreparedThermalEmission) (thermal_emission.jl:241-301; T-A1)."""
+    CR = vsm.CoreRT
+    pol = vsm.host_model.polarization_type("IQU")
+    qp = vsm.host_model.rt_set_streams(5, 30.0, [10.0], pol, FT)
+    opol, oqp = O.polarization("IQU"), O.rt_set_streams_gausslegquad(5, 30.0, [10.0], O.polarization("IQU"), FT)
+    dq = CR.device_quad(qp, pol, arch, FT)
+    S, N = 4, qp.Nquad * 3
+    varpi, dtau, B = np.array([0.0, 0.2, 0.5, 0.8]), np.array([0.1, 0.5, 1.0, 2.0]), np.array([10.0, 20.0, 30.0, 40.0])
+    added = CR.make_added_layer(FT, arch, (N, N), S)
+    added.j0_p.fill_(7.0)
+    conv = vsm.Architectures.array_type(arch)
+    q, a = dq.cstruct(), added.cstruct()
+    t = [conv(x.astype(FT)) for x in (dtau, varpi, B)]
+    vsm._lib.call("vsm_thermal_source", added.dtype, C.byref(q), S, CR._ptr(t[0]), CR._ptr(t[1]), CR._ptr(t[2]), C.byref(a),
+                  CR._stream_ptr())
+    ref = O.thermal_source(opol, oqp, dtau.astype(FT), varpi.astype(FT), B.astype(FT), FT)
+    tol = 1e-14 if FT == np.float64 else 1e-6
+    assert _rel(vsm.Architectures.to_host(added.j0_p), ref) < tol and _rel(vsm.Architectures.to_host(added.j0_m), ref) < tol
+    assert np.all(vsm.Architectures.to_host(added.j0_p)[:, 1::3] == 0)
+
+
+@pytest.mark.parametrize("pol", ["I", "IQUV"])
+def test_rt_run_thermal_slot_vs_oracle(vsm, arch, pol):
+    """rt_run(model; sources = ThermalEmission) and sources = SolarBeam + ThermalEmission against the oracle's slot pass."""
+    H = vsm.host_model
+    B = 0.1 + 0.01 * np.arange(4)[:, None] * np.array([1.0, 2.0, 3.0])[None, :]
+    om, pm = _models(vsm, arch, 30.0, 0.05, (H.ThermalEmission(B_layer=B),), pol=pol)
+    Rt, Tt = O.rt_run_thermal(om, B)
+    R, T = vsm.CoreRT.rt_run(pm)
+    assert np.max(np.abs(Rt[:, 0])) > 0
+    # without a SolarBeam the solar slot runs with F0 = 0; like the reference's, the Lambertian surface layer still carries its
+    # beam term (lambertian_surface.jl:67-73 uses pol_type.I0, not F0), so the thermal-only total over a reflecting surface is
+    # "solar slot at F0 = 0" + thermal slot
+    om0 = O.build_model(pol, 9, 30.0, [0.0, 35.0], [0.0, 60.0], tau_rayl=om.tau_rayl, tau_abs=om.tau_abs, depol=0.03, albedo=om.albedo,
+                        m_max=om.m_max)
+    om0.F0 = np.zeros((om.pol.n, om.tau_rayl.shape[0]))
+    R0, T0 = O.rt_run(om0)
+    assert _rel(R, R0 + Rt) < 1e-9 and _rel(T, T0 + Tt) < 1e-9
+    _, pm2 = _models(vsm, arch, 30.0, 0.05, (H.SolarBeam(), H.ThermalEmission(B_layer=B)), pol=pol)
+    Rs, Ts = O.rt_run(om)
+    R2, T2 = vsm.CoreRT.rt_run(pm2)
+    assert _rel(R2, Rs + Rt) < 1e-9 and _rel(T2, Ts + Tt) < 1e-9
+
+
+def test_thermal_is_independent_of_sza_and_opaque_column_is_a_blackbody(vsm, arch):
+    """T-A6: the emergent thermal radiance does not depend on the SZA (rel. 1e-6); T-A7: an opaque isothermal column emits
+    B(T) (R / B = 1, atol 1e-3) for m_max = 0, 1, 2 (test_thermal_emission.jl:267-400)."""
+    H = vsm.host_model
+    B = 0.1 + 0.01 * np.arange(4)[:, None] * np.ones((1, 3))
+    R30, _ = vsm.CoreRT.rt_run(_models(vsm, arch, 30.0, 0.05, (H.ThermalEmission(B_layer=B),), albedo=0.0)[1])
+    R60, _ = vsm.CoreRT.rt_run(_models(vsm, arch, 60.0, 0.05, (H.ThermalEmission(B_layer=B),), albedo=0.0)[1])
+    assert np.max(np.abs(R30[:, 0])) > 0 and np.max(np.abs(R30 - R60)) / np.max(np.abs(R30)) < 1e-6
+    nu = np.array([800.0, 1000.0, 1200.0])
+    for m_max in (0, 1, 2):
+        src = (H.ThermalEmission(T_layers=[250.0] * 4, nu=nu),)
+        R, _ = vsm.CoreRT.rt_run(_models(vsm, arch, 30.0, 100.0, src, albedo=0.0, m_max=m_max)[1])
+        assert np.allclose(R[0, 0, :] / H.planck_spectrum_wn(250.0, nu), 1.0, atol=1e-3), m_max

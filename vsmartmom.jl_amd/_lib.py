@@ -96,6 +96,7 @@ _SIGS = {
     "vsm_elemental_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
     "vsm_doubling_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "vsm_noscat_layer_{T}": (_I, [_P, _I, _P, _P, _P]),
+    "vsm_thermal_source_{T}": (_I, [_P, _I, _P, _P, _P, _P, _P]),
     "vsm_copy_added_to_composite_{T}": (_I, [_I, _I, _P, _P, _P]),
     "vsm_interaction_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "vsm_interaction_oplevel_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),

@@ -514,6 +514,21 @@ class Scene:
         if F0 is None:
             F0 = np.zeros((pol.n, S_full))
             F0[0, :] = 1.0
+        # sources (rt_run(model; sources = ...)): the solar slot lives inside the layer kernels (F0), every other source
+        # has a slot of its own (here: :thermal)
+        srcs = tuple(model.sources) if model.sources is not None else (H.SolarBeam(),)
+        unknown = [s_ for s_ in srcs if not isinstance(s_, (H.SolarBeam, H.ThermalEmission))]
+        if unknown:
+            raise _lib.VSMError("rt_run: unsupported source %r (SolarBeam, ThermalEmission)" % (unknown[0],))
+        if not any(isinstance(s_, H.SolarBeam) for s_ in srcs):
+            F0 = np.zeros((pol.n, S_full))
+        th = [s_ for s_ in srcs if isinstance(s_, H.ThermalEmission) and s_.B_layer is not None and np.any(s_.B_layer != 0)]
+        self.thermal_B = None
+        if th:
+            B = th[0].B_layer
+            if B.shape[1] != S_full:
+                raise _lib.VSMError("ThermalEmission: B_layer has %d spectral points, the model %d" % (B.shape[1], S_full))
+            self.thermal_B = conv(np.ascontiguousarray(B[:, self.sl].astype(FT)))          # (rows, S)
         self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, self.sl].T))  # [n,S] col-major == (S,n)
         N, S, L, C_ = self.N, self.S, self.Nz, 1 + len(model.aerosol_optics)
         # device state of the optics pass (full spectral axis; layout [nSpec, Nz] column-major == tensors (Nz, nSpec))
@@ -686,10 +701,53 @@ class Scene:
                                   self.hdr_J, self.hdr, self.bhr_uw, self.bhr_dw)
             postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
                                 self.T_SFI)
+            if m == 0 and self.thermal_B is not None:
+                self._thermal_slot(mom, float(weight))
         if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
             apply_ss_correction_(self.R_SFI, model.surface, pol, model.vza, model.vaz, self.qp.mu0,
                                  self.moments[-1]["tau_sum_surface"], model.m_max, self.arch, FT)
         return self.R_SFI, self.T_SFI
+
+    def _thermal_slot(self, mom, weight):
+        """The `:thermal` per-source slot (rt_kernel.jl:205-232, doubling.jl:62-81, interaction.jl per-source recurrences,
+        postprocessing_vza.jl:68-82): the solar slot's linear source recurrences driven by the thermal source
+        (vsm_thermal_source between elemental! and doubling!, the slot's own expk = 1), m = 0 only; its J0 is added to
+        R_SFI / T_SFI.  Operator level, on an AddedLayer / CompositeLayer of its own (r, t, R, T evolve exactly like the solar
+        pass's).  A non-scattering layer contributes no thermal source (the reference's contribute! sits in the scatter branch)
+        and the slot is zeroed there (the reference leaves the previous layer's doubled slot in place)."""
+        model, pol, FT = self.model, self.pol, self.FT
+        N, S = self.N, self.S
+        if getattr(self, "_th_added", None) is None:
+            self._th_added = make_added_layer(FT, self.arch, (N, N), S, d_symmetric=0)
+            self._th_surf = make_added_layer(FT, self.arch, (N, N), S, shared=not self.spectral_surface)
+            self._th_comp = make_composite_layer(FT, self.arch, (N, N), S)
+            self._th_F0 = torch.zeros_like(self.F0)
+            self._th_ones = torch.ones(max(S, 1), dtype=self.dt, device=self.dev)
+        added, comp = self._th_added, self._th_comp
+        q = self.dq.cstruct()
+        for iz, ly in enumerate(mom["layers"]):
+            props = ly["props"]
+            if props.max_tau_varpi > 2 * np.finfo(FT).eps:
+                elemental_(pol, ly["tau_sum"], ly["dtau"], self._th_F0, props.materialize(), 0, ly["nd"], self.dq, added)
+                if iz < self.thermal_B.shape[0]:
+                    a = added.cstruct()
+                    _lib.call("vsm_thermal_source", self.dt, C.byref(q), S, _ptr(ly["dtau"]), _ptr(props.varpi),
+                              _ptr(self.thermal_B[iz]), C.byref(a), _stream_ptr())
+                self._th_ones.fill_(1.0)             # doubling! squares the slot's expk in place (1 stays 1)
+                doubling_(pol, self._th_ones, ly["nd"], added)
+            else:
+                zero_added_noscat_(added, props.tau, self.dq)
+                added.j0_p.zero_()
+                added.j0_m.zero_()
+            if iz == 0:
+                copy_added_to_composite_(comp, added)
+            else:
+                interaction_(ly["iface"], comp, added, oplevel=True, work=self.work)
+        create_surface_layer_(model.surface, self._th_surf, 0, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
+        self._th_surf.j0_p.zero_()      # no solar beam in this slot (surface emission is a separate source type)
+        self._th_surf.j0_m.zero_()
+        interaction_(mom["iface_surface"], comp, self._th_surf, oplevel=True, work=self.work)
+        postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, 0, weight, self.R_SFI, self.T_SFI)
 
     def run_graph(self):
         """`run()` replayed from a HIP graph: the launch sequence of a scene (per moment: one launch per layer, surface,

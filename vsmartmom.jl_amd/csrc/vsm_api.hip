@@ -323,6 +323,20 @@ int vsm_doubling_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const 
   return doubling<float>(N, n_stokes, S, ndoubl, expk, cvt_added<float>(added), work, as_stream(stream));
 }
 
+int vsm_thermal_source_f64(const vsm_quad_f64* q, int S, const double* dtau, const double* varpi, const double* B,
+                           const vsm_added_f64* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(S >= 0 && (S == 0 || (dtau && varpi && B)), "thermal_source: null input");
+  return thermal_source<double>(cvt_quad<double>(q), S, dtau, varpi, B, cvt_added<double>(added), as_stream(stream));
+}
+int vsm_thermal_source_f32(const vsm_quad_f32* q, int S, const float* dtau, const float* varpi, const float* B,
+                           const vsm_added_f32* added, void* stream) {
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_added(added))) return rc;
+  VSM_REQUIRE(S >= 0 && (S == 0 || (dtau && varpi && B)), "thermal_source: null input");
+  return thermal_source<float>(cvt_quad<float>(q), S, dtau, varpi, B, cvt_added<float>(added), as_stream(stream));
+}
 int vsm_noscat_layer_f64(const vsm_quad_f64* q, int S, const double* tau, const vsm_added_f64* added, void* stream) {
   int rc;
   VSM_REQUIRE(added && added->d_symmetric == 0, "vsm_noscat_layer_f64: d_symmetric layers are not accepted here");

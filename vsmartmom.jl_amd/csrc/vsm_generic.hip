@@ -382,6 +382,31 @@ int noscat_layer(const quad<T>& q, int S, const T* tau, const added<T>& a, hipSt
   return VSM_OK;
 }
 
+// contribute!(::PreparedThermalEmission, ...) (Sources/thermal_emission.jl:241-301): the `:thermal` source slot of an elemental
+// layer, j0+ = j0- = 2 pi (1 - varpi) B (1 - exp(-dtau / mu_i)) on the Stokes-I rows, zero elsewhere.  One thread per (row, point).
+template <typename T>
+__global__ void k_thermal_source(int N, int ns, int S, const T* __restrict__ dtau, const T* __restrict__ varpi,
+                                 const T* __restrict__ B, const T* __restrict__ mu, T* j0_p, T* j0_m) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)N * S) return;
+  const int i = (int)(e % N);
+  const long long s = e / N;
+  T v = T(0);
+  if (i % ns == 0 && mu[i] > num<T>::eps())
+    v = T(6.283185307179586476925286766559) * (T(1) - varpi[s]) * B[s] * (-expm1(-dtau[s] / mu[i]));
+  j0_p[e] = v;
+  j0_m[e] = v;
+}
+template <typename T>
+int thermal_source(const quad<T>& q, int S, const T* dtau, const T* varpi, const T* B, const added<T>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const long long n = (long long)q.N * S;
+  hipLaunchKernelGGL(k_thermal_source<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, q.N, q.n_stokes, S, dtau, varpi, B,
+                     q.mu, a.j0_p, a.j0_m);
+  VSM_LAUNCH_CHECK("k_thermal_source");
+  return VSM_OK;
+}
+
 // dst = D src D  (r+- from r-+, t-- from t++; doubling.jl:178-201)
 template <typename T>
 __global__ void k_copy_dsym(int N, int ns, const T* __restrict__ src, long long ss, T* dst) {
@@ -594,6 +619,7 @@ int postprocess_vza(int N, int n_stokes, int S, int nV, const int* row0_h, const
                             long long, const added<T>&, hipStream_t);                                                  \
   template int doubling<T>(int, int, int, int, T*, const added<T>&, T*, hipStream_t);                                  \
   template int noscat_layer<T>(const quad<T>&, int, const T*, const added<T>&, hipStream_t);                           \
+  template int thermal_source<T>(const quad<T>&, int, const T*, const T*, const T*, const added<T>&, hipStream_t);      \
   template int copy_added_to_composite<T>(int, int, const added<T>&, const composite<T>&, hipStream_t);                \
   template int interaction_generic<T>(int, int, int, const composite<T>&, const added<T>&, T*, hipStream_t);           \
   template int lambertian_surface<T>(const quad<T>&, int, int, T, const T*, const added<T>&, hipStream_t);             \

@@ -43,6 +43,8 @@ int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a,
 template <typename T>
 int noscat_layer(const quad<T>& q, int S, const T* tau, const added<T>& a, hipStream_t st);
 template <typename T>
+int thermal_source(const quad<T>& q, int S, const T* dtau, const T* varpi, const T* B, const added<T>& a, hipStream_t st);
+template <typename T>
 int copy_added_to_composite(int N, int S, const added<T>& a, const composite<T>& c, hipStream_t st);
 template <typename T>
 int interaction_generic(int iface, int N, int S, const composite<T>& c, const added<T>& a, T* work, hipStream_t st);

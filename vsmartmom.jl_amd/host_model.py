@@ -418,6 +418,26 @@ class RTNumericalParameters:
     dtau_min_floor: Optional[float] = None
 
 
+def planck_spectrum_wn(T: float, nu) -> np.ndarray:
+    """src/SolarModel/SolarModel.jl:26-35: Planck radiance [mW / (m^2 sr cm^-1)] on a wavenumber grid [cm^-1]."""
+    nu = np.asarray(nu, dtype=np.float64)
+    return 1.1910427e-5 * nu ** 3 / (np.exp(1.4387752 * nu / T) - 1.0)
+
+
+class SolarBeam:
+    """The default source (Sources/solar_beam.jl): the SFI solar slot of the layer kernels."""
+
+
+class ThermalEmission:
+    """ThermalEmission (Sources/thermal_emission.jl): per-layer Planck volume source.  `ThermalEmission(B_layer=B)` with
+    B [Nz, nSpec], or `ThermalEmission(T_layers, nu)` which evaluates planck_spectrum_wn per layer."""
+
+    def __init__(self, T_layers=None, nu=None, B_layer=None):
+        if B_layer is None and T_layers is not None:
+            B_layer = np.stack([planck_spectrum_wn(float(T), nu) for T in T_layers])
+        self.B_layer = None if B_layer is None else np.atleast_2d(np.asarray(B_layer, dtype=np.float64))
+
+
 @dataclass
 class RTModel:
     """The fields of the reference's RTModel that rt_run consumes on this path (one band)."""
@@ -439,6 +459,7 @@ class RTModel:
     numerics: RTNumericalParameters = field(default_factory=RTNumericalParameters)
     F0: Optional[np.ndarray] = None   # [nStokes, S]; None = SolarBeam default e1
     surface: Optional[object] = None  # LambertianSurfaceScalar | CoxMunkSurface; None = LambertianSurfaceScalar(albedo)
+    sources: Optional[Sequence] = None   # None = (SolarBeam(),); e.g. (ThermalEmission(...),) or (SolarBeam(), ThermalEmission(...))
 
     def __post_init__(self):
         if self.surface is None:
@@ -449,7 +470,7 @@ class RTModel:
 
 def model_from_arrays(architecture, polarization: str, l_trunc: int, sza: float, vza, vaz, tau_rayl, tau_abs=None,
                       tau_aer=None, aerosol_optics=(), depol=0.0, albedo=0.0, m_max=2, float_type=np.float64,
-                      numerics=None, surface=None) -> RTModel:
+                      numerics=None, surface=None, sources=None) -> RTModel:
     """Build the RTModel subset directly from optical-depth arrays -- what the reference's tests
     do after model_from_parameters by overwriting model.τ_rayl/τ_abs/τ_aer
     (e.g. test/vlidort_baseline/cases/case_B_solar_tester.jl:62-74)."""
@@ -462,7 +483,7 @@ def model_from_arrays(architecture, polarization: str, l_trunc: int, sza: float,
                else np.atleast_2d(np.asarray(tau_aer, dtype=np.float64)))
     return RTModel(architecture, pol, qp, float(sza), np.asarray(vza, float), np.asarray(vaz, float), tau_rayl,
                    tau_abs, tau_aer, list(aerosol_optics), get_greek_rayleigh(depol), float(albedo), int(m_max),
-                   float_type, 1.0, numerics or RTNumericalParameters(), None, surface)
+                   float_type, 1.0, numerics or RTNumericalParameters(), None, surface, sources)
 
 
 def constructCoreOpticalProperties(model: RTModel, m: int) -> List[CoreScatteringOpticalProperties]:
