@@ -387,3 +387,21 @@ def test_host_aerosol_jacobian_optics_equal_the_oracle_chain():
         for x, y in zip(a, b):
             for u, v in ((x.tau_dot, y.tau_dot), (x.varpi_dot, y.varpi_dot), (x.Zpp_dot, y.Zpp_dot), (x.Zmp_dot, y.Zmp_dot)):
                 assert np.max(np.abs(u - v)) <= 1e-12 * max(np.max(np.abs(v)), 1e-30), m
+
+
+def test_land_brdf_surfaces_host_equals_oracle_and_yaml_parses():
+    """host_model.brdf_reflectance (rpvSurfaceScalar / RossLiSurfaceScalar Fourier blocks) against the oracle's restatement, and
+    the surface constructors of config/vegetation_rpv.yaml / vegetation_rossli.yaml through parse_surface."""
+    import vsmartmom_jl_amd as vsm
+    from oracle import vsm_oracle_brdf as OB
+    H, io = vsm.host_model, vsm.io_yaml
+    s1, s2 = io.parse_surface("rpvSurfaceScalar(0.12, 0.08, 0.75, -0.25)"), io.parse_surface("RossLiSurfaceScalar(0.05, 0.03, 0.10)")
+    assert (s1.rho0, s1.rho_c, s1.k, s1.Theta) == (0.12, 0.08, 0.75, -0.25) and (s2.fvol, s2.fgeo, s2.fiso) == (0.05, 0.03, 0.10)
+    mu = np.array([0.05, 0.3, 0.5, 0.7660444431189781, 0.95, 1.0])
+    for hs, osf in ((s1, OB.RPVSurface(0.12, 0.08, 0.75, -0.25)), (s2, OB.RossLiSurface(0.05, 0.03, 0.10))):
+        for m in (0, 1, 4, 9):
+            for ns in (1, 3):
+                a, b = H.brdf_reflectance(hs, ns, mu, m), OB.reflectance(osf, ns, mu, m)
+                assert np.max(np.abs(a - b)) <= 1e-13 * np.max(np.abs(b)), (type(hs).__name__, m, ns)
+    with pytest.raises(NotImplementedError):
+        io.parse_surface("CanopySurface(1.0)")

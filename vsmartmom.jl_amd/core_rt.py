@@ -332,9 +332,17 @@ def _coxmunk_cstruct(surf: H.CoxMunkSurface, dtype):
                int(bool(surf.shadowing)))
 
 
-def reflectance(surf: H.CoxMunkSurface, dq: DeviceQuad, m: int, arch, FT, deriv: bool = False):
-    """reflectance(surf, pol_type, qp_mu, m) / reflectance_and_deriv (coxmunk_surface.jl:381-460) on the device.
-    Returns layout tensors (N, N) [column-major rho[N,N]]; drho/dU is None unless deriv."""
+BRDF_SURFACES = (H.CoxMunkSurface, H.rpvSurfaceScalar, H.RossLiSurfaceScalar)
+
+
+def reflectance(surf, dq: DeviceQuad, m: int, arch, FT, deriv: bool = False):
+    """reflectance(surf, pol_type, qp_mu, m) / reflectance_and_deriv (coxmunk_surface.jl:381-460) on the device; for the
+    kernel-driven land BRDFs (rpvSurfaceScalar, RossLiSurfaceScalar: rpv_surface.jl:160-190) the block is a per-moment scene
+    constant evaluated on the host and uploaded.  Returns layout tensors (N, N) [column-major rho[N,N]]; drho/dU is None unless deriv."""
+    if isinstance(surf, (H.rpvSurfaceScalar, H.RossLiSurfaceScalar)):
+        if deriv:
+            raise _lib.VSMError("%s has no linearization (types.jl:472-512)" % type(surf).__name__)
+        return to_device_matrix(H.brdf_reflectance(surf, dq.n_stokes, dq.host.qp_mu.astype(np.float64), m), arch, FT)[0].contiguous(), None
     N = int(dq.mu.numel())
     rho = torch.empty((N, N), dtype=dq.dtype, device=dq.mu.device)
     drho = torch.empty_like(rho) if deriv else None
@@ -367,13 +375,14 @@ def create_surface_layer_(surface, added_surface: AddedLayer, m: int, dq: Device
         _lib.call("vsm_lambertian_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, alb, _ptr(tau_sum),
                   C.byref(a), _stream_ptr())
         return
-    if isinstance(surface, H.CoxMunkSurface):
+    if isinstance(surface, BRDF_SURFACES):
         if rho is None:
             rho, _ = reflectance(surface, dq, m, arch, FT)
         _lib.call("vsm_brdf_surface", added_surface.dtype, C.byref(q), added_surface.nSpec, m, _ptr(rho), _ptr(tau_sum),
                   C.byref(a), _stream_ptr())
         return
-    raise _lib.VSMError("surface %r is not built in this backend (LambertianSurfaceScalar / Legendre / Spline, CoxMunkSurface)"
+    raise _lib.VSMError("surface %r is not built in this backend (LambertianSurfaceScalar / Legendre / Spline, CoxMunkSurface, "
+                        "rpvSurfaceScalar, RossLiSurfaceScalar)"
                         % (surface,))
 
 
@@ -633,7 +642,7 @@ class Scene:
                 layers.append(dict(props=props, iface=tags[iz], nd=nds[iz], dtau=self.dtau[iz, lo:hi],
                                    tau_sum=self.tau_sum[iz, lo:hi]))
             rho = self.albedo_d
-            if isinstance(model.surface, H.CoxMunkSurface):   # scene constant like Z(m): one N x N block per moment
+            if isinstance(model.surface, BRDF_SURFACES):   # scene constant like Z(m): one N x N block per moment
                 rho, _ = reflectance(model.surface, self.dq, m, self.arch, FT)
             self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, tau_sum_surface=self.tau_sum[L, lo:hi]))
         all11 = all(t == "11" for t in tags)

@@ -382,6 +382,60 @@ _WATER_K = (
 )
 
 
+@dataclass
+class rpvSurfaceScalar:
+    """rpvSurfaceScalar (types.jl:482-491): Rahman-Pinty-Verstraete BRDF, scalar (I -> I) only."""
+    rho0: float
+    rho_c: float
+    k: float
+    Theta: float
+
+
+@dataclass
+class RossLiSurfaceScalar:
+    """RossLiSurfaceScalar (types.jl:505-512): f_vol K_RossThick + f_geo K_LiSparse + f_iso, scalar only."""
+    fvol: float
+    fgeo: float
+    fiso: float
+
+
+def brdf_reflectance(surface, n_stokes: int, mu: np.ndarray, m: int, nquad: int = 100) -> np.ndarray:
+    """reflectance(brdf, pol_type, mu, m) (Surfaces/rpv_surface.jl:160-190) for the kernel-driven land BRDFs
+    (rpv_surface.jl:99-150, rossli_surface.jl:12-98): the Fourier block [N, N] = ff / pi * int_0^pi rho(mu_i, mu_j, x) cos(m x) dx on
+    the I -> I elements, ff = 1 (m = 0) or 2 -- a scene constant per moment like Z(m), evaluated on the host (N^2 x 100 values)
+    and uploaded once; create_surface_layer! (vsm_brdf_surface) doubles the m = 0 block."""
+    mu = np.asarray(mu, dtype=np.float64)
+    x, w = np.polynomial.legendre.leggauss(nquad)
+    phi = (0.5 * math.pi * (x + 1.0))[:, None, None]
+    wphi = 0.5 * math.pi * w
+    mi, mr = mu[None, :, None], mu[None, None, :]
+    si, sr = np.sqrt(1.0 - mi ** 2), np.sqrt(1.0 - mr ** 2)
+    ti, tr = si / mi, sr / mr                                       # tan(theta)
+    if isinstance(surface, rpvSurfaceScalar):
+        cosg = -mi * mr + si * sr * np.cos(phi)
+        G = np.sqrt(ti ** 2 + tr ** 2 + 2.0 * ti * tr * np.cos(phi))
+        th = -surface.Theta
+        rho = (surface.rho0 * (mi * mr) ** (surface.k - 1.0) / (mi + mr) ** (1.0 - surface.k)
+               * (1.0 - th ** 2) / (1.0 + th ** 2 + 2.0 * th * cosg) ** 1.5 * (1.0 + (1.0 - surface.rho_c) / (1.0 + G)))
+    elif isinstance(surface, RossLiSurfaceScalar):
+        cd, sd = np.cos(math.pi - phi), np.sin(math.pi - phi)
+        cxi = np.clip(mi * mr + si * sr * cd, -1.0, 1.0)
+        xi = np.arccos(cxi)
+        K_vol = ((0.5 * math.pi - xi) * cxi + np.sin(xi)) / (mi + mr) - 0.25 * math.pi
+        sec = 1.0 / mi + 1.0 / mr                                    # b/r = 1: primed angles == angles
+        D2 = np.maximum(ti ** 2 + tr ** 2 - 2.0 * ti * tr * cd, 0.0)
+        t = np.arccos(np.clip(2.0 * np.sqrt(D2 + (ti * tr * sd) ** 2) / sec, -1.0, 1.0))      # h/b = 2
+        K_geo = (t - np.sin(t) * np.cos(t)) * sec / math.pi - sec + 0.5 * (1.0 + cxi) / (mi * mr)
+        rho = surface.fiso + surface.fvol * K_vol + surface.fgeo * K_geo
+    else:
+        raise TypeError("brdf_reflectance: %r" % (surface,))
+    block = np.tensordot(wphi * np.cos(m * phi[:, 0, 0]), rho, axes=(0, 0)) / math.pi
+    N = len(mu) * n_stokes
+    R = np.zeros((N, N))
+    R[0::n_stokes, 0::n_stokes] = block
+    return (1.0 if m == 0 else 2.0) * R
+
+
 def water_refractive_index(lam_nm: float) -> complex:
     """water_refraction.jl:61-102: n linear, k log-linear in log(wavelength); clamped outside 200-2600 nm."""
     lg = [math.log(x) for x in _WATER_NM]

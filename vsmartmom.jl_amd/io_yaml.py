@@ -130,7 +130,8 @@ def _complex(v: str) -> complex:
 
 def parse_surface(s: str):
     """`parse_surface` (src/IO/Parameters.jl:145-156,327-372): a constructor call string, without eval.
-    Built here: LambertianSurfaceScalar(albedo), CoxMunkSurface(U) / CoxMunkSurface(wind_speed=U, n_water=, whitecap_albedo=,
+    Built here: LambertianSurfaceScalar(albedo), rpvSurfaceScalar(rho0, rho_c, k, Theta), RossLiSurfaceScalar(fvol, fgeo, fiso),
+    CoxMunkSurface(U) / CoxMunkSurface(wind_speed=U, n_water=, whitecap_albedo=,
     include_whitecaps=, shadowing=)."""
     m = re.fullmatch(r"(\w+)(?:\{\w+\})?\((.*)\)", str(s).strip())
     if not m:
@@ -159,8 +160,16 @@ def parse_surface(s: str):
         if len(args) != 1:
             raise ValueError("CoxMunkSurface expects 1 argument (wind_speed)")
         return H.CoxMunkSurface(wind_speed=_num(args[0]))
-    raise NotImplementedError("surface %r: LambertianSurfaceScalar / LambertianSurfaceLegendre and CoxMunkSurface are built in "
-                              "this backend" % s)
+    if name == "rpvSurfaceScalar":
+        if len(args) != 4 or kw:
+            raise ValueError("rpvSurfaceScalar expects 4 arguments (rho0, rho_c, k, Theta)")
+        return H.rpvSurfaceScalar(*[_num(a) for a in args])
+    if name == "RossLiSurfaceScalar":
+        if len(args) != 3 or kw:
+            raise ValueError("RossLiSurfaceScalar expects 3 arguments (fvol, fgeo, fiso)")
+        return H.RossLiSurfaceScalar(*[_num(a) for a in args])
+    raise NotImplementedError("surface %r: LambertianSurfaceScalar / LambertianSurfaceLegendre, CoxMunkSurface, rpvSurfaceScalar and "
+                              "RossLiSurfaceScalar are built in this backend" % s)
 
 
 def _surface_albedo(s: str) -> float:
@@ -216,7 +225,8 @@ def model_from_parameters(params: vSmartMOM_Parameters, architecture, iBand: int
     # user_l_cap (>= 5 here, so it never binds for Rayleigh + Lambertian).
     surface = params.brdf[iBand - 1]
     user_l_cap = min(2 * params.nstreams - 1, params.max_m - 1, params.l_trunc)
-    m_max = min(max(2, user_l_cap if isinstance(surface, H.CoxMunkSurface) else 0), user_l_cap)
+    brdf = isinstance(surface, (H.CoxMunkSurface, H.rpvSurfaceScalar, H.RossLiSurfaceScalar))   # component_m_max.jl:72-74
+    m_max = min(max(2, user_l_cap if brdf else 0), user_l_cap)
     alb = surface.albedo if isinstance(surface, H.LambertianSurfaceScalar) else 0.0
     if isinstance(surface, H.LambertianSurfaceLegendre) and len(surface.legendre_coeff) < 2:
         raise ValueError("LambertianSurfaceLegendre needs at least two coefficients")
