@@ -124,7 +124,23 @@ function rt_kernel!(RS::noRS{FT}, pol_type, SFI, a::AddedLayer{FT}, c::Composite
            τ_sum, m, qp, I_static, arch, qp_μN, iz; workspace, dτ_max_threshold, dτ_min_floor)
 end
 
+# contribute!(::PreparedThermalEmission, ...) (Sources/thermal_emission.jl:241-301): the :thermal slot of the elemental layer
+function CoreRT.contribute!(prep::CoreRT.PreparedThermalEmission, a::AddedLayer{FT}, ϖ::ROCArray, dτ::ROCArray, iz::Integer, m::Integer,
+                            pol_type, qp::QuadPoints, arch) where {FT<:FTs}
+    (m == 0 && iz <= size(prep.B_layer, 1) && haskey(a.j₀_by_src, :thermal)) || return nothing
+    slot = a.j₀_by_src[:thermal]
+    th = VsmAdded(_p(a.r⁻⁺), _p(a.t⁺⁺), _p(a.r⁺⁻), _p(a.t⁻⁻), _p(slot.j₀⁺), _p(slot.j₀⁻), _ms(a.r⁻⁺), 0, 0)   # the slot's vectors
+    _call(_fn("vsm_thermal_source", FT), (Ref{VsmQuad{FT}}, Cint, PV, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(dτ),
+          _p(dτ), _p(ϖ), _p(ROCArray(prep.B_layer[iz, :])), th, _stream())
+end
+
 # ---- surfaces + post-processing ------------------------------------------------------------------------------------------
+# any BRDF surface (rpv_surface.jl:51-97): its Fourier block comes from the reference's own reflectance(brdf, pol_type, μ, m)
+function create_surface_layer!(brdf::CoreRT.AbstractSurfaceType, a::AddedLayer{FT}, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
+    ρ = ROCArray(FT.(CoreRT.reflectance(brdf, pol_type, collect(qp.qp_μ), m)))
+    _call(_fn("vsm_brdf_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(τ_sum), m,
+          _p(ρ), _p(τ_sum), _c(a), _stream())
+end
 function create_surface_layer!(s::LambertianSurfaceScalar{FT}, a::AddedLayer, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
     _call(_fn("vsm_lambertian_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, FT, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT),
           length(τ_sum), m, s.albedo, _p(τ_sum), _c(a), _stream())
