@@ -454,10 +454,21 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   }
   __syncthreads();
   VSM_STAMP(14);
+#ifdef VSM_IA_NO_Z
   G.zero();
   mm_ab<KS>(G, P, H, p);
   sstrip Rpm;
   load_strip(Rpm, P, p);                  // R+- strip from its A-form (no second global read)
+#else
+  // R+- = r+- + (T21 R+-) t-- is evaluated as r+- + T21 (R+- t--):  Z = R+- t-- shares the fragments of [R+-] with G2 - I = R+- H,
+  // the last two products share those of [T21]; neither [T21 R+-] nor the R+- strip goes through LDS (one barrier, one A-form
+  // store and one strip read-back less); t-- = D t++ D is formed in place (t_s is not needed as t++ any more: [t++] is in Q)
+  sstrip Z;
+  if (ns) dsym_strip(t_s, t_s, ns, p); else load_strip_global_c8(t_s, t_mm, N, p, xw);
+  G.zero();
+  Z.zero();
+  mm_ab2<KS>(G, Z, P, H, t_s, p);
+#endif
   if (own_wave) {
     double* zd = laneB ? vz : sm.vec[7];
 #pragma unroll
@@ -483,6 +494,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   store_strip(P, X, p, keepN);            // [T21] -> P
   __syncthreads();
   VSM_STAMP(15);
+#ifdef VSM_IA_NO_Z
   // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; tmp = T21 R+- ----------------------------------
   {
     sstrip acc1, acc2;
@@ -499,8 +511,6 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     acc2.zero();
     mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);   // (Rpm: strip of R+-, read back from its A-form before that was overwritten)
     store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
-    // ---- R+- = r+- + tmp t-- ;  both results are stored at the very end: loads and stores retire through one in-order
-    // counter, so anything fetched after a store (here: the spilled strips of the added layer) would wait for it
     sstrip tmm, acc;
     if (ns) {
       dsym_strip(tmm, t_s, ns, p);
@@ -524,6 +534,34 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     }
     store_strip_global_c8(R_pm, acc, N, p, xw);
   }
+#else
+  // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; R+- = r+- + T21 Z ------------------------------------
+  {
+    sstrip acc1;
+    load_strip_global_c8(Tpp, T_pp, N, p, xw);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
+    }
+    if (ns) dsym_strip(r_s, r_s, ns, p); else load_strip_global_c8(r_s, r_pm, N, p, xw);   // r_s <- r+-
+    acc1.zero();
+    mm_ab2<KS>(acc1, r_s, P, Tpp, Z, p);
+    VSM_STAMP(16);
+    store_strip_global_c8(T_pp, acc1, N, p, xw);
+    if (laneA) {
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          if (row < N) J0_p[row] = vjp[row] + acc1.v[ta][r];
+        }
+    }
+    store_strip_global_c8(R_pm, r_s, N, p, xw);
+  }
+#endif
   VSM_STAMP(17);
 }
 
