@@ -306,6 +306,10 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
   VSM_LAUNCH_CHECK("k_ekl_init");
   int n0 = 0;
   if constexpr (std::is_same<T, double>::value) {
+    // one active parameter: all steps in one launch (state stays on the chip between the steps)
+    rc = strip_doubling_lin_multi(N, S, P, ndoubl, expk, ekl, a, al, st);
+    if (rc == VSM_OK) n0 = ndoubl;
+    else if (rc != VSM_ERR_UNSUPPORTED) return rc;
     // fused column-strip step (vsm_striplin.hip): one launch per doubling step, forward + all active parameters
     for (; n0 < ndoubl; ++n0) {
       rc = strip_doubling_lin_step(N, S, P, expk, ekl, a, al, st);

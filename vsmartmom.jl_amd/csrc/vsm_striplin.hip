@@ -320,6 +320,183 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
 }
 
 // ---------------------------------------------------------------------------
+// ALL ndoubl doubling steps of a layer in ONE launch, for ONE active parameter (the common case: one gas column; the surface
+// slot is not doubled).  Same arithmetic and statement order as k_dbl_lin_step, but the state stays on the chip between the
+// steps: [r] lives in BR and [rdot] in BX (rewritten at the end of a step), t and tdot live as strips in registers (their
+// A-form buffers are overwritten within a step: BT by tt, BY by the series scratch / Y), the source vectors in LDS, expk / ekl
+// in registers.  Per step that removes the staging of four matrices, two strip loads and four strip stores through global
+// memory (the per-step kernel spends ~30 % of its time there) and seven of eight launches.
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, double* __restrict__ expk, double* __restrict__ ekl,
+                                                          added<double> a, added_lin<double> al) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  lsmem& sm = *reinterpret_cast<lsmem*>(smem_raw);
+  double* BR = sm.BR;
+  double* BT = sm.BT;
+  double* BX = sm.BX;
+  double* BY = sm.BY;
+  double* jp = sm.vec[0];
+  double* jm = sm.vec[1];
+  double* ajp = sm.vec[2];
+  double* ajm = sm.vec[3];
+  spos p;
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const long long NN = (long long)N * N;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const spare sp(p, Kend);
+  double* xw = sm.xw[p.wave];
+  double k = expk[s], kl = ekl[s];
+  double* g_r = a.r_mp + (long long)s * NN;
+  double* g_t = a.t_pp + (long long)s * NN;
+  double* g_ar = al.ap_r_mp + (long long)s * NN;
+  double* g_at = al.ap_t_pp + (long long)s * NN;
+  auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
+  // a strip with its two spare columns cleared (they carry riders during a product)
+  auto clean = [&](sstrip& x) { sp.put(x, p, [](int, double) { return 0.0; }, [](int, double) { return 0.0; }); };
+  // the riders of a result strip go back to the LDS vectors (only the wave that owns the spare columns touches them)
+  auto take = [&](const sstrip& x, double* dA, double* dB) {
+    if (sp.AB) {
+      double* d = sp.A ? dA : dB;
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          if (row < N) d[row] = x.v[ta][r];
+        }
+    }
+  };
+
+  stage_aform_full2(BR, g_r, BX, g_ar, N, p);
+  if (tid < SNP) {
+    jp[tid] = (tid < N) ? a.j0_p[(long long)s * N + tid] : 0.0;
+    jm[tid] = (tid < N) ? a.j0_m[(long long)s * N + tid] : 0.0;
+    ajp[tid] = (tid < N) ? al.ap_J0_p[(long long)s * N + tid] : 0.0;
+    ajm[tid] = (tid < N) ? al.ap_J0_m[(long long)s * N + tid] : 0.0;
+  }
+  sstrip t_s, td_s, r_new, rd_new;
+  load_strip_global_c(t_s, g_t, N, p, xw);
+  load_strip_global_c(td_s, g_at, N, p, xw);
+  int slot = 0;
+  for (int n = 0; n < nd; ++n) {
+    // on entry: BR = [r], BX = [rdot] stored (visible after the barrier below), t_s / td_s clean strips, vectors in LDS
+    store_strip(BT, t_s, p, keepN);
+    __syncthreads();
+    auto load_r_with_riders = [&](sstrip& x) {
+      load_strip(x, BR, p);
+      sp.put(x, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
+    };
+    sstrip G, rt;
+    {
+      sstrip E, r_s;
+      load_strip(r_s, BR, p);
+      E.zero();
+      mm_ab<KS>(E, BR, r_s, p);
+      invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+    }
+    sp.put(t_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
+    {
+      sstrip tt;
+      tt.zero();
+      mm_ab<KS>(tt, BT, G, p);
+      rt.zero();
+      mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
+      __syncthreads();             // BT (t) and BY (series powers) no longer read
+      store_strip(BT, tt, p, keepN);
+      store_strip(BY, td_s, p, keepN);   // [tdot] -> BY
+    }
+    sp.put(rt, p, [&](int row, double o) { return jm[row] * k + o; }, [&](int row, double o) { return jp[row] + o; });
+    __syncthreads();   // tt complete in BT, tdot in BY
+    // ---- the parameter -----------------------------------------------------------------------------------------------------
+    sstrip X1, Q2;
+    X1.zero();
+    Q2.zero();
+    {
+      sstrip r_s;
+      load_r_with_riders(r_s);
+      mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
+    }
+    sstrip rd;
+    load_strip(rd, BX, p);                    // rdot's strip (kept: BX is overwritten by ttdot below)
+    {
+      sstrip rdr = rd;
+      sp.put(rdr, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl; });
+      mm_ab2<KS>(X1, Q2, BR, rdr, td_s, p);   // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
+    }
+    if (sp.own) {   // v = aJ1- + rdot j0+ + r aJ+ ; u = aJ+ + rdot j1- + r aJ1-   -> spare columns of Q2
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          const double x = X1.v[ta][r];
+          const double v = ajm[row] * k + jm[row] * kl + x, u = ajp[row] + x;
+          Q2.v[ta][r] = sp.A ? v : (sp.B ? u : Q2.v[ta][r]);
+        }
+    }
+    {
+      sstrip Y = td_s;
+      mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
+      __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
+      store_strip(BY, Y, p, keepN);
+    }
+    __syncthreads();   // Y complete in BY
+    {
+      sstrip ttl;
+      ttl.zero();
+      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+      store_strip(BX, ttl, p, keepN);
+    }
+    sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl; });
+    sstrip tdn;
+    tdn.zero();
+    __syncthreads();   // ttdot complete in BX
+    mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);      // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
+    mm_ab2<KS>(rd, tdn, BT, Q2, td_s, p);     // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
+    // forward update: r' = r + tt rt (+ tt A, tt B on top of j0-, j1+) ; t' = tt t   (reads BR, BT, the OLD forward vectors)
+    sstrip r_s;
+    load_strip(r_s, BR, p);
+    sp.put(r_s, p, [&](int row, double) { return jm[row]; }, [&](int row, double) { return jp[row] * k; });
+    sstrip tn;
+    tn.zero();
+    mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
+    // new vectors (the owning wave is the only reader and writer of the vectors), then the riders are cleared
+    take(rd, ajm, ajp);
+    take(r_s, jm, jp);
+    clean(rd);
+    clean(tdn);
+    clean(r_s);
+    clean(tn);
+    td_s = tdn;
+    t_s = tn;
+    rd_new = rd;
+    r_new = r_s;
+    kl = 2.0 * k * kl;
+    k = k * k;
+    __syncthreads();   // everybody is done reading BR, BT, BX, BY of this step
+    if (n + 1 < nd) {
+      store_strip(BR, r_new, p, keepN);
+      store_strip(BX, rd_new, p, keepN);
+    }
+  }
+  store_strip_global_c(g_r, r_new, N, p, xw);
+  store_strip_global_c(g_t, t_s, N, p, xw);
+  store_strip_global_c(g_ar, rd_new, N, p, xw);
+  store_strip_global_c(g_at, td_s, N, p, xw);
+  if (tid < N) {   // (the vectors were last written by the owning wave before the final barrier of the loop)
+    a.j0_p[(long long)s * N + tid] = jp[tid];
+    a.j0_m[(long long)s * N + tid] = jm[tid];
+    al.ap_J0_p[(long long)s * N + tid] = ajp[tid];
+    al.ap_J0_m[(long long)s * N + tid] = ajm[tid];
+  }
+  if (tid == 0) {
+    expk[s] = k;
+    ekl[s] = kl;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Linearized interaction, ScatteringInterface_11 (interaction_lin.jl:217-331): each of its two halves has the shape of
 // the doubling step above,
 //     G = (I - LA ER)^-1 ; tt = LT G ; rt = LA S2 ;                    out0 = ACC0 + tt rt ; out1 = tt S3
@@ -455,7 +632,8 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
 #define VSM_CAT(a, b) VSM_CAT2(a, b)
 #define VSM_STRIPLIN_DECL(KS)                                                                                                      \
   int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t); \
-  int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);
+  int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);                                                \
+  int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIPLIN_DECL(VSM_STRIP_KS)
@@ -469,6 +647,19 @@ int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* exp
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_dbl_lin_step<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_step");
+  return VSM_OK;
+}
+
+int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int nd, double* expk, double* ekl, const added<double>& a,
+                                                 const added_lin<double>& al, hipStream_t st) {
+  static int prepared = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
+    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_dbl_lin_multi)");
+  }();
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(k_dbl_lin_multi<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+  VSM_LAUNCH_CHECK("k_dbl_lin_multi");
   return VSM_OK;
 }
 
@@ -505,6 +696,29 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
 #define VSM_CASE(KS) \
   case KS:           \
     return VSM_CAT(launch_dbl_lin_step_, KS)(N, S, P, expk, ekl, a, al, st);
+    VSM_CASE(9)
+    VSM_CASE(10)
+    VSM_CASE(11)
+    VSM_CASE(12)
+    VSM_CASE(13)
+    VSM_CASE(14)
+    VSM_CASE(15)
+#undef VSM_CASE
+    default:
+      return VSM_ERR_UNSUPPORTED;
+  }
+}
+
+// All ndoubl doubling steps in one launch (one active parameter); VSM_ERR_UNSUPPORTED otherwise.
+int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
+                             const added_lin<double>& al, hipStream_t st) {
+  static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_LIN_MULTI") != nullptr;
+  if (off || P != 1 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+    return VSM_ERR_UNSUPPORTED;
+  switch ((N + 3) / 4) {
+#define VSM_CASE(KS) \
+  case KS:           \
+    return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, nd, expk, ekl, a, al, st);
     VSM_CASE(9)
     VSM_CASE(10)
     VSM_CASE(11)
