@@ -110,6 +110,62 @@ __device__ __forceinline__ void load_strip_global_c(sstrip& x, const double* __r
       for (int r = 0; r < 4; ++r) x.v[2 * h + t][r] = xw[p.l15 * XS + 16 * t + p.kq + 4 * r];
   }
 }
+// The same load in two halves: `issue` only requests the 16 doubles of the lane (they stay in flight while the wave goes on with
+// its MFMAs), `finish` runs them through the transposer.  With one wave per SIMD nothing else hides a global round trip.
+struct raw_strip {
+  double v[2][8];
+};
+__device__ __forceinline__ void issue_strip_load(raw_strip& w, const double* __restrict__ g, int N, const spos& p) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  const double* src = g + (long long)N * min(col, N - 1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row0 = 32 * h + 8 * q;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const int r = row0 + i;
+      if (col < N && r + 1 < N) {
+        const d2_t t = *reinterpret_cast<const d2_t*>(src + r);
+        w.v[h][i] = t.a;
+        w.v[h][i + 1] = t.b;
+      } else {
+        w.v[h][i] = (col < N && r < N) ? src[r] : 0.0;
+        w.v[h][i + 1] = 0.0;
+      }
+    }
+  }
+}
+__device__ __forceinline__ void finish_strip_load(sstrip& x, const raw_strip& w, const spos& p, double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xw[c * XS + 8 * q + i] = w.v[h][i];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x.v[2 * h + t][r] = xw[p.l15 * XS + 16 * t + p.kq + 4 * r];
+  }
+}
+// A-form staging in two halves (the lane's 16 column values: wave w takes the columns w, w + 4, ...)
+struct raw_aform {
+  double v[16];
+};
+__device__ __forceinline__ void issue_aform_load(raw_aform& w, const double* __restrict__ g, int N, const spos& p) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int j = p.wave + 4 * i;
+    w.v[i] = (p.lane < N && j < N) ? g[p.lane + (long long)N * j] : 0.0;
+  }
+}
+__device__ __forceinline__ void finish_aform_load(double* L, const raw_aform& w, const spos& p) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) L[lidx<SNP>(p.lane, p.wave + 4 * i)] = w.v[i];
+}
+
 __device__ __forceinline__ void store_strip_global_c(double* __restrict__ g, const sstrip& x, int N, const spos& p,
                                                      double* __restrict__ xw) {
   const int c = p.lane >> 2, q = p.lane & 3;
@@ -531,6 +587,123 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
   auto keep_old = [](int, double o) { return o; };
 
+#ifdef VSM_IA_LIN_ASYNC_LOADS
+  // (experiment, not the default: 580 B/lane of scratch, 9 % slower) ---- every global strip / A-form is REQUESTED a phase before it is used and transposed where it is needed -------------------
+  raw_strip w_er, w_s2;
+  issue_strip_load(w_er, h.ER + s * h.sER, N, p);
+  issue_strip_load(w_s2, h.S2 + s * h.sS2, N, p);
+  stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
+  if (tid < SNP) {
+    const long long o = (long long)s * N + tid;
+    vr[tid] = (tid < N) ? h.VR[o] : 0.0;
+    vadd[tid] = (tid < N) ? h.VADD[o] : 0.0;
+    vacc[tid] = (tid < N) ? h.VACC[o] : 0.0;
+  }
+  __syncthreads();
+  sstrip er, s2, G, rt;
+  finish_strip_load(er, w_er, p, xw);
+  finish_strip_load(s2, w_s2, p, xw);
+  raw_strip w_d1, w_d2;      // the first parameter's strips fly behind the forward products
+  raw_aform w_pa;
+  if (P > 0) {
+    issue_strip_load(w_d1, h.D1 + s * h.sD1, N, p);
+    issue_strip_load(w_d2, h.D2 + s * h.sD2, N, p);
+    issue_aform_load(w_pa, h.PA + s * h.sPA, N, p);
+  }
+  int slot = 0;
+  {
+    sstrip E;
+    E.zero();
+    mm_ab<KS>(E, BR, er, p);
+    invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+  }
+  sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
+  {
+    sstrip tt;
+    tt.zero();
+    mm_ab<KS>(tt, BT, G, p);
+    rt.zero();
+    mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
+    __syncthreads();            // BT (LT) and BY (series powers) no longer read
+    store_strip(BT, tt, p, keepN);
+  }
+  sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
+  __syncthreads();   // tt complete in BT
+
+  for (int pp = 0; pp < P; ++pp) {
+    sstrip d1, d2;
+    finish_strip_load(d1, w_d1, p, xw);
+    finish_strip_load(d2, w_d2, p, xw);
+    finish_aform_load(BX, w_pa, p);
+    raw_strip w_y, w_acc;      // needed after the four X products
+    issue_strip_load(w_y, h.YI + s * h.sYI + pp * h.pYI, N, p);
+    issue_strip_load(w_acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
+    if (tid < SNP) {
+      const long long o = (long long)pp * VS + (long long)s * N + tid;
+      vdr[tid] = (tid < N) ? h.VDR[o] : 0.0;
+      vdadd[tid] = (tid < N) ? h.VDADD[o] : 0.0;
+      vdacc[tid] = (tid < N) ? h.VDACC[o] : 0.0;
+    }
+    __syncthreads();
+    sstrip X1, X2;
+    X1.zero();
+    X2.zero();
+    mm_ab2<KS>(X1, X2, BX, er, s2, p);   // PA ER ; PA S2 (+ PA VR)
+    sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
+    mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
+    sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
+    raw_strip w_s3, w_d3;      // needed after Y and ttdot
+    issue_strip_load(w_s3, h.S3 + s * h.sS3, N, p);
+    issue_strip_load(w_d3, h.D3 + s * h.sD3 + pp * h.pD3, N, p);
+    {
+      sstrip Y;
+      finish_strip_load(Y, w_y, p, xw);
+      mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
+      store_strip(BY, Y, p, keepN);
+    }
+    sstrip acc;
+    finish_strip_load(acc, w_acc, p, xw);
+    __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
+    {
+      sstrip ttl;
+      ttl.zero();
+      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+      store_strip(BX, ttl, p, keepN);
+    }
+    sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
+    sstrip tdn, s3;
+    tdn.zero();
+    finish_strip_load(s3, w_s3, p, xw);
+    if (pp + 1 < P) {          // the next parameter's strips fly behind the last four products
+      issue_strip_load(w_d1, h.D1 + s * h.sD1 + (pp + 1) * h.pD1, N, p);
+      issue_strip_load(w_d2, h.D2 + s * h.sD2 + (pp + 1) * h.pD2, N, p);
+      issue_aform_load(w_pa, h.PA + s * h.sPA + (pp + 1) * h.pPA, N, p);
+    }
+    __syncthreads();   // ttdot complete in BX
+    mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
+    finish_strip_load(s3, w_d3, p, xw);
+    mm_ab2<KS>(acc, tdn, BT, X2, s3, p);   // + tt X2 ; + tt D3
+    store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
+    store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
+    sp.get(acc, p, N, h.VDOUT + (long long)pp * VS + (long long)s * N, nullptr);
+    __syncthreads();   // BX, BY, the parameter's vectors free
+  }
+
+  sstrip acc0, tn;
+  load_strip_global_c(acc0, h.ACC0 + s * h.sACC0, N, p, xw);
+  sp.put(acc0, p, [&](int row, double) { return vacc[row]; }, keep_old);
+  tn.zero();
+  {
+    sstrip s3;
+    load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
+    mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
+  }
+  store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
+  store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
+#else
+  raw_strip w_er, w_s2;      // requested before the A-form staging: the two round trips overlap
+  issue_strip_load(w_er, h.ER + s * h.sER, N, p);
+  issue_strip_load(w_s2, h.S2 + s * h.sS2, N, p);
   if (!EXP_NO_STAGE) stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
   if (tid < SNP) {
     const long long o = (long long)s * N + tid;
@@ -540,8 +713,8 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   }
   __syncthreads();
   sstrip er, s2, G, rt;
-  if (EXP_NO_LOAD) er.zero(); else load_strip_global_c(er, h.ER + s * h.sER, N, p, xw);
-  if (EXP_NO_LOAD) s2.zero(); else load_strip_global_c(s2, h.S2 + s * h.sS2, N, p, xw);
+  finish_strip_load(er, w_er, p, xw);
+  finish_strip_load(s2, w_s2, p, xw);
   int slot = 0;
   {
     sstrip E;
@@ -623,6 +796,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   }
   if (!EXP_NO_STORE) store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
   if (!EXP_NO_STORE) store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
+#endif
   sp.get(acc0, p, N, h.VOUT + (long long)s * N, nullptr);
 }
 
