@@ -64,7 +64,7 @@ def _al_host(vsm, al):
 @pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7),
                                               ("I", 71), ("IQU", 27), ("IQUV", 25), ("IQU", 33)])   # N = 38, 48, 60, 57: fused strip step
 @pytest.mark.parametrize("ndoubl", [0, 3, -2])   # -2: two doublings of THICK layers (every inverse path of the fused step)
-@pytest.mark.parametrize("n_layer_params", [3, 1])   # 1: all doubling steps in ONE launch (k_dbl_lin_multi) for 32 < N <= 60
+@pytest.mark.parametrize("n_layer_params", [3, 1, 2])   # 1, 2: all doubling steps in ONE launch (k_dbl_lin_multi) for 32 < N <= 60
 def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl, n_layer_params):
     FT = np.float64
     thick = ndoubl < 0

@@ -376,14 +376,14 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
 }
 
 // ---------------------------------------------------------------------------
-// ALL ndoubl doubling steps of a layer in ONE launch, for ONE active parameter (the common case: one gas column; the surface
-// slot is not doubled).  Same arithmetic and statement order as k_dbl_lin_step, but the state stays on the chip between the
-// steps: [r] lives in BR and [rdot] in BX (rewritten at the end of a step), t and tdot live as strips in registers (their
-// A-form buffers are overwritten within a step: BT by tt, BY by the series scratch / Y), the source vectors in LDS, expk / ekl
+// ALL ndoubl doubling steps of a layer in ONE launch, for PA = 1 or 2 active parameters (gas columns; the surface slot is not
+// doubled).  Same arithmetic and statement order as k_dbl_lin_step, but the state stays on the chip between the
+// steps: [r] lives in BR (rewritten at the end of a step), t, rdot_p and tdot_p live as strips in registers (their A-form
+// buffers are overwritten within a step: BT by tt, BX by ttdot, BY by the series scratch / Y), the source vectors in LDS, expk / ekl
 // in registers.  Per step that removes the staging of four matrices, two strip loads and four strip stores through global
 // memory (the per-step kernel spends ~30 % of its time there) and seven of eight launches.
 // ---------------------------------------------------------------------------
-template <int KS>
+template <int KS, int PA>
 __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, double* __restrict__ expk, double* __restrict__ ekl,
                                                           added<double> a, added_lin<double> al) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -394,19 +394,16 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   double* BY = sm.BY;
   double* jp = sm.vec[0];
   double* jm = sm.vec[1];
-  double* ajp = sm.vec[2];
-  double* ajm = sm.vec[3];
   spos p;
   const int s = blockIdx.x, tid = threadIdx.x;
-  const long long NN = (long long)N * N;
+  const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int Kend = ((N + 3) >> 2) << 2;
   const spare sp(p, Kend);
   double* xw = sm.xw[p.wave];
-  double k = expk[s], kl = ekl[s];
+  double k = expk[s];
+  double kl[PA];
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
-  double* g_ar = al.ap_r_mp + (long long)s * NN;
-  double* g_at = al.ap_t_pp + (long long)s * NN;
   auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
   // a strip with its two spare columns cleared (they carry riders during a product)
   auto clean = [&](sstrip& x) { sp.put(x, p, [](int, double) { return 0.0; }, [](int, double) { return 0.0; }); };
@@ -424,19 +421,28 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
     }
   };
 
-  stage_aform_full2(BR, g_r, BX, g_ar, N, p);
+  stage_aform_full(BR, g_r, N, p);
   if (tid < SNP) {
     jp[tid] = (tid < N) ? a.j0_p[(long long)s * N + tid] : 0.0;
     jm[tid] = (tid < N) ? a.j0_m[(long long)s * N + tid] : 0.0;
-    ajp[tid] = (tid < N) ? al.ap_J0_p[(long long)s * N + tid] : 0.0;
-    ajm[tid] = (tid < N) ? al.ap_J0_m[(long long)s * N + tid] : 0.0;
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) {
+      sm.vec[2 + 2 * pp][tid] = (tid < N) ? al.ap_J0_p[pp * VS + (long long)s * N + tid] : 0.0;
+      sm.vec[3 + 2 * pp][tid] = (tid < N) ? al.ap_J0_m[pp * VS + (long long)s * N + tid] : 0.0;
+    }
   }
-  sstrip t_s, td_s, r_new, rd_new;
+  sstrip t_s, r_new;
+  sstrip rd_s[PA], td_s[PA];          // rdot_p, tdot_p: register strips between the steps
   load_strip_global_c(t_s, g_t, N, p, xw);
-  load_strip_global_c(td_s, g_at, N, p, xw);
+#pragma unroll
+  for (int pp = 0; pp < PA; ++pp) {
+    kl[pp] = ekl[s + (long long)S * pp];
+    load_strip_global_c(rd_s[pp], al.ap_r_mp + pp * MS + (long long)s * NN, N, p, xw);
+    load_strip_global_c(td_s[pp], al.ap_t_pp + pp * MS + (long long)s * NN, N, p, xw);
+  }
   int slot = 0;
   for (int n = 0; n < nd; ++n) {
-    // on entry: BR = [r], BX = [rdot] stored (visible after the barrier below), t_s / td_s clean strips, vectors in LDS
+    // on entry: BR = [r] stored (visible after the barrier below), t_s / rd_s / td_s clean strips, vectors in LDS
     store_strip(BT, t_s, p, keepN);
     __syncthreads();
     auto load_r_with_riders = [&](sstrip& x) {
@@ -460,95 +466,104 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
       mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
       __syncthreads();             // BT (t) and BY (series powers) no longer read
       store_strip(BT, tt, p, keepN);
-      store_strip(BY, td_s, p, keepN);   // [tdot] -> BY
     }
     sp.put(rt, p, [&](int row, double o) { return jm[row] * k + o; }, [&](int row, double o) { return jp[row] + o; });
-    __syncthreads();   // tt complete in BT, tdot in BY
-    // ---- the parameter -----------------------------------------------------------------------------------------------------
-    sstrip X1, Q2;
-    X1.zero();
-    Q2.zero();
-    {
-      sstrip r_s;
-      load_r_with_riders(r_s);
-      mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
-    }
-    sstrip rd;
-    load_strip(rd, BX, p);                    // rdot's strip (kept: BX is overwritten by ttdot below)
-    {
-      sstrip rdr = rd;
-      sp.put(rdr, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl; });
-      mm_ab2<KS>(X1, Q2, BR, rdr, td_s, p);   // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
-    }
-    if (sp.own) {   // v = aJ1- + rdot j0+ + r aJ+ ; u = aJ+ + rdot j1- + r aJ1-   -> spare columns of Q2
+    // ---- the parameters ----------------------------------------------------------------------------------------------------
 #pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
+    for (int pp = 0; pp < PA; ++pp) {
+      double* ajp = sm.vec[2 + 2 * pp];
+      double* ajm = sm.vec[3 + 2 * pp];
+      sstrip& rd = rd_s[pp];
+      sstrip& td = td_s[pp];
+      store_strip(BX, rd, p, keepN);   // [rdot_p] -> BX, [tdot_p] -> BY  (both free: barrier above / end of the previous parameter)
+      store_strip(BY, td, p, keepN);
+      __syncthreads();   // tt complete in BT (first parameter), rdot_p / tdot_p complete
+      sstrip X1, Q2;
+      X1.zero();
+      Q2.zero();
+      {
+        sstrip r_s;
+        load_r_with_riders(r_s);
+        mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
+      }
+      {
+        sstrip rdr = rd;
+        sp.put(rdr, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl[pp]; });
+        mm_ab2<KS>(X1, Q2, BR, rdr, td, p);    // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
+      }
+      if (sp.own) {   // v = aJ1- + rdot j0+ + r aJ+ ; u = aJ+ + rdot j1- + r aJ1-   -> spare columns of Q2
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = p.row(ta, r);
-          const double x = X1.v[ta][r];
-          const double v = ajm[row] * k + jm[row] * kl + x, u = ajp[row] + x;
-          Q2.v[ta][r] = sp.A ? v : (sp.B ? u : Q2.v[ta][r]);
-        }
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = p.row(ta, r);
+            const double x = X1.v[ta][r];
+            const double v = ajm[row] * k + jm[row] * kl[pp] + x, u = ajp[row] + x;
+            Q2.v[ta][r] = sp.A ? v : (sp.B ? u : Q2.v[ta][r]);
+          }
+      }
+      {
+        sstrip Y = td;
+        mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
+        __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
+        store_strip(BY, Y, p, keepN);
+      }
+      __syncthreads();   // Y complete in BY
+      {
+        sstrip ttl;
+        ttl.zero();
+        mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+        store_strip(BX, ttl, p, keepN);
+      }
+      sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl[pp]; });
+      sstrip tdn;
+      tdn.zero();
+      __syncthreads();   // ttdot complete in BX
+      mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);      // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
+      mm_ab2<KS>(rd, tdn, BT, Q2, td, p);       // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
+      take(rd, ajm, ajp);                       // (this parameter's vectors are not read again in this step)
+      clean(rd);
+      clean(tdn);
+      td = tdn;
+      kl[pp] = 2.0 * k * kl[pp];
+      if (pp + 1 < PA) __syncthreads();   // BX, BY free for the next parameter
     }
-    {
-      sstrip Y = td_s;
-      mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
-      __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
-      store_strip(BY, Y, p, keepN);
-    }
-    __syncthreads();   // Y complete in BY
-    {
-      sstrip ttl;
-      ttl.zero();
-      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, keepN);
-    }
-    sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl; });
-    sstrip tdn;
-    tdn.zero();
-    __syncthreads();   // ttdot complete in BX
-    mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);      // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
-    mm_ab2<KS>(rd, tdn, BT, Q2, td_s, p);     // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
-    // forward update: r' = r + tt rt (+ tt A, tt B on top of j0-, j1+) ; t' = tt t   (reads BR, BT, the OLD forward vectors)
+    // forward update: r' = r + tt rt (+ tt A, tt B on top of j0-, j1+) ; t' = tt t
     sstrip r_s;
     load_strip(r_s, BR, p);
     sp.put(r_s, p, [&](int row, double) { return jm[row]; }, [&](int row, double) { return jp[row] * k; });
     sstrip tn;
     tn.zero();
     mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
-    // new vectors (the owning wave is the only reader and writer of the vectors), then the riders are cleared
-    take(rd, ajm, ajp);
     take(r_s, jm, jp);
-    clean(rd);
-    clean(tdn);
     clean(r_s);
     clean(tn);
-    td_s = tdn;
     t_s = tn;
-    rd_new = rd;
     r_new = r_s;
-    kl = 2.0 * k * kl;
     k = k * k;
     __syncthreads();   // everybody is done reading BR, BT, BX, BY of this step
-    if (n + 1 < nd) {
-      store_strip(BR, r_new, p, keepN);
-      store_strip(BX, rd_new, p, keepN);
-    }
+    if (n + 1 < nd) store_strip(BR, r_new, p, keepN);
   }
   store_strip_global_c(g_r, r_new, N, p, xw);
   store_strip_global_c(g_t, t_s, N, p, xw);
-  store_strip_global_c(g_ar, rd_new, N, p, xw);
-  store_strip_global_c(g_at, td_s, N, p, xw);
+#pragma unroll
+  for (int pp = 0; pp < PA; ++pp) {
+    store_strip_global_c(al.ap_r_mp + pp * MS + (long long)s * NN, rd_s[pp], N, p, xw);
+    store_strip_global_c(al.ap_t_pp + pp * MS + (long long)s * NN, td_s[pp], N, p, xw);
+  }
   if (tid < N) {   // (the vectors were last written by the owning wave before the final barrier of the loop)
     a.j0_p[(long long)s * N + tid] = jp[tid];
     a.j0_m[(long long)s * N + tid] = jm[tid];
-    al.ap_J0_p[(long long)s * N + tid] = ajp[tid];
-    al.ap_J0_m[(long long)s * N + tid] = ajm[tid];
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) {
+      al.ap_J0_p[pp * VS + (long long)s * N + tid] = sm.vec[2 + 2 * pp][tid];
+      al.ap_J0_m[pp * VS + (long long)s * N + tid] = sm.vec[3 + 2 * pp][tid];
+    }
   }
   if (tid == 0) {
     expk[s] = k;
-    ekl[s] = kl;
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) ekl[s + (long long)S * pp] = kl[pp];
   }
 }
 
@@ -807,7 +822,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
 #define VSM_STRIPLIN_DECL(KS)                                                                                                      \
   int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t); \
   int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);                                                \
-  int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
+  int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIPLIN_DECL(VSM_STRIP_KS)
@@ -824,15 +839,21 @@ int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* exp
   return VSM_OK;
 }
 
-int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int nd, double* expk, double* ekl, const added<double>& a,
+int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, double* expk, double* ekl, const added<double>& a,
                                                  const added_lin<double>& al, hipStream_t st) {
   static int prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 1>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
     return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_dbl_lin_multi)");
   }();
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_dbl_lin_multi<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+  if (PA == 1)
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 1>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+  else
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 2>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_multi");
   return VSM_OK;
 }
@@ -883,16 +904,16 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
   }
 }
 
-// All ndoubl doubling steps in one launch (one active parameter); VSM_ERR_UNSUPPORTED otherwise.
+// All ndoubl doubling steps in one launch (one or two active parameters); VSM_ERR_UNSUPPORTED otherwise.
 int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st) {
   static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_LIN_MULTI") != nullptr;
-  if (off || P != 1 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+  if (off || P < 1 || P > 2 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   switch ((N + 3) / 4) {
 #define VSM_CASE(KS) \
   case KS:           \
-    return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, nd, expk, ekl, a, al, st);
+    return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, P, nd, expk, ekl, a, al, st);
     VSM_CASE(9)
     VSM_CASE(10)
     VSM_CASE(11)
