@@ -67,7 +67,7 @@ struct lsmem {
   double BT[SNP * SNP];
   double BX[SNP * SNP];
   double BY[SNP * SNP];
-  double vec[6][SNP];   // doubling: j0+, j0-, aJ+_p, aJ-_p ; interaction halves: VR, VADD, VACC, VDR, VDADD, VDACC
+  double vec[8][SNP];   // doubling: j0+, j0-, (aJ+_p, aJ-_p) x up to 3 ; interaction halves: VR, VADD, VACC, VDR, VDADD, VDACC
   float red[2][4];
   gj_scratch<double, SNP> gj;
   double xw[4][16 * 34];   // per-wave transposer of load/store_strip_global_c
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
 }
 
 // ---------------------------------------------------------------------------
-// ALL ndoubl doubling steps of a layer in ONE launch, for PA = 1 or 2 active parameters (gas columns; the surface slot is not
+// ALL ndoubl doubling steps of a layer in ONE launch, for PA = 1..3 active parameters (gas columns; the surface slot is not
 // doubled).  Same arithmetic and statement order as k_dbl_lin_step, but the state stays on the chip between the
 // steps: [r] lives in BR (rewritten at the end of a step), t, rdot_p and tdot_p live as strips in registers (their A-form
 // buffers are overwritten within a step: BT by tt, BX by ttdot, BY by the series scratch / Y), the source vectors in LDS, expk / ekl
@@ -847,13 +847,18 @@ int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, d
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
     return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_dbl_lin_multi)");
   }();
   if (prepared) return prepared;
   if (PA == 1)
     hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 1>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
-  else
+  else if (PA == 2)
     hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 2>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+  else
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 3>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_multi");
   return VSM_OK;
 }
@@ -904,11 +909,11 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
   }
 }
 
-// All ndoubl doubling steps in one launch (one or two active parameters); VSM_ERR_UNSUPPORTED otherwise.
+// All ndoubl doubling steps in one launch (one to three active parameters); VSM_ERR_UNSUPPORTED otherwise.
 int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st) {
   static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_LIN_MULTI") != nullptr;
-  if (off || P < 1 || P > 2 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+  if (off || P < 1 || P > 3 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   switch ((N + 3) / 4) {
 #define VSM_CASE(KS) \
