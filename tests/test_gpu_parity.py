@@ -920,3 +920,25 @@ def test_c4_full_size_properties_and_oracle_sample(vsm, arch):
     om = O.build_model(*geo, tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx], depol=0.0279, albedo=0.15, m_max=2)
     Ro, To = O.rt_run(om)
     assert _rel(R1[:, :, idx], Ro) < 1e-2 and _rel(T1[:, :, idx], To) < 1e-2, (_rel(R1[:, :, idx], Ro), _rel(T1[:, :, idx], To))
+
+
+def test_more_than_64_viewing_geometries(vsm, arch):
+    """postprocessing_vza! has no limit on the number of viewing geometries (tools/postprocessing_vza.jl:23-94): 150 of them
+    (10 zenith angles x 15 azimuths) through the chunked post-processing launch, forward incl. the HDRF leg and linearized."""
+    from oracle import vsm_oracle_lin as OL
+    vza = np.repeat(np.linspace(5.0, 70.0, 10), 15)
+    vaz = np.tile(np.linspace(0.0, 350.0, 15), 10)
+    rng = np.random.default_rng(3)
+    S, L = 3, 2
+    tau_rayl = np.tile(np.array([0.05, 0.15]), (S, 1))
+    ga = 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga, depol=0.03, albedo=0.3, m_max=2)
+    om, pm = _both_models(vsm, arch, "IQU", 5, 40.0, vza, vaz, **kw)
+    hd = {}
+    Ro, To = O.rt_run(om, hdrf=hd)
+    R, T, _, _, hdr, _, _ = vsm.CoreRT.rt_run(pm, full_output=True)
+    assert R.shape == (150, 3, S)
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9 and _rel(hdr, hd["hdr"]) < 1e-9
+    Rl, Tl, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, vsm.host_model.LinModel([ga]), 0, 1, 1)
+    Rlo, Tlo, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
+    assert _rel(Rl, Rlo) < 1e-9 and _rel(Rd, Rdo) < 1e-8 and _rel(Td, Tdo) < 1e-8

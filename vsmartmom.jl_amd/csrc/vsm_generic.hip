@@ -577,8 +577,9 @@ struct pp_args {
   double w[256];
 };
 template <typename T>
-__global__ void k_postprocess(int N, int n_stokes, int S, int nV, pp_args pa, const T* __restrict__ J0_m,
+__global__ void k_postprocess(int N, int n_stokes, int S, int nV, int nVtot, int v0, pp_args pa, const T* __restrict__ J0_m,
                               const T* __restrict__ J0_p, T* R, T* Tt) {
+  // one chunk of <= 64 viewing angles [v0, v0 + nV) of the nVtot of the output arrays [S][n_stokes][nVtot]
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long tot = (long long)nV * n_stokes * S;
   if (e >= tot) return;
@@ -587,24 +588,29 @@ __global__ void k_postprocess(int N, int n_stokes, int S, int nV, pp_args pa, co
   const long long s = e / ((long long)nV * n_stokes);
   const T w = (T)pa.w[v + nV * k];
   const long long src = s * N + pa.row0[v] + k;
-  R[e] += w * J0_m[src];
-  Tt[e] += w * J0_p[src];
+  const long long dst = (s * n_stokes + k) * nVtot + v0 + v;
+  R[dst] += w * J0_m[src];
+  Tt[dst] += w * J0_p[src];
 }
 template <typename T>
 int postprocess_vza(int N, int n_stokes, int S, int nV, const int* row0_h, const T* w_h, const T* J0_m, const T* J0_p,
                     T* R, T* Tt, hipStream_t st) {
-  if (nV > 64 || nV * n_stokes > 256) {
-    set_error("postprocess_vza: at most 64 viewing angles per call (got %d)", nV);
+  if (n_stokes > 4) {
+    set_error("postprocess_vza: n_stokes <= 4 (got %d)", n_stokes);
     return VSM_ERR_UNSUPPORTED;
   }
   if (S <= 0 || nV <= 0) return VSM_OK;
-  pp_args pa;
-  for (int v = 0; v < nV; ++v) pa.row0[v] = row0_h[v];
-  for (int x = 0; x < nV * n_stokes; ++x) pa.w[x] = (double)w_h[x];
-  const long long tot = (long long)nV * n_stokes * S;
-  hipLaunchKernelGGL(k_postprocess<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, n_stokes, S, nV, pa,
-                     J0_m, J0_p, R, Tt);
-  VSM_LAUNCH_CHECK("k_postprocess");
+  for (int v0 = 0; v0 < nV; v0 += 64) {   // the launch arguments carry 64 viewing angles: any number, in chunks
+    const int nc = nV - v0 < 64 ? nV - v0 : 64;
+    pp_args pa;
+    for (int v = 0; v < nc; ++v) pa.row0[v] = row0_h[v0 + v];
+    for (int k = 0; k < n_stokes; ++k)
+      for (int v = 0; v < nc; ++v) pa.w[v + nc * k] = (double)w_h[v0 + v + nV * k];
+    const long long tot = (long long)nc * n_stokes * S;
+    hipLaunchKernelGGL(k_postprocess<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, n_stokes, S, nc, nV, v0, pa,
+                       J0_m, J0_p, R, Tt);
+    VSM_LAUNCH_CHECK("k_postprocess");
+  }
   return VSM_OK;
 }
 

@@ -693,8 +693,9 @@ struct pp_args_lin {
   double w[256];
 };
 template <typename T>
-__global__ void k_postprocess_lin(int N, int ns, int S, int nV, int P, pp_args_lin pa, const T* __restrict__ Jm,
+__global__ void k_postprocess_lin(int N, int ns, int S, int nV, int nVtot, int v0, int P, pp_args_lin pa, const T* __restrict__ Jm,
                                   const T* __restrict__ Jp, T* Rd, T* Td) {
+  // one chunk of <= 64 viewing angles [v0, v0 + nV) of the nVtot of the output arrays [P][S][ns][nVtot]
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long per = (long long)nV * ns * S;
   if (e >= per * P) return;
@@ -705,24 +706,29 @@ __global__ void k_postprocess_lin(int N, int ns, int S, int nV, int P, pp_args_l
   const long long s = x / ((long long)nV * ns);
   const T w = (T)pa.w[v + nV * k];
   const long long src = (long long)N * S * p + s * N + pa.row0[v] + k;
-  Rd[e] += w * Jm[src];
-  Td[e] += w * Jp[src];
+  const long long dst = (((long long)p * S + s) * ns + k) * nVtot + v0 + v;
+  Rd[dst] += w * Jm[src];
+  Td[dst] += w * Jp[src];
 }
 template <typename T>
 int postprocess_vza_lin(int N, int ns, int S, int nV, int P, const int* row0_h, const T* w_h, const T* Jd_m,
                         const T* Jd_p, T* Rd, T* Td, hipStream_t st) {
-  if (nV > 64 || nV * ns > 256) {
-    set_error("postprocess_vza_lin: at most 64 viewing angles per call (got %d)", nV);
+  if (ns > 4) {
+    set_error("postprocess_vza_lin: n_stokes <= 4 (got %d)", ns);
     return VSM_ERR_UNSUPPORTED;
   }
   if (S <= 0 || nV <= 0 || P <= 0) return VSM_OK;
-  pp_args_lin pa;
-  for (int v = 0; v < nV; ++v) pa.row0[v] = row0_h[v];
-  for (int x = 0; x < nV * ns; ++x) pa.w[x] = (double)w_h[x];
-  const long long tot = (long long)nV * ns * S * P;
-  hipLaunchKernelGGL(k_postprocess_lin<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, ns, S, nV, P, pa,
-                     Jd_m, Jd_p, Rd, Td);
-  VSM_LAUNCH_CHECK("k_postprocess_lin");
+  for (int v0 = 0; v0 < nV; v0 += 64) {
+    const int nc = nV - v0 < 64 ? nV - v0 : 64;
+    pp_args_lin pa;
+    for (int v = 0; v < nc; ++v) pa.row0[v] = row0_h[v0 + v];
+    for (int k = 0; k < ns; ++k)
+      for (int v = 0; v < nc; ++v) pa.w[v + nc * k] = (double)w_h[v0 + v + nV * k];
+    const long long tot = (long long)nc * ns * S * P;
+    hipLaunchKernelGGL(k_postprocess_lin<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, ns, S, nc, nV, v0, P, pa,
+                       Jd_m, Jd_p, Rd, Td);
+    VSM_LAUNCH_CHECK("k_postprocess_lin");
+  }
   return VSM_OK;
 }
 

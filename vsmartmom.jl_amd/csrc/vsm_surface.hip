@@ -555,12 +555,13 @@ __global__ void __launch_bounds__(128) k_interaction_hdrf(int N, int ns, int m, 
   }
 }
 template <typename T>
-__global__ void k_postprocess_hdrf(int N, int ns, long long S, int nV, pp_args_s pa, const T* __restrict__ hdr_J, T* hdr) {
+__global__ void k_postprocess_hdrf(int N, int ns, long long S, int nV, int nVtot, int v0, pp_args_s pa, const T* __restrict__ hdr_J,
+                                   T* hdr) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
   if (e >= (long long)nV * ns * S) return;
   const int v = (int)(e % nV), k = (int)((e / nV) % ns);
   const long long s = e / ((long long)nV * ns);
-  hdr[e] += (T)pa.w[v + nV * k] * hdr_J[s * N + pa.row0[v] + k];
+  hdr[(s * ns + k) * nVtot + v0 + v] += (T)pa.w[v + nV * k] * hdr_J[s * N + pa.row0[v] + k];
 }
 template <typename T>
 int interaction_hdrf(const quad<T>& q, int S, int m, const composite<T>& c, const added<T>& a, T* hdr_J, T* bhr_uw, T* bhr_dw,
@@ -577,18 +578,22 @@ int interaction_hdrf(const quad<T>& q, int S, int m, const composite<T>& c, cons
 }
 template <typename T>
 int postprocess_vza_hdrf(int N, int ns, int S, int nV, const int* row0_h, const T* w_h, const T* hdr_J, T* hdr, hipStream_t st) {
-  if (nV > 64 || nV * ns > 256) {
-    set_error("postprocess_vza_hdrf: at most 64 viewing angles per call (got %d)", nV);
+  if (ns > 4) {
+    set_error("postprocess_vza_hdrf: n_stokes <= 4 (got %d)", ns);
     return VSM_ERR_UNSUPPORTED;
   }
   if (S <= 0 || nV <= 0) return VSM_OK;
-  pp_args_s pa;
-  for (int v = 0; v < nV; ++v) pa.row0[v] = row0_h[v];
-  for (int x = 0; x < nV * ns; ++x) pa.w[x] = (double)w_h[x];
-  const long long tot = (long long)nV * ns * S;
-  hipLaunchKernelGGL(k_postprocess_hdrf<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, ns, (long long)S, nV, pa,
-                     hdr_J, hdr);
-  VSM_LAUNCH_CHECK("k_postprocess_hdrf");
+  for (int v0 = 0; v0 < nV; v0 += 64) {
+    const int nc = nV - v0 < 64 ? nV - v0 : 64;
+    pp_args_s pa;
+    for (int v = 0; v < nc; ++v) pa.row0[v] = row0_h[v0 + v];
+    for (int k = 0; k < ns; ++k)
+      for (int v = 0; v < nc; ++v) pa.w[v + nc * k] = (double)w_h[v0 + v + nV * k];
+    const long long tot = (long long)nc * ns * S;
+    hipLaunchKernelGGL(k_postprocess_hdrf<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, ns, (long long)S, nc, nV, v0,
+                       pa, hdr_J, hdr);
+    VSM_LAUNCH_CHECK("k_postprocess_hdrf");
+  }
   return VSM_OK;
 }
 
