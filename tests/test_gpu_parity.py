@@ -942,3 +942,22 @@ def test_more_than_64_viewing_geometries(vsm, arch):
     Rl, Tl, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, vsm.host_model.LinModel([ga]), 0, 1, 1)
     Rlo, Tlo, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
     assert _rel(Rl, Rlo) < 1e-9 and _rel(Rd, Rdo) < 1e-8 and _rel(Td, Tdo) < 1e-8
+
+
+def test_more_than_65535_spectral_points_on_the_operator_level_path(vsm, arch):
+    """The reference has no nSpec limit.  70 000 points through the operator-level kernels (a non-scattering top layer gives the
+    00 / 01 interfaces, which only the operator chain implements; the spectral axis sits on gridDim.x): against the oracle."""
+    S = 70000
+    rng = np.random.default_rng(8)
+    tau_rayl = np.tile(np.array([0.0, 0.04, 0.1]), (S, 1))
+    tau_abs = np.stack([np.full(S, 0.02), 10.0 ** rng.uniform(-3, 0, S), 10.0 ** rng.uniform(-3, 0, S)], axis=1)
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.2, m_max=1)
+    om, pm = _both_models(vsm, arch, "I", 3, 35.0, [20.0], [40.0], **kw)
+    tr = []
+    R, T = vsm.CoreRT.rt_run(pm, trace=tr)
+    assert {t["iface"] for t in tr} >= {"00", "01", "11"}
+    idx = np.r_[0:40, 65530:65560, S - 40:S]
+    oms = O.build_model("I", 3, 35.0, [20.0], [40.0], tau_rayl=tau_rayl[idx], tau_abs=tau_abs[idx], depol=0.03, albedo=0.2, m_max=1)
+    Ro, To = O.rt_run(oms)
+    assert _rel(R[:, :, idx], Ro) < 1e-9 and _rel(T[:, :, idx], To) < 1e-9
+    assert np.all(np.isfinite(R)) and np.all(R[0, 0] > 0)

@@ -17,9 +17,9 @@ void set_error(const char* fmt, ...) {
 }
 int hip_fail(hipError_t e, const char* what) {
   if (e == hipErrorInvalidConfiguration || e == hipErrorInvalidValue) {
-    // the operator-level, linearized and Raman kernels index the spectral axis with gridDim.y (HIP limit 65535)
-    set_error("HIP error %d (%s) in %s -- if nSpec > 65535 on an operator-level path (non-\"11\" interfaces, N above the fused "
-              "limits, linearized / Raman passes), split the spectral batch", (int)e, hipGetErrorString(e), what);
+    // only the Raman kernels still index the spectral axis with gridDim.y (HIP limit 65535; they check it themselves)
+    set_error("HIP error %d (%s) in %s -- invalid launch configuration (Raman passes: nSpec and nRaman <= 65535)", (int)e,
+              hipGetErrorString(e), what);
     return VSM_ERR_UNSUPPORTED;
   }
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);

@@ -23,10 +23,10 @@ __global__ __launch_bounds__(256) void k_gemm(int M, int Nc, int K, const T* __r
   B += (long long)blockIdx.z * pb;
   C += (long long)blockIdx.z * pc;
   if (D) D += (long long)blockIdx.z * pd;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;   // (spectral axis on gridDim.x: no 65535 limit)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tilesM = (M + 15) >> 4, tilesN = (Nc + 15) >> 4;
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = blockIdx.y * 4 + wave;
   if (tile >= tilesM * tilesN) return;  // wave-uniform
   const int ti = tile % tilesM, tj = tile / tilesM;
   const T* As = A + (long long)s * sa;
@@ -65,7 +65,7 @@ int gemm(int M, int Nc, int K, int S, const T* A, long long sa, const T* B, long
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
   const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
-  dim3 grid((tiles + 3) / 4, S);
+  dim3 grid(S, (tiles + 3) / 4);
   hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, 0LL,
                      0LL, 0LL, 0LL);
   VSM_LAUNCH_CHECK("k_gemm");
@@ -82,7 +82,7 @@ int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long lon
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
   const int tiles = ((M + 15) / 16) * ((Nc + 15) / 16);
-  dim3 grid((tiles + 3) / 4, S, P);
+  dim3 grid(S, (tiles + 3) / 4, P);
   hipLaunchKernelGGL(k_gemm<T>, grid, dim3(256), 0, st, M, Nc, K, A, sa, B, sb, C, sc, alpha, D, sd, beta, gamma, pa,
                      pb, pc, pd);
   VSM_LAUNCH_CHECK("k_gemm(P)");
@@ -97,9 +97,9 @@ int gemm2(int M, int Nc, int K, int S, int P, const T* A, long long sa, long lon
 template <typename T>
 __global__ void k_mix_Z(long long NN, int ncomp, const T* __restrict__ Zc_pp, const T* __restrict__ Zc_mp,
                         const T* __restrict__ fcomp, T* Zpp, T* Zmp) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long e = (long long)blockIdx.y * 256 + threadIdx.x;
   if (e >= NN) return;
-  const long long s = blockIdx.y;
+  const long long s = blockIdx.x;
   T ap = 0, am = 0;
   for (int k = 0; k < ncomp; ++k) {
     const T f = fcomp[s * ncomp + k];
@@ -113,7 +113,7 @@ template <typename T>
 int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T* fcomp, T* Zpp, T* Zmp, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   const long long NN = (long long)N * N;
-  hipLaunchKernelGGL(k_mix_Z<T>, dim3((unsigned)((NN + 255) / 256), S), dim3(256), 0, st, NN, ncomp, Zpp_comp, Zmp_comp, fcomp,
+  hipLaunchKernelGGL(k_mix_Z<T>, dim3(S, (unsigned)((NN + 255) / 256)), dim3(256), 0, st, NN, ncomp, Zpp_comp, Zmp_comp, fcomp,
                      Zpp, Zmp);
   VSM_LAUNCH_CHECK("k_mix_Z");
   return VSM_OK;
@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256) void k_elemental(int N, int n_stokes, int m, i
                                                    const T* __restrict__ varpi, const T* __restrict__ Zpp,
                                                    const T* __restrict__ Zmp, long long zs, const T* __restrict__ mu,
                                                    const T* __restrict__ wt, T* r_mp, T* t_pp, T* r_pm, T* t_mm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const int i = e % N, j = e / N;
   const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
   const T mi = mu[i], mj = mu[j];
@@ -254,7 +254,7 @@ int elemental(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T
               const T* F0, const T* Zpp, const T* Zmp, long long zs, const added<T>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   const int N = q.N;
-  hipLaunchKernelGGL(k_elemental<T>, dim3((N * N + 255) / 256, S), dim3(256), 0, st, N, q.n_stokes, m, ndoubl, dtau,
+  hipLaunchKernelGGL(k_elemental<T>, dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, m, ndoubl, dtau,
                      varpi, Zpp, Zmp, zs, q.mu, q.wt, a.r_mp, a.t_pp, a.r_pm, a.t_mm);
   VSM_LAUNCH_CHECK("k_elemental");
   hipLaunchKernelGGL(k_elemental_sfi<T>, dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
@@ -283,15 +283,15 @@ __global__ void k_square(int S, T* x) {
 // dst[N*N*S] <- src with slice stride ss (0 = broadcast one matrix)
 template <typename T>
 __global__ void k_copy_strided(long long per, int S, const T* __restrict__ src, long long ss, T* dst) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long e = (long long)blockIdx.y * 256 + threadIdx.x;
   if (e >= per) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   dst[(long long)s * per + e] = src[(long long)s * ss + e];
 }
 template <typename T>
 int copy_strided(long long per, int S, const T* src, long long ss, T* dst, hipStream_t st) {
   if (S <= 0 || per <= 0) return VSM_OK;
-  hipLaunchKernelGGL(k_copy_strided<T>, dim3((unsigned)((per + 255) / 256), S), dim3(256), 0, st, per, S, src, ss, dst);
+  hipLaunchKernelGGL(k_copy_strided<T>, dim3(S, (unsigned)((per + 255) / 256)), dim3(256), 0, st, per, S, src, ss, dst);
   VSM_LAUNCH_CHECK("k_copy_strided");
   return VSM_OK;
 }
@@ -299,9 +299,9 @@ int copy_strided(long long per, int S, const T* src, long long ss, T* dst, hipSt
 // apply_D! + apply_D_SFI! after doubling (doubling.jl:178-252)
 template <typename T>
 __global__ void k_apply_D(int N, int n_stokes, T* r_mp, const T* __restrict__ t_pp, T* r_pm, T* t_mm, T* j0_m) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const int i = e % N, j = e / N;
   const long long o = (long long)s * N * N + e;
   T r = r_mp[o];
@@ -348,7 +348,7 @@ int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a,
     hipLaunchKernelGGL(k_square<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
     VSM_LAUNCH_CHECK("k_square");
   }
-  hipLaunchKernelGGL(k_apply_D<T>, dim3((unsigned)((NN + 255) / 256), S), dim3(256), 0, st, N, n_stokes, a.r_mp, a.t_pp,
+  hipLaunchKernelGGL(k_apply_D<T>, dim3(S, (unsigned)((NN + 255) / 256)), dim3(256), 0, st, N, n_stokes, a.r_mp, a.t_pp,
                      a.r_pm, a.t_mm, a.j0_m);
   VSM_LAUNCH_CHECK("k_apply_D");
   return VSM_OK;
@@ -360,9 +360,9 @@ int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a,
 template <typename T>
 __global__ void k_noscat(int N, const T* __restrict__ tau, const T* __restrict__ mu, T* r_mp, T* r_pm, T* t_pp,
                          T* t_mm, T* j0_m) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const int i = e % N, j = e / N;
   const long long o = (long long)s * N * N + e;
   const T t = (i == j) ? exp(-tau[s] / mu[i]) : T(0);
@@ -376,7 +376,7 @@ template <typename T>
 int noscat_layer(const quad<T>& q, int S, const T* tau, const added<T>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   const int N = q.N;
-  hipLaunchKernelGGL(k_noscat<T>, dim3((N * N + 255) / 256, S), dim3(256), 0, st, N, tau, q.mu, a.r_mp, a.r_pm, a.t_pp,
+  hipLaunchKernelGGL(k_noscat<T>, dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, tau, q.mu, a.r_mp, a.r_pm, a.t_pp,
                      a.t_mm, a.j0_m);
   VSM_LAUNCH_CHECK("k_noscat");
   return VSM_OK;
@@ -410,9 +410,9 @@ int thermal_source(const quad<T>& q, int S, const T* dtau, const T* varpi, const
 // dst = D src D  (r+- from r-+, t-- from t++; doubling.jl:178-201)
 template <typename T>
 __global__ void k_copy_dsym(int N, int ns, const T* __restrict__ src, long long ss, T* dst) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const T x = src[(long long)s * ss + e];
   dst[(long long)s * N * N + e] = (is_uv_row(e % N, ns) == is_uv_row(e / N, ns)) ? x : -x;
 }
@@ -424,7 +424,7 @@ int copy_added_to_composite(int N, int S, const added<T>& a, const composite<T>&
   if ((rc = copy_strided<T>(NN, S, a.r_mp, a.mat_stride, c.R_mp, st))) return rc;
   if (a.d_symmetric) {
     if (S > 0) {
-      dim3 grid((unsigned)((NN + 255) / 256), S);
+      dim3 grid(S, (unsigned)((NN + 255) / 256));
       hipLaunchKernelGGL(k_copy_dsym<T>, grid, dim3(256), 0, st, N, a.d_symmetric, a.t_pp, a.mat_stride, c.T_mm);
       hipLaunchKernelGGL(k_copy_dsym<T>, grid, dim3(256), 0, st, N, a.d_symmetric, a.r_mp, a.mat_stride, c.R_pm);
       VSM_LAUNCH_CHECK("k_copy_dsym");

@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
                                                        const T* __restrict__ mu, const T* __restrict__ wt, T* r_mp,
                                                        T* t_pp, T* r_pm, T* t_mm, T* ap_r_mp, T* ap_t_pp, T* ap_r_pm,
                                                        T* ap_t_mm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const int i = e % N, j = e / N;
   const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
   const T mi = mu[i], mj = mu[j];
@@ -181,7 +181,7 @@ int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, con
   VSM_HIP(hipMemsetAsync(al.ap_t_mm, 0, mb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_p, 0, vb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_m, 0, vb, st));
-  hipLaunchKernelGGL(k_elemental_lin<T>, dim3((N * N + 255) / 256, S), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+  hipLaunchKernelGGL(k_elemental_lin<T>, dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
                      p_layer, dtau, varpi, Zpp, Zmp, zs, dtau_dot, varpi_dot, Zpp_dot, Zmp_dot, zds, zdp, q.mu, q.wt,
                      a.r_mp, a.t_pp, a.r_pm, a.t_mm, al.ap_r_mp, al.ap_t_pp, al.ap_r_pm, al.ap_t_mm);
   VSM_LAUNCH_CHECK("k_elemental_lin");
@@ -234,9 +234,9 @@ __global__ void k_square_lin(int S, T* x) {
 template <typename T>
 __global__ void k_apply_D_lin(int N, int ns, int S, int P, T* r_mp, const T* __restrict__ t_pp, T* r_pm, T* t_mm,
                               T* j0_m, T* ar, const T* __restrict__ at, T* arpm, T* atmm, T* aJm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
-  const int s = blockIdx.y;
+  const int s = blockIdx.x;
   const int i = e % N, j = e / N;
   const long long o = (long long)s * N * N + e;
   const bool ui = is_uv_row(i, ns), uj = is_uv_row(j, ns);
@@ -370,7 +370,7 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
     if ((rc = copy_strided<T>(MS, 1, W3, 0, a.t_pp, st))) return rc;
   }
 #undef MM
-  hipLaunchKernelGGL(k_apply_D_lin<T>, dim3((unsigned)((NN + 255) / 256), S), dim3(256), 0, st, N, ns, S, Pall, a.r_mp,
+  hipLaunchKernelGGL(k_apply_D_lin<T>, dim3(S, (unsigned)((NN + 255) / 256)), dim3(256), 0, st, N, ns, S, Pall, a.r_mp,
                      a.t_pp, a.r_pm, a.t_mm, a.j0_m, al.ap_r_mp, al.ap_t_pp, al.ap_r_pm, al.ap_t_mm, al.ap_J0_m);
   VSM_LAUNCH_CHECK("k_apply_D_lin");
   return VSM_OK;
