@@ -12,6 +12,7 @@
 // and skips pairs whose donor is out of band, so the launch count of a layer step does not depend on
 // the number of Raman lines.  Inelastic arrays are [N,N,S,K] column-major like the reference's.
 #include "vsm_internal.h"
+#include <type_traits>
 
 namespace vsm {
 
@@ -350,8 +351,13 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
     G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
     G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
     // ---- inelastic recurrences of this step (they read the OLD elastic r, t, J0+, expk) -------------------------------
-    rc = raman_doubling_lines<T>(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk, ie.ier_mp,
-                                 ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);   // N <= 30: one LDS-resident launch for all lines
+    rc = VSM_ERR_UNSUPPORTED;
+    if constexpr (std::is_same<T, double>::value)   // FP64, N <= 30: one wave per line, operands in registers
+      rc = raman_doubling_wave(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk, ie.ier_mp,
+                               ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);
+    if (rc == VSM_ERR_UNSUPPORTED)
+      rc = raman_doubling_lines<T>(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk,
+                                   ie.ier_mp, ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);   // N <= 30: one workgroup per point
     if (rc == VSM_ERR_UNSUPPORTED) {
       // operator-level chain: one launch per batched operator over all (n1, dn) pairs
       // ieJ1+- = ieJ0+- expk[n0]
