@@ -167,6 +167,7 @@ struct rs_ia_pass {
 template <typename T>
 int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st);
 // one wave per Raman line (vsm_raman_wave.hip): FP64, N <= 30
+int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,

@@ -308,6 +308,16 @@ __global__ void k_apply_D_batch(int N, int ns, T* r_mp, const T* __restrict__ t_
   if (j == 0 && ui) j0_m[b * N + i] = -j0_m[b * N + i];
 }
 
+// all lines of a recipient point in one workgroup (N <= 30): FP64 one wave per line, else one tile per wave
+template <typename T>
+static int raman_ia_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st) {
+  if constexpr (std::is_same<T, double>::value) {
+    const int rc = raman_interaction_wave(N, S, K, shift, h, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
+  return raman_interaction_lines<T>(N, S, K, shift, h, st);
+}
+
 template <typename T>
 static size_t doubling_rs_work_elems(int N, int S, int K) {
   const size_t NN = (size_t)N * N;
@@ -461,7 +471,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
     h.E3 = c.T_pp; h.sE3 = NN; h.I3 = cie.ieT_pp; h.ACCA = cie.ieR_mp; h.GX = gA; h.I4 = aie.iet_mm; h.GY = gB;
     h.OUTA = cie.ieR_mp; h.OUTB = cie.ieT_mm;
     h.VE0 = c.J0_p; h.VADD = aie.ieJ0_m; h.VI1 = cie.ieJ0_p; h.VACC = cie.ieJ0_m; h.VV = v; h.VOUT = cie.ieJ0_m;
-    rc = raman_interaction_lines<T>(N, S, K, shift, h, st);   // every line of a recipient point in one workgroup (N <= 30)
+    rc = raman_ia_lines<T>(N, S, K, shift, h, st);   // every line of a recipient point in one workgroup (N <= 30)
     if (rc == VSM_OK) fused1 = true;
     else if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
@@ -501,7 +511,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
     h.E3 = a.t_mm; h.sE3 = as; h.I3 = aie.iet_mm; h.ACCA = aie.ier_pm; h.GX = gB; h.I4 = cie.ieT_pp; h.GY = gA;
     h.OUTA = cie.ieR_pm; h.OUTB = cie.ieT_pp;
     h.VE0 = a.j0_m; h.VADD = cie.ieJ0_p; h.VI1 = aie.ieJ0_m; h.VACC = aie.ieJ0_p; h.VV = v; h.VOUT = cie.ieJ0_p;
-    rc = raman_interaction_lines<T>(N, S, K, shift, h, st);
+    rc = raman_ia_lines<T>(N, S, K, shift, h, st);   // every line of a recipient point in one workgroup (N <= 30)
     if (rc == VSM_OK) fused2 = true;
     else if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }

@@ -1,4 +1,4 @@
-// Rotational-Raman doubling, inelastic part of one doubling step -- ONE WAVE PER RAMAN LINE (FP64, N <= 30).
+// Rotational-Raman inelastic doubling step and interaction pass -- ONE WAVE PER RAMAN LINE (FP64, N <= 24).
 //
 // doubling_inelastic.jl:62-123 (the two `for dn` loops of doubling_helper!(::RRS, ...)).  Per (recipient point n1,
 // line dn; donor n0 = n1 + shift[dn]) the step is ten 32 x 32 x Kend products plus eight mat-vecs:
@@ -6,23 +6,56 @@
 //     iet' = ttg1 W1 + iet gt0            ier' = ier + iet grt0 + ttg1 W3          (+ the source recurrences, riding in
 //                                                                                     the spare columns N, N+1)
 // k_raman_doubling_lines (vsm_fused.hip) gives the four 16 x 16 output tiles of each product to four waves and needs
-// ten workgroup barriers per line around 6-MFMA bursts: measured 31 % of the FP64 MFMA rate.  Here a wave owns a whole
-// line: right operands and every intermediate live in registers in the accumulator layout (the FP64 MFMA's B operand
-// layout IS its accumulator layout, as in the strip kernels), left operands are wave-private k-major LDS images, and no
-// barrier is needed after the two shared images (r1, ttg1) are staged.  Four waves (one per SIMD) walk the in-band lines
-// of one recipient point round-robin; the 24 back-to-back MFMAs of a product keep the matrix pipe busy from one wave.
+// ten workgroup barriers per line around 6-MFMA bursts.  Here a wave owns a whole line: right operands and every
+// intermediate live in registers in the accumulator layout (the FP64 MFMA's B operand layout IS its accumulator layout,
+// as in the strip kernels), left operands are wave-private k-major LDS images, and no barrier is needed after the two
+// shared images (r1, ttg1) are staged.  Four waves (one per SIMD) walk the in-band lines of one recipient point
+// round-robin.
 //
-// LDS: 2 shared + 4 x 3 private images of 32 x 34 doubles = 119 KB.
+// Global <-> register traffic is flat: a block is read as a contiguous array (lane + 64 j: coalesced, NF registers),
+// written into a k-major image and read back in the accumulator layout by ds_read_b64 (gathering the accumulator layout
+// straight from global memory costs 16 instructions per block, each touching 16 cache lines).  N is a template parameter:
+// the chunk count, the image positions and the rider columns are compile-time, so the inner loop has no masks and no
+// uniform branches.  The images are zero outside N x N except for the rider columns N, N+1; stale riders are harmless
+// wherever they can appear (as columns k >= N of a left operand they meet zero rows of the right operand; as columns
+// N, N+1 of an output they are never stored), so nothing is masked.
+//
+// LDS: 2 shared + 4 x 4 private images of 32 x 34 doubles = 153 KB.
 #include "vsm_common.h"
 #include "vsm_internal.h"
+#include <type_traits>
 
 namespace vsm {
 namespace {
 
+// diagnostic per-phase cycle stamps of workgroup 0 / wave 0 (build with -DRW_PHASE_TIMING; tools/raman_phase_timing.py)
+#ifdef RW_PHASE_TIMING
+__device__ unsigned long long rw_phase_cycles[16];
+#define RW_STAMP_DECL                 \
+  unsigned long long _t_acc[16] = {}; \
+  unsigned long long _t_prev = __builtin_readcyclecounter()
+#define RW_STAMP(i)                                             \
+  do {                                                          \
+    const unsigned long long _t = __builtin_readcyclecounter(); \
+    _t_acc[i] += _t - _t_prev;                                  \
+    _t_prev = _t;                                               \
+  } while (0)
+#define RW_STAMP_FLUSH()                                                           \
+  do {                                                                             \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                       \
+      for (int _i = 0; _i < 16; ++_i) atomicAdd(&rw_phase_cycles[_i], _t_acc[_i]); \
+  } while (0)
+#else
+#define RW_STAMP_DECL
+#define RW_STAMP(i)
+#define RW_STAMP_FLUSH()
+#endif
+
 constexpr int WLD = 34;            // k-major row pitch: conflict-free ds_read_b64 for the (l15, kq) fragment pattern
 constexpr int WIMG = 32 * WLD;     // doubles per image
 constexpr int RW_WAVES = 4;
-constexpr int RW_PRIV = 3;         // private images per wave: ier -> WA, iet, X
+constexpr int RW_PRIV = 4;         // private images per wave
+constexpr int RW_MAXN = 24;
 
 struct wmat {
   d4_t v[2][2];  // [row tile][column tile]; element r of a tile: row 16 a + kq + 4 r, column 16 b + l15
@@ -40,40 +73,30 @@ __device__ __forceinline__ void w_zero(wmat& m) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) m.v[a][b] = acc_zero<double>();
 }
-// N x N column-major global block -> accumulator layout (zero outside)
-__device__ __forceinline__ void w_load(wmat& m, const double* __restrict__ g, int N, const wpos& p) {
+__device__ __forceinline__ void w_add(wmat& m, const wmat& o) {
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * a + p.kq + 4 * r, col = 16 * b + p.l15;
-        m.v[a][b][r] = (row < N && col < N) ? g[row + N * col] : 0.0;
-      }
+    for (int b = 0; b < 2; ++b) m.v[a][b] += o.v[a][b];
 }
-__device__ __forceinline__ void w_store(double* __restrict__ g, const wmat& m, int N, const wpos& p) {
+// accumulator layout -> k-major image (all 32 x 32)
+__device__ __forceinline__ void w_to_img(double* L, const wmat& m, const wpos& p) {
+  double* b0 = L + p.l15 + WLD * p.kq;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * a + p.kq + 4 * r, col = 16 * b + p.l15;
-        if (row < N && col < N) g[row + N * col] = m.v[a][b][r];
-      }
+      for (int r = 0; r < 4; ++r) b0[16 * b + WLD * (16 * a + 4 * r)] = m.v[a][b][r];
 }
-// accumulator layout -> k-major LDS image, columns >= N zeroed (the riders never enter a left operand)
-__device__ __forceinline__ void w_to_aform(double* L, const wmat& m, int N, const wpos& p) {
+__device__ __forceinline__ void w_from_img(wmat& m, const double* img, const wpos& p) {
+  const double* b0 = img + p.l15 + WLD * p.kq;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * a + p.kq + 4 * r, col = 16 * b + p.l15;
-        L[col + WLD * row] = (col < N) ? m.v[a][b][r] : 0.0;
-      }
+      for (int r = 0; r < 4; ++r) m.v[a][b][r] = b0[16 * b + WLD * (16 * a + 4 * r)];
 }
 // acc += A B : A from a k-major image, B from registers; k runs in the order the accumulator layout stores it
 template <int KS>
@@ -90,250 +113,593 @@ __device__ __forceinline__ void w_mm(wmat& acc, const double* A, const wmat& B, 
     }
   }
 }
-__device__ __forceinline__ void v_load(cvec& x, const double* __restrict__ g, int N, const wpos& p) {
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * a + p.kq + 4 * r;
-      x.x[a][r] = (row < N) ? g[row] : 0.0;
-    }
-}
-// column c of m, valid on the lanes that hold it (l15 == c & 15)
-__device__ __forceinline__ cvec w_col(const wmat& m, int c) {
+// column C of m, valid on the lanes that hold it (l15 == C & 15)
+template <int C>
+__device__ __forceinline__ cvec w_col(const wmat& m) {
   cvec x;
-  const bool hi = c >= 16;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x.x[a][r] = hi ? m.v[a][1][r] : m.v[a][0][r];
+    for (int r = 0; r < 4; ++r) x.x[a][r] = m.v[a][C >> 4][r];
   return x;
 }
-__device__ __forceinline__ void w_set_col(wmat& m, int c, const cvec& x, const wpos& p) {
-  const bool mine = p.l15 == (c & 15), hi = c >= 16;
+template <int C>
+__device__ __forceinline__ void w_set_col(wmat& m, const cvec& x, const wpos& p) {
+  const bool mine = p.l15 == (C & 15);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      m.v[a][0][r] = (mine && !hi) ? x.x[a][r] : m.v[a][0][r];
-      m.v[a][1][r] = (mine && hi) ? x.x[a][r] : m.v[a][1][r];
-    }
+    for (int r = 0; r < 4; ++r) m.v[a][C >> 4][r] = mine ? x.x[a][r] : m.v[a][C >> 4][r];
 }
-// copy the values held by the lanes of column c to every lane of the same kq group
-__device__ __forceinline__ cvec v_bcast(const cvec& x, int c, const wpos& p) {
+// copy the values held by the lanes of column C to every lane of the same kq group
+template <int C>
+__device__ __forceinline__ cvec v_bcast(const cvec& x, const wpos& p) {
   cvec y;
-  const int src = (p.lane & 48) | (c & 15);
+  const int src = (p.lane & 48) | (C & 15);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) y.x[a][r] = __shfl(x.x[a][r], src, 64);
   return y;
 }
-// keep the columns < N
-__device__ __forceinline__ void w_mask_cols(wmat& m, int N, const wpos& p) {
+// column `col` of an image (the pad columns 32, 33 hold vectors), rows in the cvec order
+__device__ __forceinline__ void v_from_img(cvec& x, const double* img, int col, const wpos& p) {
+  const double* b0 = img + col + WLD * p.kq;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const bool keep = 16 * b + p.l15 < N;
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x.x[a][r] = b0[WLD * (16 * a + 4 * r)];
+}
+// the values the lanes of column C hold -> column `col` of an image
+template <int C>
+__device__ __forceinline__ void v_to_img(double* img, int col, const cvec& x, const wpos& p) {
+  if (p.l15 == (C & 15)) {
+    double* b0 = img + col + WLD * p.kq;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) m.v[a][b][r] = keep ? m.v[a][b][r] : 0.0;
+      for (int r = 0; r < 4; ++r) b0[WLD * (16 * a + 4 * r)] = x.x[a][r];
   }
 }
 
-template <int KS>
+// ---- flat (coalesced) block <-> image copies; chunk j covers the elements lane + 64 j ------------------------------------------
+template <int N>
+struct flat {
+  static constexpr int NN = N * N, NF = (NN + 63) / 64, TAIL = NN - 64 * (NF - 1);   // TAIL lanes in the last chunk
+  double f[NF];
+};
+template <int N>
+struct flat_idx {
+  int aidx[flat<N>::NF];   // image position of element lane + 64 j (the lanes past the block: an unused pad word)
+  int etail;               // min(lane, TAIL - 1) + 64 (NF - 1)
+};
+template <int N>
+__device__ __forceinline__ void f_index(flat_idx<N>& ix, int lane) {
+  using F = flat<N>;
+#pragma unroll
+  for (int j = 0; j < F::NF; ++j) {
+    const int e = lane + 64 * j, ec = min(e, F::NN - 1), col = ec / N;
+    ix.aidx[j] = (e < F::NN) ? col + WLD * (ec - col * N) : 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+  }
+  ix.etail = min(lane, F::TAIL - 1) + 64 * (F::NF - 1);
+}
+template <int N>
+__device__ __forceinline__ void f_load(flat<N>& x, const double* __restrict__ g, const flat_idx<N>& ix, int lane) {
+  using F = flat<N>;
+  const double* gl = g + lane;
+#pragma unroll
+  for (int j = 0; j < F::NF - 1; ++j) x.f[j] = gl[64 * j];
+  x.f[F::NF - 1] = g[ix.etail];
+}
+template <int N>
+__device__ __forceinline__ void f_to_img(double* img, const flat<N>& x, const flat_idx<N>& ix) {
+#pragma unroll
+  for (int j = 0; j < flat<N>::NF; ++j) img[ix.aidx[j]] = x.f[j];
+}
+template <int N>
+__device__ __forceinline__ void img_to_global(double* __restrict__ g, const double* img, const flat_idx<N>& ix, int lane) {
+  using F = flat<N>;
+  double* gl = g + lane;
+#pragma unroll
+  for (int j = 0; j < F::NF - 1; ++j) gl[64 * j] = img[ix.aidx[j]];
+  if (lane < F::TAIL) gl[64 * (F::NF - 1)] = img[ix.aidx[F::NF - 1]];
+}
+
+// the in-band lines of one wave (every RW_WAVES-th in-band line of the recipient point) as a 128-bit mask
+struct line_list {
+  unsigned long long mine[2];
+  int sh[2];   // lane i: shift[i], shift[64 + i]
+  int K;
+  __device__ __forceinline__ void build(const int* __restrict__ shift, int K_, int S, int n1, int lane, int wave) {
+    K = K_;
+    int base = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = 64 * h + lane;
+      sh[h] = (i < K) ? shift[i] : 0;
+      const int n0 = n1 + sh[h];
+      const bool inb = i < K && n0 >= 0 && n0 < S;
+      const unsigned long long bal = __ballot(inb);
+      const int before = base + __popcll(bal & ((1ull << lane) - 1ull));
+      base += __popcll(bal);
+      mine[h] = __ballot(inb && (before & (RW_WAVES - 1)) == wave);
+    }
+  }
+  __device__ __forceinline__ int next(int d) const {   // next line >= d of this wave, K if none
+    if (d < 64) {
+      const unsigned long long mm = mine[0] & (~0ull << d);
+      if (mm) return __ffsll((long long)mm) - 1;
+      d = 64;
+    }
+    if (d < 128) {
+      const unsigned long long mm = mine[1] & (~0ull << (d - 64));
+      if (mm) return 64 + __ffsll((long long)mm) - 1;
+    }
+    return K;
+  }
+  __device__ __forceinline__ int shift_of(int d) const { return __builtin_amdgcn_readlane(d < 64 ? sh[0] : sh[1], d & 63); }
+};
+
+// stage two shared N x N blocks as k-major images, zero the private images
+template <int N>
+__device__ __forceinline__ void stage_shared(double* A1, const double* __restrict__ g1, double* A2,
+                                             const double* __restrict__ g2, double* priv, int tid) {
+  for (int e = tid; e < 1024; e += 64 * RW_WAVES) {
+    const int row = e & 31, col = e >> 5;
+    const bool in = row < N && col < N;
+    A1[col + WLD * row] = in ? g1[row + N * col] : 0.0;
+    A2[col + WLD * row] = in ? g2[row + N * col] : 0.0;
+  }
+  for (int e = tid & 63; e < RW_PRIV * WIMG; e += 64) priv[e] = 0.0;
+}
+
+template <int N>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
-    int N, int S, int K, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
+    int S, int K, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
     const double* __restrict__ ttg, const double* __restrict__ gt, const double* __restrict__ gr,
     const double* __restrict__ grt, const double* __restrict__ jp, const double* __restrict__ j1m,
     const double* __restrict__ tmp1, const double* __restrict__ tmp2, const double* __restrict__ expk, double* ier,
     double* iet, double* ieJp, double* ieJm) {
+  constexpr int KS = (N + 3) / 4, NN = N * N, cA = N, cB = N + 1;
   extern __shared__ __attribute__((aligned(16))) double rw_smem[];
   const int tid = threadIdx.x, wave = tid >> 6;
   wpos p;
   p.lane = tid & 63;
   p.l15 = p.lane & 15;
   p.kq = p.lane >> 4;
+  const int lane = p.lane;
   double* R1a = rw_smem;
   double* TTGa = rw_smem + WIMG;
-  double* IERa = rw_smem + (2 + RW_PRIV * wave) * WIMG;   // ier, later WA
-  double* IETa = IERa + WIMG;
-  double* Xa = IETa + WIMG;
+  double* IERa = rw_smem + (2 + RW_PRIV * wave) * WIMG;   // ier ; pad columns: iej0+, iej0-
+  double* IETa = IERa + WIMG;                             // iet (+ columns N, N+1: iej1-, iej0+)
+  double* Xa = IETa + WIMG;                               // X, later WA
+  double* STa = Xa + WIMG;                                // staging of the right operands and of the outputs
   const int n1 = blockIdx.x;
-  const int NN = N * N;
-  const int cA = N, cB = N + 1;
-  {
-    const double* g1 = r + (long long)n1 * NN;
-    const double* g2 = ttg + (long long)n1 * NN;
-    for (int e = tid; e < 1024; e += 64 * RW_WAVES) {
-      const int row = e & 31, col = e >> 5;
-      const bool in = row < N && col < N;
-      R1a[col + WLD * row] = in ? g1[row + N * col] : 0.0;
-      TTGa[col + WLD * row] = in ? g2[row + N * col] : 0.0;
-    }
-  }
+  flat_idx<N> ix;
+  f_index<N>(ix, lane);
+  stage_shared<N>(R1a, r + (long long)n1 * NN, TTGa, ttg + (long long)n1 * NN, IERa, tid);
   __syncthreads();
-  int cnt = 0;
-  for (int d = 0; d < K; ++d) {
-    const int n0 = n1 + shift[d];
-    if (n0 < 0 || n0 >= S) continue;
-    if ((cnt++ & (RW_WAVES - 1)) != wave) continue;
-    const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
+  line_list ll;
+  ll.build(shift, K, S, n1, lane, wave);
+  // the operands of a line as flat blocks (NF registers each) and one element per lane of the vectors;
+  // rolling prefetch, at most five blocks in flight: a block is requested two to four product groups before its use
+  flat<N> fIER, fIET, fR0, fGT, fGR, fGRT, fT0;
+  double vJp = 0.0, vJm = 0.0, vj1m = 0.0, vjp0 = 0.0, vt1 = 0.0, vt2 = 0.0, e0 = 0.0;
+  const bool vin = lane < N;
+  const int vl = vin ? lane : 0;
+  auto issue_ier = [&](int dd) {
+    const long long o4 = ((long long)n1 + (long long)S * dd) * NN, o4v = ((long long)n1 + (long long)S * dd) * N;
+    f_load<N>(fIER, ier + o4, ix, lane);
+    vJp = ieJp[o4v + vl];
+    vJm = ieJm[o4v + vl];
+    e0 = expk[n1 + ll.shift_of(dd)];
+  };
+  auto issue_iet = [&](int dd) { f_load<N>(fIET, iet + ((long long)n1 + (long long)S * dd) * NN, ix, lane); };
+  auto issue_r0_gt_gr = [&](int dd) {
+    const int n0 = n1 + ll.shift_of(dd);
     const long long e4 = (long long)n0 * NN, e1 = (long long)n0 * N;
-    wmat IERw, IETw, Bw;
-    w_load(IERw, ier + o4, N, p);
-    w_load(IETw, iet + o4, N, p);
-    w_load(Bw, r + e4, N, p);
-    cvec cJp, cJm, cx, cy;
-    v_load(cJp, ieJp + o4v, N, p);
-    v_load(cJm, ieJm + o4v, N, p);
-    v_load(cx, j1m + e1, N, p);
-    v_load(cy, jp + e1, N, p);
-    const double e0 = expk[n0];
-    cvec cJ1m;   // iej1- = iej0- expk[n0]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cJ1m.x[a][q] = cJm.x[a][q] * e0;
-    w_to_aform(IERa, IERw, N, p);
-    w_to_aform(IETa, IETw, N, p);
-    w_set_col(IETw, cA, cJ1m, p);
-    w_set_col(IETw, cB, cJp, p);
-    w_set_col(Bw, cA, cx, p);
-    w_set_col(Bw, cB, cy, p);
-    // X = ier r0 + r1 ier (columns N, N+1: ier j1-, ier j0+) ;  r1 iet (columns N, N+1: r1 iej1-, r1 iej0+)
-    wmat X, R1IET;
-    w_zero(X);
-    w_mm<KS>(X, IERa, Bw, p);
-    w_mm<KS>(X, R1a, IERw, p);
-    w_zero(R1IET);
-    w_mm<KS>(R1IET, R1a, IETw, p);
-    w_to_aform(Xa, X, N, p);
-    // X gt0 (column N: X tmp1), iet gt0 (column N: iet tmp1)
-    v_load(cx, tmp1 + e1, N, p);
-    v_load(cy, tmp2 + e1, N, p);
-    w_load(Bw, gt + e4, N, p);
-    w_set_col(Bw, cA, cx, p);
-    wmat W1, O1;
-    w_zero(W1);
-    w_mm<KS>(W1, Xa, Bw, p);
-    w_zero(O1);
-    w_mm<KS>(O1, IETa, Bw, p);
-    // X gr0 (column N: X tmp2)
-    w_load(Bw, gr + e4, N, p);
-    w_set_col(Bw, cA, cy, p);
-    wmat WA;
-    w_zero(WA);
-    w_mm<KS>(WA, Xa, Bw, p);
-    // ier + iet grt0 (column N: iet tmp2)
-    w_load(Bw, grt + e4, N, p);
-    w_set_col(Bw, cA, cy, p);
-    wmat O2 = IERw;
-    w_mm<KS>(O2, IETa, Bw, p);
-    // W1 = iet + X gt0, column N = a3 = iej0+ + r1 iej1- + ier j1- + X tmp1
+    f_load<N>(fR0, r + e4, ix, lane);
+    f_load<N>(fGT, gt + e4, ix, lane);
+    f_load<N>(fGR, gr + e4, ix, lane);
+    vj1m = j1m[e1 + vl];
+    vjp0 = jp[e1 + vl];
+    vt1 = tmp1[e1 + vl];
+    vt2 = tmp2[e1 + vl];
+  };
+  RW_STAMP_DECL;
+  int d = ll.next(0);
+  if (d < K) {
+    issue_ier(d);
+    issue_iet(d);
+    issue_r0_gt_gr(d);
+  }
+  while (d < K) {
+    const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
+    const long long e4 = (long long)(n1 + ll.shift_of(d)) * NN;
+    const int dnext = ll.next(d + 1);
+    const double e0c = e0;
+    RW_STAMP(15);
+    // ---- images of ier, iet (+ riders iej1-, iej0+), r0 (+ riders j1-[n0], j0+[n0]); vectors into the pad columns
+    f_to_img<N>(IERa, fIER, ix);
+    f_to_img<N>(IETa, fIET, ix);
+    f_to_img<N>(STa, fR0, ix);
+    if (vin) {
+      IERa[32 + WLD * lane] = vJp;
+      IERa[33 + WLD * lane] = vJm;
+      IETa[cA + WLD * lane] = vJm * e0c;
+      IETa[cB + WLD * lane] = vJp;
+      STa[cA + WLD * lane] = vj1m;
+      STa[cB + WLD * lane] = vjp0;
+    }
+    f_load<N>(fGRT, grt + e4, ix, lane);
+    RW_STAMP(0);
+    wmat X, R1IET, O2;
     {
-      const cvec q1 = w_col(R1IET, cA), q2 = w_col(X, cA), q3 = w_col(W1, cA);
+      wmat Bw;
+      w_from_img(Bw, STa, p);
+      // X = ier r0 + r1 ier (columns N, N+1: ier j1-, ier j0+) ;  r1 iet (columns N, N+1: r1 iej1-, r1 iej0+)
+      w_zero(X);
+      w_mm<KS>(X, IERa, Bw, p);
+      w_from_img(O2, IERa, p);
+      w_mm<KS>(X, R1a, O2, p);
+      w_from_img(Bw, IETa, p);
+      w_zero(R1IET);
+      w_mm<KS>(R1IET, R1a, Bw, p);
+    }
+    RW_STAMP(1);
+    // ---- gt0 (+ rider tmp1) ;  X gt0 (column N: X tmp1), iet gt0 (column N: iet tmp1)
+    f_to_img<N>(STa, fGT, ix);
+    if (vin) {
+      STa[cA + WLD * lane] = vt1;
+      STa[cB + WLD * lane] = 0.0;
+    }
+    w_to_img(Xa, X, p);
+    f_load<N>(fT0, t + e4, ix, lane);
+    RW_STAMP(2);
+    wmat W1, O1;
+    {
+      wmat Bw;
+      w_from_img(Bw, STa, p);
+      w_zero(W1);
+      w_mm<KS>(W1, Xa, Bw, p);
+      w_zero(O1);
+      w_mm<KS>(O1, IETa, Bw, p);
+    }
+    RW_STAMP(3);
+    // ---- gr0 (+ rider tmp2) ;  X gr0 (column N: X tmp2)
+    f_to_img<N>(STa, fGR, ix);
+    if (vin) STa[cA + WLD * lane] = vt2;
+    if (dnext < K) issue_ier(dnext);
+    RW_STAMP(4);
+    wmat WA;
+    {
+      wmat Bw;
+      w_from_img(Bw, STa, p);
+      w_zero(WA);
+      w_mm<KS>(WA, Xa, Bw, p);
+    }
+    RW_STAMP(5);
+    // ---- grt0 (+ rider tmp2) ;  ier + iet grt0 (column N: iet tmp2)
+    f_to_img<N>(STa, fGRT, ix);   // (the rider column still holds tmp2)
+    if (dnext < K) issue_iet(dnext);
+    RW_STAMP(6);
+    {
+      wmat Bw;
+      w_from_img(Bw, STa, p);
+      w_mm<KS>(O2, IETa, Bw, p);
+    }
+    RW_STAMP(7);
+    // ---- W1 = iet + X gt0, column N = a3 = iej0+ + r1 iej1- + ier j1- + X tmp1
+    cvec cJp, cJm;
+    v_from_img(cJp, IERa, 32, p);
+    v_from_img(cJm, IERa, 33, p);
+    {
+      const cvec q1 = w_col<cA>(R1IET), q2 = w_col<cA>(X), q3 = w_col<cA>(W1);
       cvec a3;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int q = 0; q < 4; ++q) a3.x[a][q] = cJp.x[a][q] + q1.x[a][q] + q2.x[a][q] + q3.x[a][q];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) W1.v[a][b] += IETw.v[a][b];
-      w_mask_cols(W1, N, p);
-      w_set_col(W1, cA, a3, p);
+      wmat Bw;
+      w_from_img(Bw, IETa, p);
+      w_add(W1, Bw);
+      w_set_col<cA>(W1, a3, p);
     }
-    // WA = ier + X gr0 ;  a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2
+    // ---- WA = ier + X gr0 ;  a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2
     cvec a4;
     {
-      const cvec q1 = w_col(X, cB), q2 = w_col(R1IET, cB), q3 = w_col(WA, cA);
-      cvec s;
+      const cvec q1 = w_col<cB>(X), q2 = w_col<cB>(R1IET), q3 = w_col<cA>(WA);
+      cvec sv;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) s.x[a][q] = q1.x[a][q] + q2.x[a][q];
-      s = v_bcast(s, cB, p);
+        for (int q = 0; q < 4; ++q) sv.x[a][q] = q1.x[a][q] + q2.x[a][q];
+      sv = v_bcast<cB>(sv, p);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a4.x[a][q] = cJ1m.x[a][q] + s.x[a][q] + q3.x[a][q];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) WA.v[a][b] += IERw.v[a][b];
+        for (int q = 0; q < 4; ++q) a4.x[a][q] = cJm.x[a][q] * e0c + sv.x[a][q] + q3.x[a][q];
+      wmat Bw;
+      w_from_img(Bw, IERa, p);
+      w_add(WA, Bw);
     }
-    w_to_aform(IERa, WA, N, p);   // ier's image is dead (the wave's own earlier reads retire in order)
-    // W3 = WA t0 + r1 iet, column N = a4
-    w_load(Bw, t + e4, N, p);
-    w_mask_cols(R1IET, N, p);
-    w_mm<KS>(R1IET, IERa, Bw, p);
-    w_set_col(R1IET, cA, a4, p);
+    w_to_img(Xa, WA, p);   // X is dead (the wave's own earlier reads retire in order)
+    RW_STAMP(8);
+    // ---- t0 ;  W3 = WA t0 + r1 iet, column N = a4
+    f_to_img<N>(STa, fT0, ix);
+    if (vin) STa[cA + WLD * lane] = 0.0;
+    if (dnext < K) issue_r0_gt_gr(dnext);
+    RW_STAMP(9);
+    {
+      wmat Bw;
+      w_from_img(Bw, STa, p);
+      w_mm<KS>(R1IET, Xa, Bw, p);
+      w_set_col<cA>(R1IET, a4, p);
+    }
     // iet' = ttg1 W1 + iet gt0 ;  ieJ0+' = iej0+ expk0 + ttg1 a3 + iet tmp1  (column N of the same accumulator)
     w_mm<KS>(O1, TTGa, W1, p);
     // ier' = ier + iet grt0 + ttg1 W3 ;  ieJ0-' = iej0- + ttg1 a4 + iet tmp2
     w_mm<KS>(O2, TTGa, R1IET, p);
-    w_store(iet + o4, O1, N, p);
-    w_store(ier + o4, O2, N, p);
+    RW_STAMP(10);
+    // ---- outputs through the staging image: coalesced stores
     {
-      const cvec q1 = w_col(O1, cA), q2 = w_col(O2, cA);
-      if (p.l15 == (cA & 15)) {
+      cvec q1 = w_col<cA>(O1), q2 = w_col<cA>(O2);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int row = 16 * a + p.kq + 4 * q;
-            if (row < N) {
-              ieJp[o4v + row] = cJp.x[a][q] * e0 + q1.x[a][q];
-              ieJm[o4v + row] = cJm.x[a][q] + q2.x[a][q];
-            }
-          }
-      }
+        for (int q = 0; q < 4; ++q) {
+          q1.x[a][q] += cJp.x[a][q] * e0c;
+          q2.x[a][q] += cJm.x[a][q];
+        }
+      v_to_img<cA>(STa, 32, q1, p);
+      v_to_img<cA>(STa, 33, q2, p);
     }
+    w_to_img(STa, O1, p);
+    img_to_global<N>(iet + o4, STa, ix, lane);
+    w_to_img(STa, O2, p);
+    img_to_global<N>(ier + o4, STa, ix, lane);
+    if (vin) {
+      ieJp[o4v + lane] = STa[32 + WLD * lane];
+      ieJm[o4v + lane] = STa[33 + WLD * lane];
+    }
+    RW_STAMP(11);
+    d = dnext;
+  }
+  RW_STAMP_FLUSH();
+}
+
+// One pass of interaction_helper!(::RRS, ::ScatteringInterface_11) (interaction_inelastic.jl:319-521), one wave per line
+// (operand roles: rs_ia_pass in vsm_internal.h):
+//   W1 = L1 E0[n0] + L2 I1 ;  Y = YA + TI W1 ;  W3 = L1 E3[n0] + L2 I3
+//   OUTA = ACCA + TI W3 + Y GX[n0] ;  OUTB = TI I4 + Y GY[n0]
+//   V1 = L1 VE0[n0] + L2 VI1 + VADD ;  VOUT = VACC + TI V1 + Y VV[n0]          (riding in spare column N)
+// Shared images: L2, TI; private: L1, Y, two staging images (right operands alternate between them).
+template <int N>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_interaction_wave(int S, int K, const int* __restrict__ shift,
+                                                                             rs_ia_pass<double> h) {
+  constexpr int KS = (N + 3) / 4, NN = N * N, cA = N;
+  extern __shared__ __attribute__((aligned(16))) double rw_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  wpos p;
+  p.lane = tid & 63;
+  p.l15 = p.lane & 15;
+  p.kq = p.lane >> 4;
+  const int lane = p.lane;
+  double* L2a = rw_smem;
+  double* TIa = rw_smem + WIMG;
+  double* L1a = rw_smem + (2 + RW_PRIV * wave) * WIMG;   // pad columns: VADD, VACC
+  double* Ya = L1a + WIMG;
+  double* SAa = Ya + WIMG;
+  double* SBa = SAa + WIMG;
+  const int n1 = blockIdx.x;
+  flat_idx<N> ix;
+  f_index<N>(ix, lane);
+  stage_shared<N>(L2a, h.L2 + (long long)n1 * h.sL2, TIa, h.TI + (long long)n1 * NN, L1a, tid);
+  __syncthreads();
+  line_list ll;
+  ll.build(shift, K, S, n1, lane, wave);
+  // blocks in use order: L1, E0, I1 | E3, I3 | YA, ACCA | I4 | GX, GY
+  flat<N> fL1, fE0, fI1, fE3, fI3, fYA, fAC, fI4, fGX, fGY;
+  double vE0 = 0.0, vI1 = 0.0, vVV = 0.0, vAD = 0.0, vAC = 0.0;
+  const bool vin = lane < N;
+  const int vl = vin ? lane : 0;
+  auto issue_a = [&](int dd) {   // L1, E0, I1 (+ VE0, VI1, VADD, VACC)
+    const int n0 = n1 + ll.shift_of(dd);
+    const long long o4 = ((long long)n1 + (long long)S * dd) * NN, o4v = ((long long)n1 + (long long)S * dd) * N;
+    f_load<N>(fL1, h.L1 + o4, ix, lane);
+    f_load<N>(fE0, h.E0 + n0 * h.sE0, ix, lane);
+    f_load<N>(fI1, h.I1 + o4, ix, lane);
+    vE0 = h.VE0[(long long)n0 * N + vl];
+    vI1 = h.VI1[o4v + vl];
+    vAD = h.VADD[o4v + vl];
+    vAC = h.VACC[o4v + vl];
+  };
+  auto issue_b = [&](int dd) {   // E3, I3
+    const int n0 = n1 + ll.shift_of(dd);
+    const long long o4 = ((long long)n1 + (long long)S * dd) * NN;
+    f_load<N>(fE3, h.E3 + n0 * h.sE3, ix, lane);
+    f_load<N>(fI3, h.I3 + o4, ix, lane);
+  };
+  int d = ll.next(0);
+  if (d < K) {
+    issue_a(d);
+    issue_b(d);
+  }
+  while (d < K) {
+    const int n0 = n1 + ll.shift_of(d);
+    const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
+    const int dnext = ll.next(d + 1);
+    // ---- L1 image; E0 (+ rider VE0[n0]) and I1 (+ rider VI1) ;  W1 = L1 E0 + L2 I1
+    f_to_img<N>(L1a, fL1, ix);
+    f_to_img<N>(SAa, fE0, ix);
+    f_to_img<N>(SBa, fI1, ix);
+    if (vin) {
+      L1a[32 + WLD * lane] = vAD;
+      L1a[33 + WLD * lane] = vAC;
+      SAa[cA + WLD * lane] = vE0;
+      SBa[cA + WLD * lane] = vI1;
+    }
+    f_load<N>(fYA, h.YA + o4, ix, lane);
+    f_load<N>(fAC, h.ACCA + o4, ix, lane);
+    wmat W1;
+    {
+      wmat Bw;
+      w_from_img(Bw, SAa, p);
+      w_zero(W1);
+      w_mm<KS>(W1, L1a, Bw, p);
+      w_from_img(Bw, SBa, p);
+      w_mm<KS>(W1, L2a, Bw, p);
+    }
+    // ---- E3, I3 ;  W3 = L1 E3 + L2 I3
+    f_to_img<N>(SAa, fE3, ix);
+    f_to_img<N>(SBa, fI3, ix);
+    if (vin) {
+      SAa[cA + WLD * lane] = 0.0;
+      SBa[cA + WLD * lane] = 0.0;
+    }
+    f_load<N>(fI4, h.I4 + o4, ix, lane);
+    f_load<N>(fGX, h.GX + (long long)n0 * NN, ix, lane);
+    vVV = h.VV[(long long)n0 * N + vl];
+    wmat W3;
+    {
+      wmat Bw;
+      w_from_img(Bw, SAa, p);
+      w_zero(W3);
+      w_mm<KS>(W3, L1a, Bw, p);
+      w_from_img(Bw, SBa, p);
+      w_mm<KS>(W3, L2a, Bw, p);
+    }
+    // column N of W1 becomes V1 = L1 VE0 + L2 VI1 + VADD
+    cvec cAD, cAC;
+    v_from_img(cAD, L1a, 32, p);
+    v_from_img(cAC, L1a, 33, p);
+    {
+      cvec q = w_col<cA>(W1);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q.x[a][i] += cAD.x[a][i];
+      w_set_col<cA>(W1, q, p);
+    }
+    // ---- YA, ACCA as accumulator seeds ;  Y = YA + TI W1 (column N: TI V1) ;  A = ACCA + TI W3
+    f_to_img<N>(SAa, fYA, ix);
+    f_to_img<N>(SBa, fAC, ix);
+    f_load<N>(fGY, h.GY + (long long)n0 * NN, ix, lane);
+    wmat Y, A, B;
+    w_from_img(Y, SAa, p);
+    w_mm<KS>(Y, TIa, W1, p);
+    w_from_img(A, SBa, p);
+    w_mm<KS>(A, TIa, W3, p);
+    // ---- I4 ;  B = TI I4
+    f_to_img<N>(SAa, fI4, ix);
+    if (dnext < K) issue_a(dnext);
+    {
+      wmat Bw;
+      w_from_img(Bw, SAa, p);
+      w_zero(B);
+      w_mm<KS>(B, TIa, Bw, p);
+    }
+    const cvec vt = w_col<cA>(Y);
+    w_to_img(Ya, Y, p);   // (its column N = TI V1 meets the zero row N of GX, GY)
+    // ---- GX (+ rider VV[n0]), GY ;  A += Y GX (column N: Y VV) ;  B += Y GY
+    f_to_img<N>(SBa, fGX, ix);
+    if (vin) SBa[cA + WLD * lane] = vVV;
+    f_to_img<N>(SAa, fGY, ix);
+    if (dnext < K) issue_b(dnext);
+    {
+      wmat Bw;
+      w_from_img(Bw, SBa, p);
+      w_mm<KS>(A, Ya, Bw, p);
+      w_from_img(Bw, SAa, p);
+      w_mm<KS>(B, Ya, Bw, p);
+    }
+    // ---- outputs through the staging images
+    {
+      cvec q = w_col<cA>(A);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q.x[a][i] += cAC.x[a][i] + vt.x[a][i];
+      v_to_img<cA>(SAa, 32, q, p);
+    }
+    w_to_img(SBa, A, p);
+    img_to_global<N>(h.OUTA + o4, SBa, ix, lane);
+    w_to_img(SAa, B, p);
+    img_to_global<N>(h.OUTB + o4, SAa, ix, lane);
+    if (vin) h.VOUT[o4v + lane] = SAa[32 + WLD * lane];
+    d = dnext;
   }
 }
 
-template <int KS>
-int launch_rw(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg, const double* gt,
+constexpr size_t RW_LDS_BYTES = (size_t)(2 + RW_PRIV * RW_WAVES) * WIMG * sizeof(double);
+
+template <int N>
+int launch_rw(int S, int K, const int* shift, const double* r, const double* t, const double* ttg, const double* gt,
               const double* gr, const double* grt, const double* jp, const double* j1m, const double* tmp1,
               const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, hipStream_t st) {
-  auto kern = k_raman_doubling_wave<KS>;
-  const size_t bytes = (size_t)(2 + RW_PRIV * RW_WAVES) * WIMG * sizeof(double);
-  static hipError_t prepared =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  auto kern = k_raman_doubling_wave<N>;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), bytes, st, N, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
+  hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
                      tmp2, expk, ier, iet, ieJp, ieJm);
   VSM_LAUNCH_CHECK("k_raman_doubling_wave");
   return VSM_OK;
 }
+template <int N>
+int launch_rw_ia(int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
+  auto kern = k_raman_interaction_wave<N>;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, h);
+  VSM_LAUNCH_CHECK("k_raman_interaction_wave");
+  return VSM_OK;
+}
+
+// N -> instantiation (1..RW_MAXN)
+template <int N, typename F>
+int dispatch_n(int n, F f) {
+  if constexpr (N > RW_MAXN) {
+    return VSM_ERR_UNSUPPORTED;
+  } else {
+    if (n == N) return f(std::integral_constant<int, N>{});
+    return dispatch_n<N + 1>(n, f);
+  }
+}
 
 }  // namespace
 
-// FP64, N <= 30; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator chain)
+// FP64, N <= 24, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
+// chain).  N 25..30: the flat blocks in flight no longer fit the registers; K > 128: the line list is a 128-bit mask.
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
                         double* ieJm, hipStream_t st) {
   static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr;
-  if (off || N > 30 || N < 1) return VSM_ERR_UNSUPPORTED;
+  if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0 || K <= 0) return VSM_OK;
-#define RW_CASE(KS_)                                                                                                 \
-  case KS_:                                                                                                          \
-    return launch_rw<KS_>(N, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm, st)
-  switch ((N + 3) >> 2) {
-    RW_CASE(1);
-    RW_CASE(2);
-    RW_CASE(3);
-    RW_CASE(4);
-    RW_CASE(5);
-    RW_CASE(6);
-    RW_CASE(7);
-    RW_CASE(8);
-  }
-#undef RW_CASE
-  return VSM_ERR_UNSUPPORTED;
+  return dispatch_n<1>(N, [&](auto tag) {
+    return launch_rw<decltype(tag)::value>(S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm,
+                                           st);
+  });
 }
 
+int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
+  static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr || getenv("VSM_NO_RAMAN_IA_WAVE") != nullptr;
+  if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
+  if (S <= 0 || K <= 0) return VSM_OK;
+  return dispatch_n<1>(N, [&](auto tag) { return launch_rw_ia<decltype(tag)::value>(S, K, shift, h, st); });
+}
+
+#ifdef RW_PHASE_TIMING
+extern "C" int vsm_debug_rw_phase(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(rw_phase_cycles), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(rw_phase_cycles), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 }  // namespace vsm
