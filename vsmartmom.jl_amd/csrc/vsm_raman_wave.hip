@@ -287,6 +287,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
   double vJp = 0.0, vJm = 0.0, vj1m = 0.0, vjp0 = 0.0, vt1 = 0.0, vt2 = 0.0, e0 = 0.0;
   const bool vin = lane < N;
   const int vl = vin ? lane : 0;
+  // per-lane image positions of the vector / rider stores; the lanes >= N write to an unused pad word, so the loop body
+  // has no divergent branches and stays one scheduling region
+  const int vdummy = 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+  const int vp32 = vin ? 32 + WLD * lane : vdummy, vp33 = vin ? 33 + WLD * lane : vdummy;
+  const int vpA = vin ? cA + WLD * lane : vdummy, vpB = vin ? cB + WLD * lane : vdummy;
   auto issue_ier = [&](int dd) {
     const long long o4 = ((long long)n1 + (long long)S * dd) * NN, o4v = ((long long)n1 + (long long)S * dd) * N;
     f_load<N>(fIER, ier + o4, ix, lane);
@@ -317,20 +322,19 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     const long long o4 = ((long long)n1 + (long long)S * d) * NN, o4v = ((long long)n1 + (long long)S * d) * N;
     const long long e4 = (long long)(n1 + ll.shift_of(d)) * NN;
     const int dnext = ll.next(d + 1);
+    const int dpre = dnext < K ? dnext : d;   // (past the last line: re-request this line, unused)
     const double e0c = e0;
     RW_STAMP(15);
     // ---- images of ier, iet (+ riders iej1-, iej0+), r0 (+ riders j1-[n0], j0+[n0]); vectors into the pad columns
     f_to_img<N>(IERa, fIER, ix);
     f_to_img<N>(IETa, fIET, ix);
     f_to_img<N>(STa, fR0, ix);
-    if (vin) {
-      IERa[32 + WLD * lane] = vJp;
-      IERa[33 + WLD * lane] = vJm;
-      IETa[cA + WLD * lane] = vJm * e0c;
-      IETa[cB + WLD * lane] = vJp;
-      STa[cA + WLD * lane] = vj1m;
-      STa[cB + WLD * lane] = vjp0;
-    }
+    IERa[vp32] = vJp;
+    IERa[vp33] = vJm;
+    IETa[vpA] = vJm * e0c;
+    IETa[vpB] = vJp;
+    STa[vpA] = vj1m;
+    STa[vpB] = vjp0;
     f_load<N>(fGRT, grt + e4, ix, lane);
     RW_STAMP(0);
     wmat X, R1IET, O2;
@@ -349,10 +353,8 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     RW_STAMP(1);
     // ---- gt0 (+ rider tmp1) ;  X gt0 (column N: X tmp1), iet gt0 (column N: iet tmp1)
     f_to_img<N>(STa, fGT, ix);
-    if (vin) {
-      STa[cA + WLD * lane] = vt1;
-      STa[cB + WLD * lane] = 0.0;
-    }
+    STa[vpA] = vt1;
+    STa[vpB] = 0.0;
     w_to_img(Xa, X, p);
     f_load<N>(fT0, t + e4, ix, lane);
     RW_STAMP(2);
@@ -368,8 +370,8 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     RW_STAMP(3);
     // ---- gr0 (+ rider tmp2) ;  X gr0 (column N: X tmp2)
     f_to_img<N>(STa, fGR, ix);
-    if (vin) STa[cA + WLD * lane] = vt2;
-    if (dnext < K) issue_ier(dnext);
+    STa[vpA] = vt2;
+    issue_ier(dpre);
     RW_STAMP(4);
     wmat WA;
     {
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     RW_STAMP(5);
     // ---- grt0 (+ rider tmp2) ;  ier + iet grt0 (column N: iet tmp2)
     f_to_img<N>(STa, fGRT, ix);   // (the rider column still holds tmp2)
-    if (dnext < K) issue_iet(dnext);
+    issue_iet(dpre);
     RW_STAMP(6);
     {
       wmat Bw;
@@ -427,8 +429,8 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     RW_STAMP(8);
     // ---- t0 ;  W3 = WA t0 + r1 iet, column N = a4
     f_to_img<N>(STa, fT0, ix);
-    if (vin) STa[cA + WLD * lane] = 0.0;
-    if (dnext < K) issue_r0_gt_gr(dnext);
+    STa[vpA] = 0.0;
+    issue_r0_gt_gr(dpre);
     RW_STAMP(9);
     {
       wmat Bw;
@@ -466,6 +468,333 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     d = dnext;
   }
   RW_STAMP_FLUSH();
+}
+
+// ---- software-pipelined variant --------------------------------------------------------------------------------------------
+// One wave per SIMD: nothing but the wave's own instruction order can overlap the LDS / VALU / global work with the MFMAs.
+// Every product is issued as 2 KS "slots" of two MFMAs; between the slots run the units of the side work that belongs to
+// LATER products (staging the next right operand, reading it back, writing an intermediate's image, the rider algebra,
+// the output copies), pinned in place by scheduling barriers.  The first phase of the next line (images of ier / iet / r0)
+// rides in the last product of the current one.
+#define RW_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <int LO, int HI, typename G>
+__device__ __forceinline__ void static_for(G&& g) {
+  if constexpr (LO < HI) {
+    g(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(g);
+  }
+}
+// U units spread over the slots [S0, S1): run those of slot s
+template <int U, int S0, int S1, int s, typename G>
+__device__ __forceinline__ void units(G&& g) {
+  if constexpr (s >= S0 && s < S1) {
+    constexpr int n = S1 - S0, k = s - S0;
+    static_for<k * U / n, (k + 1) * U / n>(g);
+  }
+}
+template <int KS, typename F>
+__device__ __forceinline__ void w_mm_s(wmat& acc, const double* A, const wmat& B, const wpos& p, F&& side) {
+  const double* a0 = A + p.kq + WLD * p.l15;
+  double af[KS][2];
+#pragma unroll
+  for (int i = 0; i < KS; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) af[i][t] = a0[16 * (i >> 2) + 4 * (i & 3) + WLD * 16 * t];
+  static_for<0, 2 * KS>([&](auto slot) {
+    constexpr int s = decltype(slot)::value, i = s >> 1, t = s & 1, a = i >> 2, r = i & 3;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc.v[t][b] = mfma<double>::mma(af[i][t], B.v[a][b][r], acc.v[t][b]);
+    RW_PIN();
+    side(slot);
+    RW_PIN();
+  });
+}
+// unit u of the 16 of an image <-> accumulator-layout copy
+template <int u>
+__device__ __forceinline__ void w_rd(wmat& m, const double* b0) {
+  constexpr int a = u >> 3, b = (u >> 2) & 1, r = u & 3;
+  m.v[a][b][r] = b0[16 * b + WLD * (16 * a + 4 * r)];
+}
+template <int u>
+__device__ __forceinline__ void w_wr(double* b0, const wmat& m) {
+  constexpr int a = u >> 3, b = (u >> 2) & 1, r = u & 3;
+  b0[16 * b + WLD * (16 * a + 4 * r)] = m.v[a][b][r];
+}
+template <int u>
+__device__ __forceinline__ void v_rd(cvec& x, const double* b0) {   // b0 = img + col + WLD kq
+  x.x[u >> 2][u & 3] = b0[WLD * (16 * (u >> 2) + 4 * (u & 3))];
+}
+
+template <int N>
+__global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
+    int S, int K, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
+    const double* __restrict__ ttg, const double* __restrict__ gt, const double* __restrict__ gr,
+    const double* __restrict__ grt, const double* __restrict__ jp, const double* __restrict__ j1m,
+    const double* __restrict__ tmp1, const double* __restrict__ tmp2, const double* __restrict__ expk, double* ier,
+    double* iet, double* ieJp, double* ieJm) {
+  constexpr int KS = (N + 3) / 4, SL = 2 * KS, H = KS, NN = N * N, cA = N, cB = N + 1;
+  using F = flat<N>;
+  constexpr int NF = F::NF;
+  extern __shared__ __attribute__((aligned(16))) double rw_smem[];
+  const int tid = threadIdx.x, wave = tid >> 6;
+  wpos p;
+  p.lane = tid & 63;
+  p.l15 = p.lane & 15;
+  p.kq = p.lane >> 4;
+  const int lane = p.lane;
+  double* R1a = rw_smem;
+  double* TTGa = rw_smem + WIMG;
+  double* IERa = rw_smem + (2 + RW_PRIV * wave) * WIMG;   // ier ; pad columns: iej0+, iej0-
+  double* IETa = IERa + WIMG;                             // iet (+ columns N, N+1: iej1-, iej0+) ; pad column: iej0+ expk0
+  double* Xa = IETa + WIMG;                               // X, later WA, later the image of ier'
+  double* STa = Xa + WIMG;                                // staging of the right operands and of iet'
+  const int n1 = blockIdx.x;
+  flat_idx<N> ix;
+  f_index<N>(ix, lane);
+  stage_shared<N>(R1a, r + (long long)n1 * NN, TTGa, ttg + (long long)n1 * NN, IERa, tid);
+  __syncthreads();
+  line_list ll;
+  ll.build(shift, K, S, n1, lane, wave);
+  flat<N> fIER, fIET, fR0, fGT, fGR, fGRT, fT0;
+  double vJp = 0.0, vJm = 0.0, vj1m = 0.0, vjp0 = 0.0, vt1 = 0.0, vt2 = 0.0, e0 = 0.0;
+  const bool vin = lane < N;
+  const int vl = vin ? lane : 0;
+  const int vdummy = 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+  const int vp32 = vin ? 32 + WLD * lane : vdummy, vp33 = vin ? 33 + WLD * lane : vdummy;
+  const int vpA = vin ? cA + WLD * lane : vdummy, vpB = vin ? cB + WLD * lane : vdummy;
+  // accumulator-layout base offsets of the images
+  const int wofs = p.l15 + WLD * p.kq, vofs = WLD * p.kq;
+  auto o4_of = [&](int dd) { return ((long long)n1 + (long long)S * dd) * NN; };
+  auto o4v_of = [&](int dd) { return ((long long)n1 + (long long)S * dd) * N; };
+  auto issue_ier = [&](int dd) {
+    f_load<N>(fIER, ier + o4_of(dd), ix, lane);
+    vJp = ieJp[o4v_of(dd) + vl];
+    vJm = ieJm[o4v_of(dd) + vl];
+    e0 = expk[n1 + ll.shift_of(dd)];
+  };
+  auto issue_iet = [&](int dd) { f_load<N>(fIET, iet + o4_of(dd), ix, lane); };
+  auto issue_r0 = [&](int dd) {
+    const int n0 = n1 + ll.shift_of(dd);
+    f_load<N>(fR0, r + (long long)n0 * NN, ix, lane);
+    vj1m = j1m[(long long)n0 * N + vl];
+    vjp0 = jp[(long long)n0 * N + vl];
+  };
+  auto issue_gt_gr = [&](int dd) {
+    const int n0 = n1 + ll.shift_of(dd);
+    f_load<N>(fGT, gt + (long long)n0 * NN, ix, lane);
+    f_load<N>(fGR, gr + (long long)n0 * NN, ix, lane);
+    vt1 = tmp1[(long long)n0 * N + vl];
+    vt2 = tmp2[(long long)n0 * N + vl];
+  };
+  auto issue_grt = [&](int dd) { f_load<N>(fGRT, grt + (long long)(n1 + ll.shift_of(dd)) * NN, ix, lane); };
+  auto issue_t0 = [&](int dd) { f_load<N>(fT0, t + (long long)(n1 + ll.shift_of(dd)) * NN, ix, lane); };
+  // unit lists of the first phase of a line (images of ier, iet, r0 with riders and pad vectors; then r0 read back)
+  wmat Br0;
+  auto head_units_a = [&](auto u) {   // NF + NF + 5 units
+    constexpr int k = decltype(u)::value;
+    if constexpr (k < NF) IERa[ix.aidx[k]] = fIER.f[k];
+    else if constexpr (k < 2 * NF) IETa[ix.aidx[k - NF]] = fIET.f[k - NF];
+    else if constexpr (k == 2 * NF) IERa[vp32] = vJp;
+    else if constexpr (k == 2 * NF + 1) IERa[vp33] = vJm;
+    else if constexpr (k == 2 * NF + 2) IETa[vpA] = vJm * e0;
+    else if constexpr (k == 2 * NF + 3) IETa[vpB] = vJp;
+    else IETa[vp32] = vJp * e0;
+  };
+  auto head_units_b = [&](auto u) {   // NF + 2 + 16 units
+    constexpr int k = decltype(u)::value;
+    if constexpr (k < NF) STa[ix.aidx[k]] = fR0.f[k];
+    else if constexpr (k == NF) STa[vpA] = vj1m;
+    else if constexpr (k == NF + 1) STa[vpB] = vjp0;
+    else w_rd<k - NF - 2>(Br0, STa + wofs);
+  };
+  int d = ll.next(0);
+  if (d < K) {
+    issue_ier(d);
+    issue_iet(d);
+    issue_r0(d);
+    issue_gt_gr(d);
+    issue_grt(d);
+    issue_t0(d);
+    static_for<0, 2 * NF + 5>(head_units_a);
+    static_for<0, NF + 18>(head_units_b);
+  }
+  while (d < K) {
+    const long long o4 = o4_of(d), o4v = o4v_of(d);
+    const int dnext = ll.next(d + 1);
+    const int dpre = dnext < K ? dnext : d;   // (past the last line: re-request this line, unused)
+    wmat X, R1IET, O1, O2, W1, WA, Biet, Bgt, Bgr, Bgrt, Bt0;
+    cvec cJp, cJm, cJ1m, cJpe, a3, a4;
+    // P1: X = ier r0                                   | read ier (seed of ier', right operand of r1 ier) ; read iet + riders
+    w_zero(X);
+    w_mm_s<KS>(X, IERa, Br0, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(O2, IERa + wofs); });
+      units<16, H, SL, s>([&](auto u) { w_rd<decltype(u)::value>(Biet, IETa + wofs); });
+    });
+    // P2: X += r1 ier                                  | stage gt0 (+ riders tmp1, 0) ; read it back
+    w_mm_s<KS>(X, R1a, O2, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<NF + 2, 0, H, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < NF) STa[ix.aidx[k]] = fGT.f[k];
+        else if constexpr (k == NF) STa[vpA] = vt1;
+        else STa[vpB] = 0.0;
+      });
+      units<16, H, SL, s>([&](auto u) { w_rd<decltype(u)::value>(Bgt, STa + wofs); });
+    });
+    // P3: r1 iet (+ riders r1 iej1-, r1 iej0+)        | image of X ; stage gr0 (+ rider tmp2)
+    w_zero(R1IET);
+    w_mm_s<KS>(R1IET, R1a, Biet, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<16, 0, H, s>([&](auto u) { w_wr<decltype(u)::value>(Xa + wofs, X); });
+      units<NF + 1, H, SL, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < NF) STa[ix.aidx[k]] = fGR.f[k];
+        else STa[vpA] = vt2;
+      });
+    });
+    // P4: iet gt0 (column N: iet tmp1)                 | read gr0 ; stage grt0 (rider column still tmp2) ; next gt0, gr0
+    w_zero(O1);
+    w_mm_s<KS>(O1, IETa, Bgt, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(Bgr, STa + wofs); });
+      units<NF, H, SL, s>([&](auto u) { STa[ix.aidx[decltype(u)::value]] = fGRT.f[decltype(u)::value]; });
+      if constexpr (s == SL - 1) issue_gt_gr(dpre);
+    });
+    // P5: X gt0 (column N: X tmp1)                     | read grt0 ; next grt0
+    w_zero(W1);
+    w_mm_s<KS>(W1, Xa, Bgt, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(Bgrt, STa + wofs); });
+      if constexpr (s == SL - 1) issue_grt(dpre);
+    });
+    // P6: X gr0 (column N: X tmp2)                     | read iet, ier again (addends), pad vectors ; W1 += iet ; stage t0
+    w_zero(WA);
+    wmat Tiet, Tier;
+    cvec w1A;
+    w_mm_s<KS>(WA, Xa, Bgr, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      if constexpr (s == 0) w1A = w_col<cA>(W1);   // X tmp1, before the riders of iet are added
+      units<64, 0, H, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < 16) w_rd<k>(Tiet, IETa + wofs);
+        else if constexpr (k < 32) w_rd<k - 16>(Tier, IERa + wofs);
+        else if constexpr (k < 40) v_rd<k - 32>(cJp, IERa + 32 + vofs);
+        else if constexpr (k < 48) v_rd<k - 40>(cJm, IERa + 33 + vofs);
+        else if constexpr (k < 56) v_rd<k - 48>(cJ1m, IETa + cA + vofs);
+        else v_rd<k - 56>(cJpe, IETa + 32 + vofs);
+      });
+      units<NF + 1 + 4, H, SL, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < NF) STa[ix.aidx[k]] = fT0.f[k];
+        else if constexpr (k == NF) STa[vpA] = 0.0;
+        else W1.v[(k - NF - 1) >> 1][(k - NF - 1) & 1] += Tiet.v[(k - NF - 1) >> 1][(k - NF - 1) & 1];
+      });
+      if constexpr (s == SL - 1) issue_ier(dpre);
+    });
+    // P7: ier + iet grt0 (column N: iet tmp2)          | a3, W1 column N ; WA += ier, a4 ; image of WA ; read t0 ; next t0, iet
+    w_mm_s<KS>(O2, IETa, Bgrt, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      if constexpr (s == 0) {
+        // W1 column N = a3 = iej0+ + r1 iej1- + ier j1- + X tmp1
+        const cvec q1 = w_col<cA>(R1IET), q2 = w_col<cA>(X);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a3.x[a][q] = cJp.x[a][q] + q1.x[a][q] + q2.x[a][q] + w1A.x[a][q];
+        w_set_col<cA>(W1, a3, p);
+      }
+      if constexpr (s == (SL > 1 ? 1 : 0)) {
+        // a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2
+        const cvec q1 = w_col<cB>(X), q2 = w_col<cB>(R1IET), q3 = w_col<cA>(WA);
+        cvec sv;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sv.x[a][q] = q1.x[a][q] + q2.x[a][q];
+        sv = v_bcast<cB>(sv, p);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) a4.x[a][q] = cJ1m.x[a][q] + sv.x[a][q] + q3.x[a][q];
+      }
+      // three 16-unit lists in the slots after the algebra (in thirds when there are at least three slots left)
+      constexpr int B0 = SL > 2 ? 2 : SL - 1, R = SL - B0, T = R >= 3 ? R / 3 : 1;
+      constexpr int A_lo = B0, A_hi = B0 + T;
+      constexpr int B_lo = R >= 2 ? B0 + T : B0, B_hi = R >= 3 ? B0 + 2 * T : SL;
+      constexpr int C_lo = R >= 3 ? B0 + 2 * T : B_lo, C_hi = SL;
+      units<4, A_lo, A_hi, s>([&](auto u) {   // WA += ier
+        constexpr int k = decltype(u)::value;
+        WA.v[k >> 1][k & 1] += Tier.v[k >> 1][k & 1];
+      });
+      units<16, B_lo, B_hi, s>([&](auto u) { w_wr<decltype(u)::value>(Xa + wofs, WA); });
+      units<16, C_lo, C_hi, s>([&](auto u) { w_rd<decltype(u)::value>(Bt0, STa + wofs); });
+      if constexpr (s == SL - 1) {
+        issue_t0(dpre);
+        issue_iet(dpre);
+      }
+    });
+    // P8: iet' = iet gt0 + ttg1 W1 (column N: ttg1 a3 + iet tmp1)     | next r0
+    w_mm_s<KS>(O1, TTGa, W1, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      if constexpr (s == SL - 1) issue_r0(dpre);
+    });
+    // P9: W3 = r1 iet + WA t0                           | image of iet' (+ ieJ0+' into a pad column), its coalesced store
+    flat<N> fOut;
+    double vOut = 0.0;
+    w_mm_s<KS>(R1IET, Xa, Bt0, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<17, 0, H, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < 16) {
+          w_wr<k>(STa + wofs, O1);
+        } else {
+          cvec q1 = w_col<cA>(O1);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) q1.x[a][q] += cJpe.x[a][q];
+          v_to_img<cA>(STa, 32, q1, p);
+        }
+      });
+      constexpr int M0 = H + (SL - H) / 2, R_hi = (M0 > H) ? M0 : H + 1, W_lo = (M0 > H) ? M0 : H;
+      units<NF + 1, H, R_hi, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < NF) fOut.f[k] = STa[ix.aidx[k]];
+        else vOut = STa[vin ? 32 + WLD * lane : vdummy];
+      });
+      units<NF + 1, W_lo, SL, s>([&](auto u) {
+        constexpr int k = decltype(u)::value;
+        if constexpr (k < NF - 1) (iet + o4 + lane)[64 * k] = fOut.f[k];
+        else if constexpr (k == NF - 1) {
+          if (lane < F::TAIL) (iet + o4 + lane)[64 * k] = fOut.f[k];
+        } else {
+          if (vin) ieJp[o4v + lane] = vOut;
+        }
+      });
+    });
+    w_set_col<cA>(R1IET, a4, p);   // W3 column N = a4
+    // P10: ier' = ier + iet grt0 + ttg1 W3 (column N: ttg1 a4 + iet tmp2)    | first phase of the next line
+    w_mm_s<KS>(O2, TTGa, R1IET, p, [&](auto sl) {
+      constexpr int s = decltype(sl)::value;
+      units<2 * NF + 5, 0, H, s>(head_units_a);
+      units<NF + 18, H, SL, s>(head_units_b);
+    });
+    // image of ier' (+ ieJ0-'), coalesced store
+    {
+      cvec q2 = w_col<cA>(O2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) q2.x[a][q] += cJm.x[a][q];
+      v_to_img<cA>(Xa, 33, q2, p);
+      w_to_img(Xa, O2, p);
+      img_to_global<N>(ier + o4, Xa, ix, lane);
+      if (vin) ieJm[o4v + lane] = Xa[33 + WLD * lane];
+    }
+    d = dnext;
+  }
 }
 
 // One pass of interaction_helper!(::RRS, ::ScatteringInterface_11) (interaction_inelastic.jl:319-521), one wave per line
@@ -637,9 +966,15 @@ template <int N>
 int launch_rw(int S, int K, const int* shift, const double* r, const double* t, const double* ttg, const double* gt,
               const double* gr, const double* grt, const double* jp, const double* j1m, const double* tmp1,
               const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, hipStream_t st) {
-  auto kern = k_raman_doubling_wave<N>;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+  static const bool plain = getenv("VSM_RAMAN_WAVE_PLAIN") != nullptr;   // the unpipelined body (A/B)
+  auto kern = plain ? k_raman_doubling_wave<N> : k_raman_doubling_wave_sp<N>;
+  static hipError_t prepared = [] {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave<N>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+  }();
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
                      tmp2, expk, ier, iet, ieJp, ieJm);
