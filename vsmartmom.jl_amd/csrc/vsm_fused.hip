@@ -1005,6 +1005,148 @@ __global__ __launch_bounds__(64 * NW) void k_inv_one_minus_ab(int N, const T* __
 }
 
 // ---------------------------------------------------------------------------
+// Rotational-Raman doubling, ELASTIC part of one doubling step around the line kernels (doubling_inelastic.jl:36-61 and
+// :132-164): per spectral point, everything the inelastic recurrences read and the update of the elastic operators
+// afterwards.  The operator-level chain spends 18 launches per step on N x N products; here it is two, LDS-resident.
+//   pre :  gp = (I - r r)^-1 ; ttg = t gp ; gt = gp t ; gr = gp r ; grt = gr t ; J1+- = J0+- expk ;
+//          u = J0+ + r J1- ; u2 = J1- + r J0+ ; tmp1 = gp u ; tmp2 = gp u2
+//   post:  J0- += ttg u2 ; J0+ = J1+ + ttg u ; expk <- expk^2 ; r <- r + (ttg r) t ; t <- ttg t
+// ---------------------------------------------------------------------------
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_raman_elastic_pre(int N, const T* __restrict__ r, const T* __restrict__ t,
+                                                               const T* __restrict__ j0p, const T* __restrict__ j0m,
+                                                               const T* __restrict__ expk, T* ttg, T* gt, T* gr, T* grt,
+                                                               T* j1p, T* j1m, T* u, T* u2, T* tmp1, T* tmp2) {
+  using C = fcfg<NP, NW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
+  const long long s = blockIdx.x, NN = (long long)N * N;
+  const int tid = threadIdx.x, Kend = ((N + 3) >> 2) << 2;
+  T *R = sm.L[0], *Tt = sm.L[1], *G = sm.L[2], *W = sm.L[3];
+  T *vjp = sm.vec[0], *vj1m = sm.vec[1], *vu = sm.vec[2], *vu2 = sm.vec[3];
+  stage<T, NP, NW>(R, r + s * NN, N);
+  stage<T, NP, NW>(Tt, t + s * NN, N);
+  if (tid < NP) {
+    const T e = expk[s];
+    const T a = (tid < N) ? j0p[s * N + tid] : T(0), b = (tid < N) ? j0m[s * N + tid] : T(0);
+    vjp[tid] = a;
+    vj1m[tid] = b * e;
+    if (tid < N) {
+      j1p[s * N + tid] = a * e;
+      j1m[s * N + tid] = b * e;
+    }
+  }
+  __syncthreads();
+  acc_block<T, NP, NW> acc;
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, R, R, Kend);
+  __syncthreads();
+  int slot = 0;
+  invert_one_minus<T, NP, NW>(acc, G, W, N, Kend, sm, slot, 0);
+  __syncthreads();
+  const int row = tid / C::TPR;
+  const bool lead = row < NP && (tid % C::TPR) == 0;
+  {
+    T y1, y2;
+    matvec2<T, NP, NW>(R, vj1m, vjp, y1, y2);
+    if (lead) {
+      const T a = (row < N) ? vjp[row] + y1 : T(0), b = (row < N) ? vj1m[row] + y2 : T(0);
+      vu[row] = a;
+      vu2[row] = b;
+      if (row < N) {
+        u[s * N + row] = a;
+        u2[s * N + row] = b;
+      }
+    }
+  }
+  const auto ident = [](T a, int, int, T) { return a; };
+  // ttg = t gp
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, Tt, G, Kend);
+  acc_store<T, NP, NW>(W, acc, ident);
+  __syncthreads();   // vu, vu2 and the image of ttg complete
+  {
+    T y1, y2;
+    matvec2<T, NP, NW>(G, vu, vu2, y1, y2);
+    if (lead && row < N) {
+      tmp1[s * N + row] = y1;
+      tmp2[s * N + row] = y2;
+    }
+  }
+  lds_to_global<T, NP, NW>(ttg + s * NN, W, N);
+  // gt = gp t
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, G, Tt, Kend);
+  __syncthreads();   // ttg's image has been copied out
+  acc_store<T, NP, NW>(W, acc, ident);
+  __syncthreads();
+  lds_to_global<T, NP, NW>(gt + s * NN, W, N);
+  // gr = gp r
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, G, R, Kend);
+  __syncthreads();   // gt's image has been copied out; gp has been read by every wave
+  acc_store<T, NP, NW>(W, acc, ident);
+  __syncthreads();
+  lds_to_global<T, NP, NW>(gr + s * NN, W, N);
+  // grt = gr t   (gp's image is free)
+  acc.zero();
+  mm_ll<T, NP, NW>(acc, W, Tt, Kend);
+  acc_store<T, NP, NW>(G, acc, ident);
+  __syncthreads();
+  lds_to_global<T, NP, NW>(grt + s * NN, G, N);
+}
+
+template <typename T, int NP, int NW>
+__global__ __launch_bounds__(64 * NW) void k_raman_elastic_post(int N, T* r, T* t, const T* __restrict__ ttg,
+                                                                const T* __restrict__ u, const T* __restrict__ u2,
+                                                                const T* __restrict__ j1p, T* j0p, T* j0m, T* expk) {
+  using C = fcfg<NP, NW>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  fsmem<T, NP, NW>& sm = *reinterpret_cast<fsmem<T, NP, NW>*>(smem_raw);
+  const long long s = blockIdx.x, NN = (long long)N * N;
+  const int tid = threadIdx.x, Kend = ((N + 3) >> 2) << 2;
+  T *TG = sm.L[0], *R = sm.L[1], *Tt = sm.L[2], *W = sm.L[3];
+  T *vu = sm.vec[0], *vu2 = sm.vec[1];
+  stage<T, NP, NW>(TG, ttg + s * NN, N);
+  stage<T, NP, NW>(R, r + s * NN, N);
+  stage<T, NP, NW>(Tt, t + s * NN, N);
+  if (tid < NP) {
+    vu[tid] = (tid < N) ? u[s * N + tid] : T(0);
+    vu2[tid] = (tid < N) ? u2[s * N + tid] : T(0);
+  }
+  if (tid == 0) {
+    const T e = expk[s];
+    expk[s] = e * e;
+  }
+  __syncthreads();
+  {
+    const int row = tid / C::TPR;
+    T y1, y2;
+    matvec2<T, NP, NW>(TG, vu2, vu, y1, y2);
+    if (row < N && (tid % C::TPR) == 0) {
+      j0m[s * N + row] += y1;
+      j0p[s * N + row] = j1p[s * N + row] + y2;
+    }
+  }
+  const auto ident = [](T a, int, int, T) { return a; };
+  acc_block<T, NP, NW> accM, accT;
+  accM.zero();
+  mm_ll<T, NP, NW>(accM, TG, R, Kend);    // ttg r
+  acc_store<T, NP, NW>(W, accM, ident);
+  accT.zero();
+  mm_ll<T, NP, NW>(accT, TG, Tt, Kend);   // t' = ttg t
+  __syncthreads();
+  accM.zero();
+  mm_ll<T, NP, NW>(accM, W, Tt, Kend);    // (ttg r) t
+  __syncthreads();   // ttg, t and ttg r have been read by every wave
+  acc_store<T, NP, NW>(TG, accM, [=](T a, int rr, int c, T) { return a + R[lidx<NP>(rr, c)]; });
+  acc_store<T, NP, NW>(W, accT, ident);
+  __syncthreads();
+  lds_to_global<T, NP, NW>(r + s * NN, TG, N);
+  lds_to_global<T, NP, NW>(t + s * NN, W, N);
+}
+
+// ---------------------------------------------------------------------------
 // Rotational-Raman doubling, inelastic part of ONE doubling step for all Raman lines of one recipient point
 // (doubling_inelastic.jl:62-123: the two `for dn` loops), N <= 30.
 // One workgroup per recipient point n1 walks the lines dn; per line the ten N^3 products
@@ -1537,6 +1679,44 @@ int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, lo
 
 // inelastic part of one Raman doubling step (all lines); VSM_ERR_UNSUPPORTED for N > 30 (callers use the operator-level chain)
 template <typename T>
+int raman_elastic_pre(int N, int S, const T* r, const T* t, const T* j0p, const T* j0m, const T* expk, T* ttg, T* gt, T* gr,
+                      T* grt, T* j1p, T* j1m, T* u, T* u2, T* tmp1, T* tmp2, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+  if (off || N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
+  return dispatch_np<T>(N, [&](auto tag) {
+    constexpr int NP = decltype(tag)::value;
+    constexpr int NW = 4;
+    auto kern = k_raman_elastic_pre<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
+    static int prepared = enable_lds(kern, bytes);
+    if (prepared) return prepared;
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, r, t, j0p, j0m, expk, ttg, gt, gr, grt, j1p, j1m,
+                       u, u2, tmp1, tmp2);
+    VSM_LAUNCH_CHECK("k_raman_elastic_pre");
+    return (int)VSM_OK;
+  });
+}
+template <typename T>
+int raman_elastic_post(int N, int S, T* r, T* t, const T* ttg, const T* u, const T* u2, const T* j1p, T* j0p, T* j0m,
+                       T* expk, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+  if (off || N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
+  return dispatch_np<T>(N, [&](auto tag) {
+    constexpr int NP = decltype(tag)::value;
+    constexpr int NW = 4;
+    auto kern = k_raman_elastic_post<T, NP, NW>;
+    const size_t bytes = sizeof(fsmem<T, NP, NW>);
+    static int prepared = enable_lds(kern, bytes);
+    if (prepared) return prepared;
+    hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, r, t, ttg, u, u2, j1p, j0p, j0m, expk);
+    VSM_LAUNCH_CHECK("k_raman_elastic_post");
+    return (int)VSM_OK;
+  });
+}
+
+template <typename T>
 int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
                          const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,
                          T* ieJp, T* ieJm, hipStream_t st) {
@@ -1572,6 +1752,9 @@ int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_p
                                            const T*, const T*, long long, const added<T>&, hipStream_t);           \
   template int fused_interaction<T>(int, int, int, const composite<T>&, const added<T>&, hipStream_t);              \
   template int inv_one_minus_product<T>(int, int, const T*, long long, const T*, long long, T*, hipStream_t);       \
+  template int raman_elastic_pre<T>(int, int, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*, T*, T*, T*, \
+                                    T*, T*, T*, hipStream_t);                                                        \
+  template int raman_elastic_post<T>(int, int, T*, T*, const T*, const T*, const T*, const T*, T*, T*, T*, hipStream_t); \
   template int raman_doubling_lines<T>(int, int, int, const int*, const T*, const T*, const T*, const T*, const T*, \
                                        const T*, const T*, const T*, const T*, const T*, const T*, T*, T*, T*, T*,  \
                                        hipStream_t);                                                                \

@@ -166,7 +166,15 @@ struct rs_ia_pass {
 };
 template <typename T>
 int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st);
-// one wave per Raman line (vsm_raman_wave.hip): FP64, N <= 30
+// elastic part of one Raman doubling step, LDS-resident per spectral point (vsm_fused.hip); VSM_ERR_UNSUPPORTED past the
+// on-chip limit
+template <typename T>
+int raman_elastic_pre(int N, int S, const T* r, const T* t, const T* j0p, const T* j0m, const T* expk, T* ttg, T* gt, T* gr,
+                      T* grt, T* j1p, T* j1m, T* u, T* u2, T* tmp1, T* tmp2, hipStream_t st);
+template <typename T>
+int raman_elastic_post(int N, int S, T* r, T* t, const T* ttg, const T* u, const T* u2, const T* j1p, T* j0p, T* j0m,
+                       T* expk, hipStream_t st);
+// one wave per Raman line (vsm_raman_wave.hip): FP64, N <= 24
 int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,

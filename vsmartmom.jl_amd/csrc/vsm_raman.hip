@@ -344,22 +344,29 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
 #define G4(M_, Nc_, A_, B_, C_, D_) if ((rc = gemm_rs<T>(M_, Nc_, N, S, K, shift, A_, B_, C_, D_, st))) return rc
   const dim3 gv((unsigned)((pv + 255) / 256));
   for (int n = 0; n < ndoubl; ++n) {
-    // gp = (I - r r)^-1 ; ttg = t gp
-    if ((rc = inv_one_minus<T>(N, S, a.r_mp, NN, a.r_mp, NN, gp, tM, st))) return rc;
-    G3(N, N, N, S, a.t_pp, NN, gp, NN, ttg, NN, one, nul, 0, zero, zero);
-    // J1+- = J0+- expk
-    hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_p, j1p);
-    hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_m, j1m);
-    VSM_LAUNCH_CHECK("k_scale_vec");
-    // tmp1 = gp (J0+ + r J1-) ; tmp2 = gp (J1- + r J0+)
-    G3(N, 1, N, S, a.r_mp, NN, j1m, N, u, N, one, a.j0_p, N, one, zero);
-    G3(N, 1, N, S, gp, NN, u, N, tmp1, N, one, nul, 0, zero, zero);
-    G3(N, 1, N, S, a.r_mp, NN, a.j0_p, N, u2, N, one, j1m, N, one, zero);
-    G3(N, 1, N, S, gp, NN, u2, N, tmp2, N, one, nul, 0, zero, zero);
-    // gt = gp t ; gr = gp r ; grt = gr t   (old r, t)
-    G3(N, N, N, S, gp, NN, a.t_pp, NN, gt, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
+    // elastic operands of the step: one LDS-resident launch per point, else the operator chain
+    rc = raman_elastic_pre<T>(N, S, a.r_mp, a.t_pp, a.j0_p, a.j0_m, expk, ttg, gt, gr, grt, j1p, j1m, u, u2, tmp1, tmp2, st);
+    const bool fused_elastic = rc == VSM_OK;
+    if (rc == VSM_ERR_UNSUPPORTED) {
+      // gp = (I - r r)^-1 ; ttg = t gp
+      if ((rc = inv_one_minus<T>(N, S, a.r_mp, NN, a.r_mp, NN, gp, tM, st))) return rc;
+      G3(N, N, N, S, a.t_pp, NN, gp, NN, ttg, NN, one, nul, 0, zero, zero);
+      // J1+- = J0+- expk
+      hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_p, j1p);
+      hipLaunchKernelGGL(k_scale_vec<T>, gv, dim3(256), 0, st, N, S, expk, a.j0_m, j1m);
+      VSM_LAUNCH_CHECK("k_scale_vec");
+      // tmp1 = gp (J0+ + r J1-) ; tmp2 = gp (J1- + r J0+)
+      G3(N, 1, N, S, a.r_mp, NN, j1m, N, u, N, one, a.j0_p, N, one, zero);
+      G3(N, 1, N, S, gp, NN, u, N, tmp1, N, one, nul, 0, zero, zero);
+      G3(N, 1, N, S, a.r_mp, NN, a.j0_p, N, u2, N, one, j1m, N, one, zero);
+      G3(N, 1, N, S, gp, NN, u2, N, tmp2, N, one, nul, 0, zero, zero);
+      // gt = gp t ; gr = gp r ; grt = gr t   (old r, t)
+      G3(N, N, N, S, gp, NN, a.t_pp, NN, gt, NN, one, nul, 0, zero, zero);
+      G3(N, N, N, S, gp, NN, a.r_mp, NN, gr, NN, one, nul, 0, zero, zero);
+      G3(N, N, N, S, gr, NN, a.t_pp, NN, grt, NN, one, nul, 0, zero, zero);
+    } else if (rc) {
+      return rc;
+    }
     // ---- inelastic recurrences of this step (they read the OLD elastic r, t, J0+, expk) -------------------------------
     rc = VSM_ERR_UNSUPPORTED;
     if constexpr (std::is_same<T, double>::value)   // FP64, N <= 30: one wave per line, operands in registers
@@ -405,16 +412,21 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
     } else if (rc) {
       return rc;
     }
-    // J0- += ttg (J1- + r J0+) ; J0+ = J1+ + ttg (J0+ + r J1-)      (u2, u from above: old J0+)
-    G3(N, 1, N, S, ttg, NN, u2, N, a.j0_m, N, one, a.j0_m, N, one, zero);
-    G3(N, 1, N, S, ttg, NN, u, N, a.j0_p, N, one, j1p, N, one, zero);
-    hipLaunchKernelGGL(k_square_v<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
-    VSM_LAUNCH_CHECK("k_square_v");
-    // r <- r + ttg r t ; t <- ttg t
-    G3(N, N, N, S, ttg, NN, a.r_mp, NN, tM, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, ttg, NN, a.t_pp, NN, tM2, NN, one, nul, 0, zero, zero);
-    G3(N, N, N, S, tM, NN, a.t_pp, NN, a.r_mp, NN, one, a.r_mp, NN, one, zero);
-    if ((rc = copy_strided<T>(per, 1, tM2, 0, a.t_pp, st))) return rc;
+    rc = fused_elastic ? raman_elastic_post<T>(N, S, a.r_mp, a.t_pp, ttg, u, u2, j1p, a.j0_p, a.j0_m, expk, st) : VSM_ERR_UNSUPPORTED;
+    if (rc == VSM_ERR_UNSUPPORTED) {
+      // J0- += ttg (J1- + r J0+) ; J0+ = J1+ + ttg (J0+ + r J1-)      (u2, u from above: old J0+)
+      G3(N, 1, N, S, ttg, NN, u2, N, a.j0_m, N, one, a.j0_m, N, one, zero);
+      G3(N, 1, N, S, ttg, NN, u, N, a.j0_p, N, one, j1p, N, one, zero);
+      hipLaunchKernelGGL(k_square_v<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, expk);
+      VSM_LAUNCH_CHECK("k_square_v");
+      // r <- r + ttg r t ; t <- ttg t
+      G3(N, N, N, S, ttg, NN, a.r_mp, NN, tM, NN, one, nul, 0, zero, zero);
+      G3(N, N, N, S, ttg, NN, a.t_pp, NN, tM2, NN, one, nul, 0, zero, zero);
+      G3(N, N, N, S, tM, NN, a.t_pp, NN, a.r_mp, NN, one, a.r_mp, NN, one, zero);
+      if ((rc = copy_strided<T>(per, 1, tM2, 0, a.t_pp, st))) return rc;
+    } else if (rc) {
+      return rc;
+    }
   }
   const dim3 gm((unsigned)((NN + 255) / 256), S);
   hipLaunchKernelGGL(k_apply_D_batch<T>, gm, dim3(256), 0, st, N, ns, a.r_mp, a.t_pp, a.r_pm, a.t_mm, a.j0_m);
