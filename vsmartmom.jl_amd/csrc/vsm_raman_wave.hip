@@ -493,18 +493,22 @@ __device__ __forceinline__ void units(G&& g) {
     static_for<k * U / n, (k + 1) * U / n>(g);
   }
 }
+// the 2 KS left-operand fragments of a product; requested during the previous product (units of its side work)
+template <int KS>
+struct afrag {
+  double v[KS][2];
+};
+template <int KS, int u>
+__device__ __forceinline__ void af_rd(afrag<KS>& f, const double* a0) {   // a0 = image + kq + WLD l15
+  constexpr int i = u >> 1, t = u & 1;
+  f.v[i][t] = a0[16 * (i >> 2) + 4 * (i & 3) + WLD * 16 * t];
+}
 template <int KS, typename F>
-__device__ __forceinline__ void w_mm_s(wmat& acc, const double* A, const wmat& B, const wpos& p, F&& side) {
-  const double* a0 = A + p.kq + WLD * p.l15;
-  double af[KS][2];
-#pragma unroll
-  for (int i = 0; i < KS; ++i)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) af[i][t] = a0[16 * (i >> 2) + 4 * (i & 3) + WLD * 16 * t];
+__device__ __forceinline__ void w_mm_s(wmat& acc, const afrag<KS>& af, const wmat& B, F&& side) {
   static_for<0, 2 * KS>([&](auto slot) {
     constexpr int s = decltype(slot)::value, i = s >> 1, t = s & 1, a = i >> 2, r = i & 3;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc.v[t][b] = mfma<double>::mma(af[i][t], B.v[a][b][r], acc.v[t][b]);
+    for (int b = 0; b < 2; ++b) acc.v[t][b] = mfma<double>::mma(af.v[i][t], B.v[a][b][r], acc.v[t][b]);
     RW_PIN();
     side(slot);
     RW_PIN();
@@ -564,7 +568,11 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
   const int vp32 = vin ? 32 + WLD * lane : vdummy, vp33 = vin ? 33 + WLD * lane : vdummy;
   const int vpA = vin ? cA + WLD * lane : vdummy, vpB = vin ? cB + WLD * lane : vdummy;
   // accumulator-layout base offsets of the images
-  const int wofs = p.l15 + WLD * p.kq, vofs = WLD * p.kq;
+  const int wofs = p.l15 + WLD * p.kq, vofs = WLD * p.kq, aofs = p.kq + WLD * p.l15;
+  afrag<KS> afA, afB;   // fragments of the current / next product's left operand
+  auto af_units = [&](afrag<KS>& f, const double* img) {
+    return [&f, img, aofs](auto u) { af_rd<KS, decltype(u)::value>(f, img + aofs); };
+  };
   auto o4_of = [&](int dd) { return ((long long)n1 + (long long)S * dd) * NN; };
   auto o4v_of = [&](int dd) { return ((long long)n1 + (long long)S * dd) * N; };
   auto issue_ier = [&](int dd) {
@@ -618,6 +626,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     issue_t0(d);
     static_for<0, 2 * NF + 5>(head_units_a);
     static_for<0, NF + 18>(head_units_b);
+    static_for<0, 2 * KS>(af_units(afA, IERa));
   }
   while (d < K) {
     const long long o4 = o4_of(d), o4v = o4v_of(d);
@@ -627,14 +636,16 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     cvec cJp, cJm, cJ1m, cJpe, a3, a4;
     // P1: X = ier r0                                   | read ier (seed of ier', right operand of r1 ier) ; read iet + riders
     w_zero(X);
-    w_mm_s<KS>(X, IERa, Br0, p, [&](auto sl) {
+    w_mm_s<KS>(X, afA, Br0, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, H, SL, s>(af_units(afB, R1a));
       units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(O2, IERa + wofs); });
       units<16, H, SL, s>([&](auto u) { w_rd<decltype(u)::value>(Biet, IETa + wofs); });
     });
     // P2: X += r1 ier                                  | stage gt0 (+ riders tmp1, 0) ; read it back
-    w_mm_s<KS>(X, R1a, O2, p, [&](auto sl) {
+    w_mm_s<KS>(X, afB, O2, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, H, SL, s>(af_units(afA, IETa));
       units<NF + 2, 0, H, s>([&](auto u) {
         constexpr int k = decltype(u)::value;
         if constexpr (k < NF) STa[ix.aidx[k]] = fGT.f[k];
@@ -645,7 +656,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     });
     // P3: r1 iet (+ riders r1 iej1-, r1 iej0+)        | image of X ; stage gr0 (+ rider tmp2)
     w_zero(R1IET);
-    w_mm_s<KS>(R1IET, R1a, Biet, p, [&](auto sl) {
+    w_mm_s<KS>(R1IET, afB, Biet, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
       units<16, 0, H, s>([&](auto u) { w_wr<decltype(u)::value>(Xa + wofs, X); });
       units<NF + 1, H, SL, s>([&](auto u) {
@@ -656,15 +667,16 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     });
     // P4: iet gt0 (column N: iet tmp1)                 | read gr0 ; stage grt0 (rider column still tmp2) ; next gt0, gr0
     w_zero(O1);
-    w_mm_s<KS>(O1, IETa, Bgt, p, [&](auto sl) {
+    w_mm_s<KS>(O1, afA, Bgt, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, H, SL, s>(af_units(afB, Xa));
       units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(Bgr, STa + wofs); });
       units<NF, H, SL, s>([&](auto u) { STa[ix.aidx[decltype(u)::value]] = fGRT.f[decltype(u)::value]; });
       if constexpr (s == SL - 1) issue_gt_gr(dpre);
     });
     // P5: X gt0 (column N: X tmp1)                     | read grt0 ; next grt0
     w_zero(W1);
-    w_mm_s<KS>(W1, Xa, Bgt, p, [&](auto sl) {
+    w_mm_s<KS>(W1, afB, Bgt, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
       units<16, 0, H, s>([&](auto u) { w_rd<decltype(u)::value>(Bgrt, STa + wofs); });
       if constexpr (s == SL - 1) issue_grt(dpre);
@@ -673,7 +685,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     w_zero(WA);
     wmat Tiet, Tier;
     cvec w1A;
-    w_mm_s<KS>(WA, Xa, Bgr, p, [&](auto sl) {
+    w_mm_s<KS>(WA, afB, Bgr, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
       if constexpr (s == 0) w1A = w_col<cA>(W1);   // X tmp1, before the riders of iet are added
       units<64, 0, H, s>([&](auto u) {
@@ -694,8 +706,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
       if constexpr (s == SL - 1) issue_ier(dpre);
     });
     // P7: ier + iet grt0 (column N: iet tmp2)          | a3, W1 column N ; WA += ier, a4 ; image of WA ; read t0 ; next t0, iet
-    w_mm_s<KS>(O2, IETa, Bgrt, p, [&](auto sl) {
+    w_mm_s<KS>(O2, afA, Bgrt, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, 0, H, s>(af_units(afB, TTGa));
       if constexpr (s == 0) {
         // W1 column N = a3 = iej0+ + r1 iej1- + ier j1- + X tmp1
         const cvec q1 = w_col<cA>(R1IET), q2 = w_col<cA>(X);
@@ -736,14 +749,15 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
       }
     });
     // P8: iet' = iet gt0 + ttg1 W1 (column N: ttg1 a3 + iet tmp1)     | next r0
-    w_mm_s<KS>(O1, TTGa, W1, p, [&](auto sl) {
+    w_mm_s<KS>(O1, afB, W1, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, H, SL, s>(af_units(afA, Xa));
       if constexpr (s == SL - 1) issue_r0(dpre);
     });
     // P9: W3 = r1 iet + WA t0                           | image of iet' (+ ieJ0+' into a pad column), its coalesced store
     flat<N> fOut;
     double vOut = 0.0;
-    w_mm_s<KS>(R1IET, Xa, Bt0, p, [&](auto sl) {
+    w_mm_s<KS>(R1IET, afA, Bt0, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
       units<17, 0, H, s>([&](auto u) {
         constexpr int k = decltype(u)::value;
@@ -776,8 +790,9 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     });
     w_set_col<cA>(R1IET, a4, p);   // W3 column N = a4
     // P10: ier' = ier + iet grt0 + ttg1 W3 (column N: ttg1 a4 + iet tmp2)    | first phase of the next line
-    w_mm_s<KS>(O2, TTGa, R1IET, p, [&](auto sl) {
+    w_mm_s<KS>(O2, afB, R1IET, [&](auto sl) {
       constexpr int s = decltype(sl)::value;
+      units<2 * KS, H, SL, s>(af_units(afA, IERa));
       units<2 * NF + 5, 0, H, s>(head_units_a);
       units<NF + 18, H, SL, s>(head_units_b);
     });
