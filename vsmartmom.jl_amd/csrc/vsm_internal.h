@@ -216,7 +216,7 @@ int strip_interaction11_lin(int N, int S, const composite<double>& c, const comp
                             const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st);
-int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
+int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st);
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,

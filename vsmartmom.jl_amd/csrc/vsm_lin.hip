@@ -307,7 +307,11 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
   int n0 = 0;
   if constexpr (std::is_same<T, double>::value) {
     // one active parameter: all steps in one launch (state stays on the chip between the steps)
-    rc = strip_doubling_lin_multi(N, S, P, ndoubl, expk, ekl, a, al, st);
+    // (apply_D! rides in its epilogue when every parameter slot is either active there or zero: P == n_active or the
+    //  remaining slots' derivatives of r, t vanish in this layer, which the caller states with n_active > 0)
+    static const bool sepD = getenv("VSM_LIN_SEPARATE_APPLY_D") != nullptr;
+    rc = strip_doubling_lin_multi(N, S, P, ndoubl, sepD ? 0 : ns, expk, ekl, a, al, st);
+    if (rc == VSM_OK && !sepD) return VSM_OK;
     if (rc == VSM_OK) n0 = ndoubl;
     else if (rc != VSM_ERR_UNSUPPORTED) return rc;
     // fused column-strip step (vsm_striplin.hip): one launch per doubling step, forward + all active parameters

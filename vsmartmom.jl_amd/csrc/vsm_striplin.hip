@@ -384,8 +384,8 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
 // memory (the per-step kernel spends ~30 % of its time there) and seven of eight launches.
 // ---------------------------------------------------------------------------
 template <int KS, int PA>
-__global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, double* __restrict__ expk, double* __restrict__ ekl,
-                                                          added<double> a, added_lin<double> al) {
+__global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, int ns, double* __restrict__ expk,
+                                                          double* __restrict__ ekl, added<double> a, added_lin<double> al) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   lsmem& sm = *reinterpret_cast<lsmem*>(smem_raw);
   double* BR = sm.BR;
@@ -544,20 +544,59 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
     __syncthreads();   // everybody is done reading BR, BT, BX, BY of this step
     if (n + 1 < nd) store_strip(BR, r_new, p, keepN);
   }
-  store_strip_global_c(g_r, r_new, N, p, xw);
-  store_strip_global_c(g_t, t_s, N, p, xw);
+  // apply_D! with derivative slots (doubling_lin.jl:374-421) on the way out when ns > 0: r-+ gets its U,V rows negated,
+  // r+- = D r-+ D and t-- = D t++ D are derived (also for the derivatives; the slots of the inactive parameters are zero)
+  const bool uj = ns > 0 && is_uv_row(p.col, ns);
+  auto dsign = [&](const sstrip& x, sstrip& rowflip, sstrip& both, bool flip) {
 #pragma unroll
-  for (int pp = 0; pp < PA; ++pp) {
-    store_strip_global_c(al.ap_r_mp + pp * MS + (long long)s * NN, rd_s[pp], N, p, xw);
-    store_strip_global_c(al.ap_t_pp + pp * MS + (long long)s * NN, td_s[pp], N, p, xw);
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ui = is_uv_row(p.row(ta, r), ns);
+        const double v = (flip && ui) ? -x.v[ta][r] : x.v[ta][r];
+        rowflip.v[ta][r] = v;
+        both.v[ta][r] = (ui == uj) ? v : -v;
+      }
+  };
+  if (ns > 0) {
+    sstrip f, b;
+    dsign(r_new, f, b, true);
+    store_strip_global_c(g_r, f, N, p, xw);
+    store_strip_global_c(a.r_pm + (long long)s * NN, b, N, p, xw);
+    dsign(t_s, f, b, false);
+    store_strip_global_c(g_t, f, N, p, xw);
+    store_strip_global_c(a.t_mm + (long long)s * NN, b, N, p, xw);
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) {
+      dsign(rd_s[pp], f, b, true);
+      store_strip_global_c(al.ap_r_mp + pp * MS + (long long)s * NN, f, N, p, xw);
+      store_strip_global_c(al.ap_r_pm + pp * MS + (long long)s * NN, b, N, p, xw);
+      dsign(td_s[pp], f, b, false);
+      store_strip_global_c(al.ap_t_pp + pp * MS + (long long)s * NN, f, N, p, xw);
+      store_strip_global_c(al.ap_t_mm + pp * MS + (long long)s * NN, b, N, p, xw);
+    }
+    f.zero();
+    for (int pp = PA; pp < al.P; ++pp) {
+      store_strip_global_c(al.ap_r_pm + pp * MS + (long long)s * NN, f, N, p, xw);
+      store_strip_global_c(al.ap_t_mm + pp * MS + (long long)s * NN, f, N, p, xw);
+    }
+  } else {
+    store_strip_global_c(g_r, r_new, N, p, xw);
+    store_strip_global_c(g_t, t_s, N, p, xw);
+#pragma unroll
+    for (int pp = 0; pp < PA; ++pp) {
+      store_strip_global_c(al.ap_r_mp + pp * MS + (long long)s * NN, rd_s[pp], N, p, xw);
+      store_strip_global_c(al.ap_t_pp + pp * MS + (long long)s * NN, td_s[pp], N, p, xw);
+    }
   }
   if (tid < N) {   // (the vectors were last written by the owning wave before the final barrier of the loop)
+    const double sg = (ns > 0 && is_uv_row(tid, ns)) ? -1.0 : 1.0;
     a.j0_p[(long long)s * N + tid] = jp[tid];
-    a.j0_m[(long long)s * N + tid] = jm[tid];
+    a.j0_m[(long long)s * N + tid] = sg * jm[tid];
 #pragma unroll
     for (int pp = 0; pp < PA; ++pp) {
       al.ap_J0_p[pp * VS + (long long)s * N + tid] = sm.vec[2 + 2 * pp][tid];
-      al.ap_J0_m[pp * VS + (long long)s * N + tid] = sm.vec[3 + 2 * pp][tid];
+      al.ap_J0_m[pp * VS + (long long)s * N + tid] = sg * sm.vec[3 + 2 * pp][tid];
     }
   }
   if (tid == 0) {
@@ -822,7 +861,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
 #define VSM_STRIPLIN_DECL(KS)                                                                                                      \
   int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t); \
   int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);                                                \
-  int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
+  int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIPLIN_DECL(VSM_STRIP_KS)
@@ -839,7 +878,7 @@ int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* exp
   return VSM_OK;
 }
 
-int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, double* expk, double* ekl, const added<double>& a,
+int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                                                  const added_lin<double>& al, hipStream_t st) {
   static int prepared = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 1>),
@@ -854,11 +893,11 @@ int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, d
   }();
   if (prepared) return prepared;
   if (PA == 1)
-    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 1>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 1>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, ns, expk, ekl, a, al);
   else if (PA == 2)
-    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 2>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 2>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, ns, expk, ekl, a, al);
   else
-    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 3>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, expk, ekl, a, al);
+    hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 3>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, ns, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_multi");
   return VSM_OK;
 }
@@ -909,8 +948,9 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
   }
 }
 
-// All ndoubl doubling steps in one launch (one to three active parameters); VSM_ERR_UNSUPPORTED otherwise.
-int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
+// All ndoubl doubling steps in one launch (one to three active parameters), apply_D! included when ns (n_stokes) > 0;
+// VSM_ERR_UNSUPPORTED otherwise.
+int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st) {
   static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_LIN_MULTI") != nullptr;
   if (off || P < 1 || P > 3 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
@@ -918,7 +958,7 @@ int strip_doubling_lin_multi(int N, int S, int P, int nd, double* expk, double* 
   switch ((N + 3) / 4) {
 #define VSM_CASE(KS) \
   case KS:           \
-    return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, P, nd, expk, ekl, a, al, st);
+    return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, P, nd, ns, expk, ekl, a, al, st);
     VSM_CASE(9)
     VSM_CASE(10)
     VSM_CASE(11)
