@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 rocprofv3 evidence (run on the GPU box through gpurun): stats + PMC passes for the kernels VERDICT r01 names.
-# usage: tools/profile_r02.sh [c2|c4|lin|raman ...]
+# usage: tools/profile_r02.sh [c2|c4|lin|raman|ia ...]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for w in "$@"; do
@@ -10,6 +10,7 @@ for w in "$@"; do
     c4)    python tools/profile_any.py --out gpurun_out/prof_r02_c4 --dtype f32 -- python bench.py --config C4 --points 4096 --steps 1 --warmup 0 --no-cpu-baseline ;;
     c4full) python tools/profile_any.py --skip-pmc --out gpurun_out/prof_r02_c4_default -- python bench.py --config C4 --no-cpu-baseline ;;
     lin)   python tools/profile_any.py --out gpurun_out/prof_r02_lin --dtype f64 -- python tools/lin_timing.py --points 2048 ;;
+    ia)    python tools/profile_any.py --out gpurun_out/prof_r02_ia --dtype f64 -- python tools/ia_timing.py --points 4096 --refl 0.1 ;;
     raman) python tools/profile_any.py --out gpurun_out/prof_r02_raman --dtype f64 -- python tools/raman_timing.py --points 4000 ;;
   esac
 done
