@@ -142,10 +142,10 @@ def test_elemental_inelastic(vsm, arch, FT, pol, m, ndmode):
 
 
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
-# N = 4, 7, 11, 16, 19, 21, 24: one wave per line (vsm_raman_wave.hip, k-step counts 1..6); 27: one workgroup per point;
-# 63: operator chain
+# FP64 N = 4, 7, 11, 16, 19, 21, 24, 27, 30: one wave per line (vsm_raman_wave.hip, k-step counts 1..8; pipelined body up to 24);
+# FP32 N <= 30: one workgroup per point; 63: operator chain
 @pytest.mark.parametrize("pol,l_trunc", [("I", 1), ("I", 7), ("I", 15), ("I", 25), ("I", 31), ("IQU", 7), ("IQU", 9),
-                                         ("IQU", 11), ("IQU", 35)])
+                                         ("IQU", 11), ("IQU", 13), ("IQU", 35)])
 def test_doubling_inelastic(vsm, arch, FT, pol, l_trunc):
     S = 14 if l_trunc < 20 else 9
     c = _setup(vsm, arch, FT, pol, S=S, l_trunc=l_trunc, seed=3)
@@ -190,7 +190,7 @@ def _random_composite(c, FT, rng):
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
 @pytest.mark.parametrize("pol,l_trunc,surface", [("I", 1, False), ("I", 7, False), ("I", 15, False), ("I", 25, False),
                                                  ("I", 31, True), ("IQU", 7, False), ("IQU", 7, True), ("IQU", 9, False),
-                                                 ("IQU", 11, False), ("IQU", 35, False)])
+                                                 ("IQU", 11, False), ("IQU", 13, True), ("IQU", 35, False)])
 def test_interaction_inelastic(vsm, arch, FT, pol, l_trunc, surface):
     CR, RR = vsm.CoreRT, vsm.CoreRTRaman
     S = 14 if l_trunc < 20 else 9

@@ -174,7 +174,7 @@ int raman_elastic_pre(int N, int S, const T* r, const T* t, const T* j0p, const 
 template <typename T>
 int raman_elastic_post(int N, int S, T* r, T* t, const T* ttg, const T* u, const T* u2, const T* j1p, T* j0p, T* j0m,
                        T* expk, hipStream_t st);
-// one wave per Raman line (vsm_raman_wave.hip): FP64, N <= 24
+// one wave per Raman line (vsm_raman_wave.hip): FP64, N <= 30
 int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,

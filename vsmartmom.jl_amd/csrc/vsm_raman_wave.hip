@@ -1,4 +1,4 @@
-// Rotational-Raman inelastic doubling step and interaction pass -- ONE WAVE PER RAMAN LINE (FP64, N <= 24).
+// Rotational-Raman inelastic doubling step and interaction pass -- ONE WAVE PER RAMAN LINE (FP64, N <= 30).
 //
 // doubling_inelastic.jl:62-123 (the two `for dn` loops of doubling_helper!(::RRS, ...)).  Per (recipient point n1,
 // line dn; donor n0 = n1 + shift[dn]) the step is ten 32 x 32 x Kend products plus eight mat-vecs:
@@ -55,7 +55,8 @@ constexpr int WLD = 34;            // k-major row pitch: conflict-free ds_read_b
 constexpr int WIMG = 32 * WLD;     // doubles per image
 constexpr int RW_WAVES = 4;
 constexpr int RW_PRIV = 4;         // private images per wave
-constexpr int RW_MAXN = 24;
+constexpr int RW_MAXN = 30;      // (rider columns N, N+1 must exist; rows 30, 31 of the pad columns take the stray lanes)
+constexpr int RW_MAXN_SP = 24;   // software-pipelined doubling body: beyond, its blocks in flight spill
 
 struct wmat {
   d4_t v[2][2];  // [row tile][column tile]; element r of a tile: row 16 a + kq + 4 r, column 16 b + l15
@@ -179,7 +180,7 @@ __device__ __forceinline__ void f_index(flat_idx<N>& ix, int lane) {
 #pragma unroll
   for (int j = 0; j < F::NF; ++j) {
     const int e = lane + 64 * j, ec = min(e, F::NN - 1), col = ec / N;
-    ix.aidx[j] = (e < F::NN) ? col + WLD * (ec - col * N) : 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+    ix.aidx[j] = (e < F::NN) ? col + WLD * (ec - col * N) : 32 + (lane & 1) + WLD * (30 + ((lane >> 1) & 1));
   }
   ix.etail = min(lane, F::TAIL - 1) + 64 * (F::NF - 1);
 }
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
   const int vl = vin ? lane : 0;
   // per-lane image positions of the vector / rider stores; the lanes >= N write to an unused pad word, so the loop body
   // has no divergent branches and stays one scheduling region
-  const int vdummy = 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+  const int vdummy = 32 + (lane & 1) + WLD * (30 + ((lane >> 1) & 1));
   const int vp32 = vin ? 32 + WLD * lane : vdummy, vp33 = vin ? 33 + WLD * lane : vdummy;
   const int vpA = vin ? cA + WLD * lane : vdummy, vpB = vin ? cB + WLD * lane : vdummy;
   auto issue_ier = [&](int dd) {
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
   double vJp = 0.0, vJm = 0.0, vj1m = 0.0, vjp0 = 0.0, vt1 = 0.0, vt2 = 0.0, e0 = 0.0;
   const bool vin = lane < N;
   const int vl = vin ? lane : 0;
-  const int vdummy = 32 + (lane & 1) + WLD * (25 + ((lane >> 1) % 7));
+  const int vdummy = 32 + (lane & 1) + WLD * (30 + ((lane >> 1) & 1));
   const int vp32 = vin ? 32 + WLD * lane : vdummy, vp33 = vin ? 33 + WLD * lane : vdummy;
   const int vpA = vin ? cA + WLD * lane : vdummy, vpB = vin ? cB + WLD * lane : vdummy;
   // accumulator-layout base offsets of the images
@@ -982,13 +983,21 @@ int launch_rw(int S, int K, const int* shift, const double* r, const double* t, 
               const double* gr, const double* grt, const double* jp, const double* j1m, const double* tmp1,
               const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, hipStream_t st) {
   static const bool plain = getenv("VSM_RAMAN_WAVE_PLAIN") != nullptr;   // the unpipelined body (A/B)
-  auto kern = plain ? k_raman_doubling_wave<N> : k_raman_doubling_wave_sp<N>;
+  void (*kern)(int, int, const int*, const double*, const double*, const double*, const double*, const double*, const double*,
+               const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*) =
+      k_raman_doubling_wave<N>;
+  if constexpr (N <= RW_MAXN_SP) {
+    if (!plain) kern = k_raman_doubling_wave_sp<N>;
+  }
   static hipError_t prepared = [] {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave<N>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+    if constexpr (N <= RW_MAXN_SP) {
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+    }
+    return e;
   }();
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
@@ -1020,8 +1029,8 @@ int dispatch_n(int n, F f) {
 
 }  // namespace
 
-// FP64, N <= 24, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
-// chain).  N 25..30: the flat blocks in flight no longer fit the registers; K > 128: the line list is a 128-bit mask.
+// FP64, N <= 30, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
+// chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
