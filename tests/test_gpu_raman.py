@@ -274,6 +274,25 @@ def test_rt_run_rrs_end_to_end(vsm, arch, FT, pol, l_trunc, S):
     assert np.max(np.abs(ref[2])) > 1e-5
 
 
+@pytest.mark.parametrize("K", [100, 130])
+def test_rt_run_rrs_many_lines(vsm, arch, K):
+    """Line lists longer than one 64-bit ballot: K = 100 (both halves of the 128-bit line mask of the wave-per-line
+    kernels, most lines out of band at the edges) and K = 130 (past the mask: the workgroup-per-point kernels)."""
+    FT, S = np.float64, 40
+    om, pm = _raman_models(vsm, arch, "I", 7, S, 2, FT, m_max=1)
+    shifts = np.array([d for d in range(-(K // 2), K - K // 2 + 1) if d != 0])[:K]
+    rng = np.random.default_rng(4)
+    w_ie = (0.04 / K) * (0.5 + rng.random(K))
+    graman = O.get_greek_rayleigh(6.0 / 7.0 * 0.5)
+    ors = OR.RRS(i_shift=shifts, varpi_ie=w_ie, greek_raman=graman)
+    prs = vsm.CoreRTRaman.RRS(shifts, w_ie, vsm.host_model.GreekCoefs(**vars(graman)))
+    ref = OR.rt_run_rrs(om, ors)
+    got = vsm.CoreRTRaman.rt_run(prs, pm, 1)
+    for name, g, r in zip(("R", "T", "ieR", "ieT"), got, ref):
+        assert _rel(g, r) <= 1e-8, (name, _rel(g, r))
+    assert np.max(np.abs(ref[2])) > 1e-6
+
+
 def test_rt_run_rrs_perturbation_property_large(vsm, arch):
     """Size-independent property at S = 96, K = 7, N = 24: on a spectrally uniform atmosphere with the Raman phase
     matrix equal to the elastic one, ieR(n1) = dR/d(varpi_Cabannes) * sum of the in-band varpi_ie (first-order
