@@ -12,6 +12,7 @@
 // and skips pairs whose donor is out of band, so the launch count of a layer step does not depend on
 // the number of Raman lines.  Inelastic arrays are [N,N,S,K] column-major like the reference's.
 #include "vsm_internal.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace vsm {
@@ -548,6 +549,11 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   }
   // ---- elastic part last (every inelastic right-hand side above used the pre-update composite) -----
   (void)elastic_work_elems;
+  if (N <= fused_max_n<T>()) {   // LDS-resident k_interaction11 (one launch), else the operator chain
+    static const bool off = getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+    rc = off ? VSM_ERR_UNSUPPORTED : fused_interaction<T>(VSM_IFACE_11, N, S, c, a, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  }
   return interaction_generic<T>(VSM_IFACE_11, N, S, c, a, ework, st);
 }
 #undef G3
