@@ -356,8 +356,10 @@ atmospheric_profile: {T: [250.0, 275.0], p: [100.0, 500.0, 1000.0]}
     assert mc.surface == V.host_model.CoxMunkSurface(5.0, None, 0.22, True, False) and mc.m_max == 5   # user_l_cap = 2*3 - 1
     assert io.parse_surface("CoxMunkSurface(3.5)").wind_speed == 3.5
     assert io.parse_surface("CoxMunkSurface(wind_speed=4, n_water=1.34+0.01im)").n_water == complex(1.34, 0.01)
-    with pytest.raises(NotImplementedError):
-        io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", '"rpvSurfaceScalar(0.1, 0.2, 0.3, 0.4)"'))
+    prpv = io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", '"rpvSurfaceScalar(0.1, 0.2, 0.3, 0.4)"'))
+    assert isinstance(io.model_from_parameters(prpv, None).surface, V.host_model.rpvSurfaceScalar)
+    with pytest.raises(NotImplementedError):   # (the canopy surface is outside SURVEY 8)
+        io.parameters_from_yaml(text.replace("LambertianSurfaceScalar(0.15)", '"CanopySurface(LAI=3.0)"'))
     with pytest.raises(ValueError):
         io.parse_surface("CoxMunkSurface(n_water=1.33)")
     with pytest.raises(NotImplementedError):
