@@ -344,6 +344,8 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
 #define G3(...) if ((rc = gemm<T>(__VA_ARGS__, st))) return rc
 #define G4(M_, Nc_, A_, B_, C_, D_) if ((rc = gemm_rs<T>(M_, Nc_, N, S, K, shift, A_, B_, C_, D_, st))) return rc
   const dim3 gv((unsigned)((pv + 255) / 256));
+  static const bool sepD = getenv("VSM_RAMAN_SEPARATE_APPLY_D") != nullptr;
+  bool ie_D_done = false;   // apply_D! of the inelastic operators done by the last step's line kernel
   for (int n = 0; n < ndoubl; ++n) {
     // elastic operands of the step: one LDS-resident launch per point, else the operator chain
     rc = raman_elastic_pre<T>(N, S, a.r_mp, a.t_pp, a.j0_p, a.j0_m, expk, ttg, gt, gr, grt, j1p, j1m, u, u2, tmp1, tmp2, st);
@@ -372,7 +374,8 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
     rc = VSM_ERR_UNSUPPORTED;
     if constexpr (std::is_same<T, double>::value)   // FP64, N <= 30: one wave per line, operands in registers
       rc = raman_doubling_wave(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk, ie.ier_mp,
-                               ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);
+                               ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, (n == ndoubl - 1 && !sepD) ? ns : 0, ie.ier_pm, ie.iet_mm, st);
+    ie_D_done = rc == VSM_OK && n == ndoubl - 1 && !sepD;
     if (rc == VSM_ERR_UNSUPPORTED)
       rc = raman_doubling_lines<T>(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk,
                                    ie.ier_mp, ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, st);   // N <= 30: one workgroup per point
@@ -431,8 +434,10 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
   }
   const dim3 gm((unsigned)((NN + 255) / 256), S);
   hipLaunchKernelGGL(k_apply_D_batch<T>, gm, dim3(256), 0, st, N, ns, a.r_mp, a.t_pp, a.r_pm, a.t_mm, a.j0_m);
-  const dim3 gk((unsigned)((NN + 255) / 256), (unsigned)((long long)S * K));
-  hipLaunchKernelGGL(k_apply_D_batch<T>, gk, dim3(256), 0, st, N, ns, ie.ier_mp, ie.iet_pp, ie.ier_pm, ie.iet_mm, ie.ieJ0_m);
+  if (!ie_D_done) {
+    const dim3 gk((unsigned)((NN + 255) / 256), (unsigned)((long long)S * K));
+    hipLaunchKernelGGL(k_apply_D_batch<T>, gk, dim3(256), 0, st, N, ns, ie.ier_mp, ie.iet_pp, ie.ier_pm, ie.iet_mm, ie.ieJ0_m);
+  }
   VSM_LAUNCH_CHECK("k_apply_D_batch");
   return VSM_OK;
 }

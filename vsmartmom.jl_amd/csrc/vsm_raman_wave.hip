@@ -163,6 +163,14 @@ __device__ __forceinline__ void v_to_img(double* img, int col, const cvec& x, co
   }
 }
 
+// compile-time loop: g(integral_constant<int, i>) for i in [LO, HI)
+template <int LO, int HI, typename G>
+__device__ __forceinline__ void static_for(G&& g) {
+  if constexpr (LO < HI) {
+    g(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(g);
+  }
+}
 // ---- flat (coalesced) block <-> image copies; chunk j covers the elements lane + 64 j ------------------------------------------
 template <int N>
 struct flat {
@@ -206,6 +214,46 @@ __device__ __forceinline__ void img_to_global(double* __restrict__ g, const doub
   if (lane < F::TAIL) gl[64 * (F::NF - 1)] = img[ix.aidx[F::NF - 1]];
 }
 
+// apply_D! on the way out of the LAST doubling step (doubling_inelastic.jl:166-195): per flat chunk k, bit k of `flip`
+// says the element sits in a U/V row, bit k of `diff` that row and column differ in that property.
+struct dsign_masks {
+  unsigned flip, diff;
+  int ns;
+};
+template <int N>
+__device__ __forceinline__ dsign_masks d_masks(int ns, int lane) {
+  using F = flat<N>;
+  dsign_masks m{0u, 0u, ns};
+  if (ns > 0) {
+#pragma unroll
+    for (int j = 0; j < F::NF; ++j) {
+      const int e = min(lane + 64 * j, F::NN - 1), col = e / N, row = e - col * N;
+      const bool ui = is_uv_row(row, ns), uj = is_uv_row(col, ns);
+      m.flip |= (ui ? 1u : 0u) << j;
+      m.diff |= ((ui != uj) ? 1u : 0u) << j;
+    }
+  }
+  return m;
+}
+// chunk k of an output block: g[e] = (FLIP and U/V row) ? -v : v ; when this is the last step also the D-mirror gm[e]
+template <int N, int k, bool FLIP>
+__device__ __forceinline__ void out_chunk(double* __restrict__ g, double* __restrict__ gm, double v, const dsign_masks& m,
+                                          int lane) {
+  using F = flat<N>;
+  if (k < F::NF - 1 || lane < F::TAIL) {
+    const double a = (FLIP && ((m.flip >> k) & 1u)) ? -v : v;
+    g[lane + 64 * k] = a;
+    if (m.ns > 0) gm[lane + 64 * k] = ((m.diff >> k) & 1u) ? -a : a;
+  }
+}
+// out-of-band lines keep zero D-mirrors (the operator-level apply_D! writes every block)
+template <int N>
+__device__ __forceinline__ void zero_block(double* __restrict__ g, int lane) {
+  using F = flat<N>;
+#pragma unroll
+  for (int j = 0; j < F::NF; ++j)
+    if (j < F::NF - 1 || lane < F::TAIL) g[lane + 64 * j] = 0.0;
+}
 // the in-band lines of one wave (every RW_WAVES-th in-band line of the recipient point) as a 128-bit mask
 struct line_list {
   unsigned long long mine[2];
@@ -254,13 +302,14 @@ __device__ __forceinline__ void stage_shared(double* A1, const double* __restric
   for (int e = tid & 63; e < RW_PRIV * WIMG; e += 64) priv[e] = 0.0;
 }
 
-template <int N>
+template <int N, bool LAST>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
     int S, int K, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
     const double* __restrict__ ttg, const double* __restrict__ gt, const double* __restrict__ gr,
     const double* __restrict__ grt, const double* __restrict__ jp, const double* __restrict__ j1m,
     const double* __restrict__ tmp1, const double* __restrict__ tmp2, const double* __restrict__ expk, double* ier,
-    double* iet, double* ieJp, double* ieJm) {
+    double* iet, double* ieJp, double* ieJm, int ns_arg, double* ier_pm, double* iet_mm) {
+  const int ns = LAST ? ns_arg : 0;   // (compile-time zero in the steps before the last one: no D-mirror code at all)
   constexpr int KS = (N + 3) / 4, NN = N * N, cA = N, cB = N + 1;
   extern __shared__ __attribute__((aligned(16))) double rw_smem[];
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -282,6 +331,16 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
   __syncthreads();
   line_list ll;
   ll.build(shift, K, S, n1, lane, wave);
+  const dsign_masks dm = d_masks<N>(ns, lane);
+  if (ns > 0) {
+    for (int dz = wave; dz < K; dz += RW_WAVES) {
+      const int n0 = n1 + shift[dz];
+      if (n0 >= 0 && n0 < S) continue;
+      const long long oz = ((long long)n1 + (long long)S * dz) * (N * N);
+      zero_block<N>(ier_pm + oz, lane);
+      zero_block<N>(iet_mm + oz, lane);
+    }
+  }
   // the operands of a line as flat blocks (NF registers each) and one element per lane of the vectors;
   // rolling prefetch, at most five blocks in flight: a block is requested two to four product groups before its use
   flat<N> fIER, fIET, fR0, fGT, fGR, fGRT, fT0;
@@ -458,12 +517,19 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
       v_to_img<cA>(STa, 33, q2, p);
     }
     w_to_img(STa, O1, p);
-    img_to_global<N>(iet + o4, STa, ix, lane);
+    static_for<0, flat<N>::NF>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      out_chunk<N, k, false>(iet + o4, iet_mm + o4, STa[ix.aidx[k]], dm, lane);
+    });
     w_to_img(STa, O2, p);
-    img_to_global<N>(ier + o4, STa, ix, lane);
+    static_for<0, flat<N>::NF>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      out_chunk<N, k, true>(ier + o4, ier_pm + o4, STa[ix.aidx[k]], dm, lane);
+    });
     if (vin) {
       ieJp[o4v + lane] = STa[32 + WLD * lane];
-      ieJm[o4v + lane] = STa[33 + WLD * lane];
+      const double x = STa[33 + WLD * lane];
+      ieJm[o4v + lane] = (ns > 0 && is_uv_row(lane, ns)) ? -x : x;
     }
     RW_STAMP(11);
     d = dnext;
@@ -479,13 +545,6 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
 // rides in the last product of the current one.
 #define RW_PIN() __builtin_amdgcn_sched_barrier(0)
 
-template <int LO, int HI, typename G>
-__device__ __forceinline__ void static_for(G&& g) {
-  if constexpr (LO < HI) {
-    g(std::integral_constant<int, LO>{});
-    static_for<LO + 1, HI>(g);
-  }
-}
 // U units spread over the slots [S0, S1): run those of slot s
 template <int U, int S0, int S1, int s, typename G>
 __device__ __forceinline__ void units(G&& g) {
@@ -531,13 +590,14 @@ __device__ __forceinline__ void v_rd(cvec& x, const double* b0) {   // b0 = img 
   x.x[u >> 2][u & 3] = b0[WLD * (16 * (u >> 2) + 4 * (u & 3))];
 }
 
-template <int N>
+template <int N, bool LAST>
 __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     int S, int K, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
     const double* __restrict__ ttg, const double* __restrict__ gt, const double* __restrict__ gr,
     const double* __restrict__ grt, const double* __restrict__ jp, const double* __restrict__ j1m,
     const double* __restrict__ tmp1, const double* __restrict__ tmp2, const double* __restrict__ expk, double* ier,
-    double* iet, double* ieJp, double* ieJm) {
+    double* iet, double* ieJp, double* ieJm, int ns_arg, double* ier_pm, double* iet_mm) {
+  const int ns = LAST ? ns_arg : 0;   // (compile-time zero in the steps before the last one: no D-mirror code at all)
   constexpr int KS = (N + 3) / 4, SL = 2 * KS, H = KS, NN = N * N, cA = N, cB = N + 1;
   using F = flat<N>;
   constexpr int NF = F::NF;
@@ -561,6 +621,16 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
   __syncthreads();
   line_list ll;
   ll.build(shift, K, S, n1, lane, wave);
+  const dsign_masks dm = d_masks<N>(ns, lane);
+  if (ns > 0) {
+    for (int dz = wave; dz < K; dz += RW_WAVES) {
+      const int n0 = n1 + shift[dz];
+      if (n0 >= 0 && n0 < S) continue;
+      const long long oz = ((long long)n1 + (long long)S * dz) * (N * N);
+      zero_block<N>(ier_pm + oz, lane);
+      zero_block<N>(iet_mm + oz, lane);
+    }
+  }
   flat<N> fIER, fIET, fR0, fGT, fGR, fGRT, fT0;
   double vJp = 0.0, vJm = 0.0, vj1m = 0.0, vjp0 = 0.0, vt1 = 0.0, vt2 = 0.0, e0 = 0.0;
   const bool vin = lane < N;
@@ -781,10 +851,8 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
       });
       units<NF + 1, W_lo, SL, s>([&](auto u) {
         constexpr int k = decltype(u)::value;
-        if constexpr (k < NF - 1) (iet + o4 + lane)[64 * k] = fOut.f[k];
-        else if constexpr (k == NF - 1) {
-          if (lane < F::TAIL) (iet + o4 + lane)[64 * k] = fOut.f[k];
-        } else {
+        if constexpr (k < NF) out_chunk<N, k, false>(iet + o4, iet_mm + o4, fOut.f[k], dm, lane);
+        else {
           if (vin) ieJp[o4v + lane] = vOut;
         }
       });
@@ -806,8 +874,14 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
         for (int q = 0; q < 4; ++q) q2.x[a][q] += cJm.x[a][q];
       v_to_img<cA>(Xa, 33, q2, p);
       w_to_img(Xa, O2, p);
-      img_to_global<N>(ier + o4, Xa, ix, lane);
-      if (vin) ieJm[o4v + lane] = Xa[33 + WLD * lane];
+      static_for<0, NF>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        out_chunk<N, k, true>(ier + o4, ier_pm + o4, Xa[ix.aidx[k]], dm, lane);
+      });
+      if (vin) {
+        const double x = Xa[33 + WLD * lane];
+        ieJm[o4v + lane] = (ns > 0 && is_uv_row(lane, ns)) ? -x : x;
+      }
     }
     d = dnext;
   }
@@ -981,27 +1055,36 @@ constexpr size_t RW_LDS_BYTES = (size_t)(2 + RW_PRIV * RW_WAVES) * WIMG * sizeof
 template <int N>
 int launch_rw(int S, int K, const int* shift, const double* r, const double* t, const double* ttg, const double* gt,
               const double* gr, const double* grt, const double* jp, const double* j1m, const double* tmp1,
-              const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, hipStream_t st) {
+              const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, int ns,
+              double* ier_pm, double* iet_mm, hipStream_t st) {
   static const bool plain = getenv("VSM_RAMAN_WAVE_PLAIN") != nullptr;   // the unpipelined body (A/B)
-  void (*kern)(int, int, const int*, const double*, const double*, const double*, const double*, const double*, const double*,
-               const double*, const double*, const double*, const double*, const double*, double*, double*, double*, double*) =
-      k_raman_doubling_wave<N>;
+  using kern_t = void (*)(int, int, const int*, const double*, const double*, const double*, const double*, const double*,
+                          const double*, const double*, const double*, const double*, const double*, const double*, double*,
+                          double*, double*, double*, int, double*, double*);
+  const bool last = ns > 0;
+  kern_t kern = last ? (kern_t)k_raman_doubling_wave<N, true> : (kern_t)k_raman_doubling_wave<N, false>;
   if constexpr (N <= RW_MAXN_SP) {
-    if (!plain) kern = k_raman_doubling_wave_sp<N>;
+    if (!plain) kern = last ? (kern_t)k_raman_doubling_wave_sp<N, true> : (kern_t)k_raman_doubling_wave_sp<N, false>;
   }
   static hipError_t prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave<N>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+    const kern_t all[4] = {k_raman_doubling_wave<N, false>, k_raman_doubling_wave<N, true>, nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(all[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)RW_LDS_BYTES);
     if constexpr (N <= RW_MAXN_SP) {
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
     }
     return e;
   }();
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
   hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
-                     tmp2, expk, ier, iet, ieJp, ieJm);
+                     tmp2, expk, ier, iet, ieJp, ieJm, ns, ier_pm, iet_mm);
   VSM_LAUNCH_CHECK("k_raman_doubling_wave");
   return VSM_OK;
 }
@@ -1030,17 +1113,18 @@ int dispatch_n(int n, F f) {
 }  // namespace
 
 // FP64, N <= 30, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
-// chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.
+// chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.  ns > 0 (n_stokes) marks the
+// LAST doubling step of a layer: apply_D! of the inelastic operators happens on the way out (ier_pm, iet_mm are written).
 int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
-                        double* ieJm, hipStream_t st) {
+                        double* ieJm, int ns, double* ier_pm, double* iet_mm, hipStream_t st) {
   static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr;
   if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0 || K <= 0) return VSM_OK;
   return dispatch_n<1>(N, [&](auto tag) {
     return launch_rw<decltype(tag)::value>(S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm,
-                                           st);
+                                           ns, ier_pm, iet_mm, st);
   });
 }
 
