@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../vsmartmom.jl_amd/csrc"
 mkdir -p ../lib_dbg
-OTHER=$(ls *.o | grep -v '^vsm_raman_wave\.o$')
+OTHER=$(ls *.o | grep -v '^vsm_raman_wave')
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-function $flags \

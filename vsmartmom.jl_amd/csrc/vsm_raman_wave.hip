@@ -1099,10 +1099,27 @@ int launch_rw_ia(int S, int K, const int* shift, const rs_ia_pass<double>& h, hi
   return VSM_OK;
 }
 
-// N -> instantiation (1..RW_MAXN)
+// N -> instantiation.  The file is built in RW_PARTS objects (parallel build: each covers a range of N; -DRW_PART=k) or,
+// without RW_PART, as one object with every N (tools/variantsrw.sh).
+#ifdef RW_PART
+#if RW_PART == 0
+#define RW_N_LO 1
+#define RW_N_HI 15
+#elif RW_PART == 1
+#define RW_N_LO 16
+#define RW_N_HI 21
+#else
+#define RW_N_LO 22
+#define RW_N_HI 30
+#endif
+#else
+#define RW_N_LO 1
+#define RW_N_HI 30
+#endif
+static_assert(RW_N_HI <= RW_MAXN, "range");
 template <int N, typename F>
 int dispatch_n(int n, F f) {
-  if constexpr (N > RW_MAXN) {
+  if constexpr (N > RW_N_HI) {
     return VSM_ERR_UNSUPPORTED;
   } else {
     if (n == N) return f(std::integral_constant<int, N>{});
@@ -1112,28 +1129,71 @@ int dispatch_n(int n, F f) {
 
 }  // namespace
 
-// FP64, N <= 30, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
-// chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.  ns > 0 (n_stokes) marks the
-// LAST doubling step of a layer: apply_D! of the inelastic operators happens on the way out (ier_pm, iet_mm are written).
-int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
-                        const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
-                        const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
-                        double* ieJm, int ns, double* ier_pm, double* iet_mm, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr;
-  if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
-  if (S <= 0 || K <= 0) return VSM_OK;
-  return dispatch_n<1>(N, [&](auto tag) {
+#define RW_DBL_ARGS                                                                                                        \
+  int N, int S, int K, const int *shift, const double *r, const double *t, const double *ttg, const double *gt,            \
+      const double *gr, const double *grt, const double *jp, const double *j1m, const double *tmp1, const double *tmp2,    \
+      const double *expk, double *ier, double *iet, double *ieJp, double *ieJm, int ns, double *ier_pm, double *iet_mm,    \
+      hipStream_t st
+#define RW_DBL_PASS N, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm, ns, ier_pm, iet_mm, st
+#define RW_CAT_(a, b) a##b
+#define RW_CAT(a, b) RW_CAT_(a, b)
+#ifdef RW_PART
+#define RW_PART_FN(name) RW_CAT(name, RW_PART)
+#else
+#define RW_PART_FN(name) RW_CAT(name, all)
+#endif
+int raman_doubling_wave_part_0(RW_DBL_ARGS);
+int raman_doubling_wave_part_1(RW_DBL_ARGS);
+int raman_doubling_wave_part_2(RW_DBL_ARGS);
+int raman_interaction_wave_part_0(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
+int raman_interaction_wave_part_1(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
+int raman_interaction_wave_part_2(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
+
+int RW_PART_FN(raman_doubling_wave_part_)(RW_DBL_ARGS) {
+  if (N < RW_N_LO || N > RW_N_HI) return VSM_ERR_UNSUPPORTED;
+  return dispatch_n<RW_N_LO>(N, [&](auto tag) {
     return launch_rw<decltype(tag)::value>(S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm,
                                            ns, ier_pm, iet_mm, st);
   });
+}
+int RW_PART_FN(raman_interaction_wave_part_)(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h,
+                                             hipStream_t st) {
+  if (N < RW_N_LO || N > RW_N_HI) return VSM_ERR_UNSUPPORTED;
+  return dispatch_n<RW_N_LO>(N, [&](auto tag) { return launch_rw_ia<decltype(tag)::value>(S, K, shift, h, st); });
+}
+
+#if !defined(RW_PART) || RW_PART == 0
+// FP64, N <= 30, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller falls back to k_raman_doubling_lines / the operator
+// chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.  ns > 0 (n_stokes) marks the
+// LAST doubling step of a layer: apply_D! of the inelastic operators happens on the way out (ier_pm, iet_mm are written).
+int raman_doubling_wave(RW_DBL_ARGS) {
+  static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr;
+  if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
+  if (S <= 0 || K <= 0) return VSM_OK;
+#ifdef RW_PART
+  int rc = raman_doubling_wave_part_0(RW_DBL_PASS);
+  if (rc == VSM_ERR_UNSUPPORTED) rc = raman_doubling_wave_part_1(RW_DBL_PASS);
+  if (rc == VSM_ERR_UNSUPPORTED) rc = raman_doubling_wave_part_2(RW_DBL_PASS);
+  return rc;
+#else
+  return raman_doubling_wave_part_all(RW_DBL_PASS);
+#endif
 }
 
 int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
   static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr || getenv("VSM_NO_RAMAN_IA_WAVE") != nullptr;
   if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0 || K <= 0) return VSM_OK;
-  return dispatch_n<1>(N, [&](auto tag) { return launch_rw_ia<decltype(tag)::value>(S, K, shift, h, st); });
+#ifdef RW_PART
+  int rc = raman_interaction_wave_part_0(N, S, K, shift, h, st);
+  if (rc == VSM_ERR_UNSUPPORTED) rc = raman_interaction_wave_part_1(N, S, K, shift, h, st);
+  if (rc == VSM_ERR_UNSUPPORTED) rc = raman_interaction_wave_part_2(N, S, K, shift, h, st);
+  return rc;
+#else
+  return raman_interaction_wave_part_all(N, S, K, shift, h, st);
+#endif
 }
+#endif
 
 #ifdef RW_PHASE_TIMING
 extern "C" int vsm_debug_rw_phase(unsigned long long* out_h, int reset) {
