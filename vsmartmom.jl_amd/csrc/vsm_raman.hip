@@ -143,47 +143,70 @@ __global__ __launch_bounds__(256) void k_elemental_rrs(int N, int ns, int S, int
                                                        const T* __restrict__ dtau, const T* __restrict__ Zpp,
                                                        const T* __restrict__ Zmp, const T* __restrict__ mu,
                                                        const T* __restrict__ wt, T* ier_mp, T* iet_pp, T* ier_pm, T* iet_mm) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= N * N) return;
-  const int n1 = blockIdx.y, dn = blockIdx.z;
+  // One workgroup per (recipient n1, line dn).  The exponentials are separable over the two points: x_i = dtau[n1]/mu_i,
+  // y_j = dtau[n0]/mu_j, exp(-x), expm1(-x) (and the same for y) are tabulated once per workgroup (2 N values instead of
+  // N^2), and  -expm1(-(x + y)) = -(p + q + p q)  with p = expm1(-x), q = expm1(-y)  (both negative: no cancellation).
+  // Per element one transcendental is left (the expm1 of the difference inside expdiff_neg) instead of three.
+  __shared__ T sx[2][128], se[2][128], sp[2][128], smu[128];
+  const int n1 = blockIdx.x, dn = blockIdx.y, tid = threadIdx.x;
   const int n0 = n1 + shift[dn];
-  const int i = e % N, j = e / N;
-  T r = T(0), t = T(0);
-  const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
-  if (n0 >= 0 && n0 < S && wct > tol<T>::weight()) {
-    const T mi = mu[i], mj = mu[j];
-    const T d1 = dtau[n1], d0 = dtau[n0];
-    const T w = varpi_ie[dn], f = fscatt[n0];
-    const T ratio = d1 / d0;
-    r = f * w * Zmp[e] * (T(1) / ((mi / mj) + ratio)) * (-expm1(-((d1 / mi) + (d0 / mj)))) * wct;
-    if (mi == mj) {
-      if (fabs(d0 - d1) > tol<T>::loose())
-        t = w * f * Zpp[e] * wct * expdiff_neg<T>(d1 / mi, d0 / mj) / (T(1) - ratio);
-      else
-        t = (d0 / mi) * w * f * Zpp[e] * wct * exp(-d0 / mj);
-    } else {
-      const T den = (mi / mj) - ratio;
-      if (fabs(den) < tol<T>::close())
-        t = (d0 / mi) * w * f * Zpp[e] * wct * exp(-d0 / mj);
-      else
-        t = w * f * Zpp[e] * (T(1) / den) * wct * expdiff_neg<T>(d1 / mi, d0 / mj);
+  const bool inband = n0 >= 0 && n0 < S;
+  {
+    const int h = tid >> 7, i = tid & 127;
+    if (i < N && (h == 0 || inband)) {
+      const T mi = mu[i];
+      const T x = dtau[h == 0 ? n1 : n0] / mi;
+      sx[h][i] = x;
+      se[h][i] = exp(-x);
+      sp[h][i] = expm1(-x);
+      if (h == 0) smu[i] = mi;
     }
   }
-  const long long o = ((long long)n1 + (long long)S * dn) * N * N + e;
-  if (ns == 1) {
-    ier_mp[o] = r;
-    iet_pp[o] = t;
-    ier_pm[o] = r;
-    iet_mm[o] = t;
-  } else if (ndoubl < 1) {
-    const bool same = is_uv_row(i, ns) == is_uv_row(j, ns);
-    ier_mp[o] = r;
-    iet_pp[o] = t;
-    ier_pm[o] = same ? r : -r;
-    iet_mm[o] = same ? t : -t;
-  } else {
-    ier_mp[o] = is_uv_row(i, ns) ? -r : r;
-    iet_pp[o] = t;
+  __syncthreads();
+  const T d1 = dtau[n1], d0 = inband ? dtau[n0] : T(1);
+  const T w = varpi_ie[dn], f = inband ? fscatt[n0] : T(0);
+  const T ratio = d1 / d0;
+  const long long ob = ((long long)n1 + (long long)S * dn) * N * N;
+  for (int e = tid; e < N * N; e += 256) {
+    const int i = e % N, j = e / N;
+    T r = T(0), t = T(0);
+    const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
+    if (inband && wct > tol<T>::weight()) {
+      const T mi = smu[i], mj = smu[j];
+      const T x = sx[0][i], y = sx[1][j];
+      const T p = sp[0][i], q = sp[1][j];
+      const T ey = se[1][j];
+      r = f * w * Zmp[e] * (T(1) / ((mi / mj) + ratio)) * (-(p + q + p * q)) * wct;
+      const T ed = (x == y) ? T(0) : ((x < y) ? se[0][i] * (-expm1(-(y - x))) : -ey * (-expm1(-(x - y))));   // expdiff_neg(x, y)
+      if (mi == mj) {
+        if (fabs(d0 - d1) > tol<T>::loose())
+          t = w * f * Zpp[e] * wct * ed / (T(1) - ratio);
+        else
+          t = (d0 / mi) * w * f * Zpp[e] * wct * ey;
+      } else {
+        const T den = (mi / mj) - ratio;
+        if (fabs(den) < tol<T>::close())
+          t = (d0 / mi) * w * f * Zpp[e] * wct * ey;
+        else
+          t = w * f * Zpp[e] * (T(1) / den) * wct * ed;
+      }
+    }
+    const long long o = ob + e;
+    if (ns == 1) {
+      ier_mp[o] = r;
+      iet_pp[o] = t;
+      ier_pm[o] = r;
+      iet_mm[o] = t;
+    } else if (ndoubl < 1) {
+      const bool same = is_uv_row(i, ns) == is_uv_row(j, ns);
+      ier_mp[o] = r;
+      iet_pp[o] = t;
+      ier_pm[o] = same ? r : -r;
+      iet_mm[o] = same ? t : -t;
+    } else {
+      ier_mp[o] = is_uv_row(i, ns) ? -r : r;
+      iet_pp[o] = t;
+    }
   }
 }
 
@@ -261,7 +284,11 @@ static int elemental_inelastic_rrs(const quad<T>& q, int S, int m, int ndoubl, c
                                    const rrs_in<T>& rs, const added_rs<T>& a, hipStream_t st) {
   if (S <= 0 || a.K <= 0) return VSM_OK;
   const int N = q.N;
-  hipLaunchKernelGGL(k_elemental_rrs<T>, dim3((N * N + 255) / 256, S, a.K), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+  if (N > 128) {
+    set_error("elemental_inelastic_rrs: N = %d exceeds 128", N);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_elemental_rrs<T>, dim3(S, a.K), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
                      rs.shift, rs.varpi_ie, rs.fscatt, dtau, rs.Zpp, rs.Zmp, q.mu, q.wt, a.ier_mp, a.iet_pp, a.ier_pm,
                      a.iet_mm);
   VSM_LAUNCH_CHECK("k_elemental_rrs");
