@@ -1,4 +1,4 @@
 for v in "" "$@"; do
   if [ -n "$v" ]; then export VSM_LIB_PATH=$PWD/vsmartmom.jl_amd/lib_dbg/libv_$v.so; fi
-  echo "== ${v:-base}: $(VSM_NO_RAMAN_IA_WAVE=1 timeout 200 python tools/raman_timing.py --points 4000 2>&1 | grep 'Raman RRS' | sed 's/.*second run//')"
+  echo "== ${v:-base}: $(timeout 200 python tools/raman_timing.py --points 4000 2>&1 | grep 'Raman RRS' | sed 's/.*second run//')"
 done
