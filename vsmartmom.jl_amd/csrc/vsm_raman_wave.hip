@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
 
 // ---- software-pipelined variant --------------------------------------------------------------------------------------------
 // One wave per SIMD: nothing but the wave's own instruction order can overlap the LDS / VALU / global work with the MFMAs.
-// Every product is issued as 2 KS "slots" of two MFMAs; between the slots run the units of the side work that belongs to
+// Every product is issued as 4 KS "slots" of one MFMA; between the slots run the units of the side work that belongs to
 // LATER products (staging the next right operand, reading it back, writing an intermediate's image, the rider algebra,
 // the output copies), pinned in place by scheduling barriers.  The first phase of the next line (images of ier / iet / r0)
 // rides in the last product of the current one.
@@ -569,10 +569,9 @@ __device__ __forceinline__ void af_rd(afrag<KS>& f, const double* a0) {   // a0 
 }
 template <int KS, typename F>
 __device__ __forceinline__ void w_mm_s(wmat& acc, const afrag<KS>& af, const wmat& B, F&& side) {
-  static_for<0, 2 * KS>([&](auto slot) {
-    constexpr int s = decltype(slot)::value, i = s >> 1, t = s & 1, a = i >> 2, r = i & 3;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc.v[t][b] = mfma<double>::mma(af.v[i][t], B.v[a][b][r], acc.v[t][b]);
+  static_for<0, 4 * KS>([&](auto slot) {
+    constexpr int s = decltype(slot)::value, i = s >> 2, t = (s >> 1) & 1, b = s & 1, a = i >> 2, r = i & 3;
+    acc.v[t][b] = mfma<double>::mma(af.v[i][t], B.v[a][b][r], acc.v[t][b]);
     RW_PIN();
     side(slot);
     RW_PIN();
@@ -602,7 +601,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
     const double* __restrict__ tmp1, const double* __restrict__ tmp2, const double* __restrict__ expk, double* ier,
     double* iet, double* ieJp, double* ieJm, int ns_arg, double* ier_pm, double* iet_mm) {
   const int ns = LAST ? ns_arg : 0;   // (compile-time zero in the steps before the last one: no D-mirror code at all)
-  constexpr int KS = (N + 3) / 4, SL = 2 * KS, H = KS, NN = N * N, cA = N, cB = N + 1;
+  constexpr int KS = (N + 3) / 4, SL = 4 * KS, H = 2 * KS, NN = N * N, cA = N, cB = N + 1;   // SL slots of ONE MFMA per product
   using F = flat<N>;
   constexpr int NF = F::NF;
   extern __shared__ __attribute__((aligned(16))) double rw_smem[];
@@ -793,7 +792,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
           for (int q = 0; q < 4; ++q) a3.x[a][q] = cJp.x[a][q] + q1.x[a][q] + q2.x[a][q] + w1A.x[a][q];
         w_set_col<cA>(W1, a3, p);
       }
-      if constexpr (s == (SL > 1 ? 1 : 0)) {
+      if constexpr (s == 2) {
         // a4 = iej1- + ier j0+ + r1 iej0+ + X tmp2
         const cvec q1 = w_col<cB>(X), q2 = w_col<cB>(R1IET), q3 = w_col<cA>(WA);
         cvec sv;
@@ -808,7 +807,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave_sp(
           for (int q = 0; q < 4; ++q) a4.x[a][q] = cJ1m.x[a][q] + sv.x[a][q] + q3.x[a][q];
       }
       // three 16-unit lists in the slots after the algebra (in thirds when there are at least three slots left)
-      constexpr int B0 = SL > 2 ? 2 : SL - 1, R = SL - B0, T = R >= 3 ? R / 3 : 1;
+      constexpr int B0 = SL > 4 ? 4 : 3, R = SL - B0, T = R >= 3 ? R / 3 : 1;
       constexpr int A_lo = B0, A_hi = B0 + T;
       constexpr int B_lo = R >= 2 ? B0 + T : B0, B_hi = R >= 3 ? B0 + 2 * T : SL;
       constexpr int C_lo = R >= 3 ? B0 + 2 * T : B_lo, C_hi = SL;
