@@ -145,7 +145,7 @@ def test_elemental_inelastic(vsm, arch, FT, pol, m, ndmode):
 # FP64 N = 4, 7, 11, 16, 19, 21, 24, 27, 30: one wave per line (vsm_raman_wave.hip, k-step counts 1..8; pipelined body up to 24);
 # FP32 N <= 30: one workgroup per point; 63: operator chain
 @pytest.mark.parametrize("pol,l_trunc", [("I", 1), ("I", 7), ("I", 15), ("I", 25), ("I", 31), ("IQU", 7), ("IQU", 9),
-                                         ("IQU", 11), ("IQU", 13), ("IQU", 35)])
+                                         ("IQU", 11), ("IQU", 13), ("IQU", 35), ("IQU", 55)])   # 55: N = 93 (FP32: NP = 96 elastic kernels)
 def test_doubling_inelastic(vsm, arch, FT, pol, l_trunc):
     S = 14 if l_trunc < 20 else 9
     c = _setup(vsm, arch, FT, pol, S=S, l_trunc=l_trunc, seed=3)
