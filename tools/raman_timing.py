@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--l-trunc", type=int, default=9)
     ap.add_argument("--oracle-points", type=int, default=0)
+    ap.add_argument("--json", action="store_true", help="also print one JSON line in the shape of the bench.py contract")
     a = ap.parse_args()
     S, K, L = a.points, a.lines, a.layers
     rng = np.random.default_rng(20260929)
@@ -60,6 +61,18 @@ def main():
     tf = flops_pt * S / (t2 - t1) / 1e12
     print("  ndoubl per layer %s, %.1f in-band lines per recipient: algorithmic %.2f GFLOP/point -> %.1f TFLOP/s = %.3f of the FP64 MFMA "
           "peak (78.6 TF)" % (nds, kin, flops_pt / 1e9, tf, tf / 78.6))
+    if a.json:
+        import json
+        print(json.dumps({
+            "metric": "spectral-points/s for rt_run(RRS), C5 shape (BASELINE.json configs[4])", "value": S / (t2 - t1),
+            "unit": "spectral-points/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": 1e3 * (t2 - t1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C5: rotational Raman, nStokes=3, N=%d, %d layers, %d spectral points, %d Raman lines, m=0..2"
+                                   % (N, L, S, len(shifts)),
+                       "timed_step": "rt_run(RS_type::RRS, model, 1) incl. host optics + H2D + D2H (second call)",
+                       "algorithmic_gflop_per_point": flops_pt / 1e9, "in_band_lines_per_point": kin},
+            "roofline": {"bound": "mfma", "kernel": "whole run (k_raman_doubling_wave_sp 72 %, k_raman_interaction_wave 16 %)",
+                         "achieved": tf, "peak": 78.6, "unit": "TFLOP/s", "frac": tf / 78.6, "traffic": None}}))
     if a.oracle_points:
         from oracle import vsm_oracle as O
         from oracle import vsm_oracle_raman as OR
