@@ -54,7 +54,10 @@ TOL = {np.float64: 1e-10, np.float32: 2e-4}
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(4, 4, 4), (16, 16, 16), (15, 15, 15), (60, 60, 60), (33, 7, 21), (112, 112, 112),
-                                   (60, 60, 1), (5, 3, 1)])
+                                   (60, 60, 1), (5, 3, 1),
+                                   # k_gemm_lds: every (row tiles, column tiles per wave) variant, ragged edges in M / K / Nc
+                                   (17, 17, 17), (32, 9, 16), (33, 33, 70), (64, 64, 64), (65, 65, 65), (66, 13, 100),
+                                   (96, 96, 96), (97, 50, 31), (99, 99, 99), (128, 128, 128), (127, 126, 125), (128, 8, 17)])
 def test_batched_mul(vsm, arch, FT, shape):
     """batched_mul vs dense products (test/test_batched_kernels.jl:21-23); asymmetric operands and an
     A = I probe catch row/column swaps in the MFMA fragment maps."""
