@@ -161,7 +161,9 @@ def test_interaction_lin(vsm, arch, N, shared, iface):
         assert _rel(vsm.Architectures.to_host(getattr(pcl, k)), getattr(cl, k)) < 1e-9, "d" + k
 
 
-@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 7, 21, 57 (fused strip kernels)
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33),   # N = 7, 21, 57 (fused strip kernels)
+                                         ("IQU", 37), ("IQUV", 43),          # N = 66, 100: operator level (LDS-staged products)
+                                         ("IQUV", 61)])                      # N = 136: past every on-chip kernel (global-memory inverse)
 def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     """rt_run(model, lin_model, 0, NGas, 1): R, T and the Jacobians vs the oracle; the albedo Jacobian also vs a
     finite difference of the device forward run (the reference's own check: test_jacobians_unit.jl:105-123)."""

@@ -82,7 +82,7 @@ def test_batched_mul(vsm, arch, FT, shape):
 
 
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
-@pytest.mark.parametrize("N", [1, 4, 15, 31, 32, 36, 60, 64, 65, 96, 112, 128])
+@pytest.mark.parametrize("N", [1, 4, 15, 31, 32, 36, 60, 64, 65, 96, 112, 128, 129, 160, 203])   # > 128: global-memory kernel
 def test_batch_inv(vsm, arch, FT, N):
     """batch_inv! vs dense inverse (test/test_batched_kernels.jl:14-19), incl. matrices that NEED pivoting."""
     rng = np.random.default_rng(N)
@@ -820,7 +820,7 @@ def test_edge_cases_empty_batch_singleton_and_size_limits(vsm, arch):
     out = torch.empty_like(tX)
     CR.batch_inv_(out, tX)
     assert _rel(vsm.Architectures.to_host(out), np.eye(5)[None] / 2.0) < 1e-14
-    big = conv(np.tile(np.eye(129)[None], (2, 1, 1)))
+    big = conv(np.eye(2600)[None])      # past the LDS budget of the global-memory Gauss-Jordan kernel (N <= 2142 in FP64)
     with pytest.raises(vsm.VSMError):
         CR.batch_inv_(torch.empty_like(big), big)
 
@@ -868,7 +868,8 @@ def test_rt_run_spectrally_varying_lambertian_surfaces(vsm, arch, pol, l_trunc, 
         vsm.CoreRTLin.rt_run_lin(flat, H.LinModel([tau_abs]), 0, 1, 1)     # the reference has no linearized builder for them
 
 
-@pytest.mark.parametrize("pol,l_trunc,albedo", [("I", 9, 0.3), ("IQU", 33, 0.15), ("IQUV", 7, 0.0)])
+@pytest.mark.parametrize("pol,l_trunc,albedo", [("I", 9, 0.3), ("IQU", 33, 0.15), ("IQUV", 7, 0.0),
+                                                ("IQUV", 61, 0.15)])   # N = 136: past every on-chip kernel
 def test_rt_run_full_output_hdrf_bhr(vsm, arch, pol, l_trunc, albedo):
     """The reference's SFI return tuple (rt_run.jl:535): hdr (interaction_hdrf! + postprocessing_vza_hdrf!), bhr_uw[1,:],
     bhr_dw[1,:] vs the oracle; zero inelastic slots; for a Lambertian surface the m = 0 flux ratio is the albedo

@@ -546,7 +546,7 @@ static int check_cl(const C* c) {
     int rc;                                                                                                            \
     if ((rc = check_added(added)) || (rc = check_al(al))) return rc;                                                   \
     VSM_REQUIRE(added->d_symmetric == 0, "doubling_lin: d_symmetric layers are not accepted here");                    \
-    VSM_REQUIRE(N > 0 && N <= 128 && S >= 0 && ndoubl >= 0 && expk && dtau_dot_all && (work || ndoubl == 0) &&         \
+    VSM_REQUIRE(N > 0 && S >= 0 && ndoubl >= 0 && expk && dtau_dot_all && (work || ndoubl == 0) &&         \
                     n_active >= 0 && n_active <= al->P, "doubling_lin: bad argument");                                 \
     return doubling_lin<T>(N, n_stokes, S, ndoubl, expk, dtau_dot_all, mu0, n_active, cvt_added<T>(added),             \
                            cvt_al<T>(al), work, as_stream(stream));                                                    \
@@ -557,7 +557,7 @@ static int check_cl(const C* c) {
     int rc;                                                                                                            \
     if ((rc = check_comp(comp)) || (rc = check_cl(cl)) || (rc = check_added(added)) || (rc = check_al(al))) return rc; \
     VSM_REQUIRE(added->d_symmetric == 0, "interaction_lin: d_symmetric layers are not accepted here");                 \
-    VSM_REQUIRE(N > 0 && N <= 128 && S >= 0 && work && cl->P == al->P, "interaction_lin: bad argument");               \
+    VSM_REQUIRE(N > 0 && S >= 0 && work && cl->P == al->P, "interaction_lin: bad argument");               \
     return interaction_lin<T>(iface, N, S, cvt_comp<T>(comp), cvt_cl<T>(cl), cvt_added<T>(added), cvt_al<T>(al), work, \
                               as_stream(stream));                                                                      \
   }                                                                                                                    \

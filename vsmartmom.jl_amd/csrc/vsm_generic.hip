@@ -208,12 +208,116 @@ __global__ __launch_bounds__(256) void k_batch_inv(int N, const T* A, T* X, int*
   if (info && threadIdx.x == 0) info[s] = sc.info;
 }
 
+// N > 128: the same in-place Gauss-Jordan with partial pivoting (same pivot rule), the matrix in global memory (X, L2-resident:
+// one workgroup of 1024 threads per matrix), pivot row / column / the displaced row k published through LDS per step.  A is
+// copied to X first (A is not clobbered).  A fallback for sizes past every on-chip kernel, not a fast path.
+template <typename T>
+__global__ __launch_bounds__(1024) void k_batch_inv_big(int N, const T* __restrict__ A, T* X, int* info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char inv_smem[];
+  T* col = reinterpret_cast<T*>(inv_smem);   // column k before the step
+  T* rowP = col + N;                         // pivot row (row p) before the step
+  T* rowK = rowP + N;                        // row k before the step (needed where the rows are exchanged)
+  int* piv = reinterpret_cast<int*>(rowK + N);
+  __shared__ T red_v[16];
+  __shared__ int red_i[16];
+  __shared__ int s_p, s_info;
+  const long long NN = (long long)N * N;
+  const T* As = A + (long long)blockIdx.x * NN;
+  T* Xs = X + (long long)blockIdx.x * NN;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+  for (long long e = tid; e < NN; e += nt) Xs[e] = As[e];
+  if (tid == 0) s_info = 0;
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    // pivot: largest |X[i,k]|, i >= k, first occurrence
+    T best = T(-1);
+    int bi = k;
+    for (int i = k + tid; i < N; i += nt) {
+      const T v = fabs(Xs[i + (long long)N * k]);
+      if (v > best) {
+        best = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const T ov = __shfl_xor(best, off);
+      const int oi = __shfl_xor(bi, off);
+      if (ov > best || (ov == best && oi < bi)) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (lane == 0) {
+      red_v[wave] = best;
+      red_i[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      T b = red_v[0];
+      int p = red_i[0];
+      for (int w = 1; w < nw; ++w)
+        if (red_v[w] > b || (red_v[w] == b && red_i[w] < p)) {
+          b = red_v[w];
+          p = red_i[w];
+        }
+      s_p = p;
+      piv[k] = p;
+    }
+    __syncthreads();
+    const int p = s_p;
+    for (int i = tid; i < N; i += nt) {
+      col[i] = Xs[i + (long long)N * k];
+      rowP[i] = Xs[p + (long long)N * i];
+      rowK[i] = Xs[k + (long long)N * i];
+    }
+    __syncthreads();
+    const T pv = rowP[k];
+    if (tid == 0 && pv == T(0) && s_info == 0) s_info = k + 1;
+    const T d = T(1) / pv;
+    // after the exchange row p carries the old row k (column-k entry col[k]); every other row keeps its own
+    for (long long e = tid; e < NN; e += nt) {
+      const int i = (int)(e % N), j = (int)(e / N);
+      const T u = (j == k) ? d : rowP[j] * d;     // new row k
+      T v;
+      if (i == k) {
+        v = u;
+      } else {
+        const T f = (i == p) ? col[k] : col[i];
+        const T src = (i == p) ? rowK[j] : Xs[e];
+        v = (j == k) ? -f * d : src - f * u;
+      }
+      Xs[e] = v;
+    }
+    __syncthreads();
+  }
+  // undo the row exchanges as column exchanges of the inverse, last first
+  for (int k = N - 1; k >= 0; --k) {
+    const int p = piv[k];
+    if (p != k) {
+      for (int i = tid; i < N; i += nt) {
+        const T a = Xs[i + (long long)N * k], b = Xs[i + (long long)N * p];
+        Xs[i + (long long)N * k] = b;
+        Xs[i + (long long)N * p] = a;
+      }
+      __syncthreads();
+    }
+  }
+  if (info && tid == 0) info[blockIdx.x] = s_info;
+}
+
 template <typename T>
 int batch_inv(int N, int S, const T* A, T* X, int* info, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   if (N > 128) {
-    set_error("batch_inv: N=%d > 128 is not supported by the register-resident Gauss-Jordan kernel", N);
-    return VSM_ERR_UNSUPPORTED;
+    const size_t bytes = 3 * (size_t)N * sizeof(T) + (size_t)N * sizeof(int);
+    if (bytes > 60000) {
+      set_error("batch_inv: N=%d is past the LDS budget of the global-memory Gauss-Jordan kernel", N);
+      return VSM_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(k_batch_inv_big<T>, dim3(S), dim3(1024), bytes, st, N, A, X, info);
+    VSM_LAUNCH_CHECK("k_batch_inv_big");
+    return VSM_OK;
   }
   if (N <= 32)
     hipLaunchKernelGGL((k_batch_inv<T, 32>), dim3(S), dim3(256), 0, st, N, A, X, info);

@@ -524,12 +524,12 @@ int coxmunk_ss_correction(const cm_surf<T>& sf, int n_stokes, int S, int nV, con
 // bhr_dw[c, s] = sum_{j = c mod n} J0+[j] w_j mu_j + j0+_surf[i_mu0 n] mu[i_mu0 n]  (the reference adds the I entry of the direct
 // beam to every component).  One workgroup per spectral point.
 template <typename T>
-__global__ void __launch_bounds__(128) k_interaction_hdrf(int N, int ns, int m, int i_mu0, const T* __restrict__ mu,
+__global__ void __launch_bounds__(512) k_interaction_hdrf(int N, int ns, int m, int i_mu0, const T* __restrict__ mu,
                                                           const T* __restrict__ wt, const T* __restrict__ r_mp, long long rstride,
                                                           const T* __restrict__ j0_p, const T* __restrict__ j0_m,
                                                           const T* __restrict__ J0_p, T* hdr_J, T* bhr_uw, T* bhr_dw) {
-  __shared__ T Jp[128];
-  __shared__ T up[128];
+  __shared__ T Jp[512];
+  __shared__ T up[512];
   const long long s = blockIdx.x;
   const int i = threadIdx.x;
   Jp[i] = (i < N) ? J0_p[s * N + i] : T(0);
@@ -566,12 +566,12 @@ __global__ void k_postprocess_hdrf(int N, int ns, long long S, int nV, int nVtot
 template <typename T>
 int interaction_hdrf(const quad<T>& q, int S, int m, const composite<T>& c, const added<T>& a, T* hdr_J, T* bhr_uw, T* bhr_dw,
                      hipStream_t st) {
-  if (q.N > 128) {
-    set_error("interaction_hdrf: N <= 128 (got %d)", q.N);
+  if (q.N > 512) {
+    set_error("interaction_hdrf: N <= 512 (got %d)", q.N);
     return VSM_ERR_UNSUPPORTED;
   }
   if (S <= 0) return VSM_OK;
-  hipLaunchKernelGGL(k_interaction_hdrf<T>, dim3(S), dim3(128), 0, st, q.N, q.n_stokes, m, q.i_mu0, q.mu, q.wt, a.r_mp,
+  hipLaunchKernelGGL(k_interaction_hdrf<T>, dim3(S), dim3(q.N <= 128 ? 128 : 512), 0, st, q.N, q.n_stokes, m, q.i_mu0, q.mu, q.wt, a.r_mp,
                      a.mat_stride, a.j0_p, a.j0_m, c.J0_p, hdr_J, bhr_uw, bhr_dw);
   VSM_LAUNCH_CHECK("k_interaction_hdrf");
   return VSM_OK;
