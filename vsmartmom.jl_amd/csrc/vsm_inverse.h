@@ -12,6 +12,30 @@
 
 namespace vsm {
 
+// ---- wave maximum (all 64 lanes active): quad_perm xor 1, xor 2, row_half_mirror, row_mirror, then the four row maxima ----
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ __forceinline__ double lane_value(double x, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+template <typename T>
+__device__ __forceinline__ T wave_max(T x) {
+  x = fmax(x, dpp_mov<0xB1>(x));    // quad_perm [1,0,3,2]
+  x = fmax(x, dpp_mov<0x4E>(x));    // quad_perm [2,3,0,1]
+  x = fmax(x, dpp_mov<0x141>(x));   // row_half_mirror
+  x = fmax(x, dpp_mov<0x140>(x));   // row_mirror: every lane of a 16-lane row holds the row maximum
+  return fmax(fmax(lane_value(x, 0), lane_value(x, 16)), fmax(lane_value(x, 32), lane_value(x, 48)));
+}
+
 template <int NPAD, int NT = 256>
 struct gj_cfg {
   static_assert(NPAD == 32 || NPAD == 64 || NPAD == 96 || NPAD == 128, "NPAD must be 32/64/96/128");
@@ -46,7 +70,7 @@ using gj_regs = T[gj_cfg<NPAD, NT>::RB][gj_cfg<NPAD, NT>::CB];
 struct wg_sync {
   __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
-template <typename T, int NPAD, int NT = 256, typename SC, typename SYNC = wg_sync>
+template <typename T, int NPAD, int NT = 256, bool DPP_SEARCH = true, typename SC, typename SYNC = wg_sync>
 __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc, int tid = threadIdx.x, SYNC sync = SYNC()) {
   using C = gj_cfg<NPAD, NT>;
   const int lane = tid & 63;
@@ -66,25 +90,39 @@ __device__ __forceinline__ void gj_invert(gj_regs<T, NPAD, NT>& a, int N, SC& sc
           for (int rb = 0; rb < C::RB; ++rb) sc.col[par][tr + C::TR * rb] = a[rb][cbk];
         }
         sync();
-        // (b) pivot search, redundantly in every wave (no second barrier needed)
-        T best = T(-1);
-        int bi = k;
-        for (int i = lane; i < NPAD; i += 64) {
-          if (i >= k && i < N) {
-            T v = fabs(sc.col[par][i]);
-            if (v > best) {
-              best = v;
-              bi = i;
+        int bi;
+        if constexpr (DPP_SEARCH) {
+          // (b) pivot search, redundantly in every wave (no second barrier needed): the wave maximum of |a_ik| by DPP (no LDS
+          // round trips), then the FIRST row that attains it from two ballots (row i = lane, lane + 64)
+          const bool in0 = lane >= k && lane < N, in1 = NPAD > 64 && lane + 64 >= k && lane + 64 < N;
+          T v0 = T(-1), v1 = T(-1);
+          if (in0) v0 = fabs(sc.col[par][lane]);
+          if (in1) v1 = fabs(sc.col[par][(lane + 64) % NPAD]);
+          const T best = wave_max(v0 > v1 ? v0 : v1);
+          const unsigned long long m0 = __ballot(in0 && v0 == best), m1 = __ballot(in1 && v1 == best);
+          bi = m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 64 + __ffsll((long long)m1) - 1 : k);
+        } else {
+          // the same search by butterfly shuffles (LDS round trips; kept for the strip layer kernels, whose register
+          // allocation -- 1.8 % (C2) / 4 % (C4) of the layer time -- is tuned around this form)
+          T best = T(-1);
+          bi = k;
+          for (int i = lane; i < NPAD; i += 64) {
+            if (i >= k && i < N) {
+              T v = fabs(sc.col[par][i]);
+              if (v > best) {
+                best = v;
+                bi = i;
+              }
             }
           }
-        }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          T ov = __shfl_xor(best, off);
-          int oi = __shfl_xor(bi, off);
-          if (ov > best || (ov == best && oi < bi)) {
-            best = ov;
-            bi = oi;
+          for (int off = 32; off >= 1; off >>= 1) {
+            T ov = __shfl_xor(best, off);
+            int oi = __shfl_xor(bi, off);
+            if (ov > best || (ov == best && oi < bi)) {
+              best = ov;
+              bi = oi;
+            }
           }
         }
         const int p = __builtin_amdgcn_readfirstlane(bi);

@@ -406,7 +406,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, fsmem32& sm, const
   float* pad = V + FNP;
   gj_pad_scratch sc{pad_vec2{pad}, pad_vec2{pad + 2}, pad_vec2{pad + 4}, pad_ivec{reinterpret_cast<int*>(pad + 6)},
                     pad_ivec{reinterpret_cast<int*>(pad + 7)}, sm.gj_info};
-  gj_invert<float, FNP, FNT>(g, N, sc, p.tid, half_sync{&p});
+  gj_invert<float, FNP, FNT, false>(g, N, sc, p.tid, half_sync{&p});
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll

@@ -256,7 +256,7 @@ __device__ __forceinline__ void gj_lds_strip(float* V, int N, gj_scratch<float, 
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
       g[rb][cb] = (i < N && j < N) ? V[lidx32(i, j)] : ((i == j) ? 1.0f : 0.0f);
     }
-  gj_invert<float, FNP, FNT>(g, N, *sc);
+  gj_invert<float, FNP, FNT, false>(g, N, *sc);
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll

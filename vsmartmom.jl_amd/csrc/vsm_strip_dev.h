@@ -157,7 +157,7 @@ __device__ __forceinline__ void gj_lds_strip(double* V, int N, gj_scratch<double
       const int i = tr + G::TR * rb, j = tc * G::CB + cb;
       g[rb][cb] = (i < N && j < N) ? V[lidx<SNP>(i, j)] : ((i == j) ? 1.0 : 0.0);
     }
-  gj_invert<double, SNP, SNT>(g, N, *sc);
+  gj_invert<double, SNP, SNT, false>(g, N, *sc);
 #pragma unroll
   for (int rb = 0; rb < G::RB; ++rb)
 #pragma unroll
