@@ -418,6 +418,20 @@ int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
                           const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
                           int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream);
 
+/* The `:thermal` per-source slot of one scattering layer (rt_kernel.jl:205-232: contribute!(::PreparedThermalEmission)
+ * between elemental! and doubling!, Sources/thermal_emission.jl:241-301; the slot's own expk = 1, doubling.jl:62-81; the
+ * per-source recurrences of interaction.jl) in the launch of vsm_layer_forward(_mix)_*: m = 0, the solar source replaced by
+ * j0+- = 2 pi (1 - varpi) B (1 - exp(-dtau/mu_i)) on the I rows, thermal_B[S] = Planck radiance of the layer per point.
+ * ncomp = 0: Zpp / Zmp [N,N,S] with z_stride (0 = shared block); ncomp >= 1: component stacks [N,N,ncomp] + fcomp[ncomp,S].
+ * `comp` is the composite of the thermal slot.  Fused for FP64 with 32 < N <= 60 and ncomp <= 4; any other shape returns
+ * VSM_ERR_UNSUPPORTED (callers then run vsm_elemental + vsm_thermal_source + vsm_doubling + vsm_interaction). */
+int vsm_layer_forward_thermal_f64(const vsm_quad_f64* q, int S, int ndoubl, const double* dtau, const double* varpi,
+                                  const double* thermal_B, int ncomp, const double* Zpp, const double* Zmp, long long z_stride,
+                                  const double* fcomp, int toa, const vsm_composite_f64* comp, void* stream);
+int vsm_layer_forward_thermal_f32(const vsm_quad_f32* q, int S, int ndoubl, const float* dtau, const float* varpi,
+                                  const float* thermal_B, int ncomp, const float* Zpp, const float* Zmp, long long z_stride,
+                                  const float* fcomp, int toa, const vsm_composite_f32* comp, void* stream);
+
 /* Layer optics with several scatterers: the reference mixes Z per spectral point on the host,
  * Z = sum_k (tau_k varpi_k Z_k) / sum_k (tau_k varpi_k)  (`+` of CoreScatteringOpticalProperties, src/CoreRT/types.jl:1262-1292;
  * compEffectiveLayerProperties.jl:43-54) and ships [N,N,nSpec] arrays to the device.  Here the ncomp component

@@ -29,12 +29,12 @@ def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300))
 
 
-def _models(vsm, arch, sza, tau_abs, sources, pol="IQUV", S=3, L=4, albedo=0.1, FT=np.float64, m_max=2):
+def _models(vsm, arch, sza, tau_abs, sources, pol="IQUV", S=3, L=4, albedo=0.1, FT=np.float64, m_max=2, l_trunc=9):
     tau_rayl = np.tile(np.array([0.02, 0.05, 0.1, 0.2])[:L], (S, 1))
     kw = dict(tau_rayl=tau_rayl, tau_abs=np.full((S, L), tau_abs) * (1 + 0.3 * np.arange(S))[:, None], depol=0.03, albedo=albedo,
               m_max=m_max)
-    om = O.build_model(pol, 9, sza, [0.0, 35.0], [0.0, 60.0], FT=FT, **kw)
-    pm = vsm.host_model.model_from_arrays(arch, pol, 9, sza, [0.0, 35.0], [0.0, 60.0], float_type=FT, sources=sources, **kw)
+    om = O.build_model(pol, l_trunc, sza, [0.0, 35.0], [0.0, 60.0], FT=FT, **kw)
+    pm = vsm.host_model.model_from_arrays(arch, pol, l_trunc, sza, [0.0, 35.0], [0.0, 60.0], float_type=FT, sources=sources, **kw)
     return om, pm
 
 
@@ -61,24 +61,25 @@ def test_thermal_source_operator(vsm, arch, FT):
     assert np.all(vsm.Architectures.to_host(added.j0_p)[:, 1::3] == 0)
 
 
-@pytest.mark.parametrize("pol", ["I", "IQUV"])
-def test_rt_run_thermal_slot_vs_oracle(vsm, arch, pol):
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQUV", 9),        # N = 8, 32: operator level
+                                         ("IQUV", 19), ("IQU", 33)])    # N = 52, 60: the slot rides in the fused strip layer kernel
+def test_rt_run_thermal_slot_vs_oracle(vsm, arch, pol, l_trunc):
     """rt_run(model; sources = ThermalEmission) and sources = SolarBeam + ThermalEmission against the oracle's slot pass."""
     H = vsm.host_model
     B = 0.1 + 0.01 * np.arange(4)[:, None] * np.array([1.0, 2.0, 3.0])[None, :]
-    om, pm = _models(vsm, arch, 30.0, 0.05, (H.ThermalEmission(B_layer=B),), pol=pol)
+    om, pm = _models(vsm, arch, 30.0, 0.05, (H.ThermalEmission(B_layer=B),), pol=pol, l_trunc=l_trunc)
     Rt, Tt = O.rt_run_thermal(om, B)
     R, T = vsm.CoreRT.rt_run(pm)
     assert np.max(np.abs(Rt[:, 0])) > 0
     # without a SolarBeam the solar slot runs with F0 = 0; like the reference's, the Lambertian surface layer still carries its
     # beam term (lambertian_surface.jl:67-73 uses pol_type.I0, not F0), so the thermal-only total over a reflecting surface is
     # "solar slot at F0 = 0" + thermal slot
-    om0 = O.build_model(pol, 9, 30.0, [0.0, 35.0], [0.0, 60.0], tau_rayl=om.tau_rayl, tau_abs=om.tau_abs, depol=0.03, albedo=om.albedo,
+    om0 = O.build_model(pol, l_trunc, 30.0, [0.0, 35.0], [0.0, 60.0], tau_rayl=om.tau_rayl, tau_abs=om.tau_abs, depol=0.03, albedo=om.albedo,
                         m_max=om.m_max)
     om0.F0 = np.zeros((om.pol.n, om.tau_rayl.shape[0]))
     R0, T0 = O.rt_run(om0)
     assert _rel(R, R0 + Rt) < 1e-9 and _rel(T, T0 + Tt) < 1e-9
-    _, pm2 = _models(vsm, arch, 30.0, 0.05, (H.SolarBeam(), H.ThermalEmission(B_layer=B)), pol=pol)
+    _, pm2 = _models(vsm, arch, 30.0, 0.05, (H.SolarBeam(), H.ThermalEmission(B_layer=B)), pol=pol, l_trunc=l_trunc)
     Rs, Ts = O.rt_run(om)
     R2, T2 = vsm.CoreRT.rt_run(pm2)
     assert _rel(R2, Rs + Rt) < 1e-9 and _rel(T2, Ts + Tt) < 1e-9
@@ -97,3 +98,32 @@ def test_thermal_is_independent_of_sza_and_opaque_column_is_a_blackbody(vsm, arc
         src = (H.ThermalEmission(T_layers=[250.0] * 4, nu=nu),)
         R, _ = vsm.CoreRT.rt_run(_models(vsm, arch, 30.0, 100.0, src, albedo=0.0, m_max=m_max)[1])
         assert np.allclose(R[0, 0, :] / H.planck_spectrum_wn(250.0, nu), 1.0, atol=1e-3), m_max
+
+
+def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch):
+    """The fused thermal slot (vsm_layer_forward_thermal, FP64 32 < N <= 60) against the operator-level slot pass on the same
+    scenes: Rayleigh + absorption with a non-scattering layer in the middle (that layer stays operator level inside the fused
+    pass), thick layers (many doublings), and layers with two aerosol types (Z mixed per point inside the kernel)."""
+    H = vsm.host_model
+    rng = np.random.default_rng(3)
+    S, L = 5, 4
+    B = 0.05 + 0.02 * rng.random((L, S))
+    geo = ("IQU", 29, 35.0, [0.0, 50.0], [0.0, 120.0])     # N = 54
+    tau_rayl = np.tile(np.array([0.02, 0.0, 0.3, 0.6]), (S, 1))        # layer 2 does not scatter
+    tau_abs = 10.0 ** rng.uniform(-2, 0.5, (S, L))
+    tau_aer = np.array([[0.0, 0.0, 0.2, 0.1], [0.03, 0.0, 0.1, 0.3]])
+    aos = [H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.7, 12))), 0.95, 0.1),
+           H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.5, 8))), 0.9, 0.0)]
+    for kw in (dict(tau_rayl=tau_rayl, tau_abs=tau_abs),
+               dict(tau_rayl=tau_rayl, tau_abs=tau_abs, tau_aer=tau_aer, aerosol_optics=aos)):
+        model = H.model_from_arrays(arch, *geo, depol=0.03, albedo=0.2, m_max=3, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)),
+                                    **kw)
+        monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
+        Rf, Tf = vsm.CoreRT.rt_run(model)
+        monkeypatch.setenv("VSM_NO_THERMAL_FUSION", "1")
+        Ro, To = vsm.CoreRT.rt_run(model)
+        monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
+        solar = H.model_from_arrays(arch, *geo, depol=0.03, albedo=0.2, m_max=3, **kw)
+        Rs, Ts = vsm.CoreRT.rt_run(solar)
+        assert np.max(np.abs(Ro - Rs)) > 1e-4                      # the slot contributes
+        assert _rel(Rf - Rs, Ro - Rs) < 1e-9 and _rel(Tf - Ts, To - Ts) < 1e-9

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional
 
@@ -734,9 +735,21 @@ class Scene:
             self._th_ones = torch.ones(max(S, 1), dtype=self.dt, device=self.dev)
         added, comp = self._th_added, self._th_comp
         q = self.dq.cstruct()
+        # FP64, 32 < N <= 60: a scattering layer's slot in ONE fused launch (vsm_layer_forward_thermal: the strip layer kernel
+        # with the thermal source and expk = 1); everything else operator level, layer by layer on the same composite
+        fused = (FT == np.float64 and 32 < N and 4 * ((N + 3) // 4) + 2 <= 64 and os.environ.get("VSM_NO_THERMAL_FUSION") is None)
         for iz, ly in enumerate(mom["layers"]):
             props = ly["props"]
-            if props.max_tau_varpi > 2 * np.finfo(FT).eps:
+            scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps
+            if (fused and scatter and (iz == 0 or ly["iface"] == "11") and iz < self.thermal_B.shape[0]
+                    and (props.fcomp is None or props.fcomp.shape[1] <= 4)):
+                c = comp.cstruct()
+                ncomp = 0 if props.fcomp is None else int(props.fcomp.shape[1])
+                _lib.call("vsm_layer_forward_thermal", self.dt, C.byref(q), S, ly["nd"], _ptr(ly["dtau"]), _ptr(props.varpi),
+                          _ptr(self.thermal_B[iz]), ncomp, _ptr(props.Zpp), _ptr(props.Zmp),
+                          0 if ncomp else props.z_stride, _ptr(props.fcomp), 1 if iz == 0 else 0, C.byref(c), _stream_ptr())
+                continue
+            if scatter:
                 elemental_(pol, ly["tau_sum"], ly["dtau"], self._th_F0, props.materialize(), 0, ly["nd"], self.dq, added)
                 if iz < self.thermal_B.shape[0]:
                     a = added.cstruct()

@@ -218,9 +218,10 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
                             const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st);
+// thermal != 0: the layer's `:thermal` source slot (F0 = B[S], expk = 1) instead of the solar beam
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,
-                        hipStream_t st);
+                        hipStream_t st, int thermal = 0);
 
 // ---- column-strip kernels, FP32 (64 < N <= 96; two workgroups of 6 waves per CU): vsm_strip32.hip ----
 bool strip32_supported(int N);

@@ -51,7 +51,10 @@ namespace {
 // ---------------------------------------------------------------------------
 // Body shared by k_ed_strip and k_layer_strip.  On return (all waves past a barrier): r_s = strip of the final
 // r-+ (row signs of apply_D applied), t_s = strip of t++, sm.vec[0] = j0+, sm.vec[1] = j0- (final sign).
-template <int KS, bool MIX>   // KS k-steps per product: 4 KS >= N (columns >= N of the A-forms are zero); MIX: Z = sum_k f_k Z_k
+// THERMAL: the `:thermal` per-source slot of the layer (rt_kernel.jl:205-232; contribute!(::PreparedThermalEmission),
+// Sources/thermal_emission.jl:241-301) instead of the solar beam: j0+- = 2 pi (1 - varpi) B (1 - e^{-dtau/mu_i}) on the I rows,
+// the slot's expk = 1 (doubling.jl:62-81); `F0` then points at B[S] and tau_sum is not read.
+template <int KS, bool MIX, bool THERMAL = false>   // KS k-steps per product: 4 KS >= N (columns >= N of the A-forms are zero); MIX: Z = sum_k f_k Z_k
 __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& q, int m, int ndoubl,
                                         const double* __restrict__ dtau, const double* __restrict__ varpi,
                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
@@ -153,7 +156,10 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   // ---- SFI source (elemental.jl:348-392) -> LDS vectors jp, jm ---------------------------------------------
   if (tid < SNP) {
     double vjp = 0.0, vjm = 0.0;
-    if (tid < N) {
+    if (THERMAL) {
+      if (tid < N && tid % ns == 0 && mus[tid] > num<double>::eps())
+        vjp = vjm = 6.283185307179586476925286766559 * (1.0 - w) * F0[s] * (-expm1(-d / mus[tid]));
+    } else if (tid < N) {
       const int i = tid;
       const int i_start = ns * q.i_mu0;
       const double wct02 = (m == 0) ? 0.5 : 0.25;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   __syncthreads();
 
   // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------
-  double expk = exp(-d / q.mu0);
+  double expk = THERMAL ? 1.0 : exp(-d / q.mu0);
   int slot = 0;
   VSM_STAMP_DECL;
   VSM_STAMP(0);
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
 // rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
 // either the TOA copy (iz == 1: copy_added_to_composite!, rt_helpers.jl:188-200) or interaction!(::_11).  The added
 // layer never leaves the chip.
-template <int KS, bool MIX>
+template <int KS, bool MIX, bool THERMAL = false>
 __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
                                                         const double* __restrict__ varpi,
                                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
+  ed_body<KS, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -686,7 +692,8 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
                                     const double*, const zsrc<double>&, const added<double>&, hipStream_t);                 \
   int VSM_CAT(launch_ia_strip_, KS)(int, int, const composite<double>&, const added<double>&, hipStream_t);                \
   int VSM_CAT(launch_layer_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,    \
-                                       const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t);
+                                       const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t,      \
+                                       int);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIP_DECL(VSM_STRIP_KS)
@@ -715,11 +722,26 @@ int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double
 }
 int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
                                                const double* varpi, const double* tau_sum, const double* F0,
-                                               const zsrc<double>& z, int toa, const composite<double>& c, hipStream_t st) {
+                                               const zsrc<double>& z, int toa, const composite<double>& c, hipStream_t st,
+                                               int thermal) {
   static int prepared = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_layer_strip)");
   static int prepared_mix = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_layer_strip mix)");
   if (prepared) return prepared;
   if (prepared_mix) return prepared_mix;
+  if (thermal) {   // F0 = B[S]
+    static int prepared_th = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false, true>, "hipFuncSetAttribute(k_layer_strip th)");
+    static int prepared_thm = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true, true>, "hipFuncSetAttribute(k_layer_strip thm)");
+    if (prepared_th) return prepared_th;
+    if (prepared_thm) return prepared_thm;
+    if (z.ncomp > 0)
+      hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
+                         varpi, tau_sum, F0, z, toa, c);
+    else
+      hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
+                         varpi, tau_sum, F0, z, toa, c);
+    VSM_LAUNCH_CHECK("k_layer_strip(thermal)");
+    return VSM_OK;
+  }
   if (z.ncomp > 0)
     hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
                        tau_sum, F0, z, toa, c);
@@ -785,9 +807,9 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
 
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
-                        const composite<double>& c, hipStream_t st) {
+                        const composite<double>& c, hipStream_t st, int thermal) {
   if (S <= 0) return VSM_OK;
-#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st)
+#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal)
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_layer_forward: N=%d outside (32, 60]", q.N);
