@@ -423,8 +423,10 @@ int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
  * per-source recurrences of interaction.jl) in the launch of vsm_layer_forward(_mix)_*: m = 0, the solar source replaced by
  * j0+- = 2 pi (1 - varpi) B (1 - exp(-dtau/mu_i)) on the I rows, thermal_B[S] = Planck radiance of the layer per point.
  * ncomp = 0: Zpp / Zmp [N,N,S] with z_stride (0 = shared block); ncomp >= 1: component stacks [N,N,ncomp] + fcomp[ncomp,S].
- * `comp` is the composite of the thermal slot.  Fused for FP64 with 32 < N <= 60 and ncomp <= 4; any other shape returns
- * VSM_ERR_UNSUPPORTED (callers then run vsm_elemental + vsm_thermal_source + vsm_doubling + vsm_interaction). */
+ * `comp` is the composite of the thermal slot.  Fused for FP64 with 32 < N <= 60 and FP32 with 64 < N <= 96, ncomp <= 4
+ * (vsm_layer_thermal_fused(N, is_f64) != 0); any other shape returns VSM_ERR_UNSUPPORTED (callers then run
+ * vsm_elemental + vsm_thermal_source + vsm_doubling + vsm_interaction). */
+int vsm_layer_thermal_fused(int N, int is_f64);
 int vsm_layer_forward_thermal_f64(const vsm_quad_f64* q, int S, int ndoubl, const double* dtau, const double* varpi,
                                   const double* thermal_B, int ncomp, const double* Zpp, const double* Zmp, long long z_stride,
                                   const double* fcomp, int toa, const vsm_composite_f64* comp, void* stream);

@@ -100,30 +100,34 @@ def test_thermal_is_independent_of_sza_and_opaque_column_is_a_blackbody(vsm, arc
         assert np.allclose(R[0, 0, :] / H.planck_spectrum_wn(250.0, nu), 1.0, atol=1e-3), m_max
 
 
-def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch):
-    """The fused thermal slot (vsm_layer_forward_thermal, FP64 32 < N <= 60) against the operator-level slot pass on the same
-    scenes: Rayleigh + absorption with a non-scattering layer in the middle (that layer stays operator level inside the fused
-    pass), thick layers (many doublings), and layers with two aerosol types (Z mixed per point inside the kernel)."""
+@pytest.mark.parametrize("FT,geo,tol", [(np.float64, ("IQU", 29, 35.0, [0.0, 50.0], [0.0, 120.0]), 1e-9),     # N = 54
+                                        (np.float32, ("IQUV", 37, 35.0, [0.0, 50.0], [0.0, 120.0]), 2e-3),   # N = 88
+                                        (np.float32, ("IQU", 51, 35.0, [0.0, 50.0], [0.0, 120.0]), 2e-3)])   # N = 87 (N % 4 != 0)
+def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch, FT, geo, tol):
+    """The fused thermal slot (vsm_layer_forward_thermal: FP64 32 < N <= 60, FP32 64 < N <= 96) against the operator-level slot
+    pass on the same scenes: Rayleigh + absorption with a non-scattering layer in the middle (that layer stays operator level
+    inside the fused pass), thick layers (many doublings), and layers with two aerosol types (Z mixed per point inside the
+    kernel)."""
     H = vsm.host_model
     rng = np.random.default_rng(3)
     S, L = 5, 4
     B = 0.05 + 0.02 * rng.random((L, S))
-    geo = ("IQU", 29, 35.0, [0.0, 50.0], [0.0, 120.0])     # N = 54
     tau_rayl = np.tile(np.array([0.02, 0.0, 0.3, 0.6]), (S, 1))        # layer 2 does not scatter
     tau_abs = 10.0 ** rng.uniform(-2, 0.5, (S, L))
     tau_aer = np.array([[0.0, 0.0, 0.2, 0.1], [0.03, 0.0, 0.1, 0.3]])
     aos = [H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.7, 12))), 0.95, 0.1),
            H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.5, 8))), 0.9, 0.0)]
+    N = H.rt_set_streams(geo[1], geo[2], geo[3], H.polarization_type(geo[0]), FT).Nquad * H.polarization_type(geo[0]).n
+    assert vsm._lib.lib().vsm_layer_thermal_fused(N, 1 if FT == np.float64 else 0) == 1
     for kw in (dict(tau_rayl=tau_rayl, tau_abs=tau_abs),
                dict(tau_rayl=tau_rayl, tau_abs=tau_abs, tau_aer=tau_aer, aerosol_optics=aos)):
-        model = H.model_from_arrays(arch, *geo, depol=0.03, albedo=0.2, m_max=3, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)),
-                                    **kw)
+        com = dict(depol=0.03, albedo=0.2, m_max=3, float_type=FT, **kw)
+        model = H.model_from_arrays(arch, *geo, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **com)
         monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
         Rf, Tf = vsm.CoreRT.rt_run(model)
         monkeypatch.setenv("VSM_NO_THERMAL_FUSION", "1")
         Ro, To = vsm.CoreRT.rt_run(model)
         monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
-        solar = H.model_from_arrays(arch, *geo, depol=0.03, albedo=0.2, m_max=3, **kw)
-        Rs, Ts = vsm.CoreRT.rt_run(solar)
+        Rs, Ts = vsm.CoreRT.rt_run(H.model_from_arrays(arch, *geo, **com))
         assert np.max(np.abs(Ro - Rs)) > 1e-4                      # the slot contributes
-        assert _rel(Rf - Rs, Ro - Rs) < 1e-9 and _rel(Tf - Ts, To - Ts) < 1e-9
+        assert _rel(Rf - Rs, Ro - Rs) < tol and _rel(Tf - Ts, To - Ts) < tol

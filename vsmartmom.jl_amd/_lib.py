@@ -84,6 +84,7 @@ _SIGS = {
     "vsm_device_name": (_I, [_I, C.c_char_p, _SZ]),
     "vsm_sync": (_I, [_P]),
     "vsm_fused_max_n": (_I, [_I]),
+    "vsm_layer_thermal_fused": (_I, [_I, _I]),
     "vsm_doubling_work_elems": (_SZ, [_I, _I]),
     "vsm_interaction_work_elems": (_SZ, [_I, _I]),
     "vsm_batched_mul_{T}": (_I, [_I, _I, _I, _I, _P, _LL, _P, _LL, _P, _P]),

@@ -735,9 +735,10 @@ class Scene:
             self._th_ones = torch.ones(max(S, 1), dtype=self.dt, device=self.dev)
         added, comp = self._th_added, self._th_comp
         q = self.dq.cstruct()
-        # FP64, 32 < N <= 60: a scattering layer's slot in ONE fused launch (vsm_layer_forward_thermal: the strip layer kernel
+        # FP64, 32 < N <= 60 / FP32, 64 < N <= 96: a scattering layer's slot in ONE fused launch (vsm_layer_forward_thermal: the strip layer kernel
         # with the thermal source and expk = 1); everything else operator level, layer by layer on the same composite
-        fused = (FT == np.float64 and 32 < N and 4 * ((N + 3) // 4) + 2 <= 64 and os.environ.get("VSM_NO_THERMAL_FUSION") is None)
+        fused = (os.environ.get("VSM_NO_THERMAL_FUSION") is None
+                 and _lib.lib().vsm_layer_thermal_fused(N, 1 if FT == np.float64 else 0) != 0)
         for iz, ly in enumerate(mom["layers"]):
             props = ly["props"]
             scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps

@@ -416,6 +416,13 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
   VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 1 && Zpp_comp && Zmp_comp && fcomp && Zpp && Zmp, "mix_Z: bad argument");
   return mix_Z<float>(N, S, ncomp, Zpp_comp, Zmp_comp, fcomp, Zpp, Zmp, as_stream(stream));
 }
+// does vsm_layer_forward_thermal_* fuse this shape?  (FP64: the strip kernels, 32 < N <= 60; FP32: 64 < N <= 96)
+int vsm_layer_thermal_fused(int N, int is_f64) {
+  static const bool off = getenv("VSM_NO_LAYER_FUSION") != nullptr || getenv("VSM_NO_STRIP") != nullptr;
+  static const bool v1 = getenv("VSM_STRIP32_V1") != nullptr;
+  if (off) return 0;
+  return is_f64 ? (strip_supported(N) ? 1 : 0) : ((strip32_supported(N) && !v1) ? 1 : 0);
+}
 // the `:thermal` per-source slot of a scattering layer through the fused layer kernel (m = 0; FP64, 32 < N <= 60, ncomp <= 4):
 // same launch as vsm_layer_forward(_mix) with the solar source replaced by the thermal one and expk = 1
 int vsm_layer_forward_thermal_f64(const vsm_quad_f64* q, int S, int ndoubl, const double* dtau, const double* varpi,
@@ -425,7 +432,7 @@ int vsm_layer_forward_thermal_f64(const vsm_quad_f64* q, int S, int ndoubl, cons
   if ((rc = check_quad(q)) || (rc = check_comp(comp))) return rc;
   VSM_REQUIRE(S >= 0 && ndoubl >= 0 && dtau && varpi && thermal_B && Zpp && Zmp, "layer_forward_thermal: bad argument");
   VSM_REQUIRE(ncomp >= 0 && (ncomp == 0 || fcomp), "layer_forward_thermal: bad component mix");
-  if (!strip_supported(q->N) || ncomp > 4) {
+  if (!vsm_layer_thermal_fused(q->N, 1) || ncomp > 4) {
     set_error("layer_forward_thermal: only the FP64 strip shapes (32 < N <= 60, ncomp <= 4) are fused; N=%d ncomp=%d -- use "
               "vsm_elemental / vsm_thermal_source / vsm_doubling / vsm_interaction", q->N, ncomp);
     return VSM_ERR_UNSUPPORTED;
@@ -437,9 +444,18 @@ int vsm_layer_forward_thermal_f64(const vsm_quad_f64* q, int S, int ndoubl, cons
 int vsm_layer_forward_thermal_f32(const vsm_quad_f32* q, int S, int ndoubl, const float* dtau, const float* varpi,
                                   const float* thermal_B, int ncomp, const float* Zpp, const float* Zmp, long long z_stride,
                                   const float* fcomp, int toa, const vsm_composite_f32* comp, void* stream) {
-  set_error("layer_forward_thermal: no fused FP32 thermal slot (N=%d) -- use vsm_elemental / vsm_thermal_source / vsm_doubling / "
-            "vsm_interaction", q ? q->N : 0);
-  return VSM_ERR_UNSUPPORTED;
+  int rc;
+  if ((rc = check_quad(q)) || (rc = check_comp(comp))) return rc;
+  VSM_REQUIRE(S >= 0 && ndoubl >= 0 && dtau && varpi && thermal_B && Zpp && Zmp, "layer_forward_thermal: bad argument");
+  VSM_REQUIRE(ncomp >= 0 && (ncomp == 0 || fcomp), "layer_forward_thermal: bad component mix");
+  if (!vsm_layer_thermal_fused(q->N, 0) || ncomp > 4) {
+    set_error("layer_forward_thermal: only the FP32 strip shapes (64 < N <= 96, ncomp <= 4) are fused; N=%d ncomp=%d -- use "
+              "vsm_elemental / vsm_thermal_source / vsm_doubling / vsm_interaction", q->N, ncomp);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  return strip32_layer_forward(cvt_quad<float>(q), S, 0, ndoubl, dtau, varpi, dtau /* tau_sum: not read */, thermal_B,
+                               zsrc<float>{Zpp, Zmp, ncomp ? 0 : z_stride, ncomp, fcomp}, toa, cvt_comp<float>(comp),
+                               as_stream(stream), 1);
 }
 int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,

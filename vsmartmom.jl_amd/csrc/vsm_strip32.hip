@@ -494,7 +494,8 @@ __device__ __forceinline__ int invert_strip_own(fstrip& E, fstrip& G, float* W, 
 // On return: r_s = strip of r-+, t_s = strip of t++, sm.vec[2 jpair] = j0+, sm.vec[2 jpair + 1] = j0-, all waves past a
 // barrier.
 // ---------------------------------------------------------------------------
-template <int KB, bool MIX>
+// THERMAL: the `:thermal` per-source slot instead of the solar beam (see vsm_strip.hip): F0 = B[S], expk = 1
+template <int KB, bool MIX, bool THERMAL = false>
 __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>& q, int m, int ndoubl,
                                         const float* __restrict__ dtau, const float* __restrict__ varpi,
                                         const float* __restrict__ tau_sum, const float* __restrict__ F0,
@@ -588,7 +589,10 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   }
   // ---- SFI source (elemental.jl:348-392) -----------------------------------------------------------------------
   float vjp = 0.0f, vjm = 0.0f;
-  if (tid < N) {
+  if (THERMAL) {
+    if (tid < N && tid % ns == 0 && mus[tid] > num<float>::eps())
+      vjp = vjm = 6.283185307179586476925286766559f * (1.0f - w) * F0[s] * (-expm1(-d / mus[tid]));
+  } else if (tid < N) {
     const int i = tid;
     const int i_start = ns * q.i_mu0;
     const float wct02 = (m == 0) ? 0.5f : 0.25f;
@@ -623,7 +627,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   half_barrier(p);
 
   // ---- doubling (rt_helpers.jl:102-166) ------------------------------------------------------------------------
-  float expk = exp(-d / q.mu0);
+  float expk = THERMAL ? 1.0f : exp(-d / q.mu0);
   int slot = 0;
   const int mrow = 16 * p.wave + p.l15;   // row of the mat-vecs
   const bool mlead = p.kq == 0;
@@ -896,7 +900,7 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composi
                   a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
 }
 
-template <int KB, bool MIX, bool AL>
+template <int KB, bool MIX, bool AL, bool THERMAL = false>
 __global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int S, int m, int ndoubl,
                                                               const float* __restrict__ dtau, const float* __restrict__ varpi,
                                                               const float* __restrict__ tau_sum, const float* __restrict__ F0,
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int
   VSM_HALF_PROLOGUE();
   fstrip r_s, t_s;
   int jpair;
-  ed_body<KB, MIX>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
+  ed_body<KB, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = p.s, tid = p.tid;
@@ -944,17 +948,31 @@ static int enable_lds32(K kern, const char* what) {
 template <int KB, bool AL>
 static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
-                          hipStream_t st) {
+                          hipStream_t st, int thermal) {
   static int prepared = enable_lds32(k_layer_strip32<KB, false, AL>, "hipFuncSetAttribute(k_layer_strip32)");
   static int prepared_mix = enable_lds32(k_layer_strip32<KB, true, AL>, "hipFuncSetAttribute(k_layer_strip32 mix)");
   if (prepared) return prepared;
   if (prepared_mix) return prepared_mix;
+  const dim3 grid((S + 1) / 2), block(2 * FNT);
+  const size_t lds = 2 * sizeof(fsmem32);
+  if (thermal) {   // F0 = B[S]
+    static int prepared_th = enable_lds32(k_layer_strip32<KB, false, AL, true>, "hipFuncSetAttribute(k_layer_strip32 th)");
+    static int prepared_thm = enable_lds32(k_layer_strip32<KB, true, AL, true>, "hipFuncSetAttribute(k_layer_strip32 thm)");
+    if (prepared_th) return prepared_th;
+    if (prepared_thm) return prepared_thm;
+    if (z.ncomp > 0)
+      hipLaunchKernelGGL((k_layer_strip32<KB, true, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
+                         toa, c);
+    else
+      hipLaunchKernelGGL((k_layer_strip32<KB, false, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
+                         toa, c);
+    VSM_LAUNCH_CHECK("k_layer_strip32(thermal)");
+    return VSM_OK;
+  }
   if (z.ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip32<KB, true, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, q, S, m, ndoubl, dtau, varpi, tau_sum,
-                       F0, z, toa, c);
+    hipLaunchKernelGGL((k_layer_strip32<KB, true, AL>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
   else
-    hipLaunchKernelGGL((k_layer_strip32<KB, false, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, q, S, m, ndoubl, dtau, varpi, tau_sum,
-                       F0, z, toa, c);
+    hipLaunchKernelGGL((k_layer_strip32<KB, false, AL>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip32");
   return VSM_OK;
 }
@@ -987,13 +1005,19 @@ bool strip32_supported(int N) {
 
 int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
-                          hipStream_t st) {
+                          hipStream_t st, int thermal) {
   if (S <= 0) return VSM_OK;
-  if (use_v1()) return strip32v1_layer_forward(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  if (use_v1()) {
+    if (thermal) {
+      set_error("strip32_layer_forward: the first-generation FP32 strip kernels (VSM_STRIP32_V1) have no thermal slot");
+      return VSM_ERR_UNSUPPORTED;
+    }
+    return strip32v1_layer_forward(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  }
   // N % 4 != 0: element-wise global accesses, one instantiation (KB = 6) for all such N
-  if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  return launch_layer32<5, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
+  if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
+  if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
+  return launch_layer32<5, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
 }
 
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
