@@ -134,6 +134,19 @@ function CoreRT.contribute!(prep::CoreRT.PreparedThermalEmission, a::AddedLayer{
           _p(dτ), _p(ϖ), _p(ROCArray(prep.B_layer[iz, :])), th, _stream())
 end
 
+# the :thermal slot of a whole scattering "11" / TOA layer on the slot's own composite `cth` in ONE launch where the shape is fused
+# (vsm_layer_thermal_fused; rt_kernel.jl:205-232, doubling.jl:62-81): call it from the patched rt_kernel! next to vsm_layer_forward
+function thermal_layer_forward!(prep::CoreRT.PreparedThermalEmission, cth::CompositeLayer{FT}, p::CoreScatteringOpticalProperties, dτ::ROCArray,
+                                ndoubl::Integer, pol_type, qp::QuadPoints, iz::Integer) where {FT<:FTs}
+    N = size(cth.R⁻⁺, 1)
+    ccall((:vsm_layer_thermal_fused, libvsm), Cint, (Cint, Cint), N, FT == Float64 ? 1 : 0) == 1 || return false
+    _call(_fn("vsm_layer_forward_thermal", FT),
+          (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, Cint, PV, PV, Clonglong, PV, Cint, Ref{VsmComposite}, PV),
+          _q(qp, pol_type.n, FT), length(dτ), ndoubl, _p(dτ), _p(p.ϖ), _p(ROCArray(prep.B_layer[iz, :])), 0, _p(p.Z⁺⁺), _p(p.Z⁻⁺),
+          _ms(p.Z⁺⁺), C_NULL, iz == 1 ? 1 : 0, _c(cth), _stream())
+    return true
+end
+
 # ---- surfaces + post-processing ------------------------------------------------------------------------------------------
 # any BRDF surface (rpv_surface.jl:51-97): its Fourier block comes from the reference's own reflectance(brdf, pol_type, μ, m)
 function create_surface_layer!(brdf::CoreRT.AbstractSurfaceType, a::AddedLayer{FT}, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
