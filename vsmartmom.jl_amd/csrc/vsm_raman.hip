@@ -89,40 +89,31 @@ __global__ __launch_bounds__(256) void k_gemm_rs(int M, int Nc, int K, int S, co
 
 // the same for 16 < M <= 128, 16 <= Nc <= 128: one workgroup per (n1, dn), operands cross the memory system once
 // (vsm_gemm_lds.h)
-template <typename T, int MT, int CT>
-__global__ __launch_bounds__(256) void k_gemm_rs_lds(int M, int Nc, int K, int S, const int* __restrict__ shift, rs_op<T> A,
-                                                     rs_op<T> B, T* C, T alpha, rs_op<T> D, T beta, int zero_oob) {
-  __shared__ __attribute__((aligned(16))) T As_lds[gemm_lds_cfg<MT>::KC * gemm_lds_cfg<MT>::LDA];
+template <typename T, int MT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gemm_rs_lds(int M, int Nc, int K, int S, const int* __restrict__ shift, rs_op<T> A,
+                                                         rs_op<T> B, T* C, T alpha, rs_op<T> D, T beta, int zero_oob) {
+  constexpr int KC = 16;
+  __shared__ __attribute__((aligned(16))) T As_lds[gemm_lds_cfg<MT, KC>::LDS_ELEMS];
   const int n1 = blockIdx.x, dn = blockIdx.y;
   const int n0 = n1 + shift[dn];
   T* Cs = C + ((long long)n1 + (long long)S * dn) * ((long long)M * Nc);
   if (n0 < 0 || n0 >= S) {   // workgroup-uniform
     if (zero_oob)
-      for (int e = threadIdx.x; e < M * Nc; e += 256) Cs[e] = T(0);
+      for (int e = threadIdx.x; e < M * Nc; e += 64 * NW) Cs[e] = T(0);
     return;
   }
-  gemm_lds_body<T, MT, CT>(M, Nc, K, rs_block(A, n1, n0, dn, S), rs_block(B, n1, n0, dn, S), Cs,
-                           D.p ? rs_block(D, n1, n0, dn, S) : nullptr, alpha, beta, T(0), As_lds);
+  gemm_lds_body<T, MT, NW, KC>(M, Nc, K, rs_block(A, n1, n0, dn, S), rs_block(B, n1, n0, dn, S), Cs,
+                               D.p ? rs_block(D, n1, n0, dn, S) : nullptr, alpha, beta, T(0), As_lds);
 }
 template <typename T>
 static bool gemm_rs_lds(int M, int Nc, int K, int S, int Kr, const int* shift, rs_op<T> A, rs_op<T> B, T* C, rs_op<T> D,
                         hipStream_t st, int zero_oob) {
   static const bool off = getenv("VSM_NO_GEMM_LDS") != nullptr;
   if (off || M <= 16 || M > 128 || Nc < 16 || Nc > 128 || K < 8 || Kr > 65535) return false;
-  const int mt = (M + 15) / 16;
   const dim3 grid(S, Kr);
-#define VSM_GL(MT_, CT_) \
-  hipLaunchKernelGGL((k_gemm_rs_lds<T, MT_, CT_>), grid, dim3(256), 0, st, M, Nc, K, S, shift, A, B, C, T(1), D, T(1), zero_oob)
-#define VSM_GL_CT(MT_)            \
-  do {                            \
-    if (Nc > 64) VSM_GL(MT_, 2);  \
-    else VSM_GL(MT_, 1);          \
-  } while (0)
-  if (mt <= 2) VSM_GL_CT(2);
-  else if (mt <= 4) VSM_GL_CT(4);
-  else if (mt <= 6) VSM_GL_CT(6);
-  else VSM_GL_CT(8);
-#undef VSM_GL_CT
+#define VSM_GL(MT_, NW_) \
+  hipLaunchKernelGGL((k_gemm_rs_lds<T, MT_, NW_>), grid, dim3(64 * NW_), 0, st, M, Nc, K, S, shift, A, B, C, T(1), D, T(1), zero_oob)
+  VSM_GEMM_LDS_DISPATCH(M, Nc, VSM_GL);
 #undef VSM_GL
   return true;
 }
