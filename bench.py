@@ -177,27 +177,31 @@ def main():
     # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
     # one extra pass with an event pair around every layer-step launch; the same pass gives the device-only time of run()
     ev = []
-    orig = vsm.CoreRT.layer_forward_
+    orig, orig_multi = vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_
 
-    def timed(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        orig(*a, **k)
-        e1.record()
-        ev.append((e0, e1, a[5], a[7]))  # ndoubl, toa
+    def timed_with(f, moments_of):
+        def timed(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            f(*a, **k)
+            e1.record()
+            ev.append((e0, e1, a[5], a[7], moments_of(a)))  # ndoubl, toa, Fourier moments in the launch
+        return timed
 
-    vsm.CoreRT.layer_forward_ = timed
+    vsm.CoreRT.layer_forward_ = timed_with(orig, lambda a: 1)
+    vsm.CoreRT.layer_forward_multi_ = timed_with(orig_multi, lambda a: len(a[4]))
     r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r0.record()
     scene.run()
     r1.record()
     torch.cuda.synchronize()
-    vsm.CoreRT.layer_forward_ = orig
+    vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_ = orig, orig_multi
     run_ms = r0.elapsed_time(r1)
     n3, n2 = float(N) ** 3, float(N) ** 2
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in ev)
-    # algorithmic flops of one layer step: nd doublings + (unless TOA) one _11 interaction
-    k_flops = sum(S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2)) for _, _, nd, toa in ev)
+    k_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+    # algorithmic flops of one layer step: nd doublings + (unless TOA) one _11 interaction, per point and moment
+    k_flops = sum(nmom * S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2)) for _, _, nd, toa, nmom in ev)
+    moments_per_launch = max([e[4] for e in ev], default=1)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
     if cfg["FT"] == "f64" and 32 < N <= 60:
@@ -234,7 +238,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1)},
+                         "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1),
+                         "fourier_moments_per_launch": moments_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, L)

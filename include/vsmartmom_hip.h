@@ -418,6 +418,21 @@ int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
                           const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
                           int toa, const vsm_composite_f32* comp, const vsm_added_f32* added_scratch, void* stream);
 
+/* vsm_layer_forward(_mix)_* for nm Fourier moments of ONE layer (the moments of rt_run's outer loop, rt_run.jl:383, are
+ * independent until post-processing): m[nm] (host), Zpp[nm] / Zmp[nm] (host arrays of device pointers: the moment's Z block or
+ * component stack), comps[nm] (host array: one CompositeLayer per moment); dtau, varpi, tau_sum, F0, fcomp, ndoubl are the
+ * layer's and shared.  FP64 with 32 < N <= 60 runs the moments in ONE launch (three times the workgroups per launch: a third of
+ * the launch tails); other shapes run vsm_layer_forward(_mix) moment by moment through `added_scratch` / `z_scratch`. */
+int vsm_layer_forward_multi_f64(const vsm_quad_f64* q, int S, int nm, const int* m, int ndoubl, const double* dtau,
+                                const double* varpi, const double* tau_sum, const double* F0, int ncomp,
+                                const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
+                                double* z_scratch, int toa, const vsm_composite_f64* comps, const vsm_added_f64* added_scratch,
+                                void* stream);
+int vsm_layer_forward_multi_f32(const vsm_quad_f32* q, int S, int nm, const int* m, int ndoubl, const float* dtau,
+                                const float* varpi, const float* tau_sum, const float* F0, int ncomp, const float* const* Zpp,
+                                const float* const* Zmp, long long z_stride, const float* fcomp, float* z_scratch, int toa,
+                                const vsm_composite_f32* comps, const vsm_added_f32* added_scratch, void* stream);
+
 /* The `:thermal` per-source slot of one scattering layer (rt_kernel.jl:205-232: contribute!(::PreparedThermalEmission)
  * between elemental! and doubling!, Sources/thermal_emission.jl:241-301; the slot's own expk = 1, doubling.jl:62-81; the
  * per-source recurrences of interaction.jl) in the launch of vsm_layer_forward(_mix)_*: m = 0, the solar source replaced by

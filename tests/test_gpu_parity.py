@@ -674,6 +674,38 @@ def test_rt_run_component_mixing_on_device(vsm, arch, FT, pol, l_trunc, tol):
     assert _rel(vsm.CoreRT.from_device_matrix(mat.Zpp), ref) < (1e-14 if FT == np.float64 else 1e-6)
 
 
+@pytest.mark.parametrize("pol,l_trunc,FT,aer", [("IQU", 33, np.float64, False),   # N = 57: one launch per layer for the moments
+                                                ("IQU", 33, np.float64, True),    # ... component-mixed Z, 6 moments = 4 + 2
+                                                ("IQUV", 43, np.float32, False),  # N = 96 FP32: moment by moment in the library
+                                                ("I", 9, np.float64, True)])      # N = 7: LDS-resident kernels
+def test_moment_batched_run_equals_moment_by_moment(vsm, arch, monkeypatch, pol, l_trunc, FT, aer):
+    """Scene.run walks the Fourier moments of a group together (vsm_layer_forward_multi: one launch per layer step for the
+    group where the strip kernel takes the shape); the results are the bits of the moment-by-moment walk, with a thermal
+    slot riding along.  (A scene with a non-scattering layer is walked moment by moment: that layer reads the added layer's
+    j0+ as the previous step left it, like the reference.)"""
+    H = vsm.host_model
+    rng = np.random.default_rng(9)
+    S, L = 7, 4
+    tau_rayl = np.tile(np.array([0.03, 0.05, 0.1, 0.2]), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.1, m_max=2, float_type=FT)
+    if aer:
+        kw.update(tau_aer=np.array([[0.0, 0.0, 0.2, 0.1], [0.03, 0.0, 0.1, 0.3]]), m_max=5,
+                  aerosol_optics=[H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.7, 12))), 0.95, 0.1),
+                                  H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.5, 8))), 0.9, 0.0)])
+    B = 0.05 + 0.02 * rng.random((L, S))
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 0.0], [0.0, 75.0],
+                                sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **kw)
+    monkeypatch.delenv("VSM_NO_MOMENT_BATCH", raising=False)
+    out_b = vsm.CoreRT.rt_run(model, full_output=True)
+    monkeypatch.setenv("VSM_NO_MOMENT_BATCH", "1")
+    out_s = vsm.CoreRT.rt_run(model, full_output=True)
+    monkeypatch.delenv("VSM_NO_MOMENT_BATCH", raising=False)
+    for a, b in zip(out_b, out_s):
+        assert np.array_equal(a, b)
+    assert np.max(np.abs(out_b[0])) > 0
+
+
 def test_c2_full_size_properties_and_oracle_sample(vsm, arch):
     """BASELINE.json configs[1] at its FULL size (N = 60, 40 layers, 10 000 spectral points, FP64, m = 0..2) through the
     fused strip layer kernel: determinism, permutation equivariance over the spectral axis, linearity in F0, |Q|,|U| <= I,

@@ -92,6 +92,7 @@ _SIGS = {
     "vsm_batch_solve_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_elemental_doubling_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
     "vsm_layer_forward_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P]),
+    "vsm_layer_forward_multi_{T}": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _P, _I, _P, _P, _P]),
     "vsm_layer_forward_thermal_{T}": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
     "vsm_layer_forward_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "vsm_mix_Z_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -32,6 +32,7 @@ from . import host_model as H
 from .architectures import GPU, CPU, architecture, array_type, devi, synchronize_if_gpu, to_host
 
 IFACE = {"00": 0, "01": 1, "10": 2, "11": 3}
+MOMENT_BATCH = 4      # Fourier moments per layer-step call of Scene.run (VSM_MM_MAX of the library)
 
 
 def _require_gpu(arch):
@@ -291,6 +292,24 @@ def copy_added_to_composite_(comp: CompositeLayer, added: AddedLayer):
 
 
 _work_cache = {}
+
+
+def layer_forward_multi_(tau_sum, dtau, F0, props_list, ms, ndoubl: int, dq: DeviceQuad, toa: bool, comps, added: AddedLayer):
+    """The scattering branch of rt_kernel! (rt_kernel.jl:204-249) for SEVERAL Fourier moments of one layer (same dtau, varpi,
+    tau_sum, F0; per moment its Z and its CompositeLayer): one launch where the strip kernel takes the shape
+    (vsm_layer_forward_multi), else moment by moment inside the library."""
+    nm = len(ms)
+    p0 = props_list[0]
+    q, a = dq.cstruct(), added.cstruct()
+    dtype = comps[0].dtype
+    carr = (type(comps[0].cstruct()) * nm)(*[c.cstruct() for c in comps])
+    marr = (C.c_int * nm)(*[int(m) for m in ms])
+    zpp = (C.c_void_p * nm)(*[p.Zpp.data_ptr() for p in props_list])
+    zmp = (C.c_void_p * nm)(*[p.Zmp.data_ptr() for p in props_list])
+    ncomp = 0 if p0.fcomp is None else int(p0.fcomp.shape[1])
+    _lib.call("vsm_layer_forward_multi", dtype, C.byref(q), comps[0].nSpec, nm, marr, ndoubl, _ptr(dtau), _ptr(p0.varpi),
+              _ptr(tau_sum), _ptr(F0), ncomp, zpp, zmp, 0 if ncomp else p0.z_stride, _ptr(p0.fcomp), None, 1 if toa else 0,
+              carr, C.byref(a), _stream_ptr())
 
 
 def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False,
@@ -558,6 +577,7 @@ class Scene:
         self.albedo_d = (conv(np.ascontiguousarray(H.surface_albedo_spectrum(model.surface, S_full, FT)[self.sl]))
                          if self.spectral_surface else None)
         self.composite = make_composite_layer(FT, arch, (N, N), S)
+        self._composites = [self.composite]     # one per Fourier moment of a batch (run() allocates the others on first use)
         # the interaction work buffer belongs to the scene (a captured graph must not point into a shared cache)
         self.work = _lib.poison(torch.empty(max(int(_lib.lib().vsm_interaction_work_elems(N, max(S, 1))), 1), dtype=dt, device=dev))
         nV = len(model.vza)
@@ -697,22 +717,42 @@ class Scene:
         if self.S == 0:          # a rank that owns no spectral point (world > nSpec): nothing to launch
             return self.R_SFI, self.T_SFI
         self.added.j0_p.zero_()  # a fresh make_added_layer: zero_added_noscat! never writes j0+ (rt_helpers.jl:174-180)
-        for mom in self.moments:
-            m = mom["m"]
-            weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
-            for iz, ly in enumerate(mom["layers"]):
-                rt_kernel_(pol, self.added, self.composite, ly["props"], ly["iface"], ly["tau_sum"], m, self.dq,
-                           self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace,
-                           work=self.work)
-            create_surface_layer_(model.surface, self.added_surface, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
-            interaction_(mom["iface_surface"], self.composite, self.added_surface, work=self.work)
-            if self.compute_hdrf:
-                interaction_hdrf_(pol, self.composite, self.added_surface, m, self.dq, model.vza, model.vaz, self.qp, float(weight),
-                                  self.hdr_J, self.hdr, self.bhr_uw, self.bhr_dw)
-            postprocessing_vza_(pol, self.composite, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI,
-                                self.T_SFI)
-            if m == 0 and self.thermal_B is not None:
-                self._thermal_slot(mom, float(weight))
+        # Fourier moments are independent until post-processing (rt_run.jl:383): groups of up to MOMENT_BATCH moments walk the
+        # layers together, a scattering "11" / TOA layer step being ONE call for the group (vsm_layer_forward_multi: one launch
+        # with three times the workgroups where the strip kernel takes the shape), each moment on a CompositeLayer of its own
+        # (only when every layer scatters: a non-scattering layer reads the added layer's j0+ as the previous step left it --
+        # zero_added_noscat! never writes it, rt_helpers.jl:174-180 -- which ties the moments to their sequential order)
+        eps2 = 2 * np.finfo(FT).eps
+        sequential = (trace is not None or os.environ.get("VSM_NO_MOMENT_BATCH") is not None
+                      or any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"]))
+        nb = 1 if sequential else min(MOMENT_BATCH, len(self.moments))
+        while len(self._composites) < nb:
+            self._composites.append(make_composite_layer(FT, self.arch, (self.N, self.N), self.S))
+        for g0 in range(0, len(self.moments), nb):
+            group = self.moments[g0:g0 + nb]
+            comps = self._composites[:len(group)]
+            for iz in range(self.Nz):
+                ly0 = group[0]["layers"][iz]
+                if len(group) > 1 and ly0["props"].max_tau_varpi > eps2 and (iz == 0 or ly0["iface"] == "11"):
+                    layer_forward_multi_(ly0["tau_sum"], ly0["dtau"], self.F0, [mom["layers"][iz]["props"] for mom in group],
+                                         [mom["m"] for mom in group], ly0["nd"], self.dq, iz == 0, comps, self.added)
+                    continue
+                for mom, comp in zip(group, comps):
+                    ly = mom["layers"][iz]
+                    rt_kernel_(pol, self.added, comp, ly["props"], ly["iface"], ly["tau_sum"], mom["m"], self.dq,
+                               self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace,
+                               work=self.work)
+            for mom, comp in zip(group, comps):
+                m = mom["m"]
+                weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+                create_surface_layer_(model.surface, self.added_surface, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
+                interaction_(mom["iface_surface"], comp, self.added_surface, work=self.work)
+                if self.compute_hdrf:
+                    interaction_hdrf_(pol, comp, self.added_surface, m, self.dq, model.vza, model.vaz, self.qp, float(weight),
+                                      self.hdr_J, self.hdr, self.bhr_uw, self.bhr_dw)
+                postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI, self.T_SFI)
+                if m == 0 and self.thermal_B is not None:
+                    self._thermal_slot(mom, float(weight))
         if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
             apply_ss_correction_(self.R_SFI, model.surface, pol, model.vza, model.vaz, self.qp.mu0,
                                  self.moments[-1]["tau_sum_surface"], model.m_max, self.arch, FT)

@@ -213,6 +213,49 @@ static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dta
   return interaction_impl<T>(VSM_IFACE_11, q->N, S, c, ad, (T*)nullptr, stream, false);
 }
 
+// vsm_layer_forward(_mix) for nm Fourier moments of one layer: ONE launch with gridDim.y = nm where the strip kernel takes the
+// shape (FP64, 32 < N <= 60, ncomp <= 4, groups of VSM_MM_MAX moments), else the single-moment path moment by moment
+template <typename T, typename Q, typename C, typename A>
+static int layer_forward_multi_impl(const Q* q, int S, int nm, const int* m, int ndoubl, const T* dtau, const T* varpi,
+                                    const T* tau_sum, const T* F0, int ncomp, const T* const* Zpp, const T* const* Zmp,
+                                    long long zs, const T* fcomp, T* z_scratch, int toa, const C* comps, const A* ad,
+                                    void* stream) {
+  int rc;
+  if ((rc = check_quad(q))) return rc;
+  VSM_REQUIRE(nm >= 0 && (nm == 0 || (m && Zpp && Zmp && comps)), "layer_forward_multi: bad moment list");
+  VSM_REQUIRE(S >= 0 && ndoubl >= 0, "layer_forward_multi: bad S/ndoubl");
+  VSM_REQUIRE(ncomp >= 0 && (ncomp == 0 || fcomp), "layer_forward_multi: bad component mix");
+  for (int i = 0; i < nm; ++i) {
+    if ((rc = check_comp(&comps[i]))) return rc;
+    VSM_REQUIRE(m[i] >= 0 && Zpp[i] && Zmp[i], "layer_forward_multi: bad moment %d", i);
+  }
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_fuse = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_LAYER_FUSION") != nullptr ||
+                                getenv("VSM_NO_MOMENT_BATCH") != nullptr;
+    if (!no_fuse && strip_supported(q->N) && ncomp <= 4) {
+      VSM_REQUIRE(dtau && varpi && tau_sum && F0, "layer_forward_multi: null input");
+      for (int i0 = 0; i0 < nm; i0 += VSM_MM_MAX) {
+        const int n = nm - i0 < VSM_MM_MAX ? nm - i0 : VSM_MM_MAX;
+        layer_mm_args<double> a;
+        for (int i = 0; i < VSM_MM_MAX; ++i) {
+          const int j = i0 + (i < n ? i : 0);
+          a.m[i] = m[j];
+          a.z[i] = zsrc<double>{Zpp[j], Zmp[j], ncomp ? 0 : zs, ncomp, fcomp};
+          a.c[i] = cvt_comp<double>(&comps[j]);
+        }
+        if ((rc = strip_layer_forward_mm(cvt_quad<double>(q), S, n, ndoubl, dtau, varpi, tau_sum, F0, a, toa, as_stream(stream))))
+          return rc;
+      }
+      return VSM_OK;
+    }
+  }
+  for (int i = 0; i < nm; ++i)
+    if ((rc = layer_forward_impl<T>(q, S, m[i], ndoubl, dtau, varpi, tau_sum, F0, Zpp[i], Zmp[i], ncomp ? 0 : zs, ncomp, fcomp,
+                                    z_scratch, toa, &comps[i], ad, stream)))
+      return rc;
+  return VSM_OK;
+}
+
 }  // namespace vsm
 
 using namespace vsm;
@@ -415,6 +458,21 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
                   float* Zmp, void* stream) {
   VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 1 && Zpp_comp && Zmp_comp && fcomp && Zpp && Zmp, "mix_Z: bad argument");
   return mix_Z<float>(N, S, ncomp, Zpp_comp, Zmp_comp, fcomp, Zpp, Zmp, as_stream(stream));
+}
+int vsm_layer_forward_multi_f64(const vsm_quad_f64* q, int S, int nm, const int* m, int ndoubl, const double* dtau,
+                                const double* varpi, const double* tau_sum, const double* F0, int ncomp,
+                                const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
+                                double* z_scratch, int toa, const vsm_composite_f64* comps, const vsm_added_f64* added_scratch,
+                                void* stream) {
+  return layer_forward_multi_impl<double>(q, S, nm, m, ndoubl, dtau, varpi, tau_sum, F0, ncomp, Zpp, Zmp, z_stride, fcomp,
+                                          z_scratch, toa, comps, added_scratch, stream);
+}
+int vsm_layer_forward_multi_f32(const vsm_quad_f32* q, int S, int nm, const int* m, int ndoubl, const float* dtau,
+                                const float* varpi, const float* tau_sum, const float* F0, int ncomp, const float* const* Zpp,
+                                const float* const* Zmp, long long z_stride, const float* fcomp, float* z_scratch, int toa,
+                                const vsm_composite_f32* comps, const vsm_added_f32* added_scratch, void* stream) {
+  return layer_forward_multi_impl<float>(q, S, nm, m, ndoubl, dtau, varpi, tau_sum, F0, ncomp, Zpp, Zmp, z_stride, fcomp,
+                                         z_scratch, toa, comps, added_scratch, stream);
 }
 // does vsm_layer_forward_thermal_* fuse this shape?  (FP64: the strip kernels, 32 < N <= 60; FP32: 64 < N <= 96)
 int vsm_layer_thermal_fused(int N, int is_f64) {

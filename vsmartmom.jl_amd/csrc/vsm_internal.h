@@ -218,6 +218,17 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
                             const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st);
+// several Fourier moments of one layer in ONE launch (gridDim.y = nm <= VSM_MM_MAX): same dtau / varpi / tau_sum / F0, per
+// moment its m, Z source and composite -- three times the workgroups per launch, i.e. a third of the launch tails
+constexpr int VSM_MM_MAX = 4;
+template <typename T>
+struct layer_mm_args {
+  int m[VSM_MM_MAX];
+  zsrc<T> z[VSM_MM_MAX];
+  composite<T> c[VSM_MM_MAX];
+};
+int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
+                           const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa, hipStream_t st);
 // thermal != 0: the layer's `:thermal` source slot (F0 = B[S], expk = 1) instead of the solar beam
 int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,

@@ -593,11 +593,11 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
 // rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
 // either the TOA copy (iz == 1: copy_added_to_composite!, rt_helpers.jl:188-200) or interaction!(::_11).  The added
 // layer never leaves the chip.
-template <int KS, bool MIX, bool THERMAL = false>
-__global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
-                                                        const double* __restrict__ varpi,
-                                                        const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                                        zsrc<double> z, int toa, composite<double> c) {
+template <int KS, bool MIX, bool THERMAL>
+__device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndoubl, const double* __restrict__ dtau,
+                                           const double* __restrict__ varpi, const double* __restrict__ tau_sum,
+                                           const double* __restrict__ F0, const zsrc<double>& z, int toa,
+                                           const composite<double>& c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
@@ -622,6 +622,22 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
     return;
   }
   ia_body<KS>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
+}
+template <int KS, bool MIX, bool THERMAL = false>
+__global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
+                                                        const double* __restrict__ varpi,
+                                                        const double* __restrict__ tau_sum, const double* __restrict__ F0,
+                                                        zsrc<double> z, int toa, composite<double> c) {
+  layer_body<KS, MIX, THERMAL>(q, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
+}
+// the same for several Fourier moments at once: blockIdx.y picks the moment's m, Z source and composite
+template <int KS, bool MIX>
+__global__ __launch_bounds__(SNT, 2) void k_layer_strip_mm(quad<double> q, int ndoubl, const double* __restrict__ dtau,
+                                                           const double* __restrict__ varpi,
+                                                           const double* __restrict__ tau_sum, const double* __restrict__ F0,
+                                                           layer_mm_args<double> a, int toa) {
+  const int im = blockIdx.y;
+  layer_body<KS, MIX, false>(q, a.m[im], ndoubl, dtau, varpi, tau_sum, F0, a.z[im], toa, a.c[im]);
 }
 
 
@@ -693,7 +709,9 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
   int VSM_CAT(launch_ia_strip_, KS)(int, int, const composite<double>&, const added<double>&, hipStream_t);                \
   int VSM_CAT(launch_layer_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,    \
                                        const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t,      \
-                                       int);
+                                       int);                                                                                \
+  int VSM_CAT(launch_layer_strip_mm_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*, \
+                                          const double*, const layer_mm_args<double>&, int, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIP_DECL(VSM_STRIP_KS)
@@ -749,6 +767,23 @@ int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int
     hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
                        tau_sum, F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip");
+  return VSM_OK;
+}
+
+int VSM_CAT(launch_layer_strip_mm_, VSM_STRIP_KS)(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau,
+                                                  const double* varpi, const double* tau_sum, const double* F0,
+                                                  const layer_mm_args<double>& a, int toa, hipStream_t st) {
+  static int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_layer_strip_mm)");
+  static int prepared_mix = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_layer_strip_mm mix)");
+  if (prepared) return prepared;
+  if (prepared_mix) return prepared_mix;
+  if (a.z[0].ncomp > 0)
+    hipLaunchKernelGGL((k_layer_strip_mm<VSM_STRIP_KS, true>), dim3(S, nm), dim3(SNT), sizeof(ssmem), st, q, ndoubl, dtau, varpi,
+                       tau_sum, F0, a, toa);
+  else
+    hipLaunchKernelGGL((k_layer_strip_mm<VSM_STRIP_KS, false>), dim3(S, nm), dim3(SNT), sizeof(ssmem), st, q, ndoubl, dtau, varpi,
+                       tau_sum, F0, a, toa);
+  VSM_LAUNCH_CHECK("k_layer_strip_mm");
   return VSM_OK;
 }
 
@@ -813,6 +848,16 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_layer_forward: N=%d outside (32, 60]", q.N);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
+                           const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa, hipStream_t st) {
+  if (S <= 0 || nm <= 0) return VSM_OK;
+#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_mm_, KS)(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st)
+  VSM_STRIP_SWITCH(q.N, VSM_CALL)
+#undef VSM_CALL
+  set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
   return VSM_ERR_UNSUPPORTED;
 }
 
