@@ -249,6 +249,26 @@ static int layer_forward_multi_impl(const Q* q, int S, int nm, const int* m, int
       return VSM_OK;
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    static const bool no_fuse32 = getenv("VSM_NO_LAYER_FUSION") != nullptr || getenv("VSM_NO_MOMENT_BATCH") != nullptr ||
+                                  getenv("VSM_STRIP32_V1") != nullptr;
+    if (!no_fuse32 && strip32_supported(q->N) && ncomp <= 4) {
+      VSM_REQUIRE(dtau && varpi && tau_sum && F0, "layer_forward_multi: null input");
+      for (int i0 = 0; i0 < nm; i0 += VSM_MM_MAX) {
+        const int n = nm - i0 < VSM_MM_MAX ? nm - i0 : VSM_MM_MAX;
+        layer_mm_args<float> a;
+        for (int i = 0; i < VSM_MM_MAX; ++i) {
+          const int j = i0 + (i < n ? i : 0);
+          a.m[i] = m[j];
+          a.z[i] = zsrc<float>{Zpp[j], Zmp[j], ncomp ? 0 : zs, ncomp, fcomp};
+          a.c[i] = cvt_comp<float>(&comps[j]);
+        }
+        if ((rc = strip32_layer_forward_mm(cvt_quad<float>(q), S, n, ndoubl, dtau, varpi, tau_sum, F0, a, toa, as_stream(stream))))
+          return rc;
+      }
+      return VSM_OK;
+    }
+  }
   for (int i = 0; i < nm; ++i)
     if ((rc = layer_forward_impl<T>(q, S, m[i], ndoubl, dtau, varpi, tau_sum, F0, Zpp[i], Zmp[i], ncomp ? 0 : zs, ncomp, fcomp,
                                     z_scratch, toa, &comps[i], ad, stream)))

@@ -239,6 +239,8 @@ bool strip32_supported(int N);
 int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st, int thermal = 0);
+int strip32_layer_forward_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
+                             const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st);
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st);
 
 // grow-only device scratch (one per element type); not for concurrent streams.

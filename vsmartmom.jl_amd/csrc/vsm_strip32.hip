@@ -900,12 +900,11 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composi
                   a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
 }
 
-template <int KB, bool MIX, bool AL, bool THERMAL = false>
-__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int S, int m, int ndoubl,
-                                                              const float* __restrict__ dtau, const float* __restrict__ varpi,
-                                                              const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                                              zsrc<float> z, int toa, composite<float> c) {
-  VSM_HALF_PROLOGUE();
+template <int KB, bool MIX, bool AL, bool THERMAL>
+__device__ __forceinline__ void layer_body32(fsmem32& sm, fpos& p, const quad<float>& q, int S, int m, int ndoubl,
+                                             const float* __restrict__ dtau, const float* __restrict__ varpi,
+                                             const float* __restrict__ tau_sum, const float* __restrict__ F0,
+                                             const zsrc<float>& z, int toa, const composite<float>& c) {
   fstrip r_s, t_s;
   int jpair;
   ed_body<KB, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
@@ -936,6 +935,26 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int
   }
 #endif
   ia_body<KB, AL>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr, jpair);
+}
+
+
+template <int KB, bool MIX, bool AL, bool THERMAL = false>
+__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int S, int m, int ndoubl,
+                                                              const float* __restrict__ dtau, const float* __restrict__ varpi,
+                                                              const float* __restrict__ tau_sum, const float* __restrict__ F0,
+                                                              zsrc<float> z, int toa, composite<float> c) {
+  VSM_HALF_PROLOGUE();
+  layer_body32<KB, MIX, AL, THERMAL>(sm, p, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
+}
+// the same for several Fourier moments at once: blockIdx.y picks the moment's m, Z source and composite
+template <int KB, bool MIX, bool AL>
+__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32_mm(quad<float> q, int S, int ndoubl, const float* __restrict__ dtau,
+                                                                 const float* __restrict__ varpi,
+                                                                 const float* __restrict__ tau_sum, const float* __restrict__ F0,
+                                                                 layer_mm_args<float> a, int toa) {
+  VSM_HALF_PROLOGUE();
+  const int im = blockIdx.y;
+  layer_body32<KB, MIX, AL, false>(sm, p, q, S, a.m[im], ndoubl, dtau, varpi, tau_sum, F0, a.z[im], toa, a.c[im]);
 }
 
 template <typename K>
@@ -974,6 +993,22 @@ static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const 
   else
     hipLaunchKernelGGL((k_layer_strip32<KB, false, AL>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
   VSM_LAUNCH_CHECK("k_layer_strip32");
+  return VSM_OK;
+}
+template <int KB, bool AL>
+static int launch_layer32_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
+                             const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st) {
+  static int prepared = enable_lds32(k_layer_strip32_mm<KB, false, AL>, "hipFuncSetAttribute(k_layer_strip32_mm)");
+  static int prepared_mix = enable_lds32(k_layer_strip32_mm<KB, true, AL>, "hipFuncSetAttribute(k_layer_strip32_mm mix)");
+  if (prepared) return prepared;
+  if (prepared_mix) return prepared_mix;
+  const dim3 grid((S + 1) / 2, nm), block(2 * FNT);
+  const size_t lds = 2 * sizeof(fsmem32);
+  if (a.z[0].ncomp > 0)
+    hipLaunchKernelGGL((k_layer_strip32_mm<KB, true, AL>), grid, block, lds, st, q, S, ndoubl, dtau, varpi, tau_sum, F0, a, toa);
+  else
+    hipLaunchKernelGGL((k_layer_strip32_mm<KB, false, AL>), grid, block, lds, st, q, S, ndoubl, dtau, varpi, tau_sum, F0, a, toa);
+  VSM_LAUNCH_CHECK("k_layer_strip32_mm");
   return VSM_OK;
 }
 template <int KB, bool AL>
@@ -1018,6 +1053,18 @@ int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const 
   if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
   if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
   return launch_layer32<5, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
+}
+
+int strip32_layer_forward_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
+                             const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st) {
+  if (S <= 0 || nm <= 0) return VSM_OK;
+  if (use_v1()) {
+    set_error("strip32_layer_forward_mm: not with the first-generation FP32 strip kernels (VSM_STRIP32_V1)");
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (q.N & 3) return launch_layer32_mm<6, false>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
+  if (q.N > 80) return launch_layer32_mm<6, true>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
+  return launch_layer32_mm<5, true>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
 }
 
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
