@@ -124,6 +124,21 @@ function rt_kernel!(RS::noRS{FT}, pol_type, SFI, a::AddedLayer{FT}, c::Composite
            τ_sum, m, qp, I_static, arch, qp_μN, iz; workspace, dτ_max_threshold, dτ_min_floor)
 end
 
+# All Fourier moments of a scattering "11" / TOA layer in ONE launch (vsm_layer_forward_multi): for a patched rt_run that walks
+# `for iz` outside `for m` with one CompositeLayer per moment (the moments are independent until postprocessing_vza!);
+# ps[i] = the layer's CoreScatteringOpticalProperties of moment ms[i] (they differ in Z only), cs[i] its composite.
+function rt_kernel_moments!(RS::noRS{FT}, pol_type, a::AddedLayer{FT}, cs::Vector{<:CompositeLayer{FT}}, ps::Vector, τ_sum::ROCArray,
+                            ms::Vector{<:Integer}, qp, iz; dτ_max_threshold=nothing, dτ_min_floor=nothing) where {FT<:FTs}
+    dτ, ndoubl = get_dtau_ndoubl(ps[1], qp; dτ_max_threshold, dτ_min_floor)
+    comps = [_c(c) for c in cs]
+    zpp, zmp = [_p(p.Z⁺⁺) for p in ps], [_p(p.Z⁻⁺) for p in ps]
+    _call(_fn("vsm_layer_forward_multi", FT),
+          (Ref{VsmQuad{FT}}, Cint, Cint, Ptr{Cint}, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, PV, Cint,
+           Ptr{VsmComposite}, Ref{VsmAdded}, PV),
+          _q(qp, pol_type.n, FT), length(τ_sum), length(ms), Cint.(ms), ndoubl, _p(dτ), _p(ps[1].ϖ), _p(τ_sum), _p(RS.F₀), 0, zpp, zmp,
+          _ms(ps[1].Z⁺⁺), C_NULL, C_NULL, iz == 1 ? 1 : 0, comps, _c(a), _stream())
+end
+
 # contribute!(::PreparedThermalEmission, ...) (Sources/thermal_emission.jl:241-301): the :thermal slot of the elemental layer
 function CoreRT.contribute!(prep::CoreRT.PreparedThermalEmission, a::AddedLayer{FT}, ϖ::ROCArray, dτ::ROCArray, iz::Integer, m::Integer,
                             pol_type, qp::QuadPoints, arch) where {FT<:FTs}
