@@ -586,6 +586,28 @@ def test_noscat_and_mixed_interfaces(vsm, arch):
     assert _rel(Rg, Ro) < 1e-9 and _rel(Tg, To) < 1e-9
 
 
+@pytest.mark.parametrize("pol,l_trunc,FT,tol", [("I", 9, np.float64, 1e-9), ("IQU", 33, np.float64, 1e-9), ("IQUV", 41, np.float32, 2e-3)])
+def test_noscat_layer_below_scattering_layers(vsm, arch, pol, l_trunc, FT, tol):
+    """A non-scattering layer in the MIDDLE of the column (scatter, scatter, none, scatter): zero_added_noscat! never writes
+    j0+ (rt_helpers.jl:174-180), so that layer's interaction sees the doubled j0+ of the layer above -- and the first layers of
+    moment m + 1 would see the last layer of moment m if they did not scatter (the reference allocates its AddedLayer once,
+    rt_run.jl:326-335).  The device keeps the added layer in HBM for such scenes (no fused layer step) and meets the oracle,
+    which carries the same state."""
+    S, L = 4, 4
+    tau_rayl = np.tile(np.array([0.05, 0.1, 0.0, 0.2]), (S, 1))
+    tau_abs = np.tile(np.array([0.01, 0.2, 0.3, 0.05]), (S, 1)) * (1 + np.arange(S))[:, None]
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 35.0, [20.0, 0.0], [0.0, 100.0], FT=FT, tau_rayl=tau_rayl, tau_abs=tau_abs,
+                          depol=0.03, albedo=0.3, m_max=2)
+    tro, trg = [], []
+    Ro, To = O.rt_run(om, trace=tro)
+    Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
+    assert [t["iface"] for t in tro] == [t["iface"] for t in trg]
+    assert [t["scatter"] for t in trg[:4]] == [True, True, False, True]
+    assert _rel(Rg, Ro) < tol and _rel(Tg, To) < tol, (_rel(Rg, Ro), _rel(Tg, To))
+    Rg2, Tg2 = vsm.CoreRT.rt_run(pm)                      # without a trace: the same walk
+    assert np.array_equal(Rg, Rg2) and np.array_equal(Tg, Tg2)
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
 def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
     """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers

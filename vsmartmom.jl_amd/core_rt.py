@@ -477,16 +477,17 @@ def init_layer(props: DeviceLayerOptics, qp: H.QuadPoints, FT, numerics: H.RTNum
 def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerOptics, scattering_interface: str,
                tau_sum: torch.Tensor, m: int, dq: DeviceQuad, arch, iz: int, F0: torch.Tensor, FT,
                numerics: H.RTNumericalParameters, dtau: Optional[torch.Tensor] = None, ndoubl: Optional[int] = None,
-               trace: Optional[list] = None, work: Optional[torch.Tensor] = None):
+               trace: Optional[list] = None, work: Optional[torch.Tensor] = None, keep_added: bool = False):
     """rt_kernel!(::noRS, ...) (rt_kernel.jl:175-250).  iz is 1-based.  dtau/ndoubl may be
-    passed pre-computed (they only depend on the layer optics)."""
+    passed pre-computed (they only depend on the layer optics).  keep_added: leave the doubled layer in `added` (no fused
+    layer step) -- a later non-scattering layer reads its j0+ (zero_added_noscat! never writes it, rt_helpers.jl:174-180)."""
     scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps
     nd = 0
     if scatter:
         if dtau is None:
             dtau, ndoubl = init_layer(props, dq.host, FT, numerics, arch)
         nd = ndoubl
-        if iz == 1 or scattering_interface == "11":
+        if (iz == 1 or scattering_interface == "11") and not keep_added:
             # the whole layer step in one call (one launch when the strip kernels take the shape)
             if trace is not None:
                 trace.append(dict(iz=iz, m=m, scatter=True, ndoubl=nd, iface=scattering_interface))
@@ -723,8 +724,8 @@ class Scene:
         # (only when every layer scatters: a non-scattering layer reads the added layer's j0+ as the previous step left it --
         # zero_added_noscat! never writes it, rt_helpers.jl:174-180 -- which ties the moments to their sequential order)
         eps2 = 2 * np.finfo(FT).eps
-        sequential = (trace is not None or os.environ.get("VSM_NO_MOMENT_BATCH") is not None
-                      or any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"]))
+        has_noscat = any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"])
+        sequential = trace is not None or os.environ.get("VSM_NO_MOMENT_BATCH") is not None or has_noscat
         nb = 1 if sequential else min(MOMENT_BATCH, len(self.moments))
         while len(self._composites) < nb:
             self._composites.append(make_composite_layer(FT, self.arch, (self.N, self.N), self.S))
@@ -741,7 +742,7 @@ class Scene:
                     ly = mom["layers"][iz]
                     rt_kernel_(pol, self.added, comp, ly["props"], ly["iface"], ly["tau_sum"], mom["m"], self.dq,
                                self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace,
-                               work=self.work)
+                               work=self.work, keep_added=has_noscat)
             for mom, comp in zip(group, comps):
                 m = mom["m"]
                 weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
