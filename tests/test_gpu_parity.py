@@ -608,6 +608,27 @@ def test_noscat_layer_below_scattering_layers(vsm, arch, pol, l_trunc, FT, tol):
     assert np.array_equal(Rg, Rg2) and np.array_equal(Tg, Tg2)
 
 
+@pytest.mark.parametrize("pol,l_trunc,FT,tol", [("I", 9, np.float64, 1e-9), ("IQU", 33, np.float64, 1e-9), ("IQUV", 19, np.float64, 1e-9),
+                                                ("IQUV", 41, np.float32, 2e-3), ("IQU", 19, np.float32, 2e-3)])
+def test_rt_run_layers_without_doubling(vsm, arch, pol, l_trunc, FT, tol):
+    """Scattering layers so thin that doubling_number gives ndoubl = 0 (the elemental layer IS the layer; apply_D takes its
+    ndoubl < 1 branch, doubling.jl:178-201) between ordinary layers, at the TOA and next to the surface, through every fused
+    layer kernel (LDS-resident, FP64 strip, FP32 strip) -- rt_run vs the oracle with the same ndoubl / interface trace."""
+    S, L = 4, 5
+    tau_rayl = np.tile(np.array([1e-6, 0.05, 5e-7, 0.1, 8e-7]), (S, 1)) * (1 + 0.2 * np.arange(S))[:, None]
+    tau_abs = np.tile(np.array([1e-8, 0.02, 1e-9, 0.3, 1e-8]), (S, 1))
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 35.0, [20.0, 0.0], [0.0, 100.0], FT=FT, tau_rayl=tau_rayl, tau_abs=tau_abs,
+                          depol=0.03, albedo=0.3, m_max=2)
+    tro, trg = [], []
+    Ro, To = O.rt_run(om, trace=tro)
+    Rg, Tg = vsm.CoreRT.rt_run(pm, trace=trg)
+    assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
+    assert [t["ndoubl"] for t in trg[:5]].count(0) == 3 and all(t["scatter"] for t in trg)
+    assert _rel(Rg, Ro) < tol and _rel(Tg, To) < tol, (_rel(Rg, Ro), _rel(Tg, To))
+    Rb, Tb = vsm.CoreRT.rt_run(pm)                        # the moment-batched walk
+    assert _rel(Rb, Ro) < tol and _rel(Tb, To) < tol
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
 def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
     """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers
