@@ -189,6 +189,37 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     assert err.max() < 1e-3 and err.mean() < 1e-4
 
 
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 33), ("IQUV", 43)])   # N = 7, 57 (fused strip kernels), 100 (operator level)
+@pytest.mark.parametrize("column", ["noscat_in_the_middle", "layers_without_doubling"])
+def test_rt_run_lin_corner_columns(vsm, arch, pol, l_trunc, column):
+    """The linearized run on columns that leave the common path: a non-scattering layer below scattering layers (its interaction
+    reads the j0+ / ap_j0+ the layer above left in the added layer, zero_added_noscat! does not write them) and scattering
+    layers with ndoubl = 0 (the elemental layer and its derivatives are the layer) -- R, T and the Jacobians vs the oracle."""
+    rng = np.random.default_rng(1)
+    S, L = 3, 4
+    if column == "noscat_in_the_middle":
+        tau_rayl = np.tile(np.array([0.05, 0.1, 0.0, 0.2]), (S, 1))
+    else:
+        tau_rayl = np.tile(np.array([1e-6, 0.05, 5e-7, 0.1]), (S, 1))
+    ga = np.tile(np.array([0.01, 0.2, 0.3, 0.05]), (S, 1)) * (1 + np.arange(S))[:, None]
+    if column == "layers_without_doubling":
+        ga[:, [0, 2]] = 1e-8
+    H = vsm.host_model
+    geo = (pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0])
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga, depol=0.0279, m_max=2)
+    om = O.build_model(*geo, albedo=0.2, **kw)
+    pm = H.model_from_arrays(arch, *geo, albedo=0.2, **kw)
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
+    R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga]), 0, 1, 1)
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9, (_rel(R, Ro), _rel(T, To))
+    for p in range(2):
+        assert _rel(Rd[..., p], Rdo[..., p]) < 1e-8 and _rel(Td[..., p], Tdo[..., p]) < 1e-8, p
+    if column == "layers_without_doubling":
+        Rf, Tf = vsm.CoreRT.rt_run(pm)                   # the forward run of the same model agrees; with a non-scattering layer
+        assert _rel(Rf, Ro) < 1e-9 and _rel(Tf, To) < 1e-9   # it does not, in the reference either: rt_kernel_lin.jl:87 hard-codes
+        #                                                      scatter = true (j0+ = 0 there), rt_kernel! keeps the stale j0+
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 7, 21, 57
 def test_rt_run_lin_fp32(vsm, arch, pol, l_trunc):
     """The FP32 linearized entry points (vsm_*_lin_f32; FP32 runs operator level): rt_run(model, lin_model, 0, 2, 1) in

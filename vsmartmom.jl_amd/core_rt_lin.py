@@ -180,8 +180,8 @@ class SceneLin:
             lods = H.constructCoreOpticalProperties(model, m)
             lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods, m)
             tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
-            if any(t != "11" for t in tags):
-                raise _lib.VSMError("rt_run (linearized): every layer must scatter (rt_kernel_lin.jl:87 hard-codes scatter=true)")
+            # rt_kernel_lin.jl:87 hard-codes scatter = true: a layer with tau*varpi <= 2 eps still goes through elemental! and
+            # doubling! (ndoubl = 0), only its interaction follows the 00 / 01 / 10 tag of extractEffectiveProps
             tsd = np.zeros((S_full, pl, Nz + 1))
             for iz in range(Nz):
                 tsd[:, :, iz + 1] = tsd[:, :, iz] + lins[iz].tau_dot
