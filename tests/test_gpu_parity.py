@@ -629,6 +629,31 @@ def test_rt_run_layers_without_doubling(vsm, arch, pol, l_trunc, FT, tol):
     assert _rel(Rb, Ro) < tol and _rel(Tb, To) < tol
 
 
+@pytest.mark.parametrize("pol,l_trunc,FT,tol", [("IQU", 9, np.float64, 1e-9), ("IQU", 33, np.float64, 1e-9), ("IQUV", 19, np.float64, 1e-9),
+                                                ("IQUV", 41, np.float32, 2e-3)])
+def test_rt_run_polarized_spectral_F0(vsm, arch, pol, l_trunc, FT, tol):
+    """A polarized incident beam that varies from point to point (model.F0 [nStokes, nSpec] with non-zero Q, U, V): the SFI source
+    of elemental! contracts Z with F0 per point (elemental.jl:348-392) -- rt_run vs the oracle through every fused layer kernel,
+    with an albedo of 0 (the Lambertian surface source uses pol_type.I0, not F0)."""
+    rng = np.random.default_rng(21)
+    S, L = 6, 3
+    tau_rayl = np.tile(np.array([0.05, 0.1, 0.2]), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 35.0, [20.0, 0.0, 55.0], [0.0, 100.0, 260.0], FT=FT, tau_rayl=tau_rayl,
+                          tau_abs=tau_abs, depol=0.03, albedo=0.0, m_max=2)
+    n = om.pol.n
+    F0 = np.zeros((n, S))
+    F0[0] = 1.0 + rng.random(S)
+    F0[1:] = 0.3 * rng.standard_normal((n - 1, S))
+    om.F0, pm.F0 = F0.astype(FT), F0.copy()
+    Ro, To = O.rt_run(om)
+    Rg, Tg = vsm.CoreRT.rt_run(pm)
+    assert _rel(Rg, Ro) < tol and _rel(Tg, To) < tol, (_rel(Rg, Ro), _rel(Tg, To))
+    pm.F0 = 2.0 * F0
+    R2, _ = vsm.CoreRT.rt_run(pm)
+    assert _rel(R2, 2.0 * Rg) < (1e-12 if FT == np.float64 else 1e-5)
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
 def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
     """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers
