@@ -210,7 +210,8 @@ def main():
         kernel_name = "k_layer_strip32"
     else:
         kernel_name = "k_elemental_doubling + k_interaction11"
-    traffic, traffic_src = hbm_traffic_per_launch(kernel_name, cfg, S_local)
+    # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
+    traffic, traffic_src = hbm_traffic_per_launch(kernel_name, cfg, S_local) if args.variant == "rayleigh" else (None, None)
 
     if rank == 0:
         flops_pt = scene.flops_per_point()
