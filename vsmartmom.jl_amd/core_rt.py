@@ -708,9 +708,11 @@ class Scene:
             self.zcomp = zcomp
         self._assemble(nds, tags, maxima)
 
-    def run(self, trace: Optional[list] = None):
+    def run(self, trace: Optional[list] = None, streams: Optional[list] = None):
         """The device-resident part of rt_run (rt_run.jl:383-517): Fourier loop -> layer loop ->
-        surface -> interaction -> postprocessing.  Asynchronous; returns the device tensors."""
+        surface -> interaction -> postprocessing.  Asynchronous; returns the device tensors.  `streams`: a list that receives,
+        per Fourier moment, what the reference hands its `streams_callback` (rt_run.jl:496-516): clones of the composite layer's
+        R-+, T++ and of J0-+ (per-source slots added) after the surface interaction, with m and the Fourier weight."""
         model, pol, FT = self.model, self.pol, self.FT
         self.R_SFI.zero_()
         self.T_SFI.zero_()
@@ -754,6 +756,12 @@ class Scene:
                 postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI, self.T_SFI)
                 if m == 0 and self.thermal_B is not None:
                     self._thermal_slot(mom, float(weight))
+                if streams is not None:
+                    Jm, Jp = comp.J0_m.clone(), comp.J0_p.clone()
+                    if m == 0 and self.thermal_B is not None:
+                        Jm += self._th_comp.J0_m
+                        Jp += self._th_comp.J0_p
+                    streams.append(dict(m=m, weight=float(weight), R_mp=comp.R_mp.clone(), T_pp=comp.T_pp.clone(), J0_m=Jm, J0_p=Jp))
         if isinstance(model.surface, H.CoxMunkSurface) and self.ss_correction:   # rt_run.jl:520-524 (SFI is always on here)
             apply_ss_correction_(self.R_SFI, model.surface, pol, model.vza, model.vaz, self.qp.mu0,
                                  self.moments[-1]["tau_sum_surface"], model.m_max, self.arch, FT)
@@ -860,6 +868,44 @@ class Scene:
 
 def prepare_scene(model: H.RTModel, spec_slice: Optional[slice] = None) -> Scene:
     return Scene(model, spec_slice)
+
+
+@dataclass
+class StreamRTResult:
+    """StreamRTResult of the reference (rt_run.jl:107-123): per-Fourier-moment operators and SFI vectors at ALL quadrature
+    streams instead of post-processed (vza, vaz) outputs; arrays in the reference's layout."""
+    qp_mu: np.ndarray          # quadrature nodes (one per stream, not repeated per Stokes component)
+    i_mu0: int                 # 1-based index of the SZA stream, like the reference's
+    mu0: float
+    pol_n: int
+    weight: List[float]        # Fourier weight per moment (0.5/pi for m = 0, 1/pi else)
+    R_mp_per_m: List[np.ndarray]   # [N, N, nSpec] composite R-+ at TOA
+    T_pp_per_m: List[np.ndarray]   # [N, N, nSpec] composite T++ at BOA
+    J_m_per_m: List[np.ndarray]    # [N, 1, nSpec] upwelling SFI vector, per-source slots added
+    J_p_per_m: List[np.ndarray]    # [N, 1, nSpec] downwelling
+    tau_total: np.ndarray          # [nSpec, nLayer] = tau_rayl + tau_abs (the reference leaves the aerosols out)
+    tau_rayl: np.ndarray
+    tau_abs: np.ndarray
+
+
+def rt_run_streams(model: H.RTModel) -> StreamRTResult:
+    """rt_run_streams(model) (rt_run.jl:125-192): one run, everything a caller needs to do the Fourier sum and the stream
+    lookup of postprocessing_vza! offline for any number of viewing geometries (test/test_CoreRT.jl:45-108)."""
+    scene = prepare_scene(model)
+    scene.compute_hdrf = False
+    st: list = []
+    scene.run(streams=st)
+    synchronize_if_gpu()
+    st.sort(key=lambda d: d["m"])
+    mat = lambda t: from_device_matrix(t).transpose(1, 2, 0).copy()          # (S, j, i) layout tensor -> [i, j, S]
+    vec = lambda t: to_host(t).T[:, None, :].copy()                          # (S, N) -> [N, 1, S]
+    qp = model.quad_points
+    FT = model.float_type
+    return StreamRTResult(np.asarray(qp.qp_mu, dtype=FT).copy(), int(qp.imu0) + 1, float(qp.mu0), model.polarization_type.n,
+                          [d["weight"] for d in st], [mat(d["R_mp"]) for d in st], [mat(d["T_pp"]) for d in st],
+                          [vec(d["J0_m"]) for d in st], [vec(d["J0_p"]) for d in st],
+                          (np.asarray(model.tau_rayl) + np.asarray(model.tau_abs)).astype(FT), np.asarray(model.tau_rayl, dtype=FT),
+                          np.asarray(model.tau_abs, dtype=FT))
 
 
 def rt_run(model: H.RTModel, trace: Optional[list] = None, full_output: bool = False):
