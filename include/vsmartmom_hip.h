@@ -270,6 +270,21 @@ int vsm_elemental_lin_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
                           const float* tau_sum_dot, const float* Zpp_dot, const float* Zmp_dot,
                           long long zd_stride_s, long long zd_stride_p, const vsm_added_f32* added,
                           const vsm_added_lin_f32* added_lin, void* stream);
+/* elemental! (lin) for a layer whose phase matrix is a per-point mix of component matrices (aerosol Jacobians): as
+ * vsm_elemental_lin_* with Z = sum_{c < ncomp} fz[c, s] Zc[c] (zsel < 0) or Z = Zc[zsel] (zsel >= 0, fz unused) and
+ * Z_dot[:, :, s, p] = sum_{c < ncomp_total} zdcoef[c, p, s] Zc[c]; Zc_pp / Zc_mp: [N, N, ncomp_total] blocks of one Fourier
+ * moment, fz [ncomp, S], zdcoef [ncomp_total, p_layer, S] (the layer's slices of vsm_layer_optics_lin_*'s outputs).
+ * ncomp_total <= 16. */
+int vsm_elemental_lin_mix_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                              const double* tau_sum, const double* F0, int ncomp, int ncomp_total, const double* Zc_pp,
+                              const double* Zc_mp, int zsel, const double* fz, int p_layer, const double* dtau_dot,
+                              const double* varpi_dot, const double* tau_sum_dot, const double* zdcoef,
+                              const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, void* stream);
+int vsm_elemental_lin_mix_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
+                              const float* tau_sum, const float* F0, int ncomp, int ncomp_total, const float* Zc_pp,
+                              const float* Zc_mp, int zsel, const float* fz, int p_layer, const float* dtau_dot,
+                              const float* varpi_dot, const float* tau_sum_dot, const float* zdcoef,
+                              const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, void* stream);
 /* doubling_allparams! (doubling_lin.jl:216-339): forward + the first n_active parameter slots; the D-symmetry at
  * the end covers all P slots.  dtau_dot_all[S,P] (zero beyond the layer parameters); expk[S] updated in place. */
 size_t vsm_doubling_lin_work_elems(int N, int S, int P);
@@ -405,6 +420,32 @@ int vsm_layer_optics_f32(int S, int L, int nAer, const double* tau_rayl, const d
 /* dtau[S,L] = tau ./ 2^ndoubl[l] (get_dtau_ndoubl, rt_kernel.jl:266-287); ndoubl: device int[L]. */
 int vsm_layer_dtau_f64(int S, int L, const int* ndoubl, const double* tau, double* dtau, void* stream);
 int vsm_layer_dtau_f32(int S, int L, const int* ndoubl, const float* tau, float* dtau, void* stream);
+/* constructCoreOpticalProperties with lin_model (compEffectiveLayerProperties_lin.jl:43-197; createAero with derivatives
+ * :330-395; quotient rule of the pairwise `+`, types_lin.jl:196-380) for the rank's block [lo, lo + S) of a band of S_full
+ * points: the derivatives of the layer optics with respect to the pl = 7 nAer + nGas layer parameters (slot order of
+ * parameter_layout.jl:28-56: per aerosol tau_ref, n_r, n_i, r_m, sigma_r, p0, sigma_p; then the gases).  Inputs (device, FP64,
+ * indexed on the FULL axis): tau_rayl, tau_abs [S_full, L]; tau_aer [nAer, L]; ssa, ftrunc [nAer]; tau_abs_dot [S_full, L, nGas]
+ * (lin_model.tau_abs_dot); tau_aer_dot [7, nAer, L] (lin_model.tau_aer_dot); ssa_dot, ftrunc_dot [4, nAer]
+ * (lin_aerosol_optics: d/d(n_r, n_i, r_m, sigma_r)); ndoubl: device int[L].  Outputs (block-local, column-major):
+ * dtau_dot_all [S, P, L] = tau_dot / 2^ndoubl (columns >= pl zero: the surface slots of doubling_allparams!),
+ * varpi_dot [S, pl, L], tau_sum_dot [S, pl, L+1] (layer l: derivative of the optical depth above it; L: total), and for
+ * nAer > 0 the per-point weights fz [nAer+1, S, L] of the component phase matrices in Z and the coefficients
+ * zdcoef [CT, pl, S, L] of Z_dot over the CT = (nAer+1) + 4 nAer component blocks
+ * [Z_Rayleigh, Z_aer1.., dZ_aer1/d(n_r, n_i, r_m, sigma_r), dZ_aer2/d.., ..] -- Z_dot itself is never materialised
+ * (vsm_elemental_lin_mix_* forms it where it is consumed). */
+int vsm_layer_optics_lin_f64(int S_full, int lo, int S, int L, int nAer, int nGas, int P, const double* tau_rayl,
+                             const double* tau_abs, double varpi_cabannes, const double* tau_aer, const double* ssa,
+                             const double* ftrunc, const double* tau_abs_dot, const double* tau_aer_dot,
+                             const double* ssa_dot, const double* ftrunc_dot, const int* ndoubl, double* dtau_dot_all,
+                             double* varpi_dot, double* tau_sum_dot, double* fz, double* zdcoef, void* stream);
+int vsm_layer_optics_lin_f32(int S_full, int lo, int S, int L, int nAer, int nGas, int P, const double* tau_rayl,
+                             const double* tau_abs, double varpi_cabannes, const double* tau_aer, const double* ssa,
+                             const double* ftrunc, const double* tau_abs_dot, const double* tau_aer_dot,
+                             const double* ssa_dot, const double* ftrunc_dot, const int* ndoubl, float* dtau_dot_all,
+                             float* varpi_dot, float* tau_sum_dot, float* fz, float* zdcoef, void* stream);
+/* expk[S] = exp(-dtau / mu0) (init_layer, rt_kernel.jl:339-349); doubling! squares it in place. */
+int vsm_layer_expk_f64(int S, const double* dtau, double mu0, double* expk, void* stream);
+int vsm_layer_expk_f32(int S, const float* dtau, float mu0, float* expk, void* stream);
 
 /* rt_kernel!(::noRS) for ONE scattering layer (src/CoreRT/CoreKernel/rt_kernel.jl:175-250): elemental! + doubling!
  * followed by copy_added_to_composite! (toa != 0, i.e. iz == 1; rt_helpers.jl:188-200) or

@@ -8,6 +8,7 @@
 module vSmartMOMROCmExt
 
 using AMDGPU
+using Libdl
 using vSmartMOM
 import vSmartMOM.Architectures: devi, array_type, architecture, GPU, _has_cuda, _sync_gpu
 import vSmartMOM.CoreRT: batched_mul, batch_inv!, batch_solve!, batched_pointer_cache, elemental!, doubling!,
@@ -27,7 +28,21 @@ _fn(base, FT) = Symbol(base, "_", _sfx(FT))            # e.g. :vsm_interaction_f
     rc == 0 || error("libvsmartmom_hip: status $rc: " * unsafe_string(ccall((:vsm_last_error, libvsm), Cstring, ())))
     nothing
 end
-_call(f::Symbol, types::Tuple, args...) = _chk(ccall(Libdl.dlsym(Libdl.dlopen(libvsm), f), Cint, types, args...))
+# ccall wants a LITERAL tuple of argument types (a tuple-valued variable does not lower: "ccall argument types must be a
+# tuple"), while the function may be a run-time pointer.  `@vsm "base" FT (types...) args...` therefore splices the literal
+# tuple into a ccall on the dlsym pointer of base_f64 / base_f32 (static parameters such as FT are allowed inside the tuple).
+const _handle = Ref{Ptr{Cvoid}}(C_NULL)
+const _symcache = Dict{Symbol,Ptr{Cvoid}}()
+function _sym(f::Symbol)
+    get!(_symcache, f) do
+        _handle[] == C_NULL && (_handle[] = Libdl.dlopen(libvsm))
+        Libdl.dlsym(_handle[], f)
+    end
+end
+macro vsm(base, FT, types, args...)
+    (types isa Expr && types.head === :tuple) || error("@vsm: the argument types must be a literal tuple")
+    :(_chk(ccall(_sym(_fn($(esc(base)), $(esc(FT)))), Cint, $(esc(types)), $(map(esc, args)...))))
+end
 _stream() = PV(AMDGPU.stream().stream)                  # hipStream_t of the current task
 _p(A::ROCArray) = PV(pointer(A))
 _p(::Nothing) = C_NULL
@@ -66,21 +81,22 @@ _crs(a) = VsmAddedRS(_p(a.ier⁻⁺), _p(a.iet⁺⁺), _p(a.ier⁺⁻), _p(a.iet
 _Crs(c) = VsmCompositeRS(_p(c.ieR⁻⁺), _p(c.ieR⁺⁻), _p(c.ieT⁺⁺), _p(c.ieT⁻⁻), _p(c.ieJ₀⁺), _p(c.ieJ₀⁻), size(c.ieR⁻⁺, 4), 0)
 _tag(::ScatteringInterface_00) = 0; _tag(::ScatteringInterface_01) = 1
 _tag(::ScatteringInterface_10) = 2; _tag(::ScatteringInterface_11) = 3
-_work(FT, f::Symbol, dims...) = ROCArray{FT}(undef, max(1, Int(ccall((f, libvsm), Csize_t, ntuple(_ -> Cint, length(dims)), dims...))))
+_work(FT, f::Symbol, a, b) = ROCArray{FT}(undef, max(1, Int(ccall(_sym(f), Csize_t, (Cint, Cint), a, b))))
+_work(FT, f::Symbol, a, b, c) = ROCArray{FT}(undef, max(1, Int(ccall(_sym(f), Csize_t, (Cint, Cint, Cint), a, b, c))))
 
 # ---- L1 operator API: gpu_batched_cuda.jl:65-233 -----------------------------------------------------------------------
 function batched_mul(A::ROCArray{FT,3}, B::ROCArray{FT,3}) where {FT<:FTs}
     M, K, S = size(A); Nc = size(B, 2)
     C = ROCArray{FT}(undef, M, Nc, S)
-    _call(_fn("vsm_batched_mul", FT), (Cint, Cint, Cint, Cint, PV, Clonglong, PV, Clonglong, PV, PV),
+    @vsm("vsm_batched_mul", FT, (Cint, Cint, Cint, Cint, PV, Clonglong, PV, Clonglong, PV, PV),
           M, Nc, K, S, _p(A), M * K, _p(B), size(B, 3) == 1 && S > 1 ? 0 : K * Nc, _p(C), _stream())
     C
 end
 function batch_inv!(X::ROCArray{FT,3}, A::ROCArray{FT,3}, args...) where {FT<:FTs}     # all three call forms; A intact
-    _call(_fn("vsm_batch_inv", FT), (Cint, Cint, PV, PV, PV, PV), size(A, 1), size(A, 3), _p(A), _p(X), C_NULL, _stream()); X
+    @vsm("vsm_batch_inv", FT, (Cint, Cint, PV, PV, PV, PV), size(A, 1), size(A, 3), _p(A), _p(X), C_NULL, _stream()); X
 end
 function batch_solve!(X::ROCArray{FT,3}, A::ROCArray{FT,3}, B::ROCArray{FT,3}) where {FT<:FTs}
-    _call(_fn("vsm_batch_solve", FT), (Cint, Cint, Cint, PV, PV, PV, PV, PV, PV), size(A, 1), size(B, 2), size(A, 3),
+    @vsm("vsm_batch_solve", FT, (Cint, Cint, Cint, PV, PV, PV, PV, PV, PV), size(A, 1), size(B, 2), size(A, 3),
           _p(A), _p(B), _p(X), _p(similar(A)), C_NULL, _stream()); X
 end
 batched_pointer_cache(::ROCArray) = nothing              # route batch_inv! to the 2-argument form
@@ -89,23 +105,23 @@ batched_pointer_cache(::ROCArray) = nothing              # route batch_inv! to t
 # elemental! (elemental.jl:174-230)
 function elemental!(pol_type, SFI::Bool, τ_sum::ROCArray, dτ::ROCArray, F₀::ROCArray, p::CoreScatteringOpticalProperties,
                     m::Int, ndoubl::Int, scatter::Bool, qp::QuadPoints, a::AddedLayer{FT}, arch) where {FT<:FTs}
-    _call(_fn("vsm_elemental", FT), (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Ref{VsmAdded}, PV),
+    @vsm("vsm_elemental", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Ref{VsmAdded}, PV),
           _q(qp, pol_type.n, FT), length(dτ), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺), _ms(p.Z⁺⁺), _c(a), _stream())
 end
 # doubling! (doubling.jl:121-131); expk is squared in place ndoubl times like the reference
 function doubling!(pol_type, SFI, expk::ROCArray{FT}, ndoubl::Int, a::AddedLayer, I_static, arch) where {FT<:FTs}
     N, _, S = size(a.r⁻⁺)
-    _call(_fn("vsm_doubling", FT), (Cint, Cint, Cint, Cint, PV, Ref{VsmAdded}, PV, PV), N, pol_type.n, S, ndoubl, _p(expk), _c(a),
+    @vsm("vsm_doubling", FT, (Cint, Cint, Cint, Cint, PV, Ref{VsmAdded}, PV, PV), N, pol_type.n, S, ndoubl, _p(expk), _c(a),
           _p(_work(FT, :vsm_doubling_work_elems, N, S)), _stream())
 end
 # interaction! (interaction.jl:278-285); `work` is required off the fused "11" path, so it is always supplied
 function interaction!(iface, SFI, c::CompositeLayer{FT}, a::AddedLayer{FT}, I_static) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺)
-    _call(_fn("vsm_interaction", FT), (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV, PV), _tag(iface), N, S, _c(c), _c(a),
+    @vsm("vsm_interaction", FT, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV, PV), _tag(iface), N, S, _c(c), _c(a),
           _p(_work(FT, :vsm_interaction_work_elems, N, S)), _stream())
 end
 function copy_added_to_composite!(c::CompositeLayer{FT}, a::AddedLayer{FT}) where {FT<:FTs}
-    _call(_fn("vsm_copy_added_to_composite", FT), (Cint, Cint, Ref{VsmAdded}, Ref{VsmComposite}, PV), size(c.R⁻⁺, 1), size(c.R⁻⁺, 3), _c(a), _c(c), _stream())
+    @vsm("vsm_copy_added_to_composite", FT, (Cint, Cint, Ref{VsmAdded}, Ref{VsmComposite}, PV), size(c.R⁻⁺, 1), size(c.R⁻⁺, 3), _c(a), _c(c), _stream())
 end
 # rt_kernel!(::noRS) (rt_kernel.jl:175-250): the scattering branch of a "11" / TOA layer is ONE call (elemental! + doubling! +
 # copy | interaction!); the other branches keep the reference's sequence, whose pieces are the methods above.
@@ -115,8 +131,7 @@ function rt_kernel!(RS::noRS{FT}, pol_type, SFI, a::AddedLayer{FT}, c::Composite
     scatter = maximum(Array(p.τ .* p.ϖ)) > 2eps(FT)
     if scatter && (iz == 1 || iface isa ScatteringInterface_11)
         dτ, ndoubl = get_dtau_ndoubl(p, qp; dτ_max_threshold, dτ_min_floor)
-        return _call(_fn("vsm_layer_forward", FT),
-                     (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV),
+        return @vsm("vsm_layer_forward", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV),
                      _q(qp, pol_type.n, FT), length(τ_sum), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(RS.F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺),
                      _ms(p.Z⁺⁺), iz == 1 ? 1 : 0, _c(c), _c(a), _stream())
     end
@@ -132,8 +147,7 @@ function rt_kernel_moments!(RS::noRS{FT}, pol_type, a::AddedLayer{FT}, cs::Vecto
     dτ, ndoubl = get_dtau_ndoubl(ps[1], qp; dτ_max_threshold, dτ_min_floor)
     comps = [_c(c) for c in cs]
     zpp, zmp = [_p(p.Z⁺⁺) for p in ps], [_p(p.Z⁻⁺) for p in ps]
-    _call(_fn("vsm_layer_forward_multi", FT),
-          (Ref{VsmQuad{FT}}, Cint, Cint, Ptr{Cint}, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, PV, Cint,
+    @vsm("vsm_layer_forward_multi", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Ptr{Cint}, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, PV, Cint,
            Ptr{VsmComposite}, Ref{VsmAdded}, PV),
           _q(qp, pol_type.n, FT), length(τ_sum), length(ms), Cint.(ms), ndoubl, _p(dτ), _p(ps[1].ϖ), _p(τ_sum), _p(RS.F₀), 0, zpp, zmp,
           _ms(ps[1].Z⁺⁺), C_NULL, C_NULL, iz == 1 ? 1 : 0, comps, _c(a), _stream())
@@ -145,7 +159,7 @@ function CoreRT.contribute!(prep::CoreRT.PreparedThermalEmission, a::AddedLayer{
     (m == 0 && iz <= size(prep.B_layer, 1) && haskey(a.j₀_by_src, :thermal)) || return nothing
     slot = a.j₀_by_src[:thermal]
     th = VsmAdded(_p(a.r⁻⁺), _p(a.t⁺⁺), _p(a.r⁺⁻), _p(a.t⁻⁻), _p(slot.j₀⁺), _p(slot.j₀⁻), _ms(a.r⁻⁺), 0, 0)   # the slot's vectors
-    _call(_fn("vsm_thermal_source", FT), (Ref{VsmQuad{FT}}, Cint, PV, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(dτ),
+    @vsm("vsm_thermal_source", FT, (Ref{VsmQuad{FT}}, Cint, PV, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(dτ),
           _p(dτ), _p(ϖ), _p(ROCArray(prep.B_layer[iz, :])), th, _stream())
 end
 
@@ -155,8 +169,7 @@ function thermal_layer_forward!(prep::CoreRT.PreparedThermalEmission, cth::Compo
                                 ndoubl::Integer, pol_type, qp::QuadPoints, iz::Integer) where {FT<:FTs}
     N = size(cth.R⁻⁺, 1)
     ccall((:vsm_layer_thermal_fused, libvsm), Cint, (Cint, Cint), N, FT == Float64 ? 1 : 0) == 1 || return false
-    _call(_fn("vsm_layer_forward_thermal", FT),
-          (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, Cint, PV, PV, Clonglong, PV, Cint, Ref{VsmComposite}, PV),
+    @vsm("vsm_layer_forward_thermal", FT, (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, Cint, PV, PV, Clonglong, PV, Cint, Ref{VsmComposite}, PV),
           _q(qp, pol_type.n, FT), length(dτ), ndoubl, _p(dτ), _p(p.ϖ), _p(ROCArray(prep.B_layer[iz, :])), 0, _p(p.Z⁺⁺), _p(p.Z⁻⁺),
           _ms(p.Z⁺⁺), C_NULL, iz == 1 ? 1 : 0, _c(cth), _stream())
     return true
@@ -166,11 +179,11 @@ end
 # any BRDF surface (rpv_surface.jl:51-97): its Fourier block comes from the reference's own reflectance(brdf, pol_type, μ, m)
 function create_surface_layer!(brdf::CoreRT.AbstractSurfaceType, a::AddedLayer{FT}, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
     ρ = ROCArray(FT.(CoreRT.reflectance(brdf, pol_type, collect(qp.qp_μ), m)))
-    _call(_fn("vsm_brdf_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(τ_sum), m,
+    @vsm("vsm_brdf_surface", FT, (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT), length(τ_sum), m,
           _p(ρ), _p(τ_sum), _c(a), _stream())
 end
 function create_surface_layer!(s::LambertianSurfaceScalar{FT}, a::AddedLayer, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
-    _call(_fn("vsm_lambertian_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, FT, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT),
+    @vsm("vsm_lambertian_surface", FT, (Ref{VsmQuad{FT}}, Cint, Cint, FT, PV, Ref{VsmAdded}, PV), _q(qp, pol_type.n, FT),
           length(τ_sum), m, s.albedo, _p(τ_sum), _c(a), _stream())
 end
 _cm(s::CoxMunkSurface{FT}) where {FT} = (n = _get_n_water(s, FT(550)); VsmCoxMunk{FT}(s.wind_speed, real(n), imag(n), s.whitecap_albedo, s.include_whitecaps, s.shadowing))
@@ -178,18 +191,18 @@ const _ϕw = Dict{DataType,Any}()                        # 100-point Gauss-Legen
 _phi(FT) = get!(() -> map(x -> ROCArray(FT.(x)), vSmartMOM.CoreRT.CanopyOptics.gauleg(100, 0.0, Float64(π))), _ϕw, FT)
 function _reflectance(s::CoxMunkSurface{FT}, q, m, N, deriv) where {FT}
     ρ = ROCArray{FT}(undef, N, N); ρ̇ = deriv ? similar(ρ) : nothing; ϕ, w = _phi(FT)
-    _call(_fn("vsm_coxmunk_reflectance", FT), (Ref{VsmCoxMunk{FT}}, Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, PV, PV), _cm(s), q, m,
+    @vsm("vsm_coxmunk_reflectance", FT, (Ref{VsmCoxMunk{FT}}, Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, PV, PV, PV), _cm(s), q, m,
           length(ϕ), _p(ϕ), _p(w), _p(ρ), _p(ρ̇), _stream())
     ρ, ρ̇
 end
 function create_surface_layer!(s::CoxMunkSurface{FT}, a::AddedLayer, SFI, m::Int, pol_type, qp, τ_sum::ROCArray, arch) where {FT<:FTs}
     q = _q(qp, pol_type.n, FT); ρ, _ = _reflectance(s, q, m, size(a.r⁻⁺, 1), false)
-    _call(_fn("vsm_brdf_surface", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), q, length(τ_sum), m, _p(ρ), _p(τ_sum), _c(a), _stream())
+    @vsm("vsm_brdf_surface", FT, (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Ref{VsmAdded}, PV), q, length(τ_sum), m, _p(ρ), _p(τ_sum), _c(a), _stream())
 end
 # apply_ss_correction! (coxmunk_surface.jl:481-545); R_SFI lives on the device until the end of rt_run
 function apply_ss_correction!(R_SFI::ROCArray{FT,3}, s::CoxMunkSurface{FT}, pol_type, vza, vaz, μ₀, τ_total::ROCArray, m_max, nSpec) where {FT<:FTs}
     ϕ, w = _phi(FT); nV = length(vza); coef = ROCArray{FT}(undef, nV, pol_type.n)
-    _call(_fn("vsm_coxmunk_ss_correction", FT), (Ref{VsmCoxMunk{FT}}, Cint, Cint, Cint, Ptr{FT}, Ptr{FT}, FT, Cint, Cint, PV, PV, PV, PV, PV, PV),
+    @vsm("vsm_coxmunk_ss_correction", FT, (Ref{VsmCoxMunk{FT}}, Cint, Cint, Cint, Ptr{FT}, Ptr{FT}, FT, Cint, Cint, PV, PV, PV, PV, PV, PV),
           _cm(s), pol_type.n, nSpec, nV, FT.(cosd.(vza)), FT.(deg2rad.(vaz)), FT(μ₀), m_max, length(ϕ), _p(ϕ), _p(w), _p(τ_total), _p(coef), _p(R_SFI), _stream())
 end
 # postprocessing_vza! noRS/SFI (postprocessing_vza.jl:23-94) on device-resident R_SFI / T_SFI: no per-moment D2H of J₀∓
@@ -197,7 +210,7 @@ function postprocessing_vza!(::noRS, iμ₀, pol_type, c::CompositeLayer{FT}, vz
     n = pol_type.n; nV = length(vza)
     row0 = Cint[n * (vSmartMOM.CoreRT.nearest_point(qp_μ, cosd(v)) - 1) for v in vza]
     w = FT[weight * (k <= 2 ? cosd(m * vaz[v]) : sind(m * vaz[v])) for v in 1:nV, k in 1:n]
-    _call(_fn("vsm_postprocess_vza", FT), (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{FT}, PV, PV, PV, PV, PV), size(c.J₀⁻, 1), n, nSpec, nV,
+    @vsm("vsm_postprocess_vza", FT, (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{FT}, PV, PV, PV, PV, PV), size(c.J₀⁻, 1), n, nSpec, nV,
           row0, w, _p(c.J₀⁻), _p(c.J₀⁺), _p(R_SFI), _p(T_SFI), _stream())
 end
 
@@ -205,28 +218,52 @@ end
 function elemental!(pol_type, SFI::Bool, τ_sum::ROCArray, τ̇_sum::ROCArray, dτ::ROCArray, F₀::ROCArray, p, ṗ::CoreScatteringOpticalPropertiesLin,
                     m::Int, ndoubl::Int, scatter::Bool, qp::QuadPoints, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}, arch; kw...) where {FT<:FTs}
     pl = size(ṗ.τ̇, 2); dτ̇ = ṗ.τ̇ ./ FT(2)^ndoubl; Ż = ṗ.Ż⁺⁺
-    _call(_fn("vsm_elemental_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, PV, PV, PV, PV, PV, Clonglong,
+    @vsm("vsm_elemental_lin", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, PV, PV, PV, PV, PV, Clonglong,
                                          Clonglong, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
           _q(qp, pol_type.n, FT), length(dτ), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺), _ms(p.Z⁺⁺), pl, _p(dτ̇), _p(ṗ.ϖ̇),
           _p(τ̇_sum), _p(Ż), _p(ṗ.Ż⁻⁺), _ms(Ż), size(Ż, 1)^2 * size(Ż, 3), _c(a), _c(ȧ), _stream())
 end
+# constructCoreOpticalProperties with lin_model on the device (compEffectiveLayerProperties_lin.jl:43-197, types_lin.jl:196-380):
+# one call per band fills τ̇/2^ndoubl, ϖ̇, τ̇_sum for every layer and -- with aerosol slots -- the per-point weights fz and the
+# coefficients zdcoef of Ż over the component blocks [Z_Rayleigh, Z_aer.., ∂Z_aer/∂(nᵣ, nᵢ, rₘ, σᵣ)..]; Ż[N,N,nSpec,P] is not built.
+# `d` = NamedTuple of the raw device inputs (FP64): τ_rayl, τ_abs [nSpec,Nz]; τ_aer [nAer,Nz]; ϖ̃, fᵗ [nAer]; τ̇_abs [nSpec,Nz,nGas];
+# τ̇_aer [7,nAer,Nz]; ϖ̃̇, ḟᵗ [4,nAer]; ndoubl::ROCArray{Cint} [Nz].  lo = 0-based start of this rank's block of S points.
+function layer_optics_lin!(::Type{FT}, d, S_full::Int, lo::Int, S::Int, Nz::Int, nAer::Int, nGas::Int, P::Int, ϖ_Cabannes,
+                           dτ̇::ROCArray, ϖ̇::ROCArray, τ̇_sum::ROCArray, fz, zdcoef) where {FT<:FTs}
+    @vsm("vsm_layer_optics_lin", FT, (Cint, Cint, Cint, Cint, Cint, Cint, Cint, PV, PV, Cdouble, PV, PV, PV, PV, PV, PV, PV, PV, PV, PV, PV, PV, PV, PV),
+          S_full, lo, S, Nz, nAer, nGas, P, _p(d.τ_rayl), _p(d.τ_abs), Float64(ϖ_Cabannes), _p(d.τ_aer), _p(d.ϖ̃), _p(d.fᵗ), _p(d.τ̇_abs),
+          _p(d.τ̇_aer), _p(d.ϖ̃̇), _p(d.ḟᵗ), _p(d.ndoubl), _p(dτ̇), _p(ϖ̇), _p(τ̇_sum), _p(fz), _p(zdcoef), _stream())
+end
+# elemental! (lin) of a layer whose Z / Ż are per-point mixes of the component blocks Zc (one Fourier moment): zsel = -1 mixes
+# Z = Σ fz[c,s] Zc[c], zsel ≥ 0 takes Zc[zsel + 1]; Ż[:,:,s,p] = Σ zdcoef[c,p,s] Zc[c] is formed inside the kernel.
+function elemental_mix!(pol_type, τ_sum::ROCArray, τ̇_sum::ROCArray, dτ::ROCArray, dτ̇::ROCArray, F₀::ROCArray, ϖ::ROCArray, ϖ̇::ROCArray,
+                        Zc⁺⁺::ROCArray{FT,3}, Zc⁻⁺::ROCArray{FT,3}, ncomp::Int, zsel::Int, fz, zdcoef::ROCArray, m::Int, ndoubl::Int,
+                        qp::QuadPoints, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}) where {FT<:FTs}
+    @vsm("vsm_elemental_lin_mix", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, Cint, Cint, PV, PV, Cint, PV, Cint, PV, PV, PV, PV,
+                                             Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+          _q(qp, pol_type.n, FT), length(dτ), m, ndoubl, _p(dτ), _p(ϖ), _p(τ_sum), _p(F₀), ncomp, size(Zc⁺⁺, 3), _p(Zc⁺⁺), _p(Zc⁻⁺), zsel, _p(fz),
+          size(ϖ̇, 2), _p(dτ̇), _p(ϖ̇), _p(τ̇_sum), _p(zdcoef), _c(a), _c(ȧ), _stream())
+end
+# expk = exp.(-dτ ./ μ₀) (init_layer, rt_kernel.jl:339-349) without a host round trip
+layer_expk!(expk::ROCArray{FT}, dτ::ROCArray{FT}, μ₀) where {FT<:FTs} =
+    @vsm("vsm_layer_expk", FT, (Cint, PV, FT, PV, PV), length(dτ), _p(dτ), FT(μ₀), _p(expk), _stream())
 function doubling_allparams!(pol_type, SFI, expk::ROCArray{FT}, ndoubl::Int, a::AddedLayer, ȧ::AddedLayerLin, I_static, arch, dτ̇::ROCArray, μ₀; N_active::Int=0) where {FT<:FTs}
     N, _, S = size(a.r⁻⁺); P = size(ȧ.ap_ṙ⁻⁺, 4)
-    _call(_fn("vsm_doubling_lin", FT), (Cint, Cint, Cint, Cint, PV, PV, FT, Cint, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV), N, pol_type.n, S, ndoubl,
+    @vsm("vsm_doubling_lin", FT, (Cint, Cint, Cint, Cint, PV, PV, FT, Cint, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV), N, pol_type.n, S, ndoubl,
           _p(expk), _p(dτ̇), FT(μ₀), N_active, _c(a), _c(ȧ), _p(_work(FT, :vsm_doubling_lin_work_elems, N, S, P)), _stream())
 end
 function interaction!(iface, SFI, c::CompositeLayer{FT}, ċ::CompositeLayerLin{FT}, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}, I_static) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺); P = size(ċ.Ṙ⁻⁺, 4)
-    _call(_fn("vsm_interaction_lin", FT), (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmCompositeLin}, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV),
+    @vsm("vsm_interaction_lin", FT, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmCompositeLin}, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV),
           _tag(iface), N, S, _c(c), _c(ċ), _c(a), _c(ȧ), _p(_work(FT, :vsm_interaction_lin_work_elems, N, S, P)), _stream())
 end
 function create_surface_layer!(::noRS, s::LambertianSurfaceScalar{FT}, a::AddedLayer, ȧ::AddedLayerLin, iparam::Int, SFI, m::Int, pol_type, qp, τ_sum, τ̇_sum, F₀, arch) where {FT<:FTs}
-    _call(_fn("vsm_lambertian_surface_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, FT, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+    @vsm("vsm_lambertian_surface_lin", FT, (Ref{VsmQuad{FT}}, Cint, Cint, FT, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
           _q(qp, pol_type.n, FT), length(τ_sum), m, s.albedo, iparam - 1, _p(τ_sum), _p(τ̇_sum), size(τ̇_sum, 2), _p(F₀), _c(a), _c(ȧ), _stream())
 end
 function create_surface_layer!(::noRS, s::CoxMunkSurface{FT}, a::AddedLayer, ȧ::AddedLayerLin, iparam::Int, SFI, m::Int, pol_type, qp, τ_sum, τ̇_sum, F₀, arch) where {FT<:FTs}
     q = _q(qp, pol_type.n, FT); ρ, ρ̇ = _reflectance(s, q, m, size(a.r⁻⁺, 1), true)
-    _call(_fn("vsm_brdf_surface_lin", FT), (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
+    @vsm("vsm_brdf_surface_lin", FT, (Ref{VsmQuad{FT}}, Cint, Cint, PV, PV, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
           q, length(τ_sum), m, _p(ρ), _p(ρ̇), iparam - 1, _p(τ_sum), _p(τ̇_sum), size(τ̇_sum, 2), _p(F₀), _c(a), _c(ȧ), _stream())
 end
 
@@ -234,7 +271,7 @@ end
 _rrs(RS, fscatt) = VsmRRS(_p(RS.i_λ₁λ₀), _p(RS.ϖ_λ₁λ₀), _p(fscatt), _p(RS.Z⁺⁺_λ₁λ₀), _p(RS.Z⁻⁺_λ₁λ₀))   # i_λ₁λ₀ as ROCArray{Cint}
 function interaction!(RS::RRS{FT}, iface::ScatteringInterface_11, SFI, c, a, I_static; workspace=nothing) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺); K = size(c.ieR⁻⁺, 4)
-    _call(_fn("vsm_interaction_inelastic_rrs", FT), (Cint, Cint, Cint, PV, Ref{VsmComposite}, Ref{VsmCompositeRS}, Ref{VsmAdded}, Ref{VsmAddedRS}, PV, PV),
+    @vsm("vsm_interaction_inelastic_rrs", FT, (Cint, Cint, Cint, PV, Ref{VsmComposite}, Ref{VsmCompositeRS}, Ref{VsmAdded}, Ref{VsmAddedRS}, PV, PV),
           3, N, S, _p(RS.i_λ₁λ₀), _c(c), _Crs(c), _c(a), _crs(a), _p(_work(FT, :vsm_interaction_inelastic_work_elems, N, S, K)), _stream())
 end
 # elemental_inelastic! -> vsm_elemental_inelastic_rrs_*, doubling_inelastic! -> vsm_doubling_inelastic_rrs_*, copy_added_to_composite_ie!

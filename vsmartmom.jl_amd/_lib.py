@@ -108,6 +108,9 @@ _SIGS = {
     "vsm_compute_Z_moments_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_layer_optics_{T}": (_I, [_I, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_layer_dtau_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
+    "vsm_layer_optics_lin_{T}": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, _P, C.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                      _P, _P, _P]),
+    "vsm_layer_expk_{T}": (_I, [_I, _P, "{R}", _P, _P]),
     "vsm_coxmunk_reflectance_{T}": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "vsm_lambertian_surface_spectral_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
     "vsm_brdf_surface_{T}": (_I, [_P, _I, _I, _P, _P, _P, _P]),
@@ -118,6 +121,7 @@ _SIGS = {
     "vsm_doubling_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_interaction_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_elemental_lin_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _P]),
+    "vsm_elemental_lin_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_doubling_lin_{T}": (_I, [_I, _I, _I, _I, _P, _P, "{R}", _I, _P, _P, _P, _P]),
     "vsm_interaction_lin_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_copy_added_to_composite_lin_{T}": (_I, [_I, _I, _P, _P, _P]),

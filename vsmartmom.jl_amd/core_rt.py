@@ -521,7 +521,8 @@ class Scene:
     collective; only the shard's columns feed the layer kernels.  `host_optics=True` builds the same inputs with the
     host mirror (host_model.constructLayerOpticsComponents) instead -- kept as a cross-check."""
 
-    def __init__(self, model: H.RTModel, spec_slice: Optional[slice] = None, host_optics: bool = False):
+    def __init__(self, model: H.RTModel, spec_slice: Optional[slice] = None, host_optics: bool = False,
+                 full_added_layer: bool = False):
         arch, FT = model.architecture, model.float_type
         _require_gpu(arch)
         self.model, self.arch, self.FT = model, arch, FT
@@ -529,6 +530,7 @@ class Scene:
         self.pol, self.qp = pol, qp
         self.ss_correction = True   # Cox-Munk TMS term (tests switch it off to look at the Fourier-summed field)
         self.host_optics = bool(host_optics)
+        self.full_added_layer = bool(full_added_layer)   # the linearized run's kernels take the reference's full AddedLayer
         S_full, self.Nz = model.tau_rayl.shape
         self.S_full = S_full
         self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
@@ -669,7 +671,7 @@ class Scene:
             self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, tau_sum_surface=self.tau_sum[L, lo:hi]))
         all11 = all(t == "11" for t in tags)
         fused_ok = self.N <= _lib.lib().vsm_fused_max_n(8 if np.dtype(FT) == np.float64 else 4)
-        dsym = self.pol.n if (all11 and fused_ok) else 0
+        dsym = self.pol.n if (all11 and fused_ok and not self.full_added_layer) else 0
         if self.added is None or self.added.d_symmetric != dsym:
             self.added = make_added_layer(FT, self.arch, (self.N, self.N), self.S, d_symmetric=dsym)
 

@@ -133,18 +133,25 @@ def _pp_args(pol, qp, vza, vaz, m, weight, dtype):
 
 
 class SceneLin:
-    """Everything rt_run(model, lin_model, NAer, NGas, NSurf) needs, resident in HBM (the linearized twin of
-    CoreRT.Scene): per Fourier moment and layer tau, varpi, dtau, exp(-dtau/mu0), tau_sum and their parameter
-    derivatives, Z (shared) and Zdot, interface tags and ndoubl -- built once from host numpy, then `run()` only
-    launches kernels.  `spec_slice` selects this rank's spectral shard; ndoubl and the tags always come from the FULL
-    spectral axis (rt_kernel_lin.jl:87-95 uses batch-global maxima like the forward kernel).
+    """Everything rt_run(model, lin_model, NAer, NGas, NSurf) needs, resident in HBM (the linearized twin of CoreRT.Scene).
+    The raw inputs -- tau_rayl, tau_abs, lin_model.tau_abs_dot [nSpec, Nz] and the small aerosol tables (tau_aer,
+    tau_aer_dot, ssa / f_trunc and their Mie derivatives, Greek coefficients and their derivatives) -- are uploaded ONCE; the
+    forward layer optics come from CoreRT.Scene's device pass (vsm_layer_optics, vsm_compute_Z_moments, vsm_layer_dtau) and
+    their parameter derivatives from vsm_layer_optics_lin (tau_dot, varpi_dot, tau_sum_dot and the COEFFICIENTS of Z_dot over
+    the component phase matrices: constructCoreOpticalProperties with lin_model, compEffectiveLayerProperties_lin.jl:43-197,
+    types_lin.jl:196-380).  Z_dot[N, N, nSpec, P] is never materialised: elemental! (lin) forms it from the coefficients
+    (vsm_elemental_lin_mix).  `run()` only launches kernels; exp(-dtau / mu0) is refreshed on the device per layer.
+
+    `spec_slice` selects this rank's spectral shard; ndoubl and the tags always come from the FULL spectral axis
+    (rt_kernel_lin.jl:87-95 uses batch-global maxima like the forward kernel).  `host_optics=True` builds the same inputs with
+    the host mirror (host_model.constructCoreOpticalPropertiesLin, Z_dot materialised on the host) -- kept as a cross-check.
 
     Parameter slots (parameter_layout.jl:28-56): 7 per aerosol (tau_ref, n_r, n_i, r_m, sigma_r, p0, sigma_p; their optics
     derivatives are inputs: LinModel.tau_aer_dot / lin_aerosol_optics), the gases, then ONE surface slot -- the Lambertian albedo
     (lambertian_surface_lin.jl:48-162) or the Cox-Munk wind speed (coxmunk_surface_lin.jl:27-102)."""
 
     def __init__(self, model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int,
-                 spec_slice: Optional[slice] = None):
+                 spec_slice: Optional[slice] = None, host_optics: bool = False):
         if NAer != lin_model.n_aer or NAer != len(model.aerosol_optics) or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
             raise _lib.VSMError("rt_run (linearized): NAer must equal the aerosols of model and lin_model, NGas = "
                                 "len(lin_model.tau_abs_dot), NSurf = 1")
@@ -152,90 +159,142 @@ class SceneLin:
             raise _lib.VSMError("rt_run (linearized): surface %r has no linearized builder here" % (model.surface,))
         arch, FT = model.architecture, model.float_type
         CR._require_gpu(arch)
-        self.model, self.arch, self.FT = model, arch, FT
+        self.model, self.lin_model, self.arch, self.FT = model, lin_model, arch, FT
         pol, qp = model.polarization_type, model.quad_points
         self.pol, self.qp = pol, qp
         self.layout = H.ParameterLayout(n_aerosols=NAer, n_gases=NGas, n_surface=NSurf)
         P, pl = self.layout.n_total, self.layout.n_layer_params
-        self.P, self.pl = P, pl
-        S_full, Nz = model.tau_rayl.shape
-        self.sl = spec_slice if spec_slice is not None else slice(0, S_full)
-        sl = self.sl
-        S = self.S = len(range(*sl.indices(S_full)))
-        N = self.N = qp.Nquad * pol.n
-        nV = len(model.vza)
-        conv = array_type(arch)
+        self.P, self.pl, self.nAer, self.nGas = P, pl, NAer, NGas
+        if P > 64:
+            raise _lib.VSMError("rt_run (linearized): %d parameter slots (limit 64)" % P)
+        # forward optics, quadrature, F0, composite / added / surface layers and R, T: the forward scene's device state
+        # (rt_kernel_lin.jl:87 hard-codes scatter = true: a layer with tau*varpi <= 2 eps still goes through elemental! and
+        # doubling! with ndoubl = 0 -- Scene.prepare gives such a layer ndoubl = 0 as well -- and only its interaction
+        # follows the 00 / 01 / 10 tag of extractEffectiveProps)
+        self.fwd = CR.Scene(model, spec_slice, host_optics=host_optics, full_added_layer=True)
+        self.fwd.compute_hdrf = False
+        fwd = self.fwd
+        self.sl, self.S, self.N, self.dq, self.F0 = fwd.sl, fwd.S, fwd.N, fwd.dq, fwd.F0
+        S, N, L = self.S, self.N, fwd.Nz
         dt, dev = CR._torch_dtype(FT), devi(arch)
         self.dt = dt
-        self.dq = CR.device_quad(qp, pol, arch, FT)
-        F0 = model.F0
-        if F0 is None:
-            F0 = np.zeros((pol.n, S_full))
-            F0[0, :] = 1.0
-        self.F0 = conv(np.ascontiguousarray(np.asarray(F0, dtype=FT)[:, sl].T))
-        cut = lambda x: np.ascontiguousarray(np.asarray(x)[sl])
-        self.moments = []
-        shared = None     # tau/varpi/derivative tensors do not depend on m when no aerosol is mixed in: upload once
+        nV = len(model.vza)
+        self.C_, self.CT = 1 + NAer, 1 + NAer + 4 * NAer
+        z = lambda *sh: torch.empty(sh, dtype=dt, device=dev)
+        # layouts: the reference's column-major [nSpec, p] per layer -> tensors (L, p, S)
+        self.dtau_dot_all, self.varpi_dot, self.tau_sum_dot = z(L, P, S), z(L, max(pl, 1), S), z(L + 1, max(pl, 1), S)
+        self.fz = z(L, S, self.C_) if NAer else None
+        self.zdcoef = z(L, S, pl, self.CT) if NAer else None
+        self.Zall = None          # per moment ((CT, N, N), (CT, N, N)): component blocks of Z and of the Greek derivatives
+        self.host_zdot = None     # host_optics: per moment and layer the materialised Z_dot
+        self.upload()
+        if host_optics:
+            self._prepare_host()
+        else:
+            self.prepare()
+        self.surf = []
         for m in range(model.m_max + 1):
-            lods = H.constructCoreOpticalProperties(model, m)
-            lins = H.constructCoreOpticalPropertiesLin(model, lin_model, lods, m)
-            tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
-            # rt_kernel_lin.jl:87 hard-codes scatter = true: a layer with tau*varpi <= 2 eps still goes through elemental! and
-            # doubling! (ndoubl = 0), only its interaction follows the 00 / 01 / 10 tag of extractEffectiveProps
-            tsd = np.zeros((S_full, pl, Nz + 1))
-            for iz in range(Nz):
-                tsd[:, :, iz + 1] = tsd[:, :, iz] + lins[iz].tau_dot
-            reuse = shared is not None and not model.aerosol_optics
-            layers = []
-            for iz in range(Nz):
-                lo = lods[iz]
-                tau_full = np.atleast_1d(lo.tau).astype(FT)
-                varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
-                Zpp, Zmp = CR.to_device_matrix(lo.Zpp, arch, FT), CR.to_device_matrix(lo.Zmp, arch, FT)
-                if Zpp.shape[0] != 1:
-                    Zpp, Zmp = Zpp[sl].contiguous(), Zmp[sl].contiguous()
-                if reuse:
-                    ly = dict(shared[iz])
-                    ly["props"] = CR.DeviceLayerOptics(ly["props"].tau, ly["props"].varpi, Zpp, Zmp, ly["props"].max_tau_varpi,
-                                                       tau_full, np.asarray(varpi_full))
-                    layers.append(ly)
-                    continue
-                dtau_h, nd = H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics)
-                dtd = lins[iz].tau_dot / FT(2 ** nd)
-                dall = np.zeros((S_full, P))
-                dall[:, :pl] = dtd
-                zpd, zs_, zp_ = to_device_zdot(lins[iz].Zpp_dot, arch, FT)
-                zmd, _, _ = to_device_zdot(lins[iz].Zmp_dot, arch, FT)
-                props = CR.DeviceLayerOptics(conv(cut(tau_full)), conv(cut(varpi_full)), Zpp, Zmp,
-                                             float(np.max(tau_full * varpi_full)), tau_full, np.asarray(varpi_full))
-                layers.append(dict(props=props, nd=nd, iface=tags[iz], dtau=conv(cut(dtau_h)),
-                                   expk0=conv(cut(np.exp(-dtau_h / FT(qp.mu0)).astype(FT))),
-                                   dtau_dot=to_device_sp(cut(dtd), arch, FT), dall=to_device_sp(cut(dall), arch, FT),
-                                   varpi_dot=to_device_sp(cut(lins[iz].varpi_dot), arch, FT),
-                                   tau_sum=conv(cut(tau_sum_all[:, iz].astype(FT))),
-                                   tau_sum_dot=to_device_sp(cut(tsd[:, :, iz]), arch, FT), zpd=zpd, zmd=zmd, zds=(zs_, zp_)))
-            if shared is None:
-                shared = layers
             rho = drho = None
             if isinstance(model.surface, H.CoxMunkSurface):
                 rho, drho = CR.reflectance(model.surface, self.dq, m, arch, FT, deriv=True)
-            surf = (shared_surf if reuse else
-                    dict(tau_sum=conv(cut(tau_sum_all[:, -1].astype(FT))), tau_sum_dot=to_device_sp(cut(tsd[:, :, -1]), arch, FT)))
-            shared_surf = surf
-            self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, drho=drho, **surf))
-        self.added, self.added_s = CR.AddedLayer(FT, arch, N, S), CR.AddedLayer(FT, arch, N, S, shared=True)
-        self.comp = CR.CompositeLayer(FT, arch, N, S)
+            self.surf.append((rho, drho))
+        self.added, self.added_s, self.comp = fwd.added, fwd.added_surface, fwd.composite
         self.al, self.als = AddedLayerLin(FT, arch, P, N, S), AddedLayerLin(FT, arch, P, N, S, shared=True)
         self.cl = CompositeLayerLin(FT, arch, P, N, S)
         self.expk = torch.empty(max(S, 1), dtype=dt, device=dev)
-        self.R = torch.zeros((S, pol.n, nV), dtype=dt, device=dev)
-        self.T = torch.zeros_like(self.R)
+        self.R, self.T = fwd.R_SFI, fwd.T_SFI
         self.Rd = torch.zeros((P, S, pol.n, nV), dtype=dt, device=dev)
         self.Td = torch.zeros_like(self.Rd)
 
+    # -- inputs -----------------------------------------------------------------------------------------------------------
+    def upload(self):
+        """H2D of what the linearization adds to Scene.upload(): lin_model.tau_abs_dot [nSpec, Nz, nGas] (FP64) and the
+        aerosol derivative tables."""
+        model, lin = self.model, self.lin_model
+        conv = array_type(self.arch)
+        S_full, L = model.tau_rayl.shape
+        if self.nGas:
+            g = np.stack([np.asarray(t, dtype=np.float64) for t in lin.tau_abs_dot])            # (nGas, S, L)
+            if g.shape != (self.nGas, S_full, L):
+                raise _lib.VSMError("lin_model.tau_abs_dot: %d arrays of [nSpec, Nz] = [%d, %d] expected" % (self.nGas, S_full, L))
+            self.tau_abs_dot_d = conv(g).transpose(1, 2).contiguous()                           # (nGas, L, S)
+        else:
+            self.tau_abs_dot_d = None
+        if self.nAer:
+            tad = np.asarray(lin.tau_aer_dot, dtype=np.float64)                                 # [nAer, 7, L]
+            if tad.shape != (self.nAer, 7, L):
+                raise _lib.VSMError("lin_model.tau_aer_dot: [nAer, 7, Nz] expected")
+            self.tau_aer_dot_d = conv(np.ascontiguousarray(tad.transpose(2, 0, 1)))             # (L, nAer, 7)
+            self.ssa_dot_d = conv(np.ascontiguousarray(np.stack([np.asarray(l_.ssa_dot, dtype=np.float64)
+                                                                  for l_ in lin.lin_aerosol_optics])))     # (nAer, 4)
+            self.ftr_dot_d = conv(np.ascontiguousarray(np.stack([np.asarray(l_.f_trunc_dot, dtype=np.float64)
+                                                                  for l_ in lin.lin_aerosol_optics])))
+            self.greek_dot_dev = []
+            for l_ in lin.lin_aerosol_optics:
+                for g in l_.lin_greek_coefs:
+                    tab = np.stack([np.asarray(getattr(g, k), dtype=np.float64) for k in
+                                    ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")])
+                    self.greek_dot_dev.append((conv(np.ascontiguousarray(tab)), tab.shape[1]))
+        else:
+            self.tau_aer_dot_d = self.ssa_dot_d = self.ftr_dot_d = None
+            self.greek_dot_dev = []
+
+    # -- device optics ----------------------------------------------------------------------------------------------------
+    def prepare(self):
+        model, fwd, dt = self.model, self.fwd, self.dt
+        S_full, L = model.tau_rayl.shape
+        _lib.call("vsm_layer_optics_lin", dt, S_full, fwd.lo, self.S, L, self.nAer, self.nGas, self.P, CR._ptr(fwd.tau_rayl_d),
+                  CR._ptr(fwd.tau_abs_d), C.c_double(float(model.varpi_Cabannes)), CR._ptr(fwd.tau_aer_d), CR._ptr(fwd.ssa_d),
+                  CR._ptr(fwd.ftr_d), CR._ptr(self.tau_abs_dot_d), CR._ptr(self.tau_aer_dot_d), CR._ptr(self.ssa_dot_d),
+                  CR._ptr(self.ftr_dot_d), CR._ptr(fwd.nd_dev), CR._ptr(self.dtau_dot_all), CR._ptr(self.varpi_dot),
+                  CR._ptr(self.tau_sum_dot), CR._ptr(self.fz), CR._ptr(self.zdcoef), CR._stream_ptr())
+        if self.nAer:
+            q = self.dq.cstruct()
+            N = self.N
+            self.Zall = []
+            for m in range(model.m_max + 1):
+                Zp = torch.empty((self.CT, N, N), dtype=dt, device=devi(self.arch))
+                Zm = torch.empty_like(Zp)
+                for k, (gd, lmax) in enumerate(fwd.greek_dev + self.greek_dot_dev):
+                    _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, lmax, CR._ptr(gd), CR._ptr(Zp[k]), CR._ptr(Zm[k]),
+                              CR._stream_ptr())
+                self.Zall.append((Zp, Zm))
+
+    def _prepare_host(self):
+        """The same derivative inputs from the host mirror (numpy, Z_dot materialised per layer and moment)."""
+        model, lin, FT, fwd = self.model, self.lin_model, self.FT, self.fwd
+        S_full, L = model.tau_rayl.shape
+        sl, pl = self.sl, self.pl
+        conv = array_type(self.arch)
+        self.host_zdot = []
+        for m in range(model.m_max + 1):
+            lods = H.constructCoreOpticalProperties(model, m)
+            lins = H.constructCoreOpticalPropertiesLin(model, lin, lods, m)
+            zd = []
+            tsd = np.zeros((S_full, pl))
+            for iz in range(L):
+                if m == 0:
+                    nd = fwd.moments[0]["layers"][iz]["nd"]
+                    dall = np.zeros((S_full, self.P))
+                    dall[:, :pl] = lins[iz].tau_dot / FT(2 ** nd)
+                    self.dtau_dot_all[iz].copy_(to_device_sp(dall[sl], self.arch, FT))
+                    if pl:
+                        self.varpi_dot[iz].copy_(to_device_sp(lins[iz].varpi_dot[sl], self.arch, FT))
+                        self.tau_sum_dot[iz].copy_(to_device_sp(tsd[sl], self.arch, FT))
+                    tsd = tsd + lins[iz].tau_dot
+                Zpd, Zmd = lins[iz].Zpp_dot, lins[iz].Zmp_dot
+                if Zpd is not None and Zpd.ndim == 4:      # per-point Z_dot: this rank's spectral block
+                    Zpd, Zmd = Zpd[:, sl], Zmd[:, sl]
+                zpd, zs_, zp_ = to_device_zdot(Zpd, self.arch, FT)
+                zmd, _, _ = to_device_zdot(Zmd, self.arch, FT)
+                zd.append((zpd, zmd, (zs_, zp_)))
+            if m == 0 and pl:
+                self.tau_sum_dot[L].copy_(to_device_sp(tsd[sl], self.arch, FT))
+            self.host_zdot.append(zd)
+
     def run(self):
         """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing."""
-        model, pol, qp, FT, dt = self.model, self.pol, self.qp, self.FT, self.dt
+        model, pol, qp, FT, dt, fwd = self.model, self.pol, self.qp, self.FT, self.dt, self.fwd
         N, S, P, pl = self.N, self.S, self.P, self.pl
         for t in (self.R, self.T, self.Rd, self.Td):
             t.zero_()
@@ -243,29 +302,43 @@ class SceneLin:
             return self.R, self.T, self.Rd, self.Td
         added, al, comp, cl = self.added, self.al, self.comp, self.cl
         isurf = self.layout.surface_index(0)
-        for mom in self.moments:
+        mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
+        q_ = self.dq.cstruct()
+        for mom in fwd.moments:
             m = mom["m"]
             weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
             for iz, ly in enumerate(mom["layers"]):
-                elemental_lin_(pol, ly["tau_sum"], ly["tau_sum_dot"], ly["dtau"], ly["dtau_dot"], self.F0, ly["props"],
-                               ly["varpi_dot"], ly["zpd"], ly["zmd"], ly["zds"], pl, m, ly["nd"], self.dq, added, al)
-                self.expk[:S].copy_(ly["expk0"])      # doubling! squares exp(-dtau/mu0) in place
-                doubling_allparams_(pol, self.expk, ly["nd"], added, al, ly["dall"], qp.mu0, pl)
+                props = ly["props"]
+                dtd, vd, tsd = self.dtau_dot_all[iz], self.varpi_dot[iz], self.tau_sum_dot[iz]
+                if self.Zall is not None:
+                    mixed, k = fwd.zcomp[iz]
+                    a_, al_ = added.cstruct(), al.cstruct()
+                    _lib.call("vsm_elemental_lin_mix", dt, C.byref(q_), S, m, ly["nd"], CR._ptr(ly["dtau"]), CR._ptr(props.varpi),
+                              CR._ptr(ly["tau_sum"]), CR._ptr(self.F0), self.C_, self.CT, CR._ptr(self.Zall[m][0]),
+                              CR._ptr(self.Zall[m][1]), -1 if mixed else k, CR._ptr(self.fz[iz]), pl, CR._ptr(dtd), CR._ptr(vd),
+                              CR._ptr(tsd), CR._ptr(self.zdcoef[iz]), C.byref(a_), C.byref(al_), CR._stream_ptr())
+                else:
+                    zpd, zmd, zds = self.host_zdot[m][iz] if self.host_zdot is not None else (None, None, (0, 0))
+                    elemental_lin_(pol, ly["tau_sum"], tsd, ly["dtau"], dtd, self.F0, props.materialize(), vd, zpd, zmd, zds, pl,
+                                   m, ly["nd"], self.dq, added, al)
+                _lib.call("vsm_layer_expk", dt, S, CR._ptr(ly["dtau"]), mu0, CR._ptr(self.expk), CR._stream_ptr())
+                doubling_allparams_(pol, self.expk, ly["nd"], added, al, dtd, qp.mu0, pl)
                 if iz == 0:
                     CR.copy_added_to_composite_(comp, added)
                     a_, c_ = al.cstruct(), cl.cstruct()
                     _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
                 else:
                     interaction_lin_(ly["iface"], comp, cl, added, al)
-            q_, a_, al_ = self.dq.cstruct(), self.added_s.cstruct(), self.als.cstruct()
+            a_, al_ = self.added_s.cstruct(), self.als.cstruct()
+            tau_sum_s, tsd_s = mom["tau_sum_surface"], self.tau_sum_dot[fwd.Nz]
+            rho, drho = self.surf[m]
             if isinstance(model.surface, H.CoxMunkSurface):
-                _lib.call("vsm_brdf_surface_lin", dt, C.byref(q_), S, m, CR._ptr(mom["rho"]), CR._ptr(mom["drho"]), isurf,
-                          CR._ptr(mom["tau_sum"]), CR._ptr(mom["tau_sum_dot"]), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_),
-                          CR._stream_ptr())
+                _lib.call("vsm_brdf_surface_lin", dt, C.byref(q_), S, m, CR._ptr(rho), CR._ptr(drho), isurf, CR._ptr(tau_sum_s),
+                          CR._ptr(tsd_s), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
             else:
                 alb = C.c_double(model.surface.albedo) if dt == torch.float64 else C.c_float(model.surface.albedo)
-                _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(mom["tau_sum"]),
-                          CR._ptr(mom["tau_sum_dot"]), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
+                _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(tau_sum_s), CR._ptr(tsd_s), pl,
+                          CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
             interaction_lin_(mom["iface_surface"], comp, cl, self.added_s, self.als)
             CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), self.R, self.T)
             row0, w = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
@@ -284,7 +357,7 @@ class SceneLin:
         the layer parameters and (48N^3+16N^2) per interaction for every parameter."""
         N = float(self.N)
         tot = 0.0
-        for mom in self.moments:
+        for mom in self.fwd.moments:
             for iz, ly in enumerate(mom["layers"]):
                 tot += ly["nd"] * ((12 + 24 * self.pl) * N ** 3 + (8 + 16 * self.pl) * N ** 2)
                 if iz > 0:

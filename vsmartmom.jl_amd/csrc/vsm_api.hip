@@ -16,14 +16,20 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 int hip_fail(hipError_t e, const char* what) {
-  if (e == hipErrorInvalidConfiguration || e == hipErrorInvalidValue) {
-    // only the Raman kernels still index the spectral axis with gridDim.y (HIP limit 65535; they check it themselves)
-    set_error("HIP error %d (%s) in %s -- invalid launch configuration (Raman passes: nSpec and nRaman <= 65535)", (int)e,
-              hipGetErrorString(e), what);
-    return VSM_ERR_UNSUPPORTED;
-  }
+  // a failed HIP API call (hipMalloc, hipMemsetAsync, hipFuncSetAttribute, hipMemcpy ...) is always VSM_ERR_HIP: callers that
+  // fall through to another kernel family on VSM_ERR_UNSUPPORTED must never swallow it
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return VSM_ERR_HIP;
+}
+int hip_launch_fail(hipError_t e, const char* kernel) {
+  // only a launch that the hardware limits refuse (grid dimension y/z > 65535, block size, dynamic LDS) is "unsupported shape";
+  // the entry points whose kernels put the spectral axis or the Raman lines on gridDim.y/z check S, K <= 65535 themselves
+  if (e == hipErrorInvalidConfiguration) {
+    set_error("HIP error %d (%s) launching %s -- invalid launch configuration (a grid dimension y/z above 65535?)", (int)e,
+              hipGetErrorString(e), kernel);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  return hip_fail(e, kernel);
 }
 
 // grow-only scratch, one buffer per slot (single stream per device, like the reference's
@@ -111,8 +117,6 @@ static int check_comp(const C* c) {
   return VSM_OK;
 }
 
-int launch_expk_f(int S, const void* dtau, double mu0, void* expk, int esz, hipStream_t st);
-
 template <typename T, typename Q, typename A>
 static int elemental_doubling_impl(const Q* q, int S, int m, int ndoubl, const T* dtau, const T* varpi,
                                    const T* tau_sum, const T* F0, const T* Zpp, const T* Zmp, long long zs,
@@ -135,25 +139,8 @@ static int elemental_doubling_impl(const Q* q, int S, int m, int ndoubl, const T
   if (!work) return VSM_ERR_HIP;
   T* expk = work + we;
   // expk = exp(-dtau/mu0)  (rt_kernel.jl:339-349 init_layer)
-  if ((rc = launch_expk_f(S, dtau, (double)q->mu0, expk, (int)sizeof(T), st))) return rc;
+  if ((rc = layer_expk<T>(S, dtau, (T)q->mu0, expk, st))) return rc;
   return doubling<T>(q->N, q->n_stokes, S, ndoubl, expk, aa, work, st);
-}
-
-template <typename T>
-__global__ void k_expk(int S, const T* __restrict__ dtau, T mu0, T* expk) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < S) expk[e] = exp(-dtau[e] / mu0);
-}
-int launch_expk_f(int S, const void* dtau, double mu0, void* expk, int esz, hipStream_t st) {
-  if (S <= 0) return VSM_OK;
-  if (esz == 8)
-    hipLaunchKernelGGL(k_expk<double>, dim3((S + 255) / 256), dim3(256), 0, st, S, (const double*)dtau, mu0,
-                       (double*)expk);
-  else
-    hipLaunchKernelGGL(k_expk<float>, dim3((S + 255) / 256), dim3(256), 0, st, S, (const float*)dtau, (float)mu0,
-                       (float*)expk);
-  VSM_LAUNCH_CHECK("k_expk");
-  return VSM_OK;
 }
 
 template <typename T, typename C, typename A>
@@ -184,13 +171,13 @@ static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dta
   VSM_REQUIRE(ncomp >= 0 && (ncomp == 0 || fcomp), "layer_forward: bad component mix");
   hipStream_t st = as_stream(stream);
   if constexpr (sizeof(T) == 8) {
-    static const bool no_fuse = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_LAYER_FUSION") != nullptr;
+    static const bool no_fuse = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_LAYER_FUSION");
     if (!no_fuse && strip_supported(q->N) && ncomp <= 4)
       return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
                                  toa, cvt_comp<T>(c), st);
   }
   if constexpr (sizeof(T) == 4) {
-    static const bool no_fuse32 = getenv("VSM_NO_LAYER_FUSION") != nullptr;
+    static const bool no_fuse32 = ab_switch("VSM_NO_LAYER_FUSION");
     if (!no_fuse32 && strip32_supported(q->N) && ncomp <= 4)
       return strip32_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
                                    toa, cvt_comp<T>(c), st);
@@ -230,8 +217,8 @@ static int layer_forward_multi_impl(const Q* q, int S, int nm, const int* m, int
     VSM_REQUIRE(m[i] >= 0 && Zpp[i] && Zmp[i], "layer_forward_multi: bad moment %d", i);
   }
   if constexpr (sizeof(T) == 8) {
-    static const bool no_fuse = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_LAYER_FUSION") != nullptr ||
-                                getenv("VSM_NO_MOMENT_BATCH") != nullptr;
+    static const bool no_fuse = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_LAYER_FUSION") ||
+                                ab_switch("VSM_NO_MOMENT_BATCH");
     if (!no_fuse && strip_supported(q->N) && ncomp <= 4) {
       VSM_REQUIRE(dtau && varpi && tau_sum && F0, "layer_forward_multi: null input");
       for (int i0 = 0; i0 < nm; i0 += VSM_MM_MAX) {
@@ -250,8 +237,7 @@ static int layer_forward_multi_impl(const Q* q, int S, int nm, const int* m, int
     }
   }
   if constexpr (sizeof(T) == 4) {
-    static const bool no_fuse32 = getenv("VSM_NO_LAYER_FUSION") != nullptr || getenv("VSM_NO_MOMENT_BATCH") != nullptr ||
-                                  getenv("VSM_STRIP32_V1") != nullptr;
+    static const bool no_fuse32 = ab_switch("VSM_NO_LAYER_FUSION") || ab_switch("VSM_NO_MOMENT_BATCH");
     if (!no_fuse32 && strip32_supported(q->N) && ncomp <= 4) {
       VSM_REQUIRE(dtau && varpi && tau_sum && F0, "layer_forward_multi: null input");
       for (int i0 = 0; i0 < nm; i0 += VSM_MM_MAX) {
@@ -496,10 +482,9 @@ int vsm_layer_forward_multi_f32(const vsm_quad_f32* q, int S, int nm, const int*
 }
 // does vsm_layer_forward_thermal_* fuse this shape?  (FP64: the strip kernels, 32 < N <= 60; FP32: 64 < N <= 96)
 int vsm_layer_thermal_fused(int N, int is_f64) {
-  static const bool off = getenv("VSM_NO_LAYER_FUSION") != nullptr || getenv("VSM_NO_STRIP") != nullptr;
-  static const bool v1 = getenv("VSM_STRIP32_V1") != nullptr;
+  static const bool off = ab_switch("VSM_NO_LAYER_FUSION") || ab_switch("VSM_NO_STRIP");
   if (off) return 0;
-  return is_f64 ? (strip_supported(N) ? 1 : 0) : ((strip32_supported(N) && !v1) ? 1 : 0);
+  return is_f64 ? (strip_supported(N) ? 1 : 0) : (strip32_supported(N) ? 1 : 0);
 }
 // the `:thermal` per-source slot of a scattering layer through the fused layer kernel (m = 0; FP64, 32 < N <= 60, ncomp <= 4):
 // same launch as vsm_layer_forward(_mix) with the solar source replaced by the thermal one and expk = 1
@@ -659,6 +644,23 @@ static int check_cl(const C* c) {
                             dtau_dot, varpi_dot, tau_sum_dot, Zpp_dot, Zmp_dot, zds, zdp, cvt_added<T>(added),         \
                             cvt_al<T>(al), as_stream(stream));                                                         \
   }                                                                                                                    \
+  int vsm_elemental_lin_mix_##SFX(const vsm_quad_##SFX* q, int S, int m, int ndoubl, const T* dtau, const T* varpi,    \
+                                  const T* tau_sum, const T* F0, int ncomp, int ncomp_total, const T* Zc_pp,           \
+                                  const T* Zc_mp, int zsel, const T* fz, int p_layer, const T* dtau_dot,               \
+                                  const T* varpi_dot, const T* tau_sum_dot, const T* zdcoef,                           \
+                                  const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al, void* stream) {         \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q)) || (rc = check_added(added)) || (rc = check_al(al))) return rc;                           \
+    VSM_REQUIRE(added->d_symmetric == 0, "elemental_lin_mix: d_symmetric layers are not accepted here");               \
+    VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zc_pp && Zc_mp && dtau_dot && varpi_dot && tau_sum_dot && zdcoef,    \
+                "elemental_lin_mix: null input");                                                                      \
+    VSM_REQUIRE(ncomp >= 1 && ncomp_total >= ncomp && zsel < ncomp && (zsel >= 0 || fz),                               \
+                "elemental_lin_mix: bad component selection");                                                         \
+    VSM_REQUIRE(p_layer >= 0 && p_layer <= al->P, "elemental_lin_mix: bad p_layer");                                   \
+    return elemental_lin_mix<T>(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, ncomp, ncomp_total, Zc_pp,     \
+                                Zc_mp, zsel, fz, p_layer, dtau_dot, varpi_dot, tau_sum_dot, zdcoef,                    \
+                                cvt_added<T>(added), cvt_al<T>(al), as_stream(stream));                                \
+  }                                                                                                                    \
   int vsm_doubling_lin_##SFX(int N, int n_stokes, int S, int ndoubl, T* expk, const T* dtau_dot_all, T mu0,            \
                              int n_active, const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al, T* work,       \
                              void* stream) {                                                                           \
@@ -810,6 +812,30 @@ VSM_SURF_API(float, f32)
   extern "C" int vsm_layer_dtau_##SFX(int S, int L, const int* ndoubl, const T* tau, T* dtau, void* stream) {          \
     VSM_REQUIRE(S >= 0 && L >= 0 && (S == 0 || L == 0 || (ndoubl && tau && dtau)), "layer_dtau: bad argument");       \
     return layer_dtau<T>(S, L, ndoubl, tau, dtau, as_stream(stream));                                                  \
+  }                                                                                                                    \
+  extern "C" int vsm_layer_optics_lin_##SFX(int S_full, int lo, int S, int L, int nAer, int nGas, int P,               \
+                                            const double* tau_rayl, const double* tau_abs, double varpi_cabannes,      \
+                                            const double* tau_aer, const double* ssa, const double* ftrunc,            \
+                                            const double* tau_abs_dot, const double* tau_aer_dot,                      \
+                                            const double* ssa_dot, const double* ftrunc_dot, const int* ndoubl,        \
+                                            T* dtau_dot_all, T* varpi_dot, T* tau_sum_dot, T* fz, T* zdcoef,           \
+                                            void* stream) {                                                            \
+    VSM_REQUIRE(S_full >= 0 && lo >= 0 && S >= 0 && lo + S <= S_full && L >= 0 && nAer >= 0 && nGas >= 0 &&           \
+                    P >= 7 * nAer + nGas && P <= 64,                                                                   \
+                "layer_optics_lin: bad size (0 <= lo, lo + S <= S_full, 7 nAer + nGas <= P <= 64)");                   \
+    VSM_REQUIRE(S == 0 || L == 0 || (tau_rayl && tau_abs && ndoubl && dtau_dot_all && varpi_dot && tau_sum_dot),       \
+                "layer_optics_lin: null argument");                                                                    \
+    VSM_REQUIRE(nGas == 0 || S == 0 || L == 0 || tau_abs_dot, "layer_optics_lin: tau_abs_dot missing");                \
+    VSM_REQUIRE(nAer == 0 || S == 0 || L == 0 ||                                                                       \
+                    (tau_aer && ssa && ftrunc && tau_aer_dot && ssa_dot && ftrunc_dot && fz && zdcoef),                \
+                "layer_optics_lin: aerosol tables / coefficient outputs missing");                                     \
+    return layer_optics_lin<T>(S_full, lo, S, L, nAer, nGas, P, tau_rayl, tau_abs, varpi_cabannes, tau_aer, ssa,       \
+                               ftrunc, tau_abs_dot, tau_aer_dot, ssa_dot, ftrunc_dot, ndoubl, dtau_dot_all, varpi_dot, \
+                               tau_sum_dot, nAer ? fz : nullptr, nAer ? zdcoef : nullptr, as_stream(stream));          \
+  }                                                                                                                    \
+  extern "C" int vsm_layer_expk_##SFX(int S, const T* dtau, T mu0, T* expk, void* stream) {                            \
+    VSM_REQUIRE(S >= 0 && (S == 0 || (dtau && expk)) && mu0 > T(0), "layer_expk: bad argument");                       \
+    return layer_expk<T>(S, dtau, mu0, expk, as_stream(stream));                                                       \
   }
 VSM_OPT_API(double, f64)
 VSM_OPT_API(float, f32)

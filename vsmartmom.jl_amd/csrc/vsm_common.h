@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "vsmartmom_hip.h"
 
@@ -11,7 +12,8 @@ namespace vsm {
 
 // ---- error plumbing ---------------------------------------------------------
 void set_error(const char* fmt, ...);
-int hip_fail(hipError_t e, const char* what);  // records message, returns VSM_ERR_HIP
+int hip_fail(hipError_t e, const char* what);           // failed HIP API call: records the message, returns VSM_ERR_HIP
+int hip_launch_fail(hipError_t e, const char* kernel);  // failed launch: VSM_ERR_UNSUPPORTED for an invalid configuration only
 #define VSM_HIP(call)                                            \
   do {                                                           \
     hipError_t _e = (call);                                      \
@@ -20,7 +22,7 @@ int hip_fail(hipError_t e, const char* what);  // records message, returns VSM_E
 #define VSM_LAUNCH_CHECK(name)                                   \
   do {                                                           \
     hipError_t _e = hipGetLastError();                           \
-    if (_e != hipSuccess) return ::vsm::hip_fail(_e, name);      \
+    if (_e != hipSuccess) return ::vsm::hip_launch_fail(_e, name);      \
   } while (0)
 #define VSM_REQUIRE(cond, ...)                                   \
   do {                                                           \
@@ -29,6 +31,16 @@ int hip_fail(hipError_t e, const char* what);  // records message, returns VSM_E
       return VSM_ERR_INVALID_ARG;                                \
     }                                                            \
   } while (0)
+
+// ---- A/B switches ---------------------------------------------------------------
+// Environment switches that force a shape off its fused kernel family onto the next one (VSM_NO_STRIP, VSM_NO_RAMAN_WAVE, ...)
+// exist only in a diagnostic build (make EXTRA=-DVSM_AB_SWITCHES): the shipped library has ONE kernel per shape, the one the
+// parity tests exercise.  Every family is still covered by the tests through the shapes it owns.
+#ifdef VSM_AB_SWITCHES
+inline bool ab_switch(const char* name) { return getenv(name) != nullptr; }
+#else
+constexpr bool ab_switch(const char*) { return false; }
+#endif
 
 // ---- MFMA traits --------------------------------------------------------------
 // One MFMA = a 16x16 output tile, K = 4.  Operands: lane l holds A[i = l&15][k = l>>4]

@@ -1582,7 +1582,7 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
                              const added<T>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   if constexpr (sizeof(T) == 8) {
-    static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr;   // A/B switch for benchmarking
+    static const bool no_strip = ab_switch("VSM_NO_STRIP");   // A/B switch for benchmarking
     if (!no_strip && strip_supported(q.N))
       return strip_elemental_doubling(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<double>{Zpp, Zmp, zs, 0, nullptr}, a, st);
   }
@@ -1608,7 +1608,7 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     return VSM_ERR_UNSUPPORTED;
   }
   if constexpr (sizeof(T) == 8) {
-    static const bool no_strip = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_IA") != nullptr;
+    static const bool no_strip = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_STRIP_IA");
     if (!no_strip && strip_supported(N)) return strip_interaction11(N, S, c, a, st);
   }
   if constexpr (sizeof(T) == 4) {
@@ -1682,7 +1682,7 @@ template <typename T>
 int raman_elastic_pre(int N, int S, const T* r, const T* t, const T* j0p, const T* j0m, const T* expk, T* ttg, T* gt, T* gr,
                       T* grt, T* j1p, T* j1m, T* u, T* u2, T* tmp1, T* tmp2, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_FUSION") || ab_switch("VSM_NO_RAMAN_ELASTIC_FUSION");
   if (off || N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
@@ -1701,7 +1701,7 @@ template <typename T>
 int raman_elastic_post(int N, int S, T* r, T* t, const T* ttg, const T* u, const T* u2, const T* j1p, T* j0p, T* j0m,
                        T* expk, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_FUSION") || ab_switch("VSM_NO_RAMAN_ELASTIC_FUSION");
   if (off || N > fused_max_n<T>()) return VSM_ERR_UNSUPPORTED;
   return dispatch_np<T>(N, [&](auto tag) {
     constexpr int NP = decltype(tag)::value;
@@ -1721,7 +1721,7 @@ int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, cons
                          const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,
                          T* ieJp, T* ieJm, hipStream_t st) {
   if (S <= 0 || K <= 0) return VSM_OK;
-  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_FUSION");
   if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
   auto kern = k_raman_doubling_lines<T>;
   const size_t bytes = sizeof(rdsmem<T>);
@@ -1736,7 +1736,7 @@ int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, cons
 template <typename T>
 int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st) {
   if (S <= 0 || K <= 0) return VSM_OK;
-  static const bool off = getenv("VSM_NO_RAMAN_FUSION") != nullptr || getenv("VSM_NO_RAMAN_IA_FUSION") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_FUSION") || ab_switch("VSM_NO_RAMAN_IA_FUSION");
   if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
   auto kern = k_raman_interaction_lines<T>;
   const size_t bytes = sizeof(rdsmem<T>);

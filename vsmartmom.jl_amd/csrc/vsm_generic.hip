@@ -85,7 +85,7 @@ template <typename T>
 static bool gemm_lds(int M, int Nc, int K, int S, int P, const T* A, long long sa, long long pa, const T* B, long long sb,
                      long long pb, T* C, long long sc, long long pc, T alpha, const T* D, long long sd, long long pd, T beta,
                      T gamma, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_GEMM_LDS") != nullptr;
+  static const bool off = ab_switch("VSM_NO_GEMM_LDS");
   if (off || M <= 16 || M > 128 || Nc < 16 || Nc > 128 || K < 8 || P > 65535) return false;
   const dim3 grid(S, P);
   // chunks of 16 contraction indices: 32 measured 8..15 % slower in both precisions (fewer barriers, but half the chunks in flight)

@@ -74,6 +74,11 @@ int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, con
                   const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
                   long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st);
 template <typename T>
+int elemental_lin_mix(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                      const T* F0, int ncomp, int ncomp_total, const T* Zc_pp, const T* Zc_mp, int zsel, const T* fz,
+                      int p_layer, const T* dtau_dot, const T* varpi_dot, const T* tau_sum_dot, const T* zdcoef,
+                      const added<T>& a, const added_lin<T>& al, hipStream_t st);
+template <typename T>
 size_t doubling_lin_work_elems(int N, int S, int P);
 template <typename T>
 int doubling_lin(int N, int n_stokes, int S, int ndoubl, T* expk, const T* dtau_dot_all, T mu0, int n_active,
@@ -127,6 +132,13 @@ int layer_optics(int S, int L, int nAer, const double* tau_rayl, const double* t
                  hipStream_t st);
 template <typename T>
 int layer_dtau(int S, int L, const int* nd, const T* tau, T* dtau, hipStream_t st);
+template <typename T>
+int layer_optics_lin(int S_full, int lo, int S, int L, int nAer, int nGas, int P, const double* tau_rayl, const double* tau_abs,
+                     double varpi_cab, const double* tau_aer, const double* ssa, const double* ftrunc, const double* tau_abs_dot,
+                     const double* tau_aer_dot, const double* ssa_dot, const double* ftrunc_dot, const int* nd, T* dtau_dot_all,
+                     T* varpi_dot, T* tau_sum_dot, T* fz, T* zdcoef, hipStream_t st);
+template <typename T>
+int layer_expk(int S, const T* dtau, T mu0, T* expk, hipStream_t st);
 
 // ---- fused (LDS-resident) path: vsm_fused.hip ---------------------------------
 template <typename T>

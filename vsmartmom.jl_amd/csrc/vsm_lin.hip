@@ -17,20 +17,48 @@ namespace vsm {
 // ---------------------------------------------------------------------------
 // elemental + chain rule (get_elem_rt_fused!, elemental_lin.jl:456-591)
 // ---------------------------------------------------------------------------
+// Component-mixed phase matrices (aerosol Jacobians): Z = sum_c fz[c, s] Zc[c] (or Zc[zsel]) and
+// Z_dot[:, :, s, p] = sum_c zdcoef[c, p, s] Zc[c] over CT <= VSM_LIN_CT_MAX component blocks of one Fourier moment
+// (vsm_layer_optics_lin_* produces fz / zdcoef) -- the [N, N, S, P] array Z_dot of the reference never exists.
+#define VSM_LIN_CT_MAX 16
 template <typename T>
+struct zmix {
+  const T *Zc_pp, *Zc_mp;   // [N, N, CT]
+  const T* fz;              // [C, S] (zsel < 0)
+  const T* zdcoef;          // [CT, P, S]
+  int C, CT, zsel;
+};
+
+template <typename T, bool MIX>
 __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int m, int ndoubl, int P,
                                                        const T* __restrict__ dtau, const T* __restrict__ varpi,
                                                        const T* __restrict__ Zpp, const T* __restrict__ Zmp,
                                                        long long zs, const T* __restrict__ dtau_dot,
                                                        const T* __restrict__ varpi_dot, const T* __restrict__ Zpp_dot,
                                                        const T* __restrict__ Zmp_dot, long long zds, long long zdp,
-                                                       const T* __restrict__ mu, const T* __restrict__ wt, T* r_mp,
-                                                       T* t_pp, T* r_pm, T* t_mm, T* ap_r_mp, T* ap_t_pp, T* ap_r_pm,
-                                                       T* ap_t_mm) {
+                                                       const zmix<T> zx, const T* __restrict__ mu,
+                                                       const T* __restrict__ wt, T* r_mp, T* t_pp, T* r_pm, T* t_mm,
+                                                       T* ap_r_mp, T* ap_t_pp, T* ap_r_pm, T* ap_t_mm) {
   const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
   const int s = blockIdx.x;
   const int i = e % N, j = e / N;
+  T zcp[MIX ? VSM_LIN_CT_MAX : 1], zcm[MIX ? VSM_LIN_CT_MAX : 1];
+  T zmix_p = 0, zmix_m = 0;
+  if constexpr (MIX) {
+#pragma unroll
+    for (int c = 0; c < VSM_LIN_CT_MAX; ++c) {
+      zcp[c] = (c < zx.CT) ? zx.Zc_pp[(long long)c * N * N + e] : T(0);
+      zcm[c] = (c < zx.CT) ? zx.Zc_mp[(long long)c * N * N + e] : T(0);
+    }
+#pragma unroll
+    for (int c = 0; c < VSM_LIN_CT_MAX; ++c) {
+      T f = T(0);
+      if (c < zx.C) f = (zx.zsel < 0) ? zx.fz[c + (long long)zx.C * s] : (c == zx.zsel ? T(1) : T(0));
+      zmix_p += f * zcp[c];
+      zmix_m += f * zcm[c];
+    }
+  }
   const T wct = (m == 0) ? wt[j] / T(2) : wt[j] / T(4);
   const T mi = mu[i], mj = mu[j];
   const T d = dtau[s], w = varpi[s];
@@ -40,7 +68,7 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
   const T sign_r = (ndoubl >= 1 && ui) ? T(-1) : T(1);
   T r = 0, t = 0, r_tau = 0, r_w = 0, r_Z = 0, t_tau = 0, t_w = 0, t_Z = 0;
   if (wct > num<T>::eps()) {
-    const T zm = Zmp[zo], zp = Zpp[zo];
+    const T zm = MIX ? zmix_m : Zmp[zo], zp = MIX ? zmix_p : Zpp[zo];
     const T arg = d * ((T(1) / mi) + (T(1) / mj));
     const T geo = (mj / (mi + mj)) * wct * (-expm1(-arg));
     r = w * zm * geo;
@@ -86,8 +114,20 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
   const long long pstride = (long long)N * N * S;
   for (int p = 0; p < P; ++p) {
     const T td = dtau_dot[s + (long long)S * p], wd = varpi_dot[s + (long long)S * p];
-    const T zmd = Zmp_dot ? Zmp_dot[(long long)s * zds + (long long)p * zdp + e] : T(0);
-    const T zpd = Zpp_dot ? Zpp_dot[(long long)s * zds + (long long)p * zdp + e] : T(0);
+    T zmd, zpd;
+    if constexpr (MIX) {
+      const T* cf = zx.zdcoef + (long long)zx.CT * (p + (long long)P * s);
+      zmd = zpd = T(0);
+#pragma unroll
+      for (int c = 0; c < VSM_LIN_CT_MAX; ++c)
+        if (c < zx.CT) {
+          zpd += cf[c] * zcp[c];
+          zmd += cf[c] * zcm[c];
+        }
+    } else {
+      zmd = Zmp_dot ? Zmp_dot[(long long)s * zds + (long long)p * zdp + e] : T(0);
+      zpd = Zpp_dot ? Zpp_dot[(long long)s * zds + (long long)p * zdp + e] : T(0);
+    }
     const T vr = r_tau * td + r_w * wd + r_Z * zmd;
     const T vt = t_tau * td + t_w * wd + t_Z * zpd;
     ap_r_mp[o + p * pstride] = sign_r * vr;
@@ -100,7 +140,7 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
 }
 
 // get_elem_rt_SFI_fused! (elemental_lin.jl:602-712)
-template <typename T>
+template <typename T, bool MIX>
 __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S, int m, int ndoubl, int i_mu0, int P,
                                                            const T* __restrict__ dtau, const T* __restrict__ varpi,
                                                            const T* __restrict__ tau_sum, const T* __restrict__ F0,
@@ -109,19 +149,42 @@ __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S,
                                                            const T* __restrict__ varpi_dot,
                                                            const T* __restrict__ tau_sum_dot,
                                                            const T* __restrict__ Zpp_dot, const T* __restrict__ Zmp_dot,
-                                                           long long zds, long long zdp, const T* __restrict__ mu,
-                                                           T* j0_p, T* j0_m, T* ap_J0_p, T* ap_J0_m) {
+                                                           long long zds, long long zdp, const zmix<T> zx,
+                                                           const T* __restrict__ mu, T* j0_p, T* j0_m, T* ap_J0_p,
+                                                           T* ap_J0_m) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= N * S) return;
   const int i = e % N, s = e / N;
   const int i_start = ns * i_mu0;
   const T wct02 = (m == 0) ? T(0.5) : T(0.25);
   T zp = 0, zm = 0;
-  for (int q = 0; q < ns; ++q) {
-    const long long zo = (long long)s * zs + i + (long long)N * (i_start + q);
-    const T f = F0[q + (long long)ns * s];
-    zp += Zpp[zo] * f;
-    zm += Zmp[zo] * f;
+  T zcp[MIX ? VSM_LIN_CT_MAX : 1], zcm[MIX ? VSM_LIN_CT_MAX : 1];   // (Zc[c] F0)_i per component
+  if constexpr (MIX) {
+#pragma unroll
+    for (int c = 0; c < VSM_LIN_CT_MAX; ++c) {
+      zcp[c] = zcm[c] = T(0);
+      if (c < zx.CT)
+        for (int q = 0; q < ns; ++q) {
+          const long long zo = (long long)c * N * N + i + (long long)N * (i_start + q);
+          const T f = F0[q + (long long)ns * s];
+          zcp[c] += zx.Zc_pp[zo] * f;
+          zcm[c] += zx.Zc_mp[zo] * f;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < VSM_LIN_CT_MAX; ++c) {
+      T f = T(0);
+      if (c < zx.C) f = (zx.zsel < 0) ? zx.fz[c + (long long)zx.C * s] : (c == zx.zsel ? T(1) : T(0));
+      zp += f * zcp[c];
+      zm += f * zcm[c];
+    }
+  } else {
+    for (int q = 0; q < ns; ++q) {
+      const long long zo = (long long)s * zs + i + (long long)N * (i_start + q);
+      const T f = F0[q + (long long)ns * s];
+      zp += Zpp[zo] * f;
+      zm += Zmp[zo] * f;
+    }
   }
   const T d = dtau[s], w = varpi[s];
   const T mi = mu[i], ms = mu[i_start];
@@ -151,7 +214,15 @@ __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S,
   j0_m[e] = jm;
   for (int p = 0; p < P; ++p) {
     T zpd = 0, zmd = 0;
-    if (Zpp_dot) {
+    if constexpr (MIX) {
+      const T* cf = zx.zdcoef + (long long)zx.CT * (p + (long long)P * s);
+#pragma unroll
+      for (int c = 0; c < VSM_LIN_CT_MAX; ++c)
+        if (c < zx.CT) {
+          zpd += cf[c] * zcp[c];
+          zmd += cf[c] * zcm[c];
+        }
+    } else if (Zpp_dot) {
       for (int q = 0; q < ns; ++q) {
         const long long zo = (long long)s * zds + (long long)p * zdp + i + (long long)N * (i_start + q);
         const T f = F0[q + (long long)ns * s];
@@ -166,11 +237,11 @@ __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S,
   }
 }
 
-template <typename T>
-int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
-                  const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
-                  const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
-                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st) {
+template <typename T, bool MIX>
+static int elemental_lin_impl(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                              const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
+                              const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
+                              long long zdp, const zmix<T>& zx, const added<T>& a, const added_lin<T>& al, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   const int N = q.N;
   // zero every derivative slot first (elemental_lin.jl:128-141); slots >= p_layer stay zero
@@ -181,15 +252,40 @@ int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, con
   VSM_HIP(hipMemsetAsync(al.ap_t_mm, 0, mb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_p, 0, vb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_m, 0, vb, st));
-  hipLaunchKernelGGL(k_elemental_lin<T>, dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
-                     p_layer, dtau, varpi, Zpp, Zmp, zs, dtau_dot, varpi_dot, Zpp_dot, Zmp_dot, zds, zdp, q.mu, q.wt,
+  hipLaunchKernelGGL((k_elemental_lin<T, MIX>), dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+                     p_layer, dtau, varpi, Zpp, Zmp, zs, dtau_dot, varpi_dot, Zpp_dot, Zmp_dot, zds, zdp, zx, q.mu, q.wt,
                      a.r_mp, a.t_pp, a.r_pm, a.t_mm, al.ap_r_mp, al.ap_t_pp, al.ap_r_pm, al.ap_t_mm);
   VSM_LAUNCH_CHECK("k_elemental_lin");
-  hipLaunchKernelGGL(k_elemental_sfi_lin<T>, dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+  hipLaunchKernelGGL((k_elemental_sfi_lin<T, MIX>), dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
                      q.i_mu0, p_layer, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, dtau_dot, varpi_dot, tau_sum_dot,
-                     Zpp_dot, Zmp_dot, zds, zdp, q.mu, a.j0_p, a.j0_m, al.ap_J0_p, al.ap_J0_m);
+                     Zpp_dot, Zmp_dot, zds, zdp, zx, q.mu, a.j0_p, a.j0_m, al.ap_J0_p, al.ap_J0_m);
   VSM_LAUNCH_CHECK("k_elemental_sfi_lin");
   return VSM_OK;
+}
+
+template <typename T>
+int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                  const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
+                  const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
+                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st) {
+  const zmix<T> none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
+  return elemental_lin_impl<T, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, p_layer, dtau_dot, varpi_dot,
+                                      tau_sum_dot, Zpp_dot, Zmp_dot, zds, zdp, none, a, al, st);
+}
+
+template <typename T>
+int elemental_lin_mix(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+                      const T* F0, int ncomp, int ncomp_total, const T* Zc_pp, const T* Zc_mp, int zsel, const T* fz,
+                      int p_layer, const T* dtau_dot, const T* varpi_dot, const T* tau_sum_dot, const T* zdcoef,
+                      const added<T>& a, const added_lin<T>& al, hipStream_t st) {
+  if (ncomp_total > VSM_LIN_CT_MAX) {
+    set_error("elemental_lin_mix: %d component blocks (limit %d: three aerosols with derivatives)", ncomp_total,
+              VSM_LIN_CT_MAX);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  const zmix<T> zx = {Zc_pp, Zc_mp, fz, zdcoef, ncomp, ncomp_total, zsel};
+  return elemental_lin_impl<T, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, nullptr, nullptr, 0, p_layer, dtau_dot,
+                                     varpi_dot, tau_sum_dot, nullptr, nullptr, 0, 0, zx, a, al, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -309,7 +405,7 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
     // one active parameter: all steps in one launch (state stays on the chip between the steps)
     // (apply_D! rides in its epilogue when every parameter slot is either active there or zero: P == n_active or the
     //  remaining slots' derivatives of r, t vanish in this layer, which the caller states with n_active > 0)
-    static const bool sepD = getenv("VSM_LIN_SEPARATE_APPLY_D") != nullptr;
+    static const bool sepD = ab_switch("VSM_LIN_SEPARATE_APPLY_D");
     rc = strip_doubling_lin_multi(N, S, P, ndoubl, sepD ? 0 : ns, expk, ekl, a, al, st);
     if (rc == VSM_OK && !sepD) return VSM_OK;
     if (rc == VSM_OK) n0 = ndoubl;
@@ -740,6 +836,9 @@ int postprocess_vza_lin(int N, int ns, int S, int nV, int P, const int* row0_h, 
   template int elemental_lin<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*, const T*,     \
                                 const T*, long long, int, const T*, const T*, const T*, const T*, const T*,          \
                                 long long, long long, const added<T>&, const added_lin<T>&, hipStream_t);            \
+  template int elemental_lin_mix<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*, int, int,   \
+                                    const T*, const T*, int, const T*, int, const T*, const T*, const T*, const T*,     \
+                                    const added<T>&, const added_lin<T>&, hipStream_t);                                 \
   template int doubling_lin<T>(int, int, int, int, T*, const T*, T, int, const added<T>&, const added_lin<T>&, T*,   \
                                hipStream_t);                                                                          \
   template int interaction_lin<T>(int, int, int, const composite<T>&, const composite_lin<T>&, const added<T>&,      \

@@ -275,11 +275,148 @@ int layer_dtau(int S, int L, const int* nd, const T* tau, T* dtau, hipStream_t s
   return VSM_OK;
 }
 
+
+// ---- linearized layer optics ---------------------------------------------------------------------------------------------
+// constructCoreOpticalProperties with lin_model (compEffectiveLayerProperties_lin.jl:43-197; createAero with derivatives
+// :330-395; the quotient rule of the pairwise `+`, types_lin.jl:196-380) in closed form.  A layer's optics are
+//   tau = sum_c tau_c + tau_abs,  W = sum_c w_c  (w_c = tau_c varpi_c),  varpi = W / tau,  Z = sum_c (w_c / W) Z_c
+// over the scatterers c = Rayleigh, aerosol 1, ...  For slot k of aerosol a (w_dot = tau_dot_a varpi_a + tau_a varpi_dot_a):
+//   tau_dot = tau_dot_a,  varpi_dot = (w_dot - varpi tau_dot) / tau,  Z_dot = (w_dot / W) (Z_a - Z) + (w_a / W) Zdot_{a,k}
+// and for a gas: tau_dot = tau_abs_dot, varpi_dot = -varpi tau_dot / tau, Z_dot = 0.  Z_dot is NOT materialised: the kernel
+// writes its coefficients over the component matrices [Z_0 .. Z_{C-1}, Zdot_{0,0..3}, Zdot_{1,0..3}, ...] (CT = C + 4 nAer
+// blocks of N x N per Fourier moment) and elemental! (lin) forms Z_dot where it consumes it (vsm_elemental_lin_mix).
+// One thread per spectral point of the rank's block [lo, lo + S) of the full axis (inputs are indexed on the full axis,
+// outputs are block-local); the tau_sum_dot prefix walks the layers.  Slot order: 7 per aerosol, then the gases
+// (parameter_layout.jl:28-56); dtau_dot_all has P >= pl columns (surface slots stay zero).
+template <typename T>
+__global__ void k_layer_optics_lin(int S_full, int lo, int S, int L, int nAer, int nGas, int P,
+                                   const double* __restrict__ tau_rayl, const double* __restrict__ tau_abs, double varpi_cab,
+                                   const double* __restrict__ tau_aer, const double* __restrict__ ssa,
+                                   const double* __restrict__ ftrunc, const double* __restrict__ tau_abs_dot,
+                                   const double* __restrict__ tau_aer_dot, const double* __restrict__ ssa_dot,
+                                   const double* __restrict__ ftrunc_dot, const int* __restrict__ nd, T* dtau_dot_all,
+                                   T* varpi_dot, T* tau_sum_dot, T* fz, T* zdcoef) {
+  const int sl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sl >= S) return;
+  const int s = lo + sl;
+  const int C = nAer + 1, CT = C + 4 * nAer, pl = 7 * nAer + nGas;
+  const long long SP = (long long)S * pl;
+  // tau_sum_dot[:, :, l] = sum of tau_dot over the layers above l (rt_run_lin.jl:214-222), accumulated in FP64 per slot
+  for (int p = 0; p < pl; ++p) {
+    double acc = 0.0;
+    tau_sum_dot[sl + (long long)S * p] = T(0);
+    for (int l = 0; l < L; ++l) {
+      double td;
+      if (p < 7 * nAer) {
+        const int ia = p / 7, k = p % 7;
+        const bool mie = k >= 1 && k <= 4;
+        const double f = ftrunc[ia], om = ssa[ia], ta = tau_aer[ia + nAer * l];
+        const double wd = mie ? ssa_dot[(k - 1) + 4 * ia] : 0.0, fd = mie ? ftrunc_dot[(k - 1) + 4 * ia] : 0.0;
+        td = (1.0 - f * om) * tau_aer_dot[k + 7 * (ia + nAer * l)] - (f * wd + om * fd) * ta;
+      } else {
+        td = tau_abs_dot[(long long)s + (long long)S_full * l + (long long)S_full * L * (p - 7 * nAer)];
+      }
+      acc += td;
+      tau_sum_dot[SP * (l + 1) + sl + (long long)S * p] = (T)acc;
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    const long long o = (long long)s + (long long)S_full * l;
+    const double scale = ldexp(1.0, -nd[l]);
+    T* dd = dtau_dot_all + (long long)S * P * l;
+    T* vd = varpi_dot + SP * l;
+    for (int p = pl; p < P; ++p) dd[sl + (long long)S * p] = T(0);
+    // scatterers: tau_c, varpi_c (createAero: delta-M), their sums
+    double tc[8], vc[8];
+    tc[0] = tau_rayl[o];
+    vc[0] = varpi_cab;
+    double tsum = tc[0], W = tc[0] * vc[0];
+    for (int ia = 0; ia < nAer; ++ia) {
+      const double f = ftrunc[ia], om = ssa[ia], ta = tau_aer[ia + nAer * l];
+      const double g = 1.0 - f * om;
+      tc[ia + 1] = g * ta;
+      vc[ia + 1] = (1.0 - f) * om / g;
+      tsum += tc[ia + 1];
+      W += tc[ia + 1] * vc[ia + 1];
+    }
+    const double tau = tsum + tau_abs[o];
+    const double tsafe = tau > 0 ? tau : 1.0;
+    const double varpi = W / tsafe;
+    const double Winv = W > 0 ? 1.0 / W : 0.0;
+    if (fz)
+      for (int c = 0; c < C; ++c) fz[c + (long long)C * (sl + (long long)S * l)] = (T)(tc[c] * vc[c] * Winv);
+    T* zc = zdcoef ? zdcoef + (long long)CT * pl * (sl + (long long)S * l) : nullptr;
+    for (int ia = 0; ia < nAer; ++ia) {
+      const double f = ftrunc[ia], om = ssa[ia], ta = tau_aer[ia + nAer * l];
+      const double g = 1.0 - f * om;
+      const double fa = tc[ia + 1] * vc[ia + 1] * Winv;
+      for (int k = 0; k < 7; ++k) {
+        const int p = 7 * ia + k;
+        const bool mie = k >= 1 && k <= 4;   // n_r, n_i, r_m, sigma_r move ssa and f_trunc (and the Greek coefficients)
+        const double wd = mie ? ssa_dot[(k - 1) + 4 * ia] : 0.0, fd = mie ? ftrunc_dot[(k - 1) + 4 * ia] : 0.0;
+        const double td = g * tau_aer_dot[k + 7 * (ia + nAer * l)] - (f * wd + om * fd) * ta;
+        const double vdk = (wd * (1.0 - f) - fd * (om * (1.0 - om))) / (g * g);
+        const double wdot = td * vc[ia + 1] + tc[ia + 1] * vdk;
+        dd[sl + (long long)S * p] = (T)(td * scale);
+        vd[sl + (long long)S * p] = (T)((wdot - varpi * td) / tsafe);
+        if (zc) {
+          const double r = wdot * Winv;
+          for (int c = 0; c < C; ++c) zc[c + CT * p] = (T)(r * ((c == ia + 1 ? 1.0 : 0.0) - tc[c] * vc[c] * Winv));
+          for (int c = C; c < CT; ++c) zc[c + CT * p] = (T)((mie && c == C + 4 * ia + (k - 1)) ? fa : 0.0);
+        }
+      }
+    }
+    for (int gi = 0; gi < nGas; ++gi) {
+      const int p = 7 * nAer + gi;
+      const double td = tau_abs_dot[o + (long long)S_full * L * gi];
+      dd[sl + (long long)S * p] = (T)(td * scale);
+      vd[sl + (long long)S * p] = (T)(-(varpi / tsafe) * td);
+      if (zc)
+        for (int c = 0; c < CT; ++c) zc[c + CT * p] = T(0);
+    }
+  }
+}
+
+template <typename T>
+int layer_optics_lin(int S_full, int lo, int S, int L, int nAer, int nGas, int P, const double* tau_rayl, const double* tau_abs,
+                     double varpi_cab, const double* tau_aer, const double* ssa, const double* ftrunc, const double* tau_abs_dot,
+                     const double* tau_aer_dot, const double* ssa_dot, const double* ftrunc_dot, const int* nd, T* dtau_dot_all,
+                     T* varpi_dot, T* tau_sum_dot, T* fz, T* zdcoef, hipStream_t st) {
+  if (nAer > 7) {
+    set_error("layer_optics_lin: at most 7 aerosol components (got %d)", nAer);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  if (S <= 0 || L <= 0) return VSM_OK;
+  hipLaunchKernelGGL(k_layer_optics_lin<T>, dim3((S + 127) / 128), dim3(128), 0, st, S_full, lo, S, L, nAer, nGas, P, tau_rayl,
+                     tau_abs, varpi_cab, tau_aer, ssa, ftrunc, tau_abs_dot, tau_aer_dot, ssa_dot, ftrunc_dot, nd, dtau_dot_all,
+                     varpi_dot, tau_sum_dot, fz, zdcoef);
+  VSM_LAUNCH_CHECK("k_layer_optics_lin");
+  return VSM_OK;
+}
+
+// expk = exp(-dtau / mu0) (rt_kernel.jl:339-349 init_layer): doubling! squares it in place, so a run refreshes it per layer
+template <typename T>
+__global__ void k_layer_expk(int S, const T* __restrict__ dtau, T mu0, T* expk) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < S) expk[s] = exp(-dtau[s] / mu0);
+}
+template <typename T>
+int layer_expk(int S, const T* dtau, T mu0, T* expk, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  hipLaunchKernelGGL(k_layer_expk<T>, dim3((S + 255) / 256), dim3(256), 0, st, S, dtau, mu0, expk);
+  VSM_LAUNCH_CHECK("k_layer_expk");
+  return VSM_OK;
+}
+
 #define VSM_INST_OPT(T)                                                                                                      \
   template int compute_Z_moments<T>(int, int, const T*, int, int, const double*, T*, T*, hipStream_t);                        \
   template int layer_optics<T>(int, int, int, const double*, const double*, double, const double*, const double*,             \
                                const double*, const int*, T*, T*, T*, T*, T*, hipStream_t);                                   \
-  template int layer_dtau<T>(int, int, const int*, const T*, T*, hipStream_t);
+  template int layer_dtau<T>(int, int, const int*, const T*, T*, hipStream_t);                                                \
+  template int layer_optics_lin<T>(int, int, int, int, int, int, int, const double*, const double*, double, const double*,    \
+                                   const double*, const double*, const double*, const double*, const double*, const double*, \
+                                   const int*, T*, T*, T*, T*, T*, hipStream_t);                                              \
+  template int layer_expk<T>(int, const T*, T, T*, hipStream_t);
 VSM_INST_OPT(double)
 VSM_INST_OPT(float)
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * NW) void k_gemm_rs_lds(int M, int Nc, int K, i
 template <typename T>
 static bool gemm_rs_lds(int M, int Nc, int K, int S, int Kr, const int* shift, rs_op<T> A, rs_op<T> B, T* C, rs_op<T> D,
                         hipStream_t st, int zero_oob) {
-  static const bool off = getenv("VSM_NO_GEMM_LDS") != nullptr;
+  static const bool off = ab_switch("VSM_NO_GEMM_LDS");
   if (off || M <= 16 || M > 128 || Nc < 16 || Nc > 128 || K < 8 || Kr > 65535) return false;
   const dim3 grid(S, Kr);
 #define VSM_GL(MT_, NW_) \
@@ -407,7 +407,7 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
 #define G3(...) if ((rc = gemm<T>(__VA_ARGS__, st))) return rc
 #define G4(M_, Nc_, A_, B_, C_, D_) if ((rc = gemm_rs<T>(M_, Nc_, N, S, K, shift, A_, B_, C_, D_, st))) return rc
   const dim3 gv((unsigned)((pv + 255) / 256));
-  static const bool sepD = getenv("VSM_RAMAN_SEPARATE_APPLY_D") != nullptr;
+  static const bool sepD = ab_switch("VSM_RAMAN_SEPARATE_APPLY_D");
   bool ie_D_done = false;   // apply_D! of the inelastic operators done by the last step's line kernel
   for (int n = 0; n < ndoubl; ++n) {
     // elastic operands of the step: one LDS-resident launch per point, else the operator chain
@@ -618,7 +618,7 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
   // ---- elastic part last (every inelastic right-hand side above used the pre-update composite) -----
   (void)elastic_work_elems;
   if (N <= fused_max_n<T>()) {   // LDS-resident k_interaction11 (one launch), else the operator chain
-    static const bool off = getenv("VSM_NO_RAMAN_ELASTIC_FUSION") != nullptr;
+    static const bool off = ab_switch("VSM_NO_RAMAN_ELASTIC_FUSION");
     rc = off ? VSM_ERR_UNSUPPORTED : fused_interaction<T>(VSM_IFACE_11, N, S, c, a, st);
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }

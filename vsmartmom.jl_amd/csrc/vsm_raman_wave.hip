@@ -1060,7 +1060,7 @@ int launch_rw(int S, int K, const int* shift, const double* r, const double* t, 
               const double* gr, const double* grt, const double* jp, const double* j1m, const double* tmp1,
               const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp, double* ieJm, int ns,
               double* ier_pm, double* iet_mm, hipStream_t st) {
-  static const bool plain = getenv("VSM_RAMAN_WAVE_PLAIN") != nullptr;   // the unpipelined body (A/B)
+  static const bool plain = ab_switch("VSM_RAMAN_WAVE_PLAIN");   // the unpipelined body (A/B)
   using kern_t = void (*)(int, int, const int*, const double*, const double*, const double*, const double*, const double*,
                           const double*, const double*, const double*, const double*, const double*, const double*, double*,
                           double*, double*, double*, int, double*, double*);
@@ -1170,7 +1170,7 @@ int RW_PART_FN(raman_interaction_wave_part_)(int N, int S, int K, const int* shi
 // chain).  K > 128: the line list is a 128-bit mask.  N 25..30 run the unpipelined body.  ns > 0 (n_stokes) marks the
 // LAST doubling step of a layer: apply_D! of the inelastic operators happens on the way out (ier_pm, iet_mm are written).
 int raman_doubling_wave(RW_DBL_ARGS) {
-  static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_WAVE");
   if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0 || K <= 0) return VSM_OK;
 #ifdef RW_PART
@@ -1184,7 +1184,7 @@ int raman_doubling_wave(RW_DBL_ARGS) {
 }
 
 int raman_interaction_wave(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_RAMAN_WAVE") != nullptr || getenv("VSM_NO_RAMAN_IA_WAVE") != nullptr;
+  static const bool off = ab_switch("VSM_NO_RAMAN_WAVE") || ab_switch("VSM_NO_RAMAN_IA_WAVE");
   if (off || N > RW_MAXN || N < 1 || K > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0 || K <= 0) return VSM_OK;
 #ifdef RW_PART

@@ -814,7 +814,7 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
                long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
                double beta, double gamma, hipStream_t st) {
   if (M > SNP || Nc > SNP || K > SNP || M <= 16 || Nc <= 8 || K <= 8 || P > 65535) return VSM_ERR_UNSUPPORTED;
-  static const bool off = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP_GEMM") != nullptr;
+  static const bool off = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_STRIP_GEMM");
   if (off) return VSM_ERR_UNSUPPORTED;
   const int ks = (K + 3) >> 2;
 #define VSM_G(KS) launch_gemm_strip<KS>(M, Nc, K, S, P, A, sa, pa, B, sb, pb, C, sc, pc, alpha, D, sd, pd, beta, gamma, st)

@@ -1022,19 +1022,8 @@ static int launch_ia32(int N, int S, const composite<float>& c, const added<floa
 
 }  // namespace
 
-// the previous generation (one workgroup per CU, XOR-swizzled column-major A-forms): vsm_strip32_v1.hip, kept for A/B runs
-bool strip32v1_supported(int N);
-int strip32v1_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
-                            const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
-                            hipStream_t st);
-int strip32v1_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st);
-static bool use_v1() {
-  static const bool v1 = getenv("VSM_STRIP32_V1") != nullptr;
-  return v1;
-}
-
 bool strip32_supported(int N) {
-  static const bool off = getenv("VSM_NO_STRIP") != nullptr || getenv("VSM_NO_STRIP32") != nullptr;
+  static const bool off = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_STRIP32");
   return !off && N > 64 && N <= FNP;
 }
 
@@ -1042,13 +1031,6 @@ int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const 
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st, int thermal) {
   if (S <= 0) return VSM_OK;
-  if (use_v1()) {
-    if (thermal) {
-      set_error("strip32_layer_forward: the first-generation FP32 strip kernels (VSM_STRIP32_V1) have no thermal slot");
-      return VSM_ERR_UNSUPPORTED;
-    }
-    return strip32v1_layer_forward(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st);
-  }
   // N % 4 != 0: element-wise global accesses, one instantiation (KB = 6) for all such N
   if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
   if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
@@ -1058,10 +1040,6 @@ int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const 
 int strip32_layer_forward_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
                              const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st) {
   if (S <= 0 || nm <= 0) return VSM_OK;
-  if (use_v1()) {
-    set_error("strip32_layer_forward_mm: not with the first-generation FP32 strip kernels (VSM_STRIP32_V1)");
-    return VSM_ERR_UNSUPPORTED;
-  }
   if (q.N & 3) return launch_layer32_mm<6, false>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
   if (q.N > 80) return launch_layer32_mm<6, true>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
   return launch_layer32_mm<5, true>(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
@@ -1069,7 +1047,6 @@ int strip32_layer_forward_mm(const quad<float>& q, int S, int nm, int ndoubl, co
 
 int strip32_interaction11(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  if (use_v1()) return strip32v1_interaction11(N, S, c, a, st);
   if (N & 3) return launch_ia32<6, false>(N, S, c, a, st);
   if (N > 80) return launch_ia32<6, true>(N, S, c, a, st);
   return launch_ia32<5, true>(N, S, c, a, st);

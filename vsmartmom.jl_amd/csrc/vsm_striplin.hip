@@ -928,7 +928,7 @@ VSM_STRIPLIN_DECL(15)
 // not the plain [N,N,S] layout.
 int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr;
+  static const bool off = ab_switch("VSM_NO_STRIP_LIN");
   if (off || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   switch ((N + 3) / 4) {
@@ -952,7 +952,7 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
 // VSM_ERR_UNSUPPORTED otherwise.
 int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_LIN_MULTI") != nullptr;
+  static const bool off = ab_switch("VSM_NO_STRIP_LIN") || ab_switch("VSM_NO_LIN_MULTI");
   if (off || P < 1 || P > 3 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   switch ((N + 3) / 4) {
@@ -975,7 +975,7 @@ int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, 
 // Fused ScatteringInterface_11 interaction with derivatives: two launches (first half, second half).
 int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st) {
-  static const bool off = getenv("VSM_NO_STRIP_LIN") != nullptr || getenv("VSM_NO_STRIP_LIN_IA") != nullptr;
+  static const bool off = ab_switch("VSM_NO_STRIP_LIN") || ab_switch("VSM_NO_STRIP_LIN_IA");
   if (off || !strip_supported(N)) return VSM_ERR_UNSUPPORTED;
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S;
