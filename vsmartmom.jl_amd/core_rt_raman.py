@@ -132,7 +132,7 @@ def copy_added_to_composite_ie_(comp, comp_rs: CompositeLayerRS, added, added_rs
 
 
 def rt_kernel_rrs_(drs: DeviceRRS, pol, added, added_rs, comp, comp_rs, props: CR.DeviceLayerOptics, tau_sum, m, dq, arch, iz,
-                   F0, FT, numerics, dtau=None, ndoubl=None, expk=None, trace=None):
+                   F0, FT, numerics, dtau=None, ndoubl=None, expk=None, trace=None, iface: str = "11"):
     """rt_kernel!(::RRS, ...) (rt_kernel.jl:352-391): scatter is hard-wired to true (:365).
     dtau / ndoubl / expk may be passed pre-computed (sharded runs derive them from the full spectral axis)."""
     if dtau is None:
@@ -147,7 +147,7 @@ def rt_kernel_rrs_(drs: DeviceRRS, pol, added, added_rs, comp, comp_rs, props: C
     if iz == 1:
         copy_added_to_composite_ie_(comp, comp_rs, added, added_rs)
     else:
-        interaction_inelastic_(drs, "11", comp, comp_rs, added, added_rs)
+        interaction_inelastic_(drs, iface, comp, comp_rs, added, added_rs)
 
 
 def postprocessing_vza_rs_(pol, comp, comp_rs: CompositeLayerRS, vza, vaz, qp, m, weight, R_SFI, T_SFI, ieR_SFI, ieT_SFI):
@@ -176,83 +176,112 @@ def default_fscatt(model: H.RTModel) -> np.ndarray:
     return model.tau_rayl / tau_sc
 
 
+class SceneRRS:
+    """Everything rt_run(RS_type::RRS, model, iBand) needs, resident in HBM (the Raman twin of CoreRT.Scene): the forward layer
+    optics (tau, varpi, dtau, tau_sum, the component phase matrices and their per-point weights) come from CoreRT.Scene's device
+    pass over the raw optical depths, uploaded once; the Raman phase matrices Z_λ₁λ₀(m) are computed on the device from
+    `greek_raman` (computeRamanZλ!, inelastic_helper.jl:917-924 -> vsm_compute_Z_moments), fScattRayleigh [nSpec, Nz] is
+    uploaded once, exp(-dtau/mu0) is formed per layer on the device.  `run()` only launches kernels.
+
+    `spec_slice` = the recipient points this rank owns (multi-GPU): the scene covers the slice extended by a
+    halo of max|i_λ₁λ₀| donor points on each side (`parallel.raman_halo_slices`), ndoubl comes from the FULL spectral axis,
+    and only the owned points are returned -- no exchange step is needed."""
+
+    def __init__(self, RS_type: RRS, model: H.RTModel, iBand: int = 1, spec_slice: Optional[slice] = None):
+        from . import parallel
+        arch, FT = model.architecture, model.float_type
+        CR._require_gpu(arch)
+        if iBand != 1:
+            raise _lib.VSMError("single-band models only (iBand = 1)")
+        self.model, self.rs, self.arch, self.FT = model, RS_type, arch, FT
+        pol, qp = model.polarization_type, model.quad_points
+        S_full, Nz = model.tau_rayl.shape
+        if spec_slice is None:
+            ext, crop = slice(0, S_full), slice(0, S_full)
+        else:
+            ext, crop = parallel.raman_halo_slices(S_full, spec_slice, RS_type.i_lambda1lambda0)
+        self.ext, self.crop = ext, crop
+        # the surface of the Raman driver is the Lambertian albedo (rt_run.jl:455-463 with the model's brdf; only the scalar
+        # Lambertian builder is wired here, like before)
+        self.fwd = CR.Scene(model, ext, full_added_layer=True)
+        self.fwd.compute_hdrf = False
+        fwd = self.fwd
+        S, N = fwd.S, fwd.N
+        self.S, self.N = S, N
+        conv = array_type(arch)
+        dt, dev = CR._torch_dtype(FT), devi(arch)
+        self.dt = dt
+        self.drs = device_rrs(RS_type, arch, FT)
+        K = self.drs.K
+        fscatt = RS_type.fscattRayl if RS_type.fscattRayl is not None else default_fscatt(model)
+        self.fscatt = conv(np.ascontiguousarray(np.asarray(fscatt, dtype=FT)[ext].T))          # (Nz, S): _expand_layer_rayleigh!
+        g = RS_type.greek_raman
+        tab = np.stack([np.asarray(getattr(g, k), dtype=np.float64) for k in ("alpha", "beta", "gamma", "delta", "epsilon", "zeta")])
+        gd = conv(np.ascontiguousarray(tab))
+        q = fwd.dq.cstruct()
+        self.Zie = []
+        for m in range(model.m_max + 1):
+            Zp = torch.empty((1, N, N), dtype=dt, device=dev)
+            Zm = torch.empty_like(Zp)
+            _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, tab.shape[1], CR._ptr(gd), CR._ptr(Zp), CR._ptr(Zm), CR._stream_ptr())
+            self.Zie.append((Zp, Zm))
+        nV = len(model.vza)
+        self.out = [fwd.R_SFI, fwd.T_SFI] + [torch.zeros((S, pol.n, nV), dtype=dt, device=dev) for _ in range(2)]
+        self.expk = torch.empty(max(S, 1), dtype=dt, device=dev)
+        if S > 0:
+            self.added_rs = AddedLayerRS(FT, arch, K, N, S)
+            self.surf_rs = AddedLayerRS(FT, arch, K, N, S)      # stays zero: the surface has no inelastic part
+            self.comp_rs = CompositeLayerRS(FT, arch, K, N, S)
+
+    def run(self, trace: Optional[list] = None):
+        """rt_run.jl:383-517 for RS_type::RRS: Fourier loop -> rt_kernel!(::RRS) per layer -> surface -> interaction ->
+        postprocessing_vza!(::RRS).  Returns the four (S_ext, nStokes, nVZA) device tensors R, T, ieR, ieT."""
+        model, fwd, FT, dt = self.model, self.fwd, self.FT, self.dt
+        pol, qp, drs = fwd.pol, fwd.qp, self.drs
+        for t in self.out:
+            t.zero_()
+        if self.S == 0:
+            return tuple(self.out)
+        R_SFI, T_SFI, ieR_SFI, ieT_SFI = self.out
+        added, comp = fwd.added, fwd.composite
+        mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
+        for mom in fwd.moments:
+            m = mom["m"]
+            weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+            drs.Zpp, drs.Zmp = self.Zie[m]
+            # the reference dispatches interaction!(RS_type, scattering_interfaces_all[iz], ...) on the tags of
+            # extractEffectiveProps (rt_kernel!(::RRS) itself hard-wires scatter = true, rt_kernel.jl:365)
+            for iz, ly in enumerate(mom["layers"]):
+                drs.fscatt = self.fscatt[iz]
+                _lib.call("vsm_layer_expk", dt, self.S, CR._ptr(ly["dtau"]), mu0, CR._ptr(self.expk), CR._stream_ptr())   # rt_kernel.jl:367
+                rt_kernel_rrs_(drs, pol, added, self.added_rs, comp, self.comp_rs, ly["props"].materialize(), ly["tau_sum"], m, fwd.dq,
+                               self.arch, iz + 1, fwd.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], expk=self.expk,
+                               trace=trace, iface=ly["iface"])
+            CR.create_surface_layer_(model.albedo, fwd.added_surface, m, fwd.dq, mom["tau_sum_surface"])
+            interaction_inelastic_(drs, mom["iface_surface"], comp, self.comp_rs, fwd.added_surface, self.surf_rs)
+            postprocessing_vza_rs_(pol, comp, self.comp_rs, model.vza, model.vaz, qp, m, float(weight), R_SFI, T_SFI, ieR_SFI, ieT_SFI)
+        return tuple(self.out)
+
+    def results_device(self):
+        """The owned points' (S_local, nStokes, nVZA) tensors (for the gather)."""
+        return tuple(t[self.crop].contiguous() for t in self.out)
+
+    def results_host(self):
+        return tuple(to_host(t[self.crop]).transpose(2, 1, 0).copy() for t in self.out)
+
+
 def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list] = None, spec_slice: Optional[slice] = None,
            device_out: bool = False):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:238-535): returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI) as host arrays
     [nVZA, nStokes, nSpec].  `model.greek_rayleigh` must hold the Cabannes phase matrix and `model.varpi_Cabannes`
-    the elastic Rayleigh single-scattering albedo (compEffectiveLayerProperties.jl:36-41).
-
-    `spec_slice` = the recipient points this rank owns (multi-GPU): the run covers the slice extended
-    by a halo of max|i_λ₁λ₀| donor points on each side (`parallel.raman_halo_slices`), ndoubl comes from the FULL
-    spectral axis, and only the owned points are returned -- no exchange step is needed.
+    the elastic Rayleigh single-scattering albedo (compEffectiveLayerProperties.jl:36-41).  `spec_slice`: see SceneRRS;
     `device_out=True` returns the four (S_local, nStokes, nVZA) device tensors instead (for the gather)."""
-    from . import parallel
-    arch, FT = model.architecture, model.float_type
-    CR._require_gpu(arch)
-    if iBand != 1:
-        raise _lib.VSMError("single-band models only (iBand = 1)")
-    pol, qp = model.polarization_type, model.quad_points
-    S_full, Nz = model.tau_rayl.shape
-    if spec_slice is None:
-        ext, crop = slice(0, S_full), slice(0, S_full)
-    else:
-        ext, crop = parallel.raman_halo_slices(S_full, spec_slice, RS_type.i_lambda1lambda0)
-    S = ext.stop - ext.start
-    N = qp.Nquad * pol.n
-    conv = array_type(arch)
-    up = lambda x: conv(np.ascontiguousarray(np.asarray(x, dtype=FT)))
-    dq = CR.device_quad(qp, pol, arch, FT)
-    drs = device_rrs(RS_type, arch, FT)
-    K = drs.K
-    fscatt = RS_type.fscattRayl if RS_type.fscattRayl is not None else default_fscatt(model)
-    F0 = model.F0
-    if F0 is None:
-        F0 = np.zeros((pol.n, S_full))
-        F0[0, :] = 1.0
-    F0d = up(np.asarray(F0)[:, ext].T)
-    dt, dev = CR._torch_dtype(FT), devi(arch)
-    nV = len(model.vza)
-    out = [torch.zeros((S, pol.n, nV), dtype=dt, device=dev) for _ in range(4)]
-    R_SFI, T_SFI, ieR_SFI, ieT_SFI = out
-    if S > 0:
-        added = CR.make_added_layer(FT, arch, (N, N), S)
-        added_surface = CR.make_added_layer(FT, arch, (N, N), S, shared=True)
-        comp = CR.make_composite_layer(FT, arch, (N, N), S)
-        added_rs = AddedLayerRS(FT, arch, K, N, S)
-        surf_rs = AddedLayerRS(FT, arch, K, N, S)      # stays zero: the surface has no inelastic part
-        comp_rs = CompositeLayerRS(FT, arch, K, N, S)
-    for m in range(model.m_max + 1 if S > 0 else 0):
-        weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
-        Zpp_ie, Zmp_ie = H.compute_Z_moments(pol, qp.qp_mu, RS_type.greek_raman, m)   # computeRamanZλ! (:917-924)
-        drs.Zpp, drs.Zmp = CR.to_device_matrix(Zpp_ie, arch, FT), CR.to_device_matrix(Zmp_ie, arch, FT)
-        lods = H.constructCoreOpticalProperties(model, m)
-        tags, tau_sum_all = H.extractEffectiveProps(lods, FT)
-        # the reference dispatches interaction!(RS_type, scattering_interfaces_all[iz], ...) on these tags; only the
-        # ScatteringInterface_11 inelastic method is built here (rt_kernel!(::RRS) hard-wires scatter = true, rt_kernel.jl:365)
-        if any(t != "11" for t in tags):
-            raise _lib.VSMError("rt_run(::RRS): a layer with max(tau*varpi) <= 2 eps gives interface tags %s; only "
-                                "ScatteringInterface_11 is implemented for the inelastic interaction" % sorted(set(tags)))
-        for iz, lo in enumerate(lods):
-            tau_full = np.atleast_1d(lo.tau).astype(FT)
-            varpi_full = np.broadcast_to(np.asarray(lo.varpi, dtype=FT), tau_full.shape)
-            dtau_full, nd = H.get_dtau_ndoubl(tau_full, varpi_full, qp, FT, model.numerics)   # batch-global ndoubl
-            Zpp, Zmp = np.asarray(lo.Zpp), np.asarray(lo.Zmp)
-            if Zpp.ndim == 3:
-                Zpp, Zmp = Zpp[ext], Zmp[ext]
-            props = CR.DeviceLayerOptics(up(tau_full[ext]), up(varpi_full[ext]), CR.to_device_matrix(Zpp, arch, FT),
-                                         CR.to_device_matrix(Zmp, arch, FT), float(np.max(tau_full * varpi_full)), tau_full,
-                                         np.asarray(varpi_full))
-            drs.fscatt = up(np.asarray(fscatt)[ext, iz])                                      # _expand_layer_rayleigh!
-            expk = up(np.exp(-dtau_full[ext] / FT(qp.mu0)))                                   # rt_kernel.jl:367
-            rt_kernel_rrs_(drs, pol, added, added_rs, comp, comp_rs, props, up(tau_sum_all[ext, iz]), m, dq, arch, iz + 1, F0d,
-                           FT, model.numerics, dtau=up(dtau_full[ext]), ndoubl=nd, expk=expk, trace=trace)
-        CR.create_surface_layer_(model.albedo, added_surface, m, dq, up(tau_sum_all[ext, -1]))
-        interaction_inelastic_(drs, tags[-1], comp, comp_rs, added_surface, surf_rs)
-        postprocessing_vza_rs_(pol, comp, comp_rs, model.vza, model.vaz, qp, m, float(weight), R_SFI, T_SFI, ieR_SFI, ieT_SFI)
+    scene = SceneRRS(RS_type, model, iBand, spec_slice)
+    scene.run(trace)
     if device_out:
-        return tuple(t[crop].contiguous() for t in out)
+        return scene.results_device()
     synchronize_if_gpu()
-    return tuple(to_host(t[crop]).transpose(2, 1, 0).copy() for t in out)
+    return scene.results_host()
 
 
 def rt_run_sharded(RS_type: RRS, model: H.RTModel, rank: int = 0, world: int = 1, dst: int = 0, executor=None):
