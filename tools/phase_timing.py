@@ -43,8 +43,8 @@ def main():
     torch.cuda.synchronize()
     lib.vsm_debug_phase_cycles(buf, 0)
     lib.vsm_debug_phase_cycles_strip(buf, 0)
-    names = ["elemental (per launch)", "E = r r", "norm + inverse", "tt = t G, store, 2 barriers", "tmp = tt r ; t' = tt t, store, barrier",
-             "r' = r + tmp t, sources", "barrier, store r t, barrier"]
+    names = ["elemental + rider set-up (per launch)", "[E | W] = r [r | t], rider swap-add", "norm, store [E], Horner series",
+             "tt = t G, reload t, barrier, store [tt], barrier", "[r' | t'] = [r | 0] + tt [W | t]", "riders", "barrier, store [r] [t], barrier"]
     v = np.array(list(buf)[:7], dtype=float)
     launches = L
     nd = scene.moments[0]["layers"][0]["nd"]
@@ -53,6 +53,10 @@ def main():
         per = x / launches / (nd if i else 1)
         print("  %-44s %12.0f total  %10.1f per %s" % (n, x, per, "step" if i else "launch"))
     print("  doubling loop per step: %.0f" % (v[1:].sum() / launches / nd))
+    allb = list(buf)
+    if allb[31]:
+        print("  core clock during the doubling loops of workgroup 0 (s_memtime ticks per s_memrealtime tick at 100 MHz): %.0f MHz"
+              % (allb[30] / (allb[31] / 100.0)))
     inames = ["stage [r],[T--], strips", "E1 = r R+-, u", "G1 (series) + store", "H, T01, T01 r + stores", "R-+ update (global)",
               "T-- = T01 t--, J0- (global)", "stage [R+-], [t]", "G2, z, T21 + store", "T21 T++, T21 R+- (global)", "R+- (global)"]
     lib.vsm_debug_phase_cycles_strip(buf, 0)

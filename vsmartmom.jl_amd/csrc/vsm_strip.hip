@@ -35,9 +35,31 @@ __device__ unsigned long long vsm_phase_cycles_strip[32];
       _t_prev = _t;                                                      \
     }                                                                    \
   } while (0)
+// the doubling loop's stamps accumulate in registers (a global read-modify-write per stamp would sit in every phase it precedes)
+#define VSM_RSTAMP_DECL                                  \
+  unsigned long long _rs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  const unsigned long long _rt0 = __builtin_readcyclecounter(), _rr0 = __builtin_amdgcn_s_memrealtime(); \
+  unsigned long long _rt = _rt0
+#define VSM_RSTAMP(i)                                                \
+  do {                                                               \
+    const unsigned long long _t = __builtin_readcyclecounter();      \
+    _rs[i] += _t - _rt;                                              \
+    _rt = _t;                                                        \
+  } while (0)
+#define VSM_RSTAMP_FLUSH()                                                          \
+  do {                                                                              \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                   \
+      for (int _i = 0; _i < 8; ++_i) vsm_phase_cycles_strip[_i] += _rs[_i];         \
+      vsm_phase_cycles_strip[30] += __builtin_readcyclecounter() - _rt0;            \
+      vsm_phase_cycles_strip[31] += __builtin_amdgcn_s_memrealtime() - _rr0;        \
+    }                                                                               \
+  } while (0)
 #else
 #define VSM_STAMP_DECL
 #define VSM_STAMP(i)
+#define VSM_RSTAMP_DECL
+#define VSM_RSTAMP(i)
+#define VSM_RSTAMP_FLUSH()
 #endif
 
 }  // namespace vsm
@@ -76,8 +98,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const int c1 = Kend, c2 = Kend + 1;
   const bool own_wave = (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
-  const double* jsrc = laneB ? jm : jp;                      // per-lane source / destination of the source vectors
-  double* jdst = laneA ? jp : (laneB ? jm : sm.vec[7]);
+  const double mAB = laneAB ? 1.0 : 0.0;
   const double d = dtau[s], w = varpi[s];
   // Z of this point: one block (z.ncomp == 0), or the mix  sum_k f_k(s) Z_k  of up to 4 scattering components
   // (types.jl:1262-1292 `+` of CoreScatteringOpticalProperties, evaluated where Z is consumed)
@@ -185,86 +206,118 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     jm[tid] = vjm;
   }
   auto keepN = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
-  if (ndoubl > 0) {
-    store_strip(P, r_s, p, keepN);
-    store_strip(Q, t_s, p, keepN);
-  }
-  __syncthreads();
-
-  // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------
+  // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------------------------
+  //   [E | W]   = r [r | t]                 A = P = [r]   (one pass over the fragments of [r])
+  //   G         = (I - E)^-1                Horner series on [E] in P (Gauss-Jordan / long series: out of line)
+  //   tt        = t G                       A = Q = [t]
+  //   [r' | t'] = [r | 0] + tt [W | t]      A = P = [tt]  (one pass over the fragments of [tt])
+  // i.e. r' = r + tt (r t) instead of (tt r) t: the intermediate tmp = tt r, its A-form store, its barrier and its product
+  // phase are gone (four A-form stores and six barriers per step instead of five and seven at series order 2; the same six
+  // products).  The padding rows / columns (>= N) of every strip are zero by construction (elemental writes zeros, a product
+  // inherits zero rows from its A operand and zero columns from its B operand), so the A-form stores need no mask.
+  // Sources (rt_helpers.jl:128-134: j0- += tt (j1- + r j0+), j0+ = j1+ + tt (j0+ + r j1-)) ride in the spare columns
+  // c1, c2 (>= 4 KS: never read as a contraction index) of the strips that are live anyway, for the WHOLE loop:
+  //   t_s[c1] = j0+, t_s[c2] = j1- = j0- expk  ->  W[c1] = r j0+, W[c2] = r j1-;  swap-add:  W[c1] += j1-, W[c2] += j0+
+  //   r_s[c1] = j0-, r_s[c2] = j1+ = j0+ expk  ->  r'[c1] = j0- + tt (j1- + r j0+), r'[c2] = j1+ + tt (j0+ + r j1-)
+  // -- the reference's statements term for term; the two lanes that own the columns exchange with one DPP swap: no LDS
+  // traffic, no extra live registers.
   double expk = THERMAL ? 1.0 : exp(-d / q.mu0);
   int slot = 0;
-  VSM_STAMP_DECL;
-  VSM_STAMP(0);
-  for (int n = 0; n < ndoubl; ++n) {
-    // on entry: P = r, Q = t (A-form), r_s / t_s in registers, all waves past a barrier
-    sstrip G;
-    {
-      sstrip E;
-      E.zero();
-      mm_ab<KS>(E, P, r_s, p);
-      VSM_STAMP(1);
-      invert_strip<KS>(E, G, P, N, sm, slot, p, 0);
-      VSM_STAMP(2);  // (its first barrier: every wave is done reading P = r)
-    }
-    // tt = t G
-    sstrip tt;
-    tt.zero();
-    mm_ab<KS>(tt, Q, G, p);
-    load_strip(t_s, Q, p);  // t's strip is not kept in registers across the inverse (register budget: 256)
-    __syncthreads();  // P (series powers) and Q (t) no longer read
-    store_strip(P, tt, p, keepN);
-    // j0+ and j1- = j0- expk ride in the spare columns of t_s (same wave that owns jp/jm's columns; LDS is in
-    // order within a wave, so no barrier is needed for the vectors)
-    if (own_wave) {  // (wave-uniform; the lanes of the wave read jsrc together, lanes A / B keep the value)
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double v = jsrc[p.row(ta, r)] * (laneB ? expk : 1.0);
-          t_s.v[ta][r] = laneAB ? v : t_s.v[ta][r];
-        }
-    }
-    __syncthreads();  // tt complete in P
-    VSM_STAMP(3);
-    // tmp = tt r ; t' = tt t  (+ tt j0+, tt j1- in the spare columns)
-    sstrip tmp, tn;
-    tmp.zero();
-    tn.zero();
-    mm_ab2<KS>(tmp, tn, P, r_s, t_s, p);
-    store_strip(Q, tmp, p, keepN);  // Q (t) is dead since the barrier before the tt store
-    __syncthreads();                // tmp complete in Q
-    VSM_STAMP(4);
-    // r' = r + tmp t   (+ tmp j0+, tmp j1- in the spare columns, on top of r_s's zero padding)
-    mm_ab<KS>(r_s, Q, t_s, p);
-    // sources: j0- <- j0- + tt j1- + tmp j0+ ; j0+ <- j1+ + tt j0+ + tmp j1-   (rt_helpers.jl:128-134)
+  VSM_RSTAMP_DECL;
+  auto asis = [](double a, int, int) { return a; };
+  __syncthreads();                       // jp / jm complete
+  if (ndoubl > 0) {
     if (own_wave) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-          const double x = tn.v[ta][r];                    // lane A: tt j0+    lane B: tt j1-
-          const double u = __shfl_xor(r_s.v[ta][r], 1);    // lane A: tmp j1-   lane B: tmp j0+
-          const double base = jsrc[row] * (laneB ? 1.0 : expk);   // lane A: j1+ = j0+ expk   lane B: j0-
-          jdst[row] = (row < N) ? base + x + u : 0.0;      // (other lanes write to a dummy vector)
-          r_s.v[ta][r] = laneAB ? 0.0 : r_s.v[ta][r];
-          tn.v[ta][r] = laneAB ? 0.0 : tn.v[ta][r];
+          const double vp = jp[row], vm = jm[row];          // (rows >= N hold zeros)
+          t_s.v[ta][r] = laneA ? vp : (laneB ? vm * expk : t_s.v[ta][r]);
+          r_s.v[ta][r] = laneA ? vm : (laneB ? vp * expk : r_s.v[ta][r]);
         }
     }
-    VSM_STAMP(5);
-    t_s = tn;
+    store_strip(P, r_s, p, asis);
+    store_strip(Q, t_s, p, asis);
+  }
+  __syncthreads();
+  VSM_RSTAMP(0);
+  for (int n = 0; n < ndoubl; ++n) {
+    // on entry: P = [r], Q = [t] (A-forms incl. the rider columns), r_s / t_s in registers, all waves past a barrier
+    sstrip W;
+    sstrip tt;
+    {
+      sstrip G;
+      {
+        sstrip E;
+        E.zero();
+        W.zero();
+        mm_ab2<KS>(E, W, P, r_s, t_s, p);
+        if (own_wave) {   // W[c1] += j1-, W[c2] += j0+ (neighbour lanes: one DPP quad swap; mAB = 1 on the two rider lanes, else 0)
+#pragma unroll
+          for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W.v[ta][r] = fma(dpp_swap1(t_s.v[ta][r]), mAB, W.v[ta][r]);
+        }
+        VSM_RSTAMP(1);
+        invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (masks the rider columns of E; its first barrier: [r] is free)
+        VSM_RSTAMP(2);
+      }
+      tt.zero();
+      mm_ab<KS>(tt, Q, G, p);              // tt = t G
+    }
+    load_strip(t_s, Q, p);                 // t's strip (with its riders) is not kept in registers across the inverse
+    __syncthreads();                       // P ([E]) and Q ([t]) no longer read
+    store_strip(P, tt, p, asis);
+    __syncthreads();
+    VSM_RSTAMP(3);
+    {
+      sstrip tn;
+      tn.zero();
+      mm_ab2<KS>(r_s, tn, P, W, t_s, p);   // r' = r + tt W (riders: the new j0-, j0+) ; t' = tt t
+      t_s = tn;
+    }
+    VSM_RSTAMP(4);
     expk = expk * expk;
+    if (own_wave) {
+      const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk';  r_s[c2] = j1+' = j0+' expk'
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double x = r_s.v[ta][r];                    // lane A: j0-'   lane B: j0+'
+          const double u = dpp_swap1(x) * ft;               // lane A: j0+'   lane B: j0-' expk'
+          t_s.v[ta][r] = laneAB ? u : t_s.v[ta][r];
+          r_s.v[ta][r] = x * ft;                            // (ft = 1 away from lane B)
+        }
+    }
+    VSM_RSTAMP(5);
     if (n + 1 < ndoubl) {
-      __syncthreads();  // everybody finished reading P (tt) and Q (tmp)
-      store_strip(P, r_s, p, keepN);
-      store_strip(Q, t_s, p, keepN);
+      __syncthreads();  // everybody finished reading P ([tt])
+      store_strip(P, r_s, p, asis);
+      store_strip(Q, t_s, p, asis);
       __syncthreads();
     }
-    VSM_STAMP(6);
+    VSM_RSTAMP(6);
+  }
+  if (ndoubl > 0 && own_wave) {   // the riders go back to the LDS vectors; the strips leave the loop with clean padding
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        double* dp = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
+        double* dm = laneA ? jm : sm.vec[7];
+        dp[row] = t_s.v[ta][r];           // lane A: j0+
+        dm[row] = r_s.v[ta][r];           // lane A: j0-
+        t_s.v[ta][r] = laneAB ? 0.0 : t_s.v[ta][r];
+        r_s.v[ta][r] = laneAB ? 0.0 : r_s.v[ta][r];
+      }
   }
   __syncthreads();
 
+  VSM_RSTAMP_FLUSH();
   // ---- apply_D (doubling.jl:178-252): r-+ = D r*, j0- = D j0-* ------------------------------------------------
   if (ndoubl >= 1) {
 #pragma unroll
@@ -389,7 +442,11 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
         }
     }
     VSM_STAMP(9);
-    invert_strip<KS>(E, G, P, N, sm, slot, p, 0);   // (masks the columns >= N of E; P = [r-+] is free after its first barrier)
+#ifdef VSM_IA_OLD_INV
+    invert_strip<KS>(E, G, P, N, sm, slot, p, 0);
+#else
+    invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (masks the columns >= N of E; P = [r-+] is free after its first barrier)
+#endif
   }
   __syncthreads();                        // nobody reads P (series powers) any more
   store_strip(P, G, p, keepN);            // [G1] -> P

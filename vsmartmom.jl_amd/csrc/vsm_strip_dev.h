@@ -66,6 +66,22 @@ struct spos {
   }
 };
 
+// The products keep FOUR independent accumulator chains in flight (the four row tiles of a k-step): a dependent f64 MFMA
+// waits for its predecessor's result, and the register-pressure-minimising scheduler, left alone, turns the loop tile-major
+// (one chain of KS dependent MFMAs per tile: 1.45x the issue time of the products with one wave per SIMD).  A scheduling
+// fence after every k-step keeps the written order: fragments of step ks + 1 requested, then the MFMAs of step ks.
+#ifdef VSM_NO_KSTEP_FENCE
+#define VSM_KSTEP_FENCE()
+#else
+#define VSM_KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// value of the neighbour lane (lane ^ 1): one DPP quad permutation per 32-bit half, no LDS round trip (__shfl_xor is ds_bpermute)
+__device__ __forceinline__ double dpp_swap1(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 // acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
 template <int KS>
 __device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip& B, spos& p) {
@@ -82,6 +98,26 @@ __device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip
     const double b = B.v[ks >> 2][ks & 3];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc.v[t] = mfma<double>::mma(a[ks & 1][t], b, acc.v[t]);
+    VSM_KSTEP_FENCE();
+  }
+}
+// out = C0 + A * B without copying C0 into the accumulators first (the first k-step takes C0 as its addend)
+template <int KS>
+__device__ __forceinline__ void mm_ab_c(sstrip& out, const sstrip& C0, const double* A, const sstrip& B, spos& p) {
+  p.opaque();
+  double a[2][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+    }
+    const double b = B.v[ks >> 2][ks & 3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out.v[t] = mfma<double>::mma(a[ks & 1][t], b, ks == 0 ? C0.v[t] : out.v[t]);
+    VSM_KSTEP_FENCE();
   }
 }
 // acc1 += A * B1 ; acc2 += A * B2   (shared A fragments)
@@ -104,6 +140,7 @@ __device__ __forceinline__ void mm_ab2(sstrip& acc1, sstrip& acc2, const double*
       acc1.v[t] = mfma<double>::mma(a[ks & 1][t], b1, acc1.v[t]);
       acc2.v[t] = mfma<double>::mma(a[ks & 1][t], b2, acc2.v[t]);
     }
+    VSM_KSTEP_FENCE();
   }
 }
 
@@ -145,6 +182,24 @@ __device__ __forceinline__ double strip_norm_bound(const sstrip& e, int N, SM& s
   return (double)(sqrtf(tot) * 1.001f);
 }
 
+// The same for a strip whose padding rows (>= N) are zero by construction (the doubling loop's products): no per-element
+// mask, one select for the lanes of the padding / rider columns.
+template <typename SM>
+__device__ __forceinline__ double strip_norm_bound_clean(const sstrip& e, int N, SM& sm, int& slot, const spos& p) {
+  double ss = 0;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss = fma(e.v[ta][r], e.v[ta][r], ss);
+  ss = (p.col < N) ? ss : 0.0;
+  const float ws = wave_sum(to_float_up(ss));
+  if (p.lane == 0) sm.red[slot][p.wave] = ws;
+  __syncthreads();
+  const float tot = (sm.red[slot][0] + sm.red[slot][1]) + (sm.red[slot][2] + sm.red[slot][3]);
+  slot ^= 1;
+  return (double)(sqrtf(tot) * 1.001f);
+}
+
 // In-place pivoted Gauss-Jordan of the A-form matrix V (N x N block), 256 threads.  Ends with a barrier.
 __device__ __forceinline__ void gj_lds_strip(double* V, int N, gj_scratch<double, SNP>* sc) {
   using G = gj_cfg<SNP, SNT>;
@@ -168,13 +223,9 @@ __device__ __forceinline__ void gj_lds_strip(double* V, int N, gj_scratch<double
   __syncthreads();
 }
 
-// G_s = strip of (I - E)^-1, E given as strips.  W (LDS, A-form scratch) must not be read by anybody once the
-// first barrier inside has been passed (the norm reduction), which the callers guarantee.  On return other
-// waves may still be READING W: barrier before overwriting it.  Returns 1 (Gauss-Jordan) or 1 + series order.
-template <int KS, typename SM>
-__device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int N, SM& sm, int& slot, spos& p,
-                                            int mode) {
-  const double nrm = strip_norm_bound(E, N, sm, slot, p);
+// Order K of the Neumann series sum_{k <= K} E^k that reaches (I - E)^-1 to working precision, from a bound nrm >= ||E||_2:
+// the smallest of {1,2,3,4,7,8,15,16,31} with nrm^(K+1) / (1 - nrm) <= eps / 4; 0 = no series (nrm >= 0.3: Gauss-Jordan).
+__device__ __forceinline__ int series_order(double nrm) {
   const double tol = num<double>::eps() * 0.25;
   int K = 0;
   if (nrm < 0.3) {
@@ -190,6 +241,23 @@ __device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int
     else if (n16 * nrm <= lim) K = 16;
     else if (n16 * n16 <= lim) K = 31;
   }
+  return K;
+}
+
+// G_s = strip of (I - E)^-1, E given as strips.  W (LDS, A-form scratch) must not be read by anybody once the
+// first barrier inside has been passed (the norm reduction), which the callers guarantee.  On return other
+// waves may still be READING W: barrier before overwriting it.  Returns 1 (Gauss-Jordan) or 1 + series order.
+template <int KS, typename SM>
+__device__ __forceinline__ int invert_strip_k(int K, sstrip& E, sstrip& G, double* W, int N, SM& sm, spos& p, int mode);
+template <int KS, typename SM>
+__device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int N, SM& sm, int& slot, spos& p,
+                                            int mode) {
+  const double nrm = strip_norm_bound(E, N, sm, slot, p);
+  return invert_strip_k<KS>(series_order(nrm), E, G, W, N, sm, p, mode);
+}
+// the same after the norm reduction (all waves past its barrier), for a given order
+template <int KS, typename SM>
+__device__ __forceinline__ int invert_strip_k(int K, sstrip& E, sstrip& G, double* W, int N, SM& sm, spos& p, int mode) {
   if (mode == 1) K = 0;
   if (mode == 2 && K == 0) K = 31;
   auto keep = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
@@ -235,6 +303,62 @@ __device__ __forceinline__ int invert_strip(sstrip& E, sstrip& G, double* W, int
     E = W2;
   }
   return 1 + K;
+}
+
+// The general inverse out of line: the doubling loop of the layer kernels calls it only for orders the Horner path below
+// does not take (K > 8, Gauss-Jordan) -- rare, and its four live strips and the Gauss-Jordan register block stay out of the
+// loop's register allocation.
+template <int KS, typename SM>
+__device__ __attribute__((noinline)) void invert_strip_slow(int K, sstrip& E, sstrip& G, double* W, int N, SM& sm, spos& p) {
+  invert_strip_k<KS>(K, E, G, W, N, sm, p, 0);
+}
+// (I - E)^-1 for the doubling loop: after the norm reduction, orders 1..8 by Horner's rule with ONE A-form store,
+//   X_0 = E,  X_{j+1} = E + E X_j  ->  X_{K-1} = E + E^2 + ... + E^K,  G = I + X_{K-1}
+// (A = [E] for every product: no barrier between the K - 1 products, three live strips; for K <= 4 as many products as the
+// squaring scheme of invert_strip, whose every level costs an A-form store and two barriers more).  On return other waves may
+// still be reading W.
+template <int KS, typename SM>
+__device__ __forceinline__ void invert_strip_horner(sstrip& E, sstrip& G, double* W, int N, SM& sm, int& slot, spos& p) {
+  const double nrm = strip_norm_bound_clean(E, N, sm, slot, p);
+  const int K = series_order(nrm);
+  if (K < 1 || K > 8) {   // (copies: only these objects have their address taken, and only on this path)
+    sstrip Es = E, Gs;
+    spos ps = p;
+    invert_strip_slow<KS>(K, Es, Gs, W, N, sm, ps);
+    G = Gs;
+    return;
+  }
+  if (p.col >= N) E.zero();   // the rider / padding columns (rows >= N are zero by construction)
+  if (K == 1) {
+    G = E;
+  } else {
+    store_strip(W, E, p, [](double a, int, int) { return a; });
+    __syncthreads();
+    mm_ab_c<KS>(G, E, W, E, p);              // X1 = E + E E
+    if (K >= 3) {
+      sstrip X;
+      mm_ab_c<KS>(X, E, W, G, p);            // X2 = E + E X1
+      if (K >= 4) {
+        for (int j = 3; j < K; j += 2) {     // two Horner steps per pass (ping-pong between X and G: no copies)
+          mm_ab_c<KS>(G, E, W, X, p);
+          if (j + 1 < K) mm_ab_c<KS>(X, E, W, G, p);
+        }
+        if ((K & 1) == 0) X = G;             // even K: the last step landed in G
+      }
+      G = X;
+    }
+  }
+  // + I: a lane owns at most one diagonal element, in row tile ta = wave: (r = l15 >> 2, kq = l15 & 3)
+  {
+    const bool dl = p.kq == (p.l15 & 3) && p.col < N;
+    const int dr = p.l15 >> 2;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+      if (ta == p.wave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G.v[ta][r] += (dl && dr == r) ? 1.0 : 0.0;
+      }
+  }
 }
 
 __device__ __forceinline__ void load_strip_global(sstrip& s, const double* __restrict__ g, int N, const spos& p) {
