@@ -39,33 +39,42 @@ def main():
     buf = (C.c_ulonglong * 32)()
     lib.vsm_debug_phase_cycles(None, 1)
     lib.vsm_debug_phase_cycles_strip(None, 1)
+    import time
+    t0 = time.perf_counter()
     scene.run()
     torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    print("wall time of the pass (%d layer launches + surface): %.3f ms" % (L, wall_ms))
     lib.vsm_debug_phase_cycles(buf, 0)
     lib.vsm_debug_phase_cycles_strip(buf, 0)
-    names = ["elemental + rider set-up (per launch)", "[E | W] = r [r | t], rider swap-add", "norm, store [E], Horner series",
+    names = ["rider set-up, first A-form stores (per launch)", "[E | W] = r [r | t], rider swap-add", "norm, store [E], Horner series",
              "tt = t G, reload t, barrier, store [tt], barrier", "[r' | t'] = [r | 0] + tt [W | t]", "riders", "barrier, store [r] [t], barrier"]
-    v = np.array(list(buf)[:7], dtype=float)
-    launches = L
-    nd = scene.moments[0]["layers"][0]["nd"]
-    print("S=%d layers=%d nd=%d ; cycles of workgroup 0 / thread 0 of k_layer_strip" % (S, L, nd))
-    for i, (n, x) in enumerate(zip(names, v)):
-        per = x / launches / (nd if i else 1)
-        print("  %-44s %12.0f total  %10.1f per %s" % (n, x, per, "step" if i else "launch"))
-    print("  doubling loop per step: %.0f" % (v[1:].sum() / launches / nd))
     allb = list(buf)
+    v = np.array(allb[:7], dtype=float)
+    nwg = max(allb[28], 1)                      # workgroups that ran elemental + doubling (every workgroup flushes its stamps)
+    nd = scene.moments[0]["layers"][0]["nd"]
+    print("S=%d layers=%d nd=%d ; cycles per workgroup of k_layer_strip, mean over %d workgroups (all rounds of all launches)" % (S, L, nd, nwg))
+    for i, (n, x) in enumerate(zip(names, v)):
+        per = x / nwg / (nd if i else 1)
+        print("  %-52s %10.1f per %s" % (n, per, "step" if i else "launch"))
+    print("  doubling loop per step: %.0f" % (v[1:].sum() / nwg / nd))
+    print("  elemental (entry of the body -> source vectors in LDS): %.0f per launch" % (allb[7] / nwg))
     if allb[31]:
-        print("  core clock during the doubling loops of workgroup 0 (s_memtime ticks per s_memrealtime tick at 100 MHz): %.0f MHz"
+        print("  core clock during elemental + doubling (s_memtime ticks per s_memrealtime tick at 100 MHz): %.0f MHz"
               % (allb[30] / (allb[31] / 100.0)))
-    inames = ["stage [r],[T--], strips", "E1 = r R+-, u", "G1 (series) + store", "H, T01, T01 r + stores", "R-+ update (global)",
-              "T-- = T01 t--, J0- (global)", "stage [R+-], [t]", "G2, z, T21 + store", "T21 T++, T21 R+- (global)", "R+- (global)"]
-    lib.vsm_debug_phase_cycles_strip(buf, 0)
-    w = np.array(list(buf)[8:18], dtype=float)
-    ni = L  # L-1 layer interactions + 1 surface
-    print("k_ia_strip (per launch, %d launches; two workgroups share the CU, so waits include the other one's work):" % ni)
+    inames = ["stage [R+-], [T--]", "[E2|Z] = R+- [r|t--], [S|V] = T-- [r|t--], z", "norm, store [S] [E2], series", "barrier, store [t], barrier",
+              "T21 = t G2, Y = S G2", "barrier, stores [T21] [Y], request T++ / R-+, barrier", "[R+-|T++] = [r+-|0] + T21 [Z|T++]",
+              "stores R+-, T++, J0+", "[R-+|T--] += Y [T++|Z]", "stores R-+, T--, J0-"]
+    w = np.array(allb[8:18], dtype=float)
+    ni = max(allb[29], 1)
+    print("interaction (mean over %d workgroups):" % ni)
     for n, x in zip(inames, w):
-        print("  %-36s %10.1f" % (n, x / ni))
-    print("  sum per launch: %.0f" % (w.sum() / ni))
+        print("  %-56s %10.1f" % (n, x / ni))
+    print("  sum: %.0f" % (w.sum() / ni))
+    tot = v.sum() / nwg + w.sum() / ni + allb[7] / nwg
+    if allb[26]:
+        print("  workgroup lifetime (kernel entry -> last store issued): %.0f cycles, mean over %d non-TOA workgroups" % (allb[27] / allb[26], allb[26]))
+    print("  layer total per workgroup: %.0f cycles (MFMA issue of %d doubling steps x 6 products + 11: %d)" % (tot, nd, (6 * nd + 11) * 3840))
 
 
 if __name__ == "__main__":

@@ -26,16 +26,33 @@ namespace vsm {
 
 #ifdef VSM_PHASE_TIMING
 __device__ unsigned long long vsm_phase_cycles_strip[32];
-#define VSM_STAMP_DECL unsigned long long _t_prev = __builtin_readcyclecounter()
+// Stamps accumulate in (scalar) registers and are flushed once per workgroup with atomics: a global read-modify-write per stamp
+// would sit in every phase it precedes.  EVERY workgroup contributes (slot 28 / 29 count the flushes): workgroup 0 alone shows
+// the first round of a launch, where all workgroups of a CU start in phase.
+#define VSM_STAMP_DECL                                                    \
+  unsigned long long _is[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};            \
+  unsigned long long _it = __builtin_readcyclecounter()
 #define VSM_STAMP(i)                                                     \
   do {                                                                   \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                           \
-      const unsigned long long _t = __builtin_readcyclecounter();        \
-      vsm_phase_cycles_strip[i] += _t - _t_prev;                               \
-      _t_prev = _t;                                                      \
-    }                                                                    \
+    const unsigned long long _t = __builtin_readcyclecounter();          \
+    _is[(i) - 8] += _t - _it;                                            \
+    _it = _t;                                                            \
   } while (0)
-// the doubling loop's stamps accumulate in registers (a global read-modify-write per stamp would sit in every phase it precedes)
+#define VSM_STAMP_FLUSH()                                                                         \
+  do {                                                                                            \
+    if (threadIdx.x == 0) {                                                                       \
+      for (int _i = 0; _i < 10; ++_i) atomicAdd(&vsm_phase_cycles_strip[8 + _i], _is[_i]);        \
+      atomicAdd(&vsm_phase_cycles_strip[29], 1ull);                                               \
+    }                                                                                             \
+  } while (0)
+#define VSM_LIFE_DECL const unsigned long long _lt0 = __builtin_readcyclecounter()
+#define VSM_LIFE_FLUSH()                                                                                    \
+  do {                                                                                                      \
+    if (threadIdx.x == 0) {                                                                                 \
+      atomicAdd(&vsm_phase_cycles_strip[27], (unsigned long long)(__builtin_readcyclecounter() - _lt0));    \
+      atomicAdd(&vsm_phase_cycles_strip[26], 1ull);                                                         \
+    }                                                                                                       \
+  } while (0)
 #define VSM_RSTAMP_DECL                                  \
   unsigned long long _rs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
   const unsigned long long _rt0 = __builtin_readcyclecounter(), _rr0 = __builtin_amdgcn_s_memrealtime(); \
@@ -46,17 +63,21 @@ __device__ unsigned long long vsm_phase_cycles_strip[32];
     _rs[i] += _t - _rt;                                              \
     _rt = _t;                                                        \
   } while (0)
-#define VSM_RSTAMP_FLUSH()                                                          \
-  do {                                                                              \
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {                   \
-      for (int _i = 0; _i < 8; ++_i) vsm_phase_cycles_strip[_i] += _rs[_i];         \
-      vsm_phase_cycles_strip[30] += __builtin_readcyclecounter() - _rt0;            \
-      vsm_phase_cycles_strip[31] += __builtin_amdgcn_s_memrealtime() - _rr0;        \
-    }                                                                               \
+#define VSM_RSTAMP_FLUSH()                                                                               \
+  do {                                                                                                   \
+    if (threadIdx.x == 0) {                                                                              \
+      for (int _i = 0; _i < 8; ++_i) atomicAdd(&vsm_phase_cycles_strip[_i], _rs[_i]);                    \
+      atomicAdd(&vsm_phase_cycles_strip[28], 1ull);                                                      \
+      atomicAdd(&vsm_phase_cycles_strip[30], (unsigned long long)(__builtin_readcyclecounter() - _rt0)); \
+      atomicAdd(&vsm_phase_cycles_strip[31], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - _rr0)); \
+    }                                                                                                    \
   } while (0)
 #else
 #define VSM_STAMP_DECL
 #define VSM_STAMP(i)
+#define VSM_STAMP_FLUSH()
+#define VSM_LIFE_DECL
+#define VSM_LIFE_FLUSH()
 #define VSM_RSTAMP_DECL
 #define VSM_RSTAMP(i)
 #define VSM_RSTAMP_FLUSH()
@@ -81,12 +102,13 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
                                         const double* __restrict__ dtau, const double* __restrict__ varpi,
                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
                                         const zsrc<double>& z, sstrip& r_s, sstrip& t_s) {
+  VSM_RSTAMP_DECL;
   double* P = sm.P;
   double* Q = sm.Q;
   double* jp = sm.vec[0];
   double* jm = sm.vec[1];
   double* mus = sm.vec[2];
-  double* wcs = sm.vec[3];
+  double* rsg = sm.vec[3];   // row sign of apply_D
   double* xs = sm.vec[4];
   double* es = sm.vec[5];
   double* ems = sm.vec[6];
@@ -119,93 +141,108 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     return acc;
   };
 
+  // per-row tables; `thick` = some dtau / mu_i >= 1/2 (then the differences of exponentials go through expm1 per element)
   if (tid < SNP) {
-    mus[tid] = (tid < N) ? q.mu[tid] : 1.0;
-    const double wt = (tid < N) ? q.wt[tid] : 0.0;
-    wcs[tid] = (m == 0) ? wt / 2.0 : wt / 4.0;
-    const double x = d / mus[tid];
+    const bool in = tid < N;
+    const double mu = in ? q.mu[tid] : 1.0;
+    mus[tid] = mu;
+    const double x = d / mu;
     xs[tid] = x;
     es[tid] = exp(-x);
     ems[tid] = expm1(-x);
+    rsg[tid] = (ndoubl >= 1 && is_uv_row(tid, ns)) ? -1.0 : 1.0;   // starred R* = D R (elemental.jl:403-422)
+    const unsigned long long any_thick = __ballot(in && x >= 0.5);   // (tid < 64: exactly wave 0)
+    if (tid == 0) sm.flags[0] = any_thick != 0ull;
   }
   __syncthreads();
+  const bool thick = __builtin_amdgcn_readfirstlane(sm.flags[0]) != 0;
 
-  // ---- elemental (elemental.jl:289-334), each lane computes the 16 elements of its strip -----------------
+  // ---- elemental (elemental.jl:289-334) and its SFI source (elemental.jl:348-392) -------------------------------------------
+  //   r-+_ij = varpi Z-+_ij  mu_j / (mu_i + mu_j) w_j (1 - e^{-x_i} e^{-x_j}),   1 - e^{-x_i} e^{-x_j} = -(a_i + a_j + a_i a_j), a = expm1(-x)
+  //   t++_ij = varpi Z++_ij  mu_j / (mu_i - mu_j) w_j (e^{-x_i} - e^{-x_j})      (mu_i != mu_j)
+  //          = delta_ij e^{-x_i} + e^{-x_j} varpi Z++_ij x_i w_j                 (mu_i == mu_j)
+  // A lane computes the 16 elements of its column of the strip; the results go straight into the A-forms [r] -> P, [t] -> Q (the
+  // first doubling step needs them there) and the strips are read back, so that the loop over the row tiles stays ROLLED: a
+  // quarter of the code (the unrolled form was 45 KB of straight-line code executed once per workgroup behind a cold
+  // instruction cache: 1.1 10^5 cycles per workgroup, a sixth of its lifetime) and a few live registers.
+  // The source vectors have the same form with the solar column in place of column j (mu_j -> mu_0, x_j -> dtau / mu_0,
+  // w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q):  j0+ is the "t" formula, j0- the "r" formula, times the beam
+  // attenuation exp(-tau_sum / mu_0).  The lanes that own the spare columns c1, c2 (never read as a contraction index) evaluate
+  // them in place of their (zero) matrix elements and leave them where the doubling loop wants them (see below):
+  //   t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk     (ndoubl > 0)
+  const double expk0 = THERMAL ? 1.0 : exp(-d / q.mu0);
   {
     const int j = p.col;
     const int jc = min(j, N - 1);
-    const double mj = mus[j], wct = wcs[j], xj = xs[j], emj = ems[j], ej = es[j];
+    const int i0 = ns * q.i_mu0;
+    const int jt = laneAB ? i0 : jc;               // table / Z column
+    double fz[4] = {1.0, 0.0, 0.0, 0.0};
+    double att = 1.0;
+    if (laneAB && !THERMAL) {
 #pragma unroll
+      for (int qq = 0; qq < 4; ++qq) fz[qq] = (qq < ns) ? F0[qq + (long long)ns * s] : 0.0;
+      att = exp(-tau_sum[s] / mus[i0]);
+    }
+    const int nz = (own_wave && !THERMAL) ? ns : 1;   // (wave-uniform)
+    const double wt = (j < N) ? q.wt[jc] : 0.0;
+    const double wct = laneAB ? ((m == 0) ? 0.5 : 0.25) : ((m == 0) ? wt / 2.0 : wt / 4.0);
+    const bool active = laneAB || wct > num<double>::eps();
+    const double mj = mus[jt], xj = xs[jt], emj = ems[jt], ej = es[jt];
+    const double thB = THERMAL ? 6.283185307179586476925286766559 * (1.0 - w) * F0[s] : 0.0;
+    const bool riders_in = ndoubl > 0;
+#pragma unroll 1
     for (int ta = 0; ta < 4; ++ta) {
-      double zp[4], zm[4];
+      double zp[4] = {0.0, 0.0, 0.0, 0.0}, zm[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int qq = 0; qq < nz; ++qq) {
+        const double f = (qq == 0) ? fz[0] : ((qq == 1) ? fz[1] : ((qq == 2) ? fz[2] : fz[3]));
+        const int jz = laneAB ? jt + qq : jt;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jc;
-        zp[r] = zget(Zp, zo);
-        zm[r] = zget(Zm, zo);
+        for (int r = 0; r < 4; ++r) {
+          const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jz;
+          zp[r] += zget(Zp, zo) * f;
+          zm[r] += zget(Zm, zo) * f;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = p.row(ta, r);
-        double rr = 0.0, tt = 0.0;
-        if (i < N && j < N) {
-          const double mi = mus[i], xi = xs[i];
-          if (wct > num<double>::eps()) {
-            const double emi = ems[i];
-            rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
-            if (mi == mj) {
-              if (i == j)
-                tt = es[i] * (1.0 + w * zp[r] * xi * wct);
-              else
-                tt = ej * (w * zp[r] * xi * wct);
-            } else {
-              const double xm = fmax(xi, xj);
-              const double ediff =
-                  (xm < 0.5 && fabs(xi - xj) > 0.125 * xm) ? (emi - emj) : expdiff_neg<double>(xi, xj);
-              tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
-            }
+        const double mi = mus[i], xi = xs[i], emi = ems[i], ei = es[i], sg = rsg[i];
+        const double rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
+        double ediff;
+        if (thick) ediff = expdiff_tab_thick(xi, xj, ei, ej); else ediff = expdiff_tab_thin(xi, xj, emi, emj, ej);
+        const double t_off = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
+        const double t_1 = w * zp[r] * xi * wct;
+        const double t_same = (i == j) ? ei * (1.0 + t_1) : ej * t_1;
+        const double tt = (mi == mj) ? t_same : t_off;
+        const bool in = i < N && j < N;
+        double rv = (in && active) ? rr * sg : 0.0;
+        double tv = in ? (active ? tt : ((i == j) ? ei : 0.0)) : 0.0;
+        if (own_wave) {
+          double vp, vm;
+          if (THERMAL) {
+            vp = vm = (i < N && i % ns == 0 && mi > num<double>::eps()) ? thB * (-emi) : 0.0;
           } else {
-            tt = (i == j) ? es[i] : 0.0;
+            vp = (i < N) ? tt * att : 0.0;
+            vm = (i < N) ? rr * att * sg : 0.0;
           }
-          if (ndoubl >= 1 && is_uv_row(i, ns)) rr = -rr;  // starred R* = D R (elemental.jl:403-422)
+          if (laneAB) {
+            tv = riders_in ? (laneA ? vp : vm * expk0) : 0.0;
+            rv = riders_in ? (laneA ? vm : vp * expk0) : 0.0;
+          }
+          double* dp = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
+          double* dm = laneA ? jm : sm.vec[7];
+          dp[i] = vp;
+          dm[i] = vm;
         }
-        r_s.v[ta][r] = rr;
-        t_s.v[ta][r] = tt;
+        P[p.sidx(ta, r)] = rv;
+        Q[p.sidx(ta, r)] = tv;
       }
     }
   }
-  // ---- SFI source (elemental.jl:348-392) -> LDS vectors jp, jm ---------------------------------------------
-  if (tid < SNP) {
-    double vjp = 0.0, vjm = 0.0;
-    if (THERMAL) {
-      if (tid < N && tid % ns == 0 && mus[tid] > num<double>::eps())
-        vjp = vjm = 6.283185307179586476925286766559 * (1.0 - w) * F0[s] * (-expm1(-d / mus[tid]));
-    } else if (tid < N) {
-      const int i = tid;
-      const int i_start = ns * q.i_mu0;
-      const double wct02 = (m == 0) ? 0.5 : 0.25;
-      double zp = 0, zm = 0;
-      for (int qq = 0; qq < ns; ++qq) {
-        const long long zo = i + (long long)N * (i_start + qq);
-        const double f = F0[qq + (long long)ns * s];
-        zp += zget(Zp, zo) * f;
-        zm += zget(Zm, zo) * f;
-      }
-      const double mi = mus[i], ms = mus[i_start];
-      if (i >= i_start && i < i_start + ns)
-        vjp = wct02 * w * zp * (d / mi) * exp(-d / mi);
-      else
-        vjp = wct02 * w * zp * (ms / (mi - ms)) * expdiff_neg<double>(d / mi, d / ms);
-      vjm = wct02 * w * zm * (ms / (mi + ms)) * (-expm1(-d * ((1.0 / mi) + (1.0 / ms))));
-      const double att = exp(-tau_sum[s] / ms);
-      vjp *= att;
-      vjm *= att;
-      if (ndoubl >= 1 && is_uv_row(i, ns)) vjm = -vjm;
-    }
-    jp[tid] = vjp;
-    jm[tid] = vjm;
-  }
-  auto keepN = [N](double a, int r, int c) { return (r < N && c < N) ? a : 0.0; };
+  __syncthreads();
+  load_strip(r_s, P, p);
+  load_strip(t_s, Q, p);
+  VSM_RSTAMP(7);   // elemental
   // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------------------------
   //   [E | W]   = r [r | t]                 A = P = [r]   (one pass over the fragments of [r])
   //   G         = (I - E)^-1                Horner series on [E] in P (Gauss-Jordan / long series: out of line)
@@ -221,27 +258,9 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   //   r_s[c1] = j0-, r_s[c2] = j1+ = j0+ expk  ->  r'[c1] = j0- + tt (j1- + r j0+), r'[c2] = j1+ + tt (j0+ + r j1-)
   // -- the reference's statements term for term; the two lanes that own the columns exchange with one DPP swap: no LDS
   // traffic, no extra live registers.
-  double expk = THERMAL ? 1.0 : exp(-d / q.mu0);
+  double expk = expk0;
   int slot = 0;
-  VSM_RSTAMP_DECL;
   auto asis = [](double a, int, int) { return a; };
-  __syncthreads();                       // jp / jm complete
-  if (ndoubl > 0) {
-    if (own_wave) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = p.row(ta, r);
-          const double vp = jp[row], vm = jm[row];          // (rows >= N hold zeros)
-          t_s.v[ta][r] = laneA ? vp : (laneB ? vm * expk : t_s.v[ta][r]);
-          r_s.v[ta][r] = laneA ? vm : (laneB ? vp * expk : r_s.v[ta][r]);
-        }
-    }
-    store_strip(P, r_s, p, asis);
-    store_strip(Q, t_s, p, asis);
-  }
-  __syncthreads();
   VSM_RSTAMP(0);
   for (int n = 0; n < ndoubl; ++n) {
     // on entry: P = [r], Q = [t] (A-forms incl. the rider columns), r_s / t_s in registers, all waves past a barrier
@@ -323,9 +342,8 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (is_uv_row(p.row(ta, r), ns)) r_s.v[ta][r] = -r_s.v[ta][r];
-    if (tid < SNP && is_uv_row(tid, ns)) jm[tid] = -jm[tid];
+      for (int r = 0; r < 4; ++r) r_s.v[ta][r] *= rsg[p.row(ta, r)];
+    if (tid < SNP) jm[tid] *= rsg[tid];
   }
   __syncthreads();
 }
@@ -376,10 +394,26 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
 // interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266), strip form
 // ---------------------------------------------------------------------------
 
-// Body shared by k_ia_strip and k_layer_strip.  On entry: r_s / t_s = strips of the added layer's r-+ / t++,
-// sm.vec[0] / vec[1] = its j0+ / j0-, all waves past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D
-// (added layers from doubling); ns == 0: they are read from r_pm / t_mm (surface layers).
-template <int KS>
+// Body shared by k_ia_strip and k_layer_strip.  On entry: r_s / t_s = strips of the added layer's r-+ / t++ (columns >= N zero),
+// sm.vec[0] / vec[1] = its j0+ / j0-, all waves past a barrier, P and Q free.  DSYM: r+- = D r-+ D, t-- = D t++ D (added layers
+// from doubling, ns = n_stokes); otherwise they are read from r_pm / t_mm (surface layers).
+//
+// The reference's statements (interaction.jl:207-266)
+//   T01 = T-- (I - r-+ R+-)^-1 ;  R-+ += T01 r-+ T++ ;  J0- += T01 (j0- + r-+ J0+) ;  T-- = T01 t--
+//   T21 = t++ (I - R+- r-+)^-1 ;  J0+ = j0+ + T21 (J0+ + R+- j0-) ;  T++ = T21 T++ ;  R+- = r+- + T21 R+- t--
+// are evaluated with ONE inverse G2 = (I - R+- r-+)^-1 and the push-through identities (I - r R)^-1 r = r G2,
+// (I - r R)^-1 = I + r G2 R  (exact; valid whenever the inverses exist):
+//   [E2 | Z] = R+- [r-+ | t--]          A = P = [R+-]   z  = J0+ + R+- j0-   (j0- rides in a spare column of r-+)
+//   [S  | V] = T-- [r-+ | t--]          A = Q = [T--]   vs = T-- j0-         (the same rider)
+//   G2       = (I - E2)^-1              A = P = [E2]    Horner series (Gauss-Jordan / long series out of line)
+//   T21 = t++ G2 ;  Y = S G2            A = P = [t++], Q = [S]               (Y = T01 r-+)
+//   [R+- | T++] = [r+- | 0] + T21 [Z | T++]      A = P = [T21]   J0+ = j0+ + T21 z   (z rides in a spare column of T++)
+//   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z  (the same rider)
+// since T01 t-- = T-- t-- + (T-- r G2)(R+- t--) = V + Y Z and T01 (j0- + r J0+) = T-- j0- + Y (R+- j0- + J0+).  Ten products
+// and the series (the as-written order: twelve and two inverses), seven barriers, three product phases of four, two and four
+// products, six live strips at most; every composite matrix crosses the memory system once in each direction ([R+-], [T--]
+// coalesced into their A-forms, T++ and R-+ as strips).
+template <int KS, bool DSYM>
 __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const composite<double>& c, sstrip& r_s,
                                         sstrip& t_s, const double* __restrict__ r_pm, const double* __restrict__ t_mm) {
   double* P = sm.P;
@@ -388,7 +422,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   double* vjm = sm.vec[1];
   double* vJp = sm.vec[2];
   double* vJm = sm.vec[3];
-  double* vu = sm.vec[4];
+  double* vs = sm.vec[4];
   double* vz = sm.vec[5];
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N;
@@ -405,230 +439,128 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
   int slot = 0;
   double* xw = sm.xw[p.wave];
+  const dpar dp(DSYM ? ns : 1, p);
 
   VSM_STAMP_DECL;
-  // ---- stage: composite vectors, [r-+] -> P, [T--] -> Q, strip of R+- -------------------------------------------
+  // ---- stage: composite vectors, [R+-] -> P, [T--] -> Q (all 32 column loads of a lane in flight together) ---------------
   if (tid < SNP) {
     const bool in = tid < N;
     vJp[tid] = in ? J0_p[tid] : 0.0;
     vJm[tid] = in ? J0_m[tid] : 0.0;
   }
-  sstrip X;
-  load_strip_global_c8(X, R_pm, N, p, xw);           // X = R+- strip
-  store_strip(P, r_s, p, keepN);
-  stage_aform_full(Q, T_mm, N, p);   // all 16 column loads in flight: one round trip instead of four
-  __syncthreads();
+  sstrip Z, V, G;                          // (Z doubles as the t-- strip of a surface layer until the first products)
+  if (!DSYM) load_strip_global_c8_issue(G, t_mm, N, p);
+  stage_aform_full2(P, R_pm, Q, T_mm, N, p);
+  if (!DSYM) load_strip_global_c8_finish(G, p, xw);
+  __syncthreads();                                                                                       // (a)
   VSM_STAMP(8);
-  if (own_wave) {  // J0+ rides in the spare column c1 of R+-_s:  E1[:, c1] = r-+ J0+
+  if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) X.v[ta][r] = laneA ? vJp[p.row(ta, r)] : X.v[ta][r];
+      for (int r = 0; r < 4; ++r) r_s.v[ta][r] = laneB ? vjm[p.row(ta, r)] : r_s.v[ta][r];
   }
-  // ---- E1 = r-+ R+- ; u = r-+ J0+ + j0- ; G1 = (I - E1)^-1 -------------------------------------------------
-  sstrip G;
+  if (DSYM) dsym_strip(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
   {
-    sstrip E;
-    E.zero();
-    mm_ab<KS>(E, P, X, p);
+    sstrip E, S;
+    {
+      const sstrip& tb = DSYM ? t_s : G;
+      E.zero();
+      Z.zero();
+      mm_ab2<KS>(E, Z, P, r_s, tb, p);
+      S.zero();
+      V.zero();
+      mm_ab2<KS>(S, V, Q, r_s, tb, p);
+    }
     if (own_wave) {
-      double* ud = laneA ? vu : sm.vec[7];
+      double* zd = laneB ? vz : sm.vec[7];   // (the other lanes write to a dummy vector)
+      double* sd = laneB ? vs : sm.vec[7];
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-          ud[row] = E.v[ta][r] + vjm[row];
+          zd[row] = vJp[row] + E.v[ta][r];
+          sd[row] = S.v[ta][r];
         }
     }
+    // r_s <- r+- (the accumulator of the R+- update; its rider column is never stored), t_s <- t++
+    if (DSYM) {
+      dsym_strip(r_s, r_s, dp);
+      dsym_strip(t_s, t_s, dp);
+    } else {
+      load_strip_global_c8(r_s, r_pm, N, p, xw);
+    }
     VSM_STAMP(9);
-#ifdef VSM_IA_OLD_INV
-    invert_strip<KS>(E, G, P, N, sm, slot, p, 0);
-#else
-    invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (masks the columns >= N of E; P = [r-+] is free after its first barrier)
-#endif
+    const double nrm = strip_norm_bound_clean(E, N, sm, slot, p);   // (b): every wave is done reading [R+-] and [T--]
+    store_strip(Q, S, p, keepN);                                    // [S] -> Q  (read after barrier (e))
+    invert_strip_horner_k<KS>(series_order(nrm), E, G, P, N, sm, p);   // [E2] -> P, barrier (c), series
   }
-  __syncthreads();                        // nobody reads P (series powers) any more
-  store_strip(P, G, p, keepN);            // [G1] -> P
-  __syncthreads();
   VSM_STAMP(10);
-  // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H ----------------------------------------------------------
-  sstrip H, A1;
-  H.zero();
-  mm_ab<KS>(H, P, r_s, p);
-  A1.zero();
-  mm_ab<KS>(A1, Q, G, p);
-  X.zero();
-  mm_ab<KS>(X, Q, H, p);                  // X = T01_inv r-+
-  __syncthreads();                        // [G1] (P) and [T--] (Q) no longer read
-  store_strip(P, X, p, keepN);            // [T01 r-+] -> P
-  store_strip(Q, A1, p, keepN);           // [T01] -> Q
-  // ---- R-+ += (T01 r-+) T++  (its global operands are requested before the barrier) --------------------------------
-  sstrip Tpp;                             // old T++ strip
-  load_strip_global_c8(Tpp, T_pp, N, p, xw);
-  double rpm_v[16];                       // columns of [R+-] for the second half
+  __syncthreads();                        // (d): [E2] (series) no longer read
+  store_strip(P, t_s, p, keepN);          // [t++] -> P
+  __syncthreads();                        // (e)
+  VSM_STAMP(11);
   {
-    // Both first-half results stay in their accumulators until the second half's global operand has been REQUESTED:
-    // loads and stores retire through one in-order counter, so a load issued after a store waits for the store.
-    sstrip accR, accT, tmm;
-    load_strip_global_c8(accR, R_mp, N, p, xw);
-    __syncthreads();
-    VSM_STAMP(11);
-    mm_ab<KS>(accR, P, Tpp, p);           // R-+ += (T01 r-+) T++
+    sstrip X, Y;
+    X.zero();
+    mm_ab<KS>(X, P, G, p);                // T21 = t++ G2
+    Y.zero();
+    mm_ab<KS>(Y, Q, G, p);                // Y = S G2 = T01 r-+
     VSM_STAMP(12);
-    // T-- = T01 t-- ;  J0- += T01 u  (u in the spare column c1 of t--)
-    if (ns) dsym_strip(tmm, t_s, ns, p); else load_strip_global_c8(tmm, t_mm, N, p, xw);
-    if (own_wave) {
+    __syncthreads();                      // (f): [t++], [S] no longer read
+    store_strip(P, X, p, keepN);          // [T21] -> P
+    store_strip(Q, Y, p, keepN);          // [Y]   -> Q
+  }
+  sstrip Tpp, Rmp;
+  load_strip_global_c8_issue(Tpp, T_pp, N, p);
+  load_strip_global_c8_issue(Rmp, R_mp, N, p);
+  __syncthreads();                        // (g)
+  VSM_STAMP(13);
+  load_strip_global_c8_finish(Tpp, p, xw);
+  if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
+    for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tmm.v[ta][r] = laneA ? vu[p.row(ta, r)] : tmm.v[ta][r];
-    }
-    accT.zero();
-    mm_ab<KS>(accT, Q, tmm, p);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int j = p.wave + 4 * i;
-      rpm_v[i] = (p.lane < N && j < N) ? R_pm[p.lane + (long long)N * j] : 0.0;
-    }
-    store_strip_global_c8(R_mp, accR, N, p, xw);
-    store_strip_global_c8(T_mm, accT, N, p, xw);
+      for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
+  }
+  {
+    sstrip acc;
+    acc.zero();
+    mm_ab2<KS>(r_s, acc, P, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
+    VSM_STAMP(14);
+    load_strip_global_c8_finish(Rmp, p, xw);
+    store_strip_global_c8(R_pm, r_s, N, p, xw);
+    store_strip_global_c8(T_pp, acc, N, p, xw);
     if (laneA) {
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-          if (row < N) J0_m[row] = vJm[row] + accT.v[ta][r];
+          if (row < N) J0_p[row] = vjp[row] + acc.v[ta][r];
         }
     }
   }
-  __syncthreads();                        // [T01 r-+] (P) and [T01] (Q) no longer read
-  VSM_STAMP(13);
-  // ---- G2 = (I - R+- r-+)^-1 = I + R+- H  (push-through identity, see vsm_fused.hip) ; z = J0+ + R+- j0- -----
-#pragma unroll
-  for (int i = 0; i < 16; ++i) P[lidx<SNP>(p.lane, p.wave + 4 * i)] = rpm_v[i];   // [R+-] -> P
-  store_strip(Q, t_s, p, keepN);          // [t++] -> Q
-  if (own_wave) {  // j0- rides in the spare column c2 of H
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) H.v[ta][r] = laneB ? vjm[p.row(ta, r)] : H.v[ta][r];
-  }
-  __syncthreads();
-  VSM_STAMP(14);
-#ifdef VSM_IA_NO_Z
-  G.zero();
-  mm_ab<KS>(G, P, H, p);
-  sstrip Rpm;
-  load_strip(Rpm, P, p);                  // R+- strip from its A-form (no second global read)
-#else
-  // R+- = r+- + (T21 R+-) t-- is evaluated as r+- + T21 (R+- t--):  Z = R+- t-- shares the fragments of [R+-] with G2 - I = R+- H,
-  // the last two products share those of [T21]; neither [T21 R+-] nor the R+- strip goes through LDS (one barrier, one A-form
-  // store and one strip read-back less); t-- = D t++ D is formed in place (t_s is not needed as t++ any more: [t++] is in Q)
-  sstrip Z;
-  if (ns) dsym_strip(t_s, t_s, ns, p); else load_strip_global_c8(t_s, t_mm, N, p, xw);
-  G.zero();
-  Z.zero();
-  mm_ab2<KS>(G, Z, P, H, t_s, p);
-#endif
-  if (own_wave) {
-    double* zd = laneB ? vz : sm.vec[7];
+  VSM_STAMP(15);
+  mm_ab2<KS>(Rmp, V, Q, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
+  VSM_STAMP(16);
+  store_strip_global_c8(R_mp, Rmp, N, p, xw);
+  store_strip_global_c8(T_mm, V, N, p, xw);
+  if (laneA) {
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = p.row(ta, r);
-        zd[row] = vJp[row] + G.v[ta][r];
+        if (row < N) J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
       }
   }
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const double g = keepN(G.v[ta][r], row, p.col);
-      G.v[ta][r] = (row == p.col && row < N) ? g + 1.0 : g;
-    }
-  // ---- T21 = t++ G2 -------------------------------------------------------------------------------------------
-  X.zero();
-  mm_ab<KS>(X, Q, G, p);                  // X = T21_inv
-  __syncthreads();                        // [R+-] (P), [t++] (Q) no longer read
-  store_strip(P, X, p, keepN);            // [T21] -> P
-  __syncthreads();
-  VSM_STAMP(15);
-#ifdef VSM_IA_NO_Z
-  // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; tmp = T21 R+- ----------------------------------
-  {
-    sstrip acc1, acc2;
-#ifndef VSM_IA_KEEP_TPP
-    load_strip_global_c8(Tpp, T_pp, N, p, xw);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
-#endif
-    if (own_wave) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
-    }
-    acc1.zero();
-    acc2.zero();
-    mm_ab2<KS>(acc1, acc2, P, Tpp, Rpm, p);   // (Rpm: strip of R+-, read back from its A-form before that was overwritten)
-    store_strip(Q, acc2, p, keepN);       // [T21 R+-] -> Q  ([t++] is dead since the barrier above)
-    sstrip tmm, acc;
-    if (ns) {
-      dsym_strip(tmm, t_s, ns, p);
-      dsym_strip(acc, r_s, ns, p);
-    } else {
-      load_strip_global_c8(tmm, t_mm, N, p, xw);
-      load_strip_global_c8(acc, r_pm, N, p, xw);
-    }
-    __syncthreads();                      // everybody has read the old T++ / R+- strips from global; tmp complete
-    VSM_STAMP(16);
-    mm_ab<KS>(acc, Q, tmm, p);
-    store_strip_global_c8(T_pp, acc1, N, p, xw);
-    if (laneA) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = p.row(ta, r);
-          if (row < N) J0_p[row] = vjp[row] + acc1.v[ta][r];
-        }
-    }
-    store_strip_global_c8(R_pm, acc, N, p, xw);
-  }
-#else
-  // ---- T++ = T21 T++ (+ J0+ = j0+ + T21 z in the spare column c1) ; R+- = r+- + T21 Z ------------------------------------
-  {
-    sstrip acc1;
-    load_strip_global_c8(Tpp, T_pp, N, p, xw);   // (re-read: keeping the strip live across G2 costs more in spills than the L2 hit)
-    if (own_wave) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
-    }
-    if (ns) dsym_strip(r_s, r_s, ns, p); else load_strip_global_c8(r_s, r_pm, N, p, xw);   // r_s <- r+-
-    acc1.zero();
-    mm_ab2<KS>(acc1, r_s, P, Tpp, Z, p);
-    VSM_STAMP(16);
-    store_strip_global_c8(T_pp, acc1, N, p, xw);
-    if (laneA) {
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = p.row(ta, r);
-          if (row < N) J0_p[row] = vjp[row] + acc1.v[ta][r];
-        }
-    }
-    store_strip_global_c8(R_pm, r_s, N, p, xw);
-  }
-#endif
   VSM_STAMP(17);
+  VSM_STAMP_FLUSH();
 }
 
-template <int KS>
+template <int KS, bool DSYM>
 __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c, added<double> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
@@ -643,8 +575,8 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
   load_strip_global_c8(r_s, a.r_mp + s * a.mat_stride, N, p, sm.xw[p.wave]);
   load_strip_global_c8(t_s, a.t_pp + s * a.mat_stride, N, p, sm.xw[p.wave]);
   __syncthreads();
-  ia_body<KS>(sm, p, N, a.d_symmetric, c, r_s, t_s, a.d_symmetric ? nullptr : a.r_pm + s * a.mat_stride,
-              a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride);
+  ia_body<KS, DSYM>(sm, p, N, a.d_symmetric, c, r_s, t_s, DSYM ? nullptr : a.r_pm + s * a.mat_stride,
+                    DSYM ? nullptr : a.t_mm + s * a.mat_stride);
 }
 
 // rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
@@ -657,6 +589,7 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
                                            const composite<double>& c) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
+  VSM_LIFE_DECL;
   spos p;
   sstrip r_s, t_s;
   ed_body<KS, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
@@ -668,9 +601,10 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
     store_strip_global_c8(c.R_mp + s * NN, r_s, N, p, xw);
     store_strip_global_c8(c.T_pp + s * NN, t_s, N, p, xw);
     sstrip d;
-    dsym_strip(d, r_s, ns, p);
+    const dpar dp(ns, p);
+    dsym_strip(d, r_s, dp);
     store_strip_global_c8(c.R_pm + s * NN, d, N, p, xw);
-    dsym_strip(d, t_s, ns, p);
+    dsym_strip(d, t_s, dp);
     store_strip_global_c8(c.T_mm + s * NN, d, N, p, xw);
     if (tid < N) {
       c.J0_p[(long long)s * N + tid] = sm.vec[0][tid];
@@ -678,7 +612,8 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
     }
     return;
   }
-  ia_body<KS>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
+  ia_body<KS, true>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
+  VSM_LIFE_FLUSH();
 }
 template <int KS, bool MIX, bool THERMAL = false>
 __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
@@ -789,9 +724,14 @@ int VSM_CAT(launch_ed_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m,
   return VSM_OK;
 }
 int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
-  static int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ia_strip)");
+  static int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_ia_strip)");
+  static int prepared_g = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_ia_strip general)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ia_strip<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(ssmem), st, N, c, a);
+  if (prepared_g) return prepared_g;
+  if (a.d_symmetric)   // (d_symmetric carries n_stokes)
+    hipLaunchKernelGGL((k_ia_strip<VSM_STRIP_KS, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, N, c, a);
+  else
+    hipLaunchKernelGGL((k_ia_strip<VSM_STRIP_KS, false>), dim3(S), dim3(SNT), sizeof(ssmem), st, N, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip");
   return VSM_OK;
 }

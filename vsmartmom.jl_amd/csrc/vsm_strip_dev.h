@@ -24,6 +24,7 @@ struct ssmem {
   double Q[SNP * SNP];
   double vec[8][SNP];
   float red[2][4];
+  int flags[4];
   gj_scratch<double, SNP> gj;
   double xw[4][16 * 10];   // wave-private transposer tiles of load/store_strip_global_c8
 };
@@ -80,6 +81,35 @@ __device__ __forceinline__ double dpp_swap1(double x) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
+}
+
+// exp(-xi) - exp(-xj)  (expdiff_neg, src/CoreRT/CoreKernel/rt_helpers.jl:32-40) from tabulated e = exp(-x), a = expm1(-x):
+//  * thin layers (every x < 1/2): a_i - a_j where the arguments are well separated (relative error 16 eps at most: the
+//    subtraction is exact, each a carries one rounding), otherwise e_j expm1(-(x_i - x_j)) with expm1 by its Taylor polynomial
+//    (|x_i - x_j| <= x_max / 8 < 1/16: degree 11, truncation < 2^-60 relative) -- no transcendental per matrix element;
+//  * otherwise the reference's form: exp(-min) (-expm1(-|x_i - x_j|)) with the sign of x_j - x_i; one expm1 per element.
+__device__ __forceinline__ double expm1_small(double y) {
+  double q = 1.0 / 39916800.0;
+  q = fma(q, y, 1.0 / 3628800.0);
+  q = fma(q, y, 1.0 / 362880.0);
+  q = fma(q, y, 1.0 / 40320.0);
+  q = fma(q, y, 1.0 / 5040.0);
+  q = fma(q, y, 1.0 / 720.0);
+  q = fma(q, y, 1.0 / 120.0);
+  q = fma(q, y, 1.0 / 24.0);
+  q = fma(q, y, 1.0 / 6.0);
+  q = fma(q, y, 0.5);
+  q = fma(q, y, 1.0);
+  return q * y;
+}
+__device__ __forceinline__ double expdiff_tab_thin(double xi, double xj, double ai, double aj, double ej) {
+  const double dlt = xi - xj;
+  return (fabs(dlt) > 0.125 * fmax(xi, xj)) ? (ai - aj) : ej * expm1_small(-dlt);
+}
+__device__ __forceinline__ double expdiff_tab_thick(double xi, double xj, double ei, double ej) {
+  const double dlt = xi - xj;
+  const double v = ((dlt < 0.0) ? ei : ej) * (-expm1(-fabs(dlt)));
+  return (dlt < 0.0) ? v : -v;   // (dlt == 0: v = 0)
 }
 
 // acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
@@ -317,10 +347,10 @@ __device__ __attribute__((noinline)) void invert_strip_slow(int K, sstrip& E, ss
 // (A = [E] for every product: no barrier between the K - 1 products, three live strips; for K <= 4 as many products as the
 // squaring scheme of invert_strip, whose every level costs an A-form store and two barriers more).  On return other waves may
 // still be reading W.
+// The series part for a given order K (all waves past the norm reduction's barrier, so nobody reads W any more).  From the
+// third term on, E is re-read from its A-form (16 LDS reads per term) instead of being kept: two live strips.
 template <int KS, typename SM>
-__device__ __forceinline__ void invert_strip_horner(sstrip& E, sstrip& G, double* W, int N, SM& sm, int& slot, spos& p) {
-  const double nrm = strip_norm_bound_clean(E, N, sm, slot, p);
-  const int K = series_order(nrm);
+__device__ __forceinline__ void invert_strip_horner_k(int K, sstrip& E, sstrip& G, double* W, int N, SM& sm, spos& p) {
   if (K < 1 || K > 8) {   // (copies: only these objects have their address taken, and only on this path)
     sstrip Es = E, Gs;
     spos ps = p;
@@ -335,16 +365,10 @@ __device__ __forceinline__ void invert_strip_horner(sstrip& E, sstrip& G, double
     store_strip(W, E, p, [](double a, int, int) { return a; });
     __syncthreads();
     mm_ab_c<KS>(G, E, W, E, p);              // X1 = E + E E
-    if (K >= 3) {
+    for (int j = 2; j < K; ++j) {            // X_j = E + E X_{j-1}
       sstrip X;
-      mm_ab_c<KS>(X, E, W, G, p);            // X2 = E + E X1
-      if (K >= 4) {
-        for (int j = 3; j < K; j += 2) {     // two Horner steps per pass (ping-pong between X and G: no copies)
-          mm_ab_c<KS>(G, E, W, X, p);
-          if (j + 1 < K) mm_ab_c<KS>(X, E, W, G, p);
-        }
-        if ((K & 1) == 0) X = G;             // even K: the last step landed in G
-      }
+      load_strip(X, W, p);
+      mm_ab<KS>(X, W, G, p);
       G = X;
     }
   }
@@ -359,6 +383,11 @@ __device__ __forceinline__ void invert_strip_horner(sstrip& E, sstrip& G, double
         for (int r = 0; r < 4; ++r) G.v[ta][r] += (dl && dr == r) ? 1.0 : 0.0;
       }
   }
+}
+template <int KS, typename SM>
+__device__ __forceinline__ void invert_strip_horner(sstrip& E, sstrip& G, double* W, int N, SM& sm, int& slot, spos& p) {
+  const double nrm = strip_norm_bound_clean(E, N, sm, slot, p);
+  invert_strip_horner_k<KS>(series_order(nrm), E, G, W, N, sm, p);
 }
 
 __device__ __forceinline__ void load_strip_global(sstrip& s, const double* __restrict__ g, int N, const spos& p) {
@@ -389,6 +418,27 @@ __device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, int ns, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) d.v[ta][r] = (is_uv_row(p.row(ta, r), ns) == uc) ? x.v[ta][r] : -x.v[ta][r];
 }
+// The same with the parities of the lane's 16 rows and of its column evaluated once (bit 4 ta + r of `rows`, `uc`): the `%`
+// by the run-time n_stokes costs ~20 instructions per row, and the layer kernels form D X D six times.
+struct dpar {
+  unsigned rows;
+  bool uc;
+  __device__ __forceinline__ dpar(int ns, const spos& p) {
+    rows = 0;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rows |= (is_uv_row(p.row(ta, r), ns) ? 1u : 0u) << (4 * ta + r);
+    uc = is_uv_row(p.col, ns);
+    if (uc) rows = ~rows;   // bit set = sign flip
+  }
+};
+__device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, const dpar& dp) {
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d.v[ta][r] = ((dp.rows >> (4 * ta + r)) & 1u) ? -x.v[ta][r] : x.v[ta][r];
+}
 // global column-major N x N -> A-form in LDS (zero padded); one column per wave and pass, coalesced reads
 __device__ __forceinline__ void stage_aform(double* L, const double* __restrict__ g, int N, const spos& p) {
 #pragma unroll 4
@@ -407,8 +457,9 @@ constexpr int XS8 = 10;
 struct d2_t {
   double a, b;
 } __attribute__((aligned(8)));
-__device__ __forceinline__ void load_strip_global_c8(sstrip& x, const double* __restrict__ g, int N, const spos& p,
-                                                     double* __restrict__ xw) {
+// (two halves: the request leaves 16 contiguous bytes of a column per register pair; the permutation can wait until the
+// strip is needed, so that the round trip hides behind whatever lies between)
+__device__ __forceinline__ void load_strip_global_c8_issue(sstrip& x, const double* __restrict__ g, int N, const spos& p) {
   const int c = p.lane >> 2, q = p.lane & 3;
   const int col = 16 * p.wave + c;
   const double* src = g + (long long)N * min(col, N - 1);
@@ -426,6 +477,9 @@ __device__ __forceinline__ void load_strip_global_c8(sstrip& x, const double* __
     x.v[j >> 1][2 * (j & 1)] = a;
     x.v[j >> 1][2 * (j & 1) + 1] = b;
   }
+}
+__device__ __forceinline__ void load_strip_global_c8_finish(sstrip& x, const spos& p, double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     __builtin_amdgcn_wave_barrier();
@@ -435,6 +489,11 @@ __device__ __forceinline__ void load_strip_global_c8(sstrip& x, const double* __
     x.v[j >> 1][2 * (j & 1)] = xw[p.l15 * XS8 + p.kq];
     x.v[j >> 1][2 * (j & 1) + 1] = xw[p.l15 * XS8 + p.kq + 4];
   }
+}
+__device__ __forceinline__ void load_strip_global_c8(sstrip& x, const double* __restrict__ g, int N, const spos& p,
+                                                     double* __restrict__ xw) {
+  load_strip_global_c8_issue(x, g, N, p);
+  load_strip_global_c8_finish(x, p, xw);
 }
 __device__ __forceinline__ void store_strip_global_c8(double* __restrict__ g, const sstrip& x, int N, const spos& p,
                                                       double* __restrict__ xw) {
