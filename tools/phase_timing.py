@@ -31,7 +31,7 @@ def main():
     tau_rayl, tau_abs = bench.o2a_atmosphere(S, 40)
     tau_rayl, tau_abs = tau_rayl[:, :L], tau_abs[:, :L]
     model = vsm.host_model.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs,
-                                             depol=0.0279, albedo=0.15, m_max=0)
+                                             depol=0.0279, albedo=0.15, m_max=int(os.environ.get("VSM_PT_MMAX", "2")))
     scene = vsm.CoreRT.prepare_scene(model)
     scene.run()
     torch.cuda.synchronize()
@@ -58,7 +58,9 @@ def main():
         per = x / nwg / (nd if i else 1)
         print("  %-52s %10.1f per %s" % (n, per, "step" if i else "launch"))
     print("  doubling loop per step: %.0f" % (v[1:].sum() / nwg / nd))
-    print("  elemental (entry of the body -> source vectors in LDS): %.0f per launch" % (allb[7] / nwg))
+    el = [allb[20] / nwg, allb[21] / nwg, allb[22] / nwg, allb[23] / nwg, allb[7] / nwg]
+    print("  elemental: tables %.0f, barrier %.0f, elements + sources -> A-forms %.0f, barrier %.0f, strips back %.0f  (sum %.0f per launch)"
+          % (el[0], el[1], el[2], el[3], el[4], sum(el)))
     if allb[31]:
         print("  core clock during elemental + doubling (s_memtime ticks per s_memrealtime tick at 100 MHz): %.0f MHz"
               % (allb[30] / (allb[31] / 100.0)))
@@ -71,7 +73,7 @@ def main():
     for n, x in zip(inames, w):
         print("  %-56s %10.1f" % (n, x / ni))
     print("  sum: %.0f" % (w.sum() / ni))
-    tot = v.sum() / nwg + w.sum() / ni + allb[7] / nwg
+    tot = v.sum() / nwg + w.sum() / ni + sum(el)
     if allb[26]:
         print("  workgroup lifetime (kernel entry -> last store issued): %.0f cycles, mean over %d non-TOA workgroups" % (allb[27] / allb[26], allb[26]))
     print("  layer total per workgroup: %.0f cycles (MFMA issue of %d doubling steps x 6 products + 11: %d)" % (tot, nd, (6 * nd + 11) * 3840))

@@ -54,7 +54,7 @@ __device__ unsigned long long vsm_phase_cycles_strip[32];
     }                                                                                                       \
   } while (0)
 #define VSM_RSTAMP_DECL                                  \
-  unsigned long long _rs[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  unsigned long long _rs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
   const unsigned long long _rt0 = __builtin_readcyclecounter(), _rr0 = __builtin_amdgcn_s_memrealtime(); \
   unsigned long long _rt = _rt0
 #define VSM_RSTAMP(i)                                                \
@@ -67,6 +67,7 @@ __device__ unsigned long long vsm_phase_cycles_strip[32];
   do {                                                                                                   \
     if (threadIdx.x == 0) {                                                                              \
       for (int _i = 0; _i < 8; ++_i) atomicAdd(&vsm_phase_cycles_strip[_i], _rs[_i]);                    \
+      for (int _i = 8; _i < 12; ++_i) atomicAdd(&vsm_phase_cycles_strip[12 + _i], _rs[_i]);              \
       atomicAdd(&vsm_phase_cycles_strip[28], 1ull);                                                      \
       atomicAdd(&vsm_phase_cycles_strip[30], (unsigned long long)(__builtin_readcyclecounter() - _rt0)); \
       atomicAdd(&vsm_phase_cycles_strip[31], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - _rr0)); \
@@ -97,11 +98,12 @@ namespace {
 // THERMAL: the `:thermal` per-source slot of the layer (rt_kernel.jl:205-232; contribute!(::PreparedThermalEmission),
 // Sources/thermal_emission.jl:241-301) instead of the solar beam: j0+- = 2 pi (1 - varpi) B (1 - e^{-dtau/mu_i}) on the I rows,
 // the slot's expk = 1 (doubling.jl:62-81); `F0` then points at B[S] and tau_sum is not read.
-template <int KS, bool MIX, bool THERMAL = false>   // KS k-steps per product: 4 KS >= N (columns >= N of the A-forms are zero); MIX: Z = sum_k f_k Z_k
+// PRE: the elemental layer comes from the pre-pass (k_elemental_img) as two A-form images + vectors at `img`.
+template <int KS, bool MIX, bool THERMAL = false, bool PRE = false>   // KS k-steps per product: 4 KS >= N (columns >= N of the A-forms are zero); MIX: Z = sum_k f_k Z_k
 __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& q, int m, int ndoubl,
                                         const double* __restrict__ dtau, const double* __restrict__ varpi,
                                         const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                        const zsrc<double>& z, sstrip& r_s, sstrip& t_s) {
+                                        const zsrc<double>& z, sstrip& r_s, sstrip& t_s, const double* __restrict__ img = nullptr) {
   VSM_RSTAMP_DECL;
   double* P = sm.P;
   double* Q = sm.Q;
@@ -121,125 +123,144 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const bool own_wave = (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
   const double mAB = laneAB ? 1.0 : 0.0;
-  const double d = dtau[s], w = varpi[s];
-  // Z of this point: one block (z.ncomp == 0), or the mix  sum_k f_k(s) Z_k  of up to 4 scattering components
-  // (types.jl:1262-1292 `+` of CoreScatteringOpticalProperties, evaluated where Z is consumed)
-  const int ncomp = MIX ? z.ncomp : 0;   // (a compile-time switch: the run-time one cost 4.5 % on the plain path)
-  const long long NNz = (long long)q.N * q.N;
-  const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
-  const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
-  double fk[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
-  auto zget = [&](const double* Z, long long zo) {
-    if (ncomp == 0) return Z[zo];
-    double acc = 0.0;
-#pragma unroll
+  double expk0;
+  if constexpr (PRE) {
+    // the elemental layer of the pre-pass: images -> P, Q (LDS DMA), vectors, sign tables
+    copy_image_to_lds(P, img, p);
+    copy_image_to_lds(Q, img + PRE_IMG, p);
+    if (tid < SNP) {
+      jp[tid] = img[2 * PRE_IMG + tid];
+      jm[tid] = img[2 * PRE_IMG + SNP + tid];
+      const bool uv = is_uv_row(tid, ns);
+      sm.usg[tid] = uv ? -1.0 : 1.0;
+      rsg[tid] = (ndoubl >= 1 && uv) ? -1.0 : 1.0;
+    }
+    expk0 = img[2 * PRE_IMG + 2 * SNP];
+    VSM_RSTAMP(8);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA writes have landed in LDS
+    VSM_RSTAMP(9);
+  } else {
+    const double d = dtau[s], w = varpi[s];
+    // Z of this point: one block (z.ncomp == 0), or the mix  sum_k f_k(s) Z_k  of up to 4 scattering components
+    // (types.jl:1262-1292 `+` of CoreScatteringOpticalProperties, evaluated where Z is consumed)
+    const int ncomp = MIX ? z.ncomp : 0;   // (a compile-time switch: the run-time one cost 4.5 % on the plain path)
+    const long long NNz = (long long)q.N * q.N;
+    const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+    const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+    double fk[4] = {0.0, 0.0, 0.0, 0.0};
+  #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
-    return acc;
-  };
+      if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+    auto zget = [&](const double* Z, long long zo) {
+      if (ncomp == 0) return Z[zo];
+      double acc = 0.0;
+  #pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+      return acc;
+    };
 
-  // per-row tables; `thick` = some dtau / mu_i >= 1/2 (then the differences of exponentials go through expm1 per element)
-  if (tid < SNP) {
-    const bool in = tid < N;
-    const double mu = in ? q.mu[tid] : 1.0;
-    mus[tid] = mu;
-    const double x = d / mu;
-    xs[tid] = x;
-    es[tid] = exp(-x);
-    ems[tid] = expm1(-x);
-    rsg[tid] = (ndoubl >= 1 && is_uv_row(tid, ns)) ? -1.0 : 1.0;   // starred R* = D R (elemental.jl:403-422)
-    const unsigned long long any_thick = __ballot(in && x >= 0.5);   // (tid < 64: exactly wave 0)
-    if (tid == 0) sm.flags[0] = any_thick != 0ull;
-  }
-  __syncthreads();
-  const bool thick = __builtin_amdgcn_readfirstlane(sm.flags[0]) != 0;
-
-  // ---- elemental (elemental.jl:289-334) and its SFI source (elemental.jl:348-392) -------------------------------------------
-  //   r-+_ij = varpi Z-+_ij  mu_j / (mu_i + mu_j) w_j (1 - e^{-x_i} e^{-x_j}),   1 - e^{-x_i} e^{-x_j} = -(a_i + a_j + a_i a_j), a = expm1(-x)
-  //   t++_ij = varpi Z++_ij  mu_j / (mu_i - mu_j) w_j (e^{-x_i} - e^{-x_j})      (mu_i != mu_j)
-  //          = delta_ij e^{-x_i} + e^{-x_j} varpi Z++_ij x_i w_j                 (mu_i == mu_j)
-  // A lane computes the 16 elements of its column of the strip; the results go straight into the A-forms [r] -> P, [t] -> Q (the
-  // first doubling step needs them there) and the strips are read back, so that the loop over the row tiles stays ROLLED: a
-  // quarter of the code (the unrolled form was 45 KB of straight-line code executed once per workgroup behind a cold
-  // instruction cache: 1.1 10^5 cycles per workgroup, a sixth of its lifetime) and a few live registers.
-  // The source vectors have the same form with the solar column in place of column j (mu_j -> mu_0, x_j -> dtau / mu_0,
-  // w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q):  j0+ is the "t" formula, j0- the "r" formula, times the beam
-  // attenuation exp(-tau_sum / mu_0).  The lanes that own the spare columns c1, c2 (never read as a contraction index) evaluate
-  // them in place of their (zero) matrix elements and leave them where the doubling loop wants them (see below):
-  //   t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk     (ndoubl > 0)
-  const double expk0 = THERMAL ? 1.0 : exp(-d / q.mu0);
-  {
-    const int j = p.col;
-    const int jc = min(j, N - 1);
-    const int i0 = ns * q.i_mu0;
-    const int jt = laneAB ? i0 : jc;               // table / Z column
-    double fz[4] = {1.0, 0.0, 0.0, 0.0};
-    double att = 1.0;
-    if (laneAB && !THERMAL) {
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) fz[qq] = (qq < ns) ? F0[qq + (long long)ns * s] : 0.0;
-      att = exp(-tau_sum[s] / mus[i0]);
+    // per-row tables; `thick` = some dtau / mu_i >= 1/2 (then the differences of exponentials go through expm1 per element)
+    if (tid < SNP) {
+      const bool in = tid < N;
+      const double mu = in ? q.mu[tid] : 1.0;
+      mus[tid] = mu;
+      const double x = d / mu;
+      xs[tid] = x;
+      es[tid] = exp(-x);
+      ems[tid] = expm1(-x);
+      const bool uv = is_uv_row(tid, ns);
+      sm.usg[tid] = uv ? -1.0 : 1.0;
+      rsg[tid] = (ndoubl >= 1 && uv) ? -1.0 : 1.0;   // starred R* = D R (elemental.jl:403-422)
+      const unsigned long long any_thick = __ballot(in && x >= 0.5);   // (tid < 64: exactly wave 0)
+      if (tid == 0) sm.flags[0] = any_thick != 0ull;
     }
-    const int nz = (own_wave && !THERMAL) ? ns : 1;   // (wave-uniform)
-    const double wt = (j < N) ? q.wt[jc] : 0.0;
-    const double wct = laneAB ? ((m == 0) ? 0.5 : 0.25) : ((m == 0) ? wt / 2.0 : wt / 4.0);
-    const bool active = laneAB || wct > num<double>::eps();
-    const double mj = mus[jt], xj = xs[jt], emj = ems[jt], ej = es[jt];
-    const double thB = THERMAL ? 6.283185307179586476925286766559 * (1.0 - w) * F0[s] : 0.0;
-    const bool riders_in = ndoubl > 0;
-#pragma unroll 1
-    for (int ta = 0; ta < 4; ++ta) {
-      double zp[4] = {0.0, 0.0, 0.0, 0.0}, zm[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int qq = 0; qq < nz; ++qq) {
-        const double f = (qq == 0) ? fz[0] : ((qq == 1) ? fz[1] : ((qq == 2) ? fz[2] : fz[3]));
-        const int jz = laneAB ? jt + qq : jt;
-#pragma unroll
+    VSM_RSTAMP(8);
+    __syncthreads();
+    VSM_RSTAMP(9);
+    const bool thick = __builtin_amdgcn_readfirstlane(sm.flags[0]) != 0;
+
+    // ---- elemental (elemental.jl:289-334) and its SFI source (elemental.jl:348-392) -------------------------------------------
+    //   r-+_ij = varpi Z-+_ij  mu_j / (mu_i + mu_j) w_j (1 - e^{-x_i} e^{-x_j}),   1 - e^{-x_i} e^{-x_j} = -(a_i + a_j + a_i a_j), a = expm1(-x)
+    //   t++_ij = varpi Z++_ij  mu_j / (mu_i - mu_j) w_j (e^{-x_i} - e^{-x_j})      (mu_i != mu_j)
+    //          = delta_ij e^{-x_i} + e^{-x_j} varpi Z++_ij x_i w_j                 (mu_i == mu_j)
+    // A lane computes the 16 elements of its column of the strip; the results go straight into the A-forms [r] -> P, [t] -> Q (the
+    // first doubling step needs them there) and the strips are read back, so that the loop over the row tiles stays ROLLED: a
+    // quarter of the code (the unrolled form was 45 KB of straight-line code executed once per workgroup behind a cold
+    // instruction cache: 1.1 10^5 cycles per workgroup, a sixth of its lifetime) and a few live registers.
+    // The source vectors have the same form with the solar column in place of column j (mu_j -> mu_0, x_j -> dtau / mu_0,
+    // w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q):  j0+ is the "t" formula, j0- the "r" formula, times the beam
+    // attenuation exp(-tau_sum / mu_0).  The lanes that own the spare columns c1, c2 (never read as a contraction index) evaluate
+    // them in place of their (zero) matrix elements and leave them where the doubling loop wants them (see below):
+    //   t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk     (ndoubl > 0)
+    expk0 = THERMAL ? 1.0 : exp(-d / q.mu0);
+    {
+      const int j = p.col;
+      const int jc = min(j, N - 1);
+      const int i0 = ns * q.i_mu0;
+      const int jt = laneAB ? i0 : jc;               // table / Z column
+      double fz[4] = {1.0, 0.0, 0.0, 0.0};
+      double att = 1.0;
+      if (laneAB && !THERMAL) {
+  #pragma unroll
+        for (int qq = 0; qq < 4; ++qq) fz[qq] = (qq < ns) ? F0[qq + (long long)ns * s] : 0.0;
+        att = exp(-tau_sum[s] / mus[i0]);
+      }
+      const int nz = (own_wave && !THERMAL) ? ns : 1;   // (wave-uniform)
+      const double wt = (j < N) ? q.wt[jc] : 0.0;
+      const double wct = laneAB ? ((m == 0) ? 0.5 : 0.25) : ((m == 0) ? wt / 2.0 : wt / 4.0);
+      const bool active = laneAB || wct > num<double>::eps();
+      const double mj = mus[jt], xj = xs[jt], emj = ems[jt], ej = es[jt];
+      const double thB = THERMAL ? 6.283185307179586476925286766559 * (1.0 - w) * F0[s] : 0.0;
+      const bool riders_in = ndoubl > 0;
+  #pragma unroll 1
+      for (int ta = 0; ta < 4; ++ta) {
+        double zp[4] = {0.0, 0.0, 0.0, 0.0}, zm[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int qq = 0; qq < nz; ++qq) {
+          const double f = (qq == 0) ? fz[0] : ((qq == 1) ? fz[1] : ((qq == 2) ? fz[2] : fz[3]));
+          const int jz = laneAB ? jt + qq : jt;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jz;
+            zp[r] += zget(Zp, zo) * f;
+            zm[r] += zget(Zm, zo) * f;
+          }
+        }
+  #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jz;
-          zp[r] += zget(Zp, zo) * f;
-          zm[r] += zget(Zm, zo) * f;
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = p.row(ta, r);
-        const double mi = mus[i], xi = xs[i], emi = ems[i], ei = es[i], sg = rsg[i];
-        const double rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
-        double ediff;
-        if (thick) ediff = expdiff_tab_thick(xi, xj, ei, ej); else ediff = expdiff_tab_thin(xi, xj, emi, emj, ej);
-        const double t_off = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
-        const double t_1 = w * zp[r] * xi * wct;
-        const double t_same = (i == j) ? ei * (1.0 + t_1) : ej * t_1;
-        const double tt = (mi == mj) ? t_same : t_off;
-        const bool in = i < N && j < N;
-        double rv = (in && active) ? rr * sg : 0.0;
-        double tv = in ? (active ? tt : ((i == j) ? ei : 0.0)) : 0.0;
-        if (own_wave) {
-          double vp, vm;
-          if (THERMAL) {
-            vp = vm = (i < N && i % ns == 0 && mi > num<double>::eps()) ? thB * (-emi) : 0.0;
-          } else {
-            vp = (i < N) ? tt * att : 0.0;
-            vm = (i < N) ? rr * att * sg : 0.0;
+          const int i = p.row(ta, r);
+          const double mi = mus[i], xi = xs[i], emi = ems[i], ei = es[i], sg = rsg[i];
+          double rr, tt;
+          elemental_pair(w, zp[r], zm[r], mi, xi, emi, ei, mj, xj, emj, ej, wct, i == j, thick, rr, tt);
+          const bool in = i < N && j < N;
+          double rv = (in && active) ? rr * sg : 0.0;
+          double tv = in ? (active ? tt : ((i == j) ? ei : 0.0)) : 0.0;
+          if (own_wave) {
+            double vp, vm;
+            if (THERMAL) {
+              vp = vm = (i < N && i % ns == 0 && mi > num<double>::eps()) ? thB * (-emi) : 0.0;
+            } else {
+              vp = (i < N) ? tt * att : 0.0;
+              vm = (i < N) ? rr * att * sg : 0.0;
+            }
+            if (laneAB) {
+              tv = riders_in ? (laneA ? vp : vm * expk0) : 0.0;
+              rv = riders_in ? (laneA ? vm : vp * expk0) : 0.0;
+            }
+            double* dp = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
+            double* dm = laneA ? jm : sm.vec[7];
+            dp[i] = vp;
+            dm[i] = vm;
           }
-          if (laneAB) {
-            tv = riders_in ? (laneA ? vp : vm * expk0) : 0.0;
-            rv = riders_in ? (laneA ? vm : vp * expk0) : 0.0;
-          }
-          double* dp = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
-          double* dm = laneA ? jm : sm.vec[7];
-          dp[i] = vp;
-          dm[i] = vm;
+          P[p.sidx(ta, r)] = rv;
+          Q[p.sidx(ta, r)] = tv;
         }
-        P[p.sidx(ta, r)] = rv;
-        Q[p.sidx(ta, r)] = tv;
       }
     }
+    VSM_RSTAMP(10);
   }
   __syncthreads();
+  VSM_RSTAMP(11);
   load_strip(r_s, P, p);
   load_strip(t_s, Q, p);
   VSM_RSTAMP(7);   // elemental
@@ -439,7 +460,7 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
   int slot = 0;
   double* xw = sm.xw[p.wave];
-  const dpar dp(DSYM ? ns : 1, p);
+  const dpar dp(sm.usg, p);   // (filled by the caller; all +1 for a surface layer)
 
   VSM_STAMP_DECL;
   // ---- stage: composite vectors, [R+-] -> P, [T--] -> Q (all 32 column loads of a lane in flight together) ---------------
@@ -570,6 +591,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
     const bool in = tid < N;
     sm.vec[0][tid] = in ? a.j0_p[(long long)s * N + tid] : 0.0;
     sm.vec[1][tid] = in ? a.j0_m[(long long)s * N + tid] : 0.0;
+    sm.usg[tid] = (DSYM && is_uv_row(tid, a.d_symmetric)) ? -1.0 : 1.0;
   }
   sstrip r_s, t_s;
   load_strip_global_c8(r_s, a.r_mp + s * a.mat_stride, N, p, sm.xw[p.wave]);
@@ -582,17 +604,17 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
 // rt_kernel!(::noRS) for a scattering layer (rt_kernel.jl:175-250) in ONE launch: elemental! + doubling! and then
 // either the TOA copy (iz == 1: copy_added_to_composite!, rt_helpers.jl:188-200) or interaction!(::_11).  The added
 // layer never leaves the chip.
-template <int KS, bool MIX, bool THERMAL>
+template <int KS, bool MIX, bool THERMAL, bool PRE = false>
 __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndoubl, const double* __restrict__ dtau,
                                            const double* __restrict__ varpi, const double* __restrict__ tau_sum,
                                            const double* __restrict__ F0, const zsrc<double>& z, int toa,
-                                           const composite<double>& c) {
+                                           const composite<double>& c, const double* __restrict__ img = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   VSM_LIFE_DECL;
   spos p;
   sstrip r_s, t_s;
-  ed_body<KS, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
+  ed_body<KS, MIX, THERMAL, PRE>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, img);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = blockIdx.x, tid = threadIdx.x;
@@ -601,7 +623,7 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
     store_strip_global_c8(c.R_mp + s * NN, r_s, N, p, xw);
     store_strip_global_c8(c.T_pp + s * NN, t_s, N, p, xw);
     sstrip d;
-    const dpar dp(ns, p);
+    const dpar dp(sm.usg, p);
     dsym_strip(d, r_s, dp);
     store_strip_global_c8(c.R_pm + s * NN, d, N, p, xw);
     dsym_strip(d, t_s, dp);
@@ -622,14 +644,20 @@ __global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, i
                                                         zsrc<double> z, int toa, composite<double> c) {
   layer_body<KS, MIX, THERMAL>(q, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
 }
-// the same for several Fourier moments at once: blockIdx.y picks the moment's m, Z source and composite
-template <int KS, bool MIX>
-__global__ __launch_bounds__(SNT, 2) void k_layer_strip_mm(quad<double> q, int ndoubl, const double* __restrict__ dtau,
-                                                           const double* __restrict__ varpi,
-                                                           const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                                           layer_mm_args<double> a, int toa) {
+// The same for several Fourier moments at once: blockIdx.y picks the moment's composite.  The elemental layers come from the
+// pre-pass k_elemental_img (below) as A-form images: inside this kernel their ~2 10^3 VALU / LDS instructions per wave would
+// each queue behind an FP64 MFMA of the workgroup that shares the SIMDs (on gfx950 the FP64 matrix rate equals the FP64
+// vector rate: an MFMA occupies the lanes for its 64 cycles) -- measured 1.3 10^5 cycles per workgroup, a fifth of its
+// lifetime, against ~2 10^4 for the image copy.  The pre-pass runs at full occupancy with nothing to wait for.
+struct layer_mm_comps {
+  composite<double> c[VSM_MM_MAX];
+};
+template <int KS>
+__global__ __launch_bounds__(SNT, 2) void k_layer_strip_mm(quad<double> q, int ndoubl, layer_mm_comps a, int toa,
+                                                           const double* __restrict__ pre) {
   const int im = blockIdx.y;
-  layer_body<KS, MIX, false>(q, a.m[im], ndoubl, dtau, varpi, tau_sum, F0, a.z[im], toa, a.c[im]);
+  const double* img = pre + ((long long)im * gridDim.x + blockIdx.x) * PRE_STRIDE;
+  layer_body<KS, false, false, true>(q, 0, ndoubl, nullptr, nullptr, nullptr, nullptr, zsrc<double>{}, toa, a.c[im], img);
 }
 
 
@@ -702,8 +730,8 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
   int VSM_CAT(launch_layer_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,    \
                                        const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t,      \
                                        int);                                                                                \
-  int VSM_CAT(launch_layer_strip_mm_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*, \
-                                          const double*, const layer_mm_args<double>&, int, hipStream_t);
+  int VSM_CAT(launch_layer_strip_mm_, KS)(const quad<double>&, int, int, int, const layer_mm_args<double>&, int,           \
+                                          const double*, hipStream_t);
 
 #ifdef VSM_STRIP_KS
 VSM_STRIP_DECL(VSM_STRIP_KS)
@@ -767,19 +795,13 @@ int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int
   return VSM_OK;
 }
 
-int VSM_CAT(launch_layer_strip_mm_, VSM_STRIP_KS)(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau,
-                                                  const double* varpi, const double* tau_sum, const double* F0,
-                                                  const layer_mm_args<double>& a, int toa, hipStream_t st) {
-  static int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_layer_strip_mm)");
-  static int prepared_mix = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_layer_strip_mm mix)");
+int VSM_CAT(launch_layer_strip_mm_, VSM_STRIP_KS)(const quad<double>& q, int S, int nm, int ndoubl,
+                                                  const layer_mm_args<double>& a, int toa, const double* pre, hipStream_t st) {
+  static int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS>, "hipFuncSetAttribute(k_layer_strip_mm)");
   if (prepared) return prepared;
-  if (prepared_mix) return prepared_mix;
-  if (a.z[0].ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip_mm<VSM_STRIP_KS, true>), dim3(S, nm), dim3(SNT), sizeof(ssmem), st, q, ndoubl, dtau, varpi,
-                       tau_sum, F0, a, toa);
-  else
-    hipLaunchKernelGGL((k_layer_strip_mm<VSM_STRIP_KS, false>), dim3(S, nm), dim3(SNT), sizeof(ssmem), st, q, ndoubl, dtau, varpi,
-                       tau_sum, F0, a, toa);
+  layer_mm_comps cc;
+  for (int i = 0; i < VSM_MM_MAX; ++i) cc.c[i] = a.c[i];
+  hipLaunchKernelGGL((k_layer_strip_mm<VSM_STRIP_KS>), dim3(S, nm), dim3(SNT), sizeof(ssmem), st, q, ndoubl, cc, toa, pre);
   VSM_LAUNCH_CHECK("k_layer_strip_mm");
   return VSM_OK;
 }
@@ -848,10 +870,121 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
   return VSM_ERR_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------
+// Elemental pre-pass of the multi-moment layer kernel: elemental! (elemental.jl:289-392) for every (point, moment) of a layer
+// into A-form images (layout: vsm_strip_dev.h, PRE_STRIDE).  One workgroup per (point, moment); lane = row, a wave walks the
+// columns j = wave, wave + 4, ... (uniform per wave), so the image is written in full 512-byte columns.
+// ---------------------------------------------------------------------------
+template <bool MIX>
+__global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoubl, const double* __restrict__ dtau,
+                                                       const double* __restrict__ varpi, const double* __restrict__ tau_sum,
+                                                       const double* __restrict__ F0, layer_mm_args<double> a,
+                                                       double* __restrict__ pre) {
+  __shared__ double mus[SNP], xs[SNP], es[SNP], ems[SNP];
+  __shared__ int thick_flag;
+  const int s = blockIdx.x, im = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N = q.N, ns = q.n_stokes, m = a.m[im];
+  const zsrc<double> z = a.z[im];
+  const double d = dtau[s], w = varpi[s];
+  const int ncomp = MIX ? z.ncomp : 0;
+  const long long NNz = (long long)N * N;
+  const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+  const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+  double fk[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+  auto zget = [&](const double* Z, long long zo) {
+    if (ncomp == 0) return Z[zo];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+    return acc;
+  };
+  if (tid < SNP) {
+    const bool in = tid < N;
+    const double mu = in ? q.mu[tid] : 1.0;
+    const double x = d / mu;
+    mus[tid] = mu;
+    xs[tid] = x;
+    es[tid] = exp(-x);
+    ems[tid] = expm1(-x);
+    const unsigned long long any_thick = __ballot(in && x >= 0.5);
+    if (tid == 0) thick_flag = any_thick != 0ull;
+  }
+  __syncthreads();
+  const bool thick = thick_flag != 0;
+  const int i = lane, ic = min(i, N - 1);
+  const double mi = mus[i], xi = xs[i], ai = ems[i], ei = es[i];
+  const double sg = (ndoubl >= 1 && is_uv_row(i, ns)) ? -1.0 : 1.0;   // starred R* = D R (elemental.jl:403-422)
+  double* out = pre + ((long long)im * gridDim.x + s) * PRE_STRIDE;
+  double* R = out;
+  double* T = out + PRE_IMG;
+  const int Kend = ((N + 3) >> 2) << 2;
+  const int c1 = Kend, c2 = Kend + 1;   // the spare columns that carry the source vectors through the doubling loop
+  const bool riders_in = ndoubl > 0;
+#pragma unroll 1
+  for (int j = wave; j < SNP; j += 4) {
+    if (riders_in && (j == c1 || j == c2)) continue;   // written below
+    double rv = 0.0, tv = 0.0;
+    if (j < N) {                                        // (wave-uniform)
+      const double wt = q.wt[j];
+      const double wct = (m == 0) ? wt / 2.0 : wt / 4.0;
+      const long long zo = ic + (long long)N * j;
+      double rr, tt;
+      elemental_pair(w, zget(Zp, zo), zget(Zm, zo), mi, xi, ai, ei, mus[j], xs[j], ems[j], es[j], wct, i == j, thick, rr, tt);
+      const bool active = wct > num<double>::eps();
+      if (i < N) {
+        rv = active ? rr * sg : 0.0;
+        tv = active ? tt : ((i == j) ? ei : 0.0);
+      }
+    }
+    R[lidx<SNP>(i, j)] = rv;
+    T[lidx<SNP>(i, j)] = tv;
+  }
+  if (wave == 0) {   // SFI source of the solar beam: the same formulas with the solar column (see elemental_pair)
+    const int i0 = ns * q.i_mu0;
+    double zp = 0.0, zm = 0.0;
+    for (int qq = 0; qq < ns; ++qq) {
+      const long long zo = ic + (long long)N * (i0 + qq);
+      const double f = F0[qq + (long long)ns * s];
+      zp += zget(Zp, zo) * f;
+      zm += zget(Zm, zo) * f;
+    }
+    double rr, tt;
+    elemental_pair(w, zp, zm, mi, xi, ai, ei, mus[i0], xs[i0], ems[i0], es[i0], (m == 0) ? 0.5 : 0.25, false, thick, rr, tt);
+    const double att = exp(-tau_sum[s] / mus[i0]);
+    const double vp = (i < N) ? tt * att : 0.0;
+    const double vm = (i < N) ? rr * att * sg : 0.0;
+    const double expk0 = exp(-d / q.mu0);
+    out[2 * PRE_IMG + i] = vp;
+    out[2 * PRE_IMG + SNP + i] = vm;
+    out[2 * PRE_IMG + 2 * SNP + i] = expk0;
+    if (riders_in) {   // t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk
+      T[lidx<SNP>(i, c1)] = vp;
+      T[lidx<SNP>(i, c2)] = vm * expk0;
+      R[lidx<SNP>(i, c1)] = vm;
+      R[lidx<SNP>(i, c2)] = vp * expk0;
+    }
+  }
+}
+
 int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
                            const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa, hipStream_t st) {
   if (S <= 0 || nm <= 0) return VSM_OK;
-#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_mm_, KS)(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st)
+  if (!strip_supported(q.N)) {
+    set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
+    return VSM_ERR_UNSUPPORTED;
+  }
+  double* pre = static_cast<double*>(scratch((size_t)nm * S * PRE_STRIDE * sizeof(double), 3));
+  if (!pre) return VSM_ERR_HIP;
+  if (a.z[0].ncomp > 0)
+    hipLaunchKernelGGL((k_elemental_img<true>), dim3(S, nm), dim3(SNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  else
+    hipLaunchKernelGGL((k_elemental_img<false>), dim3(S, nm), dim3(SNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  VSM_LAUNCH_CHECK("k_elemental_img");
+#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_mm_, KS)(q, S, nm, ndoubl, a, toa, pre, st)
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);

@@ -25,6 +25,7 @@ struct ssmem {
   double vec[8][SNP];
   float red[2][4];
   int flags[4];
+  double usg[SNP];   // -1.0 on the U/V rows (i mod n_stokes >= 2), +1.0 elsewhere
   gj_scratch<double, SNP> gj;
   double xw[4][16 * 10];   // wave-private transposer tiles of load/store_strip_global_c8
 };
@@ -110,6 +111,40 @@ __device__ __forceinline__ double expdiff_tab_thick(double xi, double xj, double
   const double dlt = xi - xj;
   const double v = ((dlt < 0.0) ? ei : ej) * (-expm1(-fabs(dlt)));
   return (dlt < 0.0) ? v : -v;   // (dlt == 0: v = 0)
+}
+
+// One element of the elemental layer (elemental.jl:289-334) from the per-row / per-column tables (x = dtau / mu, e = exp(-x),
+// a = expm1(-x)); straight-line selects instead of the reference's branches:
+//   r-+_ij = varpi Z-+_ij  mu_j / (mu_i + mu_j) w_j (1 - e^{-x_i} e^{-x_j}),   1 - e^{-x_i} e^{-x_j} = -(a_i + a_j + a_i a_j)
+//   t++_ij = varpi Z++_ij  mu_j / (mu_i - mu_j) w_j (e^{-x_i} - e^{-x_j})      (mu_i != mu_j)
+//          = delta_ij e^{-x_i} + e^{-x_j} varpi Z++_ij x_i w_j                 (mu_i == mu_j)
+// The SFI source (elemental.jl:348-392) has the same form with the solar column in place of column j (mu_j -> mu_0,
+// x_j -> dtau / mu_0, w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q): j0+ is the "t" formula, j0- the "r" one.
+__device__ __forceinline__ void elemental_pair(double w, double zp, double zm, double mi, double xi, double ai, double ei,
+                                               double mj, double xj, double aj, double ej, double wct, bool diag, bool thick,
+                                               double& rr, double& tt) {
+  rr = w * zm * (mj / (mi + mj)) * wct * (-(ai + aj + ai * aj));
+  double ediff;
+  if (thick) ediff = expdiff_tab_thick(xi, xj, ei, ej); else ediff = expdiff_tab_thin(xi, xj, ai, aj, ej);
+  const double t_off = w * zp * (mj / (mi - mj)) * wct * ediff;
+  const double t_1 = w * zp * xi * wct;
+  const double t_same = diag ? ei * (1.0 + t_1) : ej * t_1;
+  tt = (mi == mj) ? t_same : t_off;
+}
+
+// Added layer of the elemental pre-pass (k_elemental_img) in global memory, per (moment, point): the two A-form IMAGES [r-+*],
+// [t++] exactly as the doubling loop wants them in LDS (swizzled 64 x 64 incl. zero padding and the source vectors in the
+// spare columns), then j0+[64], j0-[64] and aux[64] (aux[0] = exp(-dtau / mu_0)).  The layer kernel copies the images with
+// global_load_lds_dwordx4: 16 instructions per lane, no registers, no address arithmetic.
+constexpr int PRE_IMG = SNP * SNP;
+constexpr int PRE_STRIDE = 2 * PRE_IMG + 3 * SNP;
+__device__ __forceinline__ void copy_image_to_lds(double* L, const double* __restrict__ g, const spos& p) {
+#pragma unroll
+  for (int i = 0; i < PRE_IMG / (SNT * 2); ++i) {   // 8 x (256 lanes x 16 B)
+    const int blk = (4 * i + p.wave) * 128;         // doubles: one wave moves 1 KB per instruction
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + blk + 2 * p.lane),
+                                     (__attribute__((address_space(3))) void*)(L + blk), 16, 0, 0);
+  }
 }
 
 // acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
@@ -423,6 +458,16 @@ __device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, int ns, c
 struct dpar {
   unsigned rows;
   bool uc;
+  // from a table usg[i] = -1.0 on the U/V rows, +1.0 elsewhere (one `%` per row of the matrix instead of 17 per lane)
+  __device__ __forceinline__ dpar(const double* usg, const spos& p) {
+    rows = 0;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rows |= (usg[p.row(ta, r)] < 0.0 ? 1u : 0u) << (4 * ta + r);
+    uc = usg[p.col] < 0.0;
+    if (uc) rows = ~rows;   // bit set = sign flip
+  }
   __device__ __forceinline__ dpar(int ns, const spos& p) {
     rows = 0;
 #pragma unroll
@@ -437,7 +482,11 @@ __device__ __forceinline__ void dsym_strip(sstrip& d, const sstrip& x, const dpa
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) d.v[ta][r] = ((dp.rows >> (4 * ta + r)) & 1u) ? -x.v[ta][r] : x.v[ta][r];
+    for (int r = 0; r < 4; ++r) {   // flip the sign bit: shift, mask, xor on the high word
+      const int n = 4 * ta + r;
+      const unsigned sb = (dp.rows << (31 - n)) & 0x80000000u;
+      d.v[ta][r] = __hiloint2double(__double2hiint(x.v[ta][r]) ^ (int)sb, __double2loint(x.v[ta][r]));
+    }
 }
 // global column-major N x N -> A-form in LDS (zero padded); one column per wave and pass, coalesced reads
 __device__ __forceinline__ void stage_aform(double* L, const double* __restrict__ g, int N, const spos& p) {
