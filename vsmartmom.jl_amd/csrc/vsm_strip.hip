@@ -252,8 +252,8 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
             dp[i] = vp;
             dm[i] = vm;
           }
-          P[p.sidx(ta, r)] = rv;
-          Q[p.sidx(ta, r)] = tv;
+          *p.sptr(p.delta(P), ta, r) = rv;
+          *p.sptr(p.delta(Q), ta, r) = tv;
         }
       }
     }
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ed_strip(quad<double> q, int m, int 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
+  p.bind(sm.P);
   sstrip r_s, t_s;
   ed_body<KS, false>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s);
   const int s = blockIdx.x, tid = threadIdx.x, N = q.N, ns = q.n_stokes;
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(SNT, 2) void k_ia_strip(int N, composite<double> c,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   spos p;
+  p.bind(sm.P);
   const int s = blockIdx.x, tid = threadIdx.x;
   if (tid < SNP) {
     const bool in = tid < N;
@@ -613,6 +615,7 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
   ssmem& sm = *reinterpret_cast<ssmem*>(smem_raw);
   VSM_LIFE_DECL;
   spos p;
+  p.bind(sm.P);
   sstrip r_s, t_s;
   ed_body<KS, MIX, THERMAL, PRE>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, img);
   const int N = q.N, ns = q.n_stokes;
@@ -679,6 +682,7 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   gsmem& sm = *reinterpret_cast<gsmem*>(smem_raw);
   spos p;
+  p.bind(sm.A);
   const long long s = blockIdx.x, pp = blockIdx.y;
   const double* As = A + s * sa + pp * pa;
   const double* Bs = B + s * sb + pp * pb;

@@ -30,15 +30,23 @@ struct ssmem {
   double xw[4][16 * 10];   // wave-private transposer tiles of load/store_strip_global_c8
 };
 
-// Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h), split into per-lane bases and compile-time
-// offsets so that every LDS access of a product is "base register + immediate":
-//   A fragment (row 16 t + l15, column 4 ks + kq):  lidx = ab[ks & 3][t] + 256 ks      (one base per (ks & 3, t):
-//   bases that differ by a small constant would be fused into ds_read2_b64, whose 8-bit offsets cannot hold 256 ks)
-//   strip element (row 16 ta + kq + 4 r, column col): lidx = ((16 ta + 4 r) ^ cm_hi) + c_lo
+// Per-lane addressing of the swizzled A-form (lidx of vsm_lds.h) in BYTES, split into per-lane bases and compile-time offsets
+// so that an LDS access of a product needs no address arithmetic at all:
+//   A fragment (row 16 t + l15, column 4 ks + kq):  ab8[ks & 3][t] + 2048 ks   (one base per (ks & 3, t); the 2048 ks and the
+//   distance of the A-form from the bound base go into the instruction's 16-bit offset field)
+//   strip element (row 16 ta + kq + 4 r, column col): ((128 ta + 32 r) ^ cm_hi8) + c_lo8    (one v_xad_u32)
+// bind(base) adds the LDS address of `base` (the first A-form of the kernel's LDS block) to the per-lane bases; the helpers
+// then address an A-form at `A` by the compile-time distance A - base.  Unbound: the distance is the full LDS address.
+using lds_d = __attribute__((address_space(3))) double;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
 struct spos {
   int lane, wave, l15, kq, col;
-  int ab[4][4];
-  int cm_hi, c_lo;
+  unsigned ab8[4][4];
+  unsigned cm_hi8, c_lo8;
+  const char* lbase;
+  bool bound;
   __device__ __forceinline__ spos() {
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
@@ -49,22 +57,42 @@ struct spos {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ab[j][t] = 64 * kq + (L ^ (4 * j)) + 16 * (t ^ pq);
+      for (int t = 0; t < 4; ++t) ab8[j][t] = 8u * (unsigned)(64 * kq + (L ^ (4 * j)) + 16 * (t ^ pq));
     const int m = ((col & 1) << 4) | (((col >> 1) & 7) << 1);
-    cm_hi = m & 0x3C;
-    c_lo = (kq ^ (m & 3)) + SNP * col;
+    cm_hi8 = 8u * (unsigned)(m & 0x3C);
+    c_lo8 = 8u * (unsigned)((kq ^ (m & 3)) + SNP * col);
+    lbase = nullptr;
+    bound = false;
+  }
+  __device__ __forceinline__ void bind(const void* base) {
+    const unsigned L = lds_addr(base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ab8[j][t] += L;
+    c_lo8 += L;
+    lbase = static_cast<const char*>(base);
+    bound = true;
+  }
+  __device__ __forceinline__ unsigned delta(const void* A) const {
+    return bound ? (unsigned)(static_cast<const char*>(A) - lbase) : lds_addr(A);
   }
   __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
-  __device__ __forceinline__ int aidx(int t, int ks) const { return ab[ks & 3][t] + 256 * ks; }
-  __device__ __forceinline__ int sidx(int ta, int r) const { return ((16 * ta + 4 * r) ^ cm_hi) + c_lo; }
+  // A fragment / strip element of the A-form at distance dA (see delta)
+  __device__ __forceinline__ const lds_d* aptr(unsigned dA, int t, int ks) const {
+    return reinterpret_cast<const lds_d*>((unsigned long long)(ab8[ks & 3][t] + (dA + 2048u * (unsigned)ks)));
+  }
+  __device__ __forceinline__ lds_d* sptr(unsigned dA, int ta, int r) const {
+    return reinterpret_cast<lds_d*>((unsigned long long)((((unsigned)(128 * ta + 32 * r)) ^ cm_hi8) + (c_lo8 + dA)));
+  }
   // hide the loop invariance of the bases from LICM (hoisting every derived address costs > 100 VGPRs)
   __device__ __forceinline__ void opaque() {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(ab[j][t]));
-    asm volatile("" : "+v"(cm_hi));
-    asm volatile("" : "+v"(c_lo));
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(ab8[j][t]));
+    asm volatile("" : "+v"(cm_hi8));
+    asm volatile("" : "+v"(c_lo8));
   }
 };
 
@@ -151,14 +179,15 @@ __device__ __forceinline__ void copy_image_to_lds(double* L, const double* __res
 template <int KS>
 __device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip& B, spos& p) {
   p.opaque();
+  const unsigned dA = p.delta(A);
   double a[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+  for (int t = 0; t < 4; ++t) a[0][t] = *p.aptr(dA, t, 0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
     }
     const double b = B.v[ks >> 2][ks & 3];
 #pragma unroll
@@ -170,14 +199,15 @@ __device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip
 template <int KS>
 __device__ __forceinline__ void mm_ab_c(sstrip& out, const sstrip& C0, const double* A, const sstrip& B, spos& p) {
   p.opaque();
+  const unsigned dA = p.delta(A);
   double a[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+  for (int t = 0; t < 4; ++t) a[0][t] = *p.aptr(dA, t, 0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
     }
     const double b = B.v[ks >> 2][ks & 3];
 #pragma unroll
@@ -190,14 +220,15 @@ template <int KS>
 __device__ __forceinline__ void mm_ab2(sstrip& acc1, sstrip& acc2, const double* A, const sstrip& B1, const sstrip& B2,
                                        spos& p) {
   p.opaque();
+  const unsigned dA = p.delta(A);
   double a[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a[0][t] = A[p.aidx(t, 0)];
+  for (int t = 0; t < 4; ++t) a[0][t] = *p.aptr(dA, t, 0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = A[p.aidx(t, ks + 1)];
+      for (int t = 0; t < 4; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
     }
     const double b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
 #pragma unroll
@@ -212,19 +243,21 @@ __device__ __forceinline__ void mm_ab2(sstrip& acc1, sstrip& acc2, const double*
 // strip -> A-form in LDS, through f(value, row, col)
 template <typename F>
 __device__ __forceinline__ void store_strip(double* dst, const sstrip& s, const spos& p, F f) {
+  const unsigned dA = p.delta(dst);
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = p.row(ta, r);
-      dst[p.sidx(ta, r)] = f(s.v[ta][r], row, p.col);
+      *p.sptr(dA, ta, r) = f(s.v[ta][r], row, p.col);
     }
 }
 __device__ __forceinline__ void load_strip(sstrip& s, const double* src, const spos& p) {
+  const unsigned dA = p.delta(src);
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s.v[ta][r] = src[p.sidx(ta, r)];
+    for (int r = 0; r < 4; ++r) s.v[ta][r] = *p.sptr(dA, ta, r);
 }
 
 // Frobenius-norm bound of the N x N block whose strips the waves hold (deterministic; see vsm_fused.hip).
