@@ -11,7 +11,7 @@ N GPUs => N x 10 000 points (weak scaling; `--total-points` = strong scaling).  
 starts its own N ranks (torch.distributed.run, one process per GPU over RCCL) or fails if N GPUs are not visible.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
-kernel (the fused layer step k_layer_strip; algorithmic flops / HIP-event launch time) and `cpu_baseline`
+kernel (the fused layer step k_layer_strip_mm with its elemental pre-pass; algorithmic flops / HIP-event time of the pair) and `cpu_baseline`
 (the oracle port timed on a bounded sample of the same workload).
 """
 import argparse
@@ -204,8 +204,12 @@ def main():
     moments_per_launch = max([e[4] for e in ev], default=1)
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
+    interval_kernels = None
     if cfg["FT"] == "f64" and 32 < N <= 60:
-        kernel_name = "k_layer_strip"
+        # the event pair of a layer step brackets the fused layer kernel AND its elemental pre-pass (k_elemental_img writes the
+        # A-form images the layer kernel copies in): the fraction below charges both to the layer kernel's flops
+        kernel_name = "k_layer_strip_mm" if moments_per_launch > 1 else "k_layer_strip"
+        interval_kernels = ["k_elemental_img", "k_layer_strip_mm"] if moments_per_launch > 1 else ["k_layer_strip"]
     elif cfg["FT"] == "f32" and 64 < N <= 96:
         kernel_name = "k_layer_strip32"
     else:
@@ -240,6 +244,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1),
+                         "kernels_in_timed_interval": interval_kernels,
                          "fourier_moments_per_launch": moments_per_launch},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -253,23 +258,26 @@ def main():
 def hbm_traffic_per_launch(kernel, cfg, S_local):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 runs by tools/profile_any.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
-    figure of profiles/r02/final/<config>/summary.json (a 4096-point run of the same command) times the points of one launch.
+    figure of profiles/r03/<config>/summary.json (r02/final as fallback; a 4096-point run of the same command) times the points of one launch.
     PMC counters cannot be read from inside the timed process, so this is the profiled value, not a live one; null
     when no profile covers the configuration."""
     tag = {"C2": "c2", "C4": "c4"}.get(cfg.get("name"))
     if tag is None:
         return None, None
-    path = os.path.join(ROOT, "profiles", "r02", "final", tag, "summary.json")
-    try:
-        prof = json.load(open(path))
-        pts = int(prof["command"].split("--points")[1].split()[0])
-        for name, rec in prof["kernels"].items():
-            if kernel in name and "fetch_bytes_per_launch" in rec:
-                per_point = (rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / pts
+    for rnd in ("r03", "r02/final"):
+        path = os.path.join(ROOT, "profiles", rnd, tag, "summary.json")
+        try:
+            prof = json.load(open(path))
+            pts = int(prof["command"].split("--points")[1].split()[0])
+            per_point = 0.0
+            for name, rec in prof["kernels"].items():   # the layer kernel and (FP64 strip shapes) its elemental pre-pass
+                if (kernel in name or "k_elemental_img" in name) and "fetch_bytes_per_launch" in rec:
+                    per_point += (rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / pts
+            if per_point > 0.0:
                 return per_point * S_local, os.path.relpath(path, ROOT)
-        return None, None
-    except Exception:
-        return None, None
+        except Exception:
+            pass
+    return None, None
 
 
 def _cpu_worker(job):

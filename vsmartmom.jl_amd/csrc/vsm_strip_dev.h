@@ -80,7 +80,9 @@ struct spos {
   __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
   // A fragment / strip element of the A-form at distance dA (see delta)
   __device__ __forceinline__ const lds_d* aptr(unsigned dA, int t, int ks) const {
-    return reinterpret_cast<const lds_d*>((unsigned long long)(ab8[ks & 3][t] + (dA + 2048u * (unsigned)ks)));
+    // (pointer + constant, not integer + constant: the constant then lands in the instruction's offset field also when dA
+    // is a run-time value, and ab8 + dA is formed once per base)
+    return reinterpret_cast<const lds_d*>((unsigned long long)(ab8[ks & 3][t] + dA)) + 256 * ks;
   }
   __device__ __forceinline__ lds_d* sptr(unsigned dA, int ta, int r) const {
     return reinterpret_cast<lds_d*>((unsigned long long)((((unsigned)(128 * ta + 32 * r)) ^ cm_hi8) + (c_lo8 + dA)));

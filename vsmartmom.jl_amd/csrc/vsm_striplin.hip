@@ -247,6 +247,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   double* ajp = sm.vec[2];
   double* ajm = sm.vec[3];
   spos p;
+  p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int Kend = ((N + 3) >> 2) << 2;
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   double* jp = sm.vec[0];
   double* jm = sm.vec[1];
   spos p;
+  p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int Kend = ((N + 3) >> 2) << 2;
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   double* vdadd = sm.vec[4];
   double* vdacc = sm.vec[5];
   spos p;
+  p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int Kend = ((N + 3) >> 2) << 2;
