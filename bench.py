@@ -58,6 +58,40 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def make_step(scene, parallel, S_total, rank, world, phase=None, sync=None):
+    """The timed step of the bench as a closure over `scene` (anything with upload() / prepare() / run() -> (R, T) torch tensors
+    whose first axis is the rank's spectral block: the HIP Scene here, an oracle-backed stand-in in the 2-rank gloo test that
+    drives this very function):  H2D of the raw optical depths, layer optics, all Fourier moments x layers x (elemental ->
+    doubling -> interaction), surface, post-processing, ONE gather of R/T over the ranks (packed into one buffer per rank),
+    D2H of the result on rank 0.  `split` adds synchronisations to attribute the time to phases (untimed pass)."""
+    import torch
+
+    def step(split=False):
+        t = [time.perf_counter()]
+
+        def mark():
+            if split:
+                if sync is not None:
+                    sync()
+                t.append(time.perf_counter())
+
+        scene.upload()
+        mark()
+        scene.prepare()
+        mark()
+        R, T = scene.run()
+        mark()
+        packed = torch.cat([R.reshape(R.shape[0], -1), T.reshape(T.shape[0], -1)], dim=1)
+        g = parallel.gather_spectral(packed, S_total, rank, world)   # the one collective (RCCL) of the data path
+        out = g.cpu() if g is not None else None                     # D2H of R/T [nSpec, 2 nStokes nVZA] on rank 0
+        mark()
+        if split and phase is not None:
+            for k, a, b in zip(phase, t[:-1], t[1:]):
+                phase[k] = b - a
+        return out
+    return step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +106,8 @@ def main():
                     help="aerosol: SURVEY 8(d) variant -- HG aerosol (g=0.7, ssa=0.95, tau=0.2) in the lowest 6 layers, "
                          "2*nstreams-1 moments: Z differs per point and all 2*nstreams Fourier moments run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip config.secondary (one timed step each of C4, the linearized C2 shape, the linearized C3 scene, C5 at 4000 points)")
     ap.add_argument("--cpu-sample", type=int, default=96, help="upper bound of spectral points PER HOST CORE of the CPU-baseline sample (sized for ~15 s)")
     args = ap.parse_args()
 
@@ -97,6 +133,8 @@ def main():
     if args.layers:
         cfg["L"] = args.layers
     scaling = "weak"
+    if args.config == "C4" and args.gpus > 1 and not args.total_points and not args.points:
+        args.total_points = 100000   # BASELINE.json configs[3] is a STRONG-scaling case: 10^5 points over the GPUs of the node
     if args.total_points:
         scaling = "strong"
         if args.total_points % world:
@@ -134,31 +172,7 @@ def main():
 
     phase = {"h2d": 0.0, "optics": 0.0, "run": 0.0, "gather_d2h": 0.0}
 
-    def step(split=False):
-        """One rt_run-equivalent: H2D of the raw optical depths, layer optics on the device, all Fourier
-        moments x layers x (elemental -> doubling -> interaction), surface, post-processing, ONE gather of R/T over the
-        ranks, D2H of the result on rank 0.  `split` adds synchronisations to attribute the time to phases (untimed pass)."""
-        t = [time.perf_counter()]
-
-        def mark():
-            if split:
-                torch.cuda.synchronize()
-                t.append(time.perf_counter())
-
-        scene.upload()
-        mark()
-        scene.prepare()
-        mark()
-        R, T = scene.run()
-        mark()
-        packed = torch.cat([R.reshape(R.shape[0], -1), T.reshape(T.shape[0], -1)], dim=1)
-        g = parallel.gather_spectral(packed, S_total, rank, world)   # the one collective (RCCL) of the data path
-        out = g.cpu() if g is not None else None                     # D2H of R/T [nVZA, nStokes, nSpec] on rank 0
-        mark()
-        if split:
-            for k, a, b in zip(phase, t[:-1], t[1:]):
-                phase[k] = b - a
-        return out
+    step = make_step(scene, parallel, S_total, rank, world, phase, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         step()
@@ -168,10 +182,24 @@ def main():
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    timed_region_s = dt
+    mg = {"rccl_ranks": 1, "per_rank_step_ms": [1e3 * dt / args.steps], "per_rank_device": [torch.cuda.get_device_name(local)]}
     if world > 1:
+        dist = torch.distributed
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)      # (a real RCCL collective: the rank count below is observed after it)
+        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+        names = [None] * world
+        dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
+              "per_rank_step_ms": [1e3 * float(x.item()) / args.steps for x in every], "per_rank_device": names}
         dt = float(tmax.item())
+        timed_region_s = dt
     step(split=True)   # phase attribution, outside the timed region
 
     # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
@@ -233,6 +261,7 @@ def main():
                        "timed_step": "full rt_run-equivalent: H2D of tau_rayl/tau_abs + device layer optics + all moments/layers/"
                                      "surface/post-processing + gather + D2H of R,T",
                        "ranks": world, "collective_backend": "nccl (RCCL)" if world > 1 else "none (1 rank)",
+                       "multi_gpu": mg, "timed_region_s": timed_region_s,
                        "N": N, "layers": L, "points_per_gpu": S_local, "fourier_moments": m_max + 1,
                        "ndoubl_per_layer": nds, "algorithmic_gflop_per_point": flops_pt / 1e9,
                        "whole_run_tflops": pts_per_s * flops_pt / 1e12,
@@ -247,6 +276,14 @@ def main():
                          "kernels_in_timed_interval": interval_kernels,
                          "fourier_moments_per_launch": moments_per_launch},
         }
+        if world == 1 and args.config == "C2" and args.variant == "rayleigh" and not args.no_secondary and not args.points:
+            import bench_secondary
+            del scene
+            torch.cuda.empty_cache()
+            t_sec = time.perf_counter()
+            line["config"]["secondary"] = bench_secondary.run_all(vsm, torch, arch, o2a_atmosphere)
+            line["config"]["secondary_wall_s"] = time.perf_counter() - t_sec
+        torch.cuda.synchronize()   # (marker: everything on the GPU is done before the CPU baseline starts)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, L)
         print(json.dumps(line))

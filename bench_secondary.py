@@ -1,0 +1,144 @@
+"""Secondary workloads of bench.py (`config.secondary` of the JSON line): one timed step each of the other BASELINE.json
+configurations that fit one GPU, so that their figures are driver-timed and not only builder-run (tools/*.py):
+
+  C4      forward, N = 96 FP32, 60 layers, 12 500 points (one GPU's share of configs[3])
+  C2-lin  rt_run(model, lin_model, 0, 1, 1) on the C2 shape (1 gas column + albedo), 2 000 points
+  C3-lin  the ocean / Cox-Munk scene of config/ocean_coxmunk.yaml (IQUV, N = 60, 33 layers, 2 points, m = 0..21), linearized
+  C5      rotational Raman, N = 21, 12 layers, K = 40 lines, 4 000 points (configs[4] at a fifth of its spectral axis)
+
+Each entry: points/s of the step, its wall time, the device time of the pass by HIP events, the algorithmic TFLOP/s and the
+fraction of the MFMA peak of its dtype, and the dominant kernel (per-kernel durations: profiles/r03/).  A step here is the
+device pass of an already-built scene (`scene.run()` + D2H of the result), with one untimed warm-up; the C5 step is a whole
+`rt_run(RRS, ...)` call (host optics, H2D, device pass, D2H).  Only bench.py imports this module, on rank 0 of a 1-GPU run.
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PEAK = {"f64": 78.6, "f32": 157.3}
+
+
+def _timed(torch, f):
+    f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    out = f()
+    e1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, e0.elapsed_time(e1), out
+
+
+def _entry(name, workload, S, wall, dev_ms, flops_pt, dtype, kernel):
+    tf = flops_pt * S / wall / 1e12 if flops_pt else None
+    return {"name": name, "workload": workload, "points": S, "value": S / wall, "unit": "spectral-points/s", "ms_per_step": 1e3 * wall,
+            "device_pass_ms": dev_ms, "dtype": dtype, "algorithmic_gflop_per_point": flops_pt / 1e9 if flops_pt else None,
+            "achieved_tflops": tf, "frac_of_mfma_peak": tf / PEAK[dtype] if tf else None, "dominant_kernel": kernel}
+
+
+def c4(vsm, torch, arch, o2a, points=12500):
+    cfg = dict(pol="IQU", l_trunc=59, L=60)
+    tau_rayl, tau_abs = o2a(points, cfg["L"])
+    model = vsm.host_model.model_from_arrays(arch, cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs,
+                                             depol=0.0279, albedo=0.15, m_max=2, float_type=np.float32)
+    scene = vsm.CoreRT.prepare_scene(model)
+
+    def step():
+        scene.upload()
+        scene.prepare()
+        R, T = scene.run()
+        return R.cpu(), T.cpu()
+    wall, dev, _ = _timed(torch, step)
+    e = _entry("C4", "N=96 FP32, 60 layers, m=0..2, Rayleigh + O2, Lambertian (one GPU's share of BASELINE configs[3])", points, wall, dev,
+               scene.flops_per_point(), "f32", "k_layer_strip32_mm<6>")
+    del scene
+    return e
+
+
+def c2_lin(vsm, torch, arch, o2a, points=2000):
+    L = 40
+    tau_rayl, tau_abs = o2a(points, L)
+    H = vsm.host_model
+    model = H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2)
+    lin = H.LinModel([tau_abs])
+    scene = vsm.CoreRTLin.SceneLin(model, lin, 0, 1, 1)
+
+    def step():
+        scene.run()
+        return scene.results_host()
+    wall, dev, _ = _timed(torch, step)
+    e = _entry("C2-lin", "linearized rt_run (1 gas column + albedo), N=60 FP64, 40 layers, m=0..2 (C2 shape)", points, wall, dev,
+               scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia_lin_half<15>)")
+    del scene
+    return e
+
+
+def c3_lin(vsm, torch, arch):
+    import yaml
+    with open(os.path.join(ROOT, "tests", "golden", "ocean_coxmunk_scene.json")) as f:
+        d = json.load(f)
+    d.pop("source")
+    io, H = vsm.io_yaml, vsm.host_model
+    model = io.model_from_parameters(io.parameters_from_yaml(yaml.safe_dump(d)), arch)
+    S, L = model.tau_rayl.shape
+    prof = np.linspace(0.2, 1.8, L)[None, :] * np.array([[0.004], [0.0015]])
+    model.tau_abs = prof * 1.0
+    lin = H.LinModel([prof * 1.0])
+    scene = vsm.CoreRTLin.SceneLin(model, lin, 0, 1, 1)
+
+    def step():
+        scene.run()
+        return scene.results_host()
+    wall, dev, _ = _timed(torch, step)
+    fl = scene.flops_per_point() if hasattr(scene, "flops_per_point") else None
+    e = _entry("C3-lin", "ocean / Cox-Munk scene (config/ocean_coxmunk.yaml): IQUV, N=60 FP64, 33 layers, m=0..21, linearized "
+               "(gas column + wind speed) -- a latency-bound two-point batch", S, wall, dev, fl, "f64", "launch latency (22 x 33 layer steps)")
+    del scene
+    return e
+
+
+def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
+    rng = np.random.default_rng(20260929)
+    S, K, L = points, lines, layers
+    dp = np.full(L, 1.0 / L)
+    tau_rayl = np.tile(0.3 * dp, (S, 1))
+    tau_abs = (10.0 ** rng.uniform(-4, 0, (S, 1))) * dp[None, :]
+    H = vsm.host_model
+    model = H.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.05, m_max=2)
+    model.varpi_Cabannes = 0.96
+    N = model.quad_points.Nquad * 3
+    shifts = np.unique(np.concatenate([np.arange(-K // 2, 0), np.arange(1, K - K // 2 + 1)]) * 7)
+    rs = vsm.CoreRTRaman.RRS(shifts, np.full(len(shifts), 0.04 / len(shifts)), H.get_greek_rayleigh(0.75))
+    wall, dev, _ = _timed(torch, lambda: vsm.CoreRTRaman.rt_run(rs, model, 1))
+    n3, n2 = float(N) ** 3, float(N) ** 2
+    lods = H.constructCoreOpticalProperties(model, 0)
+    nds = [H.get_dtau_ndoubl(np.atleast_1d(lo.tau), np.broadcast_to(np.asarray(lo.varpi), np.atleast_1d(lo.tau).shape),
+                             model.quad_points, np.float64, model.numerics)[1] for lo in lods]
+    n1 = np.arange(S)
+    kin = sum(((n1 + int(sh) >= 0) & (n1 + int(sh) < S)).astype(float) for sh in shifts).mean()
+    # as-written operation count of the reference (doubling_inelastic.jl:13-164: 16 products + 10 mat-vecs per in-band line and
+    # step; interaction_inelastic.jl:319-521: 18 products + 8 mat-vecs); the kernels execute 10 and 9 products per line
+    per_m = sum(nd * (12 * n3 + 8 * n2 + kin * (32 * n3 + 20 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (36 * n3 + 16 * n2))
+    exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
+    e = _entry("C5", "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
+               "20000 points); step = whole rt_run(RRS) incl. host optics, H2D, D2H" % (N, L, len(shifts), S), S, wall, dev, 3 * per_m, "f64",
+               "k_raman_doubling_wave_sp<21> (+ k_raman_interaction_wave<21>)")
+    e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
+    e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
+    return e
+
+
+def run_all(vsm, torch, arch, o2a):
+    out = []
+    for f in (lambda: c4(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a), lambda: c3_lin(vsm, torch, arch),
+              lambda: c5(vsm, torch, arch)):
+        try:
+            out.append(f())
+        except Exception as ex:   # a secondary workload must not take the headline line down
+            out.append({"error": "%s: %s" % (type(ex).__name__, ex)})
+        torch.cuda.empty_cache()
+    return out

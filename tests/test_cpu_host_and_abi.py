@@ -237,6 +237,73 @@ def test_two_rank_gloo_linearized_shard_and_gather():
     assert res == (True, True, True, True, (2, 3, 5, 2))
 
 
+def _worker_bench_step(rank, world, port, q):
+    """One rank of the gloo test that drives bench.py's OWN timed step (bench.make_step: upload -> prepare -> run -> pack R|T ->
+    ONE gather -> D2H) with a CPU stand-in for the HIP Scene: the oracle evaluated on the full axis and cut to the rank's block
+    (oracle use is confined to tests/).  What the driver's multi-GPU bench executes around the kernels is exercised here."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import vsmartmom_jl_amd as v
+    import bench
+    from oracle import vsm_oracle as Oo
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S, L = 7, 3                      # blocks of 4 and 3: the gather pads the last block
+    tau_rayl, tau_abs = bench.o2a_atmosphere(S, L)
+    geo = ("IQU", 9, 40.0, [30.0], [0.0])
+    om = Oo.build_model(*geo, tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2)
+    Ro, To = Oo.rt_run(om)           # [nVZA, nStokes, S]
+    sl = v.parallel.shard_slice(S, rank, world)
+
+    class OracleScene:               # the Scene surface make_step uses
+        calls = []
+
+        def upload(self):
+            self.calls.append("upload")
+
+        def prepare(self):
+            self.calls.append("prepare")
+
+        def run(self):
+            self.calls.append("run")
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, :, sl].transpose(2, 1, 0)))
+            return t(Ro), t(To)
+
+    phase = {"h2d": 0.0, "optics": 0.0, "run": 0.0, "gather_d2h": 0.0}
+    scene = OracleScene()
+    step = bench.make_step(scene, v.parallel, S, rank, world, phase)
+    out = step()
+    out2 = step(split=True)
+    if rank == 0:
+        n, nV = Ro.shape[1], Ro.shape[0]
+        g = out.numpy()
+        Rg = g[:, :n * nV].reshape(S, n, nV).transpose(2, 1, 0)
+        Tg = g[:, n * nV:].reshape(S, n, nV).transpose(2, 1, 0)
+        q.put((bool(np.array_equal(Rg, Ro)), bool(np.array_equal(Tg, To)), bool(torch.equal(out, out2)), tuple(out.shape),
+               scene.calls[:3], all(vv >= 0.0 for vv in phase.values())))
+    else:
+        assert out is None and out2 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bench_step():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == (True, True, True, (7, 6), ["upload", "prepare", "run"], True)
+
+
 def test_scene_uses_global_ndoubl_for_shards(vsm):
     """`ndoubl` of a shard must come from the full spectral axis (rt_kernel.jl:197,282-283 are batch-global)."""
     H = vsm.host_model

@@ -189,6 +189,35 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     assert err.max() < 1e-3 and err.mean() < 1e-4
 
 
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 9), ("IQU", 33)])   # N = 21 (operator level), 57 (fused strip kernels)
+def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
+    """SceneLin.run on concurrent moment lanes (small batches: the Fourier moments on several HIP streams, each with its own
+    layers and accumulators) == the moment-by-moment walk up to the reordering of the sum over moments, and == the oracle; a
+    second run on the same lanes reproduces the first bit for bit (the lanes are re-zeroed)."""
+    rng = np.random.default_rng(3)
+    S, L = 3, 4
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))
+    ga = 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    H = vsm.host_model
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga, depol=0.0279, m_max=5)
+    pm = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    scene = vsm.CoreRTLin.SceneLin(pm, H.LinModel([ga]), 0, 1, 1)
+    seq = [t.clone() for t in scene.run(lanes=1)]
+    torch.cuda.synchronize()
+    par = [t.clone() for t in scene.run(lanes=4)]
+    torch.cuda.synchronize()
+    again = scene.run()          # default for a batch this small: the lanes
+    torch.cuda.synchronize()
+    for a, b, c in zip(seq, par, again):
+        assert torch.equal(b, c)
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-13 * scale
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
+    R, T, Rd, Td = scene.results_host()
+    assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9 and _rel(Rd, Rdo) < 1e-8 and _rel(Td, Tdo) < 1e-8
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 33), ("IQUV", 43)])   # N = 7, 57 (fused strip kernels), 100 (operator level)
 @pytest.mark.parametrize("column", ["noscat_in_the_middle", "layers_without_doubling"])
 def test_rt_run_lin_corner_columns(vsm, arch, pol, l_trunc, column):

@@ -32,7 +32,8 @@ from . import host_model as H
 from .architectures import GPU, CPU, architecture, array_type, devi, synchronize_if_gpu, to_host
 
 IFACE = {"00": 0, "01": 1, "10": 2, "11": 3}
-MOMENT_BATCH = 4      # Fourier moments per layer-step call of Scene.run (VSM_MM_MAX of the library)
+MOMENT_BATCH = 4      # Fourier moments per layer-step call of Scene.run for large batches (each moment needs a CompositeLayer)
+MOMENT_BATCH_MAX = 24  # ... for small spectral batches: every moment of the run in one launch (VSM_MM_MAX of the library)
 
 
 def _require_gpu(arch):
@@ -730,7 +731,9 @@ class Scene:
         eps2 = 2 * np.finfo(FT).eps
         has_noscat = any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"])
         sequential = trace is not None or os.environ.get("VSM_NO_MOMENT_BATCH") is not None or has_noscat
-        nb = 1 if sequential else min(MOMENT_BATCH, len(self.moments))
+        # small batches are launch-latency bound (C3: 2 points, 22 moments x 33 layers): as many moments per launch as fill the chip
+        want = max(MOMENT_BATCH, min(MOMENT_BATCH_MAX, 4096 // max(self.S, 1)))
+        nb = 1 if sequential else min(want, len(self.moments))
         while len(self._composites) < nb:
             self._composites.append(make_composite_layer(FT, self.arch, (self.N, self.N), self.S))
         for g0 in range(0, len(self.moments), nb):

@@ -86,10 +86,11 @@ def elemental_lin_(pol, tau_sum, tau_sum_dot, dtau, dtau_dot, F0, props: CR.Devi
 
 
 _lin_work = {}
+_lane = 0   # the moment lane (stream) the calling thread launches on: work buffers are per lane
 
 
 def _work(kind, n, dtype, device):
-    key = (kind, dtype, str(device))
+    key = (kind, dtype, str(device), _lane)
     w = _lin_work.get(key)
     if w is None or w.numel() < n:
         w = _lib.poison(torch.empty(int(n), dtype=dtype, device=device))
@@ -205,6 +206,7 @@ class SceneLin:
         self.R, self.T = fwd.R_SFI, fwd.T_SFI
         self.Rd = torch.zeros((P, S, pol.n, nV), dtype=dt, device=dev)
         self.Td = torch.zeros_like(self.Rd)
+        self._lanes = []
 
     # -- inputs -----------------------------------------------------------------------------------------------------------
     def upload(self):
@@ -292,19 +294,85 @@ class SceneLin:
                 self.tau_sum_dot[L].copy_(to_device_sp(tsd[sl], self.arch, FT))
             self.host_zdot.append(zd)
 
-    def run(self):
-        """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing."""
-        model, pol, qp, FT, dt, fwd = self.model, self.pol, self.qp, self.FT, self.dt, self.fwd
-        N, S, P, pl = self.N, self.S, self.P, self.pl
-        for t in (self.R, self.T, self.Rd, self.Td):
-            t.zero_()
+    # Small spectral batches are latency bound: a linearized layer step of ONE workgroup is ~0.4 ms and the 33 layers of a moment
+    # are a dependent chain (C3: 2 points, 22 moments x 33 layers = 0.3 s moment by moment).  The Fourier moments are independent
+    # until post-processing (rt_run_lin.jl:200-322), so below LANE_POINTS spectral points they run on up to LANES HIP streams, each
+    # lane with its own added / composite layers (+ derivatives), work buffers and R / T / Rdot / Tdot accumulators, summed at the
+    # end.  (The sum over moments is then taken lane by lane: equal to the sequential walk up to the rounding of the reordering.)
+    LANES = 8
+    LANE_POINTS = 64
+
+    def _lane_state(self, k):
+        """Workspace of moment lane k (lane 0: the scene's own buffers)."""
+        while len(self._lanes) <= k:
+            if not self._lanes:
+                self._lanes.append(dict(added=self.added, al=self.al, comp=self.comp, cl=self.cl, added_s=self.added_s, als=self.als,
+                                        expk=self.expk, R=self.R, T=self.T, Rd=self.Rd, Td=self.Td, stream=None))
+                continue
+            FT, arch, P, N, S = self.FT, self.arch, self.P, self.N, self.S
+            self._lanes.append(dict(
+                added=CR.make_added_layer(FT, arch, (N, N), S), al=AddedLayerLin(FT, arch, P, N, S),
+                comp=CR.make_composite_layer(FT, arch, (N, N), S), cl=CompositeLayerLin(FT, arch, P, N, S),
+                added_s=self._new_surface_added(), als=AddedLayerLin(FT, arch, P, N, S, shared=True),
+                expk=torch.empty_like(self.expk), R=torch.zeros_like(self.R), T=torch.zeros_like(self.T),
+                Rd=torch.zeros_like(self.Rd), Td=torch.zeros_like(self.Td), stream=torch.cuda.Stream()))
+        return self._lanes[k]
+
+    def _new_surface_added(self):
+        a0 = self.added_s
+        return CR.AddedLayer(self.FT, self.arch, self.N, self.S, a0.shared, a0.d_symmetric)
+
+    def run(self, lanes: Optional[int] = None):
+        """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing.
+        `lanes`: number of concurrent moment lanes (default: LANES for batches below LANE_POINTS points, else 1)."""
+        global _lane
+        S = self.S
+        nm = len(self.fwd.moments)
+        if lanes is None:
+            lanes = self.LANES if 0 < S < self.LANE_POINTS else 1
+        lanes = max(1, min(lanes, nm))
+        st = [self._lane_state(k) for k in range(lanes)]
+        for w in st:
+            for t in (w["R"], w["T"], w["Rd"], w["Td"]):
+                t.zero_()
         if S == 0:
             return self.R, self.T, self.Rd, self.Td
-        added, al, comp, cl = self.added, self.al, self.comp, self.cl
+        if lanes == 1:
+            for mom in self.fwd.moments:
+                self._run_moment(mom, st[0])
+            return self.R, self.T, self.Rd, self.Td
+        main = torch.cuda.current_stream()
+        for w in st[1:]:
+            w["stream"].wait_stream(main)       # (the zeroing above and whatever produced the inputs)
+        try:
+            for i, mom in enumerate(self.fwd.moments):
+                k = i % lanes
+                _lane = k
+                if k == 0:
+                    self._run_moment(mom, st[0])
+                else:
+                    with torch.cuda.stream(st[k]["stream"]):
+                        self._run_moment(mom, st[k])
+        finally:
+            _lane = 0
+        for w in st[1:]:
+            main.wait_stream(w["stream"])
+        for w in st[1:]:
+            self.R += w["R"]
+            self.T += w["T"]
+            self.Rd += w["Rd"]
+            self.Td += w["Td"]
+        return self.R, self.T, self.Rd, self.Td
+
+    def _run_moment(self, mom, w):
+        """One Fourier moment on the workspace `w` (launches on the current stream)."""
+        model, pol, qp, FT, dt, fwd = self.model, self.pol, self.qp, self.FT, self.dt, self.fwd
+        N, S, P, pl = self.N, self.S, self.P, self.pl
+        added, al, comp, cl = w["added"], w["al"], w["comp"], w["cl"]
         isurf = self.layout.surface_index(0)
         mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
         q_ = self.dq.cstruct()
-        for mom in fwd.moments:
+        if True:
             m = mom["m"]
             weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
             for iz, ly in enumerate(mom["layers"]):
@@ -321,15 +389,15 @@ class SceneLin:
                     zpd, zmd, zds = self.host_zdot[m][iz] if self.host_zdot is not None else (None, None, (0, 0))
                     elemental_lin_(pol, ly["tau_sum"], tsd, ly["dtau"], dtd, self.F0, props.materialize(), vd, zpd, zmd, zds, pl,
                                    m, ly["nd"], self.dq, added, al)
-                _lib.call("vsm_layer_expk", dt, S, CR._ptr(ly["dtau"]), mu0, CR._ptr(self.expk), CR._stream_ptr())
-                doubling_allparams_(pol, self.expk, ly["nd"], added, al, dtd, qp.mu0, pl)
+                _lib.call("vsm_layer_expk", dt, S, CR._ptr(ly["dtau"]), mu0, CR._ptr(w["expk"]), CR._stream_ptr())
+                doubling_allparams_(pol, w["expk"], ly["nd"], added, al, dtd, qp.mu0, pl)
                 if iz == 0:
                     CR.copy_added_to_composite_(comp, added)
                     a_, c_ = al.cstruct(), cl.cstruct()
                     _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
                 else:
                     interaction_lin_(ly["iface"], comp, cl, added, al)
-            a_, al_ = self.added_s.cstruct(), self.als.cstruct()
+            a_, al_ = w["added_s"].cstruct(), w["als"].cstruct()
             tau_sum_s, tsd_s = mom["tau_sum_surface"], self.tau_sum_dot[fwd.Nz]
             rho, drho = self.surf[m]
             if isinstance(model.surface, H.CoxMunkSurface):
@@ -339,12 +407,11 @@ class SceneLin:
                 alb = C.c_double(model.surface.albedo) if dt == torch.float64 else C.c_float(model.surface.albedo)
                 _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(tau_sum_s), CR._ptr(tsd_s), pl,
                           CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
-            interaction_lin_(mom["iface_surface"], comp, cl, self.added_s, self.als)
-            CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), self.R, self.T)
-            row0, w = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
-            _lib.call("vsm_postprocess_vza_lin", dt, N, pol.n, S, len(model.vza), P, row0, w, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p),
-                      CR._ptr(self.Rd), CR._ptr(self.Td), CR._stream_ptr())
-        return self.R, self.T, self.Rd, self.Td
+            interaction_lin_(mom["iface_surface"], comp, cl, w["added_s"], w["als"])
+            CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), w["R"], w["T"])
+            row0, wts = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
+            _lib.call("vsm_postprocess_vza_lin", dt, N, pol.n, S, len(model.vza), P, row0, wts, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p),
+                      CR._ptr(w["Rd"]), CR._ptr(w["Td"]), CR._stream_ptr())
 
     def results_host(self):
         """(R, T, Rdot, Tdot) as the reference returns them: [nVZA, nStokes, nSpec] and [nVZA, nStokes, nSpec, Nparams]."""

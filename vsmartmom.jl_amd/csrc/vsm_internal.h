@@ -232,7 +232,7 @@ int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, 
                              const added_lin<double>& al, hipStream_t st);
 // several Fourier moments of one layer in ONE launch (gridDim.y = nm <= VSM_MM_MAX): same dtau / varpi / tau_sum / F0, per
 // moment its m, Z source and composite -- three times the workgroups per launch, i.e. a third of the launch tails
-constexpr int VSM_MM_MAX = 4;
+constexpr int VSM_MM_MAX = 24;   // (the argument block stays under the 4 KB kernel-argument limit: 24 x (m, Z source, composite) = 2.2 KB)
 template <typename T>
 struct layer_mm_args {
   int m[VSM_MM_MAX];
