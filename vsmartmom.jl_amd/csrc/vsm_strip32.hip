@@ -29,6 +29,7 @@
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
 #include "vsm_lds.h"
+#include "vsm_elemental.h"
 
 namespace vsm {
 
@@ -56,6 +57,11 @@ constexpr int FNT = 64 * FNW;
 constexpr int FTL = FNP / 16;  // row tiles per strip
 constexpr int LDK = 104;       // words per row of an A-form
 constexpr int NVEC = 5;
+// Added layer of the elemental pre-pass (k_elemental_img32) in global memory, per (moment, point): the A-form images [r-+*], [t++]
+// exactly as the doubling loop wants them in LDS (96 rows of LDK words, zero padding), then j0+[96], j0-[96], aux[96]
+// (aux[0] = exp(-dtau / mu_0)).  The layer kernel copies the images with global_load_lds_dwordx4.
+constexpr int PRE32_IMG = FNP * LDK;
+constexpr int PRE32_STRIDE = 2 * PRE32_IMG + 3 * FNP;
 
 struct fstrip {
   f4_t v[FTL];
@@ -495,139 +501,178 @@ __device__ __forceinline__ int invert_strip_own(fstrip& E, fstrip& G, float* W, 
 // barrier.
 // ---------------------------------------------------------------------------
 // THERMAL: the `:thermal` per-source slot instead of the solar beam (see vsm_strip.hip): F0 = B[S], expk = 1
-template <int KB, bool MIX, bool THERMAL = false>
+// LDS DMA copy of one A-form image (PRE32_IMG words = 2496 x 16 B) by the 6 waves of a half: 6.5 rounds of 6 x 1 KB
+__device__ __forceinline__ void copy_image_to_lds32(float* L, const float* __restrict__ g, const fpos& p) {
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int blk = (FNW * i + p.wave) * 256;   // words
+    if (blk < PRE32_IMG)                        // (wave-uniform; false only for waves 3..5 of the last round)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + blk + 4 * p.lane),
+                                       (__attribute__((address_space(3))) void*)(L + blk), 16, 0, 0);
+  }
+}
+
+// PRE: the elemental layer comes from the pre-pass (k_elemental_img32) as two A-form images + vectors at `img`.
+template <int KB, bool MIX, bool THERMAL = false, bool PRE = false>
 __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>& q, int m, int ndoubl,
                                         const float* __restrict__ dtau, const float* __restrict__ varpi,
                                         const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                        const zsrc<float>& z, fstrip& r_s, fstrip& t_s, int& jpair) {
+                                        const zsrc<float>& z, fstrip& r_s, fstrip& t_s, int& jpair,
+                                        const float* __restrict__ img = nullptr) {
   float* P = sm.P;
   float* Q = sm.Q;
-  float* mus = sm.vec[0];
-  float* wcs = sm.vec[1];
-  float* xs = sm.vec[2];
-  float* es = sm.vec[3];
-  float* ems = sm.vec[4];
-  const int s = p.s;
-  const int N = q.N, ns = q.n_stokes;
-  const int tid = p.tid;
-  const float d = dtau[s], w = varpi[s];
-  const int ncomp = MIX ? z.ncomp : 0;
-  const long long NNz = (long long)q.N * q.N;
-  const float* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
-  const float* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
-  float fk[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
-  auto zget = [&](const float* Z, long long zo) {
-    if (ncomp == 0) return Z[zo];
-    float acc = 0.f;
-#pragma unroll
+  float expk0 = 1.0f;
+  if constexpr (PRE) {
+    const int N = q.N, tid = p.tid;
+    copy_image_to_lds32(P, img, p);
+    copy_image_to_lds32(Q, img + PRE32_IMG, p);
+    float vjp = 0.0f, vjm = 0.0f;
+    if (tid < FNP) {
+      vjp = img[2 * PRE32_IMG + tid];
+      vjm = img[2 * PRE32_IMG + FNP + tid];
+    }
+    expk0 = img[2 * PRE32_IMG + 2 * FNP];
+    (void)N;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA writes have landed in LDS
+    if (tid < FNP) {
+      sm.vec[0][tid] = vjp;
+      sm.vec[1][tid] = vjm;
+    }
+    jpair = 0;
+    half_barrier(p);
+    load_strip(r_s, P, p);
+    load_strip(t_s, Q, p);
+  } else {
+    float* mus = sm.vec[0];
+    float* wcs = sm.vec[1];
+    float* xs = sm.vec[2];
+    float* es = sm.vec[3];
+    float* ems = sm.vec[4];
+    const int s = p.s;
+    const int N = q.N, ns = q.n_stokes;
+    const int tid = p.tid;
+    const float d = dtau[s], w = varpi[s];
+    const int ncomp = MIX ? z.ncomp : 0;
+    const long long NNz = (long long)q.N * q.N;
+    const float* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+    const float* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+    float fk[4] = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
-    return acc;
-  };
+      if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+    auto zget = [&](const float* Z, long long zo) {
+      if (ncomp == 0) return Z[zo];
+      float acc = 0.f;
+  #pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+      return acc;
+    };
 
-  if (tid < FNP) {
-    mus[tid] = (tid < N) ? q.mu[tid] : 1.0f;
-    const float wt = (tid < N) ? q.wt[tid] : 0.0f;
-    wcs[tid] = (m == 0) ? wt / 2.0f : wt / 4.0f;
-    const float x = d / mus[tid];
-    xs[tid] = x;
-    es[tid] = exp(-x);
-    ems[tid] = expm1(-x);
-  }
-  half_barrier(p);
+    if (tid < FNP) {
+      mus[tid] = (tid < N) ? q.mu[tid] : 1.0f;
+      const float wt = (tid < N) ? q.wt[tid] : 0.0f;
+      wcs[tid] = (m == 0) ? wt / 2.0f : wt / 4.0f;
+      const float x = d / mus[tid];
+      xs[tid] = x;
+      es[tid] = exp(-x);
+      ems[tid] = expm1(-x);
+    }
+    half_barrier(p);
 
-  // ---- elemental (elemental.jl:289-334) ------------------------------------------------------------------------
-  {
-    const int j = p.col;
-    const int jc = min(j, N - 1);
-    const float mj = mus[j], wct = wcs[j], xj = xs[j], emj = ems[j], ej = es[j];
-#pragma unroll
-    for (int ta = 0; ta < FTL; ++ta) {
-      float zp[4], zm[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jc;
-        zp[r] = zget(Zp, zo);
-        zm[r] = zget(Zm, zo);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = p.row(ta, r);
-        float rr = 0.0f, tt = 0.0f;
-        if (i < N && j < N) {
-          const float mi = mus[i], xi = xs[i];
-          if (wct > num<float>::eps()) {
-            const float emi = ems[i];
-            rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
-            if (mi == mj) {
-              if (i == j)
-                tt = es[i] * (1.0f + w * zp[r] * xi * wct);
-              else
-                tt = ej * (w * zp[r] * xi * wct);
-            } else {
-              const float xm = fmax(xi, xj);
-              const float ediff =
-#ifdef VSM_EXP_NOELEM
-                  (emi - emj);
-#else
-                  (xm < 0.5f && fabs(xi - xj) > 0.125f * xm) ? (emi - emj) : expdiff_neg<float>(xi, xj);
-#endif
-              tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
-            }
-          } else {
-            tt = (i == j) ? es[i] : 0.0f;
-          }
-          if (ndoubl >= 1 && is_uv_row(i, ns)) rr = -rr;
+    // ---- elemental (elemental.jl:289-334) ------------------------------------------------------------------------
+    {
+      const int j = p.col;
+      const int jc = min(j, N - 1);
+      const float mj = mus[j], wct = wcs[j], xj = xs[j], emj = ems[j], ej = es[j];
+  #pragma unroll
+      for (int ta = 0; ta < FTL; ++ta) {
+        float zp[4], zm[4];
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long zo = min(p.row(ta, r), N - 1) + (long long)N * jc;
+          zp[r] = zget(Zp, zo);
+          zm[r] = zget(Zm, zo);
         }
-        r_s.v[ta][r] = rr;
-        t_s.v[ta][r] = tt;
+  #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = p.row(ta, r);
+          float rr = 0.0f, tt = 0.0f;
+          if (i < N && j < N) {
+            const float mi = mus[i], xi = xs[i];
+            if (wct > num<float>::eps()) {
+              const float emi = ems[i];
+              rr = w * zm[r] * (mj / (mi + mj)) * wct * (-(emi + emj + emi * emj));
+              if (mi == mj) {
+                if (i == j)
+                  tt = es[i] * (1.0f + w * zp[r] * xi * wct);
+                else
+                  tt = ej * (w * zp[r] * xi * wct);
+              } else {
+                const float xm = fmax(xi, xj);
+                const float ediff =
+  #ifdef VSM_EXP_NOELEM
+                    (emi - emj);
+  #else
+                    (xm < 0.5f && fabs(xi - xj) > 0.125f * xm) ? (emi - emj) : expdiff_neg<float>(xi, xj);
+  #endif
+                tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
+              }
+            } else {
+              tt = (i == j) ? es[i] : 0.0f;
+            }
+            if (ndoubl >= 1 && is_uv_row(i, ns)) rr = -rr;
+          }
+          r_s.v[ta][r] = rr;
+          t_s.v[ta][r] = tt;
+        }
       }
     }
-  }
-  // ---- SFI source (elemental.jl:348-392) -----------------------------------------------------------------------
-  float vjp = 0.0f, vjm = 0.0f;
-  if (THERMAL) {
-    if (tid < N && tid % ns == 0 && mus[tid] > num<float>::eps())
-      vjp = vjm = 6.283185307179586476925286766559f * (1.0f - w) * F0[s] * (-expm1(-d / mus[tid]));
-  } else if (tid < N) {
-    const int i = tid;
-    const int i_start = ns * q.i_mu0;
-    const float wct02 = (m == 0) ? 0.5f : 0.25f;
-    float zp = 0, zm = 0;
-    for (int qq = 0; qq < ns; ++qq) {
-      const long long zo = i + (long long)N * (i_start + qq);
-      const float f = F0[qq + (long long)ns * s];
-      zp += zget(Zp, zo) * f;
-      zm += zget(Zm, zo) * f;
+    // ---- SFI source (elemental.jl:348-392) -----------------------------------------------------------------------
+    float vjp = 0.0f, vjm = 0.0f;
+    if (THERMAL) {
+      if (tid < N && tid % ns == 0 && mus[tid] > num<float>::eps())
+        vjp = vjm = 6.283185307179586476925286766559f * (1.0f - w) * F0[s] * (-expm1(-d / mus[tid]));
+    } else if (tid < N) {
+      const int i = tid;
+      const int i_start = ns * q.i_mu0;
+      const float wct02 = (m == 0) ? 0.5f : 0.25f;
+      float zp = 0, zm = 0;
+      for (int qq = 0; qq < ns; ++qq) {
+        const long long zo = i + (long long)N * (i_start + qq);
+        const float f = F0[qq + (long long)ns * s];
+        zp += zget(Zp, zo) * f;
+        zm += zget(Zm, zo) * f;
+      }
+      const float mi = mus[i], ms = mus[i_start];
+      if (i >= i_start && i < i_start + ns)
+        vjp = wct02 * w * zp * (d / mi) * exp(-d / mi);
+      else
+        vjp = wct02 * w * zp * (ms / (mi - ms)) * expdiff_neg<float>(d / mi, d / ms);
+      vjm = wct02 * w * zm * (ms / (mi + ms)) * (-expm1(-d * ((1.0f / mi) + (1.0f / ms))));
+      const float att = exp(-tau_sum[s] / ms);
+      vjp *= att;
+      vjm *= att;
+      if (ndoubl >= 1 && is_uv_row(i, ns)) vjm = -vjm;
     }
-    const float mi = mus[i], ms = mus[i_start];
-    if (i >= i_start && i < i_start + ns)
-      vjp = wct02 * w * zp * (d / mi) * exp(-d / mi);
-    else
-      vjp = wct02 * w * zp * (ms / (mi - ms)) * expdiff_neg<float>(d / mi, d / ms);
-    vjm = wct02 * w * zm * (ms / (mi + ms)) * (-expm1(-d * ((1.0f / mi) + (1.0f / ms))));
-    const float att = exp(-tau_sum[s] / ms);
-    vjp *= att;
-    vjm *= att;
-    if (ndoubl >= 1 && is_uv_row(i, ns)) vjm = -vjm;
+    if (ndoubl > 0) {
+      store_strip(P, r_s, p);
+      store_strip(Q, t_s, p);
+    }
+    half_barrier(p);  // (the helper vectors mus.. are dead from here on)
+    jpair = 0;
+    if (tid < FNP) {
+      sm.vec[0][tid] = vjp;
+      sm.vec[1][tid] = vjm;
+    }
+    half_barrier(p);
+    expk0 = THERMAL ? 1.0f : exp(-d / q.mu0);
   }
-  if (ndoubl > 0) {
-    store_strip(P, r_s, p);
-    store_strip(Q, t_s, p);
-  }
-  half_barrier(p);  // (the helper vectors mus.. are dead from here on)
-  jpair = 0;
-  if (tid < FNP) {
-    sm.vec[0][tid] = vjp;
-    sm.vec[1][tid] = vjm;
-  }
-  half_barrier(p);
 
   // ---- doubling (rt_helpers.jl:102-166) ------------------------------------------------------------------------
-  float expk = THERMAL ? 1.0f : exp(-d / q.mu0);
+  const int N = q.N, ns = q.n_stokes;
+  const int tid = p.tid;
+  float expk = expk0;
   int slot = 0;
   const int mrow = 16 * p.wave + p.l15;   // row of the mat-vecs
   const bool mlead = p.kq == 0;
@@ -900,14 +945,15 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composi
                   a.d_symmetric ? nullptr : a.t_mm + s * a.mat_stride, 0);
 }
 
-template <int KB, bool MIX, bool AL, bool THERMAL>
+template <int KB, bool MIX, bool AL, bool THERMAL, bool PRE = false>
 __device__ __forceinline__ void layer_body32(fsmem32& sm, fpos& p, const quad<float>& q, int S, int m, int ndoubl,
                                              const float* __restrict__ dtau, const float* __restrict__ varpi,
                                              const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                             const zsrc<float>& z, int toa, const composite<float>& c) {
+                                             const zsrc<float>& z, int toa, const composite<float>& c,
+                                             const float* __restrict__ img = nullptr) {
   fstrip r_s, t_s;
   int jpair;
-  ed_body<KB, MIX, THERMAL>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair);
+  ed_body<KB, MIX, THERMAL, PRE>(sm, p, q, m, ndoubl, dtau, varpi, tau_sum, F0, z, r_s, t_s, jpair, img);
   const int N = q.N, ns = q.n_stokes;
   if (toa) {
     const int s = p.s, tid = p.tid;
@@ -946,15 +992,130 @@ __global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32(quad<float> q, int
   VSM_HALF_PROLOGUE();
   layer_body32<KB, MIX, AL, THERMAL>(sm, p, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
 }
-// the same for several Fourier moments at once: blockIdx.y picks the moment's m, Z source and composite
-template <int KB, bool MIX, bool AL>
-__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32_mm(quad<float> q, int S, int ndoubl, const float* __restrict__ dtau,
-                                                                 const float* __restrict__ varpi,
-                                                                 const float* __restrict__ tau_sum, const float* __restrict__ F0,
-                                                                 layer_mm_args<float> a, int toa) {
+// The same for several Fourier moments at once: blockIdx.y picks the moment's composite; the elemental layers come from the
+// pre-pass k_elemental_img32 as A-form images (see k_layer_strip_mm in vsm_strip.hip: in lockstep the elemental step of both
+// points idles the MFMA pipe of the whole CU -- a tenth of the layer step at C4's two doubling steps).
+struct layer_mm_comps32 {
+  composite<float> c[VSM_MM_MAX];
+};
+template <int KB, bool AL>
+__global__ __launch_bounds__(2 * FNT, 3) void k_layer_strip32_mm(quad<float> q, int S, int ndoubl, layer_mm_comps32 a, int toa,
+                                                                 const float* __restrict__ pre) {
   VSM_HALF_PROLOGUE();
   const int im = blockIdx.y;
-  layer_body32<KB, MIX, AL, false>(sm, p, q, S, a.m[im], ndoubl, dtau, varpi, tau_sum, F0, a.z[im], toa, a.c[im]);
+  const float* img = pre + ((long long)im * S + p.s) * PRE32_STRIDE;
+  layer_body32<KB, false, AL, false, true>(sm, p, q, S, 0, ndoubl, nullptr, nullptr, nullptr, nullptr, zsrc<float>{}, toa, a.c[im], img);
+}
+
+// Elemental pre-pass of k_layer_strip32_mm: elemental! incl. the SFI source (elemental.jl:289-392) for every (point, moment) of a
+// layer into A-form images (PRE32_STRIDE).  One 384-thread workgroup per (point, moment): thread = (column j, quarter of the rows),
+// so that a wave writes 64 consecutive words of an image row.
+template <bool MIX>
+__global__ __launch_bounds__(FNT) void k_elemental_img32(quad<float> q, int ndoubl, const float* __restrict__ dtau,
+                                                         const float* __restrict__ varpi, const float* __restrict__ tau_sum,
+                                                         const float* __restrict__ F0, layer_mm_args<float> a,
+                                                         float* __restrict__ pre) {
+  __shared__ float mus[FNP], xs[FNP], es[FNP], ems[FNP], sgs[FNP];
+  __shared__ int thick_flag;
+  const int s = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+  const int N = q.N, ns = q.n_stokes, m = a.m[im];
+  const zsrc<float> z = a.z[im];
+  const float d = dtau[s], w = varpi[s];
+  const int ncomp = MIX ? z.ncomp : 0;
+  const long long NNz = (long long)N * N;
+  const float* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+  const float* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+  float fk[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+  auto zget = [&](const float* Z, long long zo) {
+    if (ncomp == 0) return Z[zo];
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+    return acc;
+  };
+  if (tid == 0) thick_flag = 0;
+  __syncthreads();
+  if (tid < FNP) {
+    const bool in = tid < N;
+    const float mu = in ? q.mu[tid] : 1.0f;
+    const float x = d / mu;
+    mus[tid] = mu;
+    xs[tid] = x;
+    es[tid] = exp(-x);
+    ems[tid] = expm1(-x);
+    sgs[tid] = (ndoubl >= 1 && is_uv_row(tid, ns)) ? -1.0f : 1.0f;   // starred R* = D R (elemental.jl:403-422)
+    if (in && x >= 0.5f) thick_flag = 1;
+  }
+  __syncthreads();
+  const bool thick = thick_flag != 0;
+  float* out = pre + ((long long)im * gridDim.x + s) * PRE32_STRIDE;
+  float* R = out;
+  float* T = out + PRE32_IMG;
+  // thread = (quad of columns 4 jq .. 4 jq + 3, group of 6 rows): one 16-byte store per image and row, the row's table entries
+  // read once per four elements
+  const int jq = tid % (FNP / 4), rg = tid / (FNP / 4);
+  float mj[4], xj[4], aj[4], ej[4], wct[4];
+  bool act[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int j = 4 * jq + c;
+    const float wt = (j < N) ? q.wt[min(j, N - 1)] : 0.0f;
+    wct[c] = (m == 0) ? wt / 2.0f : wt / 4.0f;
+    act[c] = wct[c] > num<float>::eps();
+    mj[c] = mus[j];
+    xj[c] = xs[j];
+    aj[c] = ems[j];
+    ej[c] = es[j];
+  }
+#pragma unroll 1
+  for (int k = 0; k < FNP / 16; ++k) {
+    const int i = rg * (FNP / 16) + k;
+    const float mi = mus[i], xi = xs[i], ai = ems[i], ei = es[i], sg = sgs[i];
+    f4_t rv = {0.f, 0.f, 0.f, 0.f}, tv = {0.f, 0.f, 0.f, 0.f};
+    if (i < N) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = 4 * jq + c;
+        if (j < N) {
+          const long long zo = i + (long long)N * j;
+          float rr, tt;
+          elemental_pair<float>(w, zget(Zp, zo), zget(Zm, zo), mi, xi, ai, ei, mj[c], xj[c], aj[c], ej[c], wct[c], i == j, thick, rr, tt);
+          rv[c] = act[c] ? rr * sg : 0.0f;
+          tv[c] = act[c] ? tt : ((i == j) ? ei : 0.0f);
+        }
+      }
+    }
+    const unsigned o = (unsigned)(i * LDK + 4 * jq);
+    *reinterpret_cast<f4_t*>(R + o) = rv;
+    *reinterpret_cast<f4_t*>(T + o) = tv;
+    if (jq < (LDK - FNP) / 4) {   // the padding words of the row
+      const f4_t zero = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f4_t*>(R + o + FNP) = zero;
+      *reinterpret_cast<f4_t*>(T + o + FNP) = zero;
+    }
+  }
+  if (tid < FNP) {   // SFI source of the solar beam: the same formulas with the solar column (vsm_elemental.h)
+    const int i = tid, ic = min(i, N - 1);
+    const int i0 = ns * q.i_mu0;
+    float zp = 0.0f, zm = 0.0f;
+    for (int qq = 0; qq < ns; ++qq) {
+      const long long zo = ic + (long long)N * (i0 + qq);
+      const float f = F0[qq + (long long)ns * s];
+      zp += zget(Zp, zo) * f;
+      zm += zget(Zm, zo) * f;
+    }
+    float rr, tt;
+    elemental_pair<float>(w, zp, zm, mus[i], xs[i], ems[i], es[i], mus[i0], xs[i0], ems[i0], es[i0], (m == 0) ? 0.5f : 0.25f, false,
+                          thick, rr, tt);
+    const float att = exp(-tau_sum[s] / mus[i0]);
+    out[2 * PRE32_IMG + i] = (i < N) ? tt * att : 0.0f;
+    out[2 * PRE32_IMG + FNP + i] = (i < N) ? rr * att * sgs[i] : 0.0f;
+    out[2 * PRE32_IMG + 2 * FNP + i] = exp(-d / q.mu0);
+  }
 }
 
 template <typename K>
@@ -998,16 +1159,19 @@ static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const 
 template <int KB, bool AL>
 static int launch_layer32_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
                              const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st) {
-  static int prepared = enable_lds32(k_layer_strip32_mm<KB, false, AL>, "hipFuncSetAttribute(k_layer_strip32_mm)");
-  static int prepared_mix = enable_lds32(k_layer_strip32_mm<KB, true, AL>, "hipFuncSetAttribute(k_layer_strip32_mm mix)");
+  static int prepared = enable_lds32(k_layer_strip32_mm<KB, AL>, "hipFuncSetAttribute(k_layer_strip32_mm)");
   if (prepared) return prepared;
-  if (prepared_mix) return prepared_mix;
-  const dim3 grid((S + 1) / 2, nm), block(2 * FNT);
-  const size_t lds = 2 * sizeof(fsmem32);
+  float* pre = static_cast<float*>(scratch((size_t)nm * S * PRE32_STRIDE * sizeof(float), 3));
+  if (!pre) return VSM_ERR_HIP;
   if (a.z[0].ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip32_mm<KB, true, AL>), grid, block, lds, st, q, S, ndoubl, dtau, varpi, tau_sum, F0, a, toa);
+    hipLaunchKernelGGL((k_elemental_img32<true>), dim3(S, nm), dim3(FNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
   else
-    hipLaunchKernelGGL((k_layer_strip32_mm<KB, false, AL>), grid, block, lds, st, q, S, ndoubl, dtau, varpi, tau_sum, F0, a, toa);
+    hipLaunchKernelGGL((k_elemental_img32<false>), dim3(S, nm), dim3(FNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  VSM_LAUNCH_CHECK("k_elemental_img32");
+  layer_mm_comps32 cc;
+  for (int i = 0; i < VSM_MM_MAX; ++i) cc.c[i] = a.c[i];
+  const dim3 grid((S + 1) / 2, nm), block(2 * FNT);
+  hipLaunchKernelGGL((k_layer_strip32_mm<KB, AL>), grid, block, 2 * sizeof(fsmem32), st, q, S, ndoubl, cc, toa, pre);
   VSM_LAUNCH_CHECK("k_layer_strip32_mm");
   return VSM_OK;
 }

@@ -4,6 +4,7 @@
 #include "vsm_internal.h"
 #include "vsm_inverse.h"
 #include "vsm_lds.h"
+#include "vsm_elemental.h"
 
 namespace vsm {
 namespace {
@@ -112,54 +113,6 @@ __device__ __forceinline__ double dpp_swap1(double x) {
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
-}
-
-// exp(-xi) - exp(-xj)  (expdiff_neg, src/CoreRT/CoreKernel/rt_helpers.jl:32-40) from tabulated e = exp(-x), a = expm1(-x):
-//  * thin layers (every x < 1/2): a_i - a_j where the arguments are well separated (relative error 16 eps at most: the
-//    subtraction is exact, each a carries one rounding), otherwise e_j expm1(-(x_i - x_j)) with expm1 by its Taylor polynomial
-//    (|x_i - x_j| <= x_max / 8 < 1/16: degree 11, truncation < 2^-60 relative) -- no transcendental per matrix element;
-//  * otherwise the reference's form: exp(-min) (-expm1(-|x_i - x_j|)) with the sign of x_j - x_i; one expm1 per element.
-__device__ __forceinline__ double expm1_small(double y) {
-  double q = 1.0 / 39916800.0;
-  q = fma(q, y, 1.0 / 3628800.0);
-  q = fma(q, y, 1.0 / 362880.0);
-  q = fma(q, y, 1.0 / 40320.0);
-  q = fma(q, y, 1.0 / 5040.0);
-  q = fma(q, y, 1.0 / 720.0);
-  q = fma(q, y, 1.0 / 120.0);
-  q = fma(q, y, 1.0 / 24.0);
-  q = fma(q, y, 1.0 / 6.0);
-  q = fma(q, y, 0.5);
-  q = fma(q, y, 1.0);
-  return q * y;
-}
-__device__ __forceinline__ double expdiff_tab_thin(double xi, double xj, double ai, double aj, double ej) {
-  const double dlt = xi - xj;
-  return (fabs(dlt) > 0.125 * fmax(xi, xj)) ? (ai - aj) : ej * expm1_small(-dlt);
-}
-__device__ __forceinline__ double expdiff_tab_thick(double xi, double xj, double ei, double ej) {
-  const double dlt = xi - xj;
-  const double v = ((dlt < 0.0) ? ei : ej) * (-expm1(-fabs(dlt)));
-  return (dlt < 0.0) ? v : -v;   // (dlt == 0: v = 0)
-}
-
-// One element of the elemental layer (elemental.jl:289-334) from the per-row / per-column tables (x = dtau / mu, e = exp(-x),
-// a = expm1(-x)); straight-line selects instead of the reference's branches:
-//   r-+_ij = varpi Z-+_ij  mu_j / (mu_i + mu_j) w_j (1 - e^{-x_i} e^{-x_j}),   1 - e^{-x_i} e^{-x_j} = -(a_i + a_j + a_i a_j)
-//   t++_ij = varpi Z++_ij  mu_j / (mu_i - mu_j) w_j (e^{-x_i} - e^{-x_j})      (mu_i != mu_j)
-//          = delta_ij e^{-x_i} + e^{-x_j} varpi Z++_ij x_i w_j                 (mu_i == mu_j)
-// The SFI source (elemental.jl:348-392) has the same form with the solar column in place of column j (mu_j -> mu_0,
-// x_j -> dtau / mu_0, w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q): j0+ is the "t" formula, j0- the "r" one.
-__device__ __forceinline__ void elemental_pair(double w, double zp, double zm, double mi, double xi, double ai, double ei,
-                                               double mj, double xj, double aj, double ej, double wct, bool diag, bool thick,
-                                               double& rr, double& tt) {
-  rr = w * zm * (mj / (mi + mj)) * wct * (-(ai + aj + ai * aj));
-  double ediff;
-  if (thick) ediff = expdiff_tab_thick(xi, xj, ei, ej); else ediff = expdiff_tab_thin(xi, xj, ai, aj, ej);
-  const double t_off = w * zp * (mj / (mi - mj)) * wct * ediff;
-  const double t_1 = w * zp * xi * wct;
-  const double t_same = diag ? ei * (1.0 + t_1) : ej * t_1;
-  tt = (mi == mj) ? t_same : t_off;
 }
 
 // Added layer of the elemental pre-pass (k_elemental_img) in global memory, per (moment, point): the two A-form IMAGES [r-+*],
