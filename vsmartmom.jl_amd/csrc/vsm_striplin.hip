@@ -256,7 +256,9 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   const double k = expk[s];
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
-  auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
+  // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
+  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  auto asis = [](double x, int, int) { return x; };
 
   if (!EXPD_NO_STAGE) stage_aform_full2(BR, g_r, BT, g_t, N, p);
   if (tid < SNP) {
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     load_strip(r_s, BR, p);
     E.zero();
     if (!EXPD_NO_MMA) mm_ab<KS>(E, BR, r_s, p);
-    invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+    invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
   }
   sp.put(t_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
   {
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     rt.zero();
     if (!EXPD_NO_MMA) mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
     __syncthreads();             // BT (t) and BY (series powers) no longer read
-    store_strip(BT, tt, p, keepN);
+    store_strip(BT, tt, p, asis);
   }
   sp.put(rt, p, [&](int row, double o) { return jm[row] * k + o; }, [&](int row, double o) { return jp[row] + o; });
   __syncthreads();   // tt complete in BT
@@ -336,14 +338,14 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
       load_strip(Y, BY, p);      // tdot
       if (!EXPD_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
       __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
-      store_strip(BY, Y, p, keepN);
+      store_strip(BY, Y, p, asis);
     }
     __syncthreads();   // Y complete in BY
     {
       sstrip ttl;
       ttl.zero();
       if (!EXPD_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, keepN);
+      store_strip(BX, ttl, p, asis);
     }
     sstrip rd, tdn;
     load_strip_global_c(rd, g_ar, N, p, xw);
@@ -406,7 +408,9 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   double kl[PA];
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
-  auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
+  // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
+  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  auto asis = [](double x, int, int) { return x; };
   // a strip with its two spare columns cleared (they carry riders during a product)
   auto clean = [&](sstrip& x) { sp.put(x, p, [](int, double) { return 0.0; }, [](int, double) { return 0.0; }); };
   // the riders of a result strip go back to the LDS vectors (only the wave that owns the spare columns touches them)
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   int slot = 0;
   for (int n = 0; n < nd; ++n) {
     // on entry: BR = [r] stored (visible after the barrier below), t_s / rd_s / td_s clean strips, vectors in LDS
-    store_strip(BT, t_s, p, keepN);
+    store_strip(BT, t_s, p, asis);
     __syncthreads();
     auto load_r_with_riders = [&](sstrip& x) {
       load_strip(x, BR, p);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
       load_strip(r_s, BR, p);
       E.zero();
       mm_ab<KS>(E, BR, r_s, p);
-      invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+      invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
     }
     sp.put(t_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
     {
@@ -467,7 +471,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
       rt.zero();
       mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
       __syncthreads();             // BT (t) and BY (series powers) no longer read
-      store_strip(BT, tt, p, keepN);
+      store_strip(BT, tt, p, asis);
     }
     sp.put(rt, p, [&](int row, double o) { return jm[row] * k + o; }, [&](int row, double o) { return jp[row] + o; });
     // ---- the parameters ----------------------------------------------------------------------------------------------------
@@ -477,8 +481,8 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
       double* ajm = sm.vec[3 + 2 * pp];
       sstrip& rd = rd_s[pp];
       sstrip& td = td_s[pp];
-      store_strip(BX, rd, p, keepN);   // [rdot_p] -> BX, [tdot_p] -> BY  (both free: barrier above / end of the previous parameter)
-      store_strip(BY, td, p, keepN);
+      store_strip(BX, rd, p, asis);   // [rdot_p] -> BX, [tdot_p] -> BY  (both free: barrier above / end of the previous parameter)
+      store_strip(BY, td, p, asis);
       __syncthreads();   // tt complete in BT (first parameter), rdot_p / tdot_p complete
       sstrip X1, Q2;
       X1.zero();
@@ -508,14 +512,14 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
         sstrip Y = td;
         mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
         __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
-        store_strip(BY, Y, p, keepN);
+        store_strip(BY, Y, p, asis);
       }
       __syncthreads();   // Y complete in BY
       {
         sstrip ttl;
         ttl.zero();
         mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-        store_strip(BX, ttl, p, keepN);
+        store_strip(BX, ttl, p, asis);
       }
       sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl[pp]; });
       sstrip tdn;
@@ -544,7 +548,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
     r_new = r_s;
     k = k * k;
     __syncthreads();   // everybody is done reading BR, BT, BX, BY of this step
-    if (n + 1 < nd) store_strip(BR, r_new, p, keepN);
+    if (n + 1 < nd) store_strip(BR, r_new, p, asis);
   }
   // apply_D! with derivative slots (doubling_lin.jl:374-421) on the way out when ns > 0: r-+ gets its U,V rows negated,
   // r+- = D r-+ D and t-- = D t++ D are derived (also for the derivatives; the slots of the inactive parameters are zero)
@@ -641,7 +645,9 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   const int Kend = ((N + 3) >> 2) << 2;
   const spare sp(p, Kend);
   double* xw = sm.xw[p.wave];
-  auto keepN = [N](double x, int r, int c) { return (r < N && c < N) ? x : 0.0; };
+  // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
+  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  auto asis = [](double x, int, int) { return x; };
   auto keep_old = [](int, double o) { return o; };
 
 #ifdef VSM_IA_LIN_ASYNC_LOADS
@@ -672,7 +678,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     sstrip E;
     E.zero();
     mm_ab<KS>(E, BR, er, p);
-    invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+    invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
   }
   sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
   {
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     rt.zero();
     mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
     __syncthreads();            // BT (LT) and BY (series powers) no longer read
-    store_strip(BT, tt, p, keepN);
+    store_strip(BT, tt, p, asis);
   }
   sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
   __syncthreads();   // tt complete in BT
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       sstrip Y;
       finish_strip_load(Y, w_y, p, xw);
       mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
-      store_strip(BY, Y, p, keepN);
+      store_strip(BY, Y, p, asis);
     }
     sstrip acc;
     finish_strip_load(acc, w_acc, p, xw);
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       sstrip ttl;
       ttl.zero();
       mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, keepN);
+      store_strip(BX, ttl, p, asis);
     }
     sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
     sstrip tdn, s3;
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     sstrip E;
     E.zero();
     if (!EXP_NO_MMA) mm_ab<KS>(E, BR, er, p);
-    invert_strip<KS>(E, G, BY, N, sm, slot, p, 0);
+    invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
   }
   sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
   {
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     rt.zero();
     if (!EXP_NO_MMA) mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
     __syncthreads();            // BT (LT) and BY (series powers) no longer read
-    store_strip(BT, tt, p, keepN);
+    store_strip(BT, tt, p, asis);
   }
   sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
   __syncthreads();   // tt complete in BT
@@ -817,7 +823,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       sstrip Y;
       if (EXP_NO_LOAD) Y.zero(); else load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
       if (!EXP_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
-      store_strip(BY, Y, p, keepN);
+      store_strip(BY, Y, p, asis);
     }
     sstrip acc;
     if (EXP_NO_LOAD) acc.zero(); else load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
       sstrip ttl;
       ttl.zero();
       if (!EXP_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, keepN);
+      store_strip(BX, ttl, p, asis);
     }
     sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
     sstrip tdn, s3;
