@@ -573,9 +573,11 @@ int vsm_doubling_inelastic_rrs_f64(int N, int n_stokes, int S, int ndoubl, doubl
                                    const vsm_added_f64* added, const vsm_added_rs_f64* added_rs, double* work, void* stream);
 int vsm_doubling_inelastic_rrs_f32(int N, int n_stokes, int S, int ndoubl, float* expk, const int* shift,
                                    const vsm_added_f32* added, const vsm_added_rs_f32* added_rs, float* work, void* stream);
-/* interaction_helper!(::RRS, ::ScatteringInterface_11) (CoreKernel/interaction_inelastic.jl:319-521): updates the
- * inelastic composite from pre-update elastic/inelastic values, then the elastic composite.  Other interface tags
- * return VSM_ERR_UNSUPPORTED (the RRS rt_kernel! hard-wires scatter = true, rt_kernel.jl:365).  `added` may be a
+/* interaction!(RS_type::RRS, scattering_interface, ...) (CoreKernel/interaction_inelastic.jl:523-539): updates the
+ * inelastic composite from pre-update elastic/inelastic values, then the elastic composite.  iface = VSM_IFACE_11:
+ * interaction_helper!(::RRS, ::ScatteringInterface_11) (:319-521, fused line kernels for N <= 30); VSM_IFACE_00 / _01 / _10:
+ * the statements of :74-101, :103-154, :215-262 over the in-band (recipient, line) pairs, operator level (the RRS rt_kernel!
+ * hard-wires scatter = true, rt_kernel.jl:365, but dispatches the interaction on the tag, :385).  `added` may be a
  * shared-block surface layer (mat_stride 0) with an all-zero added_rs.
  * work: vsm_interaction_inelastic_work_elems(N,S,K) elements. */
 size_t vsm_interaction_inelastic_work_elems(int N, int S, int K);

@@ -327,8 +327,51 @@ def interaction_inelastic_11(rs: RRS, comp: O.CompositeLayer, crs: CompositeLaye
         getattr(crs, f)[...] = getattr(new, f)
 
 
+def interaction_inelastic(iface, rs: RRS, comp: O.CompositeLayer, crs: CompositeLayerRS, add: O.AddedLayer, ars: AddedLayerRS, FT):
+    """interaction!(RS_type::RRS, scattering_interface, ...) (interaction_inelastic.jl:523-539) for the four interface tags.
+    _00 / _01 / _10 follow the statements of interaction_inelastic.jl:74-101, 103-154, 215-262 over the in-band (n1, dn) pairs
+    (their loop headers name an undefined `ieJ1+` upstream, so the branches cannot run there as committed; out-of-band blocks of
+    the composite become / stay zero as in the _11 pass).  Inelastic right-hand sides use the pre-update elastic composite."""
+    if iface == "11":
+        return interaction_inelastic_11(rs, comp, crs, add, ars, FT)
+    S = add.r_mp.shape[0]
+    mv = O._mv
+    if iface == "00":
+        for f in ("ieJ0_m", "ieJ0_p", "ieT_mm", "ieR_mp", "ieT_pp", "ieR_pm"):
+            getattr(crs, f)[...] = 0
+    elif iface == "01":
+        new = make_composite_layer_rs(FT, len(rs.i_shift), add.r_mp.shape[1], S)
+        for dn, shift in enumerate(rs.i_shift):
+            n0, n1 = get_n0_n1(S, int(shift))
+            if n1.stop <= n1.start:
+                continue
+            new.ieJ0_m[dn, n1] = mv(comp.T_mm[n1], mv(ars.ier_mp[dn, n1], comp.J0_p[n0]) + ars.ieJ0_m[dn, n1])
+            new.ieJ0_p[dn, n1] = ars.ieJ0_p[dn, n1] + mv(ars.iet_pp[dn, n1], comp.J0_p[n0])
+            new.ieR_mp[dn, n1] = comp.T_mm[n1] @ ars.ier_mp[dn, n1] @ comp.T_pp[n0]
+            new.ieR_pm[dn, n1] = ars.ier_pm[dn, n1]
+            new.ieT_pp[dn, n1] = ars.iet_pp[dn, n1] @ comp.T_pp[n0]
+            new.ieT_mm[dn, n1] = comp.T_mm[n1] @ ars.iet_mm[dn, n1]
+        for f in ("ieJ0_m", "ieJ0_p", "ieT_mm", "ieR_mp", "ieT_pp", "ieR_pm"):
+            getattr(crs, f)[...] = getattr(new, f)
+    elif iface == "10":
+        for dn, shift in enumerate(rs.i_shift):
+            n0, n1 = get_n0_n1(S, int(shift))
+            if n1.stop <= n1.start:
+                continue
+            Jp = mv(add.t_pp[n1], crs.ieJ0_p[dn, n1] + mv(crs.ieR_pm[dn, n1], add.j0_m[n0]))
+            Jm = crs.ieJ0_m[dn, n1] + mv(crs.ieT_mm[dn, n1], add.j0_m[n0])
+            Tpp = add.t_pp[n1] @ crs.ieT_pp[dn, n1]
+            Tmm = crs.ieT_mm[dn, n1] @ add.t_mm[n0]
+            Rpm = add.t_pp[n1] @ crs.ieR_pm[dn, n1] @ add.t_mm[n0]
+            crs.ieJ0_p[dn, n1], crs.ieJ0_m[dn, n1] = Jp, Jm
+            crs.ieT_pp[dn, n1], crs.ieT_mm[dn, n1], crs.ieR_pm[dn, n1] = Tpp, Tmm, Rpm
+    else:
+        raise ValueError(iface)
+    O.interaction(iface, comp, add, FT)
+
+
 def rt_kernel_rrs(rs: RRS, pol, added, add_rs, comp, comp_rs, props, tau_sum, m, qp, iz, F0, FT,
-                  numerics: O.Numerics = O.Numerics(), trace=None):
+                  numerics: O.Numerics = O.Numerics(), trace=None, iface="11"):
     """src/CoreRT/CoreKernel/rt_kernel.jl:352-391 (scatter hard-wired to true, :365)."""
     tau, varpi = props.tau, props.varpi
     dtau, ndoubl = O.get_dtau_ndoubl(tau, varpi, qp, FT, numerics)
@@ -341,7 +384,7 @@ def rt_kernel_rrs(rs: RRS, pol, added, add_rs, comp, comp_rs, props, tau_sum, m,
     if iz == 1:
         copy_added_to_composite_ie(comp, comp_rs, added, add_rs)
     else:
-        interaction_inelastic_11(rs, comp, comp_rs, added, add_rs, FT)
+        interaction_inelastic(iface, rs, comp, comp_rs, added, add_rs, FT)   # dispatched on the tag (rt_kernel.jl:385)
 
 
 def postprocessing_vza_rs(pol, comp, comp_rs, vza, vaz, qp, m, weight, R_SFI, T_SFI, ieR_SFI, ieT_SFI):
@@ -388,14 +431,14 @@ def rt_run_rrs(model: O.RTModel, rs: RRS, fscatt=None, trace=None, per_m=None):
         weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
         rs.Zpp_ie, rs.Zmp_ie = O.compute_Z_moments(pol, qp.qp_mu, rs.greek_raman, m)
         lods = O.construct_core_optical_properties(model, m)
-        _, tau_sum_all = O.extract_effective_props(lods, FT)
+        ifaces, tau_sum_all = O.extract_effective_props(lods, FT)
         for iz in range(L):
             rs.fscatt_rayl = np.asarray(fscatt[:, iz], dtype=FT)
             lo = O.expand_optical_properties(lods[iz], FT)
             rt_kernel_rrs(rs, pol, added, add_rs, comp, comp_rs, lo, tau_sum_all[:, iz].astype(FT), m, qp, iz + 1, F0, FT,
-                          model.numerics, trace)
+                          model.numerics, trace, ifaces[iz])
         O.create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
-        interaction_inelastic_11(rs, comp, comp_rs, added_surf, surf_rs, FT)
+        interaction_inelastic(ifaces[-1], rs, comp, comp_rs, added_surf, surf_rs, FT)
         if per_m is not None:
             per_m.append(dict(m=m, J0_m=comp.J0_m.copy(), J0_p=comp.J0_p.copy(), ieJ0_m=comp_rs.ieJ0_m.copy(),
                               ieJ0_p=comp_rs.ieJ0_p.copy(), weight=weight))

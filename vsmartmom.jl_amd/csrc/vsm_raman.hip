@@ -627,6 +627,60 @@ static int interaction_inelastic_rrs(int N, int S, const int* shift, const compo
 #undef G3
 #undef G4
 
+// ---------------------------------------------------------------------------
+// interaction_helper!(::RRS, ::ScatteringInterface_00 / _01 / _10)   (interaction_inelastic.jl:74-101, 103-154, 215-262)
+// Operator level: one launch per batched operator over all (recipient, line) pairs; out-of-band blocks of the composite become
+// (stay) zero, like the _11 pass.  The inelastic statements use the pre-update elastic composite; the elastic update comes last.
+// (Upstream these three branches cannot run as committed: their loop headers name an undefined `ieJ1+`, :109,:221 -- the
+// statements themselves are followed here.)
+// ---------------------------------------------------------------------------
+template <typename T>
+static int interaction_inelastic_rrs_plain(int iface, int N, int S, const int* shift, const composite<T>& c,
+                                           const composite_rs<T>& cie, const added<T>& a, const added_rs<T>& aie, T* work,
+                                           hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int K = cie.K;
+  const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
+  const long long as = a.mat_stride;
+  T* W1 = work;
+  T* V1 = W1 + per * K;
+  T* ework = V1 + pv * K;
+  const rs_op<T> none{nullptr, 0, 0};
+  int rc;
+#define GZ(M_, Nc_, A_, B_, C_, D_) if ((rc = gemm_rs<T>(M_, Nc_, N, S, K, shift, A_, B_, C_, D_, st, 1))) return rc
+  if (iface == VSM_IFACE_00) {
+    for (T* x : {cie.ieR_mp, cie.ieR_pm, cie.ieT_pp, cie.ieT_mm})
+      VSM_HIP(hipMemsetAsync(x, 0, sizeof(T) * (size_t)(per * K), st));
+    for (T* x : {cie.ieJ0_p, cie.ieJ0_m}) VSM_HIP(hipMemsetAsync(x, 0, sizeof(T) * (size_t)(pv * K), st));
+  } else if (iface == VSM_IFACE_01) {
+    // ieJ0- = T--[n1] (ier-+ J0+[n0] + iej0-) ;  ieJ0+ = iej0+ + iet++ J0+[n0]
+    GZ(N, 1, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.J0_p, N), V1, at_4d<T>(aie.ieJ0_m, N));
+    GZ(N, 1, at_n1<T>(c.T_mm, NN), at_4d<T>(V1, N), cie.ieJ0_m, none);
+    GZ(N, 1, at_4d<T>(aie.iet_pp, NN), at_n0<T>(c.J0_p, N), cie.ieJ0_p, at_4d<T>(aie.ieJ0_p, N));
+    // ieR-+ = T--[n1] ier-+ T++[n0] ;  ieR+- = ier+- ;  ieT++ = iet++ T++[n0] ;  ieT-- = T--[n1] iet--
+    GZ(N, N, at_4d<T>(aie.ier_mp, NN), at_n0<T>(c.T_pp, NN), W1, none);
+    GZ(N, N, at_n1<T>(c.T_mm, NN), at_4d<T>(W1, NN), cie.ieR_mp, none);
+    if ((rc = copy_strided<T>(per * K, 1, aie.ier_pm, 0, cie.ieR_pm, st))) return rc;
+    GZ(N, N, at_4d<T>(aie.iet_pp, NN), at_n0<T>(c.T_pp, NN), cie.ieT_pp, none);
+    GZ(N, N, at_n1<T>(c.T_mm, NN), at_4d<T>(aie.iet_mm, NN), cie.ieT_mm, none);
+  } else {   // VSM_IFACE_10
+    // ieJ0+ = t++[n1] (ieJ0+ + ieR+- j0-[n0]) ;  ieJ0- += ieT-- j0-[n0]
+    GZ(N, 1, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.j0_m, N), V1, at_4d<T>(cie.ieJ0_p, N));
+    GZ(N, 1, at_n1<T>(a.t_pp, as), at_4d<T>(V1, N), cie.ieJ0_p, none);
+    GZ(N, 1, at_4d<T>(cie.ieT_mm, NN), at_n0<T>(a.j0_m, N), V1, at_4d<T>(cie.ieJ0_m, N));
+    if ((rc = copy_strided<T>(pv * K, 1, V1, 0, cie.ieJ0_m, st))) return rc;
+    // ieT++ = t++[n1] ieT++ ;  ieT-- = ieT-- t--[n0] ;  ieR+- = t++[n1] ieR+- t--[n0]   (through W1: no operand is its own output)
+    GZ(N, N, at_n1<T>(a.t_pp, as), at_4d<T>(cie.ieT_pp, NN), W1, none);
+    if ((rc = copy_strided<T>(per * K, 1, W1, 0, cie.ieT_pp, st))) return rc;
+    GZ(N, N, at_4d<T>(cie.ieT_mm, NN), at_n0<T>(a.t_mm, as), W1, none);
+    if ((rc = copy_strided<T>(per * K, 1, W1, 0, cie.ieT_mm, st))) return rc;
+    GZ(N, N, at_4d<T>(cie.ieR_pm, NN), at_n0<T>(a.t_mm, as), W1, none);
+    GZ(N, N, at_n1<T>(a.t_pp, as), at_4d<T>(W1, NN), cie.ieR_pm, none);
+  }
+#undef GZ
+  return interaction_generic<T>(iface, N, S, c, a, ework, st);
+}
+
 // postprocessing_vza!(::RRS) inelastic accumulation (postprocessing_vza.jl:139-142):
 // ieR[v,k,s] += w[v,k] * sum_dn ieJ0-[row0[v]+k, s, dn]
 struct pp_rs_args {
@@ -722,15 +776,14 @@ size_t vsm_interaction_inelastic_work_elems(int N, int S, int K) { return intera
                                           const vsm_composite_rs_##SFX* comp_rs, const vsm_added_##SFX* added_,        \
                                           const vsm_added_rs_##SFX* added_rs_, T* work, void* stream) {                \
     VSM_REQUIRE(comp && comp_rs && added_ && added_rs_ && shift && work, "interaction_inelastic_rrs: null argument");  \
-    if (iface != VSM_IFACE_11) {                                                                                       \
-      set_error("interaction_inelastic_rrs: only ScatteringInterface_11 exists for RRS (rt_kernel.jl:365 hard-wires "  \
-                "scatter = true)");                                                                                    \
-      return VSM_ERR_UNSUPPORTED;                                                                                      \
-    }                                                                                                                  \
+    VSM_REQUIRE(iface >= 0 && iface <= 3, "interaction_inelastic_rrs: unknown scattering interface %d", iface);         \
     VSM_REQUIRE(added_->d_symmetric == 0 && added_->r_pm && added_->t_mm,                                              \
                 "interaction_inelastic_rrs: a full (non d_symmetric) AddedLayer is required");                         \
     VSM_REQUIRE(N > 0 && S >= 0 && S <= 65535 && comp_rs->K == added_rs_->K && comp_rs->K >= 0 && comp_rs->K <= 65535, \
                 "interaction_inelastic_rrs: bad N/S/K");                                                               \
+    if (iface != VSM_IFACE_11)                                                                                         \
+      return interaction_inelastic_rrs_plain<T>(iface, N, S, shift, cvt_comp_rs<T>(comp), cvt_crs<T>(comp_rs),        \
+                                                cvt_added_rs<T>(added_), cvt_ars<T>(added_rs_), work, as_stream(stream)); \
     return interaction_inelastic_rrs<T>(N, S, shift, cvt_comp_rs<T>(comp), cvt_crs<T>(comp_rs), cvt_added_rs<T>(added_), \
                                         cvt_ars<T>(added_rs_), work, 0, as_stream(stream));                            \
   }                                                                                                                    \
