@@ -122,7 +122,6 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const int c1 = Kend, c2 = Kend + 1;
   const bool own_wave = (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
-  const double mAB = laneAB ? 1.0 : 0.0;
   double expk0;
   if constexpr (PRE) {
     // the elemental layer of the pre-pass: images -> P, Q (LDS DMA), vectors, sign tables
@@ -192,7 +191,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     // w_j -> (1 + delta_m0) / 4, Z_ij -> sum_q Z_{i, i0 + q} F0_q):  j0+ is the "t" formula, j0- the "r" formula, times the beam
     // attenuation exp(-tau_sum / mu_0).  The lanes that own the spare columns c1, c2 (never read as a contraction index) evaluate
     // them in place of their (zero) matrix elements and leave them where the doubling loop wants them (see below):
-    //   t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk     (ndoubl > 0)
+    //   t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j0+     (ndoubl > 0)
     expk0 = THERMAL ? 1.0 : exp(-d / q.mu0);
     {
       const int j = p.col;
@@ -245,7 +244,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
             }
             if (laneAB) {
               tv = riders_in ? (laneA ? vp : vm * expk0) : 0.0;
-              rv = riders_in ? (laneA ? vm : vp * expk0) : 0.0;
+              rv = riders_in ? (laneA ? vm : vp) : 0.0;
             }
             double* dp = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
             double* dm = laneA ? jm : sm.vec[7];
@@ -275,10 +274,11 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   // inherits zero rows from its A operand and zero columns from its B operand), so the A-form stores need no mask.
   // Sources (rt_helpers.jl:128-134: j0- += tt (j1- + r j0+), j0+ = j1+ + tt (j0+ + r j1-)) ride in the spare columns
   // c1, c2 (>= 4 KS: never read as a contraction index) of the strips that are live anyway, for the WHOLE loop:
-  //   t_s[c1] = j0+, t_s[c2] = j1- = j0- expk  ->  W[c1] = r j0+, W[c2] = r j1-;  swap-add:  W[c1] += j1-, W[c2] += j0+
-  //   r_s[c1] = j0-, r_s[c2] = j1+ = j0+ expk  ->  r'[c1] = j0- + tt (j1- + r j0+), r'[c2] = j1+ + tt (j0+ + r j1-)
-  // -- the reference's statements term for term; the two lanes that own the columns exchange with one DPP swap: no LDS
-  // traffic, no extra live registers.
+  //   t_s[c1] = j0+, t_s[c2] = j1- = j0- expk  ->  W[c1] = r j0+, W[c2] = r j1-
+  //   r_s[c1] = j0-, r_s[c2] = j0+             ->  W[c1] += r_s[c1] expk (= j1-), W[c2] += r_s[c2] (= j0+), r_s[c2] *= expk (= j1+):
+  //                                                lane-local;  r'[c1] = j0- + tt (j1- + r j0+), r'[c2] = j1+ + tt (j0+ + r j1-)
+  // -- the reference's statements term for term.  The new j0-', j0+' are already where r_s wants them; the t_s riders of the
+  // next step come from the neighbour lane with one DPP quad swap per element: no LDS traffic, no extra live registers.
   double expk = expk0;
   int slot = 0;
   auto asis = [](double a, int, int) { return a; };
@@ -287,6 +287,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     // on entry: P = [r], Q = [t] (A-forms incl. the rider columns), r_s / t_s in registers, all waves past a barrier
     sstrip W;
     sstrip tt;
+    const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
     {
       sstrip G;
       {
@@ -294,11 +295,15 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
         E.zero();
         W.zero();
         mm_ab2<KS>(E, W, P, r_s, t_s, p);
-        if (own_wave) {   // W[c1] += j1-, W[c2] += j0+ (neighbour lanes: one DPP quad swap; mAB = 1 on the two rider lanes, else 0)
+        if (own_wave) {   // W[c1] += j1- = j0- expk (lane c1 holds j0- in r_s), W[c2] += j0+ (lane c2 holds it in r_s); then
+                          // r_s[c2] -> j1+ = j0+ expk, the addend of the second product: all lane-local
 #pragma unroll
           for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W.v[ta][r] = fma(dpp_swap1(t_s.v[ta][r]), mAB, W.v[ta][r]);
+            for (int r = 0; r < 4; ++r) {
+              W.v[ta][r] = fma(r_s.v[ta][r], fW, W.v[ta][r]);
+              r_s.v[ta][r] *= fR;
+            }
         }
         VSM_RSTAMP(1);
         invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (masks the rider columns of E; its first barrier: [r] is free)
@@ -321,15 +326,13 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     VSM_RSTAMP(4);
     expk = expk * expk;
     if (own_wave) {
-      const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk';  r_s[c2] = j1+' = j0+' expk'
+      const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk';  r_s[c1] = j0-', r_s[c2] = j0+' stay
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const double x = r_s.v[ta][r];                    // lane A: j0-'   lane B: j0+'
-          const double u = dpp_swap1(x) * ft;               // lane A: j0+'   lane B: j0-' expk'
+          const double u = dpp_swap1(r_s.v[ta][r]) * ft;   // lane A: j0+'   lane B: j0-' expk'
           t_s.v[ta][r] = laneAB ? u : t_s.v[ta][r];
-          r_s.v[ta][r] = x * ft;                            // (ft = 1 away from lane B)
         }
     }
     VSM_RSTAMP(5);
@@ -965,11 +968,11 @@ __global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoub
     out[2 * PRE_IMG + i] = vp;
     out[2 * PRE_IMG + SNP + i] = vm;
     out[2 * PRE_IMG + 2 * SNP + i] = expk0;
-    if (riders_in) {   // t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j1+ = j0+ expk
+    if (riders_in) {   // t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j0+
       T[lidx<SNP>(i, c1)] = vp;
       T[lidx<SNP>(i, c2)] = vm * expk0;
       R[lidx<SNP>(i, c1)] = vm;
-      R[lidx<SNP>(i, c2)] = vp * expk0;
+      R[lidx<SNP>(i, c2)] = vp;
     }
   }
 }

@@ -381,7 +381,9 @@ __device__ __forceinline__ void invert_strip_horner_k(int K, sstrip& E, sstrip& 
     G = Gs;
     return;
   }
-  if (p.col >= N) E.zero();   // the rider / padding columns (rows >= N are zero by construction)
+  // The rider columns (>= N) of E are NOT cleared: every product of the series (and every product that takes G as its right
+  // operand afterwards) maps a column of B to the same column of the result, so whatever rides there stays there -- in columns
+  // that are never read as a contraction index and never stored to the composite.  (Rows >= N are zero by construction.)
   if (K == 1) {
     G = E;
   } else {
