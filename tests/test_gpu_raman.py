@@ -362,6 +362,23 @@ def test_rt_run_rrs_halo_shard_equals_full(vsm, arch):
                 assert _rel(g, f[:, :, sl]) <= 1e-13
 
 
+def test_rt_run_rrs_blocked_equals_one_pass(vsm, arch):
+    """rt_run(RRS, ..., max_points = n): the recipient axis walked in halo-extended blocks (the bounded-footprint mode that replaces
+    the reference's host paging of the N x N x nSpec x nRaman arrays) == the one-pass run, bit for bit, also when the last block
+    is ragged and the blocks are shorter than the halo."""
+    om, pm = _raman_models(vsm, arch, "IQU", 7, 37, 3, np.float64)
+    graman = O.get_greek_rayleigh(6.0 / 7.0 * 0.5)
+    prs = vsm.CoreRTRaman.RRS(SHIFTS, W_IE, vsm.host_model.GreekCoefs(**vars(graman)))
+    full = vsm.CoreRTRaman.rt_run(prs, pm, 1)
+    for n in (10, 3):
+        blk = vsm.CoreRTRaman.rt_run(prs, pm, 1, max_points=n)
+        for a, b in zip(full, blk):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    dev = vsm.CoreRTRaman.rt_run(prs, pm, 1, max_points=16, device_out=True)
+    assert dev[2].shape[0] == 37 and np.array_equal(vsm.Architectures.to_host(dev[2]).transpose(2, 1, 0), full[2])
+    assert vsm.CoreRTRaman.raman_bytes_per_point(21, 40, 8) * 20000 > 50e9     # the C5 shape: 60 GB in one pass (measured)
+
+
 @pytest.mark.parametrize("FT", [np.float64, np.float32])
 def test_rt_run_rrs_reference_regression_phase1b(vsm, arch, golden_dir, FT):
     """The reference's own RRS regression (test/test_forward_raman_phase1b.jl; the stored run is Float32): device
@@ -431,3 +448,43 @@ def test_c5_full_size_raman_properties(vsm, arch):
     part = vsm.CoreRTRaman.rt_run(rs, pm, 1, spec_slice=sl)
     for g, f in zip(part, (R, T, ieR, ieT)):
         assert g.shape[2] == S // 2 and _rel(g, f[:, :, sl]) <= 1e-13
+
+
+def test_c5_k100_blocked_full_size(vsm, arch):
+    """The C5 shape with K = 100 Raman lines (nStokes = 3, N = 21, 20 000 points, 12 layers): 150 GB of N x N x nSpec x nRaman
+    arrays in one pass.  Walked in blocks of 4 000 recipient points (+ halo: 31 GB per block) it reproduces the perturbation
+    identity of test_c5_full_size_raman_properties on the spectrally uniform column, and a window of it equals the direct
+    halo-extended run of that window bit for bit."""
+    FT, S, L, K = np.float64, 20000, 12, 100
+    Hm = vsm.host_model
+    dp = np.full(L, 1.0 / L)
+    tau_rayl = np.tile(0.3 * dp, (S, 1))
+    tau_abs = np.tile(0.05 * dp, (S, 1))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.05, m_max=2)
+    pm = Hm.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], **kw)
+    pm.varpi_Cabannes = 0.96
+    shifts = np.unique(np.concatenate([np.arange(-K // 2, 0), np.arange(1, K - K // 2 + 1)]) * 3)
+    assert len(shifts) == K
+    w_ie = np.linspace(0.5, 1.5, K) * 0.04 / K
+    rs = vsm.CoreRTRaman.RRS(shifts, w_ie, pm.greek_rayleigh, fscattRayl=pm.tau_rayl / (pm.tau_rayl + pm.tau_abs))
+    assert vsm.CoreRTRaman.raman_bytes_per_point(21, K, 8) * S > 140e9
+    torch.cuda.reset_peak_memory_stats()
+    R, T, ieR, ieT = vsm.CoreRTRaman.rt_run(rs, pm, 1, max_points=4000)
+    assert torch.cuda.max_memory_allocated() < 45e9
+    assert R.shape == (1, 3, S) and np.all(np.isfinite(ieR)) and np.all(np.isfinite(ieT))
+    h = 1e-5
+    small = Hm.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], **{**kw, "tau_rayl": tau_rayl[:4], "tau_abs": tau_abs[:4]})
+    small.varpi_Cabannes = 0.96 + h
+    Rp, _ = vsm.CoreRT.rt_run(small)
+    small.varpi_Cabannes = 0.96 - h
+    Rm, _ = vsm.CoreRT.rt_run(small)
+    dR = (Rp - Rm)[:, :, :1] / (2 * h)
+    n1 = np.arange(S)
+    wsum = np.zeros(S)
+    for sft, w in zip(shifts, w_ie):
+        wsum += w * ((n1 + sft >= 0) & (n1 + sft < S))
+    assert _rel(ieR, dR * wsum[None, None, :]) <= 5e-7
+    win = vsm.CoreRTRaman.rt_run(rs, pm, 1, spec_slice=slice(7900, 8100))     # straddles the block boundary at 8000
+    for a, b in zip((R, T, ieR, ieT), win):
+        assert np.array_equal(a[:, :, 7900:8100], b)
+

@@ -270,18 +270,56 @@ class SceneRRS:
         return tuple(to_host(t[self.crop]).transpose(2, 1, 0).copy() for t in self.out)
 
 
+def raman_bytes_per_point(N: int, K: int, itemsize: int) -> int:
+    """Device bytes one spectral point of a SceneRRS holds: the 12 + 10 four-dimensional inelastic arrays of the added / surface /
+    composite layers and of the kernels' work space (N x N x K each), the elastic layers and their work space."""
+    return int(itemsize * (22 * K * N * N + 8 * K * N + 40 * N * N))
+
+
 def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list] = None, spec_slice: Optional[slice] = None,
-           device_out: bool = False):
+           device_out: bool = False, max_points: Optional[int] = None):
     """rt_run(RS_type::RRS, model, iBand) (rt_run.jl:238-535): returns (R_SFI, T_SFI, ieR_SFI, ieT_SFI) as host arrays
     [nVZA, nStokes, nSpec].  `model.greek_rayleigh` must hold the Cabannes phase matrix and `model.varpi_Cabannes`
     the elastic Rayleigh single-scattering albedo (compEffectiveLayerProperties.jl:36-41).  `spec_slice`: see SceneRRS;
-    `device_out=True` returns the four (S_local, nStokes, nVZA) device tensors instead (for the gather)."""
-    scene = SceneRRS(RS_type, model, iBand, spec_slice)
-    scene.run(trace)
+    `device_out=True` returns the four (S_local, nStokes, nVZA) device tensors instead (for the gather).
+
+    Footprint: the reference pages its N x N x nSpec x nRaman arrays through the host (interaction_inelastic.jl:16-35,427-438).
+    Here a run whose arrays would not fit the device (or `max_points` recipient points per pass, if given) walks the recipient
+    axis in blocks, each a SceneRRS over the block extended by the halo of max|shift| donor points -- the same construction as
+    the multi-GPU shards (no exchange: a recipient reads only ELASTIC fields of its donors), bit-identical to the one-pass run,
+    at the price of recomputing 2 max|shift| points per block."""
+    S_full = model.tau_rayl.shape[0]
+    lo, hi, _ = (spec_slice or slice(0, S_full)).indices(S_full)
+    n_own = max(hi - lo, 0)
+    if max_points is None and n_own > 0:
+        N = model.quad_points.Nquad * model.polarization_type.n
+        K = len(np.asarray(RS_type.i_lambda1lambda0).ravel())
+        per = raman_bytes_per_point(N, K, np.dtype(model.float_type).itemsize)
+        free, _total = torch.cuda.mem_get_info()
+        halo = max([abs(int(x)) for x in np.asarray(RS_type.i_lambda1lambda0).ravel() if abs(int(x)) < S_full] or [0])
+        fit = int(0.8 * free // per) - 2 * halo
+        if fit < n_own:
+            if fit < 1:
+                raise _lib.VSMError("rt_run (RRS): not even one block of recipient points fits the device (%d bytes per point, "
+                                    "halo %d)" % (per, halo))
+            max_points = fit
+    if max_points is None or max_points >= n_own or trace is not None:
+        scene = SceneRRS(RS_type, model, iBand, spec_slice)
+        scene.run(trace)
+        if device_out:
+            return scene.results_device()
+        synchronize_if_gpu()
+        return scene.results_host()
+    parts = []
+    for b0 in range(lo, hi, int(max_points)):
+        scene = SceneRRS(RS_type, model, iBand, slice(b0, min(b0 + int(max_points), hi)))
+        scene.run()
+        parts.append(scene.results_device() if device_out else scene.results_host())
+        del scene
+        torch.cuda.empty_cache()
     if device_out:
-        return scene.results_device()
-    synchronize_if_gpu()
-    return scene.results_host()
+        return tuple(torch.cat([p[i] for p in parts], dim=0) for i in range(4))
+    return tuple(np.concatenate([p[i] for p in parts], axis=2) for i in range(4))
 
 
 def rt_run_sharded(RS_type: RRS, model: H.RTModel, rank: int = 0, world: int = 1, dst: int = 0, executor=None):
