@@ -295,7 +295,14 @@ def _host_aerosol_scene(vsm, arch, pol, l_trunc, x=None, FT=np.float64):
 def test_rt_run_lin_aerosol_slots(vsm, arch, pol, l_trunc):
     """rt_run(model, lin_model, NAer = 1, NGas = 1, NSurf = 1): the 7 aerosol slots (tau_ref, n_r, n_i, r_m, sigma_r, p0,
     sigma_p; parameter_layout.jl:28-56) + gas + albedo against the oracle (whose aerosol chain rule is itself checked by
-    finite differences in tests/test_oracle_lin.py), and tau_ref / n_r / p0 against central differences of the DEVICE forward run."""
+    finite differences in tests/test_oracle_lin.py), and tau_ref / n_r / p0 against central differences of the DEVICE forward run.
+
+    What this pins and what it cannot: the reference commits no Jacobian numbers (its own gate is a finite difference,
+    test/test_jacobians_unit.jl:105-123) and its aerosol gate tolerates a known defect (test/test_forward_lin.jl:186: "Known ~10%
+    residual from Bug 19", mean error < 0.15).  Identity with the reference's aerosol Jacobians is therefore unknowable without
+    Julia: the aerosol slots here are pinned by central differences only and may be MORE correct than upstream, not identical to
+    it.  Deliberate deviation: two aerosols with derivatives use the closed-form quotient rule where the
+    reference's scattering `+` fails once Z has become per-point (types_lin.jl:268-277)."""
     om, ol, pm, pl = _host_aerosol_scene(vsm, arch, pol, l_trunc)
     Ro, To, Rdo, Tdo = OL.rt_run_lin(om, ol)
     R, T, Rd, Td = vsm.CoreRTLin.rt_run_lin(pm, pl, 1, 1, 1)
