@@ -530,6 +530,10 @@ class Scene:
         pol, qp = model.polarization_type, model.quad_points
         self.pol, self.qp = pol, qp
         self.ss_correction = True   # Cox-Munk TMS term (tests switch it off to look at the Fourier-summed field)
+        if isinstance(model.surface, H.CoxMunkSurface) and len(model.vza) > 64:
+            # fail before the Fourier loop, not after it: vsm_coxmunk_ss_correction holds 64 viewing geometries per call
+            raise _lib.VSMError("Cox-Munk scenes take at most 64 viewing geometries (TMS single-scattering correction); got %d"
+                                % len(model.vza))
         self.host_optics = bool(host_optics)
         self.full_added_layer = bool(full_added_layer)   # the linearized run's kernels take the reference's full AddedLayer
         S_full, self.Nz = model.tau_rayl.shape
