@@ -753,7 +753,12 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
 }
 
 // ---------------------------------------------------------------------------
-// interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266; see ia_body in vsm_strip.hip)
+// interaction_helper!(::ScatteringInterface_11)  (interaction.jl:207-266) with ONE inverse G2 = (I - R+- r-+)^-1 and the
+// push-through identities -- the algebra of ia_body in vsm_strip.hip (ten products + the series, seven barriers + those of the
+// series; every composite matrix crosses the memory system once in each direction):
+//   [E2 | Z] = R+- [r-+ | t--] ; [S | V] = T-- [r-+ | t--] ; T21 = t++ G2 ; Y = S G2
+//   [R+- | T++] = [r+- | 0] + T21 [Z | T++] ;  [R-+ | T--] = [R-+ | V] + Y [T++ | Z]
+//   z = J0+ + R+- j0- ; J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z          (N = 96 has no spare column: VALU mat-vecs)
 // On entry: r_s / t_s = strips of the added layer's r-+ / t++, sm.vec[2 jpair] / [2 jpair + 1] = its j0+ / j0-, all waves
 // past a barrier, P and Q free.  ns > 0: r+- = D r-+ D, t-- = D t++ D; ns == 0: read from r_pm / t_mm (surface layers).
 // ---------------------------------------------------------------------------
@@ -765,10 +770,8 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   float* Q = sm.Q;
   const float* vjp = sm.vec[2 * jpair];
   const float* vjm = sm.vec[2 * jpair + 1];
-  float* vu = sm.vec[2 * (jpair ^ 1)];
-  float* vz = sm.vec[2 * (jpair ^ 1) + 1];
-  float* vJp = sm.vec[4];
-  const int s = p.s, tid = p.tid;
+  float* vz = sm.vec[2 * (jpair ^ 1)];
+  const int s = p.s;
   const long long NN = (long long)N * N;
   float* R_mp = c.R_mp + s * NN;
   float* R_pm = c.R_pm + s * NN;
@@ -780,131 +783,107 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   const bool mlead = p.kq == 0;
   int slot = 0;
 
-  if (tid < FNP) vJp[tid] = (tid < N) ? J0_p[tid] : 0.0f;
+  const float Jp_old = (mlead && mrow < N) ? J0_p[mrow] : 0.0f;
   const float Jm_old = (mlead && mrow < N) ? J0_m[mrow] : 0.0f;
-  fstrip X;
-  load_strip_global<AL>(X, R_pm, N, p);  // R+- strip
-  store_strip(P, r_s, p);            // [r-+] -> P
   VSM_STAMP_DECL;
+  // ---- stage: [R+-] -> P, [T--] -> Q (each wave moves its own 16 columns: global strip -> A-form) -----------------------
   {
-    fstrip Y;                        // [T--] -> Q: each wave moves its own 16 columns (global strip -> A-form)
-    load_strip_global<AL>(Y, T_mm, N, p);
-    store_strip(Q, Y, p);
+    fstrip Y1, Y2;
+    load_strip_global<AL>(Y1, R_pm, N, p);
+    load_strip_global<AL>(Y2, T_mm, N, p);
+    store_strip(P, Y1, p);
+    store_strip(Q, Y2, p);
   }
-  half_barrier(p);
+  half_barrier(p);                                                                                       // (a)
   VSM_STAMP(10);
-  // u = r-+ J0+ + j0-
+  // z = J0+ + R+- j0- ; vs = T-- j0-
+  float vs_keep;
   {
-    const float y = matvec1<KB>(P, vJp, p);
-    if (mlead) vu[mrow] = (mrow < N) ? y + vjm[mrow] : 0.0f;
+    const float y1 = matvec1<KB>(P, vjm, p);
+    vs_keep = matvec1<KB>(Q, vjm, p);
+    if (mlead) vz[mrow] = (mrow < N) ? Jp_old + y1 : 0.0f;
   }
-  // ---- G1 = (I - r-+ R+-)^-1 --------------------------------------------------------------------------------------
-  fstrip G;
+  fstrip Z, V, G;
   {
-    fstrip E;
-    E.zero();
-    mm_ab<KB>(E, P, X, p);
-    VSM_STAMP(11);
-    invert_strip<KB>(E, G, P, N, sm, slot, p);
-  }
-  half_barrier(p);
-  store_strip(P, G, p);  // [G1] -> P
-  half_barrier(p);
-  VSM_STAMP(12);
-  // ---- H = G1 r-+ ; T01 = T-- G1 ; T01 r-+ = T-- H -------------------------------------------------------------------
-  fstrip H;
-  H.zero();
-  mm_ab<KB>(H, P, r_s, p);
-  {
-    fstrip A1;
-    A1.zero();
-    mm_ab<KB>(A1, Q, G, p);
-    X.zero();
-    mm_ab<KB>(X, Q, H, p);
-    half_barrier(p);
-    store_strip(P, X, p);   // [T01 r-+] -> P
-    store_strip(Q, A1, p);  // [T01] -> Q
-  }
-  half_barrier(p);
-  VSM_STAMP(13);
-  // J0- += T01 u
-  {
-    const float y = matvec1<KB>(Q, vu, p);
-    if (mlead && mrow < N && p.active) J0_m[mrow] = Jm_old + y;
-  }
-  // ---- R-+ += (T01 r-+) T++ -----------------------------------------------------------------------------------------
-  {
-    fstrip Tpp, acc;
-    load_strip_global<AL>(Tpp, T_pp, N, p);
-    load_strip_global<AL>(acc, R_mp, N, p);
-    VSM_STAMP(14);
-    mm_ab<KB>(acc, P, Tpp, p);
-    store_strip_global<AL>(R_mp, acc, N, p);
-  }
-  VSM_STAMP(15);
-  // ---- T-- = T01 t-- -------------------------------------------------------------------------------------------------
-  {
-    fstrip acc;
-    acc.zero();
-    if (ns) {   // t-- = D t++ D formed in place and undone afterwards (D is an involution): no second strip
+    fstrip E, Sx;
+    if (ns) {   // t-- = D t++ D formed in place and undone afterwards (D is an involution)
       dsym_strip(t_s, t_s, ns, p);
-      mm_ab<KB>(acc, Q, t_s, p);
+      E.zero();
+      Z.zero();
+      mm_ab2<KB>(E, Z, P, r_s, t_s, p);
+      Sx.zero();
+      V.zero();
+      mm_ab2<KB>(Sx, V, Q, r_s, t_s, p);
       dsym_strip(t_s, t_s, ns, p);
+      dsym_strip(r_s, r_s, ns, p);      // r_s <- r+- (the accumulator of the R+- update)
     } else {
       fstrip tmm;
       load_strip_global<AL>(tmm, t_mm, N, p);
-      mm_ab<KB>(acc, Q, tmm, p);
+      E.zero();
+      Z.zero();
+      mm_ab2<KB>(E, Z, P, r_s, tmm, p);
+      Sx.zero();
+      V.zero();
+      mm_ab2<KB>(Sx, V, Q, r_s, tmm, p);
+      load_strip_global<AL>(r_s, r_pm, N, p);
     }
-    store_strip_global<AL>(T_mm, acc, N, p);
+    VSM_STAMP(11);
+    // ---- G2 = (I - E2)^-1: norm (barrier (b): every wave is done reading [R+-], [T--]), [S] -> Q, series on P -------
+    float nrm_other;
+    const float nrm = strip_norm_bound(E, sm, slot, p, nrm_other);
+    store_strip(Q, Sx, p);
+    const int K = series_order(nrm);
+    invert_strip_own<KB>(E, G, P, N, sm, p, K);
+#ifndef VSM_SOFT_BARRIER
+    // the other point of the workgroup may need more barriers for its inverse: keep the two barrier sequences equal
+    const int own = inverse_barriers(K, N), oth = inverse_barriers(series_order(nrm_other), N);
+    for (int i = own; i < oth; ++i) half_barrier(p);
+#endif
   }
-  half_barrier(p);  // [T01 r-+] (P) and [T01] (Q) no longer read
+  VSM_STAMP(12);
+  half_barrier(p);            // (d): the series' powers in P no longer read
+  store_strip(P, t_s, p);     // [t++] -> P
+  half_barrier(p);            // (e)
+  VSM_STAMP(13);
+  {
+    fstrip X, Y;
+    X.zero();
+    mm_ab<KB>(X, P, G, p);    // T21 = t++ G2
+    Y.zero();
+    mm_ab<KB>(Y, Q, G, p);    // Y = S G2 = T01 r-+
+    VSM_STAMP(14);
+    half_barrier(p);          // (f): [t++], [S] no longer read
+    store_strip(P, X, p);     // [T21] -> P
+    store_strip(Q, Y, p);     // [Y]   -> Q
+  }
+  fstrip Tpp, Rmp;
+  load_strip_global<AL>(Tpp, T_pp, N, p);
+  load_strip_global<AL>(Rmp, R_mp, N, p);
+  half_barrier(p);            // (g)
+  VSM_STAMP(15);
+  // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
+  {
+    const float y1 = matvec1<KB>(P, vz, p);
+    const float y2 = matvec1<KB>(Q, vz, p);
+    if (mlead && mrow < N && p.active) {
+      J0_p[mrow] = vjp[mrow] + y1;
+      J0_m[mrow] = Jm_old + vs_keep + y2;
+    }
+  }
   VSM_STAMP(16);
-  // ---- G2 = I + R+- H  (push-through identity) ; Z = R+- t-- ; z = J0+ + R+- j0- ------------------------------------------
-  // (R+- = r+- + (T21 R+-) t-- is evaluated as r+- + T21 (R+- t--): Z shares the fragments of [R+-] with G2, the last two
-  //  products share those of [T21], and neither [T21 R+-] nor the R+- strip has to go through LDS)
   {
-    fstrip Y;                  // [R+-] -> P
-    load_strip_global<AL>(Y, R_pm, N, p);
-    store_strip(P, Y, p);
-  }
-  store_strip(Q, t_s, p);      // [t++] -> Q
-  half_barrier(p);
-  VSM_STAMP(17);
-  fstrip Z;
-  {
-    if (ns) dsym_strip(t_s, t_s, ns, p); else load_strip_global<AL>(t_s, t_mm, N, p);   // t_s <- t--
-    G.zero();
-    Z.zero();
-    mm_ab2<KB>(G, Z, P, H, t_s, p);
-  }
-  add_identity(G, N, p);
-  {
-    const float y = matvec1<KB>(P, vjm, p);
-    if (mlead) vz[mrow] = (mrow < N) ? vJp[mrow] + y : 0.0f;
-  }
-  // ---- T21 = t++ G2 -----------------------------------------------------------------------------------------------------
-  X.zero();
-  mm_ab<KB>(X, Q, G, p);
-  half_barrier(p);        // [R+-] (P), [t++] (Q) no longer read ; z complete
-  store_strip(P, X, p);   // [T21] -> P
-  half_barrier(p);
-  VSM_STAMP(18);
-  // J0+ = j0+ + T21 z
-  {
-    const float y = matvec1<KB>(P, vz, p);
-    if (mlead && mrow < N && p.active) J0_p[mrow] = vjp[mrow] + y;
-  }
-  // ---- T++ = T21 T++ ; R+- = r+- + T21 Z ---------------------------------------------------------------------------------
-  {
-    fstrip Tpp, acc1;
-    load_strip_global<AL>(Tpp, T_pp, N, p);
-    if (ns) dsym_strip(r_s, r_s, ns, p); else load_strip_global<AL>(r_s, r_pm, N, p);   // r_s <- r+-
-    acc1.zero();
-    mm_ab2<KB>(acc1, r_s, P, Tpp, Z, p);
-    store_strip_global<AL>(T_pp, acc1, N, p);
+    fstrip acc;
+    acc.zero();
+    mm_ab2<KB>(r_s, acc, P, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
+    VSM_STAMP(17);
     store_strip_global<AL>(R_pm, r_s, N, p);
+    store_strip_global<AL>(T_pp, acc, N, p);
   }
+  VSM_STAMP(18);
+  mm_ab2<KB>(Rmp, V, Q, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
   VSM_STAMP(19);
+  store_strip_global<AL>(R_mp, Rmp, N, p);
+  store_strip_global<AL>(T_mm, V, N, p);
   VSM_STAMP(20);
 }
 
