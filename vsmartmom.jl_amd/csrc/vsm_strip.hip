@@ -312,7 +312,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
       tt.zero();
       mm_ab<KS>(tt, Q, G, p);              // tt = t G
     }
-    load_strip(t_s, Q, p);                 // t's strip (with its riders) is not kept in registers across the inverse
+    load_strip(t_s, Q, p);                 // t's strip (with its riders) is not kept in registers across the inverse (kept: 75 more spilled VGPRs, no gain)
     __syncthreads();                       // P ([E]) and Q ([t]) no longer read
     store_strip(P, tt, p, asis);
     __syncthreads();
