@@ -192,7 +192,7 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 9), ("IQU", 33)])   # N = 21 (operator level), 57 (fused strip kernels)
 def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
     """SceneLin.run on concurrent moment lanes (small batches: the Fourier moments on several HIP streams, each with its own
-    layers and accumulators) == the moment-by-moment walk up to the reordering of the sum over moments, and == the oracle; a
+    layers and accumulators) and with the moments folded into the spectral axis == the moment-by-moment walk up to the reordering of the sum over moments, and == the oracle; a
     second run on the same lanes reproduces the first bit for bit (the lanes are re-zeroed)."""
     rng = np.random.default_rng(3)
     S, L = 3, 4
@@ -204,14 +204,20 @@ def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
     scene = vsm.CoreRTLin.SceneLin(pm, H.LinModel([ga]), 0, 1, 1)
     seq = [t.clone() for t in scene.run(lanes=1)]
     torch.cuda.synchronize()
-    par = [t.clone() for t in scene.run(lanes=4)]
+    par = [t.clone() for t in scene.run(lanes=4, fold=False)]
     torch.cuda.synchronize()
-    again = scene.run()          # default for a batch this small: the lanes
+    again = [t.clone() for t in scene.run(lanes=4, fold=False)]
     torch.cuda.synchronize()
-    for a, b, c in zip(seq, par, again):
-        assert torch.equal(b, c)
+    # the moments folded into the spectral axis for the layer walk (two chains of layer steps: m = 0 and m >= 1), finished on lanes
+    fold = [t.clone() for t in scene.run(lanes=4, fold=True)]
+    torch.cuda.synchronize()
+    dflt = scene.run()           # default for a batch this small: folded
+    torch.cuda.synchronize()
+    for a, b, c, d, e in zip(seq, par, again, fold, dflt):
+        assert torch.equal(b, c) and torch.equal(d, e)
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 1e-13 * scale
+        assert float((a - d).abs().max()) <= 1e-13 * scale
     om = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
     Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
     R, T, Rd, Td = scene.results_host()

@@ -31,7 +31,7 @@ def main():
         scene = mk()
         if name == "linearized" and len(sys.argv) > 1:
             run0 = scene.run
-            scene.run = lambda: run0(lanes=int(sys.argv[1]))
+            scene.run = lambda: run0(lanes=int(sys.argv[1]), fold=(len(sys.argv) > 2 and sys.argv[2] == "fold"))
         scene.run()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

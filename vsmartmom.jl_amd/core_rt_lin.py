@@ -207,6 +207,7 @@ class SceneLin:
         self.Rd = torch.zeros((P, S, pol.n, nV), dtype=dt, device=dev)
         self.Td = torch.zeros_like(self.Rd)
         self._lanes = []
+        self._fold = {}
 
     # -- inputs -----------------------------------------------------------------------------------------------------------
     def upload(self):
@@ -244,6 +245,7 @@ class SceneLin:
     # -- device optics ----------------------------------------------------------------------------------------------------
     def prepare(self):
         model, fwd, dt = self.model, self.fwd, self.dt
+        self._fold = {}   # (the folded per-layer inputs are copies of the optics)
         S_full, L = model.tau_rayl.shape
         _lib.call("vsm_layer_optics_lin", dt, S_full, fwd.lo, self.S, L, self.nAer, self.nGas, self.P, CR._ptr(fwd.tau_rayl_d),
                   CR._ptr(fwd.tau_abs_d), C.c_double(float(model.varpi_Cabannes)), CR._ptr(fwd.tau_aer_d), CR._ptr(fwd.ssa_d),
@@ -322,21 +324,31 @@ class SceneLin:
         a0 = self.added_s
         return CR.AddedLayer(self.FT, self.arch, self.N, self.S, a0.shared, a0.d_symmetric)
 
-    def run(self, lanes: Optional[int] = None):
+    def run(self, lanes: Optional[int] = None, fold: Optional[bool] = None):
         """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing.
-        `lanes`: number of concurrent moment lanes (default: LANES for batches below LANE_POINTS points, else 1)."""
+        `lanes`: number of concurrent moment lanes (default: LANES for batches below LANE_POINTS points, else 1);
+        `fold`: walk the layers with the Fourier moments folded into the spectral axis (_run_folded; default: for such small
+        batches when the scene has no aerosol Jacobian slots)."""
         global _lane
         S = self.S
         nm = len(self.fwd.moments)
+        small = 0 < S < self.LANE_POINTS
         if lanes is None:
-            lanes = self.LANES if 0 < S < self.LANE_POINTS else 1
+            lanes = self.LANES if small else 1
         lanes = max(1, min(lanes, nm))
+        can_fold = self.Zall is None and self.host_zdot is None and nm > 2 and S > 0
+        if fold is None:
+            fold = small and can_fold and lanes > 1
+        if fold and not can_fold:
+            raise _lib.VSMError("SceneLin.run(fold=True): needs a scene without aerosol Jacobian slots and more than two moments")
         st = [self._lane_state(k) for k in range(lanes)]
         for w in st:
             for t in (w["R"], w["T"], w["Rd"], w["Td"]):
                 t.zero_()
         if S == 0:
             return self.R, self.T, self.Rd, self.Td
+        if fold:
+            return self._run_folded(st)
         if lanes == 1:
             for mom in self.fwd.moments:
                 self._run_moment(mom, st[0])
@@ -353,6 +365,113 @@ class SceneLin:
                 else:
                     with torch.cuda.stream(st[k]["stream"]):
                         self._run_moment(mom, st[k])
+        finally:
+            _lane = 0
+        for w in st[1:]:
+            main.wait_stream(w["stream"])
+        for w in st[1:]:
+            self.R += w["R"]
+            self.T += w["T"]
+            self.Rd += w["Rd"]
+            self.Td += w["Td"]
+        return self.R, self.T, self.Rd, self.Td
+
+    # ---- moments folded into the spectral axis -------------------------------------------------------------------------------
+    # The layer kernels are batched over the spectral axis with per-point dtau, varpi, Z (stride N^2) and derivatives; the Fourier
+    # moment enters elemental! (lin) only through m == 0 (the weight factor 1/2 vs 1/4, elemental_lin.jl:77-206).  For a small
+    # batch the moments m >= 1 therefore walk the layers as ONE batch of (moment, point) pairs -- and m = 0 as another --: two
+    # dependent chains of layer steps instead of one per moment (C3: 22).  Each moment's block of the folded composite is then
+    # copied to a lane and finished there (surface layer, its interaction, post-processing: these depend on m).
+    def _fold_group(self, gi, group):
+        """Workspace and per-layer inputs of a folded group (cached until the optics change)."""
+        key = (gi, len(group))
+        g = self._fold.get(key)
+        if g is not None:
+            return g
+        FT, arch, P, N, S = self.FT, self.arch, self.P, self.N, self.S
+        n = len(group)
+        Sf = n * S
+        g = dict(added=CR.make_added_layer(FT, arch, (N, N), Sf), al=AddedLayerLin(FT, arch, P, N, Sf),
+                 comp=CR.make_composite_layer(FT, arch, (N, N), Sf), cl=CompositeLayerLin(FT, arch, P, N, Sf),
+                 expk=torch.empty(Sf, dtype=self.dt, device=self.expk.device), F0=self.F0.repeat(n, 1).contiguous(), layers=[])
+        for iz in range(self.fwd.Nz):
+            ly0 = group[0]["layers"][iz]
+            mats = [mom["layers"][iz]["props"].materialize() for mom in group]
+            Zpp = torch.cat([p_.Zpp.expand(S, N, N) for p_ in mats]).contiguous()
+            Zmp = torch.cat([p_.Zmp.expand(S, N, N) for p_ in mats]).contiguous()
+            p0 = mats[0]
+            props = CR.DeviceLayerOptics(p0.tau.repeat(n), p0.varpi.repeat(n), Zpp, Zmp, p0.max_tau_varpi, p0.tau_h, p0.varpi_h)
+            g["layers"].append(dict(props=props, dtau=ly0["dtau"].repeat(n), tau_sum=ly0["tau_sum"].repeat(n),
+                                    dtd=self.dtau_dot_all[iz].repeat(1, n).contiguous(), vd=self.varpi_dot[iz].repeat(1, n).contiguous(),
+                                    tsd=self.tau_sum_dot[iz].repeat(1, n).contiguous()))
+        self._fold[key] = g
+        return g
+
+    def _run_folded(self, st):
+        global _lane
+        pol, qp, dt, S, N, P, pl = self.pol, self.qp, self.dt, self.S, self.N, self.P, self.pl
+        moms = self.fwd.moments
+        groups = [[m_ for m_ in moms if m_["m"] == 0], [m_ for m_ in moms if m_["m"] > 0]]
+        mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
+        main = torch.cuda.current_stream()
+        lanes = len(st)
+        for w in st[1:]:
+            w["stream"].wait_stream(main)       # (the zeroing of the accumulators and whatever produced the inputs)
+
+        def chain(gi, group, lane):
+            """The layer walk of a folded group on the current stream (work buffers of `lane`)."""
+            global _lane
+            _lane = lane
+            g = self._fold_group(gi, group)
+            Sf = len(group) * S
+            added, al, comp, cl = g["added"], g["al"], g["comp"], g["cl"]
+            for iz, fl in enumerate(g["layers"]):
+                ly0 = group[0]["layers"][iz]
+                elemental_lin_(pol, fl["tau_sum"], fl["tsd"], fl["dtau"], fl["dtd"], g["F0"], fl["props"], fl["vd"], None, None, (0, 0),
+                               pl, group[0]["m"], ly0["nd"], self.dq, added, al)
+                _lib.call("vsm_layer_expk", dt, Sf, CR._ptr(fl["dtau"]), mu0, CR._ptr(g["expk"]), CR._stream_ptr())
+                doubling_allparams_(pol, g["expk"], ly0["nd"], added, al, fl["dtd"], qp.mu0, pl)
+                if iz == 0:
+                    CR.copy_added_to_composite_(comp, added)
+                    a_, c_ = al.cstruct(), cl.cstruct()
+                    _lib.call("vsm_copy_added_to_composite_lin", dt, N, Sf, C.byref(a_), C.byref(c_), CR._stream_ptr())
+                else:
+                    interaction_lin_(ly0["iface"], comp, cl, added, al)
+            return comp, cl
+
+        def finish(mom, w, lane, comp, cl, im):
+            """Moment `im` of a folded composite -> lane workspace `w`, then surface / interaction / post-processing."""
+            global _lane
+            _lane = lane
+            sl = slice(im * S, (im + 1) * S)
+            for f in ("R_mp", "R_pm", "T_pp", "T_mm", "J0_p", "J0_m"):
+                getattr(w["comp"], f).copy_(getattr(comp, f)[sl])
+                getattr(w["cl"], f).copy_(getattr(cl, f)[:, sl])
+            self._finish_moment(mom, w)
+
+        try:
+            # the m = 0 chain (and its finish) on lane 1's stream, concurrent with the m >= 1 chain on the main stream
+            if groups[0]:
+                if lanes > 1:
+                    with torch.cuda.stream(st[1]["stream"]):
+                        comp0, cl0 = chain(0, groups[0], 1)
+                        for im, mom in enumerate(groups[0]):
+                            finish(mom, st[1], 1, comp0, cl0, im)
+                else:
+                    comp0, cl0 = chain(0, groups[0], 0)
+                    for im, mom in enumerate(groups[0]):
+                        finish(mom, st[0], 0, comp0, cl0, im)
+            if groups[1]:
+                comp1, cl1 = chain(1, groups[1], 0)
+                for w in st[1:]:
+                    w["stream"].wait_stream(main)
+                for im, mom in enumerate(groups[1]):
+                    kk = im % lanes
+                    if st[kk]["stream"] is None:
+                        finish(mom, st[kk], kk, comp1, cl1, im)
+                    else:
+                        with torch.cuda.stream(st[kk]["stream"]):
+                            finish(mom, st[kk], kk, comp1, cl1, im)
         finally:
             _lane = 0
         for w in st[1:]:
@@ -397,6 +516,18 @@ class SceneLin:
                     _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
                 else:
                     interaction_lin_(ly["iface"], comp, cl, added, al)
+        self._finish_moment(mom, w)
+
+    def _finish_moment(self, mom, w):
+        """Surface layer, its interaction and the post-processing of one Fourier moment on the workspace `w`."""
+        model, pol, qp, FT, dt, fwd = self.model, self.pol, self.qp, self.FT, self.dt, self.fwd
+        N, S, P, pl = self.N, self.S, self.P, self.pl
+        comp, cl = w["comp"], w["cl"]
+        isurf = self.layout.surface_index(0)
+        q_ = self.dq.cstruct()
+        m = mom["m"]
+        weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+        if True:
             a_, al_ = w["added_s"].cstruct(), w["als"].cstruct()
             tau_sum_s, tsd_s = mom["tau_sum_surface"], self.tau_sum_dot[fwd.Nz]
             rho, drho = self.surf[m]
