@@ -770,35 +770,26 @@ int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double
   VSM_LAUNCH_CHECK("k_ia_strip");
   return VSM_OK;
 }
+// (the thermal slot only: a solar layer step goes through the multi-moment pair, strip_layer_forward)
 int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
                                                const double* varpi, const double* tau_sum, const double* F0,
                                                const zsrc<double>& z, int toa, const composite<double>& c, hipStream_t st,
                                                int thermal) {
-  static int prepared = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_layer_strip)");
-  static int prepared_mix = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_layer_strip mix)");
-  if (prepared) return prepared;
-  if (prepared_mix) return prepared_mix;
-  if (thermal) {   // F0 = B[S]
-    static int prepared_th = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false, true>, "hipFuncSetAttribute(k_layer_strip th)");
-    static int prepared_thm = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true, true>, "hipFuncSetAttribute(k_layer_strip thm)");
-    if (prepared_th) return prepared_th;
-    if (prepared_thm) return prepared_thm;
-    if (z.ncomp > 0)
-      hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
-                         varpi, tau_sum, F0, z, toa, c);
-    else
-      hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
-                         varpi, tau_sum, F0, z, toa, c);
-    VSM_LAUNCH_CHECK("k_layer_strip(thermal)");
-    return VSM_OK;
+  if (!thermal) {
+    set_error("launch_layer_strip: the solar layer step is the multi-moment pair");
+    return VSM_ERR_UNSUPPORTED;
   }
-  if (z.ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
-                       tau_sum, F0, z, toa, c);
+  static int prepared_th = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false, true>, "hipFuncSetAttribute(k_layer_strip th)");
+  static int prepared_thm = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true, true>, "hipFuncSetAttribute(k_layer_strip thm)");
+  if (prepared_th) return prepared_th;
+  if (prepared_thm) return prepared_thm;
+  if (z.ncomp > 0)   // F0 = B[S]
+    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
+                       varpi, tau_sum, F0, z, toa, c);
   else
-    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi,
-                       tau_sum, F0, z, toa, c);
-  VSM_LAUNCH_CHECK("k_layer_strip");
+    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
+                       varpi, tau_sum, F0, z, toa, c);
+  VSM_LAUNCH_CHECK("k_layer_strip(thermal)");
   return VSM_OK;
 }
 
@@ -870,6 +861,15 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
                         const composite<double>& c, hipStream_t st, int thermal) {
   if (S <= 0) return VSM_OK;
+  if (!thermal && strip_supported(q.N)) {   // a solar layer step of one moment: the multi-moment pair (pre-pass + layer kernel) with nm = 1
+    layer_mm_args<double> a;
+    for (int i = 0; i < VSM_MM_MAX; ++i) {
+      a.m[i] = m;
+      a.z[i] = z;
+      a.c[i] = c;
+    }
+    return strip_layer_forward_mm(q, S, 1, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
+  }
 #define VSM_CALL(KS) VSM_CAT(launch_layer_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal)
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
