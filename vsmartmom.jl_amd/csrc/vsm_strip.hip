@@ -643,13 +643,6 @@ __device__ __forceinline__ void layer_body(const quad<double>& q, int m, int ndo
   ia_body<KS, true>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr);
   VSM_LIFE_FLUSH();
 }
-template <int KS, bool MIX, bool THERMAL = false>
-__global__ __launch_bounds__(SNT, 2) void k_layer_strip(quad<double> q, int m, int ndoubl, const double* __restrict__ dtau,
-                                                        const double* __restrict__ varpi,
-                                                        const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                                        zsrc<double> z, int toa, composite<double> c) {
-  layer_body<KS, MIX, THERMAL>(q, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
-}
 // The same for several Fourier moments at once: blockIdx.y picks the moment's composite.  The elemental layers come from the
 // pre-pass k_elemental_img (below) as A-form images: inside this kernel their ~2 10^3 VALU / LDS instructions per wave would
 // each queue behind an FP64 MFMA of the workgroup that shares the SIMDs (on gfx950 the FP64 matrix rate equals the FP64
@@ -734,9 +727,6 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
   int VSM_CAT(launch_ed_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,       \
                                     const double*, const zsrc<double>&, const added<double>&, hipStream_t);                 \
   int VSM_CAT(launch_ia_strip_, KS)(int, int, const composite<double>&, const added<double>&, hipStream_t);                \
-  int VSM_CAT(launch_layer_strip_, KS)(const quad<double>&, int, int, int, const double*, const double*, const double*,    \
-                                       const double*, const zsrc<double>&, int, const composite<double>&, hipStream_t,      \
-                                       int);                                                                                \
   int VSM_CAT(launch_layer_strip_mm_, KS)(const quad<double>&, int, int, int, const layer_mm_args<double>&, int,           \
                                           const double*, hipStream_t);
 
@@ -770,29 +760,6 @@ int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double
   VSM_LAUNCH_CHECK("k_ia_strip");
   return VSM_OK;
 }
-// (the thermal slot only: a solar layer step goes through the multi-moment pair, strip_layer_forward)
-int VSM_CAT(launch_layer_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
-                                               const double* varpi, const double* tau_sum, const double* F0,
-                                               const zsrc<double>& z, int toa, const composite<double>& c, hipStream_t st,
-                                               int thermal) {
-  if (!thermal) {
-    set_error("launch_layer_strip: the solar layer step is the multi-moment pair");
-    return VSM_ERR_UNSUPPORTED;
-  }
-  static int prepared_th = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, false, true>, "hipFuncSetAttribute(k_layer_strip th)");
-  static int prepared_thm = strip_enable_lds(k_layer_strip<VSM_STRIP_KS, true, true>, "hipFuncSetAttribute(k_layer_strip thm)");
-  if (prepared_th) return prepared_th;
-  if (prepared_thm) return prepared_thm;
-  if (z.ncomp > 0)   // F0 = B[S]
-    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, true, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
-                       varpi, tau_sum, F0, z, toa, c);
-  else
-    hipLaunchKernelGGL((k_layer_strip<VSM_STRIP_KS, false, true>), dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau,
-                       varpi, tau_sum, F0, z, toa, c);
-  VSM_LAUNCH_CHECK("k_layer_strip(thermal)");
-  return VSM_OK;
-}
-
 int VSM_CAT(launch_layer_strip_mm_, VSM_STRIP_KS)(const quad<double>& q, int S, int nm, int ndoubl,
                                                   const layer_mm_args<double>& a, int toa, const double* pre, hipStream_t st) {
   static int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS>, "hipFuncSetAttribute(k_layer_strip_mm)");
@@ -857,32 +824,12 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
     default: break;                        \
   }
 
-int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
-                        const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
-                        const composite<double>& c, hipStream_t st, int thermal) {
-  if (S <= 0) return VSM_OK;
-  if (!thermal && strip_supported(q.N)) {   // a solar layer step of one moment: the multi-moment pair (pre-pass + layer kernel) with nm = 1
-    layer_mm_args<double> a;
-    for (int i = 0; i < VSM_MM_MAX; ++i) {
-      a.m[i] = m;
-      a.z[i] = z;
-      a.c[i] = c;
-    }
-    return strip_layer_forward_mm(q, S, 1, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
-  }
-#define VSM_CALL(KS) VSM_CAT(launch_layer_strip_, KS)(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal)
-  VSM_STRIP_SWITCH(q.N, VSM_CALL)
-#undef VSM_CALL
-  set_error("strip_layer_forward: N=%d outside (32, 60]", q.N);
-  return VSM_ERR_UNSUPPORTED;
-}
-
 // ---------------------------------------------------------------------------
 // Elemental pre-pass of the multi-moment layer kernel: elemental! (elemental.jl:289-392) for every (point, moment) of a layer
 // into A-form images (layout: vsm_strip_dev.h, PRE_STRIDE).  One workgroup per (point, moment); lane = row, a wave walks the
 // columns j = wave, wave + 4, ... (uniform per wave), so the image is written in full 512-byte columns.
 // ---------------------------------------------------------------------------
-template <bool MIX>
+template <bool MIX, bool THERMAL = false>   // THERMAL: the `:thermal` source slot (F0 = B[S], expk = 1; see ed_body)
 __global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoubl, const double* __restrict__ dtau,
                                                        const double* __restrict__ varpi, const double* __restrict__ tau_sum,
                                                        const double* __restrict__ F0, layer_mm_args<double> a,
@@ -951,20 +898,26 @@ __global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoub
     T[lidx<SNP>(i, j)] = tv;
   }
   if (wave == 0) {   // SFI source of the solar beam: the same formulas with the solar column (see elemental_pair)
-    const int i0 = ns * q.i_mu0;
-    double zp = 0.0, zm = 0.0;
-    for (int qq = 0; qq < ns; ++qq) {
-      const long long zo = ic + (long long)N * (i0 + qq);
-      const double f = F0[qq + (long long)ns * s];
-      zp += zget(Zp, zo) * f;
-      zm += zget(Zm, zo) * f;
+    double vp, vm, expk0;
+    if (THERMAL) {   // j0+- = 2 pi (1 - varpi) B (1 - e^{-dtau / mu_i}) on the I rows (Sources/thermal_emission.jl:241-301)
+      vp = vm = (i < N && i % ns == 0 && mi > num<double>::eps()) ? 6.283185307179586476925286766559 * (1.0 - w) * F0[s] * (-ai) : 0.0;
+      expk0 = 1.0;
+    } else {
+      const int i0 = ns * q.i_mu0;
+      double zp = 0.0, zm = 0.0;
+      for (int qq = 0; qq < ns; ++qq) {
+        const long long zo = ic + (long long)N * (i0 + qq);
+        const double f = F0[qq + (long long)ns * s];
+        zp += zget(Zp, zo) * f;
+        zm += zget(Zm, zo) * f;
+      }
+      double rr, tt;
+      elemental_pair(w, zp, zm, mi, xi, ai, ei, mus[i0], xs[i0], ems[i0], es[i0], (m == 0) ? 0.5 : 0.25, false, thick, rr, tt);
+      const double att = exp(-tau_sum[s] / mus[i0]);
+      vp = (i < N) ? tt * att : 0.0;
+      vm = (i < N) ? rr * att * sg : 0.0;
+      expk0 = exp(-d / q.mu0);
     }
-    double rr, tt;
-    elemental_pair(w, zp, zm, mi, xi, ai, ei, mus[i0], xs[i0], ems[i0], es[i0], (m == 0) ? 0.5 : 0.25, false, thick, rr, tt);
-    const double att = exp(-tau_sum[s] / mus[i0]);
-    const double vp = (i < N) ? tt * att : 0.0;
-    const double vm = (i < N) ? rr * att * sg : 0.0;
-    const double expk0 = exp(-d / q.mu0);
     out[2 * PRE_IMG + i] = vp;
     out[2 * PRE_IMG + SNP + i] = vm;
     out[2 * PRE_IMG + 2 * SNP + i] = expk0;
@@ -977,8 +930,9 @@ __global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoub
   }
 }
 
-int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
-                           const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa, hipStream_t st) {
+static int strip_layer_forward_pre(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
+                                   const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa,
+                                   hipStream_t st, int thermal) {
   if (S <= 0 || nm <= 0) return VSM_OK;
   if (!strip_supported(q.N)) {
     set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
@@ -986,16 +940,40 @@ int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, con
   }
   double* pre = static_cast<double*>(scratch((size_t)nm * S * PRE_STRIDE * sizeof(double), 3));
   if (!pre) return VSM_ERR_HIP;
-  if (a.z[0].ncomp > 0)
-    hipLaunchKernelGGL((k_elemental_img<true>), dim3(S, nm), dim3(SNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
-  else
-    hipLaunchKernelGGL((k_elemental_img<false>), dim3(S, nm), dim3(SNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  const dim3 grid(S, nm), block(SNT);
+  if (thermal) {   // F0 = B[S]; tau_sum is not read
+    if (a.z[0].ncomp > 0)
+      hipLaunchKernelGGL((k_elemental_img<true, true>), grid, block, 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+    else
+      hipLaunchKernelGGL((k_elemental_img<false, true>), grid, block, 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  } else if (a.z[0].ncomp > 0) {
+    hipLaunchKernelGGL((k_elemental_img<true>), grid, block, 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  } else {
+    hipLaunchKernelGGL((k_elemental_img<false>), grid, block, 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  }
   VSM_LAUNCH_CHECK("k_elemental_img");
 #define VSM_CALL(KS) VSM_CAT(launch_layer_strip_mm_, KS)(q, S, nm, ndoubl, a, toa, pre, st)
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
   return VSM_ERR_UNSUPPORTED;
+}
+int strip_layer_forward_mm(const quad<double>& q, int S, int nm, int ndoubl, const double* dtau, const double* varpi,
+                           const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa, hipStream_t st) {
+  return strip_layer_forward_pre(q, S, nm, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st, 0);
+}
+// one moment (solar, or the `:thermal` slot: F0 = B[S], m = 0): the same pair with nm = 1
+int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
+                        const double* tau_sum, const double* F0, const zsrc<double>& z, int toa,
+                        const composite<double>& c, hipStream_t st, int thermal) {
+  if (S <= 0) return VSM_OK;
+  layer_mm_args<double> a;
+  for (int i = 0; i < VSM_MM_MAX; ++i) {
+    a.m[i] = m;
+    a.z[i] = z;
+    a.c[i] = c;
+  }
+  return strip_layer_forward_pre(q, S, 1, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st, thermal);
 }
 
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
