@@ -694,6 +694,30 @@ def test_rt_run_streams_recovers_rt_run(vsm, arch, pol, l_trunc, FT):
     assert np.all(np.isfinite(st.R_mp_per_m[0])) and np.max(np.abs(st.R_mp_per_m[0])) > 0 and np.all(np.isfinite(st.T_pp_per_m[1]))
 
 
+@pytest.mark.parametrize("pol,l_trunc,vza,N_expected", [("I", 115, [0.0, 60.0], 61), ("I", 117, [0.0, 60.0, 20.0], 62),
+                                                        ("IQU", 37, [0.0, 60.0], 63), ("IQUV", 25, [0.0, 60.0, 20.0], 64)])
+@pytest.mark.parametrize("batched", [False, True])
+def test_rt_run_strip_kernels_without_spare_columns(vsm, arch, pol, l_trunc, vza, N_expected, batched):
+    """FP64, N = 61..64: the strips are full, so the column-strip layer kernel (KS = 16) carries the source vectors by VALU
+    mat-vecs over the A-forms instead of spare columns (the elemental pre-pass writes no riders).  The thick / thin column of
+    test_rt_run_thick_layers_strip_kernels (every inverse path, large ||r R||) vs the oracle; `batched`: the Fourier moments of
+    a layer in one launch (Scene.run's default) or moment by moment with the (ndoubl, interface) trace compared."""
+    S = 5
+    tau_rayl = np.array([[0.05, 1.5, 4.0]] * S)
+    tau_abs = np.array([[1e-3, 1e-4, 1e-5], [0.5, 0.2, 0.1], [5.0, 1.0, 3.0], [0.0, 0.0, 0.0], [1e-2, 30.0, 1e-2]])
+    om, pm = _both_models(vsm, arch, pol, l_trunc, 50.0, vza, [30.0, 120.0, 200.0][:len(vza)], tau_rayl=tau_rayl, tau_abs=tau_abs,
+                          depol=0.03, albedo=0.8, m_max=3)
+    N = om.quad_points.Nquad * om.pol.n
+    assert N == N_expected
+    assert vsm._lib.lib().vsm_layer_thermal_fused(N, 1) == 1      # the strip layer step takes the shape
+    tro, trg = [], []
+    Ro, To = O.rt_run(om, trace=tro)
+    Rg, Tg = vsm.CoreRT.rt_run(pm) if batched else vsm.CoreRT.rt_run(pm, trace=trg)
+    if not batched:
+        assert [(t["ndoubl"], t["iface"]) for t in tro] == [(t["ndoubl"], t["iface"]) for t in trg]
+    assert _rel(Rg, Ro) < 1e-8 and _rel(Tg, To) < 1e-8, (N, _rel(Rg, Ro), _rel(Tg, To))
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 19), ("IQUV", 21), ("IQU", 33), ("IQU", 31), ("I", 67)])
 def test_rt_run_thick_layers_strip_kernels(vsm, arch, pol, l_trunc):
     """FP64, 32 < N <= 60: the column-strip kernels (fused layer step).  Optically thick, nearly conservative layers

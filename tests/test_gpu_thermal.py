@@ -62,7 +62,8 @@ def test_thermal_source_operator(vsm, arch, FT):
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQUV", 9),        # N = 8, 32: operator level
-                                         ("IQUV", 19), ("IQU", 33)])    # N = 52, 60: the slot rides in the fused strip layer kernel
+                                         ("IQUV", 19), ("IQU", 33),     # N = 52, 60: the slot rides in the fused strip layer kernel
+                                         ("IQU", 35), ("IQUV", 25)])    # N = 63, 64: ... without spare columns (mat-vecs)
 def test_rt_run_thermal_slot_vs_oracle(vsm, arch, pol, l_trunc):
     """rt_run(model; sources = ThermalEmission) and sources = SolarBeam + ThermalEmission against the oracle's slot pass."""
     H = vsm.host_model
@@ -101,6 +102,7 @@ def test_thermal_is_independent_of_sza_and_opaque_column_is_a_blackbody(vsm, arc
 
 
 @pytest.mark.parametrize("FT,geo,tol", [(np.float64, ("IQU", 29, 35.0, [0.0, 50.0], [0.0, 120.0]), 1e-9),     # N = 54
+                                        (np.float64, ("IQU", 35, 35.0, [0.0, 50.0], [0.0, 120.0]), 1e-9),     # N = 63 (no spare columns)
                                         (np.float32, ("IQUV", 37, 35.0, [0.0, 50.0], [0.0, 120.0]), 2e-3),   # N = 88
                                         (np.float32, ("IQU", 51, 35.0, [0.0, 50.0], [0.0, 120.0]), 2e-3)])   # N = 87 (N % 4 != 0)
 def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch, FT, geo, tol):

@@ -172,7 +172,7 @@ static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dta
   hipStream_t st = as_stream(stream);
   if constexpr (sizeof(T) == 8) {
     static const bool no_fuse = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_LAYER_FUSION");
-    if (!no_fuse && strip_supported(q->N) && ncomp <= 4)
+    if (!no_fuse && strip_layer_supported(q->N) && ncomp <= 4)
       return strip_layer_forward(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, zsrc<T>{Zpp, Zmp, zs, ncomp, fcomp},
                                  toa, cvt_comp<T>(c), st);
   }
@@ -219,7 +219,7 @@ static int layer_forward_multi_impl(const Q* q, int S, int nm, const int* m, int
   if constexpr (sizeof(T) == 8) {
     static const bool no_fuse = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_LAYER_FUSION") ||
                                 ab_switch("VSM_NO_MOMENT_BATCH");
-    if (!no_fuse && strip_supported(q->N) && ncomp <= 4) {
+    if (!no_fuse && strip_layer_supported(q->N) && ncomp <= 4) {
       VSM_REQUIRE(dtau && varpi && tau_sum && F0, "layer_forward_multi: null input");
       for (int i0 = 0; i0 < nm; i0 += VSM_MM_MAX) {
         const int n = nm - i0 < VSM_MM_MAX ? nm - i0 : VSM_MM_MAX;
@@ -484,7 +484,7 @@ int vsm_layer_forward_multi_f32(const vsm_quad_f32* q, int S, int nm, const int*
 int vsm_layer_thermal_fused(int N, int is_f64) {
   static const bool off = ab_switch("VSM_NO_LAYER_FUSION") || ab_switch("VSM_NO_STRIP");
   if (off) return 0;
-  return is_f64 ? (strip_supported(N) ? 1 : 0) : (strip32_supported(N) ? 1 : 0);
+  return is_f64 ? (strip_layer_supported(N) ? 1 : 0) : (strip32_supported(N) ? 1 : 0);
 }
 // the `:thermal` per-source slot of a scattering layer through the fused layer kernel (m = 0; FP64, 32 < N <= 60, ncomp <= 4):
 // same launch as vsm_layer_forward(_mix) with the solar source replaced by the thermal one and expk = 1

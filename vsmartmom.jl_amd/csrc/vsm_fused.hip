@@ -1609,7 +1609,7 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
   }
   if constexpr (sizeof(T) == 8) {
     static const bool no_strip = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_STRIP_IA");
-    if (!no_strip && strip_supported(N)) return strip_interaction11(N, S, c, a, st);
+    if (!no_strip && strip_layer_supported(N)) return strip_interaction11(N, S, c, a, st);
   }
   if constexpr (sizeof(T) == 4) {
     if (strip32_supported(N)) return strip32_interaction11(N, S, c, a, st);

@@ -216,6 +216,7 @@ int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T
 
 // ---- column-strip kernels (FP64, 32 < N <= 60; two workgroups per CU): vsm_strip.hip ----------------
 bool strip_supported(int N);
+bool strip_layer_supported(int N);   // the layer step and interaction!(_11): 32 < N <= 64
 int strip_elemental_doubling(const quad<double>& q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                              const double* tau_sum, const double* F0, const zsrc<double>& z, const added<double>& a,
                              hipStream_t st);

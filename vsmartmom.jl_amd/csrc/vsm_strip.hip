@@ -120,7 +120,9 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
   const int Kend = ((N + 3) >> 2) << 2;
   // spare columns Kend, Kend+1 (>= N, never read as k) carry j0+ and j1- through the products of a step
   const int c1 = Kend, c2 = Kend + 1;
-  const bool own_wave = (p.wave == (c1 >> 4));
+  constexpr bool RID = 4 * KS + 2 <= SNP;   // spare columns for the source vectors (N <= 60); else VALU mat-vecs (N = 61..64)
+  static_assert(RID || PRE, "N > 60: the elemental step comes from the pre-pass");
+  const bool own_wave = RID && (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
   double expk0;
   if constexpr (PRE) {
@@ -288,6 +290,12 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     sstrip W;
     sstrip tt;
     const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
+    double* const mvA[4] = {sm.xw[0], sm.xw[1], sm.xw[2], sm.xw[3]};             // (the transposer tiles are idle in the loop)
+    double* const mvB[4] = {sm.xw[0] + SNP, sm.xw[1] + SNP, sm.xw[2] + SNP, sm.xw[3] + SNP};
+    if constexpr (!RID) {   // r j0+ , r j1-
+      mv_part(P, jp, 1.0, mvA[p.wave], p);
+      mv_part(P, jm, expk, mvB[p.wave], p);
+    }
     {
       sstrip G;
       {
@@ -306,8 +314,14 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
             }
         }
         VSM_RSTAMP(1);
-        invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (masks the rider columns of E; its first barrier: [r] is free)
+        invert_strip_horner<KS>(E, G, P, N, sm, slot, p);   // (its first barrier: [r] is free)
         VSM_RSTAMP(2);
+      }
+      if constexpr (!RID) {   // u1 = j1- + r j0+ , u2 = j0+ + r j1-   (every wave is past the norm reduction's barrier)
+        if (tid < SNP) {
+          sm.vec[4][tid] = jm[tid] * expk + mv_sum(mvA, tid);
+          sm.vec[5][tid] = jp[tid] + mv_sum(mvB, tid);
+        }
       }
       tt.zero();
       mm_ab<KS>(tt, Q, G, p);              // tt = t G
@@ -317,6 +331,10 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
     store_strip(P, tt, p, asis);
     __syncthreads();
     VSM_RSTAMP(3);
+    if constexpr (!RID) {   // tt u1 , tt u2   (the partial sums of r j were consumed two barriers ago)
+      mv_part(P, sm.vec[4], 1.0, mvA[p.wave], p);
+      mv_part(P, sm.vec[5], 1.0, mvB[p.wave], p);
+    }
     {
       sstrip tn;
       tn.zero();
@@ -324,6 +342,7 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
       t_s = tn;
     }
     VSM_RSTAMP(4);
+    const double expk_step = expk;
     expk = expk * expk;
     if (own_wave) {
       const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk';  r_s[c1] = j0-', r_s[c2] = j0+' stay
@@ -336,8 +355,14 @@ __device__ __forceinline__ void ed_body(ssmem& sm, spos& p, const quad<double>& 
         }
     }
     VSM_RSTAMP(5);
+    if (n + 1 < ndoubl || !RID) __syncthreads();  // everybody finished reading P ([tt])
+    if constexpr (!RID) {   // j0- += tt u1 ; j0+ = j0+ expk + tt u2   (visible after the barrier below / after the loop)
+      if (tid < SNP) {
+        jm[tid] += mv_sum(mvA, tid);
+        jp[tid] = jp[tid] * expk_step + mv_sum(mvB, tid);
+      }
+    }
     if (n + 1 < ndoubl) {
-      __syncthreads();  // everybody finished reading P ([tt])
       store_strip(P, r_s, p, asis);
       store_strip(Q, t_s, p, asis);
       __syncthreads();
@@ -459,8 +484,13 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   double* J0_m = c.J0_m + (long long)s * N;
   const int Kend = ((N + 3) >> 2) << 2;
   const int c1 = Kend, c2 = Kend + 1;
-  const bool own_wave = (p.wave == (c1 >> 4));
+  constexpr bool RID = 4 * KS + 2 <= SNP;   // spare columns for the vectors (N <= 60); else VALU mat-vecs (N = 61..64)
+  const bool own_wave = RID && (p.wave == (c1 >> 4));
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
+  // slots of the mat-vec partial sums (!RID): the Gauss-Jordan scratch (idle outside the inverse) and two spare vectors
+  double* const gjv = &sm.gj.col[0][0];
+  double* const mvA[4] = {gjv, gjv + SNP, gjv + 2 * SNP, gjv + 3 * SNP};
+  double* const mvB[4] = {gjv + 4 * SNP, gjv + 5 * SNP, sm.vec[6], sm.vec[7]};
   auto keepN = [N](double x, int r, int cc) { return (r < N && cc < N) ? x : 0.0; };
   int slot = 0;
   double* xw = sm.xw[p.wave];
@@ -479,6 +509,10 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   if (!DSYM) load_strip_global_c8_finish(G, p, xw);
   __syncthreads();                                                                                       // (a)
   VSM_STAMP(8);
+  if constexpr (!RID) {   // R+- j0- , T-- j0-
+    mv_part(P, vjm, 1.0, mvA[p.wave], p);
+    mv_part(Q, vjm, 1.0, mvB[p.wave], p);
+  }
   if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta)
@@ -518,6 +552,12 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
     }
     VSM_STAMP(9);
     const double nrm = strip_norm_bound_clean(E, N, sm, slot, p);   // (b): every wave is done reading [R+-] and [T--]
+    if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-   (before the inverse may use the Gauss-Jordan scratch)
+      if (tid < SNP) {
+        vz[tid] = vJp[tid] + mv_sum(mvA, tid);
+        vs[tid] = mv_sum(mvB, tid);
+      }
+    }
     store_strip(Q, S, p, keepN);                                    // [S] -> Q  (read after barrier (e))
     invert_strip_horner_k<KS>(series_order(nrm), E, G, P, N, sm, p);   // [E2] -> P, barrier (c), series
   }
@@ -542,6 +582,10 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
   load_strip_global_c8_issue(Rmp, R_mp, N, p);
   __syncthreads();                        // (g)
   VSM_STAMP(13);
+  if constexpr (!RID) {   // T21 z , Y z
+    mv_part(P, vz, 1.0, mvA[p.wave], p);
+    mv_part(Q, vz, 1.0, mvB[p.wave], p);
+  }
   load_strip_global_c8_finish(Tpp, p, xw);
   if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
@@ -580,6 +624,13 @@ __device__ __forceinline__ void ia_body(ssmem& sm, spos& p, int N, int ns, const
         const int row = p.row(ta, r);
         if (row < N) J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
       }
+  }
+  if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
+    __syncthreads();
+    if (tid < N) {
+      J0_p[tid] = vjp[tid] + mv_sum(mvA, tid);
+      J0_m[tid] = vJm[tid] + vs[tid] + mv_sum(mvB, tid);
+    }
   }
   VSM_STAMP(17);
   VSM_STAMP_FLUSH();
@@ -741,12 +792,16 @@ static int strip_enable_lds(K kern, const char* what) {
 int VSM_CAT(launch_ed_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
                                             const double* varpi, const double* tau_sum, const double* F0,
                                             const zsrc<double>& z, const added<double>& a, hipStream_t st) {
+#if VSM_STRIP_KS < 16
   static int prepared = strip_enable_lds(k_ed_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ed_strip)");
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_ed_strip<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z,
                      a);
   VSM_LAUNCH_CHECK("k_ed_strip");
   return VSM_OK;
+#else   // N = 61..64: elemental! + doubling! alone stay on the LDS-resident kernels (the strip form needs the pre-pass)
+  return VSM_ERR_UNSUPPORTED;
+#endif
 }
 int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
   static int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_ia_strip)");
@@ -780,11 +835,15 @@ VSM_STRIP_DECL(12)
 VSM_STRIP_DECL(13)
 VSM_STRIP_DECL(14)
 VSM_STRIP_DECL(15)
+VSM_STRIP_DECL(16)
 
 bool strip_supported(int N) {
   const int Kend = ((N + 3) >> 2) << 2;
   return N > 32 && Kend + 2 <= SNP;
 }
+// the layer step (pre-pass + layer kernel) and interaction!(_11) also take N = 61..64 (KS = 16: no spare columns, the source
+// vectors by mat-vecs over the A-forms)
+bool strip_layer_supported(int N) { return N > 32 && N <= SNP; }
 
 template <int KS>
 static void launch_gemm_strip(int M, int Nc, int K, int S, int P, const double* A, long long sa, long long pa, const double* B,
@@ -812,6 +871,8 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
   return VSM_OK;
 }
 
+#define VSM_STRIP_SWITCH16(N_, CALL)      \
+  if ((((N_) + 3) >> 2) == 16) return CALL(16);
 #define VSM_STRIP_SWITCH(N_, CALL)        \
   switch (((N_) + 3) >> 2) {               \
     case 9: return CALL(9);                \
@@ -877,7 +938,7 @@ __global__ __launch_bounds__(SNT) void k_elemental_img(quad<double> q, int ndoub
   double* T = out + PRE_IMG;
   const int Kend = ((N + 3) >> 2) << 2;
   const int c1 = Kend, c2 = Kend + 1;   // the spare columns that carry the source vectors through the doubling loop
-  const bool riders_in = ndoubl > 0;
+  const bool riders_in = ndoubl > 0 && Kend + 2 <= SNP;   // (N = 61..64: no spare column; the layer kernel uses mat-vecs)
 #pragma unroll 1
   for (int j = wave; j < SNP; j += 4) {
     if (riders_in && (j == c1 || j == c2)) continue;   // written below
@@ -934,8 +995,8 @@ static int strip_layer_forward_pre(const quad<double>& q, int S, int nm, int ndo
                                    const double* tau_sum, const double* F0, const layer_mm_args<double>& a, int toa,
                                    hipStream_t st, int thermal) {
   if (S <= 0 || nm <= 0) return VSM_OK;
-  if (!strip_supported(q.N)) {
-    set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
+  if (!strip_layer_supported(q.N)) {
+    set_error("strip_layer_forward_mm: N=%d outside (32, 64]", q.N);
     return VSM_ERR_UNSUPPORTED;
   }
   double* pre = static_cast<double*>(scratch((size_t)nm * S * PRE_STRIDE * sizeof(double), 3));
@@ -953,6 +1014,7 @@ static int strip_layer_forward_pre(const quad<double>& q, int S, int nm, int ndo
   }
   VSM_LAUNCH_CHECK("k_elemental_img");
 #define VSM_CALL(KS) VSM_CAT(launch_layer_strip_mm_, KS)(q, S, nm, ndoubl, a, toa, pre, st)
+  VSM_STRIP_SWITCH16(q.N, VSM_CALL)
   VSM_STRIP_SWITCH(q.N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_layer_forward_mm: N=%d outside (32, 60]", q.N);
@@ -979,6 +1041,7 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
 #define VSM_CALL(KS) VSM_CAT(launch_ia_strip_, KS)(N, S, c, a, st)
+  VSM_STRIP_SWITCH16(N, VSM_CALL)
   VSM_STRIP_SWITCH(N, VSM_CALL)
 #undef VSM_CALL
   set_error("strip_interaction11: N=%d outside (32, 60]", N);

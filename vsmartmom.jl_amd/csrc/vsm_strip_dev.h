@@ -130,6 +130,22 @@ __device__ __forceinline__ void copy_image_to_lds(double* L, const double* __res
   }
 }
 
+// Source vectors without spare columns (N = 61..64: the strips are full): y = A x as VALU mat-vecs over the A-form.  A wave takes
+// a quarter of the columns (lane = row: a column of the swizzled image is a permutation of 64 consecutive words, conflict-free)
+// and leaves its partial sums of two products in two 64-word slots; after a barrier mv_sum adds the four waves' slots.
+__device__ __forceinline__ void mv_part(const double* A, const double* x, double s, double* slot, const spos& p) {
+  double acc = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = 16 * p.wave + kk;
+    acc = fma(A[lidx<SNP>(p.lane, k)], x[k], acc);
+  }
+  slot[p.lane] = acc * s;
+}
+__device__ __forceinline__ double mv_sum(double* const* slots, int i) {
+  return (slots[0][i] + slots[1][i]) + (slots[2][i] + slots[3][i]);
+}
+
 // acc += A * B   (A: A-form in LDS, B: strip in registers).  Software-pipelined by one k-step.
 template <int KS>
 __device__ __forceinline__ void mm_ab(sstrip& acc, const double* A, const sstrip& B, spos& p) {
