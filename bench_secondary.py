@@ -96,7 +96,8 @@ def c3_lin(vsm, torch, arch):
     wall, dev, _ = _timed(torch, step)
     fl = scene.flops_per_point() if hasattr(scene, "flops_per_point") else None
     e = _entry("C3-lin", "ocean / Cox-Munk scene (config/ocean_coxmunk.yaml): IQUV, N=60 FP64, 33 layers, m=0..21, linearized "
-               "(gas column + wind speed) -- a latency-bound two-point batch", S, wall, dev, fl, "f64", "launch latency (22 x 33 layer steps)")
+               "(gas column + wind speed) -- a latency-bound two-point batch", S, wall, dev, fl, "f64",
+               "latency: two folded chains of 33 layer steps (k_dbl_lin_multi + 2 k_ia_lin_half per step), moments m >= 1 as one batch")
     del scene
     return e
 

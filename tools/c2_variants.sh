@@ -3,7 +3,7 @@
 # (value, avg launch of the layer kernel, fraction of peak).  Diagnostic; the shipped library is vsmartmom.jl_amd/lib/.
 cd "$(dirname "$0")/.."
 for lib in vsmartmom.jl_amd/lib_dbg/libw_*.so; do
-  out=$(VSM_LIB_PATH=$PWD/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | tail -1)
+  out=$(VSM_LIB_PATH=$PWD/$lib python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -1)
   python - "$lib" "$out" <<'PY'
 import json, sys
 try:
