@@ -7,7 +7,8 @@ FP64, Rayleigh (depol 0.0279) + synthetic O2-like absorption (40 pseudo-lines, c
 Lambertian 0.15, Fourier moments m = 0..2.   A "step" = one full rt_run-equivalent over the batch:
 H2D of the raw optical depths, layer optics on the device, all m, all layers (elemental -> doubling ->
 interaction), surface, VZA post-processing, ONE gather of R/T over the ranks and the D2H of the result.
-N GPUs => N x 10 000 points (weak scaling; `--total-points` = strong scaling).  `--gpus N` without a launcher
+N GPUs => N x 10 000 points (weak scaling; `--total-points` = strong scaling).  `--config C4`: configs[3] (N = 96, FP32; 10^5 points
+in total over the GPUs), `--config C5`: configs[4] (rotational Raman, 2 10^4 points in total, halo-extended blocks per rank).  `--gpus N` without a launcher
 starts its own N ranks (torch.distributed.run, one process per GPU over RCCL) or fails if N GPUs are not visible.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
@@ -48,6 +49,8 @@ CONFIGS = {
     # name: (polarization, l_trunc, FT, layers, points per GPU)
     "C2": dict(pol="IQU", l_trunc=35, FT="f64", L=40, S=10000, N=60),
     "C4": dict(pol="IQU", l_trunc=59, FT="f32", L=60, S=12500, N=96),
+    # BASELINE.json configs[4]: rotational Raman, 20 000 spectral points IN TOTAL (strong scaling; the reference quotes it on 2 GPUs)
+    "C5": dict(pol="IQU", l_trunc=9, FT="f64", L=12, S=20000, N=21, K=40),
 }
 
 
@@ -127,6 +130,8 @@ def main():
     from vsmartmom_jl_amd import parallel
 
     rank, world, local = parallel.init_process_group_from_env()
+    if args.config == "C5":
+        return bench_c5(args, vsm, parallel, torch, rank, world, local)
     cfg = dict(CONFIGS[args.config], name=args.config)
     if args.points:
         cfg["S"] = args.points
@@ -287,6 +292,83 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample, L)
         print(json.dumps(line))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def bench_c5(args, vsm, parallel, torch, rank, world, local):
+    """`--config C5`: rt_run(RS_type::RRS, model, iBand) on BASELINE.json configs[4] (nStokes = 3, N = 21, 12 layers, K = 40 Raman
+    lines, m = 0..2, 20 000 spectral points in TOTAL unless --points gives the points per GPU): every rank computes on its block
+    of recipient points extended by the halo of max|shift| donor points (no exchange step), then ONE gather per output array
+    (R, T, ieR, ieT).  A step = the whole call: host optics, H2D, device pass, gather, D2H."""
+    cfg = dict(CONFIGS["C5"], name="C5")
+    S_total = args.points * world if args.points else (args.total_points or cfg["S"])
+    L, K = args.layers or cfg["L"], cfg["K"]
+    arch = vsm.Architectures.GPU(local)
+    vsm._lib.lib()
+    rng = np.random.default_rng(20260929)
+    dp = np.full(L, 1.0 / L)
+    tau_rayl = np.tile(0.3 * dp, (S_total, 1))
+    tau_abs = (10.0 ** rng.uniform(-4, 0, (S_total, 1))) * dp[None, :]
+    H = vsm.host_model
+    model = H.model_from_arrays(arch, cfg["pol"], cfg["l_trunc"], 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075,
+                                albedo=0.05, m_max=2)
+    model.varpi_Cabannes = 0.96
+    N = model.quad_points.Nquad * 3
+    shifts = np.unique(np.concatenate([np.arange(-K // 2, 0), np.arange(1, K - K // 2 + 1)]) * 7)
+    rs = vsm.CoreRTRaman.RRS(shifts, np.full(len(shifts), 0.04 / len(shifts)), H.get_greek_rayleigh(0.75))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return vsm.CoreRTRaman.rt_run_sharded(rs, model, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    mg = {"rccl_ranks": 1, "per_rank_step_ms": [1e3 * dt / args.steps], "per_rank_device": [torch.cuda.get_device_name(local)]}
+    if world > 1:
+        dist = torch.distributed
+        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+        names = [None] * world
+        dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
+        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+              "per_rank_step_ms": [1e3 * float(x.item()) / args.steps for x in every], "per_rank_device": names}
+        dt = max(float(x.item()) for x in every)
+    if rank == 0:
+        n3, n2 = float(N) ** 3, float(N) ** 2
+        lods = H.constructCoreOpticalProperties(model, 0)
+        nds = [H.get_dtau_ndoubl(np.atleast_1d(lo.tau), np.broadcast_to(np.asarray(lo.varpi), np.atleast_1d(lo.tau).shape),
+                                 model.quad_points, np.float64, model.numerics)[1] for lo in lods]
+        n1 = np.arange(S_total)
+        kin = sum(((n1 + int(sh) >= 0) & (n1 + int(sh) < S_total)).astype(float) for sh in shifts).mean()
+        per_m = sum(nd * (12 * n3 + 8 * n2 + kin * (32 * n3 + 20 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (36 * n3 + 16 * n2))
+        exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
+        pts = S_total * args.steps / dt
+        tf = 3 * per_m * pts / 1e12
+        print(json.dumps({
+            "metric": "spectral-points/s (whole node) for rt_run(RRS), BASELINE configs[4]", "value": pts, "unit": "spectral-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak" if args.points else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C5: rotational Raman (RRS), nStokes=3, N=%d, %d layers, %d spectral points in total, %d Raman lines, "
+                                   "m=0..2; ranks own contiguous blocks of recipient points + halo of %d donor points" %
+                                   (N, L, S_total, len(shifts), int(np.max(np.abs(shifts)))),
+                       "timed_step": "whole rt_run(RRS) per rank (host optics, H2D, device pass) + one gather per output + D2H",
+                       "ranks": world, "multi_gpu": mg, "timed_region_s": dt, "algorithmic_gflop_per_point": 3 * per_m / 1e9,
+                       "in_band_lines_per_point": kin},
+            "roofline": {"bound": "mfma", "kernel": "whole run (k_raman_doubling_wave_sp<21> ~72 %, k_raman_interaction_wave<21> ~16 %)",
+                         "achieved": tf, "peak": PEAK_TFLOPS["f64"] * world, "unit": "TFLOP/s", "frac": tf / (PEAK_TFLOPS["f64"] * world),
+                         "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world), "traffic": None}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
