@@ -238,13 +238,14 @@ def main():
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
     interval_kernels = None
-    if cfg["FT"] == "f64" and 32 < N <= 60:
+    if cfg["FT"] == "f64" and 32 < N <= 64:
         # the event pair of a layer step brackets the fused layer kernel AND its elemental pre-pass (k_elemental_img writes the
         # A-form images the layer kernel copies in): the fraction below charges both to the layer kernel's flops
-        kernel_name = "k_layer_strip_mm" if moments_per_launch > 1 else "k_layer_strip"
-        interval_kernels = ["k_elemental_img", "k_layer_strip_mm"] if moments_per_launch > 1 else ["k_layer_strip"]
+        kernel_name = "k_layer_strip_mm"
+        interval_kernels = ["k_elemental_img", "k_layer_strip_mm"]
     elif cfg["FT"] == "f32" and 64 < N <= 96:
-        kernel_name = "k_layer_strip32"
+        kernel_name = "k_layer_strip32_mm" if moments_per_launch > 1 else "k_layer_strip32"
+        interval_kernels = ["k_elemental_img32", "k_layer_strip32_mm"] if moments_per_launch > 1 else ["k_layer_strip32"]
     else:
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
