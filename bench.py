@@ -193,16 +193,16 @@ def main():
         dist = torch.distributed
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)      # (a real RCCL collective: the rank count below is observed after it)
-        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
-        names = [None] * world
-        dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
-        try:
-            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
-        except Exception:
-            ver = None
-        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": ver,
-              "per_rank_step_ms": [1e3 * float(x.item()) / args.steps for x in every], "per_rank_device": names}
+        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        try:   # (diagnostics only: nothing here may take the bench line down)
+            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+            names = [None] * world
+            dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
+            mg.update(per_rank_step_ms=[1e3 * float(x.item()) / args.steps for x in every], per_rank_device=names)
+            mg["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as ex:
+            mg["note"] = "per-rank diagnostics unavailable: %s" % ex
         dt = float(tmax.item())
         timed_region_s = dt
     step(split=True)   # phase attribution, outside the timed region
