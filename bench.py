@@ -339,13 +339,18 @@ def bench_c5(args, vsm, parallel, torch, rank, world, local):
     mg = {"rccl_ranks": 1, "per_rank_step_ms": [1e3 * dt / args.steps], "per_rank_device": [torch.cuda.get_device_name(local)]}
     if world > 1:
         dist = torch.distributed
-        every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
-        names = [None] * world
-        dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
-        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-              "per_rank_step_ms": [1e3 * float(x.item()) / args.steps for x in every], "per_rank_device": names}
-        dt = max(float(x.item()) for x in every)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mg = {"rccl_ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        try:   # (diagnostics only)
+            every = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+            dist.all_gather(every, torch.tensor([dt], dtype=torch.float64, device="cuda"))
+            names = [None] * world
+            dist.all_gather_object(names, "%s (cuda:%d)" % (torch.cuda.get_device_name(local), local))
+            mg.update(per_rank_step_ms=[1e3 * float(x.item()) / args.steps for x in every], per_rank_device=names)
+        except Exception as ex:
+            mg["note"] = "per-rank diagnostics unavailable: %s" % ex
+        dt = float(tmax.item())
     if rank == 0:
         n3, n2 = float(N) ** 3, float(N) ** 2
         lods = H.constructCoreOpticalProperties(model, 0)
