@@ -806,10 +806,10 @@ def test_rt_run_component_mixing_on_device(vsm, arch, FT, pol, l_trunc, tol):
     assert _rel(vsm.CoreRT.from_device_matrix(mat.Zpp), ref) < (1e-14 if FT == np.float64 else 1e-6)
 
 
-@pytest.mark.parametrize("pol,l_trunc,FT,aer", [("IQU", 33, np.float64, False),   # N = 57: one launch per layer for the moments
+@pytest.mark.parametrize("pol,l_trunc,FT,aer", [("IQU", 33, np.float64, False),   # N = 60: one launch per layer for the moments
                                                 ("IQU", 33, np.float64, True),    # ... component-mixed Z, 6 moments = 4 + 2
-                                                ("IQUV", 43, np.float32, False),  # N = 96 FP32: moment by moment in the library
-                                                ("I", 9, np.float64, True)])      # N = 7: LDS-resident kernels
+                                                ("IQUV", 41, np.float32, False),  # N = 96 FP32: the FP32 pre-pass + layer-kernel pair
+                                                ("I", 9, np.float64, True)])      # N = 8: LDS-resident kernels
 def test_moment_batched_run_equals_moment_by_moment(vsm, arch, monkeypatch, pol, l_trunc, FT, aer):
     """Scene.run walks the Fourier moments of a group together (vsm_layer_forward_multi: one launch per layer step for the
     group where the strip kernel takes the shape); the results are the bits of the moment-by-moment walk, with a thermal
@@ -829,6 +829,8 @@ def test_moment_batched_run_equals_moment_by_moment(vsm, arch, monkeypatch, pol,
     model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 0.0], [0.0, 75.0],
                                 sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **kw)
     monkeypatch.delenv("VSM_NO_MOMENT_BATCH", raising=False)
+    N = model.quad_points.Nquad * model.polarization_type.n
+    assert N == {("IQU", 33): 60, ("IQUV", 41): 96, ("I", 9): 8}[(pol, l_trunc)]
     out_b = vsm.CoreRT.rt_run(model, full_output=True)
     monkeypatch.setenv("VSM_NO_MOMENT_BATCH", "1")
     out_s = vsm.CoreRT.rt_run(model, full_output=True)

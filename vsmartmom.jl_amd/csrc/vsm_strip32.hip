@@ -1104,35 +1104,28 @@ static int enable_lds32(K kern, const char* what) {
   return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
 }
 
+// (the thermal slot only: a solar layer step goes through the pre-pass pair, strip32_layer_forward)
 template <int KB, bool AL>
 static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st, int thermal) {
-  static int prepared = enable_lds32(k_layer_strip32<KB, false, AL>, "hipFuncSetAttribute(k_layer_strip32)");
-  static int prepared_mix = enable_lds32(k_layer_strip32<KB, true, AL>, "hipFuncSetAttribute(k_layer_strip32 mix)");
-  if (prepared) return prepared;
-  if (prepared_mix) return prepared_mix;
+  if (!thermal) {
+    set_error("launch_layer32: the solar layer step is the pre-pass pair");
+    return VSM_ERR_UNSUPPORTED;
+  }
+  static int prepared_th = enable_lds32(k_layer_strip32<KB, false, AL, true>, "hipFuncSetAttribute(k_layer_strip32 th)");
+  static int prepared_thm = enable_lds32(k_layer_strip32<KB, true, AL, true>, "hipFuncSetAttribute(k_layer_strip32 thm)");
+  if (prepared_th) return prepared_th;
+  if (prepared_thm) return prepared_thm;
   const dim3 grid((S + 1) / 2), block(2 * FNT);
   const size_t lds = 2 * sizeof(fsmem32);
-  if (thermal) {   // F0 = B[S]
-    static int prepared_th = enable_lds32(k_layer_strip32<KB, false, AL, true>, "hipFuncSetAttribute(k_layer_strip32 th)");
-    static int prepared_thm = enable_lds32(k_layer_strip32<KB, true, AL, true>, "hipFuncSetAttribute(k_layer_strip32 thm)");
-    if (prepared_th) return prepared_th;
-    if (prepared_thm) return prepared_thm;
-    if (z.ncomp > 0)
-      hipLaunchKernelGGL((k_layer_strip32<KB, true, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
-                         toa, c);
-    else
-      hipLaunchKernelGGL((k_layer_strip32<KB, false, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
-                         toa, c);
-    VSM_LAUNCH_CHECK("k_layer_strip32(thermal)");
-    return VSM_OK;
-  }
-  if (z.ncomp > 0)
-    hipLaunchKernelGGL((k_layer_strip32<KB, true, AL>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
+  if (z.ncomp > 0)   // F0 = B[S]
+    hipLaunchKernelGGL((k_layer_strip32<KB, true, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
+                       toa, c);
   else
-    hipLaunchKernelGGL((k_layer_strip32<KB, false, AL>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c);
-  VSM_LAUNCH_CHECK("k_layer_strip32");
+    hipLaunchKernelGGL((k_layer_strip32<KB, false, AL, true>), grid, block, lds, st, q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z,
+                       toa, c);
+  VSM_LAUNCH_CHECK("k_layer_strip32(thermal)");
   return VSM_OK;
 }
 template <int KB, bool AL>
@@ -1170,10 +1163,21 @@ bool strip32_supported(int N) {
   return !off && N > 64 && N <= FNP;
 }
 
+int strip32_layer_forward_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
+                             const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st);
 int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,
                           const float* tau_sum, const float* F0, const zsrc<float>& z, int toa, const composite<float>& c,
                           hipStream_t st, int thermal) {
   if (S <= 0) return VSM_OK;
+  if (!thermal) {   // a solar layer step of one moment: the multi-moment pair (pre-pass + layer kernel) with nm = 1
+    layer_mm_args<float> a;
+    for (int i = 0; i < VSM_MM_MAX; ++i) {
+      a.m[i] = m;
+      a.z[i] = z;
+      a.c[i] = c;
+    }
+    return strip32_layer_forward_mm(q, S, 1, ndoubl, dtau, varpi, tau_sum, F0, a, toa, st);
+  }
   // N % 4 != 0: element-wise global accesses, one instantiation (KB = 6) for all such N
   if (q.N & 3) return launch_layer32<6, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
   if (q.N > 80) return launch_layer32<6, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, z, toa, c, st, thermal);
