@@ -313,6 +313,54 @@ def test_elemental_doubling_fused_and_oplevel(vsm, arch, pol_name, l_trunc, FT, 
         assert _rel(gotb[k], getattr(oa, k)) < tol, ("oplevel", k)
 
 
+@pytest.mark.parametrize("pol_name,l_trunc,N_expected", [("I", 125, 66), ("I", 151, 79), ("IQUV", 41, 96), ("IQU", 61, 102),
+                                                         ("IQU", 67, 111), ("I", 243, 125), ("I", 245, 126)])
+@pytest.mark.parametrize("thick", [False, True])
+def test_doubling_strip_kernel_64_to_126(vsm, arch, pol_name, l_trunc, N_expected, thick):
+    """doubling! of the FP64 shapes 64 < N <= 126 (k_dbl128: one workgroup per point, the whole loop on chip) vs oracle.doubling
+    (doubling.jl:38-99, rt_helpers.jl:102-166).  N covers every row-tile count (5..8), rider columns inside a matrix strip
+    (66, 102, 125, 126) and in a strip of their own (79 -> 80, 96, 111 -> 112); `thick`: conservative Rayleigh layers of tau up
+    to 12, where ||r r|| leaves the Neumann series' range and the inverse runs by squaring levels."""
+    FT = np.float64
+    if thick:
+        rng = np.random.default_rng(11)
+        pol = O.polarization(pol_name)
+        qp = O.rt_set_streams_gausslegquad(l_trunc, 40.0, [30.0, 0.0], pol, FT)
+        tau = np.array([0.8, 3.0, 12.0])
+        lo = O.expand_optical_properties(O.CoreScatteringOpticalProperties(
+            tau, np.float64(1.0), *O.compute_Z_moments(pol, qp.qp_mu.astype(np.float64), O.get_greek_rayleigh(0.0279), 0)), FT)
+        m = 0
+    else:
+        pol, qp, props, rng = _scene(pol_name, l_trunc, 40.0, [30.0, 0.0], FT)
+        m = 1
+        lo = props[m]
+    S, N = len(lo.tau), qp.Nquad * pol.n
+    assert N == N_expected
+    dtau, nd = O.get_dtau_ndoubl(lo.tau, lo.varpi, qp, FT)
+    assert nd >= 2
+    tau_sum = rng.random(S).astype(FT)
+    F0 = np.zeros((pol.n, S), dtype=FT)
+    F0[0] = 1.0
+    oa = O.make_added_layer(FT, N, S)
+    O.elemental(pol, tau_sum, dtau, F0, lo.varpi, lo.Zpp, lo.Zmp, m, nd, qp, oa, FT)
+    expk = np.exp(-dtau / FT(qp.mu0)).astype(FT)
+    O.doubling(pol, expk, nd, oa, FT)
+    dq, hpol = _product_quad(vsm, arch, qp, pol, FT)
+    conv = vsm.Architectures.array_type(arch)
+    pb = vsm.CoreRT.make_added_layer(FT, arch, (N, N), S)
+    vsm.CoreRT.elemental_(hpol, conv(tau_sum), conv(dtau), conv(np.ascontiguousarray(F0.T)), _product_props(vsm, arch, lo, FT), m, nd,
+                          dq, pb)
+    t_expk = conv(expk)
+    vsm.CoreRT.doubling_(hpol, t_expk, nd, pb)
+    got = _added_to_host(vsm, pb)
+    # nd = 17..21 doublings here: a one-ulp perturbation of the elemental r, t moves the oracle's own result by up to
+    # 8e-10 (N = 125, nd = 21) -- the gate scales with the 2^nd amplification of the squarings
+    tol = 50 * 2.0 ** nd * np.finfo(FT).eps
+    for k in got:
+        assert _rel(got[k], getattr(oa, k)) < tol, (k, nd)
+    assert _rel(vsm.Architectures.to_host(t_expk), expk ** (2 ** nd)) < 4 * 2.0 ** nd * np.finfo(FT).eps   # squared in place
+
+
 def _random_layers(rng, N, S, FT, pol):
     """Physically shaped operators: small reflections, near-diagonal transmissions."""
     def refl(scale):

@@ -488,34 +488,31 @@ class SceneLin:
         model, pol, qp, FT, dt, fwd = self.model, self.pol, self.qp, self.FT, self.dt, self.fwd
         N, S, P, pl = self.N, self.S, self.P, self.pl
         added, al, comp, cl = w["added"], w["al"], w["comp"], w["cl"]
-        isurf = self.layout.surface_index(0)
         mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
         q_ = self.dq.cstruct()
-        if True:
-            m = mom["m"]
-            weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
-            for iz, ly in enumerate(mom["layers"]):
-                props = ly["props"]
-                dtd, vd, tsd = self.dtau_dot_all[iz], self.varpi_dot[iz], self.tau_sum_dot[iz]
-                if self.Zall is not None:
-                    mixed, k = fwd.zcomp[iz]
-                    a_, al_ = added.cstruct(), al.cstruct()
-                    _lib.call("vsm_elemental_lin_mix", dt, C.byref(q_), S, m, ly["nd"], CR._ptr(ly["dtau"]), CR._ptr(props.varpi),
-                              CR._ptr(ly["tau_sum"]), CR._ptr(self.F0), self.C_, self.CT, CR._ptr(self.Zall[m][0]),
-                              CR._ptr(self.Zall[m][1]), -1 if mixed else k, CR._ptr(self.fz[iz]), pl, CR._ptr(dtd), CR._ptr(vd),
-                              CR._ptr(tsd), CR._ptr(self.zdcoef[iz]), C.byref(a_), C.byref(al_), CR._stream_ptr())
-                else:
-                    zpd, zmd, zds = self.host_zdot[m][iz] if self.host_zdot is not None else (None, None, (0, 0))
-                    elemental_lin_(pol, ly["tau_sum"], tsd, ly["dtau"], dtd, self.F0, props.materialize(), vd, zpd, zmd, zds, pl,
-                                   m, ly["nd"], self.dq, added, al)
-                _lib.call("vsm_layer_expk", dt, S, CR._ptr(ly["dtau"]), mu0, CR._ptr(w["expk"]), CR._stream_ptr())
-                doubling_allparams_(pol, w["expk"], ly["nd"], added, al, dtd, qp.mu0, pl)
-                if iz == 0:
-                    CR.copy_added_to_composite_(comp, added)
-                    a_, c_ = al.cstruct(), cl.cstruct()
-                    _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
-                else:
-                    interaction_lin_(ly["iface"], comp, cl, added, al)
+        m = mom["m"]
+        for iz, ly in enumerate(mom["layers"]):
+            props = ly["props"]
+            dtd, vd, tsd = self.dtau_dot_all[iz], self.varpi_dot[iz], self.tau_sum_dot[iz]
+            if self.Zall is not None:
+                mixed, k = fwd.zcomp[iz]
+                a_, al_ = added.cstruct(), al.cstruct()
+                _lib.call("vsm_elemental_lin_mix", dt, C.byref(q_), S, m, ly["nd"], CR._ptr(ly["dtau"]), CR._ptr(props.varpi),
+                          CR._ptr(ly["tau_sum"]), CR._ptr(self.F0), self.C_, self.CT, CR._ptr(self.Zall[m][0]),
+                          CR._ptr(self.Zall[m][1]), -1 if mixed else k, CR._ptr(self.fz[iz]), pl, CR._ptr(dtd), CR._ptr(vd),
+                          CR._ptr(tsd), CR._ptr(self.zdcoef[iz]), C.byref(a_), C.byref(al_), CR._stream_ptr())
+            else:
+                zpd, zmd, zds = self.host_zdot[m][iz] if self.host_zdot is not None else (None, None, (0, 0))
+                elemental_lin_(pol, ly["tau_sum"], tsd, ly["dtau"], dtd, self.F0, props.materialize(), vd, zpd, zmd, zds, pl,
+                               m, ly["nd"], self.dq, added, al)
+            _lib.call("vsm_layer_expk", dt, S, CR._ptr(ly["dtau"]), mu0, CR._ptr(w["expk"]), CR._stream_ptr())
+            doubling_allparams_(pol, w["expk"], ly["nd"], added, al, dtd, qp.mu0, pl)
+            if iz == 0:
+                CR.copy_added_to_composite_(comp, added)
+                a_, c_ = al.cstruct(), cl.cstruct()
+                _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
+            else:
+                interaction_lin_(ly["iface"], comp, cl, added, al)
         self._finish_moment(mom, w)
 
     def _finish_moment(self, mom, w):
@@ -527,22 +524,21 @@ class SceneLin:
         q_ = self.dq.cstruct()
         m = mom["m"]
         weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
-        if True:
-            a_, al_ = w["added_s"].cstruct(), w["als"].cstruct()
-            tau_sum_s, tsd_s = mom["tau_sum_surface"], self.tau_sum_dot[fwd.Nz]
-            rho, drho = self.surf[m]
-            if isinstance(model.surface, H.CoxMunkSurface):
-                _lib.call("vsm_brdf_surface_lin", dt, C.byref(q_), S, m, CR._ptr(rho), CR._ptr(drho), isurf, CR._ptr(tau_sum_s),
-                          CR._ptr(tsd_s), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
-            else:
-                alb = C.c_double(model.surface.albedo) if dt == torch.float64 else C.c_float(model.surface.albedo)
-                _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(tau_sum_s), CR._ptr(tsd_s), pl,
-                          CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
-            interaction_lin_(mom["iface_surface"], comp, cl, w["added_s"], w["als"])
-            CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), w["R"], w["T"])
-            row0, wts = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
-            _lib.call("vsm_postprocess_vza_lin", dt, N, pol.n, S, len(model.vza), P, row0, wts, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p),
-                      CR._ptr(w["Rd"]), CR._ptr(w["Td"]), CR._stream_ptr())
+        a_, al_ = w["added_s"].cstruct(), w["als"].cstruct()
+        tau_sum_s, tsd_s = mom["tau_sum_surface"], self.tau_sum_dot[fwd.Nz]
+        rho, drho = self.surf[m]
+        if isinstance(model.surface, H.CoxMunkSurface):
+            _lib.call("vsm_brdf_surface_lin", dt, C.byref(q_), S, m, CR._ptr(rho), CR._ptr(drho), isurf, CR._ptr(tau_sum_s),
+                      CR._ptr(tsd_s), pl, CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
+        else:
+            alb = C.c_double(model.surface.albedo) if dt == torch.float64 else C.c_float(model.surface.albedo)
+            _lib.call("vsm_lambertian_surface_lin", dt, C.byref(q_), S, m, alb, isurf, CR._ptr(tau_sum_s), CR._ptr(tsd_s), pl,
+                      CR._ptr(self.F0), C.byref(a_), C.byref(al_), CR._stream_ptr())
+        interaction_lin_(mom["iface_surface"], comp, cl, w["added_s"], w["als"])
+        CR.postprocessing_vza_(pol, comp, model.vza, model.vaz, qp, m, float(weight), w["R"], w["T"])
+        row0, wts = _pp_args(pol, qp, model.vza, model.vaz, m, weight, dt)
+        _lib.call("vsm_postprocess_vza_lin", dt, N, pol.n, S, len(model.vza), P, row0, wts, CR._ptr(cl.J0_m), CR._ptr(cl.J0_p),
+                  CR._ptr(w["Rd"]), CR._ptr(w["Td"]), CR._stream_ptr())
 
     def results_host(self):
         """(R, T, Rdot, Tdot) as the reference returns them: [nVZA, nStokes, nSpec] and [nVZA, nStokes, nSpec, Nparams]."""

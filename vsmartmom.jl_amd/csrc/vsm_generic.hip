@@ -470,6 +470,10 @@ __global__ void k_apply_D(int N, int n_stokes, T* r_mp, const T* __restrict__ t_
 template <typename T>
 int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a, T* work, hipStream_t st) {
   if (ndoubl == 0 || S <= 0) return VSM_OK;  // doubling.jl:50
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_strip = ab_switch("VSM_NO_STRIP128");
+    if (!no_strip && strip128_supported(N)) return strip128_doubling(N, n_stokes, S, ndoubl, expk, a, st);
+  }
   const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
   T* W1 = work;
   T* W2 = W1 + per;

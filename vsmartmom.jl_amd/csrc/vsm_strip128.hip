@@ -1,0 +1,469 @@
+// FP64 column-strip kernels for 64 < N <= 126 (the reference's own baseline shapes live here: Natraj N = 108,
+// test/test_CoreRT.jl:110-157; VLIDORT case A N = 112, test/vlidort_baseline/cases/case_A_siewert2000.jl:29-50).
+//
+//   k_dbl128<RT>   doubling! (src/CoreRT/CoreKernel/doubling.jl:38-99, rt_helpers.jl:102-166, apply_D doubling.jl:178-252):
+//                  the whole doubling loop of one spectral point in one workgroup, in place on the AddedLayer
+//
+// Scheme (vsm_strip.hip's, re-dimensioned): a matrix is padded to NP = 16 RT rows (RT = 5..8 row tiles); wave w owns the
+// 16-column strip w of every operator as RT accumulator tiles of v_mfma_f64_16x16x4 -- the accumulator layout IS the B-operand
+// layout, so a strip is the right operand of the next product without any movement.  The left operand is an "A-form" of the
+// matrix in LDS that all waves read.  One A-form of 128 x 128 doubles is 128 KB: there is room for ONE (vsm_strip.hip keeps two
+// of 32 KB), and a wave's 256 registers hold THREE strips of 64, not five.  So
+//   * the products of a step are ordered by their left operand, [r] -> [E] -> [t] -> [tt], each A-form written once from the
+//     strips (two barriers), every product of that operand running off it:
+//         W = r t ; E = r r ;  G = (I - E)^-1 (Neumann series off [E]) ;  tt = t G ;  r' = r + tt W ;  t' = tt t
+//   * the strips that are not needed during the inverse (r, t) wait in a per-workgroup global scratch (lane-linear, 2 KB per
+//     instruction, L2 / MALL resident: 2 stores + 3 loads of 16 KB per wave and step against 7 x 256 MFMAs).
+// Workgroups are persistent (one per CU, 1 + RT waves at most: two waves per SIMD) and walk the spectral axis.
+// Source vectors ride in two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip:
+// N <= 126 leaves them room in at most 8 strips.  N = 127, 128 stay on the operator chain.
+//
+// A-form layout (verified conflict-free for both directions): block (ks, t) = the 16 x 4 fragment of row tile t and k-step ks,
+// 64 doubles; inside a block, element (m, k') of k-step ks sits at word
+//     k' << 4 | (m ^ (k' | j << 2)),     j = ks & 3
+// so that a fragment read (lanes = (k', m); ds_read_b64 in 32-lane groups, or ds_read2st64_b64 for two row tiles in 16-lane
+// groups) covers its part of the 512-byte block linearly, and a strip store (ds_write_b64, 16-lane groups = 16 columns = four
+// k-steps x four k': k' | j << 2 is the lane's l15) hits 16 distinct 8-byte slots of a 128-byte bank row.
+#include "vsm_internal.h"
+#include "vsm_lds.h"
+
+namespace vsm {
+namespace {
+
+using lds_d = __attribute__((address_space(3))) double;
+__device__ __forceinline__ unsigned lds_addr128(const void* p) {
+  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ double dpp_swap1_128(double x) {   // value of lane ^ 1
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int B_MAXW = 8;   // waves per workgroup at most
+
+template <int RT>
+struct bstrip {
+  d4_t v[RT];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int a = 0; a < RT; ++a) v[a] = acc_zero<double>();
+  }
+};
+
+template <int RT>
+struct bpos {
+  int lane, wave, l15, kq, col;
+  unsigned ab[4][2];   // fragment bases (bytes) by (ks & 3, ks >= 16)
+  unsigned sb[4];      // strip element bases by r
+  bool mat_wave;       // the wave's columns are columns of the A-form (wave < RT)
+  __device__ __forceinline__ bpos(unsigned af) {
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    l15 = lane & 15;
+    kq = lane >> 4;
+    col = 16 * wave + l15;
+    mat_wave = wave < RT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ab[j][0] = af + 8u * (unsigned)((kq << 4) | (l15 ^ (kq | (j << 2))));
+      ab[j][1] = ab[j][0] + 8u * 64u * 16u * RT;
+    }
+    const int j = l15 >> 2, ww = mat_wave ? wave : 0;   // (a wave without matrix columns gets valid addresses it never stores to)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      sb[r] = af + 8u * (unsigned)(((4 * ww + j) * RT * 64) + (((l15 & 3) << 4) | (kq ^ (l15 & 3)) | ((r ^ j) << 2)));
+  }
+  __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
+  __device__ __forceinline__ const lds_d* aptr(int t, int ks) const {
+    const int h = ks >= 16 ? 1 : 0;
+    return reinterpret_cast<const lds_d*>((unsigned long long)ab[ks & 3][h]) + 64 * ((ks - 16 * h) * RT + t);
+  }
+  __device__ __forceinline__ lds_d* sptr(int ta, int r) const {
+    return reinterpret_cast<lds_d*>((unsigned long long)sb[r]) + 64 * ta;
+  }
+  // hide the loop invariance of the bases from LICM (it would hoist every derived address into a register)
+  __device__ __forceinline__ void opaque() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      asm volatile("" : "+v"(ab[j][0]));
+      asm volatile("" : "+v"(ab[j][1]));
+    }
+  }
+};
+
+// acc += [A] * B.  One register per row tile for the fragments: the fragment of tile t for step ks + 1 is requested right
+// behind the MFMA that consumed its predecessor (RT MFMAs = 64 RT cycles ahead of its use).
+template <int RT>
+__device__ __forceinline__ void mm128(bstrip<RT>& acc, const bstrip<RT>& B, bpos<RT>& p) {
+  constexpr int KS = 4 * RT;
+  p.opaque();
+  double a[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) a[t] = *p.aptr(t, 0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const double b = B.v[ks >> 2][ks & 3];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      acc.v[t] = mfma<double>::mma(a[t], b, acc.v[t]);
+      if (ks + 1 < KS) a[t] = *p.aptr(t, ks + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// strip -> A-form (columns >= N, i.e. the riders and the padding, as zeros); waves without matrix columns stay out
+template <int RT>
+__device__ __forceinline__ void store_af(const bstrip<RT>& s, int N, const bpos<RT>& p) {
+  if (!p.mat_wave) return;
+  const bool keep = p.col < N;
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *p.sptr(ta, r) = keep ? s.v[ta][r] : 0.0;
+}
+template <int RT>
+__device__ __forceinline__ void load_af(bstrip<RT>& s, const bpos<RT>& p) {
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s.v[ta][r] = *p.sptr(ta, r);
+}
+// strip <-> the wave's slot of the workgroup's global scratch (lane-linear 32-byte records)
+template <int RT>
+__device__ __forceinline__ void spill(d4_t* g, const bstrip<RT>& s, const bpos<RT>& p) {
+  asm volatile("" : "+v"(g));   // (the per-tile addresses are formed here, not hoisted out of the doubling loop into registers)
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta) g[64 * ta] = s.v[ta];
+}
+template <int RT>
+__device__ __forceinline__ void fill(bstrip<RT>& s, const d4_t* g, const bpos<RT>& p) {
+  asm volatile("" : "+v"(g));
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta) s.v[ta] = g[64 * ta];
+}
+
+// Frobenius-norm bound of the N x N block (rows >= N are zero by construction).  ONE barrier inside.
+template <int RT>
+__device__ __forceinline__ double norm128(const bstrip<RT>& e, int N, int nw, float* red, int& slot, const bpos<RT>& p) {
+  double ss = 0;
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ss = fma(e.v[ta][r], e.v[ta][r], ss);
+  ss = (p.col < N) ? ss : 0.0;
+  const float ws = wave_sum(to_float_up(ss));
+  if (p.lane == 0) red[16 * slot + p.wave] = ws;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < nw; ++w) tot += red[16 * slot + w];
+  slot ^= 1;
+  return (double)(sqrtf(tot) * 1.001f);
+}
+
+// order of the Neumann series (vsm_strip_dev.h series_order); 0 = not below 0.3: levels of squaring until the power vanishes
+__device__ __forceinline__ int series_order128(double nrm) {
+  const double tol = num<double>::eps() * 0.25;
+  int K = 0;
+  if (nrm < 0.3) {
+    const double lim = tol * (1.0 - nrm);
+    const double n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
+    if (n2 <= lim) K = 1;
+    else if (n2 * nrm <= lim) K = 2;
+    else if (n4 <= lim) K = 3;
+    else if (n4 * nrm <= lim) K = 4;
+    else if (n8 <= lim) K = 7;
+    else if (n8 * nrm <= lim) K = 8;
+    else if (n16 <= lim) K = 15;
+    else if (n16 * nrm <= lim) K = 16;
+    else if (n16 * n16 <= lim) K = 31;
+  }
+  return K;
+}
+
+template <int RT>
+__device__ __forceinline__ void add_identity(bstrip<RT>& G, int N, const bpos<RT>& p) {
+  // a lane owns at most one diagonal element, in row tile ta = wave: r = l15 >> 2, kq = l15 & 3
+  const bool dl = p.kq == (p.l15 & 3) && p.col < N;
+  const int dr = p.l15 >> 2;
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+    if (ta == p.wave) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G.v[ta][r] += (dl && dr == r) ? 1.0 : 0.0;
+    }
+}
+
+// G_s = strip of (I - E)^-1 from E's strips; every wave is past a barrier behind the last read of the A-form.
+//   K = 1..4: Horner off ONE A-form [E] (K - 1 products, no further barrier, two live strips)
+//   else:     G <- (I + E^(2^l)) G level by level (an A-form store and a product more per level) -- to the series order K, or,
+//             where the norm bound gave none (K = 0; the fused kernels of the smaller shapes pivot here), until the power's norm
+//             is below eps / 4: the spectral radius of r r is < 1 for every physical layer.
+// On return other waves may still be reading the A-form.
+template <int RT>
+__device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, int N, int nw, float* red, int& slot, bpos<RT>& p) {
+  if (K == 1) {
+    G = E;
+    add_identity(G, N, p);
+    return;
+  }
+  store_af(E, N, p);
+  __syncthreads();
+  if (K >= 2 && K <= 4) {
+    G = E;
+    mm128(G, E, p);                  // X1 = E + E E
+    for (int j = 2; j < K; ++j) {    // X_j = E + E X_{j-1}
+      bstrip<RT> X;
+      load_af(X, p);
+      mm128(X, G, p);
+      G = X;
+    }
+    add_identity(G, N, p);
+    return;
+  }
+  G = E;
+  add_identity(G, N, p);             // sum_{k < 2} E^k
+  int cur = 1;                       // [A] = E^cur, E = its strip, G = sum_{k < 2 cur} E^k
+  for (int lvl = 0; lvl < 30; ++lvl) {
+    bstrip<RT> W2;
+    W2.zero();
+    mm128(W2, E, p);                 // E^(2 cur)
+    cur *= 2;
+    bool last = (K == cur);
+    if (K == 0) {
+      const double n2 = norm128(W2, N, nw, red, slot, p);
+      last = n2 <= num<double>::eps() * 0.25;
+    } else {
+      __syncthreads();
+    }
+    if (last) {
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta) G.v[ta] += W2.v[ta];
+      break;
+    }
+    store_af(W2, N, p);              // (everybody finished reading the A-form: the barrier above)
+    __syncthreads();
+    {
+      bstrip<RT> T;
+      T.zero();
+      mm128(T, G, p);                // E^(2 cur) G = sum_{2 cur <= k < 4 cur} E^k
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta) G.v[ta] += T.v[ta];
+    }
+    if (K == 2 * cur - 1) break;
+    E = W2;
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __restrict__ g, int N, const bpos<RT>& p) {
+  const bool cok = p.col < N;
+  const double* gc = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc));
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ta < RT - 1) {   // N > 16 (RT - 1): these rows exist
+        const double v = gc[16 * ta + 4 * r];
+        s.v[ta][r] = cok ? v : 0.0;
+      } else {
+        const int row = p.row(ta, r);
+        const double v = gc[min(row, N - 1) - p.kq];
+        s.v[ta][r] = (row < N && cok) ? v : 0.0;
+      }
+    }
+}
+
+// ---- doubling --------------------------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, int ndoubl, double* __restrict__ expk_g,
+                                                         added<double> a, d4_t* __restrict__ scr) {
+  constexpr int NP = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) double lds128[];
+  double* AF = lds128;
+  float* red = reinterpret_cast<float*>(lds128 + NP * NP);
+  float* dsg = red + 32;   // D of apply_D: -1 on the U / V rows, +1 elsewhere
+  bpos<RT> p(lds_addr128(AF));
+  for (int i = threadIdx.x; i < NP; i += blockDim.x) dsg[i] = is_uv_row(i, ns) ? -1.f : 1.f;
+  const int nw = blockDim.x >> 6;
+  const int cb = (N + 1) & ~1;   // rider columns cb, cb + 1: one strip, an even / odd lane pair
+  const bool own_wave = p.wave == (cb >> 4);
+  const bool laneA = own_wave && p.col == cb, laneB = own_wave && p.col == cb + 1, laneAB = laneA || laneB;
+  const long long NN = (long long)N * N;
+  d4_t* const sR = scr + ((long long)(blockIdx.x * 3 + 0) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  d4_t* const sT = scr + ((long long)(blockIdx.x * 3 + 1) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  d4_t* const sW = scr + ((long long)(blockIdx.x * 3 + 2) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  int slot = 0;
+
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    double* const g_r = a.r_mp + NN * s;
+    double* const g_t = a.t_pp + NN * s;
+    double* const g_jp = a.j0_p + (long long)N * s;
+    double* const g_jm = a.j0_m + (long long)N * s;
+    double expk = expk_g[s];
+    bstrip<RT> r_s, t_s;
+    load_global128(r_s, g_r, N, p);
+    load_global128(t_s, g_t, N, p);
+    // riders (rt_helpers.jl:128-134 term for term, see vsm_strip.hip):
+    //   t_s[cb] = j0+, t_s[cb+1] = j1- = j0- expk ;  r_s[cb] = j0-, r_s[cb+1] = j0+
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r), rc = min(row, N - 1);
+          const double vp = row < N ? g_jp[rc] : 0.0, vm = row < N ? g_jm[rc] : 0.0;
+          t_s.v[ta][r] = laneAB ? (laneA ? vp : vm * expk) : t_s.v[ta][r];
+          r_s.v[ta][r] = laneAB ? (laneA ? vm : vp) : r_s.v[ta][r];
+        }
+    }
+    spill(sT, t_s, p);
+    store_af(r_s, N, p);
+    __syncthreads();
+
+    for (int n = 0; n < ndoubl; ++n) {
+      // on entry: [A] = [r]; r_s, t_s in registers; t_s also in sT
+      bstrip<RT> W;
+      bstrip<RT> G;
+      {
+        W.zero();
+        mm128(W, t_s, p);                    // W = r t            (riders: r j0+, r j1-)
+        if (own_wave) {                      // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
+          const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
+#pragma unroll
+          for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              W.v[ta][r] = fma(r_s.v[ta][r], fW, W.v[ta][r]);
+              r_s.v[ta][r] *= fR;
+            }
+        }
+        bstrip<RT> E;
+        E.zero();
+        mm128(E, r_s, p);                    // E = r r
+        spill(sR, r_s, p);
+        const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
+        const int K = series_order128(nrm);
+        const bool deep = K < 1 || K > 4;    // the squaring levels keep four strips: W waits outside
+        if (deep) spill(sW, W, p);
+        invert128(K, E, G, N, nw, red, slot, p);
+        if (deep) fill(W, sW, p);
+      }
+      __syncthreads();                       // [E] no longer read
+      {
+        bstrip<RT> t2;
+        fill(t2, sT, p);
+        store_af(t2, N, p);
+      }
+      __syncthreads();
+      {
+        bstrip<RT> tt;
+        tt.zero();
+        mm128(tt, G, p);                     // tt = t G
+        __syncthreads();                     // [t] no longer read
+        store_af(tt, N, p);
+      }
+      __syncthreads();
+      fill(r_s, sR, p);
+      mm128(r_s, W, p);                      // r' = r + tt W      (riders: the new j0-, j0+)
+      {
+        bstrip<RT> t2;
+        fill(t2, sT, p);
+        t_s.zero();
+        mm128(t_s, t2, p);                   // t' = tt t
+      }
+      expk = expk * expk;
+      if (n + 1 < ndoubl) {
+        if (own_wave) {   // t_s[cb] = j0+', t_s[cb+1] = j1-' = j0-' expk'   (from the neighbour lane of r_s)
+          const double ft = laneB ? expk : 1.0;
+#pragma unroll
+          for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const double u = dpp_swap1_128(r_s.v[ta][r]) * ft;
+              t_s.v[ta][r] = laneAB ? u : t_s.v[ta][r];
+            }
+        }
+        spill(sT, t_s, p);
+        __syncthreads();                     // [tt] no longer read
+        store_af(r_s, N, p);
+        __syncthreads();
+      }
+    }
+
+    // ---- out: apply_D (doubling.jl:178-252) ----
+    if (ndoubl > 0) {
+      // r-+ = D r* ; r+- = D r-+ D = r* D ; t-- = D t++ D ; j0- = D j0-*      (products by +-1: exact)
+      const bool cok = p.col < N;
+      const double sc = (double)dsg[min(p.col, NP - 1)];
+      long long o = NN * s + (long long)N * p.col + p.kq;
+      asm volatile("" : "+v"(o));
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          const double sr = (double)dsg[row];
+          const double rs = r_s.v[ta][r], tv = t_s.v[ta][r], rv = rs * sr;
+          const bool rok = ta < RT - 1 || row < N;
+          if (rok && cok) {
+            const long long e = o + 16 * ta + 4 * r;
+            a.r_mp[e] = rv;
+            a.t_pp[e] = tv;
+            a.r_pm[e] = rs * sc;
+            a.t_mm[e] = tv * (sr * sc);
+          }
+          if (rok && laneA) g_jm[row] = rv;   // j0- (sign of apply_D_SFI)
+          if (rok && laneB) g_jp[row] = rs;   // j0+
+        }
+      if (threadIdx.x == 0) expk_g[s] = expk;
+    }
+    __syncthreads();   // the next point overwrites the A-form and the reduction slots
+  }
+}
+
+template <int RT>
+int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
+                  hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 128 + 4 * 16 * RT + 64;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl128<RT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_dbl128)");
+  hipLaunchKernelGGL(k_dbl128<RT>, dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr);
+  VSM_LAUNCH_CHECK("k_dbl128");
+  return VSM_OK;
+}
+
+int cu_count() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
+}  // namespace
+
+bool strip128_supported(int N) { return N > 64 && N <= 126; }
+
+int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st) {
+  if (ndoubl == 0 || S <= 0) return VSM_OK;   // doubling.jl:50
+  const int RT = (N + 15) / 16, nw = (((N + 1) & ~1) >> 4) + 1;
+  const int grid = S < cu_count() ? S : cu_count();
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
+  if (!scr) return VSM_ERR_HIP;
+  switch (RT) {
+    case 5: return launch_dbl128<5>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 6: return launch_dbl128<6>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 7: return launch_dbl128<7>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 8: return launch_dbl128<8>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+  }
+  set_error("strip128_doubling: N=%d outside 65..126", N);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+}  // namespace vsm
