@@ -398,7 +398,8 @@ def _comp_to_host(vsm, c):
 
 
 @pytest.mark.parametrize("FT,N", [(np.float64, 4), (np.float64, 15), (np.float64, 36), (np.float64, 60),
-                                  (np.float64, 112), (np.float32, 60), (np.float32, 96)])
+                                  (np.float64, 66), (np.float64, 79), (np.float64, 96), (np.float64, 102), (np.float64, 112),
+                                  (np.float64, 125), (np.float64, 126), (np.float64, 128), (np.float32, 60), (np.float32, 96)])
 @pytest.mark.parametrize("iface", ["00", "01", "10", "11"])
 @pytest.mark.parametrize("oplevel", [False, True])
 def test_interaction(vsm, arch, FT, N, iface, oplevel):
@@ -416,7 +417,7 @@ def test_interaction(vsm, arch, FT, N, iface, oplevel):
         assert _rel(v, getattr(comp, k)) < tol, k
 
 
-@pytest.mark.parametrize("FT,N", [(np.float64, 60), (np.float32, 96), (np.float64, 100)])
+@pytest.mark.parametrize("FT,N", [(np.float64, 60), (np.float32, 96), (np.float64, 100), (np.float64, 112)])
 def test_interaction_shared_surface_block(vsm, arch, FT, N):
     """Surface layers hand ONE N x N block to all spectral points (mat_stride = 0)."""
     rng = np.random.default_rng(9)
@@ -432,11 +433,13 @@ def test_interaction_shared_surface_block(vsm, arch, FT, N):
         assert _rel(v, getattr(comp, k)) < (1e-11 if FT == np.float64 else 2e-5), k
 
 
-@pytest.mark.parametrize("FT,N", [(np.float64, 60), (np.float32, 96), (np.float32, 93), (np.float32, 72)])
+@pytest.mark.parametrize("FT,N", [(np.float64, 60), (np.float32, 96), (np.float32, 93), (np.float32, 72), (np.float64, 80),
+                                  (np.float64, 108), (np.float64, 126)])
 def test_strong_reflection_needs_gauss_jordan(vsm, arch, FT, N):
     """Bright surface under a thick conservative atmosphere: ||r R|| ~ 0.7, the series path must not be taken
     and the pivoted Gauss-Jordan must agree with LAPACK (FP64 strip kernel; FP32 strip kernels, whose Gauss-Jordan
-    scratch lives in the padding of the LDS matrix it inverts)."""
+    scratch lives in the padding of the LDS matrix it inverts).  FP64 64 < N <= 126 (k_ia128): no pivoting kernel there --
+    the inverse is built by squaring levels until the power of R+- r-+ vanishes, and must agree with LAPACK as well."""
     rng = np.random.default_rng(2)
     S = 3
     comp, add = _random_layers(rng, N, S, FT, None)

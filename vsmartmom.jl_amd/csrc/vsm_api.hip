@@ -153,6 +153,11 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
   if (!oplevel && iface == VSM_IFACE_11 && N <= fused_max_n<T>())
     return fused_interaction<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
   VSM_REQUIRE(a->d_symmetric == 0, "interaction: d_symmetric layers are only accepted by the fused 11 kernel");
+  if constexpr (sizeof(T) == 8) {
+    static const bool no_strip = ab_switch("VSM_NO_STRIP128");
+    if (!oplevel && !no_strip && iface == VSM_IFACE_11 && strip128_supported(N))
+      return strip128_interaction11(N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
+  }
   if (!work) {
     work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1));
     if (!work) return VSM_ERR_HIP;

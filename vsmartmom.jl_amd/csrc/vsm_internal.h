@@ -259,6 +259,7 @@ int strip32_interaction11(int N, int S, const composite<float>& c, const added<f
 // ---- column-strip kernels, FP64, 64 < N <= 126 (one persistent workgroup of <= 8 waves per CU): vsm_strip128.hip ----
 bool strip128_supported(int N);
 int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st);
+int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 
 // grow-only device scratch (one per element type); not for concurrent streams.
 void* scratch(size_t bytes, int slot);

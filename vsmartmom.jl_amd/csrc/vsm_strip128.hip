@@ -3,6 +3,7 @@
 //
 //   k_dbl128<RT>   doubling! (src/CoreRT/CoreKernel/doubling.jl:38-99, rt_helpers.jl:102-166, apply_D doubling.jl:178-252):
 //                  the whole doubling loop of one spectral point in one workgroup, in place on the AddedLayer
+//   k_ia128<RT>    interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266), one inverse, in place on the composite
 //
 // Scheme (vsm_strip.hip's, re-dimensioned): a matrix is padded to NP = 16 RT rows (RT = 5..8 row tiles); wave w owns the
 // 16-column strip w of every operator as RT accumulator tiles of v_mfma_f64_16x16x4 -- the accumulator layout IS the B-operand
@@ -436,6 +437,243 @@ int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<do
   return VSM_OK;
 }
 
+// ---- interaction (ScatteringInterface_11) ------------------------------------------------------------------------------------
+// global column-major N x N -> the A-form (zero padded): a wave takes whole columns, lane = row (512-byte requests; the 16-lane
+// groups of the LDS store are 16 rows of one column: (m ^ const) -- conflict-free)
+template <int RT>
+__device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ g, int N, int nw, const bpos<RT>& p) {
+  constexpr int NP = 16 * RT;
+  for (int c0 = p.wave; c0 < NP; c0 += 4 * nw) {
+    double v[4][(NP + 63) / 64];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = c0 + i * nw;
+#pragma unroll
+      for (int h = 0; h < (NP + 63) / 64; ++h) {
+        const int row = 64 * h + p.lane;
+        v[i][h] = (row < N && col < N) ? g[row + (long long)N * col] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = c0 + i * nw;
+#pragma unroll
+      for (int h = 0; h < (NP + 63) / 64; ++h) {
+        const int row = 64 * h + p.lane;
+        if (row < NP && col < NP)
+          AF[(col >> 2) * (RT * 64) + (row >> 4) * 64 + ((col & 3) << 4) + ((row & 15) ^ (col & 15))] = v[i][h];
+      }
+    }
+  }
+}
+template <int RT>
+__device__ __forceinline__ void store_global128(double* __restrict__ g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
+  const bool cok = p.col < N;
+  double* gc = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc));
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rok = ta < RT - 1 || p.row(ta, r) < N;
+      if (rok && cok) gc[16 * ta + 4 * r] = s.v[ta][r];
+    }
+}
+
+// interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266) with ONE inverse G2 = (I - R+- r-+)^-1 and the
+// push-through identities of vsm_strip.hip's ia_body, ordered by left operand for the single A-form:
+//   [R+-]: E2 = R+- r-+ , Z = R+- t--      (rider: R+- j0-  ->  z = J0+ + R+- j0-)
+//   [T--]: V = T-- t-- , S = T-- r-+       (rider: vs = T-- j0-)
+//   [E2] : G2 (series)
+//   [t++]: T21 = t++ G2          [S]: Y = S G2
+//   [T21]: R+- = r+- + T21 Z , T++ = T21 T++     (rider z in a spare column of T++: J0+ = j0+ + T21 z)
+//   [Y]  : R-+ = R-+ + Y T++ , T-- = V + Y Z     (the same rider: J0- = J0- + vs + Y z)
+// Three strips live at most; E2, Z, V, S wait in the workgroup's scratch.  The composite's [R+-], [T--] and the layer's [t++]
+// are staged from global memory with whole-column requests; every other operand is a strip of its owner wave.
+template <int RT>
+__global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<double> c, added<double> a, d4_t* __restrict__ scr) {
+  constexpr int NP = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) double lds128[];
+  double* AF = lds128;
+  double* vec = lds128 + NP * NP;   // j0+, j0-, J0+, J0-, z, vs
+  double* vjp = vec, *vjm = vec + NP, *vJp = vec + 2 * NP, *vJm = vec + 3 * NP, *vz = vec + 4 * NP, *vs = vec + 5 * NP;
+  float* red = reinterpret_cast<float*>(vec + 6 * NP);
+  bpos<RT> p(lds_addr128(AF));
+  const int nw = blockDim.x >> 6, tid = threadIdx.x;
+  const int cr = (N + 1) & ~1;   // the rider column (the doubling kernel's cb: the same strip count)
+  const bool laneR = p.col == cr;
+  const long long NN = (long long)N * N;
+  d4_t* const sE = scr + ((long long)(blockIdx.x * 4 + 0) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  d4_t* const sZ = scr + ((long long)(blockIdx.x * 4 + 1) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  d4_t* const sV = scr + ((long long)(blockIdx.x * 4 + 2) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  d4_t* const sS = scr + ((long long)(blockIdx.x * 4 + 3) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+  int slot = 0;
+
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    double* const R_mp = c.R_mp + NN * s;
+    double* const R_pm = c.R_pm + NN * s;
+    double* const T_pp = c.T_pp + NN * s;
+    double* const T_mm = c.T_mm + NN * s;
+    double* const J0_p = c.J0_p + (long long)N * s;
+    double* const J0_m = c.J0_m + (long long)N * s;
+    const double* const a_r_mp = a.r_mp + a.mat_stride * s;
+    const double* const a_r_pm = a.r_pm + a.mat_stride * s;
+    const double* const a_t_pp = a.t_pp + a.mat_stride * s;
+    const double* const a_t_mm = a.t_mm + a.mat_stride * s;
+    for (int i = tid; i < NP; i += blockDim.x) {
+      const bool in = i < N;
+      vjp[i] = in ? a.j0_p[(long long)N * s + i] : 0.0;
+      vjm[i] = in ? a.j0_m[(long long)N * s + i] : 0.0;
+      vJp[i] = in ? J0_p[i] : 0.0;
+      vJm[i] = in ? J0_m[i] : 0.0;
+    }
+    stage_af(AF, R_pm, N, nw, p);
+    __syncthreads();                                    // (a)
+    bstrip<RT> r_s;
+    load_global128(r_s, a_r_mp, N, p);
+    if (laneR) {                                        // j0- rides in the spare column of r-+
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r_s.v[ta][r] = vjm[p.row(ta, r)];
+    }
+    {
+      bstrip<RT> E;
+      E.zero();
+      mm128(E, r_s, p);                                 // E2 = R+- r-+
+      if (laneR) {
+#pragma unroll
+        for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vz[p.row(ta, r)] = vJp[p.row(ta, r)] + E.v[ta][r];
+      }
+      spill(sE, E, p);
+    }
+    {
+      bstrip<RT> tm;
+      load_global128(tm, a_t_mm, N, p);
+      {
+        bstrip<RT> Z;
+        Z.zero();
+        mm128(Z, tm, p);                                // Z = R+- t--
+        spill(sZ, Z, p);
+      }
+      __syncthreads();                                  // (b) [R+-] no longer read
+      stage_af(AF, T_mm, N, nw, p);
+      __syncthreads();                                  // (c)
+      bstrip<RT> V;
+      V.zero();
+      mm128(V, tm, p);                                  // V = T-- t--
+      spill(sV, V, p);
+    }
+    {
+      bstrip<RT> Sx;
+      Sx.zero();
+      mm128(Sx, r_s, p);                                // S = T-- r-+
+      if (laneR) {
+#pragma unroll
+        for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vs[p.row(ta, r)] = Sx.v[ta][r];
+      }
+      spill(sS, Sx, p);
+    }
+    bstrip<RT> G;
+    {
+      bstrip<RT> E;
+      fill(E, sE, p);
+      const double nrm = norm128(E, N, nw, red, slot, p);   // (d) [T--] no longer read
+      invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
+    }
+    __syncthreads();                                    // (e) [E2] no longer read
+    stage_af(AF, a_t_pp, N, nw, p);
+    __syncthreads();                                    // (f)
+    bstrip<RT> X;
+    X.zero();
+    mm128(X, G, p);                                     // T21 = t++ G2
+    __syncthreads();                                    // (g) [t++] no longer read
+    {
+      bstrip<RT> Sx;
+      fill(Sx, sS, p);
+      store_af(Sx, N, p);
+    }
+    __syncthreads();                                    // (h)
+    bstrip<RT> Y;
+    Y.zero();
+    mm128(Y, G, p);                                     // Y = S G2
+    __syncthreads();                                    // (i) [S] no longer read
+    store_af(X, N, p);
+    __syncthreads();                                    // (j)
+    {
+      bstrip<RT> acc, Z;
+      load_global128(acc, a_r_pm, N, p);
+      fill(Z, sZ, p);
+      mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
+      store_global128(R_pm, acc, N, p);
+    }
+    bstrip<RT> Tpp;
+    load_global128(Tpp, T_pp, N, p);
+    if (laneR) {                                        // z rides in the spare column of T++
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tpp.v[ta][r] = vz[p.row(ta, r)];
+    }
+    {
+      bstrip<RT> acc;
+      acc.zero();
+      mm128(acc, Tpp, p);                               // T++ = T21 T++ ; rider: T21 z
+      store_global128(T_pp, acc, N, p);
+      if (laneR) {
+#pragma unroll
+        for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = p.row(ta, r);
+            if (row < N) J0_p[row] = vjp[row] + acc.v[ta][r];
+          }
+      }
+    }
+    __syncthreads();                                    // (k) [T21] no longer read
+    store_af(Y, N, p);
+    __syncthreads();                                    // (l)
+    {
+      bstrip<RT> acc;
+      load_global128(acc, R_mp, N, p);
+      mm128(acc, Tpp, p);                               // R-+ = R-+ + Y T++ ; rider: Y z
+      store_global128(R_mp, acc, N, p);
+      if (laneR) {
+#pragma unroll
+        for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = p.row(ta, r);
+            if (row < N) J0_m[row] = vJm[row] + vs[row] + acc.v[ta][r];
+          }
+      }
+    }
+    {
+      bstrip<RT> acc, Z;
+      fill(acc, sV, p);
+      fill(Z, sZ, p);
+      mm128(acc, Z, p);                                 // T-- = V + Y Z
+      store_global128(T_mm, acc, N, p);
+    }
+    __syncthreads();                                    // (m) the next point restages the A-form and the vectors
+  }
+}
+
+template <int RT>
+int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 6 * 16 * RT * sizeof(double) + 256;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia128<RT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_ia128)");
+  hipLaunchKernelGGL(k_ia128<RT>, dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr);
+  VSM_LAUNCH_CHECK("k_ia128");
+  return VSM_OK;
+}
+
 int cu_count() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -463,6 +701,22 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
     case 8: return launch_dbl128<8>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
   }
   set_error("strip128_doubling: N=%d outside 65..126", N);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int RT = (N + 15) / 16, nw = (((N + 1) & ~1) >> 4) + 1;
+  const int grid = S < cu_count() ? S : cu_count();
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
+  if (!scr) return VSM_ERR_HIP;
+  switch (RT) {
+    case 5: return launch_ia128<5>(N, S, c, a, grid, nw, scr, st);
+    case 6: return launch_ia128<6>(N, S, c, a, grid, nw, scr, st);
+    case 7: return launch_ia128<7>(N, S, c, a, grid, nw, scr, st);
+    case 8: return launch_ia128<8>(N, S, c, a, grid, nw, scr, st);
+  }
+  set_error("strip128_interaction11: N=%d outside 65..126", N);
   return VSM_ERR_UNSUPPORTED;
 }
 
