@@ -314,12 +314,14 @@ def test_elemental_doubling_fused_and_oplevel(vsm, arch, pol_name, l_trunc, FT, 
 
 
 @pytest.mark.parametrize("pol_name,l_trunc,N_expected", [("I", 125, 66), ("I", 151, 79), ("IQUV", 41, 96), ("IQU", 61, 102),
-                                                         ("IQU", 67, 111), ("I", 243, 125), ("I", 245, 126)])
+                                                         ("IQU", 67, 111), ("I", 243, 125), ("I", 245, 126), ("I", 247, 127),
+                                                         ("IQUV", 57, 128)])
 @pytest.mark.parametrize("thick", [False, True])
-def test_doubling_strip_kernel_64_to_126(vsm, arch, pol_name, l_trunc, N_expected, thick):
+def test_doubling_strip_kernel_64_to_128(vsm, arch, pol_name, l_trunc, N_expected, thick):
     """doubling! of the FP64 shapes 64 < N <= 126 (k_dbl128: one workgroup per point, the whole loop on chip) vs oracle.doubling
     (doubling.jl:38-99, rt_helpers.jl:102-166).  N covers every row-tile count (5..8), rider columns inside a matrix strip
-    (66, 102, 125, 126) and in a strip of their own (79 -> 80, 96, 111 -> 112); `thick`: conservative Rayleigh layers of tau up
+    (66, 102, 125, 126) and in a strip of their own (79 -> 80, 96, 111 -> 112), and the shapes without a spare column (127, 128:
+    the vectors as an extra MFMA tile per wave); `thick`: conservative Rayleigh layers of tau up
     to 12, where ||r r|| leaves the Neumann series' range and the inverse runs by squaring levels."""
     FT = np.float64
     if thick:
@@ -399,7 +401,8 @@ def _comp_to_host(vsm, c):
 
 @pytest.mark.parametrize("FT,N", [(np.float64, 4), (np.float64, 15), (np.float64, 36), (np.float64, 60),
                                   (np.float64, 66), (np.float64, 79), (np.float64, 96), (np.float64, 102), (np.float64, 112),
-                                  (np.float64, 125), (np.float64, 126), (np.float64, 128), (np.float32, 60), (np.float32, 96)])
+                                  (np.float64, 125), (np.float64, 126), (np.float64, 127), (np.float64, 128), (np.float64, 129),
+                                  (np.float32, 60), (np.float32, 96)])
 @pytest.mark.parametrize("iface", ["00", "01", "10", "11"])
 @pytest.mark.parametrize("oplevel", [False, True])
 def test_interaction(vsm, arch, FT, N, iface, oplevel):
@@ -434,7 +437,7 @@ def test_interaction_shared_surface_block(vsm, arch, FT, N):
 
 
 @pytest.mark.parametrize("FT,N", [(np.float64, 60), (np.float32, 96), (np.float32, 93), (np.float32, 72), (np.float64, 80),
-                                  (np.float64, 108), (np.float64, 126)])
+                                  (np.float64, 108), (np.float64, 126), (np.float64, 128)])
 def test_strong_reflection_needs_gauss_jordan(vsm, arch, FT, N):
     """Bright surface under a thick conservative atmosphere: ||r R|| ~ 0.7, the series path must not be taken
     and the pivoted Gauss-Jordan must agree with LAPACK (FP64 strip kernel; FP32 strip kernels, whose Gauss-Jordan

@@ -1,4 +1,4 @@
-// FP64 column-strip kernels for 64 < N <= 126 (the reference's own baseline shapes live here: Natraj N = 108,
+// FP64 column-strip kernels for 64 < N <= 128 (the reference's own baseline shapes live here: Natraj N = 108,
 // test/test_CoreRT.jl:110-157; VLIDORT case A N = 112, test/vlidort_baseline/cases/case_A_siewert2000.jl:29-50).
 //
 //   k_dbl128<RT>   doubling! (src/CoreRT/CoreKernel/doubling.jl:38-99, rt_helpers.jl:102-166, apply_D doubling.jl:178-252):
@@ -17,7 +17,8 @@
 //     instruction, L2 / MALL resident: 2 stores + 3 loads of 16 KB per wave and step against 7 x 256 MFMAs).
 // Workgroups are persistent (one per CU, 1 + RT waves at most: two waves per SIMD) and walk the spectral axis.
 // Source vectors ride in two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip:
-// N <= 126 leaves them room in at most 8 strips.  N = 127, 128 stay on the operator chain.
+// N <= 126 leaves them room in at most 8 strips.  N = 127, 128 (eight full strips): each wave forms one more 16 x 16 tile per
+// product that carries vectors -- row tile w of [A] (x_0 | x_1), the vectors read from an LDS table (mm128r).
 //
 // A-form layout (verified conflict-free for both directions): block (ks, t) = the 16 x 4 fragment of row tile t and k-step ks,
 // 64 doubles; inside a block, element (m, k') of k-step ks sits at word
@@ -109,6 +110,40 @@ __device__ __forceinline__ void mm128(bstrip<RT>& acc, const bstrip<RT>& B, bpos
     for (int t = 0; t < RT; ++t) {
       acc.v[t] = mfma<double>::mma(a[t], b, acc.v[t]);
       if (ks + 1 < KS) a[t] = *p.aptr(t, ks + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same with the source vectors as an extra 16 x 16 tile (N = 127, 128: the strips have no spare column): wave w also forms
+// row tile w of [A] x for the two vectors x_0, x_1 of the LDS table at byte address xb (lane: (l15 & 1) NP + kq; every even /
+// odd column of the tile holds the same product) -- one MFMA, its fragment and a table read more per k-step.
+template <int RT>
+__device__ __forceinline__ void mm128r(bstrip<RT>& acc, const bstrip<RT>& B, d4_t& yr, unsigned xb, bpos<RT>& p) {
+  constexpr int KS = 4 * RT;
+  p.opaque();
+  const unsigned wo = 512u * (unsigned)p.wave;
+  auto afr = [&](int ks) {
+    const int h = ks >= 16 ? 1 : 0;
+    return *(reinterpret_cast<const lds_d*>((unsigned long long)(p.ab[ks & 3][h] + wo)) + 64 * ((ks - 16 * h) * RT));
+  };
+  auto xfr = [&](int ks) { return *(reinterpret_cast<const lds_d*>((unsigned long long)xb) + 4 * ks); };
+  double a[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) a[t] = *p.aptr(t, 0);
+  double ar = afr(0), xv = xfr(0);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const double b = B.v[ks >> 2][ks & 3];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      acc.v[t] = mfma<double>::mma(a[t], b, acc.v[t]);
+      if (ks + 1 < KS) a[t] = *p.aptr(t, ks + 1);
+    }
+    yr = mfma<double>::mma(ar, xv, yr);
+    if (ks + 1 < KS) {
+      ar = afr(ks + 1);
+      xv = xfr(ks + 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -278,7 +313,8 @@ __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __re
 }
 
 // ---- doubling --------------------------------------------------------------------------------------------------------------
-template <int RT>
+// MR: the source vectors as an extra MFMA tile per wave (mm128r) instead of rider columns -- N = 127, 128
+template <int RT, bool MR>
 __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, int ndoubl, double* __restrict__ expk_g,
                                                          added<double> a, d4_t* __restrict__ scr) {
   constexpr int NP = 16 * RT;
@@ -286,7 +322,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
   float* dsg = red + 32;   // D of apply_D: -1 on the U / V rows, +1 elsewhere
+  double* xt = lds128 + NP * NP + 128;   // (MR) x_0, x_1 of the coming rider product ; j0+, j0-
+  double* vjp = xt + 2 * NP;
+  double* vjm = xt + 3 * NP;
   bpos<RT> p(lds_addr128(AF));
+  const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
+  const int rrow = 16 * p.wave + p.kq;   // (MR) the lane's rows of the rider tile: rrow + 4 r
   for (int i = threadIdx.x; i < NP; i += blockDim.x) dsg[i] = is_uv_row(i, ns) ? -1.f : 1.f;
   const int nw = blockDim.x >> 6;
   const int cb = (N + 1) & ~1;   // rider columns cb, cb + 1: one strip, an even / odd lane pair
@@ -309,7 +350,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
     load_global128(t_s, g_t, N, p);
     // riders (rt_helpers.jl:128-134 term for term, see vsm_strip.hip):
     //   t_s[cb] = j0+, t_s[cb+1] = j1- = j0- expk ;  r_s[cb] = j0-, r_s[cb+1] = j0+
-    if (own_wave) {
+    if (!MR && own_wave) {
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
@@ -319,6 +360,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           t_s.v[ta][r] = laneAB ? (laneA ? vp : vm * expk) : t_s.v[ta][r];
           r_s.v[ta][r] = laneAB ? (laneA ? vm : vp) : r_s.v[ta][r];
         }
+    }
+    if constexpr (MR) {   // x_0 = j0+, x_1 = j1- = j0- expk
+      for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+        const double vp = i < N ? g_jp[i] : 0.0, vm = i < N ? g_jm[i] : 0.0;
+        vjp[i] = vp;
+        vjm[i] = vm;
+        xt[i] = vp;
+        xt[NP + i] = vm * expk;
+      }
     }
     spill(sT, t_s, p);
     store_af(r_s, N, p);
@@ -330,8 +380,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       bstrip<RT> G;
       {
         W.zero();
-        mm128(W, t_s, p);                    // W = r t            (riders: r j0+, r j1-)
-        if (own_wave) {                      // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
+        d4_t u = acc_zero<double>();
+        if constexpr (MR) {
+          mm128r(W, t_s, u, xb, p);          // W = r t ; tile: r j0+ | r j1-
+#pragma unroll
+          for (int r = 0; r < 4; ++r) u[r] += xt[(1 - (p.l15 & 1)) * NP + rrow + 4 * r];   // u1 = j1- + r j0+ | u2 = j0+ + r j1-
+        } else {
+          mm128(W, t_s, p);                  // W = r t            (riders: r j0+, r j1-)
+        }
+        if (!MR && own_wave) {                      // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
           const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
 #pragma unroll
           for (int ta = 0; ta < RT; ++ta)
@@ -346,6 +403,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         mm128(E, r_s, p);                    // E = r r
         spill(sR, r_s, p);
         const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
+        if constexpr (MR) {                  // (nobody reads x any more) x_0 = u1, x_1 = u2 for the [tt] phase
+          if (p.l15 < 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xt[p.l15 * NP + rrow + 4 * r] = u[r];
+          }
+        }
         const int K = series_order128(nrm);
         const bool deep = K < 1 || K > 4;    // the squaring levels keep four strips: W waits outside
         if (deep) spill(sW, W, p);
@@ -368,7 +431,18 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       }
       __syncthreads();
       fill(r_s, sR, p);
-      mm128(r_s, W, p);                      // r' = r + tt W      (riders: the new j0-, j0+)
+      if constexpr (MR) {
+        d4_t z = acc_zero<double>();
+        mm128r(r_s, W, z, xb, p);            // r' = r + tt W ; tile: tt u1 | tt u2
+        if (p.l15 < 2) {                     // j0- += tt u1 | j0+ = j0+ expk + tt u2     (rt_helpers.jl:128-134)
+          double* vj = p.l15 ? vjp : vjm;
+          const double f = p.l15 ? expk : 1.0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vj[rrow + 4 * r] = fma(vj[rrow + 4 * r], f, z[r]);
+        }
+      } else {
+        mm128(r_s, W, p);                    // r' = r + tt W      (riders: the new j0-, j0+)
+      }
       {
         bstrip<RT> t2;
         fill(t2, sT, p);
@@ -377,7 +451,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       }
       expk = expk * expk;
       if (n + 1 < ndoubl) {
-        if (own_wave) {   // t_s[cb] = j0+', t_s[cb+1] = j1-' = j0-' expk'   (from the neighbour lane of r_s)
+        if (!MR && own_wave) {   // t_s[cb] = j0+', t_s[cb+1] = j1-' = j0-' expk'   (from the neighbour lane of r_s)
           const double ft = laneB ? expk : 1.0;
 #pragma unroll
           for (int ta = 0; ta < RT; ++ta)
@@ -390,6 +464,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         spill(sT, t_s, p);
         __syncthreads();                     // [tt] no longer read
         store_af(r_s, N, p);
+        if constexpr (MR) {
+          for (int i = threadIdx.x; i < NP; i += blockDim.x) {
+            xt[i] = vjp[i];
+            xt[NP + i] = vjm[i] * expk;
+          }
+        }
         __syncthreads();
       }
     }
@@ -416,23 +496,30 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
             a.r_pm[e] = rs * sc;
             a.t_mm[e] = tv * (sr * sc);
           }
-          if (rok && laneA) g_jm[row] = rv;   // j0- (sign of apply_D_SFI)
-          if (rok && laneB) g_jp[row] = rs;   // j0+
+          if (!MR && rok && laneA) g_jm[row] = rv;   // j0- (sign of apply_D_SFI)
+          if (!MR && rok && laneB) g_jp[row] = rs;   // j0+
         }
+      if constexpr (MR) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+          g_jp[i] = vjp[i];
+          g_jm[i] = vjm[i] * (double)dsg[i];
+        }
+      }
       if (threadIdx.x == 0) expk_g[s] = expk;
     }
     __syncthreads();   // the next point overwrites the A-form and the reduction slots
   }
 }
 
-template <int RT>
+template <int RT, bool MR>
 int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
                   hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 128 + 4 * 16 * RT + 64;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl128<RT>),
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 4 * 16 * RT * sizeof(double) : 0);
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl128<RT, MR>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_dbl128)");
-  hipLaunchKernelGGL(k_dbl128<RT>, dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr);
+  hipLaunchKernelGGL((k_dbl128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr);
   VSM_LAUNCH_CHECK("k_dbl128");
   return VSM_OK;
 }
@@ -490,18 +577,21 @@ __device__ __forceinline__ void store_global128(double* __restrict__ g, const bs
 //   [Y]  : R-+ = R-+ + Y T++ , T-- = V + Y Z     (the same rider: J0- = J0- + vs + Y z)
 // Three strips live at most; E2, Z, V, S wait in the workgroup's scratch.  The composite's [R+-], [T--] and the layer's [t++]
 // are staged from global memory with whole-column requests; every other operand is a strip of its owner wave.
-template <int RT>
+template <int RT, bool MR>
 __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<double> c, added<double> a, d4_t* __restrict__ scr) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
-  double* vec = lds128 + NP * NP;   // j0+, j0-, J0+, J0-, z, vs
+  double* vec = lds128 + NP * NP;   // j0+, j0-, J0+, J0-, z, vs, (MR) the rider table x_0 = x_1
   double* vjp = vec, *vjm = vec + NP, *vJp = vec + 2 * NP, *vJm = vec + 3 * NP, *vz = vec + 4 * NP, *vs = vec + 5 * NP;
-  float* red = reinterpret_cast<float*>(vec + 6 * NP);
+  double* xt = vec + 6 * NP;
+  float* red = reinterpret_cast<float*>(vec + 8 * NP);
   bpos<RT> p(lds_addr128(AF));
+  const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
+  const int rrow = 16 * p.wave + p.kq;
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
   const int cr = (N + 1) & ~1;   // the rider column (the doubling kernel's cb: the same strip count)
-  const bool laneR = p.col == cr;
+  const bool laneR = !MR && p.col == cr;
   const long long NN = (long long)N * N;
   d4_t* const sE = scr + ((long long)(blockIdx.x * 4 + 0) * B_MAXW + p.wave) * (RT * 64) + p.lane;
   d4_t* const sZ = scr + ((long long)(blockIdx.x * 4 + 1) * B_MAXW + p.wave) * (RT * 64) + p.lane;
@@ -526,6 +616,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       vjm[i] = in ? a.j0_m[(long long)N * s + i] : 0.0;
       vJp[i] = in ? J0_p[i] : 0.0;
       vJm[i] = in ? J0_m[i] : 0.0;
+      if constexpr (MR) xt[i] = xt[NP + i] = vjm[i];
     }
     stage_af(AF, R_pm, N, nw, p);
     __syncthreads();                                    // (a)
@@ -540,7 +631,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     {
       bstrip<RT> E;
       E.zero();
-      mm128(E, r_s, p);                                 // E2 = R+- r-+
+      if constexpr (MR) {
+        d4_t y = acc_zero<double>();
+        mm128r(E, r_s, y, xb, p);                       // E2 = R+- r-+ ; tile: R+- j0-
+        if (p.l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vz[rrow + 4 * r] = vJp[rrow + 4 * r] + y[r];
+        }
+      } else {
+        mm128(E, r_s, p);                               // E2 = R+- r-+
+      }
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -569,7 +669,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     {
       bstrip<RT> Sx;
       Sx.zero();
-      mm128(Sx, r_s, p);                                // S = T-- r-+
+      if constexpr (MR) {
+        d4_t y = acc_zero<double>();
+        mm128r(Sx, r_s, y, xb, p);                      // S = T-- r-+ ; tile: T-- j0-
+        if (p.l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vs[rrow + 4 * r] = y[r];
+        }
+      } else {
+        mm128(Sx, r_s, p);                              // S = T-- r-+
+      }
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -583,6 +692,9 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       bstrip<RT> E;
       fill(E, sE, p);
       const double nrm = norm128(E, N, nw, red, slot, p);   // (d) [T--] no longer read
+      if constexpr (MR) {                               // (nobody reads the table any more) x = z for [T21], [Y]
+        for (int i = tid; i < NP; i += blockDim.x) xt[i] = xt[NP + i] = vz[i];
+      }
       invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
     }
     __syncthreads();                                    // (e) [E2] no longer read
@@ -622,7 +734,17 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     {
       bstrip<RT> acc;
       acc.zero();
-      mm128(acc, Tpp, p);                               // T++ = T21 T++ ; rider: T21 z
+      if constexpr (MR) {
+        d4_t y = acc_zero<double>();
+        mm128r(acc, Tpp, y, xb, p);                     // T++ = T21 T++ ; tile: T21 z
+        if (p.l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (rrow + 4 * r < N) J0_p[rrow + 4 * r] = vjp[rrow + 4 * r] + y[r];
+        }
+      } else {
+        mm128(acc, Tpp, p);                             // T++ = T21 T++ ; rider: T21 z
+      }
       store_global128(T_pp, acc, N, p);
       if (laneR) {
 #pragma unroll
@@ -640,7 +762,17 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     {
       bstrip<RT> acc;
       load_global128(acc, R_mp, N, p);
-      mm128(acc, Tpp, p);                               // R-+ = R-+ + Y T++ ; rider: Y z
+      if constexpr (MR) {
+        d4_t y = acc_zero<double>();
+        mm128r(acc, Tpp, y, xb, p);                     // R-+ = R-+ + Y T++ ; tile: Y z
+        if (p.l15 == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (rrow + 4 * r < N) J0_m[rrow + 4 * r] = vJm[rrow + 4 * r] + vs[rrow + 4 * r] + y[r];
+        }
+      } else {
+        mm128(acc, Tpp, p);                             // R-+ = R-+ + Y T++ ; rider: Y z
+      }
       store_global128(R_mp, acc, N, p);
       if (laneR) {
 #pragma unroll
@@ -663,13 +795,13 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   }
 }
 
-template <int RT>
+template <int RT, bool MR>
 int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 6 * 16 * RT * sizeof(double) + 256;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia128<RT>),
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia128<RT, MR>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_ia128)");
-  hipLaunchKernelGGL(k_ia128<RT>, dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr);
+  hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr);
   VSM_LAUNCH_CHECK("k_ia128");
   return VSM_OK;
 }
@@ -686,37 +818,41 @@ int cu_count() {
 
 }  // namespace
 
-bool strip128_supported(int N) { return N > 64 && N <= 126; }
+bool strip128_supported(int N) { return N > 64 && N <= 128; }
 
 int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st) {
   if (ndoubl == 0 || S <= 0) return VSM_OK;   // doubling.jl:50
-  const int RT = (N + 15) / 16, nw = (((N + 1) & ~1) >> 4) + 1;
+  const int RT = (N + 15) / 16, nw = N > 126 ? 8 : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_dbl128<5>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 6: return launch_dbl128<6>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 7: return launch_dbl128<7>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 8: return launch_dbl128<8>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 6: return launch_dbl128<6, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 7: return launch_dbl128<7, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 8:
+      if (N > 126) return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+      return launch_dbl128<8, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
   }
-  set_error("strip128_doubling: N=%d outside 65..126", N);
+  set_error("strip128_doubling: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
 }
 
 int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  const int RT = (N + 15) / 16, nw = (((N + 1) & ~1) >> 4) + 1;
+  const int RT = (N + 15) / 16, nw = N > 126 ? 8 : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_ia128<5>(N, S, c, a, grid, nw, scr, st);
-    case 6: return launch_ia128<6>(N, S, c, a, grid, nw, scr, st);
-    case 7: return launch_ia128<7>(N, S, c, a, grid, nw, scr, st);
-    case 8: return launch_ia128<8>(N, S, c, a, grid, nw, scr, st);
+    case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, st);
+    case 6: return launch_ia128<6, false>(N, S, c, a, grid, nw, scr, st);
+    case 7: return launch_ia128<7, false>(N, S, c, a, grid, nw, scr, st);
+    case 8:
+      if (N > 126) return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, st);
+      return launch_ia128<8, false>(N, S, c, a, grid, nw, scr, st);
   }
-  set_error("strip128_interaction11: N=%d outside 65..126", N);
+  set_error("strip128_interaction11: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
 }
 
