@@ -14,7 +14,7 @@
 //     strips (two barriers), every product of that operand running off it:
 //         W = r t ; E = r r ;  G = (I - E)^-1 (Neumann series off [E]) ;  tt = t G ;  r' = r + tt W ;  t' = tt t
 //   * the strips that are not needed during the inverse (r, t) wait in a per-workgroup global scratch (lane-linear, 2 KB per
-//     instruction, L2 / MALL resident: 2 stores + 3 loads of 16 KB per wave and step against 7 x 256 MFMAs).
+//     instruction, L2 / MALL resident: 4 stores + 5 loads of 16 KB per wave and step against 7 x 256 MFMAs).
 // Workgroups are persistent (one per CU, 1 + RT waves at most: two waves per SIMD) and walk the spectral axis.
 // Source vectors ride in two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip:
 // N <= 126 leaves them room in at most 8 strips.  N = 127, 128 (eight full strips): each wave forms one more 16 x 16 tile per
@@ -115,11 +115,11 @@ __device__ __forceinline__ void mm128(bstrip<RT>& acc, const bstrip<RT>& B, bpos
   }
 }
 
-// The same with the source vectors as an extra 16 x 16 tile (N = 127, 128: the strips have no spare column): wave w also forms
-// row tile w of [A] x for the two vectors x_0, x_1 of the LDS table at byte address xb (lane: (l15 & 1) NP + kq; every even /
-// odd column of the tile holds the same product) -- one MFMA, its fragment and a table read more per k-step.
+// The source vectors where the strips have no spare column (N = 127, 128): wave w forms row tile w of [A] (x_0 | x_1) for the two
+// vectors of the LDS table at byte address xb (lane: (l15 & 1) NP + kq; every even / odd column of the tile holds the same
+// product) -- 4 RT MFMAs more behind the product of the same [A], two accumulation chains.
 template <int RT>
-__device__ __forceinline__ void mm128r(bstrip<RT>& acc, const bstrip<RT>& B, d4_t& yr, unsigned xb, bpos<RT>& p) {
+__device__ __forceinline__ void rider_tile(d4_t& yr, unsigned xb, bpos<RT>& p) {
   constexpr int KS = 4 * RT;
   p.opaque();
   const unsigned wo = 512u * (unsigned)p.wave;
@@ -128,25 +128,18 @@ __device__ __forceinline__ void mm128r(bstrip<RT>& acc, const bstrip<RT>& B, d4_
     return *(reinterpret_cast<const lds_d*>((unsigned long long)(p.ab[ks & 3][h] + wo)) + 64 * ((ks - 16 * h) * RT));
   };
   auto xfr = [&](int ks) { return *(reinterpret_cast<const lds_d*>((unsigned long long)xb) + 4 * ks); };
-  double a[RT];
+  d4_t y1 = acc_zero<double>();
 #pragma unroll
-  for (int t = 0; t < RT; ++t) a[t] = *p.aptr(t, 0);
-  double ar = afr(0), xv = xfr(0);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const double b = B.v[ks >> 2][ks & 3];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      acc.v[t] = mfma<double>::mma(a[t], b, acc.v[t]);
-      if (ks + 1 < KS) a[t] = *p.aptr(t, ks + 1);
-    }
-    yr = mfma<double>::mma(ar, xv, yr);
-    if (ks + 1 < KS) {
-      ar = afr(ks + 1);
-      xv = xfr(ks + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+  for (int ks = 0; ks < KS; ks += 2) {
+    yr = mfma<double>::mma(afr(ks), xfr(ks), yr);
+    y1 = mfma<double>::mma(afr(ks + 1), xfr(ks + 1), y1);
   }
+  yr += y1;
+}
+template <int RT>
+__device__ __forceinline__ void mm128r(bstrip<RT>& acc, const bstrip<RT>& B, d4_t& yr, unsigned xb, bpos<RT>& p) {
+  mm128(acc, B, p);
+  rider_tile(yr, xb, p);
 }
 
 // strip -> A-form (columns >= N, i.e. the riders and the padding, as zeros); waves without matrix columns stay out
@@ -322,9 +315,10 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
   float* dsg = red + 32;   // D of apply_D: -1 on the U / V rows, +1 elsewhere
-  double* xt = lds128 + NP * NP + 128;   // (MR) x_0, x_1 of the coming rider product ; j0+, j0-
-  double* vjp = xt + 2 * NP;
-  double* vjm = xt + 3 * NP;
+  double* xt = lds128 + NP * NP + 128;   // (MR) x_0 = j0+, x_1 = j1- of the [r] phase ; u1, u2 of the [tt] phase ; j0+, j0-
+  double* xu = xt + 2 * NP;
+  double* vjp = xt + 4 * NP;
+  double* vjm = xt + 5 * NP;
   bpos<RT> p(lds_addr128(AF));
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;   // (MR) the lane's rows of the rider tile: rrow + 4 r
@@ -371,49 +365,48 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       }
     }
     spill(sT, t_s, p);
+    spill(sR, r_s, p);
     store_af(r_s, N, p);
     __syncthreads();
 
+    // Register plan: a strip is 8 RT registers, the fragments RT more: three strips live at most (the series; t' = tt t with
+    // r' waiting for its A-form store), two in the products that carry the source vectors -- r and W wait in the scratch while they are not an operand.
     for (int n = 0; n < ndoubl; ++n) {
-      // on entry: [A] = [r]; r_s, t_s in registers; t_s also in sT
-      bstrip<RT> W;
+      // on entry: [A] = [r]; t_s in registers; sR = r, sT = t (strips incl. their riders)
       bstrip<RT> G;
       {
-        W.zero();
-        d4_t u = acc_zero<double>();
-        if constexpr (MR) {
-          mm128r(W, t_s, u, xb, p);          // W = r t ; tile: r j0+ | r j1-
+        {
+          bstrip<RT> W;
+          W.zero();
+          if constexpr (MR) {
+            d4_t u = acc_zero<double>();
+            mm128r(W, t_s, u, xb, p);        // W = r t ; tile: r j0+ | r j1-
+            if (p.l15 < 2) {                 // u1 = j1- + r j0+ | u2 = j0+ + r j1-   (read in the [tt] phase, barriers away)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) u[r] += xt[(1 - (p.l15 & 1)) * NP + rrow + 4 * r];   // u1 = j1- + r j0+ | u2 = j0+ + r j1-
-        } else {
-          mm128(W, t_s, p);                  // W = r t            (riders: r j0+, r j1-)
-        }
-        if (!MR && own_wave) {                      // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
-          const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
-#pragma unroll
-          for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              W.v[ta][r] = fma(r_s.v[ta][r], fW, W.v[ta][r]);
-              r_s.v[ta][r] *= fR;
+              for (int r = 0; r < 4; ++r) xu[p.l15 * NP + rrow + 4 * r] = u[r] + xt[(1 - p.l15) * NP + rrow + 4 * r];
             }
+          } else {
+            mm128(W, t_s, p);                // W = r t            (riders: r j0+, r j1-)
+          }
+          fill(r_s, sR, p);
+          if (!MR && own_wave) {             // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
+            const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
+#pragma unroll
+            for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                W.v[ta][r] = fma(r_s.v[ta][r], fW, W.v[ta][r]);
+                r_s.v[ta][r] *= fR;
+              }
+          }
+          spill(sW, W, p);
         }
         bstrip<RT> E;
         E.zero();
         mm128(E, r_s, p);                    // E = r r
-        spill(sR, r_s, p);
+        spill(sR, r_s, p);                   // (the addend of r' = r + tt W, its rider column scaled)
         const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
-        if constexpr (MR) {                  // (nobody reads x any more) x_0 = u1, x_1 = u2 for the [tt] phase
-          if (p.l15 < 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xt[p.l15 * NP + rrow + 4 * r] = u[r];
-          }
-        }
-        const int K = series_order128(nrm);
-        const bool deep = K < 1 || K > 4;    // the squaring levels keep four strips: W waits outside
-        if (deep) spill(sW, W, p);
-        invert128(K, E, G, N, nw, red, slot, p);
-        if (deep) fill(W, sW, p);
+        invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
       }
       __syncthreads();                       // [E] no longer read
       {
@@ -430,18 +423,22 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         store_af(tt, N, p);
       }
       __syncthreads();
-      fill(r_s, sR, p);
-      if constexpr (MR) {
-        d4_t z = acc_zero<double>();
-        mm128r(r_s, W, z, xb, p);            // r' = r + tt W ; tile: tt u1 | tt u2
-        if (p.l15 < 2) {                     // j0- += tt u1 | j0+ = j0+ expk + tt u2     (rt_helpers.jl:128-134)
-          double* vj = p.l15 ? vjp : vjm;
-          const double f = p.l15 ? expk : 1.0;
+      {
+        bstrip<RT> W;
+        fill(r_s, sR, p);
+        fill(W, sW, p);
+        if constexpr (MR) {
+          d4_t z = acc_zero<double>();
+          mm128r(r_s, W, z, xb + 16u * NP, p);   // r' = r + tt W ; tile: tt u1 | tt u2
+          if (p.l15 < 2) {                   // j0- += tt u1 | j0+ = j0+ expk + tt u2     (rt_helpers.jl:128-134)
+            double* vj = p.l15 ? vjp : vjm;
+            const double f = p.l15 ? expk : 1.0;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) vj[rrow + 4 * r] = fma(vj[rrow + 4 * r], f, z[r]);
+            for (int r = 0; r < 4; ++r) vj[rrow + 4 * r] = fma(vj[rrow + 4 * r], f, z[r]);
+          }
+        } else {
+          mm128(r_s, W, p);                  // r' = r + tt W      (riders: the new j0-, j0+)
         }
-      } else {
-        mm128(r_s, W, p);                    // r' = r + tt W      (riders: the new j0-, j0+)
       }
       {
         bstrip<RT> t2;
@@ -462,6 +459,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
             }
         }
         spill(sT, t_s, p);
+        spill(sR, r_s, p);
         __syncthreads();                     // [tt] no longer read
         store_af(r_s, N, p);
         if constexpr (MR) {
@@ -515,7 +513,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
 template <int RT, bool MR>
 int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
                   hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 4 * 16 * RT * sizeof(double) : 0);
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 6 * 16 * RT * sizeof(double) : 0);
   static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl128<RT, MR>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_dbl128)");
