@@ -63,7 +63,8 @@ def test_thermal_source_operator(vsm, arch, FT):
 
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQUV", 9),        # N = 8, 32: operator level
                                          ("IQUV", 19), ("IQU", 33),     # N = 52, 60: the slot rides in the fused strip layer kernel
-                                         ("IQU", 35), ("IQUV", 25)])    # N = 63, 64: ... without spare columns (mat-vecs)
+                                         ("IQU", 35), ("IQUV", 25),     # N = 63, 64: ... without spare columns (mat-vecs)
+                                         ("IQUV", 31)])                 # N = 76: operator-level slot on the strip128 kernels
 def test_rt_run_thermal_slot_vs_oracle(vsm, arch, pol, l_trunc):
     """rt_run(model; sources = ThermalEmission) and sources = SolarBeam + ThermalEmission against the oracle's slot pass."""
     H = vsm.host_model
