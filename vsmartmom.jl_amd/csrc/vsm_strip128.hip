@@ -378,6 +378,8 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         {
           bstrip<RT> W;
           W.zero();
+          constexpr bool EARLY = RT < 8;     // request parked strips a phase ahead where a fourth strip's registers exist
+          if constexpr (EARLY) fill(r_s, sR, p);   // (used behind the product: the round trip hides)
           if constexpr (MR) {
             d4_t u = acc_zero<double>();
             mm128r(W, t_s, u, xb, p);        // W = r t ; tile: r j0+ | r j1-
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           } else {
             mm128(W, t_s, p);                // W = r t            (riders: r j0+, r j1-)
           }
-          fill(r_s, sR, p);
+          if constexpr (!EARLY) fill(r_s, sR, p);
           if (!MR && own_wave) {             // W[cb] += j1- = j0- expk, W[cb+1] += j0+ ; r_s[cb+1] -> j1+ = j0+ expk
             const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
 #pragma unroll
@@ -408,25 +410,31 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
         invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
       }
+      constexpr bool EARLY = RT < 8;
+      bstrip<RT> W, t2;
+      fill(t2, sT, p);
       __syncthreads();                       // [E] no longer read
-      {
-        bstrip<RT> t2;
-        fill(t2, sT, p);
-        store_af(t2, N, p);
-      }
+      store_af(t2, N, p);
       __syncthreads();
       {
         bstrip<RT> tt;
         tt.zero();
         mm128(tt, G, p);                     // tt = t G
+        if constexpr (EARLY) {               // (the operands of the [tt] phase: requested across the barriers)
+          fill(r_s, sR, p);
+          fill(W, sW, p);
+        }
         __syncthreads();                     // [t] no longer read
         store_af(tt, N, p);
       }
       __syncthreads();
-      {
-        bstrip<RT> W;
+      if constexpr (EARLY) {
+        fill(t2, sT, p);
+      } else {
         fill(r_s, sR, p);
         fill(W, sW, p);
+      }
+      {
         if constexpr (MR) {
           d4_t z = acc_zero<double>();
           mm128r(r_s, W, z, xb + 16u * NP, p);   // r' = r + tt W ; tile: tt u1 | tt u2
@@ -440,12 +448,9 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           mm128(r_s, W, p);                  // r' = r + tt W      (riders: the new j0-, j0+)
         }
       }
-      {
-        bstrip<RT> t2;
-        fill(t2, sT, p);
-        t_s.zero();
-        mm128(t_s, t2, p);                   // t' = tt t
-      }
+      if constexpr (!EARLY) fill(t2, sT, p);
+      t_s.zero();
+      mm128(t_s, t2, p);                     // t' = tt t
       expk = expk * expk;
       if (n + 1 < ndoubl) {
         if (!MR && own_wave) {   // t_s[cb] = j0+', t_s[cb+1] = j1-' = j0-' expk'   (from the neighbour lane of r_s)
