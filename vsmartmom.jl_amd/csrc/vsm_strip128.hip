@@ -532,23 +532,23 @@ int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<do
 // groups of the LDS store are 16 rows of one column: (m ^ const) -- conflict-free)
 template <int RT>
 __device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ g, int N, int nw, const bpos<RT>& p) {
-  constexpr int NP = 16 * RT;
-  for (int c0 = p.wave; c0 < NP; c0 += 4 * nw) {
-    double v[4][(NP + 63) / 64];
+  constexpr int NP = 16 * RT, CB = 8, NH = (NP + 63) / 64;   // CB columns x NH row blocks of a wave in flight together
+  for (int c0 = p.wave; c0 < NP; c0 += CB * nw) {
+    double v[CB][NH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < CB; ++i) {
       const int col = c0 + i * nw;
 #pragma unroll
-      for (int h = 0; h < (NP + 63) / 64; ++h) {
+      for (int h = 0; h < NH; ++h) {
         const int row = 64 * h + p.lane;
         v[i][h] = (row < N && col < N) ? g[row + (long long)N * col] : 0.0;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < CB; ++i) {
       const int col = c0 + i * nw;
 #pragma unroll
-      for (int h = 0; h < (NP + 63) / 64; ++h) {
+      for (int h = 0; h < NH; ++h) {
         const int row = 64 * h + p.lane;
         if (row < NP && col < NP)
           AF[(col >> 2) * (RT * 64) + (row >> 4) * 64 + ((col & 3) << 4) + ((row & 15) ^ (col & 15))] = v[i][h];
