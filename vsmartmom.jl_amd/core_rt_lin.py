@@ -3,7 +3,7 @@
 
 Mirrors: make_added_layer / make_composite_layer (LinMode) (tools/rt_helper_functions_lin.jl:15-80),
 elemental! / doubling_allparams! / interaction! (lin) (CoreKernel/*_lin.jl), create_surface_layer! (lin),
-postprocessing_vza! (lin).  FP64 with 32 < N <= 60 runs the fused column-strip kernels (vsm_striplin.hip: one launch
+postprocessing_vza! (lin).  FP64 with 8 <= N <= 60 runs the fused column-strip kernels (vsm_striplin.hip: one launch
 per doubling step, two per interaction); other shapes run operator level (batched MFMA products over (spectral point,
 parameter)); inverses are shared by all parameters like in the reference.  `SceneLin` keeps every input in HBM.
 """

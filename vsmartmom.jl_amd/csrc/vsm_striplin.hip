@@ -933,14 +933,19 @@ VSM_STRIPLIN_DECL(13)
 VSM_STRIPLIN_DECL(14)
 VSM_STRIPLIN_DECL(15)
 
+// The linearized strip kernels take 8 <= N <= 60; shapes below 33 run on the KS = 9 instantiation (k padded to 36: the strips'
+// padding rows are zero, so the extra k-steps add nothing) -- a quarter of the MFMA work is useful at N = 30, but the operator
+// chain these shapes would take instead is launch-bound (wall ratio 20 against a flop ratio of 3.4 at N = 30).
+static bool strip_lin_supported(int N) { return N >= 8 && (strip_supported(N) || N <= 32); }
+static int strip_lin_ks(int N) { return N <= 32 ? 9 : (N + 3) / 4; }
 // One fused doubling step (forward + P parameters); VSM_ERR_UNSUPPORTED outside 32 < N <= 60 or when the added layer is
 // not the plain [N,N,S] layout.
 int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st) {
   static const bool off = ab_switch("VSM_NO_STRIP_LIN");
-  if (off || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+  if (off || !strip_lin_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
-  switch ((N + 3) / 4) {
+  switch (strip_lin_ks(N)) {
 #define VSM_CASE(KS) \
   case KS:           \
     return VSM_CAT(launch_dbl_lin_step_, KS)(N, S, P, expk, ekl, a, al, st);
@@ -962,9 +967,9 @@ int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, cons
 int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                              const added_lin<double>& al, hipStream_t st) {
   static const bool off = ab_switch("VSM_NO_STRIP_LIN") || ab_switch("VSM_NO_LIN_MULTI");
-  if (off || P < 1 || P > 3 || nd < 1 || !strip_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+  if (off || P < 1 || P > 3 || nd < 1 || !strip_lin_supported(N) || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
-  switch ((N + 3) / 4) {
+  switch (strip_lin_ks(N)) {
 #define VSM_CASE(KS) \
   case KS:           \
     return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, P, nd, ns, expk, ekl, a, al, st);
@@ -985,7 +990,7 @@ int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, 
 int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st) {
   static const bool off = ab_switch("VSM_NO_STRIP_LIN") || ab_switch("VSM_NO_STRIP_LIN_IA");
-  if (off || !strip_supported(N)) return VSM_ERR_UNSUPPORTED;
+  if (off || !strip_lin_supported(N)) return VSM_ERR_UNSUPPORTED;
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S;
   const long long as = a.mat_stride, als = al.mat_stride, alp = (als == 0) ? NN : MS;
@@ -1024,7 +1029,7 @@ int strip_interaction11_lin(int N, int S, const composite<double>& c, const comp
   h2.OUTP0 = cl.R_pm; h2.OUTP1 = cl.T_pp;
   h2.VDR = al.ap_J0_m; h2.VDADD = cl.J0_p; h2.VDACC = al.ap_J0_p; h2.VDOUT = cl.J0_p;
   int rc;
-  switch ((N + 3) / 4) {
+  switch (strip_lin_ks(N)) {
 #define VSM_CASE(KS)                                                          \
   case KS:                                                                    \
     if ((rc = VSM_CAT(launch_ia_lin_half_, KS)(N, S, P, h1, st))) return rc;  \
