@@ -374,10 +374,22 @@ def bench_c5(args, vsm, parallel, torch, rank, world, local):
                        "in_band_lines_per_point": kin},
             "roofline": {"bound": "mfma", "kernel": "whole run (k_raman_doubling_wave_sp<21> ~72 %, k_raman_interaction_wave<21> ~16 %)",
                          "achieved": tf, "peak": PEAK_TFLOPS["f64"] * world, "unit": "TFLOP/s", "frac": tf / (PEAK_TFLOPS["f64"] * world),
-                         "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world), "traffic": None}}))
+                         "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world),
+                         "traffic": c5_traffic_per_point() and c5_traffic_per_point() * S_total,
+                         "traffic_note": "HBM bytes of one whole step (all kernels; FETCH_SIZE x 2 + WRITE_SIZE per point from "
+                                         "profiles/r03/c5/summary.json, a 4000-point run, x the points of this run)"}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def c5_traffic_per_point():
+    """Whole-run HBM bytes per spectral point of the C5 workload from the committed PMC passes (profiles/r03/c5/summary.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03", "c5", "summary.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_point_whole_run"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def hbm_traffic_per_launch(kernel, cfg, S_local):

@@ -130,6 +130,11 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
                "k_raman_doubling_wave_sp<21> (+ k_raman_interaction_wave<21>)")
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
+    try:   # whole-step HBM bytes from the committed PMC passes of the same workload (profiles/r03/c5/summary.json)
+        with open(os.path.join(ROOT, "profiles", "r03", "c5", "summary.json")) as f:
+            e["hbm_bytes_per_step"] = float(json.load(f)["hbm_bytes_per_point_whole_run"]) * S
+    except (OSError, KeyError, ValueError):
+        e["hbm_bytes_per_step"] = None
     return e
 
 
