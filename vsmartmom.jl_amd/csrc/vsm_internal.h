@@ -154,11 +154,16 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
 // VSM_ERR_UNSUPPORTED).  sa / sb: element strides between spectral slices (0 = shared block).
 template <typename T>
 int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, long long sb, T* X, hipStream_t st);
+bool strip128_supported(int N);
+int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, hipStream_t st);
 // (I - A B)^-1 by the fused kernel when N fits, else gemm + batch_inv through `tmp` ([N,N,S] scratch)
 template <typename T>
 inline int inv_one_minus(int N, int S, const T* A, long long sa, const T* B, long long sb, T* X, T* tmp, hipStream_t st) {
   int rc = inv_one_minus_product<T>(N, S, A, sa, B, sb, X, st);
   if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  if constexpr (sizeof(T) == 8) {   // FP64, 64 < N <= 128: product + series / squaring levels in one strip kernel
+    if (strip128_supported(N)) return strip128_inv_one_minus(N, S, A, sa, B, sb, X, st);
+  }
   const long long NN = (long long)N * N;
   if ((rc = gemm<T>(N, N, N, S, A, sa, B, sb, tmp, NN, T(-1), (const T*)nullptr, 0, T(0), T(1), st))) return rc;
   return batch_inv<T>(N, S, tmp, X, nullptr, st);

@@ -809,6 +809,43 @@ int launch_ia128(int N, int S, const composite<double>& c, const added<double>& 
   return VSM_OK;
 }
 
+// ---- (I - A B)^-1 (the operator chains of the linearized and Raman runs at these shapes: one launch instead of a product and
+// a pivoted global-memory inverse) -------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(64 * B_MAXW) void k_inv1m128(int N, int S, const double* __restrict__ A, long long sa,
+                                                           const double* __restrict__ B, long long sb, double* __restrict__ X) {
+  constexpr int NP = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) double lds128[];
+  double* AF = lds128;
+  float* red = reinterpret_cast<float*>(lds128 + NP * NP);
+  bpos<RT> p(lds_addr128(AF));
+  const int nw = blockDim.x >> 6;
+  int slot = 0;
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    bstrip<RT> b;
+    load_global128(b, B + sb * s, N, p);
+    stage_af(AF, A + sa * s, N, nw, p);
+    __syncthreads();
+    bstrip<RT> E, G;
+    E.zero();
+    mm128(E, b, p);
+    const double nrm = norm128(E, N, nw, red, slot, p);
+    invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
+    store_global128(X + (long long)N * N * s, G, N, p);
+    __syncthreads();   // the next point restages the A-form
+  }
+}
+template <int RT>
+int launch_inv1m128(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, int grid, hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 256;
+  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv1m128<RT>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_inv1m128)");
+  hipLaunchKernelGGL(k_inv1m128<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, A, sa, B, sb, X);
+  VSM_LAUNCH_CHECK("k_inv1m128");
+  return VSM_OK;
+}
+
 int cu_count() {
   static int n = [] {
     int dev = 0, v = 0;
@@ -856,6 +893,20 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
       return launch_ia128<8, false>(N, S, c, a, grid, nw, scr, st);
   }
   set_error("strip128_interaction11: N=%d outside 65..128", N);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, hipStream_t st) {
+  if (S <= 0) return VSM_OK;
+  const int RT = (N + 15) / 16;
+  const int grid = S < cu_count() ? S : cu_count();
+  switch (RT) {
+    case 5: return launch_inv1m128<5>(N, S, A, sa, B, sb, X, grid, st);
+    case 6: return launch_inv1m128<6>(N, S, A, sa, B, sb, X, grid, st);
+    case 7: return launch_inv1m128<7>(N, S, A, sa, B, sb, X, grid, st);
+    case 8: return launch_inv1m128<8>(N, S, A, sa, B, sb, X, grid, st);
+  }
+  set_error("strip128_inv_one_minus: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
 }
 
