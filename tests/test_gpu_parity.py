@@ -394,6 +394,36 @@ def test_strip128_persistent_workgroups_walk_the_spectral_axis(vsm, arch, N):
         assert np.max(np.abs(v - ref).reshape(S, -1).max(axis=1)) / np.abs(ref).max() < 1e-11, k
 
 
+def test_strip128_every_size(vsm, arch):
+    """Every N of the window 65..128 (row tiles 5..8; rider columns at every position of a strip, in a strip of their own at
+    N = 16 k - 1 and 16 k, as an MFMA tile at 127 / 128): interaction 11 and three doubling steps on random layers vs the oracle."""
+    FT = np.float64
+    hpol = vsm.host_model.polarization_type("I")
+    pol = O.polarization("I")
+    worst = 0.0
+    for N in range(65, 129):
+        rng = np.random.default_rng(N)
+        S = 3
+        comp, add = _random_layers(rng, N, S, FT, pol)
+        pc, pa = _upload_layers(vsm, arch, comp, add, FT)
+        O.interaction("11", comp, add, FT)
+        vsm.CoreRT.interaction_("11", pc, pa)
+        for k, v in _comp_to_host(vsm, pc).items():
+            e = _rel(v, getattr(comp, k))
+            worst = max(worst, e)
+            assert e < 1e-11, (N, k, e)
+        _, add = _random_layers(rng, N, S, FT, pol)
+        add.r_mp *= 0.2
+        expk = rng.uniform(0.5, 0.99, S)
+        _, pa = _upload_layers(vsm, arch, comp, add, FT)
+        t_expk = vsm.Architectures.array_type(arch)(expk.copy())
+        O.doubling(pol, expk, 3, add, FT)
+        vsm.CoreRT.doubling_(hpol, t_expk, 3, pa)
+        for k, v in _added_to_host(vsm, pa).items():
+            e = _rel(v, getattr(add, k))
+            assert e < 1e-11, (N, k, e)
+
+
 def _random_layers(rng, N, S, FT, pol):
     """Physically shaped operators: small reflections, near-diagonal transmissions."""
     def refl(scale):
