@@ -59,7 +59,9 @@ struct bpos {
   unsigned ab[4][2];   // fragment bases (bytes) by (ks & 3, ks >= 16)
   unsigned sb[4];      // strip element bases by r
   bool mat_wave;       // the wave's columns are columns of the A-form (wave < RT)
-  __device__ __forceinline__ bpos(unsigned af) {
+  int ksn;             // k-steps that hold columns < N: ceil(N / 4) (the products skip the all-padding tail, up to three of 4 RT)
+  __device__ __forceinline__ bpos(unsigned af, int N) {
+    ksn = (N + 3) >> 2;
     lane = threadIdx.x & 63;
     wave = threadIdx.x >> 6;
     l15 = lane & 15;
@@ -105,6 +107,7 @@ __device__ __forceinline__ void mm128(bstrip<RT>& acc, const bstrip<RT>& B, bpos
   for (int t = 0; t < RT; ++t) a[t] = *p.aptr(t, 0);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
+    if (ks >= KS - 3 && ks >= p.ksn) break;   // (uniform) N > 16 (RT - 1): only the last three k-steps can be all padding
     const double b = B.v[ks >> 2][ks & 3];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   double* xu = xt + 2 * NP;
   double* vjp = xt + 4 * NP;
   double* vjm = xt + 5 * NP;
-  bpos<RT> p(lds_addr128(AF));
+  bpos<RT> p(lds_addr128(AF), N);
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;   // (MR) the lane's rows of the rider tile: rrow + 4 r
   for (int i = threadIdx.x; i < NP; i += blockDim.x) dsg[i] = is_uv_row(i, ns) ? -1.f : 1.f;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   double* vjp = vec, *vjm = vec + NP, *vJp = vec + 2 * NP, *vJm = vec + 3 * NP, *vz = vec + 4 * NP, *vs = vec + 5 * NP;
   double* xt = vec + 6 * NP;
   float* red = reinterpret_cast<float*>(vec + 8 * NP);
-  bpos<RT> p(lds_addr128(AF));
+  bpos<RT> p(lds_addr128(AF), N);
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
@@ -818,7 +821,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_inv1m128(int N, int S, const do
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
-  bpos<RT> p(lds_addr128(AF));
+  bpos<RT> p(lds_addr128(AF), N);
   const int nw = blockDim.x >> 6;
   int slot = 0;
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
