@@ -1,3 +1,4 @@
+"""Linearized run of one large FP64 shape (N = 112) for profiling the operator chain of 64 < N <= 128: python tools/lin_shape_probe.py"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch, bench
