@@ -4,6 +4,7 @@
 //   k_dbl128<RT>   doubling! (src/CoreRT/CoreKernel/doubling.jl:38-99, rt_helpers.jl:102-166, apply_D doubling.jl:178-252):
 //                  the whole doubling loop of one spectral point in one workgroup, in place on the AddedLayer
 //   k_ia128<RT>    interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266), one inverse, in place on the composite
+//   k_inv1m128<RT> (I - A B)^-1, the inverse of the operator chains (linearized / Raman runs) at these shapes
 //
 // Scheme (vsm_strip.hip's, re-dimensioned): a matrix is padded to NP = 16 RT rows (RT = 5..8 row tiles); wave w owns the
 // 16-column strip w of every operator as RT accumulator tiles of v_mfma_f64_16x16x4 -- the accumulator layout IS the B-operand
@@ -13,8 +14,8 @@
 //   * the products of a step are ordered by their left operand, [r] -> [E] -> [t] -> [tt], each A-form written once from the
 //     strips (two barriers), every product of that operand running off it:
 //         W = r t ; E = r r ;  G = (I - E)^-1 (Neumann series off [E]) ;  tt = t G ;  r' = r + tt W ;  t' = tt t
-//   * the strips that are not needed during the inverse (r, t) wait in a per-workgroup global scratch (lane-linear, 2 KB per
-//     instruction, L2 / MALL resident: 4 stores + 5 loads of 16 KB per wave and step against 7 x 256 MFMAs).
+//   * the strips that are not an operand of the running phase (r, t, W) wait in a per-workgroup global scratch (lane-linear,
+//     2 KB per instruction, L2 / MALL resident: 4 stores + 5 loads of 16 KB per wave and step against >= 6 x 32 RT MFMAs).
 // Workgroups are persistent (one per CU, 1 + RT waves at most: two waves per SIMD) and walk the spectral axis.
 // Source vectors ride in two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip:
 // N <= 126 leaves them room in at most 8 strips.  N = 127, 128 (eight full strips): each wave forms one more 16 x 16 tile per
