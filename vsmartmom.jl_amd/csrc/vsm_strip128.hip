@@ -31,6 +31,29 @@
 #include "vsm_lds.h"
 
 namespace vsm {
+#ifdef VSM_PHASE_TIMING   // diagnostic build (make timing; tools/phase_timing128.py): cycles per phase of k_ia128, every workgroup
+__device__ unsigned long long vsm_phase_cycles_128[32];
+#define B128_STAMP_DECL                  \
+  unsigned long long _bs[24] = {};       \
+  unsigned long long _bt = __builtin_readcyclecounter()
+#define B128_STAMP(i)                                             \
+  do {                                                            \
+    const unsigned long long _t = __builtin_readcyclecounter();   \
+    _bs[i] += _t - _bt;                                           \
+    _bt = _t;                                                     \
+  } while (0)
+#define B128_STAMP_FLUSH(npoints)                                                          \
+  do {                                                                                     \
+    if (threadIdx.x == 0) {                                                                \
+      for (int _i = 0; _i < 24; ++_i) atomicAdd(&vsm_phase_cycles_128[_i], _bs[_i]);       \
+      atomicAdd(&vsm_phase_cycles_128[31], (unsigned long long)(npoints));                 \
+    }                                                                                      \
+  } while (0)
+#else
+#define B128_STAMP_DECL
+#define B128_STAMP(i)
+#define B128_STAMP_FLUSH(n) (void)(n)
+#endif
 namespace {
 
 using lds_d = __attribute__((address_space(3))) double;
@@ -605,8 +628,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   d4_t* const sV = scr + ((long long)(blockIdx.x * 4 + 2) * B_MAXW + p.wave) * (RT * 64) + p.lane;
   d4_t* const sS = scr + ((long long)(blockIdx.x * 4 + 3) * B_MAXW + p.wave) * (RT * 64) + p.lane;
   int slot = 0;
+  B128_STAMP_DECL;
+  int npts = 0;
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    ++npts;
     double* const R_mp = c.R_mp + NN * s;
     double* const R_pm = c.R_pm + NN * s;
     double* const T_pp = c.T_pp + NN * s;
@@ -627,8 +653,10 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     }
     stage_af(AF, R_pm, N, nw, p);
     __syncthreads();                                    // (a)
+    B128_STAMP(0);
     bstrip<RT> r_s;
     load_global128(r_s, a_r_mp, N, p);
+    B128_STAMP(1);
     if (laneR) {                                        // j0- rides in the spare column of r-+
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta)
@@ -656,6 +684,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
       spill(sE, E, p);
     }
+    B128_STAMP(2);
     {
       bstrip<RT> tm;
       load_global128(tm, a_t_mm, N, p);
@@ -665,14 +694,17 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         mm128(Z, tm, p);                                // Z = R+- t--
         spill(sZ, Z, p);
       }
+      B128_STAMP(3);
       __syncthreads();                                  // (b) [R+-] no longer read
       stage_af(AF, T_mm, N, nw, p);
       __syncthreads();                                  // (c)
+      B128_STAMP(4);
       bstrip<RT> V;
       V.zero();
       mm128(V, tm, p);                                  // V = T-- t--
       spill(sV, V, p);
     }
+    B128_STAMP(5);
     {
       bstrip<RT> Sx;
       Sx.zero();
@@ -694,6 +726,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
       spill(sS, Sx, p);
     }
+    B128_STAMP(6);
     bstrip<RT> G;
     {
       bstrip<RT> E;
@@ -704,12 +737,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
       invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
     }
+    B128_STAMP(7);
     __syncthreads();                                    // (e) [E2] no longer read
     stage_af(AF, a_t_pp, N, nw, p);
     __syncthreads();                                    // (f)
+    B128_STAMP(8);
     bstrip<RT> X;
     X.zero();
     mm128(X, G, p);                                     // T21 = t++ G2
+    B128_STAMP(9);
     __syncthreads();                                    // (g) [t++] no longer read
     {
       bstrip<RT> Sx;
@@ -717,12 +753,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       store_af(Sx, N, p);
     }
     __syncthreads();                                    // (h)
+    B128_STAMP(10);
     bstrip<RT> Y;
     Y.zero();
     mm128(Y, G, p);                                     // Y = S G2
+    B128_STAMP(11);
     __syncthreads();                                    // (i) [S] no longer read
     store_af(X, N, p);
     __syncthreads();                                    // (j)
+    B128_STAMP(12);
     {
       bstrip<RT> acc, Z;
       load_global128(acc, a_r_pm, N, p);
@@ -730,6 +769,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
       store_global128(R_pm, acc, N, p);
     }
+    B128_STAMP(13);
     bstrip<RT> Tpp;
     load_global128(Tpp, T_pp, N, p);
     if (laneR) {                                        // z rides in the spare column of T++
@@ -764,8 +804,10 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
     }
     __syncthreads();                                    // (k) [T21] no longer read
+    B128_STAMP(14);
     store_af(Y, N, p);
     __syncthreads();                                    // (l)
+    B128_STAMP(15);
     {
       bstrip<RT> acc;
       load_global128(acc, R_mp, N, p);
@@ -796,10 +838,13 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       fill(acc, sV, p);
       fill(Z, sZ, p);
       mm128(acc, Z, p);                                 // T-- = V + Y Z
+      B128_STAMP(16);
       store_global128(T_mm, acc, N, p);
     }
     __syncthreads();                                    // (m) the next point restages the A-form and the vectors
+    B128_STAMP(17);
   }
+  B128_STAMP_FLUSH(npts);
 }
 
 template <int RT, bool MR>
@@ -915,3 +960,14 @@ int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const do
 }
 
 }  // namespace vsm
+
+#ifdef VSM_PHASE_TIMING
+extern "C" int vsm_debug_phase_cycles_128(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_128), sizeof(unsigned long long) * 32);
+  if (reset) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_phase_cycles_128), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
