@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase cycles of k_ia128 (FP64 interaction kernel for 64 < N <= 128), mean per spectral point over ALL workgroups.
 Needs the diagnostic build (make -C vsmartmom.jl_amd/csrc timing):
-  VSM_LIB_PATH=vsmartmom.jl_amd/lib_dbg/libvsmartmom_hip_timing.so python tools/phase_timing128.py [pol:l_trunc] [points]"""
+  VSM_LIB_PATH=vsmartmom.jl_amd/lib_dbg/libvsmartmom_hip_timing.so python tools/phase_timing128.py [pol:l_trunc] [points] [random]"""
 import ctypes as C
 import os
 import sys
@@ -27,26 +27,36 @@ def main():
     pol, lt = case.split(":")
     H = vsm.host_model
     N = H.rt_set_streams(int(lt), 40.0, [30.0], H.polarization_type(pol), np.float64).Nquad * H.polarization_type(pol).n
-    import test_gpu_parity as T
-    rng = np.random.default_rng(1)
-    comp, add = T._random_layers(rng, N, S, np.float64, None)
     arch = vsm.Architectures.GPU(0)
-    pc, pa = T._upload_layers(vsm, arch, comp, add, np.float64)
     lib = C.CDLL(vsm._lib.LIB_PATH)
-    vsm.CoreRT.interaction_("11", pc, pa)
+    if len(sys.argv) > 3 and sys.argv[3] == "random":   # the tests' random layers: large ||R+- r-+||, deep inverse
+        import test_gpu_parity as T
+        rng = np.random.default_rng(1)
+        comp, add = T._random_layers(rng, N, S, np.float64, None)
+        pc, pa = T._upload_layers(vsm, arch, comp, add, np.float64)
+        run = lambda: vsm.CoreRT.interaction_("11", pc, pa)
+    else:                                               # the O2-A atmosphere of tools/shape_cliff_timing.py, a whole forward run
+        import bench
+        tau_rayl, tau_abs = bench.o2a_atmosphere(S, 10)
+        model = H.model_from_arrays(arch, pol, int(lt), 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279,
+                                    albedo=0.15, m_max=2)
+        scene = vsm.CoreRT.prepare_scene(model)
+        run = lambda: scene.run()
+    run()
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 32)()
     lib.vsm_debug_phase_cycles_128(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    vsm.CoreRT.interaction_("11", pc, pa)
+    run()
     e1.record()
     torch.cuda.synchronize()
     lib.vsm_debug_phase_cycles_128(buf, 0)
     v = np.array(list(buf), dtype=float)
     npts = max(v[31], 1)
     tot = v[:18].sum() / npts
-    print("k_ia128 at N = %d, %d points: %.3f ms ; cycles per point (thread 0 of every workgroup), sum %.0f" % (N, S, e0.elapsed_time(e1), tot))
+    print("k_ia128 at N = %d, %d points (%d point-launches): timed region %.3f ms ; cycles per point (thread 0 of every workgroup), sum %.0f"
+          % (N, S, int(npts), e0.elapsed_time(e1), tot))
     mf = 64.0 * 4 * ((N + 15) // 16) * ((N + 15) // 16)   # cycles of one wave's MFMAs per product
     for n, x in zip(NAMES, v[:18]):
         print("  %-78s %9.0f  %5.1f %%" % (n, x / npts, 100 * x / npts / tot))

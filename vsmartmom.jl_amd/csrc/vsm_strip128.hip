@@ -67,6 +67,13 @@ __device__ __forceinline__ double dpp_swap1_128(double x) {   // value of lane ^
 }
 
 constexpr int B_MAXW = 8;   // waves per workgroup at most
+// A pointer that went through an empty asm (to keep LICM from hoisting every derived address) comes back as a GENERIC pointer:
+// its accesses would be flat_load / flat_store, which count on lgkmcnt as well -- every LDS wait of the products and every
+// barrier would then wait for the parked strips and the operand loads.  Cast back to the global address space.
+using gd4_p = __attribute__((address_space(1))) d4_t*;
+using gcd4_p = const __attribute__((address_space(1))) d4_t*;
+using gd_p = __attribute__((address_space(1))) double*;
+using gcd_p = const __attribute__((address_space(1))) double*;
 
 template <int RT>
 struct bstrip {
@@ -190,14 +197,16 @@ __device__ __forceinline__ void load_af(bstrip<RT>& s, const bpos<RT>& p) {
 template <int RT>
 __device__ __forceinline__ void spill(d4_t* g, const bstrip<RT>& s, const bpos<RT>& p) {
   asm volatile("" : "+v"(g));   // (the per-tile addresses are formed here, not hoisted out of the doubling loop into registers)
+  gd4_p gg = (gd4_p)g;
 #pragma unroll
-  for (int ta = 0; ta < RT; ++ta) g[64 * ta] = s.v[ta];
+  for (int ta = 0; ta < RT; ++ta) gg[64 * ta] = s.v[ta];
 }
 template <int RT>
 __device__ __forceinline__ void fill(bstrip<RT>& s, const d4_t* g, const bpos<RT>& p) {
   asm volatile("" : "+v"(g));
+  gcd4_p gg = (gcd4_p)g;
 #pragma unroll
-  for (int ta = 0; ta < RT; ++ta) s.v[ta] = g[64 * ta];
+  for (int ta = 0; ta < RT; ++ta) s.v[ta] = gg[64 * ta];
 }
 
 // Frobenius-norm bound of the N x N block (rows >= N are zero by construction).  ONE barrier inside.
@@ -315,8 +324,9 @@ __device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, i
 template <int RT>
 __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __restrict__ g, int N, const bpos<RT>& p) {
   const bool cok = p.col < N;
-  const double* gc = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc));
+  const double* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc0));
+  gcd_p gc = (gcd_p)gc0;
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
@@ -586,8 +596,9 @@ __device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ 
 template <int RT>
 __device__ __forceinline__ void store_global128(double* __restrict__ g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
   const bool cok = p.col < N;
-  double* gc = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc));
+  double* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc0));
+  gd_p gc = (gd_p)gc0;
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
@@ -663,6 +674,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
         for (int r = 0; r < 4; ++r) r_s.v[ta][r] = vjm[p.row(ta, r)];
     }
+    bstrip<RT> tm;
     {
       bstrip<RT> E;
       E.zero();
@@ -682,12 +694,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) vz[p.row(ta, r)] = vJp[p.row(ta, r)] + E.v[ta][r];
       }
+      load_global128(tm, a_t_mm, N, p);                 // (loads go ahead of stores: a load behind a store waits for its drain)
       spill(sE, E, p);
     }
     B128_STAMP(2);
     {
-      bstrip<RT> tm;
-      load_global128(tm, a_t_mm, N, p);
       {
         bstrip<RT> Z;
         Z.zero();
@@ -705,6 +716,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       spill(sV, V, p);
     }
     B128_STAMP(5);
+    bstrip<RT> E;
     {
       bstrip<RT> Sx;
       Sx.zero();
@@ -724,13 +736,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) vs[p.row(ta, r)] = Sx.v[ta][r];
       }
+      fill(E, sE, p);
       spill(sS, Sx, p);
     }
     B128_STAMP(6);
     bstrip<RT> G;
     {
-      bstrip<RT> E;
-      fill(E, sE, p);
       const double nrm = norm128(E, N, nw, red, slot, p);   // (d) [T--] no longer read
       if constexpr (MR) {                               // (nobody reads the table any more) x = z for [T21], [Y]
         for (int i = tid; i < NP; i += blockDim.x) xt[i] = xt[NP + i] = vz[i];
@@ -762,16 +773,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     store_af(X, N, p);
     __syncthreads();                                    // (j)
     B128_STAMP(12);
+    bstrip<RT> Tpp;
     {
       bstrip<RT> acc, Z;
       load_global128(acc, a_r_pm, N, p);
       fill(Z, sZ, p);
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
+      load_global128(Tpp, T_pp, N, p);
       store_global128(R_pm, acc, N, p);
     }
     B128_STAMP(13);
-    bstrip<RT> Tpp;
-    load_global128(Tpp, T_pp, N, p);
     if (laneR) {                                        // z rides in the spare column of T++
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta)
@@ -808,6 +819,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     store_af(Y, N, p);
     __syncthreads();                                    // (l)
     B128_STAMP(15);
+    bstrip<RT> V2, Z2;
     {
       bstrip<RT> acc;
       load_global128(acc, R_mp, N, p);
@@ -822,6 +834,8 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       } else {
         mm128(acc, Tpp, p);                             // R-+ = R-+ + Y T++ ; rider: Y z
       }
+      fill(V2, sV, p);                                  // (the last product's operands, requested ahead of the stores)
+      fill(Z2, sZ, p);
       store_global128(R_mp, acc, N, p);
       if (laneR) {
 #pragma unroll
@@ -834,9 +848,8 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
     }
     {
-      bstrip<RT> acc, Z;
-      fill(acc, sV, p);
-      fill(Z, sZ, p);
+      bstrip<RT>& acc = V2;
+      bstrip<RT>& Z = Z2;
       mm128(acc, Z, p);                                 // T-- = V + Y Z
       B128_STAMP(16);
       store_global128(T_mm, acc, N, p);
