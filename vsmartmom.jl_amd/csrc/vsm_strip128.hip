@@ -662,11 +662,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       vJm[i] = in ? J0_m[i] : 0.0;
       if constexpr (MR) xt[i] = xt[NP + i] = vjm[i];
     }
+    bstrip<RT> r_s;
+    load_global128(r_s, a_r_mp, N, p);                  // (in flight with the staging)
     stage_af(AF, R_pm, N, nw, p);
     __syncthreads();                                    // (a)
     B128_STAMP(0);
-    bstrip<RT> r_s;
-    load_global128(r_s, a_r_mp, N, p);
     B128_STAMP(1);
     if (laneR) {                                        // j0- rides in the spare column of r-+
 #pragma unroll
@@ -675,6 +675,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         for (int r = 0; r < 4; ++r) r_s.v[ta][r] = vjm[p.row(ta, r)];
     }
     bstrip<RT> tm;
+    load_global128(tm, a_t_mm, N, p);                   // (requested a product ahead)
     {
       bstrip<RT> E;
       E.zero();
@@ -694,7 +695,6 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) vz[p.row(ta, r)] = vJp[p.row(ta, r)] + E.v[ta][r];
       }
-      load_global128(tm, a_t_mm, N, p);                 // (loads go ahead of stores: a load behind a store waits for its drain)
       spill(sE, E, p);
     }
     B128_STAMP(2);
@@ -717,6 +717,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     }
     B128_STAMP(5);
     bstrip<RT> E;
+    fill(E, sE, p);                                     // (requested a product ahead)
     {
       bstrip<RT> Sx;
       Sx.zero();
@@ -736,7 +737,6 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) vs[p.row(ta, r)] = Sx.v[ta][r];
       }
-      fill(E, sE, p);
       spill(sS, Sx, p);
     }
     B128_STAMP(6);
@@ -753,16 +753,13 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     stage_af(AF, a_t_pp, N, nw, p);
     __syncthreads();                                    // (f)
     B128_STAMP(8);
-    bstrip<RT> X;
+    bstrip<RT> X, Sx;
+    fill(Sx, sS, p);                                    // (requested a product ahead)
     X.zero();
     mm128(X, G, p);                                     // T21 = t++ G2
     B128_STAMP(9);
     __syncthreads();                                    // (g) [t++] no longer read
-    {
-      bstrip<RT> Sx;
-      fill(Sx, sS, p);
-      store_af(Sx, N, p);
-    }
+    store_af(Sx, N, p);
     __syncthreads();                                    // (h)
     B128_STAMP(10);
     bstrip<RT> Y;
@@ -771,13 +768,13 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     B128_STAMP(11);
     __syncthreads();                                    // (i) [S] no longer read
     store_af(X, N, p);
-    __syncthreads();                                    // (j)
-    B128_STAMP(12);
     bstrip<RT> Tpp;
     {
       bstrip<RT> acc, Z;
-      load_global128(acc, a_r_pm, N, p);
+      load_global128(acc, a_r_pm, N, p);                // (requested across the barrier)
       fill(Z, sZ, p);
+      __syncthreads();                                  // (j)
+      B128_STAMP(12);
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
       load_global128(Tpp, T_pp, N, p);
       store_global128(R_pm, acc, N, p);
