@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       }
     }
     spill(sT, t_s, p);
-    spill(sR, r_s, p);
+    if constexpr (RT >= 8) spill(sR, r_s, p);   // (RT < 8: r stays in registers from one step to the next)
     store_af(r_s, N, p);
     __syncthreads();
 
@@ -416,7 +416,6 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           bstrip<RT> W;
           W.zero();
           constexpr bool EARLY = RT < 8;     // request parked strips a phase ahead where a fourth strip's registers exist
-          if constexpr (EARLY) fill(r_s, sR, p);   // (used behind the product: the round trip hides)
           if constexpr (MR) {
             d4_t u = acc_zero<double>();
             mm128r(W, t_s, u, xb, p);        // W = r t ; tile: r j0+ | r j1-
@@ -501,7 +500,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
             }
         }
         spill(sT, t_s, p);
-        spill(sR, r_s, p);
+        if constexpr (RT >= 8) spill(sR, r_s, p);
         __syncthreads();                     // [tt] no longer read
         store_af(r_s, N, p);
         if constexpr (MR) {
