@@ -44,7 +44,7 @@ def main():
         run = lambda: scene.run()
     run()
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     lib.vsm_debug_phase_cycles_128(None, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -61,6 +61,16 @@ def main():
     for n, x in zip(NAMES, v[:18]):
         print("  %-78s %9.0f  %5.1f %%" % (n, x / npts, 100 * x / npts / tot))
     print("  (one product = %d MFMAs of 64 cycles per wave = %.0f cycles; two waves share a SIMD)" % (mf / 64, mf))
+    if v[63] > 0:
+        d = v[32:43]
+        np_d = v[63]
+        dn = ["load r, t, riders, park, store [r], barrier (per point)", "W = r t, riders (+ park W)", "E = r r (+ park r)",
+              "norm, store [E], series", "fetch t, barrier, store [t], barrier", "tt = t G", "barrier, store [tt], barrier (+ fetches)",
+              "r' = r + tt W", "t' = tt t", "riders, parks, barrier, store [r'], barrier", "outputs (apply_D), end barrier (per point)"]
+        totd = d.sum() / np_d
+        print("k_dbl128: cycles per point (all doubling steps), sum %.0f" % totd)
+        for n, x in zip(dn, d):
+            print("  %-78s %9.0f  %5.1f %%" % (n, x / np_d, 100 * x / np_d / totd))
 
 
 if __name__ == "__main__":

@@ -32,9 +32,9 @@
 
 namespace vsm {
 #ifdef VSM_PHASE_TIMING   // diagnostic build (make timing; tools/phase_timing128.py): cycles per phase of k_ia128, every workgroup
-__device__ unsigned long long vsm_phase_cycles_128[32];
+__device__ unsigned long long vsm_phase_cycles_128[64];   // k_ia128: 0..17, points [31] ; k_dbl128: 32..43, steps [62], points [63]
 #define B128_STAMP_DECL                  \
-  unsigned long long _bs[24] = {};       \
+  unsigned long long _bs[20] = {};       \
   unsigned long long _bt = __builtin_readcyclecounter()
 #define B128_STAMP(i)                                             \
   do {                                                            \
@@ -42,17 +42,19 @@ __device__ unsigned long long vsm_phase_cycles_128[32];
     _bs[i] += _t - _bt;                                           \
     _bt = _t;                                                     \
   } while (0)
-#define B128_STAMP_FLUSH(npoints)                                                          \
-  do {                                                                                     \
-    if (threadIdx.x == 0) {                                                                \
-      for (int _i = 0; _i < 24; ++_i) atomicAdd(&vsm_phase_cycles_128[_i], _bs[_i]);       \
-      atomicAdd(&vsm_phase_cycles_128[31], (unsigned long long)(npoints));                 \
-    }                                                                                      \
+#define B128_STAMP_FLUSH_AT(base, cnt, npoints)                                                   \
+  do {                                                                                            \
+    if (threadIdx.x == 0) {                                                                       \
+      for (int _i = 0; _i < 20; ++_i) atomicAdd(&vsm_phase_cycles_128[(base) + _i], _bs[_i]);     \
+      atomicAdd(&vsm_phase_cycles_128[cnt], (unsigned long long)(npoints));                       \
+    }                                                                                             \
   } while (0)
+#define B128_STAMP_FLUSH(npoints) B128_STAMP_FLUSH_AT(0, 31, npoints)
 #else
 #define B128_STAMP_DECL
 #define B128_STAMP(i)
 #define B128_STAMP_FLUSH(n) (void)(n)
+#define B128_STAMP_FLUSH_AT(b, c, n) (void)(n)
 #endif
 namespace {
 
@@ -369,8 +371,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   d4_t* const sT = scr + ((long long)(blockIdx.x * 3 + 1) * B_MAXW + p.wave) * (RT * 64) + p.lane;
   d4_t* const sW = scr + ((long long)(blockIdx.x * 3 + 2) * B_MAXW + p.wave) * (RT * 64) + p.lane;
   int slot = 0;
+  B128_STAMP_DECL;
+  int npts = 0;
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    ++npts;
     double* const g_r = a.r_mp + NN * s;
     double* const g_t = a.t_pp + NN * s;
     double* const g_jp = a.j0_p + (long long)N * s;
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
     if constexpr (RT >= 8) spill(sR, r_s, p);   // (RT < 8: r stays in registers from one step to the next)
     store_af(r_s, N, p);
     __syncthreads();
+    B128_STAMP(0);
 
     // Register plan: a strip is 8 RT registers, the fragments RT more: three strips live at most (the series; t' = tt t with
     // r' waiting for its A-form store), two in the products that carry the source vectors -- r and W wait in the scratch while they are not an operand.
@@ -439,23 +445,28 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           }
           spill(sW, W, p);
         }
+        B128_STAMP(1);
         bstrip<RT> E;
         E.zero();
         mm128(E, r_s, p);                    // E = r r
         spill(sR, r_s, p);                   // (the addend of r' = r + tt W, its rider column scaled)
+        B128_STAMP(2);
         const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
         invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
       }
+      B128_STAMP(3);
       constexpr bool EARLY = RT < 8;
       bstrip<RT> W, t2;
       fill(t2, sT, p);
       __syncthreads();                       // [E] no longer read
       store_af(t2, N, p);
       __syncthreads();
+      B128_STAMP(4);
       {
         bstrip<RT> tt;
         tt.zero();
         mm128(tt, G, p);                     // tt = t G
+        B128_STAMP(5);
         if constexpr (EARLY) {               // (the operands of the [tt] phase: requested across the barriers)
           fill(r_s, sR, p);
           fill(W, sW, p);
@@ -464,6 +475,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         store_af(tt, N, p);
       }
       __syncthreads();
+      B128_STAMP(6);
       if constexpr (EARLY) {
         fill(t2, sT, p);
       } else {
@@ -484,9 +496,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           mm128(r_s, W, p);                  // r' = r + tt W      (riders: the new j0-, j0+)
         }
       }
+      B128_STAMP(7);
       if constexpr (!EARLY) fill(t2, sT, p);
       t_s.zero();
       mm128(t_s, t2, p);                     // t' = tt t
+      B128_STAMP(8);
       expk = expk * expk;
       if (n + 1 < ndoubl) {
         if (!MR && own_wave) {   // t_s[cb] = j0+', t_s[cb+1] = j1-' = j0-' expk'   (from the neighbour lane of r_s)
@@ -510,6 +524,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           }
         }
         __syncthreads();
+        B128_STAMP(9);
       }
     }
 
@@ -548,7 +563,9 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
       if (threadIdx.x == 0) expk_g[s] = expk;
     }
     __syncthreads();   // the next point overwrites the A-form and the reduction slots
+    B128_STAMP(10);
   }
+  B128_STAMP_FLUSH_AT(32, 63, npts);
 }
 
 template <int RT, bool MR>
@@ -972,9 +989,9 @@ int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const do
 
 #ifdef VSM_PHASE_TIMING
 extern "C" int vsm_debug_phase_cycles_128(unsigned long long* out_h, int reset) {
-  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_128), sizeof(unsigned long long) * 32);
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_phase_cycles_128), sizeof(unsigned long long) * 64);
   if (reset) {
-    unsigned long long z[32] = {0};
+    unsigned long long z[64] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_phase_cycles_128), z, sizeof(z));
   }
   return 0;
