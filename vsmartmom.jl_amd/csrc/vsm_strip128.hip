@@ -17,9 +17,10 @@
 //   * the strips that are not an operand of the running phase (r, t, W) wait in a per-workgroup global scratch (lane-linear,
 //     2 KB per instruction, L2 / MALL resident: 4 stores + 5 loads of 16 KB per wave and step against >= 6 x 32 RT MFMAs).
 // Workgroups are persistent (one per CU, 1 + RT waves at most: two waves per SIMD) and walk the spectral axis.
-// Source vectors ride in two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip:
-// N <= 126 leaves them room in at most 8 strips.  N = 127, 128 (eight full strips): each wave forms one more 16 x 16 tile per
-// product that carries vectors -- row tile w of [A] (x_0 | x_1), the vectors read from an LDS table (mm128r).
+// Source vectors: N <= 80 -- two spare columns cb, cb + 1 of the strips (cb = N rounded up to even), exactly as in vsm_strip.hip;
+// N > 80 -- each wave forms one more 16 x 16 tile per product that carries vectors: row tile w of [A] (x_0 | x_1), the vectors read
+// from an LDS table (mm128r).  That is the only way at N = 127, 128 (eight full strips) and measured 1 ... 5 % faster from N = 96 on
+// (no vector-only wave at N = 96 / 112, no rider lane code in the strips' registers); 3 % slower at five row tiles.
 //
 // A-form layout (verified conflict-free for both directions): block (ks, t) = the 16 x 4 fragment of row tile t and k-step ks,
 // 64 doubles; inside a block, element (m, k') of k-step ks sits at word
@@ -934,20 +935,22 @@ int cu_count() {
 }  // namespace
 
 bool strip128_supported(int N) { return N > 64 && N <= 128; }
+// Source vectors: rider columns of the strips for N <= 80 (five row tiles: +0 MFMAs, measured 3 % faster there), an extra MFMA
+// tile per wave beyond (no rider-only wave at N = 96 / 112, no rider lane code: +1 ... 5 % at N = 96 ... 126; the only way at 127, 128)
+static bool mr_policy(int N) { return N > 80; }
 
 int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st) {
   if (ndoubl == 0 || S <= 0) return VSM_OK;   // doubling.jl:50
-  const int RT = (N + 15) / 16, nw = N > 126 ? 8 : (((N + 1) & ~1) >> 4) + 1;
+  const bool mr = mr_policy(N);
+  const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
     case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 6: return launch_dbl128<6, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 7: return launch_dbl128<7, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 8:
-      if (N > 126) return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-      return launch_dbl128<8, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 6: return launch_dbl128<6, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 7: return launch_dbl128<7, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 8: return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
   }
   set_error("strip128_doubling: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
@@ -955,17 +958,16 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
 
 int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
-  const int RT = (N + 15) / 16, nw = N > 126 ? 8 : (((N + 1) & ~1) >> 4) + 1;
+  const bool mr = mr_policy(N);
+  const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
     case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, st);
-    case 6: return launch_ia128<6, false>(N, S, c, a, grid, nw, scr, st);
-    case 7: return launch_ia128<7, false>(N, S, c, a, grid, nw, scr, st);
-    case 8:
-      if (N > 126) return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, st);
-      return launch_ia128<8, false>(N, S, c, a, grid, nw, scr, st);
+    case 6: return launch_ia128<6, true>(N, S, c, a, grid, nw, scr, st);
+    case 7: return launch_ia128<7, true>(N, S, c, a, grid, nw, scr, st);
+    case 8: return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, st);
   }
   set_error("strip128_interaction11: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
