@@ -417,7 +417,8 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
     // r' waiting for its A-form store), two in the products that carry the source vectors -- r and W wait in the scratch while they are not an operand.
     for (int n = 0; n < ndoubl; ++n) {
       // on entry: [A] = [r]; t_s in registers; sR = r, sT = t (strips incl. their riders)
-      bstrip<RT> G;
+      constexpr bool KEEPW = RT <= 5;        // (five row tiles: a fourth strip fits beside the series' three -- W is not parked)
+      bstrip<RT> G, Wk;
       {
         {
           bstrip<RT> W;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
                 r_s.v[ta][r] *= fR;
               }
           }
-          spill(sW, W, p);
+          if constexpr (KEEPW) Wk = W; else spill(sW, W, p);
         }
         B128_STAMP(1);
         bstrip<RT> E;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         B128_STAMP(5);
         if constexpr (EARLY) {               // (the operands of the [tt] phase: requested across the barriers)
           fill(r_s, sR, p);
-          fill(W, sW, p);
+          if constexpr (KEEPW) W = Wk; else fill(W, sW, p);
         }
         __syncthreads();                     // [t] no longer read
         store_af(tt, N, p);
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         fill(t2, sT, p);
       } else {
         fill(r_s, sR, p);
-        fill(W, sW, p);
+        if constexpr (KEEPW) W = Wk; else fill(W, sW, p);
       }
       {
         if constexpr (MR) {
