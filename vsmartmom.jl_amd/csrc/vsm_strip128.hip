@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
     // r' waiting for its A-form store), two in the products that carry the source vectors -- r and W wait in the scratch while they are not an operand.
     for (int n = 0; n < ndoubl; ++n) {
       // on entry: [A] = [r]; t_s in registers; sR = r, sT = t (strips incl. their riders)
-      constexpr bool KEEPW = RT <= 5;        // (five row tiles: a fourth strip fits beside the series' three -- W is not parked)
+      constexpr bool KEEPW = RT <= 6;        // (five row tiles: a fourth strip fits beside the series' three -- W is not parked)
       bstrip<RT> G, Wk;
       {
         {
