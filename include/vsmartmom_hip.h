@@ -151,7 +151,8 @@ int vsm_elemental_doubling_f32(const vsm_quad_f32* q, int S, int m, int ndoubl,
                                long long z_stride, const vsm_added_f32* added, void* stream);
 
 /* The two halves separately (operator-for-operator with the reference; used for
- * N above vsm_fused_max_n and by the per-kernel parity tests). */
+ * N above vsm_fused_max_n and by the per-kernel parity tests).  vsm_doubling_f64 with 64 < N <= 128 is ONE launch for all
+ * ndoubl steps (k_dbl128); vsm_interaction_f64 (interface 11) likewise one launch (k_ia128). */
 int vsm_elemental_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau,
                       const double* varpi, const double* tau_sum, const double* F0,
                       const double* Zpp, const double* Zmp, long long z_stride,
@@ -450,8 +451,10 @@ int vsm_layer_expk_f32(int S, const float* dtau, float mu0, float* expk, void* s
 /* rt_kernel!(::noRS) for ONE scattering layer (src/CoreRT/CoreKernel/rt_kernel.jl:175-250): elemental! + doubling!
  * followed by copy_added_to_composite! (toa != 0, i.e. iz == 1; rt_helpers.jl:188-200) or
  * interaction!(::ScatteringInterface_11) (interaction.jl:207-266).  Arguments as vsm_elemental_doubling_*.
- * FP64 with 32 < N <= 60 runs as ONE launch whose added layer never leaves the chip (`added_scratch` is then not
- * touched and may be NULL); other shapes run the two launches through `added_scratch`. */
+ * FP64 with 32 < N <= 64 (and FP32 with 64 < N <= 96) runs as a pre-pass + ONE launch whose added layer never leaves the chip
+ * (`added_scratch` is then not touched and may be NULL); other shapes run elemental / doubling / interaction as separate
+ * launches through `added_scratch` -- FP64 with 64 < N <= 128: the whole doubling loop and the interaction of a point each in
+ * one persistent workgroup (vsm_strip128.hip). */
 int vsm_layer_forward_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                           const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
                           int toa, const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream);
