@@ -17,6 +17,21 @@
  *    the slowest, so one workgroup streams one point with fully coalesced reads.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
  *    are asynchronous w.r.t. the host, like the CUBLAS calls they replace.
+ *  - STREAM CONTRACT (every entry point that takes `stream`): all device work of
+ *    a call is enqueued on `stream` and nowhere else; calls on one stream execute
+ *    in call order; calls on DIFFERENT streams are independent and may be issued
+ *    concurrently from one or several host threads as long as the arrays they
+ *    write do not overlap.  Scratch the caller passes (`work`, `z_scratch`, ...)
+ *    belongs to the call's stream until the call's work has completed.  Scratch
+ *    the LIBRARY owns (the entry points marked "library scratch" below) is keyed
+ *    by (current device, stream): two streams never share it, an outgrown buffer
+ *    is freed only after the work queued on its stream has completed, and no
+ *    call synchronises the device.  vsm_release_scratch() returns it.
+ *  - DEVICE CONTRACT: a call runs on the device that is current in the calling
+ *    host thread (hipSetDevice) and `stream` must belong to that device.  One
+ *    process may drive several devices (one host thread per device or
+ *    hipSetDevice between calls): per-kernel launch attributes and the library
+ *    scratch are kept per device.  The library never calls hipSetDevice.
  *  - Return value: 0 = VSM_OK, otherwise a vsm_status; vsm_last_error() returns
  *    a thread-local message.  No C++ exception crosses this boundary.
  *  - Suffix _f64 / _f32 = the reference's `FT` (Float64 / Float32).
@@ -55,6 +70,9 @@ const char* vsm_last_error(void);      /* thread-local, never NULL */
 int vsm_device_count(int* count);      /* Architectures.jl:68-96 `_has_cuda`-style probe */
 int vsm_device_name(int device, char* buf, size_t buflen);
 int vsm_sync(void* stream);            /* Architectures.synchronize_if_gpu (Architectures.jl:96) */
+/* Frees the library-owned scratch of the CURRENT device (all streams) after a
+ * device synchronisation.  Optional: the scratch is grow-only and reused. */
+int vsm_release_scratch(void);
 /* Largest N the fused (LDS-resident) layer kernels accept for the element size
  * (8 = f64, 4 = f32); larger N use the operator-level kernels below. */
 int vsm_fused_max_n(int elem_size);
@@ -140,7 +158,8 @@ typedef struct vsm_quad_f32 {
  * decided by the host from the batch-global max(τϖ), exactly as the reference does),
  * varpi[S], tau_sum[S] (optical depth above the layer), F0[n_stokes,S].
  * Zpp/Zmp are Z⁺⁺/Z⁻⁺ [N,N,S] with slice stride z_stride (0 = one Z for all S).
- * Fills all six fields of `added`.  ndoubl == 0 reproduces the un-doubled branch. */
+ * Fills all six fields of `added`.  ndoubl == 0 reproduces the un-doubled branch.
+ * Stream: see Conventions; library scratch (doubling work of the operator-level path, N > vsm_fused_max_n). */
 int vsm_elemental_doubling_f64(const vsm_quad_f64* q, int S, int m, int ndoubl,
                                const double* dtau, const double* varpi, const double* tau_sum,
                                const double* F0, const double* Zpp, const double* Zmp,
@@ -152,7 +171,9 @@ int vsm_elemental_doubling_f32(const vsm_quad_f32* q, int S, int m, int ndoubl,
 
 /* The two halves separately (operator-for-operator with the reference; used for
  * N above vsm_fused_max_n and by the per-kernel parity tests).  vsm_doubling_f64 with 64 < N <= 128 is ONE launch for all
- * ndoubl steps (k_dbl128); vsm_interaction_f64 (interface 11) likewise one launch (k_ia128). */
+ * ndoubl steps (k_dbl128); vsm_interaction_f64 (interface 11) likewise one launch (k_ia128).
+ * Stream: see Conventions; vsm_doubling_f64 / vsm_interaction_f64 with 64 < N <= 128 park strips in library scratch (keyed by
+ * device and stream). */
 int vsm_elemental_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau,
                       const double* varpi, const double* tau_sum, const double* F0,
                       const double* Zpp, const double* Zmp, long long z_stride,
@@ -194,7 +215,8 @@ int vsm_copy_added_to_composite_f32(int N, int S, const vsm_added_f32* added,
 /* interaction! (src/CoreRT/CoreKernel/interaction.jl:52-285): composite (above) ⊕ added
  * (below) -> composite, in place, statement order as in the reference.
  * work = scratch of vsm_interaction_work_elems(N,S) elements (only used when
- * N > vsm_fused_max_n; may be NULL otherwise). */
+ * N > vsm_fused_max_n; may be NULL otherwise -- and NULL beyond the fused limit = library scratch).
+ * Stream: see Conventions. */
 size_t vsm_interaction_work_elems(int N, int S);
 int vsm_interaction_f64(int iface, int N, int S, const vsm_composite_f64* comp,
                         const vsm_added_f64* added, double* work, void* stream);
@@ -454,7 +476,8 @@ int vsm_layer_expk_f32(int S, const float* dtau, float mu0, float* expk, void* s
  * FP64 with 32 < N <= 64 (and FP32 with 64 < N <= 96) runs as a pre-pass + ONE launch whose added layer never leaves the chip
  * (`added_scratch` is then not touched and may be NULL); other shapes run elemental / doubling / interaction as separate
  * launches through `added_scratch` -- FP64 with 64 < N <= 128: the whole doubling loop and the interaction of a point each in
- * one persistent workgroup (vsm_strip128.hip). */
+ * one persistent workgroup (vsm_strip128.hip).
+ * Stream: see Conventions; library scratch (the pre-pass images of the layer; parked strips for 64 < N <= 128). */
 int vsm_layer_forward_f64(const vsm_quad_f64* q, int S, int m, int ndoubl, const double* dtau, const double* varpi,
                           const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
                           int toa, const vsm_composite_f64* comp, const vsm_added_f64* added_scratch, void* stream);
@@ -466,7 +489,8 @@ int vsm_layer_forward_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
  * independent until post-processing): m[nm] (host), Zpp[nm] / Zmp[nm] (host arrays of device pointers: the moment's Z block or
  * component stack), comps[nm] (host array: one CompositeLayer per moment); dtau, varpi, tau_sum, F0, fcomp, ndoubl are the
  * layer's and shared.  FP64 with 32 < N <= 60 runs the moments in ONE launch (three times the workgroups per launch: a third of
- * the launch tails); other shapes run vsm_layer_forward(_mix) moment by moment through `added_scratch` / `z_scratch`. */
+ * the launch tails); other shapes run vsm_layer_forward(_mix) moment by moment through `added_scratch` / `z_scratch`.
+ * Stream: see Conventions; library scratch as vsm_layer_forward_*. */
 int vsm_layer_forward_multi_f64(const vsm_quad_f64* q, int S, int nm, const int* m, int ndoubl, const double* dtau,
                                 const double* varpi, const double* tau_sum, const double* F0, int ncomp,
                                 const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,

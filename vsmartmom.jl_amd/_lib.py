@@ -83,6 +83,7 @@ _SIGS = {
     "vsm_device_count": (_I, [C.POINTER(_I)]),
     "vsm_device_name": (_I, [_I, C.c_char_p, _SZ]),
     "vsm_sync": (_I, [_P]),
+    "vsm_release_scratch": (_I, []),
     "vsm_fused_max_n": (_I, [_I]),
     "vsm_layer_thermal_fused": (_I, [_I, _I]),
     "vsm_doubling_work_elems": (_SZ, [_I, _I]),

@@ -1,5 +1,9 @@
 // extern "C" entry points of libvsmartmom_hip.so (see include/vsmartmom_hip.h).
+#include <map>
 #include <mutex>
+#include <set>
+#include <utility>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -32,29 +36,139 @@ int hip_launch_fail(hipError_t e, const char* kernel) {
   return hip_fail(e, kernel);
 }
 
-// grow-only scratch, one buffer per slot (single stream per device, like the reference's
-// single driving task; see SURVEY.md 8b "Threading").
-static std::mutex g_scratch_mu;
-static void* g_scratch_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
-static size_t g_scratch_sz[4] = {0, 0, 0, 0};
-void* scratch(size_t bytes, int slot) {
-  std::lock_guard<std::mutex> lk(g_scratch_mu);
-  if (bytes <= g_scratch_sz[slot]) return g_scratch_ptr[slot];
-  if (g_scratch_ptr[slot]) {
-    (void)hipDeviceSynchronize();
-    (void)hipFree(g_scratch_ptr[slot]);
-    g_scratch_ptr[slot] = nullptr;
-    g_scratch_sz[slot] = 0;
+// Library-owned scratch (vsm_internal.h).  One buffer per (device, stream, slot): a host that drives several streams (the
+// Fourier-moment lanes of the linearized run) or several devices from one process never shares a buffer between them.
+// A buffer is outgrown -> it goes on a retire list behind an event recorded on ITS stream and is freed by a later call once
+// that event has completed: nothing is freed under running work and no call synchronises the device.
+namespace {
+struct scratch_key {
+  int dev;
+  hipStream_t st;
+  int slot;
+  bool operator<(const scratch_key& o) const {
+    if (dev != o.dev) return dev < o.dev;
+    if (st != o.st) return st < o.st;
+    return slot < o.slot;
   }
+};
+struct scratch_buf {
+  void* ptr = nullptr;
+  size_t sz = 0;
+};
+struct retired_buf {
+  int dev;
+  void* ptr;
+  hipEvent_t ev;
+};
+std::mutex g_scratch_mu;
+std::map<scratch_key, scratch_buf> g_scratch;
+std::vector<retired_buf> g_retired;
+
+// frees the retired buffers of device `dev` whose event has completed (caller holds the mutex, `dev` is current)
+void reap_retired(int dev, bool wait) {
+  for (size_t i = 0; i < g_retired.size();) {
+    retired_buf& r = g_retired[i];
+    if (r.dev == dev && (wait ? hipEventSynchronize(r.ev) == hipSuccess : hipEventQuery(r.ev) == hipSuccess)) {
+      (void)hipEventDestroy(r.ev);
+      (void)hipFree(r.ptr);
+      g_retired[i] = g_retired.back();
+      g_retired.pop_back();
+    } else {
+      ++i;
+    }
+  }
+}
+}  // namespace
+
+void* scratch(size_t bytes, int slot, hipStream_t st) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipGetDevice(scratch)");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  scratch_buf& b = g_scratch[scratch_key{dev, st, slot}];
+  if (bytes <= b.sz) return b.ptr;
+  if (!g_retired.empty()) reap_retired(dev, false);
+  // geometric growth bounds the retired bytes by the live ones
+  size_t want = bytes;
+  if (b.sz && want < b.sz + b.sz / 2) want = b.sz + b.sz / 2;
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, bytes);
+  e = hipMalloc(&p, want);
+  if (e != hipSuccess && want > bytes) {
+    (void)hipGetLastError();
+    want = bytes;
+    e = hipMalloc(&p, want);
+  }
   if (e != hipSuccess) {
     hip_fail(e, "hipMalloc(scratch)");
     return nullptr;
   }
-  g_scratch_ptr[slot] = p;
-  g_scratch_sz[slot] = bytes;
+  if (b.ptr) {   // work already queued on `st` may still use the old buffer: retire it behind an event on that stream
+    hipEvent_t ev = nullptr;
+    e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(ev, st);
+    if (e != hipSuccess) {
+      if (ev) (void)hipEventDestroy(ev);
+      (void)hipFree(p);
+      hip_fail(e, "hipEventRecord(scratch retire)");
+      return nullptr;
+    }
+    g_retired.push_back(retired_buf{dev, b.ptr, ev});
+  }
+  b.ptr = p;
+  b.sz = want;
   return p;
+}
+
+int release_scratch() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice(release_scratch)");
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return hip_fail(e, "hipDeviceSynchronize(release_scratch)");
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  reap_retired(dev, true);
+  for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+    if (it->first.dev == dev) {
+      if (it->second.ptr) (void)hipFree(it->second.ptr);
+      it = g_scratch.erase(it);
+    } else {
+      ++it;
+    }
+  }
+  return VSM_OK;
+}
+
+namespace {
+std::mutex g_attr_mu;
+std::set<std::pair<int, const void*>> g_attr_done;
+std::mutex g_cu_mu;
+std::map<int, int> g_cu;
+}  // namespace
+
+int ensure_dyn_lds(const void* kern, size_t bytes, const char* what) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice(ensure_dyn_lds)");
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  const std::pair<int, const void*> key(dev, kern);
+  if (g_attr_done.count(key)) return VSM_OK;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return hip_fail(e, what);
+  g_attr_done.insert(key);
+  return VSM_OK;
+}
+
+int cu_count() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(g_cu_mu);
+  auto it = g_cu.find(dev);
+  if (it != g_cu.end()) return it->second;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  g_cu[dev] = v;
+  return v;
 }
 
 template <typename T, typename Q>
@@ -135,7 +249,7 @@ static int elemental_doubling_impl(const Q* q, int S, int m, int ndoubl, const T
   if ((rc = elemental<T>(qq, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, aa, st))) return rc;
   if (ndoubl == 0) return VSM_OK;
   const size_t we = vsm_doubling_work_elems(q->N, S);
-  T* work = static_cast<T*>(scratch(we * sizeof(T) + (size_t)S * sizeof(T), 0));
+  T* work = static_cast<T*>(scratch(we * sizeof(T) + (size_t)S * sizeof(T), 0, st));
   if (!work) return VSM_ERR_HIP;
   T* expk = work + we;
   // expk = exp(-dtau/mu0)  (rt_kernel.jl:339-349 init_layer)
@@ -159,7 +273,7 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
       return strip128_interaction11(N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
   }
   if (!work) {
-    work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1));
+    work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1, st));
     if (!work) return VSM_ERR_HIP;
   }
   return interaction_generic<T>(iface, N, S, cvt_comp<T>(c), cvt_added<T>(a), work, st);
@@ -190,7 +304,7 @@ static int layer_forward_impl(const Q* q, int S, int m, int ndoubl, const T* dta
   if (ncomp > 0) {  // materialise Z[N,N,S] for the kernels that do not mix on the fly
     const long long per = (long long)q->N * q->N * S;
     if (!z_scratch) {
-      z_scratch = static_cast<T*>(scratch((size_t)(2 * per) * sizeof(T), 2));
+      z_scratch = static_cast<T*>(scratch((size_t)(2 * per) * sizeof(T), 2, st));
       if (!z_scratch) return VSM_ERR_HIP;
     }
     if ((rc = mix_Z<T>(q->N, S, ncomp, Zpp, Zmp, fcomp, z_scratch, z_scratch + per, st))) return rc;
@@ -274,6 +388,7 @@ using namespace vsm;
 extern "C" {
 
 int vsm_version(void) { return 100; /* 0.1.0 */ }
+int vsm_release_scratch(void) { return release_scratch(); }
 const char* vsm_last_error(void) { return g_err; }
 int vsm_device_count(int* count) {
   VSM_REQUIRE(count != nullptr, "device_count: null");
@@ -573,11 +688,7 @@ __global__ __launch_bounds__(256) void k_poison_lds(int n64) {
 }  // namespace
 int vsm_test_poison_lds(void* stream) {
   const int bytes = 160 * 1024;
-  static int prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_poison_lds),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_poison_lds)");
-  }();
+  const int prepared = vsm::ensure_dyn_lds(reinterpret_cast<const void*>(k_poison_lds), 160 * 1024, "hipFuncSetAttribute(k_poison_lds)");
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_poison_lds, dim3(1024), dim3(256), bytes, as_stream(stream), bytes / 8);
   VSM_LAUNCH_CHECK("k_poison_lds");

@@ -1553,11 +1553,8 @@ template int fused_max_n<float>();
 #endif
 
 template <typename K>
-static int enable_lds(K kern, size_t bytes) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)bytes);
-  if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-  return VSM_OK;
+static int enable_lds(K kern, size_t bytes) {   // once per (device, kernel)
+  return ensure_dyn_lds(reinterpret_cast<const void*>(kern), bytes, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
 }
 
 // NP = N rounded up to 32; f64 fits up to 64, f32 up to 96 (4 N x N buffers in 160 KB of LDS).
@@ -1591,7 +1588,7 @@ int fused_elemental_doubling(const quad<T>& q, int S, int m, int ndoubl, const T
     constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_elemental_doubling<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, q, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp,
                        zs, a);
@@ -1619,7 +1616,7 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     constexpr int NW = (NP == 64) ? IA_WAVES_64 : (NP == 96) ? IA_WAVES_96 : 4;
     auto kern = k_interaction11<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, c, a);
     VSM_LAUNCH_CHECK("k_interaction11");
@@ -1635,7 +1632,7 @@ int test_lds_mm(int N, int S, const T* A, const T* B, T* Cout, hipStream_t st) {
     constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_test_mm<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, B, Cout);
     VSM_LAUNCH_CHECK("k_test_mm");
@@ -1651,7 +1648,7 @@ int test_lds_inv(int N, int S, const T* A, T* X, int mode, int* path_out, hipStr
     constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_test_inv<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, X, mode, path_out);
     VSM_LAUNCH_CHECK("k_test_inv");
@@ -1669,7 +1666,7 @@ int inv_one_minus_product(int N, int S, const T* A, long long sa, const T* B, lo
     constexpr int NW = (NP == 64) ? ED_WAVES_64 : (NP == 96) ? ED_WAVES_96 : 4;
     auto kern = k_inv_one_minus_ab<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, A, sa, B, sb, X);
     VSM_LAUNCH_CHECK("k_inv_one_minus_ab");
@@ -1689,7 +1686,7 @@ int raman_elastic_pre(int N, int S, const T* r, const T* t, const T* j0p, const 
     constexpr int NW = 4;
     auto kern = k_raman_elastic_pre<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, r, t, j0p, j0m, expk, ttg, gt, gr, grt, j1p, j1m,
                        u, u2, tmp1, tmp2);
@@ -1708,7 +1705,7 @@ int raman_elastic_post(int N, int S, T* r, T* t, const T* ttg, const T* u, const
     constexpr int NW = 4;
     auto kern = k_raman_elastic_post<T, NP, NW>;
     const size_t bytes = sizeof(fsmem<T, NP, NW>);
-    static int prepared = enable_lds(kern, bytes);
+    const int prepared = enable_lds(kern, bytes);
     if (prepared) return prepared;
     hipLaunchKernelGGL(kern, dim3(S), dim3(fcfg<NP, NW>::NT), bytes, st, N, r, t, ttg, u, u2, j1p, j0p, j0m, expk);
     VSM_LAUNCH_CHECK("k_raman_elastic_post");
@@ -1725,7 +1722,7 @@ int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, cons
   if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
   auto kern = k_raman_doubling_lines<T>;
   const size_t bytes = sizeof(rdsmem<T>);
-  static int prepared = enable_lds(kern, bytes);
+  const int prepared = enable_lds(kern, bytes);
   if (prepared) return prepared;
   hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier,
                      iet, ieJp, ieJm);
@@ -1740,7 +1737,7 @@ int raman_interaction_lines(int N, int S, int K, const int* shift, const rs_ia_p
   if (N > 30 || off) return VSM_ERR_UNSUPPORTED;
   auto kern = k_raman_interaction_lines<T>;
   const size_t bytes = sizeof(rdsmem<T>);
-  static int prepared = enable_lds(kern, bytes);
+  const int prepared = enable_lds(kern, bytes);
   if (prepared) return prepared;
   hipLaunchKernelGGL(kern, dim3(S), dim3(256), bytes, st, N, S, K, shift, h);
   VSM_LAUNCH_CHECK("k_raman_interaction_lines");

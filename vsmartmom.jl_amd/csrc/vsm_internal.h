@@ -266,7 +266,15 @@ bool strip128_supported(int N);
 int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st);
 int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 
-// grow-only device scratch (one per element type); not for concurrent streams.
-void* scratch(size_t bytes, int slot);
+// Library-owned device scratch, keyed by (current device, stream, slot): two streams -- or two devices driven from one
+// process -- never share a buffer, so the entry points that use it keep the contract "calls on one stream are ordered, calls on
+// different streams are independent".  Grow-only per key; a buffer that is outgrown is retired behind an event recorded on
+// its stream and freed only once that event has completed (never under running work).  nullptr + error set on failure.
+void* scratch(size_t bytes, int slot, hipStream_t st);
+int release_scratch();   // current device: synchronise, free every scratch buffer
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: raise it once per (device, kernel).
+int ensure_dyn_lds(const void* kern, size_t bytes, const char* what);
+// compute units of the CURRENT device (cached per device)
+int cu_count();
 
 }  // namespace vsm

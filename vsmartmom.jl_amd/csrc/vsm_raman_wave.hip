@@ -1069,23 +1069,8 @@ int launch_rw(int S, int K, const int* shift, const double* r, const double* t, 
   if constexpr (N <= RW_MAXN_SP) {
     if (!plain) kern = last ? (kern_t)k_raman_doubling_wave_sp<N, true> : (kern_t)k_raman_doubling_wave_sp<N, false>;
   }
-  static hipError_t prepared = [] {
-    const kern_t all[4] = {k_raman_doubling_wave<N, false>, k_raman_doubling_wave<N, true>, nullptr, nullptr};
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(all[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)RW_LDS_BYTES);
-    if constexpr (N <= RW_MAXN_SP) {
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_raman_doubling_wave_sp<N, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
-    }
-    return e;
-  }();
-  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), RW_LDS_BYTES, "hipFuncSetAttribute(k_raman_doubling_wave)"))
+    return prepared;   // once per (device, kernel)
   hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1,
                      tmp2, expk, ier, iet, ieJp, ieJm, ns, ier_pm, iet_mm);
   VSM_LAUNCH_CHECK("k_raman_doubling_wave");
@@ -1094,9 +1079,8 @@ int launch_rw(int S, int K, const int* shift, const double* r, const double* t, 
 template <int N>
 int launch_rw_ia(int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
   auto kern = k_raman_interaction_wave<N>;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RW_LDS_BYTES);
-  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), RW_LDS_BYTES, "hipFuncSetAttribute(k_raman_interaction_wave)"))
+    return prepared;
   hipLaunchKernelGGL(kern, dim3(S), dim3(64 * RW_WAVES), RW_LDS_BYTES, st, S, K, shift, h);
   VSM_LAUNCH_CHECK("k_raman_interaction_wave");
   return VSM_OK;

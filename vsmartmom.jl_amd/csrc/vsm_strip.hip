@@ -785,15 +785,13 @@ __global__ __launch_bounds__(SNT, 4) void k_gemm_strip(int M, int Nc, int K, con
 VSM_STRIP_DECL(VSM_STRIP_KS)
 template <typename K>
 static int strip_enable_lds(K kern, const char* what) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)sizeof(ssmem));
-  return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
+  return ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(ssmem), what);   // once per (device, kernel)
 }
 int VSM_CAT(launch_ed_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m, int ndoubl, const double* dtau,
                                             const double* varpi, const double* tau_sum, const double* F0,
                                             const zsrc<double>& z, const added<double>& a, hipStream_t st) {
 #if VSM_STRIP_KS < 16
-  static int prepared = strip_enable_lds(k_ed_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ed_strip)");
+  const int prepared = strip_enable_lds(k_ed_strip<VSM_STRIP_KS>, "hipFuncSetAttribute(k_ed_strip)");
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_ed_strip<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(ssmem), st, q, m, ndoubl, dtau, varpi, tau_sum, F0, z,
                      a);
@@ -804,8 +802,8 @@ int VSM_CAT(launch_ed_strip_, VSM_STRIP_KS)(const quad<double>& q, int S, int m,
 #endif
 }
 int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
-  static int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_ia_strip)");
-  static int prepared_g = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_ia_strip general)");
+  const int prepared = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, true>, "hipFuncSetAttribute(k_ia_strip)");
+  const int prepared_g = strip_enable_lds(k_ia_strip<VSM_STRIP_KS, false>, "hipFuncSetAttribute(k_ia_strip general)");
   if (prepared) return prepared;
   if (prepared_g) return prepared_g;
   if (a.d_symmetric)   // (d_symmetric carries n_stokes)
@@ -817,7 +815,7 @@ int VSM_CAT(launch_ia_strip_, VSM_STRIP_KS)(int N, int S, const composite<double
 }
 int VSM_CAT(launch_layer_strip_mm_, VSM_STRIP_KS)(const quad<double>& q, int S, int nm, int ndoubl,
                                                   const layer_mm_args<double>& a, int toa, const double* pre, hipStream_t st) {
-  static int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS>, "hipFuncSetAttribute(k_layer_strip_mm)");
+  const int prepared = strip_enable_lds(k_layer_strip_mm<VSM_STRIP_KS>, "hipFuncSetAttribute(k_layer_strip_mm)");
   if (prepared) return prepared;
   layer_mm_comps cc;
   for (int i = 0; i < VSM_MM_MAX; ++i) cc.c[i] = a.c[i];
@@ -999,7 +997,7 @@ static int strip_layer_forward_pre(const quad<double>& q, int S, int nm, int ndo
     set_error("strip_layer_forward_mm: N=%d outside (32, 64]", q.N);
     return VSM_ERR_UNSUPPORTED;
   }
-  double* pre = static_cast<double*>(scratch((size_t)nm * S * PRE_STRIDE * sizeof(double), 3));
+  double* pre = static_cast<double*>(scratch((size_t)nm * S * PRE_STRIDE * sizeof(double), 3, st));
   if (!pre) return VSM_ERR_HIP;
   const dim3 grid(S, nm), block(SNT);
   if (thermal) {   // F0 = B[S]; tau_sum is not read

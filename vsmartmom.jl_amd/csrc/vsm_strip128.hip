@@ -574,9 +574,7 @@ template <int RT, bool MR>
 int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
                   hipStream_t st) {
   constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 6 * 16 * RT * sizeof(double) : 0);
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl128<RT, MR>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_dbl128)");
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128<RT, MR>), lds, "hipFuncSetAttribute(k_dbl128)")) return prepared;
   hipLaunchKernelGGL((k_dbl128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr);
   VSM_LAUNCH_CHECK("k_dbl128");
   return VSM_OK;
@@ -878,9 +876,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 template <int RT, bool MR>
 int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, hipStream_t st) {
   constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia128<RT, MR>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_ia128)");
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128<RT, MR>), lds, "hipFuncSetAttribute(k_ia128)")) return prepared;
   hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr);
   VSM_LAUNCH_CHECK("k_ia128");
   return VSM_OK;
@@ -915,23 +911,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_inv1m128(int N, int S, const do
 template <int RT>
 int launch_inv1m128(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, int grid, hipStream_t st) {
   constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 256;
-  static hipError_t prepared = hipFuncSetAttribute(reinterpret_cast<const void*>(k_inv1m128<RT>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (prepared != hipSuccess) return hip_fail(prepared, "hipFuncSetAttribute(k_inv1m128)");
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_inv1m128<RT>), lds, "hipFuncSetAttribute(k_inv1m128)")) return prepared;
   hipLaunchKernelGGL(k_inv1m128<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, A, sa, B, sb, X);
   VSM_LAUNCH_CHECK("k_inv1m128");
   return VSM_OK;
 }
 
-int cu_count() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-    return v;
-  }();
-  return n;
-}
 
 }  // namespace
 
@@ -945,7 +930,7 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
   const bool mr = mr_policy(N);
   const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
-  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
     case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
@@ -962,7 +947,7 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
   const bool mr = mr_policy(N);
   const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
   const int grid = S < cu_count() ? S : cu_count();
-  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3));
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   if (!scr) return VSM_ERR_HIP;
   switch (RT) {
     case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, st);

@@ -1099,9 +1099,7 @@ __global__ __launch_bounds__(FNT) void k_elemental_img32(quad<float> q, int ndou
 
 template <typename K>
 static int enable_lds32(K kern, const char* what) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(2 * sizeof(fsmem32)));
-  return e == hipSuccess ? (int)VSM_OK : hip_fail(e, what);
+  return ensure_dyn_lds(reinterpret_cast<const void*>(kern), 2 * sizeof(fsmem32), what);   // once per (device, kernel)
 }
 
 // (the thermal slot only: a solar layer step goes through the pre-pass pair, strip32_layer_forward)
@@ -1113,8 +1111,8 @@ static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const 
     set_error("launch_layer32: the solar layer step is the pre-pass pair");
     return VSM_ERR_UNSUPPORTED;
   }
-  static int prepared_th = enable_lds32(k_layer_strip32<KB, false, AL, true>, "hipFuncSetAttribute(k_layer_strip32 th)");
-  static int prepared_thm = enable_lds32(k_layer_strip32<KB, true, AL, true>, "hipFuncSetAttribute(k_layer_strip32 thm)");
+  const int prepared_th = enable_lds32(k_layer_strip32<KB, false, AL, true>, "hipFuncSetAttribute(k_layer_strip32 th)");
+  const int prepared_thm = enable_lds32(k_layer_strip32<KB, true, AL, true>, "hipFuncSetAttribute(k_layer_strip32 thm)");
   if (prepared_th) return prepared_th;
   if (prepared_thm) return prepared_thm;
   const dim3 grid((S + 1) / 2), block(2 * FNT);
@@ -1131,9 +1129,9 @@ static int launch_layer32(const quad<float>& q, int S, int m, int ndoubl, const 
 template <int KB, bool AL>
 static int launch_layer32_mm(const quad<float>& q, int S, int nm, int ndoubl, const float* dtau, const float* varpi,
                              const float* tau_sum, const float* F0, const layer_mm_args<float>& a, int toa, hipStream_t st) {
-  static int prepared = enable_lds32(k_layer_strip32_mm<KB, AL>, "hipFuncSetAttribute(k_layer_strip32_mm)");
+  const int prepared = enable_lds32(k_layer_strip32_mm<KB, AL>, "hipFuncSetAttribute(k_layer_strip32_mm)");
   if (prepared) return prepared;
-  float* pre = static_cast<float*>(scratch((size_t)nm * S * PRE32_STRIDE * sizeof(float), 3));
+  float* pre = static_cast<float*>(scratch((size_t)nm * S * PRE32_STRIDE * sizeof(float), 3, st));
   if (!pre) return VSM_ERR_HIP;
   if (a.z[0].ncomp > 0)
     hipLaunchKernelGGL((k_elemental_img32<true>), dim3(S, nm), dim3(FNT), 0, st, q, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
@@ -1149,7 +1147,7 @@ static int launch_layer32_mm(const quad<float>& q, int S, int nm, int ndoubl, co
 }
 template <int KB, bool AL>
 static int launch_ia32(int N, int S, const composite<float>& c, const added<float>& a, hipStream_t st) {
-  static int prepared = enable_lds32(k_ia_strip32<KB, AL>, "hipFuncSetAttribute(k_ia_strip32)");
+  const int prepared = enable_lds32(k_ia_strip32<KB, AL>, "hipFuncSetAttribute(k_ia_strip32)");
   if (prepared) return prepared;
   hipLaunchKernelGGL((k_ia_strip32<KB, AL>), dim3((S + 1) / 2), dim3(2 * FNT), 2 * sizeof(fsmem32), st, N, S, c, a);
   VSM_LAUNCH_CHECK("k_ia_strip32");

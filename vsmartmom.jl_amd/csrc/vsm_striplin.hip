@@ -876,11 +876,7 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
 VSM_STRIPLIN_DECL(VSM_STRIP_KS)
 int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                                                 const added_lin<double>& al, hipStream_t st) {
-  static int prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_step<VSM_STRIP_KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_dbl_lin_step)");
-  }();
+  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl_lin_step<VSM_STRIP_KS>), sizeof(lsmem), "hipFuncSetAttribute(k_dbl_lin_step)");
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_dbl_lin_step<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_step");
@@ -889,17 +885,9 @@ int VSM_CAT(launch_dbl_lin_step_, VSM_STRIP_KS)(int N, int S, int P, double* exp
 
 int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                                                  const added_lin<double>& al, hipStream_t st) {
-  static int prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 3>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_dbl_lin_multi)");
-  }();
+  int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 1>), sizeof(lsmem), "hipFuncSetAttribute(k_dbl_lin_multi)");
+  if (!prepared) prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 2>), sizeof(lsmem), "hipFuncSetAttribute(k_dbl_lin_multi)");
+  if (!prepared) prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl_lin_multi<VSM_STRIP_KS, 3>), sizeof(lsmem), "hipFuncSetAttribute(k_dbl_lin_multi)");
   if (prepared) return prepared;
   if (PA == 1)
     hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 1>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, ns, expk, ekl, a, al);
@@ -912,11 +900,7 @@ int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, i
 }
 
 int VSM_CAT(launch_ia_lin_half_, VSM_STRIP_KS)(int N, int S, int P, const ia_half& h, hipStream_t st) {
-  static int prepared = [] {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ia_lin_half<VSM_STRIP_KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(lsmem));
-    return e == hipSuccess ? (int)VSM_OK : hip_fail(e, "hipFuncSetAttribute(k_ia_lin_half)");
-  }();
+  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia_lin_half<VSM_STRIP_KS>), sizeof(lsmem), "hipFuncSetAttribute(k_ia_lin_half)");
   if (prepared) return prepared;
   hipLaunchKernelGGL(k_ia_lin_half<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, h);
   VSM_LAUNCH_CHECK("k_ia_lin_half");
