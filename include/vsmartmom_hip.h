@@ -70,6 +70,16 @@ const char* vsm_last_error(void);      /* thread-local, never NULL */
 int vsm_device_count(int* count);      /* Architectures.jl:68-96 `_has_cuda`-style probe */
 int vsm_device_name(int device, char* buf, size_t buflen);
 int vsm_sync(void* stream);            /* Architectures.synchronize_if_gpu (Architectures.jl:96) */
+/* Device-side status of kernels that invert inside an asynchronous launch and therefore cannot return `info` the way
+ * vsm_batch_inv does (the reference's LU raises SingularException on the host, cpu_batched.jl:32-47).  flags_h[0] = OR of the
+ * vsm_devstat bits raised on the CURRENT device since the last reset; flags_h[1] = number of pivoted (Gauss-Jordan) inverses the
+ * 64 < N <= 128 kernels ran (k_dbl128 / k_ia128 / k_inv1m128: every inverse whose norm bound gives no series order);
+ * flags_h[2] / flags_h[3] = spectral points k_dbl128 / k_ia128 processed (which kernel family a run landed on).  SYNCHRONOUS: waits for `stream` before it reads.  reset != 0 clears the words afterwards. */
+typedef enum vsm_devstat {
+  VSM_DEVSTAT_SINGULAR = 1,    /* an exactly zero pivot: (I - R r) or (I - r r) is singular; the results of that point are not finite */
+  VSM_DEVSTAT_NONFINITE = 2    /* an operand of an in-kernel inverse was NaN / Inf */
+} vsm_devstat;
+int vsm_device_status(int* flags_h, int reset, void* stream);
 /* Frees the library-owned scratch of the CURRENT device (all streams) after a
  * device synchronisation.  Optional: the scratch is grow-only and reused. */
 int vsm_release_scratch(void);

@@ -502,8 +502,8 @@ def test_interaction_shared_surface_block(vsm, arch, FT, N):
 def test_strong_reflection_needs_gauss_jordan(vsm, arch, FT, N):
     """Bright surface under a thick conservative atmosphere: ||r R|| ~ 0.7, the series path must not be taken
     and the pivoted Gauss-Jordan must agree with LAPACK (FP64 strip kernel; FP32 strip kernels, whose Gauss-Jordan
-    scratch lives in the padding of the LDS matrix it inverts).  FP64 64 < N <= 126 (k_ia128): no pivoting kernel there --
-    the inverse is built by squaring levels until the power of R+- r-+ vanishes, and must agree with LAPACK as well."""
+    scratch lives in the padding of the LDS matrix it inverts; FP64 64 < N <= 128, k_ia128: the register-resident Gauss-Jordan
+    of vsm_inverse.h through the A-form's LDS, out of line)."""
     rng = np.random.default_rng(2)
     S = 3
     comp, add = _random_layers(rng, N, S, FT, None)
@@ -515,6 +515,75 @@ def test_strong_reflection_needs_gauss_jordan(vsm, arch, FT, N):
     got = _comp_to_host(vsm, pc)
     for k, v in got.items():
         assert _rel(v, getattr(comp, k)) < (1e-10 if FT == np.float64 else 5e-5), k
+
+
+def _device_status(vsm, reset=True):
+    import ctypes as C
+    flags = (C.c_int * 4)()
+    assert vsm._lib.lib().vsm_device_status(flags, 1 if reset else 0, None) == 0
+    return list(flags)
+
+
+@pytest.mark.parametrize("N", [72, 112, 128])
+@pytest.mark.parametrize("rho", [0.9, 0.97, 0.995, 1.0 - 1e-9, 1.7])
+def test_strip128_pivoted_inverse_near_and_beyond_unit_spectral_radius(vsm, arch, N, rho):
+    """interaction!(_11) at 64 < N <= 128 with the spectral radius of R+- r-+ at `rho` (positive matrices: rho = the Perron
+    root, fixed by scaling): the reference inverts by LU whatever rho is (cpu_batched.jl:32-47) -- so must the kernel: no
+    level-by-level series whose cost grows as rho -> 1 and which fails beyond (the round-3 kernel).  Compared with LAPACK
+    through the oracle; vsm_device_status counts one pivoted inverse per point and raises no flag."""
+    FT = np.float64
+    rng = np.random.default_rng(N)
+    S = 3
+    comp, add = _random_layers(rng, N, S, FT, None)
+    comp.R_pm[...] = rng.random((S, N, N)) / N
+    add.r_mp[...] = rng.random((S, N, N)) / N
+    for s_ in range(S):   # scale so that rho(R+- r-+) = rho exactly (up to rounding)
+        ev = np.max(np.abs(np.linalg.eigvals(comp.R_pm[s_] @ add.r_mp[s_])))
+        comp.R_pm[s_] *= np.sqrt(rho / ev)
+        add.r_mp[s_] *= np.sqrt(rho / ev)
+    pc, pa = _upload_layers(vsm, arch, comp, add, FT)
+    cond = max(np.linalg.cond(np.eye(N) - comp.R_pm[s_] @ add.r_mp[s_]) for s_ in range(S))
+    O.interaction("11", comp, add, FT)
+    _device_status(vsm)
+    vsm.CoreRT.interaction_("11", pc, pa)
+    st = _device_status(vsm)
+    assert st[0] == 0 and st[1] == S, st
+    got = _comp_to_host(vsm, pc)
+    tol = max(1e-10, 50 * cond * np.finfo(FT).eps)   # both sides solve the same ill-conditioned system
+    for k, v in got.items():
+        assert _rel(v, getattr(comp, k)) < tol, (k, cond)
+
+
+@pytest.mark.parametrize("N", [80, 128])
+def test_strip128_inverse_flags_singular_and_nonfinite(vsm, arch, N):
+    """An exactly singular I - R+- r-+ (the reference's LU raises SingularException) and a NaN operand raise the device flags
+    of vsm_device_status; a following well-posed call is not affected."""
+    FT = np.float64
+    rng = np.random.default_rng(1)
+    S = 2
+    comp, add = _random_layers(rng, N, S, FT, None)
+    comp.R_pm[...] = 0.0
+    add.r_mp[...] = 0.0
+    comp.R_pm[:, 0, 0] = 1.0
+    add.r_mp[:, 0, 0] = 1.0          # (I - R r)[0, 0] = 0, row and column 0 otherwise zero: singular; ||E||_F = 1 >= 0.3
+    pc, pa = _upload_layers(vsm, arch, comp, add, FT)
+    _device_status(vsm)
+    vsm.CoreRT.interaction_("11", pc, pa)
+    st = _device_status(vsm)
+    assert st[0] & 1 and st[1] == S, st
+    comp, add = _random_layers(rng, N, S, FT, None)
+    comp.R_pm[1, 3, 5] = np.nan
+    pc, pa = _upload_layers(vsm, arch, comp, add, FT)
+    vsm.CoreRT.interaction_("11", pc, pa)
+    st = _device_status(vsm)
+    assert st[0] & 2, st
+    comp, add = _random_layers(rng, N, S, FT, None)
+    pc, pa = _upload_layers(vsm, arch, comp, add, FT)
+    O.interaction("11", comp, add, FT)
+    vsm.CoreRT.interaction_("11", pc, pa)
+    assert _device_status(vsm)[0] == 0
+    for k, v in _comp_to_host(vsm, pc).items():
+        assert _rel(v, getattr(comp, k)) < 1e-11, k
 
 
 # ---------------------------------------------------------------------------
@@ -537,7 +606,7 @@ def _load(golden_dir, name):
 
 
 def test_rt_run_natraj(vsm, arch, golden_dir):
-    """test/test_CoreRT.jl:110-157 on the GPU (N = 108: operator-level path)."""
+    """test/test_CoreRT.jl:110-157 on the GPU (N = 108: k_dbl128 / k_ia128, vsm_strip128.hip)."""
     fx = _load(golden_dir, "natraj2009.json")
     p = fx["procedure"]
     vza = [np.degrees(np.arccos(x)) for x in p["mu_view"]]
@@ -546,7 +615,10 @@ def test_rt_run_natraj(vsm, arch, golden_dir):
     for k, az in list(enumerate(p["azimuths_deg"]))[::3]:
         om, pm = _both_models(vsm, arch, "IQUV", 21, sza, vza, [az] * 16, tau_rayl=[[0.5]], depol=0.0, albedo=0.0, m_max=2)
         Ro, To = O.rt_run(om)
+        _device_status(vsm)
         Rg, Tg = vsm.CoreRT.rt_run(pm)
+        st = _device_status(vsm)
+        assert pm.quad_points.Nquad * 4 == 108 and st[0] == 0 and st[2] > 0 and st[3] > 0, st   # the k_dbl128 / k_ia128 family ran
         assert _rel(Rg, Ro) < 1e-8 and _rel(Tg, To) < 1e-8
         assert np.max(np.abs(It[:, k] - np.pi * Rg[:, 0, 0]) / It[:, k]) < p["rtol"]["I"]
 
@@ -596,7 +668,10 @@ def test_rt_run_siewert(vsm, arch, golden_dir):
     om, pm = _both_models(vsm, arch, "IQUV", p["l_trunc"], p["sza_deg"], vza, [az] * len(vza), tau_rayl=[[0.0]],
                           tau_aer=[[1.0]], aerosols=[ao], albedo=0.0, m_max=11)
     Ro, _ = O.rt_run(om)
+    _device_status(vsm)
     Rg, _ = vsm.CoreRT.rt_run(pm)
+    st = _device_status(vsm)
+    assert pm.quad_points.Nquad * 4 == 112 and st[0] == 0 and st[2] > 0 and st[3] > 0, st   # the k_dbl128 / k_ia128 family ran
     assert _rel(Rg, Ro) < 1e-8
     cos_tab = np.array(fx["table_cosines"])
     for si, s in enumerate("IQUV"):

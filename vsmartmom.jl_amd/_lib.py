@@ -84,6 +84,7 @@ _SIGS = {
     "vsm_device_name": (_I, [_I, C.c_char_p, _SZ]),
     "vsm_sync": (_I, [_P]),
     "vsm_release_scratch": (_I, []),
+    "vsm_device_status": (_I, [C.POINTER(_I), _I, _P]),
     "vsm_fused_max_n": (_I, [_I]),
     "vsm_layer_thermal_fused": (_I, [_I, _I]),
     "vsm_doubling_work_elems": (_SZ, [_I, _I]),
@@ -187,6 +188,18 @@ def poison(t):
 def check(rc):
     if rc != 0:
         raise VSMError("libvsmartmom_hip: status %d: %s" % (rc, lib().vsm_last_error().decode()))
+
+
+def check_device_status(what="rt_run"):
+    """The in-kernel inverses cannot return `info` from an asynchronous launch; they raise device flags instead
+    (vsm_device_status).  Called after the synchronisation that ends a run: a singular (I - R r) raises here the way the
+    reference's LU raises SingularException on the host (cpu_batched.jl:32-47)."""
+    flags = (C.c_int * 4)()
+    check(lib().vsm_device_status(flags, 1, None))
+    if flags[0] & 1:
+        raise VSMError("%s: singular matrix in an in-kernel inverse ((I - R r) or (I - r r) has an exactly zero pivot)" % what)
+    if flags[0] & 2:
+        raise VSMError("%s: NaN / Inf operand in an in-kernel inverse" % what)
 
 
 def suffix(dtype) -> str:

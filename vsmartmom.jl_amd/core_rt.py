@@ -925,4 +925,5 @@ def rt_run(model: H.RTModel, trace: Optional[list] = None, full_output: bool = F
     scene.compute_hdrf = bool(full_output)
     scene.run(trace)
     synchronize_if_gpu()
+    _lib.check_device_status("rt_run")
     return scene.results_host_full() if full_output else scene.results_host()

@@ -573,4 +573,5 @@ def rt_run_lin(model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NS
     scene = SceneLin(model, lin_model, NAer, NGas, NSurf)
     scene.run()
     synchronize_if_gpu()
+    _lib.check_device_status("rt_run (linearized)")
     return scene.results_host()

@@ -309,6 +309,7 @@ def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list]
         if device_out:
             return scene.results_device()
         synchronize_if_gpu()
+        _lib.check_device_status("rt_run (RRS)")
         return scene.results_host()
     parts = []
     for b0 in range(lo, hi, int(max_points)):

@@ -147,6 +147,31 @@ std::mutex g_cu_mu;
 std::map<int, int> g_cu;
 }  // namespace
 
+namespace {
+std::mutex g_status_mu;
+std::map<int, int*> g_status;
+}  // namespace
+int* device_status() {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipGetDevice(device_status)");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  auto it = g_status.find(dev);
+  if (it != g_status.end()) return it->second;
+  int* p = nullptr;
+  e = hipMalloc(reinterpret_cast<void**>(&p), 4 * sizeof(int));
+  if (e == hipSuccess) e = hipMemset(p, 0, 4 * sizeof(int));   // (synchronous: ordered before any later launch)
+  if (e != hipSuccess) {
+    hip_fail(e, "hipMalloc(device_status)");
+    return nullptr;
+  }
+  g_status[dev] = p;
+  return p;
+}
+
 int ensure_dyn_lds(const void* kern, size_t bytes, const char* what) {
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
@@ -389,6 +414,15 @@ extern "C" {
 
 int vsm_version(void) { return 100; /* 0.1.0 */ }
 int vsm_release_scratch(void) { return release_scratch(); }
+int vsm_device_status(int* flags_h, int reset, void* stream) {
+  VSM_REQUIRE(flags_h != nullptr, "device_status: null");
+  int* d = device_status();
+  if (!d) return VSM_ERR_HIP;
+  VSM_HIP(hipStreamSynchronize(as_stream(stream)));
+  VSM_HIP(hipMemcpy(flags_h, d, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  if (reset) VSM_HIP(hipMemset(d, 0, 4 * sizeof(int)));
+  return VSM_OK;
+}
 const char* vsm_last_error(void) { return g_err; }
 int vsm_device_count(int* count) {
   VSM_REQUIRE(count != nullptr, "device_count: null");

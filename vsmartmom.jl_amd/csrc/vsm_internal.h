@@ -271,6 +271,7 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
 // different streams are independent".  Grow-only per key; a buffer that is outgrown is retired behind an event recorded on
 // its stream and freed only once that event has completed (never under running work).  nullptr + error set on failure.
 void* scratch(size_t bytes, int slot, hipStream_t st);
+int* device_status();   // 4 zero-initialised device words of the current device (vsm_device_status); nullptr + error set on failure
 int release_scratch();   // current device: synchronise, free every scratch buffer
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: raise it once per (device, kernel).
 int ensure_dyn_lds(const void* kern, size_t bytes, const char* what);

@@ -29,6 +29,7 @@
 // groups) covers its part of the 512-byte block linearly, and a strip store (ds_write_b64, 16-lane groups = 16 columns = four
 // k-steps x four k': k' | j << 2 is the lane's l15) hits 16 distinct 8-byte slots of a 128-byte bank row.
 #include "vsm_internal.h"
+#include "vsm_inverse.h"
 #include "vsm_lds.h"
 
 namespace vsm {
@@ -230,7 +231,7 @@ __device__ __forceinline__ double norm128(const bstrip<RT>& e, int N, int nw, fl
   return (double)(sqrtf(tot) * 1.001f);
 }
 
-// order of the Neumann series (vsm_strip_dev.h series_order); 0 = not below 0.3: levels of squaring until the power vanishes
+// order of the Neumann series (vsm_strip_dev.h series_order); 0 = the norm bound is not below 0.3 (or not a number): pivoted inverse
 __device__ __forceinline__ int series_order128(double nrm) {
   const double tol = num<double>::eps() * 0.25;
   int K = 0;
@@ -263,17 +264,114 @@ __device__ __forceinline__ void add_identity(bstrip<RT>& G, int N, const bpos<RT
     }
 }
 
+// ---- pivoted inverse (the contract of the reference's LU: batch_inv!, cpu_batched.jl:32-47, ext/gpu_batched_cuda.jl:149-179) ----
+// Where the norm bound gives no series order (||E||_F >= 0.3: the last doublings of thick near-conservative layers, bright
+// surfaces -- and anything a caller of the public entry points hands in, spectral radius >= 1 included) the inverse is the
+// register-resident Gauss-Jordan elimination with partial pivoting of vsm_inverse.h (the pivot rule of getrf), as in the kernels
+// of the smaller shapes: M = I - E goes through the A-form's LDS (plain column-major, pitch NP), 256 threads hold it in
+// registers, the result comes back as strips.  Its cost does not depend on the spectral radius (2 N + 2 barriers; a squaring
+// level is two products, and (1 - rho) = 1e-3 would take 15 of them).  Out of line: a cold path must not shape the register
+// allocation of the products.  status (device words, see vsm_device_status): [0] |= VSM_DEVSTAT_SINGULAR on an exactly zero
+// pivot, [1] += 1 per pivoted inverse.
+template <int RT>
+struct gj128_cfg {
+  static constexpr int NPAD = RT <= 6 ? 96 : 128;
+  static constexpr int NT = 256;
+};
+// (LDS is addressed through address_space(3) pointers rebuilt from byte offsets: generic pointers into LDS handed to an
+// out-of-line function trip the gfx950 backend -- "V_CMP_NE_U32 0, src_shared_base: operand has incorrect register class")
+using lds_i = __attribute__((address_space(3))) int;
+template <int NPAD>
+struct gjs_lds {   // the members gj_invert expects of its scratch, over LDS at byte address `base`
+  struct rows {
+    lds_d* b;
+    __device__ __forceinline__ lds_d* operator[](int par) const { return b + par * NPAD; }
+  };
+  rows col, rowP, rowK;
+  lds_i *piv, *dst;
+  lds_i& info;
+  __device__ __forceinline__ explicit gjs_lds(unsigned base)
+      : col{reinterpret_cast<lds_d*>((unsigned long long)base)},
+        rowP{reinterpret_cast<lds_d*>((unsigned long long)base) + 2 * NPAD},
+        rowK{reinterpret_cast<lds_d*>((unsigned long long)base) + 4 * NPAD},
+        piv(reinterpret_cast<lds_i*>((unsigned long long)(base + 48u * NPAD))),
+        dst(reinterpret_cast<lds_i*>((unsigned long long)(base + 52u * NPAD))),
+        info(*reinterpret_cast<lds_i*>((unsigned long long)(base + 56u * NPAD))) {}
+};
+constexpr size_t GJS_BYTES = (56 * 128 + 4 + 15) & ~size_t(15);   // LDS behind the kernels' own tables
+template <int RT>
+__device__ __noinline__ void gj128_core(int N, unsigned af_base, unsigned gjs_base, int* status) {
+  constexpr int NP = 16 * RT, NPAD = gj128_cfg<RT>::NPAD, NT = gj128_cfg<RT>::NT;
+  using C = gj_cfg<NPAD, NT>;
+  lds_d* AF = reinterpret_cast<lds_d*>((unsigned long long)af_base);
+  gjs_lds<NPAD> sc(gjs_base);
+  const int tid = threadIdx.x;
+  if (tid < NT) {
+    const int tr = tid % C::TR, tc = tid / C::TR;
+    gj_regs<double, NPAD, NT> m;
+#pragma unroll
+    for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < C::CB; ++cb) {
+        const int i = tr + C::TR * rb, j = tc * C::CB + cb;
+        m[rb][cb] = (i < N && j < N) ? AF[j * NP + i] : (i == j ? 1.0 : 0.0);
+      }
+    gj_invert<double, NPAD, NT>(m, N, sc, tid);   // (2 N + 2 workgroup barriers; the first one orders the loads above)
+#pragma unroll
+    for (int rb = 0; rb < C::RB; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < C::CB; ++cb) {
+        const int i = tr + C::TR * rb, j = sc.dst[tc * C::CB + cb];
+        if (i < N && j < N) AF[j * NP + i] = m[rb][cb];
+      }
+    if (tid == 0) {
+      if (sc.info != 0) atomicOr(&status[0], (int)VSM_DEVSTAT_SINGULAR);
+      atomicAdd(&status[1], 1);
+    }
+  } else {
+    for (int k = 0; k < 2 * N + 2; ++k) __syncthreads();   // the waves beyond the 256 threads walk the same barriers
+  }
+  __syncthreads();
+}
+
+struct inv128_ctx {   // what the pivoted path needs beside the strips
+  double* AF;         // the A-form's LDS (>= NP * NP doubles)
+  double* gjs;        // GJS_BYTES of LDS
+  int* status;
+};
+
 // G_s = strip of (I - E)^-1 from E's strips; every wave is past a barrier behind the last read of the A-form.
 //   K = 1..4: Horner off ONE A-form [E] (K - 1 products, no further barrier, two live strips)
-//   else:     G <- (I + E^(2^l)) G level by level (an A-form store and a product more per level) -- to the series order K, or,
-//             where the norm bound gave none (K = 0; the fused kernels of the smaller shapes pivot here), until the power's norm
-//             is below eps / 4: the spectral radius of r r is < 1 for every physical layer.
+//   K = 7 .. 31: G <- (I + E^(2^l)) G level by level (an A-form store and a product more per level) to the series order K
+//   K = 0 (no order from the norm bound): Gauss-Jordan with partial pivoting (above)
 // On return other waves may still be reading the A-form.
 template <int RT>
-__device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, int N, int nw, float* red, int& slot, bpos<RT>& p) {
+__device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, int N, const inv128_ctx& cx, bpos<RT>& p) {
   if (K == 1) {
     G = E;
     add_identity(G, N, p);
+    return;
+  }
+  if (K == 0) {
+    constexpr int NP = 16 * RT;
+    if (p.mat_wave && p.col < N) {       // M = I - E, plain column-major (only the N x N block is read back)
+      double* mc = cx.AF + p.col * NP + p.kq;
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mc[16 * ta + 4 * r] = (p.row(ta, r) == p.col ? 1.0 : 0.0) - E.v[ta][r];
+    }
+    __syncthreads();
+    gj128_core<RT>(N, lds_addr128(cx.AF), lds_addr128(cx.gjs), cx.status);
+    const bool cok = p.mat_wave && p.col < N;
+    const double* mc = cx.AF + (cok ? p.col : 0) * NP + p.kq;
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v = mc[16 * ta + 4 * r];
+        G.v[ta][r] = (cok && p.row(ta, r) < N) ? v : 0.0;
+      }
     return;
   }
   store_af(E, N, p);
@@ -293,19 +391,13 @@ __device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, i
   G = E;
   add_identity(G, N, p);             // sum_{k < 2} E^k
   int cur = 1;                       // [A] = E^cur, E = its strip, G = sum_{k < 2 cur} E^k
-  for (int lvl = 0; lvl < 30; ++lvl) {
+  for (int lvl = 0; lvl < 5; ++lvl) {   // (K <= 31: at most four levels)
     bstrip<RT> W2;
     W2.zero();
     mm128(W2, E, p);                 // E^(2 cur)
     cur *= 2;
-    bool last = (K == cur);
-    if (K == 0) {
-      const double n2 = norm128(W2, N, nw, red, slot, p);
-      last = n2 <= num<double>::eps() * 0.25;
-    } else {
-      __syncthreads();
-    }
-    if (last) {
+    __syncthreads();
+    if (K == cur) {
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta) G.v[ta] += W2.v[ta];
       break;
@@ -322,6 +414,11 @@ __device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, i
     if (K == 2 * cur - 1) break;
     E = W2;
   }
+}
+// the series order from the norm bound; a norm that is not finite (NaN / Inf input) is flagged and takes the pivoted path
+__device__ __forceinline__ int inv_order128(double nrm, int* status) {
+  if (!(nrm < 1e300) && threadIdx.x == 0) atomicOr(&status[0], (int)VSM_DEVSTAT_NONFINITE);
+  return series_order128(nrm);
 }
 
 template <int RT>
@@ -349,7 +446,7 @@ __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __re
 // MR: the source vectors as an extra MFMA tile per wave (mm128r) instead of rider columns -- N = 127, 128
 template <int RT, bool MR>
 __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, int ndoubl, double* __restrict__ expk_g,
-                                                         added<double> a, d4_t* __restrict__ scr) {
+                                                         added<double> a, d4_t* __restrict__ scr, int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
@@ -359,6 +456,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   double* xu = xt + 2 * NP;
   double* vjp = xt + 4 * NP;
   double* vjm = xt + 5 * NP;
+  const inv128_ctx icx{AF, lds128 + NP * NP + 128 + (MR ? 6 * NP : 0), status};
   bpos<RT> p(lds_addr128(AF), N);
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;   // (MR) the lane's rows of the rider tile: rrow + 4 r
@@ -454,7 +552,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
         spill(sR, r_s, p);                   // (the addend of r' = r + tt W, its rider column scaled)
         B128_STAMP(2);
         const double nrm = norm128(E, N, nw, red, slot, p);   // (its barrier: [r] is free)
-        invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
+        invert128(inv_order128(nrm, status), E, G, N, icx, p);
       }
       B128_STAMP(3);
       constexpr bool EARLY = RT < 8;
@@ -567,15 +665,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
     __syncthreads();   // the next point overwrites the A-form and the reduction slots
     B128_STAMP(10);
   }
+  if (threadIdx.x == 0) atomicAdd(&status[2], npts);   // (vsm_device_status: which kernel family ran)
   B128_STAMP_FLUSH_AT(32, 63, npts);
 }
 
 template <int RT, bool MR>
 int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
-                  hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 6 * 16 * RT * sizeof(double) : 0);
+                  int* status, hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 6 * 16 * RT * sizeof(double) : 0) + GJS_BYTES;
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128<RT, MR>), lds, "hipFuncSetAttribute(k_dbl128)")) return prepared;
-  hipLaunchKernelGGL((k_dbl128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr);
+  hipLaunchKernelGGL((k_dbl128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr, status);
   VSM_LAUNCH_CHECK("k_dbl128");
   return VSM_OK;
 }
@@ -635,7 +734,8 @@ __device__ __forceinline__ void store_global128(double* __restrict__ g, const bs
 // Three strips live at most; E2, Z, V, S wait in the workgroup's scratch.  The composite's [R+-], [T--] and the layer's [t++]
 // are staged from global memory with whole-column requests; every other operand is a strip of its owner wave.
 template <int RT, bool MR>
-__global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<double> c, added<double> a, d4_t* __restrict__ scr) {
+__global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<double> c, added<double> a, d4_t* __restrict__ scr,
+                                                        int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
@@ -643,6 +743,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   double* vjp = vec, *vjm = vec + NP, *vJp = vec + 2 * NP, *vJm = vec + 3 * NP, *vz = vec + 4 * NP, *vs = vec + 5 * NP;
   double* xt = vec + 6 * NP;
   float* red = reinterpret_cast<float*>(vec + 8 * NP);
+  const inv128_ctx icx{AF, vec + 8 * NP + 32, status};
   bpos<RT> p(lds_addr128(AF), N);
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;
@@ -762,7 +863,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       if constexpr (MR) {                               // (nobody reads the table any more) x = z for [T21], [Y]
         for (int i = tid; i < NP; i += blockDim.x) xt[i] = xt[NP + i] = vz[i];
       }
-      invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
+      invert128(inv_order128(nrm, status), E, G, N, icx, p);
     }
     B128_STAMP(7);
     __syncthreads();                                    // (e) [E2] no longer read
@@ -870,14 +971,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     __syncthreads();                                    // (m) the next point restages the A-form and the vectors
     B128_STAMP(17);
   }
+  if (threadIdx.x == 0) atomicAdd(&status[3], npts);   // (vsm_device_status: which kernel family ran)
   B128_STAMP_FLUSH(npts);
 }
 
 template <int RT, bool MR>
-int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256;
+int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, int* status,
+                 hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256 + GJS_BYTES;
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128<RT, MR>), lds, "hipFuncSetAttribute(k_ia128)")) return prepared;
-  hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr);
+  hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr, status);
   VSM_LAUNCH_CHECK("k_ia128");
   return VSM_OK;
 }
@@ -886,11 +989,13 @@ int launch_ia128(int N, int S, const composite<double>& c, const added<double>& 
 // a pivoted global-memory inverse) -------------------------------------------------------------------------------------------
 template <int RT>
 __global__ __launch_bounds__(64 * B_MAXW) void k_inv1m128(int N, int S, const double* __restrict__ A, long long sa,
-                                                           const double* __restrict__ B, long long sb, double* __restrict__ X) {
+                                                           const double* __restrict__ B, long long sb, double* __restrict__ X,
+                                                           int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
+  const inv128_ctx icx{AF, lds128 + NP * NP + 32, status};
   bpos<RT> p(lds_addr128(AF), N);
   const int nw = blockDim.x >> 6;
   int slot = 0;
@@ -903,16 +1008,17 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_inv1m128(int N, int S, const do
     E.zero();
     mm128(E, b, p);
     const double nrm = norm128(E, N, nw, red, slot, p);
-    invert128(series_order128(nrm), E, G, N, nw, red, slot, p);
+    invert128(inv_order128(nrm, status), E, G, N, icx, p);
     store_global128(X + (long long)N * N * s, G, N, p);
     __syncthreads();   // the next point restages the A-form
   }
 }
 template <int RT>
-int launch_inv1m128(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, int grid, hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 256;
+int launch_inv1m128(int N, int S, const double* A, long long sa, const double* B, long long sb, double* X, int grid, int* status,
+                    hipStream_t st) {
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 256 + GJS_BYTES;
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_inv1m128<RT>), lds, "hipFuncSetAttribute(k_inv1m128)")) return prepared;
-  hipLaunchKernelGGL(k_inv1m128<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, A, sa, B, sb, X);
+  hipLaunchKernelGGL(k_inv1m128<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, A, sa, B, sb, X, status);
   VSM_LAUNCH_CHECK("k_inv1m128");
   return VSM_OK;
 }
@@ -932,11 +1038,13 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 3 * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   if (!scr) return VSM_ERR_HIP;
+  int* status = device_status();
+  if (!status) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 6: return launch_dbl128<6, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 7: return launch_dbl128<7, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
-    case 8: return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, st);
+    case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 6: return launch_dbl128<6, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 7: return launch_dbl128<7, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 8: return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
   }
   set_error("strip128_doubling: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
@@ -949,11 +1057,13 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
   const int grid = S < cu_count() ? S : cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * 4 * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   if (!scr) return VSM_ERR_HIP;
+  int* status = device_status();
+  if (!status) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, st);
-    case 6: return launch_ia128<6, true>(N, S, c, a, grid, nw, scr, st);
-    case 7: return launch_ia128<7, true>(N, S, c, a, grid, nw, scr, st);
-    case 8: return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, st);
+    case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, status, st);
+    case 6: return launch_ia128<6, true>(N, S, c, a, grid, nw, scr, status, st);
+    case 7: return launch_ia128<7, true>(N, S, c, a, grid, nw, scr, status, st);
+    case 8: return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, status, st);
   }
   set_error("strip128_interaction11: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
@@ -963,11 +1073,13 @@ int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const do
   if (S <= 0) return VSM_OK;
   const int RT = (N + 15) / 16;
   const int grid = S < cu_count() ? S : cu_count();
+  int* status = device_status();
+  if (!status) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_inv1m128<5>(N, S, A, sa, B, sb, X, grid, st);
-    case 6: return launch_inv1m128<6>(N, S, A, sa, B, sb, X, grid, st);
-    case 7: return launch_inv1m128<7>(N, S, A, sa, B, sb, X, grid, st);
-    case 8: return launch_inv1m128<8>(N, S, A, sa, B, sb, X, grid, st);
+    case 5: return launch_inv1m128<5>(N, S, A, sa, B, sb, X, grid, status, st);
+    case 6: return launch_inv1m128<6>(N, S, A, sa, B, sb, X, grid, status, st);
+    case 7: return launch_inv1m128<7>(N, S, A, sa, B, sb, X, grid, status, st);
+    case 8: return launch_inv1m128<8>(N, S, A, sa, B, sb, X, grid, status, st);
   }
   set_error("strip128_inv_one_minus: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
