@@ -84,8 +84,7 @@ def make_step(scene, parallel, S_total, rank, world, phase=None, sync=None):
         mark()
         R, T = scene.run()
         mark()
-        packed = torch.cat([R.reshape(R.shape[0], -1), T.reshape(T.shape[0], -1)], dim=1)
-        g = parallel.gather_spectral(packed, S_total, rank, world)   # the one collective (RCCL) of the data path
+        g = parallel.gather_spectral(parallel.pack_RT(R, T), S_total, rank, world)   # the one collective step (RCCL) of the data path
         out = g.cpu() if g is not None else None                     # D2H of R/T [nSpec, 2 nStokes nVZA] on rank 0
         mark()
         if split and phase is not None:
@@ -249,7 +248,9 @@ def main():
     else:
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
-    traffic, traffic_src = hbm_traffic_per_launch(kernel_name, cfg, S_local) if args.variant == "rayleigh" else (None, None)
+    build = vsm._lib.build_info()
+    traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(kernel_name, cfg, S_local, build["source_hash"])
+                                                        if args.variant == "rayleigh" else (None, None, None, "no profile of this variant"))
 
     if rank == 0:
         flops_pt = scene.flops_per_point()
@@ -278,6 +279,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak,
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "traffic_profile_head": traffic_hash, "traffic_note": traffic_note, "library": build,
                          "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1),
                          "kernels_in_timed_interval": interval_kernels,
                          "fourier_moments_per_launch": moments_per_launch},
@@ -392,16 +394,21 @@ def c5_traffic_per_point():
         return None
 
 
-def hbm_traffic_per_launch(kernel, cfg, S_local):
+PROFILE_ROUNDS = ("r04", "r03", "r02/final")
+
+
+def hbm_traffic_per_launch(kernel, cfg, S_local, running_hash=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 runs by tools/profile_any.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
-    figure of profiles/r03/<config>/summary.json (r02/final as fallback; a 4096-point run of the same command) times the points of one launch.
-    PMC counters cannot be read from inside the timed process, so this is the profiled value, not a live one; null
-    when no profile covers the configuration."""
+    figure of profiles/<round>/<config>/summary.json (a 4096-point run of the same command) times the points of one launch.
+    PMC counters cannot be read from inside the timed process, so this is the profiled value, not a live one -- and it is only
+    quoted for the build it was taken on: a summary names the library it profiled (`library.source_hash`, csrc/Makefile), and a
+    profile of another build gives (None, path, its hash, note).  Returns (bytes per launch | None, path, profile hash, note)."""
     tag = {"C2": "c2", "C4": "c4"}.get(cfg.get("name"))
     if tag is None:
-        return None, None
-    for rnd in ("r03", "r02/final"):
+        return None, None, None, "no committed PMC profile for this configuration"
+    stale = None
+    for rnd in PROFILE_ROUNDS:
         path = os.path.join(ROOT, "profiles", rnd, tag, "summary.json")
         try:
             prof = json.load(open(path))
@@ -410,11 +417,18 @@ def hbm_traffic_per_launch(kernel, cfg, S_local):
             for name, rec in prof["kernels"].items():   # the layer kernel and (FP64 strip shapes) its elemental pre-pass
                 if (kernel in name or "k_elemental_img" in name) and "fetch_bytes_per_launch" in rec:
                     per_point += (rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / pts
-            if per_point > 0.0:
-                return per_point * S_local, os.path.relpath(path, ROOT)
+            if per_point <= 0.0:
+                continue
+            ph = (prof.get("library") or {}).get("source_hash")
+            rel = os.path.relpath(path, ROOT)
+            if running_hash is not None and ph != running_hash:
+                stale = stale or (None, rel, ph, "the newest committed profile (%s) was taken on library build %s, this run is build %s: "
+                                  "traffic withheld" % (rel, ph or "unnamed (before round 4)", running_hash))
+                continue
+            return per_point * S_local, rel, ph, None
         except Exception:
             pass
-    return None, None
+    return stale or (None, None, None, "no committed PMC profile for this configuration")
 
 
 def _cpu_worker(job):

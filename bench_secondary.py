@@ -5,11 +5,20 @@ configurations that fit one GPU, so that their figures are driver-timed and not 
   C2-lin  rt_run(model, lin_model, 0, 1, 1) on the C2 shape (1 gas column + albedo), 2 000 points
   C3-lin  the ocean / Cox-Munk scene of config/ocean_coxmunk.yaml (IQUV, N = 60, 33 layers, 2 points, m = 0..21), linearized
   C5      rotational Raman, N = 21, 12 layers, K = 40 lines, 4 000 points (configs[4] at a fifth of its spectral axis)
+  C1      quickstart-shaped (config/quickstart.yaml: Stokes_I, nstreams = 3, Rayleigh, Lambertian 0.15; BASELINE configs[0]:
+          ~10 layers, ~100 spectral points): the WHOLE rt_run(model) call -- host model / optics, scene allocation, H2D, device
+          pass, D2H (north_star: >= 10^4 spectral-points/s on quickstart-shaped atmospheres)
+  IA      the interaction kernel in isolation: interaction!(::ScatteringInterface_11), N = 60 FP64, 10 240 points
+          (k_ia_strip<15>; north_star: >= 40 % MFMA utilisation in the interaction kernel -- inside the headline it is part of
+          the fused layer kernel)
+  N112    forward run at the reference's VLIDORT case-A size (test/vlidort_baseline/cases/case_A_siewert2000.jl:29-50:
+          IQUV, N = 112), 2 000 points, 10 layers: the k_dbl128 / k_ia128 family
 
 Each entry: points/s of the step, its wall time, the device time of the pass by HIP events, the algorithmic TFLOP/s and the
-fraction of the MFMA peak of its dtype, and the dominant kernel (per-kernel durations: profiles/r03/).  A step here is the
-device pass of an already-built scene (`scene.run()` + D2H of the result), with one untimed warm-up; the C5 step is a whole
-`rt_run(RRS, ...)` call (host optics, H2D, device pass, D2H).  Only bench.py imports this module, on rank 0 of a 1-GPU run.
+fraction of the MFMA peak of its dtype, and the dominant kernel (per-kernel durations: profiles/r04/).  A step is what the
+headline times: H2D of the raw inputs (`upload()`), device layer optics (`prepare()`), the device pass (`run()`) and the D2H of the
+result, on a scene whose buffers are allocated beforehand, with one untimed warm-up; the C5 and C1 steps are whole `rt_run(...)`
+calls (host optics, allocation, H2D, device pass, D2H).  Only bench.py imports this module, on rank 0 of a 1-GPU run.
 """
 import json
 import os
@@ -40,6 +49,15 @@ def _entry(name, workload, S, wall, dev_ms, flops_pt, dtype, kernel):
             "achieved_tflops": tf, "frac_of_mfma_peak": tf / PEAK[dtype] if tf else None, "dominant_kernel": kernel}
 
 
+def _lin_step_inputs(scene):
+    """The input half of a linearized step, like the headline's: H2D of the raw optical depths and their derivatives, layer
+    optics and their derivatives on the device (forward scene + SceneLin)."""
+    scene.fwd.upload()
+    scene.fwd.prepare()
+    scene.upload()
+    scene.prepare()
+
+
 def c4(vsm, torch, arch, o2a, points=12500):
     cfg = dict(pol="IQU", l_trunc=59, L=60)
     tau_rayl, tau_abs = o2a(points, cfg["L"])
@@ -68,6 +86,7 @@ def c2_lin(vsm, torch, arch, o2a, points=2000):
     scene = vsm.CoreRTLin.SceneLin(model, lin, 0, 1, 1)
 
     def step():
+        _lin_step_inputs(scene)
         scene.run()
         return scene.results_host()
     wall, dev, _ = _timed(torch, step)
@@ -91,6 +110,7 @@ def c3_lin(vsm, torch, arch):
     scene = vsm.CoreRTLin.SceneLin(model, lin, 0, 1, 1)
 
     def step():
+        _lin_step_inputs(scene)
         scene.run()
         return scene.results_host()
     wall, dev, _ = _timed(torch, step)
@@ -138,10 +158,101 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
     return e
 
 
+def c1(vsm, torch, arch, points=100, layers=10, reps=20):
+    H = vsm.host_model
+    tau_rayl = np.tile(0.1 * np.diff(np.linspace(0.0, 1.0, layers + 1)), (points, 1)) * np.linspace(0.9, 1.1, points)[:, None]
+
+    def call():   # everything a user's rt_run(model) costs, from the arrays of optical depths
+        model = H.model_from_arrays(arch, "I", 5, 60.0, [60.0], [180.0], tau_rayl=tau_rayl, tau_abs=np.zeros_like(tau_rayl),
+                                    depol=0.0279, albedo=0.15, m_max=2)
+        return model, vsm.CoreRT.rt_run(model)
+
+    def step():
+        for _ in range(reps):
+            out = call()
+        return out
+    wall, dev, (model, _) = _timed(torch, step)
+    N = model.quad_points.Nquad * model.polarization_type.n
+    sc = vsm.CoreRT.prepare_scene(model)
+    e = _entry("C1", "quickstart-shaped (config/quickstart.yaml geometry: Stokes_I, nstreams=3, sza=vza=60 -> N=%d; Rayleigh, Lambertian "
+               "0.15, %d layers, %d points, FP64, m=0..2); step = whole rt_run(model) incl. host model/optics, scene allocation, H2D, "
+               "D2H; mean of %d calls" % (N, layers, points, reps), points, wall / reps, dev / reps, sc.flops_per_point(), "f64",
+               "k_elemental_doubling / k_interaction11 (LDS-resident, launch-latency bound)")
+    e["north_star_target_points_per_s"] = 1e4
+    del sc
+    return e
+
+
+def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
+    FT = np.float64
+    rng = np.random.default_rng(1)
+    CR = vsm.CoreRT
+    S = points
+    pc = CR.make_composite_layer(FT, arch, (N, N), S)
+    pa = CR.make_added_layer(FT, arch, (N, N), S)
+    dev = pc.R_mp.device
+
+    def refl(scale):   # physically shaped operators: small reflections, near-diagonal transmissions (tools/ia_timing.py)
+        return torch.rand((S, N, N), dtype=torch.float64, device=dev) * (scale / N)
+
+    def trans():
+        d = 0.3 + 0.65 * torch.rand((S, N), dtype=torch.float64, device=dev)
+        return torch.diag_embed(d) + torch.rand((S, N, N), dtype=torch.float64, device=dev) * (0.05 / N)
+    init = dict(R_mp=refl(0.4), R_pm=refl(0.4), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
+                J0_m=torch.rand((S, N), dtype=torch.float64, device=dev))
+    for k in ("r_mp", "r_pm"):
+        getattr(pa, k).copy_(refl(0.3))
+    for k in ("t_pp", "t_mm"):
+        getattr(pa, k).copy_(trans())
+    pa.j0_p.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
+    pa.j0_m.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    tot, t0 = 0.0, time.perf_counter()
+    for it in range(reps + 1):
+        for k, v in init.items():      # (the composite is updated in place: every repetition starts from the same operators)
+            getattr(pc, k).copy_(v)
+        ev[0].record()
+        CR.interaction_("11", pc, pa)
+        ev[1].record()
+        torch.cuda.synchronize()
+        if it:
+            tot += ev[0].elapsed_time(ev[1])
+    ms = tot / reps
+    flop_pt = 24.0 * N ** 3 + 8.0 * N ** 2
+    e = _entry("IA", "interaction!(::ScatteringInterface_11) alone (interaction.jl:207-266), N=%d FP64, %d points per launch, physically "
+               "shaped random layers (||rR|| ~ 3e-2: series inverse); HIP events around each of %d launches" % (N, S, reps), S, ms * 1e-3, ms,
+               flop_pt, "f64", "k_ia_strip<15>")
+    e["north_star_target_mfma_utilisation"] = 0.40
+    e["note"] = ("frac_of_mfma_peak is ALGORITHMIC flops (24N^3+8N^2 per point) / launch time / 78.6; the MFMA pipe's busy fraction "
+                 "(PMC SQ_VALU_MFMA_BUSY_CYCLES) is higher: profiles/r04/ia/summary.json")
+    del pc, pa, init
+    return e
+
+
+def n112(vsm, torch, arch, o2a, points=2000, layers=10):
+    tau_rayl, tau_abs = o2a(points, layers)
+    model = vsm.host_model.model_from_arrays(arch, "IQUV", 51, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279,
+                                             albedo=0.15, m_max=2)
+    N = model.quad_points.Nquad * 4
+    scene = vsm.CoreRT.prepare_scene(model)
+
+    def step():
+        scene.upload()
+        scene.prepare()
+        R, T = scene.run()
+        return R.cpu(), T.cpu()
+    wall, dev, _ = _timed(torch, step)
+    e = _entry("N112", "forward, IQUV N=%d FP64 (the reference's VLIDORT case-A size), %d layers, %d points, m=0..2, Rayleigh + O2, "
+               "Lambertian" % (N, layers, points), points, wall, dev, scene.flops_per_point(), "f64", "k_dbl128<7> (+ k_ia128<7>)")
+    del scene
+    return e
+
+
 def run_all(vsm, torch, arch, o2a):
     out = []
     for f in (lambda: c4(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a), lambda: c3_lin(vsm, torch, arch),
-              lambda: c5(vsm, torch, arch)):
+              lambda: c5(vsm, torch, arch), lambda: c1(vsm, torch, arch), lambda: ia_kernel(vsm, torch, arch),
+              lambda: n112(vsm, torch, arch, o2a)):
         try:
             out.append(f())
         except Exception as ex:   # a secondary workload must not take the headline line down

@@ -67,6 +67,7 @@ typedef enum vsm_iface {
 /* ---- library / device ---------------------------------------------------- */
 int vsm_version(void);                 /* 10000*major + 100*minor + patch */
 const char* vsm_last_error(void);      /* thread-local, never NULL */
+const char* vsm_build_id(void);        /* 16 hex digits: SHA-256 over the library's sources (csrc/Makefile); profiles name it */
 int vsm_device_count(int* count);      /* Architectures.jl:68-96 `_has_cuda`-style probe */
 int vsm_device_name(int device, char* buf, size_t buflen);
 int vsm_sync(void* stream);            /* Architectures.synchronize_if_gpu (Architectures.jl:96) */

@@ -928,15 +928,22 @@ def thermal_source(pol: Polarization, qp: QuadPoints, dtau, varpi, B, FT):
     return j
 
 
-def rt_run_thermal(model: RTModel, B_layer):
-    """The `:thermal` per-source slot of rt_run (rt_kernel.jl:205-232 slot reset + contribute!, doubling.jl:62-81 per-source
+def rt_run_thermal(model: RTModel, B_layer, reset_slot_in_nonscattering_layers: bool = False):
+    """The `:thermal` per-source slot of rt_run (rt_kernel.jl:204-232 slot reset + contribute!, doubling.jl:62-81 per-source
     source update with the slot's own expk = 1, interaction.jl:52-75 ... per-source J0 recurrences, postprocessing_vza.jl:68-82):
-    the same linear source recurrences as the solar slot, driven by the thermal source, m = 0 only (isotropic).  Returns the
-    slot's contribution (R_th, T_th) -- rt_run adds it to R_SFI / T_SFI.  B_layer: [L, S] Planck radiance per layer.
-    The slot recurrences are evaluated on a copy of the layer (its r, t evolve exactly like the solar pass's).
-    Deviation (documented in DESIGN.md): a non-scattering layer contributes no thermal source, like the reference (its
-    contribute! sits in the scatter branch), but the slot is ZEROED there, whereas the reference leaves the previous layer's
-    doubled slot in place (rt_kernel.jl:217-221 resets only in the scatter branch)."""
+    the same linear source recurrences as the solar slot, driven by the thermal source.  Returns the slot's contribution
+    (R_th, T_th) -- rt_run adds it to R_SFI / T_SFI.  B_layer: [L, S] Planck radiance per layer.  The slot recurrences are
+    evaluated on a copy of the layer (its r, t evolve exactly like the solar pass's).
+
+    State the reference carries, restated as written (rt_kernel.jl:204-232): the slot's j0+- live in the AddedLayer, which is
+    allocated ONCE per run (rt_run.jl:326-335).  The scatter branch resets them (:217-221), lets contribute! fill them (m = 0 only:
+    thermal emission is isotropic) and doubles them; the non-scattering branch (:229-232, zero_added_noscat!) does not touch
+    them, so a non-scattering layer interacts with the slot of the LAST SCATTERING LAYER BEFORE IT -- and when the column
+    begins with non-scattering layers, moment m = 1 starts on the doubled thermal slot that the last scattering layer of moment
+    m = 0 left behind (every later moment starts on zeros: the scattering layers of m >= 1 reset the slot and contribute nothing).
+    The Fourier loop below walks all moments the way the reference does and skips those in which the slot provably stays zero.
+    `reset_slot_in_nonscattering_layers=True` is the corrected variant (the slot of a non-scattering layer is zero: such a layer
+    emits nothing here, like the reference's, and carries nothing over) -- an explicit option, not the default."""
     FT = model.FT
     pol, qp = model.pol, model.quad_points
     S, L = model.tau_rayl.shape
@@ -946,37 +953,45 @@ def rt_run_thermal(model: RTModel, B_layer):
     T_th = np.zeros((nV, pol.n, S), dtype=FT)
     B_layer = np.asarray(B_layer, dtype=FT)
     F0 = np.zeros((pol.n, S), dtype=FT)
-    added, added_surf, comp = make_added_layer(FT, N, S), make_added_layer(FT, N, S), make_composite_layer(FT, N, S)
-    m = 0
-    weight = FT(0.5 / math.pi)
-    lods = construct_core_optical_properties(model, m)
-    ifaces, tau_sum_all = extract_effective_props(lods, FT)
-    for iz in range(L):
-        lo = expand_optical_properties(lods[iz], FT)
-        tau, varpi = lo.tau, lo.varpi
-        if np.max(tau * varpi) > 2 * eps(FT):
-            dtau, nd = get_dtau_ndoubl(tau, varpi, qp, FT, model.numerics)
-            elemental(pol, tau_sum_all[:, iz].astype(FT), dtau, F0, varpi, lo.Zpp, lo.Zmp, m, nd, qp, added, FT)
-            j = thermal_source(pol, qp, dtau, varpi, B_layer[iz], FT) if iz < B_layer.shape[0] else np.zeros((S, N), dtype=FT)
-            added.j0_p[...] = j
-            added.j0_m[...] = j
-            doubling(pol, np.ones(S, dtype=FT), nd, added, FT)
+    added, added_surf = make_added_layer(FT, N, S), make_added_layer(FT, N, S)
+    slot_p, slot_m = np.zeros((S, N), dtype=FT), np.zeros((S, N), dtype=FT)     # the AddedLayer's slot: persists over (m, layer)
+    for m in range(model.m_max + 1):
+        if m > 0 and not (np.any(slot_p != 0) or np.any(slot_m != 0)):
+            continue            # nothing is ever contributed at m > 0: with a zero slot on entry the whole moment stays zero
+        comp = make_composite_layer(FT, N, S)
+        weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
+        lods = construct_core_optical_properties(model, m)
+        ifaces, tau_sum_all = extract_effective_props(lods, FT)
+        for iz in range(L):
+            lo = expand_optical_properties(lods[iz], FT)
+            tau, varpi = lo.tau, lo.varpi
+            if np.max(tau * varpi) > 2 * eps(FT):
+                dtau, nd = get_dtau_ndoubl(tau, varpi, qp, FT, model.numerics)
+                elemental(pol, tau_sum_all[:, iz].astype(FT), dtau, F0, varpi, lo.Zpp, lo.Zmp, m, nd, qp, added, FT)
+                j = (thermal_source(pol, qp, dtau, varpi, B_layer[iz], FT) if (m == 0 and iz < B_layer.shape[0])
+                     else np.zeros((S, N), dtype=FT))                            # reset (:217-221) + contribute! (m = 0 only)
+                added.j0_p[...] = j
+                added.j0_m[...] = j
+                doubling(pol, np.ones(S, dtype=FT), nd, added, FT)
+                slot_p[...], slot_m[...] = added.j0_p, added.j0_m
+            else:
+                zero_added_noscat(added, tau, qp, FT)
+                if reset_slot_in_nonscattering_layers:
+                    slot_p[...] = 0
+                    slot_m[...] = 0
+                added.j0_p[...], added.j0_m[...] = slot_p, slot_m                # the slot as the last scattering layer left it
+            if iz == 0:
+                copy_added_to_composite(comp, added)
+            else:
+                interaction(ifaces[iz], comp, added, FT)
+        if np.ndim(model.albedo) == 1:
+            create_surface_layer_lambertian_spectral(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
         else:
-            zero_added_noscat(added, tau, qp, FT)
-            added.j0_p[...] = 0
-            added.j0_m[...] = 0
-        if iz == 0:
-            copy_added_to_composite(comp, added)
-        else:
-            interaction(ifaces[iz], comp, added, FT)
-    if np.ndim(model.albedo) == 1:
-        create_surface_layer_lambertian_spectral(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
-    else:
-        create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
-    added_surf.j0_p[...] = 0          # no solar beam in this slot (surface emission is a separate source type)
-    added_surf.j0_m[...] = 0
-    interaction(ifaces[-1], comp, added_surf, FT)
-    postprocessing_vza(pol, comp, model.vza, model.vaz, qp, m, weight, R_th, T_th)
+            create_surface_layer_lambertian(model.albedo, added_surf, m, pol, qp, tau_sum_all[:, -1], FT)
+        added_surf.j0_p[...] = 0          # no solar beam in this slot (surface emission is a separate source type)
+        added_surf.j0_m[...] = 0
+        interaction(ifaces[-1], comp, added_surf, FT)
+        postprocessing_vza(pol, comp, model.vza, model.vaz, qp, m, weight, R_th, T_th)
     return R_th, T_th
 
 

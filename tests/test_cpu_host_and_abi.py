@@ -237,7 +237,7 @@ def test_two_rank_gloo_linearized_shard_and_gather():
     assert res == (True, True, True, True, (2, 3, 5, 2))
 
 
-def _worker_bench_step(rank, world, port, q):
+def _worker_bench_step(rank, world, port, q, S=7):
     """One rank of the gloo test that drives bench.py's OWN timed step (bench.make_step: upload -> prepare -> run -> pack R|T ->
     ONE gather -> D2H) with a CPU stand-in for the HIP Scene: the oracle evaluated on the full axis and cut to the rank's block
     (oracle use is confined to tests/).  What the driver's multi-GPU bench executes around the kernels is exercised here."""
@@ -250,7 +250,7 @@ def _worker_bench_step(rank, world, port, q):
     import bench
     from oracle import vsm_oracle as Oo
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    S, L = 7, 3                      # blocks of 4 and 3: the gather pads the last block
+    L = 3                            # S = 7 over 2 ranks: blocks of 4 and 3; over 3 ranks: 3, 3, 1; S = 4 over 3 ranks: 2, 2, 0
     tau_rayl, tau_abs = bench.o2a_atmosphere(S, L)
     geo = ("IQU", 9, 40.0, [30.0], [0.0])
     om = Oo.build_model(*geo, tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2)
@@ -302,6 +302,24 @@ def test_two_rank_gloo_bench_step():
         p.join(60)
         assert p.exitcode == 0
     assert res == (True, True, True, (7, 6), ["upload", "prepare", "run"], True)
+
+
+@pytest.mark.parametrize("S", [7, 4])
+def test_three_rank_gloo_bench_step_ragged_blocks(S):
+    """bench.make_step at world size 3 with a spectral axis the ranks do not divide: blocks of 3, 3, 1 (S = 7) and 2, 2, 0
+    (S = 4: the last rank owns nothing and takes no part in the gather) -- the gather moves exactly each rank's block."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_step, args=(r, 3, port, q, S)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == (True, True, True, (S, 6), ["upload", "prepare", "run"], True)
 
 
 def test_scene_uses_global_ndoubl_for_shards(vsm):

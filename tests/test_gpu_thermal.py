@@ -125,7 +125,10 @@ def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch, FT, ge
     for kw in (dict(tau_rayl=tau_rayl, tau_abs=tau_abs),
                dict(tau_rayl=tau_rayl, tau_abs=tau_abs, tau_aer=tau_aer, aerosol_optics=aos)):
         com = dict(depol=0.03, albedo=0.2, m_max=3, float_type=FT, **kw)
-        model = H.model_from_arrays(arch, *geo, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **com)
+        # (the corrected slot variant: with the reference's slot state a column with a non-scattering layer keeps every doubled
+        # slot in the AddedLayer and takes no fused step -- test_thermal_slot_state_in_nonscattering_layers)
+        model = H.model_from_arrays(arch, *geo, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B, reset_slot_in_nonscattering_layers=True)),
+                                    **com)
         monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
         Rf, Tf = vsm.CoreRT.rt_run(model)
         monkeypatch.setenv("VSM_NO_THERMAL_FUSION", "1")
@@ -134,3 +137,32 @@ def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch, FT, ge
         Rs, Ts = vsm.CoreRT.rt_run(H.model_from_arrays(arch, *geo, **com))
         assert np.max(np.abs(Ro - Rs)) > 1e-4                      # the slot contributes
         assert _rel(Rf - Rs, Ro - Rs) < tol and _rel(Tf - Ts, To - Ts) < tol
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQUV", 19), ("IQUV", 31)])     # N = 8, 52 (fused-capable shape), 76
+@pytest.mark.parametrize("column", ["noscat_in_the_middle", "noscat_on_top", "noscat_on_top_and_below"])
+def test_thermal_slot_state_in_nonscattering_layers(vsm, arch, pol, l_trunc, column):
+    """rt_kernel.jl:204-232 as written: the `:thermal` slot of the AddedLayer is reset only in the scatter branch, so a
+    non-scattering layer interacts with the doubled slot of the last scattering layer before it, and a column that begins with
+    non-scattering layers carries the slot of m = 0 into m = 1 -- the default here, against the oracle's restatement; and the
+    corrected variant (ThermalEmission(reset_slot_in_nonscattering_layers=True)) against the oracle's."""
+    H = vsm.host_model
+    S, L = 3, 4
+    rayl = {"noscat_in_the_middle": [0.05, 0.0, 0.1, 0.2], "noscat_on_top": [0.0, 0.05, 0.1, 0.2],
+            "noscat_on_top_and_below": [0.0, 0.0, 0.1, 0.0]}[column]
+    tau_rayl = np.tile(np.array(rayl), (S, 1))
+    tau_abs = np.tile(np.array([0.3, 0.5, 0.2, 0.4]), (S, 1)) * (1 + 0.5 * np.arange(S))[:, None]
+    B = 0.1 + 0.02 * np.arange(L)[:, None] * np.array([1.0, 2.0, 3.0])[None, :]
+    geo = (pol, l_trunc, 30.0, [0.0, 35.0], [0.0, 60.0])
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.1, m_max=2)
+    om = O.build_model(*geo, **kw)
+    Rs, Ts = O.rt_run(om)
+    out = {}
+    for reset in (False, True):
+        Rt, Tt = O.rt_run_thermal(om, B, reset_slot_in_nonscattering_layers=reset)
+        pm = H.model_from_arrays(arch, *geo, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B, reset_slot_in_nonscattering_layers=reset)),
+                                 **kw)
+        R, T = vsm.CoreRT.rt_run(pm)
+        assert _rel(R - Rs, Rt) < 1e-8 and _rel(T - Ts, Tt) < 1e-8, reset
+        out[reset] = Rt
+    assert np.max(np.abs(out[False] - out[True])) > 1e-6 * np.max(np.abs(out[True]))   # the two variants do differ on these columns

@@ -49,3 +49,27 @@ def test_opaque_isothermal_column_emits_the_planck_radiance(m_max):
     Bp = O.planck_spectrum_wn(250.0, nu)
     R, _ = O.rt_run_thermal(mdl, np.tile(Bp, (4, 1)))
     assert np.allclose(R[0, 0, :] / Bp, 1.0, atol=1e-3)
+
+
+def test_thermal_slot_state_of_the_reference_in_nonscattering_layers():
+    """rt_kernel.jl:204-232: the `:thermal` slot is reset only in the scatter branch.  (1) Without a non-scattering layer the
+    restated state and the corrected variant are the same run.  (2) A non-scattering layer below a scattering one re-uses that
+    layer's doubled slot: the result equals a run in which the non-scattering layer is replaced by... nothing simpler -- so the
+    check is structural: the variants differ, and the difference is confined to m = 0 unless the column BEGINS with a
+    non-scattering layer, in which case moment m = 1 (azimuth dependent) carries thermal radiance as well."""
+    S, L = 2, 3
+    B = 0.1 + 0.05 * np.arange(L)[:, None] * np.ones((1, S))
+    geo = ("I", 7, 30.0, [20.0, 20.0], [0.0, 90.0])          # the same viewing zenith at two azimuths
+    tau_abs = np.full((S, L), 0.4)
+
+    def run(rayl, reset):
+        om = O.build_model(*geo, tau_rayl=np.tile(np.array(rayl), (S, 1)), tau_abs=tau_abs, depol=0.0, albedo=0.0, m_max=2)
+        return O.rt_run_thermal(om, B, reset_slot_in_nonscattering_layers=reset)[0]
+    a, b = run([0.05, 0.1, 0.2], False), run([0.05, 0.1, 0.2], True)
+    assert np.array_equal(a, b)
+    a, b = run([0.05, 0.0, 0.2], False), run([0.05, 0.0, 0.2], True)
+    assert np.max(np.abs(a - b)) > 1e-4 * np.max(np.abs(b))
+    assert np.max(np.abs(a[0] - a[1])) < 1e-14 and np.max(np.abs(b[0] - b[1])) < 1e-14     # m = 0 only: no azimuth dependence
+    a, b = run([0.0, 0.05, 0.2], False), run([0.0, 0.05, 0.2], True)
+    assert np.max(np.abs(b[0] - b[1])) < 1e-14
+    assert np.max(np.abs(a[0] - a[1])) > 1e-6 * np.max(np.abs(a))                           # the slot of m = 0 rides into m = 1

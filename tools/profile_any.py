@@ -67,7 +67,9 @@ def main():
             rc = subprocess.call(["rocprofv3", "--output-format", "csv"] + flags + ["-d", d, "-o", "p", "--"] + cmd, stdout=log,
                                  stderr=subprocess.STDOUT, env=env, cwd=os.getcwd())
         print("pass %-5s rc=%d" % (name, rc), flush=True)
-    summary = {"command": " ".join(cmd), "dtype": a.dtype,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vsmartmom_jl_amd import _lib as vsm_lib      # (identity of the library the profiled command loads: csrc/Makefile)
+    summary = {"command": " ".join(cmd), "dtype": a.dtype, "library": vsm_lib.build_info(),
                "corrections": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                               "requests at 64 B); WRITE_SIZE uncalibrated, taken as is", "kernels": {}}
     for f in glob.glob(os.path.join(a.out, "stats", "**", "*kernel_stats.csv"), recursive=True):

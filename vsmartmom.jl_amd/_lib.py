@@ -80,6 +80,7 @@ _P, _I, _LL, _SZ = C.c_void_p, C.c_int, C.c_longlong, C.c_size_t
 _SIGS = {
     "vsm_version": (_I, []),
     "vsm_last_error": (C.c_char_p, []),
+    "vsm_build_id": (C.c_char_p, []),
     "vsm_device_count": (_I, [C.POINTER(_I)]),
     "vsm_device_name": (_I, [_I, C.c_char_p, _SZ]),
     "vsm_sync": (_I, [_P]),
@@ -177,6 +178,21 @@ def lib():
     return L
 
 
+def build_info() -> dict:
+    """Identity of the loaded library: `source_hash` = vsm_build_id() (SHA-256 prefix over the library's sources, compiled in),
+    plus what csrc/Makefile wrote next to it (the commit checked out at build time)."""
+    import json
+    info = {"source_hash": lib().vsm_build_id().decode()}
+    try:
+        with open(os.path.join(os.path.dirname(LIB_PATH), "BUILD_INFO.json")) as f:
+            side = json.load(f)
+        if side.get("source_hash") == info["source_hash"]:
+            info.update(side)
+    except (OSError, ValueError):
+        pass
+    return info
+
+
 def poison(t):
     """Work buffers are handed to the library uninitialised; with VSM_POISON_WORK=1 (a test-run switch) they are filled
     with NaN first, so that a kernel reading scratch it has not written shows up as NaN instead of stale data."""
@@ -190,12 +206,17 @@ def check(rc):
         raise VSMError("libvsmartmom_hip: status %d: %s" % (rc, lib().vsm_last_error().decode()))
 
 
+last_device_status = [0, 0, 0, 0]
+
+
 def check_device_status(what="rt_run"):
     """The in-kernel inverses cannot return `info` from an asynchronous launch; they raise device flags instead
     (vsm_device_status).  Called after the synchronisation that ends a run: a singular (I - R r) raises here the way the
     reference's LU raises SingularException on the host (cpu_batched.jl:32-47)."""
+    global last_device_status
     flags = (C.c_int * 4)()
     check(lib().vsm_device_status(flags, 1, None))
+    last_device_status = list(flags)     # (tests read the counters: which kernel family a run landed on)
     if flags[0] & 1:
         raise VSMError("%s: singular matrix in an in-kernel inverse ((I - R r) or (I - r r) has an exactly zero pivot)" % what)
     if flags[0] & 2:

@@ -561,6 +561,8 @@ class Scene:
             F0 = np.zeros((pol.n, S_full))
         th = [s_ for s_ in srcs if isinstance(s_, H.ThermalEmission) and s_.B_layer is not None and np.any(s_.B_layer != 0)]
         self.thermal_B = None
+        self.thermal_reset_noscat = bool(th and th[0].reset_slot_in_nonscattering_layers)
+        self._thermal_carry = False
         if th:
             B = th[0].B_layer
             if B.shape[1] != S_full:
@@ -763,11 +765,12 @@ class Scene:
                     interaction_hdrf_(pol, comp, self.added_surface, m, self.dq, model.vza, model.vaz, self.qp, float(weight),
                                       self.hdr_J, self.hdr, self.bhr_uw, self.bhr_dw)
                 postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, m, float(weight), self.R_SFI, self.T_SFI)
-                if m == 0 and self.thermal_B is not None:
+                thermal_pass = self.thermal_B is not None and (m == 0 or (m == 1 and self._thermal_carry))
+                if thermal_pass:
                     self._thermal_slot(mom, float(weight))
                 if streams is not None:
                     Jm, Jp = comp.J0_m.clone(), comp.J0_p.clone()
-                    if m == 0 and self.thermal_B is not None:
+                    if thermal_pass:
                         Jm += self._th_comp.J0_m
                         Jp += self._th_comp.J0_p
                     streams.append(dict(m=m, weight=float(weight), R_mp=comp.R_mp.clone(), T_pp=comp.T_pp.clone(), J0_m=Jm, J0_p=Jp))
@@ -777,14 +780,20 @@ class Scene:
         return self.R_SFI, self.T_SFI
 
     def _thermal_slot(self, mom, weight):
-        """The `:thermal` per-source slot (rt_kernel.jl:205-232, doubling.jl:62-81, interaction.jl per-source recurrences,
+        """The `:thermal` per-source slot (rt_kernel.jl:204-232, doubling.jl:62-81, interaction.jl per-source recurrences,
         postprocessing_vza.jl:68-82): the solar slot's linear source recurrences driven by the thermal source
-        (vsm_thermal_source between elemental! and doubling!, the slot's own expk = 1), m = 0 only; its J0 is added to
-        R_SFI / T_SFI.  Operator level, on an AddedLayer / CompositeLayer of its own (r, t, R, T evolve exactly like the solar
-        pass's).  A non-scattering layer contributes no thermal source (the reference's contribute! sits in the scatter branch)
-        and the slot is zeroed there (the reference leaves the previous layer's doubled slot in place)."""
+        (vsm_thermal_source between elemental! and doubling!, the slot's own expk = 1); its J0 is added to R_SFI / T_SFI.
+        On an AddedLayer / CompositeLayer of its own (r, t, R, T evolve exactly like the solar pass's).
+
+        State, as the reference carries it (default; ThermalEmission(reset_slot_in_nonscattering_layers=True) = the corrected
+        variant): the slot's j0+- belong to the AddedLayer that is allocated once per run (rt_run.jl:326-335); only the scatter
+        branch resets them (rt_kernel.jl:217-221), so a non-scattering layer interacts with the doubled slot of the last
+        scattering layer before it, and a column that begins with non-scattering layers enters moment m = 1 with the slot the
+        last scattering layer of moment m = 0 left behind -- that is the one case in which this pass runs for m = 1 (contribute!
+        itself is m = 0 only; with a zero slot on entry every later moment stays zero)."""
         model, pol, FT = self.model, self.pol, self.FT
         N, S = self.N, self.S
+        m = mom["m"]
         if getattr(self, "_th_added", None) is None:
             self._th_added = make_added_layer(FT, self.arch, (N, N), S, d_symmetric=0)
             self._th_surf = make_added_layer(FT, self.arch, (N, N), S, shared=not self.spectral_surface)
@@ -793,13 +802,22 @@ class Scene:
             self._th_ones = torch.ones(max(S, 1), dtype=self.dt, device=self.dev)
         added, comp = self._th_added, self._th_comp
         q = self.dq.cstruct()
+        eps2 = 2 * np.finfo(FT).eps
+        scat = [ly["props"].max_tau_varpi > eps2 for ly in mom["layers"]]
+        keep_state = not self.thermal_reset_noscat          # the reference as written
+        if m == 0:
+            added.j0_p.zero_()                               # a fresh AddedLayer (rt_run.jl:326-335)
+            added.j0_m.zero_()
+            self._thermal_carry = keep_state and any(scat) and not scat[0] and model.m_max >= 1
         # FP64, 32 < N <= 60 / FP32, 64 < N <= 96: a scattering layer's slot in ONE fused launch (vsm_layer_forward_thermal: the strip layer kernel
-        # with the thermal source and expk = 1); everything else operator level, layer by layer on the same composite
-        fused = (os.environ.get("VSM_NO_THERMAL_FUSION") is None
+        # with the thermal source and expk = 1; m = 0); everything else operator level, layer by layer on the same composite.  With
+        # the reference's slot state and a non-scattering layer in the column the doubled slot must stay in the AddedLayer for the
+        # layers below: no fused step then (as in the solar pass, rt_kernel_'s keep_added)
+        fused = (os.environ.get("VSM_NO_THERMAL_FUSION") is None and m == 0 and (all(scat) or not keep_state)
                  and _lib.lib().vsm_layer_thermal_fused(N, 1 if FT == np.float64 else 0) != 0)
         for iz, ly in enumerate(mom["layers"]):
             props = ly["props"]
-            scatter = props.max_tau_varpi > 2 * np.finfo(FT).eps
+            scatter = scat[iz]
             if (fused and scatter and (iz == 0 or ly["iface"] == "11") and iz < self.thermal_B.shape[0]
                     and (props.fcomp is None or props.fcomp.shape[1] <= 4)):
                 c = comp.cstruct()
@@ -809,13 +827,18 @@ class Scene:
                           0 if ncomp else props.z_stride, _ptr(props.fcomp), 1 if iz == 0 else 0, C.byref(c), _stream_ptr())
                 continue
             if scatter:
-                elemental_(pol, ly["tau_sum"], ly["dtau"], self._th_F0, props.materialize(), 0, ly["nd"], self.dq, added)
-                if iz < self.thermal_B.shape[0]:
+                # elemental! with F0 = 0 leaves j0+- = 0: the slot reset of rt_kernel.jl:217-221
+                elemental_(pol, ly["tau_sum"], ly["dtau"], self._th_F0, props.materialize(), m, ly["nd"], self.dq, added)
+                if m == 0 and iz < self.thermal_B.shape[0]:           # contribute! (isotropic: m = 0 only)
                     a = added.cstruct()
                     _lib.call("vsm_thermal_source", self.dt, C.byref(q), S, _ptr(ly["dtau"]), _ptr(props.varpi),
                               _ptr(self.thermal_B[iz]), C.byref(a), _stream_ptr())
                 self._th_ones.fill_(1.0)             # doubling! squares the slot's expk in place (1 stays 1)
                 doubling_(pol, self._th_ones, ly["nd"], added)
+            elif keep_state:
+                jm = added.j0_m.clone()              # zero_added_noscat! zeroes the SOLAR j0-, never a per-source slot
+                zero_added_noscat_(added, props.tau, self.dq)
+                added.j0_m.copy_(jm)
             else:
                 zero_added_noscat_(added, props.tau, self.dq)
                 added.j0_p.zero_()
@@ -824,11 +847,11 @@ class Scene:
                 copy_added_to_composite_(comp, added)
             else:
                 interaction_(ly["iface"], comp, added, oplevel=True, work=self.work)
-        create_surface_layer_(model.surface, self._th_surf, 0, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
+        create_surface_layer_(model.surface, self._th_surf, m, self.dq, mom["tau_sum_surface"], rho=mom["rho"])
         self._th_surf.j0_p.zero_()      # no solar beam in this slot (surface emission is a separate source type)
         self._th_surf.j0_m.zero_()
         interaction_(mom["iface_surface"], comp, self._th_surf, oplevel=True, work=self.work)
-        postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, 0, weight, self.R_SFI, self.T_SFI)
+        postprocessing_vza_(pol, comp, model.vza, model.vaz, self.qp, m, weight, self.R_SFI, self.T_SFI)
 
     def run_graph(self):
         """`run()` replayed from a HIP graph: the launch sequence of a scene (per moment: one launch per layer, surface,

@@ -160,6 +160,11 @@ class SceneLin:
             raise _lib.VSMError("rt_run (linearized): surface %r has no linearized builder here" % (model.surface,))
         arch, FT = model.architecture, model.float_type
         CR._require_gpu(arch)
+        # vsm_elemental_lin_mix forms Z_dot from at most 16 component blocks (1 + 5 NAer: VSM_LIN_CT_MAX of vsm_lin.hip), i.e. three
+        # aerosols; the reference has no such limit, so beyond it the scene takes the host-optics path (Z_dot materialised per
+        # layer and moment, vsm_elemental_lin) from the start instead of failing inside run()
+        if 1 + 5 * NAer > 16:
+            host_optics = True
         self.model, self.lin_model, self.arch, self.FT = model, lin_model, arch, FT
         pol, qp = model.polarization_type, model.quad_points
         self.pol, self.qp = pol, qp

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "build_id.h"
 #include "vsm_internal.h"
 
 namespace vsm {
@@ -414,6 +415,7 @@ extern "C" {
 
 int vsm_version(void) { return 100; /* 0.1.0 */ }
 int vsm_release_scratch(void) { return release_scratch(); }
+const char* vsm_build_id(void) { return VSM_BUILD_ID; }
 int vsm_device_status(int* flags_h, int reset, void* stream) {
   VSM_REQUIRE(flags_h != nullptr, "device_status: null");
   int* d = device_status();

@@ -543,11 +543,7 @@ __global__ __launch_bounds__(64 * RW_WAVES, 1) void k_raman_doubling_wave(
 // LATER products (staging the next right operand, reading it back, writing an intermediate's image, the rider algebra,
 // the output copies), pinned in place by scheduling barriers.  The first phase of the next line (images of ier / iet / r0)
 // rides in the last product of the current one.
-#ifdef RW_NO_PIN
-#define RW_PIN() ((void)0)
-#else
 #define RW_PIN() __builtin_amdgcn_sched_barrier(0)
-#endif
 
 // U units spread over the slots [S0, S1): run those of slot s
 template <int U, int S0, int S1, int s, typename G>

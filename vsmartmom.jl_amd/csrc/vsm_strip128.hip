@@ -266,77 +266,91 @@ __device__ __forceinline__ void add_identity(bstrip<RT>& G, int N, const bpos<RT
 
 // ---- pivoted inverse (the contract of the reference's LU: batch_inv!, cpu_batched.jl:32-47, ext/gpu_batched_cuda.jl:149-179) ----
 // Where the norm bound gives no series order (||E||_F >= 0.3: the last doublings of thick near-conservative layers, bright
-// surfaces -- and anything a caller of the public entry points hands in, spectral radius >= 1 included) the inverse is the
-// register-resident Gauss-Jordan elimination with partial pivoting of vsm_inverse.h (the pivot rule of getrf), as in the kernels
-// of the smaller shapes: M = I - E goes through the A-form's LDS (plain column-major, pitch NP), 256 threads hold it in
-// registers, the result comes back as strips.  Its cost does not depend on the spectral radius (2 N + 2 barriers; a squaring
-// level is two products, and (1 - rho) = 1e-3 would take 15 of them).  Out of line: a cold path must not shape the register
-// allocation of the products.  status (device words, see vsm_device_status): [0] |= VSM_DEVSTAT_SINGULAR on an exactly zero
-// pivot, [1] += 1 per pivoted inverse.
-template <int RT>
-struct gj128_cfg {
-  static constexpr int NPAD = RT <= 6 ? 96 : 128;
-  static constexpr int NT = 256;
-};
-// (LDS is addressed through address_space(3) pointers rebuilt from byte offsets: generic pointers into LDS handed to an
-// out-of-line function trip the gfx950 backend -- "V_CMP_NE_U32 0, src_shared_base: operand has incorrect register class")
+// surfaces -- and anything a caller of the public entry points hands in, spectral radius >= 1 included) the inverse is an
+// in-place Gauss-Jordan elimination with partial pivoting (the pivot rule of getrf: largest |m_ik|, first occurrence) on
+// M = I - E in the A-form's LDS (plain column-major, pitch NP).  LDS-resident on purpose: a dozen registers per lane, so the
+// cold path does not shape the register allocation of the products around it (an out-of-line register-resident elimination
+// cost the product loops 2.5 %).  Lane = row (rows lane, lane + 64), wave w = columns w, w + nw, ...: per pivot step every wave
+// reads column k and finds the pivot row redundantly (DPP maximum + ballot), a barrier, every wave updates its own columns
+// (two broadcast reads, the row interchange folded into the update), a barrier.  The cost does not depend on the spectral
+// radius: 2 N barriers and N^2 LDS read-modify-writes per step (a squaring level is two products, and 1 - rho = 1e-3 would take
+// fifteen of them).  The row interchanges come back as a column permutation `src` that the strip read-back applies.
+// status (device words, vsm_device_status): [0] |= VSM_DEVSTAT_SINGULAR on an exactly zero pivot, [1] += 1 per pivoted inverse.
 using lds_i = __attribute__((address_space(3))) int;
-template <int NPAD>
-struct gjs_lds {   // the members gj_invert expects of its scratch, over LDS at byte address `base`
-  struct rows {
-    lds_d* b;
-    __device__ __forceinline__ lds_d* operator[](int par) const { return b + par * NPAD; }
-  };
-  rows col, rowP, rowK;
-  lds_i *piv, *dst;
-  lds_i& info;
-  __device__ __forceinline__ explicit gjs_lds(unsigned base)
-      : col{reinterpret_cast<lds_d*>((unsigned long long)base)},
-        rowP{reinterpret_cast<lds_d*>((unsigned long long)base) + 2 * NPAD},
-        rowK{reinterpret_cast<lds_d*>((unsigned long long)base) + 4 * NPAD},
-        piv(reinterpret_cast<lds_i*>((unsigned long long)(base + 48u * NPAD))),
-        dst(reinterpret_cast<lds_i*>((unsigned long long)(base + 52u * NPAD))),
-        info(*reinterpret_cast<lds_i*>((unsigned long long)(base + 56u * NPAD))) {}
-};
-constexpr size_t GJS_BYTES = (56 * 128 + 4 + 15) & ~size_t(15);   // LDS behind the kernels' own tables
+constexpr size_t GJS_BYTES = 2 * 128 * sizeof(int);   // piv[128], src[128]: LDS behind the kernels' own tables
 template <int RT>
-__device__ __noinline__ void gj128_core(int N, unsigned af_base, unsigned gjs_base, int* status) {
-  constexpr int NP = 16 * RT, NPAD = gj128_cfg<RT>::NPAD, NT = gj128_cfg<RT>::NT;
-  using C = gj_cfg<NPAD, NT>;
-  lds_d* AF = reinterpret_cast<lds_d*>((unsigned long long)af_base);
-  gjs_lds<NPAD> sc(gjs_base);
-  const int tid = threadIdx.x;
-  if (tid < NT) {
-    const int tr = tid % C::TR, tc = tid / C::TR;
-    gj_regs<double, NPAD, NT> m;
-#pragma unroll
-    for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < C::CB; ++cb) {
-        const int i = tr + C::TR * rb, j = tc * C::CB + cb;
-        m[rb][cb] = (i < N && j < N) ? AF[j * NP + i] : (i == j ? 1.0 : 0.0);
+__device__ __forceinline__ void gj128_lds(int N, lds_d* M, lds_i* piv, lds_i* src, int nw, int* status, const bpos<RT>& p) {
+  constexpr int NP = 16 * RT;
+  const int i0 = p.lane, i1 = p.lane + 64;
+  const bool ok0 = i0 < N, ok1 = i1 < N;
+  bool singular = false;
+  for (int k = 0; k < N; ++k) {
+    const lds_d* ck = M + k * NP;
+    double f0 = ok0 ? ck[i0] : 0.0, f1 = ok1 ? ck[i1] : 0.0;
+    const double v0 = (ok0 && i0 >= k) ? fabs(f0) : -1.0, v1 = (ok1 && i1 >= k) ? fabs(f1) : -1.0;
+    const double best = wave_max(fmax(v0, v1));
+    const unsigned long long m0 = __ballot(v0 >= 0.0 && v0 == best), m1 = __ballot(v1 >= 0.0 && v1 == best);
+    const int pr = m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 64 + __ffsll((long long)m1) - 1 : k);
+    const double ckk = ck[k], pv = ck[pr];   // (broadcast reads)
+    const double d = 1.0 / pv;
+    singular |= pv == 0.0;
+    f0 = (i0 == pr) ? ckk : f0;              // the pivot column after the interchange of rows k and pr
+    f1 = (i1 == pr) ? ckk : f1;
+    if (threadIdx.x == 0) piv[k] = pr;
+    __syncthreads();                         // every wave holds column k
+    for (int j = p.wave; j < N; j += nw) {
+      lds_d* cj = M + j * NP;
+      const bool isk = j == k;
+      const double a = cj[pr], b = cj[k];
+      const double u = isk ? d : a * d;
+      double x0 = ok0 ? cj[i0] : 0.0, x1 = ok1 ? cj[i1] : 0.0;
+      x0 = isk ? 0.0 : ((i0 == pr) ? b : x0);
+      x1 = isk ? 0.0 : ((i1 == pr) ? b : x1);
+      x0 = (i0 == k) ? u : fma(-f0, u, x0);
+      x1 = (i1 == k) ? u : fma(-f1, u, x1);
+      if (ok0) cj[i0] = x0;
+      if (ok1) cj[i1] = x1;
+    }
+    __syncthreads();
+  }
+  // undo the row interchanges as a column permutation of the inverse: for k = N-1 .. 0 swap columns k and piv[k];
+  // src[x] = the column of M that is column x of the inverse (vsm_inverse.h)
+  if (p.wave == 0) {
+    const int lane = p.lane;
+    int s0 = lane, s1 = lane + 64;
+    const int p0 = (lane < N) ? piv[lane] : lane;
+    const int p1 = (lane + 64 < N) ? piv[lane + 64] : lane + 64;
+    for (int k = N - 1; k >= 0; --k) {
+      const int ku = __builtin_amdgcn_readfirstlane(k);
+      const int q = (ku < 64) ? __builtin_amdgcn_readlane(p0, ku) : __builtin_amdgcn_readlane(p1, ku - 64);
+      if (q != ku) {
+        const int sk = (ku < 64) ? __builtin_amdgcn_readlane(s0, ku) : __builtin_amdgcn_readlane(s1, ku - 64);
+        const int sq = (q < 64) ? __builtin_amdgcn_readlane(s0, q) : __builtin_amdgcn_readlane(s1, q - 64);
+        if (ku < 64) {
+          if (lane == ku) s0 = sq;
+        } else {
+          if (lane == ku - 64) s1 = sq;
+        }
+        if (q < 64) {
+          if (lane == q) s0 = sk;
+        } else {
+          if (lane == q - 64) s1 = sk;
+        }
       }
-    gj_invert<double, NPAD, NT>(m, N, sc, tid);   // (2 N + 2 workgroup barriers; the first one orders the loads above)
-#pragma unroll
-    for (int rb = 0; rb < C::RB; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < C::CB; ++cb) {
-        const int i = tr + C::TR * rb, j = sc.dst[tc * C::CB + cb];
-        if (i < N && j < N) AF[j * NP + i] = m[rb][cb];
-      }
-    if (tid == 0) {
-      if (sc.info != 0) atomicOr(&status[0], (int)VSM_DEVSTAT_SINGULAR);
+    }
+    src[lane] = s0;
+    src[lane + 64] = s1;
+    if (lane == 0) {
+      if (singular) atomicOr(&status[0], (int)VSM_DEVSTAT_SINGULAR);
       atomicAdd(&status[1], 1);
     }
-  } else {
-    for (int k = 0; k < 2 * N + 2; ++k) __syncthreads();   // the waves beyond the 256 threads walk the same barriers
   }
   __syncthreads();
 }
 
 struct inv128_ctx {   // what the pivoted path needs beside the strips
   double* AF;         // the A-form's LDS (>= NP * NP doubles)
-  double* gjs;        // GJS_BYTES of LDS
+  double* gjs;        // GJS_BYTES of LDS (pivot rows, column permutation)
   int* status;
 };
 
@@ -362,14 +376,16 @@ __device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, i
         for (int r = 0; r < 4; ++r) mc[16 * ta + 4 * r] = (p.row(ta, r) == p.col ? 1.0 : 0.0) - E.v[ta][r];
     }
     __syncthreads();
-    gj128_core<RT>(N, lds_addr128(cx.AF), lds_addr128(cx.gjs), cx.status);
+    lds_d* M = reinterpret_cast<lds_d*>((unsigned long long)lds_addr128(cx.AF));
+    lds_i* piv = reinterpret_cast<lds_i*>((unsigned long long)lds_addr128(cx.gjs));
+    gj128_lds<RT>(N, M, piv, piv + 128, blockDim.x >> 6, cx.status, p);
     const bool cok = p.mat_wave && p.col < N;
-    const double* mc = cx.AF + (cok ? p.col : 0) * NP + p.kq;
+    const lds_d* gc = M + (cok ? piv[128 + p.col] : 0) * NP + p.kq;
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double v = mc[16 * ta + 4 * r];
+        const double v = gc[16 * ta + 4 * r];
         G.v[ta][r] = (cok && p.row(ta, r) < N) ? v : 0.0;
       }
     return;

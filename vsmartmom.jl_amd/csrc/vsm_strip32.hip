@@ -142,22 +142,11 @@ __device__ __forceinline__ f4_t lds4(const float* p) { return *reinterpret_cast<
 // never depends on its neighbour, so results are independent of the pairing.  The fences order LDS traffic only: global
 // loads and stores are not drained at a barrier (no wave reads global data another wave wrote after the start of the kernel:
 // each wave loads and stores its own 16 columns of the composite; J0+- are read at the start, many barriers before they are
-// written).  -DVSM_SOFT_BARRIER builds the independent-halves variant.
-#ifndef VSM_BAR_SLEEP
-#define VSM_BAR_SLEEP 1
-#endif
+// written).
 __device__ __forceinline__ void half_barrier(const fpos& p) {
-#ifndef VSM_SOFT_BARRIER
   // lockstep build: both points of the workgroup walk the same barrier sequence (the hardware barrier; LDS-only fences)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
   __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-  return;
-#endif
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  p.epoch += FNW;
-  if (p.lane == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while ((int)(__hip_atomic_load(p.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - p.epoch) < 0) __builtin_amdgcn_s_sleep(VSM_BAR_SLEEP);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 struct half_sync {
@@ -302,11 +291,6 @@ __device__ __forceinline__ void dsym_strip(fstrip& d, const fstrip& x, int ns, c
 template <int KB>
 __device__ __forceinline__ void matvec2(const float* A, const float* x1, const float* x2, float scale2, float& y1, float& y2,
                                         const fpos& p) {
-#ifdef VSM_EXP_NOMATVEC
-  y1 = x1[p.l15];
-  y2 = x2[p.l15] * scale2;
-  return;
-#endif
   const float* a0 = A + p.afrag + 16 * LDK * p.wave;
   const float* u0 = x1 + 4 * p.kq;
   const float* v0 = x2 + 4 * p.kq;
@@ -330,9 +314,6 @@ __device__ __forceinline__ void matvec2(const float* A, const float* x1, const f
 }
 template <int KB>
 __device__ __forceinline__ float matvec1(const float* A, const float* x, const fpos& p) {
-#ifdef VSM_EXP_NOMATVEC
-  return x[p.l15];
-#endif
   const float* a0 = A + p.afrag + 16 * LDK * p.wave;
   const float* u0 = x + 4 * p.kq;
   float s1 = 0.f;
@@ -360,10 +341,8 @@ __device__ __forceinline__ float strip_norm_bound(const fstrip& e, fsmem32& sm, 
   float tot = 0.f, tot2 = 0.f;
 #pragma unroll
   for (int w = 0; w < FNW; ++w) tot += sm.red[slot][w];
-#ifndef VSM_SOFT_BARRIER
 #pragma unroll
   for (int w = 0; w < FNW; ++w) tot2 += p.red_other[8 * slot + w];
-#endif
   slot ^= 1;
   nrm_other = sqrtf(tot2) * 1.001f;
   return sqrtf(tot) * 1.001f;
@@ -444,11 +423,9 @@ __device__ __forceinline__ int invert_strip(fstrip& E, fstrip& G, float* W, int 
   const float nrm = strip_norm_bound(E, sm, slot, p, nrm_other);
   const int K = series_order(nrm);
   const int rc = invert_strip_own<KB>(E, G, W, N, sm, p, K);
-#ifndef VSM_SOFT_BARRIER
   // the other point of the workgroup may need more barriers for its inverse: keep the two barrier sequences equal
   const int own = inverse_barriers(K, N), oth = inverse_barriers(series_order(nrm_other), N);
   for (int i = own; i < oth; ++i) half_barrier(p);
-#endif
   return rc;
 }
 template <int KB>
@@ -611,11 +588,7 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
               } else {
                 const float xm = fmax(xi, xj);
                 const float ediff =
-  #ifdef VSM_EXP_NOELEM
-                    (emi - emj);
-  #else
                     (xm < 0.5f && fabs(xi - xj) > 0.125f * xm) ? (emi - emj) : expdiff_neg<float>(xi, xj);
-  #endif
                 tt = w * zp[r] * (mj / (mi - mj)) * wct * ediff;
               }
             } else {
@@ -678,9 +651,6 @@ __device__ __forceinline__ void ed_body(fsmem32& sm, fpos& p, const quad<float>&
   const bool mlead = p.kq == 0;
   VSM_STAMP_DECL;
   VSM_STAMP(0);
-#ifdef VSM_EXP_NODBL
-  ndoubl = min(ndoubl, 0);
-#endif
   for (int n = 0; n < ndoubl; ++n) {
     // on entry: P = r, Q = t (A-form), r_s in registers, all waves past a barrier
     const float* jp = sm.vec[2 * jpair];
@@ -834,11 +804,9 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
     store_strip(Q, Sx, p);
     const int K = series_order(nrm);
     invert_strip_own<KB>(E, G, P, N, sm, p, K);
-#ifndef VSM_SOFT_BARRIER
     // the other point of the workgroup may need more barriers for its inverse: keep the two barrier sequences equal
     const int own = inverse_barriers(K, N), oth = inverse_barriers(series_order(nrm_other), N);
     for (int i = own; i < oth; ++i) half_barrier(p);
-#endif
   }
   VSM_STAMP(12);
   half_barrier(p);            // (d): the series' powers in P no longer read
@@ -888,7 +856,6 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
 }
 
 // Common prologue: the two halves of the 12-wave workgroup (two spectral points), their LDS and barrier counters.
-#ifndef VSM_SOFT_BARRIER
 #define VSM_HALF_PROLOGUE()                                                              \
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];               \
   const int half = threadIdx.x / FNT;                                                    \
@@ -896,16 +863,6 @@ __device__ __forceinline__ void ia_body(fsmem32& sm, fpos& p, int N, int ns, con
   fpos p(min(2 * (int)blockIdx.x + half, S - 1), threadIdx.x % FNT, &sm.bar);            \
   p.active = 2 * (int)blockIdx.x + half < S;                                             \
   p.red_other = &reinterpret_cast<fsmem32*>(smem_raw)[half ^ 1].red[0][0]
-#else
-#define VSM_HALF_PROLOGUE()                                                              \
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];               \
-  const int half = threadIdx.x / FNT;                                                    \
-  fsmem32& sm = reinterpret_cast<fsmem32*>(smem_raw)[half];                              \
-  if (threadIdx.x % FNT == 0) sm.bar = 0;                                                \
-  __syncthreads(); /* the only workgroup-wide barrier: counters initialised */           \
-  fpos p(2 * blockIdx.x + half, threadIdx.x % FNT, &sm.bar);                             \
-  if (p.s >= S) return
-#endif
 
 template <int KB, bool AL>
 __global__ __launch_bounds__(2 * FNT, 3) void k_ia_strip32(int N, int S, composite<float> c, added<float> a) {
@@ -950,15 +907,6 @@ __device__ __forceinline__ void layer_body32(fsmem32& sm, fpos& p, const quad<fl
     }
     return;
   }
-#ifdef VSM_EXP_NOIA
-  if (q.N > 0) {
-    const int s = p.s;
-    const long long NN = (long long)N * N;
-    store_strip_global<AL>(c.R_mp + s * NN, r_s, N, p);
-    store_strip_global<AL>(c.T_pp + s * NN, t_s, N, p);
-    return;
-  }
-#endif
   ia_body<KB, AL>(sm, p, N, ns, c, r_s, t_s, nullptr, nullptr, jpair);
 }
 

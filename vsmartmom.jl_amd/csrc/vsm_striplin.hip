@@ -29,20 +29,6 @@
 #include "vsm_internal.h"
 #include "vsm_strip_dev.h"
 
-#ifndef VSM_EXP
-#define VSM_EXP 0
-#endif
-#define EXP_NO_STORE (VSM_EXP & 1)
-#define EXP_NO_LOAD (VSM_EXP & 2)
-#define EXP_NO_MMA (VSM_EXP & 4)
-#define EXP_NO_STAGE (VSM_EXP & 8)
-#ifndef VSM_EXPD
-#define VSM_EXPD 0
-#endif
-#define EXPD_NO_STORE (VSM_EXPD & 1)
-#define EXPD_NO_MMA (VSM_EXPD & 4)
-#define EXPD_NO_STAGE (VSM_EXPD & 8)
-#define EXPD_PLAIN_STORE (VSM_EXPD & 16)
 
 namespace vsm {
 
@@ -194,6 +180,14 @@ __device__ __forceinline__ void store_strip_global_c(double* __restrict__ g, con
   }
 }
 
+// First of the two spare columns that carry the riders: N rounded up to a k-step -- and never below the 4 KS contraction range
+// of the instantiation (8 <= N <= 32 runs on KS = 9: riders at columns 36, 37; inside the range they would be contracted against
+// the zero padding rows of every right operand, harmless only as long as every source vector is finite).
+template <int KS>
+__device__ __forceinline__ int rider_base(int N) {
+  const int kend = ((N + 3) >> 2) << 2;
+  return (kend < 4 * KS && N <= 32) ? 4 * KS : kend;
+}
 // spare-column access: lanes of the owning wave with col == c1 (A) / c1 + 1 (B)
 struct spare {
   bool own, A, B, AB;
@@ -250,17 +244,17 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
-  const int Kend = ((N + 3) >> 2) << 2;
+  const int Kend = rider_base<KS>(N);
   const spare sp(p, Kend);
   double* xw = sm.xw[p.wave];
   const double k = expk[s];
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
   // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
-  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  // zero rows from their A operand) and the spare columns with their riders sit at or beyond 4 KS (rider_base): never read as k
   auto asis = [](double x, int, int) { return x; };
 
-  if (!EXPD_NO_STAGE) stage_aform_full2(BR, g_r, BT, g_t, N, p);
+  stage_aform_full2(BR, g_r, BT, g_t, N, p);
   if (tid < SNP) {
     jp[tid] = (tid < N) ? a.j0_p[(long long)s * N + tid] : 0.0;
     jm[tid] = (tid < N) ? a.j0_m[(long long)s * N + tid] : 0.0;
@@ -278,16 +272,16 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     sstrip E, r_s;
     load_strip(r_s, BR, p);
     E.zero();
-    if (!EXPD_NO_MMA) mm_ab<KS>(E, BR, r_s, p);
+    mm_ab<KS>(E, BR, r_s, p);
     invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
   }
   sp.put(t_s, p, [&](int row, double) { return jp[row]; }, [&](int row, double) { return jm[row] * k; });
   {
     sstrip tt;
     tt.zero();
-    if (!EXPD_NO_MMA) mm_ab<KS>(tt, BT, G, p);
+    mm_ab<KS>(tt, BT, G, p);
     rt.zero();
-    if (!EXPD_NO_MMA) mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
+    mm_ab<KS>(rt, BR, t_s, p);   // r t  (+ r j0+, r j1-)
     __syncthreads();             // BT (t) and BY (series powers) no longer read
     store_strip(BT, tt, p, asis);
   }
@@ -300,7 +294,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     double* g_at = al.ap_t_pp + (long long)pp * MS + (long long)s * NN;
     double* g_ajp = al.ap_J0_p + (long long)pp * VS + (long long)s * N;
     double* g_ajm = al.ap_J0_m + (long long)pp * VS + (long long)s * N;
-    if (!EXPD_NO_STAGE) stage_aform_full2(BX, g_ar, BY, g_at, N, p);
+    stage_aform_full2(BX, g_ar, BY, g_at, N, p);
     if (tid < SNP) {
       ajp[tid] = (tid < N) ? g_ajp[tid] : 0.0;
       ajm[tid] = (tid < N) ? g_ajm[tid] : 0.0;
@@ -312,14 +306,14 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     {
       sstrip r_s;
       load_r_with_riders(r_s);
-      if (!EXPD_NO_MMA) mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
+      mm_ab2<KS>(X1, Q2, BX, r_s, t_s, p);   // rdot r (+ rdot j0+, rdot j1-) ; rdot t
     }
     {
       sstrip rd, td;   // (scoped: the strips of rdot / tdot are re-read where they are needed again -- register budget)
       load_strip(rd, BX, p);
       load_strip(td, BY, p);
       sp.put(rd, p, [&](int row, double) { return ajp[row]; }, [&](int row, double) { return ajm[row] * k + jm[row] * kl; });
-      if (!EXPD_NO_MMA) mm_ab2<KS>(X1, Q2, BR, rd, td, p);     // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
+      mm_ab2<KS>(X1, Q2, BR, rd, td, p);     // + r rdot (+ r aJ+, r aJ1-)   ; + r tdot
     }
     // v = aJ1- + rdot j0+ + r aJ+ ; u = aJ+ + rdot j1- + r aJ1-   -> spare columns of Q2
     if (sp.own) {
@@ -336,7 +330,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     {
       sstrip Y;
       load_strip(Y, BY, p);      // tdot
-      if (!EXPD_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
+      mm_ab<KS>(Y, BT, X1, p);   // Y = tdot + tt X1
       __syncthreads();           // every wave has read tdot (BY) and is done with rdot's A-form (BX)
       store_strip(BY, Y, p, asis);
     }
@@ -344,7 +338,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     {
       sstrip ttl;
       ttl.zero();
-      if (!EXPD_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
+      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
       store_strip(BX, ttl, p, asis);
     }
     sstrip rd, tdn;
@@ -352,14 +346,14 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
     sp.put(rd, p, [&](int row, double) { return ajm[row]; }, [&](int row, double) { return ajp[row] * k + jp[row] * kl; });
     tdn.zero();
     __syncthreads();   // ttdot complete in BX
-    if (!EXPD_NO_MMA) mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);   // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
+    mm_ab2<KS>(rd, tdn, BX, rt, t_s, p);   // rdot += ttdot rt (+ ttdot A, ttdot B) ; tdot' = ttdot t
     {
       sstrip td;
       load_strip_global_c(td, g_at, N, p, xw);
-      if (!EXPD_NO_MMA) mm_ab2<KS>(rd, tdn, BT, Q2, td, p);    // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
+      mm_ab2<KS>(rd, tdn, BT, Q2, td, p);    // rdot += tt Q2 (+ tt v, tt u)          ; tdot' += tt tdot
     }
-    if (EXPD_PLAIN_STORE) store_strip_global(g_ar, rd, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_ar, rd, N, p, xw);
-    if (EXPD_PLAIN_STORE) store_strip_global(g_at, tdn, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_at, tdn, N, p, xw);
+    store_strip_global_c(g_ar, rd, N, p, xw);
+    store_strip_global_c(g_at, tdn, N, p, xw);
     sp.get(rd, p, N, g_ajm, g_ajp);
     if (tid == 0) ekl[s + (long long)S * pp] = 2.0 * k * kl;
     __syncthreads();   // BX, BY, aJ+- free for the next parameter
@@ -371,9 +365,9 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_step(int N, int S, int P, do
   sp.put(r_s, p, [&](int row, double) { return jm[row]; }, [&](int row, double) { return jp[row] * k; });
   sstrip tn;
   tn.zero();
-  if (!EXPD_NO_MMA) mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
-  if (EXPD_PLAIN_STORE) store_strip_global(g_r, r_s, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_r, r_s, N, p, xw);
-  if (EXPD_PLAIN_STORE) store_strip_global(g_t, tn, N, p); else if (!EXPD_NO_STORE) store_strip_global_c(g_t, tn, N, p, xw);
+  mm_ab2<KS>(r_s, tn, BT, rt, t_s, p);
+  store_strip_global_c(g_r, r_s, N, p, xw);
+  store_strip_global_c(g_t, tn, N, p, xw);
   sp.get(r_s, p, N, a.j0_m + (long long)s * N, a.j0_p + (long long)s * N);
   if (tid == 0) expk[s] = k * k;
 }
@@ -401,7 +395,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
-  const int Kend = ((N + 3) >> 2) << 2;
+  const int Kend = rider_base<KS>(N);
   const spare sp(p, Kend);
   double* xw = sm.xw[p.wave];
   double k = expk[s];
@@ -409,7 +403,7 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   double* g_r = a.r_mp + (long long)s * NN;
   double* g_t = a.t_pp + (long long)s * NN;
   // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
-  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  // zero rows from their A operand) and the spare columns with their riders sit at or beyond 4 KS (rider_base): never read as k
   auto asis = [](double x, int, int) { return x; };
   // a strip with its two spare columns cleared (they carry riders during a product)
   auto clean = [&](sstrip& x) { sp.put(x, p, [](int, double) { return 0.0; }, [](int, double) { return 0.0; }); };
@@ -642,17 +636,15 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   p.bind(sm.BR);
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
-  const int Kend = ((N + 3) >> 2) << 2;
+  const int Kend = rider_base<KS>(N);
   const spare sp(p, Kend);
   double* xw = sm.xw[p.wave];
   // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
-  // zero rows from their A operand) and the columns >= 4 KS -- the spare columns with their riders -- are never read as k
+  // zero rows from their A operand) and the spare columns with their riders sit at or beyond 4 KS (rider_base): never read as k
   auto asis = [](double x, int, int) { return x; };
   auto keep_old = [](int, double o) { return o; };
 
-#ifdef VSM_IA_LIN_ASYNC_LOADS
-  // (experiment, not the default: 580 B/lane of scratch, 9 % slower) ---- every global strip / A-form is REQUESTED a phase before it is used and transposed where it is needed -------------------
-  raw_strip w_er, w_s2;
+  raw_strip w_er, w_s2;      // requested before the A-form staging: the two round trips overlap
   issue_strip_load(w_er, h.ER + s * h.sER, N, p);
   issue_strip_load(w_s2, h.S2 + s * h.sS2, N, p);
   stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
@@ -666,13 +658,6 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   sstrip er, s2, G, rt;
   finish_strip_load(er, w_er, p, xw);
   finish_strip_load(s2, w_s2, p, xw);
-  raw_strip w_d1, w_d2;      // the first parameter's strips fly behind the forward products
-  raw_aform w_pa;
-  if (P > 0) {
-    issue_strip_load(w_d1, h.D1 + s * h.sD1, N, p);
-    issue_strip_load(w_d2, h.D2 + s * h.sD2, N, p);
-    issue_aform_load(w_pa, h.PA + s * h.sPA, N, p);
-  }
   int slot = 0;
   {
     sstrip E;
@@ -693,14 +678,13 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
   __syncthreads();   // tt complete in BT
 
+  // Global strip loads are issued one phase ahead of their use (before the preceding barrier): with one wave per SIMD
+  // nothing else hides their latency.
   for (int pp = 0; pp < P; ++pp) {
     sstrip d1, d2;
-    finish_strip_load(d1, w_d1, p, xw);
-    finish_strip_load(d2, w_d2, p, xw);
-    finish_aform_load(BX, w_pa, p);
-    raw_strip w_y, w_acc;      // needed after the four X products
-    issue_strip_load(w_y, h.YI + s * h.sYI + pp * h.pYI, N, p);
-    issue_strip_load(w_acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
+    load_strip_global_c(d1, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
+    load_strip_global_c(d2, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
+    stage_aform_full(BX, h.PA + s * h.sPA + pp * h.pPA, N, p);
     if (tid < SNP) {
       const long long o = (long long)pp * VS + (long long)s * N + tid;
       vdr[tid] = (tid < N) ? h.VDR[o] : 0.0;
@@ -715,17 +699,14 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
     mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
     sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
-    raw_strip w_s3, w_d3;      // needed after Y and ttdot
-    issue_strip_load(w_s3, h.S3 + s * h.sS3, N, p);
-    issue_strip_load(w_d3, h.D3 + s * h.sD3 + pp * h.pD3, N, p);
     {
       sstrip Y;
-      finish_strip_load(Y, w_y, p, xw);
+      load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
       mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
       store_strip(BY, Y, p, asis);
     }
     sstrip acc;
-    finish_strip_load(acc, w_acc, p, xw);
+    load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
     __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
     {
       sstrip ttl;
@@ -736,15 +717,10 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
     sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
     sstrip tdn, s3;
     tdn.zero();
-    finish_strip_load(s3, w_s3, p, xw);
-    if (pp + 1 < P) {          // the next parameter's strips fly behind the last four products
-      issue_strip_load(w_d1, h.D1 + s * h.sD1 + (pp + 1) * h.pD1, N, p);
-      issue_strip_load(w_d2, h.D2 + s * h.sD2 + (pp + 1) * h.pD2, N, p);
-      issue_aform_load(w_pa, h.PA + s * h.sPA + (pp + 1) * h.pPA, N, p);
-    }
+    load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
     __syncthreads();   // ttdot complete in BX
     mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
-    finish_strip_load(s3, w_d3, p, xw);
+    load_strip_global_c(s3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
     mm_ab2<KS>(acc, tdn, BT, X2, s3, p);   // + tt X2 ; + tt D3
     store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
     store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
@@ -763,103 +739,6 @@ __global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_
   }
   store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
   store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
-#else
-  raw_strip w_er, w_s2;      // requested before the A-form staging: the two round trips overlap
-  issue_strip_load(w_er, h.ER + s * h.sER, N, p);
-  issue_strip_load(w_s2, h.S2 + s * h.sS2, N, p);
-  if (!EXP_NO_STAGE) stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
-  if (tid < SNP) {
-    const long long o = (long long)s * N + tid;
-    vr[tid] = (tid < N) ? h.VR[o] : 0.0;
-    vadd[tid] = (tid < N) ? h.VADD[o] : 0.0;
-    vacc[tid] = (tid < N) ? h.VACC[o] : 0.0;
-  }
-  __syncthreads();
-  sstrip er, s2, G, rt;
-  finish_strip_load(er, w_er, p, xw);
-  finish_strip_load(s2, w_s2, p, xw);
-  int slot = 0;
-  {
-    sstrip E;
-    E.zero();
-    if (!EXP_NO_MMA) mm_ab<KS>(E, BR, er, p);
-    invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
-  }
-  sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
-  {
-    sstrip tt;
-    tt.zero();
-    if (!EXP_NO_MMA) mm_ab<KS>(tt, BT, G, p);
-    rt.zero();
-    if (!EXP_NO_MMA) mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
-    __syncthreads();            // BT (LT) and BY (series powers) no longer read
-    store_strip(BT, tt, p, asis);
-  }
-  sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
-  __syncthreads();   // tt complete in BT
-
-  // Global strip loads are issued one phase ahead of their use (before the preceding barrier): with one wave per SIMD
-  // nothing else hides their latency.
-  for (int pp = 0; pp < P; ++pp) {
-    sstrip d1, d2;
-    if (EXP_NO_LOAD) d1.zero(); else load_strip_global_c(d1, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
-    if (EXP_NO_LOAD) d2.zero(); else load_strip_global_c(d2, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
-    if (!EXP_NO_STAGE) stage_aform_full(BX, h.PA + s * h.sPA + pp * h.pPA, N, p);
-    if (tid < SNP) {
-      const long long o = (long long)pp * VS + (long long)s * N + tid;
-      vdr[tid] = (tid < N) ? h.VDR[o] : 0.0;
-      vdadd[tid] = (tid < N) ? h.VDADD[o] : 0.0;
-      vdacc[tid] = (tid < N) ? h.VDACC[o] : 0.0;
-    }
-    __syncthreads();
-    sstrip X1, X2;
-    X1.zero();
-    X2.zero();
-    if (!EXP_NO_MMA) mm_ab2<KS>(X1, X2, BX, er, s2, p);   // PA ER ; PA S2 (+ PA VR)
-    sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
-    if (!EXP_NO_MMA) mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
-    sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
-    {
-      sstrip Y;
-      if (EXP_NO_LOAD) Y.zero(); else load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
-      if (!EXP_NO_MMA) mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
-      store_strip(BY, Y, p, asis);
-    }
-    sstrip acc;
-    if (EXP_NO_LOAD) acc.zero(); else load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
-    __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
-    {
-      sstrip ttl;
-      ttl.zero();
-      if (!EXP_NO_MMA) mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, asis);
-    }
-    sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
-    sstrip tdn, s3;
-    tdn.zero();
-    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
-    __syncthreads();   // ttdot complete in BX
-    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
-    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
-    if (!EXP_NO_MMA) mm_ab2<KS>(acc, tdn, BT, X2, s3, p);   // + tt X2 ; + tt D3
-    if (!EXP_NO_STORE) store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
-    if (!EXP_NO_STORE) store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
-    sp.get(acc, p, N, h.VDOUT + (long long)pp * VS + (long long)s * N, nullptr);
-    __syncthreads();   // BX, BY, the parameter's vectors free
-  }
-
-  sstrip acc0, tn;
-  if (EXP_NO_LOAD) acc0.zero(); else load_strip_global_c(acc0, h.ACC0 + s * h.sACC0, N, p, xw);
-  sp.put(acc0, p, [&](int row, double) { return vacc[row]; }, keep_old);
-  tn.zero();
-  {
-    sstrip s3;
-    if (EXP_NO_LOAD) s3.zero(); else load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
-    if (!EXP_NO_MMA) mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
-  }
-  if (!EXP_NO_STORE) store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
-  if (!EXP_NO_STORE) store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
-#endif
   sp.get(acc0, p, N, h.VOUT + (long long)s * N, nullptr);
 }
 

@@ -484,12 +484,19 @@ class SolarBeam:
 
 class ThermalEmission:
     """ThermalEmission (Sources/thermal_emission.jl): per-layer Planck volume source.  `ThermalEmission(B_layer=B)` with
-    B [Nz, nSpec], or `ThermalEmission(T_layers, nu)` which evaluates planck_spectrum_wn per layer."""
+    B [Nz, nSpec], or `ThermalEmission(T_layers, nu)` which evaluates planck_spectrum_wn per layer.
 
-    def __init__(self, T_layers=None, nu=None, B_layer=None):
+    `reset_slot_in_nonscattering_layers` (default False = the reference as written): rt_kernel! resets the `:thermal` slot of
+    the AddedLayer only in its scatter branch (rt_kernel.jl:217-221); a non-scattering layer therefore interacts with the doubled
+    slot the last scattering layer before it left in place, and a column that BEGINS with non-scattering layers carries the slot
+    of moment m = 0 into moment m = 1.  True selects the corrected variant (a non-scattering layer emits nothing and carries
+    nothing over)."""
+
+    def __init__(self, T_layers=None, nu=None, B_layer=None, reset_slot_in_nonscattering_layers: bool = False):
         if B_layer is None and T_layers is not None:
             B_layer = np.stack([planck_spectrum_wn(float(T), nu) for T in T_layers])
         self.B_layer = None if B_layer is None else np.atleast_2d(np.asarray(B_layer, dtype=np.float64))
+        self.reset_slot_in_nonscattering_layers = bool(reset_slot_in_nonscattering_layers)
 
 
 @dataclass

@@ -58,34 +58,68 @@ def init_process_group_from_env(backend: Optional[str] = None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == "nccl":
+            # create the RCCL communicator with every rank present: the data path's gather is a group of point-to-point
+            # transfers in which a rank with an empty block takes no part
+            dist.all_reduce(torch.zeros(1, device="cuda"))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, world, local
 
 
 def gather_spectral(local, S_total: int, rank: int, world: int, dst: int = 0):
-    """Gather per-rank results whose FIRST axis is the local spectral block onto `dst`.
+    """Gather per-rank results whose FIRST axis is the local spectral block onto `dst` -- the ONE collective step of the data path.
 
-    `local` is a torch tensor of shape (S_local, ...) (device tensor under nccl, CPU under gloo).
-    Returns the concatenated (S_total, ...) tensor on `dst`, None elsewhere.  Blocks are padded
-    to the common block size because gather needs equal shapes."""
+    `local` is a torch tensor of shape (S_local, ...) (device tensor under nccl, CPU under gloo).  Returns the concatenated
+    (S_total, ...) tensor on `dst`, None elsewhere.  The blocks are ragged when world does not divide S_total (the last ranks
+    own fewer points, or none), so the step is one group of point-to-point transfers (ncclGroupStart/End under RCCL): every rank
+    sends exactly its block, `dst` receives each block straight into its rows of the output -- no padding to a common block
+    size, no concatenation copy."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local
-    per = -(-S_total // world)
-    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dst)
+    local = local.contiguous()
+    if local.shape[0] != shard_bounds(S_total, rank, world)[1] - shard_bounds(S_total, rank, world)[0]:
+        raise ValueError("gather_spectral: rank %d holds %d points, its block has %d" % (
+            rank, local.shape[0], shard_bounds(S_total, rank, world)[1] - shard_bounds(S_total, rank, world)[0]))
     if rank != dst:
+        if local.shape[0] > 0:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst)]):
+                w.wait()
         return None
-    out = torch.cat(bufs, dim=0)
-    return out[:S_total]
+    out = torch.empty((S_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    ops = []
+    for r in range(world):
+        lo, hi = shard_bounds(S_total, r, world)
+        if hi <= lo:
+            continue
+        if r == dst:
+            out[lo:hi] = local
+        else:
+            ops.append(dist.P2POp(dist.irecv, out[lo:hi], r))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return out
+
+
+def pack_RT(R, T):
+    """R, T (S_local, nStokes, nVZA) -> ONE buffer (S_local, 2 nStokes nVZA) per rank, so that the gather is one step."""
+    import torch
+    flat = lambda t: t.reshape(t.shape[0], int(np.prod(t.shape[1:])))     # (an empty block keeps its column count)
+    return torch.cat([flat(R), flat(T)], dim=1)
+
+
+def unpack_RT(g, n: int, nV: int):
+    """The gathered buffer (S, 2 n nV) -> host arrays R, T in the reference's axis order [nVZA, nStokes, nSpec]."""
+    g = g.detach().cpu().numpy()
+    S, k = g.shape[0], n * nV
+    return (g[:, :k].reshape(S, n, nV).transpose(2, 1, 0).copy(), g[:, k:2 * k].reshape(S, n, nV).transpose(2, 1, 0).copy())
 
 
 def rt_run_sharded(model, executor: Optional[Callable] = None, rank: int = 0, world: int = 1, dst: int = 0):
-    """rt_run over this rank's spectral block + gather on `dst`.
+    """rt_run over this rank's spectral block + ONE gather of the packed R | T on `dst` (what bench.make_step times).
 
     `executor(model, spec_slice) -> (R, T)` returns tensors shaped (S_local, nStokes, nVZA); the default
     is the HIP engine (`CoreRT.prepare_scene(model, slice).run()`).  Returns host arrays
@@ -99,12 +133,11 @@ def rt_run_sharded(model, executor: Optional[Callable] = None, rank: int = 0, wo
             scene = core_rt.prepare_scene(mdl, s)
             return scene.run()
     R, T = executor(model, sl)
-    Rg = gather_spectral(R, S, rank, world, dst)
-    Tg = gather_spectral(T, S, rank, world, dst)
+    n, nV = int(R.shape[1]), int(R.shape[2])
+    g = gather_spectral(pack_RT(R, T), S, rank, world, dst)
     if rank != dst:
         return None, None
-    to_np = lambda t: t.detach().cpu().numpy().transpose(2, 1, 0).copy()
-    return to_np(Rg), to_np(Tg)
+    return unpack_RT(g, n, nV)
 
 
 def rt_run_lin_sharded(model, lin_model, NAer: int, NGas: int, NSurf: int, executor: Optional[Callable] = None, rank: int = 0,
@@ -128,8 +161,8 @@ def rt_run_lin_sharded(model, lin_model, NAer: int, NGas: int, NSurf: int, execu
     R, T, Rd, Td = executor(model, lin_model, sl)
     P = Rd.shape[0]
     Sl, n, nV = R.shape
-    packed = torch.cat([R.reshape(Sl, -1), T.reshape(Sl, -1), Rd.permute(1, 0, 2, 3).reshape(Sl, -1),
-                        Td.permute(1, 0, 2, 3).reshape(Sl, -1)], dim=1).contiguous()
+    packed = torch.cat([R.reshape(Sl, n * nV), T.reshape(Sl, n * nV), Rd.permute(1, 0, 2, 3).reshape(Sl, P * n * nV),
+                        Td.permute(1, 0, 2, 3).reshape(Sl, P * n * nV)], dim=1).contiguous()
     g = gather_spectral(packed, S, rank, world, dst)
     if rank != dst:
         return None, None, None, None
