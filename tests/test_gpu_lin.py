@@ -62,7 +62,10 @@ def _al_host(vsm, al):
 
 
 @pytest.mark.parametrize("pol_name,l_trunc", [("I", 5), ("IQU", 9), ("IQUV", 7),
-                                              ("I", 71), ("IQU", 27), ("IQUV", 25), ("IQU", 33)])   # N = 38, 48, 60, 57: fused strip step
+                                              ("I", 71), ("IQU", 27), ("IQUV", 25), ("IQU", 33),   # N = 38, 48, 64, 57: fused strip step
+                                              # k_dbl128_lin (vsm_strip128lin.hip): N = 62, 63, 72, 80, 96, 112, 127, 128
+                                              ("I", 117), ("IQU", 35), ("IQU", 41), ("IQUV", 33), ("IQUV", 41), ("IQUV", 49),
+                                              ("I", 247), ("IQUV", 57)])
 @pytest.mark.parametrize("ndoubl", [0, 3, -2])   # -2: two doublings of THICK layers (every inverse path of the fused step)
 @pytest.mark.parametrize("n_layer_params", [3, 1, 2])   # 1, 2: all doubling steps in ONE launch (k_dbl_lin_multi) for 32 < N <= 60
 def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl, n_layer_params):
@@ -114,7 +117,9 @@ def test_elemental_and_doubling_lin(vsm, arch, pol_name, l_trunc, ndoubl, n_laye
 
 
 @pytest.mark.parametrize("iface", ["11", "00", "01", "10"])
-@pytest.mark.parametrize("N,shared", [(12, False), (60, False), (36, True)])
+@pytest.mark.parametrize("N,shared", [(12, False), (60, False), (36, True),
+                                      # k_ia128_lin (vsm_strip128lin.hip)
+                                      (62, False), (64, True), (72, False), (96, False), (112, True), (127, False), (128, False)])
 def test_interaction_lin(vsm, arch, N, shared, iface):
     FT = np.float64
     rng = np.random.default_rng(3)
@@ -162,7 +167,7 @@ def test_interaction_lin(vsm, arch, N, shared, iface):
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33),   # N = 7, 21, 57 (fused strip kernels)
-                                         ("IQU", 37), ("IQUV", 43),          # N = 66, 100: operator level (LDS-staged products)
+                                         ("IQUV", 25), ("IQU", 37), ("IQUV", 43), ("IQUV", 49), ("IQUV", 57),   # N = 64, 66, 100, 112, 128: vsm_strip128lin.hip
                                          ("IQUV", 61)])                      # N = 136: past every on-chip kernel (global-memory inverse)
 def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     """rt_run(model, lin_model, 0, NGas, 1): R, T and the Jacobians vs the oracle; the albedo Jacobian also vs a
@@ -187,6 +192,30 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
     fd = (Rp - R0) / h
     err = np.abs(fd - Rd[..., 2]) / np.abs(fd).max()
     assert err.max() < 1e-3 and err.mean() < 1e-4
+
+
+@pytest.mark.parametrize("pol,l_trunc,N", [("IQUV", 25, 64), ("IQU", 41, 72)])
+def test_strip128lin_persistent_workgroups_walk_the_spectral_axis(vsm, arch, pol, l_trunc, N):
+    """k_dbl128_lin / k_ia128_lin are persistent (grid = CUs, two per CU at four row tiles): with more spectral points than
+    workgroups every workgroup walks several points -- 1100 points tiled from 3 must reproduce the 3-point run bit for bit."""
+    rng = np.random.default_rng(4)
+    S0, L, rep = 3, 2, 367
+    H = vsm.host_model
+    ga0 = 10.0 ** rng.uniform(-2.5, -0.5, (S0, L))
+    geo = (pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0])
+
+    def run(ga):
+        S = ga.shape[0]
+        kw = dict(tau_rayl=np.tile(0.03 * np.ones(L), (S, 1)), tau_abs=ga, depol=0.0279, m_max=1)
+        pm = H.model_from_arrays(arch, *geo, albedo=0.2, **kw)
+        assert pm.quad_points.Nquad * pm.polarization_type.n == N
+        return vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga]), 0, 1, 1)
+    small = run(ga0)
+    big = run(np.tile(ga0, (rep, 1)))
+    for a, b in zip(small, big):
+        b = np.moveaxis(b, 2, 0).reshape((rep, S0) + tuple(np.moveaxis(b, 2, 0).shape[1:]))
+        a = np.moveaxis(a, 2, 0)
+        assert np.array_equal(b, np.broadcast_to(a, b.shape))
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 9), ("IQU", 33)])   # N = 21 (operator level), 57 (fused strip kernels)

@@ -169,7 +169,14 @@ def lib():
     for name, (res, args) in _SIGS.items():
         for T, R in (("f64", C.c_double), ("f32", C.c_float)):
             n = name.format(T=T)
-            fn = getattr(L, n)
+            try:
+                fn = getattr(L, n)
+            except AttributeError:
+                if os.environ.get("VSM_LIB_PATH"):     # an A/B build of an earlier round may lack the newest entry points
+                    if "{T}" not in name:
+                        break
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = [R if a == "{R}" else a for a in args]
             if "{T}" not in name:
@@ -182,7 +189,7 @@ def build_info() -> dict:
     """Identity of the loaded library: `source_hash` = vsm_build_id() (SHA-256 prefix over the library's sources, compiled in),
     plus what csrc/Makefile wrote next to it (the commit checked out at build time)."""
     import json
-    info = {"source_hash": lib().vsm_build_id().decode()}
+    info = {"source_hash": lib().vsm_build_id().decode() if hasattr(lib(), "vsm_build_id") else None}
     try:
         with open(os.path.join(os.path.dirname(LIB_PATH), "BUILD_INFO.json")) as f:
             side = json.load(f)

@@ -266,6 +266,13 @@ bool strip128_supported(int N);
 int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st);
 int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 
+// ---- linearized column-strip kernels, FP64, 60 < N <= 128 (one A-form, parked strips): vsm_strip128lin.hip ----
+bool strip128_lin_supported(int N);
+int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
+                          const added_lin<double>& al, hipStream_t st);
+int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
+                               const added_lin<double>& al, hipStream_t st);
+
 // Library-owned device scratch, keyed by (current device, stream, slot): two streams -- or two devices driven from one
 // process -- never share a buffer, so the entry points that use it keep the contract "calls on one stream are ordered, calls on
 // different streams are independent".  Grow-only per key; a buffer that is outgrown is retired behind an event recorded on

@@ -28,9 +28,7 @@
 // so that a fragment read (lanes = (k', m); ds_read_b64 in 32-lane groups, or ds_read2st64_b64 for two row tiles in 16-lane
 // groups) covers its part of the 512-byte block linearly, and a strip store (ds_write_b64, 16-lane groups = 16 columns = four
 // k-steps x four k': k' | j << 2 is the lane's l15) hits 16 distinct 8-byte slots of a 128-byte bank row.
-#include "vsm_internal.h"
-#include "vsm_inverse.h"
-#include "vsm_lds.h"
+#include "vsm_strip128_dev.h"
 
 namespace vsm {
 #ifdef VSM_PHASE_TIMING   // diagnostic build (make timing; tools/phase_timing128.py): cycles per phase of k_ia128, every workgroup
@@ -59,404 +57,6 @@ __device__ unsigned long long vsm_phase_cycles_128[64];   // k_ia128: 0..17, poi
 #define B128_STAMP_FLUSH_AT(b, c, n) (void)(n)
 #endif
 namespace {
-
-using lds_d = __attribute__((address_space(3))) double;
-__device__ __forceinline__ unsigned lds_addr128(const void* p) {
-  return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
-}
-__device__ __forceinline__ double dpp_swap1_128(double x) {   // value of lane ^ 1
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-constexpr int B_MAXW = 8;   // waves per workgroup at most
-// A pointer that went through an empty asm (to keep LICM from hoisting every derived address) comes back as a GENERIC pointer:
-// its accesses would be flat_load / flat_store, which count on lgkmcnt as well -- every LDS wait of the products and every
-// barrier would then wait for the parked strips and the operand loads.  Cast back to the global address space.
-using gd4_p = __attribute__((address_space(1))) d4_t*;
-using gcd4_p = const __attribute__((address_space(1))) d4_t*;
-using gd_p = __attribute__((address_space(1))) double*;
-using gcd_p = const __attribute__((address_space(1))) double*;
-
-template <int RT>
-struct bstrip {
-  d4_t v[RT];
-  __device__ __forceinline__ void zero() {
-#pragma unroll
-    for (int a = 0; a < RT; ++a) v[a] = acc_zero<double>();
-  }
-};
-
-template <int RT>
-struct bpos {
-  int lane, wave, l15, kq, col;
-  unsigned ab[4][2];   // fragment bases (bytes) by (ks & 3, ks >= 16)
-  unsigned sb[4];      // strip element bases by r
-  bool mat_wave;       // the wave's columns are columns of the A-form (wave < RT)
-  int ksn;             // k-steps that hold columns < N: ceil(N / 4) (the products skip the all-padding tail, up to three of 4 RT)
-  __device__ __forceinline__ bpos(unsigned af, int N) {
-    ksn = (N + 3) >> 2;
-    lane = threadIdx.x & 63;
-    wave = threadIdx.x >> 6;
-    l15 = lane & 15;
-    kq = lane >> 4;
-    col = 16 * wave + l15;
-    mat_wave = wave < RT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      ab[j][0] = af + 8u * (unsigned)((kq << 4) | (l15 ^ (kq | (j << 2))));
-      ab[j][1] = ab[j][0] + 8u * 64u * 16u * RT;
-    }
-    const int j = l15 >> 2, ww = mat_wave ? wave : 0;   // (a wave without matrix columns gets valid addresses it never stores to)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      sb[r] = af + 8u * (unsigned)(((4 * ww + j) * RT * 64) + (((l15 & 3) << 4) | (kq ^ (l15 & 3)) | ((r ^ j) << 2)));
-  }
-  __device__ __forceinline__ int row(int ta, int r) const { return 16 * ta + kq + 4 * r; }
-  __device__ __forceinline__ const lds_d* aptr(int t, int ks) const {
-    const int h = ks >= 16 ? 1 : 0;
-    return reinterpret_cast<const lds_d*>((unsigned long long)ab[ks & 3][h]) + 64 * ((ks - 16 * h) * RT + t);
-  }
-  __device__ __forceinline__ lds_d* sptr(int ta, int r) const {
-    return reinterpret_cast<lds_d*>((unsigned long long)sb[r]) + 64 * ta;
-  }
-  // hide the loop invariance of the bases from LICM (it would hoist every derived address into a register)
-  __device__ __forceinline__ void opaque() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      asm volatile("" : "+v"(ab[j][0]));
-      asm volatile("" : "+v"(ab[j][1]));
-    }
-  }
-};
-
-// acc += [A] * B.  One register per row tile for the fragments: the fragment of tile t for step ks + 1 is requested right
-// behind the MFMA that consumed its predecessor (RT MFMAs = 64 RT cycles ahead of its use).
-template <int RT>
-__device__ __forceinline__ void mm128(bstrip<RT>& acc, const bstrip<RT>& B, bpos<RT>& p) {
-  constexpr int KS = 4 * RT;
-  p.opaque();
-  double a[RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) a[t] = *p.aptr(t, 0);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks >= KS - 3 && ks >= p.ksn) break;   // (uniform) N > 16 (RT - 1): only the last three k-steps can be all padding
-    const double b = B.v[ks >> 2][ks & 3];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      acc.v[t] = mfma<double>::mma(a[t], b, acc.v[t]);
-      if (ks + 1 < KS) a[t] = *p.aptr(t, ks + 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// The source vectors where the strips have no spare column (N = 127, 128): wave w forms row tile w of [A] (x_0 | x_1) for the two
-// vectors of the LDS table at byte address xb (lane: (l15 & 1) NP + kq; every even / odd column of the tile holds the same
-// product) -- 4 RT MFMAs more behind the product of the same [A], two accumulation chains.
-template <int RT>
-__device__ __forceinline__ void rider_tile(d4_t& yr, unsigned xb, bpos<RT>& p) {
-  constexpr int KS = 4 * RT;
-  p.opaque();
-  const unsigned wo = 512u * (unsigned)p.wave;
-  auto afr = [&](int ks) {
-    const int h = ks >= 16 ? 1 : 0;
-    return *(reinterpret_cast<const lds_d*>((unsigned long long)(p.ab[ks & 3][h] + wo)) + 64 * ((ks - 16 * h) * RT));
-  };
-  auto xfr = [&](int ks) { return *(reinterpret_cast<const lds_d*>((unsigned long long)xb) + 4 * ks); };
-  d4_t y1 = acc_zero<double>();
-#pragma unroll
-  for (int ks = 0; ks < KS; ks += 2) {
-    yr = mfma<double>::mma(afr(ks), xfr(ks), yr);
-    y1 = mfma<double>::mma(afr(ks + 1), xfr(ks + 1), y1);
-  }
-  yr += y1;
-}
-template <int RT>
-__device__ __forceinline__ void mm128r(bstrip<RT>& acc, const bstrip<RT>& B, d4_t& yr, unsigned xb, bpos<RT>& p) {
-  mm128(acc, B, p);
-  rider_tile(yr, xb, p);
-}
-
-// strip -> A-form (columns >= N, i.e. the riders and the padding, as zeros); waves without matrix columns stay out
-template <int RT>
-__device__ __forceinline__ void store_af(const bstrip<RT>& s, int N, const bpos<RT>& p) {
-  if (!p.mat_wave) return;
-  const bool keep = p.col < N;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) *p.sptr(ta, r) = keep ? s.v[ta][r] : 0.0;
-}
-template <int RT>
-__device__ __forceinline__ void load_af(bstrip<RT>& s, const bpos<RT>& p) {
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) s.v[ta][r] = *p.sptr(ta, r);
-}
-// strip <-> the wave's slot of the workgroup's global scratch (lane-linear 32-byte records)
-template <int RT>
-__device__ __forceinline__ void spill(d4_t* g, const bstrip<RT>& s, const bpos<RT>& p) {
-  asm volatile("" : "+v"(g));   // (the per-tile addresses are formed here, not hoisted out of the doubling loop into registers)
-  gd4_p gg = (gd4_p)g;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta) gg[64 * ta] = s.v[ta];
-}
-template <int RT>
-__device__ __forceinline__ void fill(bstrip<RT>& s, const d4_t* g, const bpos<RT>& p) {
-  asm volatile("" : "+v"(g));
-  gcd4_p gg = (gcd4_p)g;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta) s.v[ta] = gg[64 * ta];
-}
-
-// Frobenius-norm bound of the N x N block (rows >= N are zero by construction).  ONE barrier inside.
-template <int RT>
-__device__ __forceinline__ double norm128(const bstrip<RT>& e, int N, int nw, float* red, int& slot, const bpos<RT>& p) {
-  double ss = 0;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ss = fma(e.v[ta][r], e.v[ta][r], ss);
-  ss = (p.col < N) ? ss : 0.0;
-  const float ws = wave_sum(to_float_up(ss));
-  if (p.lane == 0) red[16 * slot + p.wave] = ws;
-  __syncthreads();
-  float tot = 0.f;
-  for (int w = 0; w < nw; ++w) tot += red[16 * slot + w];
-  slot ^= 1;
-  return (double)(sqrtf(tot) * 1.001f);
-}
-
-// order of the Neumann series (vsm_strip_dev.h series_order); 0 = the norm bound is not below 0.3 (or not a number): pivoted inverse
-__device__ __forceinline__ int series_order128(double nrm) {
-  const double tol = num<double>::eps() * 0.25;
-  int K = 0;
-  if (nrm < 0.3) {
-    const double lim = tol * (1.0 - nrm);
-    const double n2 = nrm * nrm, n4 = n2 * n2, n8 = n4 * n4, n16 = n8 * n8;
-    if (n2 <= lim) K = 1;
-    else if (n2 * nrm <= lim) K = 2;
-    else if (n4 <= lim) K = 3;
-    else if (n4 * nrm <= lim) K = 4;
-    else if (n8 <= lim) K = 7;
-    else if (n8 * nrm <= lim) K = 8;
-    else if (n16 <= lim) K = 15;
-    else if (n16 * nrm <= lim) K = 16;
-    else if (n16 * n16 <= lim) K = 31;
-  }
-  return K;
-}
-
-template <int RT>
-__device__ __forceinline__ void add_identity(bstrip<RT>& G, int N, const bpos<RT>& p) {
-  // a lane owns at most one diagonal element, in row tile ta = wave: r = l15 >> 2, kq = l15 & 3
-  const bool dl = p.kq == (p.l15 & 3) && p.col < N;
-  const int dr = p.l15 >> 2;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-    if (ta == p.wave) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) G.v[ta][r] += (dl && dr == r) ? 1.0 : 0.0;
-    }
-}
-
-// ---- pivoted inverse (the contract of the reference's LU: batch_inv!, cpu_batched.jl:32-47, ext/gpu_batched_cuda.jl:149-179) ----
-// Where the norm bound gives no series order (||E||_F >= 0.3: the last doublings of thick near-conservative layers, bright
-// surfaces -- and anything a caller of the public entry points hands in, spectral radius >= 1 included) the inverse is an
-// in-place Gauss-Jordan elimination with partial pivoting (the pivot rule of getrf: largest |m_ik|, first occurrence) on
-// M = I - E in the A-form's LDS (plain column-major, pitch NP).  LDS-resident on purpose: a dozen registers per lane, so the
-// cold path does not shape the register allocation of the products around it (an out-of-line register-resident elimination
-// cost the product loops 2.5 %).  Lane = row (rows lane, lane + 64), wave w = columns w, w + nw, ...: per pivot step every wave
-// reads column k and finds the pivot row redundantly (DPP maximum + ballot), a barrier, every wave updates its own columns
-// (two broadcast reads, the row interchange folded into the update), a barrier.  The cost does not depend on the spectral
-// radius: 2 N barriers and N^2 LDS read-modify-writes per step (a squaring level is two products, and 1 - rho = 1e-3 would take
-// fifteen of them).  The row interchanges come back as a column permutation `src` that the strip read-back applies.
-// status (device words, vsm_device_status): [0] |= VSM_DEVSTAT_SINGULAR on an exactly zero pivot, [1] += 1 per pivoted inverse.
-using lds_i = __attribute__((address_space(3))) int;
-constexpr size_t GJS_BYTES = 2 * 128 * sizeof(int);   // piv[128], src[128]: LDS behind the kernels' own tables
-template <int RT>
-__device__ __forceinline__ void gj128_lds(int N, lds_d* M, lds_i* piv, lds_i* src, int nw, int* status, const bpos<RT>& p) {
-  constexpr int NP = 16 * RT;
-  const int i0 = p.lane, i1 = p.lane + 64;
-  const bool ok0 = i0 < N, ok1 = i1 < N;
-  bool singular = false;
-  for (int k = 0; k < N; ++k) {
-    const lds_d* ck = M + k * NP;
-    double f0 = ok0 ? ck[i0] : 0.0, f1 = ok1 ? ck[i1] : 0.0;
-    const double v0 = (ok0 && i0 >= k) ? fabs(f0) : -1.0, v1 = (ok1 && i1 >= k) ? fabs(f1) : -1.0;
-    const double best = wave_max(fmax(v0, v1));
-    const unsigned long long m0 = __ballot(v0 >= 0.0 && v0 == best), m1 = __ballot(v1 >= 0.0 && v1 == best);
-    const int pr = m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 64 + __ffsll((long long)m1) - 1 : k);
-    const double ckk = ck[k], pv = ck[pr];   // (broadcast reads)
-    const double d = 1.0 / pv;
-    singular |= pv == 0.0;
-    f0 = (i0 == pr) ? ckk : f0;              // the pivot column after the interchange of rows k and pr
-    f1 = (i1 == pr) ? ckk : f1;
-    if (threadIdx.x == 0) piv[k] = pr;
-    __syncthreads();                         // every wave holds column k
-    for (int j = p.wave; j < N; j += nw) {
-      lds_d* cj = M + j * NP;
-      const bool isk = j == k;
-      const double a = cj[pr], b = cj[k];
-      const double u = isk ? d : a * d;
-      double x0 = ok0 ? cj[i0] : 0.0, x1 = ok1 ? cj[i1] : 0.0;
-      x0 = isk ? 0.0 : ((i0 == pr) ? b : x0);
-      x1 = isk ? 0.0 : ((i1 == pr) ? b : x1);
-      x0 = (i0 == k) ? u : fma(-f0, u, x0);
-      x1 = (i1 == k) ? u : fma(-f1, u, x1);
-      if (ok0) cj[i0] = x0;
-      if (ok1) cj[i1] = x1;
-    }
-    __syncthreads();
-  }
-  // undo the row interchanges as a column permutation of the inverse: for k = N-1 .. 0 swap columns k and piv[k];
-  // src[x] = the column of M that is column x of the inverse (vsm_inverse.h)
-  if (p.wave == 0) {
-    const int lane = p.lane;
-    int s0 = lane, s1 = lane + 64;
-    const int p0 = (lane < N) ? piv[lane] : lane;
-    const int p1 = (lane + 64 < N) ? piv[lane + 64] : lane + 64;
-    for (int k = N - 1; k >= 0; --k) {
-      const int ku = __builtin_amdgcn_readfirstlane(k);
-      const int q = (ku < 64) ? __builtin_amdgcn_readlane(p0, ku) : __builtin_amdgcn_readlane(p1, ku - 64);
-      if (q != ku) {
-        const int sk = (ku < 64) ? __builtin_amdgcn_readlane(s0, ku) : __builtin_amdgcn_readlane(s1, ku - 64);
-        const int sq = (q < 64) ? __builtin_amdgcn_readlane(s0, q) : __builtin_amdgcn_readlane(s1, q - 64);
-        if (ku < 64) {
-          if (lane == ku) s0 = sq;
-        } else {
-          if (lane == ku - 64) s1 = sq;
-        }
-        if (q < 64) {
-          if (lane == q) s0 = sk;
-        } else {
-          if (lane == q - 64) s1 = sk;
-        }
-      }
-    }
-    src[lane] = s0;
-    src[lane + 64] = s1;
-    if (lane == 0) {
-      if (singular) atomicOr(&status[0], (int)VSM_DEVSTAT_SINGULAR);
-      atomicAdd(&status[1], 1);
-    }
-  }
-  __syncthreads();
-}
-
-struct inv128_ctx {   // what the pivoted path needs beside the strips
-  double* AF;         // the A-form's LDS (>= NP * NP doubles)
-  double* gjs;        // GJS_BYTES of LDS (pivot rows, column permutation)
-  int* status;
-};
-
-// G_s = strip of (I - E)^-1 from E's strips; every wave is past a barrier behind the last read of the A-form.
-//   K = 1..4: Horner off ONE A-form [E] (K - 1 products, no further barrier, two live strips)
-//   K = 7 .. 31: G <- (I + E^(2^l)) G level by level (an A-form store and a product more per level) to the series order K
-//   K = 0 (no order from the norm bound): Gauss-Jordan with partial pivoting (above)
-// On return other waves may still be reading the A-form.
-template <int RT>
-__device__ __forceinline__ void invert128(int K, bstrip<RT>& E, bstrip<RT>& G, int N, const inv128_ctx& cx, bpos<RT>& p) {
-  if (K == 1) {
-    G = E;
-    add_identity(G, N, p);
-    return;
-  }
-  if (K == 0) {
-    constexpr int NP = 16 * RT;
-    if (p.mat_wave && p.col < N) {       // M = I - E, plain column-major (only the N x N block is read back)
-      double* mc = cx.AF + p.col * NP + p.kq;
-#pragma unroll
-      for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mc[16 * ta + 4 * r] = (p.row(ta, r) == p.col ? 1.0 : 0.0) - E.v[ta][r];
-    }
-    __syncthreads();
-    lds_d* M = reinterpret_cast<lds_d*>((unsigned long long)lds_addr128(cx.AF));
-    lds_i* piv = reinterpret_cast<lds_i*>((unsigned long long)lds_addr128(cx.gjs));
-    gj128_lds<RT>(N, M, piv, piv + 128, blockDim.x >> 6, cx.status, p);
-    const bool cok = p.mat_wave && p.col < N;
-    const lds_d* gc = M + (cok ? piv[128 + p.col] : 0) * NP + p.kq;
-#pragma unroll
-    for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v = gc[16 * ta + 4 * r];
-        G.v[ta][r] = (cok && p.row(ta, r) < N) ? v : 0.0;
-      }
-    return;
-  }
-  store_af(E, N, p);
-  __syncthreads();
-  if (K >= 2 && K <= 4) {
-    G = E;
-    mm128(G, E, p);                  // X1 = E + E E
-    for (int j = 2; j < K; ++j) {    // X_j = E + E X_{j-1}
-      bstrip<RT> X;
-      load_af(X, p);
-      mm128(X, G, p);
-      G = X;
-    }
-    add_identity(G, N, p);
-    return;
-  }
-  G = E;
-  add_identity(G, N, p);             // sum_{k < 2} E^k
-  int cur = 1;                       // [A] = E^cur, E = its strip, G = sum_{k < 2 cur} E^k
-  for (int lvl = 0; lvl < 5; ++lvl) {   // (K <= 31: at most four levels)
-    bstrip<RT> W2;
-    W2.zero();
-    mm128(W2, E, p);                 // E^(2 cur)
-    cur *= 2;
-    __syncthreads();
-    if (K == cur) {
-#pragma unroll
-      for (int ta = 0; ta < RT; ++ta) G.v[ta] += W2.v[ta];
-      break;
-    }
-    store_af(W2, N, p);              // (everybody finished reading the A-form: the barrier above)
-    __syncthreads();
-    {
-      bstrip<RT> T;
-      T.zero();
-      mm128(T, G, p);                // E^(2 cur) G = sum_{2 cur <= k < 4 cur} E^k
-#pragma unroll
-      for (int ta = 0; ta < RT; ++ta) G.v[ta] += T.v[ta];
-    }
-    if (K == 2 * cur - 1) break;
-    E = W2;
-  }
-}
-// the series order from the norm bound; a norm that is not finite (NaN / Inf input) is flagged and takes the pivoted path
-__device__ __forceinline__ int inv_order128(double nrm, int* status) {
-  if (!(nrm < 1e300) && threadIdx.x == 0) atomicOr(&status[0], (int)VSM_DEVSTAT_NONFINITE);
-  return series_order128(nrm);
-}
-
-template <int RT>
-__device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __restrict__ g, int N, const bpos<RT>& p) {
-  const bool cok = p.col < N;
-  const double* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc0));
-  gcd_p gc = (gcd_p)gc0;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (ta < RT - 1) {   // N > 16 (RT - 1): these rows exist
-        const double v = gc[16 * ta + 4 * r];
-        s.v[ta][r] = cok ? v : 0.0;
-      } else {
-        const int row = p.row(ta, r);
-        const double v = gc[min(row, N - 1) - p.kq];
-        s.v[ta][r] = (row < N && cok) ? v : 0.0;
-      }
-    }
-}
 
 // ---- doubling --------------------------------------------------------------------------------------------------------------
 // MR: the source vectors as an extra MFMA tile per wave (mm128r) instead of rider columns -- N = 127, 128
@@ -696,49 +296,6 @@ int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<do
 }
 
 // ---- interaction (ScatteringInterface_11) ------------------------------------------------------------------------------------
-// global column-major N x N -> the A-form (zero padded): a wave takes whole columns, lane = row (512-byte requests; the 16-lane
-// groups of the LDS store are 16 rows of one column: (m ^ const) -- conflict-free)
-template <int RT>
-__device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ g, int N, int nw, const bpos<RT>& p) {
-  constexpr int NP = 16 * RT, CB = 8, NH = (NP + 63) / 64;   // CB columns x NH row blocks of a wave in flight together
-  for (int c0 = p.wave; c0 < NP; c0 += CB * nw) {
-    double v[CB][NH];
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const int col = c0 + i * nw;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int row = 64 * h + p.lane;
-        v[i][h] = (row < N && col < N) ? g[row + (long long)N * col] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const int col = c0 + i * nw;
-#pragma unroll
-      for (int h = 0; h < NH; ++h) {
-        const int row = 64 * h + p.lane;
-        if (row < NP && col < NP)
-          AF[(col >> 2) * (RT * 64) + (row >> 4) * 64 + ((col & 3) << 4) + ((row & 15) ^ (col & 15))] = v[i][h];
-      }
-    }
-  }
-}
-template <int RT>
-__device__ __forceinline__ void store_global128(double* __restrict__ g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
-  const bool cok = p.col < N;
-  double* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc0));
-  gd_p gc = (gd_p)gc0;
-#pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool rok = ta < RT - 1 || p.row(ta, r) < N;
-      if (rok && cok) gc[16 * ta + 4 * r] = s.v[ta][r];
-    }
-}
-
 // interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266) with ONE inverse G2 = (I - R+- r-+)^-1 and the
 // push-through identities of vsm_strip.hip's ia_body, ordered by left operand for the single A-form:
 //   [R+-]: E2 = R+- r-+ , Z = R+- t--      (rider: R+- j0-  ->  z = J0+ + R+- j0-)

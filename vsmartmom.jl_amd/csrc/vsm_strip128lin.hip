@@ -1,0 +1,721 @@
+// Linearized (Jacobian) doubling and interaction for FP64, 60 < N <= 128, in the column-strip scheme of vsm_strip128.hip:
+//
+//   k_dbl128_lin<RT>   doubling_allparams_helper! (src/CoreRT/CoreKernel/doubling_lin.jl:216-339) + apply_D! with derivative
+//                      slots (:374-421): ALL doubling steps of one spectral point, forward + every active parameter, in one
+//                      persistent workgroup, in place on the AddedLayer / AddedLayerLin
+//   k_ia128_lin<RT>    one half of interaction_helper!(::ScatteringInterface_11) with derivatives (interaction_lin.jl:217-331);
+//                      the interaction is two launches with different operand bindings (vsm_striplin.hip's ia_half: the second
+//                      half reads only arrays the first leaves untouched)
+//
+// Both are the same recurrence (vsm_striplin.hip): with a left operand LA, right operands ER, S2, S3, a transmission LT,
+//     E = LA ER ;  G = (I - E)^-1 ;  tt = LT G ;  rt = LA S2 ;        out0 = ACC0 + tt rt ;  out1 = tt S3
+//     per parameter:  X1 = PA ER + LA D1 ;  X2 = PA S2 + LA D2 ;  Y = YI + tt X1 ;  ttdot = Y G      (Gdot is never formed)
+//                     outp0 = ACCP + tt X2 + ttdot rt ;  outp1 = tt D3 + ttdot S3
+// (doubling: LA = ER = ACC0 = r, LT = S2 = S3 = t, PA = D1 = ACCP = rdot, D2 = D3 = YI = tdot).  The shapes of 61 <= N <= 128 leave
+// no room for the four A-forms and ten live strips the kernels of N <= 60 keep on chip, so, as in vsm_strip128.hip:
+//   * ONE A-form in LDS; the products run ordered by left operand: [LA] -> [E] -> [LT] -> [tt], then per parameter
+//     [LA] -> [PA] -> [tt] -> [Y] -> [ttdot] (parameters one after the other: the scratch does not grow with their number and the
+//     source-vector tables stay two columns wide);
+//   * every strip that is not an operand of the running product waits in the workgroup's global scratch as lane-linear 32-byte
+//     records (2 KB per instruction, L2 / MALL resident); the doubling state (r, t, rdot_p, tdot_p) stays there between steps and
+//     meets the AddedLayer's column-major arrays only on the way in and out;
+//   * source vectors: one more 16 x 16 MFMA tile per wave behind the products that carry them (rider_tile: row tile w of
+//     [A] (x_0 | x_1), x from an LDS table), the vector algebra by N threads between the phases.  nw = RT waves.
+// Workgroups are persistent (grid = CUs; two per CU at RT = 4) and walk the spectral axis.
+#include "vsm_strip128_dev.h"
+
+namespace vsm {
+namespace {
+
+// ---- shared pieces -------------------------------------------------------------------------------------------------------------
+template <int RT>
+struct lin128 {
+  static constexpr int NP = 16 * RT;
+  // LDS (doubles): A-form | reduction slots (32) | pivot / permutation of the Gauss-Jordan path (128) | NVEC vector tables of NP
+  static constexpr int NVEC = 20;
+  static constexpr size_t lds_bytes() { return (size_t)(NP * NP + 32 + 128 + NVEC * NP) * sizeof(double); }
+};
+
+// y_0 = [A] x_0, y_1 = [A] x_1 for the two vectors of the LDS table at xt (x_0 = xt[0..NP), x_1 = xt[NP..2 NP)): wave w forms row
+// tile w (rider_tile), the lanes of columns 0 / 1 leave the rows in y0 / y1.  Needs nw = RT.
+template <int RT>
+__device__ __forceinline__ void rider2(double* y0, double* y1, const double* xt, bpos<RT>& p) {
+  constexpr int NP = 16 * RT;
+  const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
+  d4_t y = acc_zero<double>();
+  rider_tile(y, xb, p);
+  if (p.l15 < 2) {
+    double* d = p.l15 ? y1 : y0;
+    const int rrow = 16 * p.wave + p.kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[rrow + 4 * r] = y[r];
+  }
+}
+
+template <int RT>
+__device__ __forceinline__ d4_t* slot_ptr(d4_t* scr, int nslots, int slot, const bpos<RT>& p) {
+  return scr + (((long long)blockIdx.x * nslots + slot) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+}
+
+// ---- doubling ------------------------------------------------------------------------------------------------------------------
+// scratch slots: 0 r, 1 t, 2 r', 3 t', 4 W = r t, 5 G, 6 tt, 7 X1 / Y, 8 Q2, then (rdot_p, tdot_p) for p = 0 .. P-1
+constexpr int DL_FIXED = 9;
+template <int RT>
+__global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, int ns, int S, int P, int nd,
+                                                                         double* __restrict__ expk_g, double* __restrict__ ekl_g,
+                                                                         added<double> a, added_lin<double> al,
+                                                                         d4_t* __restrict__ scr, int* __restrict__ status) {
+  constexpr int NP = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) double lds128[];
+  double* AF = lds128;
+  float* red = reinterpret_cast<float*>(lds128 + NP * NP);
+  double* gjs = lds128 + NP * NP + 32;
+  double* vt = gjs + 128;
+  double *jp = vt, *jm = vt + NP, *J1p = vt + 2 * NP, *J1m = vt + 3 * NP, *Av = vt + 4 * NP, *Bv = vt + 5 * NP;
+  double *xt = vt + 6 * NP;                       // x_0 | x_1 of the running rider pass (2 NP)
+  double *y0 = vt + 8 * NP, *y1 = vt + 9 * NP;    // its result
+  double *jpn = vt + 10 * NP, *jmn = vt + 11 * NP;
+  double *aJp = vt + 12 * NP, *aJm = vt + 13 * NP, *aJ1p = vt + 14 * NP, *aJ1m = vt + 15 * NP;
+  double *ra = vt + 16 * NP, *rb = vt + 17 * NP;  // r aJ+ , r aJ1-  ->  v, u
+  double *aJpn = vt + 18 * NP, *aJmn = vt + 19 * NP;
+  const inv128_ctx icx{AF, gjs, status};
+  bpos<RT> p(lds_addr128(AF), N);
+  const int nw = blockDim.x >> 6, tid = threadIdx.x;
+  const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
+  const int nslots = DL_FIXED + 2 * P;
+  int slot = 0;
+  auto sl = [&](int i) { return slot_ptr<RT>(scr, nslots, i, p); };
+
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    double k = expk_g[s];
+    int iR = 0, iT = 1, iR2 = 2, iT2 = 3;      // (old / new state slots swap after every step)
+    {
+      bstrip<RT> x;
+      load_global128(x, a.r_mp + NN * s, N, p);
+      spill(sl(iR), x, p);
+      load_global128(x, a.t_pp + NN * s, N, p);
+      spill(sl(iT), x, p);
+      for (int pp = 0; pp < P; ++pp) {
+        load_global128(x, al.ap_r_mp + pp * MS + NN * s, N, p);
+        spill(sl(DL_FIXED + 2 * pp), x, p);
+        load_global128(x, al.ap_t_pp + pp * MS + NN * s, N, p);
+        spill(sl(DL_FIXED + 2 * pp + 1), x, p);
+      }
+    }
+    for (int i = tid; i < NP; i += blockDim.x) {
+      jp[i] = i < N ? a.j0_p[(long long)N * s + i] : 0.0;
+      jm[i] = i < N ? a.j0_m[(long long)N * s + i] : 0.0;
+    }
+    __syncthreads();
+
+    for (int n = 0; n < nd; ++n) {
+      // ================= forward =================  (rt_helpers.jl:102-166; sources :128-134)
+      bstrip<RT> G;
+      {
+        bstrip<RT> r_s;
+        fill(r_s, sl(iR), p);
+        store_af(r_s, N, p);
+        for (int i = tid; i < NP; i += blockDim.x) {
+          J1p[i] = jp[i] * k;
+          J1m[i] = jm[i] * k;
+          xt[i] = jp[i];
+          xt[NP + i] = jm[i] * k;
+        }
+        __syncthreads();
+        bstrip<RT> E;
+        E.zero();
+        mm128(E, r_s, p);                      // E = r r
+        {
+          bstrip<RT> t_s, W;
+          fill(t_s, sl(iT), p);
+          W.zero();
+          mm128(W, t_s, p);                    // W = r t
+          spill(sl(4), W, p);
+        }
+        rider2(y0, y1, xt, p);                 // r j0+ | r j1-
+        const double nrm = norm128(E, N, nw, red, slot, p);   // (barrier: [r] is free, y0 / y1 complete)
+        for (int i = tid; i < NP; i += blockDim.x) {
+          Av[i] = J1m[i] + y0[i];              // A = j1- + r j0+
+          Bv[i] = jp[i] + y1[i];               // B = j0+ + r j1-
+        }
+        invert128(inv_order128(nrm, status), E, G, N, icx, p);
+        spill(sl(5), G, p);
+      }
+      {
+        bstrip<RT> t_s;
+        fill(t_s, sl(iT), p);
+        __syncthreads();                       // [E] no longer read
+        store_af(t_s, N, p);
+        __syncthreads();
+        bstrip<RT> tt;
+        tt.zero();
+        mm128(tt, G, p);                       // tt = t G
+        spill(sl(6), tt, p);
+        __syncthreads();                       // [t] no longer read
+        store_af(tt, N, p);
+        for (int i = tid; i < NP; i += blockDim.x) {
+          xt[i] = Av[i];
+          xt[NP + i] = Bv[i];
+        }
+        __syncthreads();
+      }
+      {
+        bstrip<RT> acc, B;
+        fill(acc, sl(iR), p);
+        fill(B, sl(4), p);
+        mm128(acc, B, p);                      // r' = r + tt W
+        spill(sl(iR2), acc, p);
+        fill(B, sl(iT), p);
+        acc.zero();
+        mm128(acc, B, p);                      // t' = tt t
+        spill(sl(iT2), acc, p);
+        rider2(y0, y1, xt, p);                 // tt A | tt B
+      }
+      __syncthreads();                         // [tt] free, y complete
+      for (int i = tid; i < NP; i += blockDim.x) {
+        jmn[i] = jm[i] + y0[i];                // j0-' = j0- + tt A
+        jpn[i] = J1p[i] + y1[i];               // j0+' = j1+ + tt B
+      }
+
+      // ================= parameters ================= (doubling_lin.jl:216-339; Gdot eliminated: t Gdot = tt X1 G)
+      for (int pp = 0; pp < P; ++pp) {
+        const double kl = ekl_g[s + (long long)S * pp];
+        const int iRd = DL_FIXED + 2 * pp, iTd = iRd + 1;
+        double* g_aJp = al.ap_J0_p + pp * VS + (long long)N * s;
+        double* g_aJm = al.ap_J0_m + pp * VS + (long long)N * s;
+        // ---- [r]: X1 = r rdot ; Q2 = r tdot ; riders r aJ+ | r aJ1-
+        {
+          bstrip<RT> r_s;
+          fill(r_s, sl(iR), p);
+          store_af(r_s, N, p);                 // (barrier above / at the end of the previous parameter: the A-form is free)
+        }
+        for (int i = tid; i < NP; i += blockDim.x) {
+          const double vp = i < N ? g_aJp[i] : 0.0, vm = i < N ? g_aJm[i] : 0.0;
+          aJp[i] = vp;
+          aJm[i] = vm;
+          aJ1p[i] = vp * k + jp[i] * kl;       // aJ1+- = aJ+- expk + j0+- ekl_p
+          const double v1m = vm * k + jm[i] * kl;
+          aJ1m[i] = v1m;
+          xt[i] = vp;
+          xt[NP + i] = v1m;
+        }
+        __syncthreads();
+        {
+          bstrip<RT> B, X;
+          fill(B, sl(iRd), p);
+          X.zero();
+          mm128(X, B, p);
+          spill(sl(7), X, p);                  // X1 (partial)
+          fill(B, sl(iTd), p);
+          X.zero();
+          mm128(X, B, p);
+          spill(sl(8), X, p);                  // Q2 (partial)
+          rider2(ra, rb, xt, p);
+        }
+        // ---- [rdot]: X1 += rdot r ; Q2 += rdot t ; riders rdot j0+ | rdot j1-
+        {
+          bstrip<RT> rd;
+          fill(rd, sl(iRd), p);
+          __syncthreads();                     // [r] no longer read
+          store_af(rd, N, p);
+        }
+        for (int i = tid; i < NP; i += blockDim.x) {
+          xt[i] = jp[i];
+          xt[NP + i] = J1m[i];
+        }
+        __syncthreads();
+        {
+          bstrip<RT> B, X;
+          fill(X, sl(7), p);
+          fill(B, sl(iR), p);
+          mm128(X, B, p);
+          spill(sl(7), X, p);                  // X1 = r rdot + rdot r
+          fill(X, sl(8), p);
+          fill(B, sl(iT), p);
+          mm128(X, B, p);
+          spill(sl(8), X, p);                  // Q2 = r tdot + rdot t
+          rider2(y0, y1, xt, p);
+        }
+        // ---- [tt]: Y = tdot + tt X1 ; rdot' = rdot + tt Q2 ; tdot' = tt tdot ; riders tt v | tt u
+        {
+          bstrip<RT> tt;
+          fill(tt, sl(6), p);
+          __syncthreads();                     // [rdot] no longer read, y complete
+          store_af(tt, N, p);
+        }
+        for (int i = tid; i < NP; i += blockDim.x) {
+          const double v = aJ1m[i] + y0[i] + ra[i];   // v = aJ1- + rdot j0+ + r aJ+
+          const double u = aJp[i] + y1[i] + rb[i];    // u = aJ+ + rdot j1- + r aJ1-
+          xt[i] = v;
+          xt[NP + i] = u;
+        }
+        __syncthreads();
+        {
+          bstrip<RT> acc, B;
+          fill(acc, sl(iTd), p);
+          fill(B, sl(7), p);
+          mm128(acc, B, p);
+          spill(sl(7), acc, p);                // Y (X1's slot: X1 is consumed)
+          fill(acc, sl(iRd), p);
+          fill(B, sl(8), p);
+          mm128(acc, B, p);
+          spill(sl(iRd), acc, p);              // rdot' (partial)
+          fill(B, sl(iTd), p);
+          acc.zero();
+          mm128(acc, B, p);
+          spill(sl(iTd), acc, p);              // tdot' (partial)
+          rider2(y0, y1, xt, p);
+        }
+        // ---- [Y]: ttdot = Y G
+        bstrip<RT> ttl;
+        {
+          bstrip<RT> Y;
+          fill(Y, sl(7), p);
+          __syncthreads();                     // [tt] no longer read, y complete
+          store_af(Y, N, p);
+        }
+        for (int i = tid; i < NP; i += blockDim.x) {
+          aJmn[i] = aJm[i] + y0[i];            // aJ-' = aJ- + tt v (+ ttdot A below)
+          aJpn[i] = aJ1p[i] + y1[i];           // aJ+' = aJ1+ + tt u (+ ttdot B below)
+          xt[i] = Av[i];
+          xt[NP + i] = Bv[i];
+        }
+        __syncthreads();
+        {
+          bstrip<RT> Gs;
+          fill(Gs, sl(5), p);
+          ttl.zero();
+          mm128(ttl, Gs, p);
+        }
+        // ---- [ttdot]: rdot' += ttdot W ; tdot' += ttdot t ; riders ttdot A | ttdot B
+        __syncthreads();                       // [Y] no longer read
+        store_af(ttl, N, p);
+        __syncthreads();
+        {
+          bstrip<RT> acc, B;
+          fill(acc, sl(iRd), p);
+          fill(B, sl(4), p);
+          mm128(acc, B, p);
+          spill(sl(iRd), acc, p);              // rdot' = rdot + tt Q2 + ttdot rt
+          fill(acc, sl(iTd), p);
+          fill(B, sl(iT), p);
+          mm128(acc, B, p);
+          spill(sl(iTd), acc, p);              // tdot' = tt tdot + ttdot t
+          rider2(y0, y1, xt, p);
+        }
+        __syncthreads();                       // [ttdot] free, y complete
+        if (tid < N) {
+          g_aJm[tid] = aJmn[tid] + y0[tid];
+          g_aJp[tid] = aJpn[tid] + y1[tid];
+        }
+        if (tid == 0) ekl_g[s + (long long)S * pp] = 2.0 * k * kl;      // (k_ekl_step, before expk is squared)
+      }
+      // ---- end of step
+      for (int i = tid; i < NP; i += blockDim.x) {
+        jp[i] = jpn[i];
+        jm[i] = jmn[i];
+      }
+      { const int t0 = iR; iR = iR2; iR2 = t0; }
+      { const int t0 = iT; iT = iT2; iT2 = t0; }
+      k = k * k;
+      __syncthreads();
+    }
+
+    // ---- out: apply_D! with derivative slots (doubling_lin.jl:374-421) when ns > 0, else the plain state
+    {
+      const bool cok = p.col < N;
+      const bool uj = ns > 0 && is_uv_row(min(p.col, N - 1), ns);
+      auto put = [&](const bstrip<RT>& x, double* g_f, double* g_b, bool flip) {
+        // g_f = x with its U / V rows negated (flip), g_b = D g_f D ... as k_apply_D_lin
+        long long o = NN * s + (long long)N * p.col + p.kq;
+#pragma unroll
+        for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = p.row(ta, r);
+            if (row < N && cok) {
+              const bool ui = ns > 0 && is_uv_row(row, ns);
+              const double v = (flip && ui) ? -x.v[ta][r] : x.v[ta][r];
+              const long long e = o + 16 * ta + 4 * r;
+              g_f[e] = v;
+              if (ns > 0) g_b[e] = (ui == uj) ? v : -v;
+            }
+          }
+      };
+      bstrip<RT> x;
+      fill(x, sl(iR), p);
+      put(x, a.r_mp, a.r_pm, true);
+      fill(x, sl(iT), p);
+      put(x, a.t_pp, a.t_mm, false);
+      for (int pp = 0; pp < P; ++pp) {
+        fill(x, sl(DL_FIXED + 2 * pp), p);
+        put(x, al.ap_r_mp + pp * MS, al.ap_r_pm + pp * MS, true);
+        fill(x, sl(DL_FIXED + 2 * pp + 1), p);
+        put(x, al.ap_t_pp + pp * MS, al.ap_t_mm + pp * MS, false);
+      }
+      if (ns > 0) {                            // the slots of the inactive parameters are zero (as k_dbl_lin_multi)
+        x.zero();
+        for (int pp = P; pp < al.P; ++pp) {
+          store_global128(al.ap_r_pm + pp * MS + NN * s, x, N, p);
+          store_global128(al.ap_t_mm + pp * MS + NN * s, x, N, p);
+        }
+      }
+      if (tid < N) {
+        const double sg = (ns > 0 && is_uv_row(tid, ns)) ? -1.0 : 1.0;
+        a.j0_p[(long long)N * s + tid] = jp[tid];
+        a.j0_m[(long long)N * s + tid] = sg * jm[tid];
+        if (ns > 0 && sg < 0.0)
+          for (int pp = 0; pp < P; ++pp) {
+            double* g = al.ap_J0_m + pp * VS + (long long)N * s + tid;
+            *g = -*g;                          // (written by this very thread in the last step)
+          }
+      }
+      if (tid == 0) expk_g[s] = k;
+    }
+    __syncthreads();   // the next point overwrites the tables and the A-form
+  }
+}
+
+// ---- interaction half ---------------------------------------------------------------------------------------------------------
+// operand bindings of one half (the fields of vsm_striplin.hip's ia_half)
+struct ia128_half {
+  const double *LA, *ER, *LT, *S2, *S3, *ACC0;
+  long long sLA, sER, sLT, sS2, sS3, sACC0;
+  double *OUT0, *OUT1;
+  const double *VR, *VADD, *VACC;
+  double* VOUT;
+  const double *PA, *D1, *D2, *YI, *ACCP, *D3;
+  long long sPA, pPA, sD1, pD1, sD2, pD2, sYI, pYI, sACCP, pACCP, sD3, pD3;
+  double *OUTP0, *OUTP1;
+  const double *VDR, *VDADD, *VDACC;
+  double* VDOUT;
+};
+// scratch slots: 0 ER, 1 S2, 2 S3, 3 rt, 4 G, 5 tt, 6 X1 / Y, 7 X2 / outp0, 8 outp1
+constexpr int IL_SLOTS = 9;
+template <int RT>
+__global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, int S, int P, ia128_half h, d4_t* __restrict__ scr,
+                                                                        int* __restrict__ status) {
+  constexpr int NP = 16 * RT;
+  extern __shared__ __attribute__((aligned(16))) double lds128[];
+  double* AF = lds128;
+  float* red = reinterpret_cast<float*>(lds128 + NP * NP);
+  double* gjs = lds128 + NP * NP + 32;
+  double* vt = gjs + 128;
+  double *vr = vt, *vadd = vt + NP, *vacc = vt + 2 * NP, *rtv = vt + 3 * NP;
+  double *xt = vt + 4 * NP;                       // x_0 | x_1 (2 NP)
+  double *y0 = vt + 6 * NP, *y1 = vt + 7 * NP;
+  double *vdr = vt + 8 * NP, *vdadd = vt + 9 * NP, *vdacc = vt + 10 * NP, *pv = vt + 11 * NP, *x2v = vt + 12 * NP, *vd = vt + 13 * NP;
+  const inv128_ctx icx{AF, gjs, status};
+  bpos<RT> p(lds_addr128(AF), N);
+  const int nw = blockDim.x >> 6, tid = threadIdx.x;
+  const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
+  int slot = 0;
+  auto sl = [&](int i) { return slot_ptr<RT>(scr, IL_SLOTS, i, p); };
+
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {
+    // ================= forward =================
+    bstrip<RT> G;
+    {
+      bstrip<RT> er, s2;
+      load_global128(er, h.ER + s * h.sER, N, p);
+      load_global128(s2, h.S2 + s * h.sS2, N, p);
+      stage_af(AF, h.LA + s * h.sLA, N, nw, p);
+      for (int i = tid; i < NP; i += blockDim.x) {
+        const long long o = (long long)N * s + i;
+        const double v = i < N ? h.VR[o] : 0.0;
+        vr[i] = v;
+        vadd[i] = i < N ? h.VADD[o] : 0.0;
+        vacc[i] = i < N ? h.VACC[o] : 0.0;
+        xt[i] = v;
+        xt[NP + i] = v;
+      }
+      spill(sl(0), er, p);
+      spill(sl(1), s2, p);
+      __syncthreads();
+      bstrip<RT> E;
+      E.zero();
+      mm128(E, er, p);                         // E = LA ER
+      {
+        bstrip<RT> rt;
+        rt.zero();
+        mm128(rt, s2, p);                      // rt = LA S2
+        spill(sl(3), rt, p);
+      }
+      rider2(y0, y1, xt, p);                   // LA VR
+      {
+        bstrip<RT> s3;                         // (parked now: the second half's OUT1 overwrites S3's array)
+        load_global128(s3, h.S3 + s * h.sS3, N, p);
+        spill(sl(2), s3, p);
+      }
+      const double nrm = norm128(E, N, nw, red, slot, p);     // (barrier: [LA] free, y complete)
+      for (int i = tid; i < NP; i += blockDim.x) rtv[i] = vadd[i] + y0[i];
+      invert128(inv_order128(nrm, status), E, G, N, icx, p);
+      spill(sl(4), G, p);
+    }
+    __syncthreads();                           // [E] no longer read
+    stage_af(AF, h.LT + s * h.sLT, N, nw, p);
+    __syncthreads();
+    {
+      bstrip<RT> tt;
+      tt.zero();
+      mm128(tt, G, p);                         // tt = LT G
+      spill(sl(5), tt, p);
+    }
+    __syncthreads();                           // [LT] no longer read
+
+    // ================= parameters =================
+    for (int pp = 0; pp < P; ++pp) {
+      // ---- [PA]: X1 = PA ER ; X2 = PA S2 ; rider PA VR
+      stage_af(AF, h.PA + s * h.sPA + pp * h.pPA, N, nw, p);
+      for (int i = tid; i < NP; i += blockDim.x) {
+        const long long o = (long long)pp * VS + (long long)N * s + i;
+        vdr[i] = i < N ? h.VDR[o] : 0.0;
+        vdadd[i] = i < N ? h.VDADD[o] : 0.0;
+        vdacc[i] = i < N ? h.VDACC[o] : 0.0;
+        xt[i] = vr[i];
+        xt[NP + i] = vr[i];
+      }
+      __syncthreads();
+      {
+        bstrip<RT> B, X;
+        fill(B, sl(0), p);
+        X.zero();
+        mm128(X, B, p);
+        spill(sl(6), X, p);                    // X1 (partial)
+        fill(B, sl(1), p);
+        X.zero();
+        mm128(X, B, p);
+        spill(sl(7), X, p);                    // X2 (partial)
+        rider2(pv, y1, xt, p);
+      }
+      // ---- [LA]: X1 += LA D1 ; X2 += LA D2 ; rider LA VDR
+      __syncthreads();                         // [PA] no longer read
+      stage_af(AF, h.LA + s * h.sLA, N, nw, p);
+      for (int i = tid; i < NP; i += blockDim.x) {
+        xt[i] = vdr[i];
+        xt[NP + i] = vdr[i];
+      }
+      __syncthreads();
+      {
+        bstrip<RT> B, X;
+        fill(X, sl(6), p);
+        load_global128(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p);
+        mm128(X, B, p);
+        spill(sl(6), X, p);                    // X1
+        fill(X, sl(7), p);
+        load_global128(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p);
+        mm128(X, B, p);
+        spill(sl(7), X, p);                    // X2
+        rider2(y0, y1, xt, p);
+      }
+      // ---- [tt]: Y = YI + tt X1 ; outp0 = ACCP + tt X2 ; outp1 = tt D3 ; rider tt x2v
+      {
+        bstrip<RT> tt;
+        fill(tt, sl(5), p);
+        __syncthreads();                       // [LA] no longer read, y complete
+        store_af(tt, N, p);
+      }
+      for (int i = tid; i < NP; i += blockDim.x) {
+        const double v = vdadd[i] + pv[i] + y0[i];   // X2[:, c] = PA VR + LA VDR + VDADD
+        x2v[i] = v;
+        xt[i] = v;
+        xt[NP + i] = v;
+      }
+      __syncthreads();
+      {
+        bstrip<RT> acc, B;
+        load_global128(acc, h.YI + s * h.sYI + pp * h.pYI, N, p);
+        fill(B, sl(6), p);
+        mm128(acc, B, p);
+        spill(sl(6), acc, p);                  // Y
+        load_global128(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
+        fill(B, sl(7), p);
+        mm128(acc, B, p);
+        spill(sl(7), acc, p);                  // outp0 (partial)
+        load_global128(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p);
+        acc.zero();
+        mm128(acc, B, p);
+        spill(sl(8), acc, p);                  // outp1 (partial)
+        rider2(y0, y1, xt, p);
+      }
+      // ---- [Y]: ttdot = Y G
+      bstrip<RT> ttl;
+      {
+        bstrip<RT> Y;
+        fill(Y, sl(6), p);
+        __syncthreads();                       // [tt] no longer read, y complete
+        store_af(Y, N, p);
+      }
+      for (int i = tid; i < NP; i += blockDim.x) {
+        vd[i] = vdacc[i] + y0[i];              // VDACC + tt x2v (+ ttdot rtv below)
+        xt[i] = rtv[i];
+        xt[NP + i] = rtv[i];
+      }
+      __syncthreads();
+      {
+        bstrip<RT> Gs;
+        fill(Gs, sl(4), p);
+        ttl.zero();
+        mm128(ttl, Gs, p);
+      }
+      // ---- [ttdot]: outp0 += ttdot rt ; outp1 += ttdot S3 ; rider ttdot rtv
+      __syncthreads();                         // [Y] no longer read
+      store_af(ttl, N, p);
+      __syncthreads();
+      {
+        bstrip<RT> acc, B;
+        fill(acc, sl(7), p);
+        fill(B, sl(3), p);
+        mm128(acc, B, p);
+        store_global128(h.OUTP0 + (long long)pp * MS + NN * s, acc, N, p);
+        fill(acc, sl(8), p);
+        fill(B, sl(2), p);
+        mm128(acc, B, p);
+        store_global128(h.OUTP1 + (long long)pp * MS + NN * s, acc, N, p);
+        rider2(y0, y1, xt, p);
+      }
+      __syncthreads();                         // [ttdot] free, y complete
+      if (tid < N) h.VDOUT[(long long)pp * VS + (long long)N * s + tid] = vd[tid] + y0[tid];
+    }
+
+    // ================= forward outputs (last: OUT0 / OUT1 alias operands of the parameter loop) =================
+    {
+      bstrip<RT> tt;
+      fill(tt, sl(5), p);
+      store_af(tt, N, p);                      // (barrier above / after the [LT] product: the A-form is free)
+    }
+    for (int i = tid; i < NP; i += blockDim.x) {
+      xt[i] = rtv[i];
+      xt[NP + i] = rtv[i];
+    }
+    __syncthreads();
+    {
+      bstrip<RT> acc, B;
+      load_global128(acc, h.ACC0 + s * h.sACC0, N, p);
+      fill(B, sl(3), p);
+      mm128(acc, B, p);                        // out0 = ACC0 + tt rt
+      store_global128(h.OUT0 + NN * s, acc, N, p);
+      fill(B, sl(2), p);
+      acc.zero();
+      mm128(acc, B, p);                        // out1 = tt S3
+      store_global128(h.OUT1 + NN * s, acc, N, p);
+      rider2(y0, y1, xt, p);
+    }
+    __syncthreads();
+    if (tid < N) h.VOUT[(long long)N * s + tid] = vacc[tid] + y0[tid];
+    __syncthreads();   // the next point overwrites the tables and the A-form
+  }
+}
+
+template <int RT>
+int launch_dbl128_lin(int N, int ns, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
+                      const added_lin<double>& al, hipStream_t st) {
+  constexpr size_t lds = lin128<RT>::lds_bytes();
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128_lin<RT>), lds, "hipFuncSetAttribute(k_dbl128_lin)"))
+    return prepared;
+  const int per_cu = RT <= 4 ? 2 : 1;
+  const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
+  const int nslots = DL_FIXED + 2 * P;
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * nslots * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
+  int* status = device_status();
+  if (!scr || !status) return VSM_ERR_HIP;
+  hipLaunchKernelGGL(k_dbl128_lin<RT>, dim3(grid), dim3(64 * RT), lds, st, N, ns, S, P, nd, expk, ekl, a, al, scr, status);
+  VSM_LAUNCH_CHECK("k_dbl128_lin");
+  return VSM_OK;
+}
+template <int RT>
+int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
+  constexpr size_t lds = lin128<RT>::lds_bytes();
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128_lin<RT>), lds, "hipFuncSetAttribute(k_ia128_lin)"))
+    return prepared;
+  const int per_cu = RT <= 4 ? 2 : 1;
+  const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
+  d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * IL_SLOTS * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
+  int* status = device_status();
+  if (!scr || !status) return VSM_ERR_HIP;
+  hipLaunchKernelGGL(k_ia128_lin<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, P, h, scr, status);
+  VSM_LAUNCH_CHECK("k_ia128_lin");
+  return VSM_OK;
+}
+
+}  // namespace
+
+// FP64, 60 < N <= 128 (N = 61 .. 64 on four row tiles: the strips of vsm_striplin.hip have no spare column left there)
+bool strip128_lin_supported(int N) { return N > 60 && N <= 128; }
+
+// All ndoubl doubling steps (forward + P active parameters) in one launch, apply_D! included when ns (n_stokes) > 0
+int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
+                          const added_lin<double>& al, hipStream_t st) {
+  if (!strip128_lin_supported(N) || P < 0 || nd < 1 || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+    return VSM_ERR_UNSUPPORTED;
+  if (S <= 0) return VSM_OK;
+  switch ((N + 15) / 16) {
+    case 4: return launch_dbl128_lin<4>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 5: return launch_dbl128_lin<5>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 6: return launch_dbl128_lin<6>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 7: return launch_dbl128_lin<7>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 8: return launch_dbl128_lin<8>(N, ns, S, P, nd, expk, ekl, a, al, st);
+  }
+  return VSM_ERR_UNSUPPORTED;
+}
+
+// ScatteringInterface_11 interaction with derivatives: two launches (first half, second half), bindings as
+// vsm_striplin.hip's strip_interaction11_lin
+int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
+                               const added_lin<double>& al, hipStream_t st) {
+  if (!strip128_lin_supported(N)) return VSM_ERR_UNSUPPORTED;
+  if (S <= 0) return VSM_OK;
+  const int P = cl.P;
+  const long long NN = (long long)N * N, MS = NN * S;
+  const long long as = a.mat_stride, als = al.mat_stride, alp = (als == 0) ? NN : MS;
+  ia128_half h1{};
+  h1.LA = a.r_mp;   h1.sLA = as;
+  h1.ER = c.R_pm;   h1.sER = NN;
+  h1.LT = c.T_mm;   h1.sLT = NN;
+  h1.S2 = c.T_pp;   h1.sS2 = NN;
+  h1.S3 = a.t_mm;   h1.sS3 = as;
+  h1.ACC0 = c.R_mp; h1.sACC0 = NN;
+  h1.OUT0 = c.R_mp; h1.OUT1 = c.T_mm;
+  h1.VR = c.J0_p; h1.VADD = a.j0_m; h1.VACC = c.J0_m; h1.VOUT = c.J0_m;
+  h1.PA = al.ap_r_mp; h1.sPA = als; h1.pPA = alp;
+  h1.D1 = cl.R_pm;    h1.sD1 = NN;  h1.pD1 = MS;
+  h1.D2 = cl.T_pp;    h1.sD2 = NN;  h1.pD2 = MS;
+  h1.YI = cl.T_mm;    h1.sYI = NN;  h1.pYI = MS;
+  h1.ACCP = cl.R_mp;  h1.sACCP = NN; h1.pACCP = MS;
+  h1.D3 = al.ap_t_mm; h1.sD3 = als; h1.pD3 = alp;
+  h1.OUTP0 = cl.R_mp; h1.OUTP1 = cl.T_mm;
+  h1.VDR = cl.J0_p; h1.VDADD = al.ap_J0_m; h1.VDACC = cl.J0_m; h1.VDOUT = cl.J0_m;
+  ia128_half h2{};
+  h2.LA = c.R_pm;   h2.sLA = NN;
+  h2.ER = a.r_mp;   h2.sER = as;
+  h2.LT = a.t_pp;   h2.sLT = as;
+  h2.S2 = a.t_mm;   h2.sS2 = as;
+  h2.S3 = c.T_pp;   h2.sS3 = NN;
+  h2.ACC0 = a.r_pm; h2.sACC0 = as;
+  h2.OUT0 = c.R_pm; h2.OUT1 = c.T_pp;
+  h2.VR = a.j0_m; h2.VADD = c.J0_p; h2.VACC = a.j0_p; h2.VOUT = c.J0_p;
+  h2.PA = cl.R_pm;    h2.sPA = NN;  h2.pPA = MS;
+  h2.D1 = al.ap_r_mp; h2.sD1 = als; h2.pD1 = alp;
+  h2.D2 = al.ap_t_mm; h2.sD2 = als; h2.pD2 = alp;
+  h2.YI = al.ap_t_pp; h2.sYI = als; h2.pYI = alp;
+  h2.ACCP = al.ap_r_pm; h2.sACCP = als; h2.pACCP = alp;
+  h2.D3 = cl.T_pp;    h2.sD3 = NN;  h2.pD3 = MS;
+  h2.OUTP0 = cl.R_pm; h2.OUTP1 = cl.T_pp;
+  h2.VDR = al.ap_J0_m; h2.VDADD = cl.J0_p; h2.VDACC = al.ap_J0_p; h2.VDOUT = cl.J0_p;
+  int rc;
+  switch ((N + 15) / 16) {
+#define VSM_CASE(RT)                                                  \
+  case RT:                                                            \
+    if ((rc = launch_ia128_lin<RT>(N, S, P, h1, st))) return rc;      \
+    return launch_ia128_lin<RT>(N, S, P, h2, st);
+    VSM_CASE(4)
+    VSM_CASE(5)
+    VSM_CASE(6)
+    VSM_CASE(7)
+    VSM_CASE(8)
+#undef VSM_CASE
+  }
+  return VSM_ERR_UNSUPPORTED;
+}
+
+}  // namespace vsm
