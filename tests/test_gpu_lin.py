@@ -197,7 +197,7 @@ def test_rt_run_lin_vs_oracle_and_fd(vsm, arch, pol, l_trunc):
 @pytest.mark.parametrize("pol,l_trunc,N", [("IQUV", 25, 64), ("IQU", 41, 72)])
 def test_strip128lin_persistent_workgroups_walk_the_spectral_axis(vsm, arch, pol, l_trunc, N):
     """k_dbl128_lin / k_ia128_lin are persistent (grid = CUs, two per CU at four row tiles): with more spectral points than
-    workgroups every workgroup walks several points -- 1100 points tiled from 3 must reproduce the 3-point run bit for bit."""
+    workgroups every workgroup walks several points -- 1101 points tiled from 3: every tile the same bits, equal to the 3-point run."""
     rng = np.random.default_rng(4)
     S0, L, rep = 3, 2, 367
     H = vsm.host_model
@@ -215,7 +215,10 @@ def test_strip128lin_persistent_workgroups_walk_the_spectral_axis(vsm, arch, pol
     for a, b in zip(small, big):
         b = np.moveaxis(b, 2, 0).reshape((rep, S0) + tuple(np.moveaxis(b, 2, 0).shape[1:]))
         a = np.moveaxis(a, 2, 0)
-        assert np.array_equal(b, np.broadcast_to(a, b.shape))
+        assert np.array_equal(b, np.broadcast_to(b[:1], b.shape))       # every pass of every workgroup: the same bits
+        # (the 3-point run walks its moments folded into the spectral axis, SceneLin._run_folded: equal up to the order of the
+        # sum over the Fourier moments)
+        assert np.max(np.abs(b[0] - a)) <= 1e-12 * np.max(np.abs(a))
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 9), ("IQU", 33)])   # N = 21 (operator level), 57 (fused strip kernels)

@@ -267,7 +267,8 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
 int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
 
 // ---- linearized column-strip kernels, FP64, 60 < N <= 128 (one A-form, parked strips): vsm_strip128lin.hip ----
-bool strip128_lin_supported(int N);
+bool strip128_lin_dbl_supported(int N);   // which shapes take k_dbl128_lin / k_ia128_lin
+bool strip128_lin_ia_supported(int N);
 int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                           const added_lin<double>& al, hipStream_t st);
 int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,

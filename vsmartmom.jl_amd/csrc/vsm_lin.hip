@@ -406,7 +406,7 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
     // (apply_D! rides in its epilogue when every parameter slot is either active there or zero: P == n_active or the
     //  remaining slots' derivatives of r, t vanish in this layer, which the caller states with n_active > 0)
     static const bool sepD = ab_switch("VSM_LIN_SEPARATE_APPLY_D");
-    rc = strip_doubling_lin_multi(N, S, P, ndoubl, sepD ? 0 : ns, expk, ekl, a, al, st);
+    rc = strip128_lin_dbl_supported(N) ? (int)VSM_ERR_UNSUPPORTED : strip_doubling_lin_multi(N, S, P, ndoubl, sepD ? 0 : ns, expk, ekl, a, al, st);
     // 60 < N <= 128, any number of active parameters: all steps in one persistent launch (vsm_strip128lin.hip)
     if (rc == VSM_ERR_UNSUPPORTED && !sepD) rc = strip128_doubling_lin(N, S, P, ndoubl, ns, expk, ekl, a, al, st);
     if (rc == VSM_OK && !sepD) return VSM_OK;
@@ -619,7 +619,7 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
   }
   if constexpr (std::is_same<T, double>::value) {
     // fused column-strip form (vsm_striplin.hip): two launches instead of ~60
-    rc = strip_interaction11_lin(N, S, c, cl, a, al, st);
+    rc = strip128_lin_ia_supported(N) ? (int)VSM_ERR_UNSUPPORTED : strip_interaction11_lin(N, S, c, cl, a, al, st);
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
     // 60 < N <= 128: the same two halves in the one-A-form / parked-strip scheme (vsm_strip128lin.hip)
     rc = strip128_interaction11_lin(N, S, c, cl, a, al, st);

@@ -57,15 +57,37 @@ __device__ __forceinline__ d4_t* slot_ptr(d4_t* scr, int nslots, int slot, const
   return scr + (((long long)blockIdx.x * nslots + slot) * B_MAXW + p.wave) * (RT * 64) + p.lane;
 }
 
+// Residency policy.  At four row tiles (N <= 64) a strip is 32 registers and a workgroup's wave can hold six beside the
+// fragments, so the strips every parameter needs again stay in registers (K = true): the state r, t across ALL steps, rdot_p and
+// the accumulators X1, Q2 from the [r] phase to the [tt] phase -- a doubling step with one parameter then parks / fetches 14
+// strips instead of 40.  From five row tiles on (40 .. 64 registers per strip) everything that is not an operand waits in the
+// scratch, as in vsm_strip128.hip.
+template <int RT>
+struct keep128 {
+  static constexpr bool value = RT <= 4;
+};
+// acc += [A] * (the strip `held` when K, else the parked strip at `slot`)
+template <bool K, int RT>
+__device__ __forceinline__ void mm_held(bstrip<RT>& acc, const bstrip<RT>& held, const d4_t* slot, bpos<RT>& p) {
+  if constexpr (K) {
+    mm128(acc, held, p);
+  } else {
+    bstrip<RT> B;
+    fill(B, slot, p);
+    mm128(acc, B, p);
+  }
+}
+
 // ---- doubling ------------------------------------------------------------------------------------------------------------------
-// scratch slots: 0 r, 1 t, 2 r', 3 t', 4 W = r t, 5 G, 6 tt, 7 X1 / Y, 8 Q2, then (rdot_p, tdot_p) for p = 0 .. P-1
-constexpr int DL_FIXED = 9;
+// scratch slots: 0 r, 1 t, 2 W = r t, 3 G, 4 tt, 5 X1 / Y, 6 Q2, then (rdot_p, tdot_p) for p = 0 .. P-1
+constexpr int DL_FIXED = 7;
 template <int RT>
 __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, int ns, int S, int P, int nd,
                                                                          double* __restrict__ expk_g, double* __restrict__ ekl_g,
                                                                          added<double> a, added_lin<double> al,
                                                                          d4_t* __restrict__ scr, int* __restrict__ status) {
   constexpr int NP = 16 * RT;
+  constexpr bool K = keep128<RT>::value;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
@@ -74,7 +96,6 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
   double *jp = vt, *jm = vt + NP, *J1p = vt + 2 * NP, *J1m = vt + 3 * NP, *Av = vt + 4 * NP, *Bv = vt + 5 * NP;
   double *xt = vt + 6 * NP;                       // x_0 | x_1 of the running rider pass (2 NP)
   double *y0 = vt + 8 * NP, *y1 = vt + 9 * NP;    // its result
-  double *jpn = vt + 10 * NP, *jmn = vt + 11 * NP;
   double *aJp = vt + 12 * NP, *aJm = vt + 13 * NP, *aJ1p = vt + 14 * NP, *aJ1m = vt + 15 * NP;
   double *ra = vt + 16 * NP, *rb = vt + 17 * NP;  // r aJ+ , r aJ1-  ->  v, u
   double *aJpn = vt + 18 * NP, *aJmn = vt + 19 * NP;
@@ -88,13 +109,13 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     double k = expk_g[s];
-    int iR = 0, iT = 1, iR2 = 2, iT2 = 3;      // (old / new state slots swap after every step)
+    bstrip<RT> r_s, t_s;                           // (K: the state; else scratch copies that die at once)
     {
+      load_global128(r_s, a.r_mp + NN * s, N, p);
+      if constexpr (!K) spill(sl(0), r_s, p);
+      load_global128(t_s, a.t_pp + NN * s, N, p);
+      if constexpr (!K) spill(sl(1), t_s, p);
       bstrip<RT> x;
-      load_global128(x, a.r_mp + NN * s, N, p);
-      spill(sl(iR), x, p);
-      load_global128(x, a.t_pp + NN * s, N, p);
-      spill(sl(iT), x, p);
       for (int pp = 0; pp < P; ++pp) {
         load_global128(x, al.ap_r_mp + pp * MS + NN * s, N, p);
         spill(sl(DL_FIXED + 2 * pp), x, p);
@@ -109,11 +130,9 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
     __syncthreads();
 
     for (int n = 0; n < nd; ++n) {
-      // ================= forward =================  (rt_helpers.jl:102-166; sources :128-134)
-      bstrip<RT> G;
+      // ================= forward: E, W, G, tt =================  (rt_helpers.jl:102-166; sources :128-134)
       {
-        bstrip<RT> r_s;
-        fill(r_s, sl(iR), p);
+        if constexpr (!K) fill(r_s, sl(0), p);
         store_af(r_s, N, p);
         for (int i = tid; i < NP; i += blockDim.x) {
           J1p[i] = jp[i] * k;
@@ -122,15 +141,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           xt[NP + i] = jm[i] * k;
         }
         __syncthreads();
-        bstrip<RT> E;
+        bstrip<RT> E, G;
         E.zero();
         mm128(E, r_s, p);                      // E = r r
         {
-          bstrip<RT> t_s, W;
-          fill(t_s, sl(iT), p);
+          bstrip<RT> W;
           W.zero();
-          mm128(W, t_s, p);                    // W = r t
-          spill(sl(4), W, p);
+          mm_held<K, RT>(W, t_s, sl(1), p);    // W = r t
+          spill(sl(2), W, p);
         }
         rider2(y0, y1, xt, p);                 // r j0+ | r j1-
         const double nrm = norm128(E, N, nw, red, slot, p);   // (barrier: [r] is free, y0 / y1 complete)
@@ -139,43 +157,17 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           Bv[i] = jp[i] + y1[i];               // B = j0+ + r j1-
         }
         invert128(inv_order128(nrm, status), E, G, N, icx, p);
-        spill(sl(5), G, p);
-      }
-      {
-        bstrip<RT> t_s;
-        fill(t_s, sl(iT), p);
+        spill(sl(3), G, p);
+        if constexpr (!K) fill(t_s, sl(1), p);
         __syncthreads();                       // [E] no longer read
         store_af(t_s, N, p);
         __syncthreads();
         bstrip<RT> tt;
         tt.zero();
         mm128(tt, G, p);                       // tt = t G
-        spill(sl(6), tt, p);
-        __syncthreads();                       // [t] no longer read
-        store_af(tt, N, p);
-        for (int i = tid; i < NP; i += blockDim.x) {
-          xt[i] = Av[i];
-          xt[NP + i] = Bv[i];
-        }
-        __syncthreads();
+        spill(sl(4), tt, p);
       }
-      {
-        bstrip<RT> acc, B;
-        fill(acc, sl(iR), p);
-        fill(B, sl(4), p);
-        mm128(acc, B, p);                      // r' = r + tt W
-        spill(sl(iR2), acc, p);
-        fill(B, sl(iT), p);
-        acc.zero();
-        mm128(acc, B, p);                      // t' = tt t
-        spill(sl(iT2), acc, p);
-        rider2(y0, y1, xt, p);                 // tt A | tt B
-      }
-      __syncthreads();                         // [tt] free, y complete
-      for (int i = tid; i < NP; i += blockDim.x) {
-        jmn[i] = jm[i] + y0[i];                // j0-' = j0- + tt A
-        jpn[i] = J1p[i] + y1[i];               // j0+' = j1+ + tt B
-      }
+      __syncthreads();                         // [t] no longer read
 
       // ================= parameters ================= (doubling_lin.jl:216-339; Gdot eliminated: t Gdot = tt X1 G)
       for (int pp = 0; pp < P; ++pp) {
@@ -183,12 +175,10 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         const int iRd = DL_FIXED + 2 * pp, iTd = iRd + 1;
         double* g_aJp = al.ap_J0_p + pp * VS + (long long)N * s;
         double* g_aJm = al.ap_J0_m + pp * VS + (long long)N * s;
+        bstrip<RT> rd, X1, Q2;                 // (K: live from here to the [tt] phase)
         // ---- [r]: X1 = r rdot ; Q2 = r tdot ; riders r aJ+ | r aJ1-
-        {
-          bstrip<RT> r_s;
-          fill(r_s, sl(iR), p);
-          store_af(r_s, N, p);                 // (barrier above / at the end of the previous parameter: the A-form is free)
-        }
+        if constexpr (!K) fill(r_s, sl(0), p);
+        store_af(r_s, N, p);                   // (the A-form is free: barrier above / at the end of the previous parameter)
         for (int i = tid; i < NP; i += blockDim.x) {
           const double vp = i < N ? g_aJp[i] : 0.0, vm = i < N ? g_aJm[i] : 0.0;
           aJp[i] = vp;
@@ -201,45 +191,39 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         }
         __syncthreads();
         {
-          bstrip<RT> B, X;
-          fill(B, sl(iRd), p);
-          X.zero();
-          mm128(X, B, p);
-          spill(sl(7), X, p);                  // X1 (partial)
+          fill(rd, sl(iRd), p);
+          X1.zero();
+          mm128(X1, rd, p);                    // X1 = r rdot
+          if constexpr (!K) spill(sl(5), X1, p);
+          bstrip<RT> B;
           fill(B, sl(iTd), p);
-          X.zero();
-          mm128(X, B, p);
-          spill(sl(8), X, p);                  // Q2 (partial)
+          Q2.zero();
+          mm128(Q2, B, p);                     // Q2 = r tdot
+          if constexpr (!K) spill(sl(6), Q2, p);
           rider2(ra, rb, xt, p);
         }
         // ---- [rdot]: X1 += rdot r ; Q2 += rdot t ; riders rdot j0+ | rdot j1-
-        {
-          bstrip<RT> rd;
-          fill(rd, sl(iRd), p);
-          __syncthreads();                     // [r] no longer read
-          store_af(rd, N, p);
-        }
+        if constexpr (!K) fill(rd, sl(iRd), p);
+        __syncthreads();                       // [r] no longer read
+        store_af(rd, N, p);
         for (int i = tid; i < NP; i += blockDim.x) {
           xt[i] = jp[i];
           xt[NP + i] = J1m[i];
         }
         __syncthreads();
         {
-          bstrip<RT> B, X;
-          fill(X, sl(7), p);
-          fill(B, sl(iR), p);
-          mm128(X, B, p);
-          spill(sl(7), X, p);                  // X1 = r rdot + rdot r
-          fill(X, sl(8), p);
-          fill(B, sl(iT), p);
-          mm128(X, B, p);
-          spill(sl(8), X, p);                  // Q2 = r tdot + rdot t
+          if constexpr (!K) fill(X1, sl(5), p);
+          mm_held<K, RT>(X1, r_s, sl(0), p);   // X1 = r rdot + rdot r
+          if constexpr (!K) spill(sl(5), X1, p);
+          if constexpr (!K) fill(Q2, sl(6), p);
+          mm_held<K, RT>(Q2, t_s, sl(1), p);   // Q2 = r tdot + rdot t
+          if constexpr (!K) spill(sl(6), Q2, p);
           rider2(y0, y1, xt, p);
         }
         // ---- [tt]: Y = tdot + tt X1 ; rdot' = rdot + tt Q2 ; tdot' = tt tdot ; riders tt v | tt u
         {
           bstrip<RT> tt;
-          fill(tt, sl(6), p);
+          fill(tt, sl(4), p);
           __syncthreads();                     // [rdot] no longer read, y complete
           store_af(tt, N, p);
         }
@@ -250,30 +234,27 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           xt[NP + i] = u;
         }
         __syncthreads();
+        bstrip<RT> Y, tdn;                     // (rdot' accumulates in rd)
         {
-          bstrip<RT> acc, B;
-          fill(acc, sl(iTd), p);
-          fill(B, sl(7), p);
-          mm128(acc, B, p);
-          spill(sl(7), acc, p);                // Y (X1's slot: X1 is consumed)
-          fill(acc, sl(iRd), p);
-          fill(B, sl(8), p);
-          mm128(acc, B, p);
-          spill(sl(iRd), acc, p);              // rdot' (partial)
+          fill(Y, sl(iTd), p);
+          mm_held<K, RT>(Y, X1, sl(5), p);     // Y = tdot + tt X1
+          if constexpr (!K) {
+            spill(sl(5), Y, p);                // (X1's slot: X1 is consumed)
+            fill(rd, sl(iRd), p);
+          }
+          mm_held<K, RT>(rd, Q2, sl(6), p);    // rdot' = rdot + tt Q2 (+ ttdot W below)
+          if constexpr (!K) spill(sl(iRd), rd, p);
+          bstrip<RT> B;
           fill(B, sl(iTd), p);
-          acc.zero();
-          mm128(acc, B, p);
-          spill(sl(iTd), acc, p);              // tdot' (partial)
+          tdn.zero();
+          mm128(tdn, B, p);                    // tdot' = tt tdot (+ ttdot t below)
+          if constexpr (!K) spill(sl(iTd), tdn, p);
           rider2(y0, y1, xt, p);
         }
         // ---- [Y]: ttdot = Y G
-        bstrip<RT> ttl;
-        {
-          bstrip<RT> Y;
-          fill(Y, sl(7), p);
-          __syncthreads();                     // [tt] no longer read, y complete
-          store_af(Y, N, p);
-        }
+        if constexpr (!K) fill(Y, sl(5), p);
+        __syncthreads();                       // [tt] no longer read, y complete
+        store_af(Y, N, p);
         for (int i = tid; i < NP; i += blockDim.x) {
           aJmn[i] = aJm[i] + y0[i];            // aJ-' = aJ- + tt v (+ ttdot A below)
           aJpn[i] = aJ1p[i] + y1[i];           // aJ+' = aJ1+ + tt u (+ ttdot B below)
@@ -281,9 +262,10 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           xt[NP + i] = Bv[i];
         }
         __syncthreads();
+        bstrip<RT> ttl;
         {
           bstrip<RT> Gs;
-          fill(Gs, sl(5), p);
+          fill(Gs, sl(3), p);
           ttl.zero();
           mm128(ttl, Gs, p);
         }
@@ -292,15 +274,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         store_af(ttl, N, p);
         __syncthreads();
         {
-          bstrip<RT> acc, B;
-          fill(acc, sl(iRd), p);
-          fill(B, sl(4), p);
-          mm128(acc, B, p);
-          spill(sl(iRd), acc, p);              // rdot' = rdot + tt Q2 + ttdot rt
-          fill(acc, sl(iTd), p);
-          fill(B, sl(iT), p);
-          mm128(acc, B, p);
-          spill(sl(iTd), acc, p);              // tdot' = tt tdot + ttdot t
+          bstrip<RT> B;
+          if constexpr (!K) fill(rd, sl(iRd), p);
+          fill(B, sl(2), p);
+          mm128(rd, B, p);
+          spill(sl(iRd), rd, p);               // rdot' = rdot + tt Q2 + ttdot rt
+          if constexpr (!K) fill(tdn, sl(iTd), p);
+          mm_held<K, RT>(tdn, t_s, sl(1), p);
+          spill(sl(iTd), tdn, p);              // tdot' = tt tdot + ttdot t
           rider2(y0, y1, xt, p);
         }
         __syncthreads();                       // [ttdot] free, y complete
@@ -310,13 +291,34 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         }
         if (tid == 0) ekl_g[s + (long long)S * pp] = 2.0 * k * kl;      // (k_ekl_step, before expk is squared)
       }
-      // ---- end of step
-      for (int i = tid; i < NP; i += blockDim.x) {
-        jp[i] = jpn[i];
-        jm[i] = jmn[i];
+
+      // ================= forward: r' = r + tt W ; t' = tt t ; sources (after the parameters: they read the old r, t) ==========
+      {
+        bstrip<RT> tt;
+        fill(tt, sl(4), p);
+        store_af(tt, N, p);                    // (the A-form is free: barrier above)
       }
-      { const int t0 = iR; iR = iR2; iR2 = t0; }
-      { const int t0 = iT; iT = iT2; iT2 = t0; }
+      for (int i = tid; i < NP; i += blockDim.x) {
+        xt[i] = Av[i];
+        xt[NP + i] = Bv[i];
+      }
+      __syncthreads();
+      {
+        bstrip<RT> B, tn;
+        if constexpr (!K) fill(r_s, sl(0), p);
+        fill(B, sl(2), p);
+        mm128(r_s, B, p);                      // r' = r + tt W
+        if constexpr (!K) spill(sl(0), r_s, p);
+        tn.zero();
+        mm_held<K, RT>(tn, t_s, sl(1), p);     // t' = tt t
+        if constexpr (K) t_s = tn; else spill(sl(1), tn, p);
+        rider2(y0, y1, xt, p);                 // tt A | tt B
+      }
+      __syncthreads();                         // [tt] free, y complete
+      for (int i = tid; i < NP; i += blockDim.x) {
+        jm[i] = jm[i] + y0[i];                 // j0-' = j0- + tt A
+        jp[i] = J1p[i] + y1[i];                // j0+' = j1+ + tt B
+      }
       k = k * k;
       __syncthreads();
     }
@@ -342,11 +344,11 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
             }
           }
       };
+      if constexpr (!K) fill(r_s, sl(0), p);
+      put(r_s, a.r_mp, a.r_pm, true);
+      if constexpr (!K) fill(t_s, sl(1), p);
+      put(t_s, a.t_pp, a.t_mm, false);
       bstrip<RT> x;
-      fill(x, sl(iR), p);
-      put(x, a.r_mp, a.r_pm, true);
-      fill(x, sl(iT), p);
-      put(x, a.t_pp, a.t_mm, false);
       for (int pp = 0; pp < P; ++pp) {
         fill(x, sl(DL_FIXED + 2 * pp), p);
         put(x, al.ap_r_mp + pp * MS, al.ap_r_pm + pp * MS, true);
@@ -391,11 +393,13 @@ struct ia128_half {
   double* VDOUT;
 };
 // scratch slots: 0 ER, 1 S2, 2 S3, 3 rt, 4 G, 5 tt, 6 X1 / Y, 7 X2 / outp0, 8 outp1
+// (K, four row tiles: ER, S2 stay in registers for the whole point, X1, X2, Y and the two outputs of a parameter never leave them)
 constexpr int IL_SLOTS = 9;
 template <int RT>
 __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, int S, int P, ia128_half h, d4_t* __restrict__ scr,
                                                                         int* __restrict__ status) {
   constexpr int NP = 16 * RT;
+  constexpr bool K = keep128<RT>::value;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
   float* red = reinterpret_cast<float*>(lds128 + NP * NP);
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
   double *vr = vt, *vadd = vt + NP, *vacc = vt + 2 * NP, *rtv = vt + 3 * NP;
   double *xt = vt + 4 * NP;                       // x_0 | x_1 (2 NP)
   double *y0 = vt + 6 * NP, *y1 = vt + 7 * NP;
-  double *vdr = vt + 8 * NP, *vdadd = vt + 9 * NP, *vdacc = vt + 10 * NP, *pv = vt + 11 * NP, *x2v = vt + 12 * NP, *vd = vt + 13 * NP;
+  double *vdr = vt + 8 * NP, *vdadd = vt + 9 * NP, *vdacc = vt + 10 * NP, *pv = vt + 11 * NP, *vd = vt + 13 * NP;
   const inv128_ctx icx{AF, gjs, status};
   bpos<RT> p(lds_addr128(AF), N);
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
@@ -414,9 +418,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     // ================= forward =================
-    bstrip<RT> G;
+    bstrip<RT> er, s2;                             // (K: live for the whole point)
     {
-      bstrip<RT> er, s2;
       load_global128(er, h.ER + s * h.sER, N, p);
       load_global128(s2, h.S2 + s * h.sS2, N, p);
       stage_af(AF, h.LA + s * h.sLA, N, nw, p);
@@ -429,10 +432,12 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
         xt[i] = v;
         xt[NP + i] = v;
       }
-      spill(sl(0), er, p);
-      spill(sl(1), s2, p);
+      if constexpr (!K) {
+        spill(sl(0), er, p);
+        spill(sl(1), s2, p);
+      }
       __syncthreads();
-      bstrip<RT> E;
+      bstrip<RT> E, G;
       E.zero();
       mm128(E, er, p);                         // E = LA ER
       {
@@ -451,11 +456,9 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       for (int i = tid; i < NP; i += blockDim.x) rtv[i] = vadd[i] + y0[i];
       invert128(inv_order128(nrm, status), E, G, N, icx, p);
       spill(sl(4), G, p);
-    }
-    __syncthreads();                           // [E] no longer read
-    stage_af(AF, h.LT + s * h.sLT, N, nw, p);
-    __syncthreads();
-    {
+      __syncthreads();                         // [E] no longer read
+      stage_af(AF, h.LT + s * h.sLT, N, nw, p);
+      __syncthreads();
       bstrip<RT> tt;
       tt.zero();
       mm128(tt, G, p);                         // tt = LT G
@@ -465,6 +468,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
 
     // ================= parameters =================
     for (int pp = 0; pp < P; ++pp) {
+      bstrip<RT> X1, X2;                       // (K: live to the [tt] phase)
       // ---- [PA]: X1 = PA ER ; X2 = PA S2 ; rider PA VR
       stage_af(AF, h.PA + s * h.sPA + pp * h.pPA, N, nw, p);
       for (int i = tid; i < NP; i += blockDim.x) {
@@ -477,15 +481,12 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       }
       __syncthreads();
       {
-        bstrip<RT> B, X;
-        fill(B, sl(0), p);
-        X.zero();
-        mm128(X, B, p);
-        spill(sl(6), X, p);                    // X1 (partial)
-        fill(B, sl(1), p);
-        X.zero();
-        mm128(X, B, p);
-        spill(sl(7), X, p);                    // X2 (partial)
+        X1.zero();
+        mm_held<K, RT>(X1, er, sl(0), p);      // X1 = PA ER
+        if constexpr (!K) spill(sl(6), X1, p);
+        X2.zero();
+        mm_held<K, RT>(X2, s2, sl(1), p);      // X2 = PA S2
+        if constexpr (!K) spill(sl(7), X2, p);
         rider2(pv, y1, xt, p);
       }
       // ---- [LA]: X1 += LA D1 ; X2 += LA D2 ; rider LA VDR
@@ -497,15 +498,17 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       }
       __syncthreads();
       {
-        bstrip<RT> B, X;
-        fill(X, sl(6), p);
+        bstrip<RT> B;
+        if constexpr (!K) fill(X1, sl(6), p);
         load_global128(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p);
-        mm128(X, B, p);
-        spill(sl(6), X, p);                    // X1
-        fill(X, sl(7), p);
+        mm128(X1, B, p);                       // X1 = PA ER + LA D1
+        if constexpr (!K) {
+          spill(sl(6), X1, p);
+          fill(X2, sl(7), p);
+        }
         load_global128(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p);
-        mm128(X, B, p);
-        spill(sl(7), X, p);                    // X2
+        mm128(X2, B, p);                       // X2 = PA S2 + LA D2
+        if constexpr (!K) spill(sl(7), X2, p);
         rider2(y0, y1, xt, p);
       }
       // ---- [tt]: Y = YI + tt X1 ; outp0 = ACCP + tt X2 ; outp1 = tt D3 ; rider tt x2v
@@ -517,41 +520,36 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       }
       for (int i = tid; i < NP; i += blockDim.x) {
         const double v = vdadd[i] + pv[i] + y0[i];   // X2[:, c] = PA VR + LA VDR + VDADD
-        x2v[i] = v;
         xt[i] = v;
         xt[NP + i] = v;
       }
       __syncthreads();
+      bstrip<RT> Y, o0, o1;
       {
-        bstrip<RT> acc, B;
-        load_global128(acc, h.YI + s * h.sYI + pp * h.pYI, N, p);
-        fill(B, sl(6), p);
-        mm128(acc, B, p);
-        spill(sl(6), acc, p);                  // Y
-        load_global128(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
-        fill(B, sl(7), p);
-        mm128(acc, B, p);
-        spill(sl(7), acc, p);                  // outp0 (partial)
+        load_global128(Y, h.YI + s * h.sYI + pp * h.pYI, N, p);
+        mm_held<K, RT>(Y, X1, sl(6), p);       // Y = YI + tt X1
+        if constexpr (!K) spill(sl(6), Y, p);
+        load_global128(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
+        mm_held<K, RT>(o0, X2, sl(7), p);      // outp0 = ACCP + tt X2 (+ ttdot rt below)
+        if constexpr (!K) spill(sl(7), o0, p);
+        bstrip<RT> B;
         load_global128(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p);
-        acc.zero();
-        mm128(acc, B, p);
-        spill(sl(8), acc, p);                  // outp1 (partial)
+        o1.zero();
+        mm128(o1, B, p);                       // outp1 = tt D3 (+ ttdot S3 below)
+        if constexpr (!K) spill(sl(8), o1, p);
         rider2(y0, y1, xt, p);
       }
       // ---- [Y]: ttdot = Y G
-      bstrip<RT> ttl;
-      {
-        bstrip<RT> Y;
-        fill(Y, sl(6), p);
-        __syncthreads();                       // [tt] no longer read, y complete
-        store_af(Y, N, p);
-      }
+      if constexpr (!K) fill(Y, sl(6), p);
+      __syncthreads();                         // [tt] no longer read, y complete
+      store_af(Y, N, p);
       for (int i = tid; i < NP; i += blockDim.x) {
         vd[i] = vdacc[i] + y0[i];              // VDACC + tt x2v (+ ttdot rtv below)
         xt[i] = rtv[i];
         xt[NP + i] = rtv[i];
       }
       __syncthreads();
+      bstrip<RT> ttl;
       {
         bstrip<RT> Gs;
         fill(Gs, sl(4), p);
@@ -563,15 +561,15 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       store_af(ttl, N, p);
       __syncthreads();
       {
-        bstrip<RT> acc, B;
-        fill(acc, sl(7), p);
+        bstrip<RT> B;
+        if constexpr (!K) fill(o0, sl(7), p);
         fill(B, sl(3), p);
-        mm128(acc, B, p);
-        store_global128(h.OUTP0 + (long long)pp * MS + NN * s, acc, N, p);
-        fill(acc, sl(8), p);
+        mm128(o0, B, p);
+        store_global128(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p);
+        if constexpr (!K) fill(o1, sl(8), p);
         fill(B, sl(2), p);
-        mm128(acc, B, p);
-        store_global128(h.OUTP1 + (long long)pp * MS + NN * s, acc, N, p);
+        mm128(o1, B, p);
+        store_global128(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p);
         rider2(y0, y1, xt, p);
       }
       __syncthreads();                         // [ttdot] free, y complete
@@ -641,12 +639,21 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
 }  // namespace
 
 // FP64, 60 < N <= 128 (N = 61 .. 64 on four row tiles: the strips of vsm_striplin.hip have no spare column left there)
-bool strip128_lin_supported(int N) { return N > 60 && N <= 128; }
+// Which shapes land here: beyond the reach of vsm_striplin.hip (8 <= N <= 60) by default; the thresholds are build parameters so
+// that tools/variants_lin128.sh can measure these kernels against vsm_striplin.hip's on the shapes both take.
+#ifndef VSM_LIN128_DBL_MIN
+#define VSM_LIN128_DBL_MIN 60
+#endif
+#ifndef VSM_LIN128_IA_MIN
+#define VSM_LIN128_IA_MIN 60
+#endif
+bool strip128_lin_dbl_supported(int N) { return N > VSM_LIN128_DBL_MIN && N <= 128; }
+bool strip128_lin_ia_supported(int N) { return N > VSM_LIN128_IA_MIN && N <= 128; }
 
 // All ndoubl doubling steps (forward + P active parameters) in one launch, apply_D! included when ns (n_stokes) > 0
 int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
                           const added_lin<double>& al, hipStream_t st) {
-  if (!strip128_lin_supported(N) || P < 0 || nd < 1 || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+  if (!strip128_lin_dbl_supported(N) || P < 0 || nd < 1 || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   switch ((N + 15) / 16) {
@@ -663,7 +670,7 @@ int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, dou
 // vsm_striplin.hip's strip_interaction11_lin
 int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
                                const added_lin<double>& al, hipStream_t st) {
-  if (!strip128_lin_supported(N)) return VSM_ERR_UNSUPPORTED;
+  if (!strip128_lin_ia_supported(N)) return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S;
