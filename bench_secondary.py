@@ -189,7 +189,9 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     CR = vsm.CoreRT
     S = points
     pc = CR.make_composite_layer(FT, arch, (N, N), S)
-    pa = CR.make_added_layer(FT, arch, (N, N), S)
+    # the added layer as doubling! leaves it for a scattering layer of a Stokes_IQU run: r+- = D r-+ D, t-- = D t++ D are derived
+    # inside the kernel (d_symmetric = nStokes), as in every unfused rt_kernel! step of a run whose layers all scatter
+    pa = CR.make_added_layer(FT, arch, (N, N), S, d_symmetric=3)
     dev = pc.R_mp.device
 
     def refl(scale):   # physically shaped operators: small reflections, near-diagonal transmissions (tools/ia_timing.py)
@@ -200,10 +202,8 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
         return torch.diag_embed(d) + torch.rand((S, N, N), dtype=torch.float64, device=dev) * (0.05 / N)
     init = dict(R_mp=refl(0.4), R_pm=refl(0.4), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
                 J0_m=torch.rand((S, N), dtype=torch.float64, device=dev))
-    for k in ("r_mp", "r_pm"):
-        getattr(pa, k).copy_(refl(0.3))
-    for k in ("t_pp", "t_mm"):
-        getattr(pa, k).copy_(trans())
+    pa.r_mp.copy_(refl(0.3))
+    pa.t_pp.copy_(trans())
     pa.j0_p.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
     pa.j0_m.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
     warm = 10                          # untimed launches first: the clocks have dropped during the latency-bound entries before
@@ -221,8 +221,8 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     ms = tot / reps
     flop_pt = 24.0 * N ** 3 + 8.0 * N ** 2
     e = _entry("IA", "interaction!(::ScatteringInterface_11) alone (interaction.jl:207-266), N=%d FP64, %d points per launch, physically "
-               "shaped random layers (||rR|| ~ 3e-2: series inverse); HIP events around each of %d launches" % (N, S, reps), S, ms * 1e-3, ms,
-               flop_pt, "f64", "k_ia_strip<15>")
+               "shaped random layers (||rR|| ~ 3e-2: series inverse), added layer D-symmetric as doubling! leaves it; HIP events around each of "
+               "%d launches" % (N, S, reps), S, ms * 1e-3, ms, flop_pt, "f64", "k_ia_strip<15, true>")
     e["north_star_target_mfma_utilisation"] = 0.40
     e["note"] = ("frac_of_mfma_peak is ALGORITHMIC flops (24N^3+8N^2 per point) / launch time / 78.6; the MFMA pipe's busy fraction "
                  "(PMC SQ_VALU_MFMA_BUSY_CYCLES) is higher: profiles/r04/ia/summary.json")

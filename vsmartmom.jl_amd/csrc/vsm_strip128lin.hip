@@ -645,7 +645,7 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
 #define VSM_LIN128_DBL_MIN 60
 #endif
 #ifndef VSM_LIN128_IA_MIN
-#define VSM_LIN128_IA_MIN 60
+#define VSM_LIN128_IA_MIN 32     // (k_ia128_lin<4> beats k_ia_lin_half on 33 <= N <= 60: C2 shape +5.7 % end to end)
 #endif
 bool strip128_lin_dbl_supported(int N) { return N > VSM_LIN128_DBL_MIN && N <= 128; }
 bool strip128_lin_ia_supported(int N) { return N > VSM_LIN128_IA_MIN && N <= 128; }
