@@ -468,9 +468,11 @@ def test_c5_k100_blocked_full_size(vsm, arch):
     w_ie = np.linspace(0.5, 1.5, K) * 0.04 / K
     rs = vsm.CoreRTRaman.RRS(shifts, w_ie, pm.greek_rayleigh, fscattRayl=pm.tau_rayl / (pm.tau_rayl + pm.tau_abs))
     assert vsm.CoreRTRaman.raman_bytes_per_point(21, K, 8) * S > 140e9
+    torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()       # (whatever earlier tests of the session still hold, e.g. cached work buffers)
     R, T, ieR, ieT = vsm.CoreRTRaman.rt_run(rs, pm, 1, max_points=4000)
-    assert torch.cuda.max_memory_allocated() < 45e9
+    assert torch.cuda.max_memory_allocated() - base < 45e9
     assert R.shape == (1, 3, S) and np.all(np.isfinite(ieR)) and np.all(np.isfinite(ieT))
     h = 1e-5
     small = Hm.model_from_arrays(arch, "IQU", 9, 40.0, [30.0], [0.0], **{**kw, "tau_rayl": tau_rayl[:4], "tau_abs": tau_abs[:4]})

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   double* xt = vec + 6 * NP;
   float* red = reinterpret_cast<float*>(vec + 8 * NP);
   const inv128_ctx icx{AF, vec + 8 * NP + 32, status};
+  double* xw = vec + 8 * NP + 32 + 128 + 16 * XS8B * (threadIdx.x >> 6);   // the wave's transposer tile (load_c8 / store_c8)
   bpos<RT> p(lds_addr128(AF), N);
   const unsigned xb = lds_addr128(xt) + 8u * (unsigned)((p.l15 & 1) * NP + p.kq);
   const int rrow = 16 * p.wave + p.kq;
@@ -353,8 +354,9 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       if constexpr (MR) xt[i] = xt[NP + i] = vjm[i];
     }
     bstrip<RT> r_s;
-    load_global128(r_s, a_r_mp, N, p);                  // (in flight with the staging)
+    load_c8_issue(r_s, a_r_mp, N, p);                   // (in flight with the staging)
     stage_af(AF, R_pm, N, nw, p);
+    load_c8_finish(r_s, p, xw);
     __syncthreads();                                    // (a)
     B128_STAMP(0);
     B128_STAMP(1);
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         for (int r = 0; r < 4; ++r) r_s.v[ta][r] = vjm[p.row(ta, r)];
     }
     bstrip<RT> tm;
-    load_global128(tm, a_t_mm, N, p);                   // (requested a product ahead)
+    load_c8_issue(tm, a_t_mm, N, p);                    // (requested a product ahead; permuted where it is first used)
     {
       bstrip<RT> E;
       E.zero();
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       spill(sE, E, p);
     }
     B128_STAMP(2);
+    load_c8_finish(tm, p, xw);
     {
       {
         bstrip<RT> Z;
@@ -461,13 +464,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     bstrip<RT> Tpp;
     {
       bstrip<RT> acc, Z;
-      load_global128(acc, a_r_pm, N, p);                // (requested across the barrier)
+      load_c8_issue(acc, a_r_pm, N, p);                 // (requested across the barrier)
       fill(Z, sZ, p);
       __syncthreads();                                  // (j)
       B128_STAMP(12);
+      load_c8_finish(acc, p, xw);
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
-      load_global128(Tpp, T_pp, N, p);
-      store_global128(R_pm, acc, N, p);
+      load_c8_issue(Tpp, T_pp, N, p);
+      store_c8(R_pm, acc, N, p, xw);
+      load_c8_finish(Tpp, p, xw);
     }
     B128_STAMP(13);
     if (laneR) {                                        // z rides in the spare column of T++
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       } else {
         mm128(acc, Tpp, p);                             // T++ = T21 T++ ; rider: T21 z
       }
-      store_global128(T_pp, acc, N, p);
+      store_c8(T_pp, acc, N, p, xw);
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     bstrip<RT> V2, Z2;
     {
       bstrip<RT> acc;
-      load_global128(acc, R_mp, N, p);
+      load_c8(acc, R_mp, N, p, xw);
       if constexpr (MR) {
         d4_t y = acc_zero<double>();
         mm128r(acc, Tpp, y, xb, p);                     // R-+ = R-+ + Y T++ ; tile: Y z
@@ -523,7 +528,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
       fill(V2, sV, p);                                  // (the last product's operands, requested ahead of the stores)
       fill(Z2, sZ, p);
-      store_global128(R_mp, acc, N, p);
+      store_c8(R_mp, acc, N, p, xw);
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       bstrip<RT>& Z = Z2;
       mm128(acc, Z, p);                                 // T-- = V + Y Z
       B128_STAMP(16);
-      store_global128(T_mm, acc, N, p);
+      store_c8(T_mm, acc, N, p, xw);
     }
     __syncthreads();                                    // (m) the next point restages the A-form and the vectors
     B128_STAMP(17);
@@ -551,7 +556,8 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 template <int RT, bool MR>
 int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, int* status,
                  hipStream_t st) {
-  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256 + GJS_BYTES;
+  constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256 + GJS_BYTES +
+                         B_MAXW * 16 * XS8B * sizeof(double);
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128<RT, MR>), lds, "hipFuncSetAttribute(k_ia128)")) return prepared;
   hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr, status);
   VSM_LAUNCH_CHECK("k_ia128");

@@ -451,5 +451,78 @@ __device__ __forceinline__ void store_global128(double* __restrict__ g, const bs
     }
 }
 
+// ---- strip <-> global through a wave-private 16 x 8 tile of LDS (the c8 scheme of vsm_strip_dev.h for RT row tiles) --------------
+// load_global128 / store_global128 touch 16 columns x 32 B per instruction -- sixteen quarter-used cache lines per request, and
+// sixteen requests per strip tile.  Here a lane moves 16 contiguous bytes of one column (lane = (column c = lane >> 2, q = lane & 3):
+// a wave-instruction covers 16 columns x 64 B) and the permutation to the accumulator layout happens in a 16 x 8 tile private to
+// the wave (pitch 10 doubles: conflict-free both ways) -- no workgroup barrier: LDS operations of one wave complete in order.
+// `issue` only requests (the strip's registers hold the raw doubles meanwhile), `finish` permutes: whatever lies between hides
+// the round trip.  xw: 160 doubles of LDS per wave.
+constexpr int XS8B = 10;
+typedef double d2b_t __attribute__((ext_vector_type(2), aligned(8)));   // 16 bytes, 8-byte aligned (N may be odd)
+template <int RT>
+__device__ __forceinline__ void load_c8_issue(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  const double* src0 = g + (long long)N * min(col, N - 1);
+  asm volatile("" : "+v"(src0));
+  gcd_p src = (gcd_p)src0;
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    const int r = 8 * j + 2 * q;
+    double a = 0.0, b = 0.0;
+    if (col < N && r + 1 < N) {
+      const d2b_t t = *reinterpret_cast<const __attribute__((address_space(1))) d2b_t*>(src + r);
+      a = t.x;
+      b = t.y;
+    } else if (col < N && r < N) {
+      a = src[r];
+    }
+    x.v[j >> 1][2 * (j & 1)] = a;
+    x.v[j >> 1][2 * (j & 1) + 1] = b;
+  }
+}
+template <int RT>
+__device__ __forceinline__ void load_c8_finish(bstrip<RT>& x, const bpos<RT>& p, double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    __builtin_amdgcn_wave_barrier();
+    xw[c * XS8B + 2 * q] = x.v[j >> 1][2 * (j & 1)];
+    xw[c * XS8B + 2 * q + 1] = x.v[j >> 1][2 * (j & 1) + 1];
+    __builtin_amdgcn_wave_barrier();
+    x.v[j >> 1][2 * (j & 1)] = xw[p.l15 * XS8B + p.kq];
+    x.v[j >> 1][2 * (j & 1) + 1] = xw[p.l15 * XS8B + p.kq + 4];
+  }
+}
+template <int RT>
+__device__ __forceinline__ void load_c8(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p, double* __restrict__ xw) {
+  load_c8_issue(x, g, N, p);
+  load_c8_finish(x, p, xw);
+}
+template <int RT>
+__device__ __forceinline__ void store_c8(double* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double* __restrict__ xw) {
+  const int c = p.lane >> 2, q = p.lane & 3;
+  const int col = 16 * p.wave + c;
+  double* dst0 = g + (long long)N * min(col, N - 1);
+  asm volatile("" : "+v"(dst0));
+  gd_p dst = (gd_p)dst0;
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    __builtin_amdgcn_wave_barrier();
+    xw[p.l15 * XS8B + p.kq] = x.v[j >> 1][2 * (j & 1)];
+    xw[p.l15 * XS8B + p.kq + 4] = x.v[j >> 1][2 * (j & 1) + 1];
+    __builtin_amdgcn_wave_barrier();
+    d2b_t t;
+    t.x = xw[c * XS8B + 2 * q];
+    t.y = xw[c * XS8B + 2 * q + 1];
+    const int r = 8 * j + 2 * q;
+    if (col < N && r + 1 < N)
+      *reinterpret_cast<__attribute__((address_space(1))) d2b_t*>(dst + r) = t;
+    else if (col < N && r < N)
+      dst[r] = t.x;
+  }
+}
+
 }  // namespace
 }  // namespace vsm

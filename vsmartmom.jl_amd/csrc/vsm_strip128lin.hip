@@ -32,8 +32,10 @@ template <int RT>
 struct lin128 {
   static constexpr int NP = 16 * RT;
   // LDS (doubles): A-form | reduction slots (32) | pivot / permutation of the Gauss-Jordan path (128) | NVEC vector tables of NP
+  // | one transposer tile per wave
   static constexpr int NVEC = 20;
-  static constexpr size_t lds_bytes() { return (size_t)(NP * NP + 32 + 128 + NVEC * NP) * sizeof(double); }
+  static constexpr int XW = 16 * XS8B;   // per-wave transposer tile of load_c8 / store_c8
+  static constexpr size_t lds_bytes() { return (size_t)(NP * NP + 32 + 128 + NVEC * NP + RT * XW) * sizeof(double); }
 };
 
 // y_0 = [A] x_0, y_1 = [A] x_1 for the two vectors of the LDS table at xt (x_0 = xt[0..NP), x_1 = xt[NP..2 NP)): wave w forms row
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
   double *aJpn = vt + 18 * NP, *aJmn = vt + 19 * NP;
   const inv128_ctx icx{AF, gjs, status};
   bpos<RT> p(lds_addr128(AF), N);
+  double* xw = vt + lin128<RT>::NVEC * NP + lin128<RT>::XW * p.wave;
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int nslots = DL_FIXED + 2 * P;
@@ -111,15 +114,15 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
     double k = expk_g[s];
     bstrip<RT> r_s, t_s;                           // (K: the state; else scratch copies that die at once)
     {
-      load_global128(r_s, a.r_mp + NN * s, N, p);
+      load_c8(r_s, a.r_mp + NN * s, N, p, xw);
       if constexpr (!K) spill(sl(0), r_s, p);
-      load_global128(t_s, a.t_pp + NN * s, N, p);
+      load_c8(t_s, a.t_pp + NN * s, N, p, xw);
       if constexpr (!K) spill(sl(1), t_s, p);
       bstrip<RT> x;
       for (int pp = 0; pp < P; ++pp) {
-        load_global128(x, al.ap_r_mp + pp * MS + NN * s, N, p);
+        load_c8(x, al.ap_r_mp + pp * MS + NN * s, N, p, xw);
         spill(sl(DL_FIXED + 2 * pp), x, p);
-        load_global128(x, al.ap_t_pp + pp * MS + NN * s, N, p);
+        load_c8(x, al.ap_t_pp + pp * MS + NN * s, N, p, xw);
         spill(sl(DL_FIXED + 2 * pp + 1), x, p);
       }
     }
@@ -325,24 +328,21 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
 
     // ---- out: apply_D! with derivative slots (doubling_lin.jl:374-421) when ns > 0, else the plain state
     {
-      const bool cok = p.col < N;
       const bool uj = ns > 0 && is_uv_row(min(p.col, N - 1), ns);
       auto put = [&](const bstrip<RT>& x, double* g_f, double* g_b, bool flip) {
         // g_f = x with its U / V rows negated (flip), g_b = D g_f D ... as k_apply_D_lin
-        long long o = NN * s + (long long)N * p.col + p.kq;
+        bstrip<RT> f, bb;
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = p.row(ta, r);
-            if (row < N && cok) {
-              const bool ui = ns > 0 && is_uv_row(row, ns);
-              const double v = (flip && ui) ? -x.v[ta][r] : x.v[ta][r];
-              const long long e = o + 16 * ta + 4 * r;
-              g_f[e] = v;
-              if (ns > 0) g_b[e] = (ui == uj) ? v : -v;
-            }
+            const bool ui = ns > 0 && is_uv_row(p.row(ta, r), ns);
+            const double v = (flip && ui) ? -x.v[ta][r] : x.v[ta][r];
+            f.v[ta][r] = v;
+            bb.v[ta][r] = (ui == uj) ? v : -v;
           }
+        store_c8(g_f + NN * s, f, N, p, xw);
+        if (ns > 0) store_c8(g_b + NN * s, bb, N, p, xw);
       };
       if constexpr (!K) fill(r_s, sl(0), p);
       put(r_s, a.r_mp, a.r_pm, true);
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
       if (ns > 0) {                            // the slots of the inactive parameters are zero (as k_dbl_lin_multi)
         x.zero();
         for (int pp = P; pp < al.P; ++pp) {
-          store_global128(al.ap_r_pm + pp * MS + NN * s, x, N, p);
-          store_global128(al.ap_t_mm + pp * MS + NN * s, x, N, p);
+          store_c8(al.ap_r_pm + pp * MS + NN * s, x, N, p, xw);
+          store_c8(al.ap_t_mm + pp * MS + NN * s, x, N, p, xw);
         }
       }
       if (tid < N) {
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
   double *vdr = vt + 8 * NP, *vdadd = vt + 9 * NP, *vdacc = vt + 10 * NP, *pv = vt + 11 * NP, *vd = vt + 13 * NP;
   const inv128_ctx icx{AF, gjs, status};
   bpos<RT> p(lds_addr128(AF), N);
+  double* xw = vt + lin128<RT>::NVEC * NP + lin128<RT>::XW * p.wave;
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   int slot = 0;
@@ -420,8 +421,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
     // ================= forward =================
     bstrip<RT> er, s2;                             // (K: live for the whole point)
     {
-      load_global128(er, h.ER + s * h.sER, N, p);
-      load_global128(s2, h.S2 + s * h.sS2, N, p);
+      load_c8(er, h.ER + s * h.sER, N, p, xw);
+      load_c8(s2, h.S2 + s * h.sS2, N, p, xw);
       stage_af(AF, h.LA + s * h.sLA, N, nw, p);
       for (int i = tid; i < NP; i += blockDim.x) {
         const long long o = (long long)N * s + i;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       rider2(y0, y1, xt, p);                   // LA VR
       {
         bstrip<RT> s3;                         // (parked now: the second half's OUT1 overwrites S3's array)
-        load_global128(s3, h.S3 + s * h.sS3, N, p);
+        load_c8(s3, h.S3 + s * h.sS3, N, p, xw);
         spill(sl(2), s3, p);
       }
       const double nrm = norm128(E, N, nw, red, slot, p);     // (barrier: [LA] free, y complete)
@@ -500,13 +501,13 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       {
         bstrip<RT> B;
         if constexpr (!K) fill(X1, sl(6), p);
-        load_global128(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p);
+        load_c8(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
         mm128(X1, B, p);                       // X1 = PA ER + LA D1
         if constexpr (!K) {
           spill(sl(6), X1, p);
           fill(X2, sl(7), p);
         }
-        load_global128(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p);
+        load_c8(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
         mm128(X2, B, p);                       // X2 = PA S2 + LA D2
         if constexpr (!K) spill(sl(7), X2, p);
         rider2(y0, y1, xt, p);
@@ -526,14 +527,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       __syncthreads();
       bstrip<RT> Y, o0, o1;
       {
-        load_global128(Y, h.YI + s * h.sYI + pp * h.pYI, N, p);
+        load_c8(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
         mm_held<K, RT>(Y, X1, sl(6), p);       // Y = YI + tt X1
         if constexpr (!K) spill(sl(6), Y, p);
-        load_global128(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p);
+        load_c8(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
         mm_held<K, RT>(o0, X2, sl(7), p);      // outp0 = ACCP + tt X2 (+ ttdot rt below)
         if constexpr (!K) spill(sl(7), o0, p);
         bstrip<RT> B;
-        load_global128(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p);
+        load_c8(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
         o1.zero();
         mm128(o1, B, p);                       // outp1 = tt D3 (+ ttdot S3 below)
         if constexpr (!K) spill(sl(8), o1, p);
@@ -565,11 +566,11 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
         if constexpr (!K) fill(o0, sl(7), p);
         fill(B, sl(3), p);
         mm128(o0, B, p);
-        store_global128(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p);
+        store_c8(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p, xw);
         if constexpr (!K) fill(o1, sl(8), p);
         fill(B, sl(2), p);
         mm128(o1, B, p);
-        store_global128(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p);
+        store_c8(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p, xw);
         rider2(y0, y1, xt, p);
       }
       __syncthreads();                         // [ttdot] free, y complete
@@ -589,14 +590,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
     __syncthreads();
     {
       bstrip<RT> acc, B;
-      load_global128(acc, h.ACC0 + s * h.sACC0, N, p);
+      load_c8(acc, h.ACC0 + s * h.sACC0, N, p, xw);
       fill(B, sl(3), p);
       mm128(acc, B, p);                        // out0 = ACC0 + tt rt
-      store_global128(h.OUT0 + NN * s, acc, N, p);
+      store_c8(h.OUT0 + NN * s, acc, N, p, xw);
       fill(B, sl(2), p);
       acc.zero();
       mm128(acc, B, p);                        // out1 = tt S3
-      store_global128(h.OUT1 + NN * s, acc, N, p);
+      store_c8(h.OUT1 + NN * s, acc, N, p, xw);
       rider2(y0, y1, xt, p);
     }
     __syncthreads();
