@@ -354,9 +354,9 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       if constexpr (MR) xt[i] = xt[NP + i] = vjm[i];
     }
     bstrip<RT> r_s;
-    load_c8_issue(r_s, a_r_mp, N, p);                   // (in flight with the staging)
+    ldg_issue(r_s, a_r_mp, N, p);                   // (in flight with the staging)
     stage_af(AF, R_pm, N, nw, p);
-    load_c8_finish(r_s, p, xw);
+    ldg_finish(r_s, p, xw);
     __syncthreads();                                    // (a)
     B128_STAMP(0);
     B128_STAMP(1);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         for (int r = 0; r < 4; ++r) r_s.v[ta][r] = vjm[p.row(ta, r)];
     }
     bstrip<RT> tm;
-    load_c8_issue(tm, a_t_mm, N, p);                    // (requested a product ahead; permuted where it is first used)
+    ldg_issue(tm, a_t_mm, N, p);                    // (requested a product ahead; permuted where it is first used)
     {
       bstrip<RT> E;
       E.zero();
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       spill(sE, E, p);
     }
     B128_STAMP(2);
-    load_c8_finish(tm, p, xw);
+    ldg_finish(tm, p, xw);
     {
       {
         bstrip<RT> Z;
@@ -464,15 +464,15 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     bstrip<RT> Tpp;
     {
       bstrip<RT> acc, Z;
-      load_c8_issue(acc, a_r_pm, N, p);                 // (requested across the barrier)
+      ldg_issue(acc, a_r_pm, N, p);                 // (requested across the barrier)
       fill(Z, sZ, p);
       __syncthreads();                                  // (j)
       B128_STAMP(12);
-      load_c8_finish(acc, p, xw);
+      ldg_finish(acc, p, xw);
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
-      load_c8_issue(Tpp, T_pp, N, p);
-      store_c8(R_pm, acc, N, p, xw);
-      load_c8_finish(Tpp, p, xw);
+      ldg_issue(Tpp, T_pp, N, p);
+      stg(R_pm, acc, N, p, xw);
+      ldg_finish(Tpp, p, xw);
     }
     B128_STAMP(13);
     if (laneR) {                                        // z rides in the spare column of T++
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       } else {
         mm128(acc, Tpp, p);                             // T++ = T21 T++ ; rider: T21 z
       }
-      store_c8(T_pp, acc, N, p, xw);
+      stg(T_pp, acc, N, p, xw);
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
     bstrip<RT> V2, Z2;
     {
       bstrip<RT> acc;
-      load_c8(acc, R_mp, N, p, xw);
+      ldg(acc, R_mp, N, p, xw);
       if constexpr (MR) {
         d4_t y = acc_zero<double>();
         mm128r(acc, Tpp, y, xb, p);                     // R-+ = R-+ + Y T++ ; tile: Y z
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       }
       fill(V2, sV, p);                                  // (the last product's operands, requested ahead of the stores)
       fill(Z2, sZ, p);
-      store_c8(R_mp, acc, N, p, xw);
+      stg(R_mp, acc, N, p, xw);
       if (laneR) {
 #pragma unroll
         for (int ta = 0; ta < RT; ++ta)
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
       bstrip<RT>& Z = Z2;
       mm128(acc, Z, p);                                 // T-- = V + Y Z
       B128_STAMP(16);
-      store_c8(T_mm, acc, N, p, xw);
+      stg(T_mm, acc, N, p, xw);
     }
     __syncthreads();                                    // (m) the next point restages the A-form and the vectors
     B128_STAMP(17);

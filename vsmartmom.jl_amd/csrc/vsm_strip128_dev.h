@@ -524,5 +524,31 @@ __device__ __forceinline__ void store_c8(double* __restrict__ g, const bstrip<RT
   }
 }
 
+// Which of the two a kernel uses is a matter of measurement: the tiles cost LDS round trips and wave barriers on the critical
+// path, the direct form costs sixteen requests per tile.  Forward and linearized runs, 2000 points (profiles/r04/shape_sweep):
+// five row tiles and fewer are 3 ... 4 % FASTER direct (the L2 absorbs the partial lines), six and more 0 ... 4.5 % faster
+// through the tiles.
+template <int RT>
+struct use_c8 {
+  static constexpr bool value = RT >= 6;
+};
+template <int RT>
+__device__ __forceinline__ void ldg_issue(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p) {
+  if constexpr (use_c8<RT>::value) load_c8_issue(x, g, N, p); else load_global128(x, g, N, p);
+}
+template <int RT>
+__device__ __forceinline__ void ldg_finish(bstrip<RT>& x, const bpos<RT>& p, double* __restrict__ xw) {
+  if constexpr (use_c8<RT>::value) load_c8_finish(x, p, xw);
+}
+template <int RT>
+__device__ __forceinline__ void ldg(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p, double* __restrict__ xw) {
+  ldg_issue(x, g, N, p);
+  ldg_finish(x, p, xw);
+}
+template <int RT>
+__device__ __forceinline__ void stg(double* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double* __restrict__ xw) {
+  if constexpr (use_c8<RT>::value) store_c8(g, x, N, p, xw); else store_global128(g, x, N, p);
+}
+
 }  // namespace
 }  // namespace vsm

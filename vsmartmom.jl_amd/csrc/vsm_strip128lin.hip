@@ -54,9 +54,16 @@ __device__ __forceinline__ void rider2(double* y0, double* y1, const double* xt,
   }
 }
 
+// The wave's record of scratch slot `slot`: wbase (slot 0) + slot * one slot's stride.  The base goes through an empty asm so that
+// the sum is formed where it is used (two VALU instructions) instead of twenty hoisted -- and spilled -- slot addresses.
 template <int RT>
-__device__ __forceinline__ d4_t* slot_ptr(d4_t* scr, int nslots, int slot, const bpos<RT>& p) {
-  return scr + (((long long)blockIdx.x * nslots + slot) * B_MAXW + p.wave) * (RT * 64) + p.lane;
+__device__ __forceinline__ d4_t* slot_base(d4_t* scr, int nslots, const bpos<RT>& p) {
+  return scr + ((long long)blockIdx.x * nslots * B_MAXW + p.wave) * (RT * 64) + p.lane;
+}
+template <int RT>
+__device__ __forceinline__ d4_t* slot_ptr(d4_t* wbase, int slot) {
+  asm volatile("" : "+v"(wbase));
+  return wbase + (long long)slot * (B_MAXW * RT * 64);
 }
 
 // Residency policy.  At four row tiles (N <= 64) a strip is 32 registers and a workgroup's wave can hold six beside the
@@ -67,6 +74,12 @@ __device__ __forceinline__ d4_t* slot_ptr(d4_t* scr, int nslots, int slot, const
 template <int RT>
 struct keep128 {
   static constexpr bool value = RT <= 4;
+};
+// Persistent workgroups per CU (a workgroup is RT waves; the register budget is 256 up to four row tiles, i.e. two waves per SIMD):
+// eight waves per CU up to four row tiles, one workgroup beyond.
+template <int RT>
+struct wg_per_cu {
+  static constexpr int value = RT <= 2 ? 4 : (RT <= 4 ? 2 : 1);
 };
 // acc += [A] * (the strip `held` when K, else the parked strip at `slot`)
 template <bool K, int RT>
@@ -108,21 +121,22 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   const int nslots = DL_FIXED + 2 * P;
   int slot = 0;
-  auto sl = [&](int i) { return slot_ptr<RT>(scr, nslots, i, p); };
+  d4_t* const wbase = slot_base<RT>(scr, nslots, p);
+  auto sl = [&](int i) { return slot_ptr<RT>(wbase, i); };
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     double k = expk_g[s];
     bstrip<RT> r_s, t_s;                           // (K: the state; else scratch copies that die at once)
     {
-      load_c8(r_s, a.r_mp + NN * s, N, p, xw);
+      ldg(r_s, a.r_mp + NN * s, N, p, xw);
       if constexpr (!K) spill(sl(0), r_s, p);
-      load_c8(t_s, a.t_pp + NN * s, N, p, xw);
+      ldg(t_s, a.t_pp + NN * s, N, p, xw);
       if constexpr (!K) spill(sl(1), t_s, p);
       bstrip<RT> x;
       for (int pp = 0; pp < P; ++pp) {
-        load_c8(x, al.ap_r_mp + pp * MS + NN * s, N, p, xw);
+        ldg(x, al.ap_r_mp + pp * MS + NN * s, N, p, xw);
         spill(sl(DL_FIXED + 2 * pp), x, p);
-        load_c8(x, al.ap_t_pp + pp * MS + NN * s, N, p, xw);
+        ldg(x, al.ap_t_pp + pp * MS + NN * s, N, p, xw);
         spill(sl(DL_FIXED + 2 * pp + 1), x, p);
       }
     }
@@ -341,8 +355,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
             f.v[ta][r] = v;
             bb.v[ta][r] = (ui == uj) ? v : -v;
           }
-        store_c8(g_f + NN * s, f, N, p, xw);
-        if (ns > 0) store_c8(g_b + NN * s, bb, N, p, xw);
+        stg(g_f + NN * s, f, N, p, xw);
+        if (ns > 0) stg(g_b + NN * s, bb, N, p, xw);
       };
       if constexpr (!K) fill(r_s, sl(0), p);
       put(r_s, a.r_mp, a.r_pm, true);
@@ -358,8 +372,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
       if (ns > 0) {                            // the slots of the inactive parameters are zero (as k_dbl_lin_multi)
         x.zero();
         for (int pp = P; pp < al.P; ++pp) {
-          store_c8(al.ap_r_pm + pp * MS + NN * s, x, N, p, xw);
-          store_c8(al.ap_t_mm + pp * MS + NN * s, x, N, p, xw);
+          stg(al.ap_r_pm + pp * MS + NN * s, x, N, p, xw);
+          stg(al.ap_t_mm + pp * MS + NN * s, x, N, p, xw);
         }
       }
       if (tid < N) {
@@ -415,14 +429,15 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
   const int nw = blockDim.x >> 6, tid = threadIdx.x;
   const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
   int slot = 0;
-  auto sl = [&](int i) { return slot_ptr<RT>(scr, IL_SLOTS, i, p); };
+  d4_t* const wbase = slot_base<RT>(scr, IL_SLOTS, p);
+  auto sl = [&](int i) { return slot_ptr<RT>(wbase, i); };
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     // ================= forward =================
     bstrip<RT> er, s2;                             // (K: live for the whole point)
     {
-      load_c8(er, h.ER + s * h.sER, N, p, xw);
-      load_c8(s2, h.S2 + s * h.sS2, N, p, xw);
+      ldg(er, h.ER + s * h.sER, N, p, xw);
+      ldg(s2, h.S2 + s * h.sS2, N, p, xw);
       stage_af(AF, h.LA + s * h.sLA, N, nw, p);
       for (int i = tid; i < NP; i += blockDim.x) {
         const long long o = (long long)N * s + i;
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       rider2(y0, y1, xt, p);                   // LA VR
       {
         bstrip<RT> s3;                         // (parked now: the second half's OUT1 overwrites S3's array)
-        load_c8(s3, h.S3 + s * h.sS3, N, p, xw);
+        ldg(s3, h.S3 + s * h.sS3, N, p, xw);
         spill(sl(2), s3, p);
       }
       const double nrm = norm128(E, N, nw, red, slot, p);     // (barrier: [LA] free, y complete)
@@ -501,13 +516,13 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       {
         bstrip<RT> B;
         if constexpr (!K) fill(X1, sl(6), p);
-        load_c8(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
+        ldg(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
         mm128(X1, B, p);                       // X1 = PA ER + LA D1
         if constexpr (!K) {
           spill(sl(6), X1, p);
           fill(X2, sl(7), p);
         }
-        load_c8(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
+        ldg(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
         mm128(X2, B, p);                       // X2 = PA S2 + LA D2
         if constexpr (!K) spill(sl(7), X2, p);
         rider2(y0, y1, xt, p);
@@ -527,14 +542,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       __syncthreads();
       bstrip<RT> Y, o0, o1;
       {
-        load_c8(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
+        ldg(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
         mm_held<K, RT>(Y, X1, sl(6), p);       // Y = YI + tt X1
         if constexpr (!K) spill(sl(6), Y, p);
-        load_c8(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
+        ldg(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
         mm_held<K, RT>(o0, X2, sl(7), p);      // outp0 = ACCP + tt X2 (+ ttdot rt below)
         if constexpr (!K) spill(sl(7), o0, p);
         bstrip<RT> B;
-        load_c8(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
+        ldg(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
         o1.zero();
         mm128(o1, B, p);                       // outp1 = tt D3 (+ ttdot S3 below)
         if constexpr (!K) spill(sl(8), o1, p);
@@ -566,11 +581,11 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
         if constexpr (!K) fill(o0, sl(7), p);
         fill(B, sl(3), p);
         mm128(o0, B, p);
-        store_c8(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p, xw);
+        stg(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p, xw);
         if constexpr (!K) fill(o1, sl(8), p);
         fill(B, sl(2), p);
         mm128(o1, B, p);
-        store_c8(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p, xw);
+        stg(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p, xw);
         rider2(y0, y1, xt, p);
       }
       __syncthreads();                         // [ttdot] free, y complete
@@ -590,14 +605,14 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
     __syncthreads();
     {
       bstrip<RT> acc, B;
-      load_c8(acc, h.ACC0 + s * h.sACC0, N, p, xw);
+      ldg(acc, h.ACC0 + s * h.sACC0, N, p, xw);
       fill(B, sl(3), p);
       mm128(acc, B, p);                        // out0 = ACC0 + tt rt
-      store_c8(h.OUT0 + NN * s, acc, N, p, xw);
+      stg(h.OUT0 + NN * s, acc, N, p, xw);
       fill(B, sl(2), p);
       acc.zero();
       mm128(acc, B, p);                        // out1 = tt S3
-      store_c8(h.OUT1 + NN * s, acc, N, p, xw);
+      stg(h.OUT1 + NN * s, acc, N, p, xw);
       rider2(y0, y1, xt, p);
     }
     __syncthreads();
@@ -612,7 +627,7 @@ int launch_dbl128_lin(int N, int ns, int S, int P, int nd, double* expk, double*
   constexpr size_t lds = lin128<RT>::lds_bytes();
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128_lin<RT>), lds, "hipFuncSetAttribute(k_dbl128_lin)"))
     return prepared;
-  const int per_cu = RT <= 4 ? 2 : 1;
+  const int per_cu = wg_per_cu<RT>::value;
   const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
   const int nslots = DL_FIXED + 2 * P;
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * nslots * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
@@ -627,7 +642,7 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
   constexpr size_t lds = lin128<RT>::lds_bytes();
   if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128_lin<RT>), lds, "hipFuncSetAttribute(k_ia128_lin)"))
     return prepared;
-  const int per_cu = RT <= 4 ? 2 : 1;
+  const int per_cu = wg_per_cu<RT>::value;
   const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * IL_SLOTS * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   int* status = device_status();
@@ -648,8 +663,13 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
 #ifndef VSM_LIN128_IA_MIN
 #define VSM_LIN128_IA_MIN 32     // (k_ia128_lin<4> beats k_ia_lin_half on 33 <= N <= 60: C2 shape +5.7 % end to end)
 #endif
-bool strip128_lin_dbl_supported(int N) { return N > VSM_LIN128_DBL_MIN && N <= 128; }
-bool strip128_lin_ia_supported(int N) { return N > VSM_LIN128_IA_MIN && N <= 128; }
+// ... and the shapes of two and three row tiles (16 < N <= 48), where vsm_striplin.hip pads to 64 rows (measured: see DESIGN 4.1e)
+#ifndef VSM_LIN128_SMALL_MAX
+#define VSM_LIN128_SMALL_MAX 16
+#endif
+static bool lin128_small(int N) { return N > 16 && N <= VSM_LIN128_SMALL_MAX; }
+bool strip128_lin_dbl_supported(int N) { return (N > VSM_LIN128_DBL_MIN && N <= 128) || lin128_small(N); }
+bool strip128_lin_ia_supported(int N) { return (N > VSM_LIN128_IA_MIN && N <= 128) || lin128_small(N); }
 
 // All ndoubl doubling steps (forward + P active parameters) in one launch, apply_D! included when ns (n_stokes) > 0
 int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
@@ -658,6 +678,8 @@ int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, dou
     return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   switch ((N + 15) / 16) {
+    case 2: return launch_dbl128_lin<2>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 3: return launch_dbl128_lin<3>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 4: return launch_dbl128_lin<4>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 5: return launch_dbl128_lin<5>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 6: return launch_dbl128_lin<6>(N, ns, S, P, nd, expk, ekl, a, al, st);
@@ -716,6 +738,8 @@ int strip128_interaction11_lin(int N, int S, const composite<double>& c, const c
   case RT:                                                            \
     if ((rc = launch_ia128_lin<RT>(N, S, P, h1, st))) return rc;      \
     return launch_ia128_lin<RT>(N, S, P, h2, st);
+    VSM_CASE(2)
+    VSM_CASE(3)
     VSM_CASE(4)
     VSM_CASE(5)
     VSM_CASE(6)
