@@ -79,7 +79,7 @@ struct keep128 {
 // eight waves per CU up to four row tiles, one workgroup beyond.
 template <int RT>
 struct wg_per_cu {
-  static constexpr int value = RT <= 2 ? 4 : (RT <= 4 ? 2 : 1);
+  static constexpr int value = RT == 1 ? 8 : (RT == 2 ? 4 : (RT <= 4 ? 2 : 1));
 };
 // acc += [A] * (the strip `held` when K, else the parked strip at `slot`)
 template <bool K, int RT>
@@ -663,11 +663,12 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
 #ifndef VSM_LIN128_IA_MIN
 #define VSM_LIN128_IA_MIN 32     // (k_ia128_lin<4> beats k_ia_lin_half on 33 <= N <= 60: C2 shape +5.7 % end to end)
 #endif
-// ... and the shapes of two and three row tiles (16 < N <= 48), where vsm_striplin.hip pads to 64 rows (measured: see DESIGN 4.1e)
+// ... and the shapes of one to three row tiles (N <= 48), where vsm_striplin.hip pads to 64 rows (N = 30: 27.7 -> 84.3 10^3 points/s,
+// N = 48: 20.0 -> 23.4, profiles/r04/shape_sweep_f64.txt)
 #ifndef VSM_LIN128_SMALL_MAX
-#define VSM_LIN128_SMALL_MAX 16
+#define VSM_LIN128_SMALL_MAX 48
 #endif
-static bool lin128_small(int N) { return N > 16 && N <= VSM_LIN128_SMALL_MAX; }
+static bool lin128_small(int N) { return N >= 1 && N <= VSM_LIN128_SMALL_MAX; }
 bool strip128_lin_dbl_supported(int N) { return (N > VSM_LIN128_DBL_MIN && N <= 128) || lin128_small(N); }
 bool strip128_lin_ia_supported(int N) { return (N > VSM_LIN128_IA_MIN && N <= 128) || lin128_small(N); }
 
@@ -678,6 +679,7 @@ int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, dou
     return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   switch ((N + 15) / 16) {
+    case 1: return launch_dbl128_lin<1>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 2: return launch_dbl128_lin<2>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 3: return launch_dbl128_lin<3>(N, ns, S, P, nd, expk, ekl, a, al, st);
     case 4: return launch_dbl128_lin<4>(N, ns, S, P, nd, expk, ekl, a, al, st);
@@ -738,6 +740,7 @@ int strip128_interaction11_lin(int N, int S, const composite<double>& c, const c
   case RT:                                                            \
     if ((rc = launch_ia128_lin<RT>(N, S, P, h1, st))) return rc;      \
     return launch_ia128_lin<RT>(N, S, P, h2, st);
+    VSM_CASE(1)
     VSM_CASE(2)
     VSM_CASE(3)
     VSM_CASE(4)
