@@ -9,6 +9,7 @@ module vSmartMOMROCmExt
 
 using AMDGPU
 using Libdl
+using LinearAlgebra
 using vSmartMOM
 import vSmartMOM.Architectures: devi, array_type, architecture, GPU, _has_cuda, _sync_gpu
 import vSmartMOM.CoreRT: batched_mul, batch_inv!, batch_solve!, batched_pointer_cache, elemental!, doubling!,
@@ -44,6 +45,20 @@ macro vsm(base, FT, types, args...)
     :(_chk(ccall(_sym(_fn($(esc(base)), $(esc(FT)))), Cint, $(esc(types)), $(map(esc, args)...))))
 end
 _stream() = PV(AMDGPU.stream().stream)                  # hipStream_t of the current task
+# Streams and devices (include/vsmartmom_hip.h, Conventions): every call enqueues on the stream it is given and nowhere else; tasks
+# on different streams -- or on different devices of one process (AMDGPU.device!(d) in the task, streams of that device) -- are
+# independent: the library keeps its scratch per (device, stream) and its kernel attributes per device.
+release_scratch() = _chk(ccall((:vsm_release_scratch, libvsm), Cint, ()))            # frees the current device's library scratch
+build_id() = unsafe_string(ccall((:vsm_build_id, libvsm), Cstring, ()))               # source hash of the loaded library
+# The in-kernel inverses of an asynchronous launch cannot return `info`; they raise device flags.  Call after the
+# synchronisation that ends a run (rt_run does): a singular (I - R r) then throws like the CPU path's LU (cpu_batched.jl:32-47).
+function check_device_status(what = "rt_run")
+    flags = zeros(Cint, 4)
+    _chk(ccall((:vsm_device_status, libvsm), Cint, (Ptr{Cint}, Cint, PV), flags, 1, _stream()))
+    (flags[1] & 1) != 0 && throw(LinearAlgebra.SingularException(0))
+    (flags[1] & 2) != 0 && error("$what: NaN / Inf operand in an in-kernel inverse")
+    flags
+end
 _p(A::ROCArray) = PV(pointer(A))
 _p(::Nothing) = C_NULL
 

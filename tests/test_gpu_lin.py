@@ -287,11 +287,14 @@ def test_rt_run_lin_corner_columns(vsm, arch, pol, l_trunc, column):
         #                                                      scatter = true (j0+ = 0 there), rt_kernel! keeps the stale j0+
 
 
-@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 33)])   # N = 7, 21, 57
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 9), ("IQU", 31), ("IQU", 33), ("IQUV", 41),   # N = 7, 21, 57, 60, 96
+                                         ("IQUV", 61)])                                                    # N = 136: operator chain
 def test_rt_run_lin_fp32(vsm, arch, pol, l_trunc):
-    """The FP32 linearized entry points (vsm_*_lin_f32; FP32 runs operator level): rt_run(model, lin_model, 0, 2, 1) in
-    Float32 vs the FP64 oracle at the reference's FP32 gate (test/test_float32.jl:58-64: max relative deviation < 1e-2;
-    observed ~1e-5) for R, T and every Jacobian column, and the layer operators vs the FP32 oracle."""
+    """The FP32 linearized entry points (vsm_*_lin_f32): rt_run(model, lin_model, 0, 2, 1) in Float32 vs the FP64 oracle at the
+    reference's FP32 gate (test/test_float32.jl:58-64: max relative deviation < 1e-2; observed ~1e-5) for R, T and every
+    Jacobian column, and vs the FP32 oracle.  N <= 128: doubling / interaction (lin) run on the FP64 kernels of
+    vsm_strip128lin.hip over the FP32 arrays (storage in single, arithmetic in double); the elemental layer, the surface and
+    the post-processing stay FP32 kernels."""
     rng = np.random.default_rng(0)
     S, L = 3, 3
     tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))

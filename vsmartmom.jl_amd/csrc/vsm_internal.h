@@ -269,10 +269,12 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
 // ---- linearized column-strip kernels, FP64, 60 < N <= 128 (one A-form, parked strips): vsm_strip128lin.hip ----
 bool strip128_lin_dbl_supported(int N);   // which shapes take k_dbl128_lin / k_ia128_lin
 bool strip128_lin_ia_supported(int N);
-int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
-                          const added_lin<double>& al, hipStream_t st);
-int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
-                               const added_lin<double>& al, hipStream_t st);
+template <typename ST>   // ST = double, or float (storage in single, arithmetic in double)
+int strip128_doubling_lin(int N, int S, int P, int nd, int ns, ST* expk, ST* ekl, const added<ST>& a, const added_lin<ST>& al,
+                          hipStream_t st);
+template <typename ST>
+int strip128_interaction11_lin(int N, int S, const composite<ST>& c, const composite_lin<ST>& cl, const added<ST>& a,
+                               const added_lin<ST>& al, hipStream_t st);
 
 // Library-owned device scratch, keyed by (current device, stream, slot): two streams -- or two devices driven from one
 // process -- never share a buffer, so the entry points that use it keep the contract "calls on one stream are ordered, calls on

@@ -418,6 +418,11 @@ int doubling_lin(int N, int ns, int S, int ndoubl, T* expk, const T* dtau_dot_al
       if (rc == VSM_ERR_UNSUPPORTED && n0 == 0) break;
       if (rc) return rc;
     }
+  } else {
+    // Float32 (N <= 128): the FP64 kernels of vsm_strip128lin.hip on the FP32 arrays -- storage in single, arithmetic in double:
+    // their FP64 MFMA rate is above what the FP32 operator chain below reaches (N = 96: 28.6 -> 41 TFLOP/s)
+    rc = strip128_doubling_lin<T>(N, S, P, ndoubl, ns, expk, ekl, a, al, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
   for (int n = n0; n < ndoubl; ++n) {
     // forward: G = (I - r r)^-1, tt = t G
@@ -623,6 +628,9 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
     // 60 < N <= 128: the same two halves in the one-A-form / parked-strip scheme (vsm_strip128lin.hip)
     rc = strip128_interaction11_lin(N, S, c, cl, a, al, st);
+    if (rc != VSM_ERR_UNSUPPORTED) return rc;
+  } else {
+    rc = strip128_interaction11_lin<T>(N, S, c, cl, a, al, st);     // Float32 arrays, FP64 arithmetic (see doubling_lin)
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
   // ---- first half: G1, T01_inv and everything that hangs off them --------------------------------

@@ -408,10 +408,42 @@ __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __re
 }
 
 
+// The same from / to FP32 arrays (the reference's Float32 runs on these kernels: storage in single, arithmetic in double -- the
+// FP64 MFMA rate of these shapes is above what the FP32 operator chains reach)
+template <int RT>
+__device__ __forceinline__ void load_global128(bstrip<RT>& s, const float* __restrict__ g, int N, const bpos<RT>& p) {
+  const bool cok = p.col < N;
+  const float* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc0));
+  const __attribute__((address_space(1))) float* gc = (const __attribute__((address_space(1))) float*)gc0;
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = p.row(ta, r);
+      const float v = gc[min(row, N - 1) - p.kq];
+      s.v[ta][r] = (row < N && cok) ? (double)v : 0.0;
+    }
+}
+template <int RT>
+__device__ __forceinline__ void store_global128(float* __restrict__ g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
+  const bool cok = p.col < N;
+  float* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
+  asm volatile("" : "+v"(gc0));
+  __attribute__((address_space(1))) float* gc = (__attribute__((address_space(1))) float*)gc0;
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rok = ta < RT - 1 || p.row(ta, r) < N;
+      if (rok && cok) gc[16 * ta + 4 * r] = (float)s.v[ta][r];
+    }
+}
+
 // global column-major N x N -> the A-form (zero padded): a wave takes whole columns, lane = row (512-byte requests; the 16-lane
 // groups of the LDS store are 16 rows of one column: (m ^ const) -- conflict-free)
-template <int RT>
-__device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ g, int N, int nw, const bpos<RT>& p) {
+template <int RT, typename G>
+__device__ __forceinline__ void stage_af(double* AF, const G* __restrict__ g, int N, int nw, const bpos<RT>& p) {
   constexpr int NP = 16 * RT, CB = 8, NH = (NP + 63) / 64;   // CB columns x NH row blocks of a wave in flight together
   for (int c0 = p.wave; c0 < NP; c0 += CB * nw) {
     double v[CB][NH];
@@ -421,7 +453,7 @@ __device__ __forceinline__ void stage_af(double* AF, const double* __restrict__ 
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
         const int row = 64 * h + p.lane;
-        v[i][h] = (row < N && col < N) ? g[row + (long long)N * col] : 0.0;
+        v[i][h] = (row < N && col < N) ? (double)g[row + (long long)N * col] : 0.0;
       }
     }
 #pragma unroll
@@ -548,6 +580,14 @@ __device__ __forceinline__ void ldg(bstrip<RT>& x, const double* __restrict__ g,
 template <int RT>
 __device__ __forceinline__ void stg(double* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double* __restrict__ xw) {
   if constexpr (use_c8<RT>::value) store_c8(g, x, N, p, xw); else store_global128(g, x, N, p);
+}
+template <int RT>
+__device__ __forceinline__ void ldg(bstrip<RT>& x, const float* __restrict__ g, int N, const bpos<RT>& p, double*) {
+  load_global128(x, g, N, p);
+}
+template <int RT>
+__device__ __forceinline__ void stg(float* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double*) {
+  store_global128(g, x, N, p);
 }
 
 }  // namespace

@@ -96,10 +96,11 @@ __device__ __forceinline__ void mm_held(bstrip<RT>& acc, const bstrip<RT>& held,
 // ---- doubling ------------------------------------------------------------------------------------------------------------------
 // scratch slots: 0 r, 1 t, 2 W = r t, 3 G, 4 tt, 5 X1 / Y, 6 Q2, then (rdot_p, tdot_p) for p = 0 .. P-1
 constexpr int DL_FIXED = 7;
-template <int RT>
+// ST: the element type of the caller's arrays (double, or float: Float32 runs -- storage in single, arithmetic in double)
+template <int RT, typename ST>
 __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, int ns, int S, int P, int nd,
-                                                                         double* __restrict__ expk_g, double* __restrict__ ekl_g,
-                                                                         added<double> a, added_lin<double> al,
+                                                                         ST* __restrict__ expk_g, ST* __restrict__ ekl_g,
+                                                                         added<ST> a, added_lin<ST> al,
                                                                          d4_t* __restrict__ scr, int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   constexpr bool K = keep128<RT>::value;
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
       for (int pp = 0; pp < P; ++pp) {
         const double kl = ekl_g[s + (long long)S * pp];
         const int iRd = DL_FIXED + 2 * pp, iTd = iRd + 1;
-        double* g_aJp = al.ap_J0_p + pp * VS + (long long)N * s;
-        double* g_aJm = al.ap_J0_m + pp * VS + (long long)N * s;
+        ST* g_aJp = al.ap_J0_p + pp * VS + (long long)N * s;
+        ST* g_aJm = al.ap_J0_m + pp * VS + (long long)N * s;
         bstrip<RT> rd, X1, Q2;                 // (K: live from here to the [tt] phase)
         // ---- [r]: X1 = r rdot ; Q2 = r tdot ; riders r aJ+ | r aJ1-
         if constexpr (!K) fill(r_s, sl(0), p);
@@ -303,10 +304,10 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         }
         __syncthreads();                       // [ttdot] free, y complete
         if (tid < N) {
-          g_aJm[tid] = aJmn[tid] + y0[tid];
-          g_aJp[tid] = aJpn[tid] + y1[tid];
+          g_aJm[tid] = (ST)(aJmn[tid] + y0[tid]);
+          g_aJp[tid] = (ST)(aJpn[tid] + y1[tid]);
         }
-        if (tid == 0) ekl_g[s + (long long)S * pp] = 2.0 * k * kl;      // (k_ekl_step, before expk is squared)
+        if (tid == 0) ekl_g[s + (long long)S * pp] = (ST)(2.0 * k * kl);      // (k_ekl_step, before expk is squared)
       }
 
       // ================= forward: r' = r + tt W ; t' = tt t ; sources (after the parameters: they read the old r, t) ==========
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
     // ---- out: apply_D! with derivative slots (doubling_lin.jl:374-421) when ns > 0, else the plain state
     {
       const bool uj = ns > 0 && is_uv_row(min(p.col, N - 1), ns);
-      auto put = [&](const bstrip<RT>& x, double* g_f, double* g_b, bool flip) {
+      auto put = [&](const bstrip<RT>& x, ST* g_f, ST* g_b, bool flip) {
         // g_f = x with its U / V rows negated (flip), g_b = D g_f D ... as k_apply_D_lin
         bstrip<RT> f, bb;
 #pragma unroll
@@ -378,15 +379,15 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
       }
       if (tid < N) {
         const double sg = (ns > 0 && is_uv_row(tid, ns)) ? -1.0 : 1.0;
-        a.j0_p[(long long)N * s + tid] = jp[tid];
-        a.j0_m[(long long)N * s + tid] = sg * jm[tid];
+        a.j0_p[(long long)N * s + tid] = (ST)jp[tid];
+        a.j0_m[(long long)N * s + tid] = (ST)(sg * jm[tid]);
         if (ns > 0 && sg < 0.0)
           for (int pp = 0; pp < P; ++pp) {
-            double* g = al.ap_J0_m + pp * VS + (long long)N * s + tid;
+            ST* g = al.ap_J0_m + pp * VS + (long long)N * s + tid;
             *g = -*g;                          // (written by this very thread in the last step)
           }
       }
-      if (tid == 0) expk_g[s] = k;
+      if (tid == 0) expk_g[s] = (ST)k;
     }
     __syncthreads();   // the next point overwrites the tables and the A-form
   }
@@ -394,23 +395,24 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
 
 // ---- interaction half ---------------------------------------------------------------------------------------------------------
 // operand bindings of one half (the fields of vsm_striplin.hip's ia_half)
+template <typename ST>
 struct ia128_half {
-  const double *LA, *ER, *LT, *S2, *S3, *ACC0;
+  const ST *LA, *ER, *LT, *S2, *S3, *ACC0;
   long long sLA, sER, sLT, sS2, sS3, sACC0;
-  double *OUT0, *OUT1;
-  const double *VR, *VADD, *VACC;
-  double* VOUT;
-  const double *PA, *D1, *D2, *YI, *ACCP, *D3;
+  ST *OUT0, *OUT1;
+  const ST *VR, *VADD, *VACC;
+  ST* VOUT;
+  const ST *PA, *D1, *D2, *YI, *ACCP, *D3;
   long long sPA, pPA, sD1, pD1, sD2, pD2, sYI, pYI, sACCP, pACCP, sD3, pD3;
-  double *OUTP0, *OUTP1;
-  const double *VDR, *VDADD, *VDACC;
-  double* VDOUT;
+  ST *OUTP0, *OUTP1;
+  const ST *VDR, *VDADD, *VDACC;
+  ST* VDOUT;
 };
 // scratch slots: 0 ER, 1 S2, 2 S3, 3 rt, 4 G, 5 tt, 6 X1 / Y, 7 X2 / outp0, 8 outp1
 // (K, four row tiles: ER, S2 stay in registers for the whole point, X1, X2, Y and the two outputs of a parameter never leave them)
 constexpr int IL_SLOTS = 9;
-template <int RT>
-__global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, int S, int P, ia128_half h, d4_t* __restrict__ scr,
+template <int RT, typename ST>
+__global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, int S, int P, ia128_half<ST> h, d4_t* __restrict__ scr,
                                                                         int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   constexpr bool K = keep128<RT>::value;
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
         rider2(y0, y1, xt, p);
       }
       __syncthreads();                         // [ttdot] free, y complete
-      if (tid < N) h.VDOUT[(long long)pp * VS + (long long)N * s + tid] = vd[tid] + y0[tid];
+      if (tid < N) h.VDOUT[(long long)pp * VS + (long long)N * s + tid] = (ST)(vd[tid] + y0[tid]);
     }
 
     // ================= forward outputs (last: OUT0 / OUT1 alias operands of the parameter loop) =================
@@ -616,16 +618,16 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       rider2(y0, y1, xt, p);
     }
     __syncthreads();
-    if (tid < N) h.VOUT[(long long)N * s + tid] = vacc[tid] + y0[tid];
+    if (tid < N) h.VOUT[(long long)N * s + tid] = (ST)(vacc[tid] + y0[tid]);
     __syncthreads();   // the next point overwrites the tables and the A-form
   }
 }
 
-template <int RT>
-int launch_dbl128_lin(int N, int ns, int S, int P, int nd, double* expk, double* ekl, const added<double>& a,
-                      const added_lin<double>& al, hipStream_t st) {
+template <int RT, typename ST>
+int launch_dbl128_lin(int N, int ns, int S, int P, int nd, ST* expk, ST* ekl, const added<ST>& a,
+                      const added_lin<ST>& al, hipStream_t st) {
   constexpr size_t lds = lin128<RT>::lds_bytes();
-  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128_lin<RT>), lds, "hipFuncSetAttribute(k_dbl128_lin)"))
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128_lin<RT, ST>), lds, "hipFuncSetAttribute(k_dbl128_lin)"))
     return prepared;
   const int per_cu = wg_per_cu<RT>::value;
   const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
@@ -633,21 +635,21 @@ int launch_dbl128_lin(int N, int ns, int S, int P, int nd, double* expk, double*
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * nslots * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   int* status = device_status();
   if (!scr || !status) return VSM_ERR_HIP;
-  hipLaunchKernelGGL(k_dbl128_lin<RT>, dim3(grid), dim3(64 * RT), lds, st, N, ns, S, P, nd, expk, ekl, a, al, scr, status);
+  hipLaunchKernelGGL((k_dbl128_lin<RT, ST>), dim3(grid), dim3(64 * RT), lds, st, N, ns, S, P, nd, expk, ekl, a, al, scr, status);
   VSM_LAUNCH_CHECK("k_dbl128_lin");
   return VSM_OK;
 }
-template <int RT>
-int launch_ia128_lin(int N, int S, int P, const ia128_half& h, hipStream_t st) {
+template <int RT, typename ST>
+int launch_ia128_lin(int N, int S, int P, const ia128_half<ST>& h, hipStream_t st) {
   constexpr size_t lds = lin128<RT>::lds_bytes();
-  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128_lin<RT>), lds, "hipFuncSetAttribute(k_ia128_lin)"))
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128_lin<RT, ST>), lds, "hipFuncSetAttribute(k_ia128_lin)"))
     return prepared;
   const int per_cu = wg_per_cu<RT>::value;
   const int grid = S < per_cu * cu_count() ? S : per_cu * cu_count();
   d4_t* scr = static_cast<d4_t*>(scratch((size_t)grid * IL_SLOTS * B_MAXW * RT * 64 * sizeof(d4_t), 3, st));
   int* status = device_status();
   if (!scr || !status) return VSM_ERR_HIP;
-  hipLaunchKernelGGL(k_ia128_lin<RT>, dim3(grid), dim3(64 * RT), lds, st, N, S, P, h, scr, status);
+  hipLaunchKernelGGL((k_ia128_lin<RT, ST>), dim3(grid), dim3(64 * RT), lds, st, N, S, P, h, scr, status);
   VSM_LAUNCH_CHECK("k_ia128_lin");
   return VSM_OK;
 }
@@ -673,34 +675,39 @@ bool strip128_lin_dbl_supported(int N) { return (N > VSM_LIN128_DBL_MIN && N <= 
 bool strip128_lin_ia_supported(int N) { return (N > VSM_LIN128_IA_MIN && N <= 128) || lin128_small(N); }
 
 // All ndoubl doubling steps (forward + P active parameters) in one launch, apply_D! included when ns (n_stokes) > 0
-int strip128_doubling_lin(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
-                          const added_lin<double>& al, hipStream_t st) {
-  if (!strip128_lin_dbl_supported(N) || P < 0 || nd < 1 || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
+template <typename ST>
+int strip128_doubling_lin(int N, int S, int P, int nd, int ns, ST* expk, ST* ekl, const added<ST>& a,
+                          const added_lin<ST>& al, hipStream_t st) {
+  // (Float32 arrays: every N <= 128 -- there is no other fused linearized kernel for them)
+  const bool shape_ok = sizeof(ST) == 4 ? (N >= 1 && N <= 128) : strip128_lin_dbl_supported(N);
+  if (!shape_ok || P < 0 || nd < 1 || a.mat_stride != (long long)N * N || al.mat_stride != (long long)N * N)
     return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   switch ((N + 15) / 16) {
-    case 1: return launch_dbl128_lin<1>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 2: return launch_dbl128_lin<2>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 3: return launch_dbl128_lin<3>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 4: return launch_dbl128_lin<4>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 5: return launch_dbl128_lin<5>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 6: return launch_dbl128_lin<6>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 7: return launch_dbl128_lin<7>(N, ns, S, P, nd, expk, ekl, a, al, st);
-    case 8: return launch_dbl128_lin<8>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 1: return launch_dbl128_lin<1, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 2: return launch_dbl128_lin<2, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 3: return launch_dbl128_lin<3, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 4: return launch_dbl128_lin<4, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 5: return launch_dbl128_lin<5, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 6: return launch_dbl128_lin<6, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 7: return launch_dbl128_lin<7, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
+    case 8: return launch_dbl128_lin<8, ST>(N, ns, S, P, nd, expk, ekl, a, al, st);
   }
   return VSM_ERR_UNSUPPORTED;
 }
 
 // ScatteringInterface_11 interaction with derivatives: two launches (first half, second half), bindings as
 // vsm_striplin.hip's strip_interaction11_lin
-int strip128_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
-                               const added_lin<double>& al, hipStream_t st) {
-  if (!strip128_lin_ia_supported(N)) return VSM_ERR_UNSUPPORTED;
+template <typename ST>
+int strip128_interaction11_lin(int N, int S, const composite<ST>& c, const composite_lin<ST>& cl, const added<ST>& a,
+                               const added_lin<ST>& al, hipStream_t st) {
+  const bool shape_ok = sizeof(ST) == 4 ? (N >= 1 && N <= 128) : strip128_lin_ia_supported(N);
+  if (!shape_ok) return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S;
   const long long as = a.mat_stride, als = al.mat_stride, alp = (als == 0) ? NN : MS;
-  ia128_half h1{};
+  ia128_half<ST> h1{};
   h1.LA = a.r_mp;   h1.sLA = as;
   h1.ER = c.R_pm;   h1.sER = NN;
   h1.LT = c.T_mm;   h1.sLT = NN;
@@ -717,7 +724,7 @@ int strip128_interaction11_lin(int N, int S, const composite<double>& c, const c
   h1.D3 = al.ap_t_mm; h1.sD3 = als; h1.pD3 = alp;
   h1.OUTP0 = cl.R_mp; h1.OUTP1 = cl.T_mm;
   h1.VDR = cl.J0_p; h1.VDADD = al.ap_J0_m; h1.VDACC = cl.J0_m; h1.VDOUT = cl.J0_m;
-  ia128_half h2{};
+  ia128_half<ST> h2{};
   h2.LA = c.R_pm;   h2.sLA = NN;
   h2.ER = a.r_mp;   h2.sER = as;
   h2.LT = a.t_pp;   h2.sLT = as;
@@ -738,8 +745,8 @@ int strip128_interaction11_lin(int N, int S, const composite<double>& c, const c
   switch ((N + 15) / 16) {
 #define VSM_CASE(RT)                                                  \
   case RT:                                                            \
-    if ((rc = launch_ia128_lin<RT>(N, S, P, h1, st))) return rc;      \
-    return launch_ia128_lin<RT>(N, S, P, h2, st);
+    if ((rc = launch_ia128_lin<RT, ST>(N, S, P, h1, st))) return rc;  \
+    return launch_ia128_lin<RT, ST>(N, S, P, h2, st);
     VSM_CASE(1)
     VSM_CASE(2)
     VSM_CASE(3)
@@ -752,5 +759,14 @@ int strip128_interaction11_lin(int N, int S, const composite<double>& c, const c
   }
   return VSM_ERR_UNSUPPORTED;
 }
+
+template int strip128_doubling_lin<double>(int, int, int, int, int, double*, double*, const added<double>&, const added_lin<double>&,
+                                           hipStream_t);
+template int strip128_doubling_lin<float>(int, int, int, int, int, float*, float*, const added<float>&, const added_lin<float>&,
+                                          hipStream_t);
+template int strip128_interaction11_lin<double>(int, int, const composite<double>&, const composite_lin<double>&, const added<double>&,
+                                                const added_lin<double>&, hipStream_t);
+template int strip128_interaction11_lin<float>(int, int, const composite<float>&, const composite_lin<float>&, const added<float>&,
+                                               const added_lin<float>&, hipStream_t);
 
 }  // namespace vsm
