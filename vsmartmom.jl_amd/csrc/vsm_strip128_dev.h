@@ -411,32 +411,27 @@ __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __re
 // The same from / to FP32 arrays (the reference's Float32 runs on these kernels: storage in single, arithmetic in double -- the
 // FP64 MFMA rate of these shapes is above what the FP32 operator chains reach)
 template <int RT>
-__device__ __forceinline__ void load_global128(bstrip<RT>& s, const float* __restrict__ g, int N, const bpos<RT>& p) {
+__device__ __forceinline__ void load_global128(bstrip<RT>& s, const float* g, int N, const bpos<RT>& p) {
   const bool cok = p.col < N;
-  const float* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc0));
-  const __attribute__((address_space(1))) float* gc = (const __attribute__((address_space(1))) float*)gc0;
+  const float* gc = g + (long long)N * min(p.col, N - 1);
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = p.row(ta, r);
-      const float v = gc[min(row, N - 1) - p.kq];
+      const float v = gc[min(row, N - 1)];
       s.v[ta][r] = (row < N && cok) ? (double)v : 0.0;
     }
 }
 template <int RT>
-__device__ __forceinline__ void store_global128(float* __restrict__ g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
-  const bool cok = p.col < N;
-  float* gc0 = g + (long long)N * min(p.col, N - 1) + p.kq;
-  asm volatile("" : "+v"(gc0));
-  __attribute__((address_space(1))) float* gc = (__attribute__((address_space(1))) float*)gc0;
+__device__ __forceinline__ void store_global128(float* g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
+  float* gc = g + (long long)N * min(p.col, N - 1);
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool rok = ta < RT - 1 || p.row(ta, r) < N;
-      if (rok && cok) gc[16 * ta + 4 * r] = (float)s.v[ta][r];
+      const int row = p.row(ta, r);
+      if (row < N && p.col < N) gc[row] = (float)s.v[ta][r];
     }
 }
 
