@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--refl", type=float, default=0.4,
                     help="scale of the reflection operators (||r R|| ~ 0.2 refl^2: 0.4 = a clear-sky composite, series inverse; 1.5 forces Gauss-Jordan)")
+    ap.add_argument("--dsym", type=int, default=0,
+                    help="nStokes of a D-symmetric added layer (r+- = D r-+ D, t-- = D t++ D derived in the kernel, as doubling! leaves "
+                         "a scattering layer); 0 = all four matrices of the added layer in memory (surface-layer form)")
     a = ap.parse_args()
     FT = np.float64 if a.dtype == "f64" else np.float32
     N, S = a.N, a.points
@@ -30,7 +33,7 @@ def main():
     arch = vsm.Architectures.GPU(0)
     CR = vsm.CoreRT
     pc = CR.make_composite_layer(FT, arch, (N, N), S)
-    pa = CR.make_added_layer(FT, arch, (N, N), S)
+    pa = CR.make_added_layer(FT, arch, (N, N), S, d_symmetric=a.dsym)
 
     def refl(scale):
         return CR.to_device_matrix((scale * rng.random((S, N, N)) / N).astype(FT), arch, FT)
@@ -42,9 +45,9 @@ def main():
     conv_v = vsm.Architectures.array_type(arch)
     init = dict(R_mp=refl(a.refl), R_pm=refl(a.refl), T_pp=trans(), T_mm=trans(), J0_p=conv_v(rng.random((S, N)).astype(FT)),
                 J0_m=conv_v(rng.random((S, N)).astype(FT)))
-    for k in ("r_mp", "r_pm"):
+    for k in ("r_mp", "r_pm")[:1 if a.dsym else 2]:
         getattr(pa, k).copy_(refl(0.75 * a.refl))
-    for k in ("t_pp", "t_mm"):
+    for k in ("t_pp", "t_mm")[:1 if a.dsym else 2]:
         getattr(pa, k).copy_(trans())
     pa.j0_p.copy_(conv_v(rng.random((S, N)).astype(FT)))
     pa.j0_m.copy_(conv_v(rng.random((S, N)).astype(FT)))
