@@ -463,7 +463,7 @@ def _comp_to_host(vsm, c):
 @pytest.mark.parametrize("FT,N", [(np.float64, 4), (np.float64, 15), (np.float64, 36), (np.float64, 60),
                                   (np.float64, 66), (np.float64, 79), (np.float64, 96), (np.float64, 102), (np.float64, 112),
                                   (np.float64, 125), (np.float64, 126), (np.float64, 127), (np.float64, 128), (np.float64, 129),
-                                  (np.float32, 60), (np.float32, 96)])
+                                  (np.float32, 60), (np.float32, 96), (np.float32, 102), (np.float32, 128)])
 @pytest.mark.parametrize("iface", ["00", "01", "10", "11"])
 @pytest.mark.parametrize("oplevel", [False, True])
 def test_interaction(vsm, arch, FT, N, iface, oplevel):
@@ -713,17 +713,25 @@ def _o2a_like(S, L, seed=20260929):
     return tau_rayl, tau_abs
 
 
-@pytest.mark.parametrize("FT,l_trunc,pol,rtol", [(np.float64, 35, "IQU", 1e-8), (np.float32, 59, "IQU", 1e-2)])
-def test_rt_run_o2a_shape_vs_oracle(vsm, arch, FT, l_trunc, pol, rtol):
+@pytest.mark.parametrize("FT,l_trunc,pol,rtol,N", [(np.float64, 35, "IQU", 1e-8, 60), (np.float32, 59, "IQU", 1e-2, 96),
+                                                   # Float32 beyond the FP32 strip kernels: k_dbl128 / k_ia128 over FP32 arrays
+                                                   (np.float32, 69, "IQU", 1e-2, 111), (np.float32, 59, "IQUV", 1e-2, 128)])
+def test_rt_run_o2a_shape_vs_oracle(vsm, arch, FT, l_trunc, pol, rtol, N):
     """The benchmark's own shape at reduced S, L: FP64 N = 60 (C2) and FP32 N = 96 (C4), multi-layer,
-    absorption spanning 1e-4..50, Lambertian 0.15 -- fused kernels end to end vs the oracle."""
+    absorption spanning 1e-4..50, Lambertian 0.15 -- fused kernels end to end vs the oracle; and the Float32 shapes of
+    96 < N <= 128, which run on the FP64 kernels of vsm_strip128.hip with FP32 storage (the reference's FP32 gate, 1e-2)."""
     S, L = 12, 4
     tau_rayl, tau_abs = _o2a_like(S, L)
     om, pm = _both_models(vsm, arch, pol, l_trunc, 40.0, [30.0], [0.0], FT=FT, tau_rayl=tau_rayl, tau_abs=tau_abs,
                           depol=0.0279, albedo=0.15, m_max=2)
-    assert om.quad_points.Nquad * 3 == (60 if FT == np.float64 else 96)
+    assert om.quad_points.Nquad * om.pol.n == N
+    if N > 96:
+        _device_status(vsm)
     Ro, To = O.rt_run(om)
     Rg, Tg = vsm.CoreRT.rt_run(pm)
+    if N > 96:
+        st = vsm._lib.last_device_status
+        assert st[0] == 0 and st[2] > 0 and st[3] > 0, st      # k_dbl128 / k_ia128 ran
     big = np.abs(Ro) > 1e-3 * np.abs(Ro).max()
     assert np.max(np.abs(Rg[big] - Ro[big]) / np.abs(Ro[big])) < rtol
     bigT = np.abs(To) > 1e-3 * np.abs(To).max()

@@ -297,6 +297,9 @@ static int interaction_impl(int iface, int N, int S, const C* c, const A* a, T* 
     static const bool no_strip = ab_switch("VSM_NO_STRIP128");
     if (!oplevel && !no_strip && iface == VSM_IFACE_11 && strip128_supported(N))
       return strip128_interaction11(N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
+  } else {
+    if (!oplevel && iface == VSM_IFACE_11 && strip128_f32_supported(N))
+      return strip128_interaction11<T>(N, S, cvt_comp<T>(c), cvt_added<T>(a), st);
   }
   if (!work) {
     work = static_cast<T*>(scratch(vsm_interaction_work_elems(N, S) * sizeof(T), 1, st));

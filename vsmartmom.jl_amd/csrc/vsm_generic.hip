@@ -473,6 +473,9 @@ int doubling(int N, int n_stokes, int S, int ndoubl, T* expk, const added<T>& a,
   if constexpr (sizeof(T) == 8) {
     static const bool no_strip = ab_switch("VSM_NO_STRIP128");
     if (!no_strip && strip128_supported(N)) return strip128_doubling(N, n_stokes, S, ndoubl, expk, a, st);
+  } else {
+    // Float32, 96 < N <= 128 (beyond the FP32 strip kernels): the FP64 kernels over the FP32 arrays
+    if (strip128_f32_supported(N)) return strip128_doubling<T>(N, n_stokes, S, ndoubl, expk, a, st);
   }
   const long long NN = (long long)N * N, per = NN * S, pv = (long long)N * S;
   T* W1 = work;

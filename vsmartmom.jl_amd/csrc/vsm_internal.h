@@ -263,8 +263,11 @@ int strip32_interaction11(int N, int S, const composite<float>& c, const added<f
 
 // ---- column-strip kernels, FP64, 64 < N <= 126 (one persistent workgroup of <= 8 waves per CU): vsm_strip128.hip ----
 bool strip128_supported(int N);
-int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st);
-int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
+template <typename ST>   // ST = double, or float (Float32 runs of 96 < N <= 128: storage in single, arithmetic in double)
+int strip128_doubling(int N, int n_stokes, int S, int ndoubl, ST* expk, const added<ST>& a, hipStream_t st);
+template <typename ST>
+int strip128_interaction11(int N, int S, const composite<ST>& c, const added<ST>& a, hipStream_t st);
+inline bool strip128_f32_supported(int N) { return N > 96 && N <= 128; }   // (64 < N <= 96 is the FP32 strip kernels')
 
 // ---- linearized column-strip kernels, FP64, 60 < N <= 128 (one A-form, parked strips): vsm_strip128lin.hip ----
 bool strip128_lin_dbl_supported(int N);   // which shapes take k_dbl128_lin / k_ia128_lin

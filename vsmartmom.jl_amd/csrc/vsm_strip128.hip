@@ -60,9 +60,11 @@ namespace {
 
 // ---- doubling --------------------------------------------------------------------------------------------------------------
 // MR: the source vectors as an extra MFMA tile per wave (mm128r) instead of rider columns -- N = 127, 128
-template <int RT, bool MR>
-__global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, int ndoubl, double* __restrict__ expk_g,
-                                                         added<double> a, d4_t* __restrict__ scr, int* __restrict__ status) {
+// ST: the element type of the caller's arrays (double; float = the reference's Float32 runs of 96 < N <= 128: storage in single,
+// arithmetic in double)
+template <int RT, bool MR, typename ST>
+__global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, int ndoubl, ST* __restrict__ expk_g,
+                                                         added<ST> a, d4_t* __restrict__ scr, int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
   double* AF = lds128;
@@ -91,10 +93,10 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     ++npts;
-    double* const g_r = a.r_mp + NN * s;
-    double* const g_t = a.t_pp + NN * s;
-    double* const g_jp = a.j0_p + (long long)N * s;
-    double* const g_jm = a.j0_m + (long long)N * s;
+    ST* const g_r = a.r_mp + NN * s;
+    ST* const g_t = a.t_pp + NN * s;
+    ST* const g_jp = a.j0_p + (long long)N * s;
+    ST* const g_jm = a.j0_m + (long long)N * s;
     double expk = expk_g[s];
     bstrip<RT> r_s, t_s;
     load_global128(r_s, g_r, N, p);
@@ -261,22 +263,22 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
           const bool rok = ta < RT - 1 || row < N;
           if (rok && cok) {
             const long long e = o + 16 * ta + 4 * r;
-            a.r_mp[e] = rv;
-            a.t_pp[e] = tv;
-            a.r_pm[e] = rs * sc;
-            a.t_mm[e] = tv * (sr * sc);
+            a.r_mp[e] = (ST)rv;
+            a.t_pp[e] = (ST)tv;
+            a.r_pm[e] = (ST)(rs * sc);
+            a.t_mm[e] = (ST)(tv * (sr * sc));
           }
-          if (!MR && rok && laneA) g_jm[row] = rv;   // j0- (sign of apply_D_SFI)
-          if (!MR && rok && laneB) g_jp[row] = rs;   // j0+
+          if (!MR && rok && laneA) g_jm[row] = (ST)rv;   // j0- (sign of apply_D_SFI)
+          if (!MR && rok && laneB) g_jp[row] = (ST)rs;   // j0+
         }
       if constexpr (MR) {
         __syncthreads();
         for (int i = threadIdx.x; i < N; i += blockDim.x) {
-          g_jp[i] = vjp[i];
-          g_jm[i] = vjm[i] * (double)dsg[i];
+          g_jp[i] = (ST)vjp[i];
+          g_jm[i] = (ST)(vjm[i] * (double)dsg[i]);
         }
       }
-      if (threadIdx.x == 0) expk_g[s] = expk;
+      if (threadIdx.x == 0) expk_g[s] = (ST)expk;
     }
     __syncthreads();   // the next point overwrites the A-form and the reduction slots
     B128_STAMP(10);
@@ -285,12 +287,12 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_dbl128(int N, int ns, int S, in
   B128_STAMP_FLUSH_AT(32, 63, npts);
 }
 
-template <int RT, bool MR>
-int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<double>& a, int grid, int nw, d4_t* scr,
+template <int RT, bool MR, typename ST>
+int launch_dbl128(int N, int ns, int S, int ndoubl, ST* expk, const added<ST>& a, int grid, int nw, d4_t* scr,
                   int* status, hipStream_t st) {
   constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 1024 + (MR ? 6 * 16 * RT * sizeof(double) : 0) + GJS_BYTES;
-  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128<RT, MR>), lds, "hipFuncSetAttribute(k_dbl128)")) return prepared;
-  hipLaunchKernelGGL((k_dbl128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr, status);
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_dbl128<RT, MR, ST>), lds, "hipFuncSetAttribute(k_dbl128)")) return prepared;
+  hipLaunchKernelGGL((k_dbl128<RT, MR, ST>), dim3(grid), dim3(64 * nw), lds, st, N, ns, S, ndoubl, expk, a, scr, status);
   VSM_LAUNCH_CHECK("k_dbl128");
   return VSM_OK;
 }
@@ -306,8 +308,8 @@ int launch_dbl128(int N, int ns, int S, int ndoubl, double* expk, const added<do
 //   [Y]  : R-+ = R-+ + Y T++ , T-- = V + Y Z     (the same rider: J0- = J0- + vs + Y z)
 // Three strips live at most; E2, Z, V, S wait in the workgroup's scratch.  The composite's [R+-], [T--] and the layer's [t++]
 // are staged from global memory with whole-column requests; every other operand is a strip of its owner wave.
-template <int RT, bool MR>
-__global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<double> c, added<double> a, d4_t* __restrict__ scr,
+template <int RT, bool MR, typename ST>
+__global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<ST> c, added<ST> a, d4_t* __restrict__ scr,
                                                         int* __restrict__ status) {
   constexpr int NP = 16 * RT;
   extern __shared__ __attribute__((aligned(16))) double lds128[];
@@ -335,16 +337,16 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 
   for (int s = blockIdx.x; s < S; s += gridDim.x) {
     ++npts;
-    double* const R_mp = c.R_mp + NN * s;
-    double* const R_pm = c.R_pm + NN * s;
-    double* const T_pp = c.T_pp + NN * s;
-    double* const T_mm = c.T_mm + NN * s;
-    double* const J0_p = c.J0_p + (long long)N * s;
-    double* const J0_m = c.J0_m + (long long)N * s;
-    const double* const a_r_mp = a.r_mp + a.mat_stride * s;
-    const double* const a_r_pm = a.r_pm + a.mat_stride * s;
-    const double* const a_t_pp = a.t_pp + a.mat_stride * s;
-    const double* const a_t_mm = a.t_mm + a.mat_stride * s;
+    ST* const R_mp = c.R_mp + NN * s;
+    ST* const R_pm = c.R_pm + NN * s;
+    ST* const T_pp = c.T_pp + NN * s;
+    ST* const T_mm = c.T_mm + NN * s;
+    ST* const J0_p = c.J0_p + (long long)N * s;
+    ST* const J0_m = c.J0_m + (long long)N * s;
+    const ST* const a_r_mp = a.r_mp + a.mat_stride * s;
+    const ST* const a_r_pm = a.r_pm + a.mat_stride * s;
+    const ST* const a_t_pp = a.t_pp + a.mat_stride * s;
+    const ST* const a_t_mm = a.t_mm + a.mat_stride * s;
     for (int i = tid; i < NP; i += blockDim.x) {
       const bool in = i < N;
       vjp[i] = in ? a.j0_p[(long long)N * s + i] : 0.0;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         if (p.l15 == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (rrow + 4 * r < N) J0_p[rrow + 4 * r] = vjp[rrow + 4 * r] + y[r];
+            if (rrow + 4 * r < N) J0_p[rrow + 4 * r] = (ST)(vjp[rrow + 4 * r] + y[r]);
         }
       } else {
         mm128(acc, Tpp, p);                             // T++ = T21 T++ ; rider: T21 z
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = p.row(ta, r);
-            if (row < N) J0_p[row] = vjp[row] + acc.v[ta][r];
+            if (row < N) J0_p[row] = (ST)(vjp[row] + acc.v[ta][r]);
           }
       }
     }
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
         if (p.l15 == 0) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (rrow + 4 * r < N) J0_m[rrow + 4 * r] = vJm[rrow + 4 * r] + vs[rrow + 4 * r] + y[r];
+            if (rrow + 4 * r < N) J0_m[rrow + 4 * r] = (ST)(vJm[rrow + 4 * r] + vs[rrow + 4 * r] + y[r]);
         }
       } else {
         mm128(acc, Tpp, p);                             // R-+ = R-+ + Y T++ ; rider: Y z
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = p.row(ta, r);
-            if (row < N) J0_m[row] = vJm[row] + vs[row] + acc.v[ta][r];
+            if (row < N) J0_m[row] = (ST)(vJm[row] + vs[row] + acc.v[ta][r]);
           }
       }
     }
@@ -553,13 +555,13 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<d
   B128_STAMP_FLUSH(npts);
 }
 
-template <int RT, bool MR>
-int launch_ia128(int N, int S, const composite<double>& c, const added<double>& a, int grid, int nw, d4_t* scr, int* status,
+template <int RT, bool MR, typename ST>
+int launch_ia128(int N, int S, const composite<ST>& c, const added<ST>& a, int grid, int nw, d4_t* scr, int* status,
                  hipStream_t st) {
   constexpr size_t lds = (size_t)(16 * RT) * (16 * RT) * sizeof(double) + 8 * 16 * RT * sizeof(double) + 256 + GJS_BYTES +
                          B_MAXW * 16 * XS8B * sizeof(double);
-  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128<RT, MR>), lds, "hipFuncSetAttribute(k_ia128)")) return prepared;
-  hipLaunchKernelGGL((k_ia128<RT, MR>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr, status);
+  if (const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia128<RT, MR, ST>), lds, "hipFuncSetAttribute(k_ia128)")) return prepared;
+  hipLaunchKernelGGL((k_ia128<RT, MR, ST>), dim3(grid), dim3(64 * nw), lds, st, N, S, c, a, scr, status);
   VSM_LAUNCH_CHECK("k_ia128");
   return VSM_OK;
 }
@@ -610,7 +612,8 @@ bool strip128_supported(int N) { return N > 64 && N <= 128; }
 // tile per wave beyond (no rider-only wave at N = 96 / 112, no rider lane code: +1 ... 5 % at N = 96 ... 126; the only way at 127, 128)
 static bool mr_policy(int N) { return N > 80; }
 
-int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, const added<double>& a, hipStream_t st) {
+template <typename ST>
+int strip128_doubling(int N, int n_stokes, int S, int ndoubl, ST* expk, const added<ST>& a, hipStream_t st) {
   if (ndoubl == 0 || S <= 0) return VSM_OK;   // doubling.jl:50
   const bool mr = mr_policy(N);
   const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
@@ -620,16 +623,17 @@ int strip128_doubling(int N, int n_stokes, int S, int ndoubl, double* expk, cons
   int* status = device_status();
   if (!status) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_dbl128<5, false>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
-    case 6: return launch_dbl128<6, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
-    case 7: return launch_dbl128<7, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
-    case 8: return launch_dbl128<8, true>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 5: return launch_dbl128<5, false, ST>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 6: return launch_dbl128<6, true, ST>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 7: return launch_dbl128<7, true, ST>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
+    case 8: return launch_dbl128<8, true, ST>(N, n_stokes, S, ndoubl, expk, a, grid, nw, scr, status, st);
   }
   set_error("strip128_doubling: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
 }
 
-int strip128_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+template <typename ST>
+int strip128_interaction11(int N, int S, const composite<ST>& c, const added<ST>& a, hipStream_t st) {
   if (S <= 0) return VSM_OK;
   const bool mr = mr_policy(N);
   const int RT = (N + 15) / 16, nw = mr ? RT : (((N + 1) & ~1) >> 4) + 1;
@@ -639,10 +643,10 @@ int strip128_interaction11(int N, int S, const composite<double>& c, const added
   int* status = device_status();
   if (!status) return VSM_ERR_HIP;
   switch (RT) {
-    case 5: return launch_ia128<5, false>(N, S, c, a, grid, nw, scr, status, st);
-    case 6: return launch_ia128<6, true>(N, S, c, a, grid, nw, scr, status, st);
-    case 7: return launch_ia128<7, true>(N, S, c, a, grid, nw, scr, status, st);
-    case 8: return launch_ia128<8, true>(N, S, c, a, grid, nw, scr, status, st);
+    case 5: return launch_ia128<5, false, ST>(N, S, c, a, grid, nw, scr, status, st);
+    case 6: return launch_ia128<6, true, ST>(N, S, c, a, grid, nw, scr, status, st);
+    case 7: return launch_ia128<7, true, ST>(N, S, c, a, grid, nw, scr, status, st);
+    case 8: return launch_ia128<8, true, ST>(N, S, c, a, grid, nw, scr, status, st);
   }
   set_error("strip128_interaction11: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
@@ -663,6 +667,11 @@ int strip128_inv_one_minus(int N, int S, const double* A, long long sa, const do
   set_error("strip128_inv_one_minus: N=%d outside 65..128", N);
   return VSM_ERR_UNSUPPORTED;
 }
+
+template int strip128_doubling<double>(int, int, int, int, double*, const added<double>&, hipStream_t);
+template int strip128_doubling<float>(int, int, int, int, float*, const added<float>&, hipStream_t);
+template int strip128_interaction11<double>(int, int, const composite<double>&, const added<double>&, hipStream_t);
+template int strip128_interaction11<float>(int, int, const composite<float>&, const added<float>&, hipStream_t);
 
 }  // namespace vsm
 

@@ -581,6 +581,10 @@ __device__ __forceinline__ void ldg(bstrip<RT>& x, const float* __restrict__ g, 
   load_global128(x, g, N, p);
 }
 template <int RT>
+__device__ __forceinline__ void ldg_issue(bstrip<RT>& x, const float* __restrict__ g, int N, const bpos<RT>& p) {
+  load_global128(x, g, N, p);
+}
+template <int RT>
 __device__ __forceinline__ void stg(float* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double*) {
   store_global128(g, x, N, p);
 }

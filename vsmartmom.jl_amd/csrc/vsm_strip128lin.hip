@@ -94,8 +94,9 @@ __device__ __forceinline__ void mm_held(bstrip<RT>& acc, const bstrip<RT>& held,
 }
 
 // ---- doubling ------------------------------------------------------------------------------------------------------------------
-// scratch slots: 0 r, 1 t, 2 W = r t, 3 G, 4 tt, 5 X1 / Y, 6 Q2, then (rdot_p, tdot_p) for p = 0 .. P-1
-constexpr int DL_FIXED = 7;
+// scratch slots: 0 r, 1 t, 2 W = r t, 3 G, 4 tt, then (rdot_p, tdot_p) for p = 0 .. P-1   (X1, Q2, Y never leave the registers:
+// three live strips is what a wave holds at eight row tiles, and the phases between the A-form switches need no more)
+constexpr int DL_FIXED = 5;
 // ST: the element type of the caller's arrays (double, or float: Float32 runs -- storage in single, arithmetic in double)
 template <int RT, typename ST>
 __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, int ns, int S, int P, int nd,
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         const int iRd = DL_FIXED + 2 * pp, iTd = iRd + 1;
         ST* g_aJp = al.ap_J0_p + pp * VS + (long long)N * s;
         ST* g_aJm = al.ap_J0_m + pp * VS + (long long)N * s;
-        bstrip<RT> rd, X1, Q2;                 // (K: live from here to the [tt] phase)
+        bstrip<RT> rd, X1, Q2;                 // X1, Q2 live from here to the [tt] phase at every RT; K: rd too
         // ---- [r]: X1 = r rdot ; Q2 = r tdot ; riders r aJ+ | r aJ1-
         if constexpr (!K) fill(r_s, sl(0), p);
         store_af(r_s, N, p);                   // (the A-form is free: barrier above / at the end of the previous parameter)
@@ -212,12 +213,10 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           fill(rd, sl(iRd), p);
           X1.zero();
           mm128(X1, rd, p);                    // X1 = r rdot
-          if constexpr (!K) spill(sl(5), X1, p);
           bstrip<RT> B;
           fill(B, sl(iTd), p);
           Q2.zero();
           mm128(Q2, B, p);                     // Q2 = r tdot
-          if constexpr (!K) spill(sl(6), Q2, p);
           rider2(ra, rb, xt, p);
         }
         // ---- [rdot]: X1 += rdot r ; Q2 += rdot t ; riders rdot j0+ | rdot j1-
@@ -230,12 +229,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         }
         __syncthreads();
         {
-          if constexpr (!K) fill(X1, sl(5), p);
           mm_held<K, RT>(X1, r_s, sl(0), p);   // X1 = r rdot + rdot r
-          if constexpr (!K) spill(sl(5), X1, p);
-          if constexpr (!K) fill(Q2, sl(6), p);
           mm_held<K, RT>(Q2, t_s, sl(1), p);   // Q2 = r tdot + rdot t
-          if constexpr (!K) spill(sl(6), Q2, p);
           rider2(y0, y1, xt, p);
         }
         // ---- [tt]: Y = tdot + tt X1 ; rdot' = rdot + tt Q2 ; tdot' = tt tdot ; riders tt v | tt u
@@ -255,12 +250,9 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
         bstrip<RT> Y, tdn;                     // (rdot' accumulates in rd)
         {
           fill(Y, sl(iTd), p);
-          mm_held<K, RT>(Y, X1, sl(5), p);     // Y = tdot + tt X1
-          if constexpr (!K) {
-            spill(sl(5), Y, p);                // (X1's slot: X1 is consumed)
-            fill(rd, sl(iRd), p);
-          }
-          mm_held<K, RT>(rd, Q2, sl(6), p);    // rdot' = rdot + tt Q2 (+ ttdot W below)
+          mm128(Y, X1, p);                     // Y = tdot + tt X1   (stays in registers until it becomes the A-form [Y])
+          if constexpr (!K) fill(rd, sl(iRd), p);
+          mm128(rd, Q2, p);                    // rdot' = rdot + tt Q2 (+ ttdot W below)
           if constexpr (!K) spill(sl(iRd), rd, p);
           bstrip<RT> B;
           fill(B, sl(iTd), p);
@@ -270,7 +262,6 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
           rider2(y0, y1, xt, p);
         }
         // ---- [Y]: ttdot = Y G
-        if constexpr (!K) fill(Y, sl(5), p);
         __syncthreads();                       // [tt] no longer read, y complete
         store_af(Y, N, p);
         for (int i = tid; i < NP; i += blockDim.x) {
@@ -408,9 +399,9 @@ struct ia128_half {
   const ST *VDR, *VDADD, *VDACC;
   ST* VDOUT;
 };
-// scratch slots: 0 ER, 1 S2, 2 S3, 3 rt, 4 G, 5 tt, 6 X1 / Y, 7 X2 / outp0, 8 outp1
-// (K, four row tiles: ER, S2 stay in registers for the whole point, X1, X2, Y and the two outputs of a parameter never leave them)
-constexpr int IL_SLOTS = 9;
+// scratch slots: 0 ER, 1 S2, 2 S3, 3 rt, 4 G, 5 tt, 6 outp0, 7 outp1   (X1, X2, Y never leave the registers; K, four row tiles:
+// neither do ER, S2 -- for the whole point -- and the two outputs of a parameter)
+constexpr int IL_SLOTS = 8;
 template <int RT, typename ST>
 __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, int S, int P, ia128_half<ST> h, d4_t* __restrict__ scr,
                                                                         int* __restrict__ status) {
@@ -486,7 +477,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
 
     // ================= parameters =================
     for (int pp = 0; pp < P; ++pp) {
-      bstrip<RT> X1, X2;                       // (K: live to the [tt] phase)
+      bstrip<RT> X1, X2;                       // live to the [tt] phase
       // ---- [PA]: X1 = PA ER ; X2 = PA S2 ; rider PA VR
       stage_af(AF, h.PA + s * h.sPA + pp * h.pPA, N, nw, p);
       for (int i = tid; i < NP; i += blockDim.x) {
@@ -501,10 +492,8 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       {
         X1.zero();
         mm_held<K, RT>(X1, er, sl(0), p);      // X1 = PA ER
-        if constexpr (!K) spill(sl(6), X1, p);
         X2.zero();
         mm_held<K, RT>(X2, s2, sl(1), p);      // X2 = PA S2
-        if constexpr (!K) spill(sl(7), X2, p);
         rider2(pv, y1, xt, p);
       }
       // ---- [LA]: X1 += LA D1 ; X2 += LA D2 ; rider LA VDR
@@ -517,16 +506,10 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       __syncthreads();
       {
         bstrip<RT> B;
-        if constexpr (!K) fill(X1, sl(6), p);
         ldg(B, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
         mm128(X1, B, p);                       // X1 = PA ER + LA D1
-        if constexpr (!K) {
-          spill(sl(6), X1, p);
-          fill(X2, sl(7), p);
-        }
         ldg(B, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
         mm128(X2, B, p);                       // X2 = PA S2 + LA D2
-        if constexpr (!K) spill(sl(7), X2, p);
         rider2(y0, y1, xt, p);
       }
       // ---- [tt]: Y = YI + tt X1 ; outp0 = ACCP + tt X2 ; outp1 = tt D3 ; rider tt x2v
@@ -545,20 +528,18 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       bstrip<RT> Y, o0, o1;
       {
         ldg(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
-        mm_held<K, RT>(Y, X1, sl(6), p);       // Y = YI + tt X1
-        if constexpr (!K) spill(sl(6), Y, p);
+        mm128(Y, X1, p);                       // Y = YI + tt X1   (stays in registers until it becomes the A-form [Y])
         ldg(o0, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
-        mm_held<K, RT>(o0, X2, sl(7), p);      // outp0 = ACCP + tt X2 (+ ttdot rt below)
-        if constexpr (!K) spill(sl(7), o0, p);
+        mm128(o0, X2, p);                      // outp0 = ACCP + tt X2 (+ ttdot rt below)
+        if constexpr (!K) spill(sl(6), o0, p);
         bstrip<RT> B;
         ldg(B, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
         o1.zero();
         mm128(o1, B, p);                       // outp1 = tt D3 (+ ttdot S3 below)
-        if constexpr (!K) spill(sl(8), o1, p);
+        if constexpr (!K) spill(sl(7), o1, p);
         rider2(y0, y1, xt, p);
       }
       // ---- [Y]: ttdot = Y G
-      if constexpr (!K) fill(Y, sl(6), p);
       __syncthreads();                         // [tt] no longer read, y complete
       store_af(Y, N, p);
       for (int i = tid; i < NP; i += blockDim.x) {
@@ -580,11 +561,11 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_ia128_lin(int N, i
       __syncthreads();
       {
         bstrip<RT> B;
-        if constexpr (!K) fill(o0, sl(7), p);
+        if constexpr (!K) fill(o0, sl(6), p);
         fill(B, sl(3), p);
         mm128(o0, B, p);
         stg(h.OUTP0 + (long long)pp * MS + NN * s, o0, N, p, xw);
-        if constexpr (!K) fill(o1, sl(8), p);
+        if constexpr (!K) fill(o1, sl(7), p);
         fill(B, sl(2), p);
         mm128(o1, B, p);
         stg(h.OUTP1 + (long long)pp * MS + NN * s, o1, N, p, xw);
