@@ -473,10 +473,19 @@ def test_interaction(vsm, arch, FT, N, iface, oplevel):
     pol = O.polarization("IQU" if N % 3 == 0 else ("IQUV" if N % 4 == 0 else "I"))
     comp, add = _random_layers(rng, N, S, FT, pol)
     pc, pa = _upload_layers(vsm, arch, comp, add, FT)
-    O.interaction(iface, comp, add, FT)
+    FTo = FT
+    if FT == np.float32 and N > 96 and iface == "11" and not oplevel:
+        # Float32 beyond the FP32 strip kernels runs on k_ia128 with FP32 storage and FP64 arithmetic: the reference is the
+        # oracle in double on the same single-precision operands (the FP32 oracle's own rounding is ~N eps)
+        FTo = np.float64
+        for o in (comp, add):
+            for k, v in vars(o).items():
+                if isinstance(v, np.ndarray):
+                    setattr(o, k, v.astype(np.float64))
+    O.interaction(iface, comp, add, FTo)
     vsm.CoreRT.interaction_(iface, pc, pa, oplevel=oplevel)
     got = _comp_to_host(vsm, pc)
-    tol = 1e-11 if FT == np.float64 else 2e-5
+    tol = 1e-11 if FT == np.float64 else (2e-6 if FTo == np.float64 else 2e-5)
     for k, v in got.items():
         assert _rel(v, getattr(comp, k)) < tol, k
 
