@@ -334,6 +334,17 @@ int vsm_interaction_lin_f64(int iface, int N, int S, const vsm_composite_f64* co
                             const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, double* work, void* stream);
 int vsm_interaction_lin_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_composite_lin_f32* comp_lin,
                             const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, float* work, void* stream);
+/* The same for the parameter slots [p_lo, p_hi) only (0 <= p_lo < p_hi <= P); the other slots of comp_lin are left as they are.
+ * For callers that KNOW the other slots to be zero in both operands -- the reference's loop `for iparam = 1:Nparams`
+ * (interaction_lin.jl:242,291) then computes exact zeros for them: the composite above the surface does not depend on a surface
+ * parameter, so rt_run's atmospheric layers need the layer slots only (n_layer_params of parameter_layout.jl) and only the
+ * surface interaction needs all.  Identical results; the forward composite is updated as in vsm_interaction_lin. */
+int vsm_interaction_lin_range_f64(int iface, int N, int S, const vsm_composite_f64* comp, const vsm_composite_lin_f64* comp_lin,
+                                  const vsm_added_f64* added, const vsm_added_lin_f64* added_lin, int p_lo, int p_hi, double* work,
+                                  void* stream);
+int vsm_interaction_lin_range_f32(int iface, int N, int S, const vsm_composite_f32* comp, const vsm_composite_lin_f32* comp_lin,
+                                  const vsm_added_f32* added, const vsm_added_lin_f32* added_lin, int p_lo, int p_hi, float* work,
+                                  void* stream);
 /* TOA copy of the derivative stacks (rt_kernel_lin.jl:148-166). */
 int vsm_copy_added_to_composite_lin_f64(int N, int S, const vsm_added_lin_f64* added_lin,
                                         const vsm_composite_lin_f64* comp_lin, void* stream);

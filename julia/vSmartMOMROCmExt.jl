@@ -272,6 +272,15 @@ function interaction!(iface, SFI, c::CompositeLayer{FT}, ċ::CompositeLayerLin{F
     @vsm("vsm_interaction_lin", FT, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmCompositeLin}, Ref{VsmAdded}, Ref{VsmAddedLin}, PV, PV),
           _tag(iface), N, S, _c(c), _c(ċ), _c(a), _c(ȧ), _p(_work(FT, :vsm_interaction_lin_work_elems, N, S, P)), _stream())
 end
+# The same for the parameter slots lo:hi only (1-based, inclusive).  rt_run_lin.jl's layer loop may pass 1:n_layer_params(layout) for the
+# atmospheric layers: the composite above the surface does not depend on a surface parameter, so the loop `for iparam = 1:Nparams`
+# of interaction_lin.jl:242,291 computes exact zeros for the surface slots there (identical results, the surface interaction runs all).
+function interaction!(iface, SFI, c::CompositeLayer{FT}, ċ::CompositeLayerLin{FT}, a::AddedLayer{FT}, ȧ::AddedLayerLin{FT}, I_static,
+                      slots::UnitRange{Int}) where {FT<:FTs}
+    N, _, S = size(c.R⁻⁺); P = size(ċ.Ṙ⁻⁺, 4)
+    @vsm("vsm_interaction_lin_range", FT, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmCompositeLin}, Ref{VsmAdded}, Ref{VsmAddedLin}, Cint, Cint, PV, PV),
+          _tag(iface), N, S, _c(c), _c(ċ), _c(a), _c(ȧ), first(slots) - 1, last(slots), _p(_work(FT, :vsm_interaction_lin_work_elems, N, S, P)), _stream())
+end
 function create_surface_layer!(::noRS, s::LambertianSurfaceScalar{FT}, a::AddedLayer, ȧ::AddedLayerLin, iparam::Int, SFI, m::Int, pol_type, qp, τ_sum, τ̇_sum, F₀, arch) where {FT<:FTs}
     @vsm("vsm_lambertian_surface_lin", FT, (Ref{VsmQuad{FT}}, Cint, Cint, FT, Cint, PV, PV, Cint, PV, Ref{VsmAdded}, Ref{VsmAddedLin}, PV),
           _q(qp, pol_type.n, FT), length(τ_sum), m, s.albedo, iparam - 1, _p(τ_sum), _p(τ̇_sum), size(τ̇_sum, 2), _p(F₀), _c(a), _c(ȧ), _stream())

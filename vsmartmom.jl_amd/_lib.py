@@ -127,6 +127,7 @@ _SIGS = {
     "vsm_elemental_lin_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_doubling_lin_{T}": (_I, [_I, _I, _I, _I, _P, _P, "{R}", _I, _P, _P, _P, _P]),
     "vsm_interaction_lin_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_interaction_lin_range_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vsm_copy_added_to_composite_lin_{T}": (_I, [_I, _I, _P, _P, _P]),
     "vsm_lambertian_surface_lin_{T}": (_I, [_P, _I, _I, "{R}", _I, _P, _P, _I, _P, _P, _P, _P]),
     "vsm_postprocess_vza_lin_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

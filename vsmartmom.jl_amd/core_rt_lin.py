@@ -109,11 +109,16 @@ def doubling_allparams_(pol, expk, ndoubl, added: CR.AddedLayer, added_lin: Adde
 
 
 def interaction_lin_(scattering_interface, comp: CR.CompositeLayer, comp_lin: CompositeLayerLin, added: CR.AddedLayer,
-                     added_lin: AddedLayerLin):
-    """interaction! (lin) (interaction_lin.jl:337-351)."""
+                     added_lin: AddedLayerLin, p_range=None):
+    """interaction! (lin) (interaction_lin.jl:337-351).  `p_range = (p_lo, p_hi)`: only these parameter slots (the caller knows
+    the others to be zero in both operands, where the reference's loop over all Nparams computes exact zeros)."""
     n = _lib.lib().vsm_interaction_lin_work_elems(comp.N, comp.nSpec, comp_lin.P)
     work = _work("ia", int(n), comp.dtype, comp.R_mp.device)
     c, cl, a, al = comp.cstruct(), comp_lin.cstruct(), added.cstruct(), added_lin.cstruct()
+    if p_range is not None and (p_range[0] > 0 or p_range[1] < comp_lin.P) and p_range[1] > p_range[0]:
+        _lib.call("vsm_interaction_lin_range", comp.dtype, CR.IFACE[scattering_interface], comp.N, comp.nSpec, C.byref(c),
+                  C.byref(cl), C.byref(a), C.byref(al), int(p_range[0]), int(p_range[1]), CR._ptr(work), CR._stream_ptr())
+        return
     _lib.call("vsm_interaction_lin", comp.dtype, CR.IFACE[scattering_interface], comp.N, comp.nSpec, C.byref(c),
               C.byref(cl), C.byref(a), C.byref(al), CR._ptr(work), CR._stream_ptr())
 
@@ -213,6 +218,11 @@ class SceneLin:
         self.Td = torch.zeros_like(self.Rd)
         self._lanes = []
         self._fold = {}
+        # The composite above the surface does not depend on a surface parameter: in the atmospheric layers the surface slots of
+        # the added layer's AND of the composite's derivative stacks are zero, and the reference's loop over all Nparams
+        # (interaction_lin.jl:242,291) computes exact zeros for them.  The layer interactions therefore run on the layer slots
+        # [0, n_layer_params) only; the surface interaction on all of them.
+        self._layer_slots = (0, pl) if 0 < pl < P else None
 
     # -- inputs -----------------------------------------------------------------------------------------------------------
     def upload(self):
@@ -441,7 +451,7 @@ class SceneLin:
                     a_, c_ = al.cstruct(), cl.cstruct()
                     _lib.call("vsm_copy_added_to_composite_lin", dt, N, Sf, C.byref(a_), C.byref(c_), CR._stream_ptr())
                 else:
-                    interaction_lin_(ly0["iface"], comp, cl, added, al)
+                    interaction_lin_(ly0["iface"], comp, cl, added, al, p_range=self._layer_slots)
             return comp, cl
 
         def finish(mom, w, lane, comp, cl, im):
@@ -517,7 +527,7 @@ class SceneLin:
                 a_, c_ = al.cstruct(), cl.cstruct()
                 _lib.call("vsm_copy_added_to_composite_lin", dt, N, S, C.byref(a_), C.byref(c_), CR._stream_ptr())
             else:
-                interaction_lin_(ly["iface"], comp, cl, added, al)
+                interaction_lin_(ly["iface"], comp, cl, added, al, p_range=self._layer_slots)
         self._finish_moment(mom, w)
 
     def _finish_moment(self, mom, w):

@@ -837,6 +837,26 @@ static int check_cl(const C* c) {
     return interaction_lin<T>(iface, N, S, cvt_comp<T>(comp), cvt_cl<T>(cl), cvt_added<T>(added), cvt_al<T>(al), work, \
                               as_stream(stream));                                                                      \
   }                                                                                                                    \
+  int vsm_interaction_lin_range_##SFX(int iface, int N, int S, const vsm_composite_##SFX* comp,                        \
+                                      const vsm_composite_lin_##SFX* cl, const vsm_added_##SFX* added,                 \
+                                      const vsm_added_lin_##SFX* al, int p_lo, int p_hi, T* work, void* stream) {      \
+    int rc;                                                                                                            \
+    if ((rc = check_comp(comp)) || (rc = check_cl(cl)) || (rc = check_added(added)) || (rc = check_al(al))) return rc; \
+    VSM_REQUIRE(added->d_symmetric == 0, "interaction_lin: d_symmetric layers are not accepted here");                 \
+    VSM_REQUIRE(N > 0 && S >= 0 && work && cl->P == al->P && p_lo >= 0 && p_lo < p_hi && p_hi <= cl->P,                \
+                "interaction_lin_range: bad argument");                                                                \
+    /* the slots [p_lo, p_hi) as a view of the parameter axis (the slowest one of [N,N,S,P] / [N,S,P]) */              \
+    composite_lin<T> c2 = cvt_cl<T>(cl);                                                                               \
+    added_lin<T> a2 = cvt_al<T>(al);                                                                                   \
+    const long long MS = (long long)N * N * S, VS = (long long)N * S;                                                  \
+    const long long alp = a2.mat_stride == 0 ? (long long)N * N : MS;                                                  \
+    c2.R_mp += p_lo * MS; c2.R_pm += p_lo * MS; c2.T_pp += p_lo * MS; c2.T_mm += p_lo * MS;                            \
+    c2.J0_p += p_lo * VS; c2.J0_m += p_lo * VS;                                                                        \
+    a2.ap_r_mp += p_lo * alp; a2.ap_r_pm += p_lo * alp; a2.ap_t_pp += p_lo * alp; a2.ap_t_mm += p_lo * alp;            \
+    a2.ap_J0_p += p_lo * VS; a2.ap_J0_m += p_lo * VS;                                                                  \
+    c2.P = a2.P = p_hi - p_lo;                                                                                         \
+    return interaction_lin<T>(iface, N, S, cvt_comp<T>(comp), c2, cvt_added<T>(added), a2, work, as_stream(stream));   \
+  }                                                                                                                    \
   int vsm_copy_added_to_composite_lin_##SFX(int N, int S, const vsm_added_lin_##SFX* al,                               \
                                             const vsm_composite_lin_##SFX* cl, void* stream) {                         \
     int rc;                                                                                                            \

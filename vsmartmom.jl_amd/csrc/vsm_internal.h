@@ -230,8 +230,6 @@ int strip_gemm(int M, int Nc, int K, int S, int P, const double* A, long long sa
                long long pb, double* C, long long sc, long long pc, double alpha, const double* D, long long sd, long long pd,
                double beta, double gamma, hipStream_t st);
 int strip_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
-int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
-                            const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_step(int N, int S, int P, double* expk, double* ekl, const added<double>& a,
                             const added_lin<double>& al, hipStream_t st);
 int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, double* ekl, const added<double>& a,
@@ -270,8 +268,7 @@ int strip128_interaction11(int N, int S, const composite<ST>& c, const added<ST>
 inline bool strip128_f32_supported(int N) { return N > 96 && N <= 128; }   // (64 < N <= 96 is the FP32 strip kernels')
 
 // ---- linearized column-strip kernels, FP64, 60 < N <= 128 (one A-form, parked strips): vsm_strip128lin.hip ----
-bool strip128_lin_dbl_supported(int N);   // which shapes take k_dbl128_lin / k_ia128_lin
-bool strip128_lin_ia_supported(int N);
+bool strip128_lin_dbl_supported(int N);   // which FP64 shapes take k_dbl128_lin (k_ia128_lin: every N <= 128)
 template <typename ST>   // ST = double, or float (storage in single, arithmetic in double)
 int strip128_doubling_lin(int N, int S, int P, int nd, int ns, ST* expk, ST* ekl, const added<ST>& a, const added_lin<ST>& al,
                           hipStream_t st);

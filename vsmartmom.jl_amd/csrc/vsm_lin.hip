@@ -623,10 +623,7 @@ int interaction_lin(int iface, int N, int S, const composite<T>& c, const compos
     return VSM_OK;
   }
   if constexpr (std::is_same<T, double>::value) {
-    // fused column-strip form (vsm_striplin.hip): two launches instead of ~60
-    rc = strip128_lin_ia_supported(N) ? (int)VSM_ERR_UNSUPPORTED : strip_interaction11_lin(N, S, c, cl, a, al, st);
-    if (rc != VSM_ERR_UNSUPPORTED) return rc;
-    // 60 < N <= 128: the same two halves in the one-A-form / parked-strip scheme (vsm_strip128lin.hip)
+    // fused: two launches (first half, second half) instead of ~60, every N <= 128 (vsm_strip128lin.hip)
     rc = strip128_interaction11_lin(N, S, c, cl, a, al, st);
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   } else {

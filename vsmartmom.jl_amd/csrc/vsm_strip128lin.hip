@@ -4,7 +4,7 @@
 //                      slots (:374-421): ALL doubling steps of one spectral point, forward + every active parameter, in one
 //                      persistent workgroup, in place on the AddedLayer / AddedLayerLin
 //   k_ia128_lin<RT>    one half of interaction_helper!(::ScatteringInterface_11) with derivatives (interaction_lin.jl:217-331);
-//                      the interaction is two launches with different operand bindings (vsm_striplin.hip's ia_half: the second
+//                      the interaction is two launches with different operand bindings (the second
 //                      half reads only arrays the first leaves untouched)
 //
 // Both are the same recurrence (vsm_striplin.hip): with a left operand LA, right operands ER, S2, S3, a transmission LT,
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64 * RT, RT <= 4 ? 2 : 1) void k_dbl128_lin(int N, 
 }
 
 // ---- interaction half ---------------------------------------------------------------------------------------------------------
-// operand bindings of one half (the fields of vsm_striplin.hip's ia_half)
+// operand bindings of one half
 template <typename ST>
 struct ia128_half {
   const ST *LA, *ER, *LT, *S2, *S3, *ACC0;
@@ -638,13 +638,12 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half<ST>& h, hipStream_t s
 }  // namespace
 
 // FP64, 60 < N <= 128 (N = 61 .. 64 on four row tiles: the strips of vsm_striplin.hip have no spare column left there)
-// Which shapes land here: beyond the reach of vsm_striplin.hip (8 <= N <= 60) by default; the thresholds are build parameters so
-// that tools/variants_lin128.sh can measure these kernels against vsm_striplin.hip's on the shapes both take.
+// Which shapes land here.  The interaction: every N <= 128 (vsm_striplin.hip's k_ia_lin_half, 0.39 of peak for two rounds, lost to
+// k_ia128_lin<4> on the shapes both took -- 0.867 -> 0.726 ms per half at 2048 points of the C2 shape -- and is gone).  The doubling:
+// beyond the reach of vsm_striplin.hip's k_dbl_lin_multi (49 <= N <= 60 stays there: 12.99 vs 12.61 10^3 points/s on the C2 shape)
+// and N <= 48; the thresholds are build parameters so that tools/variants_lin128.sh can re-measure.
 #ifndef VSM_LIN128_DBL_MIN
 #define VSM_LIN128_DBL_MIN 60
-#endif
-#ifndef VSM_LIN128_IA_MIN
-#define VSM_LIN128_IA_MIN 32     // (k_ia128_lin<4> beats k_ia_lin_half on 33 <= N <= 60: C2 shape +5.7 % end to end)
 #endif
 // ... and the shapes of one to three row tiles (N <= 48), where vsm_striplin.hip pads to 64 rows (N = 30: 27.7 -> 84.3 10^3 points/s,
 // N = 48: 20.0 -> 23.4, profiles/r04/shape_sweep_f64.txt)
@@ -653,7 +652,7 @@ int launch_ia128_lin(int N, int S, int P, const ia128_half<ST>& h, hipStream_t s
 #endif
 static bool lin128_small(int N) { return N >= 1 && N <= VSM_LIN128_SMALL_MAX; }
 bool strip128_lin_dbl_supported(int N) { return (N > VSM_LIN128_DBL_MIN && N <= 128) || lin128_small(N); }
-bool strip128_lin_ia_supported(int N) { return (N > VSM_LIN128_IA_MIN && N <= 128) || lin128_small(N); }
+
 
 // All ndoubl doubling steps (forward + P active parameters) in one launch, apply_D! included when ns (n_stokes) > 0
 template <typename ST>
@@ -682,8 +681,7 @@ int strip128_doubling_lin(int N, int S, int P, int nd, int ns, ST* expk, ST* ekl
 template <typename ST>
 int strip128_interaction11_lin(int N, int S, const composite<ST>& c, const composite_lin<ST>& cl, const added<ST>& a,
                                const added_lin<ST>& al, hipStream_t st) {
-  const bool shape_ok = sizeof(ST) == 4 ? (N >= 1 && N <= 128) : strip128_lin_ia_supported(N);
-  if (!shape_ok) return VSM_ERR_UNSUPPORTED;
+  if (N < 1 || N > 128) return VSM_ERR_UNSUPPORTED;
   if (S <= 0) return VSM_OK;
   const int P = cl.P;
   const long long NN = (long long)N * N, MS = NN * S;

@@ -32,20 +32,6 @@
 
 namespace vsm {
 
-// pointer bindings of one half of the linearized interaction (see k_ia_lin_half)
-struct ia_half {
-  const double *LA, *ER, *LT, *S2, *S3, *ACC0;
-  long long sLA, sER, sLT, sS2, sS3, sACC0;
-  double *OUT0, *OUT1;
-  const double *VR, *VADD, *VACC;
-  double* VOUT;
-  const double *PA, *D1, *D2, *YI, *ACCP, *D3;
-  long long sPA, pPA, sD1, pD1, sD2, pD2, sYI, pYI, sACCP, pACCP, sD3, pD3;
-  double *OUTP0, *OUTP1;
-  const double *VDR, *VDADD, *VDACC;
-  double* VDOUT;
-};
-
 namespace {
 
 struct lsmem {
@@ -61,7 +47,7 @@ struct lsmem {
 
 // Strip <-> global through a per-wave LDS transposer.  load_strip_global / store_strip_global touch 16 columns x 32 B
 // per instruction (sixteen half-used cache lines, re-fetched from L2 by the next instruction because the four waves'
-// strips overflow the vector L1): measured at half the time of k_ia_lin_half.  Here each lane moves 64 contiguous
+// strips overflow the vector L1): measured at half the time of the interaction kernel of rounds 1-3.  Here each lane moves 64 contiguous
 // bytes of one column (full lines, 16-byte accesses) and the (row, lane) permutation to the MFMA layout happens in a
 // wave-private 16 x 32 tile of LDS -- wave-private, so no barrier (LDS operations of one wave complete in order).
 constexpr int XS = 34;   // column stride of the tile in doubles: 2 l15 + kq is conflict-free over a 32-lane pass
@@ -606,149 +592,12 @@ __global__ __launch_bounds__(SNT, 1) void k_dbl_lin_multi(int N, int S, int nd, 
   }
 }
 
-// ---------------------------------------------------------------------------
-// Linearized interaction, ScatteringInterface_11 (interaction_lin.jl:217-331): each of its two halves has the shape of
-// the doubling step above,
-//     G = (I - LA ER)^-1 ; tt = LT G ; rt = LA S2 ;                    out0 = ACC0 + tt rt ; out1 = tt S3
-//     X1 = PA ER + LA D1 ; X2 = PA S2 + LA D2 ; Y = YI + tt X1 ; ttdot = Y G
-//     outp0 = ACCP + ttdot rt + tt X2 ;  outp1 = ttdot S3 + tt D3
-// with one source recurrence riding in spare column c1:  rt[:,c1] = LA VR + VADD,  X2[:,c1] = PA VR + LA VDR + VDADD,
-//     outp0[:,c1] = VDACC + ttdot rt[:,c1] + tt X2[:,c1],  out0[:,c1] = VACC + tt rt[:,c1].
-//   first half  (G1, T01):  LA = r-+  ER = R+-  LT = T--  S2 = T++  S3 = t--  ACC0 = R-+ -> R-+, T--   sources: J0-
-//   second half (G2, T21):  LA = R+-  ER = r-+  LT = t++  S2 = t--  S3 = T++  ACC0 = r+- -> R+-, T++   sources: J0+
-// The second half reads only arrays the first half leaves untouched, so the two halves are two launches of one kernel.
-
-template <int KS>
-__global__ __launch_bounds__(SNT, 1) void k_ia_lin_half(int N, int S, int P, ia_half h) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  lsmem& sm = *reinterpret_cast<lsmem*>(smem_raw);
-  double* BR = sm.BR;
-  double* BT = sm.BT;
-  double* BX = sm.BX;
-  double* BY = sm.BY;
-  double* vr = sm.vec[0];
-  double* vadd = sm.vec[1];
-  double* vacc = sm.vec[2];
-  double* vdr = sm.vec[3];
-  double* vdadd = sm.vec[4];
-  double* vdacc = sm.vec[5];
-  spos p;
-  p.bind(sm.BR);
-  const int s = blockIdx.x, tid = threadIdx.x;
-  const long long NN = (long long)N * N, MS = NN * S, VS = (long long)N * S;
-  const int Kend = rider_base<KS>(N);
-  const spare sp(p, Kend);
-  double* xw = sm.xw[p.wave];
-  // A-form stores carry no mask: the padding rows of every strip are zero by construction (zero-padded loads, products inherit
-  // zero rows from their A operand) and the spare columns with their riders sit at or beyond 4 KS (rider_base): never read as k
-  auto asis = [](double x, int, int) { return x; };
-  auto keep_old = [](int, double o) { return o; };
-
-  raw_strip w_er, w_s2;      // requested before the A-form staging: the two round trips overlap
-  issue_strip_load(w_er, h.ER + s * h.sER, N, p);
-  issue_strip_load(w_s2, h.S2 + s * h.sS2, N, p);
-  stage_aform_full2(BR, h.LA + s * h.sLA, BT, h.LT + s * h.sLT, N, p);
-  if (tid < SNP) {
-    const long long o = (long long)s * N + tid;
-    vr[tid] = (tid < N) ? h.VR[o] : 0.0;
-    vadd[tid] = (tid < N) ? h.VADD[o] : 0.0;
-    vacc[tid] = (tid < N) ? h.VACC[o] : 0.0;
-  }
-  __syncthreads();
-  sstrip er, s2, G, rt;
-  finish_strip_load(er, w_er, p, xw);
-  finish_strip_load(s2, w_s2, p, xw);
-  int slot = 0;
-  {
-    sstrip E;
-    E.zero();
-    mm_ab<KS>(E, BR, er, p);
-    invert_strip_horner<KS>(E, G, BY, N, sm, slot, p);   // (E: clean padding -- the rows of a product come from its zero-padded A-form)
-  }
-  sp.put(s2, p, [&](int row, double) { return vr[row]; }, keep_old);
-  {
-    sstrip tt;
-    tt.zero();
-    mm_ab<KS>(tt, BT, G, p);
-    rt.zero();
-    mm_ab<KS>(rt, BR, s2, p);   // LA S2 (+ LA VR)
-    __syncthreads();            // BT (LT) and BY (series powers) no longer read
-    store_strip(BT, tt, p, asis);
-  }
-  sp.put(rt, p, [&](int row, double o) { return vadd[row] + o; }, keep_old);
-  __syncthreads();   // tt complete in BT
-
-  // Global strip loads are issued one phase ahead of their use (before the preceding barrier): with one wave per SIMD
-  // nothing else hides their latency.
-  for (int pp = 0; pp < P; ++pp) {
-    sstrip d1, d2;
-    load_strip_global_c(d1, h.D1 + s * h.sD1 + pp * h.pD1, N, p, xw);
-    load_strip_global_c(d2, h.D2 + s * h.sD2 + pp * h.pD2, N, p, xw);
-    stage_aform_full(BX, h.PA + s * h.sPA + pp * h.pPA, N, p);
-    if (tid < SNP) {
-      const long long o = (long long)pp * VS + (long long)s * N + tid;
-      vdr[tid] = (tid < N) ? h.VDR[o] : 0.0;
-      vdadd[tid] = (tid < N) ? h.VDADD[o] : 0.0;
-      vdacc[tid] = (tid < N) ? h.VDACC[o] : 0.0;
-    }
-    __syncthreads();
-    sstrip X1, X2;
-    X1.zero();
-    X2.zero();
-    mm_ab2<KS>(X1, X2, BX, er, s2, p);   // PA ER ; PA S2 (+ PA VR)
-    sp.put(d2, p, [&](int row, double) { return vdr[row]; }, keep_old);
-    mm_ab2<KS>(X1, X2, BR, d1, d2, p);   // + LA D1 ; + LA D2 (+ LA VDR)
-    sp.put(X2, p, [&](int row, double o) { return vdadd[row] + o; }, keep_old);
-    {
-      sstrip Y;
-      load_strip_global_c(Y, h.YI + s * h.sYI + pp * h.pYI, N, p, xw);
-      mm_ab<KS>(Y, BT, X1, p);   // Y = YI + tt X1
-      store_strip(BY, Y, p, asis);
-    }
-    sstrip acc;
-    load_strip_global_c(acc, h.ACCP + s * h.sACCP + pp * h.pACCP, N, p, xw);
-    __syncthreads();   // Y complete in BY; every wave is done with PA's A-form (BX)
-    {
-      sstrip ttl;
-      ttl.zero();
-      mm_ab<KS>(ttl, BY, G, p);   // ttdot = Y G
-      store_strip(BX, ttl, p, asis);
-    }
-    sp.put(acc, p, [&](int row, double) { return vdacc[row]; }, keep_old);
-    sstrip tdn, s3;
-    tdn.zero();
-    load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
-    __syncthreads();   // ttdot complete in BX
-    mm_ab2<KS>(acc, tdn, BX, rt, s3, p);   // + ttdot rt ; ttdot S3
-    load_strip_global_c(s3, h.D3 + s * h.sD3 + pp * h.pD3, N, p, xw);
-    mm_ab2<KS>(acc, tdn, BT, X2, s3, p);   // + tt X2 ; + tt D3
-    store_strip_global_c(h.OUTP0 + (long long)pp * MS + (long long)s * NN, acc, N, p, xw);
-    store_strip_global_c(h.OUTP1 + (long long)pp * MS + (long long)s * NN, tdn, N, p, xw);
-    sp.get(acc, p, N, h.VDOUT + (long long)pp * VS + (long long)s * N, nullptr);
-    __syncthreads();   // BX, BY, the parameter's vectors free
-  }
-
-  sstrip acc0, tn;
-  load_strip_global_c(acc0, h.ACC0 + s * h.sACC0, N, p, xw);
-  sp.put(acc0, p, [&](int row, double) { return vacc[row]; }, keep_old);
-  tn.zero();
-  {
-    sstrip s3;
-    load_strip_global_c(s3, h.S3 + s * h.sS3, N, p, xw);
-    mm_ab2<KS>(acc0, tn, BT, rt, s3, p);
-  }
-  store_strip_global_c(h.OUT0 + (long long)s * NN, acc0, N, p, xw);
-  store_strip_global_c(h.OUT1 + (long long)s * NN, tn, N, p, xw);
-  sp.get(acc0, p, N, h.VOUT + (long long)s * N, nullptr);
-}
-
 }  // namespace
 
 #define VSM_CAT2(a, b) a##b
 #define VSM_CAT(a, b) VSM_CAT2(a, b)
 #define VSM_STRIPLIN_DECL(KS)                                                                                                      \
   int VSM_CAT(launch_dbl_lin_step_, KS)(int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t); \
-  int VSM_CAT(launch_ia_lin_half_, KS)(int, int, int, const ia_half&, hipStream_t);                                                \
   int VSM_CAT(launch_dbl_lin_multi_, KS)(int, int, int, int, int, double*, double*, const added<double>&, const added_lin<double>&, hipStream_t);
 
 #ifdef VSM_STRIP_KS
@@ -775,14 +624,6 @@ int VSM_CAT(launch_dbl_lin_multi_, VSM_STRIP_KS)(int N, int S, int PA, int nd, i
   else
     hipLaunchKernelGGL((k_dbl_lin_multi<VSM_STRIP_KS, 3>), dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, nd, ns, expk, ekl, a, al);
   VSM_LAUNCH_CHECK("k_dbl_lin_multi");
-  return VSM_OK;
-}
-
-int VSM_CAT(launch_ia_lin_half_, VSM_STRIP_KS)(int N, int S, int P, const ia_half& h, hipStream_t st) {
-  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(k_ia_lin_half<VSM_STRIP_KS>), sizeof(lsmem), "hipFuncSetAttribute(k_ia_lin_half)");
-  if (prepared) return prepared;
-  hipLaunchKernelGGL(k_ia_lin_half<VSM_STRIP_KS>, dim3(S), dim3(SNT), sizeof(lsmem), st, N, S, P, h);
-  VSM_LAUNCH_CHECK("k_ia_lin_half");
   return VSM_OK;
 }
 
@@ -836,67 +677,6 @@ int strip_doubling_lin_multi(int N, int S, int P, int nd, int ns, double* expk, 
 #define VSM_CASE(KS) \
   case KS:           \
     return VSM_CAT(launch_dbl_lin_multi_, KS)(N, S, P, nd, ns, expk, ekl, a, al, st);
-    VSM_CASE(9)
-    VSM_CASE(10)
-    VSM_CASE(11)
-    VSM_CASE(12)
-    VSM_CASE(13)
-    VSM_CASE(14)
-    VSM_CASE(15)
-#undef VSM_CASE
-    default:
-      return VSM_ERR_UNSUPPORTED;
-  }
-}
-
-// Fused ScatteringInterface_11 interaction with derivatives: two launches (first half, second half).
-int strip_interaction11_lin(int N, int S, const composite<double>& c, const composite_lin<double>& cl, const added<double>& a,
-                            const added_lin<double>& al, hipStream_t st) {
-  static const bool off = ab_switch("VSM_NO_STRIP_LIN") || ab_switch("VSM_NO_STRIP_LIN_IA");
-  if (off || !strip_lin_supported(N)) return VSM_ERR_UNSUPPORTED;
-  const int P = cl.P;
-  const long long NN = (long long)N * N, MS = NN * S;
-  const long long as = a.mat_stride, als = al.mat_stride, alp = (als == 0) ? NN : MS;
-  ia_half h1{};
-  h1.LA = a.r_mp;   h1.sLA = as;
-  h1.ER = c.R_pm;   h1.sER = NN;
-  h1.LT = c.T_mm;   h1.sLT = NN;
-  h1.S2 = c.T_pp;   h1.sS2 = NN;
-  h1.S3 = a.t_mm;   h1.sS3 = as;
-  h1.ACC0 = c.R_mp; h1.sACC0 = NN;
-  h1.OUT0 = c.R_mp; h1.OUT1 = c.T_mm;
-  h1.VR = c.J0_p; h1.VADD = a.j0_m; h1.VACC = c.J0_m; h1.VOUT = c.J0_m;
-  h1.PA = al.ap_r_mp; h1.sPA = als; h1.pPA = alp;
-  h1.D1 = cl.R_pm;    h1.sD1 = NN;  h1.pD1 = MS;
-  h1.D2 = cl.T_pp;    h1.sD2 = NN;  h1.pD2 = MS;
-  h1.YI = cl.T_mm;    h1.sYI = NN;  h1.pYI = MS;
-  h1.ACCP = cl.R_mp;  h1.sACCP = NN; h1.pACCP = MS;
-  h1.D3 = al.ap_t_mm; h1.sD3 = als; h1.pD3 = alp;
-  h1.OUTP0 = cl.R_mp; h1.OUTP1 = cl.T_mm;
-  h1.VDR = cl.J0_p; h1.VDADD = al.ap_J0_m; h1.VDACC = cl.J0_m; h1.VDOUT = cl.J0_m;
-  ia_half h2{};
-  h2.LA = c.R_pm;   h2.sLA = NN;
-  h2.ER = a.r_mp;   h2.sER = as;
-  h2.LT = a.t_pp;   h2.sLT = as;
-  h2.S2 = a.t_mm;   h2.sS2 = as;
-  h2.S3 = c.T_pp;   h2.sS3 = NN;
-  h2.ACC0 = a.r_pm; h2.sACC0 = as;
-  h2.OUT0 = c.R_pm; h2.OUT1 = c.T_pp;
-  h2.VR = a.j0_m; h2.VADD = c.J0_p; h2.VACC = a.j0_p; h2.VOUT = c.J0_p;
-  h2.PA = cl.R_pm;    h2.sPA = NN;  h2.pPA = MS;
-  h2.D1 = al.ap_r_mp; h2.sD1 = als; h2.pD1 = alp;
-  h2.D2 = al.ap_t_mm; h2.sD2 = als; h2.pD2 = alp;
-  h2.YI = al.ap_t_pp; h2.sYI = als; h2.pYI = alp;
-  h2.ACCP = al.ap_r_pm; h2.sACCP = als; h2.pACCP = alp;
-  h2.D3 = cl.T_pp;    h2.sD3 = NN;  h2.pD3 = MS;
-  h2.OUTP0 = cl.R_pm; h2.OUTP1 = cl.T_pp;
-  h2.VDR = al.ap_J0_m; h2.VDADD = cl.J0_p; h2.VDACC = al.ap_J0_p; h2.VDOUT = cl.J0_p;
-  int rc;
-  switch (strip_lin_ks(N)) {
-#define VSM_CASE(KS)                                                          \
-  case KS:                                                                    \
-    if ((rc = VSM_CAT(launch_ia_lin_half_, KS)(N, S, P, h1, st))) return rc;  \
-    return VSM_CAT(launch_ia_lin_half_, KS)(N, S, P, h2, st);
     VSM_CASE(9)
     VSM_CASE(10)
     VSM_CASE(11)
