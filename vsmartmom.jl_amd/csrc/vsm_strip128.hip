@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<S
     bstrip<RT> r_s;
     ldg_issue(r_s, a_r_mp, N, p);                   // (in flight with the staging)
     stage_af(AF, R_pm, N, nw, p);
-    ldg_finish(r_s, p, xw);
+    ldg_finish<ST>(r_s, p, xw);
     __syncthreads();                                    // (a)
     B128_STAMP(0);
     B128_STAMP(1);
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<S
       spill(sE, E, p);
     }
     B128_STAMP(2);
-    ldg_finish(tm, p, xw);
+    ldg_finish<ST>(tm, p, xw);
     {
       {
         bstrip<RT> Z;
@@ -470,11 +470,11 @@ __global__ __launch_bounds__(64 * B_MAXW) void k_ia128(int N, int S, composite<S
       fill(Z, sZ, p);
       __syncthreads();                                  // (j)
       B128_STAMP(12);
-      ldg_finish(acc, p, xw);
+      ldg_finish<ST>(acc, p, xw);
       mm128(acc, Z, p);                                 // R+- = r+- + T21 Z
       ldg_issue(Tpp, T_pp, N, p);
       stg(R_pm, acc, N, p, xw);
-      ldg_finish(Tpp, p, xw);
+      ldg_finish<ST>(Tpp, p, xw);
     }
     B128_STAMP(13);
     if (laneR) {                                        // z rides in the spare column of T++

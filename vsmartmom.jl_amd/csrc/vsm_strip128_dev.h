@@ -563,9 +563,10 @@ template <int RT>
 __device__ __forceinline__ void ldg_issue(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p) {
   if constexpr (use_c8<RT>::value) load_c8_issue(x, g, N, p); else load_global128(x, g, N, p);
 }
-template <int RT>
+// (ST: the element type the matching ldg_issue read -- FP32 arrays are always read directly, in the final layout)
+template <typename ST = double, int RT>
 __device__ __forceinline__ void ldg_finish(bstrip<RT>& x, const bpos<RT>& p, double* __restrict__ xw) {
-  if constexpr (use_c8<RT>::value) load_c8_finish(x, p, xw);
+  if constexpr (use_c8<RT>::value && sizeof(ST) == 8) load_c8_finish(x, p, xw);
 }
 template <int RT>
 __device__ __forceinline__ void ldg(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p, double* __restrict__ xw) {
