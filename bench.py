@@ -379,19 +379,21 @@ def bench_c5(args, vsm, parallel, torch, rank, world, local):
                          "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world),
                          "traffic": c5_traffic_per_point() and c5_traffic_per_point() * S_total,
                          "traffic_note": "HBM bytes of one whole step (all kernels; FETCH_SIZE x 2 + WRITE_SIZE per point from "
-                                         "profiles/r03/c5/summary.json, a 4000-point run, x the points of this run)"}}))
+                                         "the newest profiles/r0N/c5/summary.json, a 4000-point run, x the points of this run)"}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
 def c5_traffic_per_point():
-    """Whole-run HBM bytes per spectral point of the C5 workload from the committed PMC passes (profiles/r03/c5/summary.json)."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03", "c5", "summary.json")) as f:
-            return float(json.load(f)["hbm_bytes_per_point_whole_run"])
-    except (OSError, KeyError, ValueError):
-        return None
+    """Whole-run HBM bytes per spectral point of the C5 workload from the newest committed PMC passes (profiles/r0N/c5/summary.json)."""
+    for rnd in ("r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")) as f:
+                return float(json.load(f)["hbm_bytes_per_point_whole_run"])
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 PROFILE_ROUNDS = ("r04", "r03", "r02/final")

@@ -91,7 +91,7 @@ def c2_lin(vsm, torch, arch, o2a, points=2000):
         return scene.results_host()
     wall, dev, _ = _timed(torch, step)
     e = _entry("C2-lin", "linearized rt_run (1 gas column + albedo), N=60 FP64, 40 layers, m=0..2 (C2 shape)", points, wall, dev,
-               scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia_lin_half<15>)")
+               scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia128_lin<4>)")
     del scene
     return e
 
@@ -117,7 +117,7 @@ def c3_lin(vsm, torch, arch):
     fl = scene.flops_per_point() if hasattr(scene, "flops_per_point") else None
     e = _entry("C3-lin", "ocean / Cox-Munk scene (config/ocean_coxmunk.yaml): IQUV, N=60 FP64, 33 layers, m=0..21, linearized "
                "(gas column + wind speed) -- a latency-bound two-point batch", S, wall, dev, fl, "f64",
-               "latency: two folded chains of 33 layer steps (k_dbl_lin_multi + 2 k_ia_lin_half per step), moments m >= 1 as one batch")
+               "latency: two folded chains of 33 layer steps (k_dbl_lin_multi + 2 k_ia128_lin<4> per step), moments m >= 1 as one batch")
     del scene
     return e
 
@@ -147,14 +147,18 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
     exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
     e = _entry("C5", "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
                "20000 points); step = whole rt_run(RRS) incl. host optics, H2D, D2H" % (N, L, len(shifts), S), S, wall, dev, 3 * per_m, "f64",
-               "k_raman_doubling_wave_sp<21> (+ k_raman_interaction_wave<21>)")
+               "k_raman_doubling_quad<21> (+ k_raman_interaction_wave<21>)")
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
-    try:   # whole-step HBM bytes from the committed PMC passes of the same workload (profiles/r03/c5/summary.json)
-        with open(os.path.join(ROOT, "profiles", "r03", "c5", "summary.json")) as f:
-            e["hbm_bytes_per_step"] = float(json.load(f)["hbm_bytes_per_point_whole_run"]) * S
-    except (OSError, KeyError, ValueError):
-        e["hbm_bytes_per_step"] = None
+    e["hbm_bytes_per_step"] = None   # whole-step HBM bytes from the newest committed PMC passes of the same workload
+    for rnd in ("r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")) as f:
+                e["hbm_bytes_per_step"] = float(json.load(f)["hbm_bytes_per_point_whole_run"]) * S
+            e["hbm_bytes_source"] = "profiles/%s/c5/summary.json" % rnd
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     return e
 
 
@@ -200,9 +204,12 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     def trans():
         d = 0.3 + 0.65 * torch.rand((S, N), dtype=torch.float64, device=dev)
         return torch.diag_embed(d) + torch.rand((S, N, N), dtype=torch.float64, device=dev) * (0.05 / N)
-    init = dict(R_mp=refl(0.4), R_pm=refl(0.4), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
+    # clear-sky scale of the C2 run: ||R+- r-+||_F ~ 2e-3, i.e. the series inverse at order 7 (the order the layer interactions of
+    # the headline workload take); tools/ia_timing.py --refl sweeps the scale (orders 15 / 31 and the Gauss-Jordan path run out of
+    # line at about half this rate)
+    init = dict(R_mp=refl(0.1), R_pm=refl(0.1), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
                 J0_m=torch.rand((S, N), dtype=torch.float64, device=dev))
-    pa.r_mp.copy_(refl(0.3))
+    pa.r_mp.copy_(refl(0.075))
     pa.t_pp.copy_(trans())
     pa.j0_p.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
     pa.j0_m.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
@@ -221,11 +228,19 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     ms = tot / reps
     flop_pt = 24.0 * N ** 3 + 8.0 * N ** 2
     e = _entry("IA", "interaction!(::ScatteringInterface_11) alone (interaction.jl:207-266), N=%d FP64, %d points per launch, physically "
-               "shaped random layers (||rR|| ~ 3e-2: series inverse), added layer D-symmetric as doubling! leaves it; HIP events around each of "
-               "%d launches" % (N, S, reps), S, ms * 1e-3, ms, flop_pt, "f64", "k_ia_strip<15, true>")
+               "shaped random layers at the clear-sky scale of the C2 run (||R r|| ~ 2e-3: series inverse of order 7), added layer "
+               "D-symmetric as doubling! leaves it; HIP events around each of %d launches" % (N, S, reps), S, ms * 1e-3, ms, flop_pt,
+               "f64", "k_ia_strip<15, true>")
     e["north_star_target_mfma_utilisation"] = 0.40
-    e["note"] = ("frac_of_mfma_peak is ALGORITHMIC flops (24N^3+8N^2 per point) / launch time / 78.6; the MFMA pipe's busy fraction "
-                 "(PMC SQ_VALU_MFMA_BUSY_CYCLES) is higher: profiles/r04/ia/summary.json")
+    # what the MFMA pipe executes: 10 products of the one-inverse interaction + 6 of the order-7 Horner series, each 4 waves x 60
+    # v_mfma_f64_16x16x4 (2048 flop): 16 x 491 520 flop per point (the padded 64 x 64 x 60 tiles and the series are not in the
+    # algorithmic count)
+    exe_pt = 16 * 4 * 60 * 2048.0
+    e["mfma_utilisation_executed"] = exe_pt * S / (ms * 1e-3) / 1e12 / PEAK["f64"]
+    e["note"] = ("frac_of_mfma_peak is ALGORITHMIC flops (24N^3+8N^2 per point) / launch time / 78.6; mfma_utilisation_executed is the "
+                 "flops of the MFMA instructions the kernel issues (16 products of 240 v_mfma_f64_16x16x4 per point) / launch time / "
+                 "78.6 -- the pipe's busy fraction, which the PMC pass measures directly (SQ_VALU_MFMA_BUSY_CYCLES, "
+                 "profiles/r04/ia/summary.json)")
     del pc, pa, init
     return e
 

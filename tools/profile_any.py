@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--skip-pmc", action="store_true")
+    ap.add_argument("--points-per-run", type=int, default=0,
+                    help="spectral points of one run of the command: adds hbm_bytes_per_point_whole_run (all vsm:: kernels)")
+    ap.add_argument("--runs", type=int, default=1, help="runs of the workload inside the command (warm-up + timed)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
@@ -108,6 +111,13 @@ def main():
                 if s.get("SQ_BUSY_CYCLES"):
                     rec["mfma_busy_over_sq_busy"] = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / s["SQ_BUSY_CYCLES"]
                 rec["mfma_mops_per_launch"] = s.get(mops, 0) / max(s.get("launches", 1), 1)
+    if a.points_per_run and not a.skip_pmc:
+        tot = sum((v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)) * v.get("calls", 0)
+                  for v in summary["kernels"].values())
+        summary["points_per_run"], summary["runs"] = a.points_per_run, a.runs
+        summary["hbm_bytes_per_point_whole_run"] = tot / (a.runs * a.points_per_run)
+        summary["note"] = ("whole-run HBM bytes per point = sum over the vsm:: kernels of (fetch + write) per launch x calls / "
+                           "(runs x points_per_run)")
     json.dump(summary, open(os.path.join(a.out, "summary.json"), "w"), indent=1)
     import shutil
     for name in passes:      # the raw per-dispatch CSVs are tens of MB; only the condensed files travel back

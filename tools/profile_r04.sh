@@ -18,6 +18,6 @@ for w in "$@"; do
     lin30)  $P --out gpurun_out/prof_r04_lin30 --dtype f64 -- python tools/shape_cliff_timing.py --cases IQU:15 ;;
     fwd112) $P --out gpurun_out/prof_r04_fwd112 --dtype f64 -- python tools/shape_cliff_timing.py --no-lin --cases IQUV:51 ;;
     ia)     $P --out gpurun_out/prof_r04_ia --dtype f64 -- python tools/ia_timing.py --points 4096 --refl 0.1 --dsym 3 ;;
-    c5)     $P --out gpurun_out/prof_r04_c5 --dtype f64 -- python bench.py --config C5 --total-points 4000 --steps 1 --warmup 1 ;;
+    c5)     $P --out gpurun_out/prof_r04_c5 --dtype f64 --points-per-run 4000 --runs 2 -- python bench.py --config C5 --total-points 4000 --steps 1 --warmup 1 ;;
   esac
 done
