@@ -202,6 +202,7 @@ int raman_doubling_quad(int N, int S, int K, const int* shift, const double* r, 
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
                         double* ieJm, int ns_last, double* ier_pm, double* iet_mm, hipStream_t st);
+int raman_interaction_quad(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
 template <typename T>
 int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
                          const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,

@@ -376,7 +376,8 @@ __global__ void k_apply_D_batch(int N, int ns, T* r_mp, const T* __restrict__ t_
 template <typename T>
 static int raman_ia_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st) {
   if constexpr (std::is_same<T, double>::value) {
-    const int rc = raman_interaction_wave(N, S, K, shift, h, st);
+    int rc = raman_interaction_quad(N, S, K, shift, h, st);   // 13 <= N <= 22: four lines per wave on the 4 x 4 x 4 MFMA
+    if (rc == VSM_ERR_UNSUPPORTED) rc = raman_interaction_wave(N, S, K, shift, h, st);
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
   return raman_interaction_lines<T>(N, S, K, shift, h, st);

@@ -550,6 +550,165 @@ __global__ __launch_bounds__(64) void k_raman_doubling_quad(
   }
 }
 
+// ---- interaction pass (interaction_inelastic.jl:319-521, one of its two `for dn` loops; the operand bindings of rs_ia_pass) -------
+//     W1 = L1 E0 + L2 I1      W3 = L1 E3 + L2 I3      Y = YA + TI W1      A = ACCA + TI W3 + Y GX      B = TI I4 + Y GY
+// (+ the source recurrence in the rider column N: V1 = L1 VE0 + L2 VI1 + VADD, VOUT = VACC + TI V1 + Y VV).  Four lines of a recipient
+// per wave as in the doubling step.  Left operands that come from memory (L1, L2, TI) are gathered straight into registers in the
+// left-operand lane map (32 contiguous bytes per four lanes; L2, TI the same block for the four lines), right operands and the
+// accumulator seeds are staged by LDS-DMA into two alternating quad images one product ahead, Y is transposed in registers.
+template <int N>
+__global__ __launch_bounds__(64) void k_raman_interaction_quad(int S, int K, const int* __restrict__ shift, const rs_ia_pass<double> h) {
+  using Q = qcfg<N>;
+  using IM = qimg<N>;
+  constexpr int RB = Q::RB, NB = Q::NB, NN = N * N, cA = Q::cA;
+  __shared__ __attribute__((aligned(16))) double QA[4 * IM::LS];
+  __shared__ __attribute__((aligned(16))) double QB[4 * IM::LS];
+  qpos p;
+  p.lane = threadIdx.x;
+  p.q = p.lane >> 4;
+  p.b = (p.lane >> 2) & 3;
+  p.l = p.lane & 3;
+  p.tr4 = 4 * (16 * p.l + 4 * p.b + p.q);
+  // workgroup -> (recipient, quad rank): XCD-aware, quad rank by quad rank (see k_raman_doubling_quad)
+  const int per = (S + 7) >> 3;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int qi = idx / per, n1 = xcd * per + (idx - qi * per);
+  if (n1 >= S) return;
+  int dsel[4] = {-1, -1, -1, -1};
+  int cnt = 0;
+  {
+    int base = 0;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int i = 64 * hh + p.lane;
+      const int sh = (i < K) ? shift[i] : 0;
+      const int n0 = n1 + sh;
+      const bool inb = i < K && n0 >= 0 && n0 < S;
+      const unsigned long long bal = __ballot(inb);
+      const int rank = base + __popcll(bal & ((1ull << p.lane) - 1ull));
+      base += __popcll(bal);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const unsigned long long mb = __ballot(inb && rank == 4 * qi + bb);
+        if (mb) dsel[bb] = 64 * hh + __ffsll((long long)mb) - 1;
+      }
+    }
+    cnt = base;
+  }
+  if (4 * qi >= cnt) return;
+  long long o4s[4], e0s[4], e3s[4], g4s[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int db = __builtin_amdgcn_readfirstlane((4 * qi + b < cnt) ? dsel[b] : dsel[0]);
+    const int n0b = n1 + __builtin_amdgcn_readfirstlane(shift[db]);
+    o4s[b] = ((long long)n1 + (long long)S * db) * NN;
+    e0s[b] = (long long)n0b * h.sE0;
+    e3s[b] = (long long)n0b * h.sE3;
+    g4s[b] = (long long)n0b * NN;
+  }
+  const bool valid = 4 * qi + p.b < cnt;
+  const long long o4 = (p.b == 0) ? o4s[0] : ((p.b == 1) ? o4s[1] : ((p.b == 2) ? o4s[2] : o4s[3]));
+  const long long g4 = (p.b == 0) ? g4s[0] : ((p.b == 1) ? g4s[1] : ((p.b == 2) ? g4s[2] : g4s[3]));
+  const long long o4v = o4 / N, e1 = g4 / N;
+  const double* qa = QA + p.b * IM::LS;
+  const double* qb = QB + p.b * IM::LS;
+
+  // ---- prologue: E0 -> QA, I1 -> QB ;  L1, L2 in registers
+  q_dma_quad<N>(QA, h.E0, e0s, p.lane);
+  q_dma_quad<N>(QB, h.I1, o4s, p.lane);
+  qmat<RB, NB> W1, W3;
+  {
+    amat<RB> L1A, L2A;
+    q_load_a<N>(L1A, h.L1 + o4, p);
+    q_load_a<N>(L2A, h.L2 + (long long)n1 * h.sL2, p);
+    {
+      cvec<RB> v;
+      q_load_v<N>(v, h.VE0 + e1, p);
+      q_dma_wait();
+      // ---- W1 = L1 E0 (rider: L1 VE0[n0])
+      q_zero(W1);
+      q_mm_f<NB>(W1, fa_reg<RB>{L1A}, fb_lds<N, 1>(qa, p, &v));
+    }
+    q_dma_wait();
+    q_dma_quad<N>(QA, h.E3, e3s, p.lane);
+    {
+      cvec<RB> v;
+      q_load_v<N>(v, h.VI1 + o4v, p);
+      // ---- W1 += L2 I1 (rider: L2 VI1)
+      q_mm_f<NB>(W1, fa_reg<RB>{L2A}, fb_lds<N, 1>(qb, p, &v));
+    }
+    q_dma_wait();
+    q_dma_quad<N>(QB, h.I3, o4s, p.lane);
+    // ---- W3 = L1 E3 + L2 I3
+    q_zero(W3);
+    q_mm_f<RB>(W3, fa_reg<RB>{L1A}, fb_lds<N, 0>(qa, p));
+    q_dma_wait();
+    q_dma_quad<N>(QA, h.YA, o4s, p.lane);
+    q_mm_f<RB>(W3, fa_reg<RB>{L2A}, fb_lds<N, 0>(qb, p));
+  }
+  q_dma_wait();
+  q_dma_quad<N>(QB, h.ACCA, o4s, p.lane);
+  {   // column N of W1 becomes V1 = L1 VE0 + L2 VI1 + VADD
+    cvec<RB> v;
+    q_load_v<N>(v, h.VADD + o4v, p);
+    const cvec<RB> q1 = q_col<cA>(W1);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) v.x[i] += q1.x[i];
+    q_set_col<cA>(W1, v, p);
+  }
+  qmat<RB, NB> Y, A, B;
+  cvec<RB> vt;
+  {
+    amat<RB> TIA;
+    q_load_a<N>(TIA, h.TI + (long long)n1 * NN, p);
+    // ---- Y = YA + TI W1 (column N: TI V1)
+    q_read_b<N, 0, NB>(Y, fb_lds<N, 0>(qa, p));
+    q_dma_quad<N>(QA, h.I4, o4s, p.lane);
+    q_mm_f<NB>(Y, fa_reg<RB>{TIA}, fb_reg<RB, NB>{W1});
+    q_dma_wait();
+    // ---- A = ACCA + TI W3
+    q_read_b<N, 0, NB>(A, fb_lds<N, 0>(qb, p));
+    q_dma_quad<N>(QB, h.GX, g4s, p.lane);
+    q_mm_f<RB>(A, fa_reg<RB>{TIA}, fb_reg<RB, NB>{W3});
+    q_dma_wait();
+    // ---- B = TI I4
+    q_zero(B);
+    q_mm_f<RB>(B, fa_reg<RB>{TIA}, fb_lds<N, 0>(qa, p));
+  }
+  q_dma_wait();
+  q_dma_quad<N>(QA, h.GY, g4s, p.lane);
+  vt = q_col<cA>(Y);
+  {
+    amat<RB> YT;
+    q_transpose(YT, Y, p);   // (its column N = TI V1 meets the zero rows >= N of GX, GY)
+    cvec<RB> v;
+    q_load_v<N>(v, h.VV + e1, p);
+    // ---- A += Y GX (rider: Y VV[n0]) ;  B += Y GY
+    q_mm_f<NB>(A, fa_reg<RB>{YT}, fb_lds<N, 1>(qb, p, &v));
+    q_dma_wait();
+    q_mm_f<RB>(B, fa_reg<RB>{YT}, fb_lds<N, 0>(qa, p));
+  }
+  cvec<RB> vac;
+  q_load_v<N>(vac, h.VACC + o4v, p);
+  if (valid) {
+    const bool rid = p.l == (cA & 3);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = 4 * i + p.q;
+      if (rid && row < N) h.VOUT[o4v + row] = A.v[i][cA >> 2] + vac.x[i] + vt.x[i];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int col = 4 * j + p.l;
+        if (row < N && col < N) {
+          const long long o = o4 + row + N * col;
+          h.OUTA[o] = A.v[i][j];
+          h.OUTB[o] = B.v[i][j];
+        }
+      }
+    }
+  }
+}
+
 #ifndef RQ_N_LO
 #define RQ_N_LO 13
 #endif
@@ -599,6 +758,22 @@ int raman_doubling_quad(int N, int S, int K, const int* shift, const double* r, 
   return dispatch_rq<RQ_N_LO>(N, [&](auto tag) {
     return launch_rq<decltype(tag)::value>(S, K, shift, r, t, ttg, gt, gr, grt, jp, j1m, tmp1, tmp2, expk, ier, iet, ieJp, ieJm, ns,
                                            ier_pm, iet_mm, st);
+  });
+}
+
+
+// One pass of the inelastic interaction, FP64, RQ_N_LO <= N <= 22, K <= 128; VSM_ERR_UNSUPPORTED otherwise (the caller goes on to
+// raman_interaction_wave).  The outputs alias operands of the same line only; a wave reads all of its lines' blocks before it writes.
+int raman_interaction_quad(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st) {
+  static const bool off = ab_switch("VSM_NO_RAMAN_QUAD");
+  if (off || N < RQ_N_LO || N > RQ_N_HI || K > 128) return VSM_ERR_UNSUPPORTED;
+  if (S <= 0 || K <= 0) return VSM_OK;
+  const long long blocks = 8LL * ((S + 7) / 8) * ((K + 3) / 4);
+  if (blocks > 0x7fffffffLL) return VSM_ERR_UNSUPPORTED;
+  return dispatch_rq<RQ_N_LO>(N, [&](auto tag) {
+    hipLaunchKernelGGL((k_raman_interaction_quad<decltype(tag)::value>), dim3((unsigned)blocks), dim3(64), 0, st, S, K, shift, h);
+    VSM_LAUNCH_CHECK("k_raman_interaction_quad");
+    return (int)VSM_OK;
   });
 }
 
