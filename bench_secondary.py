@@ -77,7 +77,7 @@ def c4(vsm, torch, arch, o2a, points=12500):
     return e
 
 
-def c2_lin(vsm, torch, arch, o2a, points=2000):
+def c2_lin(vsm, torch, arch, o2a, points=2048):   # (24 full rounds of 256 single-workgroup CUs per layer launch: 3 moments x 2048)
     L = 40
     tau_rayl, tau_abs = o2a(points, L)
     H = vsm.host_model
