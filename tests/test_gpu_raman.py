@@ -239,6 +239,18 @@ def test_interaction_inelastic(vsm, arch, FT, pol, l_trunc, surface, iface):
         assert _rel(vsm.Architectures.to_host(getattr(pc, k)), getattr(comp, k)) <= tol, k
 
 
+@pytest.mark.parametrize("l_trunc,N", [(19, 13), (21, 14), (27, 17), (33, 20), (37, 22)])
+def test_raman_quad_kernels_every_size(vsm, arch, l_trunc, N):
+    """vsm_raman_quad.hip (four Raman lines per wave on the 4 x 4 x 4 MFMA) owns FP64 13 <= N <= 22; the lists above hit N = 15, 16,
+    18, 19, 21.  The remaining sizes -- every N mod 4, the rider columns inside / outside the last block of real columns, odd and
+    even N^2 (the late slot of the LDS-DMA images) -- through five doubling steps incl. the last one (apply_D on the way out) and
+    the _11 interaction, partial last quads (K = 7 lines) included."""
+    c = _setup(vsm, arch, np.float64, "I", S=9, l_trunc=l_trunc, seed=3)
+    assert c["N"] == N
+    test_doubling_inelastic(vsm, arch, np.float64, "I", l_trunc)
+    test_interaction_inelastic(vsm, arch, np.float64, "I", l_trunc, False, "11")
+
+
 def _raman_models(vsm, arch, pol, l_trunc, S, L, FT, uniform=False, seed=11, m_max=2):
     rng = np.random.default_rng(seed)
     tau_rayl = np.tile(np.linspace(0.02, 0.05, L), (S, 1))
