@@ -668,7 +668,7 @@ def test_rt_run_solar_tester_scalar_and_vector(vsm, arch, golden_dir):
 
 
 def test_rt_run_siewert(vsm, arch, golden_dir):
-    """VLIDORT Case A, IQUV, N = 112 (operator-level path), az = 90 deg (all four Stokes tables)."""
+    """VLIDORT Case A, IQUV, N = 112 (k_dbl128 / k_ia128, vsm_strip128.hip: asserted below), az = 90 deg (all four Stokes tables)."""
     fx = _load(golden_dir, "siewert2000_IIA.json")
     p = fx["procedure"]
     ao = O.AerosolOptics(O.greek_from_dict(fx["greek"]), p["ssa"], 0.0)
