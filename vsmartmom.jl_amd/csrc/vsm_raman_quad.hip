@@ -320,6 +320,66 @@ __device__ __forceinline__ void q_read_b(qmat<qcfg<N>::RB, C>& m, const fb_lds<N
     for (int j = 0; j < C; ++j) m.v[k][j] = fb(k, j);
 }
 
+// ---- outputs through the (now idle) images: full-line stores -------------------------------------------------------------------
+// A result in the accumulator lane map scatters as 16 pieces of 32 bytes per store instruction (36 instructions per matrix and
+// quad, partial lines at the L2: the last doubling step of a layer, which writes four matrices, took 0.5 ms more than the others).
+// Written flat into its line of an image first, a matrix leaves as 16 contiguous bytes per lane, 1 KB per instruction.
+template <int N, int C, typename F>
+__device__ __forceinline__ void q_img_put(double* img, const qmat<qcfg<N>::RB, C>& m, const qpos& p, F&& f) {
+  constexpr int RB = qcfg<N>::RB;
+  double* w0 = img + p.q + N * p.l;
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+      if (4 * i + p.q < N && 4 * j + p.l < N) w0[4 * i + N * 4 * j] = f(m.v[i][j], i);
+}
+// sign masks of the D-mirror for the flat element pairs a lane copies: bit 2 c + h set <=> element 2 (64 c + lane) + h sits in a
+// block position whose row and column differ in their U / V property
+template <int N>
+__device__ __forceinline__ unsigned q_flat_diff_mask(int ns, int lane) {
+  constexpr int NN = N * N, CH = (NN + 127) / 128;
+  unsigned m = 0u;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int e = min(2 * (64 * c + lane) + h, NN - 1), col = e / N, row = e - col * N;
+      m |= ((is_uv_row(row, ns) != is_uv_row(col, ns)) ? 1u : 0u) << (2 * c + h);
+    }
+  return m;
+}
+// the lines of an image -> global blocks (and, MIRROR, their D-mirrors); `ok` = the lane group's line is stored at all
+template <int N, bool MIRROR>
+__device__ __forceinline__ void q_img_out(const double* img, double* __restrict__ g, double* __restrict__ gm, const long long (&off)[4],
+                                          int nvalid, unsigned dmask, int lane) {
+  constexpr int NN = N * N, CH = (NN + 127) / 128, LS = qimg<N>::LS;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (b >= nvalid) break;   // (wave-uniform)
+    const double* src = img + b * LS;
+    double* dst = g + off[b];
+    double* dstm = MIRROR ? gm + off[b] : nullptr;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int e = 2 * (64 * c + lane);
+      if (e + 1 < NN) {
+        const double x0 = src[e], x1 = src[e + 1];
+        dst[e] = x0;
+        dst[e + 1] = x1;
+        if (MIRROR) {
+          dstm[e] = ((dmask >> (2 * c)) & 1u) ? -x0 : x0;
+          dstm[e + 1] = ((dmask >> (2 * c + 1)) & 1u) ? -x1 : x1;
+        }
+      } else if (e < NN) {   // the odd tail
+        const double x0 = src[e];
+        dst[e] = x0;
+        if (MIRROR) dstm[e] = ((dmask >> (2 * c)) & 1u) ? -x0 : x0;
+      }
+    }
+  }
+}
+
 template <int N, bool LAST>
 __global__ __launch_bounds__(64) void k_raman_doubling_quad(
     int S, int K, int NQ, const int* __restrict__ shift, const double* __restrict__ r, const double* __restrict__ t,
@@ -520,34 +580,30 @@ __global__ __launch_bounds__(64) void k_raman_doubling_quad(
   cvec<RB> cJp, cJm;
   q_load_v<N>(cJp, ieJp + o4v, p);
   q_load_v<N>(cJm, ieJm + o4v, p);
-  if (valid) {
-    const bool rid = p.l == (cA & 3);
+  if (valid && p.l == (cA & 3)) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = 4 * i + p.q;
-      const bool uvr = ns > 0 && is_uv_row(row, ns);
-      if (rid && row < N) {
+      if (row < N) {
         ieJp[o4v + row] = O1.v[i][cA >> 2] + cJp.x[i] * e0;
         const double x = O2.v[i][cA >> 2] + cJm.x[i];
-        ieJm[o4v + row] = uvr ? -x : x;
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int col = 4 * j + p.l;
-        if (row < N && col < N) {
-          const long long o = o4 + row + N * col;
-          const double a1 = O1.v[i][j], a2 = uvr ? -O2.v[i][j] : O2.v[i][j];
-          iet[o] = a1;
-          ier[o] = a2;
-          if (ns > 0) {
-            const bool df = uvr != is_uv_row(col, ns);
-            iet_mm[o] = df ? -a1 : a1;
-            ier_pm[o] = df ? -a2 : a2;
-          }
-        }
+        ieJm[o4v + row] = (ns > 0 && is_uv_row(row, ns)) ? -x : x;
       }
     }
   }
+  // iet' -> QA, ier' (rows flipped for U / V on the way out of the last step) -> QB, then flat to memory
+  q_dma_fence();   // (every read of the images has returned)
+  q_img_put<N>(QA + p.b * IM::LS, O1, p, [](double x, int) { return x; });
+  unsigned uvrow = 0u;   // bit i: row 4 i + q is a U / V row
+  if (ns > 0) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) uvrow |= (is_uv_row(4 * i + p.q, ns) ? 1u : 0u) << i;
+  }
+  q_img_put<N>(QB + p.b * IM::LS, O2, p, [uvrow](double x, int i) { return ((uvrow >> i) & 1u) ? -x : x; });
+  const int nvalid = min(cnt - 4 * qi, 4);
+  const unsigned dmask = LAST ? q_flat_diff_mask<N>(ns_arg > 0 ? ns_arg : 1, p.lane) : 0u;
+  q_img_out<N, LAST>(QA, iet, iet_mm, o4s, nvalid, dmask, p.lane);
+  q_img_out<N, LAST>(QB, ier, ier_pm, o4s, nvalid, dmask, p.lane);
 }
 
 // ---- interaction pass (interaction_inelastic.jl:319-521, one of its two `for dn` loops; the operand bindings of rs_ia_pass) -------
@@ -690,23 +746,20 @@ __global__ __launch_bounds__(64) void k_raman_interaction_quad(int S, int K, con
   }
   cvec<RB> vac;
   q_load_v<N>(vac, h.VACC + o4v, p);
-  if (valid) {
-    const bool rid = p.l == (cA & 3);
+  if (valid && p.l == (cA & 3)) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int row = 4 * i + p.q;
-      if (rid && row < N) h.VOUT[o4v + row] = A.v[i][cA >> 2] + vac.x[i] + vt.x[i];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int col = 4 * j + p.l;
-        if (row < N && col < N) {
-          const long long o = o4 + row + N * col;
-          h.OUTA[o] = A.v[i][j];
-          h.OUTB[o] = B.v[i][j];
-        }
-      }
+      if (row < N) h.VOUT[o4v + row] = A.v[i][cA >> 2] + vac.x[i] + vt.x[i];
     }
   }
+  // A -> QA, B -> QB, then flat to memory (full-line stores: q_img_out)
+  q_dma_fence();
+  q_img_put<N>(QA + p.b * IM::LS, A, p, [](double x, int) { return x; });
+  q_img_put<N>(QB + p.b * IM::LS, B, p, [](double x, int) { return x; });
+  const int nvalid = min(cnt - 4 * qi, 4);
+  q_img_out<N, false>(QA, h.OUTA, nullptr, o4s, nvalid, 0u, p.lane);
+  q_img_out<N, false>(QB, h.OUTB, nullptr, o4s, nvalid, 0u, p.lane);
 }
 
 #ifndef RQ_N_LO
