@@ -113,12 +113,10 @@ def c3_lin(vsm, torch, arch):
         _lin_step_inputs(scene)
         scene.run()
         return scene.results_host()
-    reps = 5                         # a 25 ms latency-bound step: the mean of five (one warm-up inside _timed)
-    ts = [_timed(torch, step)[:2] for _ in range(reps)]
-    wall, dev = sum(t[0] for t in ts) / reps, sum(t[1] for t in ts) / reps
+    wall, dev, _ = _timed(torch, step)
     fl = scene.flops_per_point() if hasattr(scene, "flops_per_point") else None
     e = _entry("C3-lin", "ocean / Cox-Munk scene (config/ocean_coxmunk.yaml): IQUV, N=60 FP64, 33 layers, m=0..21, linearized "
-               "(gas column + wind speed) -- a latency-bound two-point batch; mean of 5 steps", S, wall, dev, fl, "f64",
+               "(gas column + wind speed) -- a latency-bound two-point batch", S, wall, dev, fl, "f64",
                "latency: two folded chains of 33 layer steps (k_dbl_lin_multi + 2 k_ia128_lin<4> per step), moments m >= 1 as one batch")
     del scene
     return e
