@@ -239,10 +239,10 @@ def test_interaction_inelastic(vsm, arch, FT, pol, l_trunc, surface, iface):
         assert _rel(vsm.Architectures.to_host(getattr(pc, k)), getattr(comp, k)) <= tol, k
 
 
-@pytest.mark.parametrize("l_trunc,N", [(19, 13), (21, 14), (27, 17), (33, 20), (37, 22)])
+@pytest.mark.parametrize("l_trunc,N", [(3, 5), (5, 6), (9, 8), (11, 9), (13, 10), (19, 13), (21, 14), (27, 17), (33, 20), (37, 22)])
 def test_raman_quad_kernels_every_size(vsm, arch, l_trunc, N):
-    """vsm_raman_quad.hip (four Raman lines per wave on the 4 x 4 x 4 MFMA) owns FP64 13 <= N <= 22; the lists above hit N = 15, 16,
-    18, 19, 21.  The remaining sizes -- every N mod 4, the rider columns inside / outside the last block of real columns, odd and
+    """vsm_raman_quad.hip (four Raman lines per wave on the 4 x 4 x 4 MFMA) owns FP64 3 <= N <= 22; the lists above hit N = 4, 7, 11, 12,
+    15, 16, 18, 19, 21.  The remaining sizes -- every N mod 4, the rider columns inside / outside the last block of real columns, odd and
     even N^2 (the late slot of the LDS-DMA images) -- through five doubling steps incl. the last one (apply_D on the way out) and
     the _11 interaction, partial last quads (K = 7 lines) included."""
     c = _setup(vsm, arch, np.float64, "I", S=9, l_trunc=l_trunc, seed=3)

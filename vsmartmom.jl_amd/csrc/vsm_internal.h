@@ -197,7 +197,7 @@ int raman_doubling_wave(int N, int S, int K, const int* shift, const double* r, 
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
                         double* ieJm, int ns_last, double* ier_pm, double* iet_mm, hipStream_t st);
-// four lines per wave on the 4 x 4 x 4 MFMA (vsm_raman_quad.hip): FP64, 13 <= N <= 22
+// four lines per wave on the 4 x 4 x 4 MFMA (vsm_raman_quad.hip): FP64, 3 <= N <= 22
 int raman_doubling_quad(int N, int S, int K, const int* shift, const double* r, const double* t, const double* ttg,
                         const double* gt, const double* gr, const double* grt, const double* jp, const double* j1m,
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,

@@ -376,7 +376,7 @@ __global__ void k_apply_D_batch(int N, int ns, T* r_mp, const T* __restrict__ t_
 template <typename T>
 static int raman_ia_lines(int N, int S, int K, const int* shift, const rs_ia_pass<T>& h, hipStream_t st) {
   if constexpr (std::is_same<T, double>::value) {
-    int rc = raman_interaction_quad(N, S, K, shift, h, st);   // 13 <= N <= 22: four lines per wave on the 4 x 4 x 4 MFMA
+    int rc = raman_interaction_quad(N, S, K, shift, h, st);   // 3 <= N <= 22: four lines per wave on the 4 x 4 x 4 MFMA
     if (rc == VSM_ERR_UNSUPPORTED) rc = raman_interaction_wave(N, S, K, shift, h, st);
     if (rc != VSM_ERR_UNSUPPORTED) return rc;
   }
@@ -437,7 +437,7 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
     // ---- inelastic recurrences of this step (they read the OLD elastic r, t, J0+, expk) -------------------------------
     rc = VSM_ERR_UNSUPPORTED;
     if constexpr (std::is_same<T, double>::value) {
-      // FP64, 13 <= N <= 22: four lines per wave on the 4 x 4 x 4 MFMA; N <= 30: one wave per line on 16 x 16 x 4 tiles
+      // FP64, 3 <= N <= 22: four lines per wave on the 4 x 4 x 4 MFMA; N <= 30: one wave per line on 16 x 16 x 4 tiles
       rc = raman_doubling_quad(N, S, K, shift, a.r_mp, a.t_pp, ttg, gt, gr, grt, a.j0_p, j1m, tmp1, tmp2, expk, ie.ier_mp,
                                ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, (n == ndoubl - 1 && !sepD) ? ns : 0, ie.ier_pm, ie.iet_mm, st);
       if (rc == VSM_ERR_UNSUPPORTED)

@@ -1,4 +1,4 @@
-// Rotational-Raman inelastic doubling step -- FOUR RAMAN LINES PER WAVE on v_mfma_f64_4x4x4 (FP64, N <= 22; round 4).
+// Rotational-Raman inelastic doubling step -- FOUR RAMAN LINES PER WAVE on v_mfma_f64_4x4x4 (FP64, 3 <= N <= 22; round 4).
 //
 // doubling_inelastic.jl:62-123 (the two `for dn` loops of doubling_helper!(::RRS, ...)).  Per (recipient point n1, line dn;
 // donor n0 = n1 + shift[dn]) the step is ten N x N x N products and eight mat-vecs:
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64) void k_raman_interaction_quad(int S, int K, con
 }
 
 #ifndef RQ_N_LO
-#define RQ_N_LO 13
+#define RQ_N_LO 3
 #endif
 #ifndef RQ_N_HI
 #define RQ_N_HI 22
