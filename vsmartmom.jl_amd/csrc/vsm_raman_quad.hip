@@ -12,8 +12,9 @@
 // Here block b IS a Raman line: a wave walks four lines of one recipient at once, a matrix is NB x NB registers
 // (NB = ceil((N + 2) / 4): N = 21 -> 24 x 24, 67 % useful), element [4 I + q][4 J + l] of line b in register (I, J) -- the layout
 // of D and of B, so a product's result is the next product's right operand as it stands (as in every strip kernel of this
-// library).  Left operands have the transposed lane map: elastic ones and the state are gathered that way from memory
-// (32 contiguous bytes per four lanes), computed ones (X, WA) are transposed in registers by ds_bpermute (no LDS storage).
+// library).  Left operands have the transposed lane map: those that come from memory are read that way from their LDS image
+// (the interaction pass gathers three of them straight from memory, 32 contiguous bytes per four lanes), computed ones (X, WA, Y)
+// are transposed in registers by ds_bpermute (no LDS storage).
 //
 // Operands that come from memory never sit in registers: a first version gathered them there and the allocator, at 512 registers,
 // answered every load with "wait, spill" (4.1k points/s on C5 against the 6.0k of the wave-per-line kernel).  Now every N x N block
@@ -23,7 +24,9 @@
 // share a single-line image: 37 KB per wave, four single-wave workgroups per CU, no barrier.  Registers hold only what the products
 // produce (peak: four matrices of 72 registers).
 //
-// Per line 540 MFMAs of 16 cycles (8.6 k cycles; the 16 x 16 x 4 form: 240 of 64 = 15.4 k) and ~ 250 other instructions (~ 860).
+// Per line 540 MFMAs of 16 cycles (8.6 k cycles; the 16 x 16 x 4 form: 240 of 64 = 15.4 k) and ~ 900 other instructions (~ 860).
+// Results leave through the idle images as full lines (q_img_put / q_img_out).  Measured: DESIGN.md 4.6b -- the kernels are bound by
+// the bytes of a step (4 TB/s), not by the MFMA pipe (43 % busy) or by latency (a second wave per SIMD did not help).
 #include <type_traits>
 
 #include "vsm_common.h"
