@@ -19,6 +19,7 @@ contiguous tensor of shape (S, N, N) whose slice [s] holds the matrix
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
 import os
 from dataclasses import dataclass
@@ -674,7 +675,15 @@ class Scene:
                                    tau_sum=self.tau_sum[iz, lo:hi]))
             rho = self.albedo_d
             if isinstance(model.surface, BRDF_SURFACES):   # scene constant like Z(m): one N x N block per moment
-                rho, _ = reflectance(model.surface, self.dq, m, self.arch, FT)
+                # (kept across prepare() calls for as long as the surface's parameters stay what they were: a step that only
+                # changes the optical depths does not re-evaluate 22 Fourier blocks -- 5 of the 6 ms of the ocean scene's prepare)
+                key = (type(model.surface).__name__, dataclasses.astuple(model.surface), m)
+                cache = self.__dict__.setdefault("_rho_cache", {})
+                if key not in cache:
+                    if len(cache) > 4 * (model.m_max + 1):
+                        cache.clear()
+                    cache[key] = reflectance(model.surface, self.dq, m, self.arch, FT)[0]
+                rho = cache[key]
             self.moments.append(dict(m=m, layers=layers, iface_surface=tags[-1], rho=rho, tau_sum_surface=self.tau_sum[L, lo:hi]))
         all11 = all(t == "11" for t in tags)
         fused_ok = self.N <= _lib.lib().vsm_fused_max_n(8 if np.dtype(FT) == np.float64 else 4)
