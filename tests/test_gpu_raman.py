@@ -5,6 +5,8 @@ end to end, then a size-independent property at a larger size.
 Tolerances: FP64 operators 1e-10 relative to the array maximum (summation order only), FP64 end-to-end 1e-8,
 FP32 operators 5e-4 / end-to-end 1e-2 (the reference's own FP32 gate, test/test_float32.jl:58-64).
 """
+import sys
+
 import numpy as np
 import pytest
 
@@ -249,6 +251,23 @@ def test_raman_quad_kernels_every_size(vsm, arch, l_trunc, N):
     assert c["N"] == N
     test_doubling_inelastic(vsm, arch, np.float64, "I", l_trunc)
     test_interaction_inelastic(vsm, arch, np.float64, "I", l_trunc, False, "11")
+
+
+@pytest.mark.parametrize("K", [9, 70])
+def test_raman_quad_kernels_line_lists(vsm, arch, monkeypatch, K):
+    """The line list of the quad kernels (ranks of the in-band lines of a recipient, four per wave) on irregular offsets: K = 9 leaves
+    a last quad with one line, K = 70 crosses the 64-line ballot; offsets of both signs, one that is never in band, a zero offset;
+    recipients near the band edges get partial lists.  Doubling steps and the _11 interaction against the oracle (N = 21)."""
+    rng = np.random.default_rng(K)
+    if K == 9:
+        shifts = np.array([-9, -5, -2, 0, 2, 3, 4, 6, 40])
+    else:   # 55 offsets that are never in band (S = 14), then 15 in-band ones at line indices 55 .. 69
+        shifts = np.concatenate([np.arange(-100, -45), np.arange(-6, 9)])
+    assert len(shifts) == K and len(np.unique(shifts)) == K
+    monkeypatch.setattr(sys.modules[__name__], "SHIFTS", shifts)
+    monkeypatch.setattr(sys.modules[__name__], "W_IE", 0.3 * rng.random(K) / K)
+    test_doubling_inelastic(vsm, arch, np.float64, "IQU", 13)
+    test_interaction_inelastic(vsm, arch, np.float64, "IQU", 13, False, "11")
 
 
 def _raman_models(vsm, arch, pol, l_trunc, S, L, FT, uniform=False, seed=11, m_max=2):
