@@ -147,7 +147,7 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
     exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
     e = _entry("C5", "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
                "20000 points); step = whole rt_run(RRS) incl. host optics, H2D, D2H" % (N, L, len(shifts), S), S, wall, dev, 3 * per_m, "f64",
-               "k_raman_doubling_quad<21> (+ k_raman_interaction_quad<21>)")
+               "k_raman_doubling_chain<21> (+ k_raman_interaction_quad<21>)")
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
     e["hbm_bytes_per_step"] = None   # whole-step HBM bytes from the newest committed PMC passes of the same workload

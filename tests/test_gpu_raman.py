@@ -243,7 +243,8 @@ def test_interaction_inelastic(vsm, arch, FT, pol, l_trunc, surface, iface):
 
 @pytest.mark.parametrize("l_trunc,N", [(3, 5), (5, 6), (9, 8), (11, 9), (13, 10), (19, 13), (21, 14), (27, 17), (33, 20), (37, 22)])
 def test_raman_quad_kernels_every_size(vsm, arch, l_trunc, N):
-    """vsm_raman_quad.hip (four Raman lines per wave on the 4 x 4 x 4 MFMA) owns FP64 3 <= N <= 22; the lists above hit N = 4, 7, 11, 12,
+    """vsm_raman_quad.hip (four Raman lines per wave on the 4 x 4 x 4 MFMA) owns FP64 3 <= N <= 22 -- the doubling of N = 20, 21, 22
+    runs all its steps in vsm_raman_chain.hip (two lines per wave, the state on chip); the lists above hit N = 4, 7, 11, 12,
     15, 16, 18, 19, 21.  The remaining sizes -- every N mod 4, the rider columns inside / outside the last block of real columns, odd and
     even N^2 (the late slot of the LDS-DMA images) -- through five doubling steps incl. the last one (apply_D on the way out) and
     the _11 interaction, partial last quads (K = 7 lines) included."""
@@ -255,7 +256,7 @@ def test_raman_quad_kernels_every_size(vsm, arch, l_trunc, N):
 
 @pytest.mark.parametrize("K", [9, 70])
 def test_raman_quad_kernels_line_lists(vsm, arch, monkeypatch, K):
-    """The line list of the quad kernels (ranks of the in-band lines of a recipient, four per wave) on irregular offsets: K = 9 leaves
+    """The line lists of the quad / chain kernels (ranks of the in-band lines of a recipient, four / two per wave) on irregular offsets: K = 9 leaves
     a last quad with one line, K = 70 crosses the 64-line ballot; offsets of both signs, one that is never in band, a zero offset;
     recipients near the band edges get partial lists.  Doubling steps and the _11 interaction against the oracle (N = 21)."""
     rng = np.random.default_rng(K)

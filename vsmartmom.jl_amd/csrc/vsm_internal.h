@@ -203,6 +203,13 @@ int raman_doubling_quad(int N, int S, int K, const int* shift, const double* r, 
                         const double* tmp1, const double* tmp2, const double* expk, double* ier, double* iet, double* ieJp,
                         double* ieJm, int ns_last, double* ier_pm, double* iet_mm, hipStream_t st);
 int raman_interaction_quad(int N, int S, int K, const int* shift, const rs_ia_pass<double>& h, hipStream_t st);
+// all doubling steps of the inelastic recurrences in one launch, the state of a line on chip (vsm_raman_chain.hip: FP64, 20 <= N <= 22); `stash`: the
+// elastic operands of every step (which: 0..5 = r, t, ttg, gt, gr, grt; 6..9 = jp, j1m, tmp1, tmp2; 10 = expk)
+bool raman_chain_supported(int N, int K);
+size_t raman_chain_stash_elems(int N, int S, int nd);
+double* raman_chain_stash_ptr(double* stash, int N, int S, int nd, int step, int which);
+int raman_doubling_chain(int N, int S, int K, int nd, const int* shift, double* stash, double* ier, double* iet, double* ieJp,
+                         double* ieJm, int ns, double* ier_pm, double* iet_mm, hipStream_t st);
 template <typename T>
 int raman_doubling_lines(int N, int S, int K, const int* shift, const T* r, const T* t, const T* ttg, const T* gt, const T* gr,
                          const T* grt, const T* jp, const T* j1m, const T* tmp1, const T* tmp2, const T* expk, T* ier, T* iet,

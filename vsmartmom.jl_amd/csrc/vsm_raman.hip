@@ -410,6 +410,39 @@ static int doubling_inelastic_rrs(int N, int ns, int S, int ndoubl, T* expk, con
   const dim3 gv((unsigned)((pv + 255) / 256));
   static const bool sepD = ab_switch("VSM_RAMAN_SEPARATE_APPLY_D");
   bool ie_D_done = false;   // apply_D! of the inelastic operators done by the last step's line kernel
+  // FP64, 20 <= N <= 22: the elastic chain of ALL steps first (every step's operands kept in library scratch: 9 x 6 N^2 S numbers on
+  // the C5 shape), then ONE launch that walks the steps with the inelastic state of its lines on chip (k_raman_doubling_chain)
+  if constexpr (std::is_same<T, double>::value) {
+    if (raman_chain_supported(N, K) && !sepD && N <= fused_max_n<T>()) {
+      T* stash = static_cast<T*>(scratch(raman_chain_stash_elems(N, S, ndoubl) * sizeof(T), 4, st));
+      auto sp = [&](int step, int which) { return raman_chain_stash_ptr(stash, N, S, ndoubl, step, which); };
+      bool chained = stash != nullptr;   // (no room for the steps' operands: the step kernels below need none)
+      if (!chained) (void)hipGetLastError();
+      for (int n = 0; chained && n < ndoubl; ++n) {
+        rc = raman_elastic_pre<T>(N, S, a.r_mp, a.t_pp, a.j0_p, a.j0_m, expk, sp(n, 2), sp(n, 3), sp(n, 4), sp(n, 5), j1p, sp(n, 7), u,
+                                  u2, sp(n, 8), sp(n, 9), st);
+        if (rc == VSM_ERR_UNSUPPORTED && n == 0) {   // (an A/B build without the LDS-resident elastic kernels: nothing touched yet)
+          chained = false;
+          break;
+        }
+        if (rc) return rc;
+        VSM_HIP(hipMemcpyAsync(sp(n, 0), a.r_mp, sizeof(T) * per, hipMemcpyDeviceToDevice, st));
+        VSM_HIP(hipMemcpyAsync(sp(n, 1), a.t_pp, sizeof(T) * per, hipMemcpyDeviceToDevice, st));
+        VSM_HIP(hipMemcpyAsync(sp(n, 6), a.j0_p, sizeof(T) * pv, hipMemcpyDeviceToDevice, st));
+        VSM_HIP(hipMemcpyAsync(sp(n, 10), expk, sizeof(T) * S, hipMemcpyDeviceToDevice, st));
+        if ((rc = raman_elastic_post<T>(N, S, a.r_mp, a.t_pp, sp(n, 2), u, u2, j1p, a.j0_p, a.j0_m, expk, st))) return rc;
+      }
+      if (chained) {
+        if ((rc = raman_doubling_chain(N, S, K, ndoubl, shift, stash, ie.ier_mp, ie.iet_pp, ie.ieJ0_p, ie.ieJ0_m, ns, ie.ier_pm,
+                                       ie.iet_mm, st)))
+          return rc;
+        const dim3 gm2((unsigned)((NN + 255) / 256), S);
+        hipLaunchKernelGGL(k_apply_D_batch<T>, gm2, dim3(256), 0, st, N, ns, a.r_mp, a.t_pp, a.r_pm, a.t_mm, a.j0_m);
+        VSM_LAUNCH_CHECK("k_apply_D_batch");
+        return VSM_OK;
+      }
+    }
+  }
   for (int n = 0; n < ndoubl; ++n) {
     // elastic operands of the step: one LDS-resident launch per point, else the operator chain
     rc = raman_elastic_pre<T>(N, S, a.r_mp, a.t_pp, a.j0_p, a.j0_m, expk, ttg, gt, gr, grt, j1p, j1m, u, u2, tmp1, tmp2, st);
