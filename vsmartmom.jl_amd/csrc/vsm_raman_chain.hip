@@ -14,11 +14,15 @@
 // lane = 16 q + 4 (2 line + half) + l), a wave walks two lines with 36 registers per matrix, fits 256 registers and 19 KB of LDS, and
 // two waves share a SIMD: one wave's loads are in flight under the other's products.
 //
-// Measured (C5 shape, N = 21, K = 40, 4000 points): 11.6 ms per layer launch of nine steps against 9 x 1.29 + 0.26 ms
-// of the step kernels -- the same speed (6.78 vs 6.72 k points/s; K = 100: 2.96 vs 2.91 k) -- while 22 + 3.5 GB cross the memory
-// system per layer-moment instead of 48.  The kernel is bound by the latency of the donor stream (SQ_WAIT_ANY 0.47 at 1.8 waves per
-// SIMD; 256 registers hold a prefetch distance of one k-step, deeper ones spill).  Where the two column halves of a line are poorly
-// filled it loses (N = 15: 8.1 k against 15.1 k points/s), so it takes N = 20 ... 22 only; the other sizes stay on the step kernels.
+// The two lines of a wave share their DONOR (workgroup = donor point x pair of line offsets; recipients np - shift[d]): both pairs of
+// lane groups stream the same donor blocks, so a step's donor operands are fetched once per wave (recipient-major pairs: once per
+// line; +4 % on the C5 shape).
+//
+// Measured (C5 shape, N = 21, K = 40, 4000 points): 7.06 k points/s against 6.72 k of the step kernels (K = 100: 3.09
+// against 2.91 k), while roughly half the bytes cross the memory system per layer-moment.  The kernel is bound by the latency of the
+// donor stream (SQ_WAIT_ANY 0.47 at 1.8 waves per SIMD; 256 registers hold a prefetch distance of one k-step, deeper ones spill).
+// Where the two column halves of a line are poorly filled it loses (N = 15: 8.1 k against 15.1 k points/s), so it takes N = 20 ... 22
+// only; the other sizes stay on the step kernels.
 //
 // Layout (see vsm_raman_quad.hip for the instruction's lane map):  B / D operand register (I, j) = element [4 I + q][4 (JH half + j) + l]
 // of the lane's line;  A operand register (I, K) = element [4 I + l][4 K + q] (both lane groups of a line hold the same values).
@@ -284,11 +288,13 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
   p.init(threadIdx.x);
   coff<N> o;
   o.init(p);
-  // workgroup -> (recipient, pair rank): XCD-aware, pair rank by pair rank (see k_raman_doubling_quad)
+  // workgroup -> (DONOR point, pair rank): XCD-aware, pair rank by pair rank (see k_raman_doubling_quad).  The two lines of a
+  // wave share their donor n0 = np (recipients np - shift[d]): both lane-group pairs stream the same donor blocks -- identical
+  // addresses within an instruction -- and the donor operands of a step are fetched once per wave instead of once per line.
   const int per = (S + 7) >> 3;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int pi = idx / per, n1 = xcd * per + (idx - pi * per);
-  if (n1 >= S) return;
+  const int pi = idx / per, np = xcd * per + (idx - pi * per);
+  if (np >= S) return;
   int dsel[2] = {-1, -1};
   int cnt = 0;
   {
@@ -297,8 +303,8 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
     for (int hh = 0; hh < 2; ++hh) {
       const int i = 64 * hh + p.lane;
       const int sh = (i < K) ? shift[i] : 0;
-      const int n0 = n1 + sh;
-      const bool inb = i < K && n0 >= 0 && n0 < S;
+      const int nr = np - sh;   // the recipient of line i whose donor is np
+      const bool inb = i < K && nr >= 0 && nr < S;
       const unsigned long long bal = __ballot(inb);
       const int rank = base + __popcll(bal & ((1ull << p.lane) - 1ull));
       base += __popcll(bal);
@@ -312,9 +318,9 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
   }
   if (pi == 0) {   // out-of-band lines keep zero D-mirrors (the operator-level apply_D! writes every block)
     for (int dz = 0; dz < K; ++dz) {
-      const int n0 = n1 + shift[dz];
+      const int n0 = np + shift[dz];   // (this chore is per RECIPIENT: the wave of pair rank 0 of point np does it for recipient np)
       if (n0 >= 0 && n0 < S) continue;
-      const long long oz = ((long long)n1 + (long long)S * dz) * NN;
+      const long long oz = ((long long)np + (long long)S * dz) * NN;
       for (int el = p.lane; el < NN; el += 64) {
         ier_pm[oz + el] = 0.0;
         iet_mm[oz + el] = 0.0;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
   if (2 * pi >= cnt) return;
   const bool valid = 2 * pi + p.line < cnt;
   const int dd = (valid && p.line == 1) ? dsel[1] : dsel[0];   // (a one-line last pair repeats its line; nothing of the copy is stored)
-  const int n0 = n1 + shift[dd];
+  const int n0 = np, n1 = np - shift[dd];   // the lane's line: donor np, recipient n1
   const long long o4 = ((long long)n1 + (long long)S * dd) * NN, o4v = ((long long)n1 + (long long)S * dd) * N;
   const long long e4_ = (long long)n0 * NN, e1_ = (long long)n0 * N, s4_ = (long long)n1 * NN;
   double* ierL = IER + p.line * FL;
