@@ -214,33 +214,41 @@ struct cb_mem {
     return x;
   }
 };
-// acc += A B with the fragments requested D k-steps ahead
-template <int D, int R, int C, typename FA, typename FB>
+// acc += A B with the left / right fragments requested DA / DB k-steps ahead.  (Measured on the C5 shape: distances 1 ... 3 for the
+// operands that stream from memory are within 2 % of each other -- 7.06 / 6.94 / 7.07 / 6.89 k points/s for (DB, DA) = (1, 1), (2, 1),
+// (2, 2), (3, 2) -- the second wave of the SIMD, not the distance, covers the stream; 1 / 1 has the fewest scratch reloads.)
+template <int DA, int DB, int R, int C, typename FA, typename FB>
 __device__ __forceinline__ void c_mm(cmat<R, C>& acc, const FA& fa, const FB& fb) {
-  static_assert(D >= 1, "depth");
-  double a[D + 1][R], bb[D + 1][C];
+  static_assert(DA >= 1 && DB >= 1, "depth");
+  double a[DA + 1][R], bb[DB + 1][C];
 #pragma unroll
-  for (int d = 0; d < D; ++d)
+  for (int d = 0; d < DA; ++d)
     if (d < R) {
 #pragma unroll
       for (int i = 0; i < R; ++i) a[d][i] = fa(i, d);
+    }
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+    if (d < R) {
 #pragma unroll
       for (int j = 0; j < C; ++j) bb[d][j] = fb(d, j);
     }
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    if (k + D < R) {
+    if (k + DB < R) {
 #pragma unroll
-      for (int i = 0; i < R; ++i) a[(k + D) % (D + 1)][i] = fa(i, k + D);
+      for (int j = 0; j < C; ++j) bb[(k + DB) % (DB + 1)][j] = fb(k + DB, j);
+    }
+    if (k + DA < R) {
 #pragma unroll
-      for (int j = 0; j < C; ++j) bb[(k + D) % (D + 1)][j] = fb(k + D, j);
+      for (int i = 0; i < R; ++i) a[(k + DA) % (DA + 1)][i] = fa(i, k + DA);
     }
 #pragma unroll
     for (int i = 0; i < R; ++i)
 #pragma unroll
       for (int j = 0; j < C; ++j)
-        acc.v[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k % (D + 1)][i], bb[k % (D + 1)][j], acc.v[i][j], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);   // (keep the written order: fragments of step k + D requested, then the MFMAs of step k --
+        acc.v[i][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[k % (DA + 1)][i], bb[k % (DB + 1)][j], acc.v[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // (keep the written order: fragments of the steps ahead requested, then the MFMAs of step k --
                                          //  left alone the scheduler hoists every load of a product to its top and the wave spills)
   }
 }
@@ -272,7 +280,10 @@ struct rc_steps {
 };
 
 #ifndef RC_DEPTH
-#define RC_DEPTH 2
+#define RC_DEPTH 1
+#endif
+#ifndef RC_DEPTH_A
+#define RC_DEPTH_A 1
 #endif
 
 template <int N>
@@ -280,7 +291,8 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
                                                                 double* ier, double* iet, double* ieJp, double* ieJm, int ns,
                                                                 double* ier_pm, double* iet_mm) {
   using Q = ccfg<N>;
-  constexpr int RB = Q::RB, JH = Q::JH, NN = N * N, cA = Q::cA, cB = Q::cB, FL = Q::FL, D = RC_DEPTH;
+  constexpr int RB = Q::RB, JH = Q::JH, NN = N * N, cA = Q::cA, cB = Q::cB, FL = Q::FL;
+  constexpr int DG = RC_DEPTH, DGA = RC_DEPTH_A;   // prefetch distance (k-steps) of right / left operands that stream from memory
   __shared__ double IER[2 * FL];
   __shared__ double IET[2 * FL];
   __shared__ double VJ[2][2][4 * RB];   // iej0+, iej0- of the two lines
@@ -374,10 +386,10 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
       c_load_v<N>(v1, e.j1m + s * e.sv + e1, p);
       c_load_v<N>(v2, e.jp + s * e.sv + e1, p);
       c_zero(X);
-      c_mm<D>(X, ca_mem<N>{ierL, o}, cb_mem<N, 2>{r_s + e4, o, &v1, &v2});
+      c_mm<1, DG>(X, ca_mem<N>{ierL, o}, cb_mem<N, 2>{r_s + e4, o, &v1, &v2});
     }
     c_read_b<N, 0>(WA, cb_mem<N, 0>{ierL, o, nullptr, nullptr});   // WA <- ier (rider columns zero): the accumulator of WA = ier + X gr0
-    c_mm<D>(X, ca_mem<N>{r_s + s4, o}, cb_reg<RB, JH>{WA});
+    c_mm<DGA, 1>(X, ca_mem<N>{r_s + s4, o}, cb_reg<RB, JH>{WA});
     c_read_b<N, 0>(W1, cb_mem<N, 0>{ietL, o, nullptr, nullptr});   // W1 <- iet: the accumulator of W1 = iet + X gt0
     auto vj_read = [&](cvecr<RB>& a, const double* tab) {   // (the source vectors are re-read from their table where they are used)
 #pragma unroll
@@ -400,9 +412,9 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
     {
       cvecr<RB> vt;
       c_load_v<N>(vt, e.tmp2 + s * e.sv + e1, p);
-      c_mm<D>(WA, ca_tr<RB, JH>{X, p}, cb_mem<N, 1>{e.gr + s * e.sm + e4, o, &vt, nullptr});   // WA = ier + X gr0 ; [:, cA] += X tmp2
+      c_mm<1, DG>(WA, ca_tr<RB, JH>{X, p}, cb_mem<N, 1>{e.gr + s * e.sm + e4, o, &vt, nullptr});   // WA = ier + X gr0 ; [:, cA] += X tmp2
       c_load_v<N>(vt, e.tmp1 + s * e.sv + e1, p);
-      c_mm<D>(W1, ca_tr<RB, JH>{X, p}, cb_mem<N, 1>{e.gt + s * e.sm + e4, o, &vt, nullptr});   // W1 = iet + X gt0 ; [:, cA] += X tmp1
+      c_mm<1, DG>(W1, ca_tr<RB, JH>{X, p}, cb_mem<N, 1>{e.gt + s * e.sm + e4, o, &vt, nullptr});   // W1 = iet + X gt0 ; [:, cA] += X tmp1
     }
     // ---- R1IET = r1 [iet | iej1- | iej0+]
     cmat<RB, JH> W3;
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
 #pragma unroll
       for (int i = 0; i < RB; ++i) j1.x[i] *= e0;
       c_zero(W3);
-      c_mm<D>(W3, ca_mem<N>{r_s + s4, o}, cb_mem<N, 2>{ietL, o, &j1, &cJp});
+      c_mm<DGA, 1>(W3, ca_mem<N>{r_s + s4, o}, cb_mem<N, 2>{ietL, o, &j1, &cJp});
     }
     cvecr<RB> a4;
     {
@@ -428,20 +440,20 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
     }
     // ---- W3 = WA t0 + r1 iet, column cA = a4
     {
-      c_mm<D>(W3, ca_tr<RB, JH>{WA, p}, cb_mem<N, 0>{e.t + s * e.sm + e4, o, nullptr, nullptr});
+      c_mm<1, DG>(W3, ca_tr<RB, JH>{WA, p}, cb_mem<N, 0>{e.t + s * e.sm + e4, o, nullptr, nullptr});
       c_set_col<cA>(W3, a4, p);
     }
     // ---- iet' = ttg1 W1 + iet gt0 ;  ier' = ier + iet grt0 + ttg1 W3   (columns cA: ttg1 a3 + iet tmp1, ttg1 a4 + iet tmp2)
     c_zero(O1);
-    c_mm<D>(O1, ca_mem<N>{ttg_s + s4, o}, cb_reg<RB, JH>{W1});
+    c_mm<DGA, 1>(O1, ca_mem<N>{ttg_s + s4, o}, cb_reg<RB, JH>{W1});
     c_read_b<N, 0>(O2, cb_mem<N, 0>{ierL, o, nullptr, nullptr});
-    c_mm<D>(O2, ca_mem<N>{ttg_s + s4, o}, cb_reg<RB, JH>{W3});
+    c_mm<DGA, 1>(O2, ca_mem<N>{ttg_s + s4, o}, cb_reg<RB, JH>{W3});
     {
       cvecr<RB> vt;
       c_load_v<N>(vt, e.tmp1 + s * e.sv + e1, p);
-      c_mm<D>(O1, ca_mem<N>{ietL, o}, cb_mem<N, 1>{e.gt + s * e.sm + e4, o, &vt, nullptr});
+      c_mm<1, DG>(O1, ca_mem<N>{ietL, o}, cb_mem<N, 1>{e.gt + s * e.sm + e4, o, &vt, nullptr});
       c_load_v<N>(vt, e.tmp2 + s * e.sv + e1, p);
-      c_mm<D>(O2, ca_mem<N>{ietL, o}, cb_mem<N, 1>{e.grt + s * e.sm + e4, o, &vt, nullptr});
+      c_mm<1, DG>(O2, ca_mem<N>{ietL, o}, cb_mem<N, 1>{e.grt + s * e.sm + e4, o, &vt, nullptr});
     }
     // ---- the new state: ieJ0+' = iej0+ expk0 + O1[:, cA] ;  ieJ0-' = iej0- + O2[:, cA] ;  iet' = O1, ier' = O2
     {
