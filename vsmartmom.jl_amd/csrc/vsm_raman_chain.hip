@@ -300,12 +300,16 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
   p.init(threadIdx.x);
   coff<N> o;
   o.init(p);
-  // workgroup -> (DONOR point, pair rank): XCD-aware, pair rank by pair rank (see k_raman_doubling_quad).  The two lines of a
-  // wave share their donor n0 = np (recipients np - shift[d]): both lane-group pairs stream the same donor blocks -- identical
-  // addresses within an instruction -- and the donor operands of a step are fetched once per wave instead of once per line.
+  // workgroup -> (DONOR point, pair rank).  The two lines of a wave share their donor n0 = np (recipients np - shift[d]): both
+  // lane-group pairs stream the same donor blocks -- identical addresses within an instruction -- so a step's donor operands are
+  // fetched once per wave instead of once per line.  XCD-aware and DONOR-major (the pair rank runs fastest): XCD x owns a contiguous
+  // eighth of the points, and the ~ 256 waves in flight on it are ALL pair ranks of a dozen neighbouring donors walking the steps
+  // together -- a donor's operands of a step come into that L2 once and are hit by the other waves of the donor (pair rank by pair rank
+  // every wave fetched them itself: 12 of the 21 GB a layer-moment moved).
+  const int NP = (K + 1) >> 1;
   const int per = (S + 7) >> 3;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int pi = idx / per, np = xcd * per + (idx - pi * per);
+  const int pi = idx % NP, np = xcd * per + idx / NP;
   if (np >= S) return;
   int dsel[2] = {-1, -1};
   int cnt = 0;
