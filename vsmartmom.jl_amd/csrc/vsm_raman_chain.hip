@@ -18,11 +18,11 @@
 // lane groups stream the same donor blocks, so a step's donor operands are fetched once per wave (recipient-major pairs: once per
 // line; +4 % on the C5 shape).
 //
-// Measured (C5 shape, N = 21, K = 40, 4000 points): 7.06 k points/s against 6.72 k of the step kernels (K = 100: 3.09
-// against 2.91 k), while roughly half the bytes cross the memory system per layer-moment.  The kernel is bound by the latency of the
-// donor stream (SQ_WAIT_ANY 0.47 at 1.8 waves per SIMD; 256 registers hold a prefetch distance of one k-step, deeper ones spill).
-// Where the two column halves of a line are poorly filled it loses (N = 15: 8.1 k against 15.1 k points/s), so it takes N = 20 ... 22
-// only; the other sizes stay on the step kernels.
+// Measured (C5 shape, N = 21, K = 40, 4000 points): 9.65 ms per layer-moment of nine steps against 11.9 ms of the
+// step kernels, 13 + 3 GB through the memory system against 48: 7.7 k points/s against 6.7 k (K = 100: 3.38 against 2.91 k); MFMA
+// pipe 0.52 busy, SQ_WAIT_ANY 0.35 at 1.8 waves per SIMD (256 registers hold a prefetch distance of one k-step, deeper ones spill).
+// Where the two column halves of a line are poorly filled it loses (N = 15: 8.1 k against 15.1 k points/s with the first version),
+// so it takes N = 20 ... 22 only; the other sizes stay on the step kernels.
 //
 // Layout (see vsm_raman_quad.hip for the instruction's lane map):  B / D operand register (I, j) = element [4 I + q][4 (JH half + j) + l]
 // of the lane's line;  A operand register (I, K) = element [4 I + l][4 K + q] (both lane groups of a line hold the same values).
