@@ -374,7 +374,7 @@ def bench_c5(args, vsm, parallel, torch, rank, world, local):
                        "timed_step": "whole rt_run(RRS) per rank (host optics, H2D, device pass) + one gather per output + D2H",
                        "ranks": world, "multi_gpu": mg, "timed_region_s": dt, "algorithmic_gflop_per_point": 3 * per_m / 1e9,
                        "in_band_lines_per_point": kin},
-            "roofline": {"bound": "mfma", "kernel": "whole run (k_raman_doubling_wave_sp<21> ~72 %, k_raman_interaction_wave<21> ~16 %)",
+            "roofline": {"bound": "mfma", "kernel": "whole run (k_raman_doubling_chain<21> ~67 %, k_raman_interaction_quad<21> ~17 %)",
                          "achieved": tf, "peak": PEAK_TFLOPS["f64"] * world, "unit": "TFLOP/s", "frac": tf / (PEAK_TFLOPS["f64"] * world),
                          "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world),
                          "traffic": c5_traffic_per_point() and c5_traffic_per_point() * S_total,
