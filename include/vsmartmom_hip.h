@@ -560,6 +560,42 @@ int vsm_mix_Z_f64(int N, int S, int ncomp, const double* Zpp_comp, const double*
 int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Zmp_comp, const float* fcomp, float* Zpp,
                   float* Zmp, void* stream);
 
+/* ---- a run with the CompositeLayer in kernel-native layout (FP64) -------------
+ * The layer loop of rt_run (src/CoreRT/rt_run.jl:383-453: `for iz = 1:Nz ... rt_kernel!(RS_type, pol_type, SFI, added_layer,
+ * composite_layer, ...)`) reads and writes the CompositeLayer (make_composite_layer, tools/rt_helper_functions.jl:259-270;
+ * allocated once per run, rt_run.jl:326-335) in every layer step, and nothing else touches it until the surface interaction
+ * (rt_run.jl:455-470).  A vsm_run is that CompositeLayer for nm Fourier moments of S points, kept in the layer kernels' own
+ * strip layout for the whole loop:
+ *   vsm_run_create   = make_composite_layer (the storage is the caller's `workspace`: vsm_run_workspace_bytes bytes, 16-byte
+ *                      aligned device memory that must outlive the run; q->mu / q->wt must outlive it too)
+ *   vsm_run_layer    = rt_kernel!(::noRS) for ONE scattering layer and all nm moments (rt_kernel.jl:175-250: elemental! +
+ *                      doubling! + interaction!(::ScatteringInterface_11), or copy_added_to_composite! when toa != 0); arguments as
+ *                      vsm_layer_forward_multi_f64 (Zpp[nm] / Zmp[nm]: host arrays of device pointers, ncomp <= 4)
+ *   vsm_run_export   = the composite as the reference's arrays (comps[nm]: one CompositeLayer per moment), for the surface
+ *                      step and postprocessing_vza!; vsm_run_import is the inverse (a run that continues from existing arrays)
+ *   vsm_run_destroy  frees the host-side handle only.
+ * Stokes blocks.  `coupling[nm]` (NULL or -1 per moment = dense) tells per moment which Stokes components the phase matrices
+ * couple: bit 4 a + b set = some element Z[i, j] with i % n_stokes == a, j % n_stokes == b is non-zero.  Components that do not
+ * couple run as independent sub-problems (for m = 0 every phase matrix has exactly zero (I,Q) x (U,V) blocks,
+ * src/Scattering/compute_Z_matrices.jl:26-110: N = 60, n_stokes = 3 runs as 40 x 40 + 20 x 20) -- products with exact zeros are
+ * not formed, results are those of the dense run.  The mask MUST cover every Z later handed to vsm_run_layer:
+ * vsm_stokes_coupling_f64 computes it on the device over a stack of `nblocks` matrices (mask_d: one DEVICE int, written
+ * asynchronously on `stream`); OR the masks of all scatterers of a moment.  Every block of coupled components must fit the native
+ * kernels: (N / n_stokes) * (components in the block) <= 60 (vsm_run_supported_f64 != 0), else VSM_ERR_UNSUPPORTED.
+ * Stream: see Conventions; library scratch (the pre-pass images of the layer). */
+typedef struct vsm_run vsm_run;
+int vsm_run_supported_f64(int N, int n_stokes, int coupling);
+size_t vsm_run_workspace_bytes_f64(int N, int n_stokes, int S, int nm, const int* coupling_h);
+int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m_h, const int* coupling_h, void* workspace,
+                       size_t workspace_bytes, vsm_run** run);
+int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum,
+                      const double* F0, int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride,
+                      const double* fcomp, int toa, void* stream);
+int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
+int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
+int vsm_run_destroy(vsm_run* run);
+int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream);
+
 /* ---- rotational Raman scattering (RRS), operator level ---------------------
  * Inelastic layer state (src/CoreRT/types.jl:278-335 AddedLayerRS / CompositeLayerRS): 4-D arrays
  * [N,N,S,K] / [N,1,S,K], K = number of Raman offsets (length of RS_type.i_lambda1lambda0); element

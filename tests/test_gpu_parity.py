@@ -1035,13 +1035,13 @@ def test_moment_batched_run_equals_moment_by_moment(vsm, arch, monkeypatch, pol,
     B = 0.05 + 0.02 * rng.random((L, S))
     model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 0.0], [0.0, 75.0],
                                 sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **kw)
-    monkeypatch.delenv("VSM_NO_MOMENT_BATCH", raising=False)
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", True)
     N = model.quad_points.Nquad * model.polarization_type.n
     assert N == {("IQU", 33): 60, ("IQUV", 41): 96, ("I", 9): 8}[(pol, l_trunc)]
     out_b = vsm.CoreRT.rt_run(model, full_output=True)
-    monkeypatch.setenv("VSM_NO_MOMENT_BATCH", "1")
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", False)
     out_s = vsm.CoreRT.rt_run(model, full_output=True)
-    monkeypatch.delenv("VSM_NO_MOMENT_BATCH", raising=False)
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", True)
     for a, b in zip(out_b, out_s):
         assert np.array_equal(a, b)
     assert np.max(np.abs(out_b[0])) > 0

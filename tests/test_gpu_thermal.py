@@ -129,11 +129,11 @@ def test_thermal_slot_fused_equals_operator_level(vsm, arch, monkeypatch, FT, ge
         # slot in the AddedLayer and takes no fused step -- test_thermal_slot_state_in_nonscattering_layers)
         model = H.model_from_arrays(arch, *geo, sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B, reset_slot_in_nonscattering_layers=True)),
                                     **com)
-        monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
+        monkeypatch.setattr(vsm.CoreRT, "THERMAL_FUSION", True)
         Rf, Tf = vsm.CoreRT.rt_run(model)
-        monkeypatch.setenv("VSM_NO_THERMAL_FUSION", "1")
+        monkeypatch.setattr(vsm.CoreRT, "THERMAL_FUSION", False)
         Ro, To = vsm.CoreRT.rt_run(model)
-        monkeypatch.delenv("VSM_NO_THERMAL_FUSION", raising=False)
+        monkeypatch.setattr(vsm.CoreRT, "THERMAL_FUSION", True)
         Rs, Ts = vsm.CoreRT.rt_run(H.model_from_arrays(arch, *geo, **com))
         assert np.max(np.abs(Ro - Rs)) > 1e-4                      # the slot contributes
         assert _rel(Rf - Rs, Ro - Rs) < tol and _rel(Tf - Ts, To - Ts) < tol

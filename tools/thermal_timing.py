@@ -40,7 +40,7 @@ def main():
     both = vsm.CoreRT.prepare_scene(H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0],
                                                         sources=(H.SolarBeam(), H.ThermalEmission(B_layer=B)), **kw))
     t_f = timed(lambda: both.run())
-    os.environ["VSM_NO_THERMAL_FUSION"] = "1"
+    vsm.CoreRT.THERMAL_FUSION = False
     t_o = timed(lambda: both.run())
     print("N=60 S=%d L=%d: solar only %.3f s (%.0f points/s); + thermal slot fused %.3f s (%.0f points/s, x%.2f); + thermal slot "
           "operator level %.3f s (%.0f points/s, x%.2f)" % (S, L, t_s, S / t_s, t_f, S / t_f, t_f / t_s, t_o, S / t_o, t_o / t_s))

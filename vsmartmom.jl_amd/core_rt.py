@@ -35,6 +35,10 @@ from .architectures import GPU, CPU, architecture, array_type, devi, synchronize
 IFACE = {"00": 0, "01": 1, "10": 2, "11": 3}
 MOMENT_BATCH = 4      # Fourier moments per layer-step call of Scene.run for large batches (each moment needs a CompositeLayer)
 MOMENT_BATCH_MAX = 24  # ... for small spectral batches: every moment of the run in one launch (VSM_MM_MAX of the library)
+# A/B switches of the host path (module attributes, set by tests and tools; never read from the environment):
+MOMENT_BATCHING = True  # False: Scene.run walks the Fourier moments one by one
+THERMAL_FUSION = True   # False: the `:thermal` slot at operator level (tools/thermal_timing.py)
+NATIVE_RUN = True       # False: the layer loop on the reference-layout CompositeLayer (vsm_layer_forward_multi) instead of vsm_run_*
 
 
 def _require_gpu(arch):
@@ -645,6 +649,7 @@ class Scene:
             Zpp, Zmp = self.Zc[m]
             for k, (gd, lmax) in enumerate(self.greek_dev):
                 _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, lmax, _ptr(gd), _ptr(Zpp[k]), _ptr(Zmp[k]), _stream_ptr())
+        self._compute_coupling()
         mx = self.max_tw.cpu().numpy()          # the ONE device -> host hand-off of the optics pass (Nz scalars)
         nds, tags, tag = [], [], "00"
         for iz in range(L):
@@ -724,7 +729,22 @@ class Scene:
                     self.fcomp[iz].copy_(conv(np.ascontiguousarray(lo.coef.astype(FT))))
             self.tau_sum[L].copy_(conv(tau_sum_all[:, -1].astype(FT)))
             self.zcomp = zcomp
+        self._compute_coupling()
         self._assemble(nds, tags, maxima)
+
+    def _compute_coupling(self):
+        """Which Stokes components the phase matrices of each Fourier moment couple (vsm_stokes_coupling over the stack of ALL
+        scatterers of the moment): components that do not couple walk the layers as independent sub-problems (vsm_run_*; for
+        m = 0 the (I,Q) x (U,V) blocks of every phase matrix are exactly zero, compute_Z_matrices.jl:26-110)."""
+        self.coupling = None
+        if self.dt != torch.float64:
+            return
+        if getattr(self, "_coupling_d", None) is None:
+            self._coupling_d = torch.zeros(len(self.Zc), dtype=torch.int32, device=self.dev)
+        for m, (Zpp, Zmp) in enumerate(self.Zc):
+            _lib.check(_lib.lib().vsm_stokes_coupling_f64(self.N, self.pol.n, int(Zpp.shape[0]), _ptr(Zpp), _ptr(Zmp),
+                                                          C.c_void_p(self._coupling_d[m:].data_ptr()), _stream_ptr()))
+        self.coupling = [int(v) for v in self._coupling_d.cpu().numpy()]
 
     def run(self, trace: Optional[list] = None, streams: Optional[list] = None):
         """The device-resident part of rt_run (rt_run.jl:383-517): Fourier loop -> layer loop ->
@@ -745,22 +765,28 @@ class Scene:
         # zero_added_noscat! never writes it, rt_helpers.jl:174-180 -- which ties the moments to their sequential order)
         eps2 = 2 * np.finfo(FT).eps
         has_noscat = any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"])
-        sequential = trace is not None or os.environ.get("VSM_NO_MOMENT_BATCH") is not None or has_noscat
+        sequential = trace is not None or not MOMENT_BATCHING or has_noscat
         # small batches are launch-latency bound (C3: 2 points, 22 moments x 33 layers): as many moments per launch as fill the chip
         want = max(MOMENT_BATCH, min(MOMENT_BATCH_MAX, 4096 // max(self.S, 1)))
         nb = 1 if sequential else min(want, len(self.moments))
         while len(self._composites) < nb:
             self._composites.append(make_composite_layer(FT, self.arch, (self.N, self.N), self.S))
+        native = self._native_moments() if trace is None and not has_noscat else set()
         for g0 in range(0, len(self.moments), nb):
             group = self.moments[g0:g0 + nb]
             comps = self._composites[:len(group)]
-            for iz in range(self.Nz):
-                ly0 = group[0]["layers"][iz]
-                if len(group) > 1 and ly0["props"].max_tau_varpi > eps2 and (iz == 0 or ly0["iface"] == "11"):
-                    layer_forward_multi_(ly0["tau_sum"], ly0["dtau"], self.F0, [mom["layers"][iz]["props"] for mom in group],
-                                         [mom["m"] for mom in group], ly0["nd"], self.dq, iz == 0, comps, self.added)
+            nat = [k for k in range(len(group)) if (g0 + k) in native]
+            if nat:   # the layer loop on the native-layout composite (vsm_run_*), then the reference's arrays for the surface step
+                self._run_layers_native([group[k] for k in nat], [comps[k] for k in nat])
+            rest = [k for k in range(len(group)) if (g0 + k) not in native]
+            group_l, comps_l = [group[k] for k in rest], [comps[k] for k in rest]
+            for iz in range(self.Nz if rest else 0):
+                ly0 = group_l[0]["layers"][iz]
+                if len(group_l) > 1 and ly0["props"].max_tau_varpi > eps2 and (iz == 0 or ly0["iface"] == "11"):
+                    layer_forward_multi_(ly0["tau_sum"], ly0["dtau"], self.F0, [mom["layers"][iz]["props"] for mom in group_l],
+                                         [mom["m"] for mom in group_l], ly0["nd"], self.dq, iz == 0, comps_l, self.added)
                     continue
-                for mom, comp in zip(group, comps):
+                for mom, comp in zip(group_l, comps_l):
                     ly = mom["layers"][iz]
                     rt_kernel_(pol, self.added, comp, ly["props"], ly["iface"], ly["tau_sum"], mom["m"], self.dq,
                                self.arch, iz + 1, self.F0, FT, model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"], trace=trace,
@@ -787,6 +813,51 @@ class Scene:
             apply_ss_correction_(self.R_SFI, model.surface, pol, model.vza, model.vaz, self.qp.mu0,
                                  self.moments[-1]["tau_sum_surface"], model.m_max, self.arch, FT)
         return self.R_SFI, self.T_SFI
+
+    def _native_moments(self):
+        """Indices of the Fourier moments whose layer loop runs on the native-layout composite (vsm_run_*): FP64, every layer
+        scattering with the 11 interface (the only steps the run object takes), at most four scatterers per layer, and every
+        block of coupled Stokes components within the native kernels' size."""
+        if not NATIVE_RUN or self.dt != torch.float64 or getattr(self, "coupling", None) is None or not self.moments:
+            return set()
+        eps2 = 2 * np.finfo(self.FT).eps
+        for iz, ly in enumerate(self.moments[0]["layers"]):
+            p = ly["props"]
+            if p.max_tau_varpi <= eps2 or (iz > 0 and ly["iface"] != "11") or (p.fcomp is not None and p.fcomp.shape[1] > 4):
+                return set()
+        L = _lib.lib()
+        return {i for i, mom in enumerate(self.moments)
+                if L.vsm_run_supported_f64(self.N, self.pol.n, int(self.coupling[mom["m"]])) != 0}
+
+    def _run_layers_native(self, group, comps):
+        """rt_run's layer loop (rt_run.jl:383-453) for the moments of `group` with the CompositeLayer in kernel-native layout:
+        vsm_run_create -> Nz x vsm_run_layer -> vsm_run_export into the reference-layout CompositeLayers `comps`."""
+        L = _lib.lib()
+        nm, N, S, ns = len(group), self.N, self.S, self.pol.n
+        marr = (C.c_int * nm)(*[int(mom["m"]) for mom in group])
+        carr = (C.c_int * nm)(*[int(self.coupling[mom["m"]]) for mom in group])
+        nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, nm, carr))
+        ws = getattr(self, "_native_ws", None)
+        if ws is None or ws.numel() * 8 < nbytes:
+            ws = self._native_ws = _lib.poison(torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=self.dev))
+        q = self.dq.cstruct()
+        run = C.c_void_p()
+        _lib.check(L.vsm_run_create_f64(C.byref(q), S, nm, marr, carr, _ptr(ws), nbytes, C.byref(run)))
+        try:
+            for iz in range(self.Nz):
+                ly0 = group[0]["layers"][iz]
+                props = [mom["layers"][iz]["props"] for mom in group]
+                p0 = props[0]
+                zpp = (C.c_void_p * nm)(*[p.Zpp.data_ptr() for p in props])
+                zmp = (C.c_void_p * nm)(*[p.Zmp.data_ptr() for p in props])
+                ncomp = 0 if p0.fcomp is None else int(p0.fcomp.shape[1])
+                _lib.check(L.vsm_run_layer_f64(run, int(ly0["nd"]), _ptr(ly0["dtau"]), _ptr(p0.varpi), _ptr(ly0["tau_sum"]),
+                                               _ptr(self.F0), ncomp, zpp, zmp, 0 if ncomp else p0.z_stride, _ptr(p0.fcomp),
+                                               1 if iz == 0 else 0, _stream_ptr()))
+            cc = (type(comps[0].cstruct()) * nm)(*[c.cstruct() for c in comps])
+            _lib.check(L.vsm_run_export_f64(run, cc, _stream_ptr()))
+        finally:
+            L.vsm_run_destroy(run)
 
     def _thermal_slot(self, mom, weight):
         """The `:thermal` per-source slot (rt_kernel.jl:204-232, doubling.jl:62-81, interaction.jl per-source recurrences,
@@ -822,7 +893,7 @@ class Scene:
         # with the thermal source and expk = 1; m = 0); everything else operator level, layer by layer on the same composite.  With
         # the reference's slot state and a non-scattering layer in the column the doubled slot must stay in the AddedLayer for the
         # layers below: no fused step then (as in the solar pass, rt_kernel_'s keep_added)
-        fused = (os.environ.get("VSM_NO_THERMAL_FUSION") is None and m == 0 and (all(scat) or not keep_state)
+        fused = (THERMAL_FUSION and m == 0 and (all(scat) or not keep_state)
                  and _lib.lib().vsm_layer_thermal_fused(N, 1 if FT == np.float64 else 0) != 0)
         for iz, ly in enumerate(mom["layers"]):
             props = ly["props"]

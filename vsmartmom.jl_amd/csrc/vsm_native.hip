@@ -1,0 +1,907 @@
+// Native-layout layer kernels (FP64, sub-problems of n <= 60 rows): rt_kernel!'s scattering branch (rt_kernel.jl:175-250:
+// elemental! -> doubling! -> interaction!(::ScatteringInterface_11) | TOA copy) for a whole run with
+//   (1) the CompositeLayer kept in the kernels' own strip layout between the layer steps (vsm_run_*: the composite is converted
+//       to the reference's [N,N,S] arrays ONCE, when the surface step needs it, rt_run.jl:455-517) -- no transposer tiles, no
+//       A-form staging arithmetic, every composite matrix moves as 16-byte coalesced records;
+//   (2) Stokes blocks that do not couple run as independent sub-problems: for the Fourier moment m = 0 the phase matrices have
+//       exactly zero (I,Q) x (U,V) blocks (compute_Z_matrices.jl:26-110: the functions T_l^m carry a factor m), so r, t and every
+//       product of the doubling / adding recurrences are block diagonal after a row permutation -- a run with n_stokes = 3 and
+//       N = 60 walks a 40 x 40 and a 20 x 20 problem instead of one 60 x 60 one (products with exact zeros are not formed;
+//       results identical);
+//   (3) RT = ceil((n + 2) / 16) = 1..4 row tiles as a template parameter: RT waves per workgroup, as many workgroups per CU as
+//       give three to four waves per SIMD below four row tiles -- the same code serves every n <= 60.
+// Doubling step: rt_helpers.jl:102-166 in the [E | W] = r [r | t] form of vsm_strip.hip; interaction: interaction.jl:207-266 with
+// ONE inverse (push-through identities, vsm_strip.hip) and the product phases ordered so that at most six strips are live.
+#include <stdlib.h>
+
+#include <vector>
+
+#include "vsm_native_dev.h"
+
+namespace vsm {
+
+constexpr int NSUB_MAX = VSM_MM_MAX;   // sub-problems per launch (gridDim.y)
+struct nlayer_comps {
+  double* c[NSUB_MAX];
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// elemental (from the pre-pass images) + ndoubl x doubling step + apply_D
+// ---------------------------------------------------------------------------------------------------------------------------
+// On return (all waves past a barrier): r_s = strip of the final r-+ (row signs of apply_D applied), t_s = strip of t++ (rider
+// columns cleared), sm.vec[0] = j0+, sm.vec[1] = j0- (final sign), sm.usg filled.
+template <int RT, int KS>
+__device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int gsz, unsigned uvmask, int ndoubl,
+                                         const double* __restrict__ img, nstrip<RT>& r_s, nstrip<RT>& t_s, int* status) {
+  using G = ngeo<RT>;
+  constexpr unsigned dP = 0, dQ = G::AF * 8;
+  double* jp = sm.vec[0];
+  double* jm = sm.vec[1];
+  double* rsg = sm.vec[3];   // row sign of apply_D
+  const int tid = threadIdx.x;
+  constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;   // spare columns (>= n, never read as k) carry j0+ / j1- through a step
+  static_assert(c2 < G::NP, "no spare columns for the source vectors");
+  const bool own_wave = p.wave == (c1 >> 4);
+  const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
+  ncopy_image<RT>(sm.P, img, p);
+  ncopy_image<RT>(sm.Q, img + G::AF, p);
+  if (tid < G::NP) {
+    jp[tid] = img[2 * G::AF + tid];
+    jm[tid] = img[2 * G::AF + G::NP + tid];
+    const bool uv = (uvmask >> (tid % gsz)) & 1u;
+    sm.usg[tid] = uv ? -1.0 : 1.0;
+    rsg[tid] = (ndoubl >= 1 && uv) ? -1.0 : 1.0;
+  }
+  const double expk0 = img[2 * G::AF + 2 * G::NP];
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA writes have landed in LDS
+  __syncthreads();
+  nload(r_s, dP, p);
+  nload(t_s, dQ, p);
+  // ---- doubling (rt_helpers.jl:102-166) -----------------------------------------------------------------------------------
+  //   [E | W]   = r [r | t]                 A = P = [r]
+  //   G         = (I - E)^-1                Horner series on [E] in P
+  //   tt        = t G                       A = Q = [t]
+  //   [r' | t'] = [r | 0] + tt [W | t]      A = P = [tt]
+  // Sources (rt_helpers.jl:128-134: j0- += tt (j1- + r j0+), j0+ = j1+ + tt (j0+ + r j1-)) ride in the spare columns:
+  //   t_s[c1] = j0+, t_s[c2] = j1- = j0- expk  ->  W[c1] = r j0+, W[c2] = r j1-
+  //   r_s[c1] = j0-, r_s[c2] = j0+             ->  W[c1] += r_s[c1] expk, W[c2] += r_s[c2], r_s[c2] *= expk: lane-local;
+  //                                                r'[c1] = j0- + tt (j1- + r j0+), r'[c2] = j1+ + tt (j0+ + r j1-)
+  double expk = expk0;
+  int slot = 0;
+  const ninv_ctx cx{dP, sm.P, sm.gjs, status};
+  for (int it = 0; it < ndoubl; ++it) {
+    nstrip<RT> W, tt;
+    const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
+    {
+      nstrip<RT> Gs;
+      {
+        nstrip<RT> E;
+        E.zero();
+        W.zero();
+        nmm2<RT, KS>(E, W, dP, r_s, t_s, p);
+        if (own_wave) {
+#pragma unroll
+          for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              W.v[ta][r] = fma(r_s.v[ta][r], fW, W.v[ta][r]);
+              r_s.v[ta][r] *= fR;
+            }
+        }
+        const double nrm = nnorm(E, n, sm, slot, p);   // (its barrier: [r] is free)
+        ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);
+      }
+      tt.zero();
+      nmm<RT, KS>(tt, dQ, Gs, p);          // tt = t G
+    }
+    nload(t_s, dQ, p);                     // t's strip (with its riders) is not kept in registers across the inverse
+    __syncthreads();                       // P ([E]) and Q ([t]) no longer read
+    nstore(dP, tt, p);
+    __syncthreads();
+    {
+      nstrip<RT> tn;
+      tn.zero();
+      nmm2<RT, KS>(r_s, tn, dP, W, t_s, p);   // r' = r + tt W (riders: the new j0-, j0+) ; t' = tt t
+      t_s = tn;
+    }
+    expk = expk * expk;
+    if (own_wave) {
+      const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk'
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double u = ndpp_swap1(r_s.v[ta][r]) * ft;
+          t_s.v[ta][r] = laneAB ? u : t_s.v[ta][r];
+        }
+    }
+    if (it + 1 < ndoubl) {
+      __syncthreads();                     // everybody finished reading P ([tt])
+      nstore(dP, r_s, p);
+      nstore(dQ, t_s, p);
+      __syncthreads();
+    }
+  }
+  if (ndoubl > 0 && own_wave) {   // the riders go back to the LDS vectors; the strips leave the loop with clean padding
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        double* dpv = laneA ? jp : sm.vec[7];   // (the other lanes write to a dummy vector)
+        double* dmv = laneA ? jm : sm.vec[7];
+        dpv[row] = t_s.v[ta][r];          // lane A: j0+
+        dmv[row] = r_s.v[ta][r];          // lane A: j0-
+        t_s.v[ta][r] = laneAB ? 0.0 : t_s.v[ta][r];
+        r_s.v[ta][r] = laneAB ? 0.0 : r_s.v[ta][r];
+      }
+  }
+  __syncthreads();
+  // ---- apply_D (doubling.jl:178-252): r-+ = D r*, j0- = D j0-* ------------------------------------------------------------
+  if (ndoubl >= 1) {
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r_s.v[ta][r] *= rsg[p.row(ta, r)];
+    if (tid < G::NP) jm[tid] *= rsg[tid];
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266), native composite
+// ---------------------------------------------------------------------------------------------------------------------------
+// On entry: r_s / t_s = strips of the added layer's r-+ / t++ (columns >= n zero), sm.vec[0] / vec[1] = its j0+ / j0-, all waves
+// past a barrier, P and Q free.  r+- = D r-+ D, t-- = D t++ D (added layers from doubling).  With G2 = (I - R+- r-+)^-1 and
+// the push-through identities (I - r R)^-1 r = r G2, (I - r R)^-1 = I + r G2 R:
+//   [E2 | Z] = R+- [r-+ | t--]          A = P = [R+-]   z  = J0+ + R+- j0-   (j0- rides in a spare column of r-+)
+//   G2       = (I - E2)^-1              A = P = [E2]    BEFORE the products of [T--]: V is not live across the series
+//   [S  | V] = T-- [r-+ | t--]          A = Q = [T--]   vs = T-- j0-
+//   T21 = t++ G2 ;  Y = S G2            A = P = [t++], Q = [S]
+//   [R+- | T++] = [r+- | 0] + T21 [Z | T++]      A = P = [T21]   J0+ = j0+ + T21 z   (z rides in a spare column of T++)
+//   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z
+// Ten products and the series, seven barriers, at most six live strips.
+template <int RT, int KS>
+__device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, double* __restrict__ comp, nstrip<RT>& r_s,
+                                         nstrip<RT>& t_s, int* status) {
+  using G = ngeo<RT>;
+  constexpr unsigned dP = 0, dQ = G::AF * 8;
+  double* vjp = sm.vec[0];
+  double* vjm = sm.vec[1];
+  double* vJp = sm.vec[2];
+  double* vJm = sm.vec[3];
+  double* vs = sm.vec[4];
+  double* vz = sm.vec[5];
+  const int tid = threadIdx.x;
+  double* R_mp = comp + NC_RMP * G::AF;
+  double* R_pm = comp + NC_RPM * G::AF;
+  double* T_pp = comp + NC_TPP * G::AF;
+  double* T_mm = comp + NC_TMM * G::AF;
+  double* J0_p = comp + 4 * G::AF;
+  double* J0_m = J0_p + G::NP;
+  constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
+  const bool own_wave = p.wave == (c1 >> 4);
+  const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
+  int slot = 0;
+  const ndpar<RT> dp(sm.usg, p);
+  const ninv_ctx cx{dP, sm.P, sm.gjs, status};
+  // ---- stage: composite vectors, [R+-] -> P, [T--] -> Q ---------------------------------------------------------------------
+  if (tid < G::NP) {
+    vJp[tid] = J0_p[tid];
+    vJm[tid] = J0_m[tid];
+  }
+  nstrip<RT> Z, Gs;
+  {
+    nstrip<RT> A1, A2;
+    nld_native(A1, R_pm, p);
+    nld_native(A2, T_mm, p);
+    nstore(dP, A1, p);
+    nstore(dQ, A2, p);
+  }
+  if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r_s.v[ta][r] = laneB ? vjm[p.row(ta, r)] : r_s.v[ta][r];
+  }
+  ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
+  __syncthreads();                                                                                       // (a)
+  {
+    nstrip<RT> E;
+    E.zero();
+    Z.zero();
+    nmm2<RT, KS>(E, Z, dP, r_s, t_s, p);
+    if (own_wave) {
+      double* zd = laneB ? vz : sm.vec[7];   // (the other lanes write to a dummy vector)
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          zd[row] = vJp[row] + E.v[ta][r];
+        }
+    }
+    const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
+    ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
+  }
+  nstrip<RT> V;
+  {
+    nstrip<RT> S;
+    S.zero();
+    V.zero();
+    nmm2<RT, KS>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
+    if (own_wave) {
+      double* sd = laneB ? vs : sm.vec[7];
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sd[p.row(ta, r)] = S.v[ta][r];
+    }
+    // r_s <- r+- (the accumulator of the R+- update; its rider column is never used), t_s <- t++
+    ndsym(r_s, r_s, dp);
+    ndsym(t_s, t_s, dp);
+    __syncthreads();                      // (d): [E2] (series) and [T--] no longer read
+    nstore(dQ, S, p);                     // [S]   -> Q
+    nstore(dP, t_s, p);                   // [t++] -> P
+  }
+  __syncthreads();                        // (e)
+  {
+    nstrip<RT> X, Y;
+    X.zero();
+    nmm<RT, KS>(X, dP, Gs, p);            // T21 = t++ G2
+    Y.zero();
+    nmm<RT, KS>(Y, dQ, Gs, p);            // Y = S G2 = T01 r-+
+    __syncthreads();                      // (f): [t++], [S] no longer read
+    nstore(dP, X, p);                     // [T21] -> P
+    nstore(dQ, Y, p);                     // [Y]   -> Q
+  }
+  nstrip<RT> Tpp, Rmp;
+  nld_native(Tpp, T_pp, p);
+  nld_native(Rmp, R_mp, p);
+  __syncthreads();                        // (g)
+  if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
+        Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the native record keeps the rider column of the previous layer step)
+      }
+  }
+  {
+    nstrip<RT> acc;
+    acc.zero();
+    nmm2<RT, KS>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
+    nst_native(R_pm, r_s, p);
+    nst_native(T_pp, acc, p);
+    if (laneA) {
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          J0_p[row] = vjp[row] + acc.v[ta][r];
+        }
+    }
+  }
+  nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
+  nst_native(R_mp, Rmp, p);
+  nst_native(T_mm, V, p);
+  if (laneA) {
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
+      }
+  }
+}
+
+template <int RT, int KS>
+__global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(int n, int gsz, unsigned uvmask, int ndoubl,
+                                                                                int toa, const double* __restrict__ pre,
+                                                                                nlayer_comps a, int* status) {
+  using G = ngeo<RT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  nsmem<RT>& sm = *reinterpret_cast<nsmem<RT>*>(smem_raw);
+  npos<RT> p(sm.P);
+  const int s = blockIdx.x, isub = blockIdx.y;
+  const double* img = pre + ((long long)isub * gridDim.x + s) * G::PRE_STRIDE;
+  double* comp = a.c[isub] + (long long)s * G::COMP_STRIDE;
+  nstrip<RT> r_s, t_s;
+  ned_body<RT, KS>(sm, p, n, gsz, uvmask, ndoubl, img, r_s, t_s, status);
+  if (toa) {   // copy_added_to_composite! (rt_helpers.jl:188-200)
+    const ndpar<RT> dp(sm.usg, p);
+    nst_native(comp + NC_RMP * G::AF, r_s, p);
+    nst_native(comp + NC_TPP * G::AF, t_s, p);
+    nstrip<RT> d;
+    ndsym(d, r_s, dp);
+    nst_native(comp + NC_RPM * G::AF, d, p);
+    ndsym(d, t_s, dp);
+    nst_native(comp + NC_TMM * G::AF, d, p);
+    if (threadIdx.x < G::NP) {
+      comp[4 * G::AF + threadIdx.x] = sm.vec[0][threadIdx.x];
+      comp[4 * G::AF + G::NP + threadIdx.x] = sm.vec[1][threadIdx.x];
+    }
+    return;
+  }
+  nia_body<RT, KS>(sm, p, n, comp, r_s, t_s, status);
+}
+
+}  // namespace
+
+// one object per k-step count (parallel build): vsm_native_<KS>.o is this file built with -DVSM_NATIVE_KS=<KS>
+#define VSM_NCAT2(a, b) a##b
+#define VSM_NCAT(a, b) VSM_NCAT2(a, b)
+#define VSM_NATIVE_DECL(KS) \
+  int VSM_NCAT(launch_layer_native_, KS)(int, int, int, unsigned, int, int, int, const double*, const nlayer_comps&, int*, hipStream_t);
+
+#ifdef VSM_NATIVE_KS
+VSM_NATIVE_DECL(VSM_NATIVE_KS)
+int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsigned uvmask, int gsz, int ndoubl, int toa,
+                                                  const double* pre, const nlayer_comps& comps, int* status, hipStream_t st) {
+  constexpr int KS = VSM_NATIVE_KS;
+  constexpr int RT = (4 * KS + 2 + 15) / 16;
+  static_assert(RT >= 1 && RT <= 4, "n <= 60");
+  auto kern = k_layer_native<RT, KS>;
+  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(nsmem<RT>), "hipFuncSetAttribute(k_layer_native)");
+  if (prepared) return prepared;
+  hipLaunchKernelGGL(kern, dim3(S, nsub), dim3(ngeo<RT>::NT), sizeof(nsmem<RT>), st, n, gsz, uvmask, ndoubl, toa, pre, comps,
+                     status);
+  VSM_LAUNCH_CHECK("k_layer_native");
+  return VSM_OK;
+}
+}  // namespace vsm
+
+#else  // ---- dispatcher object: pre-pass, layout conversion, the run object and its C ABI -----------------------------------
+
+VSM_NATIVE_DECL(1)
+VSM_NATIVE_DECL(2)
+VSM_NATIVE_DECL(3)
+VSM_NATIVE_DECL(4)
+VSM_NATIVE_DECL(5)
+VSM_NATIVE_DECL(6)
+VSM_NATIVE_DECL(7)
+VSM_NATIVE_DECL(8)
+VSM_NATIVE_DECL(9)
+VSM_NATIVE_DECL(10)
+VSM_NATIVE_DECL(11)
+VSM_NATIVE_DECL(12)
+VSM_NATIVE_DECL(13)
+VSM_NATIVE_DECL(14)
+VSM_NATIVE_DECL(15)
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Elemental pre-pass: elemental! incl. the SFI source (elemental.jl:289-392) of every (point, sub-problem) of a layer as two
+// A-form images + vectors (ngeo::PRE_STRIDE).  Sub-row i of a group g (Stokes components g[0..gsz)) is row
+// (i / gsz) n_stokes + g[i % gsz] of the full problem.  Thread = (row, column phase): 16 consecutive threads write 16
+// consecutive rows of one column (128 contiguous bytes of an image block).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct nsub_pre {
+  int m, gsz;
+  int g[4];
+  zsrc<double> z;
+};
+struct npre_args {
+  nsub_pre s[NSUB_MAX];
+};
+template <int RT, bool MIX>
+__global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<double> q, int n, int ndoubl, const double* __restrict__ dtau,
+                                                              const double* __restrict__ varpi,
+                                                              const double* __restrict__ tau_sum, const double* __restrict__ F0,
+                                                              npre_args a, double* __restrict__ pre) {
+  using G = ngeo<RT>;
+  constexpr int NP = G::NP;
+  __shared__ double mus[NP], xs[NP], es[NP], ems[NP], wts[NP];
+  __shared__ int frow[NP];
+  __shared__ int thick_flag;
+  const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
+  const nsub_pre& sp = a.s[isub];
+  const int N = q.N, ns = q.n_stokes, m = sp.m, gsz = sp.gsz;
+  const zsrc<double> z = sp.z;
+  const double d = dtau[s], w = varpi[s];
+  const int ncomp = MIX ? z.ncomp : 0;
+  const long long NNz = (long long)N * N;
+  const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+  const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+  double fk[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
+  auto zget = [&](const double* Z, long long zo) {
+    if (ncomp == 0) return Z[zo];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+    return acc;
+  };
+  if (tid < NP) {
+    const bool in = tid < n;
+    const int ga = sp.g[tid % gsz];
+    const int fr = in ? (tid / gsz) * ns + ga : 0;
+    const double mu = in ? q.mu[fr] : 1.0;
+    const double x = d / mu;
+    frow[tid] = fr;
+    mus[tid] = mu;
+    xs[tid] = x;
+    es[tid] = exp(-x);
+    ems[tid] = expm1(-x);
+    wts[tid] = in ? q.wt[fr] : 0.0;
+  }
+  if (tid == 0) thick_flag = 0;
+  __syncthreads();
+  if (tid < n && xs[tid] >= 0.5) thick_flag = 1;   // (benign race: every writer stores 1)
+  __syncthreads();
+  const bool thick = thick_flag != 0;
+  const int i = tid % NP, ph = tid / NP;           // 64 RT threads = NP rows x 4 column phases
+  const int ic = min(i, n - 1);
+  const double mi = mus[i], xi = xs[i], ai = ems[i], ei = es[i];
+  const bool uvi = i < n && sp.g[i % gsz] >= 2;
+  const double sg = (ndoubl >= 1 && uvi) ? -1.0 : 1.0;   // starred R* = D R (elemental.jl:403-422)
+  double* out = pre + ((long long)isub * gridDim.x + s) * G::PRE_STRIDE;
+  double* R = out;
+  double* T = out + G::AF;
+  const int Kend = ((n + 3) >> 2) << 2;
+  const int c1 = Kend, c2 = Kend + 1;
+  const bool riders_in = ndoubl > 0;
+  const int fi = frow[ic];
+  for (int j = ph; j < NP; j += 4) {
+    if (riders_in && (j == c1 || j == c2)) continue;   // written below
+    double rv = 0.0, tv = 0.0;
+    if (j < n) {
+      const double wt = wts[j];
+      const double wct = (m == 0) ? wt / 2.0 : wt / 4.0;
+      const long long zo = fi + (long long)N * frow[j];
+      double rr, tt;
+      elemental_pair(w, zget(Zp, zo), zget(Zm, zo), mi, xi, ai, ei, mus[j], xs[j], ems[j], es[j], wct, i == j, thick, rr, tt);
+      const bool active = wct > num<double>::eps();
+      if (i < n) {
+        rv = active ? rr * sg : 0.0;
+        tv = active ? tt : ((i == j) ? ei : 0.0);
+      }
+    }
+    R[naf_idx<RT>(i, j)] = rv;
+    T[naf_idx<RT>(i, j)] = tv;
+  }
+  if (ph == 0) {   // SFI source of the solar beam: the same formulas with the solar column (see elemental_pair)
+    const int i0 = ns * q.i_mu0;
+    const double mu0n = q.mu[i0];
+    const double x0 = d / mu0n, e0 = exp(-x0), a0 = expm1(-x0);
+    double zp = 0.0, zm = 0.0;
+    for (int qq = 0; qq < ns; ++qq) {
+      const long long zo = fi + (long long)N * (i0 + qq);
+      const double f = F0[qq + (long long)ns * s];
+      zp += zget(Zp, zo) * f;
+      zm += zget(Zm, zo) * f;
+    }
+    double rr, tt;
+    // (the diagonal case mu_i == mu_0 of the source never takes the i == j form: elemental.jl:370-382)
+    elemental_pair(w, zp, zm, mi, xi, ai, ei, mu0n, x0, a0, e0, (m == 0) ? 0.5 : 0.25, false, thick || x0 >= 0.5, rr, tt);
+    const double att = exp(-tau_sum[s] / mu0n);
+    const double vp = (i < n) ? tt * att : 0.0;
+    const double vm = (i < n) ? rr * att * sg : 0.0;
+    const double expk0 = exp(-d / q.mu0);
+    out[2 * G::AF + i] = vp;
+    out[2 * G::AF + NP + i] = vm;
+    out[2 * G::AF + 2 * NP + i] = expk0;
+    if (riders_in) {   // t[:, c1] = j0+, t[:, c2] = j1- = j0- expk ;  r[:, c1] = j0-, r[:, c2] = j0+
+      T[naf_idx<RT>(i, c1)] = vp;
+      T[naf_idx<RT>(i, c2)] = vm * expk0;
+      R[naf_idx<RT>(i, c1)] = vm;
+      R[naf_idx<RT>(i, c2)] = vp;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// native <-> reference layout ([N,N,S] column-major composite arrays), one workgroup per point
+// ---------------------------------------------------------------------------------------------------------------------------
+struct ngroup_map {
+  int ngroups;
+  int grp_of[4];    // group of Stokes component a
+  int pos_in[4];    // its position inside the group
+  int gsz[4];       // per group
+  int rt[4];        // per group: row tiles
+  int n[4];         // per group: rows
+  double* base[4];  // per group: native composites [S] (stride COMP_STRIDE of its RT)
+};
+__device__ __forceinline__ int nnat_idx_rt(int rt, int i, int j) {
+  switch (rt) {
+    case 1: return nnat_idx<1>(i, j);
+    case 2: return nnat_idx<2>(i, j);
+    case 3: return nnat_idx<3>(i, j);
+    default: return nnat_idx<4>(i, j);
+  }
+}
+__global__ __launch_bounds__(256) void k_native_export(int N, int ns, ngroup_map gm, composite<double> c) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const long long NN = (long long)N * N;
+  double* out[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
+  for (int e = tid; e < N * N; e += 256) {
+    const int i = e % N, j = e / N;
+    const int ai = i % ns, aj = j % ns;
+    const int gi = gm.grp_of[ai];
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (gi == gm.grp_of[aj]) {
+      const int rt = gm.rt[gi], np = 16 * rt, af = np * np;
+      const double* cn = gm.base[gi] + (long long)s * (4 * af + 2 * np);
+      const int is = (i / ns) * gm.gsz[gi] + gm.pos_in[ai], js = (j / ns) * gm.gsz[gi] + gm.pos_in[aj];
+      const int ix = nnat_idx_rt(rt, is, js);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = cn[k * af + ix];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k][e] = v[k];
+  }
+  if (tid < N) {
+    const int ai = tid % ns, gi = gm.grp_of[ai];
+    const int rt = gm.rt[gi], np = 16 * rt, af = np * np;
+    const double* cn = gm.base[gi] + (long long)s * (4 * af + 2 * np);
+    const int is = (tid / ns) * gm.gsz[gi] + gm.pos_in[ai];
+    c.J0_p[(long long)s * N + tid] = cn[4 * af + is];
+    c.J0_m[(long long)s * N + tid] = cn[4 * af + np + is];
+  }
+}
+// reference layout -> native (padding zero); elements that couple different groups are dropped (they are exact zeros for a
+// composite that was built under the same coupling)
+__global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map gm, composite<double> c) {
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const long long NN = (long long)N * N;
+  const double* in[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
+  for (int g = 0; g < gm.ngroups; ++g) {
+    const int rt = gm.rt[g], np = 16 * rt, af = np * np, n = gm.n[g], gsz = gm.gsz[g];
+    double* cn = gm.base[g] + (long long)s * (4 * af + 2 * np);
+    int comp_of[4] = {0, 0, 0, 0};   // Stokes component of position k of the group
+    for (int a = 0; a < ns; ++a)
+      if (gm.grp_of[a] == g) comp_of[gm.pos_in[a]] = a;
+    for (int e = tid; e < af; e += 256) {
+      const int is = e % np, js = e / np;
+      double v[4] = {0.0, 0.0, 0.0, 0.0};
+      if (is < n && js < n) {
+        const int i = (is / gsz) * ns + comp_of[is % gsz], j = (js / gsz) * ns + comp_of[js % gsz];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in[k][i + (long long)N * j];
+      }
+      const int ix = nnat_idx_rt(rt, is, js);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cn[k * af + ix] = v[k];
+    }
+    if (tid < np) {
+      double vp = 0.0, vm = 0.0;
+      if (tid < n) {
+        const int i = (tid / gsz) * ns + comp_of[tid % gsz];
+        vp = c.J0_p[(long long)s * N + i];
+        vm = c.J0_m[(long long)s * N + i];
+      }
+      cn[4 * af + tid] = vp;
+      cn[4 * af + np + tid] = vm;
+    }
+  }
+}
+
+// Which Stokes components the phase matrices couple: bit 4 a + b of *mask is set when some element (i, j) with i % ns == a,
+// j % ns == b of any of the nblocks matrices Zpp / Zmp [N,N,nblocks] is not exactly zero.
+__global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, int nblocks, const double* __restrict__ Zpp,
+                                                         const double* __restrict__ Zmp, int* __restrict__ mask) {
+  unsigned mm = 0;
+  const long long tot = (long long)N * N * nblocks;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < tot; e += 256ll * gridDim.x) {
+    const int ij = (int)(e % ((long long)N * N));
+    const int i = ij % N, j = ij / N;
+    if (Zpp[e] != 0.0 || Zmp[e] != 0.0) mm |= 1u << (4 * (i % ns) + (j % ns));
+  }
+  if (mm) atomicOr(mask, (int)mm);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// the run object
+// ---------------------------------------------------------------------------------------------------------------------------
+struct nat_sub {
+  int im;          // index of the Fourier moment in the run's list
+  int m;
+  int gsz, g[4];
+  unsigned uvmask;
+  int n, rt, ks;
+  size_t comp_off;   // doubles from the workspace base
+};
+}  // namespace vsm
+
+struct vsm_run {
+  vsm::quad<double> q;
+  int S, nm;
+  std::vector<int> m;
+  std::vector<vsm::nat_sub> subs;
+  std::vector<std::vector<int>> classes;   // indices into subs with equal (n, gsz, uvmask)
+  double* ws;
+  size_t ws_doubles;
+};
+
+namespace vsm {
+namespace {
+
+// groups of Stokes components = connected components of the (symmetrised) coupling mask; coupling < 0: one dense group
+static int stokes_groups(int ns, int coupling, int grp_of[4], int groups[4][4], int gsz[4]) {
+  bool adj[4][4] = {};
+  for (int a = 0; a < ns; ++a)
+    for (int b = 0; b < ns; ++b) {
+      const bool on = coupling < 0 || ((coupling >> (4 * a + b)) & 1) || ((coupling >> (4 * b + a)) & 1) || a == b;
+      adj[a][b] = on;
+    }
+  int ng = 0;
+  for (int a = 0; a < 4; ++a) grp_of[a] = -1;
+  for (int a = 0; a < ns; ++a) {
+    if (grp_of[a] >= 0) continue;
+    int stack[4], top = 0;
+    stack[top++] = a;
+    grp_of[a] = ng;
+    while (top) {
+      const int x = stack[--top];
+      for (int b = 0; b < ns; ++b)
+        if (adj[x][b] && grp_of[b] < 0) {
+          grp_of[b] = ng;
+          stack[top++] = b;
+        }
+    }
+    ++ng;
+  }
+  for (int g = 0; g < ng; ++g) {
+    gsz[g] = 0;
+    for (int a = 0; a < ns; ++a)
+      if (grp_of[a] == g) groups[g][gsz[g]++] = a;   // ascending component order inside a group
+  }
+  return ng;
+}
+static inline int rt_of(int n) { return (4 * ((n + 3) / 4) + 2 + 15) / 16; }
+static inline size_t comp_stride_rt(int rt) { return (size_t)4 * (16 * rt) * (16 * rt) + 2 * 16 * rt; }
+static inline size_t pre_stride_rt(int rt) { return (size_t)2 * (16 * rt) * (16 * rt) + 3 * 16 * rt; }
+
+static int plan_subs(int N, int ns, int nm, const int* m, const int* coupling, std::vector<nat_sub>& subs, size_t S,
+                     size_t& total) {
+  if (N <= 0 || ns < 1 || ns > 4 || N % ns) {
+    set_error("vsm_run: bad N = %d / n_stokes = %d", N, ns);
+    return VSM_ERR_INVALID_ARG;
+  }
+  const int nq = N / ns;
+  total = 0;
+  subs.clear();
+  for (int im = 0; im < nm; ++im) {
+    int grp_of[4], groups[4][4], gsz[4];
+    const int ng = stokes_groups(ns, coupling ? coupling[im] : -1, grp_of, groups, gsz);
+    for (int g = 0; g < ng; ++g) {
+      nat_sub sb;
+      sb.im = im;
+      sb.m = m ? m[im] : 0;
+      sb.gsz = gsz[g];
+      sb.uvmask = 0;
+      for (int k = 0; k < 4; ++k) sb.g[k] = k < gsz[g] ? groups[g][k] : groups[g][0];
+      for (int k = 0; k < gsz[g]; ++k)
+        if (groups[g][k] >= 2) sb.uvmask |= 1u << k;
+      sb.n = nq * gsz[g];
+      if (sb.n > 60) {
+        set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (60)", sb.n, N,
+                  gsz[g]);
+        return VSM_ERR_UNSUPPORTED;
+      }
+      sb.ks = (sb.n + 3) / 4;
+      sb.rt = rt_of(sb.n);
+      sb.comp_off = total;
+      total += comp_stride_rt(sb.rt) * S;
+      subs.push_back(sb);
+    }
+  }
+  return VSM_OK;
+}
+
+static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, int gsz, int ndoubl, int toa, const double* pre,
+                               const nlayer_comps& comps, int* status, hipStream_t st) {
+#define VSM_NL(KS) \
+  case KS: return VSM_NCAT(launch_layer_native_, KS)(S, nsub, n, uvmask, gsz, ndoubl, toa, pre, comps, status, st);
+  switch (ks) {
+    VSM_NL(1) VSM_NL(2) VSM_NL(3) VSM_NL(4) VSM_NL(5) VSM_NL(6) VSM_NL(7) VSM_NL(8) VSM_NL(9) VSM_NL(10) VSM_NL(11) VSM_NL(12)
+    VSM_NL(13) VSM_NL(14) VSM_NL(15)
+    default: break;
+  }
+#undef VSM_NL
+  set_error("launch_layer_native: no kernel for %d k-steps", ks);
+  return VSM_ERR_UNSUPPORTED;
+}
+
+template <int RT>
+static void launch_pre(bool mix, const quad<double>& q, int S, int nsub, int n, int ndoubl, const double* dtau,
+                       const double* varpi, const double* tau_sum, const double* F0, const npre_args& a, double* pre,
+                       hipStream_t st) {
+  const dim3 grid(S, nsub), block(64 * RT);
+  if (mix)
+    hipLaunchKernelGGL((k_elemental_native<RT, true>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+  else
+    hipLaunchKernelGGL((k_elemental_native<RT, false>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+}
+
+static ngroup_map group_map(const vsm_run* run, int im) {
+  ngroup_map gm;
+  gm.ngroups = 0;
+  for (int a = 0; a < 4; ++a) {
+    gm.grp_of[a] = gm.pos_in[a] = 0;
+    gm.gsz[a] = gm.rt[a] = 1;
+    gm.n[a] = 0;
+    gm.base[a] = nullptr;
+  }
+  for (const nat_sub& sb : run->subs) {
+    if (sb.im != im) continue;
+    const int g = gm.ngroups++;
+    gm.gsz[g] = sb.gsz;
+    gm.rt[g] = sb.rt;
+    gm.n[g] = sb.n;
+    gm.base[g] = run->ws + sb.comp_off;
+    for (int k = 0; k < sb.gsz; ++k) {
+      gm.grp_of[sb.g[k]] = g;
+      gm.pos_in[sb.g[k]] = k;
+    }
+  }
+  return gm;
+}
+
+}  // namespace
+}  // namespace vsm
+
+using namespace vsm;
+
+extern "C" {
+
+int vsm_run_supported_f64(int N, int n_stokes, int coupling) {
+  if (N <= 0 || n_stokes < 1 || n_stokes > 4 || N % n_stokes) return 0;
+  int grp_of[4], groups[4][4], gsz[4];
+  const int ng = stokes_groups(n_stokes, coupling, grp_of, groups, gsz);
+  for (int g = 0; g < ng; ++g)
+    if ((N / n_stokes) * gsz[g] > 60) return 0;
+  return 1;
+}
+
+size_t vsm_run_workspace_bytes_f64(int N, int n_stokes, int S, int nm, const int* coupling) {
+  std::vector<nat_sub> subs;
+  size_t total = 0;
+  if (S < 0 || nm < 0 || plan_subs(N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
+  return total * sizeof(double);
+}
+
+int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m, const int* coupling, void* workspace,
+                       size_t workspace_bytes, vsm_run** run_out) {
+  VSM_REQUIRE(q && q->mu && q->wt && run_out && m, "vsm_run_create: null argument");
+  VSM_REQUIRE(S >= 0 && nm >= 1 && nm <= NSUB_MAX, "vsm_run_create: bad S = %d / nm = %d (at most %d moments per run)", S, nm,
+              NSUB_MAX);
+  vsm_run* run = new vsm_run;
+  run->q = quad<double>{q->mu, q->wt, q->N, q->n_stokes, q->i_mu0, q->mu0};
+  run->S = S;
+  run->nm = nm;
+  run->m.assign(m, m + nm);
+  size_t total = 0;
+  const int rc = plan_subs(q->N, q->n_stokes, nm, m, coupling, run->subs, (size_t)S, total);
+  if (rc) {
+    delete run;
+    return rc;
+  }
+  if (total * sizeof(double) > workspace_bytes || (total && !workspace) || ((size_t)workspace & 15)) {
+    set_error("vsm_run_create: workspace of %zu bytes (16-byte aligned) required, got %zu", total * sizeof(double), workspace_bytes);
+    delete run;
+    return VSM_ERR_INVALID_ARG;
+  }
+  run->ws = static_cast<double*>(workspace);
+  run->ws_doubles = total;
+  // classes: sub-problems that one launch can take (equal n, group size and U/V pattern), at most NSUB_MAX each
+  for (size_t i = 0; i < run->subs.size(); ++i) {
+    const nat_sub& sb = run->subs[i];
+    bool placed = false;
+    for (auto& cl : run->classes) {
+      const nat_sub& h = run->subs[cl[0]];
+      if (h.n == sb.n && h.gsz == sb.gsz && h.uvmask == sb.uvmask && (int)cl.size() < NSUB_MAX) {
+        cl.push_back((int)i);
+        placed = true;
+        break;
+      }
+    }
+    if (!placed) run->classes.push_back(std::vector<int>{(int)i});
+  }
+  *run_out = run;
+  return VSM_OK;
+}
+
+int vsm_run_destroy(vsm_run* run) {
+  delete run;
+  return VSM_OK;
+}
+
+int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum, const double* F0,
+                      int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
+                      int toa, void* stream) {
+  VSM_REQUIRE(run && dtau && varpi && tau_sum && F0 && Zpp && Zmp, "vsm_run_layer: null argument");
+  VSM_REQUIRE(ndoubl >= 0 && ncomp >= 0 && ncomp <= 4 && (ncomp == 0 || fcomp), "vsm_run_layer: bad ndoubl / component mix");
+  if (run->S == 0) return VSM_OK;
+  hipStream_t st = as_stream(stream);
+  int* status = device_status();
+  if (!status) return VSM_ERR_HIP;
+  // the pre-pass images of the layer: one record per (sub-problem, point)
+  size_t pre_total = 0;
+  for (const nat_sub& sb : run->subs) pre_total += pre_stride_rt(sb.rt) * (size_t)run->S;
+  double* pre = static_cast<double*>(scratch(pre_total * sizeof(double), 3, st));
+  if (!pre) return VSM_ERR_HIP;
+  size_t off = 0;
+  for (const auto& cl : run->classes) {
+    const nat_sub& h = run->subs[cl[0]];
+    const int nsub = (int)cl.size();
+    npre_args pa;
+    nlayer_comps lc;
+    for (int k = 0; k < NSUB_MAX; ++k) {
+      const nat_sub& sb = run->subs[cl[k < nsub ? k : 0]];
+      pa.s[k].m = sb.m;
+      pa.s[k].gsz = sb.gsz;
+      for (int a = 0; a < 4; ++a) pa.s[k].g[a] = sb.g[a];
+      VSM_REQUIRE(Zpp[sb.im] && Zmp[sb.im], "vsm_run_layer: null Z of moment %d", sb.im);
+      pa.s[k].z = zsrc<double>{Zpp[sb.im], Zmp[sb.im], ncomp ? 0 : z_stride, ncomp, fcomp};
+      lc.c[k] = run->ws + sb.comp_off;
+    }
+    double* pre_cl = pre + off;
+    off += pre_stride_rt(h.rt) * (size_t)run->S * nsub;
+    switch (h.rt) {
+      case 1: launch_pre<1>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 2: launch_pre<2>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 3: launch_pre<3>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      default: launch_pre<4>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+    }
+    VSM_LAUNCH_CHECK("k_elemental_native");
+    const int rc = launch_layer_native(h.ks, run->S, nsub, h.n, h.uvmask, h.gsz, ndoubl, toa, pre_cl, lc, status, st);
+    if (rc) return rc;
+  }
+  return VSM_OK;
+}
+
+int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
+  VSM_REQUIRE(run && comps, "vsm_run_export: null argument");
+  if (run->S == 0) return VSM_OK;
+  for (int im = 0; im < run->nm; ++im) {
+    const vsm_composite_f64& c = comps[im];
+    VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_export: null composite array (moment %d)", im);
+    const ngroup_map gm = group_map(run, im);
+    hipLaunchKernelGGL(k_native_export, dim3(run->S), dim3(256), 0, as_stream(stream), run->q.N, run->q.n_stokes, gm,
+                       composite<double>{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m});
+    VSM_LAUNCH_CHECK("k_native_export");
+  }
+  return VSM_OK;
+}
+
+int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
+  VSM_REQUIRE(run && comps, "vsm_run_import: null argument");
+  if (run->S == 0) return VSM_OK;
+  for (int im = 0; im < run->nm; ++im) {
+    const vsm_composite_f64& c = comps[im];
+    VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_import: null composite array (moment %d)", im);
+    const ngroup_map gm = group_map(run, im);
+    hipLaunchKernelGGL(k_native_import, dim3(run->S), dim3(256), 0, as_stream(stream), run->q.N, run->q.n_stokes, gm,
+                       composite<double>{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m});
+    VSM_LAUNCH_CHECK("k_native_import");
+  }
+  return VSM_OK;
+}
+
+int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream) {
+  VSM_REQUIRE(N > 0 && n_stokes >= 1 && n_stokes <= 4 && N % n_stokes == 0 && nblocks >= 1 && Zpp && Zmp && mask_d,
+              "vsm_stokes_coupling: bad argument");
+  hipStream_t st = as_stream(stream);
+  VSM_HIP(hipMemsetAsync(mask_d, 0, sizeof(int), st));
+  const long long tot = (long long)N * N * nblocks;
+  const int blocks = (int)((tot + 255) / 256 < 64 ? (tot + 255) / 256 : 64);
+  hipLaunchKernelGGL(k_stokes_coupling, dim3(blocks), dim3(256), 0, st, N, n_stokes, nblocks, Zpp, Zmp, mask_d);
+  VSM_LAUNCH_CHECK("k_stokes_coupling");
+  return VSM_OK;
+}
+
+}  // extern "C"
+
+#endif  // VSM_NATIVE_KS
