@@ -54,6 +54,27 @@ CONFIGS = {
 }
 
 
+def stokes_groups(ns, coupling):
+    """Blocks of Stokes components that the phase matrices couple (bit masks), from the mask of vsm_stokes_coupling: the
+    connected components the library's run object forms (vsm_native.hip stokes_groups)."""
+    if coupling is None or coupling < 0:
+        return [(1 << ns) - 1]
+    seen, out = 0, []
+    for a in range(ns):
+        if seen >> a & 1:
+            continue
+        grp, stack = 1 << a, [a]
+        while stack:
+            x = stack.pop()
+            for b in range(ns):
+                if not grp >> b & 1 and ((coupling >> (4 * x + b)) & 1 or (coupling >> (4 * b + x)) & 1):
+                    grp |= 1 << b
+                    stack.append(b)
+        seen |= grp
+        out.append(grp)
+    return out
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -207,37 +228,74 @@ def main():
     step(split=True)   # phase attribution, outside the timed region
 
     # ---- roofline of the dominant kernel: timed live with events on the launch stream ----------
-    # one extra pass with an event pair around every layer-step launch; the same pass gives the device-only time of run()
+    # one extra pass with an event pair around every layer-step call; the same pass gives the device-only time of run()
     ev = []
-    orig, orig_multi = vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_
+    orig, orig_multi, orig_native = vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_, vsm.CoreRT.run_layer_native_
 
-    def timed_with(f, moments_of):
+    def timed_with(f, rec):
         def timed(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             f(*a, **k)
             e1.record()
-            ev.append((e0, e1, a[5], a[7], moments_of(a)))  # ndoubl, toa, Fourier moments in the launch
+            ev.append((e0, e1) + rec(a))   # + (ndoubl, toa, Fourier moments in the call)
         return timed
 
-    vsm.CoreRT.layer_forward_ = timed_with(orig, lambda a: 1)
-    vsm.CoreRT.layer_forward_multi_ = timed_with(orig_multi, lambda a: len(a[4]))
+    vsm.CoreRT.layer_forward_ = timed_with(orig, lambda a: (a[5], a[7], 1))
+    vsm.CoreRT.layer_forward_multi_ = timed_with(orig_multi, lambda a: (a[5], a[7], len(a[4])))
+    vsm.CoreRT.run_layer_native_ = timed_with(orig_native, lambda a: (a[2], a[12], a[1]))
     r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r0.record()
     scene.run()
     r1.record()
     torch.cuda.synchronize()
-    vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_ = orig, orig_multi
     run_ms = r0.elapsed_time(r1)
     n3, n2 = float(N) ** 3, float(N) ** 2
-    k_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
-    # algorithmic flops of one layer step: nd doublings + (unless TOA) one _11 interaction, per point and moment
-    k_flops = sum(nmom * S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2)) for _, _, nd, toa, nmom in ev)
-    moments_per_launch = max([e[4] for e in ev], default=1)
+    step_flops = lambda evs: sum(nmom * S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2))
+                                 for _, _, nd, toa, nmom in evs)   # ALGORITHMIC flops, as written (dense N x N)
+    step_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
+    step_tflops = step_flops(ev) / (step_ms * 1e-3) / 1e12 if step_ms > 0 else 0.0
+    layer_step = {"calls": len(ev), "avg_ms": step_ms / max(len(ev), 1), "algorithmic_tflops": step_tflops,
+                  "frac_of_mfma_peak_algorithmic": step_tflops / PEAK_TFLOPS[cfg["FT"]],
+                  "fourier_moments_per_call": max([e[4] for e in ev], default=1)}
+    native = sorted(scene._native_moments())
+    interval_kernels = None
+    if native:
+        # The run walks the layers on the native-layout composite (vsm_run_*): a layer step = per class of sub-problems the
+        # elemental pre-pass + ONE k_layer_native<RT, KS> launch.  Moments whose Stokes blocks all couple are dense N x N problems
+        # (C2: m = 1, 2 on k_layer_native<4, 15>: the dominant kernel); the blocks of m = 0 run as independent sub-problems and
+        # execute fewer products than the as-written count.  The dominant kernel is timed by itself: one more walk of the layers
+        # with the dense moments only (event pair = its pre-pass + the layer launch), against ITS algorithmic flops.
+        sub = lambda mom: scene.N // scene.pol.n * max(bin(g).count("1") for g in stokes_groups(scene.pol.n, scene.coupling[mom["m"]]))
+        dense = [i for i in native if sub(scene.moments[i]) == N]
+        ev_all, ev = ev, []
+        if dense:
+            scene._run_layers_native([scene.moments[i] for i in dense], scene._composites[:len(dense)])
+            torch.cuda.synchronize()
+        ev_dense, ev = ev, ev_all
+        k_ms = sum(e[0].elapsed_time(e[1]) for e in ev_dense)
+        k_flops = step_flops(ev_dense)
+        ks = (N + 3) // 4
+        kernel_name = "k_layer_native<%d, %d>" % ((4 * ks + 2 + 15) // 16, ks)
+        interval_kernels = ["k_elemental_native", kernel_name]
+        moments_per_launch = len(dense)
+        n_launch = len(ev_dense)
+        # executed products of the whole layer step: a block of n rows costs (n / N)^3 of the dense count
+        ex = sum(sum((scene.N // scene.pol.n * bin(g).count("1") / float(N)) ** 3 for g in stokes_groups(scene.pol.n, scene.coupling[scene.moments[i]["m"]]))
+                 for i in native) + (len(scene.moments) - len(native))
+        layer_step["executed_over_algorithmic_flops"] = ex / len(scene.moments)
+        layer_step["frac_of_mfma_peak_executed"] = layer_step["frac_of_mfma_peak_algorithmic"] * ex / len(scene.moments)
+        layer_step["note"] = ("blocks of Stokes components that do not couple (m = 0: (I,Q) and U) run as independent sub-problems; "
+                              "products with exact zeros are not formed")
+    else:
+        k_ms, k_flops, n_launch = step_ms, step_flops(ev), len(ev)
+        moments_per_launch = max([e[4] for e in ev], default=1)
+    vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_, vsm.CoreRT.run_layer_native_ = orig, orig_multi, orig_native
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
-    interval_kernels = None
-    if cfg["FT"] == "f64" and 32 < N <= 64:
+    if native:
+        pass
+    elif cfg["FT"] == "f64" and 32 < N <= 64:
         # the event pair of a layer step brackets the fused layer kernel AND its elemental pre-pass (k_elemental_img writes the
         # A-form images the layer kernel copies in): the fraction below charges both to the layer kernel's flops
         kernel_name = "k_layer_strip_mm"
@@ -249,7 +307,8 @@ def main():
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
     build = vsm._lib.build_info()
-    traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(kernel_name, cfg, S_local, build["source_hash"])
+    tk = ([kernel_name, "k_elemental_native<%d," % ((4 * ((N + 3) // 4) + 2 + 15) // 16)] if native else [kernel_name, "k_elemental_img"])
+    traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(tk, cfg, S_local, build["source_hash"])
                                                         if args.variant == "rayleigh" else (None, None, None, "no profile of this variant"))
 
     if rank == 0:
@@ -280,9 +339,10 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "traffic_profile_head": traffic_hash, "traffic_note": traffic_note, "library": build,
-                         "launches": len(ev), "avg_launch_ms": k_ms / max(len(ev), 1),
+                         "launches": n_launch, "avg_launch_ms": k_ms / max(n_launch, 1),
                          "kernels_in_timed_interval": interval_kernels,
-                         "fourier_moments_per_launch": moments_per_launch},
+                         "fourier_moments_per_launch": moments_per_launch,
+                         "layer_step_all_moments": layer_step},
         }
         if world == 1 and args.config == "C2" and args.variant == "rayleigh" and not args.no_secondary and not args.points:
             import bench_secondary
@@ -396,10 +456,10 @@ def c5_traffic_per_point():
     return None
 
 
-PROFILE_ROUNDS = ("r04", "r03", "r02/final")
+PROFILE_ROUNDS = ("r05", "r04", "r03", "r02/final")
 
 
-def hbm_traffic_per_launch(kernel, cfg, S_local, running_hash=None):
+def hbm_traffic_per_launch(kernels, cfg, S_local, running_hash=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 runs by tools/profile_any.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
     figure of profiles/<round>/<config>/summary.json (a 4096-point run of the same command) times the points of one launch.
@@ -416,8 +476,9 @@ def hbm_traffic_per_launch(kernel, cfg, S_local, running_hash=None):
             prof = json.load(open(path))
             pts = int(prof["command"].split("--points")[1].split()[0])
             per_point = 0.0
-            for name, rec in prof["kernels"].items():   # the layer kernel and (FP64 strip shapes) its elemental pre-pass
-                if (kernel in name or "k_elemental_img" in name) and "fetch_bytes_per_launch" in rec:
+            want = [k.replace(" ", "") for k in kernels]
+            for name, rec in prof["kernels"].items():   # the layer kernel and its elemental pre-pass
+                if any(k in name.replace(" ", "") for k in want) and "fetch_bytes_per_launch" in rec:
                     per_point += (rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]) / pts
             if per_point <= 0.0:
                 continue

@@ -227,7 +227,9 @@ def test_c3_ocean_coxmunk_forward(vsm, arch):
     torch.cuda.synchronize()
     R0, T0 = scene.results_host()
     Ro0, _ = CM.rt_run(_oracle_model(vsm, model), CM.CoxMunkSurface(5.0), ss_correction=False)
-    assert _rel(R0, Ro0) < 1e-8 and np.array_equal(T0, T)
+    # (T is untouched by the TMS term; the traced run above walks the reference-layout layer loop, this one the native-layout run:
+    # the same operations in another summation order)
+    assert _rel(R0, Ro0) < 1e-8 and _rel(T0, T) < 1e-11
     assert np.all(R0[:, 0] > 0) and np.all(np.abs(R0[:, 1:]) <= R0[:, :1] + 1e-12)
     assert R0[6, 0, 0] > R0[2, 0, 0]      # vza 30 at vaz 0 looks into the glint of sza 30
 

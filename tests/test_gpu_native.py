@@ -1,0 +1,280 @@
+"""GPU parity tests of the native-layout run (vsm_run_*, csrc/vsm_native.hip): the layer loop of rt_run with the CompositeLayer in
+the layer kernels' strip layout and Stokes blocks that do not couple as independent sub-problems -- against the oracle
+(oracle/vsm_oracle.py, the restatement of rt_kernel.jl:175-250 / rt_helpers.jl:102-166 / interaction.jl:207-266), against the
+reference-layout layer loop (vsm_layer_forward_multi) and through the C ABI directly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from oracle import vsm_oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsm():
+    import vsmartmom_jl_amd as v
+    v._lib.lib()
+    return v
+
+
+@pytest.fixture(scope="module")
+def arch(vsm):
+    return vsm.Architectures.GPU(0)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _groups(ns, coupling):
+    import bench
+    return bench.stokes_groups(ns, coupling)
+
+
+@pytest.mark.parametrize("pol,ns", [("I", 1), ("IQ", 2), ("IQU", 3), ("IQUV", 4)])
+def test_stokes_coupling_of_the_fourier_moments(vsm, arch, pol, ns):
+    """vsm_stokes_coupling on the Z(m) the device builds (vsm_compute_Z_moments): for m = 0 no phase matrix couples (I,Q) with
+    (U,V) (compute_Z_matrices.jl:26-110; the oracle's Z has exact zeros there), for m >= 1 Rayleigh couples I, Q, U."""
+    H = vsm.host_model
+    S, L = 3, 2
+    model = H.model_from_arrays(arch, pol, 11, 40.0, [30.0], [0.0], tau_rayl=np.full((S, L), 0.1), tau_abs=np.full((S, L), 0.01),
+                                depol=0.03, albedo=0.1, m_max=2)
+    sc = vsm.CoreRT.prepare_scene(model)
+    assert sc.coupling is not None and len(sc.coupling) == 3
+    qp = O.rt_set_streams_gausslegquad(11, 40.0, [30.0], O.polarization(pol))
+    for m in range(3):
+        Zpp, Zmp = O.compute_Z_moments(O.polarization(pol), qp.qp_mu, O.get_greek_rayleigh(0.03), m)
+        want = 0
+        for a in range(ns):
+            for b in range(ns):
+                if np.any(Zpp[a::ns, b::ns] != 0) or np.any(Zmp[a::ns, b::ns] != 0):
+                    want |= 1 << (4 * a + b)
+        assert sc.coupling[m] == want, (m, hex(sc.coupling[m]), hex(want))
+        for g in _groups(ns, sc.coupling[m]):                       # no block mixes (I,Q) with (U,V) at m = 0
+            assert m > 0 or not (g & 0b0011 and g & 0b1100)
+    if ns >= 3:
+        assert len(_groups(ns, sc.coupling[0])) >= 2 and len(_groups(ns, sc.coupling[1])) < ns
+
+
+@pytest.mark.parametrize("ns,nq,coupling", [(3, 20, -1), (3, 20, 0x33 | 0x400), (4, 9, 0x33 | 0xCC00), (1, 7, -1), (3, 4, 0x33),
+                                             (4, 15, 0x8033), (2, 30, -1)])
+def test_native_layout_import_export_roundtrip(vsm, arch, ns, nq, coupling):
+    """vsm_run_import / vsm_run_export: reference layout -> native strips -> reference layout is the identity on composites whose
+    uncoupled blocks are zero (what a run under that coupling produces); the blocks between the groups come back as zeros."""
+    L = vsm._lib.lib()
+    N, S = ns * nq, 5
+    rng = np.random.default_rng(3)
+    dev = "cuda:0"
+    grp = _groups(ns, coupling)
+    same = np.zeros((ns, ns), dtype=bool)
+    for g in grp:
+        for a in range(ns):
+            for b in range(ns):
+                same[a, b] |= bool(g >> a & 1) and bool(g >> b & 1)
+    mask = np.tile(same, (nq, nq))                                    # [i, j]: rows / columns interleave the Stokes components
+    mats = [rng.standard_normal((S, N, N)) * mask.T[None] for _ in range(4)]   # device tensors hold [s, j, i]
+    vecs = [rng.standard_normal((S, N)) for _ in range(2)]
+    comp_in = vsm.CoreRT.make_composite_layer(np.float64, arch, (N, N), S)
+    comp_out = vsm.CoreRT.make_composite_layer(np.float64, arch, (N, N), S)
+    for t, a in zip((comp_in.R_mp, comp_in.R_pm, comp_in.T_pp, comp_in.T_mm, comp_in.J0_p, comp_in.J0_m), mats + vecs):
+        t.copy_(torch.as_tensor(a, device=dev))
+    for t in (comp_out.R_mp, comp_out.R_pm, comp_out.T_pp, comp_out.T_mm, comp_out.J0_p, comp_out.J0_m):
+        t.fill_(float("nan"))
+    assert L.vsm_run_supported_f64(N, ns, coupling) == 1
+    carr, marr = (C.c_int * 1)(coupling), (C.c_int * 1)(0)
+    nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, 1, carr))
+    assert nbytes > 0
+    ws = torch.full((nbytes // 8,), float("nan"), dtype=torch.float64, device=dev)
+    mu = torch.ones(N, dtype=torch.float64, device=dev)
+    q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), N, ns, 0, 1.0)
+    run = C.c_void_p()
+    vsm._lib.check(L.vsm_run_create_f64(C.byref(q), S, 1, marr, carr, C.c_void_p(ws.data_ptr()), nbytes, C.byref(run)))
+    try:
+        ci, co = (type(comp_in.cstruct()) * 1)(comp_in.cstruct()), (type(comp_out.cstruct()) * 1)(comp_out.cstruct())
+        vsm._lib.check(L.vsm_run_import_f64(run, ci, None))
+        vsm._lib.check(L.vsm_run_export_f64(run, co, None))
+        torch.cuda.synchronize()
+    finally:
+        L.vsm_run_destroy(run)
+    for name in ("R_mp", "R_pm", "T_pp", "T_mm", "J0_p", "J0_m"):
+        assert torch.equal(getattr(comp_in, name), getattr(comp_out, name)), name
+    assert bool(torch.isfinite(ws).all())           # every word of the native records was written (padding = zeros)
+
+
+def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
+    L = vsm._lib.lib()
+    assert L.vsm_run_supported_f64(80, 4, -1) == 0 and L.vsm_run_supported_f64(80, 4, 0x8033) == 1     # 40 + 20 + 20
+    assert L.vsm_run_supported_f64(63, 3, -1) == 0 and L.vsm_run_supported_f64(63, 3, 0x33) == 1        # 42 + 21
+    assert L.vsm_run_supported_f64(60, 3, -1) == 1 and L.vsm_run_supported_f64(61, 1, -1) == 0
+    assert L.vsm_run_workspace_bytes_f64(80, 4, 10, 1, (C.c_int * 1)(-1)) == 0
+    mu = torch.ones(80, dtype=torch.float64, device="cuda:0")
+    q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), 80, 4, 0, 1.0)
+    run = C.c_void_p()
+    ws = torch.zeros(16, dtype=torch.float64, device="cuda:0")
+    rc = L.vsm_run_create_f64(C.byref(q), 4, 1, (C.c_int * 1)(1), (C.c_int * 1)(-1), C.c_void_p(ws.data_ptr()), 128, C.byref(run))
+    assert rc == 2 and b"beyond the native kernels" in L.vsm_last_error()                                # VSM_ERR_UNSUPPORTED
+    q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), 60, 3, 0, 1.0)
+    rc = L.vsm_run_create_f64(C.byref(q), 4, 1, (C.c_int * 1)(1), (C.c_int * 1)(-1), C.c_void_p(ws.data_ptr()), 128, C.byref(run))
+    assert rc == 1 and b"workspace" in L.vsm_last_error()                                                # too small a workspace
+
+
+SHAPES = [("I", 3, 2), ("I", 9, 3), ("I", 21, 3), ("I", 33, 2), ("I", 55, 2), ("I", 85, 2), ("IQ", 21, 3), ("IQ", 53, 2),
+          ("IQU", 5, 4), ("IQU", 11, 3), ("IQU", 15, 3), ("IQU", 21, 3), ("IQU", 27, 2), ("IQU", 33, 3), ("IQU", 35, 3),
+          ("IQUV", 5, 2), ("IQUV", 11, 4), ("IQUV", 21, 3), ("IQUV", 25, 2), ("IQUV", 35, 2)]
+
+
+@pytest.mark.parametrize("pol,l_trunc,L", SHAPES)
+def test_native_run_vs_oracle_and_reference_layout_run(vsm, arch, monkeypatch, pol, l_trunc, L):
+    """rt_run through the native-layout run against the oracle (1e-8, the FP64 gate of every rt_run test here) and against the
+    reference-layout layer loop (the same operations in another summation order: 1e-10), for sub-problem sizes that land on every
+    row-tile count RT = 1..4, dense and split moments, two viewing angles that add zero-weight streams."""
+    H = vsm.host_model
+    rng = np.random.default_rng(17)
+    S = 11
+    tau_rayl = np.tile(np.linspace(0.02, 0.3, L), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0.5, (S, L))
+    F0 = np.zeros((O.polarization(pol).n, S))
+    F0[0] = 1.0 + 0.1 * rng.random(S)
+    if F0.shape[0] >= 3:
+        F0[1], F0[2] = 0.05 * rng.standard_normal(S), 0.04 * rng.standard_normal(S)      # a polarized beam drives the U block
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.2, m_max=2)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], **kw)
+    model.F0 = F0
+    ns = model.polarization_type.n
+    N = model.quad_points.Nquad * ns
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    sc = vsm.CoreRT.prepare_scene(model)
+    nat = sc._native_moments()
+    want = {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 60}
+    assert nat == want, (nat, want)
+    sc.run()
+    torch.cuda.synchronize()
+    vsm._lib.check_device_status("native run")
+    Rn, Tn = sc.results_host()
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", False)
+    Rl, Tl = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], **kw)
+    om.F0 = F0
+    Ro, To = O.rt_run(om)
+    assert np.all(np.isfinite(Rn)) and np.all(np.isfinite(Tn))
+    assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-8, (_rel(Rn, Ro), _rel(Tn, To))
+    assert _rel(Rn, Rl) < 1e-10 and _rel(Tn, Tl) < 1e-10, (_rel(Rn, Rl), _rel(Tn, Tl))
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("IQU", 21), ("I", 25)])
+def test_native_run_with_aerosols_mixed_per_point(vsm, arch, monkeypatch, pol, l_trunc):
+    """Two aerosols + Rayleigh: Z is mixed per spectral point inside the elemental pre-pass (types.jl:1262-1292), more Fourier
+    moments than one run takes per group (MOMENT_BATCH), layers with and without aerosol."""
+    H = vsm.host_model
+    rng = np.random.default_rng(23)
+    S, L = 6, 4
+    kw = dict(tau_rayl=np.tile(np.array([0.03, 0.05, 0.1, 0.2]), (S, 1)), tau_abs=10.0 ** rng.uniform(-3, 0, (S, L)), depol=0.03,
+              albedo=0.1, m_max=6, tau_aer=np.array([[0.0, 0.0, 0.2, 0.1], [0.03, 0.0, 0.1, 0.3]]))
+    aer = lambda M: [M.AerosolOptics(M.GreekCoefs(**vars(O.hg_greek(0.7, 12))), 0.95, 0.1),
+                     M.AerosolOptics(M.GreekCoefs(**vars(O.hg_greek(0.5, 8))), 0.9, 0.0)]
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0], [0.0], aerosol_optics=aer(H), **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    sc = vsm.CoreRT.prepare_scene(model)
+    assert len(sc._native_moments()) == 7
+    sc.run()
+    torch.cuda.synchronize()
+    Rn, Tn = sc.results_host()
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", False)
+    Rl, Tl = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    om = O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], aerosols=[O.AerosolOptics(O.hg_greek(0.7, 12), 0.95, 0.1),
+                                                                   O.AerosolOptics(O.hg_greek(0.5, 8), 0.9, 0.0)], **kw)
+    Ro, To = O.rt_run(om)
+    assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-8, (_rel(Rn, Ro), _rel(Tn, To))
+    assert _rel(Rn, Rl) < 1e-10 and _rel(Tn, Tl) < 1e-10
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("IQU", 15), ("I", 21), ("IQUV", 21)])
+def test_native_run_thick_layers_series_orders_and_pivoted_inverse(vsm, arch, monkeypatch, pol, l_trunc):
+    """Thick near-conservative layers over a bright surface: the last doublings and the interactions leave the Horner orders
+    (1..8) for the long series (15, 16, 31) and the pivoted Gauss-Jordan inverse (the contract of the reference's LU,
+    cpu_batched.jl:32-47); vsm_device_status counts the pivoted inverses and raises no flag."""
+    H = vsm.host_model
+    rng = np.random.default_rng(29)
+    S = 5
+    tau_rayl = np.tile(np.array([0.5, 4.0, 30.0]), (S, 1))
+    tau_abs = np.tile(np.array([1e-4, 1e-5, 1e-6]), (S, 1)) * (1 + rng.random((S, 1)))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.6, m_max=2)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0], [0.0], **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    Rn, Tn = vsm.CoreRT.rt_run(model)
+    st = list(vsm._lib.last_device_status)
+    assert st[0] == 0 and st[1] > 0, st
+    Ro, To = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], **kw))
+    assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-7, (_rel(Rn, Ro), _rel(Tn, To))    # (T: e^-34 of the beam; the legacy path: the same)
+
+
+def test_native_run_moment_by_moment_equals_grouped(vsm, arch, monkeypatch):
+    """The moments of a run are independent sub-problems: walking them one by one gives the bits of the grouped walk."""
+    H = vsm.host_model
+    rng = np.random.default_rng(31)
+    S, L = 8, 3
+    kw = dict(tau_rayl=np.full((S, L), 0.08), tau_abs=10.0 ** rng.uniform(-3, 0, (S, L)), depol=0.03, albedo=0.3, m_max=2)
+    model = H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], **kw)
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", True)
+    a = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", False)
+    b = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "MOMENT_BATCHING", True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_native_run_layer_by_layer_through_the_c_abi(vsm, arch):
+    """vsm_run_create / vsm_run_layer / vsm_run_export called directly, exporting after EVERY layer step: the composite equals the
+    oracle's CompositeLayer layer by layer (rt_kernel.jl:175-250: TOA copy, then interaction!(_11)), matrices and source vectors,
+    with NaN-poisoned workspace."""
+    H, L = vsm.host_model, vsm._lib.lib()
+    rng = np.random.default_rng(37)
+    S, Nz = 4, 3
+    kw = dict(tau_rayl=np.tile(np.array([0.05, 0.1, 0.3]), (S, 1)), tau_abs=10.0 ** rng.uniform(-3, 0, (S, Nz)), depol=0.03,
+              albedo=0.0, m_max=1)
+    model = H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], **kw)
+    sc = vsm.CoreRT.prepare_scene(model)
+    N, ns = sc.N, 3
+    om = O.build_model("IQU", 35, 40.0, [30.0], [0.0], **kw)
+    pol, qp = om.pol, om.quad_points
+    FT = np.float64
+    F0 = np.zeros((ns, S))
+    F0[0] = 1.0
+    for im in (0, 1):
+        mom = sc.moments[im]
+        carr, marr = (C.c_int * 1)(int(sc.coupling[im])), (C.c_int * 1)(im)
+        nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, 1, carr))
+        ws = torch.full((nbytes // 8,), float("nan"), dtype=torch.float64, device="cuda:0")
+        q = sc.dq.cstruct()
+        run = C.c_void_p()
+        vsm._lib.check(L.vsm_run_create_f64(C.byref(q), S, 1, marr, carr, C.c_void_p(ws.data_ptr()), nbytes, C.byref(run)))
+        lods = O.construct_core_optical_properties(om, im)
+        ifaces, tau_sum_all = O.extract_effective_props(lods, FT)
+        added, comp_o = O.make_added_layer(FT, N, S), O.make_composite_layer(FT, N, S)
+        comp = vsm.CoreRT.make_composite_layer(FT, arch, (N, N), S)
+        try:
+            for iz in range(Nz):
+                ly = mom["layers"][iz]
+                p = ly["props"]
+                zpp, zmp = (C.c_void_p * 1)(p.Zpp.data_ptr()), (C.c_void_p * 1)(p.Zmp.data_ptr())
+                vsm.CoreRT.run_layer_native_(run, 1, int(ly["nd"]), ly["dtau"], p.varpi, ly["tau_sum"], sc.F0, 0, zpp, zmp,
+                                             p.z_stride, None, iz == 0)
+                cc = (type(comp.cstruct()) * 1)(comp.cstruct())
+                vsm._lib.check(L.vsm_run_export_f64(run, cc, None))
+                torch.cuda.synchronize()
+                props = O.expand_optical_properties(lods[iz], FT)
+                O.rt_kernel(pol, added, comp_o, props, ifaces[iz], tau_sum_all[:, iz].astype(FT), im, qp, iz + 1, F0, FT)
+                for name in ("R_mp", "R_pm", "T_pp", "T_mm"):
+                    got = vsm.CoreRT.from_device_matrix(getattr(comp, name))
+                    assert _rel(got, getattr(comp_o, name)) < 1e-10, (im, iz, name, _rel(got, getattr(comp_o, name)))
+                for name in ("J0_p", "J0_m"):
+                    got = vsm.Architectures.to_host(getattr(comp, name))
+                    ref = np.asarray(getattr(comp_o, name)).reshape(S, N)
+                    assert _rel(got, ref) < 1e-10, (im, iz, name)
+        finally:
+            L.vsm_run_destroy(run)

@@ -318,6 +318,13 @@ def layer_forward_multi_(tau_sum, dtau, F0, props_list, ms, ndoubl: int, dq: Dev
               carr, C.byref(a), _stream_ptr())
 
 
+def run_layer_native_(run, nm: int, ndoubl: int, dtau, varpi, tau_sum, F0, ncomp: int, zpp, zmp, z_stride: int, fcomp, toa: bool):
+    """rt_kernel!(::noRS) of one scattering layer for the nm Fourier moments of a native-layout run (vsm_run_layer: per class of
+    sub-problems the elemental pre-pass and ONE layer launch); zpp / zmp: ctypes arrays of the moments' Z device pointers."""
+    _lib.check(_lib.lib().vsm_run_layer_f64(run, ndoubl, _ptr(dtau), _ptr(varpi), _ptr(tau_sum), _ptr(F0), ncomp, zpp, zmp,
+                                            z_stride, _ptr(fcomp), 1 if toa else 0, _stream_ptr()))
+
+
 def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False,
                  work: Optional[torch.Tensor] = None):
     """interaction! (interaction.jl:268-285).  `oplevel=True` forces the operator-for-operator path
@@ -851,9 +858,8 @@ class Scene:
                 zpp = (C.c_void_p * nm)(*[p.Zpp.data_ptr() for p in props])
                 zmp = (C.c_void_p * nm)(*[p.Zmp.data_ptr() for p in props])
                 ncomp = 0 if p0.fcomp is None else int(p0.fcomp.shape[1])
-                _lib.check(L.vsm_run_layer_f64(run, int(ly0["nd"]), _ptr(ly0["dtau"]), _ptr(p0.varpi), _ptr(ly0["tau_sum"]),
-                                               _ptr(self.F0), ncomp, zpp, zmp, 0 if ncomp else p0.z_stride, _ptr(p0.fcomp),
-                                               1 if iz == 0 else 0, _stream_ptr()))
+                run_layer_native_(run, nm, int(ly0["nd"]), ly0["dtau"], p0.varpi, ly0["tau_sum"], self.F0, ncomp, zpp, zmp,
+                                  0 if ncomp else p0.z_stride, p0.fcomp, iz == 0)
             cc = (type(comps[0].cstruct()) * nm)(*[c.cstruct() for c in comps])
             _lib.check(L.vsm_run_export_f64(run, cc, _stream_ptr()))
         finally:
