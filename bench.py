@@ -280,13 +280,26 @@ def main():
         interval_kernels = ["k_elemental_native", kernel_name]
         moments_per_launch = len(dense)
         n_launch = len(ev_dense)
-        # executed products of the whole layer step: a block of n rows costs (n / N)^3 of the dense count
-        ex = sum(sum((scene.N // scene.pol.n * bin(g).count("1") / float(N)) ** 3 for g in stokes_groups(scene.pol.n, scene.coupling[scene.moments[i]["m"]]))
-                 for i in native) + (len(scene.moments) - len(native))
-        layer_step["executed_over_algorithmic_flops"] = ex / len(scene.moments)
-        layer_step["frac_of_mfma_peak_executed"] = layer_step["frac_of_mfma_peak_algorithmic"] * ex / len(scene.moments)
-        layer_step["note"] = ("blocks of Stokes components that do not couple (m = 0: (I,Q) and U) run as independent sub-problems; "
-                              "products with exact zeros are not formed")
+        # executed products of the layer steps: a block of n rows costs (n / N)^3 of the dense count, a block that the phase
+        # matrices of a layer leave exactly zero costs none (an elementwise scaling of the composite)
+        ex_num = ex_den = 0.0
+        for i, mom in enumerate(scene.moments):
+            for iz, ly in enumerate(mom["layers"]):
+                wl = ly["nd"] * (12 * n3 + 8 * n2) + (24 * n3 + 8 * n2 if iz else 0.0)
+                ex_den += wl
+                if i not in native:
+                    ex_num += wl
+                    continue
+                lc = scene._layer_coupling(mom["m"], iz)
+                for g in stokes_groups(scene.pol.n, scene.coupling[mom["m"]]):
+                    comps = [a for a in range(scene.pol.n) if g >> a & 1]
+                    if any(lc >> (4 * a + b) & 1 for a in comps for b in comps):
+                        ex_num += wl * (scene.N // scene.pol.n * len(comps) / float(N)) ** 3
+        layer_step["executed_over_algorithmic_flops"] = ex_num / ex_den
+        layer_step["frac_of_mfma_peak_executed"] = layer_step["frac_of_mfma_peak_algorithmic"] * ex_num / ex_den
+        layer_step["note"] = ("blocks of Stokes components that do not couple (m = 0: (I,Q) and U) run as independent sub-problems, a "
+                              "block whose phase matrix is exactly zero in a layer takes a diagonal step: products with exact "
+                              "zeros are not formed")
     else:
         k_ms, k_flops, n_launch = step_ms, step_flops(ev), len(ev)
         moments_per_launch = max([e[4] for e in ev], default=1)

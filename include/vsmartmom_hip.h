@@ -579,8 +579,13 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
  * couple run as independent sub-problems (for m = 0 every phase matrix has exactly zero (I,Q) x (U,V) blocks,
  * src/Scattering/compute_Z_matrices.jl:26-110: N = 60, n_stokes = 3 runs as 40 x 40 + 20 x 20) -- products with exact zeros are
  * not formed, results are those of the dense run.  The mask MUST cover every Z later handed to vsm_run_layer:
- * vsm_stokes_coupling_f64 computes it on the device over a stack of `nblocks` matrices (mask_d: one DEVICE int, written
- * asynchronously on `stream`); OR the masks of all scatterers of a moment.  Every block of coupled components must fit the native
+ * vsm_stokes_coupling_f64 computes one mask per matrix of a stack of `nblocks` matrices on the device (mask_d[nblocks]: DEVICE
+ * ints, written asynchronously on `stream`); OR the masks of all scatterers of a moment.
+ * `layer_coupling_h[nm]` of vsm_run_layer (NULL = the run's) is the same mask for the phase matrices of THIS layer (the OR over the
+ * scatterers present in it): a block the layer's phase matrices leave exactly zero (U at m = 0 in a Rayleigh layer; any block of
+ * a Rayleigh-only layer at m >= 3, where the Rayleigh phase matrix vanishes) has r = 0, j = 0, t = diag(exp(-tau / mu)) and its
+ * interaction is a scaling of the composite's rows and columns -- one elementwise pass instead of the products.
+ * Every block of coupled components must fit the native
  * kernels: (N / n_stokes) * (components in the block) <= 60 (vsm_run_supported_f64 != 0), else VSM_ERR_UNSUPPORTED.
  * Stream: see Conventions; library scratch (the pre-pass images of the layer). */
 typedef struct vsm_run vsm_run;
@@ -590,7 +595,7 @@ int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m_h, con
                        size_t workspace_bytes, vsm_run** run);
 int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum,
                       const double* F0, int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride,
-                      const double* fcomp, int toa, void* stream);
+                      const double* fcomp, int toa, const int* layer_coupling_h, void* stream);
 int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
 int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
 int vsm_run_destroy(vsm_run* run);

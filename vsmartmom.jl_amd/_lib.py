@@ -141,7 +141,7 @@ _SIGS = {
     "vsm_run_supported_f64": (_I, [_I, _I, _I]),
     "vsm_run_workspace_bytes_f64": (_SZ, [_I, _I, _I, _I, _P]),
     "vsm_run_create_f64": (_I, [_P, _I, _I, _P, _P, _P, _SZ, _P]),
-    "vsm_run_layer_f64": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P]),
+    "vsm_run_layer_f64": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
     "vsm_run_export_f64": (_I, [_P, _P, _P]),
     "vsm_run_import_f64": (_I, [_P, _P, _P]),
     "vsm_run_destroy": (_I, [_P]),

@@ -318,11 +318,13 @@ def layer_forward_multi_(tau_sum, dtau, F0, props_list, ms, ndoubl: int, dq: Dev
               carr, C.byref(a), _stream_ptr())
 
 
-def run_layer_native_(run, nm: int, ndoubl: int, dtau, varpi, tau_sum, F0, ncomp: int, zpp, zmp, z_stride: int, fcomp, toa: bool):
+def run_layer_native_(run, nm: int, ndoubl: int, dtau, varpi, tau_sum, F0, ncomp: int, zpp, zmp, z_stride: int, fcomp, toa: bool,
+                      layer_coupling=None):
     """rt_kernel!(::noRS) of one scattering layer for the nm Fourier moments of a native-layout run (vsm_run_layer: per class of
-    sub-problems the elemental pre-pass and ONE layer launch); zpp / zmp: ctypes arrays of the moments' Z device pointers."""
+    sub-problems the elemental pre-pass and ONE layer launch); zpp / zmp: ctypes arrays of the moments' Z device pointers;
+    layer_coupling: ctypes int array, per moment the Stokes coupling mask of THIS layer's phase matrices (None: the run's)."""
     _lib.check(_lib.lib().vsm_run_layer_f64(run, ndoubl, _ptr(dtau), _ptr(varpi), _ptr(tau_sum), _ptr(F0), ncomp, zpp, zmp,
-                                            z_stride, _ptr(fcomp), 1 if toa else 0, _stream_ptr()))
+                                            z_stride, _ptr(fcomp), 1 if toa else 0, layer_coupling, _stream_ptr()))
 
 
 def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False,
@@ -740,18 +742,27 @@ class Scene:
         self._assemble(nds, tags, maxima)
 
     def _compute_coupling(self):
-        """Which Stokes components the phase matrices of each Fourier moment couple (vsm_stokes_coupling over the stack of ALL
-        scatterers of the moment): components that do not couple walk the layers as independent sub-problems (vsm_run_*; for
-        m = 0 the (I,Q) x (U,V) blocks of every phase matrix are exactly zero, compute_Z_matrices.jl:26-110)."""
-        self.coupling = None
+        """Which Stokes components the phase matrix of each scatterer couples, per Fourier moment (vsm_stokes_coupling: one mask
+        per block of the Z stacks): components that no scatterer of the run couples walk the layers as independent sub-problems
+        (vsm_run_*; for m = 0 the (I,Q) x (U,V) blocks of every phase matrix are exactly zero, compute_Z_matrices.jl:26-110), and
+        a block that the scatterers of ONE layer leave exactly zero takes that layer as a diagonal step."""
+        self.coupling = self.coupling_comp = None
         if self.dt != torch.float64:
             return
+        C_ = int(self.Zc[0][0].shape[0])
         if getattr(self, "_coupling_d", None) is None:
-            self._coupling_d = torch.zeros(len(self.Zc), dtype=torch.int32, device=self.dev)
+            self._coupling_d = torch.zeros((len(self.Zc), C_), dtype=torch.int32, device=self.dev)
         for m, (Zpp, Zmp) in enumerate(self.Zc):
-            _lib.check(_lib.lib().vsm_stokes_coupling_f64(self.N, self.pol.n, int(Zpp.shape[0]), _ptr(Zpp), _ptr(Zmp),
-                                                          C.c_void_p(self._coupling_d[m:].data_ptr()), _stream_ptr()))
-        self.coupling = [int(v) for v in self._coupling_d.cpu().numpy()]
+            _lib.check(_lib.lib().vsm_stokes_coupling_f64(self.N, self.pol.n, C_, _ptr(Zpp), _ptr(Zmp),
+                                                          C.c_void_p(self._coupling_d[m].data_ptr()), _stream_ptr()))
+        self.coupling_comp = self._coupling_d.cpu().numpy().astype(np.int64)             # [moment, scatterer]
+        self.coupling = [int(np.bitwise_or.reduce(row)) for row in self.coupling_comp]    # per moment: every scatterer of the run
+
+    def _layer_coupling(self, m, iz):
+        """The coupling mask of the phase matrices of layer iz at moment m: the scatterers present in the layer."""
+        mixed, k = self.zcomp[iz]
+        row = self.coupling_comp[m]
+        return int(np.bitwise_or.reduce(row)) if mixed else int(row[k])
 
     def run(self, trace: Optional[list] = None, streams: Optional[list] = None):
         """The device-resident part of rt_run (rt_run.jl:383-517): Fourier loop -> layer loop ->
@@ -858,8 +869,9 @@ class Scene:
                 zpp = (C.c_void_p * nm)(*[p.Zpp.data_ptr() for p in props])
                 zmp = (C.c_void_p * nm)(*[p.Zmp.data_ptr() for p in props])
                 ncomp = 0 if p0.fcomp is None else int(p0.fcomp.shape[1])
+                lc = (C.c_int * nm)(*[self._layer_coupling(mom["m"], iz) for mom in group])
                 run_layer_native_(run, nm, int(ly0["nd"]), ly0["dtau"], p0.varpi, ly0["tau_sum"], self.F0, ncomp, zpp, zmp,
-                                  0 if ncomp else p0.z_stride, p0.fcomp, iz == 0)
+                                  0 if ncomp else p0.z_stride, p0.fcomp, iz == 0, lc)
             cc = (type(comps[0].cstruct()) * nm)(*[c.cstruct() for c in comps])
             _lib.check(L.vsm_run_export_f64(run, cc, _stream_ptr()))
         finally:

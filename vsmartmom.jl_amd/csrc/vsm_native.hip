@@ -585,18 +585,72 @@ __global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map
   }
 }
 
-// Which Stokes components the phase matrices couple: bit 4 a + b of *mask is set when some element (i, j) with i % ns == a,
-// j % ns == b of any of the nblocks matrices Zpp / Zmp [N,N,nblocks] is not exactly zero.
-__global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, int nblocks, const double* __restrict__ Zpp,
+// Which Stokes components a phase matrix couples: bit 4 a + b of mask[b] is set when some element (i, j) with i % ns == a,
+// j % ns == b of block b of Zpp / Zmp [N,N,nblocks] is not exactly zero.
+__global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, const double* __restrict__ Zpp,
                                                          const double* __restrict__ Zmp, int* __restrict__ mask) {
   unsigned mm = 0;
-  const long long tot = (long long)N * N * nblocks;
-  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < tot; e += 256ll * gridDim.x) {
-    const int ij = (int)(e % ((long long)N * N));
-    const int i = ij % N, j = ij / N;
-    if (Zpp[e] != 0.0 || Zmp[e] != 0.0) mm |= 1u << (4 * (i % ns) + (j % ns));
+  const long long NN = (long long)N * N;
+  const double* zp = Zpp + NN * blockIdx.y;
+  const double* zm = Zmp + NN * blockIdx.y;
+  for (long long e = blockIdx.x * 256ll + threadIdx.x; e < NN; e += 256ll * gridDim.x) {
+    const int i = (int)(e % N), j = (int)(e / N);
+    if (zp[e] != 0.0 || zm[e] != 0.0) mm |= 1u << (4 * (i % ns) + (j % ns));
   }
-  if (mm) atomicOr(mask, (int)mm);
+  if (mm) atomicOr(mask + blockIdx.y, (int)mm);
+}
+
+// A layer step of a sub-problem whose block of the phase matrix is exactly zero in this layer (a Stokes block that nothing
+// scatters into -- U at m = 0 in a Rayleigh atmosphere --, a Rayleigh layer at m >= 3): elemental! gives r = 0, j = 0,
+// t = diag(e^{-dtau / mu_i}), doubling! squares t (rt_helpers.jl:102-166 with r = 0: G = I, t' = t t), and
+// interaction!(_11) with r-+ = r+- = 0, j0 = 0 (interaction.jl:207-266: T01 = T--, T21 = t++) scales the composite:
+//   T++ <- t T++,  T-- <- T-- t,  R+- <- t R+- t,  J0+ <- t J0+;   R-+, J0- unchanged.
+// t = e^{-dtau 2^nd / mu_i} here (the doubled layer in one exponential).  One workgroup per (point, sub-problem) over the native
+// records: element (i, j) from its position.  TOA: the composite is the layer itself (R = 0, T = diag(t), J = 0).
+struct ndiag_args {
+  double* comp[NSUB_MAX];
+  int gsz[NSUB_MAX];
+  int g0[NSUB_MAX];    // the group's Stokes components, 4 bits each
+};
+__global__ __launch_bounds__(256) void k_native_diag_layer(quad<double> q, int rt, int n, double scale, int toa,
+                                                           const double* __restrict__ dtau, ndiag_args a) {
+  __shared__ double tt[64];
+  const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
+  const int np = 16 * rt, af = np * np, gsz = a.gsz[isub];
+  double* comp = a.comp[isub] + (long long)s * (4 * af + 2 * np);
+  if (tid < np) {
+    double t = 0.0;
+    if (tid < n) {
+      const int fr = (tid / gsz) * q.n_stokes + ((a.g0[isub] >> (4 * (tid % gsz))) & 15);
+      t = exp(-dtau[s] * scale / q.mu[fr]);
+    }
+    tt[tid] = t;
+  }
+  __syncthreads();
+  for (int e = tid; e < af; e += 256) {
+    const int half = e & 1, lane = (e >> 1) & 63, unit = (e >> 7) % (2 * rt), w = (e >> 7) / (2 * rt);
+    const int i = 16 * (unit >> 1) + (lane >> 4) + 4 * (2 * (unit & 1) + half), j = 16 * w + (lane & 15);
+    const double ti = tt[i], tj = tt[j];
+    if (toa) {
+      const double d = (i == j) ? ti : 0.0;
+      comp[NC_RMP * af + e] = 0.0;
+      comp[NC_RPM * af + e] = 0.0;
+      comp[NC_TPP * af + e] = d;
+      comp[NC_TMM * af + e] = d;
+    } else {
+      comp[NC_RPM * af + e] *= ti * tj;
+      comp[NC_TPP * af + e] *= ti;
+      comp[NC_TMM * af + e] *= tj;
+    }
+  }
+  if (tid < np) {
+    if (toa) {
+      comp[4 * af + tid] = 0.0;
+      comp[4 * af + np + tid] = 0.0;
+    } else {
+      comp[4 * af + tid] *= tt[tid];
+    }
+  }
 }
 
 }  // namespace
@@ -820,26 +874,54 @@ int vsm_run_destroy(vsm_run* run) {
 
 int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum, const double* F0,
                       int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
-                      int toa, void* stream) {
+                      int toa, const int* layer_coupling, void* stream) {
   VSM_REQUIRE(run && dtau && varpi && tau_sum && F0 && Zpp && Zmp, "vsm_run_layer: null argument");
-  VSM_REQUIRE(ndoubl >= 0 && ncomp >= 0 && ncomp <= 4 && (ncomp == 0 || fcomp), "vsm_run_layer: bad ndoubl / component mix");
+  VSM_REQUIRE(ndoubl >= 0 && ndoubl < 60 && ncomp >= 0 && ncomp <= 4 && (ncomp == 0 || fcomp), "vsm_run_layer: bad ndoubl / component mix");
   if (run->S == 0) return VSM_OK;
   hipStream_t st = as_stream(stream);
   int* status = device_status();
   if (!status) return VSM_ERR_HIP;
+  // a sub-problem whose Stokes block the layer's phase matrices leave exactly zero takes the diagonal step
+  auto trivial = [&](const nat_sub& sb) {
+    if (!layer_coupling || layer_coupling[sb.im] < 0) return false;
+    for (int a = 0; a < sb.gsz; ++a)
+      for (int b = 0; b < sb.gsz; ++b)
+        if ((layer_coupling[sb.im] >> (4 * sb.g[a] + sb.g[b])) & 1) return false;
+    return true;
+  };
   // the pre-pass images of the layer: one record per (sub-problem, point)
   size_t pre_total = 0;
-  for (const nat_sub& sb : run->subs) pre_total += pre_stride_rt(sb.rt) * (size_t)run->S;
-  double* pre = static_cast<double*>(scratch(pre_total * sizeof(double), 3, st));
-  if (!pre) return VSM_ERR_HIP;
+  for (const nat_sub& sb : run->subs)
+    if (!trivial(sb)) pre_total += pre_stride_rt(sb.rt) * (size_t)run->S;
+  double* pre = nullptr;
+  if (pre_total) {
+    pre = static_cast<double*>(scratch(pre_total * sizeof(double), 3, st));
+    if (!pre) return VSM_ERR_HIP;
+  }
   size_t off = 0;
   for (const auto& cl : run->classes) {
     const nat_sub& h = run->subs[cl[0]];
-    const int nsub = (int)cl.size();
+    std::vector<int> act, triv;
+    for (int i : cl) (trivial(run->subs[i]) ? triv : act).push_back(i);
+    if (!triv.empty()) {
+      ndiag_args da;
+      const int nt = (int)triv.size();
+      for (int k = 0; k < NSUB_MAX; ++k) {
+        const nat_sub& sb = run->subs[triv[k < nt ? k : 0]];
+        da.comp[k] = run->ws + sb.comp_off;
+        da.gsz[k] = sb.gsz;
+        da.g0[k] = sb.g[0] | (sb.g[1] << 4) | (sb.g[2] << 8) | (sb.g[3] << 12);
+      }
+      hipLaunchKernelGGL(k_native_diag_layer, dim3(run->S, nt), dim3(256), 0, st, run->q, h.rt, h.n, ldexp(1.0, ndoubl), toa, dtau,
+                         da);
+      VSM_LAUNCH_CHECK("k_native_diag_layer");
+    }
+    const int nsub = (int)act.size();
+    if (!nsub) continue;
     npre_args pa;
     nlayer_comps lc;
     for (int k = 0; k < NSUB_MAX; ++k) {
-      const nat_sub& sb = run->subs[cl[k < nsub ? k : 0]];
+      const nat_sub& sb = run->subs[act[k < nsub ? k : 0]];
       pa.s[k].m = sb.m;
       pa.s[k].gsz = sb.gsz;
       for (int a = 0; a < 4; ++a) pa.s[k].g[a] = sb.g[a];
@@ -891,13 +973,13 @@ int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* strea
 }
 
 int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream) {
-  VSM_REQUIRE(N > 0 && n_stokes >= 1 && n_stokes <= 4 && N % n_stokes == 0 && nblocks >= 1 && Zpp && Zmp && mask_d,
-              "vsm_stokes_coupling: bad argument");
+  VSM_REQUIRE(N > 0 && n_stokes >= 1 && n_stokes <= 4 && N % n_stokes == 0 && nblocks >= 1 && nblocks <= 65535 && Zpp && Zmp &&
+                  mask_d, "vsm_stokes_coupling: bad argument");
   hipStream_t st = as_stream(stream);
-  VSM_HIP(hipMemsetAsync(mask_d, 0, sizeof(int), st));
-  const long long tot = (long long)N * N * nblocks;
-  const int blocks = (int)((tot + 255) / 256 < 64 ? (tot + 255) / 256 : 64);
-  hipLaunchKernelGGL(k_stokes_coupling, dim3(blocks), dim3(256), 0, st, N, n_stokes, nblocks, Zpp, Zmp, mask_d);
+  VSM_HIP(hipMemsetAsync(mask_d, 0, sizeof(int) * nblocks, st));
+  const long long tot = (long long)N * N;
+  const int blocks = (int)((tot + 255) / 256 < 16 ? (tot + 255) / 256 : 16);
+  hipLaunchKernelGGL(k_stokes_coupling, dim3(blocks, nblocks), dim3(256), 0, st, N, n_stokes, Zpp, Zmp, mask_d);
   VSM_LAUNCH_CHECK("k_stokes_coupling");
   return VSM_OK;
 }
