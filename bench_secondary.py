@@ -2,15 +2,17 @@
 configurations that fit one GPU, so that their figures are driver-timed and not only builder-run (tools/*.py):
 
   C4      forward, N = 96 FP32, 60 layers, 12 500 points (one GPU's share of configs[3])
-  C2-lin  rt_run(model, lin_model, 0, 1, 1) on the C2 shape (1 gas column + albedo), 2 000 points
+  C2-aer  the SURVEY 8(d) aerosol variant of C2 (HG aerosol in the lowest 6 layers, per-point Z, m = 0..35), 10 000 points
+  C2-lin  rt_run(model, lin_model, 0, 1, 1) on the C2 shape (1 gas column + albedo), 2 048 points; C2-lin-10k: 10 000 points
   C3-lin  the ocean / Cox-Munk scene of config/ocean_coxmunk.yaml (IQUV, N = 60, 33 layers, 2 points, m = 0..21), linearized
-  C5      rotational Raman, N = 21, 12 layers, K = 40 lines, 4 000 points (configs[4] at a fifth of its spectral axis)
+  C5      rotational Raman, N = 21, 12 layers, K = 40 lines, 4 000 points (configs[4] at a fifth of its spectral axis);
+          C5-10k: 10 000 points (one GPU's share of the 2-GPU configs[4])
   C1      quickstart-shaped (config/quickstart.yaml: Stokes_I, nstreams = 3, Rayleigh, Lambertian 0.15; BASELINE configs[0]:
           ~10 layers, ~100 spectral points): the WHOLE rt_run(model) call -- host model / optics, scene allocation, H2D, device
           pass, D2H (north_star: >= 10^4 spectral-points/s on quickstart-shaped atmospheres)
   IA      the interaction kernel in isolation: interaction!(::ScatteringInterface_11), N = 60 FP64, 10 240 points
           (k_ia_strip<15>; north_star: >= 40 % MFMA utilisation in the interaction kernel -- inside the headline it is part of
-          the fused layer kernel)
+          the fused layer kernel); IA-long: the same at 4 x the reflectances (series orders >= 15: the out-of-line inverse)
   N112    forward run at the reference's VLIDORT case-A size (test/vlidort_baseline/cases/case_A_siewert2000.jl:29-50:
           IQUV, N = 112), 2 000 points, 10 layers: the k_dbl128 / k_ia128 family
 
@@ -77,7 +79,7 @@ def c4(vsm, torch, arch, o2a, points=12500):
     return e
 
 
-def c2_lin(vsm, torch, arch, o2a, points=2048):   # (24 full rounds of 256 single-workgroup CUs per layer launch: 3 moments x 2048)
+def c2_lin(vsm, torch, arch, o2a, points=2048, name="C2-lin"):   # (2048: 24 full rounds of 256 single-workgroup CUs per layer launch)
     L = 40
     tau_rayl, tau_abs = o2a(points, L)
     H = vsm.host_model
@@ -90,8 +92,44 @@ def c2_lin(vsm, torch, arch, o2a, points=2048):   # (24 full rounds of 256 singl
         scene.run()
         return scene.results_host()
     wall, dev, _ = _timed(torch, step)
-    e = _entry("C2-lin", "linearized rt_run (1 gas column + albedo), N=60 FP64, 40 layers, m=0..2 (C2 shape)", points, wall, dev,
+    e = _entry(name, "linearized rt_run (1 gas column + albedo), N=60 FP64, 40 layers, m=0..2 (C2 shape)", points, wall, dev,
                scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia128_lin<4>)")
+    # the as-written count runs every parameter slot through every interaction (interaction_lin.jl:242,291); the surface slot of a
+    # layer interaction is exact zeros and is not computed (vsm_interaction_lin_range): flops of the products that are formed
+    N = float(scene.N)
+    skipped = sum(len(mom["layers"]) - 1 for mom in scene.fwd.moments) * (scene.P - scene.pl) * (48 * N ** 3 + 16 * N ** 2)
+    e["frac_of_mfma_peak_executed_products"] = (scene.flops_per_point() - skipped) * points / wall / 1e12 / PEAK["f64"]
+    del scene
+    return e
+
+
+def c2_aer(vsm, torch, arch, o2a, points=10000):
+    """SURVEY 8(d) aerosol variant of C2: HG aerosol (g = 0.7, ssa = 0.95, tau = 0.2) in the lowest 6 layers, Z mixed per spectral
+    point, all 2 nstreams = 36 Fourier moments (bench.py --variant aerosol); the full step of the headline."""
+    L, l_trunc = 40, 35
+    tau_rayl, tau_abs = o2a(points, L)
+    Hm = vsm.host_model
+    nstreams = (l_trunc + 2) // 2
+    tau_aer = np.zeros((1, L))
+    tau_aer[0, -6:] = 0.2 / 6.0
+    model = Hm.model_from_arrays(arch, "IQU", l_trunc, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279, albedo=0.15,
+                                 m_max=2 * nstreams - 1, tau_aer=tau_aer,
+                                 aerosol_optics=[Hm.AerosolOptics(Hm.henyey_greenstein_greek(0.7, 2 * nstreams - 1), 0.95, 0.0)])
+    scene = vsm.CoreRT.prepare_scene(model)
+
+    def step():
+        scene.upload()
+        scene.prepare()
+        R, T = scene.run()
+        return R.cpu(), T.cpu()
+    wall, dev, _ = _timed(torch, step)
+    nds = [ly["nd"] for ly in scene.moments[0]["layers"]]
+    e = _entry("C2-aer", "C2 with the HG aerosol of SURVEY 8(d) in the lowest 6 layers: Z mixed per point, m=0..%d, ndoubl %d..%d; N=60 "
+               "FP64, 40 layers; full step (H2D + device optics + run + D2H)" % (model.m_max, min(nds), max(nds)), points, wall, dev,
+               scene.flops_per_point(), "f64", "k_layer_native<4, 15> (m = 1, 2), k_layer_native<3, 10> / <2, 5> (blocks of m = 0 and of "
+               "the aerosol layers at m >= 3), k_native_diag_layer (Rayleigh-only layers at m >= 3: the Rayleigh phase matrix vanishes)")
+    e["note"] = ("frac_of_mfma_peak counts the as-written dense 60 x 60 products of all 36 moments x 40 layers (SURVEY 8d); the run forms "
+                 "only the products whose Stokes block the layer's phase matrices do not leave exactly zero")
     del scene
     return e
 
@@ -122,7 +160,7 @@ def c3_lin(vsm, torch, arch):
     return e
 
 
-def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
+def c5(vsm, torch, arch, points=4000, lines=40, layers=12, name="C5"):
     rng = np.random.default_rng(20260929)
     S, K, L = points, lines, layers
     dp = np.full(L, 1.0 / L)
@@ -145,13 +183,13 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12):
     # step; interaction_inelastic.jl:319-521: 18 products + 8 mat-vecs); the kernels execute 10 and 9 products per line
     per_m = sum(nd * (12 * n3 + 8 * n2 + kin * (32 * n3 + 20 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (36 * n3 + 16 * n2))
     exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
-    e = _entry("C5", "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
+    e = _entry(name, "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
                "20000 points); step = whole rt_run(RRS) incl. host optics, H2D, D2H" % (N, L, len(shifts), S), S, wall, dev, 3 * per_m, "f64",
                "k_raman_doubling_chain<21> (+ k_raman_interaction_quad<21>)")
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
     e["hbm_bytes_per_step"] = None   # whole-step HBM bytes from the newest committed PMC passes of the same workload
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")) as f:
                 e["hbm_bytes_per_step"] = float(json.load(f)["hbm_bytes_per_point_whole_run"]) * S
@@ -187,7 +225,7 @@ def c1(vsm, torch, arch, points=100, layers=10, reps=20):
     return e
 
 
-def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
+def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10, scale=1.0, name="IA"):
     FT = np.float64
     rng = np.random.default_rng(1)
     CR = vsm.CoreRT
@@ -207,9 +245,9 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     # clear-sky scale of the C2 run: ||R+- r-+||_F ~ 2e-3, i.e. the series inverse at order 7 (the order the layer interactions of
     # the headline workload take); tools/ia_timing.py --refl sweeps the scale (orders 15 / 31 and the Gauss-Jordan path run out of
     # line at about half this rate)
-    init = dict(R_mp=refl(0.1), R_pm=refl(0.1), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
+    init = dict(R_mp=refl(0.1 * scale), R_pm=refl(0.1 * scale), T_pp=trans(), T_mm=trans(), J0_p=torch.rand((S, N), dtype=torch.float64, device=dev),
                 J0_m=torch.rand((S, N), dtype=torch.float64, device=dev))
-    pa.r_mp.copy_(refl(0.075))
+    pa.r_mp.copy_(refl(0.075 * scale))
     pa.t_pp.copy_(trans())
     pa.j0_p.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
     pa.j0_m.copy_(torch.rand((S, N), dtype=torch.float64, device=dev))
@@ -227,10 +265,14 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10):
     tot = sum(a.elapsed_time(b) for a, b in evs)
     ms = tot / reps
     flop_pt = 24.0 * N ** 3 + 8.0 * N ** 2
-    e = _entry("IA", "interaction!(::ScatteringInterface_11) alone (interaction.jl:207-266), N=%d FP64, %d points per launch, physically "
-               "shaped random layers at the clear-sky scale of the C2 run (||R r|| ~ 2e-3: series inverse of order 7), added layer "
-               "D-symmetric as doubling! leaves it; HIP events around each of %d launches" % (N, S, reps), S, ms * 1e-3, ms, flop_pt,
-               "f64", "k_ia_strip<15, true>")
+    e = _entry(name, "interaction!(::ScatteringInterface_11) alone (interaction.jl:207-266), N=%d FP64, %d points per launch, physically "
+               "shaped random layers at %s, added layer D-symmetric as doubling! leaves it; HIP events around each of %d launches"
+               % (N, S, "the clear-sky scale of the C2 run (||R r|| ~ 2e-3: series inverse of order 7)" if scale == 1.0 else
+                  "%g x the reflectances of the IA entry (||R r|| ~ %.0e: the long series orders 15 / 16 / 31, out of line)"
+                  % (scale, 2e-3 * scale * scale), reps), S, ms * 1e-3, ms, flop_pt, "f64", "k_ia_strip<15, true>")
+    if scale != 1.0:
+        del pc, pa, init
+        return e
     e["north_star_target_mfma_utilisation"] = 0.40
     # what the MFMA pipe executes: 10 products of the one-inverse interaction + 6 of the order-7 Horner series, each 4 waves x 60
     # v_mfma_f64_16x16x4 (2048 flop): 16 x 491 520 flop per point (the padded 64 x 64 x 60 tiles and the series are not in the
@@ -266,8 +308,10 @@ def n112(vsm, torch, arch, o2a, points=2000, layers=10):
 
 def run_all(vsm, torch, arch, o2a):
     out = []
-    for f in (lambda: c4(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a), lambda: c3_lin(vsm, torch, arch),
-              lambda: c5(vsm, torch, arch), lambda: c1(vsm, torch, arch), lambda: ia_kernel(vsm, torch, arch),
+    for f in (lambda: c4(vsm, torch, arch, o2a), lambda: c2_aer(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a),
+              lambda: c2_lin(vsm, torch, arch, o2a, 10000, "C2-lin-10k"), lambda: c3_lin(vsm, torch, arch),
+              lambda: c5(vsm, torch, arch), lambda: c5(vsm, torch, arch, 10000, name="C5-10k"), lambda: c1(vsm, torch, arch),
+              lambda: ia_kernel(vsm, torch, arch), lambda: ia_kernel(vsm, torch, arch, scale=4.0, name="IA-long"),
               lambda: n112(vsm, torch, arch, o2a)):
         try:
             out.append(f())

@@ -69,7 +69,9 @@ function __init__()
     n = Ref{Cint}(0)
     if ccall((:vsm_device_count, libvsm), Cint, (Ref{Cint},), n) == 0 && n[] > 0
         _has_cuda[] = true
-        _sync_gpu[] = () -> _chk(ccall((:vsm_sync, libvsm), Cint, (PV,), _stream()))
+        # the synchronisation hook that ends a run (Architectures.synchronize_if_gpu) also reads the device flags of the in-kernel
+        # inverses: a singular (I - R r) throws here, like the LU of the reference's CPU path at the call (cpu_batched.jl:32-47)
+        _sync_gpu[] = () -> (_chk(ccall((:vsm_sync, libvsm), Cint, (PV,), _stream())); check_device_status("synchronize_if_gpu"); nothing)
     else
         @warn "vSmartMOMROCmExt: no MI355X visible; staying on CPU"      # vSmartMOMCUDAExt.jl:59-62
     end
@@ -167,6 +169,56 @@ function rt_kernel_moments!(RS::noRS{FT}, pol_type, a::AddedLayer{FT}, cs::Vecto
           _q(qp, pol_type.n, FT), length(τ_sum), length(ms), Cint.(ms), ndoubl, _p(dτ), _p(ps[1].ϖ), _p(τ_sum), _p(RS.F₀), 0, zpp, zmp,
           _ms(ps[1].Z⁺⁺), C_NULL, C_NULL, iz == 1 ? 1 : 0, comps, _c(a), _stream())
 end
+
+# The layer loop of rt_run (rt_run.jl:383-453) with the CompositeLayer in the layer kernels' own strip layout (vsm_run_*; FP64,
+# every block of coupled Stokes components <= 60 rows: vsm_run_supported_f64).  A patched rt_run that walks `for iz` outside
+# `for m` (every layer scattering, interface 11) replaces its per-layer rt_kernel_moments! calls by
+#     run = NativeRun(qp, pol_type, nSpec, ms, Zstacks)            # make_composite_layer of the moments ms
+#     for iz = 1:Nz;  rt_kernel!(run, ps_of_layer(iz), τ_sum[iz], RS.F₀, qp, iz);  end
+#     export!(run, cs)                                              # cs[i]: the reference's CompositeLayer of moment ms[i]
+# and continues with create_surface_layer! / interaction! / postprocessing_vza! on cs as before.  Zstacks[i] = (Z⁺⁺, Z⁻⁺) stacks
+# [N,N,nScatterers] of moment ms[i] (every phase matrix a layer of the run can hand in): their Stokes coupling decides which
+# components run as independent blocks (m = 0: (I,Q) | (U,V); compute_Z_matrices.jl:26-110).
+mutable struct NativeRun
+    handle::PV
+    ws::ROCArray{Float64,1}
+    q::VsmQuad{Float64}
+    coupling::Vector{Cint}
+end
+function stokes_coupling(N::Int, n::Int, Zpp::ROCArray{Float64,3}, Zmp::ROCArray{Float64,3})
+    nb = size(Zpp, 3)
+    mask = AMDGPU.zeros(Cint, nb)
+    _chk(ccall(_sym(:vsm_stokes_coupling_f64), Cint, (Cint, Cint, Cint, PV, PV, PV, PV), N, n, nb, _p(Zpp), _p(Zmp), PV(pointer(mask)), _stream()))
+    Array(mask)                                          # one mask per scatterer (synchronises)
+end
+function NativeRun(qp::QuadPoints, pol_type, nSpec::Int, ms::Vector{<:Integer}, Zstacks::Vector)
+    N, n = length(qp.qp_μN), pol_type.n
+    coupling = Cint[reduce(|, stokes_coupling(N, n, Z[1], Z[2])) for Z in Zstacks]
+    nbytes = ccall(_sym(:vsm_run_workspace_bytes_f64), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, nSpec, length(ms), coupling)
+    nbytes > 0 || error("vsm_run: a block of coupled Stokes components exceeds the native kernels (60 rows)")
+    ws = ROCArray{Float64}(undef, cld(Int(nbytes), 8))
+    q = _q(qp, n, Float64)
+    h = Ref{PV}(C_NULL)
+    _chk(ccall(_sym(:vsm_run_create_f64), Cint, (Ref{VsmQuad{Float64}}, Cint, Cint, Ptr{Cint}, Ptr{Cint}, PV, Csize_t, Ref{PV}),
+               q, nSpec, length(ms), Cint.(ms), coupling, _p(ws), nbytes, h))
+    run = NativeRun(h[], ws, q, coupling)
+    finalizer(r -> ccall(_sym(:vsm_run_destroy), Cint, (PV,), r.handle), run)
+end
+# rt_kernel!(::noRS) for one scattering layer and all moments of the run; layer_coupling[i]: the coupling mask of THIS layer's
+# phase matrices at moment i (OR over the scatterers present; `nothing` = the run's): a block they leave exactly zero is a
+# diagonal step
+function rt_kernel!(run::NativeRun, ps::Vector, τ_sum::ROCArray{Float64}, F₀::ROCArray{Float64}, qp, iz::Integer;
+                    layer_coupling=nothing, dτ_max_threshold=nothing, dτ_min_floor=nothing)
+    dτ, ndoubl = get_dtau_ndoubl(ps[1], qp; dτ_max_threshold, dτ_min_floor)
+    zpp, zmp = [_p(p.Z⁺⁺) for p in ps], [_p(p.Z⁻⁺) for p in ps]
+    _chk(ccall(_sym(:vsm_run_layer_f64), Cint, (PV, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, Cint, Ptr{Cint}, PV),
+               run.handle, ndoubl, _p(dτ), _p(ps[1].ϖ), _p(τ_sum), _p(F₀), 0, zpp, zmp, _ms(ps[1].Z⁺⁺), C_NULL, iz == 1 ? 1 : 0,
+               layer_coupling === nothing ? C_NULL : pointer(Cint.(layer_coupling)), _stream()))
+end
+export!(run::NativeRun, cs::Vector{<:CompositeLayer{Float64}}) =
+    _chk(ccall(_sym(:vsm_run_export_f64), Cint, (PV, Ptr{VsmComposite}, PV), run.handle, [_c(c) for c in cs], _stream()))
+import!(run::NativeRun, cs::Vector{<:CompositeLayer{Float64}}) =
+    _chk(ccall(_sym(:vsm_run_import_f64), Cint, (PV, Ptr{VsmComposite}, PV), run.handle, [_c(c) for c in cs], _stream()))
 
 # contribute!(::PreparedThermalEmission, ...) (Sources/thermal_emission.jl:241-301): the :thermal slot of the elemental layer
 function CoreRT.contribute!(prep::CoreRT.PreparedThermalEmission, a::AddedLayer{FT}, ϖ::ROCArray, dτ::ROCArray, iz::Integer, m::Integer,

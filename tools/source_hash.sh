@@ -1,5 +1,6 @@
 #!/bin/bash
-# The build identity of csrc/Makefile (vsm_build_id()) recomputed from a tree: the working tree, or a commit.
+# The build identity of csrc/Makefile (vsm_build_id()) recomputed from a tree: the working tree, or a commit (default make variables:
+# the shipped build; the hash covers the library's sources AND the make variables that change the binary).
 #   tools/source_hash.sh            -> hash of the working tree's library sources
 #   tools/source_hash.sh <commit>   -> hash of that commit's library sources
 set -e
@@ -9,5 +10,4 @@ if [ -n "$1" ]; then
   git -C "$root" archive "$1" vsmartmom.jl_amd/csrc include/vsmartmom_hip.h | tar -x -C $tmp
   root=$tmp
 fi
-cd "$root/vsmartmom.jl_amd/csrc"
-ls *.hip *.h | grep -v '^build_id.h$' | cat - <(echo ../../include/vsmartmom_hip.h; echo Makefile) | LC_ALL=C sort | xargs cat | sha256sum | cut -c1-16
+make -s -C "$root/vsmartmom.jl_amd/csrc" print-build-id

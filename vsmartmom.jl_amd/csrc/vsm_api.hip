@@ -88,6 +88,10 @@ void* scratch(size_t bytes, int slot, hipStream_t st) {
     hip_fail(e, "hipGetDevice(scratch)");
     return nullptr;
   }
+  if (st == hipStreamPerThread) {   // one handle value, a different stream in every host thread: it cannot key a buffer
+    set_error("hipStreamPerThread is not accepted by the entry points that use library scratch: pass the thread's own stream handle");
+    return nullptr;
+  }
   std::lock_guard<std::mutex> lk(g_scratch_mu);
   scratch_buf& b = g_scratch[scratch_key{dev, st, slot}];
   if (bytes <= b.sz) return b.ptr;
@@ -164,7 +168,10 @@ int* device_status() {
   if (it != g_status.end()) return it->second;
   int* p = nullptr;
   e = hipMalloc(reinterpret_cast<void**>(&p), 4 * sizeof(int));
-  if (e == hipSuccess) e = hipMemset(p, 0, 4 * sizeof(int));   // (synchronous: ordered before any later launch)
+  // zeroed once, then the device is synchronised: the null-stream memset is not ordered against non-blocking streams (torch's,
+  // AMDGPU.jl's), so the first kernel on such a stream could otherwise have its flag wiped
+  if (e == hipSuccess) e = hipMemset(p, 0, 4 * sizeof(int));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     hip_fail(e, "hipMalloc(device_status)");
     return nullptr;
@@ -423,9 +430,12 @@ int vsm_device_status(int* flags_h, int reset, void* stream) {
   VSM_REQUIRE(flags_h != nullptr, "device_status: null");
   int* d = device_status();
   if (!d) return VSM_ERR_HIP;
-  VSM_HIP(hipStreamSynchronize(as_stream(stream)));
-  VSM_HIP(hipMemcpy(flags_h, d, 4 * sizeof(int), hipMemcpyDeviceToHost));
-  if (reset) VSM_HIP(hipMemset(d, 0, 4 * sizeof(int)));
+  // read and reset ON the caller's stream (ordered behind its kernels, and the reset ahead of whatever it launches next); kernels
+  // still running on OTHER streams keep raising flags that a reset here may or may not clear -- synchronise those first
+  hipStream_t st = as_stream(stream);
+  VSM_HIP(hipMemcpyAsync(flags_h, d, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+  if (reset) VSM_HIP(hipMemsetAsync(d, 0, 4 * sizeof(int), st));
+  VSM_HIP(hipStreamSynchronize(st));
   return VSM_OK;
 }
 const char* vsm_last_error(void) { return g_err; }

@@ -234,7 +234,7 @@ __device__ __forceinline__ void load_strip(fstrip& s, const float* src, const fp
 // 16-byte access when N % 4 == 0 (then the rows of a tile are all inside or all outside the matrix).
 // (decided at run time although AL is known: with a compile-time branch the scheduler hoists every global load to the top of
 // its phase and pays for it in spills -- measured 8.4k vs 9.7k points/s on C4)
-#ifdef VSM_AL_STATIC
+#if defined(VSM_AB_SWITCHES) && defined(VSM_AL_STATIC)   // (an ablation of the diagnostic build only)
 #define VSM_ALIGNED(AL, N) (AL)
 #else
 #define VSM_ALIGNED(AL, N) (((N) & 3) == 0)

@@ -103,7 +103,7 @@ struct spos {
 // waits for its predecessor's result, and the register-pressure-minimising scheduler, left alone, turns the loop tile-major
 // (one chain of KS dependent MFMAs per tile: 1.45x the issue time of the products with one wave per SIMD).  A scheduling
 // fence after every k-step keeps the written order: fragments of step ks + 1 requested, then the MFMAs of step ks.
-#ifdef VSM_NO_KSTEP_FENCE
+#if defined(VSM_AB_SWITCHES) && defined(VSM_NO_KSTEP_FENCE)   // (an ablation of the diagnostic build only)
 #define VSM_KSTEP_FENCE()
 #else
 #define VSM_KSTEP_FENCE() __builtin_amdgcn_sched_barrier(0)
