@@ -278,3 +278,62 @@ def test_native_run_layer_by_layer_through_the_c_abi(vsm, arch):
                     assert _rel(got, ref) < 1e-10, (im, iz, name)
         finally:
             L.vsm_run_destroy(run)
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 11), ("IQU", 35), ("IQUV", 21)])
+def test_linearized_run_with_m0_as_stokes_iq_scene(vsm, arch, monkeypatch, pol, l_trunc):
+    """rt_run(model, lin_model, 0, NGas, 1) on a batch large enough for the m = 0 reduction (CoreRTLin.REDUCE_M0: the moment m = 0
+    as a Stokes_IQ scene -- no phase matrix couples (I,Q) with (U,V) at m = 0, compute_Z_matrices.jl:26-110): R, T, Rdot, Tdot equal
+    the full-Stokes walk to rounding and the oracle's linearized run (doubling_lin.jl:216-339, interaction_lin.jl:217-331)."""
+    from oracle import vsm_oracle_lin as OL
+    H = vsm.host_model
+    rng = np.random.default_rng(41)
+    S, L = 70, 3
+    tau_rayl = np.tile(0.04 * np.ones(L), (S, 1))
+    ga, gb = 10.0 ** rng.uniform(-2.5, -0.3, (S, L)), 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=ga + gb, depol=0.0279, m_max=2)
+    pm = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, **kw)
+    monkeypatch.setattr(vsm.CoreRTLin, "REDUCE_M0", True)
+    sc = vsm.CoreRTLin.SceneLin(pm, H.LinModel([ga, gb]), 0, 2, 1)
+    assert sc.sub0 is not None and sc.sub0.N == 2 * pm.quad_points.Nquad
+    sc.run()
+    torch.cuda.synchronize()
+    red = sc.results_host()
+    monkeypatch.setattr(vsm.CoreRTLin, "REDUCE_M0", False)
+    full = vsm.CoreRTLin.rt_run_lin(pm, H.LinModel([ga, gb]), 0, 2, 1)
+    monkeypatch.setattr(vsm.CoreRTLin, "REDUCE_M0", True)
+    for a, b in zip(red, full):
+        assert _rel(a, b) < 1e-11
+    sub = slice(0, S, 23)                                   # the oracle on a sample of the points
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2,
+                       **dict(kw, tau_rayl=tau_rayl[sub], tau_abs=(ga + gb)[sub]))
+    Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga[sub], gb[sub]]))
+    assert _rel(red[0][:, :, sub], Ro) < 1e-9 and _rel(red[1][:, :, sub], To) < 1e-9
+    assert _rel(red[2][:, :, sub], Rdo) < 1e-8 and _rel(red[3][:, :, sub], Tdo) < 1e-8
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 9), ("IQUV", 7)])
+def test_raman_run_with_m0_as_stokes_iq_scene(vsm, arch, monkeypatch, pol, l_trunc):
+    """rt_run(RS_type::RRS, model) with the moment m = 0 as a Stokes_IQ scene (CoreRTRaman.REDUCE_M0) equals the full-Stokes walk
+    to rounding, elastic and inelastic outputs (doubling_inelastic.jl:13-164, interaction_inelastic.jl:319-521; the oracle
+    comparisons of tests/test_gpu_raman.py run with the reduction on: it is the default)."""
+    H, R = vsm.host_model, vsm.CoreRTRaman
+    rng = np.random.default_rng(43)
+    S, L, K = 40, 3, 6
+    tau_rayl = np.tile(np.array([0.05, 0.1, 0.15]), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, -0.5, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0075, albedo=0.1, m_max=2)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0], [0.0], **kw)
+    model.varpi_Cabannes = 0.96
+    shifts = np.array([-9, -4, -1, 2, 5, 11])
+    rs = R.RRS(shifts, np.full(K, 0.04 / K), H.get_greek_rayleigh(0.75))
+    monkeypatch.setattr(R, "REDUCE_M0", True)
+    sc = R.SceneRRS(rs, model)
+    assert sc.sub0 is not None and sc.sub0.N == 2 * model.quad_points.Nquad
+    red = R.rt_run(rs, model, 1)
+    monkeypatch.setattr(R, "REDUCE_M0", False)
+    full = R.rt_run(rs, model, 1)
+    monkeypatch.setattr(R, "REDUCE_M0", True)
+    for a, b in zip(red, full):
+        assert _rel(a, b) < 1e-11
+        assert a.shape[1] < 3 or np.all(a[:, 2:, :] == b[:, 2:, :]) or _rel(a[:, 2:, :], b[:, 2:, :]) < 1e-11

@@ -10,6 +10,7 @@ parameter)); inverses are shared by all parameters like in the reference.  `Scen
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
 from typing import Optional
 
@@ -138,6 +139,9 @@ def _pp_args(pol, qp, vza, vaz, m, weight, dtype):
     return row0, w
 
 
+REDUCE_M0 = True   # A/B switch (module attribute): False = the moment m = 0 with all Stokes components of the model
+
+
 class SceneLin:
     """Everything rt_run(model, lin_model, NAer, NGas, NSurf) needs, resident in HBM (the linearized twin of CoreRT.Scene).
     The raw inputs -- tau_rayl, tau_abs, lin_model.tau_abs_dot [nSpec, Nz] and the small aerosol tables (tau_aer,
@@ -157,7 +161,7 @@ class SceneLin:
     (lambertian_surface_lin.jl:48-162) or the Cox-Munk wind speed (coxmunk_surface_lin.jl:27-102)."""
 
     def __init__(self, model: H.RTModel, lin_model: H.LinModel, NAer: int, NGas: int, NSurf: int,
-                 spec_slice: Optional[slice] = None, host_optics: bool = False):
+                 spec_slice: Optional[slice] = None, host_optics: bool = False, _reduce_m0: bool = True):
         if NAer != lin_model.n_aer or NAer != len(model.aerosol_optics) or NSurf != 1 or NGas != len(lin_model.tau_abs_dot):
             raise _lib.VSMError("rt_run (linearized): NAer must equal the aerosols of model and lin_model, NGas = "
                                 "len(lin_model.tau_abs_dot), NSurf = 1")
@@ -223,6 +227,21 @@ class SceneLin:
         # (interaction_lin.jl:242,291) computes exact zeros for them.  The layer interactions therefore run on the layer slots
         # [0, n_layer_params) only; the surface interaction on all of them.
         self._layer_slots = (0, pl) if 0 < pl < P else None
+        # The Fourier moment m = 0 as a Stokes_IQ run (large batches; models without aerosol Jacobian slots over a Lambertian
+        # surface).  At m = 0 no phase matrix couples (I,Q) with (U,V) (compute_Z_matrices.jl:26-110; the forward scene reads the
+        # exact zeros off the device: `coupling`), the Lambertian surface reflects into I only, the gas and albedo derivatives
+        # inherit the structure, and a beam without U / V components drives nothing in the (U,V) block: R, T, Rdot, Tdot of m = 0
+        # are those of the same model carried with two Stokes components, U = V = 0.
+        self.sub0 = None
+        F0m = model.F0
+        c0 = fwd.coupling[0] if getattr(fwd, "coupling", None) else None
+        if (_reduce_m0 and REDUCE_M0 and pol.n >= 3 and S >= self.LANE_POINTS and NAer == 0 and not host_optics and c0 is not None
+                and isinstance(model.surface, H.LambertianSurfaceScalar) and (F0m is None or not np.any(np.asarray(F0m)[2:] != 0))
+                and not any(c0 >> (4 * a + b) & 1 or c0 >> (4 * b + a) & 1 for a in (0, 1) for b in range(2, pol.n))):
+            qi = H.QuadPoints(qp.mu0, qp.imu0, qp.qp_mu, qp.wt_mu, np.repeat(qp.qp_mu, 2), np.repeat(qp.wt_mu, 2), qp.Nquad, qp.Nstreams)
+            m_iq = dataclasses.replace(model, polarization_type=H.Stokes_IQ(), quad_points=qi, m_max=0,
+                                       F0=None if F0m is None else np.ascontiguousarray(np.asarray(F0m)[:2]))
+            self.sub0 = SceneLin(m_iq, lin_model, NAer, NGas, NSurf, spec_slice, _reduce_m0=False)
 
     # -- inputs -----------------------------------------------------------------------------------------------------------
     def upload(self):
@@ -231,6 +250,9 @@ class SceneLin:
         model, lin = self.model, self.lin_model
         conv = array_type(self.arch)
         S_full, L = model.tau_rayl.shape
+        if getattr(self, "sub0", None) is not None:   # (a step re-uploads: the Stokes_IQ scene of m = 0 follows)
+            self.sub0.fwd.upload()
+            self.sub0.upload()
         if self.nGas:
             g = np.stack([np.asarray(t, dtype=np.float64) for t in lin.tau_abs_dot])            # (nGas, S, L)
             if g.shape != (self.nGas, S_full, L):
@@ -261,6 +283,9 @@ class SceneLin:
     def prepare(self):
         model, fwd, dt = self.model, self.fwd, self.dt
         self._fold = {}   # (the folded per-layer inputs are copies of the optics)
+        if getattr(self, "sub0", None) is not None:
+            self.sub0.fwd.prepare()
+            self.sub0.prepare()
         S_full, L = model.tau_rayl.shape
         _lib.call("vsm_layer_optics_lin", dt, S_full, fwd.lo, self.S, L, self.nAer, self.nGas, self.P, CR._ptr(fwd.tau_rayl_d),
                   CR._ptr(fwd.tau_abs_d), C.c_double(float(model.varpi_Cabannes)), CR._ptr(fwd.tau_aer_d), CR._ptr(fwd.ssa_d),
@@ -365,7 +390,16 @@ class SceneLin:
         if fold:
             return self._run_folded(st)
         if lanes == 1:
+            reduced = self.sub0 is not None
+            if reduced:   # m = 0 first, like the Fourier loop: its I, Q rows are copied in, the later moments accumulate on top
+                r0, t0, rd0, td0 = self.sub0.run(lanes=1, fold=False)
+                self.R[:, :2, :].copy_(r0)
+                self.T[:, :2, :].copy_(t0)
+                self.Rd[:, :, :2, :].copy_(rd0)
+                self.Td[:, :, :2, :].copy_(td0)
             for mom in self.fwd.moments:
+                if reduced and mom["m"] == 0:
+                    continue
                 self._run_moment(mom, st[0])
             return self.R, self.T, self.Rd, self.Td
         main = torch.cuda.current_stream()

@@ -11,6 +11,7 @@ are outside the hot path; `RRS` takes them as arrays.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -85,6 +86,8 @@ def device_rrs(rs: RRS, arch, FT) -> DeviceRRS:
     shift = torch.tensor(np.asarray(rs.i_lambda1lambda0, dtype=np.int32), dtype=torch.int32, device=dev)
     return DeviceRRS(shift, array_type(arch)(np.asarray(rs.varpi_lambda1lambda0, dtype=FT)), int(shift.numel()))
 
+
+REDUCE_M0 = True   # A/B switch (module attribute): False = the moment m = 0 with all Stokes components of the model
 
 _work = {}
 
@@ -187,7 +190,7 @@ class SceneRRS:
     halo of max|i_λ₁λ₀| donor points on each side (`parallel.raman_halo_slices`), ndoubl comes from the FULL spectral axis,
     and only the owned points are returned -- no exchange step is needed."""
 
-    def __init__(self, RS_type: RRS, model: H.RTModel, iBand: int = 1, spec_slice: Optional[slice] = None):
+    def __init__(self, RS_type: RRS, model: H.RTModel, iBand: int = 1, spec_slice: Optional[slice] = None, _reduce_m0: bool = True):
         from . import parallel
         arch, FT = model.architecture, model.float_type
         CR._require_gpu(arch)
@@ -225,6 +228,12 @@ class SceneRRS:
             Zm = torch.empty_like(Zp)
             _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, tab.shape[1], CR._ptr(gd), CR._ptr(Zp), CR._ptr(Zm), CR._stream_ptr())
             self.Zie.append((Zp, Zm))
+        zie_mask0 = None
+        if dt == torch.float64:
+            md = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(_lib.lib().vsm_stokes_coupling_f64(N, pol.n, 1, CR._ptr(self.Zie[0][0]), CR._ptr(self.Zie[0][1]), CR._ptr(md),
+                                                          CR._stream_ptr()))
+            zie_mask0 = int(md.cpu()[0])
         nV = len(model.vza)
         self.out = [fwd.R_SFI, fwd.T_SFI] + [torch.zeros((S, pol.n, nV), dtype=dt, device=dev) for _ in range(2)]
         self.expk = torch.empty(max(S, 1), dtype=dt, device=dev)
@@ -232,6 +241,22 @@ class SceneRRS:
             self.added_rs = AddedLayerRS(FT, arch, K, N, S)
             self.surf_rs = AddedLayerRS(FT, arch, K, N, S)      # stays zero: the surface has no inelastic part
             self.comp_rs = CompositeLayerRS(FT, arch, K, N, S)
+        # The Fourier moment m = 0 as a Stokes_IQ run.  No phase matrix -- Cabannes, Raman, aerosol -- couples (I,Q) with (U,V) at
+        # m = 0 (compute_Z_matrices.jl:26-110: the T_l^m functions carry a factor m; CoreRT.Scene reads the exact zeros off the
+        # device, `coupling`), the Lambertian surface reflects into I only, and a beam without U / V components drives nothing in the
+        # (U,V) block: its source vectors stay zero through every recurrence, elastic and inelastic, so R / T / ieR / ieT of
+        # m = 0 are those of the same model carried with two Stokes components (the reference's own Stokes_IQ), U = V = 0 -- at
+        # (2/3)^3 of the products and (2/3)^2 of the bytes for Stokes_IQU.
+        self.sub0 = None
+        F0 = model.F0
+        if (_reduce_m0 and REDUCE_M0 and pol.n >= 3 and S > 0 and (F0 is None or not np.any(np.asarray(F0)[2:] != 0))
+                and fwd.coupling is not None and zie_mask0 is not None
+                and not any((fwd.coupling[0] | zie_mask0) >> (4 * a + b) & 1 or (fwd.coupling[0] | zie_mask0) >> (4 * b + a) & 1
+                            for a in (0, 1) for b in range(2, pol.n))):
+            qi = H.QuadPoints(qp.mu0, qp.imu0, qp.qp_mu, qp.wt_mu, np.repeat(qp.qp_mu, 2), np.repeat(qp.wt_mu, 2), qp.Nquad, qp.Nstreams)
+            m_iq = dataclasses.replace(model, polarization_type=H.Stokes_IQ(), quad_points=qi, m_max=0,
+                                       F0=None if F0 is None else np.ascontiguousarray(np.asarray(F0)[:2]))
+            self.sub0 = SceneRRS(RS_type, m_iq, iBand, spec_slice, _reduce_m0=False)
 
     def run(self, trace: Optional[list] = None):
         """rt_run.jl:383-517 for RS_type::RRS: Fourier loop -> rt_kernel!(::RRS) per layer -> surface -> interaction ->
@@ -245,8 +270,14 @@ class SceneRRS:
         R_SFI, T_SFI, ieR_SFI, ieT_SFI = self.out
         added, comp = fwd.added, fwd.composite
         mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
+        reduced = self.sub0 is not None and trace is None
+        if reduced:      # m = 0 first, like the Fourier loop: its I, Q rows are copied in, the later moments accumulate on top
+            for full, part in zip(self.out, self.sub0.run()):
+                full[:, :2, :].copy_(part)
         for mom in fwd.moments:
             m = mom["m"]
+            if m == 0 and reduced:
+                continue           # (below: the Stokes_IQ run of this moment)
             weight = FT(0.5 / math.pi) if m == 0 else FT(1.0 / math.pi)
             drs.Zpp, drs.Zmp = self.Zie[m]
             # the reference dispatches interaction!(RS_type, scattering_interfaces_all[iz], ...) on the tags of
@@ -295,6 +326,8 @@ def rt_run(RS_type: RRS, model: H.RTModel, iBand: int = 1, trace: Optional[list]
         N = model.quad_points.Nquad * model.polarization_type.n
         K = len(np.asarray(RS_type.i_lambda1lambda0).ravel())
         per = raman_bytes_per_point(N, K, np.dtype(model.float_type).itemsize)
+        if REDUCE_M0 and model.polarization_type.n >= 3:   # + the Stokes_IQ scene of the moment m = 0
+            per += raman_bytes_per_point(2 * model.quad_points.Nquad, K, np.dtype(model.float_type).itemsize)
         free, _total = torch.cuda.mem_get_info()
         halo = max([abs(int(x)) for x in np.asarray(RS_type.i_lambda1lambda0).ravel() if abs(int(x)) < S_full] or [0])
         fit = int(0.8 * free // per) - 2 * halo
