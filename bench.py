@@ -238,12 +238,12 @@ def main():
             e0.record()
             f(*a, **k)
             e1.record()
-            ev.append((e0, e1) + rec(a))   # + (ndoubl, toa, Fourier moments in the call)
+            ev.append((e0, e1) + rec(a))   # + (ndoubl, toa, Fourier moments in the call, native-layout run?)
         return timed
 
-    vsm.CoreRT.layer_forward_ = timed_with(orig, lambda a: (a[5], a[7], 1))
-    vsm.CoreRT.layer_forward_multi_ = timed_with(orig_multi, lambda a: (a[5], a[7], len(a[4])))
-    vsm.CoreRT.run_layer_native_ = timed_with(orig_native, lambda a: (a[2], a[12], a[1]))
+    vsm.CoreRT.layer_forward_ = timed_with(orig, lambda a: (a[5], a[7], 1, False))
+    vsm.CoreRT.layer_forward_multi_ = timed_with(orig_multi, lambda a: (a[5], a[7], len(a[4]), False))
+    vsm.CoreRT.run_layer_native_ = timed_with(orig_native, lambda a: (a[2], a[12], a[1], True))
     r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     r0.record()
     scene.run()
@@ -252,12 +252,12 @@ def main():
     run_ms = r0.elapsed_time(r1)
     n3, n2 = float(N) ** 3, float(N) ** 2
     step_flops = lambda evs: sum(nmom * S_local * (nd * (12 * n3 + 8 * n2) + (0 if toa else 24 * n3 + 8 * n2))
-                                 for _, _, nd, toa, nmom in evs)   # ALGORITHMIC flops, as written (dense N x N)
+                                 for _, _, nd, toa, nmom, _nat in evs)   # ALGORITHMIC flops, as written (dense N x N)
     step_ms = sum(e[0].elapsed_time(e[1]) for e in ev)
     step_tflops = step_flops(ev) / (step_ms * 1e-3) / 1e12 if step_ms > 0 else 0.0
-    layer_step = {"calls": len(ev), "avg_ms": step_ms / max(len(ev), 1), "algorithmic_tflops": step_tflops,
+    layer_step = {"layers": scene.Nz, "avg_ms": step_ms / max(scene.Nz, 1), "algorithmic_tflops": step_tflops,
                   "frac_of_mfma_peak_algorithmic": step_tflops / PEAK_TFLOPS[cfg["FT"]],
-                  "fourier_moments_per_call": max([e[4] for e in ev], default=1)}
+                  "fourier_moments": len(scene.moments)}
     native = sorted(scene._native_moments())
     interval_kernels = None
     if native:
@@ -273,13 +273,19 @@ def main():
             scene._run_layers_native([scene.moments[i] for i in dense], scene._composites[:len(dense)])
             torch.cuda.synchronize()
         ev_dense, ev = ev, ev_all
-        k_ms = sum(e[0].elapsed_time(e[1]) for e in ev_dense)
-        k_flops = step_flops(ev_dense)
-        ks = (N + 3) // 4
-        kernel_name = "k_layer_native<%d, %d>" % ((4 * ks + 2 + 15) // 16, ks)
-        interval_kernels = ["k_elemental_native", kernel_name]
-        moments_per_launch = len(dense)
-        n_launch = len(ev_dense)
+        if dense:
+            k_ms = sum(e[0].elapsed_time(e[1]) for e in ev_dense)
+            k_flops = step_flops(ev_dense)
+            ks = (N + 3) // 4
+            kernel_name = "k_layer_native<%d, %d>" % (4 if ks == 16 else (4 * ks + 2 + 15) // 16, ks)
+            interval_kernels = ["k_elemental_native", kernel_name]
+            moments_per_launch = len(dense)
+            n_launch = len(ev_dense)
+        else:   # the dense moments are beyond the native kernels (C4: N = 96): their layer steps run on the reference-layout kernels
+            legacy = [e for e in ev if not e[5]]
+            k_ms = sum(e[0].elapsed_time(e[1]) for e in legacy)
+            k_flops, n_launch = step_flops(legacy), len(legacy)
+            moments_per_launch = max([e[4] for e in legacy], default=1)
         # executed products of the layer steps: a block of n rows costs (n / N)^3 of the dense count, a block that the phase
         # matrices of a layer leave exactly zero costs none (an elementwise scaling of the composite)
         ex_num = ex_den = 0.0
@@ -306,7 +312,7 @@ def main():
     vsm.CoreRT.layer_forward_, vsm.CoreRT.layer_forward_multi_, vsm.CoreRT.run_layer_native_ = orig, orig_multi, orig_native
     achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
     peak = PEAK_TFLOPS[cfg["FT"]]
-    if native:
+    if native and dense:
         pass
     elif cfg["FT"] == "f64" and 32 < N <= 64:
         # the event pair of a layer step brackets the fused layer kernel AND its elemental pre-pass (k_elemental_img writes the
@@ -320,7 +326,8 @@ def main():
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
     build = vsm._lib.build_info()
-    tk = ([kernel_name, "k_elemental_native<%d," % ((4 * ((N + 3) // 4) + 2 + 15) // 16)] if native else [kernel_name, "k_elemental_img"])
+    tk = ([kernel_name, "k_elemental_native<%d," % (4 if N > 60 else (4 * ((N + 3) // 4) + 2 + 15) // 16)] if native and dense
+          else [kernel_name, "k_elemental_img"])
     traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(tk, cfg, S_local, build["source_hash"])
                                                         if args.variant == "rayleigh" else (None, None, None, "no profile of this variant"))
 

@@ -560,7 +560,7 @@ int vsm_mix_Z_f64(int N, int S, int ncomp, const double* Zpp_comp, const double*
 int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Zmp_comp, const float* fcomp, float* Zpp,
                   float* Zmp, void* stream);
 
-/* ---- a run with the CompositeLayer in kernel-native layout (FP64) -------------
+/* ---- a run with the CompositeLayer in kernel-native layout ---------------------
  * The layer loop of rt_run (src/CoreRT/rt_run.jl:383-453: `for iz = 1:Nz ... rt_kernel!(RS_type, pol_type, SFI, added_layer,
  * composite_layer, ...)`) reads and writes the CompositeLayer (make_composite_layer, tools/rt_helper_functions.jl:259-270;
  * allocated once per run, rt_run.jl:326-335) in every layer step, and nothing else touches it until the surface interaction
@@ -586,20 +586,32 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
  * a Rayleigh-only layer at m >= 3, where the Rayleigh phase matrix vanishes) has r = 0, j = 0, t = diag(exp(-tau / mu)) and its
  * interaction is a scaling of the composite's rows and columns -- one elementwise pass instead of the products.
  * Every block of coupled components must fit the native
- * kernels: (N / n_stokes) * (components in the block) <= 60 (vsm_run_supported_f64 != 0), else VSM_ERR_UNSUPPORTED.
+ * kernels: (N / n_stokes) * (components in the block) <= 64 (vsm_run_supported != 0), else VSM_ERR_UNSUPPORTED.
+ * _f32: the same for a Float32 model -- the caller's arrays (quadrature, optics, Z, composites) are single precision, the native
+ * records (`workspace`: vsm_run_workspace_bytes, the same for both) and all arithmetic between vsm_run_layer's loads and
+ * vsm_run_export's stores are FP64 (the FP64 MFMA rate of these shapes is above what the FP32 kernels for N <= 64 reach, and the
+ * results are at least as accurate as the reference's Float32 path).  A run is used with the entry points of its own type.
  * Stream: see Conventions; library scratch (the pre-pass images of the layer). */
 typedef struct vsm_run vsm_run;
-int vsm_run_supported_f64(int N, int n_stokes, int coupling);
-size_t vsm_run_workspace_bytes_f64(int N, int n_stokes, int S, int nm, const int* coupling_h);
+int vsm_run_supported(int N, int n_stokes, int coupling);
+size_t vsm_run_workspace_bytes(int N, int n_stokes, int S, int nm, const int* coupling_h);
 int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m_h, const int* coupling_h, void* workspace,
+                       size_t workspace_bytes, vsm_run** run);
+int vsm_run_create_f32(const vsm_quad_f32* q, int S, int nm, const int* m_h, const int* coupling_h, void* workspace,
                        size_t workspace_bytes, vsm_run** run);
 int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum,
                       const double* F0, int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride,
                       const double* fcomp, int toa, const int* layer_coupling_h, void* stream);
+int vsm_run_layer_f32(vsm_run* run, int ndoubl, const float* dtau, const float* varpi, const float* tau_sum,
+                      const float* F0, int ncomp, const float* const* Zpp, const float* const* Zmp, long long z_stride,
+                      const float* fcomp, int toa, const int* layer_coupling_h, void* stream);
 int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
+int vsm_run_export_f32(vsm_run* run, const vsm_composite_f32* comps, void* stream);
 int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream);
+int vsm_run_import_f32(vsm_run* run, const vsm_composite_f32* comps, void* stream);
 int vsm_run_destroy(vsm_run* run);
 int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream);
+int vsm_stokes_coupling_f32(int N, int n_stokes, int nblocks, const float* Zpp, const float* Zmp, int* mask_d, void* stream);
 
 /* ---- rotational Raman scattering (RRS), operator level ---------------------
  * Inelastic layer state (src/CoreRT/types.jl:278-335 AddedLayerRS / CompositeLayerRS): 4-D arrays

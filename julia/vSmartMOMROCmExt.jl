@@ -171,7 +171,7 @@ function rt_kernel_moments!(RS::noRS{FT}, pol_type, a::AddedLayer{FT}, cs::Vecto
 end
 
 # The layer loop of rt_run (rt_run.jl:383-453) with the CompositeLayer in the layer kernels' own strip layout (vsm_run_*; FP64,
-# every block of coupled Stokes components <= 60 rows: vsm_run_supported_f64).  A patched rt_run that walks `for iz` outside
+# every block of coupled Stokes components <= 64 rows: vsm_run_supported; Float32 models: the _f32 entry points).  A patched rt_run that walks `for iz` outside
 # `for m` (every layer scattering, interface 11) replaces its per-layer rt_kernel_moments! calls by
 #     run = NativeRun(qp, pol_type, nSpec, ms, Zstacks)            # make_composite_layer of the moments ms
 #     for iz = 1:Nz;  rt_kernel!(run, ps_of_layer(iz), τ_sum[iz], RS.F₀, qp, iz);  end
@@ -194,8 +194,8 @@ end
 function NativeRun(qp::QuadPoints, pol_type, nSpec::Int, ms::Vector{<:Integer}, Zstacks::Vector)
     N, n = length(qp.qp_μN), pol_type.n
     coupling = Cint[reduce(|, stokes_coupling(N, n, Z[1], Z[2])) for Z in Zstacks]
-    nbytes = ccall(_sym(:vsm_run_workspace_bytes_f64), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, nSpec, length(ms), coupling)
-    nbytes > 0 || error("vsm_run: a block of coupled Stokes components exceeds the native kernels (60 rows)")
+    nbytes = ccall(_sym(:vsm_run_workspace_bytes), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, nSpec, length(ms), coupling)
+    nbytes > 0 || error("vsm_run: a block of coupled Stokes components exceeds the native kernels (64 rows)")
     ws = ROCArray{Float64}(undef, cld(Int(nbytes), 8))
     q = _q(qp, n, Float64)
     h = Ref{PV}(C_NULL)

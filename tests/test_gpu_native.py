@@ -83,9 +83,9 @@ def test_native_layout_import_export_roundtrip(vsm, arch, ns, nq, coupling):
         t.copy_(torch.as_tensor(a, device=dev))
     for t in (comp_out.R_mp, comp_out.R_pm, comp_out.T_pp, comp_out.T_mm, comp_out.J0_p, comp_out.J0_m):
         t.fill_(float("nan"))
-    assert L.vsm_run_supported_f64(N, ns, coupling) == 1
+    assert L.vsm_run_supported(N, ns, coupling) == 1
     carr, marr = (C.c_int * 1)(coupling), (C.c_int * 1)(0)
-    nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, 1, carr))
+    nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
     assert nbytes > 0
     ws = torch.full((nbytes // 8,), float("nan"), dtype=torch.float64, device=dev)
     mu = torch.ones(N, dtype=torch.float64, device=dev)
@@ -106,10 +106,10 @@ def test_native_layout_import_export_roundtrip(vsm, arch, ns, nq, coupling):
 
 def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
     L = vsm._lib.lib()
-    assert L.vsm_run_supported_f64(80, 4, -1) == 0 and L.vsm_run_supported_f64(80, 4, 0x8033) == 1     # 40 + 20 + 20
-    assert L.vsm_run_supported_f64(63, 3, -1) == 0 and L.vsm_run_supported_f64(63, 3, 0x33) == 1        # 42 + 21
-    assert L.vsm_run_supported_f64(60, 3, -1) == 1 and L.vsm_run_supported_f64(61, 1, -1) == 0
-    assert L.vsm_run_workspace_bytes_f64(80, 4, 10, 1, (C.c_int * 1)(-1)) == 0
+    assert L.vsm_run_supported(80, 4, -1) == 0 and L.vsm_run_supported(80, 4, 0x8033) == 1     # 40 + 20 + 20
+    assert L.vsm_run_supported(66, 3, -1) == 0 and L.vsm_run_supported(66, 3, 0x33) == 1        # 44 + 22
+    assert L.vsm_run_supported(64, 1, -1) == 1 and L.vsm_run_supported(65, 1, -1) == 0
+    assert L.vsm_run_workspace_bytes(80, 4, 10, 1, (C.c_int * 1)(-1)) == 0
     mu = torch.ones(80, dtype=torch.float64, device="cuda:0")
     q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), 80, 4, 0, 1.0)
     run = C.c_void_p()
@@ -121,7 +121,8 @@ def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
     assert rc == 1 and b"workspace" in L.vsm_last_error()                                                # too small a workspace
 
 
-SHAPES = [("I", 3, 2), ("I", 9, 3), ("I", 21, 3), ("I", 33, 2), ("I", 55, 2), ("I", 85, 2), ("IQ", 21, 3), ("IQ", 53, 2),
+SHAPES = [("I", 3, 2), ("I", 9, 3), ("I", 21, 3), ("I", 33, 2), ("I", 55, 2), ("I", 85, 2), ("I", 115, 2), ("I", 117, 2), ("I", 120, 2),
+          ("IQ", 21, 3), ("IQ", 53, 2), ("IQ", 57, 2),
           ("IQU", 5, 4), ("IQU", 11, 3), ("IQU", 15, 3), ("IQU", 21, 3), ("IQU", 27, 2), ("IQU", 33, 3), ("IQU", 35, 3),
           ("IQUV", 5, 2), ("IQUV", 11, 4), ("IQUV", 21, 3), ("IQUV", 25, 2), ("IQUV", 35, 2)]
 
@@ -130,7 +131,8 @@ SHAPES = [("I", 3, 2), ("I", 9, 3), ("I", 21, 3), ("I", 33, 2), ("I", 55, 2), ("
 def test_native_run_vs_oracle_and_reference_layout_run(vsm, arch, monkeypatch, pol, l_trunc, L):
     """rt_run through the native-layout run against the oracle (1e-8, the FP64 gate of every rt_run test here) and against the
     reference-layout layer loop (the same operations in another summation order: 1e-10), for sub-problem sizes that land on every
-    row-tile count RT = 1..4, dense and split moments, two viewing angles that add zero-weight streams."""
+    row-tile count RT = 1..4 (incl. n = 61..64: no spare columns, the source vectors by mat-vecs over the A-forms), dense and split
+    moments, two viewing angles that add zero-weight streams."""
     H = vsm.host_model
     rng = np.random.default_rng(17)
     S = 11
@@ -148,7 +150,7 @@ def test_native_run_vs_oracle_and_reference_layout_run(vsm, arch, monkeypatch, p
     monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
     sc = vsm.CoreRT.prepare_scene(model)
     nat = sc._native_moments()
-    want = {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 60}
+    want = {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 64}
     assert nat == want, (nat, want)
     sc.run()
     torch.cuda.synchronize()
@@ -248,7 +250,7 @@ def test_native_run_layer_by_layer_through_the_c_abi(vsm, arch):
     for im in (0, 1):
         mom = sc.moments[im]
         carr, marr = (C.c_int * 1)(int(sc.coupling[im])), (C.c_int * 1)(im)
-        nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, 1, carr))
+        nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
         ws = torch.full((nbytes // 8,), float("nan"), dtype=torch.float64, device="cuda:0")
         q = sc.dq.cstruct()
         run = C.c_void_p()
@@ -337,3 +339,36 @@ def test_raman_run_with_m0_as_stokes_iq_scene(vsm, arch, monkeypatch, pol, l_tru
     for a, b in zip(red, full):
         assert _rel(a, b) < 1e-11
         assert a.shape[1] < 3 or np.all(a[:, 2:, :] == b[:, 2:, :]) or _rel(a[:, 2:, :], b[:, 2:, :]) < 1e-11
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 21), ("IQU", 35), ("IQUV", 25), ("I", 120), ("IQU", 57)])
+def test_native_run_float32_models(vsm, arch, monkeypatch, pol, l_trunc):
+    """A Float32 model through the native-layout run (vsm_run_*_f32: storage in single, the native records and the arithmetic of
+    the layer loop in double): within the reference's own FP32 gate of the oracle's Float32 run (test/test_float32.jl:58-64: 1e-2
+    end to end)."""
+    H = vsm.host_model
+    rng = np.random.default_rng(47)
+    S, L = 9, 3
+    tau_rayl = np.tile(np.linspace(0.03, 0.3, L), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.2, m_max=2)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], float_type=np.float32, **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    sc = vsm.CoreRT.prepare_scene(model)
+    ns = model.polarization_type.n
+    N = model.quad_points.Nquad * ns
+    nat = sc._native_moments()
+    assert nat == {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 64} and nat
+    sc.run()
+    torch.cuda.synchronize()
+    vsm._lib.check_device_status("native run (f32)")
+    Rn, Tn = sc.results_host()
+    assert Rn.dtype == np.float32
+    Ro, To = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], FT=np.float32, **kw))
+    assert _rel(Rn, Ro) < 1e-2 and _rel(Tn, To) < 1e-2
+    # and against the Float32 kernels of the reference-layout layer loop (the same Float32 algorithm -- its ndoubl is floor-limited,
+    # so neither is close to an FP64 run --, rounded in single at every operation there)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", False)
+    Rl, Tl = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    assert _rel(Rn, Rl) < 2e-3 and _rel(Tn, Tl) < 2e-3, (_rel(Rn, Rl), _rel(Tn, Tl))

@@ -138,14 +138,14 @@ _SIGS = {
     "vsm_interaction_inelastic_rrs_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_copy_added_to_composite_ie_{T}": (_I, [_I, _I, _P, _P, _P]),
     "vsm_postprocess_vza_ie_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "vsm_run_supported_f64": (_I, [_I, _I, _I]),
-    "vsm_run_workspace_bytes_f64": (_SZ, [_I, _I, _I, _I, _P]),
-    "vsm_run_create_f64": (_I, [_P, _I, _I, _P, _P, _P, _SZ, _P]),
-    "vsm_run_layer_f64": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
-    "vsm_run_export_f64": (_I, [_P, _P, _P]),
-    "vsm_run_import_f64": (_I, [_P, _P, _P]),
+    "vsm_run_supported": (_I, [_I, _I, _I]),
+    "vsm_run_workspace_bytes": (_SZ, [_I, _I, _I, _I, _P]),
+    "vsm_run_create_{T}": (_I, [_P, _I, _I, _P, _P, _P, _SZ, _P]),
+    "vsm_run_layer_{T}": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
+    "vsm_run_export_{T}": (_I, [_P, _P, _P]),
+    "vsm_run_import_{T}": (_I, [_P, _P, _P]),
     "vsm_run_destroy": (_I, [_P]),
-    "vsm_stokes_coupling_f64": (_I, [_I, _I, _I, _P, _P, _P, _P]),
+    "vsm_stokes_coupling_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P]),
     "vsm_test_lds_mm_{T}": (_I, [_I, _I, _P, _P, _P, _P]),
     "vsm_test_lds_inv_{T}": (_I, [_I, _I, _P, _P, _I, _P, _P]),
     "vsm_test_poison_lds": (_I, [_P]),

@@ -319,12 +319,12 @@ def layer_forward_multi_(tau_sum, dtau, F0, props_list, ms, ndoubl: int, dq: Dev
 
 
 def run_layer_native_(run, nm: int, ndoubl: int, dtau, varpi, tau_sum, F0, ncomp: int, zpp, zmp, z_stride: int, fcomp, toa: bool,
-                      layer_coupling=None):
+                      layer_coupling=None, dtype=torch.float64):
     """rt_kernel!(::noRS) of one scattering layer for the nm Fourier moments of a native-layout run (vsm_run_layer: per class of
     sub-problems the elemental pre-pass and ONE layer launch); zpp / zmp: ctypes arrays of the moments' Z device pointers;
     layer_coupling: ctypes int array, per moment the Stokes coupling mask of THIS layer's phase matrices (None: the run's)."""
-    _lib.check(_lib.lib().vsm_run_layer_f64(run, ndoubl, _ptr(dtau), _ptr(varpi), _ptr(tau_sum), _ptr(F0), ncomp, zpp, zmp,
-                                            z_stride, _ptr(fcomp), 1 if toa else 0, layer_coupling, _stream_ptr()))
+    _lib.call("vsm_run_layer", dtype, run, ndoubl, _ptr(dtau), _ptr(varpi), _ptr(tau_sum), _ptr(F0), ncomp, zpp, zmp, z_stride,
+              _ptr(fcomp), 1 if toa else 0, layer_coupling, _stream_ptr())
 
 
 def interaction_(scattering_interface: str, comp: CompositeLayer, added: AddedLayer, oplevel: bool = False,
@@ -746,15 +746,12 @@ class Scene:
         per block of the Z stacks): components that no scatterer of the run couples walk the layers as independent sub-problems
         (vsm_run_*; for m = 0 the (I,Q) x (U,V) blocks of every phase matrix are exactly zero, compute_Z_matrices.jl:26-110), and
         a block that the scatterers of ONE layer leave exactly zero takes that layer as a diagonal step."""
-        self.coupling = self.coupling_comp = None
-        if self.dt != torch.float64:
-            return
         C_ = int(self.Zc[0][0].shape[0])
         if getattr(self, "_coupling_d", None) is None:
             self._coupling_d = torch.zeros((len(self.Zc), C_), dtype=torch.int32, device=self.dev)
         for m, (Zpp, Zmp) in enumerate(self.Zc):
-            _lib.check(_lib.lib().vsm_stokes_coupling_f64(self.N, self.pol.n, C_, _ptr(Zpp), _ptr(Zmp),
-                                                          C.c_void_p(self._coupling_d[m].data_ptr()), _stream_ptr()))
+            _lib.call("vsm_stokes_coupling", self.dt, self.N, self.pol.n, C_, _ptr(Zpp), _ptr(Zmp),
+                      C.c_void_p(self._coupling_d[m].data_ptr()), _stream_ptr())
         self.coupling_comp = self._coupling_d.cpu().numpy().astype(np.int64)             # [moment, scatterer]
         self.coupling = [int(np.bitwise_or.reduce(row)) for row in self.coupling_comp]    # per moment: every scatterer of the run
 
@@ -833,10 +830,11 @@ class Scene:
         return self.R_SFI, self.T_SFI
 
     def _native_moments(self):
-        """Indices of the Fourier moments whose layer loop runs on the native-layout composite (vsm_run_*): FP64, every layer
-        scattering with the 11 interface (the only steps the run object takes), at most four scatterers per layer, and every
-        block of coupled Stokes components within the native kernels' size."""
-        if not NATIVE_RUN or self.dt != torch.float64 or getattr(self, "coupling", None) is None or not self.moments:
+        """Indices of the Fourier moments whose layer loop runs on the native-layout composite (vsm_run_*): every layer scattering
+        with the 11 interface (the only steps the run object takes), at most four scatterers per layer, and every block of coupled
+        Stokes components within the native kernels' size (64 rows).  Float32 models: storage in single, the native records and
+        the arithmetic of the layer loop in double."""
+        if not NATIVE_RUN or getattr(self, "coupling", None) is None or not self.moments:
             return set()
         eps2 = 2 * np.finfo(self.FT).eps
         for iz, ly in enumerate(self.moments[0]["layers"]):
@@ -845,7 +843,7 @@ class Scene:
                 return set()
         L = _lib.lib()
         return {i for i, mom in enumerate(self.moments)
-                if L.vsm_run_supported_f64(self.N, self.pol.n, int(self.coupling[mom["m"]])) != 0}
+                if L.vsm_run_supported(self.N, self.pol.n, int(self.coupling[mom["m"]])) != 0}
 
     def _run_layers_native(self, group, comps):
         """rt_run's layer loop (rt_run.jl:383-453) for the moments of `group` with the CompositeLayer in kernel-native layout:
@@ -854,13 +852,13 @@ class Scene:
         nm, N, S, ns = len(group), self.N, self.S, self.pol.n
         marr = (C.c_int * nm)(*[int(mom["m"]) for mom in group])
         carr = (C.c_int * nm)(*[int(self.coupling[mom["m"]]) for mom in group])
-        nbytes = int(L.vsm_run_workspace_bytes_f64(N, ns, S, nm, carr))
+        nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, nm, carr))
         ws = getattr(self, "_native_ws", None)
         if ws is None or ws.numel() * 8 < nbytes:
             ws = self._native_ws = _lib.poison(torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=self.dev))
         q = self.dq.cstruct()
         run = C.c_void_p()
-        _lib.check(L.vsm_run_create_f64(C.byref(q), S, nm, marr, carr, _ptr(ws), nbytes, C.byref(run)))
+        _lib.call("vsm_run_create", self.dt, C.byref(q), S, nm, marr, carr, _ptr(ws), nbytes, C.byref(run))
         try:
             for iz in range(self.Nz):
                 ly0 = group[0]["layers"][iz]
@@ -871,9 +869,9 @@ class Scene:
                 ncomp = 0 if p0.fcomp is None else int(p0.fcomp.shape[1])
                 lc = (C.c_int * nm)(*[self._layer_coupling(mom["m"], iz) for mom in group])
                 run_layer_native_(run, nm, int(ly0["nd"]), ly0["dtau"], p0.varpi, ly0["tau_sum"], self.F0, ncomp, zpp, zmp,
-                                  0 if ncomp else p0.z_stride, p0.fcomp, iz == 0, lc)
+                                  0 if ncomp else p0.z_stride, p0.fcomp, iz == 0, lc, self.dt)
             cc = (type(comps[0].cstruct()) * nm)(*[c.cstruct() for c in comps])
-            _lib.check(L.vsm_run_export_f64(run, cc, _stream_ptr()))
+            _lib.call("vsm_run_export", self.dt, run, cc, _stream_ptr())
         finally:
             L.vsm_run_destroy(run)
 

@@ -228,12 +228,9 @@ class SceneRRS:
             Zm = torch.empty_like(Zp)
             _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, tab.shape[1], CR._ptr(gd), CR._ptr(Zp), CR._ptr(Zm), CR._stream_ptr())
             self.Zie.append((Zp, Zm))
-        zie_mask0 = None
-        if dt == torch.float64:
-            md = torch.zeros(1, dtype=torch.int32, device=dev)
-            _lib.check(_lib.lib().vsm_stokes_coupling_f64(N, pol.n, 1, CR._ptr(self.Zie[0][0]), CR._ptr(self.Zie[0][1]), CR._ptr(md),
-                                                          CR._stream_ptr()))
-            zie_mask0 = int(md.cpu()[0])
+        md = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.call("vsm_stokes_coupling", dt, N, pol.n, 1, CR._ptr(self.Zie[0][0]), CR._ptr(self.Zie[0][1]), CR._ptr(md), CR._stream_ptr())
+        zie_mask0 = int(md.cpu()[0])
         nV = len(model.vza)
         self.out = [fwd.R_SFI, fwd.T_SFI] + [torch.zeros((S, pol.n, nV), dtype=dt, device=dev) for _ in range(2)]
         self.expk = torch.empty(max(S, 1), dtype=dt, device=dev)

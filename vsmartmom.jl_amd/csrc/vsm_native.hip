@@ -42,8 +42,9 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
   double* rsg = sm.vec[3];   // row sign of apply_D
   const int tid = threadIdx.x;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;   // spare columns (>= n, never read as k) carry j0+ / j1- through a step
-  static_assert(c2 < G::NP, "no spare columns for the source vectors");
-  const bool own_wave = p.wave == (c1 >> 4);
+  constexpr bool RID = c2 < G::NP;              // n = 61..64 (KS = 16): no spare column, the source vectors by VALU mat-vecs
+  static_assert(RID || RT == 4, "no spare columns for the source vectors");
+  const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
   ncopy_image<RT>(sm.P, img, p);
   ncopy_image<RT>(sm.Q, img + G::AF, p);
@@ -74,6 +75,10 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
   for (int it = 0; it < ndoubl; ++it) {
     nstrip<RT> W, tt;
     const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
+    if constexpr (!RID) {   // r j0+ , r j1-   (P = [r])
+      nmv_part(sm.P, jp, 1.0, sm.mv[p.wave], p);
+      nmv_part(sm.P, jm, expk, sm.mv[4 + p.wave], p);
+    }
     {
       nstrip<RT> Gs;
       {
@@ -91,6 +96,12 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
             }
         }
         const double nrm = nnorm(E, n, sm, slot, p);   // (its barrier: [r] is free)
+        if constexpr (!RID) {   // u1 = j1- + r j0+ , u2 = j0+ + r j1-   (every wave is past the norm reduction's barrier)
+          if (tid < G::NP) {
+            sm.vec[4][tid] = jm[tid] * expk + nmv_sum(sm, 0, tid);
+            sm.vec[5][tid] = jp[tid] + nmv_sum(sm, 4, tid);
+          }
+        }
         ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);
       }
       tt.zero();
@@ -100,12 +111,17 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
     __syncthreads();                       // P ([E]) and Q ([t]) no longer read
     nstore(dP, tt, p);
     __syncthreads();
+    if constexpr (!RID) {   // tt u1 , tt u2   (the partial sums of r j were consumed two barriers ago)
+      nmv_part(sm.P, sm.vec[4], 1.0, sm.mv[p.wave], p);
+      nmv_part(sm.P, sm.vec[5], 1.0, sm.mv[4 + p.wave], p);
+    }
     {
       nstrip<RT> tn;
       tn.zero();
       nmm2<RT, KS>(r_s, tn, dP, W, t_s, p);   // r' = r + tt W (riders: the new j0-, j0+) ; t' = tt t
       t_s = tn;
     }
+    const double expk_step = expk;
     expk = expk * expk;
     if (own_wave) {
       const double ft = laneB ? expk : 1.0;   // t_s[c1] = j0+', t_s[c2] = j1-' = j0-' expk'
@@ -117,8 +133,14 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
           t_s.v[ta][r] = laneAB ? u : t_s.v[ta][r];
         }
     }
+    if (it + 1 < ndoubl || !RID) __syncthreads();   // everybody finished reading P ([tt])
+    if constexpr (!RID) {   // j0- += tt u1 ; j0+ = j0+ expk + tt u2   (visible after the barrier below / after the loop)
+      if (tid < G::NP) {
+        jm[tid] += nmv_sum(sm, 0, tid);
+        jp[tid] = jp[tid] * expk_step + nmv_sum(sm, 4, tid);
+      }
+    }
     if (it + 1 < ndoubl) {
-      __syncthreads();                     // everybody finished reading P ([tt])
       nstore(dP, r_s, p);
       nstore(dQ, t_s, p);
       __syncthreads();
@@ -182,7 +204,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   double* J0_p = comp + 4 * G::AF;
   double* J0_m = J0_p + G::NP;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
-  const bool own_wave = p.wave == (c1 >> 4);
+  constexpr bool RID = c2 < G::NP;
+  const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
   int slot = 0;
   const ndpar<RT> dp(sm.usg, p);
@@ -208,6 +231,10 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   }
   ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
   __syncthreads();                                                                                       // (a)
+  if constexpr (!RID) {   // R+- j0- , T-- j0-
+    nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);
+    nmv_part(sm.Q, vjm, 1.0, sm.mv[4 + p.wave], p);
+  }
   {
     nstrip<RT> E;
     E.zero();
@@ -224,6 +251,12 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
         }
     }
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
+    if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
+      if (tid < G::NP) {
+        vz[tid] = vJp[tid] + nmv_sum(sm, 0, tid);
+        vs[tid] = nmv_sum(sm, 4, tid);
+      }
+    }
     ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
   }
   nstrip<RT> V;
@@ -261,6 +294,10 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   nld_native(Tpp, T_pp, p);
   nld_native(Rmp, R_mp, p);
   __syncthreads();                        // (g)
+  if constexpr (!RID) {   // T21 z , Y z
+    nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
+    nmv_part(sm.Q, vz, 1.0, sm.mv[4 + p.wave], p);
+  }
   if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
@@ -298,7 +335,19 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
         J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
       }
   }
+  if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
+    __syncthreads();
+    if (tid < G::NP) {
+      J0_p[tid] = vjp[tid] + nmv_sum(sm, 0, tid);
+      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum(sm, 4, tid);
+    }
+  }
 }
+
+// the LDS block decides the workgroups per CU the register budgets (ngeo::WPS) are set for
+static_assert(sizeof(nsmem<2>) * 8 <= 163840, "two row tiles: eight workgroups per CU");
+static_assert(sizeof(nsmem<3>) * 4 <= 163840, "three row tiles: four workgroups per CU");
+static_assert(sizeof(nsmem<4>) * 2 <= 163840, "four row tiles: two workgroups per CU");
 
 template <int RT, int KS>
 __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(int n, int gsz, unsigned uvmask, int ndoubl,
@@ -344,8 +393,8 @@ VSM_NATIVE_DECL(VSM_NATIVE_KS)
 int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsigned uvmask, int gsz, int ndoubl, int toa,
                                                   const double* pre, const nlayer_comps& comps, int* status, hipStream_t st) {
   constexpr int KS = VSM_NATIVE_KS;
-  constexpr int RT = (4 * KS + 2 + 15) / 16;
-  static_assert(RT >= 1 && RT <= 4, "n <= 60");
+  constexpr int RT = KS == 16 ? 4 : (4 * KS + 2 + 15) / 16;   // (KS = 16, n = 61..64: no spare columns, mat-vec source path)
+  static_assert(RT >= 1 && RT <= 4, "n <= 64");
   auto kern = k_layer_native<RT, KS>;
   const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(nsmem<RT>), "hipFuncSetAttribute(k_layer_native)");
   if (prepared) return prepared;
@@ -373,6 +422,7 @@ VSM_NATIVE_DECL(12)
 VSM_NATIVE_DECL(13)
 VSM_NATIVE_DECL(14)
 VSM_NATIVE_DECL(15)
+VSM_NATIVE_DECL(16)
 
 namespace {
 
@@ -382,57 +432,61 @@ namespace {
 // (i / gsz) n_stokes + g[i % gsz] of the full problem.  Thread = (row, column phase): 16 consecutive threads write 16
 // consecutive rows of one column (128 contiguous bytes of an image block).
 // ---------------------------------------------------------------------------------------------------------------------------
+// ST = the storage type of the caller's arrays (double, or float: a Float32 run whose blocks fit these kernels -- inputs are
+// converted on load, everything from here to the export of the composite is FP64).
+template <typename ST>
 struct nsub_pre {
   int m, gsz;
   int g[4];
-  zsrc<double> z;
+  zsrc<ST> z;
 };
+template <typename ST>
 struct npre_args {
-  nsub_pre s[NSUB_MAX];
+  nsub_pre<ST> s[NSUB_MAX];
 };
-template <int RT, bool MIX>
-__global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<double> q, int n, int ndoubl, const double* __restrict__ dtau,
-                                                              const double* __restrict__ varpi,
-                                                              const double* __restrict__ tau_sum, const double* __restrict__ F0,
-                                                              npre_args a, double* __restrict__ pre) {
+template <int RT, bool MIX, typename ST>
+__global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<ST> q, int n, int ndoubl, const ST* __restrict__ dtau,
+                                                              const ST* __restrict__ varpi, const ST* __restrict__ tau_sum,
+                                                              const ST* __restrict__ F0, npre_args<ST> a,
+                                                              double* __restrict__ pre) {
   using G = ngeo<RT>;
   constexpr int NP = G::NP;
   __shared__ double mus[NP], xs[NP], es[NP], ems[NP], wts[NP];
   __shared__ int frow[NP];
   __shared__ int thick_flag;
   const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
-  const nsub_pre& sp = a.s[isub];
+  const nsub_pre<ST>& sp = a.s[isub];
   const int N = q.N, ns = q.n_stokes, m = sp.m, gsz = sp.gsz;
-  const zsrc<double> z = sp.z;
-  const double d = dtau[s], w = varpi[s];
+  const zsrc<ST> z = sp.z;
+  const double d = (double)dtau[s], w = (double)varpi[s];
   const int ncomp = MIX ? z.ncomp : 0;
   const long long NNz = (long long)N * N;
-  const double* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
-  const double* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
+  const ST* Zp = z.Zpp + (ncomp ? 0 : (long long)s * z.zs);
+  const ST* Zm = z.Zmp + (ncomp ? 0 : (long long)s * z.zs);
   double fk[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (k < ncomp) fk[k] = z.fcomp[(long long)s * ncomp + k];
-  auto zget = [&](const double* Z, long long zo) {
-    if (ncomp == 0) return Z[zo];
+    if (k < ncomp) fk[k] = (double)z.fcomp[(long long)s * ncomp + k];
+  auto zget = [&](const ST* Z, long long zo) {
+    if (ncomp == 0) return (double)Z[zo];
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (k < ncomp) acc += fk[k] * Z[k * NNz + zo];
+      if (k < ncomp) acc += fk[k] * (double)Z[k * NNz + zo];
     return acc;
   };
   if (tid < NP) {
     const bool in = tid < n;
     const int ga = sp.g[tid % gsz];
     const int fr = in ? (tid / gsz) * ns + ga : 0;
-    const double mu = in ? q.mu[fr] : 1.0;
+    const double mu = in ? (double)q.mu[fr] : 1.0;
     const double x = d / mu;
     frow[tid] = fr;
     mus[tid] = mu;
     xs[tid] = x;
     es[tid] = exp(-x);
     ems[tid] = expm1(-x);
-    wts[tid] = in ? q.wt[fr] : 0.0;
+    wts[tid] = in ? (double)q.wt[fr] : 0.0;
   }
   if (tid == 0) thick_flag = 0;
   __syncthreads();
@@ -449,7 +503,7 @@ __global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<double> q, in
   double* T = out + G::AF;
   const int Kend = ((n + 3) >> 2) << 2;
   const int c1 = Kend, c2 = Kend + 1;
-  const bool riders_in = ndoubl > 0;
+  const bool riders_in = ndoubl > 0 && c2 < NP;   // (n = 61..64: no spare column; the layer kernel uses mat-vecs)
   const int fi = frow[ic];
   for (int j = ph; j < NP; j += 4) {
     if (riders_in && (j == c1 || j == c2)) continue;   // written below
@@ -471,22 +525,22 @@ __global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<double> q, in
   }
   if (ph == 0) {   // SFI source of the solar beam: the same formulas with the solar column (see elemental_pair)
     const int i0 = ns * q.i_mu0;
-    const double mu0n = q.mu[i0];
+    const double mu0n = (double)q.mu[i0];
     const double x0 = d / mu0n, e0 = exp(-x0), a0 = expm1(-x0);
     double zp = 0.0, zm = 0.0;
     for (int qq = 0; qq < ns; ++qq) {
       const long long zo = fi + (long long)N * (i0 + qq);
-      const double f = F0[qq + (long long)ns * s];
+      const double f = (double)F0[qq + (long long)ns * s];
       zp += zget(Zp, zo) * f;
       zm += zget(Zm, zo) * f;
     }
     double rr, tt;
     // (the diagonal case mu_i == mu_0 of the source never takes the i == j form: elemental.jl:370-382)
     elemental_pair(w, zp, zm, mi, xi, ai, ei, mu0n, x0, a0, e0, (m == 0) ? 0.5 : 0.25, false, thick || x0 >= 0.5, rr, tt);
-    const double att = exp(-tau_sum[s] / mu0n);
+    const double att = exp(-(double)tau_sum[s] / mu0n);
     const double vp = (i < n) ? tt * att : 0.0;
     const double vm = (i < n) ? rr * att * sg : 0.0;
-    const double expk0 = exp(-d / q.mu0);
+    const double expk0 = exp(-d / (double)q.mu0);
     out[2 * G::AF + i] = vp;
     out[2 * G::AF + NP + i] = vm;
     out[2 * G::AF + 2 * NP + i] = expk0;
@@ -519,10 +573,11 @@ __device__ __forceinline__ int nnat_idx_rt(int rt, int i, int j) {
     default: return nnat_idx<4>(i, j);
   }
 }
-__global__ __launch_bounds__(256) void k_native_export(int N, int ns, ngroup_map gm, composite<double> c) {
+template <typename ST>
+__global__ __launch_bounds__(256) void k_native_export(int N, int ns, ngroup_map gm, composite<ST> c) {
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N;
-  double* out[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
+  ST* out[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
   for (int e = tid; e < N * N; e += 256) {
     const int i = e % N, j = e / N;
     const int ai = i % ns, aj = j % ns;
@@ -537,23 +592,24 @@ __global__ __launch_bounds__(256) void k_native_export(int N, int ns, ngroup_map
       for (int k = 0; k < 4; ++k) v[k] = cn[k * af + ix];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k][e] = v[k];
+    for (int k = 0; k < 4; ++k) out[k][e] = (ST)v[k];
   }
   if (tid < N) {
     const int ai = tid % ns, gi = gm.grp_of[ai];
     const int rt = gm.rt[gi], np = 16 * rt, af = np * np;
     const double* cn = gm.base[gi] + (long long)s * (4 * af + 2 * np);
     const int is = (tid / ns) * gm.gsz[gi] + gm.pos_in[ai];
-    c.J0_p[(long long)s * N + tid] = cn[4 * af + is];
-    c.J0_m[(long long)s * N + tid] = cn[4 * af + np + is];
+    c.J0_p[(long long)s * N + tid] = (ST)cn[4 * af + is];
+    c.J0_m[(long long)s * N + tid] = (ST)cn[4 * af + np + is];
   }
 }
 // reference layout -> native (padding zero); elements that couple different groups are dropped (they are exact zeros for a
 // composite that was built under the same coupling)
-__global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map gm, composite<double> c) {
+template <typename ST>
+__global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map gm, composite<ST> c) {
   const int s = blockIdx.x, tid = threadIdx.x;
   const long long NN = (long long)N * N;
-  const double* in[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
+  const ST* in[4] = {c.R_mp + s * NN, c.R_pm + s * NN, c.T_pp + s * NN, c.T_mm + s * NN};
   for (int g = 0; g < gm.ngroups; ++g) {
     const int rt = gm.rt[g], np = 16 * rt, af = np * np, n = gm.n[g], gsz = gm.gsz[g];
     double* cn = gm.base[g] + (long long)s * (4 * af + 2 * np);
@@ -566,7 +622,7 @@ __global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map
       if (is < n && js < n) {
         const int i = (is / gsz) * ns + comp_of[is % gsz], j = (js / gsz) * ns + comp_of[js % gsz];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = in[k][i + (long long)N * j];
+        for (int k = 0; k < 4; ++k) v[k] = (double)in[k][i + (long long)N * j];
       }
       const int ix = nnat_idx_rt(rt, is, js);
 #pragma unroll
@@ -576,8 +632,8 @@ __global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map
       double vp = 0.0, vm = 0.0;
       if (tid < n) {
         const int i = (tid / gsz) * ns + comp_of[tid % gsz];
-        vp = c.J0_p[(long long)s * N + i];
-        vm = c.J0_m[(long long)s * N + i];
+        vp = (double)c.J0_p[(long long)s * N + i];
+        vm = (double)c.J0_m[(long long)s * N + i];
       }
       cn[4 * af + tid] = vp;
       cn[4 * af + np + tid] = vm;
@@ -587,15 +643,16 @@ __global__ __launch_bounds__(256) void k_native_import(int N, int ns, ngroup_map
 
 // Which Stokes components a phase matrix couples: bit 4 a + b of mask[b] is set when some element (i, j) with i % ns == a,
 // j % ns == b of block b of Zpp / Zmp [N,N,nblocks] is not exactly zero.
-__global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, const double* __restrict__ Zpp,
-                                                         const double* __restrict__ Zmp, int* __restrict__ mask) {
+template <typename ST>
+__global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, const ST* __restrict__ Zpp, const ST* __restrict__ Zmp,
+                                                         int* __restrict__ mask) {
   unsigned mm = 0;
   const long long NN = (long long)N * N;
-  const double* zp = Zpp + NN * blockIdx.y;
-  const double* zm = Zmp + NN * blockIdx.y;
+  const ST* zp = Zpp + NN * blockIdx.y;
+  const ST* zm = Zmp + NN * blockIdx.y;
   for (long long e = blockIdx.x * 256ll + threadIdx.x; e < NN; e += 256ll * gridDim.x) {
     const int i = (int)(e % N), j = (int)(e / N);
-    if (zp[e] != 0.0 || zm[e] != 0.0) mm |= 1u << (4 * (i % ns) + (j % ns));
+    if (zp[e] != ST(0) || zm[e] != ST(0)) mm |= 1u << (4 * (i % ns) + (j % ns));
   }
   if (mm) atomicOr(mask + blockIdx.y, (int)mm);
 }
@@ -612,8 +669,9 @@ struct ndiag_args {
   int gsz[NSUB_MAX];
   int g0[NSUB_MAX];    // the group's Stokes components, 4 bits each
 };
-__global__ __launch_bounds__(256) void k_native_diag_layer(quad<double> q, int rt, int n, double scale, int toa,
-                                                           const double* __restrict__ dtau, ndiag_args a) {
+template <typename ST>
+__global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, int n, double scale, int toa,
+                                                           const ST* __restrict__ dtau, ndiag_args a) {
   __shared__ double tt[64];
   const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
   const int np = 16 * rt, af = np * np, gsz = a.gsz[isub];
@@ -622,7 +680,7 @@ __global__ __launch_bounds__(256) void k_native_diag_layer(quad<double> q, int r
     double t = 0.0;
     if (tid < n) {
       const int fr = (tid / gsz) * q.n_stokes + ((a.g0[isub] >> (4 * (tid % gsz))) & 15);
-      t = exp(-dtau[s] * scale / q.mu[fr]);
+      t = exp(-(double)dtau[s] * scale / (double)q.mu[fr]);
     }
     tt[tid] = t;
   }
@@ -669,7 +727,10 @@ struct nat_sub {
 }  // namespace vsm
 
 struct vsm_run {
-  vsm::quad<double> q;
+  const void *mu, *wt;     // the quadrature arrays of the caller (element type: elem_size)
+  int N, ns, i_mu0;
+  double mu0;
+  int elem_size;           // 8: FP64 arrays, 4: FP32 arrays (storage only: the native records and all arithmetic are FP64)
   int S, nm;
   std::vector<int> m;
   std::vector<vsm::nat_sub> subs;
@@ -713,7 +774,7 @@ static int stokes_groups(int ns, int coupling, int grp_of[4], int groups[4][4], 
   }
   return ng;
 }
-static inline int rt_of(int n) { return (4 * ((n + 3) / 4) + 2 + 15) / 16; }
+static inline int rt_of(int n) { return n > 60 ? 4 : (4 * ((n + 3) / 4) + 2 + 15) / 16; }
 static inline size_t comp_stride_rt(int rt) { return (size_t)4 * (16 * rt) * (16 * rt) + 2 * 16 * rt; }
 static inline size_t pre_stride_rt(int rt) { return (size_t)2 * (16 * rt) * (16 * rt) + 3 * 16 * rt; }
 
@@ -739,8 +800,8 @@ static int plan_subs(int N, int ns, int nm, const int* m, const int* coupling, s
       for (int k = 0; k < gsz[g]; ++k)
         if (groups[g][k] >= 2) sb.uvmask |= 1u << k;
       sb.n = nq * gsz[g];
-      if (sb.n > 60) {
-        set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (60)", sb.n, N,
+      if (sb.n > 64) {
+        set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (64)", sb.n, N,
                   gsz[g]);
         return VSM_ERR_UNSUPPORTED;
       }
@@ -760,7 +821,7 @@ static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, 
   case KS: return VSM_NCAT(launch_layer_native_, KS)(S, nsub, n, uvmask, gsz, ndoubl, toa, pre, comps, status, st);
   switch (ks) {
     VSM_NL(1) VSM_NL(2) VSM_NL(3) VSM_NL(4) VSM_NL(5) VSM_NL(6) VSM_NL(7) VSM_NL(8) VSM_NL(9) VSM_NL(10) VSM_NL(11) VSM_NL(12)
-    VSM_NL(13) VSM_NL(14) VSM_NL(15)
+    VSM_NL(13) VSM_NL(14) VSM_NL(15) VSM_NL(16)
     default: break;
   }
 #undef VSM_NL
@@ -768,15 +829,14 @@ static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, 
   return VSM_ERR_UNSUPPORTED;
 }
 
-template <int RT>
-static void launch_pre(bool mix, const quad<double>& q, int S, int nsub, int n, int ndoubl, const double* dtau,
-                       const double* varpi, const double* tau_sum, const double* F0, const npre_args& a, double* pre,
-                       hipStream_t st) {
+template <int RT, typename ST>
+static void launch_pre(bool mix, const quad<ST>& q, int S, int nsub, int n, int ndoubl, const ST* dtau, const ST* varpi,
+                       const ST* tau_sum, const ST* F0, const npre_args<ST>& a, double* pre, hipStream_t st) {
   const dim3 grid(S, nsub), block(64 * RT);
   if (mix)
-    hipLaunchKernelGGL((k_elemental_native<RT, true>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+    hipLaunchKernelGGL((k_elemental_native<RT, true, ST>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
   else
-    hipLaunchKernelGGL((k_elemental_native<RT, false>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
+    hipLaunchKernelGGL((k_elemental_native<RT, false, ST>), grid, block, 0, st, q, n, ndoubl, dtau, varpi, tau_sum, F0, a, pre);
 }
 
 static ngroup_map group_map(const vsm_run* run, int im) {
@@ -803,36 +863,25 @@ static ngroup_map group_map(const vsm_run* run, int im) {
   return gm;
 }
 
-}  // namespace
-}  // namespace vsm
-
-using namespace vsm;
-
-extern "C" {
-
-int vsm_run_supported_f64(int N, int n_stokes, int coupling) {
-  if (N <= 0 || n_stokes < 1 || n_stokes > 4 || N % n_stokes) return 0;
-  int grp_of[4], groups[4][4], gsz[4];
-  const int ng = stokes_groups(n_stokes, coupling, grp_of, groups, gsz);
-  for (int g = 0; g < ng; ++g)
-    if ((N / n_stokes) * gsz[g] > 60) return 0;
-  return 1;
+template <typename ST>
+static quad<ST> run_quad(const vsm_run* run) {
+  return quad<ST>{static_cast<const ST*>(run->mu), static_cast<const ST*>(run->wt), run->N, run->ns, run->i_mu0, (ST)run->mu0};
 }
 
-size_t vsm_run_workspace_bytes_f64(int N, int n_stokes, int S, int nm, const int* coupling) {
-  std::vector<nat_sub> subs;
-  size_t total = 0;
-  if (S < 0 || nm < 0 || plan_subs(N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
-  return total * sizeof(double);
-}
-
-int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m, const int* coupling, void* workspace,
-                       size_t workspace_bytes, vsm_run** run_out) {
+template <typename ST, typename Q>
+static int run_create(const Q* q, int S, int nm, const int* m, const int* coupling, void* workspace, size_t workspace_bytes,
+                      vsm_run** run_out) {
   VSM_REQUIRE(q && q->mu && q->wt && run_out && m, "vsm_run_create: null argument");
   VSM_REQUIRE(S >= 0 && nm >= 1 && nm <= NSUB_MAX, "vsm_run_create: bad S = %d / nm = %d (at most %d moments per run)", S, nm,
               NSUB_MAX);
   vsm_run* run = new vsm_run;
-  run->q = quad<double>{q->mu, q->wt, q->N, q->n_stokes, q->i_mu0, q->mu0};
+  run->mu = q->mu;
+  run->wt = q->wt;
+  run->N = q->N;
+  run->ns = q->n_stokes;
+  run->i_mu0 = q->i_mu0;
+  run->mu0 = (double)q->mu0;
+  run->elem_size = (int)sizeof(ST);
   run->S = S;
   run->nm = nm;
   run->m.assign(m, m + nm);
@@ -867,20 +916,18 @@ int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m, const
   return VSM_OK;
 }
 
-int vsm_run_destroy(vsm_run* run) {
-  delete run;
-  return VSM_OK;
-}
-
-int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum, const double* F0,
-                      int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
-                      int toa, const int* layer_coupling, void* stream) {
+template <typename ST>
+static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, const ST* tau_sum, const ST* F0, int ncomp,
+                     const ST* const* Zpp, const ST* const* Zmp, long long z_stride, const ST* fcomp, int toa,
+                     const int* layer_coupling, void* stream) {
   VSM_REQUIRE(run && dtau && varpi && tau_sum && F0 && Zpp && Zmp, "vsm_run_layer: null argument");
+  VSM_REQUIRE(run->elem_size == (int)sizeof(ST), "vsm_run_layer: the run was created for %d-byte arrays", run->elem_size);
   VSM_REQUIRE(ndoubl >= 0 && ndoubl < 60 && ncomp >= 0 && ncomp <= 4 && (ncomp == 0 || fcomp), "vsm_run_layer: bad ndoubl / component mix");
   if (run->S == 0) return VSM_OK;
   hipStream_t st = as_stream(stream);
   int* status = device_status();
   if (!status) return VSM_ERR_HIP;
+  const quad<ST> q = run_quad<ST>(run);
   // a sub-problem whose Stokes block the layer's phase matrices leave exactly zero takes the diagonal step
   auto trivial = [&](const nat_sub& sb) {
     if (!layer_coupling || layer_coupling[sb.im] < 0) return false;
@@ -912,13 +959,13 @@ int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double
         da.gsz[k] = sb.gsz;
         da.g0[k] = sb.g[0] | (sb.g[1] << 4) | (sb.g[2] << 8) | (sb.g[3] << 12);
       }
-      hipLaunchKernelGGL(k_native_diag_layer, dim3(run->S, nt), dim3(256), 0, st, run->q, h.rt, h.n, ldexp(1.0, ndoubl), toa, dtau,
+      hipLaunchKernelGGL((k_native_diag_layer<ST>), dim3(run->S, nt), dim3(256), 0, st, q, h.rt, h.n, ldexp(1.0, ndoubl), toa, dtau,
                          da);
       VSM_LAUNCH_CHECK("k_native_diag_layer");
     }
     const int nsub = (int)act.size();
     if (!nsub) continue;
-    npre_args pa;
+    npre_args<ST> pa;
     nlayer_comps lc;
     for (int k = 0; k < NSUB_MAX; ++k) {
       const nat_sub& sb = run->subs[act[k < nsub ? k : 0]];
@@ -926,16 +973,16 @@ int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double
       pa.s[k].gsz = sb.gsz;
       for (int a = 0; a < 4; ++a) pa.s[k].g[a] = sb.g[a];
       VSM_REQUIRE(Zpp[sb.im] && Zmp[sb.im], "vsm_run_layer: null Z of moment %d", sb.im);
-      pa.s[k].z = zsrc<double>{Zpp[sb.im], Zmp[sb.im], ncomp ? 0 : z_stride, ncomp, fcomp};
+      pa.s[k].z = zsrc<ST>{Zpp[sb.im], Zmp[sb.im], ncomp ? 0 : z_stride, ncomp, fcomp};
       lc.c[k] = run->ws + sb.comp_off;
     }
     double* pre_cl = pre + off;
     off += pre_stride_rt(h.rt) * (size_t)run->S * nsub;
     switch (h.rt) {
-      case 1: launch_pre<1>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
-      case 2: launch_pre<2>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
-      case 3: launch_pre<3>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
-      default: launch_pre<4>(ncomp > 0, run->q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 1: launch_pre<1, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 2: launch_pre<2, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 3: launch_pre<3, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      default: launch_pre<4, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
     }
     VSM_LAUNCH_CHECK("k_elemental_native");
     const int rc = launch_layer_native(h.ks, run->S, nsub, h.n, h.uvmask, h.gsz, ndoubl, toa, pre_cl, lc, status, st);
@@ -944,44 +991,104 @@ int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double
   return VSM_OK;
 }
 
-int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
-  VSM_REQUIRE(run && comps, "vsm_run_export: null argument");
+template <typename ST, typename CS, bool IMPORT>
+static int run_convert(vsm_run* run, const CS* comps, void* stream) {
+  VSM_REQUIRE(run && comps, "vsm_run_export / import: null argument");
+  VSM_REQUIRE(run->elem_size == (int)sizeof(ST), "vsm_run_export / import: the run was created for %d-byte arrays", run->elem_size);
   if (run->S == 0) return VSM_OK;
   for (int im = 0; im < run->nm; ++im) {
-    const vsm_composite_f64& c = comps[im];
-    VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_export: null composite array (moment %d)", im);
+    const CS& c = comps[im];
+    VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_export / import: null composite array (moment %d)", im);
     const ngroup_map gm = group_map(run, im);
-    hipLaunchKernelGGL(k_native_export, dim3(run->S), dim3(256), 0, as_stream(stream), run->q.N, run->q.n_stokes, gm,
-                       composite<double>{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m});
-    VSM_LAUNCH_CHECK("k_native_export");
+    const composite<ST> cc{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m};
+    if (IMPORT)
+      hipLaunchKernelGGL((k_native_import<ST>), dim3(run->S), dim3(256), 0, as_stream(stream), run->N, run->ns, gm, cc);
+    else
+      hipLaunchKernelGGL((k_native_export<ST>), dim3(run->S), dim3(256), 0, as_stream(stream), run->N, run->ns, gm, cc);
+    VSM_LAUNCH_CHECK("k_native_export / import");
   }
   return VSM_OK;
 }
 
-int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
-  VSM_REQUIRE(run && comps, "vsm_run_import: null argument");
-  if (run->S == 0) return VSM_OK;
-  for (int im = 0; im < run->nm; ++im) {
-    const vsm_composite_f64& c = comps[im];
-    VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_import: null composite array (moment %d)", im);
-    const ngroup_map gm = group_map(run, im);
-    hipLaunchKernelGGL(k_native_import, dim3(run->S), dim3(256), 0, as_stream(stream), run->q.N, run->q.n_stokes, gm,
-                       composite<double>{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m});
-    VSM_LAUNCH_CHECK("k_native_import");
-  }
-  return VSM_OK;
-}
-
-int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream) {
+template <typename ST>
+static int stokes_coupling(int N, int n_stokes, int nblocks, const ST* Zpp, const ST* Zmp, int* mask_d, void* stream) {
   VSM_REQUIRE(N > 0 && n_stokes >= 1 && n_stokes <= 4 && N % n_stokes == 0 && nblocks >= 1 && nblocks <= 65535 && Zpp && Zmp &&
                   mask_d, "vsm_stokes_coupling: bad argument");
   hipStream_t st = as_stream(stream);
   VSM_HIP(hipMemsetAsync(mask_d, 0, sizeof(int) * nblocks, st));
   const long long tot = (long long)N * N;
   const int blocks = (int)((tot + 255) / 256 < 16 ? (tot + 255) / 256 : 16);
-  hipLaunchKernelGGL(k_stokes_coupling, dim3(blocks, nblocks), dim3(256), 0, st, N, n_stokes, Zpp, Zmp, mask_d);
+  hipLaunchKernelGGL((k_stokes_coupling<ST>), dim3(blocks, nblocks), dim3(256), 0, st, N, n_stokes, Zpp, Zmp, mask_d);
   VSM_LAUNCH_CHECK("k_stokes_coupling");
   return VSM_OK;
+}
+
+}  // namespace
+}  // namespace vsm
+
+using namespace vsm;
+
+extern "C" {
+
+int vsm_run_supported(int N, int n_stokes, int coupling) {
+  if (N <= 0 || n_stokes < 1 || n_stokes > 4 || N % n_stokes) return 0;
+  int grp_of[4], groups[4][4], gsz[4];
+  const int ng = stokes_groups(n_stokes, coupling, grp_of, groups, gsz);
+  for (int g = 0; g < ng; ++g)
+    if ((N / n_stokes) * gsz[g] > 64) return 0;
+  return 1;
+}
+
+size_t vsm_run_workspace_bytes(int N, int n_stokes, int S, int nm, const int* coupling) {
+  std::vector<nat_sub> subs;
+  size_t total = 0;
+  if (S < 0 || nm < 0 || plan_subs(N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
+  return total * sizeof(double);
+}
+
+int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m, const int* coupling, void* workspace,
+                       size_t workspace_bytes, vsm_run** run_out) {
+  return run_create<double>(q, S, nm, m, coupling, workspace, workspace_bytes, run_out);
+}
+int vsm_run_create_f32(const vsm_quad_f32* q, int S, int nm, const int* m, const int* coupling, void* workspace,
+                       size_t workspace_bytes, vsm_run** run_out) {
+  return run_create<float>(q, S, nm, m, coupling, workspace, workspace_bytes, run_out);
+}
+
+int vsm_run_destroy(vsm_run* run) {
+  delete run;
+  return VSM_OK;
+}
+
+int vsm_run_layer_f64(vsm_run* run, int ndoubl, const double* dtau, const double* varpi, const double* tau_sum, const double* F0,
+                      int ncomp, const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,
+                      int toa, const int* layer_coupling, void* stream) {
+  return run_layer<double>(run, ndoubl, dtau, varpi, tau_sum, F0, ncomp, Zpp, Zmp, z_stride, fcomp, toa, layer_coupling, stream);
+}
+int vsm_run_layer_f32(vsm_run* run, int ndoubl, const float* dtau, const float* varpi, const float* tau_sum, const float* F0,
+                      int ncomp, const float* const* Zpp, const float* const* Zmp, long long z_stride, const float* fcomp,
+                      int toa, const int* layer_coupling, void* stream) {
+  return run_layer<float>(run, ndoubl, dtau, varpi, tau_sum, F0, ncomp, Zpp, Zmp, z_stride, fcomp, toa, layer_coupling, stream);
+}
+
+int vsm_run_export_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
+  return run_convert<double, vsm_composite_f64, false>(run, comps, stream);
+}
+int vsm_run_export_f32(vsm_run* run, const vsm_composite_f32* comps, void* stream) {
+  return run_convert<float, vsm_composite_f32, false>(run, comps, stream);
+}
+int vsm_run_import_f64(vsm_run* run, const vsm_composite_f64* comps, void* stream) {
+  return run_convert<double, vsm_composite_f64, true>(run, comps, stream);
+}
+int vsm_run_import_f32(vsm_run* run, const vsm_composite_f32* comps, void* stream) {
+  return run_convert<float, vsm_composite_f32, true>(run, comps, stream);
+}
+
+int vsm_stokes_coupling_f64(int N, int n_stokes, int nblocks, const double* Zpp, const double* Zmp, int* mask_d, void* stream) {
+  return stokes_coupling<double>(N, n_stokes, nblocks, Zpp, Zmp, mask_d, stream);
+}
+int vsm_stokes_coupling_f32(int N, int n_stokes, int nblocks, const float* Zpp, const float* Zmp, int* mask_d, void* stream) {
+  return stokes_coupling<float>(N, n_stokes, nblocks, Zpp, Zmp, mask_d, stream);
 }
 
 }  // extern "C"

@@ -462,9 +462,17 @@ __device__ __forceinline__ int ninv_order(double nrm, int* status) {
   return nseries_order(nrm);
 }
 
+// partial sums of the mat-vec source path (n = 61..64: no spare columns): four row tiles only -- the other sizes must not pay for
+// them (three row tiles sit exactly at four workgroups per CU)
+template <int RT, bool ON>
+struct nmv_slots {};
+template <int RT>
+struct nmv_slots<RT, true> {
+  double mv[8][16 * RT];
+};
 // LDS block of a workgroup
 template <int RT>
-struct nsmem {
+struct nsmem : nmv_slots<RT, RT == 4> {
   double P[ngeo<RT>::AF];
   double Q[ngeo<RT>::AF];
   double vec[8][ngeo<RT>::NP];
@@ -473,6 +481,22 @@ struct nsmem {
   int flags[4];
   int gjs[128];
 };
+
+// Source vectors without spare columns (n = 61..64: the strips are full): y = [A] x as VALU mat-vecs over the A-form.  A wave
+// takes a quarter of the columns (lane = row) and leaves its partial sum in a slot; after a barrier nmv_sum adds the four slots.
+__device__ __forceinline__ void nmv_part(const double* A, const double* x, double sc, double* slot, const npos<4>& p) {
+  double acc = 0.0;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = 16 * p.wave + kk;
+    acc = fma(A[naf_idx<4>(p.lane, k)], x[k], acc);
+  }
+  slot[p.lane] = acc * sc;
+}
+template <typename SM>
+__device__ __forceinline__ double nmv_sum(SM& sm, int base, int i) {
+  return (sm.mv[base][i] + sm.mv[base + 1][i]) + (sm.mv[base + 2][i] + sm.mv[base + 3][i]);
+}
 
 }  // namespace
 }  // namespace vsm
