@@ -83,9 +83,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
       nstrip<RT> Gs;
       {
         nstrip<RT> E;
-        E.zero();
-        W.zero();
-        nmm2<RT, KS>(E, W, dP, r_s, t_s, p);
+        nmm2<RT, KS, true, true>(E, W, dP, r_s, t_s, p);
         if (own_wave) {
 #pragma unroll
           for (int ta = 0; ta < RT; ++ta)
@@ -104,8 +102,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
         }
         ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);
       }
-      tt.zero();
-      nmm<RT, KS>(tt, dQ, Gs, p);          // tt = t G
+      nmm<RT, KS, true>(tt, dQ, Gs, p);    // tt = t G
     }
     nload(t_s, dQ, p);                     // t's strip (with its riders) is not kept in registers across the inverse
     __syncthreads();                       // P ([E]) and Q ([t]) no longer read
@@ -117,8 +114,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
     }
     {
       nstrip<RT> tn;
-      tn.zero();
-      nmm2<RT, KS>(r_s, tn, dP, W, t_s, p);   // r' = r + tt W (riders: the new j0-, j0+) ; t' = tt t
+      nmm2<RT, KS, false, true>(r_s, tn, dP, W, t_s, p);   // r' = r + tt W (riders: the new j0-, j0+) ; t' = tt t
       t_s = tn;
     }
     const double expk_step = expk;
@@ -237,9 +233,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   }
   {
     nstrip<RT> E;
-    E.zero();
-    Z.zero();
-    nmm2<RT, KS>(E, Z, dP, r_s, t_s, p);
+    nmm2<RT, KS, true, true>(E, Z, dP, r_s, t_s, p);
     if (own_wave) {
       double* zd = laneB ? vz : sm.vec[7];   // (the other lanes write to a dummy vector)
 #pragma unroll
@@ -262,9 +256,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   nstrip<RT> V;
   {
     nstrip<RT> S;
-    S.zero();
-    V.zero();
-    nmm2<RT, KS>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
+    nmm2<RT, KS, true, true>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
     if (own_wave) {
       double* sd = laneB ? vs : sm.vec[7];
 #pragma unroll
@@ -282,14 +274,13 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   __syncthreads();                        // (e)
   {
     nstrip<RT> X, Y;
-    X.zero();
-    nmm<RT, KS>(X, dP, Gs, p);            // T21 = t++ G2
-    Y.zero();
-    nmm<RT, KS>(Y, dQ, Gs, p);            // Y = S G2 = T01 r-+
+    nmm<RT, KS, true>(X, dP, Gs, p);      // T21 = t++ G2
+    nmm<RT, KS, true>(Y, dQ, Gs, p);      // Y = S G2 = T01 r-+
     __syncthreads();                      // (f): [t++], [S] no longer read
     nstore(dP, X, p);                     // [T21] -> P
     nstore(dQ, Y, p);                     // [Y]   -> Q
   }
+  __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
   nstrip<RT> Tpp, Rmp;
   nld_native(Tpp, T_pp, p);
   nld_native(Rmp, R_mp, p);
@@ -309,8 +300,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   }
   {
     nstrip<RT> acc;
-    acc.zero();
-    nmm2<RT, KS>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
+    nmm2<RT, KS, false, true>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
     nst_native(R_pm, r_s, p);
     nst_native(T_pp, acc, p);
     if (laneA) {

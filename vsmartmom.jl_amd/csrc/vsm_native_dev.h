@@ -107,7 +107,8 @@ __device__ __forceinline__ double ndpp_swap1(double x) {
 }
 
 // ---- products: acc += [A] B, A-form at byte distance dA, B a strip in registers; pipelined by one k-step -------------------
-template <int RT, int KS>
+// (Z / Z1 / Z2: the accumulator starts from zero -- the first k-step takes the constant 0 as its addend: no register is cleared)
+template <int RT, int KS, bool Z = false>
 __device__ __forceinline__ void nmm(nstrip<RT>& acc, unsigned dA, const nstrip<RT>& B, npos<RT>& p) {
   p.opaque();
   double a[2][RT];
@@ -121,7 +122,7 @@ __device__ __forceinline__ void nmm(nstrip<RT>& acc, unsigned dA, const nstrip<R
     }
     const double b = B.v[ks >> 2][ks & 3];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc.v[t] = mfma<double>::mma(a[ks & 1][t], b, acc.v[t]);
+    for (int t = 0; t < RT; ++t) acc.v[t] = mfma<double>::mma(a[ks & 1][t], b, (Z && ks == 0) ? acc_zero<double>() : acc.v[t]);
     VSM_NKSTEP_FENCE();
   }
 }
@@ -145,7 +146,7 @@ __device__ __forceinline__ void nmm_c(nstrip<RT>& out, const nstrip<RT>& C0, uns
   }
 }
 // acc1 += [A] B1 ; acc2 += [A] B2  (shared fragments)
-template <int RT, int KS>
+template <int RT, int KS, bool Z1 = false, bool Z2 = false>
 __device__ __forceinline__ void nmm2(nstrip<RT>& acc1, nstrip<RT>& acc2, unsigned dA, const nstrip<RT>& B1,
                                      const nstrip<RT>& B2, npos<RT>& p) {
   p.opaque();
@@ -161,8 +162,8 @@ __device__ __forceinline__ void nmm2(nstrip<RT>& acc1, nstrip<RT>& acc2, unsigne
     const double b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      acc1.v[t] = mfma<double>::mma(a[ks & 1][t], b1, acc1.v[t]);
-      acc2.v[t] = mfma<double>::mma(a[ks & 1][t], b2, acc2.v[t]);
+      acc1.v[t] = mfma<double>::mma(a[ks & 1][t], b1, (Z1 && ks == 0) ? acc_zero<double>() : acc1.v[t]);
+      acc2.v[t] = mfma<double>::mma(a[ks & 1][t], b2, (Z2 && ks == 0) ? acc_zero<double>() : acc2.v[t]);
     }
     VSM_NKSTEP_FENCE();
   }
