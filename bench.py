@@ -479,6 +479,17 @@ def c5_traffic_per_point():
 PROFILE_ROUNDS = ("r05", "r04", "r03", "r02/final")
 
 
+def tag_sources_hash(sources, command):
+    """tools/profile_any.py's `tag_sources_hash`: SHA-256 over the files a profile tag depends on (+ its command)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted({f for pat in sources.split(",") for f in glob.glob(os.path.join(ROOT, pat.strip()))}):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0" + open(f, "rb").read())
+    h.update(command.encode())
+    return h.hexdigest()[:16]
+
+
 def hbm_traffic_per_launch(kernels, cfg, S_local, running_hash=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 runs by tools/profile_any.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
@@ -504,6 +515,11 @@ def hbm_traffic_per_launch(kernels, cfg, S_local, running_hash=None):
                 continue
             ph = (prof.get("library") or {}).get("source_hash")
             rel = os.path.relpath(path, ROOT)
+            if prof.get("tag_sources") and prof.get("tag_sources_hash"):
+                # the sources that decide what this tag measures (kernels of the workload + host path) are unchanged since the
+                # profile was taken: its per-launch bytes hold for the running build even if other kernel families were edited
+                if tag_sources_hash(prof["tag_sources"], prof["command"]) == prof["tag_sources_hash"]:
+                    return per_point * S_local, rel, ph, "tag sources unchanged since the profile (tag_sources_hash %s)" % prof["tag_sources_hash"]
             if running_hash is not None and ph != running_hash:
                 stale = stale or (None, rel, ph, "the newest committed profile (%s) was taken on library build %s, this run is build %s: "
                                   "traffic withheld" % (rel, ph or "unnamed (before round 4)", running_hash))

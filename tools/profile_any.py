@@ -48,9 +48,30 @@ def main():
     ap.add_argument("--points-per-run", type=int, default=0,
                     help="spectral points of one run of the command: adds hbm_bytes_per_point_whole_run (all vsm:: kernels)")
     ap.add_argument("--runs", type=int, default=1, help="runs of the workload inside the command (warm-up + timed)")
+    ap.add_argument("--sources", default="", help="comma-separated source files / globs (relative to the repo root) that decide what "
+                    "this tag measures: their SHA-256 goes into summary.json as `tag_sources_hash`")
+    ap.add_argument("--skip-if-unchanged", default="", help="path of a committed summary.json of the same tag: when its "
+                    "tag_sources_hash equals the current one the tag is not re-profiled (a Raman edit does not re-take C2)")
     ap.add_argument("cmd", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     cmd = a.cmd[1:] if a.cmd and a.cmd[0] == "--" else a.cmd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tag_hash = None
+    if a.sources:
+        import hashlib
+        h = hashlib.sha256()
+        files = sorted({f for pat in a.sources.split(",") for f in glob.glob(os.path.join(root, pat.strip()))})
+        for f in files:
+            h.update(os.path.relpath(f, root).encode() + b"\0" + open(f, "rb").read())
+        h.update(" ".join(cmd).encode())
+        tag_hash = h.hexdigest()[:16]
+        if a.skip_if_unchanged and os.path.exists(a.skip_if_unchanged):
+            try:
+                if json.load(open(a.skip_if_unchanged)).get("tag_sources_hash") == tag_hash:
+                    print("tag unchanged (tag_sources_hash %s = %s): not re-profiled" % (tag_hash, a.skip_if_unchanged), flush=True)
+                    return
+            except (OSError, ValueError):
+                pass
     os.makedirs(a.out, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     mops = "SQ_INSTS_VALU_MFMA_MOPS_F64" if a.dtype == "f64" else "SQ_INSTS_VALU_MFMA_MOPS_F32"
@@ -72,7 +93,7 @@ def main():
         print("pass %-5s rc=%d" % (name, rc), flush=True)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from vsmartmom_jl_amd import _lib as vsm_lib      # (identity of the library the profiled command loads: csrc/Makefile)
-    summary = {"command": " ".join(cmd), "dtype": a.dtype, "library": vsm_lib.build_info(),
+    summary = {"command": " ".join(cmd), "dtype": a.dtype, "library": vsm_lib.build_info(), "tag_sources_hash": tag_hash, "tag_sources": a.sources,
                "corrections": "FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
                               "requests at 64 B); WRITE_SIZE uncalibrated, taken as is", "kernels": {}}
     for f in glob.glob(os.path.join(a.out, "stats", "**", "*kernel_stats.csv"), recursive=True):
