@@ -372,3 +372,35 @@ def test_native_run_float32_models(vsm, arch, monkeypatch, pol, l_trunc):
     Rl, Tl = vsm.CoreRT.rt_run(model)
     monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
     assert _rel(Rn, Rl) < 2e-3 and _rel(Tn, Tl) < 2e-3, (_rel(Rn, Rl), _rel(Tn, Tl))
+
+
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("I", 15)])
+def test_native_run_diagonal_steps_of_rayleigh_layers_at_high_moments(vsm, arch, monkeypatch, pol, l_trunc):
+    """The Rayleigh phase matrix vanishes for m >= 3: Rayleigh-only layers above an aerosol layer are diagonal steps of every Stokes
+    block there (only the two diagonals of T change while the composite is still diagonal; a scaling of the composite below the first
+    aerosol layer), and U at m = 0 is a diagonal step in every layer -- rt_run equals the oracle (which forms every product, like
+    the reference) and the reference-layout layer loop."""
+    H = vsm.host_model
+    rng = np.random.default_rng(53)
+    S, L = 6, 6
+    tau_aer = np.array([[0.0, 0.0, 0.0, 0.15, 0.0, 0.25]])       # Rayleigh | Rayleigh | Rayleigh | mixed | Rayleigh | mixed
+    kw = dict(tau_rayl=np.tile(np.linspace(0.02, 0.12, L), (S, 1)), tau_abs=10.0 ** rng.uniform(-3, -0.5, (S, L)), depol=0.03,
+              albedo=0.15, m_max=7, tau_aer=tau_aer)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0], [0.0],
+                                aerosol_optics=[H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.7, 10))), 0.95, 0.0)], **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    sc = vsm.CoreRT.prepare_scene(model)
+    assert len(sc._native_moments()) == 8
+    ns = model.polarization_type.n
+    diag = lambda m, iz: all(not any(sc._layer_coupling(m, iz) >> (4 * a + b) & 1 for a in range(ns) for b in range(ns) if g >> a & 1 and g >> b & 1)
+                             for g in _groups(ns, sc.coupling[m]))
+    assert diag(5, 0) and diag(5, 4) and not diag(5, 3) and not diag(1, 0)     # Rayleigh layers at m = 5; an aerosol layer; m = 1
+    sc.run()
+    torch.cuda.synchronize()
+    Rn, Tn = sc.results_host()
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", False)
+    Rl, Tl = vsm.CoreRT.rt_run(model)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    Ro, To = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], aerosols=[O.AerosolOptics(O.hg_greek(0.7, 10), 0.95, 0.0)], **kw))
+    assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-8, (_rel(Rn, Ro), _rel(Tn, To))
+    assert _rel(Rn, Rl) < 1e-10 and _rel(Tn, Tl) < 1e-10

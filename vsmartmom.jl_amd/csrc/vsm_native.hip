@@ -659,8 +659,10 @@ struct ndiag_args {
   int gsz[NSUB_MAX];
   int g0[NSUB_MAX];    // the group's Stokes components, 4 bits each
 };
+// mode 0: the scaling above; 1: TOA; 2: the composite is still (R = 0, T = diag, J = 0) -- every layer above was such a step --:
+// only the two diagonals change.
 template <typename ST>
-__global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, int n, double scale, int toa,
+__global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, int n, double scale, int mode,
                                                            const ST* __restrict__ dtau, ndiag_args a) {
   __shared__ double tt[64];
   const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
@@ -673,7 +675,14 @@ __global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, i
       t = exp(-(double)dtau[s] * scale / (double)q.mu[fr]);
     }
     tt[tid] = t;
+    if (mode == 2 && tid < n) {
+      const int ix = nnat_idx_rt(rt, tid, tid);
+      comp[NC_TPP * af + ix] *= t;
+      comp[NC_TMM * af + ix] *= t;
+    }
   }
+  if (mode == 2) return;
+  const int toa = mode == 1;
   __syncthreads();
   for (int e = tid; e < af; e += 256) {
     const int half = e & 1, lane = (e >> 1) & 63, unit = (e >> 7) % (2 * rt), w = (e >> 7) / (2 * rt);
@@ -727,6 +736,7 @@ struct vsm_run {
   std::vector<std::vector<int>> classes;   // indices into subs with equal (n, gsz, uvmask)
   double* ws;
   size_t ws_doubles;
+  std::vector<char> pure_diag;   // per sub-problem: its composite is still (R = 0, T = diag, J = 0): only diagonal steps so far
 };
 
 namespace vsm {
@@ -888,6 +898,7 @@ static int run_create(const Q* q, int S, int nm, const int* m, const int* coupli
   }
   run->ws = static_cast<double*>(workspace);
   run->ws_doubles = total;
+  run->pure_diag.assign(run->subs.size(), 0);
   // classes: sub-problems that one launch can take (equal n, group size and U/V pattern), at most NSUB_MAX each
   for (size_t i = 0; i < run->subs.size(); ++i) {
     const nat_sub& sb = run->subs[i];
@@ -938,18 +949,30 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
   size_t off = 0;
   for (const auto& cl : run->classes) {
     const nat_sub& h = run->subs[cl[0]];
-    std::vector<int> act, triv;
-    for (int i : cl) (trivial(run->subs[i]) ? triv : act).push_back(i);
-    if (!triv.empty()) {
+    // diagonal steps: the full pass (mode 0 / 1 at TOA), or only the diagonals while the composite is still diagonal (mode 2)
+    std::vector<int> act, triv[3];
+    for (int i : cl) {
+      if (!trivial(run->subs[i])) {
+        act.push_back(i);
+        run->pure_diag[i] = 0;
+      } else if (toa) {
+        triv[1].push_back(i);
+        run->pure_diag[i] = 1;
+      } else {
+        triv[run->pure_diag[i] ? 2 : 0].push_back(i);
+      }
+    }
+    for (int mode = 0; mode < 3; ++mode) {
+      if (triv[mode].empty()) continue;
       ndiag_args da;
-      const int nt = (int)triv.size();
+      const int nt = (int)triv[mode].size();
       for (int k = 0; k < NSUB_MAX; ++k) {
-        const nat_sub& sb = run->subs[triv[k < nt ? k : 0]];
+        const nat_sub& sb = run->subs[triv[mode][k < nt ? k : 0]];
         da.comp[k] = run->ws + sb.comp_off;
         da.gsz[k] = sb.gsz;
         da.g0[k] = sb.g[0] | (sb.g[1] << 4) | (sb.g[2] << 8) | (sb.g[3] << 12);
       }
-      hipLaunchKernelGGL((k_native_diag_layer<ST>), dim3(run->S, nt), dim3(256), 0, st, q, h.rt, h.n, ldexp(1.0, ndoubl), toa, dtau,
+      hipLaunchKernelGGL((k_native_diag_layer<ST>), dim3(run->S, nt), dim3(256), 0, st, q, h.rt, h.n, ldexp(1.0, ndoubl), mode, dtau,
                          da);
       VSM_LAUNCH_CHECK("k_native_diag_layer");
     }
@@ -986,6 +1009,7 @@ static int run_convert(vsm_run* run, const CS* comps, void* stream) {
   VSM_REQUIRE(run && comps, "vsm_run_export / import: null argument");
   VSM_REQUIRE(run->elem_size == (int)sizeof(ST), "vsm_run_export / import: the run was created for %d-byte arrays", run->elem_size);
   if (run->S == 0) return VSM_OK;
+  if (IMPORT) run->pure_diag.assign(run->subs.size(), 0);
   for (int im = 0; im < run->nm; ++im) {
     const CS& c = comps[im];
     VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_export / import: null composite array (moment %d)", im);
