@@ -515,13 +515,21 @@ __global__ __launch_bounds__(64, 2) void k_raman_doubling_chain(int S, int K, in
 #ifndef RC_N_HI
 #define RC_N_HI 22
 #endif
-template <int N, typename F>
+// second window (round 5): N = 13, 14 -- N + 2 = 15, 16 columns fill the two column halves of a line exactly (two blocks of four
+// each), unlike N = 15 ... 19; N = 14 is the Stokes_IQ scene of the moment m = 0 of a 7-stream Stokes_IQU run (C5).
+#ifndef RC_N2_LO
+#define RC_N2_LO 13
+#endif
+#ifndef RC_N2_HI
+#define RC_N2_HI 14
+#endif
+template <int N, int HI, typename F>
 int dispatch_rc(int n, F f) {
-  if constexpr (N > RC_N_HI) {
+  if constexpr (N > HI) {
     return VSM_ERR_UNSUPPORTED;
   } else {
     if (n == N) return f(std::integral_constant<int, N>{});
-    return dispatch_rc<N + 1>(n, f);
+    return dispatch_rc<N + 1, HI>(n, f);
   }
 }
 
@@ -540,7 +548,7 @@ double* raman_chain_stash_ptr(double* stash, int N, int S, int nd, int step, int
 }
 bool raman_chain_supported(int N, int K) {
   static const bool off = ab_switch("VSM_NO_RAMAN_CHAIN");
-  return !off && N >= RC_N_LO && N <= RC_N_HI && K <= 128 && K > 0;
+  return !off && ((N >= RC_N_LO && N <= RC_N_HI) || (N >= RC_N2_LO && N <= RC_N2_HI)) && K <= 128 && K > 0;
 }
 // All nd doubling steps of the inelastic recurrences in one launch (FP64, 20 <= N <= 22, K <= 128; VSM_ERR_UNSUPPORTED otherwise).
 // apply_D! of the inelastic operators happens on the way out (ns = n_stokes).  A wave reads and writes the blocks of its own lines only.
@@ -565,12 +573,14 @@ int raman_doubling_chain(int N, int S, int K, int nd, const int* shift, double* 
   e.sm = (long long)N * N * S;
   e.sv = (long long)N * S;
   e.ss = S;
-  return dispatch_rc<RC_N_LO>(N, [&](auto tag) {
+  auto launch = [&](auto tag) {
     hipLaunchKernelGGL((k_raman_doubling_chain<decltype(tag)::value>), dim3((unsigned)blocks), dim3(64), 0, st, S, K, nd, shift, e, ier,
                        iet, ieJp, ieJm, ns, ier_pm, iet_mm);
     VSM_LAUNCH_CHECK("k_raman_doubling_chain");
     return (int)VSM_OK;
-  });
+  };
+  if (N <= RC_N2_HI) return dispatch_rc<RC_N2_LO, RC_N2_HI>(N, launch);
+  return dispatch_rc<RC_N_LO, RC_N_HI>(N, launch);
 }
 
 }  // namespace vsm
