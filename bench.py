@@ -54,6 +54,12 @@ CONFIGS = {
 }
 
 
+def native_rt(n):
+    """Row tiles of the native layer kernel of a block of n rows (vsm_native.hip rt_of)."""
+    ks = (n + 3) // 4
+    return ks // 4 if (ks % 4 == 0 and ks >= 8) else (4 * ks + 2 + 15) // 16
+
+
 def stokes_groups(ns, coupling):
     """Blocks of Stokes components that the phase matrices couple (bit masks), from the mask of vsm_stokes_coupling: the
     connected components the library's run object forms (vsm_native.hip stokes_groups)."""
@@ -277,7 +283,7 @@ def main():
             k_ms = sum(e[0].elapsed_time(e[1]) for e in ev_dense)
             k_flops = step_flops(ev_dense)
             ks = (N + 3) // 4
-            kernel_name = "k_layer_native<%d, %d>" % (4 if ks == 16 else (4 * ks + 2 + 15) // 16, ks)
+            kernel_name = "k_layer_native<%d, %d>" % (native_rt(N), ks)
             interval_kernels = ["k_elemental_native", kernel_name]
             moments_per_launch = len(dense)
             n_launch = len(ev_dense)
@@ -326,7 +332,7 @@ def main():
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
     build = vsm._lib.build_info()
-    tk = ([kernel_name, "k_elemental_native<%d," % (4 if N > 60 else (4 * ((N + 3) // 4) + 2 + 15) // 16)] if native and dense
+    tk = ([kernel_name, "k_elemental_native<%d," % native_rt(N)] if native and dense
           else [kernel_name, "k_elemental_img"])
     traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(tk, cfg, S_local, build["source_hash"])
                                                         if args.variant == "rayleigh" else (None, None, None, "no profile of this variant"))

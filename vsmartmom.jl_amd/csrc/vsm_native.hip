@@ -33,7 +33,7 @@ namespace {
 // On return (all waves past a barrier): r_s = strip of the final r-+ (row signs of apply_D applied), t_s = strip of t++ (rider
 // columns cleared), sm.vec[0] = j0+, sm.vec[1] = j0- (final sign), sm.usg filled.
 template <int RT, int KS>
-__device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int gsz, unsigned uvmask, int ndoubl,
+__device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, npos<RT>& p, int n, int gsz, unsigned uvmask, int ndoubl,
                                          const double* __restrict__ img, nstrip<RT>& r_s, nstrip<RT>& t_s, int* status) {
   using G = ngeo<RT>;
   constexpr unsigned dP = 0, dQ = G::AF * 8;
@@ -42,8 +42,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
   double* rsg = sm.vec[3];   // row sign of apply_D
   const int tid = threadIdx.x;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;   // spare columns (>= n, never read as k) carry j0+ / j1- through a step
-  constexpr bool RID = c2 < G::NP;              // n = 61..64 (KS = 16): no spare column, the source vectors by VALU mat-vecs
-  static_assert(RID || RT == 4, "no spare columns for the source vectors");
+  constexpr bool RID = c2 < G::NP;              // KS = 4 RT (n = 29..32, 45..48, 61..64): no spare column, the source vectors by VALU mat-vecs
+  static_assert(RID || KS == 4 * RT, "no spare columns for the source vectors");
   const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
   ncopy_image<RT>(sm.P, img, p);
@@ -77,7 +77,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
     const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
     if constexpr (!RID) {   // r j0+ , r j1-   (P = [r])
       nmv_part(sm.P, jp, 1.0, sm.mv[p.wave], p);
-      nmv_part(sm.P, jm, expk, sm.mv[4 + p.wave], p);
+      nmv_part(sm.P, jm, expk, sm.mv[RT + p.wave], p);
     }
     {
       nstrip<RT> Gs;
@@ -96,8 +96,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
         const double nrm = nnorm(E, n, sm, slot, p);   // (its barrier: [r] is free)
         if constexpr (!RID) {   // u1 = j1- + r j0+ , u2 = j0+ + r j1-   (every wave is past the norm reduction's barrier)
           if (tid < G::NP) {
-            sm.vec[4][tid] = jm[tid] * expk + nmv_sum(sm, 0, tid);
-            sm.vec[5][tid] = jp[tid] + nmv_sum(sm, 4, tid);
+            sm.vec[4][tid] = jm[tid] * expk + nmv_sum<RT>(sm, 0, tid);
+            sm.vec[5][tid] = jp[tid] + nmv_sum<RT>(sm, RT, tid);
           }
         }
         ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);
@@ -110,7 +110,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
     __syncthreads();
     if constexpr (!RID) {   // tt u1 , tt u2   (the partial sums of r j were consumed two barriers ago)
       nmv_part(sm.P, sm.vec[4], 1.0, sm.mv[p.wave], p);
-      nmv_part(sm.P, sm.vec[5], 1.0, sm.mv[4 + p.wave], p);
+      nmv_part(sm.P, sm.vec[5], 1.0, sm.mv[RT + p.wave], p);
     }
     {
       nstrip<RT> tn;
@@ -132,8 +132,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
     if (it + 1 < ndoubl || !RID) __syncthreads();   // everybody finished reading P ([tt])
     if constexpr (!RID) {   // j0- += tt u1 ; j0+ = j0+ expk + tt u2   (visible after the barrier below / after the loop)
       if (tid < G::NP) {
-        jm[tid] += nmv_sum(sm, 0, tid);
-        jp[tid] = jp[tid] * expk_step + nmv_sum(sm, 4, tid);
+        jm[tid] += nmv_sum<RT>(sm, 0, tid);
+        jp[tid] = jp[tid] * expk_step + nmv_sum<RT>(sm, RT, tid);
       }
     }
     if (it + 1 < ndoubl) {
@@ -182,7 +182,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT>& sm, npos<RT>& p, int n, int 
 //   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z
 // Ten products and the series, seven barriers, at most six live strips.
 template <int RT, int KS>
-__device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, double* __restrict__ comp, nstrip<RT>& r_s,
+__device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, npos<RT>& p, int n, double* __restrict__ comp, nstrip<RT>& r_s,
                                          nstrip<RT>& t_s, int* status) {
   using G = ngeo<RT>;
   constexpr unsigned dP = 0, dQ = G::AF * 8;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   __syncthreads();                                                                                       // (a)
   if constexpr (!RID) {   // R+- j0- , T-- j0-
     nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vjm, 1.0, sm.mv[4 + p.wave], p);
+    nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);
   }
   {
     nstrip<RT> E;
@@ -247,8 +247,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
     if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
       if (tid < G::NP) {
-        vz[tid] = vJp[tid] + nmv_sum(sm, 0, tid);
-        vs[tid] = nmv_sum(sm, 4, tid);
+        vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
+        vs[tid] = nmv_sum<RT>(sm, RT, tid);
       }
     }
     ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
@@ -287,7 +287,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   __syncthreads();                        // (g)
   if constexpr (!RID) {   // T21 z , Y z
     nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vz, 1.0, sm.mv[4 + p.wave], p);
+    nmv_part(sm.Q, vz, 1.0, sm.mv[RT + p.wave], p);
   }
   if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
@@ -328,8 +328,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
   if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
     __syncthreads();
     if (tid < G::NP) {
-      J0_p[tid] = vjp[tid] + nmv_sum(sm, 0, tid);
-      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum(sm, 4, tid);
+      J0_p[tid] = vjp[tid] + nmv_sum<RT>(sm, 0, tid);
+      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid);
     }
   }
 }
@@ -337,7 +337,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT>& sm, npos<RT>& p, int n, doub
 // the LDS block decides the workgroups per CU the register budgets (ngeo::WPS) are set for
 static_assert(sizeof(nsmem<2>) * 8 <= 163840, "two row tiles: eight workgroups per CU");
 static_assert(sizeof(nsmem<3>) * 4 <= 163840, "three row tiles: four workgroups per CU");
-static_assert(sizeof(nsmem<4>) * 2 <= 163840, "four row tiles: two workgroups per CU");
+static_assert(sizeof(nsmem<3, true>) * 3 <= 163840, "three row tiles, mat-vec sources: three workgroups per CU");
+static_assert(sizeof(nsmem<4, true>) * 2 <= 163840, "four row tiles: two workgroups per CU");
 
 template <int RT, int KS>
 __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(int n, int gsz, unsigned uvmask, int ndoubl,
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(in
                                                                                 nlayer_comps a, int* status) {
   using G = ngeo<RT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  nsmem<RT>& sm = *reinterpret_cast<nsmem<RT>*>(smem_raw);
+  using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
+  SM& sm = *reinterpret_cast<SM*>(smem_raw);
   npos<RT> p(sm.P);
   const int s = blockIdx.x, isub = blockIdx.y;
   const double* img = pre + ((long long)isub * gridDim.x + s) * G::PRE_STRIDE;
@@ -383,13 +385,15 @@ VSM_NATIVE_DECL(VSM_NATIVE_KS)
 int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsigned uvmask, int gsz, int ndoubl, int toa,
                                                   const double* pre, const nlayer_comps& comps, int* status, hipStream_t st) {
   constexpr int KS = VSM_NATIVE_KS;
-  constexpr int RT = KS == 16 ? 4 : (4 * KS + 2 + 15) / 16;   // (KS = 16, n = 61..64: no spare columns, mat-vec source path)
+  // KS = 8, 12, 16 (n = 29..32, 45..48, 61..64): KS / 4 row tiles without spare columns (mat-vec source path) instead of one row
+  // tile more for the two rider columns
+  constexpr int RT = (KS % 4 == 0 && KS >= 8) ? KS / 4 : (4 * KS + 2 + 15) / 16;
   static_assert(RT >= 1 && RT <= 4, "n <= 64");
+  using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
   auto kern = k_layer_native<RT, KS>;
-  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(nsmem<RT>), "hipFuncSetAttribute(k_layer_native)");
+  const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(SM), "hipFuncSetAttribute(k_layer_native)");
   if (prepared) return prepared;
-  hipLaunchKernelGGL(kern, dim3(S, nsub), dim3(ngeo<RT>::NT), sizeof(nsmem<RT>), st, n, gsz, uvmask, ndoubl, toa, pre, comps,
-                     status);
+  hipLaunchKernelGGL(kern, dim3(S, nsub), dim3(ngeo<RT>::NT), sizeof(SM), st, n, gsz, uvmask, ndoubl, toa, pre, comps, status);
   VSM_LAUNCH_CHECK("k_layer_native");
   return VSM_OK;
 }
@@ -774,7 +778,10 @@ static int stokes_groups(int ns, int coupling, int grp_of[4], int groups[4][4], 
   }
   return ng;
 }
-static inline int rt_of(int n) { return n > 60 ? 4 : (4 * ((n + 3) / 4) + 2 + 15) / 16; }
+static inline int rt_of(int n) {   // (as the launchers of the layer kernels choose it)
+  const int ks = (n + 3) / 4;
+  return (ks % 4 == 0 && ks >= 8) ? ks / 4 : (4 * ks + 2 + 15) / 16;
+}
 static inline size_t comp_stride_rt(int rt) { return (size_t)4 * (16 * rt) * (16 * rt) + 2 * 16 * rt; }
 static inline size_t pre_stride_rt(int rt) { return (size_t)2 * (16 * rt) * (16 * rt) + 3 * 16 * rt; }
 

@@ -463,17 +463,17 @@ __device__ __forceinline__ int ninv_order(double nrm, int* status) {
   return nseries_order(nrm);
 }
 
-// partial sums of the mat-vec source path (n = 61..64: no spare columns): four row tiles only -- the other sizes must not pay for
-// them (three row tiles sit exactly at four workgroups per CU)
+// Partial sums of the mat-vec source path (blocks without spare columns: 4 KS + 2 > 16 RT, i.e. n = 29..32, 45..48, 61..64): the
+// other blocks must not pay for them (three row tiles with rider columns sit exactly at four workgroups per CU).
 template <int RT, bool ON>
 struct nmv_slots {};
 template <int RT>
 struct nmv_slots<RT, true> {
-  double mv[8][16 * RT];
+  double mv[2 * RT][16 * RT];
 };
 // LDS block of a workgroup
-template <int RT>
-struct nsmem : nmv_slots<RT, RT == 4> {
+template <int RT, bool MV = false>
+struct nsmem : nmv_slots<RT, MV> {
   double P[ngeo<RT>::AF];
   double Q[ngeo<RT>::AF];
   double vec[8][ngeo<RT>::NP];
@@ -483,20 +483,26 @@ struct nsmem : nmv_slots<RT, RT == 4> {
   int gjs[128];
 };
 
-// Source vectors without spare columns (n = 61..64: the strips are full): y = [A] x as VALU mat-vecs over the A-form.  A wave
-// takes a quarter of the columns (lane = row) and leaves its partial sum in a slot; after a barrier nmv_sum adds the four slots.
-__device__ __forceinline__ void nmv_part(const double* A, const double* x, double sc, double* slot, const npos<4>& p) {
-  double acc = 0.0;
+// Source vectors without spare columns: y = [A] x as VALU mat-vecs over the A-form.  Wave w takes the columns of its own strip
+// (lane = row) and leaves its partial sum in slot w; after a barrier nmv_sum adds the RT slots.
+template <int RT>
+__device__ __forceinline__ void nmv_part(const double* A, const double* x, double sc, double* slot, const npos<RT>& p) {
+  if (p.lane < 16 * RT) {
+    double acc = 0.0;
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
-    const int k = 16 * p.wave + kk;
-    acc = fma(A[naf_idx<4>(p.lane, k)], x[k], acc);
+    for (int kk = 0; kk < 16; ++kk) {
+      const int k = 16 * p.wave + kk;
+      acc = fma(A[naf_idx<RT>(p.lane, k)], x[k], acc);
+    }
+    slot[p.lane] = acc * sc;
   }
-  slot[p.lane] = acc * sc;
 }
-template <typename SM>
+template <int RT, typename SM>
 __device__ __forceinline__ double nmv_sum(SM& sm, int base, int i) {
-  return (sm.mv[base][i] + sm.mv[base + 1][i]) + (sm.mv[base + 2][i] + sm.mv[base + 3][i]);
+  double v = sm.mv[base][i];
+#pragma unroll
+  for (int w = 1; w < RT; ++w) v += sm.mv[base + w][i];
+  return v;
 }
 
 }  // namespace
