@@ -17,7 +17,10 @@ configurations that fit one GPU, so that their figures are driver-timed and not 
           IQUV, N = 112), 2 000 points, 10 layers: the k_dbl128 / k_ia128 family
 
 Each entry: points/s of the step, its wall time, the device time of the pass by HIP events, the algorithmic TFLOP/s and the
-fraction of the MFMA peak of its dtype, and the dominant kernel (per-kernel durations: profiles/r04/).  A step is what the
+fraction of the MFMA peak of its dtype BY THE AS-WRITTEN (dense N x N) OPERATION COUNT of SURVEY 8(d), and the dominant kernel
+(per-kernel durations: profiles/r05/).  Since round 5 the runs do not form products with exact zeros (Stokes blocks the phase matrices
+do not couple: DESIGN 4.0), so an as-written fraction can exceed what the MFMA pipe could deliver on the dense problem; entries whose
+executed work differs say so (`frac_of_mfma_peak_executed_products`, `note`).  A step is what the
 headline times: H2D of the raw inputs (`upload()`), device layer optics (`prepare()`), the device pass (`run()`) and the D2H of the
 result, on a scene whose buffers are allocated beforehand, with one untimed warm-up; the C5 and C1 steps are whole `rt_run(...)`
 calls (host optics, allocation, H2D, device pass, D2H).  Only bench.py imports this module, on rank 0 of a 1-GPU run.
@@ -74,7 +77,8 @@ def c4(vsm, torch, arch, o2a, points=12500):
         return R.cpu(), T.cpu()
     wall, dev, _ = _timed(torch, step)
     e = _entry("C4", "N=96 FP32, 60 layers, m=0..2, Rayleigh + O2, Lambertian (one GPU's share of BASELINE configs[3])", points, wall, dev,
-               scene.flops_per_point(), "f32", "k_layer_strip32_mm<6>")
+               scene.flops_per_point(), "f32", "k_layer_strip32_mm<6> (m = 1, 2) + k_layer_native<4, 16> (m = 0: a 64-row (I,Q) block on the "
+               "native FP64 kernels with FP32 storage, U as a diagonal step)")
     del scene
     return e
 
@@ -93,7 +97,8 @@ def c2_lin(vsm, torch, arch, o2a, points=2048, name="C2-lin"):   # (2048: 24 ful
         return scene.results_host()
     wall, dev, _ = _timed(torch, step)
     e = _entry(name, "linearized rt_run (1 gas column + albedo), N=60 FP64, 40 layers, m=0..2 (C2 shape)", points, wall, dev,
-               scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia128_lin<4>)")
+               scene.flops_per_point(), "f64", "k_dbl_lin_multi<15,1> (+ k_ia128_lin<4>) for m = 1, 2; m = 0 as a Stokes_IQ scene (N = 40): "
+               "k_dbl128_lin<3> + k_ia128_lin<3>")
     # the as-written count runs every parameter slot through every interaction (interaction_lin.jl:242,291); the surface slot of a
     # layer interaction is exact zeros and is not computed (vsm_interaction_lin_range): flops of the products that are formed
     N = float(scene.N)
@@ -185,7 +190,8 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12, name="C5"):
     exe_m = sum(nd * (12 * n3 + 8 * n2 + kin * (20 * n3 + 16 * n2)) for nd in nds) + L * (24 * n3 + 8 * n2 + kin * (18 * n3 + 12 * n2))
     e = _entry(name, "rotational Raman (RRS), nStokes=3, N=%d FP64, %d layers, %d Raman lines, m=0..2 (BASELINE configs[4] at %d of its "
                "20000 points); step = whole rt_run(RRS) incl. host optics, H2D, D2H" % (N, L, len(shifts), S), S, wall, dev, 3 * per_m, "f64",
-               "k_raman_doubling_chain<21> (+ k_raman_interaction_quad<21>)")
+               "k_raman_doubling_chain<21> (+ k_raman_interaction_quad<21>) for m = 1, 2; m = 0 as a Stokes_IQ scene (N = 14): "
+               "k_raman_doubling_chain<14> + k_raman_interaction_quad<14>")
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
     e["hbm_bytes_per_step"] = None   # whole-step HBM bytes from the newest committed PMC passes of the same workload
@@ -301,7 +307,8 @@ def n112(vsm, torch, arch, o2a, points=2000, layers=10):
         return R.cpu(), T.cpu()
     wall, dev, _ = _timed(torch, step)
     e = _entry("N112", "forward, IQUV N=%d FP64 (the reference's VLIDORT case-A size), %d layers, %d points, m=0..2, Rayleigh + O2, "
-               "Lambertian" % (N, layers, points), points, wall, dev, scene.flops_per_point(), "f64", "k_dbl128<7> (+ k_ia128<7>)")
+               "Lambertian" % (N, layers, points), points, wall, dev, scene.flops_per_point(), "f64",
+               "k_dbl128<7> (+ k_ia128<7>) for m = 1, 2; m = 0 as native blocks of 56 + 28 rows (k_layer_native<4, 14>, <2, 7>)")
     del scene
     return e
 

@@ -8,7 +8,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 C="vsmartmom.jl_amd/csrc"
-COMMON="$C/vsm_internal.h,$C/vsm_common.h,$C/vsm_inverse.h,$C/vsm_lds.h,$C/vsm_elemental.h,$C/vsm_api.hip,$C/vsm_generic.hip,$C/vsm_gemm_lds.h,$C/vsm_optics.hip,$C/vsm_surface.hip,$C/Makefile,include/vsmartmom_hip.h,vsmartmom.jl_amd/*.py,bench.py,bench_secondary.py"
+COMMON="$C/vsm_internal.h,$C/vsm_common.h,$C/vsm_inverse.h,$C/vsm_lds.h,$C/vsm_elemental.h,$C/vsm_api.hip,$C/vsm_generic.hip,$C/vsm_gemm_lds.h,$C/vsm_optics.hip,$C/vsm_surface.hip,$C/Makefile,include/vsmartmom_hip.h,vsmartmom.jl_amd/*.py,bench.py"
 FWD="$COMMON,$C/vsm_native.hip,$C/vsm_native_dev.h,$C/vsm_strip.hip,$C/vsm_strip_dev.h,$C/vsm_fused.hip"
 F32="$FWD,$C/vsm_strip32.hip"
 LIN="$FWD,$C/vsm_lin.hip,$C/vsm_striplin.hip,$C/vsm_strip128lin.hip,$C/vsm_strip128_dev.h,tools/lin_timing.py,tools/shape_cliff_timing.py"
