@@ -364,11 +364,48 @@ class SceneLin:
         a0 = self.added_s
         return CR.AddedLayer(self.FT, self.arch, self.N, self.S, a0.shared, a0.d_symmetric)
 
-    def run(self, lanes: Optional[int] = None, fold: Optional[bool] = None):
+    def run(self, lanes: Optional[int] = None, fold: Optional[bool] = None, graph: Optional[bool] = None):
         """The device-resident part of rt_run_lin.jl:200-322: Fourier loop -> layers -> surface -> post-processing.
         `lanes`: number of concurrent moment lanes (default: LANES for batches below LANE_POINTS points, else 1);
         `fold`: walk the layers with the Fourier moments folded into the spectral axis (_run_folded; default: for such small
-        batches when the scene has no aerosol Jacobian slots)."""
+        batches when the scene has no aerosol Jacobian slots);
+        `graph`: replay the pass from a HIP graph (default: `self.graph_replay`, which a caller that steps the SAME scene many
+        times -- a retrieval loop, the bench -- switches on; the first such call costs a warm-up pass and the capture).  A small
+        batch is bound by the HOST: a pass of the C3 scene is ~ 2500 launches and library calls of ~ 15 us each, issued by one
+        thread, so its two layer chains never overlap on the device (`tools/trace_timeline.py`: chain after chain, 14 ms each, with
+        5 ms of launch-bound input folding in front of either).  The launch sequence depends only on the layer structure (ndoubl,
+        interface tags, lanes / fold) -- the graph is captured once per such key, on buffers the scene owns, and reads the
+        optics where `prepare()` puts them."""
+        if graph is None:
+            graph = bool(getattr(self, "graph_replay", False)) and self.S > 0 and not torch.cuda.is_current_stream_capturing()
+        if graph:
+            return self._run_graph(lanes, fold)
+        return self._run_eager(lanes, fold)
+
+    def _run_graph(self, lanes, fold):
+        key = (lanes, fold, tuple((ly["nd"], ly["iface"]) for ly in self.fwd.moments[0]["layers"]), len(self.fwd.moments),
+               self.fwd.moments[0]["iface_surface"])
+        if getattr(self, "_graph_key", None) != key:
+            self._graph = None
+            # The library's scratch is keyed by (device, stream) and may not grow under a capture: the warm-up pass runs on the
+            # very stream the capture uses (and on the same lane streams), so every buffer the captured launches need exists.
+            if getattr(self, "_graph_stream", None) is None:
+                self._graph_stream = torch.cuda.Stream()
+            gs = self._graph_stream
+            gs.wait_stream(torch.cuda.current_stream())
+            self._fold = {}                       # (the folded per-layer inputs are copies of the optics: they must be formed
+            with torch.cuda.stream(gs):           #  INSIDE the graph, not come out of the cache of an earlier pass)
+                self._run_eager(lanes, fold)
+            torch.cuda.synchronize()
+            self._fold = {}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=gs):
+                self._run_eager(lanes, fold)
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
+        return self.R, self.T, self.Rd, self.Td
+
+    def _run_eager(self, lanes: Optional[int] = None, fold: Optional[bool] = None):
         global _lane
         S = self.S
         nm = len(self.fwd.moments)
