@@ -286,7 +286,7 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10, scale=1.0, name="IA
                "shaped random layers at %s, added layer D-symmetric as doubling! leaves it; HIP events around each of %d launches"
                % (N, S, "the clear-sky scale of the C2 run (||R r|| ~ 2e-3: series inverse of order 7)" if scale == 1.0 else
                   "%g x the reflectances of the IA entry (||R r|| ~ %.0e: the long series orders 15 / 16 / 31, out of line)"
-                  % (scale, 2e-3 * scale * scale), reps), S, ms * 1e-3, ms, flop_pt, "f64", "k_ia_strip<15, true>")
+                  % (scale, 2e-3 * scale * scale), reps), S, ms * 1e-3, ms, flop_pt, "f64", "k_ia_native<4, 15, true>")
     if scale != 1.0:
         del pc, pa, init
         return e

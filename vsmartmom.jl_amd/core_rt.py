@@ -960,12 +960,17 @@ class Scene:
             if self.added.d_symmetric == 0 or any(ly["props"].fcomp is not None for ly in self.moments[0]["layers"]):
                 raise _lib.VSMError("run_graph(): only scenes that run entirely in the fused layer kernels (every layer "
                                     "scattering, N within the on-chip limit, one scatterer per layer) can be captured")
-            self.run()                      # warm-up outside the capture: lazy initialisation inside the library
+            # warm-up outside the capture, on the very stream the capture uses: the library's lazy initialisation, and its
+            # scratch, which is keyed by (device, stream) and may not grow under a capture
+            gs = torch.cuda.Stream()
+            gs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(gs):
+                self.run()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=gs):
                 self.run()
-            self._graph = g
+            self._graph, self._graph_stream = g, gs
         self._graph.replay()
         return self.R_SFI, self.T_SFI
 

@@ -1605,6 +1605,8 @@ int fused_interaction(int iface, int N, int S, const composite<T>& c, const adde
     return VSM_ERR_UNSUPPORTED;
   }
   if constexpr (sizeof(T) == 8) {
+    static const bool no_native = ab_switch("VSM_NO_NATIVE_IA");
+    if (!no_native && N <= 64) return native_interaction11(N, S, c, a, st);
     static const bool no_strip = ab_switch("VSM_NO_STRIP") || ab_switch("VSM_NO_STRIP_IA");
     if (!no_strip && strip_layer_supported(N)) return strip_interaction11(N, S, c, a, st);
   }

@@ -263,6 +263,9 @@ int strip_layer_forward(const quad<double>& q, int S, int m, int ndoubl, const d
                         const double* tau_sum, const double* F0, const zsrc<double>& z, int toa, const composite<double>& c,
                         hipStream_t st, int thermal = 0);
 
+// ---- native-layout family (vsm_native.hip): interaction!(_11) on the reference's arrays, FP64, N <= 64 ----
+int native_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st);
+
 // ---- column-strip kernels, FP32 (64 < N <= 96; two workgroups of 6 waves per CU): vsm_strip32.hip ----
 bool strip32_supported(int N);
 int strip32_layer_forward(const quad<float>& q, int S, int m, int ndoubl, const float* dtau, const float* varpi,

@@ -169,6 +169,117 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Where the interaction finds the composite: the native records of a run (k_layer_native), or the reference's [N,N,S] arrays
+// (k_ia_native: vsm_interaction_f64 for N <= 64 -- the surface interaction of every run, callers of the operator API).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int RT>
+struct nio_native {
+  double* comp;
+  static constexpr bool REF = false;
+  __device__ __forceinline__ void ld(nstrip<RT>& x, int which, const npos<RT>& p) const { nld_native(x, comp + which * ngeo<RT>::AF, p); }
+  __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const { nst_native(comp + which * ngeo<RT>::AF, x, p); }
+  __device__ __forceinline__ double ldJ(int pm, int i) const { return comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i]; }
+  __device__ __forceinline__ void stJ(int pm, int i, double v) const { comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i] = v; }
+  __device__ __forceinline__ void ld_added(nstrip<RT>&, int, const npos<RT>&) const {}
+  __device__ __forceinline__ void prefetch(int, double*) const {}
+};
+template <int RT>
+struct nio_ref {
+  int N;
+  double* m[4];          // R-+, R+-, T++, T-- of this point (NC_* order)
+  double* J[2];          // J0+, J0-
+  const double* a[4];    // the added layer's r-+, r+-, t++, t-- of this point (r+- / t-- only read when it is not D-symmetric)
+  bool raw;              // R+- / T-- arrive as raw images in Q / P (k_ia_native requested them by DMA)
+  double jpre[2];        // J0+[tid], J0-[tid], requested at the entry of the kernel
+  static constexpr bool REF = true;
+  // direct accesses in the accumulator layout (16 columns x 32 B per instruction: the L2 absorbs the partial lines -- measured
+  // faster than the transposer tiles up to five row tiles, vsm_strip128_dev.h)
+  __device__ __forceinline__ void ldg(nstrip<RT>& x, const double* __restrict__ g, const npos<RT>& p) const {
+    const bool cok = p.col < N;
+    const double* gc = g + (long long)N * min(p.col, N - 1);
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+#ifdef VSM_IA_NOIO   // (experiment: what the direct accesses cost)
+        const double v = (row == p.col) ? 0.5 : 1e-4;
+#else
+        const double v = gc[min(row, N - 1)];
+#endif
+        x.v[ta][r] = (cok && row < N) ? v : 0.0;
+      }
+  }
+  __device__ __forceinline__ void ld(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, m[which], p); }
+  __device__ __forceinline__ void ld_added(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, a[which], p); }
+  __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const {
+    if (p.col < N) {
+      double* gc = m[which] + (long long)N * p.col;
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+#ifdef VSM_IA_NOIO
+          if (row < N && x.v[ta][r] == 1.2345) gc[row] = x.v[ta][r];
+#else
+          if (row < N) gc[row] = x.v[ta][r];
+#endif
+        }
+    }
+  }
+  __device__ __forceinline__ double ldJ(int pm, int) const { return jpre[pm]; }   // (only ever asked for i = threadIdx.x)
+  __device__ __forceinline__ void stJ(int pm, int i, double v) const {
+    if (i < N) J[pm][i] = v;
+  }
+  // Whole matrix -> LDS as it lies in memory (column-major, leading dimension N) by LDS DMA: 1 KB per wave instruction, every
+  // line fetched once; ld_raw then picks the lane's accumulator elements out of the image.  (N * N even: 16-B pieces.)
+  __device__ __forceinline__ void dma_raw(const double* __restrict__ g, double* L, const npos<RT>& p) const {
+    if ((N & 1) == 0) {   // 16-B pieces: every matrix of the batch starts on a 16-B boundary
+      const int chunks = (N * N) >> 1;
+      for (int c0 = 64 * p.wave; c0 < chunks; c0 += ngeo<RT>::NT) {
+        if (c0 + p.lane < chunks)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 2 * (c0 + p.lane)),
+                                           (__attribute__((address_space(3))) void*)(L + 2 * c0), 16, 0, 0);
+      }
+    } else {              // 4-B pieces
+      const int chunks = 2 * N * N;
+      const float* g4 = reinterpret_cast<const float*>(g);
+      float* L4 = reinterpret_cast<float*>(L);
+      for (int c0 = 64 * p.wave; c0 < chunks; c0 += ngeo<RT>::NT) {
+        if (c0 + p.lane < chunks)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g4 + c0 + p.lane),
+                                           (__attribute__((address_space(3))) void*)(L4 + c0), 4, 0, 0);
+      }
+    }
+  }
+  __device__ __forceinline__ void ld_raw(nstrip<RT>& x, const double* L, const npos<RT>& p) const {
+    const bool cok = p.col < N;
+    const double* Lc = L + N * min(p.col, N - 1);
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        const double v = Lc[min(row, N - 1)];
+        x.v[ta][r] = (cok && row < N) ? v : 0.0;
+      }
+  }
+  // Ask for a composite matrix ahead of its use: one dword of every 128-B line by LDS DMA into a junk vector (no register is
+  // tied up, the lines wait in the L2 / MALL) -- the strips that are read just before the closing products would otherwise be
+  // fetched with nothing to overlap them, the six live strips leave no room to request them earlier.
+  __device__ __forceinline__ void prefetch(int which, double* junk) const {
+    const int lines = (N * N * 8 + 127) >> 7;
+    const char* g = reinterpret_cast<const char*>(m[which]);
+    for (int k0 = 0; k0 < lines; k0 += ngeo<RT>::NT) {
+      const int k = min(k0 + (int)threadIdx.x, lines - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + 128 * k),
+                                       (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266), native composite
 // ---------------------------------------------------------------------------------------------------------------------------
 // On entry: r_s / t_s = strips of the added layer's r-+ / t++ (columns >= n zero), sm.vec[0] / vec[1] = its j0+ / j0-, all waves
@@ -181,8 +292,22 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 //   [R+- | T++] = [r+- | 0] + T21 [Z | T++]      A = P = [T21]   J0+ = j0+ + T21 z   (z rides in a spare column of T++)
 //   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z
 // Ten products and the series, seven barriers, at most six live strips.
-template <int RT, int KS>
-__device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, npos<RT>& p, int n, double* __restrict__ comp, nstrip<RT>& r_s,
+#ifdef VSM_IA_PHASES   // diagnostic build (tools/ia_phases.py): cycles of wave 0 between the stamps, summed over the workgroups
+__device__ unsigned long long vsm_ia_phase_cycles[16];
+#define VSM_IA_STAMP(k)                                                  \
+  do {                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();        \
+    if (threadIdx.x == 0) atomicAdd(&vsm_ia_phase_cycles[k], now_ - t_); \
+    t_ = now_;                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                   \
+  } while (0)
+#else
+#define VSM_IA_STAMP(k)
+#endif
+// DSYM: r+- = D r-+ D, t-- = D t++ D (added layers from doubling); else they are read through io.ld_added (surface layers).
+template <int RT, int KS, bool DSYM = true, typename IO>
+__device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, npos<RT>& p, int n, const IO& io, nstrip<RT>& r_s,
                                          nstrip<RT>& t_s, int* status) {
   using G = ngeo<RT>;
   constexpr unsigned dP = 0, dQ = G::AF * 8;
@@ -193,12 +318,6 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   double* vs = sm.vec[4];
   double* vz = sm.vec[5];
   const int tid = threadIdx.x;
-  double* R_mp = comp + NC_RMP * G::AF;
-  double* R_pm = comp + NC_RPM * G::AF;
-  double* T_pp = comp + NC_TPP * G::AF;
-  double* T_mm = comp + NC_TMM * G::AF;
-  double* J0_p = comp + 4 * G::AF;
-  double* J0_m = J0_p + G::NP;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
   constexpr bool RID = c2 < G::NP;
   const bool own_wave = RID && p.wave == (c1 >> 4);
@@ -206,18 +325,35 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   int slot = 0;
   const ndpar<RT> dp(sm.usg, p);
   const ninv_ctx cx{dP, sm.P, sm.gjs, status};
+#ifdef VSM_IA_PHASES
+  unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
   // ---- stage: composite vectors, [R+-] -> P, [T--] -> Q ---------------------------------------------------------------------
   if (tid < G::NP) {
-    vJp[tid] = J0_p[tid];
-    vJm[tid] = J0_m[tid];
+    vJp[tid] = io.ldJ(0, tid);
+    vJm[tid] = io.ldJ(1, tid);
   }
   nstrip<RT> Z, Gs;
+  nstrip<RT> A2;
   {
-    nstrip<RT> A1, A2;
-    nld_native(A1, R_pm, p);
-    nld_native(A2, T_mm, p);
+    nstrip<RT> A1;
+    bool direct = true;
+    if constexpr (IO::REF) {
+      if (io.raw) {
+        direct = false;
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        io.ld_raw(A1, sm.Q, p);
+        io.ld_raw(A2, sm.P, p);
+        __syncthreads();
+      }
+    }
+    if (direct) {
+      io.ld(A1, NC_RPM, p);
+      io.ld(A2, NC_TMM, p);             // (REF: in flight under the products of [R+-]; [T--] is first read after barrier (c))
+    }
     nstore(dP, A1, p);
-    nstore(dQ, A2, p);
+    if constexpr (!IO::REF) nstore(dQ, A2, p);
   }
   if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
 #pragma unroll
@@ -225,15 +361,19 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) r_s.v[ta][r] = laneB ? vjm[p.row(ta, r)] : r_s.v[ta][r];
   }
-  ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
+  if constexpr (DSYM) ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
   __syncthreads();                                                                                       // (a)
-  if constexpr (!RID) {   // R+- j0- , T-- j0-
-    nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);
-  }
+  VSM_IA_STAMP(0);
+  if constexpr (!RID) nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);   // R+- j0-
   {
     nstrip<RT> E;
-    nmm2<RT, KS, true, true>(E, Z, dP, r_s, t_s, p);
+    if constexpr (DSYM) {
+      nmm2<RT, KS, true, true>(E, Z, dP, r_s, t_s, p);
+    } else {   // (a surface layer: t-- from memory, here and again for the products of [T--] -- it is not kept across the inverse)
+      nstrip<RT> tb;
+      io.ld_added(tb, NC_TMM, p);
+      nmm2<RT, KS, true, true>(E, Z, dP, r_s, tb, p);
+    }
     if (own_wave) {
       double* zd = laneB ? vz : sm.vec[7];   // (the other lanes write to a dummy vector)
 #pragma unroll
@@ -244,19 +384,28 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
           zd[row] = vJp[row] + E.v[ta][r];
         }
     }
+    VSM_IA_STAMP(1);
+    if constexpr (IO::REF) nstore(dQ, A2, p);      // [T--] -> Q (free since the entry; read after barrier (c))
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
-    if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
-      if (tid < G::NP) {
-        vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
-        vs[tid] = nmv_sum<RT>(sm, RT, tid);
-      }
+    if constexpr (!RID) {   // z = J0+ + R+- j0-
+      if (tid < G::NP) vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
     }
+    VSM_IA_STAMP(2);
     ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
+    VSM_IA_STAMP(3);
   }
+  if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))
+  io.prefetch(NC_TPP, sm.vec[7]);         // (four products ahead of its use: a line lives some tens of microseconds in the L2)
   nstrip<RT> V;
   {
     nstrip<RT> S;
-    nmm2<RT, KS, true, true>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
+    if constexpr (DSYM) {
+      nmm2<RT, KS, true, true>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
+    } else {
+      nstrip<RT> tb;
+      io.ld_added(tb, NC_TMM, p);
+      nmm2<RT, KS, true, true>(S, V, dQ, r_s, tb, p);
+    }
     if (own_wave) {
       double* sd = laneB ? vs : sm.vec[7];
 #pragma unroll
@@ -265,26 +414,58 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
         for (int r = 0; r < 4; ++r) sd[p.row(ta, r)] = S.v[ta][r];
     }
     // r_s <- r+- (the accumulator of the R+- update; its rider column is never used), t_s <- t++
-    ndsym(r_s, r_s, dp);
-    ndsym(t_s, t_s, dp);
+    if constexpr (DSYM) {
+      ndsym(r_s, r_s, dp);
+      ndsym(t_s, t_s, dp);
+    } else {
+      io.ld_added(r_s, NC_RPM, p);
+    }
+    VSM_IA_STAMP(4);
     __syncthreads();                      // (d): [E2] (series) and [T--] no longer read
+    if constexpr (!RID) {
+      if (tid < G::NP) vs[tid] = nmv_sum<RT>(sm, RT, tid);
+    }
     nstore(dQ, S, p);                     // [S]   -> Q
     nstore(dP, t_s, p);                   // [t++] -> P
   }
   __syncthreads();                        // (e)
+  io.prefetch(NC_RMP, sm.vec[7]);
+  VSM_IA_STAMP(5);
+  nstrip<RT> Tpp;
   {
     nstrip<RT> X, Y;
     nmm<RT, KS, true>(X, dP, Gs, p);      // T21 = t++ G2
     nmm<RT, KS, true>(Y, dQ, Gs, p);      // Y = S G2 = T01 r-+
+    VSM_IA_STAMP(6);
     __syncthreads();                      // (f): [t++], [S] no longer read
-    nstore(dP, X, p);                     // [T21] -> P
-    nstore(dQ, Y, p);                     // [Y]   -> Q
+    bool direct = true;
+    if constexpr (IO::REF) {
+      if (io.raw) {                       // T++ as a raw image through P (its lines wait in the L2), before [T21] moves in
+        direct = false;
+        io.dma_raw(io.m[NC_TPP], sm.P, p);
+        nstore(dQ, Y, p);                 // [Y]   -> Q
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        io.ld_raw(Tpp, sm.P, p);
+        __syncthreads();
+        nstore(dP, X, p);                 // [T21] -> P
+      }
+    }
+    if (direct) {
+      nstore(dP, X, p);                   // [T21] -> P
+      nstore(dQ, Y, p);                   // [Y]   -> Q
+    }
   }
   __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
-  nstrip<RT> Tpp, Rmp;
-  nld_native(Tpp, T_pp, p);
-  nld_native(Rmp, R_mp, p);
+  nstrip<RT> Rmp;
+  if constexpr (IO::REF) {
+    if (!io.raw) io.ld(Tpp, NC_TPP, p);
+  } else {
+    io.ld(Tpp, NC_TPP, p);
+    io.ld(Rmp, NC_RMP, p);
+  }
   __syncthreads();                        // (g)
+  VSM_IA_STAMP(7);
   if constexpr (!RID) {   // T21 z , Y z
     nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
     nmv_part(sm.Q, vz, 1.0, sm.mv[RT + p.wave], p);
@@ -295,43 +476,126 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
-        Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the native record keeps the rider column of the previous layer step)
+        if constexpr (!IO::REF) Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the record keeps the rider column of the previous step)
       }
   }
   {
     nstrip<RT> acc;
     nmm2<RT, KS, false, true>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
-    nst_native(R_pm, r_s, p);
-    nst_native(T_pp, acc, p);
+    VSM_IA_STAMP(8);
+    if constexpr (IO::REF) io.ld(Rmp, NC_RMP, p);   // (ahead of the stores in the memory pipeline; it arrives under the last products)
+    io.st(NC_RPM, r_s, p);
+    io.st(NC_TPP, acc, p);
     if (laneA) {
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-          J0_p[row] = vjp[row] + acc.v[ta][r];
+          io.stJ(0, row, vjp[row] + acc.v[ta][r]);
         }
     }
   }
-  nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
-  nst_native(R_mp, Rmp, p);
-  nst_native(T_mm, V, p);
+  VSM_IA_STAMP(9);
+  if constexpr (IO::REF) {   // R-+ as a late addend (its strip was still on the way)
+    nstrip<RT> YT;
+    nmm2<RT, KS, true, false>(YT, V, dQ, Tpp, Z, p);       // Y T++ ; T-- = V + Y Z
+    VSM_IA_STAMP(10);
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Rmp.v[ta][r] += YT.v[ta][r];
+  } else {
+    nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);                   // R-+ = R-+ + Y T++ ; T-- = V + Y Z
+  }
+  io.st(NC_RMP, Rmp, p);
+  io.st(NC_TMM, V, p);
   if (laneA) {
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = p.row(ta, r);
-        J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
+        io.stJ(1, row, vJm[row] + vs[row] + Rmp.v[ta][r]);
       }
   }
   if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
     __syncthreads();
     if (tid < G::NP) {
-      J0_p[tid] = vjp[tid] + nmv_sum<RT>(sm, 0, tid);
-      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid);
+      io.stJ(0, tid, vjp[tid] + nmv_sum<RT>(sm, 0, tid));
+      io.stJ(1, tid, vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid));
     }
   }
+#ifdef VSM_IA_PHASES
+  __builtin_amdgcn_s_waitcnt(0);   // (the stores have left)
+  VSM_IA_STAMP(11);
+  if (threadIdx.x == 0) atomicAdd(&vsm_ia_phase_cycles[15], 1ull);
+#endif
+}
+
+// interaction!(::ScatteringInterface_11) on the reference's arrays (vsm_interaction_f64, N <= 64): one workgroup per point
+template <int RT, int KS, bool DSYM>
+__global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N, int ns, composite<double> c, added<double> a,
+                                                                            int* status) {
+  using G = ngeo<RT>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
+  SM& sm = *reinterpret_cast<SM*>(smem_raw);
+  npos<RT> p(sm.P);
+  const long long s = blockIdx.x, NN = (long long)N * N;
+  const int tid = threadIdx.x;
+  nio_ref<RT> io;
+  io.N = N;
+  io.m[NC_RMP] = c.R_mp + s * NN;
+  io.m[NC_RPM] = c.R_pm + s * NN;
+  io.m[NC_TPP] = c.T_pp + s * NN;
+  io.m[NC_TMM] = c.T_mm + s * NN;
+  io.J[0] = c.J0_p + s * N;
+  io.J[1] = c.J0_m + s * N;
+  io.a[NC_RMP] = a.r_mp + s * a.mat_stride;
+  io.a[NC_TPP] = a.t_pp + s * a.mat_stride;
+  io.a[NC_RPM] = DSYM ? nullptr : a.r_pm + s * a.mat_stride;
+  io.a[NC_TMM] = DSYM ? nullptr : a.t_mm + s * a.mat_stride;
+#ifdef VSM_IA_PHASES
+  unsigned long long t_ = __builtin_amdgcn_s_memtime();
+#endif
+  // every request the entry can make goes out before the first wait: the four source vectors into registers, r-+ / t++ as raw
+  // images by DMA, and the lines of R+- / T-- into the L2 (their images follow as soon as P and Q have been read)
+  const bool in = tid < N;
+  const double j0p = in ? a.j0_p[s * N + tid] : 0.0, j0m = in ? a.j0_m[s * N + tid] : 0.0;
+  io.jpre[0] = in ? io.J[0][tid] : 0.0;
+  io.jpre[1] = in ? io.J[1][tid] : 0.0;
+  nstrip<RT> r_s, t_s;
+  io.raw = true;
+  if (io.raw) {
+    io.dma_raw(io.a[NC_RMP], sm.P, p);
+    io.dma_raw(io.a[NC_TPP], sm.Q, p);
+    io.prefetch(NC_RPM, sm.vec[7]);
+    io.prefetch(NC_TMM, sm.vec[7]);
+  }
+  if (tid < G::NP) {
+    sm.vec[0][tid] = j0p;
+    sm.vec[1][tid] = j0m;
+    sm.usg[tid] = (DSYM && (tid % ns) >= 2) ? -1.0 : 1.0;
+  }
+  if (io.raw) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    io.ld_raw(r_s, sm.P, p);
+    io.ld_raw(t_s, sm.Q, p);
+    __syncthreads();
+    io.dma_raw(io.m[NC_RPM], sm.Q, p);   // (nia_body waits for them)
+    io.dma_raw(io.m[NC_TMM], sm.P, p);
+  } else {
+    io.ld_added(r_s, NC_RMP, p);
+    io.ld_added(t_s, NC_TPP, p);
+    __syncthreads();
+  }
+#ifdef VSM_IA_PHASES
+  __builtin_amdgcn_s_waitcnt(0);
+  VSM_IA_STAMP(12);
+#endif
+  nia_body<RT, KS, DSYM>(sm, p, N, io, r_s, t_s, status);
 }
 
 // the LDS block decides the workgroups per CU the register budgets (ngeo::WPS) are set for
@@ -369,7 +633,7 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(in
     }
     return;
   }
-  nia_body<RT, KS>(sm, p, n, comp, r_s, t_s, status);
+  nia_body<RT, KS, true>(sm, p, n, nio_native<RT>{comp}, r_s, t_s, status);
 }
 
 }  // namespace
@@ -378,7 +642,8 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(in
 #define VSM_NCAT2(a, b) a##b
 #define VSM_NCAT(a, b) VSM_NCAT2(a, b)
 #define VSM_NATIVE_DECL(KS) \
-  int VSM_NCAT(launch_layer_native_, KS)(int, int, int, unsigned, int, int, int, const double*, const nlayer_comps&, int*, hipStream_t);
+  int VSM_NCAT(launch_layer_native_, KS)(int, int, int, unsigned, int, int, int, const double*, const nlayer_comps&, int*, hipStream_t); \
+  int VSM_NCAT(launch_ia_native_, KS)(int, int, const composite<double>&, const added<double>&, int*, hipStream_t);
 
 #ifdef VSM_NATIVE_KS
 VSM_NATIVE_DECL(VSM_NATIVE_KS)
@@ -397,7 +662,34 @@ int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsign
   VSM_LAUNCH_CHECK("k_layer_native");
   return VSM_OK;
 }
+int VSM_NCAT(launch_ia_native_, VSM_NATIVE_KS)(int N, int S, const composite<double>& c, const added<double>& a, int* status,
+                                               hipStream_t st) {
+  constexpr int KS = VSM_NATIVE_KS;
+  constexpr int RT = (KS % 4 == 0 && KS >= 8) ? KS / 4 : (4 * KS + 2 + 15) / 16;
+  using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
+  auto kd = k_ia_native<RT, KS, true>;
+  auto kg = k_ia_native<RT, KS, false>;
+  int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kd), sizeof(SM), "hipFuncSetAttribute(k_ia_native)");
+  if (!prepared) prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kg), sizeof(SM), "hipFuncSetAttribute(k_ia_native general)");
+  if (prepared) return prepared;
+  if (a.d_symmetric)   // (d_symmetric carries n_stokes)
+    hipLaunchKernelGGL(kd, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, a.d_symmetric, c, a, status);
+  else
+    hipLaunchKernelGGL(kg, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, 1, c, a, status);
+  VSM_LAUNCH_CHECK("k_ia_native");
+  return VSM_OK;
+}
 }  // namespace vsm
+#ifdef VSM_IA_PHASES
+extern "C" int vsm_debug_ia_phases(unsigned long long* out_h, int reset) {
+  if (out_h) (void)hipMemcpyFromSymbol(out_h, HIP_SYMBOL(vsm::vsm_ia_phase_cycles), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(vsm::vsm_ia_phase_cycles), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
 
 #else  // ---- dispatcher object: pre-pass, layout conversion, the run object and its C ABI -----------------------------------
 
@@ -835,6 +1127,25 @@ static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, 
   set_error("launch_layer_native: no kernel for %d k-steps", ks);
   return VSM_ERR_UNSUPPORTED;
 }
+
+}  // namespace
+// interaction!(::ScatteringInterface_11) on the reference-layout arrays, FP64, N <= 64 (VSM_ERR_UNSUPPORTED beyond)
+int native_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
+  if (N < 1 || N > 64) return VSM_ERR_UNSUPPORTED;
+  if (S <= 0) return VSM_OK;
+  int* status = device_status();
+  if (!status) return VSM_ERR_HIP;
+#define VSM_NI(KS) \
+  case KS: return VSM_NCAT(launch_ia_native_, KS)(N, S, c, a, status, st);
+  switch ((N + 3) / 4) {
+    VSM_NI(1) VSM_NI(2) VSM_NI(3) VSM_NI(4) VSM_NI(5) VSM_NI(6) VSM_NI(7) VSM_NI(8) VSM_NI(9) VSM_NI(10) VSM_NI(11) VSM_NI(12)
+    VSM_NI(13) VSM_NI(14) VSM_NI(15) VSM_NI(16)
+    default: break;
+  }
+#undef VSM_NI
+  return VSM_ERR_UNSUPPORTED;
+}
+namespace {
 
 template <int RT, typename ST>
 static void launch_pre(bool mix, const quad<ST>& q, int S, int nsub, int n, int ndoubl, const ST* dtau, const ST* varpi,
