@@ -291,15 +291,15 @@ def ia_kernel(vsm, torch, arch, points=10240, N=60, reps=10, scale=1.0, name="IA
         del pc, pa, init
         return e
     e["north_star_target_mfma_utilisation"] = 0.40
-    # what the MFMA pipe executes: 10 products of the one-inverse interaction + 6 of the order-7 Horner series, each 4 waves x 60
-    # v_mfma_f64_16x16x4 (2048 flop): 16 x 491 520 flop per point (the padded 64 x 64 x 60 tiles and the series are not in the
-    # algorithmic count)
-    exe_pt = 16 * 4 * 60 * 2048.0
+    # what the MFMA pipe executes: 10 products of the one-inverse interaction + 4 of the order-7 inverse in its factored form
+    # (I + E)(I + E^2)(I + E^4) (ninvert7; Horner's rule took 6), each 4 waves x 60 v_mfma_f64_16x16x4 (2048 flop): 14 x 491 520
+    # flop per point (the padded 64 x 64 x 60 tiles and the series are not in the algorithmic count)
+    exe_pt = 14 * 4 * 60 * 2048.0
     e["mfma_utilisation_executed"] = exe_pt * S / (ms * 1e-3) / 1e12 / PEAK["f64"]
     e["note"] = ("frac_of_mfma_peak is ALGORITHMIC flops (24N^3+8N^2 per point) / launch time / 78.6; mfma_utilisation_executed is the "
-                 "flops of the MFMA instructions the kernel issues (16 products of 240 v_mfma_f64_16x16x4 per point) / launch time / "
+                 "flops of the MFMA instructions the kernel issues (14 products of 240 v_mfma_f64_16x16x4 per point) / launch time / "
                  "78.6 -- the pipe's busy fraction, which the PMC pass measures directly (SQ_VALU_MFMA_BUSY_CYCLES, "
-                 "profiles/r04/ia/summary.json)")
+                 "profiles/r05/ia/summary.json)")
     del pc, pa, init
     return e
 

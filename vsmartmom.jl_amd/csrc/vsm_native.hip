@@ -391,7 +391,9 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
       if (tid < G::NP) vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
     }
     VSM_IA_STAMP(2);
-    ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
+    const int K = ninv_order(nrm, status);                       // [E2] -> P, barrier (c), series
+    if (K == 7) ninvert7<RT, KS>(E, Gs, n, cx, p);
+    else ninvert<RT, KS, IO::REF>(K, E, Gs, n, cx, p);
     VSM_IA_STAMP(3);
   }
   if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))

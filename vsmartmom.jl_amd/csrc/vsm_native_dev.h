@@ -366,8 +366,26 @@ struct ninv_ctx {
 // level by level): rare, and their live strips stay out of the hot path's register allocation.  Every wave is past the norm
 // reduction's barrier (nobody reads W any more); on return other waves may still be reading W.
 template <int RT, int KS>
-__device__ __attribute__((noinline)) void ninvert_slow(int K, nstrip<RT>& E, nstrip<RT>& G, int n, const ninv_ctx& cx,
-                                                       npos<RT>& p) {
+__device__ __forceinline__ void ninvert_slow_body(int K, nstrip<RT>& E, nstrip<RT>& G, int n, const ninv_ctx& cx, npos<RT>& p);
+// REGS: copy the arguments (the caller's stack objects) into registers once -- working through the references puts a flat load
+// in front of every k-step (the standalone interaction's long orders: 0.21 -> 0.37 of the peak).  The layer kernels keep the
+// by-reference form: a callee with ~250 VGPRs makes their register allocator spill around the call site in the hot path
+// (measured: C2 -1.8 %), and their atmospheres hardly ever take this path.
+template <int RT, int KS, bool REGS>
+__device__ __attribute__((noinline)) void ninvert_slow(int K, nstrip<RT>& E_in, nstrip<RT>& G_out, int n, const ninv_ctx& cx_in,
+                                                       npos<RT>& p_in) {
+  if constexpr (REGS) {
+    nstrip<RT> E = E_in, G;
+    npos<RT> p = p_in;
+    const ninv_ctx cx = cx_in;
+    ninvert_slow_body<RT, KS>(K, E, G, n, cx, p);
+    G_out = G;
+  } else {
+    ninvert_slow_body<RT, KS>(K, E_in, G_out, n, cx_in, p_in);
+  }
+}
+template <int RT, int KS>
+__device__ __forceinline__ void ninvert_slow_body(int K, nstrip<RT>& E, nstrip<RT>& G, int n, const ninv_ctx& cx, npos<RT>& p) {
   constexpr int NP = 16 * RT;
   if (K == 0) {
     if (p.col < n) {     // M = I - E, plain column-major (only the n x n block is read back)
@@ -434,12 +452,12 @@ __device__ __attribute__((noinline)) void ninvert_slow(int K, nstrip<RT>& E, nst
 // result, so whatever rides there stays in columns that are never a contraction index.  On the slow path the riders of G are
 // lost -- RIDERS tells whether the caller needs them (then it restores them itself: see the callers).
 // On return other waves may still be reading W.
-template <int RT, int KS>
+template <int RT, int KS, bool REGS = false>
 __device__ __forceinline__ void ninvert(int K, nstrip<RT>& E, nstrip<RT>& G, int n, const ninv_ctx& cx, npos<RT>& p) {
   if (K < 1 || K > 8) {
     nstrip<RT> Es = E, Gs;
     npos<RT> ps = p;
-    ninvert_slow<RT, KS>(K, Es, Gs, n, cx, ps);
+    ninvert_slow<RT, KS, REGS>(K, Es, Gs, n, cx, ps);
     G = Gs;
     return;
   }
@@ -456,6 +474,28 @@ __device__ __forceinline__ void ninvert(int K, nstrip<RT>& E, nstrip<RT>& G, int
       G = X;
     }
   }
+  nadd_identity(G, n, p);
+}
+// Order 7 without riders in G, in four products instead of Horner's six:  (I + E)(I + E^2)(I + E^4)  with
+//   W2 = E E,  T = E W2,  W4 = E T  (A = [E]),  S = E + W2 + T,  G = I + S + W4 + W4 S  (A = [W4]: one more A-form store).
+// The interaction's inverse: its G is only ever a B operand whose rider columns nobody reads.  Three live strips.
+template <int RT, int KS>
+__device__ __forceinline__ void ninvert7(nstrip<RT>& E, nstrip<RT>& G, int n, const ninv_ctx& cx, npos<RT>& p) {
+  nstore(cx.dW, E, p);
+  __syncthreads();
+  nstrip<RT> X, Y;
+  nmm_c<RT, KS>(X, E, cx.dW, E, p);          // X = E + E^2
+  nload(Y, cx.dW, p);
+  nmm<RT, KS>(Y, cx.dW, X, p);               // Y = E + E X = S
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta) X.v[ta] = Y.v[ta] - X.v[ta];   // E^3
+  nmm<RT, KS, true>(G, cx.dW, X, p);         // W4 = E E^3
+  __syncthreads();                           // [E] no longer read
+  nstore(cx.dW, G, p);
+#pragma unroll
+  for (int ta = 0; ta < RT; ++ta) G.v[ta] += Y.v[ta];
+  __syncthreads();
+  nmm<RT, KS>(G, cx.dW, Y, p);               // S + W4 + W4 S
   nadd_identity(G, n, p);
 }
 __device__ __forceinline__ int ninv_order(double nrm, int* status) {
