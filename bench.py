@@ -81,6 +81,30 @@ def stokes_groups(ns, coupling):
     return out
 
 
+def executed_over_algorithmic(scene, native=None):
+    """Executed / as-written flops of the layer steps of a scene: a block of n rows costs (n / N)^3 of the dense count, a block
+    that the phase matrices of a layer leave exactly zero costs none (an elementwise scaling of the composite); moments outside
+    `native` (default: the scene's native moments) run dense."""
+    N = scene.N
+    n3, n2 = float(N) ** 3, float(N) ** 2
+    if native is None:
+        native = set(scene._native_moments())
+    ex_num = ex_den = 0.0
+    for i, mom in enumerate(scene.moments):
+        for iz, ly in enumerate(mom["layers"]):
+            wl = ly["nd"] * (12 * n3 + 8 * n2) + (24 * n3 + 8 * n2 if iz else 0.0)
+            ex_den += wl
+            if i not in native:
+                ex_num += wl
+                continue
+            lc = scene._layer_coupling(mom["m"], iz)
+            for g in stokes_groups(scene.pol.n, scene.coupling[mom["m"]]):
+                comps = [a for a in range(scene.pol.n) if g >> a & 1]
+                if any(lc >> (4 * a + b) & 1 for a in comps for b in comps):
+                    ex_num += wl * (scene.N // scene.pol.n * len(comps) / float(N)) ** 3
+    return ex_num / ex_den if ex_den else 1.0
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -292,23 +316,9 @@ def main():
             k_ms = sum(e[0].elapsed_time(e[1]) for e in legacy)
             k_flops, n_launch = step_flops(legacy), len(legacy)
             moments_per_launch = max([e[4] for e in legacy], default=1)
-        # executed products of the layer steps: a block of n rows costs (n / N)^3 of the dense count, a block that the phase
-        # matrices of a layer leave exactly zero costs none (an elementwise scaling of the composite)
-        ex_num = ex_den = 0.0
-        for i, mom in enumerate(scene.moments):
-            for iz, ly in enumerate(mom["layers"]):
-                wl = ly["nd"] * (12 * n3 + 8 * n2) + (24 * n3 + 8 * n2 if iz else 0.0)
-                ex_den += wl
-                if i not in native:
-                    ex_num += wl
-                    continue
-                lc = scene._layer_coupling(mom["m"], iz)
-                for g in stokes_groups(scene.pol.n, scene.coupling[mom["m"]]):
-                    comps = [a for a in range(scene.pol.n) if g >> a & 1]
-                    if any(lc >> (4 * a + b) & 1 for a in comps for b in comps):
-                        ex_num += wl * (scene.N // scene.pol.n * len(comps) / float(N)) ** 3
-        layer_step["executed_over_algorithmic_flops"] = ex_num / ex_den
-        layer_step["frac_of_mfma_peak_executed"] = layer_step["frac_of_mfma_peak_algorithmic"] * ex_num / ex_den
+        ex_ratio = executed_over_algorithmic(scene, native)
+        layer_step["executed_over_algorithmic_flops"] = ex_ratio
+        layer_step["frac_of_mfma_peak_executed"] = layer_step["frac_of_mfma_peak_algorithmic"] * ex_ratio
         layer_step["note"] = ("blocks of Stokes components that do not couple (m = 0: (I,Q) and U) run as independent sub-problems, a "
                               "block whose phase matrix is exactly zero in a layer takes a diagonal step: products with exact "
                               "zeros are not formed")

@@ -133,8 +133,15 @@ def c2_aer(vsm, torch, arch, o2a, points=10000):
                "FP64, 40 layers; full step (H2D + device optics + run + D2H)" % (model.m_max, min(nds), max(nds)), points, wall, dev,
                scene.flops_per_point(), "f64", "k_layer_native<4, 15> (m = 1, 2), k_layer_native<3, 10> / <2, 5> (blocks of m = 0 and of "
                "the aerosol layers at m >= 3), k_native_diag_layer (Rayleigh-only layers at m >= 3: the Rayleigh phase matrix vanishes)")
-    e["note"] = ("frac_of_mfma_peak counts the as-written dense 60 x 60 products of all 36 moments x 40 layers (SURVEY 8d); the run forms "
-                 "only the products whose Stokes block the layer's phase matrices do not leave exactly zero")
+    import bench
+    ratio = bench.executed_over_algorithmic(scene)
+    e["frac_of_mfma_peak_as_written"] = e["frac_of_mfma_peak"]
+    e["executed_over_algorithmic_flops"] = ratio
+    e["frac_of_mfma_peak"] = e["frac_of_mfma_peak_as_written"] * ratio
+    e["note"] = ("frac_of_mfma_peak_as_written counts the dense 60 x 60 products of all 36 moments x 40 layers as the reference writes "
+                 "them (SURVEY 8d) -- above 1 because the run forms only the products whose Stokes block the layer's phase matrices do "
+                 "not leave exactly zero (the Rayleigh phase matrix vanishes for m >= 3: 34 of the 40 layers take a diagonal step there; "
+                 "HG aerosol couples I alone: a 20-row block); frac_of_mfma_peak is the flops of the products that ARE formed, whole step")
     del scene
     return e
 

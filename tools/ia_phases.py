@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a workgroup of k_ia_native<4,15> spends its cycles: needs the diagnostic build
-(hipcc ... -DVSM_NATIVE_KS=15 -DVSM_IA_PHASES vsm_native.hip, linked into lib_dbg/libvsm_ph.so).  Not part of the product.
-    VSM_LIB_PATH=.../lib_dbg/libvsm_ph.so python tools/ia_phases.py [--points S] [--dsym 3] [--refl 0.1]"""
+(make -C vsmartmom.jl_amd/csrc ia_phases -> lib_dbg/libvsm_ia_phases.so).  Not part of the product.
+    VSM_LIB_PATH=$PWD/vsmartmom.jl_amd/lib_dbg/libvsm_ia_phases.so python tools/ia_phases.py [--points S] [--dsym 3] [--refl 0.1]"""
 import argparse
 import ctypes as C
 import os
@@ -14,10 +14,11 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import vsmartmom_jl_amd as vsm  # noqa: E402
 
-NAMES = ["composite loads R+-, T--, A-form stores, barrier (a)", "[E2 | Z] = R+- [r-+ | t--]", "norm (barrier b)",
-         "store [E2], barrier (c), Horner series", "[S | V] = T-- [r-+ | t--], D r D", "barrier (d), store [S] [t++], barrier (e)",
-         "T21 = t++ G2, Y = S G2", "barrier (f), store [T21] [Y], loads T++ R-+, barrier (g)", "[R+- | T++] products",
-         "stores R+- T++ issued", "[R-+ | T--] products", "stores R-+ T-- issued and drained", "added-layer loads r-+ t++ (kernel head)"]
+NAMES = ["images of R+- / T-- read, [R+-] stored, riders, barrier (a)", "[E2 | Z] = R+- [r-+ | t--]", "store [T--], norm (barrier b)",
+         "store [E2], barrier (c), inverse of order 7 in four products", "[S | V] = T-- [r-+ | t--], D r D",
+         "barrier (d), store [S] [t++], barrier (e)", "T21 = t++ G2, Y = S G2", "barrier (f), image of T++ through P, store [T21] [Y], barrier (g)",
+         "[R+- | T++] products", "R-+ requested, stores R+- T++ issued", "[R-+ | T--] products (R-+ arrives underneath)",
+         "stores R-+ T-- issued and drained (the wait is the stamp's)", "kernel head: vectors, images of r-+ t++ by DMA, images of R+- T-- requested"]
 
 
 def main():
@@ -62,11 +63,11 @@ def main():
     v = np.array(list(buf), dtype=float)
     nwg = max(v[15], 1.0)
     tot = v[:13].sum() / nwg
-    print("k_ia_native<4,15,%s> S=%d: %.4f ms per launch; s_memtime ticks of wave 0 per workgroup (100 MHz counter), %d workgroups"
+    print("k_ia_native<4,15,%s> S=%d: %.4f ms per launch; s_memtime ticks (shader clock) of wave 0 per workgroup, mean over %d workgroups"
           % ("true" if a.dsym else "false", S, ms, nwg))
     for i in [12] + list(range(12)):
         print("  %-62s %9.1f  %5.1f %%" % (NAMES[i], v[i] / nwg, 100 * v[i] / nwg / tot))
-    print("  total %.1f ticks = %.1f us per workgroup" % (tot, tot / 100.0))
+    print("  total %.1f ticks per workgroup" % tot)
 
 
 if __name__ == "__main__":

@@ -181,7 +181,7 @@ struct nio_native {
   __device__ __forceinline__ double ldJ(int pm, int i) const { return comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i]; }
   __device__ __forceinline__ void stJ(int pm, int i, double v) const { comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i] = v; }
   __device__ __forceinline__ void ld_added(nstrip<RT>&, int, const npos<RT>&) const {}
-  __device__ __forceinline__ void prefetch(int, double*) const {}
+  __device__ __forceinline__ void prefetch(int, double*) const {}   // (measured in the layer kernel: -0.4 %; its loads are not exposed)
 };
 template <int RT>
 struct nio_ref {
@@ -192,39 +192,70 @@ struct nio_ref {
   bool raw;              // R+- / T-- arrive as raw images in Q / P (k_ia_native requested them by DMA)
   double jpre[2];        // J0+[tid], J0-[tid], requested at the entry of the kernel
   static constexpr bool REF = true;
-  // direct accesses in the accumulator layout (16 columns x 32 B per instruction: the L2 absorbs the partial lines -- measured
-  // faster than the transposer tiles up to five row tiles, vsm_strip128_dev.h)
+  // Direct accesses in the accumulator layout.  A lane holds rows kq + 4 r of a row tile: 8-byte accesses would touch 32-byte
+  // pieces of 16 lines per instruction (measured: ~ 350 cycles of issue each while the memory pipeline is busy).  N even:
+  // v_permlane16_swap trades the odd 16-lane rows of register r = 2h with the even ones of r = 2h + 1, which leaves lane-row kq
+  // with the ADJACENT rows (4 (kq & 1) + 2 (kq >> 1), + 1) + 8 h of its column -- one 16-byte access, 64 contiguous bytes per
+  // column and instruction, half the instructions.  (The swap is its own inverse: loads apply it after, stores before.)
+  static __device__ __forceinline__ void swap16(double& a, double& b) {
+    const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+    b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+  }
   __device__ __forceinline__ void ldg(nstrip<RT>& x, const double* __restrict__ g, const npos<RT>& p) const {
     const bool cok = p.col < N;
     const double* gc = g + (long long)N * min(p.col, N - 1);
+    if ((N & 1) == 0) {
+      const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = 16 * ta + 8 * h + rb;
+          const double2 v = *reinterpret_cast<const double2*>(gc + min(row, N - 2));
+          const bool ok = cok && row < N;
+          double a = ok ? v.x : 0.0, b = ok ? v.y : 0.0;
+          swap16(a, b);
+          x.v[ta][2 * h] = a;
+          x.v[ta][2 * h + 1] = b;
+        }
+      return;
+    }
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = p.row(ta, r);
-#ifdef VSM_IA_NOIO   // (experiment: what the direct accesses cost)
-        const double v = (row == p.col) ? 0.5 : 1e-4;
-#else
         const double v = gc[min(row, N - 1)];
-#endif
         x.v[ta][r] = (cok && row < N) ? v : 0.0;
       }
   }
   __device__ __forceinline__ void ld(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, m[which], p); }
   __device__ __forceinline__ void ld_added(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, a[which], p); }
   __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const {
+    double* gc = m[which] + (long long)N * min(p.col, N - 1);
+    if ((N & 1) == 0) {
+      const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double a = x.v[ta][2 * h], b = x.v[ta][2 * h + 1];
+          swap16(a, b);
+          const int row = 16 * ta + 8 * h + rb;
+          if (p.col < N && row < N) *reinterpret_cast<double2*>(gc + row) = make_double2(a, b);
+        }
+      return;
+    }
     if (p.col < N) {
-      double* gc = m[which] + (long long)N * p.col;
 #pragma unroll
       for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = p.row(ta, r);
-#ifdef VSM_IA_NOIO
-          if (row < N && x.v[ta][r] == 1.2345) gc[row] = x.v[ta][r];
-#else
           if (row < N) gc[row] = x.v[ta][r];
-#endif
         }
     }
   }
@@ -291,7 +322,16 @@ struct nio_ref {
 //   T21 = t++ G2 ;  Y = S G2            A = P = [t++], Q = [S]
 //   [R+- | T++] = [r+- | 0] + T21 [Z | T++]      A = P = [T21]   J0+ = j0+ + T21 z   (z rides in a spare column of T++)
 //   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z
-// Ten products and the series, seven barriers, at most six live strips.
+// Ten products and the inverse (order 7, the usual one: four products, ninvert7), at most six live strips.
+// IO says where the composite lives.  nio_native (the run's records): coalesced 16-byte accesses, the order above.  nio_ref (the
+// reference's [N,N,S] arrays, k_ia_native): a lane's accumulator elements are 32-byte pieces of 16 different lines there, and a
+// workgroup that waits for such loads has nothing to overlap them with -- stamped (tools/ia_phases.py), the loads were 55 % of a
+// workgroup's life.  So on that side (a) every matrix that is read while P or Q is free comes in as a raw image by LDS DMA (whole
+// lines, no registers) and the lanes pick their elements out of LDS: r-+ / t++, then R+- / T--, later T++ through P before [T21]
+// moves in; (b) what cannot (R-+: P and Q hold [T21], [Y]) is asked into the L2 a few products ahead by a one-dword-per-line DMA
+// into a junk vector and loaded as a late addend UNDER the last products, its request issued ahead of the stores of R+- / T++ (the
+// memory pipeline is in order); (c) the kernel's entry issues every request it can before its first wait.  0.34 -> 0.45 of the
+// FP64 MFMA peak at N = 60.  The layer kernel keeps the plain order: the same steps measured -0.4 ... -1.8 % there.
 #ifdef VSM_IA_PHASES   // diagnostic build (tools/ia_phases.py): cycles of wave 0 between the stamps, summed over the workgroups
 __device__ unsigned long long vsm_ia_phase_cycles[16];
 #define VSM_IA_STAMP(k)                                                  \

@@ -551,22 +551,103 @@ __device__ __forceinline__ void store_c8(double* __restrict__ g, const bstrip<RT
   }
 }
 
-// Which of the two a kernel uses is a matter of measurement: the tiles cost LDS round trips and wave barriers on the critical
-// path, the direct form costs sixteen requests per tile.  Forward and linearized runs, 2000 points (profiles/r04/shape_sweep):
-// five row tiles and fewer are 3 ... 4 % FASTER direct (the L2 absorbs the partial lines), six and more 0 ... 4.5 % faster
-// through the tiles.
+// ---- strip <-> global with v_permlane16_swap (round 5): the access geometry of the c8 scheme without its LDS round trips -------
+// A lane holds rows kq + 4 r of a row tile.  v_permlane16_swap trades the odd 16-lane rows of register r = 2h with the even ones of
+// r = 2h + 1 (tools/permlane_probe.hip); afterwards lane-row kq holds the ADJACENT rows rb, rb + 1 with rb = 4 (kq & 1) + 2 (kq >> 1)
+// + 8 h of its column: one 16-byte access per pair, 16 columns x 64 contiguous bytes per instruction, two instructions per row tile
+// instead of four.  The swap is its own inverse: loads request the pairs (`issue`) and swap when they are needed (`finish`: four
+// VALU instructions per pair, no LDS, no barrier), stores swap first.
+__device__ __forceinline__ void swap16_128(double& a, double& b) {
+  const unsigned long long ua = __double_as_longlong(a), ub = __double_as_longlong(b);
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
+  b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+}
+template <int RT>
+__device__ __forceinline__ void load_sw_issue(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p) {
+  const double* src0 = g + (long long)N * min(p.col, N - 1) + 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+  asm volatile("" : "+v"(src0));
+  gcd_p src = (gcd_p)src0;
+  const bool cok = p.col < N;
+  const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    double a = 0.0, b = 0.0;
+    if (j < 2 * (RT - 1)) {   // N > 16 (RT - 1): these rows exist
+      const d2b_t t = *reinterpret_cast<const __attribute__((address_space(1))) d2b_t*>(src + 8 * j);
+      a = cok ? t.x : 0.0;
+      b = cok ? t.y : 0.0;
+    } else {
+      const int r = 8 * j + rb;
+      if (cok && r + 1 < N) {
+        const d2b_t t = *reinterpret_cast<const __attribute__((address_space(1))) d2b_t*>(src + 8 * j);
+        a = t.x;
+        b = t.y;
+      } else if (cok && r < N) {
+        a = src[8 * j];
+      }
+    }
+    x.v[j >> 1][2 * (j & 1)] = a;
+    x.v[j >> 1][2 * (j & 1) + 1] = b;
+  }
+}
+template <int RT>
+__device__ __forceinline__ void load_sw_finish(bstrip<RT>& x) {
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    double a = x.v[j >> 1][2 * (j & 1)], b = x.v[j >> 1][2 * (j & 1) + 1];
+    swap16_128(a, b);
+    x.v[j >> 1][2 * (j & 1)] = a;
+    x.v[j >> 1][2 * (j & 1) + 1] = b;
+  }
+}
+template <int RT>
+__device__ __forceinline__ void store_sw(double* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p) {
+  double* dst0 = g + (long long)N * min(p.col, N - 1) + 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+  asm volatile("" : "+v"(dst0));
+  gd_p dst = (gd_p)dst0;
+  const bool cok = p.col < N;
+  const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+#pragma unroll
+  for (int j = 0; j < 2 * RT; ++j) {
+    double a = x.v[j >> 1][2 * (j & 1)], b = x.v[j >> 1][2 * (j & 1) + 1];
+    swap16_128(a, b);
+    d2b_t t;
+    t.x = a;
+    t.y = b;
+    const int r = 8 * j + rb;
+    if (cok && (j < 2 * (RT - 1) || r + 1 < N))
+      *reinterpret_cast<__attribute__((address_space(1))) d2b_t*>(dst + 8 * j) = t;
+    else if (cok && r < N)
+      dst[8 * j] = a;
+  }
+}
+
+// Which of the three a kernel uses is a matter of measurement.  Round 4 (direct 8-byte accesses against the c8 tiles, forward and
+// linearized runs, 2000 points): five row tiles and fewer 3 ... 4 % faster direct, six and more 0 ... 4.5 % faster through the tiles.
+// Round 5: the permlane pairs replace both (VSM_S128_OLD_IO restores the round-4 choice for A/B builds).
 template <int RT>
 struct use_c8 {
-  static constexpr bool value = RT >= 6;
+#if defined(VSM_AB_SWITCHES) && defined(VSM_S128_OLD_IO)
+  static constexpr bool value = RT >= 6, sw = false;
+#else
+  static constexpr bool value = false, sw = true;
+#endif
 };
 template <int RT>
 __device__ __forceinline__ void ldg_issue(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p) {
-  if constexpr (use_c8<RT>::value) load_c8_issue(x, g, N, p); else load_global128(x, g, N, p);
+  if constexpr (use_c8<RT>::sw) load_sw_issue(x, g, N, p);
+  else if constexpr (use_c8<RT>::value) load_c8_issue(x, g, N, p);
+  else load_global128(x, g, N, p);
 }
 // (ST: the element type the matching ldg_issue read -- FP32 arrays are always read directly, in the final layout)
 template <typename ST = double, int RT>
 __device__ __forceinline__ void ldg_finish(bstrip<RT>& x, const bpos<RT>& p, double* __restrict__ xw) {
-  if constexpr (use_c8<RT>::value && sizeof(ST) == 8) load_c8_finish(x, p, xw);
+  if constexpr (sizeof(ST) == 8) {
+    if constexpr (use_c8<RT>::sw) load_sw_finish(x);
+    else if constexpr (use_c8<RT>::value) load_c8_finish(x, p, xw);
+  }
 }
 template <int RT>
 __device__ __forceinline__ void ldg(bstrip<RT>& x, const double* __restrict__ g, int N, const bpos<RT>& p, double* __restrict__ xw) {
@@ -575,7 +656,9 @@ __device__ __forceinline__ void ldg(bstrip<RT>& x, const double* __restrict__ g,
 }
 template <int RT>
 __device__ __forceinline__ void stg(double* __restrict__ g, const bstrip<RT>& x, int N, const bpos<RT>& p, double* __restrict__ xw) {
-  if constexpr (use_c8<RT>::value) store_c8(g, x, N, p, xw); else store_global128(g, x, N, p);
+  if constexpr (use_c8<RT>::sw) store_sw(g, x, N, p);
+  else if constexpr (use_c8<RT>::value) store_c8(g, x, N, p, xw);
+  else store_global128(g, x, N, p);
 }
 template <int RT>
 __device__ __forceinline__ void ldg(bstrip<RT>& x, const float* __restrict__ g, int N, const bpos<RT>& p, double*) {
