@@ -404,3 +404,55 @@ def test_native_run_diagonal_steps_of_rayleigh_layers_at_high_moments(vsm, arch,
     Ro, To = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], aerosols=[O.AerosolOptics(O.hg_greek(0.7, 10), 0.95, 0.0)], **kw))
     assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-8, (_rel(Rn, Ro), _rel(Tn, To))
     assert _rel(Rn, Rl) < 1e-10 and _rel(Tn, Tl) < 1e-10
+
+
+@pytest.mark.parametrize("N,ns", [(1, 1), (3, 3), (9, 3), (21, 3), (29, 1), (32, 4), (33, 3), (45, 3), (47, 1), (48, 4), (57, 3),
+                                  (60, 3), (61, 1), (63, 3), (64, 4)])
+@pytest.mark.parametrize("dsym", [False, True])
+@pytest.mark.parametrize("scale", [1.0, 4.0, 12.0])
+def test_standalone_interaction_native(vsm, arch, N, ns, dsym, scale):
+    """interaction!(::ScatteringInterface_11) (interaction.jl:207-266) through vsm_interaction_f64 for N <= 64: k_ia_native, the
+    native kernel body on the reference's [N,N,S] arrays -- every row-tile / k-step family (rider columns and the mat-vec source
+    path of N = 29..32, 45..48, 61..64), odd N (4-byte DMA pieces, 8-byte accesses) and even N (16-byte pieces, permlane pairs), an
+    added layer with all four matrices in memory and a D-symmetric one (r+- = D r-+ D, t-- = D t++ D derived in the kernel, as
+    doubling! leaves it), at reflectances that take the order-7 inverse in four products, the long orders (out of line) and the
+    pivoted Gauss-Jordan -- against the oracle."""
+    FT = np.float64
+    rng = np.random.default_rng(100 * N + int(scale))
+    S = 5
+    CR = vsm.CoreRT
+
+    def refl(sc):
+        return (sc * rng.random((S, N, N)) / N).astype(FT)
+
+    def trans():
+        return (np.eye(N)[None] * rng.uniform(0.3, 0.95, (S, N, 1)) + 0.05 * rng.random((S, N, N)) / N).astype(FT)
+    comp = O.CompositeLayer(refl(0.1 * scale), refl(0.1 * scale), trans(), trans(), rng.random((S, N)), rng.random((S, N)))
+    r, t = refl(0.075 * scale), trans()
+    if dsym:
+        D = np.where(np.arange(N) % ns >= 2, -1.0, 1.0)
+        add = O.AddedLayer(r, t, D[None, :, None] * r * D[None, None, :], D[None, :, None] * t * D[None, None, :],
+                           rng.random((S, N)), rng.random((S, N)))
+    else:
+        add = O.AddedLayer(r, t, refl(0.075 * scale), trans(), rng.random((S, N)), rng.random((S, N)))
+    conv_m = lambda x: CR.to_device_matrix(x, arch, FT)
+    conv_v = vsm.Architectures.array_type(arch)
+    pc = CR.make_composite_layer(FT, arch, (N, N), S)
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        getattr(pc, k).copy_(conv_m(getattr(comp, k)))
+    pc.J0_p.copy_(conv_v(comp.J0_p))
+    pc.J0_m.copy_(conv_v(comp.J0_m))
+    pa = CR.make_added_layer(FT, arch, (N, N), S, d_symmetric=ns if dsym else 0)
+    for k in ("r_mp", "t_pp") if dsym else ("r_mp", "t_pp", "r_pm", "t_mm"):
+        getattr(pa, k).copy_(conv_m(getattr(add, k)))
+    pa.j0_p.copy_(conv_v(add.j0_p))
+    pa.j0_m.copy_(conv_v(add.j0_m))
+    O.interaction("11", comp, add, FT)
+    CR.interaction_("11", pc, pa)
+    torch.cuda.synchronize()
+    f, h = CR.from_device_matrix, vsm.Architectures.to_host
+    got = dict(R_mp=f(pc.R_mp), R_pm=f(pc.R_pm), T_pp=f(pc.T_pp), T_mm=f(pc.T_mm), J0_p=h(pc.J0_p), J0_m=h(pc.J0_m))
+    for k, v in got.items():
+        want = getattr(comp, k)
+        assert np.all(np.isfinite(v)), k
+        assert np.max(np.abs(v - want)) / np.max(np.abs(want)) < 1e-10, (k, N, dsym, scale)
