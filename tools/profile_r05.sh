@@ -4,7 +4,7 @@
 # (library.source_hash = vsm_build_id(), tools/source_hash.sh <commit> recomputes it from a tree) and the hash of the sources that
 # decide what ITS tag measures (tag_sources_hash): a tag whose committed summary carries the current hash is skipped, so an edit of
 # the Raman kernels does not re-take C2 / C4 / the linearized tags.
-# usage: tools/profile_r05.sh [c2 c2full c2aer c4 c4full lin lin112 fwd112 ia c5 ...]
+# usage: tools/profile_r05.sh [c2 c2full c2aer c4 c4full lin lin112 fwd112 ia ialong c5 ...]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 C="vsmartmom.jl_amd/csrc"
@@ -13,7 +13,7 @@ FWD="$COMMON,$C/vsm_native.hip,$C/vsm_native_dev.h,$C/vsm_strip.hip,$C/vsm_strip
 F32="$FWD,$C/vsm_strip32.hip"
 LIN="$FWD,$C/vsm_lin.hip,$C/vsm_striplin.hip,$C/vsm_strip128lin.hip,$C/vsm_strip128_dev.h,tools/lin_timing.py,tools/shape_cliff_timing.py"
 BIG="$COMMON,$C/vsm_native.hip,$C/vsm_native_dev.h,$C/vsm_strip128.hip,$C/vsm_strip128_dev.h,tools/shape_cliff_timing.py"
-RAM="$COMMON,$C/vsm_raman.hip,$C/vsm_raman_quad.hip,$C/vsm_raman_chain.hip,$C/vsm_raman_wave.hip,$C/vsm_fused.hip"
+RAM="$COMMON,$C/vsm_raman.hip,$C/vsm_raman_quad.hip,$C/vsm_raman_chain.hip,$C/vsm_raman_wave.hip,$C/vsm_fused.hip,$C/vsm_native.hip,$C/vsm_native_dev.h"
 prof() {   # tag sources [profile_any options ...] -- command
   local tag=$1 src=$2; shift 2
   python tools/profile_any.py --out gpurun_out/prof_r05_$tag --sources "$src" --skip-if-unchanged profiles/r05/$tag/summary.json "$@"
@@ -30,6 +30,7 @@ for w in "$@"; do
     lin64)  prof lin64 "$LIN" --dtype f64 -- python tools/shape_cliff_timing.py --cases IQUV:27 ;;
     fwd112) prof fwd112 "$BIG" --dtype f64 -- python tools/shape_cliff_timing.py --no-lin --cases IQUV:51 ;;
     ia)     prof ia "$FWD,tools/ia_timing.py" --dtype f64 -- python tools/ia_timing.py --points 4096 --refl 0.1 --dsym 3 ;;
+    ialong) prof ia_long "$FWD,tools/ia_timing.py" --dtype f64 -- python tools/ia_timing.py --points 4096 --refl 0.4 --dsym 3 ;;
     c5)     prof c5 "$RAM" --dtype f64 --points-per-run 4000 --runs 2 -- python bench.py --config C5 --total-points 4000 --steps 1 --warmup 1 ;;
   esac
 done
