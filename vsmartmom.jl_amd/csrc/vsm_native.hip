@@ -432,8 +432,16 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     }
     VSM_IA_STAMP(2);
     const int K = ninv_order(nrm, status);                       // [E2] -> P, barrier (c), series
-    if (K == 7) ninvert7<RT, KS>(E, Gs, n, cx, p);
-    else ninvert<RT, KS, IO::REF>(K, E, Gs, n, cx, p);
+    // (the standalone kernel takes the usual order 7 in four products; in the layer kernel that costs a strip parked in scratch
+    //  across them -- 48 spilled VGPRs, + 5 % HBM traffic -- for + 0.5 %: it keeps Horner's rule)
+    bool done = false;
+    if constexpr (IO::REF) {
+      if (K == 7) {
+        ninvert7<RT, KS>(E, Gs, n, cx, p);
+        done = true;
+      }
+    }
+    if (!done) ninvert<RT, KS, IO::REF>(K, E, Gs, n, cx, p);
     VSM_IA_STAMP(3);
   }
   if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))

@@ -410,29 +410,75 @@ __device__ __forceinline__ void load_global128(bstrip<RT>& s, const double* __re
 
 // The same from / to FP32 arrays (the reference's Float32 runs on these kernels: storage in single, arithmetic in double -- the
 // FP64 MFMA rate of these shapes is above what the FP32 operator chains reach)
+// 4 x 4 transposition of (register r, 16-lane row q) in two swap stages (v_permlane32_swap on (r0, r2), (r1, r3), then
+// v_permlane16_swap on (r0, r1), (r2, r3); tools/permlane_probe.hip): X[r][q] -> X[q][r].  With r_r = accumulator register r (row
+// q + 4 r of the tile in lane-row q) it leaves lane-row q with the four CONSECUTIVE rows 4 q .. 4 q + 3 -- one 16-byte access per
+// row tile and lane for single-precision arrays, 16 columns x 64 contiguous bytes per instruction instead of sixteen 16-byte
+// pieces per request and four requests.  Its own inverse.
+typedef float f4u_t __attribute__((ext_vector_type(4), aligned(4)));   // 16 bytes, 4-byte aligned (any N)
+__device__ __forceinline__ void transpose4_f32(float& r0, float& r1, float& r2, float& r3) {
+  const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(r0), __float_as_uint(r2), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1), __float_as_uint(r3), false, false);
+  const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+  const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+  r0 = __uint_as_float(c[0]);
+  r1 = __uint_as_float(c[1]);
+  r2 = __uint_as_float(d[0]);
+  r3 = __uint_as_float(d[1]);
+}
 template <int RT>
 __device__ __forceinline__ void load_global128(bstrip<RT>& s, const float* g, int N, const bpos<RT>& p) {
   const bool cok = p.col < N;
-  const float* gc = g + (long long)N * min(p.col, N - 1);
+  const float* gc = g + (long long)N * min(p.col, N - 1) + 4 * p.kq;
 #pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      const float v = gc[min(row, N - 1)];
-      s.v[ta][r] = (row < N && cok) ? (double)v : 0.0;
+  for (int ta = 0; ta < RT; ++ta) {
+    const int r0 = 16 * ta + 4 * p.kq;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (ta < RT - 1 || r0 + 3 < N) {     // (N > 16 (RT - 1): the rows of the tiles before the last exist)
+      const f4u_t t = *reinterpret_cast<const f4u_t*>(gc + 16 * ta);
+      v0 = t.x;
+      v1 = t.y;
+      v2 = t.z;
+      v3 = t.w;
+    } else {
+      if (r0 < N) v0 = gc[16 * ta];
+      if (r0 + 1 < N) v1 = gc[16 * ta + 1];
+      if (r0 + 2 < N) v2 = gc[16 * ta + 2];
     }
+    v0 = cok ? v0 : 0.f;
+    v1 = cok ? v1 : 0.f;
+    v2 = cok ? v2 : 0.f;
+    v3 = cok ? v3 : 0.f;
+    transpose4_f32(v0, v1, v2, v3);
+    s.v[ta][0] = (double)v0;
+    s.v[ta][1] = (double)v1;
+    s.v[ta][2] = (double)v2;
+    s.v[ta][3] = (double)v3;
+  }
 }
 template <int RT>
 __device__ __forceinline__ void store_global128(float* g, const bstrip<RT>& s, int N, const bpos<RT>& p) {
-  float* gc = g + (long long)N * min(p.col, N - 1);
+  float* gc = g + (long long)N * min(p.col, N - 1) + 4 * p.kq;
 #pragma unroll
-  for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = p.row(ta, r);
-      if (row < N && p.col < N) gc[row] = (float)s.v[ta][r];
+  for (int ta = 0; ta < RT; ++ta) {
+    float v0 = (float)s.v[ta][0], v1 = (float)s.v[ta][1], v2 = (float)s.v[ta][2], v3 = (float)s.v[ta][3];
+    transpose4_f32(v0, v1, v2, v3);
+    const int r0 = 16 * ta + 4 * p.kq;
+    if (p.col < N) {
+      if (ta < RT - 1 || r0 + 3 < N) {
+        f4u_t t;
+        t.x = v0;
+        t.y = v1;
+        t.z = v2;
+        t.w = v3;
+        *reinterpret_cast<f4u_t*>(gc + 16 * ta) = t;
+      } else {
+        if (r0 < N) gc[16 * ta] = v0;
+        if (r0 + 1 < N) gc[16 * ta + 1] = v1;
+        if (r0 + 2 < N) gc[16 * ta + 2] = v2;
+      }
     }
+  }
 }
 
 // global column-major N x N -> the A-form (zero padded): a wave takes whole columns, lane = row (512-byte requests; the 16-lane
