@@ -189,7 +189,6 @@ struct nio_ref {
   double* m[4];          // R-+, R+-, T++, T-- of this point (NC_* order)
   double* J[2];          // J0+, J0-
   const double* a[4];    // the added layer's r-+, r+-, t++, t-- of this point (r+- / t-- only read when it is not D-symmetric)
-  bool raw;              // R+- / T-- arrive as raw images in Q / P (k_ia_native requested them by DMA)
   double jpre[2];        // J0+[tid], J0-[tid], requested at the entry of the kernel
   static constexpr bool REF = true;
   // Direct accesses in the accumulator layout.  A lane holds rows kq + 4 r of a row tile: 8-byte accesses would touch 32-byte
@@ -377,23 +376,19 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   nstrip<RT> A2;
   {
     nstrip<RT> A1;
-    bool direct = true;
-    if constexpr (IO::REF) {
-      if (io.raw) {
-        direct = false;
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        io.ld_raw(A1, sm.Q, p);
-        io.ld_raw(A2, sm.P, p);
-        __syncthreads();
-      }
-    }
-    if (direct) {
+    if constexpr (IO::REF) {              // their raw images are on the way to Q / P (k_ia_native)
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      io.ld_raw(A1, sm.Q, p);
+      io.ld_raw(A2, sm.P, p);
+      __syncthreads();
+      nstore(dP, A1, p);                  // ([T--] goes to Q after the products of [R+-]: it is first read after barrier (c))
+    } else {
       io.ld(A1, NC_RPM, p);
-      io.ld(A2, NC_TMM, p);             // (REF: in flight under the products of [R+-]; [T--] is first read after barrier (c))
+      io.ld(A2, NC_TMM, p);
+      nstore(dP, A1, p);
+      nstore(dQ, A2, p);
     }
-    nstore(dP, A1, p);
-    if constexpr (!IO::REF) nstore(dQ, A2, p);
   }
   if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
 #pragma unroll
@@ -488,29 +483,22 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nmm<RT, KS, true>(Y, dQ, Gs, p);      // Y = S G2 = T01 r-+
     VSM_IA_STAMP(6);
     __syncthreads();                      // (f): [t++], [S] no longer read
-    bool direct = true;
-    if constexpr (IO::REF) {
-      if (io.raw) {                       // T++ as a raw image through P (its lines wait in the L2), before [T21] moves in
-        direct = false;
-        io.dma_raw(io.m[NC_TPP], sm.P, p);
-        nstore(dQ, Y, p);                 // [Y]   -> Q
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        io.ld_raw(Tpp, sm.P, p);
-        __syncthreads();
-        nstore(dP, X, p);                 // [T21] -> P
-      }
-    }
-    if (direct) {
+    if constexpr (IO::REF) {              // T++ as a raw image through P (its lines wait in the L2), before [T21] moves in
+      io.dma_raw(io.m[NC_TPP], sm.P, p);
+      nstore(dQ, Y, p);                   // [Y]   -> Q
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      io.ld_raw(Tpp, sm.P, p);
+      __syncthreads();
+      nstore(dP, X, p);                   // [T21] -> P
+    } else {
       nstore(dP, X, p);                   // [T21] -> P
       nstore(dQ, Y, p);                   // [Y]   -> Q
     }
   }
   __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
   nstrip<RT> Rmp;
-  if constexpr (IO::REF) {
-    if (!io.raw) io.ld(Tpp, NC_TPP, p);
-  } else {
+  if constexpr (!IO::REF) {
     io.ld(Tpp, NC_TPP, p);
     io.ld(Rmp, NC_RMP, p);
   }
@@ -616,31 +604,22 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N
   io.jpre[0] = in ? io.J[0][tid] : 0.0;
   io.jpre[1] = in ? io.J[1][tid] : 0.0;
   nstrip<RT> r_s, t_s;
-  io.raw = true;
-  if (io.raw) {
-    io.dma_raw(io.a[NC_RMP], sm.P, p);
-    io.dma_raw(io.a[NC_TPP], sm.Q, p);
-    io.prefetch(NC_RPM, sm.vec[7]);
-    io.prefetch(NC_TMM, sm.vec[7]);
-  }
+  io.dma_raw(io.a[NC_RMP], sm.P, p);
+  io.dma_raw(io.a[NC_TPP], sm.Q, p);
+  io.prefetch(NC_RPM, sm.vec[7]);
+  io.prefetch(NC_TMM, sm.vec[7]);
   if (tid < G::NP) {
     sm.vec[0][tid] = j0p;
     sm.vec[1][tid] = j0m;
     sm.usg[tid] = (DSYM && (tid % ns) >= 2) ? -1.0 : 1.0;
   }
-  if (io.raw) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    io.ld_raw(r_s, sm.P, p);
-    io.ld_raw(t_s, sm.Q, p);
-    __syncthreads();
-    io.dma_raw(io.m[NC_RPM], sm.Q, p);   // (nia_body waits for them)
-    io.dma_raw(io.m[NC_TMM], sm.P, p);
-  } else {
-    io.ld_added(r_s, NC_RMP, p);
-    io.ld_added(t_s, NC_TPP, p);
-    __syncthreads();
-  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  io.ld_raw(r_s, sm.P, p);
+  io.ld_raw(t_s, sm.Q, p);
+  __syncthreads();
+  io.dma_raw(io.m[NC_RPM], sm.Q, p);   // (nia_body waits for them)
+  io.dma_raw(io.m[NC_TMM], sm.P, p);
 #ifdef VSM_IA_PHASES
   __builtin_amdgcn_s_waitcnt(0);
   VSM_IA_STAMP(12);
