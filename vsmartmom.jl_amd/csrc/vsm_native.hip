@@ -169,20 +169,168 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Where the interaction finds the composite: the native records of a run (k_layer_native), or the reference's [N,N,S] arrays
-// (k_ia_native: vsm_interaction_f64 for N <= 64 -- the surface interaction of every run, callers of the operator API).
+// interaction_helper!(::ScatteringInterface_11) (interaction.jl:207-266) on the run's native records: the layer kernel's copy.  The
+// steps are those of nia_body below (which documents them) in the plain order -- every composite strip is a coalesced 16-byte
+// record here and nothing of what nia_body does about exposed loads pays (each measured: DESIGN.md 4.0b).  Kept as a function of
+// its own: routed through nia_body's I/O policy the same statements came out with 14 spilled VGPRs instead of 8.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int RT>
-struct nio_native {
-  double* comp;
-  static constexpr bool REF = false;
-  __device__ __forceinline__ void ld(nstrip<RT>& x, int which, const npos<RT>& p) const { nld_native(x, comp + which * ngeo<RT>::AF, p); }
-  __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const { nst_native(comp + which * ngeo<RT>::AF, x, p); }
-  __device__ __forceinline__ double ldJ(int pm, int i) const { return comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i]; }
-  __device__ __forceinline__ void stJ(int pm, int i, double v) const { comp[4 * ngeo<RT>::AF + pm * ngeo<RT>::NP + i] = v; }
-  __device__ __forceinline__ void ld_added(nstrip<RT>&, int, const npos<RT>&) const {}
-  __device__ __forceinline__ void prefetch(int, double*) const {}   // (measured in the layer kernel: -0.4 %; its loads are not exposed)
-};
+template <int RT, int KS>
+__device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, npos<RT>& p, int n, double* __restrict__ comp, nstrip<RT>& r_s,
+                                         nstrip<RT>& t_s, int* status) {
+  using G = ngeo<RT>;
+  constexpr unsigned dP = 0, dQ = G::AF * 8;
+  double* vjp = sm.vec[0];
+  double* vjm = sm.vec[1];
+  double* vJp = sm.vec[2];
+  double* vJm = sm.vec[3];
+  double* vs = sm.vec[4];
+  double* vz = sm.vec[5];
+  const int tid = threadIdx.x;
+  double* R_mp = comp + NC_RMP * G::AF;
+  double* R_pm = comp + NC_RPM * G::AF;
+  double* T_pp = comp + NC_TPP * G::AF;
+  double* T_mm = comp + NC_TMM * G::AF;
+  double* J0_p = comp + 4 * G::AF;
+  double* J0_m = J0_p + G::NP;
+  constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
+  constexpr bool RID = c2 < G::NP;
+  const bool own_wave = RID && p.wave == (c1 >> 4);
+  const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
+  int slot = 0;
+  const ndpar<RT> dp(sm.usg, p);
+  const ninv_ctx cx{dP, sm.P, sm.gjs, status};
+  // ---- stage: composite vectors, [R+-] -> P, [T--] -> Q ---------------------------------------------------------------------
+  if (tid < G::NP) {
+    vJp[tid] = J0_p[tid];
+    vJm[tid] = J0_m[tid];
+  }
+  nstrip<RT> Z, Gs;
+  {
+    nstrip<RT> A1, A2;
+    nld_native(A1, R_pm, p);
+    nld_native(A2, T_mm, p);
+    nstore(dP, A1, p);
+    nstore(dQ, A2, p);
+  }
+  if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r_s.v[ta][r] = laneB ? vjm[p.row(ta, r)] : r_s.v[ta][r];
+  }
+  ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
+  __syncthreads();                                                                                       // (a)
+  if constexpr (!RID) {   // R+- j0- , T-- j0-
+    nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);
+    nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);
+  }
+  {
+    nstrip<RT> E;
+    nmm2<RT, KS, true, true>(E, Z, dP, r_s, t_s, p);
+    if (own_wave) {
+      double* zd = laneB ? vz : sm.vec[7];   // (the other lanes write to a dummy vector)
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          zd[row] = vJp[row] + E.v[ta][r];
+        }
+    }
+    const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
+    if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
+      if (tid < G::NP) {
+        vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
+        vs[tid] = nmv_sum<RT>(sm, RT, tid);
+      }
+    }
+    ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
+  }
+  nstrip<RT> V;
+  {
+    nstrip<RT> S;
+    nmm2<RT, KS, true, true>(S, V, dQ, r_s, t_s, p);   // (Q = [T--] has not been touched since (a))
+    if (own_wave) {
+      double* sd = laneB ? vs : sm.vec[7];
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sd[p.row(ta, r)] = S.v[ta][r];
+    }
+    // r_s <- r+- (the accumulator of the R+- update; its rider column is never used), t_s <- t++
+    ndsym(r_s, r_s, dp);
+    ndsym(t_s, t_s, dp);
+    __syncthreads();                      // (d): [E2] (series) and [T--] no longer read
+    nstore(dQ, S, p);                     // [S]   -> Q
+    nstore(dP, t_s, p);                   // [t++] -> P
+  }
+  __syncthreads();                        // (e)
+  {
+    nstrip<RT> X, Y;
+    nmm<RT, KS, true>(X, dP, Gs, p);      // T21 = t++ G2
+    nmm<RT, KS, true>(Y, dQ, Gs, p);      // Y = S G2 = T01 r-+
+    __syncthreads();                      // (f): [t++], [S] no longer read
+    nstore(dP, X, p);                     // [T21] -> P
+    nstore(dQ, Y, p);                     // [Y]   -> Q
+  }
+  __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
+  nstrip<RT> Tpp, Rmp;
+  nld_native(Tpp, T_pp, p);
+  nld_native(Rmp, R_mp, p);
+  __syncthreads();                        // (g)
+  if constexpr (!RID) {   // T21 z , Y z
+    nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
+    nmv_part(sm.Q, vz, 1.0, sm.mv[RT + p.wave], p);
+  }
+  if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
+        Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the native record keeps the rider column of the previous layer step)
+      }
+  }
+  {
+    nstrip<RT> acc;
+    nmm2<RT, KS, false, true>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
+    nst_native(R_pm, r_s, p);
+    nst_native(T_pp, acc, p);
+    if (laneA) {
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = p.row(ta, r);
+          J0_p[row] = vjp[row] + acc.v[ta][r];
+        }
+    }
+  }
+  nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
+  nst_native(R_mp, Rmp, p);
+  nst_native(T_mm, V, p);
+  if (laneA) {
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = p.row(ta, r);
+        J0_m[row] = vJm[row] + vs[row] + Rmp.v[ta][r];
+      }
+  }
+  if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
+    __syncthreads();
+    if (tid < G::NP) {
+      J0_p[tid] = vjp[tid] + nmv_sum<RT>(sm, 0, tid);
+      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// I/O of the standalone interaction (k_ia_native: vsm_interaction_f64 for N <= 64 -- the surface interaction of every run, the
+// callers of the operator API): the composite and the added layer in the reference's [N,N,S] arrays.
+// ---------------------------------------------------------------------------------------------------------------------------
 template <int RT>
 struct nio_ref {
   int N;
@@ -322,15 +470,16 @@ struct nio_ref {
 //   [R+- | T++] = [r+- | 0] + T21 [Z | T++]      A = P = [T21]   J0+ = j0+ + T21 z   (z rides in a spare column of T++)
 //   [R-+ | T--] = [R-+ | V] + Y [T++ | Z]        A = Q = [Y]     J0- = J0- + vs + Y z
 // Ten products and the inverse (order 7, the usual one: four products, ninvert7), at most six live strips.
-// IO says where the composite lives.  nio_native (the run's records): coalesced 16-byte accesses, the order above.  nio_ref (the
-// reference's [N,N,S] arrays, k_ia_native): a lane's accumulator elements are 32-byte pieces of 16 different lines there, and a
-// workgroup that waits for such loads has nothing to overlap them with -- stamped (tools/ia_phases.py), the loads were 55 % of a
-// workgroup's life.  So on that side (a) every matrix that is read while P or Q is free comes in as a raw image by LDS DMA (whole
-// lines, no registers) and the lanes pick their elements out of LDS: r-+ / t++, then R+- / T--, later T++ through P before [T21]
-// moves in; (b) what cannot (R-+: P and Q hold [T21], [Y]) is asked into the L2 a few products ahead by a one-dword-per-line DMA
-// into a junk vector and loaded as a late addend UNDER the last products, its request issued ahead of the stores of R+- / T++ (the
-// memory pipeline is in order); (c) the kernel's entry issues every request it can before its first wait.  0.34 -> 0.45 of the
-// FP64 MFMA peak at N = 60.  The layer kernel keeps the plain order: the same steps measured -0.4 ... -1.8 % there.
+// This is the body of the STANDALONE kernel (k_ia_native): the composite lives in the reference's [N,N,S] arrays (IO = nio_ref),
+// where a lane's accumulator elements are 32-byte pieces of 16 different lines, and a workgroup that waits for such loads has
+// nothing to overlap them with -- stamped (tools/ia_phases.py), the loads were 55 % of a workgroup's life.  So (a) every matrix
+// that is read while P or Q is free comes in as a raw image by LDS DMA (whole lines, no registers) and the lanes pick their
+// elements out of LDS: r-+ / t++, then R+- / T--, later T++ through P before [T21] moves in; (b) what cannot (R-+: P and Q hold
+// [T21], [Y]) is asked into the L2 a few products ahead by a one-dword-per-line DMA into a junk vector and loaded as a late addend
+// UNDER the last products, its request issued ahead of the stores of R+- / T++ (the memory pipeline is in order); (c) the kernel's
+// entry issues every request it can before its first wait; (d) direct accesses move 16 bytes (permlane pairs).  0.34 -> 0.46 of
+// the FP64 MFMA peak at N = 60.  The layer kernel keeps nia_body_native: the same steps measured -0.4 ... -1.8 %
+// on coalesced native records.
 #ifdef VSM_IA_PHASES   // diagnostic build (tools/ia_phases.py): cycles of wave 0 between the stamps, summed over the workgroups
 __device__ unsigned long long vsm_ia_phase_cycles[16];
 #define VSM_IA_STAMP(k)                                                  \
@@ -376,19 +525,12 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   nstrip<RT> A2;
   {
     nstrip<RT> A1;
-    if constexpr (IO::REF) {              // their raw images are on the way to Q / P (k_ia_native)
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      io.ld_raw(A1, sm.Q, p);
-      io.ld_raw(A2, sm.P, p);
-      __syncthreads();
-      nstore(dP, A1, p);                  // ([T--] goes to Q after the products of [R+-]: it is first read after barrier (c))
-    } else {
-      io.ld(A1, NC_RPM, p);
-      io.ld(A2, NC_TMM, p);
-      nstore(dP, A1, p);
-      nstore(dQ, A2, p);
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // their raw images are on the way to Q / P (k_ia_native)
+    __syncthreads();
+    io.ld_raw(A1, sm.Q, p);
+    io.ld_raw(A2, sm.P, p);
+    __syncthreads();
+    nstore(dP, A1, p);                    // ([T--] goes to Q after the products of [R+-]: it is first read after barrier (c))
   }
   if (own_wave) {  // j0- rides in the spare column c2 of r-+:  E2[:, c2] = R+- j0-, S[:, c2] = T-- j0-
 #pragma unroll
@@ -420,23 +562,15 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
         }
     }
     VSM_IA_STAMP(1);
-    if constexpr (IO::REF) nstore(dQ, A2, p);      // [T--] -> Q (free since the entry; read after barrier (c))
+    nstore(dQ, A2, p);                             // [T--] -> Q (free since the entry; read after barrier (c))
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
     if constexpr (!RID) {   // z = J0+ + R+- j0-
       if (tid < G::NP) vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
     }
     VSM_IA_STAMP(2);
     const int K = ninv_order(nrm, status);                       // [E2] -> P, barrier (c), series
-    // (the standalone kernel takes the usual order 7 in four products; in the layer kernel that costs a strip parked in scratch
-    //  across them -- 48 spilled VGPRs, + 5 % HBM traffic -- for + 0.5 %: it keeps Horner's rule)
-    bool done = false;
-    if constexpr (IO::REF) {
-      if (K == 7) {
-        ninvert7<RT, KS>(E, Gs, n, cx, p);
-        done = true;
-      }
-    }
-    if (!done) ninvert<RT, KS, IO::REF>(K, E, Gs, n, cx, p);
+    if (K == 7) ninvert7<RT, KS>(E, Gs, n, cx, p);               // (the usual order, in four products)
+    else ninvert<RT, KS, true>(K, E, Gs, n, cx, p);
     VSM_IA_STAMP(3);
   }
   if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))
@@ -483,25 +617,16 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nmm<RT, KS, true>(Y, dQ, Gs, p);      // Y = S G2 = T01 r-+
     VSM_IA_STAMP(6);
     __syncthreads();                      // (f): [t++], [S] no longer read
-    if constexpr (IO::REF) {              // T++ as a raw image through P (its lines wait in the L2), before [T21] moves in
-      io.dma_raw(io.m[NC_TPP], sm.P, p);
-      nstore(dQ, Y, p);                   // [Y]   -> Q
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();
-      io.ld_raw(Tpp, sm.P, p);
-      __syncthreads();
-      nstore(dP, X, p);                   // [T21] -> P
-    } else {
-      nstore(dP, X, p);                   // [T21] -> P
-      nstore(dQ, Y, p);                   // [Y]   -> Q
-    }
+    io.dma_raw(io.m[NC_TPP], sm.P, p);    // T++ as a raw image through P (its lines wait in the L2), before [T21] moves in
+    nstore(dQ, Y, p);                     // [Y]   -> Q
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    io.ld_raw(Tpp, sm.P, p);
+    __syncthreads();
+    nstore(dP, X, p);                     // [T21] -> P
   }
   __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
   nstrip<RT> Rmp;
-  if constexpr (!IO::REF) {
-    io.ld(Tpp, NC_TPP, p);
-    io.ld(Rmp, NC_RMP, p);
-  }
   __syncthreads();                        // (g)
   VSM_IA_STAMP(7);
   if constexpr (!RID) {   // T21 z , Y z
@@ -514,14 +639,13 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
-        if constexpr (!IO::REF) Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the record keeps the rider column of the previous step)
       }
   }
   {
     nstrip<RT> acc;
     nmm2<RT, KS, false, true>(r_s, acc, dP, Z, Tpp, p);   // R+- = r+- + T21 Z ; T++ = T21 T++
     VSM_IA_STAMP(8);
-    if constexpr (IO::REF) io.ld(Rmp, NC_RMP, p);   // (ahead of the stores in the memory pipeline; it arrives under the last products)
+    io.ld(Rmp, NC_RMP, p);                   // (ahead of the stores in the memory pipeline; it arrives under the last products)
     io.st(NC_RPM, r_s, p);
     io.st(NC_TPP, acc, p);
     if (laneA) {
@@ -535,7 +659,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     }
   }
   VSM_IA_STAMP(9);
-  if constexpr (IO::REF) {   // R-+ as a late addend (its strip was still on the way)
+  {   // R-+ as a late addend (its strip was still on the way)
     nstrip<RT> YT;
     nmm2<RT, KS, true, false>(YT, V, dQ, Tpp, Z, p);       // Y T++ ; T-- = V + Y Z
     VSM_IA_STAMP(10);
@@ -543,8 +667,6 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Rmp.v[ta][r] += YT.v[ta][r];
-  } else {
-    nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);                   // R-+ = R-+ + Y T++ ; T-- = V + Y Z
   }
   io.st(NC_RMP, Rmp, p);
   io.st(NC_TMM, V, p);
@@ -662,7 +784,7 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(in
     }
     return;
   }
-  nia_body<RT, KS, true>(sm, p, n, nio_native<RT>{comp}, r_s, t_s, status);
+  nia_body_native<RT, KS>(sm, p, n, comp, r_s, t_s, status);
 }
 
 }  // namespace
