@@ -57,7 +57,7 @@ CONFIGS = {
 def native_rt(n):
     """Row tiles of the native layer kernel of a block of n rows (vsm_native.hip rt_of)."""
     ks = (n + 3) // 4
-    return ks // 4 if (ks % 4 == 0 and ks >= 8) else (4 * ks + 2 + 15) // 16
+    return ks // 4 if (ks % 4 == 0 and ks >= 4) else (4 * ks + 2 + 15) // 16
 
 
 def stokes_groups(ns, coupling):

@@ -406,14 +406,14 @@ def test_native_run_diagonal_steps_of_rayleigh_layers_at_high_moments(vsm, arch,
     assert _rel(Rn, Rl) < 1e-10 and _rel(Tn, Tl) < 1e-10
 
 
-@pytest.mark.parametrize("N,ns", [(1, 1), (3, 3), (9, 3), (21, 3), (29, 1), (32, 4), (33, 3), (45, 3), (47, 1), (48, 4), (57, 3),
+@pytest.mark.parametrize("N,ns", [(1, 1), (3, 3), (9, 3), (13, 1), (16, 4), (21, 3), (29, 1), (32, 4), (33, 3), (45, 3), (47, 1), (48, 4), (57, 3),
                                   (60, 3), (61, 1), (63, 3), (64, 4)])
 @pytest.mark.parametrize("dsym", [False, True])
 @pytest.mark.parametrize("scale", [1.0, 4.0, 12.0])
 def test_standalone_interaction_native(vsm, arch, N, ns, dsym, scale):
     """interaction!(::ScatteringInterface_11) (interaction.jl:207-266) through vsm_interaction_f64 for N <= 64: k_ia_native, the
     native kernel body on the reference's [N,N,S] arrays -- every row-tile / k-step family (rider columns and the mat-vec source
-    path of N = 29..32, 45..48, 61..64), odd N (4-byte DMA pieces, 8-byte accesses) and even N (16-byte pieces, permlane pairs), an
+    path of N = 13..16, 29..32, 45..48, 61..64), odd N (4-byte DMA pieces, 8-byte accesses) and even N (16-byte pieces, permlane pairs), an
     added layer with all four matrices in memory and a D-symmetric one (r+- = D r-+ D, t-- = D t++ D derived in the kernel, as
     doubling! leaves it), at reflectances that take the order-7 inverse in four products, the long orders (out of line) and the
     pivoted Gauss-Jordan -- against the oracle."""

@@ -42,7 +42,7 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   double* rsg = sm.vec[3];   // row sign of apply_D
   const int tid = threadIdx.x;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;   // spare columns (>= n, never read as k) carry j0+ / j1- through a step
-  constexpr bool RID = c2 < G::NP;              // KS = 4 RT (n = 29..32, 45..48, 61..64): no spare column, the source vectors by VALU mat-vecs
+  constexpr bool RID = c2 < G::NP;              // KS = 4 RT (n = 13..16, 29..32, 45..48, 61..64): no spare column, the source vectors by VALU mat-vecs
   static_assert(RID || KS == 4 * RT, "no spare columns for the source vectors");
   const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2), laneAB = laneA || laneB;
@@ -801,9 +801,9 @@ VSM_NATIVE_DECL(VSM_NATIVE_KS)
 int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsigned uvmask, int gsz, int ndoubl, int toa,
                                                   const double* pre, const nlayer_comps& comps, int* status, hipStream_t st) {
   constexpr int KS = VSM_NATIVE_KS;
-  // KS = 8, 12, 16 (n = 29..32, 45..48, 61..64): KS / 4 row tiles without spare columns (mat-vec source path) instead of one row
+  // KS = 4, 8, 12, 16 (n = 13..16, 29..32, 45..48, 61..64): KS / 4 row tiles without spare columns (mat-vec source path) instead of one row
   // tile more for the two rider columns
-  constexpr int RT = (KS % 4 == 0 && KS >= 8) ? KS / 4 : (4 * KS + 2 + 15) / 16;
+  constexpr int RT = (KS % 4 == 0 && KS >= 4) ? KS / 4 : (4 * KS + 2 + 15) / 16;
   static_assert(RT >= 1 && RT <= 4, "n <= 64");
   using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
   auto kern = k_layer_native<RT, KS>;
@@ -816,7 +816,7 @@ int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsign
 int VSM_NCAT(launch_ia_native_, VSM_NATIVE_KS)(int N, int S, const composite<double>& c, const added<double>& a, int* status,
                                                hipStream_t st) {
   constexpr int KS = VSM_NATIVE_KS;
-  constexpr int RT = (KS % 4 == 0 && KS >= 8) ? KS / 4 : (4 * KS + 2 + 15) / 16;
+  constexpr int RT = (KS % 4 == 0 && KS >= 4) ? KS / 4 : (4 * KS + 2 + 15) / 16;
   using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
   auto kd = k_ia_native<RT, KS, true>;
   auto kg = k_ia_native<RT, KS, false>;
@@ -1223,7 +1223,7 @@ static int stokes_groups(int ns, int coupling, int grp_of[4], int groups[4][4], 
 }
 static inline int rt_of(int n) {   // (as the launchers of the layer kernels choose it)
   const int ks = (n + 3) / 4;
-  return (ks % 4 == 0 && ks >= 8) ? ks / 4 : (4 * ks + 2 + 15) / 16;
+  return (ks % 4 == 0 && ks >= 4) ? ks / 4 : (4 * ks + 2 + 15) / 16;
 }
 static inline size_t comp_stride_rt(int rt) { return (size_t)4 * (16 * rt) * (16 * rt) + 2 * 16 * rt; }
 static inline size_t pre_stride_rt(int rt) { return (size_t)2 * (16 * rt) * (16 * rt) + 3 * 16 * rt; }

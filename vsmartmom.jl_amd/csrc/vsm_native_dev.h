@@ -503,7 +503,7 @@ __device__ __forceinline__ int ninv_order(double nrm, int* status) {
   return nseries_order(nrm);
 }
 
-// Partial sums of the mat-vec source path (blocks without spare columns: 4 KS + 2 > 16 RT, i.e. n = 29..32, 45..48, 61..64): the
+// Partial sums of the mat-vec source path (blocks without spare columns: 4 KS + 2 > 16 RT, i.e. n = 13..16, 29..32, 45..48, 61..64): the
 // other blocks must not pay for them (three row tiles with rider columns sit exactly at four workgroups per CU).
 template <int RT, bool ON>
 struct nmv_slots {};
