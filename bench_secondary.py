@@ -11,8 +11,8 @@ configurations that fit one GPU, so that their figures are driver-timed and not 
           ~10 layers, ~100 spectral points): the WHOLE rt_run(model) call -- host model / optics, scene allocation, H2D, device
           pass, D2H (north_star: >= 10^4 spectral-points/s on quickstart-shaped atmospheres)
   IA      the interaction kernel in isolation: interaction!(::ScatteringInterface_11), N = 60 FP64, 10 240 points
-          (k_ia_strip<15>; north_star: >= 40 % MFMA utilisation in the interaction kernel -- inside the headline it is part of
-          the fused layer kernel); IA-long: the same at 4 x the reflectances (series orders >= 15: the out-of-line inverse)
+          (k_ia_native<4, 15>; north_star: >= 40 % MFMA utilisation in the interaction kernel -- inside the headline it is part
+          of the fused layer kernel); IA-long: the same at 4 x the reflectances (series orders >= 15: the out-of-line inverse)
   N112    forward run at the reference's VLIDORT case-A size (test/vlidort_baseline/cases/case_A_siewert2000.jl:29-50:
           IQUV, N = 112), 2 000 points, 10 layers: the k_dbl128 / k_ia128 family
 
@@ -243,7 +243,7 @@ def c1(vsm, torch, arch, points=100, layers=10, reps=20):
     e = _entry("C1", "quickstart-shaped (config/quickstart.yaml geometry: Stokes_I, nstreams=3, sza=vza=60 -> N=%d; Rayleigh, Lambertian "
                "0.15, %d layers, %d points, FP64, m=0..2); step = whole rt_run(model) incl. host model/optics, scene allocation, H2D, "
                "D2H; mean of %d calls" % (N, layers, points, reps), points, wall / reps, dev / reps, sc.flops_per_point(), "f64",
-               "k_elemental_doubling / k_interaction11 (LDS-resident, launch-latency bound)")
+               "k_layer_native<1, KS> per layer, k_ia_native for the surface (launch-latency bound)")
     e["north_star_target_points_per_s"] = 1e4
     del sc
     return e

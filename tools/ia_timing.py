@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The interaction kernel in isolation (north_star: ">= 40 % MFMA utilisation in the interaction kernel"): repeated
-interaction!(::ScatteringInterface_11) on random physical layers, N = 60 FP64 (k_ia_strip<15>) or N = 96 FP32
+interaction!(::ScatteringInterface_11) on random physical layers, N <= 64 FP64 (k_ia_native<RT, KS, DSYM>) or N = 96 FP32
 (k_ia_strip32<6>).  Wrap in tools/profile_any.py for the PMC MFMA-busy fraction.  Diagnostic; not the bench contract."""
 import argparse
 import os
