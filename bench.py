@@ -509,15 +509,16 @@ def tag_sources_hash(sources, command):
 def hbm_traffic_per_launch(kernels, cfg, S_local, running_hash=None):
     """HBM bytes per launch of `kernel` from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate
     rocprofv3 runs by tools/profile_any.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): the per-point
-    figure of profiles/<round>/<config>/summary.json (a 4096-point run of the same command) times the points of one launch.
+    figure of profiles/<round>/<config>/summary.json (the same command: C2 at the bench's own 10^4 points -- c2_10k -- else a
+    4096-point run) times the points of one launch.
     PMC counters cannot be read from inside the timed process, so this is the profiled value, not a live one -- and it is only
     quoted for the build it was taken on: a summary names the library it profiled (`library.source_hash`, csrc/Makefile), and a
     profile of another build gives (None, path, its hash, note).  Returns (bytes per launch | None, path, profile hash, note)."""
-    tag = {"C2": "c2", "C4": "c4"}.get(cfg.get("name"))
-    if tag is None:
+    tags = {"C2": ("c2_10k", "c2"), "C4": ("c4",)}.get(cfg.get("name"))   # (c2_10k: the PMC passes at the bench's own batch)
+    if tags is None:
         return None, None, None, "no committed PMC profile for this configuration"
     stale = None
-    for rnd in PROFILE_ROUNDS:
+    for rnd, tag in [(r, t) for r in PROFILE_ROUNDS for t in tags]:
         path = os.path.join(ROOT, "profiles", rnd, tag, "summary.json")
         try:
             prof = json.load(open(path))

@@ -4,7 +4,7 @@
 # (library.source_hash = vsm_build_id(), tools/source_hash.sh <commit> recomputes it from a tree) and the hash of the sources that
 # decide what ITS tag measures (tag_sources_hash): a tag whose committed summary carries the current hash is skipped, so an edit of
 # the Raman kernels does not re-take C2 / C4 / the linearized tags.
-# usage: tools/profile_r05.sh [c2 c2full c2aer c4 c4full lin lin112 fwd112 ia ialong c5 ...]
+# usage: tools/profile_r05.sh [c2 c2pmc10k c2full c2aer c4 c4full lin lin112 fwd112 ia ialong c5 ...]
 set -u
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 C="vsmartmom.jl_amd/csrc"
@@ -21,6 +21,7 @@ prof() {   # tag sources [profile_any options ...] -- command
 for w in "$@"; do
   case $w in
     c2)     prof c2 "$FWD" --dtype f64 -- python bench.py --points 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary ;;
+    c2pmc10k) prof c2_10k "$FWD" --dtype f64 -- python bench.py --points 10000 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary ;;
     c2full) prof c2_default "$FWD" --skip-pmc -- python bench.py --no-cpu-baseline --no-secondary ;;
     c2aer)  prof c2_aer "$FWD" --dtype f64 -- python bench.py --variant aerosol --points 4096 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary ;;
     c4)     prof c4 "$F32" --dtype f32 -- python bench.py --config C4 --points 4096 --steps 1 --warmup 0 --no-cpu-baseline ;;
