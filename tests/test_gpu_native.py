@@ -456,3 +456,60 @@ def test_standalone_interaction_native(vsm, arch, N, ns, dsym, scale):
         want = getattr(comp, k)
         assert np.all(np.isfinite(v)), k
         assert np.max(np.abs(v - want)) / np.max(np.abs(want)) < 1e-10, (k, N, dsym, scale)
+
+
+@pytest.mark.parametrize("N,ns,dsym", [(60, 3, True), (60, 3, False), (20, 4, False), (33, 3, True)])
+def test_standalone_interaction_arrays_on_8_byte_boundaries(vsm, arch, N, ns, dsym):
+    """vsm_interaction_f64 makes no alignment promise beyond the element type: composite and added-layer arrays that start on an
+    8-byte boundary only (views one element into a larger allocation) must take the 4-byte DMA pieces and the 8-byte-aligned pair
+    accesses of k_ia_native and give the oracle's result."""
+    FT = np.float64
+    rng = np.random.default_rng(7 * N + dsym)
+    S = 4
+    CR = vsm.CoreRT
+    dev = torch.device("cuda:0")
+
+    def refl(sc):
+        return (sc * rng.random((S, N, N)) / N).astype(FT)
+
+    def trans():
+        return (np.eye(N)[None] * rng.uniform(0.3, 0.95, (S, N, 1)) + 0.05 * rng.random((S, N, N)) / N).astype(FT)
+    comp = O.CompositeLayer(refl(0.1), refl(0.1), trans(), trans(), rng.random((S, N)), rng.random((S, N)))
+    r, t = refl(0.075), trans()
+    if dsym:
+        D = np.where(np.arange(N) % ns >= 2, -1.0, 1.0)
+        add = O.AddedLayer(r, t, D[None, :, None] * r * D[None, None, :], D[None, :, None] * t * D[None, None, :],
+                           rng.random((S, N)), rng.random((S, N)))
+    else:
+        add = O.AddedLayer(r, t, refl(0.075), trans(), rng.random((S, N)), rng.random((S, N)))
+    pc = CR.make_composite_layer(FT, arch, (N, N), S)
+    pa = CR.make_added_layer(FT, arch, (N, N), S, d_symmetric=ns if dsym else 0)
+
+    def odd_view(shape):   # a tensor of this shape whose first element sits 8 bytes into a 256-byte aligned allocation
+        n = int(np.prod(shape))
+        buf = torch.zeros(n + 1, dtype=torch.float64, device=dev)
+        v = buf[1:].view(*shape)
+        assert v.data_ptr() % 16 == 8
+        return v
+    conv_m = lambda x: CR.to_device_matrix(x, arch, FT)
+    for k in ("R_mp", "R_pm", "T_pp", "T_mm"):
+        v = odd_view((S, N, N))
+        v.copy_(conv_m(getattr(comp, k)))
+        setattr(pc, k, v)
+    for k in ("r_mp", "t_pp") if dsym else ("r_mp", "t_pp", "r_pm", "t_mm"):
+        v = odd_view((S, N, N))
+        v.copy_(conv_m(getattr(add, k)))
+        setattr(pa, k, v)
+    conv_v = vsm.Architectures.array_type(arch)
+    pc.J0_p.copy_(conv_v(comp.J0_p))
+    pc.J0_m.copy_(conv_v(comp.J0_m))
+    pa.j0_p.copy_(conv_v(add.j0_p))
+    pa.j0_m.copy_(conv_v(add.j0_m))
+    O.interaction("11", comp, add, FT)
+    CR.interaction_("11", pc, pa)
+    torch.cuda.synchronize()
+    f, h = CR.from_device_matrix, vsm.Architectures.to_host
+    got = dict(R_mp=f(pc.R_mp), R_pm=f(pc.R_pm), T_pp=f(pc.T_pp), T_mm=f(pc.T_mm), J0_p=h(pc.J0_p), J0_m=h(pc.J0_m))
+    for k, v in got.items():
+        want = getattr(comp, k)
+        assert np.max(np.abs(v - want)) / np.max(np.abs(want)) < 1e-10, (k, N, dsym)

@@ -338,9 +338,10 @@ struct nio_ref {
   double* J[2];          // J0+, J0-
   const double* a[4];    // the added layer's r-+, r+-, t++, t-- of this point (r+- / t-- only read when it is not D-symmetric)
   double jpre[2];        // J0+[tid], J0-[tid], requested at the entry of the kernel
+  bool al16;             // the matrices start on 16-byte boundaries (launcher: N even and every array 16-byte aligned)
   static constexpr bool REF = true;
   // Direct accesses in the accumulator layout.  A lane holds rows kq + 4 r of a row tile: 8-byte accesses would touch 32-byte
-  // pieces of 16 lines per instruction (measured: ~ 350 cycles of issue each while the memory pipeline is busy).  N even:
+  // pieces of 16 lines per instruction (measured: ~ 350 cycles of issue each while the memory pipeline is busy).
   // v_permlane16_swap trades the odd 16-lane rows of register r = 2h with the even ones of r = 2h + 1, which leaves lane-row kq
   // with the ADJACENT rows (4 (kq & 1) + 2 (kq >> 1), + 1) + 8 h of its column -- one 16-byte access, 64 contiguous bytes per
   // column and instruction, half the instructions.  (The swap is its own inverse: loads apply it after, stores before.)
@@ -351,60 +352,102 @@ struct nio_ref {
     a = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]);
     b = __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
   }
+  // (pair types: 16-byte aligned where the launcher found every matrix on a 16-byte boundary and N even -- one dwordx4 access;
+  //  8-byte aligned otherwise -- a column of an odd N, or a caller's array off a 16-byte boundary: still one request per pair)
+  typedef double npair16_t __attribute__((ext_vector_type(2)));
+  typedef double npair8_t __attribute__((ext_vector_type(2), aligned(8)));
+  template <typename PT>
+  __device__ __forceinline__ void ldg_even(nstrip<RT>& x, const double* __restrict__ gc, bool cok, int rb) const {
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)   // (N even: a pair never straddles the last row -- unconditional loads, clamped addresses)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = 16 * ta + 8 * h + rb;
+        const PT v = *reinterpret_cast<const PT*>(gc + min(row, N - 2));
+        const bool ok = cok && row < N;
+        double a = ok ? v.x : 0.0, b = ok ? v.y : 0.0;
+        swap16(a, b);
+        x.v[ta][2 * h] = a;
+        x.v[ta][2 * h + 1] = b;
+      }
+  }
   __device__ __forceinline__ void ldg(nstrip<RT>& x, const double* __restrict__ g, const npos<RT>& p) const {
     const bool cok = p.col < N;
+    const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
     const double* gc = g + (long long)N * min(p.col, N - 1);
+    if (al16) {
+      ldg_even<npair16_t>(x, gc, cok, rb);
+      return;
+    }
     if ((N & 1) == 0) {
-      const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
-#pragma unroll
-      for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int row = 16 * ta + 8 * h + rb;
-          const double2 v = *reinterpret_cast<const double2*>(gc + min(row, N - 2));
-          const bool ok = cok && row < N;
-          double a = ok ? v.x : 0.0, b = ok ? v.y : 0.0;
-          swap16(a, b);
-          x.v[ta][2 * h] = a;
-          x.v[ta][2 * h + 1] = b;
-        }
+      ldg_even<npair8_t>(x, gc, cok, rb);
       return;
     }
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = p.row(ta, r);
-        const double v = gc[min(row, N - 1)];
-        x.v[ta][r] = (cok && row < N) ? v : 0.0;
+      for (int h = 0; h < 2; ++h) {
+        const int row = 16 * ta + 8 * h + rb;
+        double a = 0.0, b = 0.0;
+        if (cok && row + 1 < N) {
+          const npair8_t v = *reinterpret_cast<const npair8_t*>(gc + row);
+          a = v.x;
+          b = v.y;
+        } else if (cok && row < N) {
+          a = gc[row];
+        }
+        swap16(a, b);
+        x.v[ta][2 * h] = a;
+        x.v[ta][2 * h + 1] = b;
       }
   }
   __device__ __forceinline__ void ld(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, m[which], p); }
   __device__ __forceinline__ void ld_added(nstrip<RT>& x, int which, const npos<RT>& p) const { ldg(x, a[which], p); }
-  __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const {
-    double* gc = m[which] + (long long)N * min(p.col, N - 1);
-    if ((N & 1) == 0) {
-      const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+  template <typename PT>
+  __device__ __forceinline__ void st_even(double* gc, const nstrip<RT>& x, bool cok, int rb) const {
 #pragma unroll
-      for (int ta = 0; ta < RT; ++ta)
+    for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          double a = x.v[ta][2 * h], b = x.v[ta][2 * h + 1];
-          swap16(a, b);
-          const int row = 16 * ta + 8 * h + rb;
-          if (p.col < N && row < N) *reinterpret_cast<double2*>(gc + row) = make_double2(a, b);
+      for (int h = 0; h < 2; ++h) {
+        double a = x.v[ta][2 * h], b = x.v[ta][2 * h + 1];
+        swap16(a, b);
+        const int row = 16 * ta + 8 * h + rb;
+        if (cok && row < N) {
+          PT v;
+          v.x = a;
+          v.y = b;
+          *reinterpret_cast<PT*>(gc + row) = v;
         }
+      }
+  }
+  __device__ __forceinline__ void st(int which, const nstrip<RT>& x, const npos<RT>& p) const {
+    const int rb = 4 * (p.kq & 1) + 2 * (p.kq >> 1);
+    double* gc = m[which] + (long long)N * min(p.col, N - 1);
+    const bool cok = p.col < N;
+    if (al16) {
+      st_even<npair16_t>(gc, x, cok, rb);
       return;
     }
-    if (p.col < N) {
-#pragma unroll
-      for (int ta = 0; ta < RT; ++ta)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = p.row(ta, r);
-          if (row < N) gc[row] = x.v[ta][r];
-        }
+    if ((N & 1) == 0) {
+      st_even<npair8_t>(gc, x, cok, rb);
+      return;
     }
+#pragma unroll
+    for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        double a = x.v[ta][2 * h], b = x.v[ta][2 * h + 1];
+        swap16(a, b);
+        const int row = 16 * ta + 8 * h + rb;
+        if (cok && row + 1 < N) {
+          npair8_t v;
+          v.x = a;
+          v.y = b;
+          *reinterpret_cast<npair8_t*>(gc + row) = v;
+        } else if (cok && row < N) {
+          gc[row] = a;
+        }
+      }
   }
   __device__ __forceinline__ double ldJ(int pm, int) const { return jpre[pm]; }   // (only ever asked for i = threadIdx.x)
   __device__ __forceinline__ void stJ(int pm, int i, double v) const {
@@ -413,7 +456,7 @@ struct nio_ref {
   // Whole matrix -> LDS as it lies in memory (column-major, leading dimension N) by LDS DMA: 1 KB per wave instruction, every
   // line fetched once; ld_raw then picks the lane's accumulator elements out of the image.  (N * N even: 16-B pieces.)
   __device__ __forceinline__ void dma_raw(const double* __restrict__ g, double* L, const npos<RT>& p) const {
-    if ((N & 1) == 0) {   // 16-B pieces: every matrix of the batch starts on a 16-B boundary
+    if (al16) {           // 16-B pieces: every matrix of the batch starts on a 16-B boundary (N even, the arrays 16-byte aligned)
       const int chunks = (N * N) >> 1;
       for (int c0 = 64 * p.wave; c0 < chunks; c0 += ngeo<RT>::NT) {
         if (c0 + p.lane < chunks)
@@ -695,8 +738,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
 
 // interaction!(::ScatteringInterface_11) on the reference's arrays (vsm_interaction_f64, N <= 64): one workgroup per point
 template <int RT, int KS, bool DSYM>
-__global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N, int ns, composite<double> c, added<double> a,
-                                                                            int* status) {
+__global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N, int ns, int al16, composite<double> c,
+                                                                            added<double> a, int* status) {
   using G = ngeo<RT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
@@ -706,6 +749,7 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N
   const int tid = threadIdx.x;
   nio_ref<RT> io;
   io.N = N;
+  io.al16 = al16 != 0;
   io.m[NC_RMP] = c.R_mp + s * NN;
   io.m[NC_RPM] = c.R_pm + s * NN;
   io.m[NC_TPP] = c.T_pp + s * NN;
@@ -823,10 +867,16 @@ int VSM_NCAT(launch_ia_native_, VSM_NATIVE_KS)(int N, int S, const composite<dou
   int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kd), sizeof(SM), "hipFuncSetAttribute(k_ia_native)");
   if (!prepared) prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kg), sizeof(SM), "hipFuncSetAttribute(k_ia_native general)");
   if (prepared) return prepared;
+  // 16-byte DMA pieces need every matrix of the batch on a 16-byte boundary: N even (a matrix is N N 8 bytes) and aligned arrays
+  unsigned long long bits = (unsigned long long)c.R_mp | (unsigned long long)c.R_pm | (unsigned long long)c.T_pp |
+                            (unsigned long long)c.T_mm | (unsigned long long)a.r_mp | (unsigned long long)a.t_pp |
+                            (unsigned long long)(a.mat_stride * 8);
+  if (!a.d_symmetric) bits |= (unsigned long long)a.r_pm | (unsigned long long)a.t_mm;
+  const int al16 = ((N & 1) == 0 && (bits & 15ull) == 0) ? 1 : 0;
   if (a.d_symmetric)   // (d_symmetric carries n_stokes)
-    hipLaunchKernelGGL(kd, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, a.d_symmetric, c, a, status);
+    hipLaunchKernelGGL(kd, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, a.d_symmetric, al16, c, a, status);
   else
-    hipLaunchKernelGGL(kg, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, 1, c, a, status);
+    hipLaunchKernelGGL(kg, dim3(S), dim3(ngeo<RT>::NT), sizeof(SM), st, N, 1, al16, c, a, status);
   VSM_LAUNCH_CHECK("k_ia_native");
   return VSM_OK;
 }
