@@ -12,8 +12,10 @@ in total over the GPUs), `--config C5`: configs[4] (rotational Raman, 2 10^4 poi
 starts its own N ranks (torch.distributed.run, one process per GPU over RCCL) or fails if N GPUs are not visible.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including `roofline` for the dominant
-kernel (the fused layer step k_layer_strip_mm with its elemental pre-pass; algorithmic flops / HIP-event time of the pair) and `cpu_baseline`
-(the oracle port timed on a bounded sample of the same workload).
+kernel (the native-layout layer step k_layer_native<4, 15> with its elemental pre-pass k_elemental_native<4, ...>; algorithmic flops /
+HIP-event time of the pair) and `cpu_baseline` (the oracle port timed on a bounded sample of the same workload, with `anchor`: the
+same port on the reference's published CPU shape).  `config.secondary` holds the other configurations and the two DROP-IN entries:
+the same C2 step issued in the call order of the reference's unpatched driver (rt_run.jl:383-453).
 """
 import argparse
 import json
@@ -474,25 +476,43 @@ def bench_c5(args, vsm, parallel, torch, rank, world, local):
                          "achieved": tf, "peak": PEAK_TFLOPS["f64"] * world, "unit": "TFLOP/s", "frac": tf / (PEAK_TFLOPS["f64"] * world),
                          "frac_executed_products": 3 * exe_m * pts / 1e12 / (PEAK_TFLOPS["f64"] * world),
                          "traffic": c5_traffic_per_point() and c5_traffic_per_point() * S_total,
+                         "traffic_source": c5_traffic_per_point(True)[1],
                          "traffic_note": "HBM bytes of one whole step (all kernels; FETCH_SIZE x 2 + WRITE_SIZE per point from "
-                                         "the newest profiles/r0N/c5/summary.json, a 4000-point run, x the points of this run)"}}))
+                                         "the newest profiles/rNN/c5/summary.json whose tag sources are unchanged, a 4000-point run, x "
+                                         "the points of this run)"}}))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 
-def c5_traffic_per_point():
-    """Whole-run HBM bytes per spectral point of the C5 workload from the newest committed PMC passes (profiles/r0N/c5/summary.json)."""
-    for rnd in ("r04", "r03"):
+PROFILE_ROUNDS = ("r06", "r05", "r04", "r03", "r02/final")
+
+
+def c5_traffic_per_point(with_source=False):
+    """Whole-run HBM bytes per spectral point of the C5 workload from the newest committed PMC passes (profiles/rNN/c5/summary.json)
+    -- quoted only while the sources that decide what that tag measures are what they were when it was taken (`tag_sources_hash`,
+    the guard of hbm_traffic_per_launch): a profile of other kernels gives None."""
+    for rnd in PROFILE_ROUNDS[:3]:
+        path = os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")
         try:
-            with open(os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")) as f:
-                return float(json.load(f)["hbm_bytes_per_point_whole_run"])
+            with open(path) as f:
+                prof = json.load(f)
+            val = float(prof["hbm_bytes_per_point_whole_run"])
         except (OSError, KeyError, ValueError):
             continue
-    return None
-
-
-PROFILE_ROUNDS = ("r05", "r04", "r03", "r02/final")
+        fresh = (prof.get("tag_sources") and prof.get("tag_sources_hash")
+                 and tag_sources_hash(prof["tag_sources"], prof["command"]) == prof["tag_sources_hash"])
+        if not fresh:
+            try:
+                import vsmartmom_jl_amd as vsm
+                fresh = (prof.get("library") or {}).get("source_hash") == vsm._lib.build_info()["source_hash"]
+            except Exception:
+                fresh = False
+        src = os.path.relpath(path, ROOT)
+        if not fresh:
+            return (None, src + " (stale: taken on other sources)") if with_source else None
+        return (val, src) if with_source else val
+    return (None, None) if with_source else None
 
 
 def tag_sources_hash(sources, command):
@@ -575,6 +595,34 @@ def host_cores():
     return max(1, n)
 
 
+def cpu_anchor(cores):
+    """the same C + OpenMP port on the ONE shape for which the reference publishes a CPU figure -- noRS rt_run of
+    test/test_parameters/Phase1b_RRS_761-764nm.yaml: 103 spectral points, 12 layers, Stokes_IQU, nstreams = 3 (N = 15), Float32,
+    0.304 s wall = 340 points/s on a 64-core EPYC 7H12 (dev_notes/phase5_headroom.md:7-14) -- so that the port's rate at C2 can be
+    placed against a number of the reference itself.  Synthetic optical depths of that shape (no HITRAN here); the port computes in
+    FP64 with ndoubl from the reference's Float32 rule (the 1024 eps(Float32) floor binds: fewer doublings than FP64)."""
+    from oracle import vsm_oracle as O, vsm_oracle_c as OC
+    S, L = 103, 12
+    tau_rayl, tau_abs = o2a_atmosphere(S, L)
+    mdl = O.build_model("IQU", 5, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279, albedo=0.15, m_max=2)
+    N = mdl.quad_points.Nquad * 3
+    nthr = min(cores, S)
+    OC.rt_run(mdl, nthreads=nthr, ndoubl_float_type=np.float32)
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        OC.rt_run(mdl, nthreads=nthr, ndoubl_float_type=np.float32)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": S / med, "unit": "spectral-points/s", "cores": nthr, "wall_s_median_of_5": med,
+            "shape": "noRS rt_run, %d points, %d layers, Stokes_IQU, nstreams=3 (N=%d), m=0..2, whole call incl. the numpy host optics" % (S, L, N),
+            "reference_published": {"value": 340.0, "wall_s": 0.304, "hardware": "AMD EPYC 7H12 64-core, Julia 1.12.5, Float32",
+                                    "source": "dev_notes/phase5_headroom.md:7-14"},
+            "note": "the port at the reference's own published CPU shape: the ratio value / 340 says how this box's %d cores and "
+                    "the C port compare with the Julia CPU path on 64 EPYC cores (a 103-point call is dominated by fixed costs on "
+                    "both sides)" % nthr}
+
+
 def cpu_baseline(cfg, n_per_core, L):
     """CPU baseline on a bounded sample of the same workload, on ALL host cores of the box.
 
@@ -606,7 +654,8 @@ def cpu_baseline(cfg, n_per_core, L):
         return {"value": n_sample / dt, "unit": "spectral-points/s", "cores": cores, "kind": "port",
                 "sample": "%d of the %d spectral points (evenly spaced, %d per core), all %d layers, m=0..2, C + OpenMP "
                           "restatement (oracle/vsm_oracle_c.c, gcc -O3 -march=x86-64-v3), %d threads over the spectral axis, "
-                          "%.1f s wall" % (n_sample, cfg["S"], n_per_core, L, cores, dt)}
+                          "%.1f s wall" % (n_sample, cfg["S"], n_per_core, L, cores, dt),
+                "anchor": cpu_anchor(cores)}
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     cores = min(cores, 64)

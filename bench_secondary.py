@@ -1,6 +1,9 @@
 """Secondary workloads of bench.py (`config.secondary` of the JSON line): one timed step each of the other BASELINE.json
 configurations that fit one GPU, so that their figures are driver-timed and not only builder-run (tools/*.py):
 
+  C2-dropin / C2-dropin-native   the headline's C2 step in the call order of the reference's unpatched driver (m outside, one
+          rt_kernel_ call per (m, iz) on ONE CompositeLayer): on the reference-layout kernels / with rt_kernel_'s per-composite
+          registry keeping the composite in native layout (the path julia/vSmartMOMROCmExt.jl's rt_kernel!(::noRS) takes)
   C4      forward, N = 96 FP32, 60 layers, 12 500 points (one GPU's share of configs[3])
   C2-aer  the SURVEY 8(d) aerosol variant of C2 (HG aerosol in the lowest 6 layers, per-point Z, m = 0..35), 10 000 points
   C2-lin  rt_run(model, lin_model, 0, 1, 1) on the C2 shape (1 gas column + albedo), 2 048 points; C2-lin-10k: 10 000 points
@@ -81,6 +84,52 @@ def c4(vsm, torch, arch, o2a, points=12500):
                "native FP64 kernels with FP32 storage, U as a diagonal step)")
     del scene
     return e
+
+
+def c2_dropin(vsm, torch, arch, o2a, native, points=10000):
+    """The headline's C2 step issued in the call order of the reference's UNPATCHED driver (rt_run.jl:383-470: `for m` outside
+    `for iz`, one rt_kernel! call per (m, iz) on ONE CompositeLayer, then create_surface_layer! / interaction! /
+    postprocessing_vza!) -- what julia/vSmartMOMROCmExt.jl is reached through; CoreRT.REFERENCE_ORDER makes Scene.run issue
+    exactly that sequence.  native = False: every layer step on the reference-layout composite (vsm_layer_forward: one Fourier
+    moment per launch, the round-4 kernel); native = True: rt_kernel_ keeps the composite in the kernels' strip layout between its
+    calls (the per-composite registry: a one-moment vsm_run created at the TOA call, exported lazily by the surface interaction)."""
+    L = 40
+    tau_rayl, tau_abs = o2a(points, L)
+    model = vsm.host_model.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.0279,
+                                             albedo=0.15, m_max=2)
+    CR = vsm.CoreRT
+    saved = (CR.REFERENCE_ORDER, CR.NATIVE_RUN, CR.NATIVE_DROPIN)
+    CR.REFERENCE_ORDER, CR.NATIVE_RUN, CR.NATIVE_DROPIN = True, bool(native), bool(native)
+    try:
+        scene = CR.prepare_scene(model)
+        calls = []
+        orig = CR._rt_kernel_native
+        CR._rt_kernel_native = lambda *a: (calls.append(orig(*a)), calls[-1])[1]
+
+        def step():
+            scene.upload()
+            scene.prepare()
+            R, T = scene.run()
+            return R.cpu(), T.cpu()
+        try:
+            wall, dev, _ = _timed(torch, step)
+        finally:
+            CR._rt_kernel_native = orig
+        vsm._lib.check_device_status("C2-dropin")
+        e = _entry("C2-dropin-native" if native else "C2-dropin",
+                   "the headline's C2 step (N=60 FP64, 40 layers, m=0..2, %d points; H2D + device optics + run + D2H) in the call order of "
+                   "the reference's unpatched driver: for m: for iz: rt_kernel!(..., composite_layer, ...) -- %s" %
+                   (points, "the composite kept in native layout by rt_kernel_'s per-composite registry (vsm_run_create at the TOA "
+                    "call, one vsm_run_layer per call, lazy vsm_run_export by the surface interaction)" if native else
+                    "every layer step on the reference-layout composite (vsm_layer_forward, one moment per launch)"),
+                   points, wall, dev, scene.flops_per_point(), "f64",
+                   "k_layer_native<4, 15> (m = 1, 2), k_layer_native<3, 10> (m = 0)" if native else "k_layer_strip_mm<15>")
+        e["rt_kernel_calls_on_the_native_copy"] = int(sum(calls) // 2)     # (warm-up + timed step)
+        e["rt_kernel_calls"] = 3 * L
+        del scene
+        return e
+    finally:
+        CR.REFERENCE_ORDER, CR.NATIVE_RUN, CR.NATIVE_DROPIN = saved
 
 
 def c2_lin(vsm, torch, arch, o2a, points=2048, name="C2-lin"):   # (2048: 24 full rounds of 256 single-workgroup CUs per layer launch)
@@ -213,14 +262,11 @@ def c5(vsm, torch, arch, points=4000, lines=40, layers=12, name="C5"):
     e["frac_of_mfma_peak_executed_products"] = 3 * exe_m * S / wall / 1e12 / PEAK["f64"]
     e["peak_device_memory_gb"] = torch.cuda.max_memory_allocated() / 1e9
     e["hbm_bytes_per_step"] = None   # whole-step HBM bytes from the newest committed PMC passes of the same workload
-    for rnd in ("r05", "r04", "r03"):
-        try:
-            with open(os.path.join(ROOT, "profiles", rnd, "c5", "summary.json")) as f:
-                e["hbm_bytes_per_step"] = float(json.load(f)["hbm_bytes_per_point_whole_run"]) * S
-            e["hbm_bytes_source"] = "profiles/%s/c5/summary.json" % rnd
-            break
-        except (OSError, KeyError, ValueError):
-            continue
+    import bench
+    per_point, src = bench.c5_traffic_per_point(True)     # (newest committed PMC passes; None while their tag sources have changed)
+    if per_point is not None:
+        e["hbm_bytes_per_step"] = per_point * S
+    e["hbm_bytes_source"] = src
     return e
 
 
@@ -333,7 +379,8 @@ def n112(vsm, torch, arch, o2a, points=2000, layers=10):
 
 def run_all(vsm, torch, arch, o2a):
     out = []
-    for f in (lambda: c4(vsm, torch, arch, o2a), lambda: c2_aer(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a),
+    for f in (lambda: c2_dropin(vsm, torch, arch, o2a, False), lambda: c2_dropin(vsm, torch, arch, o2a, True),
+              lambda: c4(vsm, torch, arch, o2a), lambda: c2_aer(vsm, torch, arch, o2a), lambda: c2_lin(vsm, torch, arch, o2a),
               lambda: c2_lin(vsm, torch, arch, o2a, 10000, "C2-lin-10k"), lambda: c3_lin(vsm, torch, arch),
               lambda: c5(vsm, torch, arch), lambda: c5(vsm, torch, arch, 10000, name="C5-10k"), lambda: c1(vsm, torch, arch),
               lambda: ia_kernel(vsm, torch, arch), lambda: ia_kernel(vsm, torch, arch, scale=4.0, name="IA-long"),

@@ -78,7 +78,10 @@ int vsm_sync(void* stream);            /* Architectures.synchronize_if_gpu (Arch
  * flags_h[2] / flags_h[3] = spectral points k_dbl128 / k_ia128 processed (which kernel family a run landed on).  SYNCHRONOUS: waits for `stream` before it reads.  reset != 0 clears the words afterwards. */
 typedef enum vsm_devstat {
   VSM_DEVSTAT_SINGULAR = 1,    /* an exactly zero pivot: (I - R r) or (I - r r) is singular; the results of that point are not finite */
-  VSM_DEVSTAT_NONFINITE = 2    /* an operand of an in-kernel inverse was NaN / Inf */
+  VSM_DEVSTAT_NONFINITE = 2,   /* an operand of an in-kernel inverse was NaN / Inf */
+  VSM_DEVSTAT_MASK = 4         /* vsm_run_layer: a phase matrix has a non-zero element outside the declared Stokes coupling (the run's
+                                  `coupling`, or a block that `layer_coupling_h` called zero): that coupling was dropped, the results of
+                                  the run are not those of the dense walk */
 } vsm_devstat;
 int vsm_device_status(int* flags_h, int reset, void* stream);
 /* Frees the library-owned scratch of the CURRENT device (all streams) after a
@@ -578,7 +581,8 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
  * couple: bit 4 a + b set = some element Z[i, j] with i % n_stokes == a, j % n_stokes == b is non-zero.  Components that do not
  * couple run as independent sub-problems (for m = 0 every phase matrix has exactly zero (I,Q) x (U,V) blocks,
  * src/Scattering/compute_Z_matrices.jl:26-110: N = 60, n_stokes = 3 runs as 40 x 40 + 20 x 20) -- products with exact zeros are
- * not formed, results are those of the dense run.  The mask MUST cover every Z later handed to vsm_run_layer:
+ * not formed, results are those of the dense run.  The mask MUST cover every Z later handed to vsm_run_layer (every call checks
+ * the layer's matrices against the masks on the device and raises VSM_DEVSTAT_MASK, vsm_device_status, on a violation):
  * vsm_stokes_coupling_f64 computes one mask per matrix of a stack of `nblocks` matrices on the device (mask_d[nblocks]: DEVICE
  * ints, written asynchronously on `stream`); OR the masks of all scatterers of a moment.
  * `layer_coupling_h[nm]` of vsm_run_layer (NULL = the run's) is the same mask for the phase matrices of THIS layer (the OR over the

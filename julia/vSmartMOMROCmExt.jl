@@ -17,7 +17,7 @@ import vSmartMOM.CoreRT: batched_mul, batch_inv!, batch_solve!, batched_pointer_
     AddedLayer, CompositeLayer, AddedLayerLin, CompositeLayerLin, AddedLayerRS, CompositeLayerRS, noRS, RRS,
     LambertianSurfaceScalar, CoxMunkSurface, QuadPoints, CoreScatteringOpticalProperties,
     CoreScatteringOpticalPropertiesLin, ScatteringInterface_00, ScatteringInterface_01, ScatteringInterface_10,
-    ScatteringInterface_11, get_dtau_ndoubl, _get_n_water
+    ScatteringInterface_11, get_dtau_ndoubl, _get_n_water, expandOpticalProperties
 
 const libvsm = get(ENV, "VSMARTMOM_HIP_LIB", "libvsmartmom_hip.so")
 const FTs = Union{Float32,Float64}
@@ -57,6 +57,7 @@ function check_device_status(what = "rt_run")
     _chk(ccall((:vsm_device_status, libvsm), Cint, (Ptr{Cint}, Cint, PV), flags, 1, _stream()))
     (flags[1] & 1) != 0 && throw(LinearAlgebra.SingularException(0))
     (flags[1] & 2) != 0 && error("$what: NaN / Inf operand in an in-kernel inverse")
+    (flags[1] & 4) != 0 && error("$what: a phase matrix handed to vsm_run_layer couples Stokes components outside the declared mask (VSM_DEVSTAT_MASK)")
     flags
 end
 _p(A::ROCArray) = PV(pointer(A))
@@ -133,27 +134,153 @@ function doubling!(pol_type, SFI, expk::ROCArray{FT}, ndoubl::Int, a::AddedLayer
 end
 # interaction! (interaction.jl:278-285); `work` is required off the fused "11" path, so it is always supplied
 function interaction!(iface, SFI, c::CompositeLayer{FT}, a::AddedLayer{FT}, I_static) where {FT<:FTs}
-    N, _, S = size(c.R⁻⁺)
+    N, _, S = size(materialize!(c).R⁻⁺)                  # (the surface interaction of rt_run.jl:455-470 is the usual first consumer)
     @vsm("vsm_interaction", FT, (Cint, Cint, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV, PV), _tag(iface), N, S, _c(c), _c(a),
           _p(_work(FT, :vsm_interaction_work_elems, N, S)), _stream())
 end
 function copy_added_to_composite!(c::CompositeLayer{FT}, a::AddedLayer{FT}) where {FT<:FTs}
+    _drop_native!(c)
     @vsm("vsm_copy_added_to_composite", FT, (Cint, Cint, Ref{VsmAdded}, Ref{VsmComposite}, PV), size(c.R⁻⁺, 1), size(c.R⁻⁺, 3), _c(a), _c(c), _stream())
 end
+# ---- the native-layout run behind the reference's OWN driver: a per-CompositeLayer registry ---------------------------------------
+# rt_run.jl:383-453 loops `for m` outside `for iz` and hands rt_kernel! ONE CompositeLayer; nothing else reads that composite until
+# the surface interaction (rt_run.jl:455-470).  rt_kernel!(::noRS) therefore keeps it in the layer kernels' strip layout
+# (vsm_run_*: FP64 / FP32 storage, every block of coupled Stokes components <= 64 rows) from the TOA call -- where a one-moment run
+# is created for it -- to the first method of this extension that needs the reference's [N,N,S] arrays (interaction!,
+# copy_added_to_composite!, postprocessing_vza!: they call materialize! first).  No change to rt_run.jl.  The blocks of the run are
+# the connected Stokes components of the phase matrices seen so far (vsm_stokes_coupling on the layer's Z: at m = 0 no phase matrix
+# couples (I,Q) with (U,V), compute_Z_matrices.jl:26-110); a layer that couples two blocks re-opens the run under the wider mask
+# (export -> create -> import); vsm_run_layer checks every Z against the masks on the device (VSM_DEVSTAT_MASK).  The Python host
+# mirrors this registry line by line (vsmartmom.jl_amd/core_rt.py: _rt_kernel_native, CompositeLayer.materialize) and is what the
+# -m gpu tests and bench.py's C2-dropin-native entry drive, since no Julia exists in the build image.
+const NATIVE_DROPIN = Ref(true)
+mutable struct NativeSlot
+    handle::PV
+    q::Any                       # VsmQuad{FT} (the run keeps its mu / wt pointers: qp outlives the run)
+    m::Int
+    coupling::Cint
+    grp::Vector{Int}             # block of each Stokes component under `coupling`
+    F₀::Any                      # device copy of RS.F₀ (the reference keeps it on the host, rt_run.jl:369-373)
+end
+const _native = IdDict{Any,NativeSlot}()                 # CompositeLayer => its native copy
+const _native_ws = IdDict{Any,ROCArray{Float64,1}}()     # CompositeLayer => workspace (grow-only, reused from moment to moment)
+_dev(x::ROCArray) = x
+_dev(x::AbstractArray) = ROCArray(x)
+function _groups(ns::Int, mask::Integer)                 # the rule of vsm_run_create: connected components of the symmetrised mask
+    adj(a, b) = a == b || mask < 0 || (mask >> (4a + b)) & 1 == 1 || (mask >> (4b + a)) & 1 == 1
+    grp = fill(-1, ns); ng = 0
+    for a in 0:ns-1
+        grp[a+1] >= 0 && continue
+        grp[a+1] = ng; stack = [a]
+        while !isempty(stack)
+            x = pop!(stack)
+            for b in 0:ns-1
+                if adj(x, b) && grp[b+1] < 0
+                    grp[b+1] = ng; push!(stack, b)
+                end
+            end
+        end
+        ng += 1
+    end
+    grp
+end
+function _layer_coupling(p::CoreScatteringOpticalProperties, N::Int, n::Int, ::Type{FT}) where {FT<:FTs}
+    nb = size(p.Z⁺⁺, 3); mask = AMDGPU.zeros(Cint, nb); acc = Cint(0)
+    for b0 in 1:65535:nb                                  # (vsm_stokes_coupling: at most 65535 matrices per call)
+        b1 = min(nb, b0 + 65534); off = (b0 - 1) * N * N * sizeof(FT)
+        @vsm("vsm_stokes_coupling", FT, (Cint, Cint, Cint, PV, PV, PV, PV), N, n, b1 - b0 + 1, _p(p.Z⁺⁺) + off, _p(p.Z⁻⁺) + off,
+              PV(pointer(mask)) + (b0 - 1) * sizeof(Cint), _stream())
+    end
+    for v in Array(mask); acc |= v; end                   # (one small D2H; the reference's own rt_kernel! reads maximum(τ .* ϖ) per layer)
+    acc
+end
+function _native_open!(c::CompositeLayer{FT}, qp::QuadPoints, n::Int, m::Int, mask::Cint, F₀, import_arrays::Bool) where {FT<:FTs}
+    N, _, S = size(c.R⁻⁺)
+    ccall(_sym(:vsm_run_supported), Cint, (Cint, Cint, Cint), N, n, mask) == 1 || return false
+    cm = Cint[mask]; ms = Cint[m]
+    nbytes = ccall(_sym(:vsm_run_workspace_bytes), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, S, 1, cm)
+    ws = get(_native_ws, c, nothing)
+    if ws === nothing || sizeof(ws) < nbytes
+        ws = _native_ws[c] = ROCArray{Float64}(undef, max(2, cld(Int(nbytes), 8)))
+    end
+    q = _q(qp, n, FT); h = Ref{PV}(C_NULL)
+    @vsm("vsm_run_create", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Ptr{Cint}, Ptr{Cint}, PV, Csize_t, Ref{PV}), q, S, 1, ms, cm, _p(ws), nbytes, h)
+    import_arrays && @vsm("vsm_run_import", FT, (PV, Ref{VsmComposite}, PV), h[], _c(c), _stream())
+    _native[c] = NativeSlot(h[], q, m, mask, _groups(n, mask), F₀)
+    true
+end
+# the composite as the reference's arrays again: every method below that touches a CompositeLayer calls this first
+function materialize!(c::CompositeLayer{FT}) where {FT<:FTs}
+    slot = pop!(_native, c, nothing)
+    slot === nothing && return c
+    try
+        @vsm("vsm_run_export", FT, (PV, Ref{VsmComposite}, PV), slot.handle, _c(c), _stream())
+    finally
+        ccall(_sym(:vsm_run_destroy), Cint, (PV,), slot.handle)
+    end
+    c
+end
+function _drop_native!(c)
+    slot = pop!(_native, c, nothing)
+    slot === nothing || ccall(_sym(:vsm_run_destroy), Cint, (PV,), slot.handle)
+    nothing
+end
+# the scattering "11" / TOA branch on the native copy; false = not taken (the caller continues on the reference's arrays)
+function _rt_kernel_native!(RS::noRS{FT}, pol_type, c::CompositeLayer{FT}, p::CoreScatteringOpticalProperties, τ_sum::ROCArray, m::Int,
+                            qp::QuadPoints, iz::Int, dτ::ROCArray, ndoubl::Int) where {FT<:FTs}
+    N = size(c.R⁻⁺, 1); n = pol_type.n
+    lc = _layer_coupling(p, N, n, FT)
+    if iz == 1
+        _drop_native!(c)                                  # copy_added_to_composite! overwrites whatever the composite held
+        _native_open!(c, qp, n, m, lc, _dev(RS.F₀), false) || return false
+    end
+    slot = get(_native, c, nothing)
+    (slot === nothing || slot.m != m) && return false
+    g = slot.grp
+    if any((lc >> (4a + b)) & 1 == 1 && g[a+1] != g[b+1] for a in 0:n-1, b in 0:n-1)
+        wider = slot.coupling | lc; F₀ = slot.F₀
+        materialize!(c)
+        _native_open!(c, qp, n, m, wider, F₀, true) || return false
+        slot = _native[c]
+    end
+    zpp = PV[_p(p.Z⁺⁺)]; zmp = PV[_p(p.Z⁻⁺)]; lcv = Cint[lc]        # (bound to names: ccall roots its array arguments for the call)
+    @vsm("vsm_run_layer", FT, (PV, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, Cint, Ptr{Cint}, PV),
+          slot.handle, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(slot.F₀), 0, zpp, zmp, _ms(p.Z⁺⁺), C_NULL, iz == 1 ? 1 : 0, lcv, _stream())
+    true
+end
+# expandOpticalProperties (compEffectiveLayerProperties.jl:106-117) for this array type: a phase matrix that is the same for all
+# spectral points stays ONE N x N block on the device (every entry point takes a slice stride, 0 = shared: `_ms`), instead of nSpec
+# host-side copies and their H2D per layer and moment (2 N^2 nSpec sizeof(FT): 576 MB at N = 60, 10^4 points)
+const SHARE_Z = Ref(true)
+function expandOpticalProperties(in::CoreScatteringOpticalProperties, arr_type::Type{<:ROCArray})
+    (; τ, ϖ, Z⁺⁺, Z⁻⁺) = in
+    @assert length(τ) == length(ϖ) "τ and ϖ sizes need to match"
+    if size(Z⁺⁺, 3) == 1 && !SHARE_Z[]
+        Z⁺⁺ = repeat(Z⁺⁺, 1, 1, length(τ)); Z⁻⁺ = repeat(Z⁻⁺, 1, 1, length(τ))
+    end
+    @assert size(Z⁺⁺, 3) in (1, length(τ)) "Z and τ dimensions need to match"
+    CoreScatteringOpticalProperties(arr_type(τ), arr_type(ϖ), arr_type(Z⁺⁺), arr_type(Z⁻⁺))
+end
+
 # rt_kernel!(::noRS) (rt_kernel.jl:175-250): the scattering branch of a "11" / TOA layer is ONE call (elemental! + doubling! +
-# copy | interaction!); the other branches keep the reference's sequence, whose pieces are the methods above.
+# copy | interaction!) -- on the composite's native copy where the blocks fit (registry above), else on the reference's arrays
+# (vsm_layer_forward); the other branches keep the reference's sequence, whose pieces are the methods above.
 function rt_kernel!(RS::noRS{FT}, pol_type, SFI, a::AddedLayer{FT}, c::CompositeLayer{FT}, p::CoreScatteringOpticalProperties,
-                    iface, τ_sum::ROCArray, m, qp, I_static, arch, qp_μN, iz; workspace=nothing, prepared_sources=nothing,
+                    iface, τ_sum::ROCArray, m, qp, I_static, arch, qp_μN, iz; workspace=nothing, prepared_sources=CoreRT.NoSource(),
                     dτ_max_threshold=nothing, dτ_min_floor=nothing) where {FT<:FTs}
     scatter = maximum(Array(p.τ .* p.ϖ)) > 2eps(FT)
-    if scatter && (iz == 1 || iface isa ScatteringInterface_11)
+    # (per-source slots, e.g. :thermal: the reference's sequence -- elemental!, contribute!, doubling!, interaction! are methods here)
+    if scatter && (iz == 1 || iface isa ScatteringInterface_11) && isempty(a.j₀_by_src)
         dτ, ndoubl = get_dtau_ndoubl(p, qp; dτ_max_threshold, dτ_min_floor)
+        NATIVE_DROPIN[] && _rt_kernel_native!(RS, pol_type, c, p, τ_sum, Int(m), qp, Int(iz), dτ, Int(ndoubl)) && return nothing
+        materialize!(c)
         return @vsm("vsm_layer_forward", FT, (Ref{VsmQuad{FT}}, Cint, Cint, Cint, PV, PV, PV, PV, PV, PV, Clonglong, Cint, Ref{VsmComposite}, Ref{VsmAdded}, PV),
-                     _q(qp, pol_type.n, FT), length(τ_sum), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(RS.F₀), _p(p.Z⁺⁺), _p(p.Z⁻⁺),
+                     _q(qp, pol_type.n, FT), length(τ_sum), m, ndoubl, _p(dτ), _p(p.ϖ), _p(τ_sum), _p(_dev(RS.F₀)), _p(p.Z⁺⁺), _p(p.Z⁻⁺),
                      _ms(p.Z⁺⁺), iz == 1 ? 1 : 0, _c(c), _c(a), _stream())
     end
+    materialize!(c)
     invoke(rt_kernel!, Tuple{noRS, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any, Any}, RS, pol_type, SFI, a, c, p, iface,
-           τ_sum, m, qp, I_static, arch, qp_μN, iz; workspace, dτ_max_threshold, dτ_min_floor)
+           τ_sum, m, qp, I_static, arch, qp_μN, iz; workspace, prepared_sources, dτ_max_threshold, dτ_min_floor)
 end
 
 # All Fourier moments of a scattering "11" / TOA layer in ONE launch (vsm_layer_forward_multi): for a patched rt_run that walks
@@ -170,9 +297,10 @@ function rt_kernel_moments!(RS::noRS{FT}, pol_type, a::AddedLayer{FT}, cs::Vecto
           _ms(ps[1].Z⁺⁺), C_NULL, C_NULL, iz == 1 ? 1 : 0, comps, _c(a), _stream())
 end
 
-# The layer loop of rt_run (rt_run.jl:383-453) with the CompositeLayer in the layer kernels' own strip layout (vsm_run_*; FP64,
-# every block of coupled Stokes components <= 64 rows: vsm_run_supported; Float32 models: the _f32 entry points).  A patched rt_run that walks `for iz` outside
-# `for m` (every layer scattering, interface 11) replaces its per-layer rt_kernel_moments! calls by
+# Optional, for a driver that is willing to interchange its loops (NOT needed for the native layout: rt_kernel!(::noRS) above reaches
+# it through the per-composite registry in the reference's own call order).  The layer loop of rt_run (rt_run.jl:383-453) with the
+# CompositeLayers of SEVERAL moments in one run (vsm_run_*: one launch per layer and class of blocks for all of them): a rt_run
+# that walks `for iz` outside `for m` (every layer scattering, interface 11) replaces its per-layer rt_kernel_moments! calls by
 #     run = NativeRun(qp, pol_type, nSpec, ms, Zstacks)            # make_composite_layer of the moments ms
 #     for iz = 1:Nz;  rt_kernel!(run, ps_of_layer(iz), τ_sum[iz], RS.F₀, qp, iz);  end
 #     export!(run, cs)                                              # cs[i]: the reference's CompositeLayer of moment ms[i]
@@ -211,9 +339,12 @@ function rt_kernel!(run::NativeRun, ps::Vector, τ_sum::ROCArray{Float64}, F₀:
                     layer_coupling=nothing, dτ_max_threshold=nothing, dτ_min_floor=nothing)
     dτ, ndoubl = get_dtau_ndoubl(ps[1], qp; dτ_max_threshold, dτ_min_floor)
     zpp, zmp = [_p(p.Z⁺⁺) for p in ps], [_p(p.Z⁻⁺) for p in ps]
+    # (the converted mask is bound to a name and passed as an array: ccall roots its arguments for the call -- a bare
+    #  pointer(Cint.(layer_coupling)) would leave the temporary to the GC while the library reads it)
+    lc = layer_coupling === nothing ? Cint[] : Cint.(layer_coupling)
     _chk(ccall(_sym(:vsm_run_layer_f64), Cint, (PV, Cint, PV, PV, PV, PV, Cint, Ptr{PV}, Ptr{PV}, Clonglong, PV, Cint, Ptr{Cint}, PV),
                run.handle, ndoubl, _p(dτ), _p(ps[1].ϖ), _p(τ_sum), _p(F₀), 0, zpp, zmp, _ms(ps[1].Z⁺⁺), C_NULL, iz == 1 ? 1 : 0,
-               layer_coupling === nothing ? C_NULL : pointer(Cint.(layer_coupling)), _stream()))
+               isempty(lc) ? Ptr{Cint}(C_NULL) : lc, _stream()))
 end
 export!(run::NativeRun, cs::Vector{<:CompositeLayer{Float64}}) =
     _chk(ccall(_sym(:vsm_run_export_f64), Cint, (PV, Ptr{VsmComposite}, PV), run.handle, [_c(c) for c in cs], _stream()))
@@ -274,7 +405,7 @@ function apply_ss_correction!(R_SFI::ROCArray{FT,3}, s::CoxMunkSurface{FT}, pol_
 end
 # postprocessing_vza! noRS/SFI (postprocessing_vza.jl:23-94) on device-resident R_SFI / T_SFI: no per-moment D2H of J₀∓
 function postprocessing_vza!(::noRS, iμ₀, pol_type, c::CompositeLayer{FT}, vza, qp_μ, m, vaz, μ₀, weight, nSpec, SFI, R, R_SFI::ROCArray, T, T_SFI::ROCArray, ie...) where {FT<:FTs}
-    n = pol_type.n; nV = length(vza)
+    n = pol_type.n; nV = length(vza); materialize!(c)
     row0 = Cint[n * (vSmartMOM.CoreRT.nearest_point(qp_μ, cosd(v)) - 1) for v in vza]
     w = FT[weight * (k <= 2 ? cosd(m * vaz[v]) : sind(m * vaz[v])) for v in 1:nV, k in 1:n]
     @vsm("vsm_postprocess_vza", FT, (Cint, Cint, Cint, Cint, Ptr{Cint}, Ptr{FT}, PV, PV, PV, PV, PV), size(c.J₀⁻, 1), n, nSpec, nV,

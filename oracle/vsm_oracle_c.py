@@ -29,7 +29,7 @@ def lib():
     return _lib
 
 
-def rt_run(model: O.RTModel, nthreads: int = 0):
+def rt_run(model: O.RTModel, nthreads: int = 0, ndoubl_float_type=np.float64):
     """rt_run(model) -> (R_SFI, T_SFI) [nVZA, nStokes, S] for FP64 scenes with ONE scatterer (Rayleigh) + absorption over a
     scalar Lambertian surface whose layers all scatter -- the scenes of BASELINE configs C1 / C2 / C4."""
     if model.aerosol_optics or np.ndim(model.albedo) != 0:
@@ -44,7 +44,8 @@ def rt_run(model: O.RTModel, nthreads: int = 0):
         raise ValueError("every layer must scatter (ScatteringInterface_11)")
     tau = np.ascontiguousarray(np.stack([np.atleast_1d(lo.tau) for lo in lods], axis=1), dtype=np.float64)
     varpi = np.ascontiguousarray(np.stack([np.broadcast_to(lo.varpi, (S,)) for lo in lods], axis=1), dtype=np.float64)
-    nd = np.array([O.get_dtau_ndoubl(tau[:, l], varpi[:, l], qp, np.float64, model.numerics)[1] for l in range(L)], dtype=np.int32)
+    # (ndoubl_float_type: the float type whose doubling_number rule applies -- rt_kernel.jl:266-287; Float32 models double less)
+    nd = np.array([O.get_dtau_ndoubl(tau[:, l], varpi[:, l], qp, ndoubl_float_type, model.numerics)[1] for l in range(L)], dtype=np.int32)
     Zpp = np.zeros((M, N, N))
     Zmp = np.zeros((M, N, N))
     for m in range(M):

@@ -394,3 +394,32 @@ def test_scene_lin_graph_replay_follows_the_optics(vsm, arch):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(ref2, rep2))
     assert not torch.equal(rep[0], rep2[0])
+
+
+def test_scene_lin_step_reaches_the_m0_stokes_iq_subscene(vsm, arch):
+    """The stepping pattern (rebind model.tau_abs and scene.lin_model, then upload() / prepare() of the forward and of the linearized
+    scene) on a batch large enough for the m = 0 reduction (SceneLin.sub0: the moment m = 0 as a Stokes_IQ scene of the same model):
+    the sub-scene must re-derive its model from the parent's CURRENT one -- its constructor-time copy is a shallow snapshot -- so
+    that R, T, Rdot, Tdot after the step are those of a fresh scene on the new arrays, bit for bit, and differ from the old ones."""
+    rng = np.random.default_rng(14)
+    S, L = 70, 3
+    H = vsm.host_model
+    tau_rayl = np.tile(0.03 * np.ones(L), (S, 1))
+    ga = 10.0 ** rng.uniform(-2.5, -0.5, (S, L))
+    mk = lambda g: H.model_from_arrays(arch, "IQU", 11, 40.0, [30.0, 5.0], [0.0, 60.0], albedo=0.2, tau_rayl=tau_rayl, tau_abs=g,
+                                       depol=0.0279, m_max=2)
+    model = mk(ga)
+    scene = vsm.CoreRTLin.SceneLin(model, H.LinModel([ga]), 0, 1, 1)
+    assert scene.sub0 is not None
+    first = [t.clone() for t in scene.run()]
+    torch.cuda.synchronize()
+    gb = ga * (1.0 + 0.05 * rng.random((S, L)))          # small changes: the same ndoubl and interface tags
+    model.tau_abs = gb
+    scene.lin_model = H.LinModel([2.0 * gb])             # (another derivative array too: Rdot must follow it)
+    scene.fwd.upload(); scene.fwd.prepare(); scene.upload(); scene.prepare()
+    stepped = [t.clone() for t in scene.run()]
+    torch.cuda.synchronize()
+    fresh = vsm.CoreRTLin.SceneLin(mk(gb), H.LinModel([2.0 * gb]), 0, 1, 1).run()
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(fresh, stepped))
+    assert not torch.equal(first[0], stepped[0]) and not torch.equal(first[2], stepped[2])

@@ -513,3 +513,180 @@ def test_standalone_interaction_arrays_on_8_byte_boundaries(vsm, arch, N, ns, ds
     for k, v in got.items():
         want = getattr(comp, k)
         assert np.max(np.abs(v - want)) / np.max(np.abs(want)) < 1e-10, (k, N, dsym)
+
+
+# ---- the drop-in form: rt_kernel_ called in the reference driver's order on ONE CompositeLayer (per-composite registry) ----------
+def _spy_native(vsm, monkeypatch):
+    calls = []
+    orig = vsm.CoreRT._rt_kernel_native
+
+    def spy(comp, props, tau_sum, m, dq, iz, F0, dtau, nd):
+        ok = orig(comp, props, tau_sum, m, dq, iz, F0, dtau, nd)
+        calls.append((int(m), int(iz), bool(ok)))
+        return ok
+    monkeypatch.setattr(vsm.CoreRT, "_rt_kernel_native", spy)
+    return calls
+
+
+@pytest.mark.parametrize("pol,l_trunc,L,FT", [("IQU", 35, 3, np.float64), ("IQU", 21, 4, np.float64), ("IQUV", 21, 3, np.float64),
+                                               ("I", 55, 2, np.float64), ("IQU", 35, 3, np.float32), ("IQUV", 35, 2, np.float64)])
+def test_reference_call_order_reaches_the_native_run_through_rt_kernel(vsm, arch, monkeypatch, pol, l_trunc, L, FT):
+    """CoreRT.REFERENCE_ORDER: Scene.run issues exactly the call sequence of the unpatched driver (rt_run.jl:383-470: `for m` outside
+    `for iz`, rt_kernel! on ONE CompositeLayer, then create_surface_layer! / interaction! / postprocessing_vza!).  rt_kernel_ keeps
+    that composite in native layout from the TOA call on (a one-moment vsm_run per composite, NATIVE_DROPIN) and the first
+    consumer of its arrays exports it.  Results: the oracle's (1e-8; FP32 at the reference's FP32 gate), the layers-outside native
+    run's bits where the blocks are the same, the reference-layout walk's to rounding; the registry took every layer step of every
+    moment whose blocks fit (IQUV, N = 80: m = 0 only -- the dense moments stay on vsm_layer_forward)."""
+    H = vsm.host_model
+    rng = np.random.default_rng(61)
+    S = 9
+    tau_rayl = np.tile(np.linspace(0.02, 0.3, L), (S, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0.5, (S, L))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=tau_abs, depol=0.03, albedo=0.2, m_max=2)
+    model = H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], float_type=FT, **kw)
+    ns = model.polarization_type.n
+    N = model.quad_points.Nquad * ns
+    Ra, Ta = vsm.CoreRT.rt_run(model)                                  # layers outside moments, vsm_run_* from Scene.run
+    monkeypatch.setattr(vsm.CoreRT, "REFERENCE_ORDER", True)
+    calls = _spy_native(vsm, monkeypatch)
+    Rb, Tb = vsm.CoreRT.rt_run(model)
+    sc = vsm.CoreRT.prepare_scene(model)
+    fits = [max(bin(g).count("1") for g in _groups(ns, sc.coupling[m])) * (N // ns) <= 64 for m in range(3)]
+    assert [c for c in calls if c[2]] == [(m, iz, True) for m in range(3) if fits[m] for iz in range(1, L + 1)], calls
+    assert any(fits)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_DROPIN", False)
+    Rc, Tc = vsm.CoreRT.rt_run(model)                                  # the same order on the reference-layout kernels
+    om = O.build_model(pol, l_trunc, 40.0, [30.0, 10.0], [0.0, 75.0], **kw)
+    Ro, To = O.rt_run(om)
+    if FT == np.float64:
+        assert np.array_equal(Ra, Rb) and np.array_equal(Ta, Tb)
+        assert _rel(Rb, Rc) < 1e-10 and _rel(Tb, Tc) < 1e-10
+        assert _rel(Rb, Ro) < 1e-8 and _rel(Tb, To) < 1e-8, (_rel(Rb, Ro), _rel(Tb, To))
+    else:
+        assert _rel(Rb, Ro) < 1e-2 and _rel(Tb, To) < 1e-2 and _rel(Rb, Ra) < 1e-4
+
+
+def test_rt_kernel_registry_lazy_export_layer_by_layer(vsm, arch):
+    """rt_kernel_ called directly like the reference's driver does, reading the composite after EVERY layer: the first access
+    exports the native copy (CompositeLayer.materialize), the next rt_kernel_ call -- no longer at the TOA -- continues on the
+    reference's arrays; both ways the composite equals the oracle's layer by layer (rt_kernel.jl:175-250)."""
+    H, CR = vsm.host_model, vsm.CoreRT
+    rng = np.random.default_rng(67)
+    S, Nz = 4, 4
+    kw = dict(tau_rayl=np.tile(np.array([0.05, 0.1, 0.2, 0.3]), (S, 1)), tau_abs=10.0 ** rng.uniform(-3, 0, (S, Nz)), depol=0.03,
+              albedo=0.0, m_max=1)
+    model = H.model_from_arrays(arch, "IQU", 35, 40.0, [30.0], [0.0], **kw)
+    sc = CR.prepare_scene(model)
+    N, FT = sc.N, np.float64
+    om = O.build_model("IQU", 35, 40.0, [30.0], [0.0], **kw)
+    F0 = np.zeros((3, S))
+    F0[0] = 1.0
+    for im in (0, 1):
+        for peek_every in (1, 3, 99):        # export after every layer / once in the middle / only at the end
+            lods = O.construct_core_optical_properties(om, im)
+            ifaces, tau_sum_all = O.extract_effective_props(lods, FT)
+            added_o, comp_o = O.make_added_layer(FT, N, S), O.make_composite_layer(FT, N, S)
+            comp = CR.make_composite_layer(FT, arch, (N, N), S)
+            for t in comp._arr.values():
+                t.fill_(float("nan"))
+            exported = False
+            for iz in range(Nz):
+                ly = sc.moments[im]["layers"][iz]
+                CR.rt_kernel_(sc.pol, sc.added, comp, ly["props"], ly["iface"], ly["tau_sum"], im, sc.dq, arch, iz + 1, sc.F0, FT,
+                              model.numerics, dtau=ly["dtau"], ndoubl=ly["nd"])
+                O.rt_kernel(om.pol, added_o, comp_o, O.expand_optical_properties(lods[iz], FT), ifaces[iz],
+                            tau_sum_all[:, iz].astype(FT), im, om.quad_points, iz + 1, F0, FT)
+                assert (comp._native is not None) == (not exported), (iz, peek_every)   # native until somebody read the arrays
+                if (iz + 1) % peek_every == 0 or iz == Nz - 1:
+                    exported = True
+                    for name in ("R_mp", "R_pm", "T_pp", "T_mm"):
+                        got = CR.from_device_matrix(getattr(comp, name))
+                        assert _rel(got, getattr(comp_o, name)) < 1e-10, (im, iz, name)
+                    assert comp._native is None
+                    for name in ("J0_p", "J0_m"):
+                        got = vsm.Architectures.to_host(getattr(comp, name))
+                        assert _rel(got, np.asarray(getattr(comp_o, name)).reshape(S, N)) < 1e-10, (im, iz, name)
+    torch.cuda.synchronize()
+    vsm._lib.check_device_status("registry")
+
+
+def test_rt_kernel_registry_reopens_the_run_when_a_layer_couples_more(vsm, arch, monkeypatch):
+    """A column whose TOA layer holds only a Henyey-Greenstein aerosol (its phase matrix couples I with I alone: three one-component
+    blocks) above Rayleigh layers (I-Q coupled): the registry re-opens the run under the wider mask at the first Rayleigh layer
+    (export -> vsm_run_create -> vsm_run_import).  Same results as the layers-outside run (whose mask is the OR over the run's
+    scatterers from the start) and as the oracle."""
+    H = vsm.host_model
+    rng = np.random.default_rng(71)
+    S, L = 5, 3
+    tau_rayl = np.tile(np.array([0.0, 0.1, 0.2]), (S, 1))
+    kw = dict(tau_rayl=tau_rayl, tau_abs=10.0 ** rng.uniform(-3, -0.5, (S, L)), depol=0.03, albedo=0.1, m_max=3,
+              tau_aer=np.array([[0.3, 0.0, 0.0]]))
+    model = H.model_from_arrays(arch, "IQU", 21, 40.0, [30.0], [0.0],
+                                aerosol_optics=[H.AerosolOptics(H.GreekCoefs(**vars(O.hg_greek(0.6, 10))), 0.9, 0.0)], **kw)
+    Ra, Ta = vsm.CoreRT.rt_run(model)
+    opened = []
+    orig = vsm.CoreRT._native_open
+    monkeypatch.setattr(vsm.CoreRT, "_native_open", lambda comp, dq, m, mask, imp: (opened.append((m, mask, imp)), orig(comp, dq, m, mask, imp))[1])
+    monkeypatch.setattr(vsm.CoreRT, "REFERENCE_ORDER", True)
+    Rb, Tb = vsm.CoreRT.rt_run(model)
+    assert (0, 0x1, False) in opened and any(m == 0 and imp and mask & 0x12 for m, mask, imp in opened), opened
+    om = O.build_model("IQU", 21, 40.0, [30.0], [0.0], aerosols=[O.AerosolOptics(O.hg_greek(0.6, 10), 0.9, 0.0)], **kw)
+    Ro, To = O.rt_run(om)
+    assert _rel(Rb, Ra) < 1e-11 and _rel(Tb, Ta) < 1e-11, (_rel(Rb, Ra), _rel(Tb, Ta))
+    assert _rel(Rb, Ro) < 1e-8 and _rel(Tb, To) < 1e-8, (_rel(Rb, Ro), _rel(Tb, To))
+
+
+def test_run_layer_flags_a_phase_matrix_outside_the_declared_coupling(vsm, arch):
+    """VSM_DEVSTAT_MASK: vsm_run_layer checks the layer's phase matrices against the masks on the device.  A run created for the
+    blocks (I,Q) | U that is handed a Z with a non-zero (Q,U) element, and a layer whose `layer_coupling_h` calls the U block zero
+    while its Z has a U-U element, both raise the flag (vsm_device_status; check_device_status throws); the clean call does not."""
+    H, L, CR = vsm.host_model, vsm._lib.lib(), vsm.CoreRT
+    S = 3
+    kw = dict(tau_rayl=np.full((S, 2), 0.1), tau_abs=np.full((S, 2), 0.01), depol=0.03, albedo=0.1, m_max=1)
+    model = H.model_from_arrays(arch, "IQU", 11, 40.0, [30.0], [0.0], **kw)
+    sc = CR.prepare_scene(model)
+    N, ns = sc.N, 3
+    ly = sc.moments[0]["layers"][0]
+    p = ly["props"]
+    mask0 = int(sc.coupling[0])
+    assert mask0 == 0x33                    # Rayleigh at m = 0: I-Q coupled, U alone and -- its block being zero -- a diagonal step
+
+    def one_call(Zpp, Zmp, run_mask, layer_mask):
+        carr, marr = (C.c_int * 1)(run_mask), (C.c_int * 1)(0)
+        nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
+        ws = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda:0")
+        q = sc.dq.cstruct()
+        run = C.c_void_p()
+        vsm._lib.check(L.vsm_run_create_f64(C.byref(q), S, 1, marr, carr, C.c_void_p(ws.data_ptr()), nbytes, C.byref(run)))
+        try:
+            zpp, zmp = (C.c_void_p * 1)(Zpp.data_ptr()), (C.c_void_p * 1)(Zmp.data_ptr())
+            CR.run_layer_native_(run, 1, int(ly["nd"]), ly["dtau"], p.varpi, ly["tau_sum"], sc.F0, 0, zpp, zmp, 0, None, True,
+                                 (C.c_int * 1)(layer_mask))
+            torch.cuda.synchronize()
+        finally:
+            L.vsm_run_destroy(run)
+        flags = (C.c_int * 4)()
+        vsm._lib.check(L.vsm_device_status(flags, 1, None))
+        return flags[0]
+
+    assert one_call(p.Zpp, p.Zmp, mask0, mask0) == 0
+    Zbad = p.Zpp.clone()
+    Zbad[0, 2, 1] = 1e-3                     # element (i = 1 (Q), j = 2 (U)): couples the two blocks of the run
+    assert one_call(Zbad, p.Zmp, mask0, mask0) & 4
+    Zuu = p.Zmp.clone()
+    Zuu[0, 5, 2] = 1e-3                      # (i = 2 (U), j = 5 (U)): inside the U block, which layer_mask calls zero
+    assert one_call(p.Zpp, Zuu, mask0 | 0x400, mask0) & 4
+    assert one_call(p.Zpp, Zuu, mask0 | 0x400, mask0 | 0x400) == 0
+    # the Python host raises on the flag at the end of a run
+    zpp, zmp = (C.c_void_p * 1)(Zbad.data_ptr()), (C.c_void_p * 1)(p.Zmp.data_ptr())
+    carr = (C.c_int * 1)(mask0)
+    nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
+    ws = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda:0")
+    q = sc.dq.cstruct()
+    run = C.c_void_p()
+    vsm._lib.check(L.vsm_run_create_f64(C.byref(q), S, 1, (C.c_int * 1)(0), carr, C.c_void_p(ws.data_ptr()), nbytes, C.byref(run)))
+    CR.run_layer_native_(run, 1, int(ly["nd"]), ly["dtau"], p.varpi, ly["tau_sum"], sc.F0, 0, zpp, zmp, 0, None, True, carr)
+    torch.cuda.synchronize()
+    L.vsm_run_destroy(run)
+    with pytest.raises(vsm.VSMError, match="VSM_DEVSTAT_MASK"):
+        vsm._lib.check_device_status("mask test")

@@ -237,6 +237,9 @@ def check_device_status(what="rt_run"):
         raise VSMError("%s: singular matrix in an in-kernel inverse ((I - R r) or (I - r r) has an exactly zero pivot)" % what)
     if flags[0] & 2:
         raise VSMError("%s: NaN / Inf operand in an in-kernel inverse" % what)
+    if flags[0] & 4:
+        raise VSMError("%s: a phase matrix handed to vsm_run_layer has a non-zero element outside the declared Stokes coupling "
+                       "(VSM_DEVSTAT_MASK): the native run dropped that coupling" % what)
 
 
 def suffix(dtype) -> str:

@@ -39,6 +39,10 @@ MOMENT_BATCH_MAX = 24  # ... for small spectral batches: every moment of the run
 MOMENT_BATCHING = True  # False: Scene.run walks the Fourier moments one by one
 THERMAL_FUSION = True   # False: the `:thermal` slot at operator level (tools/thermal_timing.py)
 NATIVE_RUN = True       # False: the layer loop on the reference-layout CompositeLayer (vsm_layer_forward_multi) instead of vsm_run_*
+NATIVE_DROPIN = True    # rt_kernel_ keeps the CompositeLayer it is handed in the kernels' native layout between its calls (a per-
+#                         composite registry, exported lazily: the path of the reference's own driver order, rt_run.jl:383-453)
+REFERENCE_ORDER = False  # True: Scene.run walks `for m` outside `for iz`, one rt_kernel_ call per (m, iz) on ONE CompositeLayer --
+#                         exactly the call sequence of the unpatched rt_run.jl (what julia/vSmartMOMROCmExt.jl is reached through)
 
 
 def _require_gpu(arch):
@@ -182,14 +186,55 @@ class CompositeLayer:
     def __init__(self, FT, arch, N, nSpec):
         dev, dt = devi(arch), _torch_dtype(FT)
         z = lambda: torch.zeros((nSpec, N, N), dtype=dt, device=dev)
-        self.R_mp, self.R_pm, self.T_pp, self.T_mm = z(), z(), z(), z()
-        self.J0_p = torch.zeros((nSpec, N), dtype=dt, device=dev)
-        self.J0_m = torch.zeros((nSpec, N), dtype=dt, device=dev)
+        self._native = None       # NativeSlot while rt_kernel_ keeps this composite in the kernels' strip layout
+        self._native_ws = None    # its workspace (grow-only, reused from moment to moment)
+        # the reference's arrays; read through the properties below, which bring them up to date first
+        self._arr = dict(R_mp=z(), R_pm=z(), T_pp=z(), T_mm=z(), J0_p=torch.zeros((nSpec, N), dtype=dt, device=dev),
+                         J0_m=torch.zeros((nSpec, N), dtype=dt, device=dev))
         self.N, self.nSpec, self.dtype = N, nSpec, dt
 
+    R_mp = property(lambda self: self.materialize()._arr["R_mp"])
+    R_pm = property(lambda self: self.materialize()._arr["R_pm"])
+    T_pp = property(lambda self: self.materialize()._arr["T_pp"])
+    T_mm = property(lambda self: self.materialize()._arr["T_mm"])
+    J0_p = property(lambda self: self.materialize()._arr["J0_p"])
+    J0_m = property(lambda self: self.materialize()._arr["J0_m"])
+
+    def materialize(self):
+        """If rt_kernel_ holds this composite in native layout (a vsm_run of one Fourier moment), write it into the reference's
+        arrays (vsm_run_export) and release the run.  Every consumer reaches the arrays through cstruct(), which calls this:
+        interaction_, create_surface_layer_'s interaction, postprocessing_vza_, interaction_hdrf_, copy_added_to_composite_."""
+        slot = self._native
+        if slot is None:
+            return self
+        self._native = None
+        try:
+            cc = (_lib.vsm_composite * 1)(self._cstruct_raw())
+            _lib.call("vsm_run_export", self.dtype, slot.run, cc, _stream_ptr())
+        finally:
+            _lib.lib().vsm_run_destroy(slot.run)
+        return self
+
+    def drop_native(self):
+        """Forget the native copy without exporting it (a TOA layer overwrites the composite)."""
+        slot, self._native = self._native, None
+        if slot is not None:
+            _lib.lib().vsm_run_destroy(slot.run)
+
+    def _cstruct_raw(self):
+        a = self._arr
+        return _lib.vsm_composite(a["R_mp"].data_ptr(), a["R_pm"].data_ptr(), a["T_pp"].data_ptr(), a["T_mm"].data_ptr(),
+                                  a["J0_p"].data_ptr(), a["J0_m"].data_ptr())
+
     def cstruct(self):
-        return _lib.vsm_composite(self.R_mp.data_ptr(), self.R_pm.data_ptr(), self.T_pp.data_ptr(),
-                                  self.T_mm.data_ptr(), self.J0_p.data_ptr(), self.J0_m.data_ptr())
+        self.materialize()
+        return self._cstruct_raw()
+
+    def __del__(self):
+        try:
+            self.drop_native()
+        except Exception:
+            pass
 
 
 def make_added_layer(FT, arch, dims, nSpec, shared=False, d_symmetric=0) -> AddedLayer:
@@ -216,6 +261,9 @@ class DeviceLayerOptics:
     # several scatterers: Zpp/Zmp hold the ncomp COMPONENT matrices (ncomp, N, N) and fcomp (S, ncomp) the per-point
     # weights; Z = sum_k fcomp[s,k] Z_k is formed where it is consumed (vsm_layer_forward_mix) or by materialize()
     fcomp: Optional[torch.Tensor] = None
+    # Stokes coupling mask of THIS layer's phase matrices at this moment (vsm_stokes_coupling; bit 4a+b); None: not known yet --
+    # layer_coupling() computes it on the device (one small D2H) and keeps it here
+    coupling: Optional[int] = None
 
     @property
     def z_stride(self):
@@ -489,6 +537,115 @@ def init_layer(props: DeviceLayerOptics, qp: H.QuadPoints, FT, numerics: H.RTNum
     return array_type(arch)(dtau_h), nd
 
 
+# ---- the per-CompositeLayer registry behind rt_kernel_ (the drop-in form of the native-layout run) -------------------------------
+# The reference's driver (rt_run.jl:383-453) loops `for m` outside `for iz` and hands rt_kernel! ONE CompositeLayer; nothing else
+# reads that composite until the surface interaction (rt_run.jl:455-470).  rt_kernel_ therefore may keep it in the layer kernels'
+# strip layout from the TOA call (iz == 1: a one-moment vsm_run is created for it) to the first consumer that needs the reference's
+# [N,N,S] arrays (CompositeLayer.cstruct -> materialize -> vsm_run_export).  julia/vSmartMOMROCmExt.jl does the same with an IdDict.
+@dataclass
+class NativeSlot:
+    run: C.c_void_p
+    m: int
+    coupling: int          # the run's Stokes coupling mask (vsm_run_create)
+    grp_of: List[int]      # block of each Stokes component under that mask
+
+
+def stokes_groups(n_stokes: int, coupling: int) -> List[int]:
+    """Block (connected component of the symmetrised mask) of each Stokes component -- the rule of vsm_run_create."""
+    adj = [[a == b or coupling < 0 or bool((coupling >> (4 * a + b)) & 1) or bool((coupling >> (4 * b + a)) & 1)
+            for b in range(n_stokes)] for a in range(n_stokes)]
+    grp = [-1] * n_stokes
+    ng = 0
+    for a in range(n_stokes):
+        if grp[a] >= 0:
+            continue
+        grp[a], stack = ng, [a]
+        while stack:
+            x = stack.pop()
+            for b in range(n_stokes):
+                if adj[x][b] and grp[b] < 0:
+                    grp[b] = ng
+                    stack.append(b)
+        ng += 1
+    return grp
+
+
+def layer_coupling(props: DeviceLayerOptics, N: int, n_stokes: int) -> int:
+    """The Stokes coupling mask of a layer's phase matrices (OR over its scatterers / spectral points), from the data
+    (vsm_stokes_coupling).  Scene fills props.coupling from its per-scatterer masks; a bare caller pays one small D2H here."""
+    if props.coupling is None:
+        Zpp, Zmp = props.Zpp.contiguous(), props.Zmp.contiguous()
+        nb = int(Zpp.shape[0])
+        mask = torch.zeros(nb, dtype=torch.int32, device=Zpp.device)
+        for b0 in range(0, nb, 65535):
+            b1 = min(nb, b0 + 65535)
+            _lib.call("vsm_stokes_coupling", Zpp.dtype, N, n_stokes, b1 - b0, _ptr(Zpp[b0:b1]), _ptr(Zmp[b0:b1]),
+                      C.c_void_p(mask[b0:b1].data_ptr()), _stream_ptr())
+        props.coupling = int(np.bitwise_or.reduce(mask.cpu().numpy().astype(np.int64)))
+    return props.coupling
+
+
+def _native_open(comp: CompositeLayer, dq: DeviceQuad, m: int, mask: int, import_arrays: bool) -> bool:
+    """make_composite_layer in native layout for ONE Fourier moment (vsm_run_create on the composite's own workspace);
+    import_arrays: continue from the composite's current [N,N,S] arrays (vsm_run_import).  False: the blocks do not fit."""
+    L = _lib.lib()
+    N, ns, S = comp.N, dq.n_stokes, comp.nSpec
+    if not L.vsm_run_supported(N, ns, mask):
+        return False
+    marr, carr = (C.c_int * 1)(int(m)), (C.c_int * 1)(int(mask))
+    nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
+    ws = comp._native_ws
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = comp._native_ws = _lib.poison(torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=comp._arr["R_mp"].device))
+    q = dq.cstruct()
+    comp._native_q = (q, dq)                     # (the run keeps q's mu / wt pointers: they must outlive it)
+    run = C.c_void_p()
+    _lib.call("vsm_run_create", comp.dtype, C.byref(q), S, 1, marr, carr, _ptr(ws), nbytes, C.byref(run))
+    if import_arrays:
+        try:
+            cc = (_lib.vsm_composite * 1)(comp._cstruct_raw())
+            _lib.call("vsm_run_import", comp.dtype, run, cc, _stream_ptr())
+        except Exception:
+            L.vsm_run_destroy(run)
+            raise
+    comp._native = NativeSlot(run, int(m), int(mask), stokes_groups(ns, mask))
+    return True
+
+
+def _rt_kernel_native(comp: CompositeLayer, props: DeviceLayerOptics, tau_sum, m: int, dq: DeviceQuad, iz: int, F0, dtau,
+                      ndoubl: int) -> bool:
+    """The scattering "11" / TOA branch of rt_kernel! on the native copy of `comp` (vsm_run_layer).  The blocks of the run are the
+    connected Stokes components of the phase matrices seen SO FAR (data, vsm_stokes_coupling: at m = 0 no phase matrix couples (I,Q)
+    with (U,V), compute_Z_matrices.jl:26-110; Rayleigh leaves U alone there): a layer whose matrices couple two of the run's blocks
+    (the first aerosol layer of a column, say) re-opens the run under the wider mask (export -> create -> import: once per
+    widening).  False: not taken (shape outside the native kernels) -- the caller continues on the reference's arrays, which
+    cstruct() brings up to date."""
+    N, ns, S = comp.N, dq.n_stokes, comp.nSpec
+    ncomp = 0 if props.fcomp is None else int(props.fcomp.shape[1])
+    if ncomp > 4 or S == 0:
+        return False
+    lc = layer_coupling(props, N, ns)
+    if iz == 1:
+        comp.drop_native()                       # copy_added_to_composite! overwrites whatever the composite held
+        if not _native_open(comp, dq, m, lc, False):
+            return False
+    slot = comp._native
+    if slot is None or slot.m != m:
+        return False
+    g = slot.grp_of
+    if any((lc >> (4 * a + b)) & 1 and g[a] != g[b] for a in range(ns) for b in range(ns)):
+        wider = slot.coupling | lc
+        comp.materialize()
+        if not _native_open(comp, dq, m, wider, True):
+            return False
+        slot = comp._native
+    zpp, zmp = (C.c_void_p * 1)(props.Zpp.data_ptr()), (C.c_void_p * 1)(props.Zmp.data_ptr())
+    lcarr = (C.c_int * 1)(int(lc))
+    run_layer_native_(slot.run, 1, int(ndoubl), dtau, props.varpi, tau_sum, F0, ncomp, zpp, zmp,
+                      0 if ncomp else props.z_stride, props.fcomp, iz == 1, lcarr, comp.dtype)
+    return True
+
+
 def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerOptics, scattering_interface: str,
                tau_sum: torch.Tensor, m: int, dq: DeviceQuad, arch, iz: int, F0: torch.Tensor, FT,
                numerics: H.RTNumericalParameters, dtau: Optional[torch.Tensor] = None, ndoubl: Optional[int] = None,
@@ -506,6 +663,8 @@ def rt_kernel_(pol, added: AddedLayer, comp: CompositeLayer, props: DeviceLayerO
             # the whole layer step in one call (one launch when the strip kernels take the shape)
             if trace is not None:
                 trace.append(dict(iz=iz, m=m, scatter=True, ndoubl=nd, iface=scattering_interface))
+            elif NATIVE_DROPIN and NATIVE_RUN and _rt_kernel_native(comp, props, tau_sum, m, dq, iz, F0, dtau, nd):
+                return                      # the layer step ran on the composite's native copy (exported lazily)
             layer_forward_(tau_sum, dtau, F0, props, m, nd, dq, iz == 1, comp, added)
             return
         elemental_doubling_(pol, tau_sum, dtau, F0, props.materialize(), m, nd, dq, added)
@@ -684,7 +843,8 @@ class Scene:
                     Zp, Zm, fc = Zpp, Zmp, self.fcomp[iz, lo:hi]
                 else:
                     Zp, Zm, fc = Zpp[k:k + 1], Zmp[k:k + 1], None
-                props = DeviceLayerOptics(self.tau[iz, lo:hi], self.varpi[iz, lo:hi], Zp, Zm, maxima[iz], None, None, fc)
+                props = DeviceLayerOptics(self.tau[iz, lo:hi], self.varpi[iz, lo:hi], Zp, Zm, maxima[iz], None, None, fc,
+                                          coupling=self._layer_coupling(m, iz))
                 layers.append(dict(props=props, iface=tags[iz], nd=nds[iz], dtau=self.dtau[iz, lo:hi],
                                    tau_sum=self.tau_sum[iz, lo:hi]))
             rho = self.albedo_d
@@ -747,6 +907,8 @@ class Scene:
         (vsm_run_*; for m = 0 the (I,Q) x (U,V) blocks of every phase matrix are exactly zero, compute_Z_matrices.jl:26-110), and
         a block that the scatterers of ONE layer leave exactly zero takes that layer as a diagonal step."""
         C_ = int(self.Zc[0][0].shape[0])
+        if not self.host_optics and getattr(self, "coupling_comp", None) is not None:
+            return      # device optics: Z(m) depends on the Greek tables and the quadrature only -- scene constants, like the masks
         if getattr(self, "_coupling_d", None) is None:
             self._coupling_d = torch.zeros((len(self.Zc), C_), dtype=torch.int32, device=self.dev)
         for m, (Zpp, Zmp) in enumerate(self.Zc):
@@ -780,13 +942,15 @@ class Scene:
         # zero_added_noscat! never writes it, rt_helpers.jl:174-180 -- which ties the moments to their sequential order)
         eps2 = 2 * np.finfo(FT).eps
         has_noscat = any(ly["props"].max_tau_varpi <= eps2 for ly in self.moments[0]["layers"])
-        sequential = trace is not None or not MOMENT_BATCHING or has_noscat
+        sequential = trace is not None or not MOMENT_BATCHING or has_noscat or REFERENCE_ORDER
         # small batches are launch-latency bound (C3: 2 points, 22 moments x 33 layers): as many moments per launch as fill the chip
         want = max(MOMENT_BATCH, min(MOMENT_BATCH_MAX, 4096 // max(self.S, 1)))
         nb = 1 if sequential else min(want, len(self.moments))
         while len(self._composites) < nb:
             self._composites.append(make_composite_layer(FT, self.arch, (self.N, self.N), self.S))
-        native = self._native_moments() if trace is None and not has_noscat else set()
+        # (REFERENCE_ORDER: every layer step is an rt_kernel_ call on the ONE CompositeLayer, like the reference's driver; the native
+        # layout is then reached through rt_kernel_'s per-composite registry, NATIVE_DROPIN, instead of _run_layers_native)
+        native = self._native_moments() if trace is None and not has_noscat and not REFERENCE_ORDER else set()
         for g0 in range(0, len(self.moments), nb):
             group = self.moments[g0:g0 + nb]
             comps = self._composites[:len(group)]

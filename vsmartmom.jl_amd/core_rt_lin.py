@@ -238,10 +238,16 @@ class SceneLin:
         if (_reduce_m0 and REDUCE_M0 and pol.n >= 3 and S >= self.LANE_POINTS and NAer == 0 and not host_optics and c0 is not None
                 and isinstance(model.surface, H.LambertianSurfaceScalar) and (F0m is None or not np.any(np.asarray(F0m)[2:] != 0))
                 and not any(c0 >> (4 * a + b) & 1 or c0 >> (4 * b + a) & 1 for a in (0, 1) for b in range(2, pol.n))):
-            qi = H.QuadPoints(qp.mu0, qp.imu0, qp.qp_mu, qp.wt_mu, np.repeat(qp.qp_mu, 2), np.repeat(qp.wt_mu, 2), qp.Nquad, qp.Nstreams)
-            m_iq = dataclasses.replace(model, polarization_type=H.Stokes_IQ(), quad_points=qi, m_max=0,
-                                       F0=None if F0m is None else np.ascontiguousarray(np.asarray(F0m)[:2]))
-            self.sub0 = SceneLin(m_iq, lin_model, NAer, NGas, NSurf, spec_slice, _reduce_m0=False)
+            self.sub0 = SceneLin(self._sub0_model(), lin_model, NAer, NGas, NSurf, spec_slice, _reduce_m0=False)
+
+    def _sub0_model(self):
+        """The Stokes_IQ model of the moment m = 0, derived from the parent's model AS IT IS NOW (a step rebinds model.tau_abs,
+        scene.lin_model, ... and re-uploads: the sub-scene must see the new arrays, not the constructor-time snapshot)."""
+        model, qp = self.model, self.model.quad_points
+        F0m = model.F0
+        qi = H.QuadPoints(qp.mu0, qp.imu0, qp.qp_mu, qp.wt_mu, np.repeat(qp.qp_mu, 2), np.repeat(qp.wt_mu, 2), qp.Nquad, qp.Nstreams)
+        return dataclasses.replace(model, polarization_type=H.Stokes_IQ(), quad_points=qi, m_max=0,
+                                   F0=None if F0m is None else np.ascontiguousarray(np.asarray(F0m)[:2]))
 
     # -- inputs -----------------------------------------------------------------------------------------------------------
     def upload(self):
@@ -250,7 +256,10 @@ class SceneLin:
         model, lin = self.model, self.lin_model
         conv = array_type(self.arch)
         S_full, L = model.tau_rayl.shape
-        if getattr(self, "sub0", None) is not None:   # (a step re-uploads: the Stokes_IQ scene of m = 0 follows)
+        if getattr(self, "sub0", None) is not None:   # (a step re-uploads: the Stokes_IQ scene of m = 0 follows -- with the
+            # parent's CURRENT model and lin_model: dataclasses.replace() is a shallow snapshot, so it is taken again here)
+            self.sub0.model = self.sub0.fwd.model = self._sub0_model()
+            self.sub0.lin_model = self.lin_model
             self.sub0.fwd.upload()
             self.sub0.upload()
         if self.nGas:

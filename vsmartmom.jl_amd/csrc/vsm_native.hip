@@ -489,7 +489,10 @@ struct nio_ref {
   // Ask for a composite matrix ahead of its use: one dword of every 128-B line by LDS DMA into a junk vector (no register is
   // tied up, the lines wait in the L2 / MALL) -- the strips that are read just before the closing products would otherwise be
   // fetched with nothing to overlap them, the six live strips leave no room to request them earlier.
-  __device__ __forceinline__ void prefetch(int which, double* junk) const {
+  // junk: >= 256 bytes of LDS nobody reads while the requests are in flight (one dword per lane lands there) -- the callers hand in
+  // sm.gjs (512 B: touched by the pivoted inverse only, which never runs between a request and the wait that covers it); a
+  // vec[] row is too small below two row tiles (NP * 8 = 128 B).
+  __device__ __forceinline__ void prefetch(int which, int* junk) const {
     const int lines = (N * N * 8 + 127) >> 7;
     const char* g = reinterpret_cast<const char*>(m[which]);
     for (int k0 = 0; k0 < lines; k0 += ngeo<RT>::NT) {
@@ -617,7 +620,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     VSM_IA_STAMP(3);
   }
   if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))
-  io.prefetch(NC_TPP, sm.vec[7]);         // (four products ahead of its use: a line lives some tens of microseconds in the L2)
+  io.prefetch(NC_TPP, sm.gjs);         // (four products ahead of its use: a line lives some tens of microseconds in the L2)
   nstrip<RT> V;
   {
     nstrip<RT> S;
@@ -651,7 +654,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nstore(dP, t_s, p);                   // [t++] -> P
   }
   __syncthreads();                        // (e)
-  io.prefetch(NC_RMP, sm.vec[7]);
+  io.prefetch(NC_RMP, sm.gjs);
   VSM_IA_STAMP(5);
   nstrip<RT> Tpp;
   {
@@ -772,8 +775,8 @@ __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_ia_native(int N
   nstrip<RT> r_s, t_s;
   io.dma_raw(io.a[NC_RMP], sm.P, p);
   io.dma_raw(io.a[NC_TPP], sm.Q, p);
-  io.prefetch(NC_RPM, sm.vec[7]);
-  io.prefetch(NC_TMM, sm.vec[7]);
+  io.prefetch(NC_RPM, sm.gjs);
+  io.prefetch(NC_TMM, sm.gjs);
   if (tid < G::NP) {
     sm.vec[0][tid] = j0p;
     sm.vec[1][tid] = j0m;
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(64 * RT) void k_elemental_native(quad<ST> q, int n,
       const long long zo = fi + (long long)N * frow[j];
       double rr, tt;
       elemental_pair(w, zget(Zp, zo), zget(Zm, zo), mi, xi, ai, ei, mus[j], xs[j], ems[j], es[j], wct, i == j, thick, rr, tt);
-      const bool active = wct > num<double>::eps();
+      const bool active = wct > (double)num<ST>::eps();   // eps(FT) of the MODEL's float type (elemental.jl:296)
       if (i < n) {
         rv = active ? rr * sg : 0.0;
         tv = active ? tt : ((i == j) ? ei : 0.0);
@@ -1142,6 +1145,31 @@ __global__ __launch_bounds__(256) void k_stokes_coupling(int N, int ns, const ST
     if (zp[e] != ST(0) || zm[e] != ST(0)) mm |= 1u << (4 * (i % ns) + (j % ns));
   }
   if (mm) atomicOr(mask + blockIdx.y, (int)mm);
+}
+
+// Guard of the contract "the coupling masks cover every Z handed to vsm_run_layer" (a caller outside this repository derives the
+// masks itself): bit 4 a + b of allowed[moment] = an element (i, j) with i % ns == a, j % ns == b may be non-zero -- a and b in one
+// block of the run AND that block not taken as a diagonal step in this layer.  Any other non-zero element of the layer's phase
+// matrices raises VSM_DEVSTAT_MASK (vsm_device_status): the run drops that coupling silently otherwise.  One workgroup per matrix
+// (blockIdx.x: the scatterer's block of a component stack, the spectral point of a per-point Z, or the one shared matrix).
+template <typename ST>
+struct nguard_args {
+  const ST* zp[NSUB_MAX];
+  const ST* zm[NSUB_MAX];
+  unsigned allowed[NSUB_MAX];
+};
+template <typename ST>
+__global__ __launch_bounds__(256) void k_coupling_guard(int N, int ns, long long mat_stride, nguard_args<ST> a, int* status) {
+  const long long NN = (long long)N * N;
+  const int im = blockIdx.y;
+  const ST* zp = a.zp[im] + mat_stride * blockIdx.x;
+  const ST* zm = a.zm[im] + mat_stride * blockIdx.x;
+  unsigned mm = 0;
+  for (int e = threadIdx.x; e < NN; e += 256) {
+    const int i = e % N, j = e / N;
+    if (zp[e] != ST(0) || zm[e] != ST(0)) mm |= 1u << (4 * (i % ns) + (j % ns));
+  }
+  if (mm & ~a.allowed[im]) atomicOr(&status[0], (int)VSM_DEVSTAT_MASK);
 }
 
 // A layer step of a sub-problem whose block of the phase matrix is exactly zero in this layer (a Stokes block that nothing
@@ -1456,6 +1484,25 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
         if ((layer_coupling[sb.im] >> (4 * sb.g[a] + sb.g[b])) & 1) return false;
     return true;
   };
+  {   // the masks against the layer's actual phase matrices (VSM_DEVSTAT_MASK)
+    nguard_args<ST> ga;
+    for (int k = 0; k < NSUB_MAX; ++k) {
+      const int im = k < run->nm ? k : 0;
+      VSM_REQUIRE(Zpp[im] && Zmp[im], "vsm_run_layer: null Z of moment %d", im);
+      ga.zp[k] = Zpp[im];
+      ga.zm[k] = Zmp[im];
+      ga.allowed[k] = 0;
+    }
+    for (const nat_sub& sb : run->subs) {
+      if (trivial(sb)) continue;
+      for (int a = 0; a < sb.gsz; ++a)
+        for (int b = 0; b < sb.gsz; ++b) ga.allowed[sb.im] |= 1u << (4 * sb.g[a] + sb.g[b]);
+    }
+    const int nmat = ncomp ? ncomp : (z_stride ? run->S : 1);
+    hipLaunchKernelGGL((k_coupling_guard<ST>), dim3(nmat, run->nm), dim3(256), 0, st, run->N, run->ns,
+                       ncomp ? (long long)run->N * run->N : z_stride, ga, status);
+    VSM_LAUNCH_CHECK("k_coupling_guard");
+  }
   // the pre-pass images of the layer: one record per (sub-problem, point)
   size_t pre_total = 0;
   for (const nat_sub& sb : run->subs)
