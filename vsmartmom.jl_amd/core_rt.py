@@ -180,6 +180,17 @@ class AddedLayer:
                               self.d_symmetric, 0)
 
 
+def _composite_field(name):
+    """A CompositeLayer array as a property.  Read: bring the array up to date first (materialize).  Assign: the caller rebinds the
+    array -- CompositeLayer is a mutable struct in the reference -- after the native copy, if any, has been written out."""
+    def fget(self):
+        return self.materialize()._arr[name]
+
+    def fset(self, value):
+        self.materialize()._arr[name] = value
+    return property(fget, fset)
+
+
 class CompositeLayer:
     """src/CoreRT/types.jl CompositeLayer."""
 
@@ -193,12 +204,8 @@ class CompositeLayer:
                          J0_m=torch.zeros((nSpec, N), dtype=dt, device=dev))
         self.N, self.nSpec, self.dtype = N, nSpec, dt
 
-    R_mp = property(lambda self: self.materialize()._arr["R_mp"])
-    R_pm = property(lambda self: self.materialize()._arr["R_pm"])
-    T_pp = property(lambda self: self.materialize()._arr["T_pp"])
-    T_mm = property(lambda self: self.materialize()._arr["T_mm"])
-    J0_p = property(lambda self: self.materialize()._arr["J0_p"])
-    J0_m = property(lambda self: self.materialize()._arr["J0_m"])
+    R_mp, R_pm, T_pp = _composite_field("R_mp"), _composite_field("R_pm"), _composite_field("T_pp")
+    T_mm, J0_p, J0_m = _composite_field("T_mm"), _composite_field("J0_p"), _composite_field("J0_m")
 
     def materialize(self):
         """If rt_kernel_ holds this composite in native layout (a vsm_run of one Fourier moment), write it into the reference's
