@@ -591,14 +591,16 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
  * interaction is a scaling of the composite's rows and columns -- one elementwise pass instead of the products.
  * Every block of coupled components must fit the native
  * kernels: (N / n_stokes) * (components in the block) <= 64 (vsm_run_supported != 0), else VSM_ERR_UNSUPPORTED.
- * _f32: the same for a Float32 model -- the caller's arrays (quadrature, optics, Z, composites) are single precision, the native
- * records (`workspace`: vsm_run_workspace_bytes, the same for both) and all arithmetic between vsm_run_layer's loads and
- * vsm_run_export's stores are FP64 (the FP64 MFMA rate of these shapes is above what the FP32 kernels for N <= 64 reach, and the
- * results are at least as accurate as the reference's Float32 path).  A run is used with the entry points of its own type.
+ * _f32: the same for a Float32 model in the model's own float type, as the reference runs it (doubling.jl:38-131 and
+ * interaction.jl:207-266 compute in FT): the caller's arrays, the native records and the arithmetic (v_mfma_f32_16x16x4_f32) are
+ * single precision, blocks of up to 96 rows (vsm_run_supported_f32; workspace: vsm_run_workspace_bytes_f32 -- half of
+ * vsm_run_workspace_bytes, which stays sufficient).  A run is used with the entry points of its own type.
  * Stream: see Conventions; library scratch (the pre-pass images of the layer). */
 typedef struct vsm_run vsm_run;
 int vsm_run_supported(int N, int n_stokes, int coupling);
 size_t vsm_run_workspace_bytes(int N, int n_stokes, int S, int nm, const int* coupling_h);
+int vsm_run_supported_f32(int N, int n_stokes, int coupling);
+size_t vsm_run_workspace_bytes_f32(int N, int n_stokes, int S, int nm, const int* coupling_h);
 int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m_h, const int* coupling_h, void* workspace,
                        size_t workspace_bytes, vsm_run** run);
 int vsm_run_create_f32(const vsm_quad_f32* q, int S, int nm, const int* m_h, const int* coupling_h, void* workspace,

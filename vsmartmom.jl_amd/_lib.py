@@ -140,6 +140,8 @@ _SIGS = {
     "vsm_postprocess_vza_ie_{T}": (_I, [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_run_supported": (_I, [_I, _I, _I]),
     "vsm_run_workspace_bytes": (_SZ, [_I, _I, _I, _I, _P]),
+    "vsm_run_supported_f32": (_I, [_I, _I, _I]),
+    "vsm_run_workspace_bytes_f32": (_SZ, [_I, _I, _I, _I, _P]),
     "vsm_run_create_{T}": (_I, [_P, _I, _I, _P, _P, _P, _SZ, _P]),
     "vsm_run_layer_{T}": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
     "vsm_run_export_{T}": (_I, [_P, _P, _P]),

@@ -592,15 +592,26 @@ def layer_coupling(props: DeviceLayerOptics, N: int, n_stokes: int) -> int:
     return props.coupling
 
 
+def run_supported(dtype, N: int, ns: int, mask: int) -> bool:
+    """vsm_run_supported of the model's float type: blocks of <= 64 rows (FP64), <= 96 rows (Float32: the FP32 native kernels)."""
+    L = _lib.lib()
+    return (L.vsm_run_supported_f32 if dtype == torch.float32 else L.vsm_run_supported)(int(N), int(ns), int(mask)) != 0
+
+
+def run_workspace_bytes(dtype, N: int, ns: int, S: int, nm: int, carr) -> int:
+    L = _lib.lib()
+    return int((L.vsm_run_workspace_bytes_f32 if dtype == torch.float32 else L.vsm_run_workspace_bytes)(N, ns, S, nm, carr))
+
+
 def _native_open(comp: CompositeLayer, dq: DeviceQuad, m: int, mask: int, import_arrays: bool) -> bool:
     """make_composite_layer in native layout for ONE Fourier moment (vsm_run_create on the composite's own workspace);
     import_arrays: continue from the composite's current [N,N,S] arrays (vsm_run_import).  False: the blocks do not fit."""
     L = _lib.lib()
     N, ns, S = comp.N, dq.n_stokes, comp.nSpec
-    if not L.vsm_run_supported(N, ns, mask):
+    if not run_supported(comp.dtype, N, ns, mask):
         return False
     marr, carr = (C.c_int * 1)(int(m)), (C.c_int * 1)(int(mask))
-    nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, 1, carr))
+    nbytes = run_workspace_bytes(comp.dtype, N, ns, S, 1, carr)
     ws = comp._native_ws
     if ws is None or ws.numel() * 8 < nbytes:
         ws = comp._native_ws = _lib.poison(torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=comp._arr["R_mp"].device))
@@ -1003,8 +1014,7 @@ class Scene:
     def _native_moments(self):
         """Indices of the Fourier moments whose layer loop runs on the native-layout composite (vsm_run_*): every layer scattering
         with the 11 interface (the only steps the run object takes), at most four scatterers per layer, and every block of coupled
-        Stokes components within the native kernels' size (64 rows).  Float32 models: storage in single, the native records and
-        the arithmetic of the layer loop in double."""
+        Stokes components within the native kernels' size (FP64: 64 rows; Float32 models: 96 rows, FP32 records and arithmetic)."""
         if not NATIVE_RUN or getattr(self, "coupling", None) is None or not self.moments:
             return set()
         eps2 = 2 * np.finfo(self.FT).eps
@@ -1012,9 +1022,7 @@ class Scene:
             p = ly["props"]
             if p.max_tau_varpi <= eps2 or (iz > 0 and ly["iface"] != "11") or (p.fcomp is not None and p.fcomp.shape[1] > 4):
                 return set()
-        L = _lib.lib()
-        return {i for i, mom in enumerate(self.moments)
-                if L.vsm_run_supported(self.N, self.pol.n, int(self.coupling[mom["m"]])) != 0}
+        return {i for i, mom in enumerate(self.moments) if run_supported(self.dt, self.N, self.pol.n, int(self.coupling[mom["m"]]))}
 
     def _run_layers_native(self, group, comps):
         """rt_run's layer loop (rt_run.jl:383-453) for the moments of `group` with the CompositeLayer in kernel-native layout:
@@ -1023,7 +1031,7 @@ class Scene:
         nm, N, S, ns = len(group), self.N, self.S, self.pol.n
         marr = (C.c_int * nm)(*[int(mom["m"]) for mom in group])
         carr = (C.c_int * nm)(*[int(self.coupling[mom["m"]]) for mom in group])
-        nbytes = int(L.vsm_run_workspace_bytes(N, ns, S, nm, carr))
+        nbytes = run_workspace_bytes(self.dt, N, ns, S, nm, carr)
         ws = getattr(self, "_native_ws", None)
         if ws is None or ws.numel() * 8 < nbytes:
             ws = self._native_ws = _lib.poison(torch.empty(max(nbytes // 8, 2), dtype=torch.float64, device=self.dev))

@@ -17,10 +17,10 @@
 #include <vector>
 
 #include "vsm_native_dev.h"
+#include "vsm_native_run.h"
 
 namespace vsm {
 
-constexpr int NSUB_MAX = VSM_MM_MAX;   // sub-problems per launch (gridDim.y)
 struct nlayer_comps {
   double* c[NSUB_MAX];
 };
@@ -1238,31 +1238,9 @@ __global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, i
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// the run object
+// the run object (vsm_native_run.h)
 // ---------------------------------------------------------------------------------------------------------------------------
-struct nat_sub {
-  int im;          // index of the Fourier moment in the run's list
-  int m;
-  int gsz, g[4];
-  unsigned uvmask;
-  int n, rt, ks;
-  size_t comp_off;   // doubles from the workspace base
-};
 }  // namespace vsm
-
-struct vsm_run {
-  const void *mu, *wt;     // the quadrature arrays of the caller (element type: elem_size)
-  int N, ns, i_mu0;
-  double mu0;
-  int elem_size;           // 8: FP64 arrays, 4: FP32 arrays (storage only: the native records and all arithmetic are FP64)
-  int S, nm;
-  std::vector<int> m;
-  std::vector<vsm::nat_sub> subs;
-  std::vector<std::vector<int>> classes;   // indices into subs with equal (n, gsz, uvmask)
-  double* ws;
-  size_t ws_doubles;
-  std::vector<char> pure_diag;   // per sub-problem: its composite is still (R = 0, T = diag, J = 0): only diagonal steps so far
-};
 
 namespace vsm {
 namespace {
@@ -1306,7 +1284,8 @@ static inline int rt_of(int n) {   // (as the launchers of the layer kernels cho
 static inline size_t comp_stride_rt(int rt) { return (size_t)4 * (16 * rt) * (16 * rt) + 2 * 16 * rt; }
 static inline size_t pre_stride_rt(int rt) { return (size_t)2 * (16 * rt) * (16 * rt) + 3 * 16 * rt; }
 
-static int plan_subs(int N, int ns, int nm, const int* m, const int* coupling, std::vector<nat_sub>& subs, size_t S,
+// f32: the FP32 family (vsm_native32.hip: blocks of <= 96 rows, records in floats); else the FP64 one (<= 64 rows, doubles)
+static int plan_subs(bool f32, int N, int ns, int nm, const int* m, const int* coupling, std::vector<nat_sub>& subs, size_t S,
                      size_t& total) {
   if (N <= 0 || ns < 1 || ns > 4 || N % ns) {
     set_error("vsm_run: bad N = %d / n_stokes = %d", N, ns);
@@ -1328,15 +1307,16 @@ static int plan_subs(int N, int ns, int nm, const int* m, const int* coupling, s
       for (int k = 0; k < gsz[g]; ++k)
         if (groups[g][k] >= 2) sb.uvmask |= 1u << k;
       sb.n = nq * gsz[g];
-      if (sb.n > 64) {
-        set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (64)", sb.n, N,
-                  gsz[g]);
+      const int max_rows = f32 ? NATIVE32_MAX_ROWS : 64;
+      if (sb.n > max_rows) {
+        set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (%d)", sb.n, N,
+                  gsz[g], max_rows);
         return VSM_ERR_UNSUPPORTED;
       }
       sb.ks = (sb.n + 3) / 4;
-      sb.rt = rt_of(sb.n);
+      sb.rt = f32 ? native32_rt_of(sb.n) : rt_of(sb.n);
       sb.comp_off = total;
-      total += comp_stride_rt(sb.rt) * S;
+      total += (f32 ? native32_comp_stride(sb.rt) : comp_stride_rt(sb.rt)) * S;
       subs.push_back(sb);
     }
   }
@@ -1401,7 +1381,7 @@ static ngroup_map group_map(const vsm_run* run, int im) {
     gm.gsz[g] = sb.gsz;
     gm.rt[g] = sb.rt;
     gm.n[g] = sb.n;
-    gm.base[g] = run->ws + sb.comp_off;
+    gm.base[g] = static_cast<double*>(run->ws) + sb.comp_off;
     for (int k = 0; k < sb.gsz; ++k) {
       gm.grp_of[sb.g[k]] = g;
       gm.pos_in[sb.g[k]] = k;
@@ -1433,18 +1413,18 @@ static int run_create(const Q* q, int S, int nm, const int* m, const int* coupli
   run->nm = nm;
   run->m.assign(m, m + nm);
   size_t total = 0;
-  const int rc = plan_subs(q->N, q->n_stokes, nm, m, coupling, run->subs, (size_t)S, total);
+  const int rc = plan_subs(sizeof(ST) == 4, q->N, q->n_stokes, nm, m, coupling, run->subs, (size_t)S, total);
   if (rc) {
     delete run;
     return rc;
   }
-  if (total * sizeof(double) > workspace_bytes || (total && !workspace) || ((size_t)workspace & 15)) {
-    set_error("vsm_run_create: workspace of %zu bytes (16-byte aligned) required, got %zu", total * sizeof(double), workspace_bytes);
+  if (total * sizeof(ST) > workspace_bytes || (total && !workspace) || ((size_t)workspace & 15)) {
+    set_error("vsm_run_create: workspace of %zu bytes (16-byte aligned) required, got %zu", total * sizeof(ST), workspace_bytes);
     delete run;
     return VSM_ERR_INVALID_ARG;
   }
-  run->ws = static_cast<double*>(workspace);
-  run->ws_doubles = total;
+  run->ws = workspace;
+  run->ws_elems = total;
   run->pure_diag.assign(run->subs.size(), 0);
   // classes: sub-problems that one launch can take (equal n, group size and U/V pattern), at most NSUB_MAX each
   for (size_t i = 0; i < run->subs.size(); ++i) {
@@ -1503,6 +1483,10 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
                        ncomp ? (long long)run->N * run->N : z_stride, ga, status);
     VSM_LAUNCH_CHECK("k_coupling_guard");
   }
+  if constexpr (sizeof(ST) == 4) {   // Float32 model: FP32 records and arithmetic (vsm_native32.hip)
+    return native32_run_layer(run, ndoubl, dtau, varpi, tau_sum, F0, ncomp, Zpp, Zmp, z_stride, fcomp, toa, layer_coupling, status, st);
+  } else {
+  double* const ws = static_cast<double*>(run->ws);
   // the pre-pass images of the layer: one record per (sub-problem, point)
   size_t pre_total = 0;
   for (const nat_sub& sb : run->subs)
@@ -1534,7 +1518,7 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
       const int nt = (int)triv[mode].size();
       for (int k = 0; k < NSUB_MAX; ++k) {
         const nat_sub& sb = run->subs[triv[mode][k < nt ? k : 0]];
-        da.comp[k] = run->ws + sb.comp_off;
+        da.comp[k] = ws + sb.comp_off;
         da.gsz[k] = sb.gsz;
         da.g0[k] = sb.g[0] | (sb.g[1] << 4) | (sb.g[2] << 8) | (sb.g[3] << 12);
       }
@@ -1553,7 +1537,7 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
       for (int a = 0; a < 4; ++a) pa.s[k].g[a] = sb.g[a];
       VSM_REQUIRE(Zpp[sb.im] && Zmp[sb.im], "vsm_run_layer: null Z of moment %d", sb.im);
       pa.s[k].z = zsrc<ST>{Zpp[sb.im], Zmp[sb.im], ncomp ? 0 : z_stride, ncomp, fcomp};
-      lc.c[k] = run->ws + sb.comp_off;
+      lc.c[k] = ws + sb.comp_off;
     }
     double* pre_cl = pre + off;
     off += pre_stride_rt(h.rt) * (size_t)run->S * nsub;
@@ -1568,6 +1552,7 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
     if (rc) return rc;
   }
   return VSM_OK;
+  }
 }
 
 template <typename ST, typename CS, bool IMPORT>
@@ -1579,8 +1564,13 @@ static int run_convert(vsm_run* run, const CS* comps, void* stream) {
   for (int im = 0; im < run->nm; ++im) {
     const CS& c = comps[im];
     VSM_REQUIRE(c.R_mp && c.R_pm && c.T_pp && c.T_mm && c.J0_p && c.J0_m, "vsm_run_export / import: null composite array (moment %d)", im);
-    const ngroup_map gm = group_map(run, im);
     const composite<ST> cc{c.R_mp, c.R_pm, c.T_pp, c.T_mm, c.J0_p, c.J0_m};
+    if constexpr (sizeof(ST) == 4) {
+      const int rc = native32_convert(run, im, cc, IMPORT, as_stream(stream));
+      if (rc) return rc;
+      continue;
+    }
+    const ngroup_map gm = group_map(run, im);
     if (IMPORT)
       hipLaunchKernelGGL((k_native_import<ST>), dim3(run->S), dim3(256), 0, as_stream(stream), run->N, run->ns, gm, cc);
     else
@@ -1610,20 +1600,28 @@ using namespace vsm;
 
 extern "C" {
 
-int vsm_run_supported(int N, int n_stokes, int coupling) {
+static int run_supported(int N, int n_stokes, int coupling, int max_rows) {
   if (N <= 0 || n_stokes < 1 || n_stokes > 4 || N % n_stokes) return 0;
   int grp_of[4], groups[4][4], gsz[4];
   const int ng = stokes_groups(n_stokes, coupling, grp_of, groups, gsz);
   for (int g = 0; g < ng; ++g)
-    if ((N / n_stokes) * gsz[g] > 64) return 0;
+    if ((N / n_stokes) * gsz[g] > max_rows) return 0;
   return 1;
 }
+int vsm_run_supported(int N, int n_stokes, int coupling) { return run_supported(N, n_stokes, coupling, 64); }
+int vsm_run_supported_f32(int N, int n_stokes, int coupling) { return run_supported(N, n_stokes, coupling, NATIVE32_MAX_ROWS); }
 
 size_t vsm_run_workspace_bytes(int N, int n_stokes, int S, int nm, const int* coupling) {
   std::vector<nat_sub> subs;
   size_t total = 0;
-  if (S < 0 || nm < 0 || plan_subs(N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
+  if (S < 0 || nm < 0 || plan_subs(false, N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
   return total * sizeof(double);
+}
+size_t vsm_run_workspace_bytes_f32(int N, int n_stokes, int S, int nm, const int* coupling) {
+  std::vector<nat_sub> subs;
+  size_t total = 0;
+  if (S < 0 || nm < 0 || plan_subs(true, N, n_stokes, nm, nullptr, coupling, subs, (size_t)S, total)) return 0;
+  return total * sizeof(float);
 }
 
 int vsm_run_create_f64(const vsm_quad_f64* q, int S, int nm, const int* m, const int* coupling, void* workspace,
