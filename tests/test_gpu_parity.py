@@ -747,26 +747,30 @@ def _o2a_like(S, L, seed=20260929):
 @pytest.mark.parametrize("FT,l_trunc,pol,rtol,N", [(np.float64, 35, "IQU", 1e-8, 60), (np.float32, 59, "IQU", 1e-2, 96),
                                                    # Float32 beyond the FP32 strip kernels: k_dbl128 / k_ia128 over FP32 arrays
                                                    (np.float32, 69, "IQU", 1e-2, 111), (np.float32, 59, "IQUV", 1e-2, 128)])
-def test_rt_run_o2a_shape_vs_oracle(vsm, arch, FT, l_trunc, pol, rtol, N):
+def test_rt_run_o2a_shape_vs_oracle(vsm, arch, monkeypatch, FT, l_trunc, pol, rtol, N):
     """The benchmark's own shape at reduced S, L: FP64 N = 60 (C2) and FP32 N = 96 (C4), multi-layer,
     absorption spanning 1e-4..50, Lambertian 0.15 -- fused kernels end to end vs the oracle; and the Float32 shapes of
-    96 < N <= 128, which run on the FP64 kernels of vsm_strip128.hip with FP32 storage (the reference's FP32 gate, 1e-2)."""
+    96 < N <= 128: on the reference-layout layer loop they run on the FP64 kernels of vsm_strip128.hip with FP32 storage (the
+    reference's FP32 gate, 1e-2); the native run takes the moments whose Stokes blocks stay within 96 rows (N = 128, Stokes_IQUV:
+    all of them -- the Rayleigh matrix leaves V uncoupled)."""
     S, L = 12, 4
     tau_rayl, tau_abs = _o2a_like(S, L)
     om, pm = _both_models(vsm, arch, pol, l_trunc, 40.0, [30.0], [0.0], FT=FT, tau_rayl=tau_rayl, tau_abs=tau_abs,
                           depol=0.0279, albedo=0.15, m_max=2)
     assert om.quad_points.Nquad * om.pol.n == N
-    if N > 96:
-        _device_status(vsm)
     Ro, To = O.rt_run(om)
-    Rg, Tg = vsm.CoreRT.rt_run(pm)
-    if N > 96:
-        st = vsm._lib.last_device_status
-        assert st[0] == 0 and st[2] > 0 and st[3] > 0, st      # k_dbl128 / k_ia128 ran
     big = np.abs(Ro) > 1e-3 * np.abs(Ro).max()
-    assert np.max(np.abs(Rg[big] - Ro[big]) / np.abs(Ro[big])) < rtol
     bigT = np.abs(To) > 1e-3 * np.abs(To).max()
-    assert np.max(np.abs(Tg[bigT] - To[bigT]) / np.abs(To[bigT])) < rtol
+    for native in ((False, True) if N > 96 else (True,)):
+        monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", native)
+        if N > 96:
+            _device_status(vsm)
+        Rg, Tg = vsm.CoreRT.rt_run(pm)
+        if N > 96:
+            st = vsm._lib.last_device_status
+            assert st[0] == 0 and st[3] > 0 and (native or st[2] > 0), st      # k_ia128 (and, reference layout: k_dbl128) ran
+        assert np.max(np.abs(Rg[big] - Ro[big]) / np.abs(Ro[big])) < rtol
+        assert np.max(np.abs(Tg[bigT] - To[bigT]) / np.abs(To[bigT])) < rtol
 
 
 def test_rt_run_full_size_properties(vsm, arch):

@@ -76,8 +76,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nstrip<RT> W, tt;
     const double fW = laneA ? expk : (laneB ? 1.0 : 0.0), fR = laneB ? expk : 1.0;
     if constexpr (!RID) {   // r j0+ , r j1-   (P = [r])
-      nmv_part(sm.P, jp, 1.0, sm.mv[p.wave], p);
-      nmv_part(sm.P, jm, expk, sm.mv[RT + p.wave], p);
+      nmv_rows<RT, KS>(dP, jp, 1.0, sm.mv[0], p);
+      nmv_rows<RT, KS>(dP, jm, expk, sm.mv[1], p);
     }
     {
       nstrip<RT> Gs;
@@ -96,8 +96,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
         const double nrm = nnorm(E, n, sm, slot, p);   // (its barrier: [r] is free)
         if constexpr (!RID) {   // u1 = j1- + r j0+ , u2 = j0+ + r j1-   (every wave is past the norm reduction's barrier)
           if (tid < G::NP) {
-            sm.vec[4][tid] = jm[tid] * expk + nmv_sum<RT>(sm, 0, tid);
-            sm.vec[5][tid] = jp[tid] + nmv_sum<RT>(sm, RT, tid);
+            sm.vec[4][tid] = jm[tid] * expk + sm.mv[0][tid];
+            sm.vec[5][tid] = jp[tid] + sm.mv[1][tid];
           }
         }
         ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);
@@ -109,8 +109,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nstore(dP, tt, p);
     __syncthreads();
     if constexpr (!RID) {   // tt u1 , tt u2   (the partial sums of r j were consumed two barriers ago)
-      nmv_part(sm.P, sm.vec[4], 1.0, sm.mv[p.wave], p);
-      nmv_part(sm.P, sm.vec[5], 1.0, sm.mv[RT + p.wave], p);
+      nmv_rows<RT, KS>(dP, sm.vec[4], 1.0, sm.mv[0], p);
+      nmv_rows<RT, KS>(dP, sm.vec[5], 1.0, sm.mv[1], p);
     }
     {
       nstrip<RT> tn;
@@ -132,8 +132,8 @@ __device__ __forceinline__ void ned_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     if (it + 1 < ndoubl || !RID) __syncthreads();   // everybody finished reading P ([tt])
     if constexpr (!RID) {   // j0- += tt u1 ; j0+ = j0+ expk + tt u2   (visible after the barrier below / after the loop)
       if (tid < G::NP) {
-        jm[tid] += nmv_sum<RT>(sm, 0, tid);
-        jp[tid] = jp[tid] * expk_step + nmv_sum<RT>(sm, RT, tid);
+        jm[tid] += sm.mv[0][tid];
+        jp[tid] = jp[tid] * expk_step + sm.mv[1][tid];
       }
     }
     if (it + 1 < ndoubl) {
@@ -221,8 +221,8 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
   __syncthreads();                                                                                       // (a)
   if constexpr (!RID) {   // R+- j0- , T-- j0-
-    nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);
+    nmv_rows<RT, KS>(dP, vjm, 1.0, sm.mv[0], p);
+    nmv_rows<RT, KS>(dQ, vjm, 1.0, sm.mv[1], p);
   }
   {
     nstrip<RT> E;
@@ -240,8 +240,8 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
     if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
       if (tid < G::NP) {
-        vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
-        vs[tid] = nmv_sum<RT>(sm, RT, tid);
+        vz[tid] = vJp[tid] + sm.mv[0][tid];
+        vs[tid] = sm.mv[1][tid];
       }
     }
     ninvert<RT, KS>(ninv_order(nrm, status), E, Gs, n, cx, p);   // [E2] -> P, barrier (c), series
@@ -279,8 +279,8 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   nld_native(Rmp, R_mp, p);
   __syncthreads();                        // (g)
   if constexpr (!RID) {   // T21 z , Y z
-    nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vz, 1.0, sm.mv[RT + p.wave], p);
+    nmv_rows<RT, KS>(dP, vz, 1.0, sm.mv[0], p);
+    nmv_rows<RT, KS>(dQ, vz, 1.0, sm.mv[1], p);
   }
   if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
@@ -321,8 +321,8 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
     __syncthreads();
     if (tid < G::NP) {
-      J0_p[tid] = vjp[tid] + nmv_sum<RT>(sm, 0, tid);
-      J0_m[tid] = vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid);
+      J0_p[tid] = vjp[tid] + sm.mv[0][tid];
+      J0_m[tid] = vJm[tid] + vs[tid] + sm.mv[1][tid];
     }
   }
 }
@@ -587,7 +587,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   if constexpr (DSYM) ndsym(t_s, t_s, dp);   // t-- = D t++ D in place (undone below: D is an involution)
   __syncthreads();                                                                                       // (a)
   VSM_IA_STAMP(0);
-  if constexpr (!RID) nmv_part(sm.P, vjm, 1.0, sm.mv[p.wave], p);   // R+- j0-
+  if constexpr (!RID) nmv_rows<RT, KS>(dP, vjm, 1.0, sm.mv[0], p);   // R+- j0-
   {
     nstrip<RT> E;
     if constexpr (DSYM) {
@@ -611,7 +611,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     nstore(dQ, A2, p);                             // [T--] -> Q (free since the entry; read after barrier (c))
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
     if constexpr (!RID) {   // z = J0+ + R+- j0-
-      if (tid < G::NP) vz[tid] = vJp[tid] + nmv_sum<RT>(sm, 0, tid);
+      if (tid < G::NP) vz[tid] = vJp[tid] + sm.mv[0][tid];
     }
     VSM_IA_STAMP(2);
     const int K = ninv_order(nrm, status);                       // [E2] -> P, barrier (c), series
@@ -619,7 +619,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     else ninvert<RT, KS, true>(K, E, Gs, n, cx, p);
     VSM_IA_STAMP(3);
   }
-  if constexpr (!RID) nmv_part(sm.Q, vjm, 1.0, sm.mv[RT + p.wave], p);   // T-- j0- (summed after barrier (d))
+  if constexpr (!RID) nmv_rows<RT, KS>(dQ, vjm, 1.0, sm.mv[1], p);   // T-- j0- (summed after barrier (d))
   io.prefetch(NC_TPP, sm.gjs);         // (four products ahead of its use: a line lives some tens of microseconds in the L2)
   nstrip<RT> V;
   {
@@ -648,7 +648,7 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
     VSM_IA_STAMP(4);
     __syncthreads();                      // (d): [E2] (series) and [T--] no longer read
     if constexpr (!RID) {
-      if (tid < G::NP) vs[tid] = nmv_sum<RT>(sm, RT, tid);
+      if (tid < G::NP) vs[tid] = sm.mv[1][tid];
     }
     nstore(dQ, S, p);                     // [S]   -> Q
     nstore(dP, t_s, p);                   // [t++] -> P
@@ -676,8 +676,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   __syncthreads();                        // (g)
   VSM_IA_STAMP(7);
   if constexpr (!RID) {   // T21 z , Y z
-    nmv_part(sm.P, vz, 1.0, sm.mv[p.wave], p);
-    nmv_part(sm.Q, vz, 1.0, sm.mv[RT + p.wave], p);
+    nmv_rows<RT, KS>(dP, vz, 1.0, sm.mv[0], p);
+    nmv_rows<RT, KS>(dQ, vz, 1.0, sm.mv[1], p);
   }
   if (own_wave) {  // z rides in the spare column c1 of T++:  (T21 T++)[:, c1] = T21 z, (Y T++)[:, c1] = Y z
 #pragma unroll
@@ -728,8 +728,8 @@ __device__ __forceinline__ void nia_body(nsmem<RT, (4 * KS + 2 > 16 * RT)>& sm, 
   if constexpr (!RID) {   // J0+ = j0+ + T21 z ; J0- = J0- + T-- j0- + Y z
     __syncthreads();
     if (tid < G::NP) {
-      io.stJ(0, tid, vjp[tid] + nmv_sum<RT>(sm, 0, tid));
-      io.stJ(1, tid, vJm[tid] + vs[tid] + nmv_sum<RT>(sm, RT, tid));
+      io.stJ(0, tid, vjp[tid] + sm.mv[0][tid]);
+      io.stJ(1, tid, vJm[tid] + vs[tid] + sm.mv[1][tid]);
     }
   }
 #ifdef VSM_IA_PHASES

@@ -25,6 +25,9 @@
 #ifndef VSM_N32_WPS4
 #define VSM_N32_WPS4 4
 #endif
+#ifndef VSM_N32_SINGLE_FRAG_RT
+#define VSM_N32_SINGLE_FRAG_RT 9
+#endif
 
 namespace vsm {
 namespace {
@@ -123,22 +126,46 @@ __device__ __forceinline__ float n32dpp_swap1(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
 }
 
-// ---- products: acc += [A] B, A-form at byte distance dA, B a strip in registers; fragments requested one k-step ahead -----------
-template <int RT, int KS, bool Z = false>
-__device__ __forceinline__ void n32mm(n32strip<RT>& acc, unsigned dA, const n32strip<RT>& B, n32pos<RT>& p) {
-  p.opaque();
-  float a[2][RT];
+// ---- products: acc += [A] B, A-form at byte distance dA, B a strip in registers ------------------------------------------------
+// One fragment register per row tile: the fragment of the next k-step is requested right behind the MFMA that has consumed the
+// current one (RT - 1 MFMAs = 32 (RT - 1) cycles of latency cover below it from three row tiles on); one and two row tiles keep
+// two sets (requested a whole k-step ahead).
+// (Z / Z1 / Z2: the accumulator starts from zero -- the first k-step takes the constant 0 as its addend: no register is cleared)
+template <int RT>
+struct n32frag {
+  static constexpr int SETS = (RT >= VSM_N32_SINGLE_FRAG_RT) ? 1 : 2;
+  float a[SETS][RT];
+  __device__ __forceinline__ void first(const n32pos<RT>& p, unsigned dA) {
 #pragma unroll
-  for (int t = 0; t < RT; ++t) a[0][t] = *p.aptr(dA, t, 0);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
+    for (int t = 0; t < RT; ++t) a[0][t] = *p.aptr(dA, t, 0);
+  }
+  template <int KS>
+  __device__ __forceinline__ void ahead(const n32pos<RT>& p, unsigned dA, int ks) {   // SETS == 2: before the MFMAs of k-step ks
+    if (SETS == 2 && ks + 1 < KS) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
     }
+  }
+  __device__ __forceinline__ float get(int ks, int t) const { return a[SETS == 2 ? (ks & 1) : 0][t]; }
+  template <int KS>
+  __device__ __forceinline__ void behind(const n32pos<RT>& p, unsigned dA, int ks, int t) {   // SETS == 1: behind the MFMA (ks, t)
+    if (SETS == 1 && ks + 1 < KS) a[0][t] = *p.aptr(dA, t, ks + 1);
+  }
+};
+template <int RT, int KS, bool Z = false>
+__device__ __forceinline__ void n32mm(n32strip<RT>& acc, unsigned dA, const n32strip<RT>& B, n32pos<RT>& p) {
+  p.opaque();
+  n32frag<RT> f;
+  f.first(p, dA);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    f.template ahead<KS>(p, dA, ks);
     const float b = B.v[ks >> 2][ks & 3];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc.v[t] = mfma<float>::mma(a[ks & 1][t], b, (Z && ks == 0) ? acc_zero<float>() : acc.v[t]);
+    for (int t = 0; t < RT; ++t) {
+      acc.v[t] = mfma<float>::mma(f.get(ks, t), b, (Z && ks == 0) ? acc_zero<float>() : acc.v[t]);
+      f.template behind<KS>(p, dA, ks, t);
+    }
     VSM_N32KSTEP_FENCE();
   }
 }
@@ -146,18 +173,17 @@ __device__ __forceinline__ void n32mm(n32strip<RT>& acc, unsigned dA, const n32s
 template <int RT, int KS>
 __device__ __forceinline__ void n32mm_c(n32strip<RT>& out, const n32strip<RT>& C0, unsigned dA, const n32strip<RT>& B, n32pos<RT>& p) {
   p.opaque();
-  float a[2][RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) a[0][t] = *p.aptr(dA, t, 0);
+  n32frag<RT> f;
+  f.first(p, dA);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int t = 0; t < RT; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
-    }
+    f.template ahead<KS>(p, dA, ks);
     const float b = B.v[ks >> 2][ks & 3];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) out.v[t] = mfma<float>::mma(a[ks & 1][t], b, ks == 0 ? C0.v[t] : out.v[t]);
+    for (int t = 0; t < RT; ++t) {
+      out.v[t] = mfma<float>::mma(f.get(ks, t), b, ks == 0 ? C0.v[t] : out.v[t]);
+      f.template behind<KS>(p, dA, ks, t);
+    }
     VSM_N32KSTEP_FENCE();
   }
 }
@@ -166,20 +192,17 @@ template <int RT, int KS, bool Z1 = false, bool Z2 = false>
 __device__ __forceinline__ void n32mm2(n32strip<RT>& acc1, n32strip<RT>& acc2, unsigned dA, const n32strip<RT>& B1,
                                        const n32strip<RT>& B2, n32pos<RT>& p) {
   p.opaque();
-  float a[2][RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) a[0][t] = *p.aptr(dA, t, 0);
+  n32frag<RT> f;
+  f.first(p, dA);
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
-#pragma unroll
-      for (int t = 0; t < RT; ++t) a[(ks + 1) & 1][t] = *p.aptr(dA, t, ks + 1);
-    }
+    f.template ahead<KS>(p, dA, ks);
     const float b1 = B1.v[ks >> 2][ks & 3], b2 = B2.v[ks >> 2][ks & 3];
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      acc1.v[t] = mfma<float>::mma(a[ks & 1][t], b1, (Z1 && ks == 0) ? acc_zero<float>() : acc1.v[t]);
-      acc2.v[t] = mfma<float>::mma(a[ks & 1][t], b2, (Z2 && ks == 0) ? acc_zero<float>() : acc2.v[t]);
+      acc1.v[t] = mfma<float>::mma(f.get(ks, t), b1, (Z1 && ks == 0) ? acc_zero<float>() : acc1.v[t]);
+      acc2.v[t] = mfma<float>::mma(f.get(ks, t), b2, (Z2 && ks == 0) ? acc_zero<float>() : acc2.v[t]);
+      f.template behind<KS>(p, dA, ks, t);
     }
     VSM_N32KSTEP_FENCE();
   }

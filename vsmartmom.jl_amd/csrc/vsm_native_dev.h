@@ -509,7 +509,7 @@ template <int RT, bool ON>
 struct nmv_slots {};
 template <int RT>
 struct nmv_slots<RT, true> {
-  double mv[2 * RT][16 * RT];
+  double mv[2][16 * RT];
 };
 // LDS block of a workgroup
 template <int RT, bool MV = false>
@@ -523,26 +523,30 @@ struct nsmem : nmv_slots<RT, MV> {
   int gjs[128];
 };
 
-// Source vectors without spare columns: y = [A] x as VALU mat-vecs over the A-form.  Wave w takes the columns of its own strip
-// (lane = row) and leaves its partial sum in slot w; after a barrier nmv_sum adds the RT slots.
-template <int RT>
-__device__ __forceinline__ void nmv_part(const double* A, const double* x, double sc, double* slot, const npos<RT>& p) {
-  if (p.lane < 16 * RT) {
-    double acc = 0.0;
+// Source vectors without spare columns: y = sc [A] x as a VALU mat-vec over the A-form.  Wave w takes the rows of row tile w
+// through the fragment pattern of the products (lane (m, kq): row 16 w + m, k = 4 ks + kq -- conflict-free, four per-lane bases +
+// instruction offsets: nothing for LICM to hoist into registers, which is what the column-wise form of round 5 paid its 160
+// spilled registers for), reduces over the four lane groups and writes its sixteen finished rows: no partial sums.
+template <int RT, int KS>
+__device__ __forceinline__ void nmv_rows(unsigned dA, const double* x, double sc, double* out, npos<RT>& p) {
+  unsigned ab[4];
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int k = 16 * p.wave + kk;
-      acc = fma(A[naf_idx<RT>(p.lane, k)], x[k], acc);
-    }
-    slot[p.lane] = acc * sc;
+  for (int j = 0; j < 4; ++j) {
+    ab[j] = p.fb[j] + dA + 512u * (unsigned)p.wave;
+    asm volatile("" : "+v"(ab[j]));
   }
-}
-template <int RT, typename SM>
-__device__ __forceinline__ double nmv_sum(SM& sm, int base, int i) {
-  double v = sm.mv[base][i];
+  unsigned xb = nlds_addr(x) + 8u * (unsigned)p.kq;
+  asm volatile("" : "+v"(xb));
+  double acc = 0.0;
 #pragma unroll
-  for (int w = 1; w < RT; ++w) v += sm.mv[base + w][i];
-  return v;
+  for (int ks = 0; ks < KS; ++ks) {
+    const double a = *(reinterpret_cast<const nlds_d*>((unsigned long long)ab[ks & 3]) + 64 * ks * RT);
+    const double xv = *(reinterpret_cast<const nlds_d*>((unsigned long long)xb) + 4 * ks);
+    acc = fma(a, xv, acc);
+  }
+  acc += __shfl_xor(acc, 16);
+  acc += __shfl_xor(acc, 32);
+  if (p.kq == 0) out[16 * p.wave + p.l15] = acc * sc;
 }
 
 }  // namespace
