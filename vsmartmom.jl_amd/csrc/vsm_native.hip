@@ -19,6 +19,10 @@
 #include "vsm_native_dev.h"
 #include "vsm_native_run.h"
 
+#ifndef VSM_NATIVE_PARK_RT
+#define VSM_NATIVE_PARK_RT 3
+#endif
+
 namespace vsm {
 
 struct nlayer_comps {
@@ -194,6 +198,10 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   double* J0_m = J0_p + G::NP;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
   constexpr bool RID = c2 < G::NP;
+  // Three row tiles (168 registers, strips of 24): at most FIVE live strips.  Z = R+- t-- is not needed between its product and
+  // the closing pairs: it waits in the R+- record of the composite (consumed into P at the entry, overwritten by the new R+- at
+  // the end; a lane reads back exactly the addresses it wrote), and R-+ is requested after R+- / T++ have left.
+  constexpr bool PARK = VSM_NATIVE_PARK_RT > 0 && RT == VSM_NATIVE_PARK_RT;
   const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
   int slot = 0;
@@ -237,6 +245,7 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
           zd[row] = vJp[row] + E.v[ta][r];
         }
     }
+    if constexpr (PARK) nst_native(R_pm, Z, p);   // (its old contents are in P; the new R+- overwrites it at the end)
     const double nrm = nnorm(E, n, sm, slot, p);   // (b): every wave is done reading [R+-]
     if constexpr (!RID) {   // z = J0+ + R+- j0- ; vs = T-- j0-
       if (tid < G::NP) {
@@ -276,7 +285,7 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   __builtin_amdgcn_sched_barrier(0);      // (the composite strips are requested once X and Y are dead, not above their stores)
   nstrip<RT> Tpp, Rmp;
   nld_native(Tpp, T_pp, p);
-  nld_native(Rmp, R_mp, p);
+  if constexpr (PARK) nld_native(Z, R_pm, p); else nld_native(Rmp, R_mp, p);
   __syncthreads();                        // (g)
   if constexpr (!RID) {   // T21 z , Y z
     nmv_rows<RT, KS>(dP, vz, 1.0, sm.mv[0], p);
@@ -288,7 +297,7 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Tpp.v[ta][r] = laneA ? vz[p.row(ta, r)] : Tpp.v[ta][r];
-        Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the native record keeps the rider column of the previous layer step)
+        if constexpr (!PARK) Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];   // (the native record keeps the rider column of the previous layer step)
       }
   }
   {
@@ -304,6 +313,16 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
           const int row = p.row(ta, r);
           J0_p[row] = vjp[row] + acc.v[ta][r];
         }
+    }
+  }
+  if constexpr (PARK) {
+    __builtin_amdgcn_sched_barrier(0);      // (requested once r_s and acc have left)
+    nld_native(Rmp, R_mp, p);
+    if (own_wave) {
+#pragma unroll
+      for (int ta = 0; ta < RT; ++ta)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Rmp.v[ta][r] = laneA ? 0.0 : Rmp.v[ta][r];
     }
   }
   nmm2<RT, KS>(Rmp, V, dQ, Tpp, Z, p);       // R-+ = R-+ + Y T++ ; T-- = V + Y Z
