@@ -266,12 +266,14 @@ struct n32dpar {
 };
 template <int RT>
 __device__ __forceinline__ void n32dsym(n32strip<RT>& d, const n32strip<RT>& x, const n32dpar<RT>& dp) {
+  unsigned rows = dp.rows;   // (opaque: the sign masks are two VALU operations each -- not 4 RT registers kept from call to call)
+  asm volatile("" : "+v"(rows));
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = 4 * ta + r;
-      const unsigned sbit = (dp.rows << (31 - n)) & 0x80000000u;
+      const unsigned sbit = (rows << (31 - n)) & 0x80000000u;
       d.v[ta][r] = __int_as_float(__float_as_int(x.v[ta][r]) ^ (int)sbit);
     }
 }

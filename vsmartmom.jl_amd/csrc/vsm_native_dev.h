@@ -234,12 +234,14 @@ struct ndpar {
 };
 template <int RT>
 __device__ __forceinline__ void ndsym(nstrip<RT>& d, const nstrip<RT>& x, const ndpar<RT>& dp) {
+  unsigned rows = dp.rows;   // (opaque: the sign masks are two VALU operations each -- not 4 RT registers kept from call to call)
+  asm volatile("" : "+v"(rows));
 #pragma unroll
   for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = 4 * ta + r;
-      const unsigned sbit = (dp.rows << (31 - n)) & 0x80000000u;
+      const unsigned sbit = (rows << (31 - n)) & 0x80000000u;
       d.v[ta][r] = __hiloint2double(__double2hiint(x.v[ta][r]) ^ (int)sbit, __double2loint(x.v[ta][r]));
     }
 }
