@@ -309,11 +309,12 @@ def main():
             k_ms = sum(e[0].elapsed_time(e[1]) for e in ev_dense)
             k_flops = step_flops(ev_dense)
             ks = (N + 3) // 4
-            kernel_name = "k_layer_native<%d, %d>" % (native_rt(N), ks)
-            interval_kernels = ["k_elemental_native", kernel_name]
+            fam = "native32" if cfg["FT"] == "f32" else "native"   # (Float32 models: the FP32 family, vsm_native32.hip)
+            kernel_name = "k_layer_%s<%d, %d>" % (fam, native_rt(N), ks)
+            interval_kernels = ["k_elemental_" + fam, kernel_name]
             moments_per_launch = len(dense)
             n_launch = len(ev_dense)
-        else:   # the dense moments are beyond the native kernels (C4: N = 96): their layer steps run on the reference-layout kernels
+        else:   # the dense moments are beyond the native kernels: their layer steps run on the reference-layout kernels
             legacy = [e for e in ev if not e[5]]
             k_ms = sum(e[0].elapsed_time(e[1]) for e in legacy)
             k_flops, n_launch = step_flops(legacy), len(legacy)
@@ -344,7 +345,7 @@ def main():
         kernel_name = "k_elemental_doubling + k_interaction11"
     # the committed PMC passes cover the default (Rayleigh, m = 0..2) workload of a config only
     build = vsm._lib.build_info()
-    tk = ([kernel_name, "k_elemental_native<%d," % native_rt(N)] if native and dense
+    tk = ([kernel_name, "k_elemental_%s<%d," % ("native32" if cfg["FT"] == "f32" else "native", native_rt(N))] if native and dense
           else [kernel_name, "k_elemental_img"])
     traffic, traffic_src, traffic_hash, traffic_note = (hbm_traffic_per_launch(tk, cfg, S_local, build["source_hash"])
                                                         if args.variant == "rayleigh" else (None, None, None, "no profile of this variant"))

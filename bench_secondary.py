@@ -80,8 +80,8 @@ def c4(vsm, torch, arch, o2a, points=12500):
         return R.cpu(), T.cpu()
     wall, dev, _ = _timed(torch, step)
     e = _entry("C4", "N=96 FP32, 60 layers, m=0..2, Rayleigh + O2, Lambertian (one GPU's share of BASELINE configs[3])", points, wall, dev,
-               scene.flops_per_point(), "f32", "k_layer_strip32_mm<6> (m = 1, 2) + k_layer_native<4, 16> (m = 0: a 64-row (I,Q) block on the "
-               "native FP64 kernels with FP32 storage, U as a diagonal step)")
+               scene.flops_per_point(), "f32", "k_layer_native32<6, 24> (m = 1, 2: two points per workgroup) + k_layer_native32<4, 16> (m = 0: a 64-row "
+               "(I,Q) block, U as a diagonal step): FP32 records and arithmetic")
     del scene
     return e
 

@@ -196,9 +196,12 @@ function _layer_coupling(p::CoreScatteringOpticalProperties, N::Int, n::Int, ::T
 end
 function _native_open!(c::CompositeLayer{FT}, qp::QuadPoints, n::Int, m::Int, mask::Cint, F₀, import_arrays::Bool) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺)
-    ccall(_sym(:vsm_run_supported), Cint, (Cint, Cint, Cint), N, n, mask) == 1 || return false
+    # (Float32 models: FP32 records and arithmetic, blocks of up to 96 rows -- vsm_run_supported_f32 / vsm_run_workspace_bytes_f32)
+    f_sup = FT === Float32 ? :vsm_run_supported_f32 : :vsm_run_supported
+    f_ws = FT === Float32 ? :vsm_run_workspace_bytes_f32 : :vsm_run_workspace_bytes
+    ccall(_sym(f_sup), Cint, (Cint, Cint, Cint), N, n, mask) == 1 || return false
     cm = Cint[mask]; ms = Cint[m]
-    nbytes = ccall(_sym(:vsm_run_workspace_bytes), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, S, 1, cm)
+    nbytes = ccall(_sym(f_ws), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, S, 1, cm)
     ws = get(_native_ws, c, nothing)
     if ws === nothing || sizeof(ws) < nbytes
         ws = _native_ws[c] = ROCArray{Float64}(undef, max(2, cld(Int(nbytes), 8)))
