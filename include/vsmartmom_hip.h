@@ -562,6 +562,15 @@ int vsm_mix_Z_f64(int N, int S, int ncomp, const double* Zpp_comp, const double*
                   double* Zmp, void* stream);
 int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Zmp_comp, const float* fcomp, float* Zpp,
                   float* Zmp, void* stream);
+/* vsm_mix_Z_moments_*: the same for nm <= 24 Fourier moments of one layer in one launch, the moments folded into the batch axis
+ * (the layer walk of a small batch takes its moments as ONE batch: rt_kernel!'s arguments of layer iz for (moment, point) pairs):
+ * Zpp_comp_h / Zmp_comp_h[nm] = HOST arrays of device pointers to the moments' component stacks [N,N,ncomp]; block im * S + s of
+ * Zpp / Zmp [N,N,nm*S] = sum_k fcomp[k + ncomp*s] Z_k(moment im).  ncomp = 0: a layer with one scatterer -- block `single` of
+ * every stack, copied (fcomp unused). */
+int vsm_mix_Z_moments_f64(int N, int S, int ncomp, int nm, const double* const* Zpp_comp_h, const double* const* Zmp_comp_h, int single,
+                          const double* fcomp, double* Zpp, double* Zmp, void* stream);
+int vsm_mix_Z_moments_f32(int N, int S, int ncomp, int nm, const float* const* Zpp_comp_h, const float* const* Zmp_comp_h, int single,
+                          const float* fcomp, float* Zpp, float* Zmp, void* stream);
 
 /* ---- a run with the CompositeLayer in kernel-native layout ---------------------
  * The layer loop of rt_run (src/CoreRT/rt_run.jl:383-453: `for iz = 1:Nz ... rt_kernel!(RS_type, pol_type, SFI, added_layer,

@@ -99,6 +99,7 @@ _SIGS = {
     "vsm_layer_forward_thermal_{T}": (_I, [_P, _I, _I, _P, _P, _P, _I, _P, _P, _LL, _P, _I, _P, _P]),
     "vsm_layer_forward_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "vsm_mix_Z_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "vsm_mix_Z_moments_{T}": (_I, [_I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "vsm_elemental_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _P, _P]),
     "vsm_doubling_{T}": (_I, [_I, _I, _I, _I, _P, _P, _P, _P]),
     "vsm_noscat_layer_{T}": (_I, [_P, _I, _P, _P, _P]),

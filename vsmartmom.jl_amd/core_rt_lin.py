@@ -352,6 +352,11 @@ class SceneLin:
     # end.  (The sum over moments is then taken lane by lane: equal to the sequential walk up to the rounding of the reordering.)
     LANES = 8
     LANE_POINTS = 64
+    # A folded group of at most PARALLEL_LAYER_POINTS (moment, point) pairs doubles all its layers side by side on the lane streams
+    # (each layer into an added layer of its own: 12 (1 + P) N^2 elements per pair and layer) before the interactions walk the
+    # column (_run_folded)
+    PARALLEL_LAYERS = True
+    PARALLEL_LAYER_POINTS = 128
 
     def _lane_state(self, k):
         """Workspace of moment lane k (lane 0: the scene's own buffers)."""
@@ -428,9 +433,7 @@ class SceneLin:
         if fold and not can_fold:
             raise _lib.VSMError("SceneLin.run(fold=True): needs a scene without aerosol Jacobian slots and more than two moments")
         st = [self._lane_state(k) for k in range(lanes)]
-        for w in st:
-            for t in (w["R"], w["T"], w["Rd"], w["Td"]):
-                t.zero_()
+        torch._foreach_zero_([t for w in st for t in (w["R"], w["T"], w["Rd"], w["Td"])])
         if S == 0:
             return self.R, self.T, self.Rd, self.Td
         if fold:
@@ -489,16 +492,31 @@ class SceneLin:
         g = dict(added=CR.make_added_layer(FT, arch, (N, N), Sf), al=AddedLayerLin(FT, arch, P, N, Sf),
                  comp=CR.make_composite_layer(FT, arch, (N, N), Sf), cl=CompositeLayerLin(FT, arch, P, N, Sf),
                  expk=torch.empty(Sf, dtype=self.dt, device=self.expk.device), F0=self.F0.repeat(n, 1).contiguous(), layers=[])
-        for iz in range(self.fwd.Nz):
-            ly0 = group[0]["layers"][iz]
-            mats = [mom["layers"][iz]["props"].materialize() for mom in group]
-            Zpp = torch.cat([p_.Zpp.expand(S, N, N) for p_ in mats]).contiguous()
-            Zmp = torch.cat([p_.Zmp.expand(S, N, N) for p_ in mats]).contiguous()
-            p0 = mats[0]
-            props = CR.DeviceLayerOptics(p0.tau.repeat(n), p0.varpi.repeat(n), Zpp, Zmp, p0.max_tau_varpi, p0.tau_h, p0.varpi_h)
-            g["layers"].append(dict(props=props, dtau=ly0["dtau"].repeat(n), tau_sum=ly0["tau_sum"].repeat(n),
-                                    dtd=self.dtau_dot_all[iz].repeat(1, n).contiguous(), vd=self.varpi_dot[iz].repeat(1, n).contiguous(),
-                                    tsd=self.tau_sum_dot[iz].repeat(1, n).contiguous()))
+        # per-layer inputs of the folded walk: the optics of a layer do not depend on the moment (repeated along the folded axis, all
+        # layers in one operation each), its phase matrices do (vsm_mix_Z_moments: every moment's Z of a layer in one launch)
+        fwd = self.fwd
+        lo, hi, L = fwd.lo, fwd.hi, fwd.Nz
+        tau_f, varpi_f = fwd.tau[:L, lo:hi].repeat(1, n), fwd.varpi[:L, lo:hi].repeat(1, n)
+        dtau_f, tsum_f = fwd.dtau[:L, lo:hi].repeat(1, n), fwd.tau_sum[:L, lo:hi].repeat(1, n)
+        dtd_f, vd_f = self.dtau_dot_all.repeat(1, 1, n), self.varpi_dot.repeat(1, 1, n)
+        tsd_f = self.tau_sum_dot.repeat(1, 1, n)
+        Zf = torch.empty((2, L, Sf, N, N), dtype=self.dt, device=self.expk.device)
+        for iz in range(L):
+            props_m = [mom["layers"][iz]["props"] for mom in group]
+            p0 = props_m[0]
+            mixed = p0.fcomp is not None
+            single = 0
+            if not mixed:   # (one scatterer: the props hold the one-block views Zc[m][k : k + 1])
+                single = int(fwd.zcomp[iz][1])
+            zp = (C.c_void_p * n)(*[fwd.Zc[mom["m"]][0].data_ptr() for mom in group])
+            zm = (C.c_void_p * n)(*[fwd.Zc[mom["m"]][1].data_ptr() for mom in group])
+            _lib.call("vsm_mix_Z_moments", self.dt, N, S, int(p0.fcomp.shape[1]) if mixed else 0, n, zp, zm, single,
+                      CR._ptr(p0.fcomp) if mixed else None, CR._ptr(Zf[0, iz]), CR._ptr(Zf[1, iz]), CR._stream_ptr())
+            props = CR.DeviceLayerOptics(tau_f[iz], varpi_f[iz], Zf[0, iz], Zf[1, iz], p0.max_tau_varpi, p0.tau_h, p0.varpi_h)
+            g["layers"].append(dict(props=props, dtau=dtau_f[iz], tau_sum=tsum_f[iz], dtd=dtd_f[iz], vd=vd_f[iz], tsd=tsd_f[iz]))
+        if self.PARALLEL_LAYERS and 0 < Sf <= self.PARALLEL_LAYER_POINTS:
+            g["per_layer"] = [dict(added=CR.make_added_layer(FT, arch, (N, N), Sf), al=AddedLayerLin(FT, arch, P, N, Sf),
+                                   expk=torch.empty(Sf, dtype=self.dt, device=self.expk.device)) for _ in range(self.fwd.Nz)]
         self._fold[key] = g
         return g
 
@@ -513,19 +531,56 @@ class SceneLin:
         for w in st[1:]:
             w["stream"].wait_stream(main)       # (the zeroing of the accumulators and whatever produced the inputs)
 
+        def double_layer(gi, group, iz, lane, added, al, expk):
+            """elemental! (lin) + doubling! (lin) of layer iz of a folded group on the current stream (work buffers of `lane`)."""
+            global _lane
+            _lane = lane
+            g = self._fold_group(gi, group)
+            fl, ly0 = g["layers"][iz], group[0]["layers"][iz]
+            elemental_lin_(pol, fl["tau_sum"], fl["tsd"], fl["dtau"], fl["dtd"], g["F0"], fl["props"], fl["vd"], None, None, (0, 0),
+                           pl, group[0]["m"], ly0["nd"], self.dq, added, al)
+            _lib.call("vsm_layer_expk", dt, len(group) * S, CR._ptr(fl["dtau"]), mu0, CR._ptr(expk), CR._stream_ptr())
+            doubling_allparams_(pol, expk, ly0["nd"], added, al, fl["dtd"], qp.mu0, pl)
+
+        # elemental! + doubling! of a layer depend on nothing but its own optics (rt_kernel_lin.jl:87-160: the added layer is built
+        # before interaction! is called).  With so few (moment, point) pairs that one layer's launch fills a sixth of the chip, ALL
+        # layers of both groups are doubled side by side on the lane streams, each into an added layer of its own, and only the
+        # interactions -- the one sequential part of the adding method -- walk the column in order.  (Plain fork / join of the lane
+        # streams from the main stream: what a HIP graph capture takes; layer streams forked from a lane stream crashed
+        # hipStreamEndCapture.)
+        gstate = [self._fold_group(gi, grp) if grp else None for gi, grp in enumerate(groups)]
+        pre = lanes > 1 and all(g_ is None or g_.get("per_layer") is not None for g_ in gstate)
+        if pre:
+            cnt = 0
+            for gi, grp in enumerate(groups):
+                if not grp:
+                    continue
+                for iz in range(self.fwd.Nz):
+                    k = 1 + cnt % (lanes - 1)
+                    cnt += 1
+                    b = gstate[gi]["per_layer"][iz]
+                    with torch.cuda.stream(st[k]["stream"]):
+                        double_layer(gi, grp, iz, k, b["added"], b["al"], b["expk"])
+            _lane = 0
+            for w in st[1:]:
+                main.wait_stream(w["stream"])
+            for w in st[1:]:
+                w["stream"].wait_stream(main)
+
         def chain(gi, group, lane):
             """The layer walk of a folded group on the current stream (work buffers of `lane`)."""
             global _lane
             _lane = lane
-            g = self._fold_group(gi, group)
+            g = gstate[gi]
             Sf = len(group) * S
-            added, al, comp, cl = g["added"], g["al"], g["comp"], g["cl"]
-            for iz, fl in enumerate(g["layers"]):
+            comp, cl = g["comp"], g["cl"]
+            for iz in range(self.fwd.Nz):
                 ly0 = group[0]["layers"][iz]
-                elemental_lin_(pol, fl["tau_sum"], fl["tsd"], fl["dtau"], fl["dtd"], g["F0"], fl["props"], fl["vd"], None, None, (0, 0),
-                               pl, group[0]["m"], ly0["nd"], self.dq, added, al)
-                _lib.call("vsm_layer_expk", dt, Sf, CR._ptr(fl["dtau"]), mu0, CR._ptr(g["expk"]), CR._stream_ptr())
-                doubling_allparams_(pol, g["expk"], ly0["nd"], added, al, fl["dtd"], qp.mu0, pl)
+                if pre:
+                    added, al = g["per_layer"][iz]["added"], g["per_layer"][iz]["al"]
+                else:
+                    added, al = g["added"], g["al"]
+                    double_layer(gi, group, iz, lane, added, al, g["expk"])
                 if iz == 0:
                     CR.copy_added_to_composite_(comp, added)
                     a_, c_ = al.cstruct(), cl.cstruct()
@@ -539,9 +594,9 @@ class SceneLin:
             global _lane
             _lane = lane
             sl = slice(im * S, (im + 1) * S)
-            for f in ("R_mp", "R_pm", "T_pp", "T_mm", "J0_p", "J0_m"):
-                getattr(w["comp"], f).copy_(getattr(comp, f)[sl])
-                getattr(w["cl"], f).copy_(getattr(cl, f)[:, sl])
+            fields = ("R_mp", "R_pm", "T_pp", "T_mm", "J0_p", "J0_m")
+            torch._foreach_copy_([getattr(w["comp"], f) for f in fields] + [getattr(w["cl"], f) for f in fields],
+                                 [getattr(comp, f)[sl] for f in fields] + [getattr(cl, f)[:, sl] for f in fields])   # (one multi-tensor launch)
             self._finish_moment(mom, w)
 
         try:
@@ -572,10 +627,7 @@ class SceneLin:
         for w in st[1:]:
             main.wait_stream(w["stream"])
         for w in st[1:]:
-            self.R += w["R"]
-            self.T += w["T"]
-            self.Rd += w["Rd"]
-            self.Td += w["Td"]
+            torch._foreach_add_([self.R, self.T, self.Rd, self.Td], [w["R"], w["T"], w["Rd"], w["Td"]])
         return self.R, self.T, self.Rd, self.Td
 
     def _run_moment(self, mom, w):

@@ -634,6 +634,18 @@ int vsm_mix_Z_f32(int N, int S, int ncomp, const float* Zpp_comp, const float* Z
   VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 1 && Zpp_comp && Zmp_comp && fcomp && Zpp && Zmp, "mix_Z: bad argument");
   return mix_Z<float>(N, S, ncomp, Zpp_comp, Zmp_comp, fcomp, Zpp, Zmp, as_stream(stream));
 }
+int vsm_mix_Z_moments_f64(int N, int S, int ncomp, int nm, const double* const* Zpp_comp, const double* const* Zmp_comp, int single,
+                          const double* fcomp, double* Zpp, double* Zmp, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 0 && nm >= 0 && Zpp_comp && Zmp_comp && (ncomp == 0 || fcomp) && Zpp && Zmp && single >= 0,
+              "mix_Z_moments: bad argument");
+  return mix_Z_moments<double>(N, S, ncomp, nm, Zpp_comp, Zmp_comp, single, fcomp, Zpp, Zmp, as_stream(stream));
+}
+int vsm_mix_Z_moments_f32(int N, int S, int ncomp, int nm, const float* const* Zpp_comp, const float* const* Zmp_comp, int single,
+                          const float* fcomp, float* Zpp, float* Zmp, void* stream) {
+  VSM_REQUIRE(N > 0 && S >= 0 && ncomp >= 0 && nm >= 0 && Zpp_comp && Zmp_comp && (ncomp == 0 || fcomp) && Zpp && Zmp && single >= 0,
+              "mix_Z_moments: bad argument");
+  return mix_Z_moments<float>(N, S, ncomp, nm, Zpp_comp, Zmp_comp, single, fcomp, Zpp, Zmp, as_stream(stream));
+}
 int vsm_layer_forward_multi_f64(const vsm_quad_f64* q, int S, int nm, const int* m, int ndoubl, const double* dtau,
                                 const double* varpi, const double* tau_sum, const double* F0, int ncomp,
                                 const double* const* Zpp, const double* const* Zmp, long long z_stride, const double* fcomp,

@@ -158,6 +158,59 @@ __global__ void k_mix_Z(long long NN, int ncomp, const T* __restrict__ Zc_pp, co
   Zpp[s * NN + e] = ap;
   Zmp[s * NN + e] = am;
 }
+// The same for nm Fourier moments of ONE layer in one launch, the moments folded into the spectral axis: block (im S + s) of the
+// output is the mix of moment im's component stack with point s's weights (the weights do not depend on the moment); ncomp = 0:
+// the layer has a single scatterer -- block `single` of every stack, copied.  (A small batch walks the layers with its moments
+// as one batch: this is the per-layer input of that walk, one launch instead of nm mixes and a concatenation.)
+template <typename T>
+struct mixm_args {
+  const T* zp[VSM_MM_MAX];
+  const T* zm[VSM_MM_MAX];
+};
+template <typename T>
+__global__ void k_mix_Z_moments(long long NN, int S, int ncomp, int single, mixm_args<T> a, const T* __restrict__ fcomp, T* Zpp, T* Zmp) {
+  const long long e = (long long)blockIdx.z * 256 + threadIdx.x;
+  if (e >= NN) return;
+  const long long s = blockIdx.x, im = blockIdx.y;
+  const T* zp = a.zp[im];
+  const T* zm = a.zm[im];
+  T ap = 0, am = 0;
+  if (ncomp == 0) {
+    ap = zp[single * NN + e];
+    am = zm[single * NN + e];
+  } else {
+    for (int k = 0; k < ncomp; ++k) {
+      const T f = fcomp[s * ncomp + k];
+      ap += f * zp[k * NN + e];
+      am += f * zm[k * NN + e];
+    }
+  }
+  Zpp[(im * S + s) * NN + e] = ap;
+  Zmp[(im * S + s) * NN + e] = am;
+}
+template <typename T>
+int mix_Z_moments(int N, int S, int ncomp, int nm, const T* const* Zpp_comp, const T* const* Zmp_comp, int single, const T* fcomp,
+                  T* Zpp, T* Zmp, hipStream_t st) {
+  if (S <= 0 || nm <= 0) return VSM_OK;
+  if (nm > VSM_MM_MAX) {
+    set_error("mix_Z_moments: %d moments per call (limit %d)", nm, VSM_MM_MAX);
+    return VSM_ERR_INVALID_ARG;
+  }
+  mixm_args<T> a;
+  for (int k = 0; k < VSM_MM_MAX; ++k) {
+    a.zp[k] = Zpp_comp[k < nm ? k : 0];
+    a.zm[k] = Zmp_comp[k < nm ? k : 0];
+  }
+  const long long NN = (long long)N * N;
+  hipLaunchKernelGGL(k_mix_Z_moments<T>, dim3(S, nm, (unsigned)((NN + 255) / 256)), dim3(256), 0, st, NN, S, ncomp, single, a, fcomp, Zpp,
+                     Zmp);
+  VSM_LAUNCH_CHECK("k_mix_Z_moments");
+  return VSM_OK;
+}
+template int mix_Z_moments<double>(int, int, int, int, const double* const*, const double* const*, int, const double*, double*, double*,
+                                   hipStream_t);
+template int mix_Z_moments<float>(int, int, int, int, const float* const*, const float* const*, int, const float*, float*, float*, hipStream_t);
+
 template <typename T>
 int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T* fcomp, T* Zpp, T* Zmp, hipStream_t st) {
   if (S <= 0) return VSM_OK;

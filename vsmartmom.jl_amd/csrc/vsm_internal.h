@@ -231,6 +231,9 @@ struct zsrc {
 };
 template <typename T>
 int mix_Z(int N, int S, int ncomp, const T* Zpp_comp, const T* Zmp_comp, const T* fcomp, T* Zpp, T* Zmp, hipStream_t st);
+template <typename T>
+int mix_Z_moments(int N, int S, int ncomp, int nm, const T* const* Zpp_comp, const T* const* Zmp_comp, int single, const T* fcomp,
+                  T* Zpp, T* Zmp, hipStream_t st);
 
 // ---- column-strip kernels (FP64, 32 < N <= 60; two workgroups per CU): vsm_strip.hip ----------------
 bool strip_supported(int N);
