@@ -307,6 +307,18 @@ int vsm_elemental_lin_f32(const vsm_quad_f32* q, int S, int m, int ndoubl, const
                           const float* tau_sum_dot, const float* Zpp_dot, const float* Zmp_dot,
                           long long zd_stride_s, long long zd_stride_p, const vsm_added_f32* added,
                           const vsm_added_lin_f32* added_lin, void* stream);
+/* vsm_elemental_lin_fold_*: vsm_elemental_lin_* (no Z_dot) for a batch with Fourier moments folded into it -- a small batch walks
+ * the layers with its (moment, point) pairs as ONE batch (per-point Z: z_stride = N*N), and the moment enters elemental! only
+ * through m == 0 (the weight 1/2 against 1/4, elemental_lin.jl:77-206): the first n_m0 points of the batch are pairs of m = 0, the
+ * others of moments m > 0 (`m`: any of them). */
+int vsm_elemental_lin_fold_f64(const vsm_quad_f64* q, int S, int m, int n_m0, int ndoubl, const double* dtau, const double* varpi,
+                               const double* tau_sum, const double* F0, const double* Zpp, const double* Zmp, long long z_stride,
+                               int p_layer, const double* dtau_dot, const double* varpi_dot, const double* tau_sum_dot,
+                               const vsm_added_f64* added, const vsm_added_lin_f64* al, void* stream);
+int vsm_elemental_lin_fold_f32(const vsm_quad_f32* q, int S, int m, int n_m0, int ndoubl, const float* dtau, const float* varpi,
+                               const float* tau_sum, const float* F0, const float* Zpp, const float* Zmp, long long z_stride,
+                               int p_layer, const float* dtau_dot, const float* varpi_dot, const float* tau_sum_dot,
+                               const vsm_added_f32* added, const vsm_added_lin_f32* al, void* stream);
 /* elemental! (lin) for a layer whose phase matrix is a per-point mix of component matrices (aerosol Jacobians): as
  * vsm_elemental_lin_* with Z = sum_{c < ncomp} fz[c, s] Zc[c] (zsel < 0) or Z = Zc[zsel] (zsel >= 0, fz unused) and
  * Z_dot[:, :, s, p] = sum_{c < ncomp_total} zdcoef[c, p, s] Zc[c]; Zc_pp / Zc_mp: [N, N, ncomp_total] blocks of one Fourier

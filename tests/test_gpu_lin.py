@@ -255,6 +255,21 @@ def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
     Ro, To, Rdo, Tdo = OL.rt_run_lin(om, OL.LinModel([ga]))
     R, T, Rd, Td = scene.results_host()
     assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9 and _rel(Rd, Rdo) < 1e-8 and _rel(Td, Tdo) < 1e-8
+    # the folded walk's own forms: all layers doubled side by side before the interactions (PARALLEL_LAYERS) and the pairs of m = 0
+    # in the same batch as those of m > 0 (MERGE_M0, vsm_elemental_lin_fold) reorder launches, not arithmetic: bit for bit
+    SL = vsm.CoreRTLin.SceneLin
+    saved = (SL.PARALLEL_LAYERS, SL.MERGE_M0)
+    try:
+        for pl_, mg_ in ((False, False), (True, False), (False, True)):
+            SL.PARALLEL_LAYERS, SL.MERGE_M0 = pl_, mg_
+            scene._fold = {}
+            alt = [t.clone() for t in scene.run(lanes=4, fold=True)]
+            torch.cuda.synchronize()
+            for a, b in zip(fold, alt):
+                assert torch.equal(a, b), (pl_, mg_)
+    finally:
+        SL.PARALLEL_LAYERS, SL.MERGE_M0 = saved
+        scene._fold = {}
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 33), ("IQUV", 43)])   # N = 7, 57 (fused strip kernels), 100 (operator level)

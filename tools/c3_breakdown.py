@@ -33,7 +33,7 @@ def t(f):
     return 1e3 * (time.perf_counter() - t0), r
 
 
-for graph in (False, True):
+for graph in ((False,) if "--eager-only" in sys.argv else (False, True)):
     scene.graph_replay = graph
     for rep in range(3):
         a, _ = t(lambda: (scene.fwd.upload(), scene.fwd.prepare()))

@@ -125,6 +125,7 @@ _SIGS = {
     "vsm_doubling_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_interaction_lin_work_elems": (_SZ, [_I, _I, _I]),
     "vsm_elemental_lin_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P, _LL, _LL, _P, _P, _P]),
+    "vsm_elemental_lin_fold_{T}": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P, _P]),
     "vsm_elemental_lin_mix_{T}": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "vsm_doubling_lin_{T}": (_I, [_I, _I, _I, _I, _P, _P, "{R}", _I, _P, _P, _P, _P]),
     "vsm_interaction_lin_{T}": (_I, [_I, _I, _I, _P, _P, _P, _P, _P, _P]),

@@ -77,9 +77,16 @@ def to_device_zdot(Zd: Optional[np.ndarray], arch, FT):
 
 
 def elemental_lin_(pol, tau_sum, tau_sum_dot, dtau, dtau_dot, F0, props: CR.DeviceLayerOptics, varpi_dot, Zpp_dot,
-                   Zmp_dot, zd_strides, p_layer, m, ndoubl, dq: CR.DeviceQuad, added: CR.AddedLayer, added_lin: AddedLayerLin):
-    """elemental! (lin): elemental_lin.jl:77-206."""
+                   Zmp_dot, zd_strides, p_layer, m, ndoubl, dq: CR.DeviceQuad, added: CR.AddedLayer, added_lin: AddedLayerLin,
+                   n_m0: int = 0):
+    """elemental! (lin): elemental_lin.jl:77-206.  n_m0 > 0: a batch with Fourier moments folded into it whose first n_m0 points are
+    (moment 0, point) pairs and the others pairs of moments m > 0 (vsm_elemental_lin_fold)."""
     q, a, al = dq.cstruct(), added.cstruct(), added_lin.cstruct()
+    if n_m0:
+        _lib.call("vsm_elemental_lin_fold", added.dtype, C.byref(q), added.nSpec, m, int(n_m0), ndoubl, CR._ptr(dtau),
+                  CR._ptr(props.varpi), CR._ptr(tau_sum), CR._ptr(F0), CR._ptr(props.Zpp), CR._ptr(props.Zmp), props.z_stride, p_layer,
+                  CR._ptr(dtau_dot), CR._ptr(varpi_dot), CR._ptr(tau_sum_dot), C.byref(a), C.byref(al), CR._stream_ptr())
+        return
     _lib.call("vsm_elemental_lin", added.dtype, C.byref(q), added.nSpec, m, ndoubl, CR._ptr(dtau), CR._ptr(props.varpi),
               CR._ptr(tau_sum), CR._ptr(F0), CR._ptr(props.Zpp), CR._ptr(props.Zmp), props.z_stride, p_layer,
               CR._ptr(dtau_dot), CR._ptr(varpi_dot), CR._ptr(tau_sum_dot), CR._ptr(Zpp_dot), CR._ptr(Zmp_dot),
@@ -357,6 +364,7 @@ class SceneLin:
     # column (_run_folded)
     PARALLEL_LAYERS = True
     PARALLEL_LAYER_POINTS = 128
+    MERGE_M0 = True          # the folded walk takes m = 0 and the moments m > 0 as one batch (False: two batches, two chains)
 
     def _lane_state(self, k):
         """Workspace of moment lane k (lane 0: the scene's own buffers)."""
@@ -525,6 +533,10 @@ class SceneLin:
         pol, qp, dt, S, N, P, pl = self.pol, self.qp, self.dt, self.S, self.N, self.P, self.pl
         moms = self.fwd.moments
         groups = [[m_ for m_ in moms if m_["m"] == 0], [m_ for m_ in moms if m_["m"] > 0]]
+        if self.MERGE_M0 and groups[0] and groups[1] and len(moms) <= 24:
+            # ONE folded batch: the pairs of m = 0 in front (vsm_elemental_lin_fold tells them apart; doubling! and interaction!
+            # do not know the moment) -- half the launches of the layer walk, one chain of interactions instead of two
+            groups = [[], groups[0] + groups[1]]
         mu0 = C.c_double(qp.mu0) if dt == torch.float64 else C.c_float(qp.mu0)
         main = torch.cuda.current_stream()
         lanes = len(st)
@@ -537,8 +549,9 @@ class SceneLin:
             _lane = lane
             g = self._fold_group(gi, group)
             fl, ly0 = g["layers"][iz], group[0]["layers"][iz]
+            n_m0 = S * sum(1 for m_ in group if m_["m"] == 0) if group[-1]["m"] > 0 else 0
             elemental_lin_(pol, fl["tau_sum"], fl["tsd"], fl["dtau"], fl["dtd"], g["F0"], fl["props"], fl["vd"], None, None, (0, 0),
-                           pl, group[0]["m"], ly0["nd"], self.dq, added, al)
+                           pl, group[-1]["m"], ly0["nd"], self.dq, added, al, n_m0=n_m0)
             _lib.call("vsm_layer_expk", dt, len(group) * S, CR._ptr(fl["dtau"]), mu0, CR._ptr(expk), CR._stream_ptr())
             doubling_allparams_(pol, expk, ly0["nd"], added, al, fl["dtd"], qp.mu0, pl)
 

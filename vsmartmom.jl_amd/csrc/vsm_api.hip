@@ -821,6 +821,22 @@ static int check_cl(const C* c) {
                             dtau_dot, varpi_dot, tau_sum_dot, Zpp_dot, Zmp_dot, zds, zdp, cvt_added<T>(added),         \
                             cvt_al<T>(al), as_stream(stream));                                                         \
   }                                                                                                                    \
+  int vsm_elemental_lin_fold_##SFX(const vsm_quad_##SFX* q, int S, int m, int n_m0, int ndoubl, const T* dtau,         \
+                                   const T* varpi, const T* tau_sum, const T* F0, const T* Zpp, const T* Zmp,          \
+                                   long long z_stride, int p_layer, const T* dtau_dot, const T* varpi_dot,             \
+                                   const T* tau_sum_dot, const vsm_added_##SFX* added, const vsm_added_lin_##SFX* al,  \
+                                   void* stream) {                                                                     \
+    int rc;                                                                                                            \
+    if ((rc = check_quad(q)) || (rc = check_added(added)) || (rc = check_al(al))) return rc;                           \
+    VSM_REQUIRE(added->d_symmetric == 0, "elemental_lin_fold: d_symmetric layers are not accepted here");              \
+    VSM_REQUIRE(dtau && varpi && tau_sum && F0 && Zpp && Zmp && dtau_dot && varpi_dot && tau_sum_dot,                  \
+                "elemental_lin_fold: null input");                                                                     \
+    VSM_REQUIRE(p_layer >= 0 && p_layer <= al->P && n_m0 >= 0 && n_m0 <= S && (m > 0 || n_m0 == 0 || n_m0 == S),      \
+                "elemental_lin_fold: bad p_layer / n_m0");                                                             \
+    return elemental_lin<T>(cvt_quad<T>(q), S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, z_stride, p_layer,       \
+                            dtau_dot, varpi_dot, tau_sum_dot, (const T*)nullptr, (const T*)nullptr, 0, 0,              \
+                            cvt_added<T>(added), cvt_al<T>(al), as_stream(stream), n_m0);                              \
+  }                                                                                                                    \
   int vsm_elemental_lin_mix_##SFX(const vsm_quad_##SFX* q, int S, int m, int ndoubl, const T* dtau, const T* varpi,    \
                                   const T* tau_sum, const T* F0, int ncomp, int ncomp_total, const T* Zc_pp,           \
                                   const T* Zc_mp, int zsel, const T* fz, int p_layer, const T* dtau_dot,               \

@@ -72,7 +72,7 @@ template <typename T>
 int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
                   const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
                   const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
-                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st);
+                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st, int n_m0 = 0);
 template <typename T>
 int elemental_lin_mix(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
                       const T* F0, int ncomp, int ncomp_total, const T* Zc_pp, const T* Zc_mp, int zsel, const T* fz,

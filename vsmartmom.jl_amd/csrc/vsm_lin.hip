@@ -30,7 +30,7 @@ struct zmix {
 };
 
 template <typename T, bool MIX>
-__global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int m, int ndoubl, int P,
+__global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int m_rest, int n_m0, int ndoubl, int P,
                                                        const T* __restrict__ dtau, const T* __restrict__ varpi,
                                                        const T* __restrict__ Zpp, const T* __restrict__ Zmp,
                                                        long long zs, const T* __restrict__ dtau_dot,
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
   const int e = blockIdx.y * 256 + threadIdx.x;
   if (e >= N * N) return;
   const int s = blockIdx.x;
+  const int m = (s < n_m0) ? 0 : m_rest;   // (a batch with Fourier moments folded into it: the first n_m0 points belong to m = 0)
   const int i = e % N, j = e / N;
   T zcp[MIX ? VSM_LIN_CT_MAX : 1], zcm[MIX ? VSM_LIN_CT_MAX : 1];
   T zmix_p = 0, zmix_m = 0;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_elemental_lin(int N, int ns, int S, int
 
 // get_elem_rt_SFI_fused! (elemental_lin.jl:602-712)
 template <typename T, bool MIX>
-__global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S, int m, int ndoubl, int i_mu0, int P,
+__global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S, int m_rest, int n_m0, int ndoubl, int i_mu0, int P,
                                                            const T* __restrict__ dtau, const T* __restrict__ varpi,
                                                            const T* __restrict__ tau_sum, const T* __restrict__ F0,
                                                            const T* __restrict__ Zpp, const T* __restrict__ Zmp,
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S,
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= N * S) return;
   const int i = e % N, s = e / N;
+  const int m = (s < n_m0) ? 0 : m_rest;
   const int i_start = ns * i_mu0;
   const T wct02 = (m == 0) ? T(0.5) : T(0.25);
   T zp = 0, zm = 0;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(256) void k_elemental_sfi_lin(int N, int ns, int S,
 }
 
 template <typename T, bool MIX>
-static int elemental_lin_impl(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
+static int elemental_lin_impl(const quad<T>& q, int S, int m, int n_m0, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
                               const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
                               const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
                               long long zdp, const zmix<T>& zx, const added<T>& a, const added_lin<T>& al, hipStream_t st) {
@@ -252,11 +254,11 @@ static int elemental_lin_impl(const quad<T>& q, int S, int m, int ndoubl, const 
   VSM_HIP(hipMemsetAsync(al.ap_t_mm, 0, mb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_p, 0, vb, st));
   VSM_HIP(hipMemsetAsync(al.ap_J0_m, 0, vb, st));
-  hipLaunchKernelGGL((k_elemental_lin<T, MIX>), dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+  hipLaunchKernelGGL((k_elemental_lin<T, MIX>), dim3(S, (N * N + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, n_m0, ndoubl,
                      p_layer, dtau, varpi, Zpp, Zmp, zs, dtau_dot, varpi_dot, Zpp_dot, Zmp_dot, zds, zdp, zx, q.mu, q.wt,
                      a.r_mp, a.t_pp, a.r_pm, a.t_mm, al.ap_r_mp, al.ap_t_pp, al.ap_r_pm, al.ap_t_mm);
   VSM_LAUNCH_CHECK("k_elemental_lin");
-  hipLaunchKernelGGL((k_elemental_sfi_lin<T, MIX>), dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, ndoubl,
+  hipLaunchKernelGGL((k_elemental_sfi_lin<T, MIX>), dim3((N * S + 255) / 256), dim3(256), 0, st, N, q.n_stokes, S, m, n_m0, ndoubl,
                      q.i_mu0, p_layer, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, dtau_dot, varpi_dot, tau_sum_dot,
                      Zpp_dot, Zmp_dot, zds, zdp, zx, q.mu, a.j0_p, a.j0_m, al.ap_J0_p, al.ap_J0_m);
   VSM_LAUNCH_CHECK("k_elemental_sfi_lin");
@@ -267,9 +269,9 @@ template <typename T>
 int elemental_lin(const quad<T>& q, int S, int m, int ndoubl, const T* dtau, const T* varpi, const T* tau_sum,
                   const T* F0, const T* Zpp, const T* Zmp, long long zs, int p_layer, const T* dtau_dot,
                   const T* varpi_dot, const T* tau_sum_dot, const T* Zpp_dot, const T* Zmp_dot, long long zds,
-                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st) {
+                  long long zdp, const added<T>& a, const added_lin<T>& al, hipStream_t st, int n_m0) {
   const zmix<T> none = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
-  return elemental_lin_impl<T, false>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, p_layer, dtau_dot, varpi_dot,
+  return elemental_lin_impl<T, false>(q, S, m, n_m0, ndoubl, dtau, varpi, tau_sum, F0, Zpp, Zmp, zs, p_layer, dtau_dot, varpi_dot,
                                       tau_sum_dot, Zpp_dot, Zmp_dot, zds, zdp, none, a, al, st);
 }
 
@@ -284,7 +286,7 @@ int elemental_lin_mix(const quad<T>& q, int S, int m, int ndoubl, const T* dtau,
     return VSM_ERR_UNSUPPORTED;
   }
   const zmix<T> zx = {Zc_pp, Zc_mp, fz, zdcoef, ncomp, ncomp_total, zsel};
-  return elemental_lin_impl<T, true>(q, S, m, ndoubl, dtau, varpi, tau_sum, F0, nullptr, nullptr, 0, p_layer, dtau_dot,
+  return elemental_lin_impl<T, true>(q, S, m, 0, ndoubl, dtau, varpi, tau_sum, F0, nullptr, nullptr, 0, p_layer, dtau_dot,
                                      varpi_dot, tau_sum_dot, nullptr, nullptr, 0, 0, zx, a, al, st);
 }
 
@@ -845,7 +847,7 @@ int postprocess_vza_lin(int N, int ns, int S, int nV, int P, const int* row0_h, 
 #define VSM_INST_L(T)                                                                                                 \
   template int elemental_lin<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*, const T*,     \
                                 const T*, long long, int, const T*, const T*, const T*, const T*, const T*,          \
-                                long long, long long, const added<T>&, const added_lin<T>&, hipStream_t);            \
+                                long long, long long, const added<T>&, const added_lin<T>&, hipStream_t, int);       \
   template int elemental_lin_mix<T>(const quad<T>&, int, int, int, const T*, const T*, const T*, const T*, int, int,   \
                                     const T*, const T*, int, const T*, int, const T*, const T*, const T*, const T*,     \
                                     const added<T>&, const added_lin<T>&, hipStream_t);                                 \
