@@ -215,6 +215,44 @@ def test_native_run_thick_layers_series_orders_and_pivoted_inverse(vsm, arch, mo
     assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-7, (_rel(Rn, Ro), _rel(Tn, To))    # (T: e^-34 of the beam; the legacy path: the same)
 
 
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("I", 21), ("IQU", 57), ("I", 150)])   # N = 60, 14, 96 (two points per workgroup), 79
+def test_native_run_float32_thick_layers_and_mixed_orders(vsm, arch, monkeypatch, pol, l_trunc):
+    """The FP32 native kernels beyond the Horner orders: thick near-conservative layers over a bright surface (long series, the
+    pivoted Gauss-Jordan inverse -- vsm_device_status counts them and raises no flag), in a batch that ALTERNATES thin and thick
+    columns, so that the two points of a workgroup (five / six row tiles) take different inverse paths in the same step: each keeps
+    the result of its own order (the arithmetic of a point does not depend on its neighbour: the batch reversed gives the same
+    numbers, point by point)."""
+    H = vsm.host_model
+    S = 7                                           # (odd: the last workgroup of two carries a filler point)
+    thick = np.array([0.5, 4.0, 30.0])
+    thin = np.array([0.02, 0.03, 0.05])
+    tau_rayl = np.stack([thick if s % 2 else thin for s in range(S)])
+    tau_abs = np.stack([np.array([1e-4, 1e-5, 1e-6]) * (1 + 0.1 * s) for s in range(S)])
+    kw = dict(depol=0.03, albedo=0.6, m_max=2)
+    mk = lambda tr, ta: H.model_from_arrays(arch, pol, l_trunc, 40.0, [30.0], [0.0], tau_rayl=tr, tau_abs=ta, float_type=np.float32, **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    sc = vsm.CoreRT.prepare_scene(mk(tau_rayl, tau_abs))
+    assert len(sc._native_moments()) == 3
+    Rn, Tn = vsm.CoreRT.rt_run(mk(tau_rayl, tau_abs))
+    st = list(vsm._lib.last_device_status)
+    assert st[0] == 0 and st[1] > 0, st
+    Rr, Tr = vsm.CoreRT.rt_run(mk(tau_rayl[::-1].copy(), tau_abs[::-1].copy()))
+    assert np.array_equal(Rn, Rr[:, :, ::-1]) and np.array_equal(Tn, Tr[:, :, ::-1])
+    Ro, To = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, FT=np.float32, **kw))
+    assert _rel(Rn, Ro) < 1e-2, _rel(Rn, Ro)
+    # T of these columns is the end of ~ 30 single-precision doublings of a conservative layer (the thick columns' direct beam is
+    # e^-34): two Float32 evaluations of it differ by more than the reference's gate for ordinary atmospheres -- both are compared
+    # with the FP64 oracle, and the kernels' error may not exceed twice the Float32 oracle's own
+    O64 = O.rt_run(O.build_model(pol, l_trunc, 40.0, [30.0], [0.0], tau_rayl=tau_rayl, tau_abs=tau_abs, **kw))[1]
+    big = np.abs(O64) > 1e-3 * np.abs(O64).max()
+    err = lambda T_: float(np.max(np.abs(T_[big] - O64[big]) / np.abs(O64[big])))
+    assert err(Tn) < max(1e-2, 2 * err(To)), (err(Tn), err(To))
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", False)
+    Rl, Tl = vsm.CoreRT.rt_run(mk(tau_rayl, tau_abs))
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    assert _rel(Rn, Rl) < 5e-3, _rel(Rn, Rl)
+
+
 def test_native_run_moment_by_moment_equals_grouped(vsm, arch, monkeypatch):
     """The moments of a run are independent sub-problems: walking them one by one gives the bits of the grouped walk."""
     H = vsm.host_model
