@@ -256,7 +256,8 @@ def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
     R, T, Rd, Td = scene.results_host()
     assert _rel(R, Ro) < 1e-9 and _rel(T, To) < 1e-9 and _rel(Rd, Rdo) < 1e-8 and _rel(Td, Tdo) < 1e-8
     # the folded walk's own forms: all layers doubled side by side before the interactions (PARALLEL_LAYERS) and the pairs of m = 0
-    # in the same batch as those of m > 0 (MERGE_M0, vsm_elemental_lin_fold) reorder launches, not arithmetic: bit for bit
+    # in the same batch as those of m > 0 (MERGE_M0, vsm_elemental_lin_fold) reorder launches, not the arithmetic of a moment; which
+    # lane a moment is finished on -- the order of the sum over moments -- moves with them
     SL = vsm.CoreRTLin.SceneLin
     saved = (SL.PARALLEL_LAYERS, SL.MERGE_M0)
     try:
@@ -266,7 +267,7 @@ def test_rt_run_lin_moment_lanes_equal_sequential(vsm, arch, pol, l_trunc):
             alt = [t.clone() for t in scene.run(lanes=4, fold=True)]
             torch.cuda.synchronize()
             for a, b in zip(fold, alt):
-                assert torch.equal(a, b), (pl_, mg_)
+                assert float((a - b).abs().max()) <= 1e-13 * float(a.abs().max()), (pl_, mg_)
     finally:
         SL.PARALLEL_LAYERS, SL.MERGE_M0 = saved
         scene._fold = {}

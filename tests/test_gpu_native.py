@@ -106,12 +106,14 @@ def test_native_layout_import_export_roundtrip(vsm, arch, ns, nq, coupling):
 
 def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
     L = vsm._lib.lib()
-    assert L.vsm_run_supported(80, 4, -1) == 0 and L.vsm_run_supported(80, 4, 0x8033) == 1     # 40 + 20 + 20
-    assert L.vsm_run_supported(66, 3, -1) == 0 and L.vsm_run_supported(66, 3, 0x33) == 1        # 44 + 22
-    assert L.vsm_run_supported(64, 1, -1) == 1 and L.vsm_run_supported(65, 1, -1) == 0
-    assert L.vsm_run_workspace_bytes(80, 4, 10, 1, (C.c_int * 1)(-1)) == 0
-    mu = torch.ones(80, dtype=torch.float64, device="cuda:0")
-    q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), 80, 4, 0, 1.0)
+    assert L.vsm_run_supported(120, 4, -1) == 0 and L.vsm_run_supported(120, 4, 0x8033) == 1     # 60 + 30 + 30
+    assert L.vsm_run_supported(99, 3, -1) == 0 and L.vsm_run_supported(99, 3, 0x33) == 1          # 66 + 33
+    assert L.vsm_run_supported(96, 1, -1) == 1 and L.vsm_run_supported(97, 1, -1) == 0
+    assert L.vsm_run_supported_f32(96, 1, -1) == 1 and L.vsm_run_supported_f32(97, 1, -1) == 0
+    assert L.vsm_run_workspace_bytes(120, 4, 10, 1, (C.c_int * 1)(-1)) == 0
+    assert L.vsm_run_workspace_bytes_f32(96, 3, 10, 1, (C.c_int * 1)(-1)) * 2 == L.vsm_run_workspace_bytes(96, 3, 10, 1, (C.c_int * 1)(-1))
+    mu = torch.ones(120, dtype=torch.float64, device="cuda:0")
+    q = vsm._lib.vsm_quad_f64(mu.data_ptr(), mu.data_ptr(), 120, 4, 0, 1.0)
     run = C.c_void_p()
     ws = torch.zeros(16, dtype=torch.float64, device="cuda:0")
     rc = L.vsm_run_create_f64(C.byref(q), 4, 1, (C.c_int * 1)(1), (C.c_int * 1)(-1), C.c_void_p(ws.data_ptr()), 128, C.byref(run))
@@ -124,14 +126,16 @@ def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
 SHAPES = [("I", 3, 2), ("I", 9, 3), ("I", 21, 3), ("I", 33, 2), ("I", 55, 2), ("I", 85, 2), ("I", 115, 2), ("I", 117, 2), ("I", 120, 2),
           ("IQ", 21, 3), ("IQ", 53, 2), ("IQ", 57, 2),
           ("IQU", 5, 4), ("IQU", 11, 3), ("IQU", 15, 3), ("IQU", 21, 3), ("IQU", 27, 2), ("IQU", 33, 3), ("IQU", 35, 3),
-          ("IQUV", 5, 2), ("IQUV", 11, 4), ("IQUV", 21, 3), ("IQUV", 25, 2), ("IQUV", 35, 2)]
+          ("IQUV", 5, 2), ("IQUV", 11, 4), ("IQUV", 21, 3), ("IQUV", 25, 2), ("IQUV", 35, 2),
+          # five and six row tiles (65 .. 96 rows): N = 65, 78, 79 (no spare column), 87, 95 (no spare column), 66 / 93 (IQU), 96 (IQUV: 72 + 24)
+          ("I", 123, 2), ("I", 149, 2), ("I", 151, 2), ("I", 167, 2), ("I", 183, 2), ("IQU", 37, 2), ("IQU", 55, 2), ("IQUV", 41, 2)]
 
 
 @pytest.mark.parametrize("pol,l_trunc,L", SHAPES)
 def test_native_run_vs_oracle_and_reference_layout_run(vsm, arch, monkeypatch, pol, l_trunc, L):
     """rt_run through the native-layout run against the oracle (1e-8, the FP64 gate of every rt_run test here) and against the
     reference-layout layer loop (the same operations in another summation order: 1e-10), for sub-problem sizes that land on every
-    row-tile count RT = 1..4 (incl. n = 61..64: no spare columns, the source vectors by mat-vecs over the A-forms), dense and split
+    row-tile count RT = 1..6 (incl. n = 61..64, 77..80, 93..96: no spare columns, the source vectors by mat-vecs over the A-forms), dense and split
     moments, two viewing angles that add zero-weight streams."""
     H = vsm.host_model
     rng = np.random.default_rng(17)
@@ -150,7 +154,7 @@ def test_native_run_vs_oracle_and_reference_layout_run(vsm, arch, monkeypatch, p
     monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
     sc = vsm.CoreRT.prepare_scene(model)
     nat = sc._native_moments()
-    want = {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 64}
+    want = {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 96}
     assert nat == want, (nat, want)
     sc.run()
     torch.cuda.synchronize()
@@ -590,7 +594,7 @@ def test_reference_call_order_reaches_the_native_run_through_rt_kernel(vsm, arch
     calls = _spy_native(vsm, monkeypatch)
     Rb, Tb = vsm.CoreRT.rt_run(model)
     sc = vsm.CoreRT.prepare_scene(model)
-    fits = [max(bin(g).count("1") for g in _groups(ns, sc.coupling[m])) * (N // ns) <= 64 for m in range(3)]
+    fits = [max(bin(g).count("1") for g in _groups(ns, sc.coupling[m])) * (N // ns) <= 96 for m in range(3)]
     assert [c for c in calls if c[2]] == [(m, iz, True) for m in range(3) if fits[m] for iz in range(1, L + 1)], calls
     assert any(fits)
     monkeypatch.setattr(vsm.CoreRT, "NATIVE_DROPIN", False)

@@ -198,10 +198,10 @@ __device__ __forceinline__ void nia_body_native(nsmem<RT, (4 * KS + 2 > 16 * RT)
   double* J0_m = J0_p + G::NP;
   constexpr int c1 = 4 * KS, c2 = 4 * KS + 1;
   constexpr bool RID = c2 < G::NP;
-  // Three row tiles (168 registers, strips of 24): at most FIVE live strips.  Z = R+- t-- is not needed between its product and
+  // Three row tiles (168 registers, strips of 24) and five / six (256 registers, strips of 40 / 48): at most FIVE live strips.  Z = R+- t-- is not needed between its product and
   // the closing pairs: it waits in the R+- record of the composite (consumed into P at the entry, overwritten by the new R+- at
   // the end; a lane reads back exactly the addresses it wrote), and R-+ is requested after R+- / T++ have left.
-  constexpr bool PARK = VSM_NATIVE_PARK_RT > 0 && RT == VSM_NATIVE_PARK_RT;
+  constexpr bool PARK = VSM_NATIVE_PARK_RT > 0 && (RT == VSM_NATIVE_PARK_RT || RT >= 5);
   const bool own_wave = RID && p.wave == (c1 >> 4);
   const bool laneA = own_wave && (p.col == c1), laneB = own_wave && (p.col == c2);
   int slot = 0;
@@ -820,6 +820,7 @@ static_assert(sizeof(nsmem<2>) * 8 <= 163840, "two row tiles: eight workgroups p
 static_assert(sizeof(nsmem<3>) * 4 <= 163840, "three row tiles: four workgroups per CU");
 static_assert(sizeof(nsmem<3, true>) * 3 <= 163840, "three row tiles, mat-vec sources: three workgroups per CU");
 static_assert(sizeof(nsmem<4, true>) * 2 <= 163840, "four row tiles: two workgroups per CU");
+static_assert(sizeof(nsmem<6, true>) <= 163840 && sizeof(nsmem<6>) <= 163840, "six row tiles: one workgroup per CU");
 
 template <int RT, int KS>
 __global__ __launch_bounds__(ngeo<RT>::NT, ngeo<RT>::WPS) void k_layer_native(int n, int gsz, unsigned uvmask, int ndoubl,
@@ -870,7 +871,7 @@ int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsign
   // KS = 4, 8, 12, 16 (n = 13..16, 29..32, 45..48, 61..64): KS / 4 row tiles without spare columns (mat-vec source path) instead of one row
   // tile more for the two rider columns
   constexpr int RT = (KS % 4 == 0 && KS >= 4) ? KS / 4 : (4 * KS + 2 + 15) / 16;
-  static_assert(RT >= 1 && RT <= 4, "n <= 64");
+  static_assert(RT >= 1 && RT <= 6, "n <= 96");
   using SM = nsmem<RT, (4 * KS + 2 > 16 * RT)>;
   auto kern = k_layer_native<RT, KS>;
   const int prepared = ensure_dyn_lds(reinterpret_cast<const void*>(kern), sizeof(SM), "hipFuncSetAttribute(k_layer_native)");
@@ -879,6 +880,7 @@ int VSM_NCAT(launch_layer_native_, VSM_NATIVE_KS)(int S, int nsub, int n, unsign
   VSM_LAUNCH_CHECK("k_layer_native");
   return VSM_OK;
 }
+#if VSM_NATIVE_KS <= 16
 int VSM_NCAT(launch_ia_native_, VSM_NATIVE_KS)(int N, int S, const composite<double>& c, const added<double>& a, int* status,
                                                hipStream_t st) {
   constexpr int KS = VSM_NATIVE_KS;
@@ -902,6 +904,7 @@ int VSM_NCAT(launch_ia_native_, VSM_NATIVE_KS)(int N, int S, const composite<dou
   VSM_LAUNCH_CHECK("k_ia_native");
   return VSM_OK;
 }
+#endif
 }  // namespace vsm
 #ifdef VSM_IA_PHASES
 extern "C" int vsm_debug_ia_phases(unsigned long long* out_h, int reset) {
@@ -932,6 +935,14 @@ VSM_NATIVE_DECL(13)
 VSM_NATIVE_DECL(14)
 VSM_NATIVE_DECL(15)
 VSM_NATIVE_DECL(16)
+VSM_NATIVE_DECL(17)
+VSM_NATIVE_DECL(18)
+VSM_NATIVE_DECL(19)
+VSM_NATIVE_DECL(20)
+VSM_NATIVE_DECL(21)
+VSM_NATIVE_DECL(22)
+VSM_NATIVE_DECL(23)
+VSM_NATIVE_DECL(24)
 
 namespace {
 
@@ -1074,13 +1085,10 @@ struct ngroup_map {
   int n[4];         // per group: rows
   double* base[4];  // per group: native composites [S] (stride COMP_STRIDE of its RT)
 };
-__device__ __forceinline__ int nnat_idx_rt(int rt, int i, int j) {
-  switch (rt) {
-    case 1: return nnat_idx<1>(i, j);
-    case 2: return nnat_idx<2>(i, j);
-    case 3: return nnat_idx<3>(i, j);
-    default: return nnat_idx<4>(i, j);
-  }
+__device__ __forceinline__ int nnat_idx_rt(int rt, int i, int j) {   // nnat_idx<RT> with the row-tile count as an argument
+  const int w = j >> 4, l15 = j & 15, ta = i >> 4, mm = i & 15, kq = mm & 3, r = mm >> 2;
+  const int lane = (kq << 4) | l15, u = 2 * ta + (r >> 1);
+  return ((w * 2 * rt + u) * 64 + lane) * 2 + (r & 1);
 }
 template <typename ST>
 __global__ __launch_bounds__(256) void k_native_export(int N, int ns, ngroup_map gm, composite<ST> c) {
@@ -1208,7 +1216,7 @@ struct ndiag_args {
 template <typename ST>
 __global__ __launch_bounds__(256) void k_native_diag_layer(quad<ST> q, int rt, int n, double scale, int mode,
                                                            const ST* __restrict__ dtau, ndiag_args a) {
-  __shared__ double tt[64];
+  __shared__ double tt[NATIVE_MAX_ROWS];
   const int s = blockIdx.x, isub = blockIdx.y, tid = threadIdx.x;
   const int np = 16 * rt, af = np * np, gsz = a.gsz[isub];
   double* comp = a.comp[isub] + (long long)s * (4 * af + 2 * np);
@@ -1326,7 +1334,7 @@ static int plan_subs(bool f32, int N, int ns, int nm, const int* m, const int* c
       for (int k = 0; k < gsz[g]; ++k)
         if (groups[g][k] >= 2) sb.uvmask |= 1u << k;
       sb.n = nq * gsz[g];
-      const int max_rows = f32 ? NATIVE32_MAX_ROWS : 64;
+      const int max_rows = f32 ? NATIVE32_MAX_ROWS : NATIVE_MAX_ROWS;
       if (sb.n > max_rows) {
         set_error("vsm_run: a block of %d rows (N = %d, %d coupled Stokes components) is beyond the native kernels (%d)", sb.n, N,
                   gsz[g], max_rows);
@@ -1348,7 +1356,7 @@ static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, 
   case KS: return VSM_NCAT(launch_layer_native_, KS)(S, nsub, n, uvmask, gsz, ndoubl, toa, pre, comps, status, st);
   switch (ks) {
     VSM_NL(1) VSM_NL(2) VSM_NL(3) VSM_NL(4) VSM_NL(5) VSM_NL(6) VSM_NL(7) VSM_NL(8) VSM_NL(9) VSM_NL(10) VSM_NL(11) VSM_NL(12)
-    VSM_NL(13) VSM_NL(14) VSM_NL(15) VSM_NL(16)
+    VSM_NL(13) VSM_NL(14) VSM_NL(15) VSM_NL(16) VSM_NL(17) VSM_NL(18) VSM_NL(19) VSM_NL(20) VSM_NL(21) VSM_NL(22) VSM_NL(23) VSM_NL(24)
     default: break;
   }
 #undef VSM_NL
@@ -1359,7 +1367,7 @@ static int launch_layer_native(int ks, int S, int nsub, int n, unsigned uvmask, 
 }  // namespace
 // interaction!(::ScatteringInterface_11) on the reference-layout arrays, FP64, N <= 64 (VSM_ERR_UNSUPPORTED beyond)
 int native_interaction11(int N, int S, const composite<double>& c, const added<double>& a, hipStream_t st) {
-  if (N < 1 || N > 64) return VSM_ERR_UNSUPPORTED;
+  if (N < 1 || N > 64) return VSM_ERR_UNSUPPORTED;   // (six live strips: beyond four row tiles the interaction alone stays on k_ia128)
   if (S <= 0) return VSM_OK;
   int* status = device_status();
   if (!status) return VSM_ERR_HIP;
@@ -1564,7 +1572,9 @@ static int run_layer(vsm_run* run, int ndoubl, const ST* dtau, const ST* varpi, 
       case 1: launch_pre<1, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
       case 2: launch_pre<2, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
       case 3: launch_pre<3, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
-      default: launch_pre<4, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 4: launch_pre<4, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 5: launch_pre<5, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      default: launch_pre<6, ST>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
     }
     VSM_LAUNCH_CHECK("k_elemental_native");
     const int rc = launch_layer_native(h.ks, run->S, nsub, h.n, h.uvmask, h.gsz, ndoubl, toa, pre_cl, lc, status, st);
@@ -1627,7 +1637,7 @@ static int run_supported(int N, int n_stokes, int coupling, int max_rows) {
     if ((N / n_stokes) * gsz[g] > max_rows) return 0;
   return 1;
 }
-int vsm_run_supported(int N, int n_stokes, int coupling) { return run_supported(N, n_stokes, coupling, 64); }
+int vsm_run_supported(int N, int n_stokes, int coupling) { return run_supported(N, n_stokes, coupling, NATIVE_MAX_ROWS); }
 int vsm_run_supported_f32(int N, int n_stokes, int coupling) { return run_supported(N, n_stokes, coupling, NATIVE32_MAX_ROWS); }
 
 size_t vsm_run_workspace_bytes(int N, int n_stokes, int S, int nm, const int* coupling) {

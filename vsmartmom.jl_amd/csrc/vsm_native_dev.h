@@ -306,20 +306,23 @@ __device__ __forceinline__ void nadd_identity(nstrip<RT>& G, int n, const npos<R
 template <int RT>
 __device__ __forceinline__ void ngj_lds(int n, nlds_d* M, nlds_i* piv, nlds_i* src, int* status, const npos<RT>& p) {
   constexpr int NP = 16 * RT;
-  const int i0 = p.lane;
-  const bool ok0 = i0 < n;
+  constexpr bool TWO = NP > 64;     // (five and six row tiles: a lane carries rows lane and lane + 64)
+  const int i0 = p.lane, i1 = p.lane + 64;
+  const bool ok0 = i0 < n, ok1 = TWO && i1 < n;
   bool singular = false;
   for (int k = 0; k < n; ++k) {
     const nlds_d* ck = M + k * NP;
-    double f0 = ok0 ? ck[i0] : 0.0;
-    const double v0 = (ok0 && i0 >= k) ? fabs(f0) : -1.0;
-    const double best = wave_max(v0);
+    double f0 = ok0 ? ck[i0] : 0.0, f1 = ok1 ? ck[i1] : 0.0;
+    const double v0 = (ok0 && i0 >= k) ? fabs(f0) : -1.0, v1 = (ok1 && i1 >= k) ? fabs(f1) : -1.0;
+    const double best = wave_max(v0 > v1 ? v0 : v1);
     const unsigned long long m0 = __ballot(v0 >= 0.0 && v0 == best);
-    const int pr = m0 ? (__ffsll((long long)m0) - 1) : k;
+    const unsigned long long m1 = __ballot(v1 >= 0.0 && v1 == best);
+    const int pr = m0 ? (__ffsll((long long)m0) - 1) : (m1 ? 64 + __ffsll((long long)m1) - 1 : k);
     const double ckk = ck[k], pv = ck[pr];
     const double d = 1.0 / pv;
     singular |= pv == 0.0;
     f0 = (i0 == pr) ? ckk : f0;
+    f1 = (i1 == pr) ? ckk : f1;
     if (threadIdx.x == 0) piv[k] = pr;
     __syncthreads();
     for (int j = p.wave; j < n; j += RT) {
@@ -331,25 +334,45 @@ __device__ __forceinline__ void ngj_lds(int n, nlds_d* M, nlds_i* piv, nlds_i* s
       x0 = isk ? 0.0 : ((i0 == pr) ? b : x0);
       x0 = (i0 == k) ? u : fma(-f0, u, x0);
       if (ok0) cj[i0] = x0;
+      if constexpr (TWO) {
+        double x1 = ok1 ? cj[i1] : 0.0;
+        x1 = isk ? 0.0 : ((i1 == pr) ? b : x1);
+        x1 = (i1 == k) ? u : fma(-f1, u, x1);
+        if (ok1) cj[i1] = x1;
+      }
     }
     __syncthreads();
   }
   if (p.wave == 0) {
-    const int lane = p.lane;
-    int s0 = lane;
-    const int p0 = (lane < n) ? piv[lane] : lane;
-    for (int k = n - 1; k >= 0; --k) {
-      const int ku = __builtin_amdgcn_readfirstlane(k);
-      const int q = __builtin_amdgcn_readlane(p0, ku);
-      if (q != ku) {
-        const int sk = __builtin_amdgcn_readlane(s0, ku);
-        const int sq = __builtin_amdgcn_readlane(s0, q);
-        if (lane == ku) s0 = sq;
-        if (lane == q) s0 = sk;
+    if constexpr (TWO) {   // the column permutation that undoes the row interchanges, by one thread (a rare path)
+      if (p.lane == 0) {
+        for (int x = 0; x < n; ++x) src[x] = x;
+        for (int k = n - 1; k >= 0; --k) {
+          const int q = piv[k];
+          if (q != k) {
+            const int t = src[k];
+            src[k] = src[q];
+            src[q] = t;
+          }
+        }
       }
+    } else {
+      const int lane = p.lane;
+      int s0 = lane;
+      const int p0 = (lane < n) ? piv[lane] : lane;
+      for (int k = n - 1; k >= 0; --k) {
+        const int ku = __builtin_amdgcn_readfirstlane(k);
+        const int q = __builtin_amdgcn_readlane(p0, ku);
+        if (q != ku) {
+          const int sk = __builtin_amdgcn_readlane(s0, ku);
+          const int sq = __builtin_amdgcn_readlane(s0, q);
+          if (lane == ku) s0 = sq;
+          if (lane == q) s0 = sk;
+        }
+      }
+      src[lane] = s0;
     }
-    src[lane] = s0;
-    if (lane == 0) {
+    if (p.lane == 0) {
       if (singular) atomicOr(&status[0], (int)VSM_DEVSTAT_SINGULAR);
       atomicAdd(&status[1], 1);
     }
@@ -360,7 +383,7 @@ __device__ __forceinline__ void ngj_lds(int n, nlds_d* M, nlds_i* piv, nlds_i* s
 struct ninv_ctx {
   unsigned dW;     // byte distance of the scratch A-form (= P: 0)
   double* W;       // the same A-form as a pointer (plain column-major use by the pivoted path)
-  int* gjs;        // 128 ints of LDS: piv[64], src[64]
+  int* gjs;        // LDS: piv[max(NP, 64)], src[max(NP, 64)]
   int* status;
 };
 
@@ -400,9 +423,10 @@ __device__ __forceinline__ void ninvert_slow_body(int K, nstrip<RT>& E, nstrip<R
     __syncthreads();
     nlds_d* M = reinterpret_cast<nlds_d*>((unsigned long long)nlds_addr(cx.W));
     nlds_i* piv = reinterpret_cast<nlds_i*>((unsigned long long)nlds_addr(cx.gjs));
-    ngj_lds<RT>(n, M, piv, piv + 64, cx.status, p);
+    constexpr int PV = NP > 64 ? NP : 64;
+    ngj_lds<RT>(n, M, piv, piv + PV, cx.status, p);
     const bool cok = p.col < n;
-    const nlds_d* gc = M + (cok ? piv[64 + p.col] : 0) * NP + p.kq;
+    const nlds_d* gc = M + (cok ? piv[PV + p.col] : 0) * NP + p.kq;
 #pragma unroll
     for (int ta = 0; ta < RT; ++ta)
 #pragma unroll
@@ -520,9 +544,9 @@ struct nsmem : nmv_slots<RT, MV> {
   double Q[ngeo<RT>::AF];
   double vec[8][ngeo<RT>::NP];
   double usg[ngeo<RT>::NP];   // -1.0 on the U/V rows of the sub-problem, +1.0 elsewhere
-  float red[2][4];
+  float red[2][8];
   int flags[4];
-  int gjs[128];
+  int gjs[2 * (ngeo<RT>::NP > 64 ? ngeo<RT>::NP : 64)];
 };
 
 // Source vectors without spare columns: y = sc [A] x as a VALU mat-vec over the A-form.  Wave w takes the rows of row tile w

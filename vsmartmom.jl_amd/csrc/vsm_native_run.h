@@ -38,6 +38,7 @@ struct vsm_run {
 namespace vsm {
 
 // ---- FP32 family (vsm_native32.hip) ------------------------------------------------------------------------------------------
+constexpr int NATIVE_MAX_ROWS = 96;     // FP64 family (vsm_native.hip): blocks of up to six row tiles
 constexpr int NATIVE32_MAX_ROWS = 96;
 int native32_rt_of(int n);                 // row tiles of a block of n rows
 size_t native32_comp_stride(int rt);       // floats per point of a native composite
