@@ -57,6 +57,19 @@ def _entry(name, workload, S, wall, dev_ms, flops_pt, dtype, kernel):
             "achieved_tflops": tf, "frac_of_mfma_peak": tf / PEAK[dtype] if tf else None, "dominant_kernel": kernel}
 
 
+def _executed(e, scene, what):
+    """frac_of_mfma_peak by the products that ARE formed (blocks of Stokes components that do not couple run as independent
+    sub-problems: the as-written count of SURVEY 8d stays beside it as frac_of_mfma_peak_as_written)."""
+    import bench
+    ratio = bench.executed_over_algorithmic(scene)
+    e["frac_of_mfma_peak_as_written"] = e["frac_of_mfma_peak"]
+    e["executed_over_algorithmic_flops"] = ratio
+    e["frac_of_mfma_peak"] = e["frac_of_mfma_peak_as_written"] * ratio
+    e["note"] = ("frac_of_mfma_peak_as_written counts every layer step as a dense N x N problem, as the reference writes it (SURVEY 8d); the run "
+                 "forms the products of the Stokes blocks that couple only (%s): frac_of_mfma_peak is by those, whole step" % what)
+    return e
+
+
 def _lin_step_inputs(scene):
     """The input half of a linearized step, like the headline's: H2D of the raw optical depths and their derivatives, layer
     optics and their derivatives on the device (forward scene + SceneLin)."""
@@ -82,6 +95,7 @@ def c4(vsm, torch, arch, o2a, points=12500):
     e = _entry("C4", "N=96 FP32, 60 layers, m=0..2, Rayleigh + O2, Lambertian (one GPU's share of BASELINE configs[3])", points, wall, dev,
                scene.flops_per_point(), "f32", "k_layer_native32<6, 24> (m = 1, 2: two points per workgroup) + k_layer_native32<4, 16> (m = 0: a 64-row "
                "(I,Q) block, U as a diagonal step): FP32 records and arithmetic")
+    _executed(e, scene, "m = 0: a 64-row (I,Q) block and a diagonal step for U; m = 1, 2 dense")
     del scene
     return e
 
@@ -224,8 +238,8 @@ def c3_lin(vsm, torch, arch):
     e = _entry("C3-lin", "ocean / Cox-Munk scene (config/ocean_coxmunk.yaml): IQUV, N=60 FP64, 33 layers, m=0..21, linearized "
                "(gas column + wind speed) -- a latency-bound two-point batch; step = H2D + device optics + the pass REPLAYED FROM A HIP "
                "GRAPH + D2H", S, wall, dev, fl, "f64",
-               "latency: two folded chains of 33 layer steps (k_dbl_lin_multi + 2 k_ia128_lin<4> per step), moments m >= 1 as one batch; "
-               "concurrent on the device under graph replay")
+               "latency: ONE folded batch of (moment, point) pairs (m = 0 in front); the 33 layers doubled side by side on the lane "
+               "streams (k_dbl128_lin<4>), then one chain of 32 interactions (2 k_ia128_lin<4> each); graph replay")
     e["ms_per_step_launch_by_launch"] = 1e3 * wall_eager
     e["graph_replay_equals_launch_by_launch"] = bool(same)
     del scene
@@ -372,7 +386,9 @@ def n112(vsm, torch, arch, o2a, points=2000, layers=10):
     wall, dev, _ = _timed(torch, step)
     e = _entry("N112", "forward, IQUV N=%d FP64 (the reference's VLIDORT case-A size), %d layers, %d points, m=0..2, Rayleigh + O2, "
                "Lambertian" % (N, layers, points), points, wall, dev, scene.flops_per_point(), "f64",
-               "k_dbl128<7> (+ k_ia128<7>) for m = 1, 2; m = 0 as native blocks of 56 + 28 rows (k_layer_native<4, 14>, <2, 7>)")
+               "k_layer_native<6, 21> (m = 1, 2: the 84-row (I,Q,U) block; V, which the Rayleigh matrix couples with nothing, as a 28-row "
+               "block k_layer_native<2, 7>); m = 0 as its uncoupled blocks (k_layer_native<4, 14> for (I,Q)); the surface interaction on k_ia128<7>")
+    _executed(e, scene, "Rayleigh: V couples with nothing, m = 0 splits into (I,Q) and (U,V)")
     del scene
     return e
 
