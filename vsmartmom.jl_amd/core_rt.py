@@ -830,11 +830,16 @@ class Scene:
                   C.c_double(float(model.varpi_Cabannes)), _ptr(self.tau_aer_d), _ptr(self.ssa_d), _ptr(self.ftr_d),
                   _ptr(self.mode_d), _ptr(self.tau), _ptr(self.varpi), _ptr(self.tau_sum), _ptr(self.fcomp), _ptr(self.max_tw),
                   _stream_ptr())
-        q = self.dq.cstruct()
-        for m in range(model.m_max + 1):
-            Zpp, Zmp = self.Zc[m]
-            for k, (gd, lmax) in enumerate(self.greek_dev):
-                _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, lmax, _ptr(gd), _ptr(Zpp[k]), _ptr(Zmp[k]), _stream_ptr())
+        if getattr(self, "_zc_of", None) is not self.greek_dev:
+            # Z(m) of every scatterer depends on its Greek table and the quadrature only: scene constants like the tables (a step
+            # re-uploads optical depths; `greek_dev = None` before upload() re-uploads the tables and recomputes these)
+            q = self.dq.cstruct()
+            for m in range(model.m_max + 1):
+                Zpp, Zmp = self.Zc[m]
+                for k, (gd, lmax) in enumerate(self.greek_dev):
+                    _lib.call("vsm_compute_Z_moments", dt, C.byref(q), m, lmax, _ptr(gd), _ptr(Zpp[k]), _ptr(Zmp[k]), _stream_ptr())
+            self._zc_of = self.greek_dev
+            self.coupling_comp = None
         self._compute_coupling()
         mx = self.max_tw.cpu().numpy()          # the ONE device -> host hand-off of the optics pass (Nz scalars)
         nds, tags, tag = [], [], "00"
