@@ -614,7 +614,7 @@ int vsm_mix_Z_moments_f32(int N, int S, int ncomp, int nm, const float* const* Z
  * kernels: (N / n_stokes) * (components in the block) <= 64 (vsm_run_supported != 0), else VSM_ERR_UNSUPPORTED.
  * _f32: the same for a Float32 model in the model's own float type, as the reference runs it (doubling.jl:38-131 and
  * interaction.jl:207-266 compute in FT): the caller's arrays, the native records and the arithmetic (v_mfma_f32_16x16x4_f32) are
- * single precision, blocks of up to 96 rows (vsm_run_supported_f32; workspace: vsm_run_workspace_bytes_f32 -- half of
+ * single precision, blocks of up to 128 rows (vsm_run_supported_f32; workspace: vsm_run_workspace_bytes_f32 -- half of
  * vsm_run_workspace_bytes, which stays sufficient).  A run is used with the entry points of its own type.
  * Stream: see Conventions; library scratch (the pre-pass images of the layer). */
 typedef struct vsm_run vsm_run;

@@ -109,7 +109,7 @@ def test_run_create_rejects_what_the_native_kernels_do_not_take(vsm, arch):
     assert L.vsm_run_supported(120, 4, -1) == 0 and L.vsm_run_supported(120, 4, 0x8033) == 1     # 60 + 30 + 30
     assert L.vsm_run_supported(99, 3, -1) == 0 and L.vsm_run_supported(99, 3, 0x33) == 1          # 66 + 33
     assert L.vsm_run_supported(96, 1, -1) == 1 and L.vsm_run_supported(97, 1, -1) == 0
-    assert L.vsm_run_supported_f32(96, 1, -1) == 1 and L.vsm_run_supported_f32(97, 1, -1) == 0
+    assert L.vsm_run_supported_f32(128, 1, -1) == 1 and L.vsm_run_supported_f32(129, 1, -1) == 0
     assert L.vsm_run_workspace_bytes(120, 4, 10, 1, (C.c_int * 1)(-1)) == 0
     assert L.vsm_run_workspace_bytes_f32(96, 3, 10, 1, (C.c_int * 1)(-1)) * 2 == L.vsm_run_workspace_bytes(96, 3, 10, 1, (C.c_int * 1)(-1))
     mu = torch.ones(120, dtype=torch.float64, device="cuda:0")
@@ -219,7 +219,7 @@ def test_native_run_thick_layers_series_orders_and_pivoted_inverse(vsm, arch, mo
     assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-7, (_rel(Rn, Ro), _rel(Tn, To))    # (T: e^-34 of the beam; the legacy path: the same)
 
 
-@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("I", 21), ("IQU", 57), ("I", 150)])   # N = 60, 14, 96 (two points per workgroup), 79
+@pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("I", 21), ("IQU", 57), ("I", 150), ("I", 247)])   # N = 60, 14, 96 (two points per workgroup), 79, 127
 def test_native_run_float32_thick_layers_and_mixed_orders(vsm, arch, monkeypatch, pol, l_trunc):
     """The FP32 native kernels beyond the Horner orders: thick near-conservative layers over a bright surface (long series, the
     pivoted Gauss-Jordan inverse -- vsm_device_status counts them and raises no flag), in a batch that ALTERNATES thin and thick
@@ -384,10 +384,10 @@ def test_raman_run_with_m0_as_stokes_iq_scene(vsm, arch, monkeypatch, pol, l_tru
 
 
 @pytest.mark.parametrize("pol,l_trunc", [("I", 9), ("IQU", 21), ("IQU", 35), ("IQUV", 25), ("I", 120), ("IQU", 57), ("I", 130), ("I", 150),
-                                         ("I", 170), ("IQU", 45), ("IQUV", 39)])
+                                         ("I", 170), ("IQU", 45), ("IQUV", 39), ("IQU", 61), ("I", 235), ("I", 247)])
 def test_native_run_float32_models(vsm, arch, monkeypatch, pol, l_trunc):
-    """A Float32 model through the native-layout run (vsm_run_*_f32: FP32 records and arithmetic, blocks of up to 96 rows -- every
-    row-tile count 1..6, rider columns and the mat-vec source path, two points per workgroup from five row tiles on with an odd
+    """A Float32 model through the native-layout run (vsm_run_*_f32: FP32 records and arithmetic, blocks of up to 128 rows -- every
+    row-tile count 1..8, rider columns and the mat-vec source path, two points per workgroup at five and six row tiles with an odd
     batch): within the reference's own FP32 gate of the oracle's Float32 run (test/test_float32.jl:58-64: 1e-2 end to end)."""
     H = vsm.host_model
     rng = np.random.default_rng(47)
@@ -401,7 +401,7 @@ def test_native_run_float32_models(vsm, arch, monkeypatch, pol, l_trunc):
     ns = model.polarization_type.n
     N = model.quad_points.Nquad * ns
     nat = sc._native_moments()
-    assert nat == {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 96} and nat
+    assert nat == {i for i in range(3) if max(bin(g).count("1") for g in _groups(ns, sc.coupling[i])) * (N // ns) <= 128} and nat
     sc.run()
     torch.cuda.synchronize()
     vsm._lib.check_device_status("native run (f32)")
@@ -594,7 +594,7 @@ def test_reference_call_order_reaches_the_native_run_through_rt_kernel(vsm, arch
     calls = _spy_native(vsm, monkeypatch)
     Rb, Tb = vsm.CoreRT.rt_run(model)
     sc = vsm.CoreRT.prepare_scene(model)
-    fits = [max(bin(g).count("1") for g in _groups(ns, sc.coupling[m])) * (N // ns) <= 96 for m in range(3)]
+    fits = [max(bin(g).count("1") for g in _groups(ns, sc.coupling[m])) * (N // ns) <= (128 if FT == np.float32 else 96) for m in range(3)]
     assert [c for c in calls if c[2]] == [(m, iz, True) for m in range(3) if fits[m] for iz in range(1, L + 1)], calls
     assert any(fits)
     monkeypatch.setattr(vsm.CoreRT, "NATIVE_DROPIN", False)

@@ -593,7 +593,7 @@ def layer_coupling(props: DeviceLayerOptics, N: int, n_stokes: int) -> int:
 
 
 def run_supported(dtype, N: int, ns: int, mask: int) -> bool:
-    """vsm_run_supported of the model's float type: blocks of <= 64 rows (FP64), <= 96 rows (Float32: the FP32 native kernels)."""
+    """vsm_run_supported of the model's float type: blocks of <= 96 rows (FP64), <= 128 rows (Float32: the FP32 native kernels)."""
     L = _lib.lib()
     return (L.vsm_run_supported_f32 if dtype == torch.float32 else L.vsm_run_supported)(int(N), int(ns), int(mask)) != 0
 
@@ -1040,7 +1040,7 @@ class Scene:
     def _native_moments(self):
         """Indices of the Fourier moments whose layer loop runs on the native-layout composite (vsm_run_*): every layer scattering
         with the 11 interface (the only steps the run object takes), at most four scatterers per layer, and every block of coupled
-        Stokes components within the native kernels' size (FP64: 64 rows; Float32 models: 96 rows, FP32 records and arithmetic)."""
+        Stokes components within the native kernels' size (FP64: 96 rows; Float32 models: 128 rows, FP32 records and arithmetic)."""
         if not NATIVE_RUN or getattr(self, "coupling", None) is None or not self.moments:
             return set()
         eps2 = 2 * np.finfo(self.FT).eps

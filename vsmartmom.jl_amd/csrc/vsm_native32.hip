@@ -7,6 +7,7 @@
 // coincide with the FP64 one, 16-byte units of four rows, two spectral points per workgroup from five row tiles on.
 //   RT = 1..4 (n <= 64):  RT waves per workgroup, four waves per SIMD (a strip is 4 RT registers)
 //   RT = 5, 6 (n <= 96):  two points per workgroup of 2 RT waves, three waves per SIMD (168 registers) -- C4's dense moments (N = 96)
+//   RT = 7, 8 (n <= 128): one point per workgroup of 7 / 8 waves, two waves per SIMD (256 registers: six live strips of 32)
 #include <stdlib.h>
 
 #include <vector>
@@ -422,7 +423,7 @@ int VSM_N32CAT(launch_layer_native32_, VSM_NATIVE32_KS)(int S, int nsub, int n, 
   constexpr int KS = VSM_NATIVE32_KS;
   // KS = 4, 8, ... 24: KS / 4 row tiles without spare columns (mat-vec source path) instead of one row tile more for two columns
   constexpr int RT = native32_rt_of_ks(KS);
-  static_assert(RT >= 1 && RT <= 6, "n <= 96");
+  static_assert(RT >= 1 && RT <= 8, "n <= 128");
   using G = n32geo<RT>;
   using SM = n32smem<RT, (4 * KS + 2 > 16 * RT)>;
   auto kern = k_layer_native32<RT, KS>;
@@ -461,6 +462,14 @@ VSM_NATIVE32_DECL(21)
 VSM_NATIVE32_DECL(22)
 VSM_NATIVE32_DECL(23)
 VSM_NATIVE32_DECL(24)
+VSM_NATIVE32_DECL(25)
+VSM_NATIVE32_DECL(26)
+VSM_NATIVE32_DECL(27)
+VSM_NATIVE32_DECL(28)
+VSM_NATIVE32_DECL(29)
+VSM_NATIVE32_DECL(30)
+VSM_NATIVE32_DECL(31)
+VSM_NATIVE32_DECL(32)
 
 namespace {
 
@@ -764,7 +773,8 @@ static int launch_layer_native32(int ks, int S, int nsub, int n, unsigned uvmask
   switch (ks) {
     VSM_N32L(1) VSM_N32L(2) VSM_N32L(3) VSM_N32L(4) VSM_N32L(5) VSM_N32L(6) VSM_N32L(7) VSM_N32L(8) VSM_N32L(9) VSM_N32L(10)
     VSM_N32L(11) VSM_N32L(12) VSM_N32L(13) VSM_N32L(14) VSM_N32L(15) VSM_N32L(16) VSM_N32L(17) VSM_N32L(18) VSM_N32L(19)
-    VSM_N32L(20) VSM_N32L(21) VSM_N32L(22) VSM_N32L(23) VSM_N32L(24)
+    VSM_N32L(20) VSM_N32L(21) VSM_N32L(22) VSM_N32L(23) VSM_N32L(24) VSM_N32L(25) VSM_N32L(26) VSM_N32L(27) VSM_N32L(28)
+    VSM_N32L(29) VSM_N32L(30) VSM_N32L(31) VSM_N32L(32)
     default: break;
   }
 #undef VSM_N32L
@@ -861,7 +871,9 @@ int native32_run_layer(vsm_run* run, int ndoubl, const float* dtau, const float*
       case 3: launch_pre32<3>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
       case 4: launch_pre32<4>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
       case 5: launch_pre32<5>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
-      default: launch_pre32<6>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 6: launch_pre32<6>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      case 7: launch_pre32<7>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
+      default: launch_pre32<8>(ncomp > 0, q, run->S, nsub, h.n, ndoubl, dtau, varpi, tau_sum, F0, pa, pre_cl, st); break;
     }
     VSM_LAUNCH_CHECK("k_elemental_native32");
     const int rc = launch_layer_native32(h.ks, run->S, nsub, h.n, h.uvmask, h.gsz, ndoubl, toa, pre_cl, lc, status, st);

@@ -1,7 +1,7 @@
 // Device building blocks of the FP32 NATIVE-LAYOUT layer kernels (vsm_native32.hip): the scheme of vsm_native_dev.h -- wave w owns
 // the 16-column strip w of every matrix in accumulator registers that ARE the B operands of the next product, left operands as
 // A-forms in LDS, the composite in strip records between the layer steps -- in single precision on v_mfma_f32_16x16x4_f32, for
-// sub-problems of n <= 96 rows in RT = 1..6 row tiles.
+// sub-problems of n <= 128 rows in RT = 1..8 row tiles.
 //
 // Accumulator layout.  v_mfma_f32_16x16x4 leaves element (M index i, column j) of a tile in lane 16 (i >> 2) + j, register i & 3
 // (the FP64 instruction: lane 16 (i & 3) + j, register i >> 2).  The kernels feed the A operand with the rows of a tile PERMUTED:
@@ -42,13 +42,13 @@ template <int RT>
 struct n32geo {
   static constexpr int NP = 16 * RT;                  // padded size of a sub-problem
   static constexpr int NTP = 64 * RT;                 // threads per spectral point (RT waves)
-  static constexpr int PP = RT >= 5 ? 2 : 1;          // spectral points per workgroup
+  static constexpr int PP = (RT == 5 || RT == 6) ? 2 : 1;   // spectral points per workgroup (7 / 8 row tiles: 7 / 8 waves fill the SIMDs by themselves)
   static constexpr int NT = NTP * PP;                 // threads per workgroup
   static constexpr int AF = NP * NP;                  // floats per A-form / per pre-pass image / per native matrix
   static constexpr int PRE_STRIDE = 2 * AF + 3 * NP;  // pre-pass record: [r-+*] image, [t++] image, j0+, j0-, aux (aux[0] = expk)
   static constexpr int COMP_STRIDE = 4 * AF + 2 * NP; // native composite of one point: R-+, R+-, T++, T--, J0+, J0-
   // minimum waves per SIMD the register budget is set for (launch bounds): a strip is 4 RT registers
-  static constexpr int WPS = RT <= 3 ? 4 : (RT == 4 ? VSM_N32_WPS4 : 3);
+  static constexpr int WPS = RT <= 3 ? 4 : (RT == 4 ? VSM_N32_WPS4 : (RT <= 6 ? 3 : 2));
 };
 enum { N32_RMP = 0, N32_RPM = 1, N32_TPP = 2, N32_TMM = 3 };
 
@@ -582,6 +582,7 @@ struct n32smem<RT, true> {
 };
 static_assert(sizeof(n32smem<6, true>) * 2 <= 163840 && sizeof(n32smem<6, false>) * 2 <= 163840, "six row tiles: two points per CU");
 static_assert(sizeof(n32smem<4, true>) * 4 <= 163840, "four row tiles: four workgroups per CU");
+static_assert(sizeof(n32smem<8, true>) <= 163840 && sizeof(n32smem<8, false>) <= 163840, "eight row tiles: one workgroup per CU");
 
 // Source vectors without spare columns: y = sc [A] x as a VALU mat-vec over the A-form.  Wave w takes the rows of row tile w
 // through the fragment pattern of the products (lane (m, kq): row pi(m), k = 4 ks + kq -- conflict-free, per-lane bases +

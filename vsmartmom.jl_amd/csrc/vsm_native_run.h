@@ -39,7 +39,7 @@ namespace vsm {
 
 // ---- FP32 family (vsm_native32.hip) ------------------------------------------------------------------------------------------
 constexpr int NATIVE_MAX_ROWS = 96;     // FP64 family (vsm_native.hip): blocks of up to six row tiles
-constexpr int NATIVE32_MAX_ROWS = 96;
+constexpr int NATIVE32_MAX_ROWS = 128;   // FP32 family (vsm_native32.hip): up to eight row tiles
 int native32_rt_of(int n);                 // row tiles of a block of n rows
 size_t native32_comp_stride(int rt);       // floats per point of a native composite
 int native32_run_layer(vsm_run* run, int ndoubl, const float* dtau, const float* varpi, const float* tau_sum, const float* F0,
