@@ -196,7 +196,7 @@ function _layer_coupling(p::CoreScatteringOpticalProperties, N::Int, n::Int, ::T
 end
 function _native_open!(c::CompositeLayer{FT}, qp::QuadPoints, n::Int, m::Int, mask::Cint, F₀, import_arrays::Bool) where {FT<:FTs}
     N, _, S = size(c.R⁻⁺)
-    # (Float32 models: FP32 records and arithmetic, blocks of up to 96 rows -- vsm_run_supported_f32 / vsm_run_workspace_bytes_f32)
+    # (Float32 models: FP32 records and arithmetic, blocks of up to 128 rows -- vsm_run_supported_f32 / vsm_run_workspace_bytes_f32)
     f_sup = FT === Float32 ? :vsm_run_supported_f32 : :vsm_run_supported
     f_ws = FT === Float32 ? :vsm_run_workspace_bytes_f32 : :vsm_run_workspace_bytes
     ccall(_sym(f_sup), Cint, (Cint, Cint, Cint), N, n, mask) == 1 || return false
