@@ -239,7 +239,7 @@ def c3_lin(vsm, torch, arch):
                "(gas column + wind speed) -- a latency-bound two-point batch; step = H2D + device optics + the pass REPLAYED FROM A HIP "
                "GRAPH + D2H", S, wall, dev, fl, "f64",
                "latency: ONE folded batch of (moment, point) pairs (m = 0 in front); the 33 layers doubled side by side on the lane "
-               "streams (k_dbl128_lin<4>), then one chain of 32 interactions (2 k_ia128_lin<4> each); graph replay")
+               "streams (k_dbl128_lin<4>), then their interactions as a tree of composites (6 dependent levels, 2 k_ia128_lin<4> each); graph replay")
     e["ms_per_step_launch_by_launch"] = 1e3 * wall_eager
     e["graph_replay_equals_launch_by_launch"] = bool(same)
     del scene
