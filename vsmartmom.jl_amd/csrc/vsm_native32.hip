@@ -73,9 +73,6 @@ __device__ __forceinline__ void n32ed_body(n32smem<RT, (4 * KS + 2 > 16 * RT)>& 
   float expk = expk0;
   int slot = 0;
   const n32inv_ctx cx{dP, sm.P, sm.gjs(), status};
-#ifdef VSM_N32_ONLY_IA
-  ndoubl = 0;
-#endif
   for (int it = 0; it < ndoubl; ++it) {
     n32strip<RT> W, tt;
     const float fW = laneA ? expk : (laneB ? 1.0f : 0.0f), fR = laneB ? expk : 1.0f;
@@ -401,9 +398,7 @@ __global__ __launch_bounds__(n32geo<RT>::NT, n32geo<RT>::WPS) void k_layer_nativ
     }
     return;
   }
-#ifndef VSM_N32_ONLY_TOA
   n32ia_body<RT, KS>(sm, p, n, comp, r_s, t_s, status);
-#endif
 }
 
 }  // namespace

@@ -543,7 +543,7 @@ __device__ __forceinline__ void n32invert_pair(int K_own, int K_other, const n32
     n32add_identity(G, n, p);
     return;
   }
-#ifndef VSM_N32_NO_RARE
+#if !(defined(VSM_N32_NO_RARE) && defined(VSM_AB_SWITCHES))   // (A/B build only: the hot path without the call site of the rare one)
   n32strip<RT> Es = E, Gs;
   n32pos<RT> ps = p;
   n32invert_rare<RT, KS>(p.pt == 0 ? K_own : K_other, p.pt == 0 ? K_other : K_own, Es, Gs, n, cx, ps);
