@@ -219,6 +219,25 @@ def test_native_run_thick_layers_series_orders_and_pivoted_inverse(vsm, arch, mo
     assert _rel(Rn, Ro) < 1e-8 and _rel(Tn, To) < 1e-7, (_rel(Rn, Ro), _rel(Tn, To))    # (T: e^-34 of the beam; the legacy path: the same)
 
 
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_native_run_float32_two_points_per_workgroup_tiny_batches(vsm, arch, monkeypatch, S):
+    """Five / six row tiles run two spectral points per workgroup: a batch of one point (its partner is a filler that walks the
+    barriers and stores nothing), of two, of three -- each point's numbers are those it has in a larger batch."""
+    H = vsm.host_model
+    rng = np.random.default_rng(5)
+    L, S_big = 3, 6
+    tau_rayl = np.tile(np.linspace(0.03, 0.3, L), (S_big, 1))
+    tau_abs = 10.0 ** rng.uniform(-3, 0, (S_big, L))
+    kw = dict(depol=0.03, albedo=0.2, m_max=2)
+    mk = lambda n: H.model_from_arrays(arch, "IQU", 57, 40.0, [30.0], [0.0], tau_rayl=tau_rayl[:n], tau_abs=tau_abs[:n], float_type=np.float32, **kw)
+    monkeypatch.setattr(vsm.CoreRT, "NATIVE_RUN", True)
+    Rb, Tb = vsm.CoreRT.rt_run(mk(S_big))
+    # (ndoubl is batch-global, rt_kernel.jl:282-283: the sub-batches here share the big batch's maxima -- every column has the same
+    #  tau_rayl and the largest tau varpi of a layer is its Rayleigh part's)
+    Rs, Ts = vsm.CoreRT.rt_run(mk(S))
+    assert np.array_equal(Rs, Rb[:, :, :S]) and np.array_equal(Ts, Tb[:, :, :S])
+
+
 @pytest.mark.parametrize("pol,l_trunc", [("IQU", 35), ("I", 21), ("IQU", 57), ("I", 150), ("I", 247)])   # N = 60, 14, 96 (two points per workgroup), 79, 127
 def test_native_run_float32_thick_layers_and_mixed_orders(vsm, arch, monkeypatch, pol, l_trunc):
     """The FP32 native kernels beyond the Horner orders: thick near-conservative layers over a bright surface (long series, the
