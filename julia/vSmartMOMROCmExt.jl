@@ -326,7 +326,7 @@ function NativeRun(qp::QuadPoints, pol_type, nSpec::Int, ms::Vector{<:Integer}, 
     N, n = length(qp.qp_μN), pol_type.n
     coupling = Cint[reduce(|, stokes_coupling(N, n, Z[1], Z[2])) for Z in Zstacks]
     nbytes = ccall(_sym(:vsm_run_workspace_bytes), Csize_t, (Cint, Cint, Cint, Cint, Ptr{Cint}), N, n, nSpec, length(ms), coupling)
-    nbytes > 0 || error("vsm_run: a block of coupled Stokes components exceeds the native kernels (64 rows)")
+    nbytes > 0 || error("vsm_run: a block of coupled Stokes components exceeds the native kernels (96 rows; Float32: 128)")
     ws = ROCArray{Float64}(undef, cld(Int(nbytes), 8))
     q = _q(qp, n, Float64)
     h = Ref{PV}(C_NULL)
